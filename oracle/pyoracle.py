@@ -1,0 +1,215 @@
+"""pyoracle -- second, independent CPU ORACLE (test infrastructure, NOT product code).
+
+A deliberately tiny pure-Python restatement of the same SpiceDB semantics as
+oracle/acl_oracle.c (see that file's header for the reference call sites:
+pkg/authz/check.go:48, pkg/authz/lookups.go:65, pkg/authz/watch.go:50, engine
+config pkg/spicedb/spicedb.go:34,60).  It exists because the real engine
+(github.com/authzed/spicedb, go.mod:9) cannot run here, so two independently
+written restatements arbitrate each other under hypothesis-generated graphs.
+
+Written in a different style on purpose: regex schema parser, dict-of-sets
+store, recursive evaluation returning a 3-valued result.
+Pure-Python loops: small cases only.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass, field
+
+MAX_DEPTH = 50  # pkg/spicedb/spicedb.go:34
+
+NO, HAS, ERR = "NO", "HAS", "ERR"
+
+
+class SchemaError(ValueError):
+    pass
+
+
+@dataclass
+class Relation:
+    name: str
+    allowed: list  # [(subject_type, subject_relation_or_None, expiring)]
+
+
+@dataclass
+class Permission:
+    name: str
+    expr: tuple  # ('union', a, b) | ('ref', name) | ('arrow', tupleset, computed) | ('nil',)
+
+
+@dataclass
+class Definition:
+    name: str
+    members: dict = field(default_factory=dict)  # name -> Relation | Permission
+
+
+def _strip_comments(text: str) -> str:
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", text)
+
+
+def _parse_expr(tokens: list, pos: int):
+    def term(p):
+        t = tokens[p]
+        if t == "(":
+            e, p = _parse_expr(tokens, p + 1)
+            if tokens[p] != ")":
+                raise SchemaError("expected )")
+            return e, p + 1
+        if not re.fullmatch(r"[A-Za-z_][\w/]*", t):
+            raise SchemaError(f"unexpected token {t!r}")
+        if t == "nil":
+            return ("nil",), p + 1
+        if p + 1 < len(tokens) and tokens[p + 1] == "->":
+            return ("arrow", t, tokens[p + 2]), p + 3
+        if p + 1 < len(tokens) and tokens[p + 1] == ".":
+            if tokens[p + 2] != "any":
+                raise SchemaError("unsupported: .all()")
+            return ("arrow", t, tokens[p + 4]), p + 6
+        return ("ref", t), p + 1
+
+    left, pos = term(pos)
+    while pos < len(tokens) and tokens[pos] in "+&-" and tokens[pos] != "->":
+        if tokens[pos] != "+":
+            raise SchemaError("unsupported: intersection/exclusion")
+        right, pos = term(pos + 1)
+        left = ("union", left, right)
+    return left, pos
+
+
+def parse_schema(text: str) -> dict:
+    text = _strip_comments(text)
+    if re.search(r"\bcaveat\s+\w+\s*\(", text):
+        raise SchemaError("unsupported: caveats")
+    defs: dict[str, Definition] = {}
+    text = re.sub(r"^\s*use\s+\w+\s*$", "", text, flags=re.M)
+    for m in re.finditer(r"definition\s+([\w/]+)\s*\{(.*?)\}", text, flags=re.S):
+        d = Definition(m.group(1))
+        if d.name in defs:
+            raise SchemaError("duplicate definition")
+        body = m.group(2)
+        for line in re.finditer(r"(relation|permission)\s+(\w+)\s*([:=])\s*([^\n]*?)(?=\s*(?:relation\s|permission\s|$))", body, flags=re.S):
+            kind, name, sep, rest = line.groups()
+            if name in d.members:
+                raise SchemaError("duplicate member")
+            if kind == "relation":
+                if sep != ":":
+                    raise SchemaError("relation needs ':'")
+                allowed = []
+                for alt in rest.split("|"):
+                    alt = alt.strip()
+                    mm = re.fullmatch(r"([\w/]+)(?:#(\w+))?(\s+with\s+expiration)?", alt)
+                    if not mm:
+                        raise SchemaError(f"unsupported subject reference {alt!r}")
+                    allowed.append((mm.group(1), mm.group(2), bool(mm.group(3))))
+                d.members[name] = Relation(name, allowed)
+            else:
+                if sep != "=":
+                    raise SchemaError("permission needs '='")
+                toks = re.findall(r"->|[A-Za-z_][\w/]*|[()+&\-.]", rest)
+                expr, pos = _parse_expr(toks, 0)
+                if pos != len(toks):
+                    raise SchemaError("trailing tokens in permission expression")
+                d.members[name] = Permission(name, expr)
+        defs[d.name] = d
+    leftover = re.sub(r"definition\s+[\w/]+\s*\{.*?\}", "", text, flags=re.S).strip()
+    if leftover:
+        raise SchemaError(f"unparsed schema text: {leftover[:40]!r}")
+    for d in defs.values():
+        for mem in d.members.values():
+            if isinstance(mem, Relation):
+                for (st, sr, _e) in mem.allowed:
+                    if st not in defs or (sr and sr not in defs[st].members):
+                        raise SchemaError(f"unknown subject reference {st}#{sr}")
+            else:
+                _validate(defs, d, mem.expr)
+    return defs
+
+
+def _validate(defs, d, e):
+    if e[0] == "union":
+        _validate(defs, d, e[1])
+        _validate(defs, d, e[2])
+    elif e[0] == "ref" and e[1] not in d.members:
+        raise SchemaError(f"unknown reference {e[1]}")
+    elif e[0] == "arrow" and not isinstance(d.members.get(e[1]), Relation):
+        raise SchemaError(f"arrow over non-relation {e[1]}")
+
+
+class PyOracle:
+    """Relationship store + evaluator.  Tuples are 6-tuples of strings
+    (rtype, rid, rel, stype, sid, srel) with srel == '' for no subject relation."""
+
+    def __init__(self, schema: str):
+        self.defs = parse_schema(schema)
+        self.rows: dict = {}  # (rtype, rid, rel) -> {(stype, sid, srel): expires}
+        self.now = 0
+
+    # -- writes (TOUCH semantics; the C oracle covers CREATE/preconditions)
+    def touch(self, rtype, rid, rel, stype, sid, srel="", expires=0):
+        mem = self.defs[rtype].members[rel]
+        assert isinstance(mem, Relation)
+        assert any(a[0] == stype and (a[1] or "") == srel for a in mem.allowed), "subject not allowed"
+        self.rows.setdefault((rtype, rid, rel), {})[(stype, sid, srel)] = expires
+
+    def delete(self, rtype, rid, rel, stype, sid, srel=""):
+        self.rows.get((rtype, rid, rel), {}).pop((stype, sid, srel), None)
+
+    def _subjects(self, rtype, rid, rel):
+        return [s for s, exp in self.rows.get((rtype, rid, rel), {}).items() if exp == 0 or exp > self.now]
+
+    # -- evaluation: one call == one dispatch
+    def _check(self, rtype, rid, rel, subject, depth):
+        # pure in (state, depth) for one top-level call: memoised so that cyclic
+        # data stays polynomial (answers are unchanged by the memo)
+        key = (rtype, rid, rel, depth)
+        if key not in self._memo:
+            self._memo[key] = self._check_body(rtype, rid, rel, subject, depth)
+        return self._memo[key]
+
+    def _check_body(self, rtype, rid, rel, subject, depth):
+        if depth <= 0:
+            return ERR
+        if subject == (rtype, rid, rel):
+            return HAS
+        mem = self.defs[rtype].members[rel]
+        results = []
+        if isinstance(mem, Relation):
+            subs = self._subjects(rtype, rid, rel)
+            if subject in subs:
+                return HAS
+            for (st, sid, sr) in subs:
+                if sr:
+                    results.append(self._check(st, sid, sr, subject, depth - 1))
+        else:
+            results.append(self._eval(rtype, rid, mem.expr, subject, depth))
+        return HAS if HAS in results else ERR if ERR in results else NO
+
+    def _eval(self, rtype, rid, e, subject, depth):
+        if e[0] == "nil":
+            return NO
+        if e[0] == "union":
+            rs = [self._eval(rtype, rid, e[1], subject, depth), self._eval(rtype, rid, e[2], subject, depth)]
+        elif e[0] == "ref":
+            rs = [self._check(rtype, rid, e[1], subject, depth - 1)]
+        else:  # arrow
+            rs = []
+            for (st, sid, _sr) in self._subjects(rtype, rid, e[1]):
+                if e[2] in self.defs[st].members:
+                    rs.append(self._check(st, sid, e[2], subject, depth - 1))
+        return HAS if HAS in rs else ERR if ERR in rs else NO
+
+    def check(self, rtype, rid, perm, stype, sid, srel=""):
+        """returns 'HAS' | 'NO' | 'ERR' (depth) ; raises KeyError for unknown type/relation."""
+        if perm not in self.defs[rtype].members:
+            raise KeyError(perm)
+        if srel and srel not in self.defs[stype].members:
+            raise KeyError(srel)
+        self._memo = {}
+        return self._check(rtype, rid, perm, (stype, sid, srel), MAX_DEPTH)
+
+    def lookup_resources(self, rtype, perm, stype, sid, srel=""):
+        ids = {k[1] for k in self.rows if k[0] == rtype}
+        if stype == rtype:
+            ids.add(sid)
+        return {i for i in ids if self.check(rtype, i, perm, stype, sid, srel) == HAS}
