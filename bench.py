@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- Check decisions/s of the MI355X ACL engine on BASELINE.json's headline workload.
+
+A "step" = one pass of the hot path (bulk Check through the C ABI, acl_check_bulk_ids_device)
+over one HBM-resident batch of interned requests.  Default workload: C4 (10 M relationships /
+1 M objects, 5-level nested groups, 256 k-item batch) -- the configuration BASELINE.json's
+metric is quoted on.  N > 1: one process per GPU (torchrun), every rank holds a full replica of
+the graph and answers its own batch (weak scaling, no data-path collective: requests are
+independent -- SURVEY.md 8(e)); the timed region is bracketed by barrier + synchronize and the
+MAX over ranks is reported.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic bytes / HIP-event kernel
+time vs HBM peak) and `cpu_baseline` (the CPU oracle, a single-thread restatement of SpiceDB's
+dispatch -- NOT the embedded SpiceDB, which cannot be built here -- timed on a bounded sample of
+the same batch on this box's host cores, and used at the same time to verify the GPU answers).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "spicedb-kubeapi-proxy_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOAD_DESC = {
+    "C1": "C1: 1k-object / 10k-relationship flat namespace#view@user graph, Check",
+    "C2": "C2: 100k-object / 1M-relationship 3-level (cluster->namespace->pod) graph, 64k-batch Check",
+    "C4": "C4: 10M-relationship / 1M-object 5-level nested-group graph, 256k-batch Check",
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C4"])
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU evaluation path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import aclgpu
+    from aclgpu import workloads
+
+    kw = {}
+    if args.workload in ("C2", "C4"):
+        kw["scale"] = args.scale
+        if args.batch:
+            kw["batch"] = args.batch
+    t0 = time.time()
+    w = workloads.by_name(args.workload, **kw)
+    if world > 1:  # every rank answers a different request stream against the same graph
+        rng = np.random.default_rng(0x5ACE0000 + rank)
+        perm = rng.permutation(w.res.size)
+        w.res = w.res[perm]
+        w.subj = np.roll(w.subj[perm], rank * 7919) if rank else w.subj[perm]
+    t_gen = time.time() - t0
+    rt, perm_name, st = w.check
+    n = int(w.res.size)
+
+    eng = aclgpu.Engine(w.schema, device=local_rank)
+    t0 = time.time()
+    w.load(eng)
+    eng.snapshot()
+    t_load = time.time() - t0
+    items = eng.make_items(rt, perm_name, w.res, st, "", w.subj)
+    d_items = torch.from_numpy(items.view(np.uint8).copy()).cuda()
+    d_perm = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_err = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    def step():
+        eng.check_bulk_ids_device(d_items.data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
+        eng.sync()
+
+    for _ in range(args.warmup):
+        step()
+    eng.stats_reset()
+    eng.set_timing(True)  # HIP events around every engine kernel, on the engine's own stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        step()
+        lat.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    eng.set_timing(False)
+    stats = eng.stats()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gpu_perm = d_perm.cpu().numpy()
+    gpu_err = d_err.cpu().numpy()
+
+    out = None
+    if rank == 0:
+        total = n * args.steps * world
+        launches = max(1, stats["expand_launches"])
+        out = {
+            "metric": "check_decisions_per_sec", "value": total / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": WORKLOAD_DESC[args.workload], "batch_per_gpu": n, "relationships": w.ntuples,
+                       "objects": int(sum(w.nobjects.values())), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)"},
+            "p50_batch_ms": 1e3 * float(np.median(lat)), "p95_batch_ms": 1e3 * float(np.percentile(lat, 95)),
+            "has_fraction": float((gpu_perm == 2).mean()), "levels": int(stats["levels_last"]),
+            "expand_launches_per_batch": launches / args.steps, "kernel_ms_per_batch": stats["kernel_ms"] / args.steps,
+            "setup_s": {"generate": round(t_gen, 2), "load+snapshot": round(t_load, 2)},
+            "snapshot_bytes": int(stats["snapshot_bytes"]),
+        }
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "k_expand", "kernel_avg_us": 1e3 * stats["expand_ms"] / launches}
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            from oracle import orc
+            t0 = time.time()
+            o = orc.Oracle(w.schema)
+            w.load(o)
+            o.freeze()
+            t_oload = time.time() - t0
+            # calibrate, then time a bounded sample of the SAME batch (prefix), single thread
+            m0 = min(n, 512)
+            t0 = time.perf_counter()
+            o.check_bulk_ids(rt, perm_name, w.res[:m0], st, "", w.subj[:m0])
+            per = (time.perf_counter() - t0) / m0
+            m = int(min(n, max(m0, args.cpu_seconds / max(per, 1e-9))))
+            t0 = time.perf_counter()
+            operm, oerr = o.check_bulk_ids(rt, perm_name, w.res[:m], st, "", w.subj[:m])
+            t_cpu = time.perf_counter() - t0
+            mism = int((operm != gpu_perm[:m]).sum() + (oerr != gpu_err[:m]).sum())
+            cpu = {"value": m / t_cpu, "unit": "decisions/s", "cores": 1, "kind": "port",
+                   "sample": f"first {m} of the {n}-item batch, single thread, restated CPU oracle (not embedded SpiceDB)",
+                   "seconds": round(t_cpu, 2), "load_s": round(t_oload, 2)}
+            out["parity"] = {"checked_against_oracle": m, "mismatches": mism}
+            # algorithmic bytes per Check (SURVEY.md 8(d) model) from the oracle's counter on a sub-sample
+            mb = min(m, 4096)
+            tot = 0
+            for i in range(mb):
+                b, _r = o.check_bytes(rt, perm_name, int(w.res[i]), st, "", int(w.subj[i]))
+                tot += b
+            bytes_per_check = tot / mb
+            batch_bytes = bytes_per_check * n
+            ach = batch_bytes * args.steps / (stats["expand_ms"] * 1e-3) / 1e9 if stats["expand_ms"] > 0 else None
+            roof.update({"achieved": ach, "frac": (ach / HBM_PEAK_GBS) if ach else None, "algorithmic_bytes_per_check": bytes_per_check,
+                         "algorithmic_bytes_per_launch": batch_bytes * args.steps / launches})
+            tr = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tr):
+                try:
+                    roof["traffic"] = json.load(open(tr)).get(args.workload)
+                except Exception:  # noqa: BLE001
+                    pass
+        out["roofline"] = roof
+        out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out and out.get("parity", {}).get("mismatches"):
+        raise SystemExit("PARITY FAILURE: GPU answers differ from the oracle")
+
+
+if __name__ == "__main__":
+    main()

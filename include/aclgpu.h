@@ -1,0 +1,180 @@
+/*
+ * aclgpu.h -- C ABI of libaclgpu.so, the MI355X-native batched ACL-check engine.
+ *
+ * This is the drop-in boundary for ONE path of authzed/spicedb-kubeapi-proxy: the
+ * embedded-SpiceDB Check / Filter (LookupResources) path.  The reference has no
+ * C ABI (it is pure Go, CGO_ENABLED=0); the seam it replaces is the Go interface
+ * v1.PermissionsServiceClient held in proxy.Options.PermissionsClient
+ * (reference pkg/proxy/options.go:82, auto-constructed only when nil at
+ * options.go:371-377).  Every entry point below names the reference call site
+ * whose request it answers; INTEGRATION.md shows the cgo binding that implements
+ * the Go interface on top of these symbols.
+ *
+ * Conventions
+ *  - plain C types only; the caller owns every input for the duration of the call
+ *    and provides every output buffer; engine-owned strings stay valid until the
+ *    next mutating call on the same handle or acl_close().
+ *  - every function returns 0 (ACL_OK) or a gRPC status code (the codes the
+ *    reference inspects: codes.InvalidArgument pkg/authz/distributedtx/workflow.go:115,
+ *    precondition / already-exists failures activity.go:62-74); the message is
+ *    available from acl_last_error() (thread-local).
+ *  - all entry points are thread-safe (the proxy calls the seam from arbitrary
+ *    goroutines: pkg/authz/check.go:77-93, responsefilterer.go:165).
+ *  - there is NO CPU evaluation path in this library: if no gfx950 device is
+ *    usable acl_open() fails with ACL_ERR_UNAVAILABLE.
+ */
+#ifndef ACLGPU_H
+#define ACLGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct acl_engine acl_engine_t;
+
+/* gRPC status codes used as return values */
+enum {
+    ACL_OK = 0,
+    ACL_ERR_INVALID_ARGUMENT = 3,    /* codes.InvalidArgument   */
+    ACL_ERR_NOT_FOUND = 5,           /* codes.NotFound          */
+    ACL_ERR_ALREADY_EXISTS = 6,      /* codes.AlreadyExists: CREATE of an existing relationship */
+    ACL_ERR_RESOURCE_EXHAUSTED = 8,  /* codes.ResourceExhausted: frontier capacity exceeded */
+    ACL_ERR_FAILED_PRECONDITION = 9, /* codes.FailedPrecondition: precondition failed, unknown type/relation */
+    ACL_ERR_INTERNAL = 13,           /* codes.Internal (HIP runtime failure) */
+    ACL_ERR_UNAVAILABLE = 14,        /* codes.Unavailable: no usable GPU */
+    ACL_ERR_DEPTH = 100              /* per-item: max dispatch depth (50) exceeded, pkg/spicedb/spicedb.go:34 */
+};
+
+/* authzed.api.v1.CheckPermissionResponse.Permissionship (authzed-go v1.10.0, go.mod:6);
+ * only HAS_PERMISSION allows: pkg/authz/check.go:63, postfilter.go:169, watch.go:104 */
+enum { ACL_PERM_UNSPECIFIED = 0, ACL_PERM_NO_PERMISSION = 1, ACL_PERM_HAS_PERMISSION = 2, ACL_PERM_CONDITIONAL = 3 };
+/* authzed.api.v1.RelationshipUpdate.Operation (used by pkg/authz/distributedtx/activity.go:47-77) */
+enum { ACL_OP_CREATE = 1, ACL_OP_TOUCH = 2, ACL_OP_DELETE = 3 };
+/* authzed.api.v1.Precondition.Operation (workflow.go:452-462) */
+enum { ACL_PRE_MUST_NOT_MATCH = 1, ACL_PRE_MUST_MATCH = 2 };
+
+#define ACL_NO_RELATION 0xFFFFu /* "no subject relation" (ellipsis) in interned items */
+
+typedef struct {
+    int32_t device;              /* HIP device ordinal; -1 = current (LOCAL_RANK for one-process-per-GPU) */
+    uint64_t frontier_entries;   /* capacity of EACH of the two frontier buffers, in 16-byte entries; 0 = default */
+    uint32_t max_sub_batch;      /* Check items evaluated per device pass; 0 = default */
+    uint32_t flags;              /* ACL_FLAG_* */
+} acl_config_t;
+/* open only the relationship store (writes, reads, preconditions) without touching a GPU: every entry
+ * point that evaluates permissions then fails with ACL_ERR_UNAVAILABLE.  For tooling and CPU-side tests. */
+#define ACL_FLAG_STORE_ONLY 1u
+
+/* replaces spicedb.NewServer (pkg/spicedb/spicedb.go:18-71): builds the engine. */
+int acl_open(const acl_config_t *cfg, acl_engine_t **out);
+void acl_close(acl_engine_t *h);
+const char *acl_last_error(void);
+
+/* bootstrap: schema text + relationship lines, as in pkg/spicedb/bootstrap.yaml:1-40
+ * (spicedb.go:19-24).  rels_utf8 may be NULL; one `type:id#rel@type:id[#rel]` per line
+ * (grammar pkg/rules/rules.go:1053-1055). Replaces any previous schema and data. */
+int acl_load_bootstrap(acl_engine_t *h, const char *schema_utf8, size_t schema_len, const char *rels_utf8, size_t rels_len);
+
+/* ---- identifiers (pre-interned fast path) ---- */
+int acl_type_id(acl_engine_t *h, const char *type);                 /* -1 if unknown */
+int acl_relation_id(acl_engine_t *h, int type, const char *name);   /* relation or permission; -1 if unknown */
+int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out); /* creates if missing */
+int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out);   /* ACL_ERR_NOT_FOUND if missing */
+const char *acl_object_name(acl_engine_t *h, int type, uint32_t id); /* NULL for anonymous/unknown ids */
+uint32_t acl_object_count(acl_engine_t *h, int type);                /* size of the type's dense id space */
+
+/* ---- relationship store: the write side of the seam ---- */
+typedef struct {
+    const char *resource_type, *resource_id, *relation;
+    const char *subject_type, *subject_id, *subject_relation; /* NULL or "" = none */
+    int64_t expires_at;                                      /* unix seconds; 0 = never (spicedb.go:60) */
+} acl_relationship_t;
+typedef struct { int32_t op; acl_relationship_t rel; } acl_update_t;
+typedef struct {
+    int32_t op;                /* ACL_PRE_*; ignored by read/delete */
+    const char *resource_type; /* required */
+    const char *resource_id;   /* NULL/"" = any */
+    const char *relation;      /* NULL/"" = any */
+    const char *subject_type;  /* NULL = no subject filter */
+    const char *subject_id;    /* NULL/"" = any */
+    const char *subject_relation; /* NULL = any; "" = only "no relation"; else exact */
+} acl_filter_t;
+
+/* WriteRelationships (activity.go:60): atomic; preconditions see the pre-write state;
+ * <=1000 updates and <=1000 preconditions (spicedb.go:35-36).  *revision_out = ZedToken. */
+int acl_write(acl_engine_t *h, const acl_update_t *updates, int n_updates, const acl_filter_t *preconditions, int n_pre,
+              uint64_t *revision_out);
+/* DeleteRelationships (e2e/util_test.go:66) */
+int acl_delete_by_filter(acl_engine_t *h, const acl_filter_t *filter, uint64_t *n_deleted, uint64_t *revision_out);
+/* ReadRelationships (activity.go:107, e2e/util_test.go:27): cb per matching relationship */
+typedef void (*acl_read_cb)(void *user, const acl_relationship_t *rel);
+int acl_read(acl_engine_t *h, const acl_filter_t *filter, acl_read_cb cb, void *user);
+/* bulk load with caller-chosen dense numeric ids (ImportBulkRelationships analogue; TOUCH semantics) */
+int acl_add_edges(acl_engine_t *h, int rtype, int relation, int stype, int srel /* -1 none */, size_t n, const uint32_t *resource_ids,
+                  const uint32_t *subject_ids);
+uint64_t acl_revision(acl_engine_t *h);
+/* test clock for relationship expiration; 0 = wall clock */
+int acl_set_now(acl_engine_t *h, int64_t unix_seconds);
+/* build + upload the HBM snapshot now (otherwise done lazily by the next read) */
+int acl_snapshot(acl_engine_t *h);
+
+/* ---- Check: CheckBulkPermissions (check.go:48, postfilter.go:134), CheckPermission (watch.go:50) ---- */
+typedef struct {
+    const char *resource_type, *resource_id, *permission;
+    const char *subject_type, *subject_id, *subject_relation; /* NULL or "" = none (check.go:36) */
+} acl_check_item_t;
+/* order preserving: perm_out[i] / err_out[i] answer items[i] (check.go:54-57).
+ * err_out[i] != 0 is that pair's Error (check.go:55); perm_out[i] is then UNSPECIFIED. */
+int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
+
+/* 16-byte interned request (SURVEY 8(a) a3 "interned it is 16 B") */
+typedef struct {
+    uint16_t resource_type, permission; /* acl_type_id / acl_relation_id */
+    uint32_t resource_id;
+    uint16_t subject_type, subject_relation; /* ACL_NO_RELATION = none */
+    uint32_t subject_id;
+} acl_item_t;
+int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
+/* same, but items / outputs are DEVICE pointers (HBM-resident batch; asynchronous on acl_stream()
+ * until acl_sync()); err_out may be NULL */
+int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out);
+void *acl_stream(acl_engine_t *h); /* hipStream_t the engine launches on */
+int acl_sync(acl_engine_t *h);
+
+/* ---- Filter: LookupResources (lookups.go:49-65) ----
+ * Result = dense bitmap over the resource type's local ids (bit id set <=> HAS_PERMISSION);
+ * the Go side intersects it with the kube list (lookups.go:25-36, responsefilterer.go:349-415). */
+int acl_lookup_resources(acl_engine_t *h, const char *resource_type, const char *permission, const char *subject_type,
+                         const char *subject_id, const char *subject_relation, uint32_t *bitmap_out, size_t bitmap_words,
+                         uint64_t *count_out);
+int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int permission, int stype, int srel /* -1 none */, uint32_t subject_id,
+                             uint32_t *bitmap_out, size_t bitmap_words, uint64_t *count_out);
+/* batched form: n subjects of one (stype, srel) against one (rtype, permission); bitmaps_out is n * bitmap_words */
+int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int stype, int srel, const uint32_t *subject_ids, size_t n,
+                               uint32_t *bitmaps_out, size_t bitmap_words, uint64_t *counts_out);
+
+/* ---- measurement ---- */
+typedef struct {
+    uint64_t check_items;      /* items answered since open / last reset */
+    uint64_t check_passes;     /* device passes (sub-batches) */
+    uint64_t expand_launches;  /* frontier-expansion kernel launches */
+    uint64_t levels_last;      /* levels the last pass needed */
+    uint64_t frontier_entries; /* frontier entries produced (all levels) */
+    double kernel_ms;          /* HIP-event time of all engine kernels since reset (needs timing on) */
+    double expand_ms;          /* ... of the frontier-expansion kernel only */
+    uint64_t snapshot_edges;   /* edges in the current HBM snapshot */
+    uint64_t snapshot_bytes;   /* bytes of the current HBM snapshot */
+    uint64_t snapshot_builds;
+    uint64_t overflow_retries;
+} acl_stats_t;
+int acl_stats(acl_engine_t *h, acl_stats_t *out);
+int acl_stats_reset(acl_engine_t *h);
+int acl_set_timing(acl_engine_t *h, int on); /* bracket every kernel with HIP events on acl_stream() */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACLGPU_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libaclgpu.so (include/aclgpu.h).
+
+The product path: there is no fallback here.  If the shared library is missing
+or no MI355X is usable, loading / opening the engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libaclgpu.so")
+
+# every symbol include/aclgpu.h declares (checked by tests/test_abi.py against the header)
+SYMBOLS = [
+    "acl_open", "acl_close", "acl_last_error", "acl_load_bootstrap", "acl_type_id", "acl_relation_id", "acl_intern", "acl_find",
+    "acl_object_name", "acl_object_count", "acl_write", "acl_delete_by_filter", "acl_read", "acl_add_edges", "acl_revision",
+    "acl_set_now", "acl_snapshot", "acl_check_bulk", "acl_check_bulk_ids", "acl_check_bulk_ids_device", "acl_stream", "acl_sync",
+    "acl_lookup_resources", "acl_lookup_resources_ids", "acl_lookup_resources_batch", "acl_stats", "acl_stats_reset", "acl_set_timing",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("frontier_entries", C.c_uint64), ("max_sub_batch", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Relationship(C.Structure):
+    _fields_ = [(n, C.c_char_p) for n in ("resource_type", "resource_id", "relation", "subject_type", "subject_id", "subject_relation")] + [
+        ("expires_at", C.c_int64)]
+
+
+class Update(C.Structure):
+    _fields_ = [("op", C.c_int32), ("rel", Relationship)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("op", C.c_int32)] + [(n, C.c_char_p) for n in ("resource_type", "resource_id", "relation", "subject_type", "subject_id", "subject_relation")]
+
+
+class CheckItem(C.Structure):
+    _fields_ = [(n, C.c_char_p) for n in ("resource_type", "resource_id", "permission", "subject_type", "subject_id", "subject_relation")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("check_items", C.c_uint64), ("check_passes", C.c_uint64), ("expand_launches", C.c_uint64), ("levels_last", C.c_uint64),
+                ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
+                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64)]
+
+
+READ_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Relationship))
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """hipcc cross-compile for gfx950 (works without a GPU)."""
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_PKG, "csrc", f)) > os.path.getmtime(LIB_PATH) for f in os.listdir(os.path.join(_PKG, "csrc"))):
+        subprocess.check_call(["make", "-C", _PKG, "-s", "-j8", "lib/libaclgpu.so"])
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing torch first makes the
+    # dynamic linker resolve libaclgpu.so's DT_NEEDED libamdhip64.so.7 to that already-loaded copy, so torch tensors,
+    # torch.distributed (RCCL) and the engine share one runtime.  (A Go/C host simply gets /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.acl_open.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    L.acl_close.argtypes = [H]
+    L.acl_close.restype = None
+    L.acl_last_error.restype = C.c_char_p
+    L.acl_load_bootstrap.argtypes = [H, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.acl_type_id.argtypes = [H, C.c_char_p]
+    L.acl_relation_id.argtypes = [H, C.c_int, C.c_char_p]
+    L.acl_intern.argtypes = [H, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
+    L.acl_find.argtypes = [H, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
+    L.acl_object_name.argtypes = [H, C.c_int, C.c_uint32]
+    L.acl_object_name.restype = C.c_char_p
+    L.acl_object_count.argtypes = [H, C.c_int]
+    L.acl_object_count.restype = C.c_uint32
+    L.acl_write.argtypes = [H, C.POINTER(Update), C.c_int, C.POINTER(Filter), C.c_int, C.POINTER(C.c_uint64)]
+    L.acl_delete_by_filter.argtypes = [H, C.POINTER(Filter), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.acl_read.argtypes = [H, C.POINTER(Filter), READ_CB, C.c_void_p]
+    L.acl_add_edges.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_revision.argtypes = [H]
+    L.acl_revision.restype = C.c_uint64
+    L.acl_set_now.argtypes = [H, C.c_int64]
+    L.acl_snapshot.argtypes = [H]
+    L.acl_check_bulk.argtypes = [H, C.POINTER(CheckItem), C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_check_bulk_ids.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_check_bulk_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_stream.argtypes = [H]
+    L.acl_stream.restype = C.c_void_p
+    L.acl_sync.argtypes = [H]
+    L.acl_lookup_resources.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.acl_lookup_resources_ids.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.acl_lookup_resources_batch.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_stats.argtypes = [H, C.POINTER(Stats)]
+    L.acl_stats_reset.argtypes = [H]
+    L.acl_set_timing.argtypes = [H, C.c_int]
+    _lib = L
+    return L

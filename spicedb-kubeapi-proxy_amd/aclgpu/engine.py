@@ -1,0 +1,252 @@
+"""Engine: thin Python handle over the C ABI (include/aclgpu.h).
+
+Numeric entry points take / return numpy arrays; the string entry points mirror
+the request shapes the reference builds in pkg/authz/check.go:23-39 and
+pkg/authz/lookups.go:49-62.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update
+
+PERM_UNSPECIFIED, PERM_NO, PERM_HAS, PERM_CONDITIONAL = 0, 1, 2, 3
+OP_CREATE, OP_TOUCH, OP_DELETE = 1, 2, 3
+PRE_MUST_NOT_MATCH, PRE_MUST_MATCH = 1, 2
+ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_ALREADY_EXISTS, ERR_RESOURCE_EXHAUSTED, ERR_FAILED_PRECONDITION = 3, 5, 6, 8, 9
+ERR_INTERNAL, ERR_UNAVAILABLE, ERR_DEPTH = 13, 14, 100
+NO_RELATION = 0xFFFF
+
+ITEM_DTYPE = np.dtype([("resource_type", "<u2"), ("permission", "<u2"), ("resource_id", "<u4"), ("subject_type", "<u2"),
+                       ("subject_relation", "<u2"), ("subject_id", "<u4")])
+assert ITEM_DTYPE.itemsize == 16
+
+
+class AclError(Exception):
+    """Carries the gRPC status code the Go shim would return (status.Code(err))."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+        self.message = msg
+
+
+def _b(s):
+    return None if s is None else s.encode()
+
+
+class Engine:
+    def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
+                 max_sub_batch: int = 0, store_only: bool = False):
+        self._L = _lib.load()
+        cfg = Config(device, frontier_entries, max_sub_batch, 1 if store_only else 0)
+        h = C.c_void_p()
+        rc = self._L.acl_open(C.byref(cfg), C.byref(h))
+        self._h = h if rc == 0 else None
+        self._check(rc)
+        if schema is not None:
+            self.load_bootstrap(schema, relationships)
+
+    # ---- plumbing
+    def _check(self, rc):
+        if rc:
+            raise AclError(rc, (self._L.acl_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.acl_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def load_bootstrap(self, schema: str, relationships: str | None = None):
+        s = schema.encode()
+        r = relationships.encode() if relationships else None
+        self._check(self._L.acl_load_bootstrap(self._h, s, len(s), r, len(r) if r else 0))
+
+    # ---- ids
+    def type_id(self, t: str) -> int:
+        return self._L.acl_type_id(self._h, _b(t))
+
+    def relation_id(self, t: str, r: str | None) -> int:
+        return -1 if not r else self._L.acl_relation_id(self._h, self.type_id(t), _b(r))
+
+    def intern(self, t: str, oid: str) -> int:
+        out = C.c_uint32()
+        self._check(self._L.acl_intern(self._h, self.type_id(t), _b(oid), C.byref(out)))
+        return out.value
+
+    def find(self, t: str, oid: str):
+        out = C.c_uint32()
+        rc = self._L.acl_find(self._h, self.type_id(t), _b(oid), C.byref(out))
+        return out.value if rc == 0 else None
+
+    def object_name(self, t: str, i: int):
+        n = self._L.acl_object_name(self._h, self.type_id(t), int(i))
+        return None if n is None else n.decode()
+
+    def object_count(self, t: str) -> int:
+        return self._L.acl_object_count(self._h, self.type_id(t))
+
+    # ---- writes
+    @staticmethod
+    def _mkrel(r, expires=0):
+        rt, rid, rel, st, sid, srel = r
+        return Relationship(_b(rt), _b(rid), _b(rel), _b(st), _b(sid), _b(srel or ""), int(expires))
+
+    @staticmethod
+    def _mkfilter(op=0, rtype=None, rid=None, rel=None, stype=None, sid=None, srel=None):
+        return Filter(op, _b(rtype), _b(rid), _b(rel), _b(stype), _b(sid), _b(srel))
+
+    def write(self, updates, preconditions=()):
+        """updates: [(op, (rt, rid, rel, st, sid, srel) | 'text', expires?)]; preconditions: [(op, {filter kwargs})]."""
+        from .text import parse_relationship
+        ups = (Update * max(1, len(updates)))()
+        for i, u in enumerate(updates):
+            r = parse_relationship(u[1]) if isinstance(u[1], str) else u[1]
+            ups[i] = Update(u[0], self._mkrel(r, u[2] if len(u) > 2 else 0))
+        pre = (Filter * max(1, len(preconditions)))()
+        for i, (op, f) in enumerate(preconditions):
+            pre[i] = self._mkfilter(op, **f)
+        rev = C.c_uint64()
+        self._check(self._L.acl_write(self._h, ups, len(updates), pre, len(preconditions), C.byref(rev)))
+        return rev.value
+
+    def touch(self, *rels):
+        return self.write([(OP_TOUCH, r) for r in rels])
+
+    def delete_by_filter(self, **f):
+        n, rev = C.c_uint64(), C.c_uint64()
+        flt = self._mkfilter(0, **f)
+        self._check(self._L.acl_delete_by_filter(self._h, C.byref(flt), C.byref(n), C.byref(rev)))
+        return n.value
+
+    def read(self, **f):
+        out = []
+
+        def cb(_u, rp):
+            r = rp.contents
+            out.append((r.resource_type.decode(), r.resource_id.decode(), r.relation.decode(), r.subject_type.decode(), r.subject_id.decode(),
+                        (r.subject_relation or b"").decode(), r.expires_at))
+
+        flt = self._mkfilter(0, **f)
+        self._check(self._L.acl_read(self._h, C.byref(flt), READ_CB(cb), None))
+        return out
+
+    def add_edges(self, rtype, rel, stype, srel, res, subj):
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        subj = np.ascontiguousarray(subj, dtype=np.uint32)
+        assert res.shape == subj.shape
+        self._check(self._L.acl_add_edges(self._h, self.type_id(rtype), self.relation_id(rtype, rel), self.type_id(stype),
+                                          self.relation_id(stype, srel), res.size, res.ctypes.data, subj.ctypes.data))
+
+    def set_now(self, t: int):
+        self._check(self._L.acl_set_now(self._h, int(t)))
+
+    @property
+    def revision(self):
+        return self._L.acl_revision(self._h)
+
+    def snapshot(self):
+        self._check(self._L.acl_snapshot(self._h))
+
+    # ---- checks
+    def check_bulk(self, items):
+        """items: [(rt, rid, perm, st, sid, srel)] -> (perms list, errs list); index aligned (check.go:54-57)."""
+        n = len(items)
+        arr = (CheckItem * max(1, n))()
+        for i, it in enumerate(items):
+            arr[i] = CheckItem(*[_b(x if x is not None else "") for x in it])
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_check_bulk(self._h, arr, n, perm.ctypes.data, err.ctypes.data))
+        return perm[:n].tolist(), err[:n].tolist()
+
+    def check(self, rt, rid, perm, st, sid, srel=""):
+        p, e = self.check_bulk([(rt, rid, perm, st, sid, srel)])
+        return p[0], e[0]
+
+    def make_items(self, rtype, perm, res, stype, srel, subj):
+        """Interned 16-byte items (acl_item_t) for one (type#perm, subject class) and id arrays."""
+        res = np.asarray(res, dtype=np.uint32)
+        items = np.zeros(res.size, dtype=ITEM_DTYPE)
+        items["resource_type"] = self.type_id(rtype)
+        items["permission"] = self.relation_id(rtype, perm)
+        items["resource_id"] = res
+        items["subject_type"] = self.type_id(stype)
+        r = self.relation_id(stype, srel)
+        items["subject_relation"] = NO_RELATION if r < 0 else r
+        items["subject_id"] = np.asarray(subj, dtype=np.uint32)
+        return items
+
+    def check_bulk_ids(self, items: np.ndarray):
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n = items.size
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_check_bulk_ids(self._h, items.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
+        return perm[:n], err[:n]
+
+    def check_bulk_ids_device(self, d_items: int, n: int, d_perm: int, d_err: int = 0):
+        """Device pointers (ints); asynchronous after return only w.r.t. the output buffers' readers on acl_stream."""
+        self._check(self._L.acl_check_bulk_ids_device(self._h, d_items, n, d_perm, d_err or None))
+
+    def sync(self):
+        self._check(self._L.acl_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return self._L.acl_stream(self._h) or 0
+
+    # ---- lookups
+    def lookup_bitmap(self, rt, perm, st, sid, srel=""):
+        words = (self.object_count(rt) + 1 + 31) // 32 + 1  # +1: the subject may be interned by the call
+        bm = np.zeros(words, dtype=np.uint32)
+        cnt = C.c_uint64()
+        self._check(self._L.acl_lookup_resources(self._h, _b(rt), _b(perm), _b(st), _b(sid), _b(srel or ""), bm.ctypes.data, words, C.byref(cnt)))
+        return bm, cnt.value
+
+    def lookup(self, rt, perm, st, sid, srel=""):
+        """-> set of resource ids (strings), as pkg/authz/lookups.go:129 collects them."""
+        bm, _ = self.lookup_bitmap(rt, perm, st, sid, srel)
+        ids = np.flatnonzero(np.unpackbits(bm.view(np.uint8), bitorder="little"))
+        return {self.object_name(rt, int(i)) for i in ids}
+
+    def lookup_ids_batch(self, rtype, perm, stype, srel, subject_ids):
+        sids = np.ascontiguousarray(subject_ids, dtype=np.uint32)
+        words = (self.object_count(rtype) + 31) // 32
+        bms = np.zeros((sids.size, max(1, words)), dtype=np.uint32)
+        counts = np.zeros(sids.size, dtype=np.uint64)
+        self._check(self._L.acl_lookup_resources_batch(self._h, self.type_id(rtype), self.relation_id(rtype, perm), self.type_id(stype),
+                                                       self.relation_id(stype, srel), sids.ctypes.data, sids.size, bms.ctypes.data, max(1, words),
+                                                       counts.ctypes.data))
+        return bms, counts
+
+    def lookup_ids(self, rtype, perm, stype, srel, subject_id):
+        bms, _ = self.lookup_ids_batch(rtype, perm, stype, srel, [subject_id])
+        return np.flatnonzero(np.unpackbits(bms[0].view(np.uint8), bitorder="little")).astype(np.uint32)
+
+    # ---- measurement
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(self._L.acl_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_}
+
+    def stats_reset(self):
+        self._check(self._L.acl_stats_reset(self._h))
+
+    def set_timing(self, on: bool):
+        self._check(self._L.acl_set_timing(self._h, 1 if on else 0))

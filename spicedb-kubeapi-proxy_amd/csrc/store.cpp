@@ -1,0 +1,369 @@
+// store.cpp -- see store.hpp.  Error codes follow what the reference's callers
+// observe from SpiceDB at the seam (SURVEY.md 8(b) "Error conventions").
+#include "store.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+
+#include "../../include/aclgpu.h"
+
+namespace acl {
+
+// ---------------------------------------------------------------- ObjectTable
+uint32_t ObjectTable::intern(const std::string &name) {
+    auto it = by_name_.find(name);
+    if (it != by_name_.end()) return it->second;
+    uint32_t id = count_++;
+    by_name_.emplace(name, id);
+    names_.emplace(id, name);
+    return id;
+}
+bool ObjectTable::find(const std::string &name, uint32_t *id) const {
+    auto it = by_name_.find(name);
+    if (it == by_name_.end()) return false;
+    *id = it->second;
+    return true;
+}
+const std::string *ObjectTable::name(uint32_t id) const {
+    auto it = names_.find(id);
+    return it == names_.end() ? nullptr : &it->second;
+}
+
+// ----------------------------------------------------------------- ClassTable
+void ClassTable::settle() {
+    if (pending.empty()) return;
+    std::sort(pending.begin(), pending.end());
+    pending.erase(std::unique(pending.begin(), pending.end()), pending.end());
+    if (keys.empty()) {
+        keys.swap(pending);
+    } else {
+        std::vector<uint64_t> merged;
+        merged.reserve(keys.size() + pending.size());
+        std::set_union(keys.begin(), keys.end(), pending.begin(), pending.end(), std::back_inserter(merged));
+        keys.swap(merged);
+    }
+    pending.clear();
+    pending.shrink_to_fit();
+}
+bool ClassTable::contains(uint64_t k) const { return std::binary_search(keys.begin(), keys.end(), k); }
+
+// ---------------------------------------------------------------------- text
+bool parse_relationship_text(const std::string &line, RelText *out) {
+    // grammar of pkg/rules/rules.go:1053-1055 (lazy groups => split at the FIRST separator)
+    size_t c1 = line.find(':');
+    if (c1 == std::string::npos) return false;
+    size_t h1 = line.find('#', c1 + 1);
+    if (h1 == std::string::npos) return false;
+    size_t at = line.find('@', h1 + 1);
+    if (at == std::string::npos) return false;
+    size_t c2 = line.find(':', at + 1);
+    if (c2 == std::string::npos) return false;
+    size_t h2 = line.find('#', c2 + 1);
+    out->rtype = line.substr(0, c1);
+    out->rid = line.substr(c1 + 1, h1 - c1 - 1);
+    out->rel = line.substr(h1 + 1, at - h1 - 1);
+    out->stype = line.substr(at + 1, c2 - at - 1);
+    if (h2 == std::string::npos) {
+        out->sid = line.substr(c2 + 1);
+        out->srel.clear();
+    } else {
+        out->sid = line.substr(c2 + 1, h2 - c2 - 1);
+        out->srel = line.substr(h2 + 1);
+    }
+    out->expires_at = 0;
+    return true;
+}
+
+// ---------------------------------------------------------------------- Store
+Status Store::load_schema(const std::string &text) {
+    Schema s;
+    std::string err;
+    if (!parse_schema(text, &s, &err)) return Status::Err(ACL_ERR_INVALID_ARGUMENT, err);
+    schema_ = std::move(s);
+    schema_loaded_ = true;
+    objects_.assign(schema_.defs.size(), ObjectTable());
+    tables_.assign(schema_.nslots, {});
+    for (int slot = 0; slot < schema_.nslots; slot++) {
+        auto [t, m] = schema_.slot_owner[slot];
+        tables_[slot].assign(schema_.defs[t].members[m].classes.size(), ClassTable());
+    }
+    revision_++;
+    return Status::Ok();
+}
+
+int64_t Store::now() const {
+    if (now_override_) return now_override_;
+    return std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+
+int Store::class_index(int slot, int stype, int srel) const {
+    auto [t, m] = schema_.slot_owner[slot];
+    const auto &cls = schema_.defs[t].members[m].classes;
+    for (size_t k = 0; k < cls.size(); k++)
+        if (cls[k].stype == stype && cls[k].srel == srel) return (int)k;
+    return -1;
+}
+
+void Store::settle_all() {
+    for (auto &slot : tables_)
+        for (auto &ct : slot) ct.settle();
+}
+
+void Store::expiry_window(int64_t now, int64_t *lo, int64_t *hi) const {
+    *lo = LLONG_MIN;
+    *hi = LLONG_MAX;
+    for (const auto &slot : tables_)
+        for (const auto &ct : slot)
+            for (const auto &kv : ct.expiry) {
+                if (kv.second <= now) *lo = std::max(*lo, kv.second);
+                else *hi = std::min(*hi, kv.second);
+            }
+}
+
+Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
+    if (r.rtype.empty() || r.rid.empty() || r.rel.empty() || r.stype.empty() || r.sid.empty())
+        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: empty field");
+    int rt = schema_.type_of(r.rtype);
+    if (rt < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + r.rtype + "` not found");
+    int rl = schema_.defs[rt].find(r.rel);
+    if (rl < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "relation/permission `" + r.rel + "` not found under definition `" + r.rtype + "`");
+    int st = schema_.type_of(r.stype);
+    if (st < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + r.stype + "` not found");
+    int sr = kNoRelation;
+    if (!r.srel.empty() && r.srel != "...") {
+        sr = schema_.defs[st].find(r.srel);
+        if (sr < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "relation/permission `" + r.srel + "` not found under definition `" + r.stype + "`");
+    }
+    const Member &mem = schema_.defs[rt].members[rl];
+    if (mem.is_permission) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "cannot write a relationship to permission `" + r.rel + "`");
+    out->slot = mem.slot;
+    out->rtype = rt;
+    out->stype = st;
+    out->cls = class_index(mem.slot, st, sr);
+    if (out->cls < 0)
+        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "subjects of type `" + r.stype + (sr == kNoRelation ? "" : "#" + r.srel) + "` are not allowed on relation `" + r.rtype + "#" + r.rel + "`");
+    if (r.expires_at && !mem.classes[out->cls].expiring)
+        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relation `" + r.rtype + "#" + r.rel + "` does not allow expiration for that subject type");
+    if (create_ids) {
+        out->res = objects_[rt].intern(r.rid);
+        out->subj = objects_[st].intern(r.sid);
+    } else {
+        if (!objects_[rt].find(r.rid, &out->res) || !objects_[st].find(r.sid, &out->subj)) return Status::Err(ACL_ERR_NOT_FOUND, "unknown object");
+    }
+    out->expires = r.expires_at;
+    return Status::Ok();
+}
+
+Status Store::validate_filter(const FilterText &f) const {
+    if (f.rtype.empty()) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: resource type is required");
+    int rt = schema_.type_of(f.rtype);
+    if (rt < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + f.rtype + "` not found");
+    if (f.has_rel && !f.rel.empty() && schema_.defs[rt].find(f.rel) < 0)
+        return Status::Err(ACL_ERR_FAILED_PRECONDITION, "relation `" + f.rel + "` not found under definition `" + f.rtype + "`");
+    if (f.has_stype && schema_.type_of(f.stype) < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + f.stype + "` not found");
+    return Status::Ok();
+}
+
+void Store::scan(const FilterText &f, int64_t now, const std::function<bool(int, int, uint64_t)> &fn) {
+    int rt = schema_.type_of(f.rtype);
+    const Definition &d = schema_.defs[rt];
+    bool want_rid = f.has_rid && !f.rid.empty();
+    uint32_t rid = 0;
+    if (want_rid && !objects_[rt].find(f.rid, &rid)) return;
+    for (size_t m = 0; m < d.members.size(); m++) {
+        const Member &mem = d.members[m];
+        if (mem.is_permission) continue;
+        if (f.has_rel && !f.rel.empty() && mem.name != f.rel) continue;
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            const SubjectClass &sc = mem.classes[k];
+            bool want_sid = false;
+            uint32_t sid = 0;
+            if (f.has_stype) {
+                if (schema_.defs[sc.stype].name != f.stype) continue;
+                if (f.has_srel) {
+                    bool only_none = f.srel.empty() || f.srel == "...";
+                    if (only_none ? sc.srel != kNoRelation : (sc.srel == kNoRelation || schema_.defs[sc.stype].members[sc.srel].name != f.srel)) continue;
+                }
+                if (f.has_sid && !f.sid.empty()) {
+                    want_sid = true;
+                    if (!objects_[sc.stype].find(f.sid, &sid)) continue;
+                }
+            }
+            ClassTable &ct = tables_[mem.slot][k];
+            ct.settle();
+            auto lo = ct.keys.begin(), hi = ct.keys.end();
+            if (want_rid) {
+                lo = std::lower_bound(ct.keys.begin(), ct.keys.end(), (uint64_t)rid << 32);
+                hi = std::lower_bound(lo, ct.keys.end(), ((uint64_t)rid + 1) << 32);
+            }
+            for (auto it = lo; it != hi; ++it) {
+                if (want_sid && (uint32_t)*it != sid) continue;
+                if (!live(ct, *it, now)) continue;
+                if (!fn(mem.slot, (int)k, *it)) return;
+            }
+        }
+    }
+}
+
+Status Store::write(const std::vector<UpdateText> &updates, const std::vector<FilterText> &pre, uint64_t *revision) {
+    if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    // limits pinned by the reference's engine config: pkg/spicedb/spicedb.go:35-36
+    if (updates.size() > 1000) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "update count of " + std::to_string(updates.size()) + " is greater than maximum allowed of 1000");
+    if (pre.size() > 1000) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "precondition count of " + std::to_string(pre.size()) + " is greater than maximum allowed of 1000");
+    for (const FilterText &f : pre) {
+        if (f.op != ACL_PRE_MUST_MATCH && f.op != ACL_PRE_MUST_NOT_MATCH) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid precondition operation");
+        Status s = validate_filter(f);
+        if (!s.ok()) return s;
+    }
+    std::vector<Resolved> rs(updates.size());
+    for (size_t i = 0; i < updates.size(); i++) {
+        if (updates[i].op < ACL_OP_CREATE || updates[i].op > ACL_OP_DELETE) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid update operation");
+        Status s = resolve(updates[i].rel, true, &rs[i]);
+        if (!s.ok()) return s;
+        for (size_t j = 0; j < i; j++)
+            if (rs[j].slot == rs[i].slot && rs[j].cls == rs[i].cls && rs[j].res == rs[i].res && rs[j].subj == rs[i].subj)
+                return Status::Err(ACL_ERR_INVALID_ARGUMENT, "found more than one update with relationship `" + updates[i].rel.rtype + ":" + updates[i].rel.rid + "#" + updates[i].rel.rel + "` in this request");
+    }
+    const int64_t t = now();
+    // all preconditions see the pre-write state (workflow.go:452-462)
+    for (const FilterText &f : pre) {
+        bool any = false;
+        scan(f, t, [&](int, int, uint64_t) {
+            any = true;
+            return false;
+        });
+        if ((f.op == ACL_PRE_MUST_MATCH && !any) || (f.op == ACL_PRE_MUST_NOT_MATCH && any))
+            return Status::Err(ACL_ERR_FAILED_PRECONDITION, "unable to satisfy write precondition");
+    }
+    for (size_t i = 0; i < updates.size(); i++) {
+        ClassTable &ct = tables_[rs[i].slot][rs[i].cls];
+        ct.settle();
+        if (updates[i].op != ACL_OP_CREATE) continue;
+        uint64_t key = (uint64_t)rs[i].res << 32 | rs[i].subj;
+        if (ct.contains(key) && live(ct, key, t))
+            return Status::Err(ACL_ERR_ALREADY_EXISTS, "could not CREATE relationship `" + updates[i].rel.rtype + ":" + updates[i].rel.rid + "#" + updates[i].rel.rel + "@" + updates[i].rel.stype + ":" + updates[i].rel.sid + "`, as it already existed");
+    }
+    for (size_t i = 0; i < updates.size(); i++) {
+        ClassTable &ct = tables_[rs[i].slot][rs[i].cls];
+        uint64_t key = (uint64_t)rs[i].res << 32 | rs[i].subj;
+        auto it = std::lower_bound(ct.keys.begin(), ct.keys.end(), key);
+        bool present = it != ct.keys.end() && *it == key;
+        if (updates[i].op == ACL_OP_DELETE) {
+            if (present) ct.keys.erase(it);
+            ct.expiry.erase(key);
+        } else {
+            if (!present) ct.keys.insert(it, key);
+            if (rs[i].expires) ct.expiry[key] = rs[i].expires;
+            else ct.expiry.erase(key);
+        }
+    }
+    revision_++;
+    if (revision) *revision = revision_;
+    return Status::Ok();
+}
+
+Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t *revision) {
+    if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    Status s = validate_filter(f);
+    if (!s.ok()) return s;
+    struct Hit { int slot, cls; uint64_t key; };
+    std::vector<Hit> hits;
+    scan(f, now(), [&](int slot, int cls, uint64_t key) {
+        hits.push_back({slot, cls, key});
+        return true;
+    });
+    for (const Hit &h : hits) {
+        ClassTable &ct = tables_[h.slot][h.cls];
+        auto it = std::lower_bound(ct.keys.begin(), ct.keys.end(), h.key);
+        if (it != ct.keys.end() && *it == h.key) ct.keys.erase(it);
+        ct.expiry.erase(h.key);
+    }
+    revision_++;
+    if (ndeleted) *ndeleted = hits.size();
+    if (revision) *revision = revision_;
+    return Status::Ok();
+}
+
+Status Store::read(const FilterText &f, const std::function<void(const RelText &)> &cb) {
+    if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    Status s = validate_filter(f);
+    if (!s.ok()) return s;
+    scan(f, now(), [&](int slot, int cls, uint64_t key) {
+        auto [t, m] = schema_.slot_owner[slot];
+        const Member &mem = schema_.defs[t].members[m];
+        const SubjectClass &sc = mem.classes[cls];
+        RelText r;
+        r.rtype = schema_.defs[t].name;
+        const std::string *rn = objects_[t].name((uint32_t)(key >> 32));
+        r.rid = rn ? *rn : "#" + std::to_string((uint32_t)(key >> 32));
+        r.rel = mem.name;
+        r.stype = schema_.defs[sc.stype].name;
+        const std::string *sn = objects_[sc.stype].name((uint32_t)key);
+        r.sid = sn ? *sn : "#" + std::to_string((uint32_t)key);
+        r.srel = sc.srel == kNoRelation ? "" : schema_.defs[sc.stype].members[sc.srel].name;
+        auto e = tables_[slot][cls].expiry.find(key);
+        r.expires_at = e == tables_[slot][cls].expiry.end() ? 0 : e->second;
+        cb(r);
+        return true;
+    });
+    return Status::Ok();
+}
+
+Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj) {
+    if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    if (rtype < 0 || rtype >= (int)schema_.defs.size() || stype < 0 || stype >= (int)schema_.defs.size() || rel < 0 ||
+        rel >= (int)schema_.defs[rtype].members.size())
+        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: type or relation index out of range");
+    const Member &mem = schema_.defs[rtype].members[rel];
+    if (mem.is_permission) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: cannot write a relationship to a permission");
+    int cls = class_index(mem.slot, stype, srel < 0 ? kNoRelation : srel);
+    if (cls < 0) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: subject type not allowed on relation");
+    ClassTable &ct = tables_[mem.slot][cls];
+    ct.pending.reserve(ct.pending.size() + n);
+    uint32_t maxr = 0, maxs = 0;
+    for (size_t i = 0; i < n; i++) {
+        ct.pending.push_back((uint64_t)res[i] << 32 | subj[i]);
+        maxr = std::max(maxr, res[i]);
+        maxs = std::max(maxs, subj[i]);
+    }
+    if (n) {
+        objects_[rtype].reserve_ids(maxr + 1);
+        objects_[stype].reserve_ids(maxs + 1);
+    }
+    revision_++;
+    return Status::Ok();
+}
+
+Status Store::load_relationship_lines(const std::string &text) {
+    size_t pos = 0;
+    std::vector<UpdateText> batch;
+    auto flush = [&]() -> Status {
+        if (batch.empty()) return Status::Ok();
+        Status s = write(batch, {}, nullptr);
+        batch.clear();
+        return s;
+    };
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        std::string line = text.substr(pos, e - pos);
+        pos = e + 1;
+        size_t b = line.find_first_not_of(" \t\r");
+        if (b == std::string::npos) continue;
+        size_t l = line.find_last_not_of(" \t\r");
+        line = line.substr(b, l - b + 1);
+        if (line.rfind("//", 0) == 0) continue;
+        UpdateText u;
+        u.op = ACL_OP_TOUCH;
+        if (!parse_relationship_text(line, &u.rel)) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship line `" + line + "`");
+        batch.push_back(std::move(u));
+        if (batch.size() == 1000) {
+            Status s = flush();
+            if (!s.ok()) return s;
+        }
+    }
+    return flush();
+}
+
+}  // namespace acl

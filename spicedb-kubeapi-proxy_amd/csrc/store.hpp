@@ -1,0 +1,131 @@
+// store.hpp -- host-side relationship store (the write side of the seam).
+//
+// Holds what the reference keeps in SpiceDB's memdb datastore
+// (pkg/spicedb/spicedb.go:61-68): every relationship written through
+// WriteRelationships (pkg/authz/distributedtx/activity.go:47-77), with the
+// CREATE / TOUCH / DELETE + precondition semantics its callers rely on
+// (workflow.go:134-201,452-462) and relationship expiration (spicedb.go:60).
+// It is the source the HBM snapshot (plan.hpp) is built from; no permission is
+// ever evaluated here.
+//
+// Layout: one ClassTable per (relation slot, subject class).  A relationship
+// inside a class is the 64-bit key (resource_id << 32 | subject_id); tables are
+// kept sorted, i.e. already in CSR order (rows = resources, columns sorted).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "schema.hpp"
+
+namespace acl {
+
+struct Status {
+    int code = 0;  // 0 or a gRPC code (aclgpu.h ACL_ERR_*)
+    std::string msg;
+    bool ok() const { return code == 0; }
+    static Status Ok() { return Status(); }
+    static Status Err(int c, std::string m) {
+        Status s;
+        s.code = c;
+        s.msg = std::move(m);
+        return s;
+    }
+};
+
+struct RelText {  // authzed.api.v1.Relationship as strings
+    std::string rtype, rid, rel, stype, sid, srel;
+    int64_t expires_at = 0;
+};
+struct UpdateText {
+    int op = 0;
+    RelText rel;
+};
+struct FilterText {  // authzed.api.v1.RelationshipFilter (+ precondition op)
+    int op = 0;
+    std::string rtype;
+    bool has_rid = false, has_rel = false, has_stype = false, has_sid = false, has_srel = false;
+    std::string rid, rel, stype, sid, srel;  // srel: "" means "only relationships without subject relation"
+};
+
+class ObjectTable {  // dense local ids of one object type
+  public:
+    uint32_t intern(const std::string &name);
+    bool find(const std::string &name, uint32_t *id) const;
+    const std::string *name(uint32_t id) const;  // nullptr for anonymous ids
+    uint32_t count() const { return count_; }
+    void reserve_ids(uint32_t n) {  // numeric bulk loads: ids < n exist (anonymous)
+        if (n > count_) count_ = n;
+    }
+
+  private:
+    std::unordered_map<std::string, uint32_t> by_name_;
+    std::unordered_map<uint32_t, std::string> names_;
+    uint32_t count_ = 0;
+};
+
+struct ClassTable {
+    std::vector<uint64_t> keys;     // sorted unique (res << 32 | subj)
+    std::vector<uint64_t> pending;  // unsorted bulk appends, merged by settle()
+    std::unordered_map<uint64_t, int64_t> expiry;  // only relationships with an expiration
+    void settle();
+    bool contains(uint64_t k) const;
+};
+
+class Store {
+  public:
+    Status load_schema(const std::string &text);
+    const Schema &schema() const { return schema_; }
+    bool has_schema() const { return !schema_.defs.empty() || schema_loaded_; }
+
+    ObjectTable &objects(int type) { return objects_[type]; }
+    const ObjectTable &objects(int type) const { return objects_[type]; }
+    // tables[slot][class]
+    std::vector<std::vector<ClassTable>> &tables() { return tables_; }
+
+    Status write(const std::vector<UpdateText> &updates, const std::vector<FilterText> &preconditions, uint64_t *revision);
+    Status delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t *revision);
+    Status read(const FilterText &f, const std::function<void(const RelText &)> &cb);
+    Status add_edges(int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj);
+    Status load_relationship_lines(const std::string &text);
+
+    uint64_t revision() const { return revision_; }
+    void settle_all();
+
+    // expiration clock (unix seconds).  now_override_ == 0 -> wall clock.
+    void set_now(int64_t t) { now_override_ = t; }
+    int64_t now() const;
+    bool live(const ClassTable &ct, uint64_t key, int64_t now) const {
+        if (ct.expiry.empty()) return true;
+        auto it = ct.expiry.find(key);
+        return it == ct.expiry.end() || it->second > now;
+    }
+    // interval of `now` values for which a snapshot built at `now` stays exact: [lo, hi)
+    void expiry_window(int64_t now, int64_t *lo, int64_t *hi) const;
+
+    int class_index(int slot, int stype, int srel) const;
+
+  private:
+    struct Resolved {
+        int slot, cls, rtype, stype;
+        uint32_t res, subj;
+        int64_t expires;
+    };
+    Status resolve(const RelText &r, bool create_ids, Resolved *out);
+    Status validate_filter(const FilterText &f) const;
+    // calls fn(slot, class, key) for every live relationship matching f; stops when fn returns false
+    void scan(const FilterText &f, int64_t now, const std::function<bool(int, int, uint64_t)> &fn);
+
+    Schema schema_;
+    bool schema_loaded_ = false;
+    std::vector<ObjectTable> objects_;
+    std::vector<std::vector<ClassTable>> tables_;
+    uint64_t revision_ = 1;
+    int64_t now_override_ = 0;
+};
+
+bool parse_relationship_text(const std::string &line, RelText *out);
+
+}  // namespace acl

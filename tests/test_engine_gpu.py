@@ -1,0 +1,185 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP frontier kernels, called
+through the C ABI, against the CPU oracle on the same inputs.  Bit-exact bar:
+identical permissionship AND identical per-item error code for every request,
+identical id SETS for every LookupResources."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests import kat_runner
+from tests.test_oracle_cross import QUERIES, SCHEMA, tuples_strategy
+
+pytestmark = pytest.mark.gpu
+
+KATS = kat_runner.load_kats()
+
+
+@pytest.fixture(scope="module")
+def aclgpu(aclgpu_lib):
+    import aclgpu as m
+    return m
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[k["name"] for k in KATS])
+def test_engine_kat(kat, aclgpu):
+    """Golden vectors of the reference's own tests through the GPU engine."""
+    schema, rels = kat_runner.kat_schema(kat)
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        kat_runner.run_kat(kat, e)
+
+
+def test_client_mirror_reads_like_reference_tests(aclgpu):
+    """KAT-1 written the way pkg/authz/distributedtx/workflow_test.go:79-119 does it, through the
+    PermissionsServiceClient mirror; plus the post-filter rule of postfilter.go:144-178."""
+    from aclgpu import client as v1
+    b = kat_runner.load_bootstrap()
+    with aclgpu.Engine(b["schema"], "\n".join(b["relationships"])) as e:
+        c = v1.PermissionsServiceClient(e)
+        c.WriteRelationships([v1.RelationshipUpdate(v1.OPERATION_CREATE, v1.Relationship(
+            v1.ObjectReference("namespace", "my_object_meta"), "creator", v1.SubjectReference(v1.ObjectReference("user", "janedoe"))))])
+        r = c.CheckPermission(v1.CheckPermissionRequest(v1.ObjectReference("namespace", "my_object_meta"), "view",
+                                                        v1.SubjectReference(v1.ObjectReference("user", "janedoe"))))
+        assert r.permissionship == v1.PERMISSIONSHIP_HAS_PERMISSION
+        with pytest.raises(aclgpu.AclError) as ei:  # pkg/proxy/options_test.go:101-102
+            c.CheckPermission(v1.CheckPermissionRequest())
+        assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
+        items = [v1.CheckPermissionRequest(v1.ObjectReference("namespace", n), "view", v1.SubjectReference(v1.ObjectReference("user", u)))
+                 for n, u in [("my_object_meta", "janedoe"), ("my_object_meta", "rakis"), ("spicedb-kubeapi-proxy", "rakis"), ("nope", "janedoe")]]
+        resp = c.CheckBulkPermissions(items)
+        assert [v1.is_allowed(p) for p in resp.pairs] == [True, False, True, False]
+        got = {r.resource_object_id for r in c.LookupResources(v1.LookupResourcesRequest("namespace", "view", v1.SubjectReference(v1.ObjectReference("user", "rakis"))))}
+        assert got == {"spicedb-kubeapi-proxy"}
+        assert c.DeleteRelationships(v1.RelationshipFilter("namespace", "my_object_meta")).relationships_deleted_count == 1
+        assert list(c.ReadRelationships(v1.RelationshipFilter("namespace", "my_object_meta"))) == []
+
+
+def test_depth_limit_chain(aclgpu):
+    """Dispatch depth 50 (pkg/spicedb/spicedb.go:34): HAS while <= 50 dispatches, error beyond -- same as the oracle."""
+    schema = "definition user {}\ndefinition group { relation member: user | group#member }"
+    n = 60
+    rels = [f"group:g{i}#member@group:g{i+1}#member" for i in range(n)] + [f"group:g{n}#member@user:deep"]
+    o = orc.Oracle(schema)
+    for i in range(0, len(rels), 500):
+        o.write([(orc.OP_TOUCH, r) for r in rels[i:i + 500]])
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        for k in range(0, n + 1):
+            assert e.check("group", f"g{k}", "member", "user", "deep") == o.check("group", f"g{k}", "member", "user", "deep"), k
+        assert e.check("group", f"g{n - 49}", "member", "user", "deep") == (2, 0)
+        assert e.check("group", f"g{n - 50}", "member", "user", "deep") == (0, aclgpu.ERR_DEPTH)
+        assert e.lookup("group", "member", "user", "deep") == o.lookup("group", "member", "user", "deep")
+
+
+def test_engine_matches_oracle_hypothesis(aclgpu):
+    """Random small graphs incl. cyclic group nesting, arrows, usersets with permissions as subject
+    relations: every query's (permissionship, error) and every lookup set equal the oracle's."""
+    from hypothesis import given, settings
+
+    eng = aclgpu.Engine(SCHEMA)
+    subjects = [("user", "u0", ""), ("group", "g0", "member"), ("group", "g1", "manage")]
+
+    @settings(max_examples=40, deadline=None)
+    @given(tuples_strategy())
+    def run(tuples):
+        eng.load_bootstrap(SCHEMA)
+        co = orc.Oracle(SCHEMA)
+        tuples = list(dict.fromkeys(tuples))
+        if tuples:
+            co.write([(orc.OP_TOUCH, t) for t in tuples])
+            eng.write([(aclgpu.OP_TOUCH, t) for t in tuples])
+        perms, errs = eng.check_bulk(QUERIES)
+        want = [co.check(*q) for q in QUERIES]
+        assert list(zip(perms, errs)) == want
+        for s in subjects:
+            for rt, p in [("doc", "view"), ("org", "view"), ("group", "member"), ("group", "manage"), ("doc", "nothing")]:
+                assert eng.lookup(rt, p, *s) == co.lookup(rt, p, *s), (rt, p, s)
+
+    run()
+    eng.close()
+
+
+WORKLOADS = [("C1", {}), ("C2", dict(scale=0.05, batch=20000)), ("C3", dict(scale=0.05, batch=5000, power_users=8)),
+             ("C4", dict(scale=0.02, batch=30000, n_user=20000))]
+
+
+@pytest.mark.parametrize("name,kw", WORKLOADS, ids=[w[0] for w in WORKLOADS])
+def test_workload_parity(name, kw, aclgpu):
+    """BASELINE configs at reduced scale: interned-id bulk Check and Filter bitmaps vs the oracle."""
+    from aclgpu import workloads
+    w = workloads.by_name(name, **kw)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        rt, perm, st = w.check
+        items = e.make_items(rt, perm, w.res, st, "", w.subj)
+        perms, errs = e.check_bulk_ids(items)
+        operms, oerrs = o.check_bulk_ids(rt, perm, w.res, st, "", w.subj)
+        assert np.array_equal(perms, operms)
+        assert np.array_equal(errs, oerrs)
+        assert 0 < (perms == 2).sum() < perms.size or name == "C4"
+        # device-resident entry point gives the same bytes
+        import torch
+        d_items = torch.from_numpy(items.view(np.uint8).copy()).cuda()
+        d_perm = torch.zeros(items.size, dtype=torch.uint8, device="cuda")
+        d_err = torch.zeros(items.size, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        e.check_bulk_ids_device(d_items.data_ptr(), items.size, d_perm.data_ptr(), d_err.data_ptr())
+        e.sync()
+        assert np.array_equal(d_perm.cpu().numpy(), operms) and np.array_equal(d_err.cpu().numpy(), oerrs)
+        # Filter: LookupResources bitmaps == {id : oracle check == HAS}
+        rng = np.random.default_rng(7)
+        subs = list(rng.integers(0, w.nobjects[st], size=6))
+        if w.lookup_subjects is not None:
+            subs += list(w.lookup_subjects[:6])
+        bms, counts = e.lookup_ids_batch(rt, perm, st, "", subs)
+        for i, s in enumerate(subs):
+            want = np.sort(o.lookup_ids(rt, perm, st, "", int(s)))
+            got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little")).astype(np.uint32)
+            assert np.array_equal(got, want), (name, s, got.size, want.size)
+            assert counts[i] == want.size
+
+
+def test_edge_cases(aclgpu):
+    """Empty batch, empty graph, ragged batch sizes around the chunk size, invalid interned items."""
+    from aclgpu import workloads
+    w = workloads.c1()
+    with aclgpu.Engine(w.schema) as e:
+        items = e.make_items("namespace", "view", w.res, "user", "", w.subj)
+        p, er = e.check_bulk_ids(items[:0])
+        assert p.size == 0
+        p, er = e.check_bulk_ids(items)  # no relationships at all
+        assert (p == 1).all() and (er == 0).all()
+        assert e.lookup_ids("namespace", "view", "user", "", 3).size == 0
+        w.load(e)
+        o = orc.Oracle(w.schema)
+        w.load(o)
+        rng = np.random.default_rng(1)
+        for n in (1, 63, 64, 65, 1023, 1024, 1025, 4097):
+            res = rng.integers(0, 1000, size=n).astype(np.uint32)
+            sub = rng.integers(0, 1000, size=n).astype(np.uint32)
+            p, er = e.check_bulk_ids(e.make_items("namespace", "view", res, "user", "", sub))
+            op, oe = o.check_bulk_ids("namespace", "view", res, "user", "", sub)
+            assert np.array_equal(p, op) and np.array_equal(er, oe), n
+        bad = e.make_items("namespace", "view", [1, 2, 3], "user", "", [1, 2, 3])
+        bad["permission"][1] = 77
+        bad["resource_type"][2] = 999
+        p, er = e.check_bulk_ids(bad)
+        assert er.tolist()[1:] == [aclgpu.ERR_FAILED_PRECONDITION] * 2 and p.tolist()[1:] == [0, 0]
+        # ids beyond the dense id space have no relationships
+        far = e.make_items("namespace", "view", [4_000_000_000], "user", "", [5])
+        assert e.check_bulk_ids(far)[0].tolist() == [1]
+
+
+def test_frontier_overflow_grows(aclgpu):
+    """A frontier too small for the batch is grown and the pass redone -- same answers."""
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.02, batch=20000, n_user=20000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    with aclgpu.Engine(w.schema, frontier_entries=4096) as e:
+        w.load(e)
+        p, er = e.check_bulk_ids(e.make_items("pod", "view", w.res, "user", "", w.subj))
+        op, oe = o.check_bulk_ids("pod", "view", w.res, "user", "", w.subj)
+        assert np.array_equal(p, op) and np.array_equal(er, oe)
+        assert e.stats()["overflow_retries"] >= 1
