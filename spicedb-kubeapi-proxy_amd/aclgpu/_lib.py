@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libaclgpu.so")
+LIB_PATH = os.environ.get("ACLGPU_LIB") or os.path.join(_PKG, "lib", "libaclgpu.so")  # ACLGPU_LIB: A/B a kernel variant build
 
 # every symbol include/aclgpu.h declares (checked by tests/test_abi.py against the header)
 SYMBOLS = [

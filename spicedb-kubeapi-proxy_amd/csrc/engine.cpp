@@ -74,7 +74,7 @@ struct acl_engine {
     hipStream_t stream = nullptr;
     int grid_blocks = 2048;
     // forward graph
-    DevArray<uint32_t> d_off, d_edges, d_tsb, d_tnm;
+    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
     DevArray<FwdOp> d_ops;
     DevArray<SlotProg> d_progs;
     // reverse graph
@@ -83,7 +83,7 @@ struct acl_engine {
     DevArray<RevProg> d_rprogs, d_rseeds;
     // frontier
     DevArray<uint4> d_fbuf[2];
-    DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] + overflow
+    DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow
     uint64_t frontier_entries = 0;
     uint32_t max_chunks = 0;
     uint32_t *h_status = nullptr;  // pinned
@@ -101,7 +101,7 @@ struct acl_engine {
     std::vector<int> ev_kind;  // per pair: 0 other, 1 expand
 
     DevGraph dev_graph() const {
-        return DevGraph{d_off.p, d_edges.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes};
+        return DevGraph{d_meta.p, d_edges.p, d_buckets.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
     }
     DevFrontier dev_frontier() const {
         DevFrontier f;
@@ -110,7 +110,9 @@ struct acl_engine {
         f.counts[0] = d_fcounts[0].p;
         f.counts[1] = d_fcounts[1].p;
         f.nchunks = d_status.p;
-        f.overflow = d_status.p + kLevelSlots;
+        f.any = d_status.p + kLevelSlots;
+        f.overflow = d_status.p + 2 * kLevelSlots;
+        f.nwaves = (uint32_t)grid_blocks * kWavesPerBlock;
         f.max_chunks = max_chunks;
         return f;
     }
@@ -119,7 +121,8 @@ struct acl_engine {
 namespace {
 
 int alloc_frontier(acl_engine *h, uint64_t entries) {
-    entries = std::max<uint64_t>(entries, 4 * kChunk);
+    // every wave of an expand launch owns one static chunk; at least one dynamic chunk on top
+    entries = std::max<uint64_t>(entries, ((uint64_t)h->grid_blocks * kWavesPerBlock + 1) * kChunk);
     uint64_t chunks = (entries + kChunk - 1) / kChunk;
     if (chunks > 0x3FFFFFu) chunks = 0x3FFFFFu;  // entry indices stay below 2^32
     for (int i = 0; i < 2; i++) {
@@ -169,8 +172,9 @@ int ensure_snapshot(acl_engine *h) {
     const int64_t now = h->store.now();
     if (h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi) return ACL_OK;
     build_forward(h->store, now, &h->snap);
-    HIP_TRY(h->d_off.upload(h->snap.off, h->stream));
+    HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
     HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
+    HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
     HIP_TRY(h->d_ops.upload(h->snap.ops, h->stream));
     HIP_TRY(h->d_progs.upload(h->snap.progs, h->stream));
     HIP_TRY(h->d_tsb.upload(h->snap.type_slot_base, h->stream));
@@ -180,7 +184,7 @@ int ensure_snapshot(acl_engine *h) {
     h->rev_uploaded = false;
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
-    h->stats.snapshot_bytes = h->snap.off.size() * 4 + h->snap.edges.size() * 4 + h->snap.ops.size() * sizeof(FwdOp) + h->snap.progs.size() * sizeof(SlotProg);
+    h->stats.snapshot_bytes = h->snap.meta.size() * 4 + h->snap.edges.size() * 4 + h->snap.buckets.size() * 4 + h->snap.ops.size() * sizeof(FwdOp) + h->snap.progs.size() * sizeof(SlotProg);
     return ACL_OK;
 }
 
@@ -215,17 +219,17 @@ int level_loop(acl_engine *h, uint32_t max_iter, F launch, uint32_t *levels_out)
             ev_end(h);
             h->stats.expand_launches++;
         }
-        HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, (kLevelSlots + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         ev_collect(h);
-        if (h->h_status[kLevelSlots] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
-        if (h->h_status[kLevelSlots]) return ACL_ERR_RESOURCE_EXHAUSTED;
+        if (h->h_status[2 * kLevelSlots] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+        if (h->h_status[2 * kLevelSlots]) return ACL_ERR_RESOURCE_EXHAUSTED;
         uint32_t done_at = 0;
         for (uint32_t it = next; it <= last; it++)
-            if (h->h_status[it] == 0) { done_at = it; break; }
+            if (h->h_status[kLevelSlots + it] == 0) { done_at = it; break; }  // any[it]: iteration `it` produced nothing
         if (done_at || last == max_iter) {
             uint32_t lv = done_at ? done_at : max_iter;
-            for (uint32_t it = 0; it < lv; it++) h->stats.frontier_entries += (uint64_t)h->h_status[it] * kChunk;  // upper bound (chunk granularity)
+            for (uint32_t it = 0; it < lv; it++) h->stats.frontier_entries += (uint64_t)h->h_status[it] * kChunk;  // dynamic chunks only (lower bound)
             *levels_out = lv;
             return ACL_OK;
         }
@@ -245,13 +249,13 @@ int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm,
         }
         DevGraph g = h->dev_graph();
         DevFrontier f = h->dev_frontier();
-        HIP_TRY(hipMemsetAsync(h->d_status.p, 0, (kLevelSlots + 1) * sizeof(uint32_t), h->stream));
+        HIP_TRY(hipMemsetAsync(h->d_status.p, 0, kStatusWords * sizeof(uint32_t), h->stream));
         ev_begin(h, 0);
-        launch_seed(h->stream, g, f, d_items, n, 0, h->d_has.p, h->d_err.p);
+        launch_seed(h->stream, g, f, d_items, n, h->d_has.p, h->d_err.p);
         ev_end(h);
         uint32_t levels = 0;
-        int rc = level_loop(h, kMaxLevels, [&](uint32_t it) { launch_expand(h->stream, h->grid_blocks, g, f, it, h->d_has.p, h->d_err.p); }, &levels);
-        if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[kLevelSlots] == 1) {
+        int rc = level_loop(h, kMaxLevels, [&](uint32_t it) { launch_expand(h->stream, g, f, it, h->d_has.p, h->d_err.p); }, &levels);
+        if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
             // frontier out of chunks: grow (up to 2^32 entries) and redo the pass
             h->stats.overflow_retries++;
             if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8)
@@ -328,17 +332,17 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     h->device = dev;
     hipError_t e = hipSetDevice(dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = h->d_status.ensure(kLevelSlots + 1);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_status, (kLevelSlots + 1) * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = h->d_status.ensure(kStatusWords);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::string m = std::string("acl_open: ") + hipGetErrorString(e);
         delete h;
         return fail(ACL_ERR_UNAVAILABLE, m);
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->grid_blocks = prop.multiProcessorCount * 8;
+    h->grid_blocks = expand_grid_blocks(dev);
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
-    int rc = alloc_frontier(h, cfg && cfg->frontier_entries ? cfg->frontier_entries : (uint64_t)(16u << 20));
+    int rc = alloc_frontier(h, cfg && cfg->frontier_entries ? cfg->frontier_entries
+                                                            : std::max<uint64_t>(16u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));
     if (rc) {
         delete h;
         return rc;
@@ -598,16 +602,19 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
             DevFrontier f = h->dev_frontier();
             seeds.resize(m);
             for (size_t i = 0; i < m; i++) seeds[i] = make_uint4(sids[b + i], (uint32_t)i, key /* dist 0 */, 0);
-            std::vector<uint32_t> st(kLevelSlots + 1, 0), cc((m + kChunk - 1) / kChunk);
-            st[0] = (uint32_t)cc.size();
-            for (size_t c = 0; c < cc.size(); c++) cc[c] = (uint32_t)std::min<size_t>(kChunk, m - c * kChunk);
+            // seeds fill chunks [0, need); the reader scans every static chunk, so publish counts for all of them
+            const size_t need_chunks = (m + kChunk - 1) / kChunk;
+            std::vector<uint32_t> st(kStatusWords, 0), cc(std::max<size_t>(need_chunks, f.nwaves), 0);
+            st[0] = need_chunks > f.nwaves ? (uint32_t)(need_chunks - f.nwaves) : 0u;  // dynamic chunks of "iteration 0"
+            st[kLevelSlots] = 1;                                                         // any[0]
+            for (size_t c = 0; c < need_chunks; c++) cc[c] = (uint32_t)std::min<size_t>(kChunk, m - c * kChunk);
             HIP_TRY(hipMemcpyAsync(h->d_status.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(f.buf[0], seeds.data(), m * sizeof(uint4), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(f.counts[0], cc.data(), cc.size() * 4, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope below
             uint32_t levels = 0;
-            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, h->grid_blocks, r, f, it, h->snap.nslots); }, &levels);
-            if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[kLevelSlots] == 1) {
+            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels);
+            if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
                 h->stats.overflow_retries++;
                 if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
                 int rc2 = alloc_frontier(h, h->frontier_entries * 4);

@@ -7,18 +7,23 @@
 // dispatch level per launch:
 //
 //   frontier entry = (request, object#relation state)                16 B
-//   k_expand: every lane takes one entry, interprets the state's flattened
-//             program (plan.hpp): binary-search probes of the sorted CSR row for the
-//             request's subject, and "enumerate" operations whose child states are
-//             produced by a wave-cooperative, load-balanced expansion:
+//   k_expand: every lane takes one entry and interprets the state's flattened
+//             program (plan.hpp, cached in LDS): probes of the request's subject in
+//             hashed 4-slot bucket rows (one 16 B gather) or sorted rows (binary
+//             search), and "enumerate" operations whose child states are produced by
+//             a wave-cooperative, load-balanced expansion:
 //               - per-lane tasks (row start, degree) are compacted into LDS with
 //                 wave64 ballot + mbcnt,
-//               - a wave prefix-sum over task degrees sizes the output,
-//               - lanes then take consecutive OUTPUT slots, find their task by
-//                 binary search in the LDS prefix array, and load consecutive edges
-//                 of a row (coalesced) and store consecutive 16 B entries (coalesced).
-//   Output space comes from wave-private 16 KiB chunks, so the only global atomic
-//   is one per ~1024 produced entries.
+//               - a wave prefix-sum over task degrees sizes the work,
+//               - lanes then take consecutive work items, find their task by binary
+//                 search in the LDS prefix array and load consecutive edges of a row
+//                 (coalesced),
+//               - each child's own probes are evaluated RIGHT THERE (child mode); only
+//                 children that still have something to enumerate are written, compacted
+//                 with a second ballot, as consecutive 16 B entries (coalesced).  Leaf
+//                 states therefore never enter the frontier.
+//   Output space: every wave owns one static 16 KiB chunk per level (no allocation at
+//   all for the common case); further chunks come from one atomicAdd per 1024 entries.
 //
 // Bound: HBM/L2 transactions (random row gathers); no MFMA anywhere by design.
 #include "kernels.hpp"
@@ -26,12 +31,22 @@
 namespace acl {
 namespace {
 
-constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWavesPerBlock * 64;
-constexpr uint32_t kTaskCap = 192;  // LDS task slots per wave
+#ifndef ACL_MIN_WAVES_PER_SIMD
+#define ACL_MIN_WAVES_PER_SIMD 8  // 8 blocks of 4 waves per CU: the kernels are latency bound, residency is what hides it
+#endif
+constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kSelfBit = 0x80000000u;
-constexpr uint32_t kNoChunk = 0xFFFFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
+
+// entry meta: slot[0:13) | level[13:19) | probed[19] | subject key[20:32)
+constexpr uint32_t kProbedBit = 1u << 19;
+__device__ __forceinline__ uint32_t meta_slot(uint32_t m) { return m & 0x1FFFu; }
+__device__ __forceinline__ uint32_t meta_level(uint32_t m) { return (m >> 13) & 63u; }
+__device__ __forceinline__ uint32_t meta_key(uint32_t m) { return m >> 20; }
+__device__ __forceinline__ uint32_t make_meta(uint32_t slot, uint32_t level, uint32_t key) { return slot | (level << 13) | (key << 20); }
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
@@ -57,7 +72,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// LDS-staged task list of one wave + its private output chunk.
+// LDS-staged task list of one wave.
 struct TaskLds {
     uint32_t start[kTaskCap];  // first edge (absolute index) -- or the object id for a "self" task
     uint32_t count[kTaskCap];  // degree (| kSelfBit)
@@ -67,69 +82,32 @@ struct TaskLds {
     uint32_t scan[64];
 };
 
+// Wave-private output cursor.  The wave starts on its static chunk (id = wave index); when that is full it
+// closes it (count store) and takes a dynamic chunk.  All fields wave-uniform.
 struct WaveOut {
-    uint32_t cur = kNoChunk;  // wave-uniform
-    uint32_t fill = 0;
+    uint32_t cur, fill, produced;
 };
 
-// Reserve `total` consecutive output entries for this wave. Returns the first entry index
-// or 0xFFFFFFFF when the frontier is out of chunks (overflow flag raised).
-__device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t total, uint32_t lane, uint32_t *out_counts, uint32_t *out_nchunks,
-                                            uint32_t max_chunks, uint32_t *overflow) {
-    if (wo.cur != kNoChunk && wo.fill + total <= kChunk) {
-        uint32_t base = wo.cur * kChunk + wo.fill;
-        wo.fill += total;
-        return base;
-    }
-    if (wo.cur != kNoChunk && lane == 0) out_counts[wo.cur] = wo.fill;
-    uint32_t m = (total + kChunk - 1) / kChunk;
-    uint32_t cb = 0;
-    if (lane == 0) cb = atomicAdd(out_nchunks, m);
-    cb = uniform(cb);
-    if (cb + m > max_chunks || cb + m < cb) {
-        if (lane == 0) *overflow = 1u;
-        wo.cur = kNoChunk;
-        wo.fill = 0;
-        return 0xFFFFFFFFu;
-    }
-    for (uint32_t c = lane; c + 1 < m; c += 64) out_counts[cb + c] = kChunk;
-    wo.cur = cb + m - 1;
-    wo.fill = total - (m - 1) * kChunk;
-    return cb * kChunk;
-}
-
-// Expand the first T tasks of the wave's LDS list into output entries.
-__device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const uint32_t *__restrict__ edges,
-                                            uint4 *__restrict__ out, uint32_t *out_counts, uint32_t *out_nchunks, uint32_t max_chunks,
-                                            uint32_t *overflow) {
-    wave_lds_fence();
-    for (uint32_t g = 0; g < T; g += 64) {
-        uint32_t cnt = (g + lane < T) ? (t.count[g + lane] & ~kSelfBit) : 0u;
-        uint32_t incl = wave_incl_scan(cnt, lane);
-        uint32_t total = uniform(__shfl(incl, 63, 64));
-        t.scan[lane] = incl - cnt;
-        wave_lds_fence();
-        if (total) {
-            uint32_t base = reserve(wo, total, lane, out_counts, out_nchunks, max_chunks, overflow);
-            if (base != 0xFFFFFFFFu) {
-                for (uint32_t w0 = 0; w0 < total; w0 += 64) {
-                    uint32_t w = w0 + lane;
-                    if (w < total) {
-                        // largest j with scan[j] <= w
-                        uint32_t j = 0;
-#pragma unroll
-                        for (uint32_t step = 32; step >= 1; step >>= 1)
-                            if (t.scan[j + step] <= w) j += step;
-                        uint32_t tj = g + j;
-                        uint32_t c = t.count[tj], s = t.start[tj];
-                        uint32_t child = (c & kSelfBit) ? s : edges[s + (w - t.scan[j])];
-                        out[base + w] = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
-                    }
-                }
-            }
+// room for `need` (<= 64) consecutive entries; returns the first entry index
+__device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane, const DevFrontier &f, uint32_t *out_counts, uint32_t *out_nchunks) {
+    if (wo.cur == kNoSpace) return kNoSpace;
+    if (wo.fill + need > kChunk) {
+        if (lane == 0) out_counts[wo.cur] = wo.fill;
+        uint32_t c = 0;
+        if (lane == 0) c = atomicAdd(out_nchunks, 1u);
+        c = uniform(c) + f.nwaves;
+        if (c >= f.max_chunks) {
+            if (lane == 0) *f.overflow = 1u;
+            wo.cur = kNoSpace;
+            return kNoSpace;
         }
-        wave_lds_fence();
+        wo.cur = c;
+        wo.fill = 0;
     }
+    const uint32_t base = wo.cur * kChunk + wo.fill;
+    wo.fill += need;
+    wo.produced += need;
+    return base;
 }
 
 __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges, uint32_t lo, uint32_t hi, uint32_t key) {
@@ -142,12 +120,127 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
     return lo < end && edges[lo] == key;
 }
 
+// hashed sub-row: nb = b1 - b0 buckets of 4 ids; same placement rule as plan.cpp (hash_bucket + linear probing)
+__device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t sid) {
+    const uint32_t nb = b1 - b0;
+    uint32_t b = (uint32_t)(((uint64_t)(sid * 0x9E3779B1u) * nb) >> 32);
+    for (uint32_t i = 0; i < nb; i++) {
+        const uint4 q = buckets[b0 + b];
+        if (q.x == sid || q.y == sid || q.z == sid || q.w == sid) return true;
+        if (q.x == kEmptySlot || q.y == kEmptySlot || q.z == kEmptySlot || q.w == kEmptySlot) return false;
+        b = b + 1 == nb ? 0 : b + 1;
+    }
+    return false;
+}
+
+// Row descriptor {start, end} of (object id, class op.k).  Relations with two subject classes keep both
+// descriptors in one aligned 16 B record, fetched once per state and reused by the state's next op.
+struct RowCache {
+    uint32_t base = 0xFFFFFFFFu;
+    uint4 v;
+};
+__device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, uint32_t id, RowCache &rc) {
+    if (op.K == 2) {
+        if (rc.base != op.meta_base) {
+            rc.v = reinterpret_cast<const uint4 *>(g.meta)[(op.meta_base >> 1) + id];
+            rc.base = op.meta_base;
+        }
+        return op.k ? make_uint2(rc.v.z, rc.v.w) : make_uint2(rc.v.x, rc.v.y);
+    }
+    return reinterpret_cast<const uint2 *>(g.meta)[op.meta_base + (size_t)id * op.K + op.k];
+}
+
+// Child mode: evaluate every probe of state (slot, id) at `level` for subject (key, sid) without creating tasks.
+// Returns true when the state still has something to enumerate (=> it must be written to the frontier).
+__device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *progs, const FwdOp *ops, uint32_t slot, uint32_t level, uint32_t key,
+                                           uint32_t id, uint32_t sid, bool &hit, bool &depth_err) {
+    const SlotProg p = progs[slot];
+    if (level + p.max_dlevel > kMaxLevels) depth_err = true;
+    const uint32_t nops = key < g.nslots ? p.n_total : p.n_main;
+    bool push = false;
+    RowCache rc;
+    for (uint32_t j = 0; j < nops; j++) {
+        const FwdOp op = ops[p.first + j];
+        const uint32_t L = level + op.dlevel;
+        if (L > kMaxLevels) continue;
+        if (op.flags & OP_REFLEX) {
+            if (key == op.key && id == sid) hit = true;
+        } else if (op.flags & OP_PUSH_SAME) {
+            push = true;
+        } else if (id < op.nrows) {
+            const uint2 md = row_meta(g, op, id, rc);
+            if (md.y > md.x) {
+                if (key == op.key) {
+                    if (op.flags & OP_PROBE_HASH) hit |= bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, sid);
+                    else if (op.flags & OP_PROBE) hit |= row_contains(g.edges, md.x, md.y, sid);
+                }
+                if (op.flags & OP_ENUM) push = true;
+            }
+        }
+    }
+    return push;
+}
+
+// Expand the first T tasks of the wave's LDS list.  INLINE: children are probed here and only the ones with
+// remaining enumeration work are written (forward Check); otherwise every child is written (reverse walk).
+template <bool INLINE>
+__device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
+                                            const FwdOp *ops, const uint32_t *__restrict__ edges, const DevFrontier &f, uint4 *__restrict__ out,
+                                            uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err) {
+    wave_lds_fence();
+    for (uint32_t gq = 0; gq < T; gq += 64) {
+        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & ~kSelfBit) : 0u;
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        t.scan[lane] = incl - cnt;
+        wave_lds_fence();
+        for (uint32_t w0 = 0; w0 < total; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            bool push = false;
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (w < total) {
+                uint32_t j = 0;  // largest j with scan[j] <= w
+#pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1)
+                    if (t.scan[j + step] <= w) j += step;
+                const uint32_t tj = gq + j;
+                const uint32_t c = t.count[tj], s = t.start[tj];
+                const uint32_t child = (c & kSelfBit) ? s : edges[s + (w - t.scan[j])];
+                e = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
+                push = true;
+                if (INLINE) {
+                    bool hit = false, derr = false;
+                    push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, hit, derr);
+                    if (hit) {
+                        has[e.y] = 1;
+                        push = false;
+                    } else if (derr) {
+                        err[e.y] = ITEM_ERR_DEPTH;
+                    }
+                    e.z |= kProbedBit;
+                }
+            }
+            const uint64_t b = __ballot(push);
+            if (b) {
+                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                if (push && base != kNoSpace) out[base + lanes_below(b)] = e;
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 // ------------------------------------------------------------------ seed
 // items: acl_item_t (16 B): x = rtype | perm << 16, y = resource id, z = stype | srel << 16, w = subject id
 __global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const uint4 *__restrict__ items, uint32_t n, uint8_t *has, uint8_t *err) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) f.nchunks[0] = (n + kChunk - 1) / kChunk;
-    if (i < (n + kChunk - 1) / kChunk) f.counts[0][i] = min(kChunk, n - i * kChunk);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t need = (n + kChunk - 1) / kChunk;       // chunks holding seeds: ids [0, need)
+    const uint32_t readable = max(need, f.nwaves);          // the reader scans every static chunk
+    if (i == 0) {
+        f.nchunks[0] = need > f.nwaves ? need - f.nwaves : 0u;
+        f.any[0] = 1u;
+    }
+    if (i < readable) f.counts[0][i] = i < need ? min(kChunk, n - i * kChunk) : 0u;
     if (i >= n) return;
     uint4 it = items[i];
     uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
@@ -159,48 +252,69 @@ __global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const u
     if (ok) {
         uint32_t slot = g.type_slot_base[rtype] + perm;
         uint32_t key = srel == 0xFFFFu ? g.nslots + stype : g.type_slot_base[stype] + srel;
-        meta = slot | (1u << 13) | (key << 19);
+        meta = make_meta(slot, 1u, key);
     }
     f.buf[0][i] = make_uint4(it.y, i, meta, it.w);
 }
 
 // ---------------------------------------------------------------- expand
-__global__ __launch_bounds__(kBlock) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err) {
+template <bool LDSPROG>
+__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err) {
     __shared__ TaskLds lds[kWavesPerBlock];
+    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
+    const SlotProg *progs = g.progs;
+    const FwdOp *ops = g.ops;
+    if (LDSPROG) {  // the whole program table (a few hundred bytes for real schemas) lives in LDS
+        const uint32_t np = g.nslots * 2, no = g.nops * 2;
+        for (uint32_t i = threadIdx.x; i < np; i += kBlock) s_prog[i] = reinterpret_cast<const uint4 *>(g.progs)[i];
+        for (uint32_t i = threadIdx.x; i < no; i += kBlock) s_prog[np + i] = reinterpret_cast<const uint4 *>(g.ops)[i];
+        __syncthreads();
+        progs = reinterpret_cast<const SlotProg *>(s_prog);
+        ops = reinterpret_cast<const FwdOp *>(s_prog + np);
+    }
     const uint32_t lane = lane_id();
     const uint32_t wib = threadIdx.x >> 6;
     TaskLds &t = lds[wib];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
     const uint32_t pin = (iter + 1) & 1u, pout = iter & 1u;  // iteration i reads parity (i-1)&1
     const uint4 *__restrict__ in = f.buf[pin];
     const uint32_t *__restrict__ in_counts = f.counts[pin];
     uint4 *__restrict__ out = f.buf[pout];
     uint32_t *out_counts = f.counts[pout];
     uint32_t *out_nchunks = f.nchunks + iter;
-    if (*f.overflow) return;
-    uint32_t C = min(f.nchunks[iter - 1], f.max_chunks);
-    WaveOut wo;
+    const bool live = !*f.overflow && f.any[iter - 1];
+    const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
+    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
+    WaveOut wo{wave, 0u, 0u};
     for (uint32_t x = wave; x < C * kSegsPerChunk; x += nwaves) {
-        const uint32_t c = x / kSegsPerChunk, s = x % kSegsPerChunk;
+        // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
+        // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
+        // (each segment layer is rotated so that one wave does not keep landing on the same chunk)
+        const uint32_t s = x / C, c = (x % C + s * 509u) % C;
         const uint32_t cnt = in_counts[c];
         if (s * 64 >= cnt) continue;
         const bool valid = s * 64 + lane < cnt;
-        uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
         bool active = valid && meta != kDeadMeta;
         if (active && has[req]) active = false;  // request already answered HAS: drop its pending work
-        const uint32_t slot = meta & 0x1FFFu, level = (meta >> 13) & 63u, key = meta >> 19;
-        SlotProg p = active ? g.progs[slot] : SlotProg{0, 0, 0, 0};
-        const uint32_t nops = active ? (key < g.nslots ? p.n_total : p.n_main) : 0u;
+        const uint32_t slot = meta_slot(meta), level = meta_level(meta), key = meta_key(meta);
+        const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
+        SlotProg p{};
+        if (active) p = progs[slot];
+        const uint32_t j0 = probed ? p.n_probe : 0u;
+        const uint32_t j1 = active ? ((probed || key >= g.nslots) ? p.n_main : p.n_total) : 0u;
         bool depth_err = active && level + p.max_dlevel > kMaxLevels;
         bool hit = false;
         uint32_t T = 0;
-        const uint32_t maxops = uniform(wave_max(nops));
-        for (uint32_t j = 0; j < maxops; j++) {
+        RowCache rc;
+        const uint32_t maxops = uniform(wave_max(j1 > j0 ? j1 - j0 : 0u));
+        for (uint32_t jj = 0; jj < maxops; jj++) {
+            const uint32_t j = j0 + jj;
             bool want = false;
             uint32_t tstart = 0, tcount = 0, tmeta = 0;
-            if (j < nops) {
-                const FwdOp op = g.ops[p.first + j];
+            if (j < j1) {
+                const FwdOp op = ops[p.first + j];
                 const uint32_t L = level + op.dlevel;
                 if (L <= kMaxLevels) {
                     if (op.flags & OP_REFLEX) {
@@ -211,21 +325,23 @@ __global__ __launch_bounds__(kBlock) void k_expand(DevGraph g, DevFrontier f, ui
                             want = true;
                             tstart = id;
                             tcount = 1u | kSelfBit;
-                            tmeta = op.key | ((L + 1) << 13) | (key << 19);
+                            tmeta = make_meta(op.key, L + 1, key);
                         }
                     } else if (id < op.nrows) {
-                        const uint32_t *o = g.off + op.off_base + (size_t)id * op.K + op.k;
-                        const uint32_t s0 = o[0], s1 = o[1];
-                        if (s1 > s0) {
-                            if ((op.flags & OP_PROBE) && key == op.key && row_contains(g.edges, s0, s1, sid)) hit = true;
+                        const uint2 md = row_meta(g, op, id, rc);
+                        if (md.y > md.x) {
+                            if (key == op.key) {
+                                if (op.flags & OP_PROBE_HASH) hit |= bucket_row_contains(buckets, md.x, md.y, sid);
+                                else if (op.flags & OP_PROBE) hit |= row_contains(g.edges, md.x, md.y, sid);
+                            }
                             if (op.flags & OP_ENUM) {
                                 if (L + 1 > kMaxLevels) depth_err = true;
-                                else if (s1 - s0 > kMaxRow) *f.overflow = 2u;
-                                else {
+                                else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
+                                else if (!hit) {
                                     want = true;
-                                    tstart = s0;
-                                    tcount = s1 - s0;
-                                    tmeta = (op.flags & OP_PROBE ? op.key : op.key) | ((L + 1) << 13) | (key << 19);
+                                    tstart = md.x;
+                                    tcount = md.y - md.x;
+                                    tmeta = make_meta(op.key, L + 1, key);
                                 }
                             }
                         }
@@ -244,16 +360,19 @@ __global__ __launch_bounds__(kBlock) void k_expand(DevGraph g, DevFrontier f, ui
                 }
                 T += (uint32_t)__popcll(b);
                 if (T > kTaskCap - 64) {
-                    flush_tasks(t, T, wo, lane, g.edges, out, out_counts, out_nchunks, f.max_chunks, f.overflow);
+                    flush_tasks<true>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err);
                     T = 0;
                 }
             }
         }
         if (hit) has[req] = 1;
         else if (depth_err) err[req] = ITEM_ERR_DEPTH;
-        if (T) flush_tasks(t, T, wo, lane, g.edges, out, out_counts, out_nchunks, f.max_chunks, f.overflow);
+        if (T) flush_tasks<true>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err);
     }
-    if (wo.cur != kNoChunk && lane == 0) out_counts[wo.cur] = wo.fill;
+    if (lane == 0) {
+        if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
+        if (wo.produced) f.any[iter] = 1u;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__restrict__ has, const uint8_t *__restrict__ err, uint8_t *perm_out,
@@ -269,27 +388,31 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
 // ----------------------------------------------------------- reverse expand
 // entry: x = object id, y = lookup request, z = meta (slot | dist << 13), w unused.
 // dist == 0 marks a seed entry: slot field holds the SUBJECT KEY and the program is rseeds[key].
-__global__ __launch_bounds__(kBlock) void k_rev_expand(DevReverse r, DevFrontier f, uint32_t iter, uint32_t nslots) {
+__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(DevReverse r, DevFrontier f, uint32_t iter) {
     __shared__ TaskLds lds[kWavesPerBlock];
     const uint32_t lane = lane_id();
     const uint32_t wib = threadIdx.x >> 6;
     TaskLds &t = lds[wib];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = gridDim.x * kWavesPerBlock;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
     const uint32_t pin = (iter + 1) & 1u, pout = iter & 1u;
     const uint4 *__restrict__ in = f.buf[pin];
     const uint32_t *__restrict__ in_counts = f.counts[pin];
     uint4 *__restrict__ out = f.buf[pout];
     uint32_t *out_counts = f.counts[pout];
     uint32_t *out_nchunks = f.nchunks + iter;
-    if (*f.overflow) return;
-    uint32_t C = min(f.nchunks[iter - 1], f.max_chunks);
-    WaveOut wo;
+    const bool live = !*f.overflow && f.any[iter - 1];
+    const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
+    const DevGraph nog{};
+    WaveOut wo{wave, 0u, 0u};
     for (uint32_t x = wave; x < C * kSegsPerChunk; x += nwaves) {
-        const uint32_t c = x / kSegsPerChunk, s = x % kSegsPerChunk;
+        // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
+        // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
+        // (each segment layer is rotated so that one wave does not keep landing on the same chunk)
+        const uint32_t s = x / C, c = (x % C + s * 509u) % C;
         const uint32_t cnt = in_counts[c];
         if (s * 64 >= cnt) continue;
         const bool valid = s * 64 + lane < cnt;
-        uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z;
         bool active = valid && meta != kDeadMeta;
         const uint32_t slot = meta & 0x1FFFu, dist = (meta >> 13) & 63u;
@@ -343,32 +466,46 @@ __global__ __launch_bounds__(kBlock) void k_rev_expand(DevReverse r, DevFrontier
                 }
                 T += (uint32_t)__popcll(b);
                 if (T > kTaskCap - 64) {
-                    flush_tasks(t, T, wo, lane, r.redges, out, out_counts, out_nchunks, f.max_chunks, f.overflow);
+                    flush_tasks<false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr);
                     T = 0;
                 }
             }
         }
-        if (T) flush_tasks(t, T, wo, lane, r.redges, out, out_counts, out_nchunks, f.max_chunks, f.overflow);
+        if (T) flush_tasks<false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr);
     }
-    if (wo.cur != kNoChunk && lane == 0) out_counts[wo.cur] = wo.fill;
-    (void)nslots;
+    if (lane == 0) {
+        if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;
+        if (wo.produced) f.any[iter] = 1u;
+    }
 }
 
 }  // namespace
 
-void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint32_t, uint8_t *has, uint8_t *err) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_seed, dim3((n + 255) / 256), dim3(256), 0, s, g, f, items, n, has, err);
+int expand_grid_blocks(int device) {
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int per_cu = 8;  // 256-thread blocks, <= 64 VGPRs, ~20 KiB LDS
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true>, kBlock, 0) == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
+    return cus * per_cu;
 }
-void launch_expand(hipStream_t s, int grid_blocks, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err) {
-    hipLaunchKernelGGL(k_expand, dim3(grid_blocks), dim3(kBlock), 0, s, g, f, iter, has, err);
+
+void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err) {
+    const uint32_t threads = n > f.nwaves ? n : f.nwaves;
+    hipLaunchKernelGGL(k_seed, dim3((threads + 255) / 256), dim3(256), 0, s, g, f, items, n, has, err);
+}
+void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err) {
+    const dim3 grid(f.nwaves / kWavesPerBlock);
+    if (g.nslots + g.nops <= kProgLdsEntries) hipLaunchKernelGGL(k_expand<true>, grid, dim3(kBlock), 0, s, g, f, iter, has, err);
+    else hipLaunchKernelGGL(k_expand<false>, grid, dim3(kBlock), 0, s, g, f, iter, has, err);
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
 }
-void launch_rev_expand(hipStream_t s, int grid_blocks, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t nslots) {
-    hipLaunchKernelGGL(k_rev_expand, dim3(grid_blocks), dim3(kBlock), 0, s, r, f, iter, nslots);
+void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter) {
+    hipLaunchKernelGGL(k_rev_expand, dim3(f.nwaves / kWavesPerBlock), dim3(kBlock), 0, s, r, f, iter);
 }
 
 }  // namespace acl

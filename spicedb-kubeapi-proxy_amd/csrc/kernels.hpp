@@ -12,21 +12,24 @@ namespace acl {
 constexpr uint32_t kChunk = 1024;         // entries per frontier chunk (16 KiB)
 constexpr uint32_t kSegsPerChunk = kChunk / 64;
 constexpr uint32_t kMaxLevels = 50;       // dispatch max depth, reference pkg/spicedb/spicedb.go:34
-constexpr uint32_t kLevelSlots = 64;      // per-iteration chunk counters
+constexpr uint32_t kLevelSlots = 64;      // per-iteration counters
+constexpr uint32_t kStatusWords = 2 * kLevelSlots + 1;  // nchunks[64] | any[64] | overflow
 constexpr uint32_t kDeadMeta = 0xFFFFFFFFu;
+constexpr int kWavesPerBlock = 4;
+constexpr uint32_t kProgLdsEntries = 256;  // ops + progs (32 B each) cached in LDS when they fit
 
 // per-item status byte written by the kernels
 enum : uint8_t { ITEM_ERR_NONE = 0, ITEM_ERR_DEPTH = 1, ITEM_ERR_INVALID = 2 };
 
 // frontier entry: one pending sub-check (req, state) -- 16 B, one dwordx4 per lane
 //   x = object id, y = request index, z = meta, w = subject id of the request
-//   meta = slot[0:13) | level[13:19) | subject key[19:32)
+//   meta = slot[0:13) | level[13:19) | probed[19] | subject key[20:32)
 struct DevGraph {
-    const uint32_t *off, *edges;
+    const uint32_t *meta, *edges, *buckets;  // plan.hpp: row descriptors (uint2), sorted rows, hashed 4-slot buckets (uint4)
     const FwdOp *ops;
     const SlotProg *progs;
     const uint32_t *type_slot_base, *type_nmembers;
-    uint32_t nslots, ntypes;
+    uint32_t nslots, ntypes, nops;
 };
 struct DevReverse {
     const uint32_t *roff, *redges;
@@ -37,17 +40,23 @@ struct DevReverse {
     uint32_t *visited;              // [nreq][visited_words]
     uint32_t visited_words;
 };
+// Chunk ids: [0, nwaves) are the waves' static first chunks (no allocation), ids >= nwaves come from the
+// level's dynamic counter nchunks[iter].  counts[] holds every readable chunk's fill.
 struct DevFrontier {
     uint4 *buf[2];
     uint32_t *counts[2];   // per-chunk fill
-    uint32_t *nchunks;     // [kLevelSlots] chunks produced by iteration i (0 = seed)
+    uint32_t *nchunks;     // [kLevelSlots] dynamic chunks produced by iteration i (0 = seed)
+    uint32_t *any;         // [kLevelSlots] iteration i produced at least one entry
     uint32_t *overflow;    // set when a frontier buffer ran out of chunks
     uint32_t max_chunks;
+    uint32_t nwaves;       // waves of every expand launch == number of static chunks
 };
 
-void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint32_t req_base, uint8_t *has, uint8_t *err);
-void launch_expand(hipStream_t s, int grid_blocks, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err);
+void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err);
+void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err);
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
-void launch_rev_expand(hipStream_t s, int grid_blocks, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t nslots);
+void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter);
+// blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
+int expand_grid_blocks(int device);
 
 }  // namespace acl

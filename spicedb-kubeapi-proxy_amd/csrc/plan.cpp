@@ -12,23 +12,28 @@ constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
 struct RelLayout {
     bool any = false;
-    uint32_t off_base = 0, nrows = 0, K = 0;
-    std::vector<uint8_t> class_live;  // class has >= 1 live relationship
+    uint32_t meta_base = 0, nrows = 0, K = 0;  // meta_base in uint2 units
+    std::vector<uint8_t> class_live;    // class has >= 1 live relationship
+    std::vector<uint8_t> class_hashed;  // class is stored as hashed buckets (never enumerated)
 };
+
+inline uint32_t hash_bucket(uint32_t sid, uint32_t nb) { return (uint32_t)(((uint64_t)(sid * 0x9E3779B1u) * nb) >> 32); }
+inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }
 
 struct Flattener {
     const Schema &sc;
     const std::vector<RelLayout> &lay;  // [slot]
-    std::vector<FwdOp> main, reflex;
+    std::vector<FwdOp> probes, makers, reflex;
     std::vector<int> stack;
     uint32_t max_d = 0;
 
+    size_t nops() const { return probes.size() + makers.size() + reflex.size(); }
     void push_same(int target, uint32_t d) {
         FwdOp op{};
         op.flags = OP_PUSH_SAME;
         op.dlevel = d;
         op.key = (uint32_t)target;
-        main.push_back(op);
+        makers.push_back(op);
     }
     void row_op(uint32_t flags, int rel_slot, int k, uint32_t d, uint32_t key) {
         const RelLayout &l = lay[rel_slot];
@@ -36,12 +41,12 @@ struct Flattener {
         FwdOp op{};
         op.flags = flags;
         op.dlevel = d;
-        op.off_base = l.off_base;
+        op.meta_base = l.meta_base;
         op.nrows = l.nrows;
         op.K = l.K;
         op.k = (uint32_t)k;
         op.key = key;
-        main.push_back(op);
+        ((flags & (OP_ENUM | OP_PUSH_SAME)) ? makers : probes).push_back(op);
     }
     // state (type, member) entered at depth offset d
     void state(int type, int member, uint32_t d) {
@@ -55,10 +60,13 @@ struct Flattener {
             reflex.push_back(op);
         }
         if (!m.is_permission) {
+            const RelLayout &l = lay[m.slot];
             for (size_t k = 0; k < m.classes.size(); k++) {
                 const SubjectClass &c = m.classes[k];
-                if (c.srel == kNoRelation) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
-                else row_op(OP_PROBE | OP_ENUM, m.slot, (int)k, d, (uint32_t)sc.slot(c.stype, c.srel));
+                if (c.srel == kNoRelation)
+                    row_op(l.any && l.class_hashed[k] ? OP_PROBE_HASH : OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
+                else
+                    row_op(OP_PROBE | OP_ENUM, m.slot, (int)k, d, (uint32_t)sc.slot(c.stype, c.srel));
             }
             return;
         }
@@ -77,7 +85,7 @@ struct Flattener {
                 int tm = def.find(n.a);
                 int tslot = sc.slot(type, tm);
                 bool recursive = std::find(stack.begin(), stack.end(), tslot) != stack.end();
-                if (recursive || d + 1 > kMaxDepth || main.size() + reflex.size() >= kMaxOpsPerSlot) push_same(tslot, d);
+                if (recursive || d + 1 > kMaxDepth || nops() >= kMaxOpsPerSlot) push_same(tslot, d);
                 else state(type, tm, d + 1);
                 break;
             }
@@ -116,9 +124,18 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         s.type_nmembers.push_back((uint32_t)sc.defs[t].members.size());
         s.type_nobjects.push_back(store.objects((int)t).count());
     }
+    // relations that some arrow walks as a tupleset must stay enumerable (SORTED)
+    std::vector<uint8_t> is_tupleset(sc.nslots, 0);
+    for (const Definition &d : sc.defs)
+        for (const Member &m : d.members) {
+            if (!m.is_permission) continue;
+            std::vector<const Node *> arrows;
+            collect(m.expr, Node::kArrow, &arrows);
+            for (const Node *a : arrows) is_tupleset[d.members[d.find(a->a)].slot] = 1;
+        }
     std::vector<RelLayout> lay(sc.nslots);
     auto &tables = store.tables();
-    std::vector<uint32_t> cursor;
+    std::vector<uint32_t> row;  // scratch: live subjects of one (object, class) sub-row
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
         const Member &mem = sc.defs[t].members[m];
@@ -127,9 +144,11 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         l.K = (uint32_t)mem.classes.size();
         l.nrows = store.objects(t).count();
         l.class_live.assign(l.K, 0);
+        l.class_hashed.assign(l.K, 0);
         size_t total = 0;
         for (uint32_t k = 0; k < l.K; k++) {
             const ClassTable &ct = tables[slot][k];
+            l.class_hashed[k] = mem.classes[k].srel == kNoRelation && !is_tupleset[slot];
             if (ct.expiry.empty()) {
                 if (!ct.keys.empty()) l.class_live[k] = 1;
                 total += ct.keys.size();
@@ -140,47 +159,67 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         }
         if (!total) continue;
         l.any = true;
-        l.off_base = (uint32_t)s.off.size();
+        if (s.meta.size() % 4) s.meta.resize(s.meta.size() + 2, 0);  // 16-byte alignment: K == 2 rows load as one dwordx4
+        l.meta_base = (uint32_t)(s.meta.size() / 2);
         const size_t nrow = (size_t)l.nrows * l.K;
-        s.off.resize(s.off.size() + nrow + 1, 0);
-        uint32_t *off = s.off.data() + l.off_base;
+        s.meta.resize(s.meta.size() + 2 * nrow, 0);
+        uint32_t *meta = s.meta.data() + 2 * (size_t)l.meta_base;
         for (uint32_t k = 0; k < l.K; k++) {
             const ClassTable &ct = tables[slot][k];
             const bool filt = !ct.expiry.empty();
-            for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) off[(size_t)(key >> 32) * l.K + k]++;
-        }
-        uint32_t run = (uint32_t)s.edges.size();
-        for (size_t i = 0; i < nrow; i++) {
-            uint32_t c = off[i];
-            off[i] = run;
-            run += c;
-        }
-        off[nrow] = run;
-        s.edges.resize(run);
-        cursor.assign(off, off + nrow);
-        for (uint32_t k = 0; k < l.K; k++) {
-            const ClassTable &ct = tables[slot][k];
-            const bool filt = !ct.expiry.empty();
-            for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) s.edges[cursor[(size_t)(key >> 32) * l.K + k]++] = (uint32_t)key;
+            size_t i = 0;
+            const size_t nk = ct.keys.size();
+            while (i < nk) {  // one resource at a time (keys ascend by resource, then subject)
+                const uint32_t res = (uint32_t)(ct.keys[i] >> 32);
+                row.clear();
+                for (; i < nk && (uint32_t)(ct.keys[i] >> 32) == res; i++)
+                    if (!filt || store.live(ct, ct.keys[i], now)) row.push_back((uint32_t)ct.keys[i]);
+                if (row.empty()) continue;
+                uint32_t *md = meta + 2 * ((size_t)res * l.K + k);
+                if (l.class_hashed[k]) {
+                    const uint32_t nb = buckets_for((uint32_t)row.size());
+                    const uint32_t b0 = (uint32_t)(s.buckets.size() / 4);
+                    s.buckets.resize(s.buckets.size() + 4 * (size_t)nb, 0xFFFFFFFFu);
+                    uint32_t *bk = s.buckets.data() + 4 * (size_t)b0;
+                    for (uint32_t sid : row) {
+                        uint32_t b = hash_bucket(sid, nb);
+                        for (;;) {
+                            uint32_t *q = bk + 4 * (size_t)b;
+                            int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
+                            if (f >= 0) { q[f] = sid; break; }
+                            b = b + 1 == nb ? 0 : b + 1;
+                        }
+                    }
+                    md[0] = b0;
+                    md[1] = b0 + nb;
+                } else {
+                    md[0] = (uint32_t)s.edges.size();
+                    s.edges.insert(s.edges.end(), row.begin(), row.end());
+                    md[1] = (uint32_t)s.edges.size();
+                }
+            }
         }
     }
-    s.nedges = s.edges.size();
-    if (s.off.empty()) s.off.push_back(0);
+    s.nedges = 0;
+    for (const auto &slot : tables)
+        for (const auto &ct : slot) s.nedges += ct.keys.size();
+    if (s.meta.empty()) s.meta.assign(4, 0);
     if (s.edges.empty()) s.edges.push_back(0);
+    if (s.buckets.empty()) s.buckets.assign(4, 0xFFFFFFFFu);
     // programs
     s.progs.resize(sc.nslots);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
-        Flattener f{sc, lay, {}, {}, {}, 0};
+        Flattener f{sc, lay, {}, {}, {}, {}, 0};
         f.state(t, m, 0);
-        SlotProg p;
+        SlotProg p{};
         p.first = (uint32_t)s.ops.size();
-        p.n_main = (uint32_t)f.main.size();
-        p.n_total = (uint32_t)(f.main.size() + f.reflex.size());
+        p.n_probe = (uint32_t)f.probes.size();
+        p.n_main = (uint32_t)(f.probes.size() + f.makers.size());
+        p.n_total = (uint32_t)f.nops();
         p.max_dlevel = f.max_d;
-        s.ops.insert(s.ops.end(), f.main.begin(), f.main.end());
+        s.ops.insert(s.ops.end(), f.probes.begin(), f.probes.end());
+        s.ops.insert(s.ops.end(), f.makers.begin(), f.makers.end());
         s.ops.insert(s.ops.end(), f.reflex.begin(), f.reflex.end());
         s.progs[slot] = p;
     }

@@ -18,23 +18,31 @@
 namespace acl {
 
 // ---- device-visible structs (plain, shared with kernels.hip) ----
-enum : uint32_t { OP_PROBE = 1u, OP_ENUM = 2u, OP_REFLEX = 4u, OP_PUSH_SAME = 8u };
+enum : uint32_t {
+    OP_PROBE = 1u,      // membership test of the request's subject in a SORTED sub-row (binary search)
+    OP_ENUM = 2u,       // every subject of a SORTED sub-row becomes a child state
+    OP_REFLEX = 4u,     // subject == this very object#relation
+    OP_PUSH_SAME = 8u,  // non-inlined computed userset: child state on the same object
+    OP_PROBE_HASH = 16u // membership test in a HASHED sub-row (4-slot buckets)
+};
 
 struct FwdOp {        // 32 B
     uint32_t flags;   // OP_* bits; PROBE|ENUM may be combined (userset class)
     uint32_t dlevel;  // dispatch-depth offset of the state this op belongs to (inlined computed usersets)
-    uint32_t off_base;  // index into `off` of this relation's row-offset array
+    uint32_t meta_base; // index (in uint2 units) into `meta` of this relation's row descriptors
     uint32_t nrows;     // objects covered (ids >= nrows have no relationships)
     uint32_t K;         // subject classes of the relation (row stride)
     uint32_t k;         // subject class of this op
-    uint32_t key;       // PROBE/REFLEX: subject key to match; ENUM/PUSH_SAME: target slot
+    uint32_t key;       // PROBE*/REFLEX: subject key to match; ENUM/PUSH_SAME: target slot
     uint32_t pad;
 };
-struct SlotProg {       // 16 B
+struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create children][REFLEX ops]
     uint32_t first;     // first op
-    uint32_t n_main;    // ops every request runs
+    uint32_t n_probe;   // leading ops that only probe (skipped for a state whose probes were done by its parent)
+    uint32_t n_main;    // n_probe + child-creating ops
     uint32_t n_total;   // n_main + REFLEX ops (only requests whose subject carries a relation)
     uint32_t max_dlevel;  // deepest inlined state
+    uint32_t pad[3];
 };
 struct RevOp {          // 16 B
     uint32_t flags;     // OP_ENUM (reverse row) or OP_PUSH_SAME
@@ -51,8 +59,9 @@ struct Snapshot {
     uint64_t revision = 0;     // store revision it was built from
     int64_t valid_lo = 0, valid_hi = 0;  // expiration window of `now`
     // forward
-    std::vector<uint32_t> off;    // row offsets (absolute indices into edges)
-    std::vector<uint32_t> edges;  // subject ids
+    std::vector<uint32_t> meta;     // uint2 {start, end} per (object, class): SORTED -> edge indices, HASHED -> bucket indices
+    std::vector<uint32_t> edges;    // SORTED sub-rows: subject ids ascending
+    std::vector<uint32_t> buckets;  // HASHED sub-rows: uint4 buckets, empty slot = 0xFFFFFFFF
     std::vector<FwdOp> ops;
     std::vector<SlotProg> progs;  // [nslots]
     // per type: first slot + member count (request validation on device)

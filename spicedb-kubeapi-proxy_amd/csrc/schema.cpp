@@ -233,7 +233,7 @@ bool parse_schema(const std::string &text, Schema *out, std::string *err) {
                 s.slot_owner.emplace_back((int)t, (int)m);
             }
         }
-        if (s.nslots + s.defs.size() >= 8191) throw std::runtime_error("schema: too many relations/permissions (limit 8190 incl. types)");
+        if (s.nslots + s.defs.size() >= 4095) throw std::runtime_error("schema: too many relations/permissions (limit 4094 incl. types)");
         // resolve subject classes
         for (size_t t = 0; t < s.defs.size(); t++)
             for (size_t m = 0; m < s.defs[t].members.size(); m++) {
