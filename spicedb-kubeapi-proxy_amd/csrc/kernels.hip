@@ -36,7 +36,9 @@ constexpr int kBlock = kWavesPerBlock * 64;
 #define ACL_MIN_WAVES_PER_SIMD 8  // 8 blocks of 4 waves per CU: the kernels are latency bound, residency is what hides it
 #endif
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
-constexpr uint32_t kSelfBit = 0x80000000u;
+constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
+constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
+constexpr uint32_t kCountMask = 0x3FFFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
@@ -110,30 +112,41 @@ __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t
     return base;
 }
 
+// sorted sub-row (ids ascending; bit 31 of an edge is the leaf flag, not part of the id)
 __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges, uint32_t lo, uint32_t hi, uint32_t key) {
     uint32_t end = hi;
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        if (edges[mid] < key) lo = mid + 1;
+        if ((edges[mid] & kIdMask) < key) lo = mid + 1;
         else hi = mid;
     }
-    return lo < end && edges[lo] == key;
+    return lo < end && (edges[lo] & kIdMask) == key;
 }
 
-// hashed sub-row: nb = b1 - b0 buckets of 4 ids; same placement rule as plan.cpp (hash_bucket + linear probing)
-__device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t sid) {
+// hashed row: nb = b1 - b0 buckets of 4 ids; same placement rule as plan.cpp (hash_bucket + linear probing)
+__device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
     const uint32_t nb = b1 - b0;
-    uint32_t b = (uint32_t)(((uint64_t)(sid * 0x9E3779B1u) * nb) >> 32);
+    uint32_t b = (uint32_t)(((uint64_t)(want * 0x9E3779B1u) * nb) >> 32);
     for (uint32_t i = 0; i < nb; i++) {
         const uint4 q = buckets[b0 + b];
-        if (q.x == sid || q.y == sid || q.z == sid || q.w == sid) return true;
+        if (q.x == want || q.y == want || q.z == want || q.w == want) return true;
         if (q.x == kEmptySlot || q.y == kEmptySlot || q.z == kEmptySlot || q.w == kEmptySlot) return false;
         b = b + 1 == nb ? 0 : b + 1;
     }
     return false;
 }
 
-// Row descriptor {start, end} of (object id, class op.k).  Relations with two subject classes keep both
+// Membership of (resource id, subject sid) in a membership-only class.  The class is stored SUBJECT-indexed:
+// one hashed row of resource ids per subject.  All pending sub-checks of one request share the subject, so the
+// lanes of a wave (which hold a few requests' worth of neighbouring entries) keep hitting the same descriptor
+// and the same few bucket lines instead of 64 different resource rows.
+__device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const FwdOp &op, uint32_t id, uint32_t sid) {
+    if (sid >= op.nrows) return false;
+    const uint2 md = reinterpret_cast<const uint2 *>(g.meta)[op.base + sid];
+    return md.y > md.x && bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, id);
+}
+
+// Row descriptor {start, end} of (object id, sorted class op.k).  Relations with two sorted classes keep both
 // descriptors in one aligned 16 B record, fetched once per state and reused by the state's next op.
 struct RowCache {
     uint32_t base = 0xFFFFFFFFu;
@@ -141,23 +154,27 @@ struct RowCache {
 };
 __device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, uint32_t id, RowCache &rc) {
     if (op.K == 2) {
-        if (rc.base != op.meta_base) {
-            rc.v = reinterpret_cast<const uint4 *>(g.meta)[(op.meta_base >> 1) + id];
-            rc.base = op.meta_base;
+        if (rc.base != op.base) {
+            rc.v = reinterpret_cast<const uint4 *>(g.meta)[(op.base >> 1) + id];
+            rc.base = op.base;
         }
         return op.k ? make_uint2(rc.v.z, rc.v.w) : make_uint2(rc.v.x, rc.v.y);
     }
-    return reinterpret_cast<const uint2 *>(g.meta)[op.meta_base + (size_t)id * op.K + op.k];
+    return reinterpret_cast<const uint2 *>(g.meta)[op.base + (size_t)id * op.K + op.k];
 }
 
 // Child mode: evaluate every probe of state (slot, id) at `level` for subject (key, sid) without creating tasks.
 // Returns true when the state still has something to enumerate (=> it must be written to the frontier).
+// `leaf_known`: the edge that produced this child carried an authoritative leaf flag (`leaf`), so the child's
+// own rows need not be looked at -- a plain-subject child then touches only the request subject's rows.
 __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *progs, const FwdOp *ops, uint32_t slot, uint32_t level, uint32_t key,
-                                           uint32_t id, uint32_t sid, bool &hit, bool &depth_err) {
+                                           uint32_t id, uint32_t sid, bool leaf_known, bool leaf, bool &hit, bool &depth_err) {
     const SlotProg p = progs[slot];
     if (level + p.max_dlevel > kMaxLevels) depth_err = true;
-    const uint32_t nops = key < g.nslots ? p.n_total : p.n_main;
-    bool push = false;
+    const bool userset_subject = key < g.nslots;
+    // plain subjects with a known leaf flag only need the probe-only ops
+    const uint32_t nops = userset_subject ? p.n_total : (leaf_known ? p.n_probe : p.n_main);
+    bool push = leaf_known && !leaf;
     RowCache rc;
     for (uint32_t j = 0; j < nops; j++) {
         const FwdOp op = ops[p.first + j];
@@ -167,14 +184,17 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
             if (key == op.key && id == sid) hit = true;
         } else if (op.flags & OP_PUSH_SAME) {
             push = true;
+        } else if (op.flags & OP_PROBE_HASH) {
+            if (key == op.key) hit |= subject_row_contains(g, op, id, sid);
         } else if (id < op.nrows) {
-            const uint2 md = row_meta(g, op, id, rc);
-            if (md.y > md.x) {
-                if (key == op.key) {
-                    if (op.flags & OP_PROBE_HASH) hit |= bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, sid);
-                    else if (op.flags & OP_PROBE) hit |= row_contains(g.edges, md.x, md.y, sid);
+            const bool probe = (op.flags & OP_PROBE) && key == op.key;
+            const bool look = (op.flags & OP_ENUM) && !leaf_known;
+            if (probe || look) {
+                const uint2 md = row_meta(g, op, id, rc);
+                if (md.y > md.x) {
+                    if (probe) hit |= row_contains(g.edges, md.x, md.y, sid);
+                    if (look) push = true;
                 }
-                if (op.flags & OP_ENUM) push = true;
             }
         }
     }
@@ -189,7 +209,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                                             uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err) {
     wave_lds_fence();
     for (uint32_t gq = 0; gq < T; gq += 64) {
-        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & ~kSelfBit) : 0u;
+        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
         const uint32_t incl = wave_incl_scan(cnt, lane);
         const uint32_t total = uniform(__shfl(incl, 63, 64));
         t.scan[lane] = incl - cnt;
@@ -205,12 +225,14 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     if (t.scan[j + step] <= w) j += step;
                 const uint32_t tj = gq + j;
                 const uint32_t c = t.count[tj], s = t.start[tj];
-                const uint32_t child = (c & kSelfBit) ? s : edges[s + (w - t.scan[j])];
+                const uint32_t edge = (c & kSelfBit) ? s : edges[s + (w - t.scan[j])];
+                const uint32_t child = INLINE ? (edge & kIdMask) : edge;
                 e = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
                 push = true;
                 if (INLINE) {
                     bool hit = false, derr = false;
-                    push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, hit, derr);
+                    push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, (c & kLeafAuthBit) != 0,
+                                      (edge & kLeafBit) != 0, hit, derr);
                     if (hit) {
                         has[e.y] = 1;
                         push = false;
@@ -284,7 +306,6 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     uint32_t *out_nchunks = f.nchunks + iter;
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
-    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     WaveOut wo{wave, 0u, 0u};
     for (uint32_t x = wave; x < C * kSegsPerChunk; x += nwaves) {
         // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
@@ -327,20 +348,19 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                             tcount = 1u | kSelfBit;
                             tmeta = make_meta(op.key, L + 1, key);
                         }
+                    } else if (op.flags & OP_PROBE_HASH) {
+                        if (key == op.key) hit |= subject_row_contains(g, op, id, sid);
                     } else if (id < op.nrows) {
                         const uint2 md = row_meta(g, op, id, rc);
                         if (md.y > md.x) {
-                            if (key == op.key) {
-                                if (op.flags & OP_PROBE_HASH) hit |= bucket_row_contains(buckets, md.x, md.y, sid);
-                                else if (op.flags & OP_PROBE) hit |= row_contains(g.edges, md.x, md.y, sid);
-                            }
+                            if ((op.flags & OP_PROBE) && key == op.key) hit |= row_contains(g.edges, md.x, md.y, sid);
                             if (op.flags & OP_ENUM) {
                                 if (L + 1 > kMaxLevels) depth_err = true;
                                 else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
                                 else if (!hit) {
                                     want = true;
                                     tstart = md.x;
-                                    tcount = md.y - md.x;
+                                    tcount = (md.y - md.x) | ((op.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
                                     tmeta = make_meta(op.key, L + 1, key);
                                 }
                             }

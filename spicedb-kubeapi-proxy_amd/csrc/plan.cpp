@@ -1,8 +1,8 @@
-// plan.cpp -- builds the HBM snapshot (CSR rows) and the frontier programs.  See plan.hpp.
+// plan.cpp -- builds the forward HBM snapshot (sorted rows, subject-indexed hashed rows) and the frontier
+// programs.  See plan.hpp.
 #include "plan.hpp"
 
 #include <algorithm>
-#include <functional>
 
 namespace acl {
 namespace {
@@ -10,15 +10,19 @@ namespace {
 constexpr uint32_t kMaxOpsPerSlot = 256;
 constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
+struct ClassLayout {
+    bool live = false;    // >= 1 live relationship in this snapshot
+    bool hashed = false;  // membership-only class: subject-indexed hashed rows
+    uint32_t ks = 0;      // sorted-class index inside the relation's row descriptors
+    uint32_t smeta_base = 0, nsubjects = 0;  // hashed: per-subject descriptors (uint2 units) and their count
+};
 struct RelLayout {
-    bool any = false;
-    uint32_t meta_base = 0, nrows = 0, K = 0;  // meta_base in uint2 units
-    std::vector<uint8_t> class_live;    // class has >= 1 live relationship
-    std::vector<uint8_t> class_hashed;  // class is stored as hashed buckets (never enumerated)
+    uint32_t meta_base = 0, nrows = 0, Ks = 0;  // meta_base in uint2 units
+    std::vector<ClassLayout> cls;
 };
 
-inline uint32_t hash_bucket(uint32_t sid, uint32_t nb) { return (uint32_t)(((uint64_t)(sid * 0x9E3779B1u) * nb) >> 32); }
-inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }
+inline uint32_t hash_bucket(uint32_t v, uint32_t nb) { return (uint32_t)(((uint64_t)(v * 0x9E3779B1u) * nb) >> 32); }
+inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }  // load <= 0.75 (<= 1.0 for a single bucket)
 
 struct Flattener {
     const Schema &sc;
@@ -37,16 +41,23 @@ struct Flattener {
     }
     void row_op(uint32_t flags, int rel_slot, int k, uint32_t d, uint32_t key) {
         const RelLayout &l = lay[rel_slot];
-        if (!l.any || !l.class_live[k]) return;  // empty class: nothing to probe or enumerate in this snapshot
+        const ClassLayout &c = l.cls[k];
+        if (!c.live) return;  // empty class: nothing to probe or enumerate in this snapshot
         FwdOp op{};
-        op.flags = flags;
         op.dlevel = d;
-        op.meta_base = l.meta_base;
-        op.nrows = l.nrows;
-        op.K = l.K;
-        op.k = (uint32_t)k;
         op.key = key;
-        ((flags & (OP_ENUM | OP_PUSH_SAME)) ? makers : probes).push_back(op);
+        if (c.hashed) {  // only ever asked for membership
+            op.flags = OP_PROBE_HASH;
+            op.base = c.smeta_base;
+            op.nrows = c.nsubjects;
+        } else {
+            op.flags = flags;
+            op.base = l.meta_base;
+            op.nrows = l.nrows;
+            op.K = l.Ks;
+            op.k = c.ks;
+        }
+        ((op.flags & (OP_ENUM | OP_PUSH_SAME)) ? makers : probes).push_back(op);
     }
     // state (type, member) entered at depth offset d
     void state(int type, int member, uint32_t d) {
@@ -60,13 +71,10 @@ struct Flattener {
             reflex.push_back(op);
         }
         if (!m.is_permission) {
-            const RelLayout &l = lay[m.slot];
             for (size_t k = 0; k < m.classes.size(); k++) {
                 const SubjectClass &c = m.classes[k];
-                if (c.srel == kNoRelation)
-                    row_op(l.any && l.class_hashed[k] ? OP_PROBE_HASH : OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
-                else
-                    row_op(OP_PROBE | OP_ENUM, m.slot, (int)k, d, (uint32_t)sc.slot(c.stype, c.srel));
+                if (c.srel == kNoRelation) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
+                else row_op(OP_PROBE | OP_ENUM | OP_LEAFBIT, m.slot, (int)k, d, (uint32_t)sc.slot(c.stype, c.srel));
             }
             return;
         }
@@ -135,68 +143,81 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         }
     std::vector<RelLayout> lay(sc.nslots);
     auto &tables = store.tables();
-    std::vector<uint32_t> row;  // scratch: live subjects of one (object, class) sub-row
+    std::vector<uint32_t> cnt, fill;
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
         const Member &mem = sc.defs[t].members[m];
         if (mem.is_permission) continue;
         RelLayout &l = lay[slot];
-        l.K = (uint32_t)mem.classes.size();
         l.nrows = store.objects(t).count();
-        l.class_live.assign(l.K, 0);
-        l.class_hashed.assign(l.K, 0);
-        size_t total = 0;
-        for (uint32_t k = 0; k < l.K; k++) {
+        l.cls.resize(mem.classes.size());
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            ClassLayout &c = l.cls[k];
             const ClassTable &ct = tables[slot][k];
-            l.class_hashed[k] = mem.classes[k].srel == kNoRelation && !is_tupleset[slot];
-            if (ct.expiry.empty()) {
-                if (!ct.keys.empty()) l.class_live[k] = 1;
-                total += ct.keys.size();
-            } else {
+            c.hashed = mem.classes[k].srel == kNoRelation && !is_tupleset[slot];
+            if (ct.expiry.empty()) c.live = !ct.keys.empty();
+            else
                 for (uint64_t key : ct.keys)
-                    if (store.live(ct, key, now)) { l.class_live[k] = 1; total++; }
-            }
+                    if (store.live(ct, key, now)) { c.live = true; break; }
+            if (c.live && !c.hashed) c.ks = l.Ks++;
         }
-        if (!total) continue;
-        l.any = true;
-        if (s.meta.size() % 4) s.meta.resize(s.meta.size() + 2, 0);  // 16-byte alignment: K == 2 rows load as one dwordx4
-        l.meta_base = (uint32_t)(s.meta.size() / 2);
-        const size_t nrow = (size_t)l.nrows * l.K;
-        s.meta.resize(s.meta.size() + 2 * nrow, 0);
-        uint32_t *meta = s.meta.data() + 2 * (size_t)l.meta_base;
-        for (uint32_t k = 0; k < l.K; k++) {
+        // ---- membership-only classes: one hashed row of RESOURCE ids per SUBJECT
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            ClassLayout &c = l.cls[k];
+            if (!c.live || !c.hashed) continue;
             const ClassTable &ct = tables[slot][k];
             const bool filt = !ct.expiry.empty();
+            const uint32_t ns = store.objects(mem.classes[k].stype).count();
+            c.nsubjects = ns;
+            c.smeta_base = (uint32_t)(s.meta.size() / 2);
+            s.meta.resize(s.meta.size() + 2 * (size_t)ns, 0);
+            cnt.assign(ns, 0);
+            for (uint64_t key : ct.keys)
+                if (!filt || store.live(ct, key, now)) cnt[(uint32_t)key]++;
+            uint32_t b = (uint32_t)(s.buckets.size() / 4);
+            for (uint32_t sid = 0; sid < ns; sid++) {
+                uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
+                md[0] = b;
+                if (cnt[sid]) b += buckets_for(cnt[sid]);
+                md[1] = b;
+            }
+            s.buckets.resize(4 * (size_t)b, 0xFFFFFFFFu);
+            for (uint64_t key : ct.keys) {
+                if (filt && !store.live(ct, key, now)) continue;
+                const uint32_t res = (uint32_t)(key >> 32), sid = (uint32_t)key;
+                const uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
+                const uint32_t nb = md[1] - md[0];
+                uint32_t *row = s.buckets.data() + 4 * (size_t)md[0];
+                uint32_t bi = hash_bucket(res, nb);
+                for (;;) {
+                    uint32_t *q = row + 4 * (size_t)bi;
+                    int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
+                    if (f >= 0) { q[f] = res; break; }
+                    bi = bi + 1 == nb ? 0 : bi + 1;
+                }
+            }
+        }
+        // ---- enumerable classes: sorted sub-rows per (object, class)
+        if (!l.Ks) continue;
+        if (s.meta.size() % 4) s.meta.resize(s.meta.size() + 2, 0);  // 16-byte alignment: Ks == 2 rows load as one dwordx4
+        l.meta_base = (uint32_t)(s.meta.size() / 2);
+        s.meta.resize(s.meta.size() + 2 * (size_t)l.nrows * l.Ks, 0);
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            const ClassLayout &c = l.cls[k];
+            if (!c.live || c.hashed) continue;
+            const ClassTable &ct = tables[slot][k];
+            const bool filt = !ct.expiry.empty();
+            uint32_t *meta = s.meta.data() + 2 * (size_t)l.meta_base;
             size_t i = 0;
             const size_t nk = ct.keys.size();
             while (i < nk) {  // one resource at a time (keys ascend by resource, then subject)
                 const uint32_t res = (uint32_t)(ct.keys[i] >> 32);
-                row.clear();
+                const uint32_t start = (uint32_t)s.edges.size();
                 for (; i < nk && (uint32_t)(ct.keys[i] >> 32) == res; i++)
-                    if (!filt || store.live(ct, ct.keys[i], now)) row.push_back((uint32_t)ct.keys[i]);
-                if (row.empty()) continue;
-                uint32_t *md = meta + 2 * ((size_t)res * l.K + k);
-                if (l.class_hashed[k]) {
-                    const uint32_t nb = buckets_for((uint32_t)row.size());
-                    const uint32_t b0 = (uint32_t)(s.buckets.size() / 4);
-                    s.buckets.resize(s.buckets.size() + 4 * (size_t)nb, 0xFFFFFFFFu);
-                    uint32_t *bk = s.buckets.data() + 4 * (size_t)b0;
-                    for (uint32_t sid : row) {
-                        uint32_t b = hash_bucket(sid, nb);
-                        for (;;) {
-                            uint32_t *q = bk + 4 * (size_t)b;
-                            int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
-                            if (f >= 0) { q[f] = sid; break; }
-                            b = b + 1 == nb ? 0 : b + 1;
-                        }
-                    }
-                    md[0] = b0;
-                    md[1] = b0 + nb;
-                } else {
-                    md[0] = (uint32_t)s.edges.size();
-                    s.edges.insert(s.edges.end(), row.begin(), row.end());
-                    md[1] = (uint32_t)s.edges.size();
-                }
+                    if (!filt || store.live(ct, ct.keys[i], now)) s.edges.push_back((uint32_t)ct.keys[i]);
+                uint32_t *md = meta + 2 * ((size_t)res * l.Ks + c.ks);
+                md[0] = start;
+                md[1] = (uint32_t)s.edges.size();
             }
         }
     }
@@ -206,7 +227,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
     if (s.meta.empty()) s.meta.assign(4, 0);
     if (s.edges.empty()) s.edges.push_back(0);
     if (s.buckets.empty()) s.buckets.assign(4, 0xFFFFFFFFu);
-    // programs
+    // ---- programs
     s.progs.resize(sc.nslots);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
@@ -224,144 +245,44 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         s.progs[slot] = p;
     }
     if (s.ops.empty()) s.ops.push_back(FwdOp{});
-    *snap = std::move(s);
-}
-
-void build_reverse(Store &store, int64_t now, Snapshot *snap) {
-    const Schema &sc = store.schema();
-    Snapshot &s = *snap;
-    auto &tables = store.tables();
-    s.roff.clear();
-    s.redges.clear();
-    s.rops.clear();
-    // reverse rows per (relation slot, class): subject id -> sorted resource ids
-    struct RevLayout { bool any = false; uint32_t roff_base = 0, nrows = 0; };
-    std::vector<std::vector<RevLayout>> rl(sc.nslots);
-    std::vector<uint32_t> cursor;
+    // ---- leaf bits: a userset edge `... @ T:c#m` always expands into the state (slot(T, m), c); mark the edges whose
+    // child state has nothing left to enumerate, so the expansion can skip both the child's row descriptors and the
+    // frontier write (kernels.hip, eval_child)
+    auto row_nonempty = [&](const FwdOp &op, uint32_t id) {
+        if (id >= op.nrows) return false;
+        const uint32_t *md = s.meta.data() + 2 * ((size_t)op.base + (size_t)id * op.K + op.k);
+        return md[1] > md[0];
+    };
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
         const Member &mem = sc.defs[t].members[m];
-        rl[slot].resize(mem.classes.size());
+        if (mem.is_permission) continue;
+        const RelLayout &l = lay[slot];
         for (size_t k = 0; k < mem.classes.size(); k++) {
-            const ClassTable &ct = tables[slot][k];
-            const bool filt = !ct.expiry.empty();
-            const uint32_t ns = store.objects(mem.classes[k].stype).count();
-            size_t total = 0;
-            for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) total++;
-            if (!total) continue;
-            RevLayout &l = rl[slot][k];
-            l.any = true;
-            l.nrows = ns;
-            l.roff_base = (uint32_t)s.roff.size();
-            s.roff.resize(s.roff.size() + ns + 1, 0);
-            uint32_t *ro = s.roff.data() + l.roff_base;
-            for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) ro[(uint32_t)key]++;
-            uint32_t run = (uint32_t)s.redges.size();
-            for (uint32_t i = 0; i < ns; i++) {
-                uint32_t c = ro[i];
-                ro[i] = run;
-                run += c;
+            const ClassLayout &c = l.cls[k];
+            if (!c.live || c.hashed || mem.classes[k].srel == kNoRelation) continue;
+            const SlotProg &tp = s.progs[sc.slot(mem.classes[k].stype, mem.classes[k].srel)];
+            bool always = false;
+            std::vector<FwdOp> enums;
+            for (uint32_t j = tp.n_probe; j < tp.n_main; j++) {
+                const FwdOp &op = s.ops[tp.first + j];
+                if (op.flags & OP_PUSH_SAME) always = true;
+                else if (op.flags & OP_ENUM) enums.push_back(op);
             }
-            ro[ns] = run;
-            s.redges.resize(run);
-            cursor.assign(ro, ro + ns);
-            for (uint64_t key : ct.keys)  // keys ascend by resource => each reverse row ascends by resource
-                if (!filt || store.live(ct, key, now)) s.redges[cursor[(uint32_t)key]++] = (uint32_t)(key >> 32);
-        }
-    }
-    if (s.roff.empty()) s.roff.push_back(0);
-    if (s.redges.empty()) s.redges.push_back(0);
-    auto enum_op = [&](int rel_slot, size_t k, int target) {
-        const RevLayout &l = rl[rel_slot][k];
-        if (!l.any) return;
-        RevOp op{};
-        op.flags = OP_ENUM;
-        op.roff_base = l.roff_base;
-        op.nrows = l.nrows;
-        op.target = (uint32_t)target;
-        s.rops.push_back(op);
-    };
-    // parents of a true state X = (t, m)
-    s.rprogs.assign(sc.nslots, RevProg{0, 0});
-    for (int slot = 0; slot < sc.nslots; slot++) {
-        auto [t, m] = sc.slot_owner[slot];
-        const std::string &xname = sc.defs[t].members[m].name;
-        RevProg p;
-        p.first = (uint32_t)s.rops.size();
-        for (size_t t2 = 0; t2 < sc.defs.size(); t2++) {
-            const Definition &d2 = sc.defs[t2];
-            for (const Member &m2 : d2.members) {
-                if (!m2.is_permission) {
-                    // userset subjects `t:id#m` stored on relation m2
-                    for (size_t k = 0; k < m2.classes.size(); k++)
-                        if (m2.classes[k].stype == t && m2.classes[k].srel == m) enum_op(m2.slot, k, m2.slot);
-                    continue;
-                }
-                std::vector<const Node *> refs, arrows;
-                collect(m2.expr, Node::kRef, &refs);
-                collect(m2.expr, Node::kArrow, &arrows);
-                if ((int)t2 == t)
-                    for (const Node *r : refs)
-                        if (r->a == xname) {
-                            RevOp op{};
-                            op.flags = OP_PUSH_SAME;
-                            op.target = (uint32_t)m2.slot;
-                            s.rops.push_back(op);
-                            break;
-                        }
-                for (const Node *a : arrows) {
-                    if (a->b != xname) continue;
-                    const Member &ts = d2.members[d2.find(a->a)];
-                    for (size_t k = 0; k < ts.classes.size(); k++)
-                        if (ts.classes[k].stype == t) enum_op(ts.slot, k, m2.slot);
+            if (always) continue;
+            for (uint32_t id = 0; id < l.nrows; id++) {
+                const uint32_t *md = s.meta.data() + 2 * ((size_t)l.meta_base + (size_t)id * l.Ks + c.ks);
+                for (uint32_t e = md[0]; e < md[1]; e++) {
+                    const uint32_t child = s.edges[e];
+                    bool work = false;
+                    for (const FwdOp &op : enums)
+                        if (row_nonempty(op, child)) { work = true; break; }
+                    if (!work) s.edges[e] = child | kLeafBit;
                 }
             }
         }
-        p.n = (uint32_t)s.rops.size() - p.first;
-        s.rprogs[slot] = p;
     }
-    // seeds for a subject key
-    s.rseeds.assign(sc.nkeys(), RevProg{0, 0});
-    for (uint32_t key = 0; key < sc.nkeys(); key++) {
-        int st, sr;
-        if (key < (uint32_t)sc.nslots) {
-            st = sc.slot_owner[key].first;
-            sr = sc.slot_owner[key].second;
-        } else {
-            st = (int)key - sc.nslots;
-            sr = kNoRelation;
-        }
-        RevProg p;
-        p.first = (uint32_t)s.rops.size();
-        if (sr != kNoRelation) {  // reflexive: `t:id#m` is a member of t:id#m
-            RevOp op{};
-            op.flags = OP_PUSH_SAME;
-            op.target = key;
-            s.rops.push_back(op);
-        }
-        for (int slot = 0; slot < sc.nslots; slot++) {
-            auto [t2, m2] = sc.slot_owner[slot];
-            const Member &mem = sc.defs[t2].members[m2];
-            for (size_t k = 0; k < mem.classes.size(); k++)
-                if (mem.classes[k].stype == st && mem.classes[k].srel == sr) enum_op(slot, k, slot);
-        }
-        p.n = (uint32_t)s.rops.size() - p.first;
-        s.rseeds[key] = p;
-    }
-    if (s.rops.empty()) s.rops.push_back(RevOp{});
-    s.slot_bit_base.assign(sc.nslots + 1, 0);
-    s.slot_nobjects.assign(sc.nslots, 0);
-    uint64_t bits = 0;
-    for (int slot = 0; slot < sc.nslots; slot++) {
-        s.slot_bit_base[slot] = (uint32_t)bits;
-        s.slot_nobjects[slot] = store.objects(sc.slot_owner[slot].first).count();
-        bits += ((uint64_t)s.slot_nobjects[slot] + 31) / 32 * 32;
-    }
-    s.slot_bit_base[sc.nslots] = (uint32_t)bits;
-    s.visited_bits = bits;
-    s.has_reverse = true;
+    *snap = std::move(s);
 }
 
 }  // namespace acl

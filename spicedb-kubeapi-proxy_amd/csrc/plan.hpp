@@ -23,17 +23,21 @@ enum : uint32_t {
     OP_ENUM = 2u,       // every subject of a SORTED sub-row becomes a child state
     OP_REFLEX = 4u,     // subject == this very object#relation
     OP_PUSH_SAME = 8u,  // non-inlined computed userset: child state on the same object
-    OP_PROBE_HASH = 16u // membership test in a HASHED sub-row (4-slot buckets)
+    OP_PROBE_HASH = 16u, // membership test in a membership-only class: SUBJECT-indexed hashed rows (4-slot buckets)
+    OP_LEAFBIT = 32u     // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
 };
+constexpr uint32_t kLeafBit = 0x80000000u;  // object ids are < 2^31
+constexpr uint32_t kIdMask = 0x7FFFFFFFu;
 
 struct FwdOp {        // 32 B
     uint32_t flags;   // OP_* bits; PROBE|ENUM may be combined (userset class)
     uint32_t dlevel;  // dispatch-depth offset of the state this op belongs to (inlined computed usersets)
-    uint32_t meta_base; // index (in uint2 units) into `meta` of this relation's row descriptors
-    uint32_t nrows;     // objects covered (ids >= nrows have no relationships)
-    uint32_t K;         // subject classes of the relation (row stride)
-    uint32_t k;         // subject class of this op
-    uint32_t key;       // PROBE*/REFLEX: subject key to match; ENUM/PUSH_SAME: target slot
+    uint32_t base;    // index (uint2 units) into `meta`: sorted ops -> the relation's per-object row descriptors,
+                      // PROBE_HASH -> the class's per-SUBJECT row descriptors
+    uint32_t nrows;   // ids covered by those descriptors (ids >= nrows have no relationships)
+    uint32_t K;       // sorted subject classes of the relation (row stride); unused by PROBE_HASH
+    uint32_t k;       // sorted-class index of this op
+    uint32_t key;     // PROBE*/REFLEX: subject key to match; ENUM/PUSH_SAME: target slot
     uint32_t pad;
 };
 struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create children][REFLEX ops]
@@ -59,9 +63,9 @@ struct Snapshot {
     uint64_t revision = 0;     // store revision it was built from
     int64_t valid_lo = 0, valid_hi = 0;  // expiration window of `now`
     // forward
-    std::vector<uint32_t> meta;     // uint2 {start, end} per (object, class): SORTED -> edge indices, HASHED -> bucket indices
-    std::vector<uint32_t> edges;    // SORTED sub-rows: subject ids ascending
-    std::vector<uint32_t> buckets;  // HASHED sub-rows: uint4 buckets, empty slot = 0xFFFFFFFF
+    std::vector<uint32_t> meta;     // uint2 {start, end}: per (object, sorted class) into edges; per (hashed class, SUBJECT) into buckets
+    std::vector<uint32_t> edges;    // SORTED sub-rows: subject ids ascending (| kLeafBit, see OP_LEAFBIT)
+    std::vector<uint32_t> buckets;  // hashed rows: uint4 buckets of RESOURCE ids of one subject, empty slot = 0xFFFFFFFF
     std::vector<FwdOp> ops;
     std::vector<SlotProg> progs;  // [nslots]
     // per type: first slot + member count (request validation on device)

@@ -1,0 +1,159 @@
+// plan_reverse.cpp -- reverse rows + parent programs for LookupResources (reference pkg/authz/lookups.go:49-65).
+// A state X = (type, relation|permission, id) being TRUE for the subject makes its parents true:
+//   - permissions on the same object whose rewrite references X's member (computed userset),
+//   - permissions with an arrow `a->b` (b == X's member) on every resource whose tupleset `a` holds X's object,
+//   - relations that store `type:id#member` as a userset subject.
+// The walk starts from the relationships that name the subject directly (plus the subject itself when it
+// carries a relation).  See plan.hpp.
+#include <algorithm>
+
+#include "plan.hpp"
+
+namespace acl {
+namespace {
+
+void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
+    if (n.kind == kind) out->push_back(&n);
+    for (const Node &k : n.kids) collect(k, kind, out);
+}
+
+}  // namespace
+
+void build_reverse(Store &store, int64_t now, Snapshot *snap) {
+    const Schema &sc = store.schema();
+    Snapshot &s = *snap;
+    auto &tables = store.tables();
+    s.roff.clear();
+    s.redges.clear();
+    s.rops.clear();
+    // reverse rows per (relation slot, class): subject id -> sorted resource ids
+    struct RevLayout { bool any = false; uint32_t roff_base = 0, nrows = 0; };
+    std::vector<std::vector<RevLayout>> rl(sc.nslots);
+    std::vector<uint32_t> cursor;
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        auto [t, m] = sc.slot_owner[slot];
+        const Member &mem = sc.defs[t].members[m];
+        rl[slot].resize(mem.classes.size());
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            const ClassTable &ct = tables[slot][k];
+            const bool filt = !ct.expiry.empty();
+            const uint32_t ns = store.objects(mem.classes[k].stype).count();
+            size_t total = 0;
+            for (uint64_t key : ct.keys)
+                if (!filt || store.live(ct, key, now)) total++;
+            if (!total) continue;
+            RevLayout &l = rl[slot][k];
+            l.any = true;
+            l.nrows = ns;
+            l.roff_base = (uint32_t)s.roff.size();
+            s.roff.resize(s.roff.size() + ns + 1, 0);
+            uint32_t *ro = s.roff.data() + l.roff_base;
+            for (uint64_t key : ct.keys)
+                if (!filt || store.live(ct, key, now)) ro[(uint32_t)key]++;
+            uint32_t run = (uint32_t)s.redges.size();
+            for (uint32_t i = 0; i < ns; i++) {
+                uint32_t c = ro[i];
+                ro[i] = run;
+                run += c;
+            }
+            ro[ns] = run;
+            s.redges.resize(run);
+            cursor.assign(ro, ro + ns);
+            for (uint64_t key : ct.keys)  // keys ascend by resource => each reverse row ascends by resource
+                if (!filt || store.live(ct, key, now)) s.redges[cursor[(uint32_t)key]++] = (uint32_t)(key >> 32);
+        }
+    }
+    if (s.roff.empty()) s.roff.push_back(0);
+    if (s.redges.empty()) s.redges.push_back(0);
+    auto enum_op = [&](int rel_slot, size_t k, int target) {
+        const RevLayout &l = rl[rel_slot][k];
+        if (!l.any) return;
+        RevOp op{};
+        op.flags = OP_ENUM;
+        op.roff_base = l.roff_base;
+        op.nrows = l.nrows;
+        op.target = (uint32_t)target;
+        s.rops.push_back(op);
+    };
+    // parents of a true state X = (t, m)
+    s.rprogs.assign(sc.nslots, RevProg{0, 0});
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        auto [t, m] = sc.slot_owner[slot];
+        const std::string &xname = sc.defs[t].members[m].name;
+        RevProg p;
+        p.first = (uint32_t)s.rops.size();
+        for (size_t t2 = 0; t2 < sc.defs.size(); t2++) {
+            const Definition &d2 = sc.defs[t2];
+            for (const Member &m2 : d2.members) {
+                if (!m2.is_permission) {
+                    // userset subjects `t:id#m` stored on relation m2
+                    for (size_t k = 0; k < m2.classes.size(); k++)
+                        if (m2.classes[k].stype == t && m2.classes[k].srel == m) enum_op(m2.slot, k, m2.slot);
+                    continue;
+                }
+                std::vector<const Node *> refs, arrows;
+                collect(m2.expr, Node::kRef, &refs);
+                collect(m2.expr, Node::kArrow, &arrows);
+                if ((int)t2 == t)
+                    for (const Node *r : refs)
+                        if (r->a == xname) {
+                            RevOp op{};
+                            op.flags = OP_PUSH_SAME;
+                            op.target = (uint32_t)m2.slot;
+                            s.rops.push_back(op);
+                            break;
+                        }
+                for (const Node *a : arrows) {
+                    if (a->b != xname) continue;
+                    const Member &ts = d2.members[d2.find(a->a)];
+                    for (size_t k = 0; k < ts.classes.size(); k++)
+                        if (ts.classes[k].stype == t) enum_op(ts.slot, k, m2.slot);
+                }
+            }
+        }
+        p.n = (uint32_t)s.rops.size() - p.first;
+        s.rprogs[slot] = p;
+    }
+    // seeds for a subject key
+    s.rseeds.assign(sc.nkeys(), RevProg{0, 0});
+    for (uint32_t key = 0; key < sc.nkeys(); key++) {
+        int st, sr;
+        if (key < (uint32_t)sc.nslots) {
+            st = sc.slot_owner[key].first;
+            sr = sc.slot_owner[key].second;
+        } else {
+            st = (int)key - sc.nslots;
+            sr = kNoRelation;
+        }
+        RevProg p;
+        p.first = (uint32_t)s.rops.size();
+        if (sr != kNoRelation) {  // reflexive: `t:id#m` is a member of t:id#m
+            RevOp op{};
+            op.flags = OP_PUSH_SAME;
+            op.target = key;
+            s.rops.push_back(op);
+        }
+        for (int slot = 0; slot < sc.nslots; slot++) {
+            auto [t2, m2] = sc.slot_owner[slot];
+            const Member &mem = sc.defs[t2].members[m2];
+            for (size_t k = 0; k < mem.classes.size(); k++)
+                if (mem.classes[k].stype == st && mem.classes[k].srel == sr) enum_op(slot, k, slot);
+        }
+        p.n = (uint32_t)s.rops.size() - p.first;
+        s.rseeds[key] = p;
+    }
+    if (s.rops.empty()) s.rops.push_back(RevOp{});
+    s.slot_bit_base.assign(sc.nslots + 1, 0);
+    s.slot_nobjects.assign(sc.nslots, 0);
+    uint64_t bits = 0;
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        s.slot_bit_base[slot] = (uint32_t)bits;
+        s.slot_nobjects[slot] = store.objects(sc.slot_owner[slot].first).count();
+        bits += ((uint64_t)s.slot_nobjects[slot] + 31) / 32 * 32;
+    }
+    s.slot_bit_base[sc.nslots] = (uint32_t)bits;
+    s.visited_bits = bits;
+    s.has_reverse = true;
+}
+
+}  // namespace acl

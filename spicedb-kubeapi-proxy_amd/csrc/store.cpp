@@ -320,6 +320,8 @@ Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const
     int cls = class_index(mem.slot, stype, srel < 0 ? kNoRelation : srel);
     if (cls < 0) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: subject type not allowed on relation");
     ClassTable &ct = tables_[mem.slot][cls];
+    for (size_t i = 0; i < n; i++)  // bit 31 of a stored subject id is the snapshot's leaf flag
+        if ((res[i] | subj[i]) & 0x80000000u) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: object ids must be below 2^31");
     ct.pending.reserve(ct.pending.size() + n);
     uint32_t maxr = 0, maxs = 0;
     for (size_t i = 0; i < n; i++) {
