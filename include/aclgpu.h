@@ -156,6 +156,38 @@ int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int permission, int sty
 int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int stype, int srel, const uint32_t *subject_ids, size_t n,
                                uint32_t *bitmaps_out, size_t bitmap_words, uint64_t *counts_out);
 
+/* ---- sharded graph: the north star's multi-GPU configuration ----
+ * One engine per GPU holds the rows of the object types with fnv1a(type name) mod world == rank; the
+ * relationship store (ids, writes) stays replicated.  A batch advances one dispatch level at a time on every
+ * shard; sub-checks whose rows live elsewhere are appended to the caller's export buffer (16-byte frontier
+ * entries) and the host exchanges them between levels -- RCCL all-gather in aclgpu/sharded.py, ncclAllGather in
+ * the cgo shim -- then hands every other shard's segment to *_import.  The non-sharded evaluating entry points
+ * fail with ACL_ERR_FAILED_PRECONDITION on a sharded engine.  All buffers are device pointers owned by the caller. */
+typedef struct {
+    uint64_t exported; /* entries this step wanted to export; > export_cap means entries were dropped: redo the batch with a larger buffer */
+    uint32_t produced; /* != 0: this shard's own next frontier is not empty */
+    uint32_t overflow; /* 0 ok; 1 frontier out of chunks (acl_shard_grow_frontier, redo the batch); 2 a row exceeds the enumeration limit */
+} acl_shard_step_t;
+enum { ACL_SHARD_VISIT = 1, ACL_SHARD_EXPAND = 2 };
+int acl_shard_configure(acl_engine_t *h, uint32_t rank, uint32_t world); /* world == 1 restores the single-GPU engine */
+int acl_shard_of_type(acl_engine_t *h, int type);                        /* shard holding the type's rows; -1 if unknown */
+int acl_shard_grow_frontier(acl_engine_t *h);
+/* Check (check.go:48): d_items = the WHOLE batch on every shard (each seeds the items whose resource type it owns);
+ * d_has / d_err = n bytes each, per shard; after the last level the host MAX-reduces both across shards. */
+int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *d_has, void *d_err);
+int acl_shard_check_step(acl_engine_t *h, uint32_t level /* 1..50 */, void *d_has, void *d_err, void *d_export, size_t export_cap,
+                         acl_shard_step_t *out);
+int acl_shard_check_import(acl_engine_t *h, uint32_t level, const void *d_entries, size_t n);
+int acl_shard_check_finish(acl_engine_t *h, const void *d_has, const void *d_err, size_t n, void *d_perm_out, void *d_err_out);
+/* LookupResources (lookups.go:65) for n subjects of one class.  Iteration 1 expands the seeds (ACL_SHARD_EXPAND);
+ * then ACL_SHARD_VISIT (marks first visits, exports the states other shards hold parent rows for), exchange +
+ * import, ACL_SHARD_EXPAND, ... until no shard produced or exported anything in a visit step. */
+int acl_shard_lookup_begin(acl_engine_t *h, int rtype, int permission, int stype, int srel /* -1 none */, const uint32_t *subject_ids, size_t n);
+int acl_shard_lookup_step(acl_engine_t *h, uint32_t iter, int phase, void *d_export, size_t export_cap, acl_shard_step_t *out);
+int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entries, size_t n);
+/* n rows of bitmap_words words: the resource type's owner returns the result bits, every other shard zeros */
+int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_words);
+
 /* ---- measurement ---- */
 typedef struct {
     uint64_t check_items;      /* items answered since open / last reset */

@@ -18,6 +18,9 @@ SYMBOLS = [
     "acl_object_name", "acl_object_count", "acl_write", "acl_delete_by_filter", "acl_read", "acl_add_edges", "acl_revision",
     "acl_set_now", "acl_snapshot", "acl_check_bulk", "acl_check_bulk_ids", "acl_check_bulk_ids_device", "acl_stream", "acl_sync",
     "acl_lookup_resources", "acl_lookup_resources_ids", "acl_lookup_resources_batch", "acl_stats", "acl_stats_reset", "acl_set_timing",
+    "acl_shard_configure", "acl_shard_of_type", "acl_shard_grow_frontier", "acl_shard_check_begin", "acl_shard_check_step",
+    "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
+    "acl_shard_lookup_finish",
 ]
 
 
@@ -46,6 +49,10 @@ class Stats(C.Structure):
     _fields_ = [("check_items", C.c_uint64), ("check_passes", C.c_uint64), ("expand_launches", C.c_uint64), ("levels_last", C.c_uint64),
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
                 ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64)]
+
+
+class ShardStep(C.Structure):
+    _fields_ = [("exported", C.c_uint64), ("produced", C.c_uint32), ("overflow", C.c_uint32)]
 
 
 READ_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Relationship))
@@ -109,5 +116,16 @@ def load():
     L.acl_stats.argtypes = [H, C.POINTER(Stats)]
     L.acl_stats_reset.argtypes = [H]
     L.acl_set_timing.argtypes = [H, C.c_int]
+    L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
+    L.acl_shard_of_type.argtypes = [H, C.c_int]
+    L.acl_shard_grow_frontier.argtypes = [H]
+    L.acl_shard_check_begin.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_shard_check_step.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ShardStep)]
+    L.acl_shard_check_import.argtypes = [H, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.acl_shard_check_finish.argtypes = [H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_shard_lookup_begin.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.acl_shard_lookup_step.argtypes = [H, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ShardStep)]
+    L.acl_shard_lookup_import.argtypes = [H, C.c_uint32, C.c_void_p, C.c_size_t]
+    L.acl_shard_lookup_finish.argtypes = [H, C.c_void_p, C.c_size_t]
     _lib = L
     return L

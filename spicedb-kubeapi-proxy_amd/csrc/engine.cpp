@@ -68,6 +68,7 @@ struct acl_engine {
     std::mutex mu;
     Store store;
     Snapshot snap;
+    ShardSpec shard;  // world > 1: this engine holds one shard of the graph and only the acl_shard_* entry points evaluate
     bool snap_valid = false, rev_uploaded = false;
     int device = 0;
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
@@ -93,6 +94,8 @@ struct acl_engine {
     DevArray<uint4> d_items;
     uint32_t max_sub_batch = 1u << 20;
     uint32_t levels_hint = 6;
+    uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
+    size_t lk_n = 0;
     // measurement
     acl_stats_t stats{};
     bool timing = false;
@@ -111,7 +114,7 @@ struct acl_engine {
         f.counts[1] = d_fcounts[1].p;
         f.nchunks = d_status.p;
         f.any = d_status.p + kLevelSlots;
-        f.overflow = d_status.p + 2 * kLevelSlots;
+        f.overflow = d_status.p + 2 * kLevelSlots;  // [+1]: the level's export counter (sharded graph)
         f.nwaves = (uint32_t)grid_blocks * kWavesPerBlock;
         f.max_chunks = max_chunks;
         return f;
@@ -171,7 +174,7 @@ int ensure_snapshot(acl_engine *h) {
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     const int64_t now = h->store.now();
     if (h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi) return ACL_OK;
-    build_forward(h->store, now, &h->snap);
+    build_forward(h->store, now, &h->snap, h->shard);
     HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
     HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
     HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
@@ -192,7 +195,7 @@ int ensure_reverse(acl_engine *h) {
     int rc = ensure_snapshot(h);
     if (rc) return rc;
     if (h->rev_uploaded) return ACL_OK;
-    build_reverse(h->store, h->store.now(), &h->snap);
+    build_reverse(h->store, h->store.now(), &h->snap, h->shard);
     HIP_TRY(h->d_roff.upload(h->snap.roff, h->stream));
     HIP_TRY(h->d_redges.upload(h->snap.redges, h->stream));
     HIP_TRY(h->d_rops.upload(h->snap.rops, h->stream));
@@ -276,8 +279,16 @@ int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm,
     }
 }
 
+int not_sharded(acl_engine *h) {
+    if (h->shard.world > 1)
+        return fail(ACL_ERR_FAILED_PRECONDITION, "this engine holds one shard of the graph: evaluate through acl_shard_* with the other shards");
+    return ACL_OK;
+}
+
 int check_device(acl_engine *h, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout) {
-    int rc = ensure_snapshot(h);
+    int rc = not_sharded(h);
+    if (rc) return rc;
+    rc = ensure_snapshot(h);
     if (rc) return rc;
     for (size_t b = 0; b < n; b += h->max_sub_batch) {
         uint32_t m = (uint32_t)std::min<size_t>(h->max_sub_batch, n - b);
@@ -574,8 +585,10 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
     std::lock_guard<std::mutex> lk(h->mu);
     if (n && (!sids || !bitmaps)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_resources_batch: NULL buffer");
     if (h->store_only) return ensure_snapshot(h);
+    int rc = not_sharded(h);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
-    int rc = ensure_reverse(h);
+    rc = ensure_reverse(h);
     if (rc) return rc;
     const Schema &sc = h->store.schema();
     if (rtype < 0 || rtype >= (int)sc.defs.size() || stype < 0 || stype >= (int)sc.defs.size() || perm < 0 ||
@@ -692,6 +705,214 @@ int acl_stats_reset(acl_engine_t *h) {
 int acl_set_timing(acl_engine_t *h, int on) {
     std::lock_guard<std::mutex> lk(h->mu);
     h->timing = on != 0;
+    return ACL_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- sharded graph
+// One engine = one shard.  The host drives every shard one level at a time and moves the exported frontier
+// entries between them (RCCL all-gather in aclgpu/sharded.py); nothing here talks to another GPU.
+namespace {
+
+DevShard dev_shard(acl_engine *h, void *d_export, size_t cap) {
+    DevShard sh;
+    sh.exp = (uint4 *)d_export;
+    sh.exp_count = h->d_status.p + 2 * kLevelSlots + 1;
+    sh.cap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu);
+    sh.rank = h->shard.rank;
+    sh.world = h->shard.world;
+    return sh;
+}
+
+// reads back the status block after a level and fills the step report
+int shard_report(acl_engine *h, uint32_t iter, acl_shard_step_t *out) {
+    HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ev_collect(h);
+    out->exported = h->h_status[2 * kLevelSlots + 1];
+    out->produced = h->h_status[kLevelSlots + iter];
+    out->overflow = h->h_status[2 * kLevelSlots];
+    return ACL_OK;
+}
+
+int shard_ready(acl_engine *h, uint32_t iter) {
+    if (h->store_only) return ensure_snapshot(h);
+    if (iter == 0 || iter >= kLevelSlots) return fail(ACL_ERR_INVALID_ARGUMENT, "shard step: iteration out of range");
+    if (!h->snap_valid) return fail(ACL_ERR_FAILED_PRECONDITION, "shard step without acl_shard_*_begin");
+    HIP_TRY(hipSetDevice(h->device));
+    return ACL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int acl_shard_configure(acl_engine_t *h, uint32_t rank, uint32_t world) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (world == 0 || rank >= world) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_configure: rank must be < world");
+    h->shard.rank = rank;
+    h->shard.world = world;
+    h->snap_valid = false;
+    return ACL_OK;
+}
+
+int acl_shard_of_type(acl_engine_t *h, int type) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return -1;
+    return (int)shard_of_type(sc.defs[type].name, h->shard.world);
+}
+
+int acl_shard_grow_frontier(acl_engine_t *h) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->store_only) return ensure_snapshot(h);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded");
+    h->stats.overflow_retries++;
+    return alloc_frontier(h, h->frontier_entries * 4);
+}
+
+int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *d_has, void *d_err) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n && (!d_items || !d_has || !d_err)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_begin: NULL buffer");
+    if (n > 0xFFFFFFFFu) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_begin: batch too large");
+    if (h->store_only) return ensure_snapshot(h);
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_snapshot(h);
+    if (rc) return rc;
+    if ((uint64_t)n > h->frontier_entries) {
+        rc = alloc_frontier(h, (uint64_t)n * 4);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(h->d_status.p, 0, kStatusWords * sizeof(uint32_t), h->stream));
+    ev_begin(h, 0);
+    launch_seed(h->stream, h->dev_graph(), h->dev_frontier(), (const uint4 *)d_items, (uint32_t)n, (uint8_t *)d_has, (uint8_t *)d_err,
+                dev_shard(h, nullptr, 0));
+    ev_end(h);
+    h->stats.check_items += n;
+    h->stats.check_passes++;
+    return ACL_OK;
+}
+
+int acl_shard_check_step(acl_engine_t *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t export_cap, acl_shard_step_t *out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!out || !d_has || !d_err || (export_cap && !d_export)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: NULL buffer");
+    int rc = shard_ready(h, level);
+    if (rc) return rc;
+    if (level > kMaxLevels) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: level beyond the dispatch depth limit");
+    HIP_TRY(hipMemsetAsync(h->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), h->stream));
+    ev_begin(h, 1);
+    launch_expand(h->stream, h->dev_graph(), h->dev_frontier(), level, (uint8_t *)d_has, (uint8_t *)d_err, dev_shard(h, d_export, export_cap));
+    ev_end(h);
+    h->stats.expand_launches++;
+    h->stats.levels_last = level;
+    return shard_report(h, level, out);
+}
+
+int acl_shard_check_import(acl_engine_t *h, uint32_t level, const void *d_entries, size_t n) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n && !d_entries) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_import: NULL buffer");
+    int rc = shard_ready(h, level);
+    if (rc) return rc;
+    ev_begin(h, 0);
+    launch_import(h->stream, h->dev_graph(), h->dev_frontier(), level, (const uint4 *)d_entries, (uint32_t)n, dev_shard(h, nullptr, 0));
+    ev_end(h);
+    return ACL_OK;
+}
+
+int acl_shard_check_finish(acl_engine_t *h, const void *d_has, const void *d_err, size_t n, void *d_perm_out, void *d_err_out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n && (!d_has || !d_err || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_finish: NULL buffer");
+    if (h->store_only) return ensure_snapshot(h);
+    HIP_TRY(hipSetDevice(h->device));
+    ev_begin(h, 0);
+    launch_finalize(h->stream, (uint32_t)n, (const uint8_t *)d_has, (const uint8_t *)d_err, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
+    ev_end(h);
+    return ACL_OK;
+}
+
+int acl_shard_lookup_begin(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n && !sids) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_begin: NULL buffer");
+    if (h->store_only) return ensure_snapshot(h);
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_reverse(h);
+    if (rc) return rc;
+    const Schema &sc = h->store.schema();
+    if (rtype < 0 || rtype >= (int)sc.defs.size() || stype < 0 || stype >= (int)sc.defs.size() || perm < 0 ||
+        perm >= (int)sc.defs[rtype].members.size() || srel >= (int)sc.defs[stype].members.size())
+        return fail(ACL_ERR_FAILED_PRECONDITION, "lookup: unknown type, permission or subject relation");
+    const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
+    if (n * vwords > ((size_t)1 << 30)) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "lookup batch too large for one pass (visited bitmaps > 4 GiB)");
+    if (n > h->frontier_entries) {
+        rc = alloc_frontier(h, n * 4);
+        if (rc) return rc;
+    }
+    h->lk_target = (uint32_t)sc.slot(rtype, perm);
+    h->lk_n = n;
+    const uint32_t key = sc.subject_key(stype, srel < 0 ? kNoRelation : srel);
+    HIP_TRY(h->d_visited.ensure(std::max<size_t>(n, 1) * vwords));
+    HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, std::max<size_t>(n, 1) * vwords * 4, h->stream));
+    DevFrontier f = h->dev_frontier();
+    std::vector<uint4> seeds(n);
+    for (size_t i = 0; i < n; i++) seeds[i] = make_uint4(sids[i], (uint32_t)i, key /* dist 0 */, 0);
+    const size_t need_chunks = (n + kChunk - 1) / kChunk;
+    std::vector<uint32_t> st(kStatusWords, 0), cc(std::max<size_t>(need_chunks, f.nwaves), 0);
+    st[0] = need_chunks > f.nwaves ? (uint32_t)(need_chunks - f.nwaves) : 0u;
+    st[kLevelSlots] = n ? 1 : 0;
+    for (size_t c = 0; c < need_chunks; c++) cc[c] = (uint32_t)std::min<size_t>(kChunk, n - c * kChunk);
+    HIP_TRY(hipMemcpyAsync(h->d_status.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, h->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(f.buf[0], seeds.data(), n * sizeof(uint4), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(f.counts[0], cc.data(), cc.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ACL_OK;
+}
+
+int acl_shard_lookup_step(acl_engine_t *h, uint32_t iter, int phase, void *d_export, size_t export_cap, acl_shard_step_t *out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!out || (export_cap && !d_export)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_step: NULL buffer");
+    if (phase != ACL_SHARD_VISIT && phase != ACL_SHARD_EXPAND) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_step: bad phase");
+    int rc = shard_ready(h, iter);
+    if (rc) return rc;
+    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_step without acl_shard_lookup_begin");
+    const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
+    DevReverse r{h->d_roff.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
+    HIP_TRY(hipMemsetAsync(h->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), h->stream));
+    ev_begin(h, 1);
+    launch_rev_expand(h->stream, r, h->dev_frontier(), iter, phase == ACL_SHARD_VISIT ? REV_VISIT : REV_EXPAND, dev_shard(h, d_export, export_cap));
+    ev_end(h);
+    h->stats.expand_launches++;
+    return shard_report(h, iter, out);
+}
+
+int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entries, size_t n) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (n && !d_entries) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_import: NULL buffer");
+    int rc = shard_ready(h, iter);
+    if (rc) return rc;
+    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_import without acl_shard_lookup_begin");
+    DevReverse r{h->d_roff.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, 0};
+    launch_rev_import(h->stream, r, h->dev_frontier(), iter, (const uint4 *)d_entries, (uint32_t)n);
+    return ACL_OK;
+}
+
+int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_words) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (h->store_only) return ensure_snapshot(h);
+    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_finish without acl_shard_lookup_begin");
+    HIP_TRY(hipSetDevice(h->device));
+    const uint32_t nobj = h->snap.slot_nobjects[h->lk_target];
+    const size_t need = (nobj + 31) / 32;
+    if (h->lk_n && (!d_bitmaps_out || bitmap_words < need))
+        return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
+    const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
+    const size_t woff = h->snap.slot_bit_base[h->lk_target] / 32;
+    // rows of the result: only the owner of the resource type ever marks them, other shards hand back zeros
+    HIP_TRY(hipMemsetAsync(d_bitmaps_out, 0, h->lk_n * bitmap_words * 4, h->stream));
+    if (need)
+        HIP_TRY(hipMemcpy2DAsync(d_bitmaps_out, bitmap_words * 4, h->d_visited.p + woff, vwords * 4, need * 4, h->lk_n, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return ACL_OK;
 }
 

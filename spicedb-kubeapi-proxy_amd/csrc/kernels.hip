@@ -203,10 +203,20 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 
 // Expand the first T tasks of the wave's LDS list.  INLINE: children are probed here and only the ones with
 // remaining enumeration work are written (forward Check); otherwise every child is written (reverse walk).
-template <bool INLINE>
+// wave-cooperative append of the flagged lanes' entries to the shard's export buffer (one atomic per call)
+__device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint32_t lane, const DevShard &sh) {
+    const uint64_t bx = __ballot(xport);
+    if (!bx) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(sh.exp_count, (uint32_t)__popcll(bx));
+    const uint32_t at = uniform(base) + lanes_below(bx);
+    if (xport && at < sh.cap) sh.exp[at] = e;
+}
+
+template <bool INLINE, bool SHARDED>
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
                                             const FwdOp *ops, const uint32_t *__restrict__ edges, const DevFrontier &f, uint4 *__restrict__ out,
-                                            uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err) {
+                                            uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err, const DevShard &sh) {
     wave_lds_fence();
     for (uint32_t gq = 0; gq < T; gq += 64) {
         const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
@@ -216,7 +226,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
         wave_lds_fence();
         for (uint32_t w0 = 0; w0 < total; w0 += 64) {
             const uint32_t w = w0 + lane;
-            bool push = false;
+            bool push = false, xport = false;
             uint4 e = make_uint4(0, 0, 0, 0);
             if (w < total) {
                 uint32_t j = 0;  // largest j with scan[j] <= w
@@ -229,7 +239,11 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                 const uint32_t child = INLINE ? (edge & kIdMask) : edge;
                 e = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
                 push = true;
-                if (INLINE) {
+                if (INLINE && SHARDED && progs[meta_slot(e.z)].owner != sh.rank) {
+                    // the child's rows live on another shard: it leaves unprobed and is evaluated by its owner
+                    push = false;
+                    xport = true;
+                } else if (INLINE) {
                     bool hit = false, derr = false;
                     push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, (c & kLeafAuthBit) != 0,
                                       (edge & kLeafBit) != 0, hit, derr);
@@ -247,6 +261,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                 const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
                 if (push && base != kNoSpace) out[base + lanes_below(b)] = e;
             }
+            if (INLINE && SHARDED) export_entries(xport, e, lane, sh);
         }
         wave_lds_fence();
     }
@@ -254,7 +269,8 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
 
 // ------------------------------------------------------------------ seed
 // items: acl_item_t (16 B): x = rtype | perm << 16, y = resource id, z = stype | srel << 16, w = subject id
-__global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const uint4 *__restrict__ items, uint32_t n, uint8_t *has, uint8_t *err) {
+__global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const uint4 *__restrict__ items, uint32_t n, uint8_t *has, uint8_t *err,
+                                              DevShard sh) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t need = (n + kChunk - 1) / kChunk;       // chunks holding seeds: ids [0, need)
     const uint32_t readable = max(need, f.nwaves);          // the reader scans every static chunk
@@ -275,13 +291,15 @@ __global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const u
         uint32_t slot = g.type_slot_base[rtype] + perm;
         uint32_t key = srel == 0xFFFFu ? g.nslots + stype : g.type_slot_base[stype] + srel;
         meta = make_meta(slot, 1u, key);
+        if (sh.world > 1 && g.progs[slot].owner != sh.rank) meta = kDeadMeta;  // seeded by the shard that owns the resource type
     }
     f.buf[0][i] = make_uint4(it.y, i, meta, it.w);
 }
 
 // ---------------------------------------------------------------- expand
-template <bool LDSPROG>
-__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err) {
+template <bool LDSPROG, bool SHARDED>
+__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
+                                                                           DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs = g.progs;
@@ -380,14 +398,14 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                 }
                 T += (uint32_t)__popcll(b);
                 if (T > kTaskCap - 64) {
-                    flush_tasks<true>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err);
+                    flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
                     T = 0;
                 }
             }
         }
         if (hit) has[req] = 1;
         else if (depth_err) err[req] = ITEM_ERR_DEPTH;
-        if (T) flush_tasks<true>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err);
+        if (T) flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
     }
     if (lane == 0) {
         if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
@@ -406,9 +424,16 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
 }
 
 // ----------------------------------------------------------- reverse expand
-// entry: x = object id, y = lookup request, z = meta (slot | dist << 13), w unused.
+// entry: x = object id, y = lookup request, z = meta (slot | dist << 13 | flags), w unused.
 // dist == 0 marks a seed entry: slot field holds the SUBJECT KEY and the program is rseeds[key].
-__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(DevReverse r, DevFrontier f, uint32_t iter) {
+// PHASE: REV_FUSED  (unsharded) visit + expand in one pass;
+//        REV_VISIT  (sharded)   test-and-set `visited`, pass first visits on (kRevVisited) and export the ones whose
+//                               parent rows also live on other shards (kRevForeign) -- no expansion;
+//        REV_EXPAND (sharded)   expand seeds / visited / foreign entries, never touching `visited`.
+// Two phases keep the sharded walk level-synchronous: a state and its foreign copies are expanded in the same
+// iteration, so "first visit wins" still records the minimum distance (the depth-50 cut depends on it).
+template <uint32_t PHASE>
+__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(DevReverse r, DevFrontier f, uint32_t iter, DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
     const uint32_t lane = lane_id();
     const uint32_t wib = threadIdx.x >> 6;
@@ -437,21 +462,38 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
         bool active = valid && meta != kDeadMeta;
         const uint32_t slot = meta & 0x1FFFu, dist = (meta >> 13) & 63u;
         RevProg p{0, 0};
+        bool first_visit = false;
         if (active) {
             if (dist == 0) {
                 p = r.rseeds[slot];
+            } else if (PHASE == REV_EXPAND) {
+                p = r.rprogs[slot];  // kRevVisited or kRevForeign: the visit already happened (here or on the owner)
             } else if (id < r.slot_nobjects[slot]) {
                 // first visit wins: level-synchronous order makes it the minimum distance
                 const uint32_t bit = r.slot_bit_base[slot] + id;
                 const uint32_t m = 1u << (bit & 31u);
                 const uint32_t old = atomicOr(r.visited + (size_t)req * r.visited_words + (bit >> 5), m);
                 if (old & m) active = false;
-                else p = r.rprogs[slot];
+                else {
+                    p = r.rprogs[slot];
+                    first_visit = true;
+                }
             } else {
                 active = false;
             }
         }
-        const uint32_t nops = (active && dist < kMaxLevels) ? p.n : 0u;  // parents of a dist-50 state would need 51 levels
+        if (PHASE == REV_VISIT) {
+            // seeds and first visits move on to the expand phase; states with parents elsewhere are also exported
+            const uint4 o = make_uint4(id, req, first_visit ? (meta | kRevVisited) : meta, 0);
+            const uint64_t b = __ballot(active);
+            if (b) {
+                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                if (active && base != kNoSpace) out[base + lanes_below(b)] = o;
+            }
+            export_entries(first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels, make_uint4(id, req, meta | kRevForeign, 0), lane, sh);
+            continue;
+        }
+        const uint32_t nops = (active && dist < kMaxLevels) ? (p.n & ~kRevRemoteBit) : 0u;  // parents of a dist-50 state would need 51 levels
         uint32_t T = 0;
         const uint32_t maxops = uniform(wave_max(nops));
         for (uint32_t j = 0; j < maxops; j++) {
@@ -486,16 +528,60 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                 }
                 T += (uint32_t)__popcll(b);
                 if (T > kTaskCap - 64) {
-                    flush_tasks<false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr);
+                    flush_tasks<false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr, sh);
                     T = 0;
                 }
             }
         }
-        if (T) flush_tasks<false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr);
+        if (T) flush_tasks<false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr, sh);
     }
     if (lane == 0) {
         if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;
         if (wo.produced) f.any[iter] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------ import
+// Appends entries of an exchanged export buffer to the frontier iteration `iter` produced (dynamic chunks only:
+// the static chunks belong to that iteration's expand waves).  FWD: keep the entries whose slot this shard owns.
+// Reverse: keep foreign states for which this shard holds parent rows.
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_import(DevFrontier f, uint32_t iter, const uint4 *__restrict__ in, uint32_t n, const SlotProg *progs,
+                                                const RevProg *rprogs, uint32_t rank) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    uint4 *__restrict__ out = f.buf[iter & 1u];
+    uint32_t *out_counts = f.counts[iter & 1u];
+    uint32_t *out_nchunks = f.nchunks + iter;
+    uint32_t cur = kNoSpace, fill = kChunk, produced = 0;
+    for (uint32_t x = wave; (uint64_t)x * 64 < n; x += nw) {
+        const uint32_t i = x * 64 + lane;
+        const uint4 e = i < n ? in[i] : make_uint4(0, 0, kDeadMeta, 0);
+        bool mine = i < n && e.z != kDeadMeta;
+        if (mine) mine = FWD ? progs[meta_slot(e.z)].owner == rank : (rprogs[e.z & 0x1FFFu].n & ~kRevRemoteBit) != 0;
+        const uint64_t b = __ballot(mine);
+        if (!b) continue;
+        const uint32_t need = (uint32_t)__popcll(b);
+        if (fill + need > kChunk) {
+            if (lane == 0 && cur != kNoSpace) out_counts[cur] = fill;
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(out_nchunks, 1u);
+            c = uniform(c) + f.nwaves;
+            if (c >= f.max_chunks) {
+                if (lane == 0) *f.overflow = 1u;
+                cur = kNoSpace;
+                break;
+            }
+            cur = c;
+            fill = 0;
+        }
+        if (mine) out[(size_t)cur * kChunk + fill + lanes_below(b)] = e;
+        fill += need;
+        produced += need;
+    }
+    if (lane == 0) {
+        if (cur != kNoSpace) out_counts[cur] = fill;
+        if (produced) f.any[iter] = 1u;
     }
 }
 
@@ -507,25 +593,46 @@ int expand_grid_blocks(int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int per_cu = 8;  // 256-thread blocks, <= 64 VGPRs, ~20 KiB LDS
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true>, kBlock, 0) == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 0) == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
     return cus * per_cu;
 }
 
-void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err) {
+void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const uint32_t threads = n > f.nwaves ? n : f.nwaves;
-    hipLaunchKernelGGL(k_seed, dim3((threads + 255) / 256), dim3(256), 0, s, g, f, items, n, has, err);
+    hipLaunchKernelGGL(k_seed, dim3((threads + 255) / 256), dim3(256), 0, s, g, f, items, n, has, err, sh);
 }
-void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err) {
+void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const dim3 grid(f.nwaves / kWavesPerBlock);
-    if (g.nslots + g.nops <= kProgLdsEntries) hipLaunchKernelGGL(k_expand<true>, grid, dim3(kBlock), 0, s, g, f, iter, has, err);
-    else hipLaunchKernelGGL(k_expand<false>, grid, dim3(kBlock), 0, s, g, f, iter, has, err);
+    const bool lds = g.nslots + g.nops <= kProgLdsEntries;
+    if (sh.world > 1) {
+        if (lds) hipLaunchKernelGGL((k_expand<true, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+        else hipLaunchKernelGGL((k_expand<false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+    } else {
+        if (lds) hipLaunchKernelGGL((k_expand<true, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+        else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+    }
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
 }
-void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter) {
-    hipLaunchKernelGGL(k_rev_expand, dim3(f.nwaves / kWavesPerBlock), dim3(kBlock), 0, s, r, f, iter);
+void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase, const DevShard &sh) {
+    const dim3 grid(f.nwaves / kWavesPerBlock);
+    if (phase == REV_VISIT) hipLaunchKernelGGL(k_rev_expand<REV_VISIT>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
+    else if (phase == REV_EXPAND) hipLaunchKernelGGL(k_rev_expand<REV_EXPAND>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
+    else hipLaunchKernelGGL(k_rev_expand<REV_FUSED>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
+}
+static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input per wave, at most 256 blocks
+    const uint32_t b = (n + 4095) / 4096;
+    return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
+void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n, const DevShard &sh) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_import<true>, dim3(import_blocks(n)), dim3(256), 0, s, f, iter, in, n, g.progs, (const RevProg *)nullptr, sh.rank);
+}
+void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_import<false>, dim3(import_blocks(n)), dim3(256), 0, s, f, iter, in, n, (const SlotProg *)nullptr, r.rprogs, 0u);
 }
 
 }  // namespace acl

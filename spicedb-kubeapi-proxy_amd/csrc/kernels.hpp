@@ -12,8 +12,8 @@ namespace acl {
 constexpr uint32_t kChunk = 1024;         // entries per frontier chunk (16 KiB)
 constexpr uint32_t kSegsPerChunk = kChunk / 64;
 constexpr uint32_t kMaxLevels = 50;       // dispatch max depth, reference pkg/spicedb/spicedb.go:34
-constexpr uint32_t kLevelSlots = 64;      // per-iteration counters
-constexpr uint32_t kStatusWords = 2 * kLevelSlots + 1;  // nchunks[64] | any[64] | overflow
+constexpr uint32_t kLevelSlots = 128;     // per-iteration counters (the sharded reverse walk runs two iterations per level)
+constexpr uint32_t kStatusWords = 2 * kLevelSlots + 2;  // nchunks[] | any[] | overflow | export count
 constexpr uint32_t kDeadMeta = 0xFFFFFFFFu;
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kProgLdsEntries = 256;  // ops + progs (32 B each) cached in LDS when they fit
@@ -52,10 +52,32 @@ struct DevFrontier {
     uint32_t nwaves;       // waves of every expand launch == number of static chunks
 };
 
-void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err);
-void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err);
+// Sharded graph: pending sub-checks whose rows live on another shard leave through `exp`
+// (16 B frontier entries, one contiguous buffer per level) and are exchanged by the host between levels.
+// `exp_count` keeps counting past `cap` (entries beyond it are dropped) so the host can size a retry.
+struct DevShard {
+    uint4 *exp = nullptr;
+    uint32_t *exp_count = nullptr;
+    uint32_t cap = 0;
+    uint32_t rank = 0;
+    uint32_t world = 1;
+};
+// reverse-walk entry flags (meta = slot[0:13) | dist[13:19) | flags)
+constexpr uint32_t kRevForeign = 1u << 19;  // state visited on its owner shard: expand it here, do not touch `visited`
+constexpr uint32_t kRevVisited = 1u << 20;  // state already passed the visit phase
+enum RevPhase : uint32_t { REV_FUSED = 0, REV_VISIT = 1, REV_EXPAND = 2 };
+
+void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err,
+                 const DevShard &sh = DevShard());
+void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err,
+                   const DevShard &sh = DevShard());
+// appends the entries of `in` (an all-gathered export buffer) whose slot this shard owns to the frontier that
+// iteration `iter` produced
+void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n, const DevShard &sh);
+void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n);
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
-void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter);
+void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase = REV_FUSED,
+                       const DevShard &sh = DevShard());
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 

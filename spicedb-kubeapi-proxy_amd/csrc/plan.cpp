@@ -27,6 +27,8 @@ inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }  /
 struct Flattener {
     const Schema &sc;
     const std::vector<RelLayout> &lay;  // [slot]
+    const std::vector<uint32_t> &type_owner;
+    uint32_t rank;
     std::vector<FwdOp> probes, makers, reflex;
     std::vector<int> stack;
     uint32_t max_d = 0;
@@ -74,7 +76,9 @@ struct Flattener {
             for (size_t k = 0; k < m.classes.size(); k++) {
                 const SubjectClass &c = m.classes[k];
                 if (c.srel == kNoRelation) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
-                else row_op(OP_PROBE | OP_ENUM | OP_LEAFBIT, m.slot, (int)k, d, (uint32_t)sc.slot(c.stype, c.srel));
+                else  // leaf flags are only computed (and only trusted) for children whose rows this shard holds
+                    row_op(OP_PROBE | OP_ENUM | (type_owner[c.stype] == rank ? (uint32_t)OP_LEAFBIT : 0u), m.slot, (int)k, d,
+                           (uint32_t)sc.slot(c.stype, c.srel));
             }
             return;
         }
@@ -119,10 +123,17 @@ void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
 
 }  // namespace
 
-void build_forward(Store &store, int64_t now, Snapshot *snap) {
+uint32_t shard_of_type(const std::string &type_name, uint32_t world) {
+    uint32_t h = 2166136261u;  // FNV-1a
+    for (unsigned char c : type_name) h = (h ^ c) * 16777619u;
+    return world > 1 ? h % world : 0u;
+}
+
+void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     store.settle_all();
     const Schema &sc = store.schema();
     Snapshot s;
+    for (const Definition &d : sc.defs) s.type_owner.push_back(shard_of_type(d.name, shard.world));
     s.revision = store.revision();
     store.expiry_window(now, &s.valid_lo, &s.valid_hi);
     s.nslots = (uint32_t)sc.nslots;
@@ -151,6 +162,8 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         RelLayout &l = lay[slot];
         l.nrows = store.objects(t).count();
         l.cls.resize(mem.classes.size());
+        if (s.type_owner[t] != shard.rank) continue;  // another shard holds this type's rows
+        for (const ClassTable &ct : tables[slot]) s.nedges_local += ct.keys.size();
         for (size_t k = 0; k < mem.classes.size(); k++) {
             ClassLayout &c = l.cls[k];
             const ClassTable &ct = tables[slot][k];
@@ -231,9 +244,10 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
     s.progs.resize(sc.nslots);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
-        Flattener f{sc, lay, {}, {}, {}, {}, 0};
+        Flattener f{sc, lay, s.type_owner, shard.rank, {}, {}, {}, {}, 0};
         f.state(t, m, 0);
         SlotProg p{};
+        p.owner = s.type_owner[t];
         p.first = (uint32_t)s.ops.size();
         p.n_probe = (uint32_t)f.probes.size();
         p.n_main = (uint32_t)(f.probes.size() + f.makers.size());
@@ -261,6 +275,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap) {
         for (size_t k = 0; k < mem.classes.size(); k++) {
             const ClassLayout &c = l.cls[k];
             if (!c.live || c.hashed || mem.classes[k].srel == kNoRelation) continue;
+            if (s.type_owner[mem.classes[k].stype] != shard.rank) continue;  // child rows are elsewhere: no leaf flags
             const SlotProg &tp = s.progs[sc.slot(mem.classes[k].stype, mem.classes[k].srel)];
             bool always = false;
             std::vector<FwdOp> enums;

@@ -46,7 +46,8 @@ struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create
     uint32_t n_main;    // n_probe + child-creating ops
     uint32_t n_total;   // n_main + REFLEX ops (only requests whose subject carries a relation)
     uint32_t max_dlevel;  // deepest inlined state
-    uint32_t pad[3];
+    uint32_t owner;       // shard that holds this slot's type (rows + program); 0 when the graph is not sharded
+    uint32_t pad[2];
 };
 struct RevOp {          // 16 B
     uint32_t flags;     // OP_ENUM (reverse row) or OP_PUSH_SAME
@@ -55,8 +56,9 @@ struct RevOp {          // 16 B
     uint32_t target;    // slot that becomes true
 };
 struct RevProg {
-    uint32_t first, n;
+    uint32_t first, n;  // bit 31 of n (kRevRemoteBit): other shards hold parent rows of this state too
 };
+constexpr uint32_t kRevRemoteBit = 0x80000000u;
 
 // ---- host-side snapshot ----
 struct Snapshot {
@@ -72,7 +74,9 @@ struct Snapshot {
     std::vector<uint32_t> type_slot_base, type_nmembers;
     std::vector<uint32_t> type_nobjects;
     uint32_t nslots = 0, ntypes = 0;
-    uint64_t nedges = 0;
+    uint64_t nedges = 0;        // relationships in the store
+    uint64_t nedges_local = 0;  // ... whose resource type this shard owns
+    std::vector<uint32_t> type_owner;  // [ntypes] shard of each type
     // reverse (built on demand)
     bool has_reverse = false;
     std::vector<uint32_t> roff, redges;
@@ -84,7 +88,14 @@ struct Snapshot {
     uint64_t visited_bits = 0;
 };
 
-void build_forward(Store &store, int64_t now, Snapshot *snap);
-void build_reverse(Store &store, int64_t now, Snapshot *snap);
+// Graph partition of the north star's multi-GPU configuration: rows (and programs) of an object type live on
+// shard fnv1a(type name) mod world.  world == 1: everything is local.
+struct ShardSpec {
+    uint32_t rank = 0, world = 1;
+};
+uint32_t shard_of_type(const std::string &type_name, uint32_t world);
+
+void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
+void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
 
 }  // namespace acl

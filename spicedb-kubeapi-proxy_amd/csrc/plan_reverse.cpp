@@ -19,9 +19,11 @@ void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
 
 }  // namespace
 
-void build_reverse(Store &store, int64_t now, Snapshot *snap) {
+void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     const Schema &sc = store.schema();
     Snapshot &s = *snap;
+    std::vector<uint32_t> type_owner;
+    for (const Definition &d : sc.defs) type_owner.push_back(shard_of_type(d.name, shard.world));
     auto &tables = store.tables();
     s.roff.clear();
     s.redges.clear();
@@ -36,6 +38,14 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
         rl[slot].resize(mem.classes.size());
         for (size_t k = 0; k < mem.classes.size(); k++) {
             const ClassTable &ct = tables[slot][k];
+            // `any` is a property of the whole graph (it decides which shards a true state must be sent to);
+            // the rows themselves are only built on the shard that owns the relation's type
+            if (type_owner[t] != shard.rank) {
+                const bool f2 = !ct.expiry.empty();
+                for (uint64_t key : ct.keys)
+                    if (!f2 || store.live(ct, key, now)) { rl[slot][k].any = true; break; }
+                continue;
+            }
             const bool filt = !ct.expiry.empty();
             const uint32_t ns = store.objects(mem.classes[k].stype).count();
             size_t total = 0;
@@ -65,9 +75,14 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
     }
     if (s.roff.empty()) s.roff.push_back(0);
     if (s.redges.empty()) s.redges.push_back(0);
+    bool remote = false;  // set by enum_op when a live parent row set belongs to another shard
     auto enum_op = [&](int rel_slot, size_t k, int target) {
         const RevLayout &l = rl[rel_slot][k];
         if (!l.any) return;
+        if (type_owner[sc.slot_owner[rel_slot].first] != shard.rank) {
+            remote = true;
+            return;
+        }
         RevOp op{};
         op.flags = OP_ENUM;
         op.roff_base = l.roff_base;
@@ -82,6 +97,8 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
         const std::string &xname = sc.defs[t].members[m].name;
         RevProg p;
         p.first = (uint32_t)s.rops.size();
+        remote = false;
+        const bool mine = type_owner[t] == shard.rank;  // computed usersets stay on the object: only its owner runs them
         for (size_t t2 = 0; t2 < sc.defs.size(); t2++) {
             const Definition &d2 = sc.defs[t2];
             for (const Member &m2 : d2.members) {
@@ -94,7 +111,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
                 std::vector<const Node *> refs, arrows;
                 collect(m2.expr, Node::kRef, &refs);
                 collect(m2.expr, Node::kArrow, &arrows);
-                if ((int)t2 == t)
+                if ((int)t2 == t && mine)
                     for (const Node *r : refs)
                         if (r->a == xname) {
                             RevOp op{};
@@ -111,7 +128,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
                 }
             }
         }
-        p.n = (uint32_t)s.rops.size() - p.first;
+        p.n = ((uint32_t)s.rops.size() - p.first) | (remote && mine ? kRevRemoteBit : 0u);
         s.rprogs[slot] = p;
     }
     // seeds for a subject key
@@ -127,7 +144,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap) {
         }
         RevProg p;
         p.first = (uint32_t)s.rops.size();
-        if (sr != kNoRelation) {  // reflexive: `t:id#m` is a member of t:id#m
+        if (sr != kNoRelation && type_owner[st] == shard.rank) {  // reflexive: `t:id#m` is a member of t:id#m
             RevOp op{};
             op.flags = OP_PUSH_SAME;
             op.target = key;
