@@ -48,7 +48,8 @@ def test_sharded_workload_parity(name, kw, world, aclgpu):
         items = se.shard.e.make_items(rt, perm, w.res, st, "", w.subj)
         p, er = se.check_bulk_ids(items)
         bm = se.lookup_ids_batch(rt, perm, st, "", subs)
-        return p.cpu().numpy(), er.cpu().numpy(), bm.cpu(), se.exchanged_entries, se.shard.e.stats()["snapshot_edges"], se.levels_last
+        owners = {se.shard.owner_of_type(t) for t in w.nobjects if t != st}  # the types that hold relationships
+        return p.cpu().numpy(), er.cpu().numpy(), bm.cpu(), se.exchanged_entries, owners, se.levels_last
 
     try:
         outs = sharded.run_logical_shards(world, make, run)
@@ -59,7 +60,8 @@ def test_sharded_workload_parity(name, kw, world, aclgpu):
         assert np.array_equal(p, operms) and np.array_equal(er, oerrs)
         for i, s in enumerate(subs):
             assert np.array_equal(bits(bm[i]), np.sort(o.lookup_ids(rt, perm, st, "", s))), (name, world, s)
-    assert sum(x[3] for x in outs) > 0, "nothing crossed a shard boundary"
+    if len(outs[0][4]) > 1:  # the type hash may put every relation-bearing type on one shard (few types, small world)
+        assert sum(x[3] for x in outs) > 0, "nothing crossed a shard boundary"
 
 
 @pytest.mark.parametrize("world", [2, 3, 5])
