@@ -36,6 +36,104 @@ WORKLOAD_DESC = {
 }
 
 
+def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
+    """The north star's multi-GPU layout: rows partitioned by fnv1a(object type) mod G, one shard per
+    rank, per-level all-gather of cross-shard frontier entries over RCCL.  All ranks answer ONE batch together; the
+    answers are compared with the replica engine's.  world == 1: G logical shards (threads) on this device -- emulated."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    import aclgpu
+    from aclgpu import sharded
+
+    rt, perm_name, st = w.check
+    n = int(res.size)
+    steps = max(2, min(args.steps, 10))
+    items = replica.make_items(rt, perm_name, res, st, "", subj)
+    want_p, want_e = replica.check_bulk_ids(items)
+    G = world if world > 1 else args.logical_shards
+    result = {}
+    box = {}
+
+    def run(se, comm_barrier):
+        d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
+        p = e = None
+        for _ in range(2):
+            p, e = se.check_bulk_ids(d_items)
+        x0, c0 = se.exchanged_entries, se.exchanges
+        comm_barrier()
+        t0 = time.perf_counter()
+        lat = []
+        for _ in range(steps):
+            t1 = time.perf_counter()
+            p, e = se.check_bulk_ids(d_items)
+            lat.append(time.perf_counter() - t1)
+        comm_barrier()
+        el = time.perf_counter() - t0
+        mism = int((p.cpu().numpy() != want_p).sum() + (e.cpu().numpy() != want_e).sum())
+        return {"elapsed": el, "lat": lat, "mismatches": mism, "levels": se.levels_last, "recv_entries_per_batch": (se.exchanged_entries - x0) / steps,
+                "exchanges_per_batch": (se.exchanges - c0) / steps, "shard_relationships": None, "export_cap": se.cap}
+
+    def done(outs):
+        el = max(o["elapsed"] for o in outs)
+        result.update({
+            "layout": f"fnv1a(object type) mod {G}; per-level all-gather of 16 B frontier entries",
+            "collective": "RCCL all_gather_into_tensor over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
+            "shards": G, "batch": n, "steps": steps, "decisions_per_s": n * steps / el, "ms_per_batch": 1e3 * el / steps,
+            "p50_batch_ms": 1e3 * float(np.median(outs[0]["lat"])), "levels": outs[0]["levels"],
+            "exchanges_per_batch": outs[0]["exchanges_per_batch"], "recv_entries_per_batch_by_shard": [o["recv_entries_per_batch"] for o in outs],
+            "shard_relationships": [o["shard_relationships"] for o in outs],
+            "mismatches_vs_replica": int(sum(o["mismatches"] for o in outs)),
+        })
+
+    if world > 1:
+        e2 = aclgpu.Engine(w.schema, device=local_rank)
+        w.load(e2)
+        sh = sharded.GpuShard(e2, rank, world)
+        se = sharded.ShardedEngine(sh, sharded.TorchComm(device=f"cuda:{local_rank}"), export_entries=1 << 20)
+        # watchdog: a wedged collective must not take the bench line with it
+        timer = threading.Timer(240.0, lambda: (print(json.dumps({"metric": "check_decisions_per_sec", "error": "sharded leg timed out"}), flush=True) if rank == 0 else None, os._exit(3)))
+        timer.daemon = True
+        timer.start()
+        try:
+            o = run(se, dist.barrier)
+            o["shard_relationships"] = int(_local_edges(e2))
+            gathered = [None] * world
+            dist.all_gather_object(gathered, {k: v for k, v in o.items()})
+            if rank == 0:
+                done(gathered)
+        finally:
+            timer.cancel()
+            e2.close()
+    else:
+        engines = []
+
+        def make(r, g):
+            e2 = aclgpu.Engine(w.schema, device=local_rank)
+            w.load(e2)
+            engines.append((r, e2))
+            return sharded.GpuShard(e2, r, g)
+
+        def fn(se):
+            se._alloc(1 << 20)
+            o = run(se, se.comm.barrier)
+            o["shard_relationships"] = int(_local_edges(se.shard.e))
+            return o
+
+        try:
+            done(sharded.run_logical_shards(G, make, fn))
+        finally:
+            for _r, e2 in engines:
+                e2.close()
+    return result if rank == 0 else None
+
+
+def _local_edges(engine):
+    return engine.stats().get("snapshot_edges_local", 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +144,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
+                    help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "
+                         "frontiers (north star's 8-GPU layout).  auto = on at 8 ranks.  Reported beside `value`, never as `value`.")
+    ap.add_argument("--logical-shards", type=int, default=0, help="with 1 GPU: run the sharded leg as G logical shards on this device (emulated)")
     args = ap.parse_args()
 
     import torch
@@ -73,6 +175,7 @@ def main():
             kw["batch"] = args.batch
     t0 = time.time()
     w = workloads.by_name(args.workload, **kw)
+    canon_res, canon_subj = w.res.copy(), w.subj.copy()  # the sharded leg answers ONE stream with all ranks together
     if world > 1:  # every rank answers a different request stream against the same graph
         rng = np.random.default_rng(0x5ACE0000 + rank)
         perm = rng.permutation(w.res.size)
@@ -122,6 +225,12 @@ def main():
         elapsed = float(tt.item())
     gpu_perm = d_perm.cpu().numpy()
     gpu_err = d_err.cpu().numpy()
+
+    # ---- extra leg (outside the timed region above): the sharded graph
+    sharded_out = None
+    want_sharded = args.sharded == "on" or (args.sharded == "auto" and world == 8)
+    if want_sharded and (world > 1 or args.logical_shards > 1):
+        sharded_out = sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank)
 
     out = None
     if rank == 0:
@@ -182,6 +291,8 @@ def main():
                     pass
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
+        if sharded_out is not None:
+            out["sharded"] = sharded_out
         print(json.dumps(out))
     eng.close()
     if world > 1:

@@ -201,6 +201,7 @@ typedef struct {
     uint64_t snapshot_bytes;   /* bytes of the current HBM snapshot */
     uint64_t snapshot_builds;
     uint64_t overflow_retries;
+    uint64_t snapshot_edges_local; /* relationships whose rows THIS engine holds (== snapshot_edges unless sharded) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

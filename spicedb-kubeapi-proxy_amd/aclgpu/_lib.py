@@ -48,7 +48,7 @@ class CheckItem(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("check_items", C.c_uint64), ("check_passes", C.c_uint64), ("expand_launches", C.c_uint64), ("levels_last", C.c_uint64),
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
-                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64)]
+                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64)]
 
 
 class ShardStep(C.Structure):

@@ -187,6 +187,7 @@ int ensure_snapshot(acl_engine *h) {
     h->rev_uploaded = false;
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
+    h->stats.snapshot_edges_local = h->snap.nedges_local;
     h->stats.snapshot_bytes = h->snap.meta.size() * 4 + h->snap.edges.size() * 4 + h->snap.buckets.size() * 4 + h->snap.ops.size() * sizeof(FwdOp) + h->snap.progs.size() * sizeof(SlotProg);
     return ACL_OK;
 }
@@ -696,8 +697,9 @@ int acl_stats(acl_engine_t *h, acl_stats_t *out) {
 }
 int acl_stats_reset(acl_engine_t *h) {
     std::lock_guard<std::mutex> lk(h->mu);
-    uint64_t e = h->stats.snapshot_edges, b = h->stats.snapshot_bytes;
+    uint64_t e = h->stats.snapshot_edges, b = h->stats.snapshot_bytes, el = h->stats.snapshot_edges_local;
     h->stats = acl_stats_t{};
+    h->stats.snapshot_edges_local = el;
     h->stats.snapshot_edges = e;
     h->stats.snapshot_bytes = b;
     return ACL_OK;

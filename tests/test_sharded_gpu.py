@@ -131,3 +131,49 @@ def test_sharded_engine_refuses_unsharded_entry_points(aclgpu):
         assert ei.value.code == aclgpu.ERR_FAILED_PRECONDITION
         with pytest.raises(aclgpu.AclError):
             e.lookup("doc", "view", "user", "u0")
+
+
+NCCL_WORLD1 = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [os.environ["ACL_ROOT"], os.path.join(os.environ["ACL_ROOT"], "spicedb-kubeapi-proxy_amd")]
+import aclgpu
+from aclgpu import sharded, workloads
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+w = workloads.c4(scale=0.02, batch=20000, n_user=20000)
+e = aclgpu.Engine(w.schema); w.load(e)
+items = e.make_items("pod", "view", w.res, "user", "", w.subj)
+want = e.check_bulk_ids(items)
+wl = e.lookup_ids_batch("pod", "view", "user", "", [int(w.subj[0]), int(w.subj[1])])[0]
+se = sharded.ShardedEngine(sharded.GpuShard(e, 0, 1), sharded.TorchComm(device="cuda:0"))
+p, er = se.check_bulk_ids(items)
+bm = se.lookup_ids_batch("pod", "view", "user", "", [int(w.subj[0]), int(w.subj[1])])
+ok = bool(np.array_equal(p.cpu().numpy(), want[0]) and np.array_equal(er.cpu().numpy(), want[1]) and np.array_equal(bm.cpu().numpy().view(np.uint32), wl))
+# the collectives the protocol uses, with the dtypes it uses, on the engine's stream
+with se.shard.stream():
+    se.comm.all_gather(se.gather[:64], se.export[:64])
+    h = torch.ones(8, dtype=torch.uint8, device="cuda"); se.comm.all_reduce_max(h)
+    se.comm.broadcast(bm, 0)
+print(json.dumps({"ok": ok, "levels": se.levels_last}))
+e.close(); dist.destroy_process_group()
+"""
+
+
+def test_protocol_over_rccl_world1(aclgpu, tmp_path):
+    """The SPMD protocol with the REAL communicator (torch.distributed nccl == RCCL) on the one GPU a test box has:
+    world_size 1 still runs every collective call, dtype and stream hand-off the multi-GPU path uses."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ACL_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", NCCL_WORLD1], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"], out
