@@ -43,6 +43,7 @@ enum {
     ACL_ERR_ALREADY_EXISTS = 6,      /* codes.AlreadyExists: CREATE of an existing relationship */
     ACL_ERR_RESOURCE_EXHAUSTED = 8,  /* codes.ResourceExhausted: frontier capacity exceeded */
     ACL_ERR_FAILED_PRECONDITION = 9, /* codes.FailedPrecondition: precondition failed, unknown type/relation */
+    ACL_ERR_OUT_OF_RANGE = 11,       /* codes.OutOfRange: watch cursor older than the retained change feed */
     ACL_ERR_INTERNAL = 13,           /* codes.Internal (HIP runtime failure) */
     ACL_ERR_UNAVAILABLE = 14,        /* codes.Unavailable: no usable GPU */
     ACL_ERR_DEPTH = 100              /* per-item: max dispatch depth (50) exceeded, pkg/spicedb/spicedb.go:34 */
@@ -155,6 +156,32 @@ int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int permission, int sty
 /* batched form: n subjects of one (stype, srel) against one (rtype, permission); bitmaps_out is n * bitmap_words */
 int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int stype, int srel, const uint32_t *subject_ids, size_t n,
                                uint32_t *bitmaps_out, size_t bitmap_words, uint64_t *counts_out);
+
+/* ---- the callers either side of the kernels ----
+ * PostFilter: filterItemsWithBulkPermissions (postfilter.go:58-182).  The K list items' resolved pairs are ONE bulk
+ * check; pairs [item_off[i], item_off[i+1]) belong to list item i (itemToRequestMap, postfilter.go:65,117-119);
+ * keep_out[i] = 1 iff all of them are HAS_PERMISSION without error (postfilter.go:152-178); an item without pairs
+ * is kept (postfilter.go:145-150).  The *_ids forms do the AND on the device and return K bytes. */
+int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
+int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
+int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);
+/* PreFilter: prefilterResult.IsAllowed (lookups.go:25-36; consumers responsefilterer.go:349-415) over the bitmap of
+ * acl_lookup_resources*: allowed_out[i] = 1 iff object_ids[i] (the rule's `ns/name` object id text) is set. */
+int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *const *object_ids, size_t n,
+                          uint8_t *allowed_out);
+/* Watch (watch.go:29-38): every update committed by acl_write / acl_delete_by_filter with revision > after_revision
+ * whose resource type is in `types` (ntypes == 0: all), in commit order; op = ACL_OP_TOUCH or ACL_OP_DELETE.
+ * after_revision == UINT64_MAX or cb == NULL only reports the head revision ("start from now").  *revision_out
+ * is the cursor for the next poll.  ACL_ERR_OUT_OF_RANGE when the cursor fell out of the retained feed. */
+typedef void (*acl_watch_cb)(void *user, uint64_t revision, int32_t op, const acl_relationship_t *rel);
+int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, int ntypes, acl_watch_cb cb, void *user, uint64_t *revision_out);
+/* Micro-batching front-end for the proxy's call shape -- many concurrent 1-item checks (check.go:76-94 one goroutine
+ * per check expression, watch.go:50 one per update).  acl_check_one blocks its caller; while a batcher runs,
+ * concurrent callers share ONE device pass (drained after at most max_wait_us or when max_items are waiting). */
+int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us);
+int acl_batcher_stop(acl_engine_t *h);
+int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items);
+int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out);
 
 /* ---- sharded graph: the north star's multi-GPU configuration ----
  * One engine per GPU holds the rows of the object types with fnv1a(type name) mod world == rank; the

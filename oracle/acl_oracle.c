@@ -36,6 +36,7 @@
  * the engine: own schema parser, own interner, own sorted tuple index.
  */
 #define _GNU_SOURCE
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -924,6 +925,56 @@ void orc_check_bulk_ids(orc_t *o, size_t n, int rtype, int perm, const uint32_t 
         out[i] = r == R_HAS ? ORC_PERM_HAS : (r == R_ERR ? ORC_PERM_UNSPEC : ORC_PERM_NO);
         if (err) err[i] = r == R_ERR ? ORC_ERR_DEPTH : 0;
     }
+}
+
+/* Same, split statically over `nthreads` host threads (the "all host cores" CPU baseline of SURVEY.md 8(d)).
+ * Every thread evaluates with a private shallow copy of the handle: the frozen tuple and type tables are only
+ * read, the per-call memo and the work counters are per thread. */
+typedef struct {
+    orc_t ctx;
+    size_t lo, hi;
+    int rtype, perm, stype, srel;
+    const uint32_t *res, *subj;
+    uint8_t *out;
+    int32_t *err;
+} mt_job_t;
+static void *mt_run(void *p) {
+    mt_job_t *j = (mt_job_t *)p;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        subject_t s = {j->stype, j->srel < 0 ? ELLIPSIS : (unsigned)j->srel, j->subj[i]};
+        memo_reset(&j->ctx);
+        int r = check_rel(&j->ctx, j->rtype, j->perm, j->res[i], &s, ORC_MAX_DEPTH);
+        j->out[i] = r == R_HAS ? ORC_PERM_HAS : (r == R_ERR ? ORC_PERM_UNSPEC : ORC_PERM_NO);
+        if (j->err) j->err[i] = r == R_ERR ? ORC_ERR_DEPTH : 0;
+    }
+    return NULL;
+}
+void orc_check_bulk_ids_mt(orc_t *o, int nthreads, size_t n, int rtype, int perm, const uint32_t *res, int stype, int srel, const uint32_t *subj,
+                           uint8_t *out, int32_t *err) {
+    ensure_sorted(o);
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n && n) nthreads = (int)n;
+    mt_job_t *jobs = calloc((size_t)nthreads, sizeof *jobs);
+    pthread_t *th = calloc((size_t)nthreads, sizeof *th);
+    for (int t = 0; t < nthreads; t++) {
+        mt_job_t *j = &jobs[t];
+        j->ctx = *o;
+        j->ctx.memo_k = NULL; j->ctx.memo_v = NULL; j->ctx.memo_cap = j->ctx.memo_n = 0;
+        j->ctx.lr_ids = NULL; j->ctx.lr_n = j->ctx.lr_cap = 0;
+        j->ctx.cnt_dispatch = j->ctx.cnt_rows = j->ctx.cnt_edges = 0;
+        j->lo = n * (size_t)t / (size_t)nthreads;
+        j->hi = n * (size_t)(t + 1) / (size_t)nthreads;
+        j->rtype = rtype; j->perm = perm; j->stype = stype; j->srel = srel;
+        j->res = res; j->subj = subj; j->out = out; j->err = err;
+        pthread_create(&th[t], NULL, mt_run, j);
+    }
+    o->cnt_dispatch = o->cnt_rows = o->cnt_edges = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        o->cnt_dispatch += jobs[t].ctx.cnt_dispatch; o->cnt_rows += jobs[t].ctx.cnt_rows; o->cnt_edges += jobs[t].ctx.cnt_edges;
+        free(jobs[t].ctx.memo_k); free(jobs[t].ctx.memo_v);
+    }
+    free(jobs); free(th);
 }
 
 /* LookupResources restated as its definition: { id : Check(T:id#p @ S) == HAS }

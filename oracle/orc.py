@@ -69,6 +69,7 @@ def lib():
         L.orc_read.argtypes = [C.c_void_p, C.POINTER(_Filter), _READ_CB, C.c_void_p]
         L.orc_check.argtypes = [C.c_void_p] + [C.c_char_p] * 6 + [C.POINTER(C.c_int)]
         L.orc_check_bulk_ids.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_check_bulk_ids_mt.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lookup_ids.restype = C.c_long
         L.orc_lookup_ids.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.orc_lookup.restype = C.c_long
@@ -229,6 +230,16 @@ class Oracle:
         err = np.zeros(res.size, dtype=np.int32)
         self._L.orc_check_bulk_ids(self._h, res.size, self.type_id(rtype), self.rel_id(rtype, perm), res.ctypes.data,
                                    self.type_id(stype), self.rel_id(stype, srel), subj.ctypes.data, out.ctypes.data, err.ctypes.data)
+        return out, err
+
+    def check_bulk_ids_mt(self, nthreads, rtype, perm, res, stype, srel, subj):
+        """Same answers as check_bulk_ids, the batch split statically over `nthreads` host threads."""
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        subj = np.ascontiguousarray(subj, dtype=np.uint32)
+        out = np.zeros(res.size, dtype=np.uint8)
+        err = np.zeros(res.size, dtype=np.int32)
+        self._L.orc_check_bulk_ids_mt(self._h, int(nthreads), res.size, self.type_id(rtype), self.rel_id(rtype, perm), res.ctypes.data,
+                                      self.type_id(stype), self.rel_id(stype, srel), subj.ctypes.data, out.ctypes.data, err.ctypes.data)
         return out, err
 
     def lookup_ids(self, rtype, perm, stype, srel, subj):

@@ -21,6 +21,8 @@ SYMBOLS = [
     "acl_shard_configure", "acl_shard_of_type", "acl_shard_grow_frontier", "acl_shard_check_begin", "acl_shard_check_step",
     "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
     "acl_shard_lookup_finish",
+    "acl_check_bulk_keep", "acl_check_bulk_keep_ids", "acl_check_bulk_keep_ids_device", "acl_bitmap_test_names", "acl_watch_poll",
+    "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one",
 ]
 
 
@@ -56,6 +58,7 @@ class ShardStep(C.Structure):
 
 
 READ_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Relationship))
+WATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(Relationship))
 
 _lib = None
 
@@ -116,6 +119,15 @@ def load():
     L.acl_stats.argtypes = [H, C.POINTER(Stats)]
     L.acl_stats_reset.argtypes = [H]
     L.acl_set_timing.argtypes = [H, C.c_int]
+    L.acl_check_bulk_keep.argtypes = [H, C.POINTER(CheckItem), C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_check_bulk_keep_ids.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_check_bulk_keep_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_bitmap_test_names.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_void_p]
+    L.acl_watch_poll.argtypes = [H, C.c_uint64, C.POINTER(C.c_int), C.c_int, WATCH_CB, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.acl_batcher_start.argtypes = [H, C.c_uint32, C.c_uint32]
+    L.acl_batcher_stop.argtypes = [H]
+    L.acl_batcher_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.acl_check_one.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]
     L.acl_shard_grow_frontier.argtypes = [H]

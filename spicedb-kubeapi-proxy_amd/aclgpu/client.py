@@ -211,6 +211,78 @@ class PermissionsServiceClient:
     LookupSubjects = ExpandPermissionTree = ExportBulkRelationships = ImportBulkRelationships = _unimplemented
 
 
+@dataclass
+class WatchUpdate:
+    operation: int = OPERATION_TOUCH
+    relationship: Relationship = field(default_factory=Relationship)
+
+
+@dataclass
+class WatchResponse:
+    updates: List[WatchUpdate] = field(default_factory=list)
+    changes_through: int = 0
+
+
+class WatchServiceClient:
+    """`v1.WatchServiceClient` mirror (proxy.Options.WatchClient, reference pkg/proxy/options.go:81; consumer
+    pkg/authz/watch.go:27-38).  Watch() starts at the head revision, like a Watch without a start cursor; every
+    call of the returned poller yields the WatchResponses committed since the previous one (one per revision)."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+    def Watch(self, optional_object_types=()):
+        from .engine import WATCH_FROM_NOW
+        types = list(optional_object_types)
+        _, cursor = self.engine.watch_poll(WATCH_FROM_NOW, types)
+        state = {"cursor": cursor}
+
+        def recv() -> List[WatchResponse]:
+            ups, nxt = self.engine.watch_poll(state["cursor"], types)
+            state["cursor"] = nxt
+            out: List[WatchResponse] = []
+            for rev, op, (rt, rid, rel, st, sid, srel) in ups:
+                if not out or out[-1].changes_through != rev:
+                    out.append(WatchResponse([], rev))
+                out[-1].updates.append(WatchUpdate(op, Relationship(ObjectReference(rt, rid), rel, SubjectReference(ObjectReference(st, sid), srel))))
+            return out
+
+        return recv
+
+
+def filter_items_with_bulk_permissions(client: PermissionsServiceClient, resolved: List[Optional[List[CheckPermissionRequest]]]) -> List[bool]:
+    """pkg/authz/postfilter.go:58-182 on the engine: `resolved[i]` holds list item i's resolved PostFilter checks
+    (None / [] when no template resolved -> the item is kept, postfilter.go:145-150).  One bulk check, keep mask back."""
+    items, off = [], [0]
+    for checks in resolved:
+        for c in checks or []:
+            items.append(_item_tuple(c))
+        off.append(len(items))
+    if not items:
+        return [True] * len(resolved)
+    return [bool(k) for k in client.engine.check_bulk_keep(items, off)]
+
+
+class PrefilterResult:
+    """prefilterResult of pkg/authz/lookups.go:25-36, backed by the LookupResources bitmap instead of a set of
+    NamespacedNames: IsAllowed(object id text) is one hash lookup + one bit test; filter() answers a whole kube list."""
+
+    def __init__(self, engine: Engine, resource_type: str, bitmap):
+        self.engine, self.resource_type, self.bitmap = engine, resource_type, bitmap
+
+    @classmethod
+    def run_lookup_resources(cls, engine: Engine, req: LookupResourcesRequest) -> "PrefilterResult":
+        bm, _ = engine.lookup_bitmap(req.resource_object_type, req.permission, req.subject.object.object_type, req.subject.object.object_id,
+                                     req.subject.optional_relation)
+        return cls(engine, req.resource_object_type, bm)
+
+    def filter(self, object_ids: List[str]) -> List[bool]:
+        return self.engine.bitmap_test_names(self.resource_type, self.bitmap, object_ids).tolist()
+
+    def is_allowed(self, object_id: str) -> bool:
+        return self.filter([object_id])[0]
+
+
 def is_allowed(pair: CheckBulkPermissionsPair) -> bool:
     """The reference's allow rule: no error and HAS_PERMISSION (pkg/authz/check.go:55-69)."""
     return pair.error is None and pair.item is not None and pair.item.permissionship == PERM_HAS

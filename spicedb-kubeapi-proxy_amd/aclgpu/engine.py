@@ -11,13 +11,15 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update
+from ._lib import CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
 
 PERM_UNSPECIFIED, PERM_NO, PERM_HAS, PERM_CONDITIONAL = 0, 1, 2, 3
 OP_CREATE, OP_TOUCH, OP_DELETE = 1, 2, 3
 PRE_MUST_NOT_MATCH, PRE_MUST_MATCH = 1, 2
 ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_ALREADY_EXISTS, ERR_RESOURCE_EXHAUSTED, ERR_FAILED_PRECONDITION = 3, 5, 6, 8, 9
 ERR_INTERNAL, ERR_UNAVAILABLE, ERR_DEPTH = 13, 14, 100
+ERR_OUT_OF_RANGE = 11
+WATCH_FROM_NOW = 0xFFFFFFFFFFFFFFFF
 NO_RELATION = 0xFFFF
 
 ITEM_DTYPE = np.dtype([("resource_type", "<u2"), ("permission", "<u2"), ("resource_id", "<u4"), ("subject_type", "<u2"),
@@ -210,6 +212,73 @@ class Engine:
     @property
     def stream(self) -> int:
         return self._L.acl_stream(self._h) or 0
+
+    # ---- callers either side of the kernels
+    def check_bulk_keep(self, items, item_off):
+        """filterItemsWithBulkPermissions (postfilter.go:58-182): items = all resolved pairs [(rt, rid, perm, st, sid, srel)],
+        pairs [item_off[i], item_off[i+1]) belong to list item i -> keep mask (uint8[K])."""
+        n = len(items)
+        arr = (CheckItem * max(1, n))()
+        for i, it in enumerate(items):
+            arr[i] = CheckItem(*[_b(x if x is not None else "") for x in it])
+        off = np.ascontiguousarray(item_off, dtype=np.uint32)
+        keep = np.zeros(max(1, off.size - 1), dtype=np.uint8)
+        self._check(self._L.acl_check_bulk_keep(self._h, arr, n, off.ctypes.data, off.size - 1, keep.ctypes.data))
+        return keep[:off.size - 1]
+
+    def check_bulk_keep_ids(self, items: np.ndarray, item_off):
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        off = np.ascontiguousarray(item_off, dtype=np.uint32)
+        keep = np.zeros(max(1, off.size - 1), dtype=np.uint8)
+        self._check(self._L.acl_check_bulk_keep_ids(self._h, items.ctypes.data, items.size, off.ctypes.data, off.size - 1, keep.ctypes.data))
+        return keep[:off.size - 1]
+
+    def check_bulk_keep_ids_device(self, d_items: int, n: int, d_item_off: int, k_items: int, d_keep: int):
+        self._check(self._L.acl_check_bulk_keep_ids_device(self._h, d_items, n, d_item_off, k_items, d_keep))
+
+    def bitmap_test_names(self, rtype: str, bitmap: np.ndarray, object_ids):
+        """prefilterResult.IsAllowed (lookups.go:25-36) over a LookupResources bitmap -> bool array."""
+        bm = np.ascontiguousarray(bitmap, dtype=np.uint32)
+        n = len(object_ids)
+        arr = (C.c_char_p * max(1, n))(*[_b(x) for x in object_ids])
+        out = np.zeros(max(1, n), dtype=np.uint8)
+        self._check(self._L.acl_bitmap_test_names(self._h, self.type_id(rtype), bm.ctypes.data, bm.size, arr, n, out.ctypes.data))
+        return out[:n].astype(bool)
+
+    def watch_poll(self, after_revision: int, types=()):
+        """-> (updates [(revision, op, (rt, rid, rel, st, sid, srel))], next cursor).  after_revision=WATCH_FROM_NOW: just the cursor."""
+        out = []
+
+        def cb(_u, rev, op, rp):
+            r = rp.contents
+            out.append((rev, op, (r.resource_type.decode(), r.resource_id.decode(), r.relation.decode(), r.subject_type.decode(),
+                                  r.subject_id.decode(), (r.subject_relation or b"").decode())))
+
+        tids = [self.type_id(t) for t in types]
+        if any(t < 0 for t in tids):
+            raise AclError(ERR_FAILED_PRECONDITION, "unknown object type in watch request")
+        arr = (C.c_int * max(1, len(tids)))(*tids)
+        cur = C.c_uint64()
+        self._check(self._L.acl_watch_poll(self._h, after_revision, arr, len(tids), WATCH_CB(cb), None, C.byref(cur)))
+        return out, cur.value
+
+    def batcher_start(self, max_items: int = 4096, max_wait_us: int = 200):
+        self._check(self._L.acl_batcher_start(self._h, max_items, max_wait_us))
+
+    def batcher_stop(self):
+        self._check(self._L.acl_batcher_stop(self._h))
+
+    def batcher_stats(self):
+        b, i = C.c_uint64(), C.c_uint64()
+        self._check(self._L.acl_batcher_stats(self._h, C.byref(b), C.byref(i)))
+        return {"batches": b.value, "items": i.value}
+
+    def check_one(self, rt, rid, perm, st, sid, srel=""):
+        """One CheckPermission (watch.go:50); rides the micro-batcher when it is running.  Blocks; releases the GIL."""
+        it = CheckItem(*[_b(x if x is not None else "") for x in (rt, rid, perm, st, sid, srel)])
+        p, e = C.c_uint8(), C.c_int32()
+        self._check(self._L.acl_check_one(self._h, C.byref(it), C.byref(p), C.byref(e)))
+        return p.value, e.value
 
     # ---- lookups
     def lookup_bitmap(self, rt, perm, st, sid, srel=""):

@@ -423,6 +423,17 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
     if (err_out) err_out[i] = e == ITEM_ERR_DEPTH ? 100 : (e == ITEM_ERR_INVALID ? 9 : 0);
 }
 
+// Post-filter hand-off (reference pkg/authz/postfilter.go:144-178): list item i owns the bulk-check pairs
+// [item_off[i], item_off[i+1]); it is kept iff every one of them is HAS_PERMISSION without error -- an item
+// with no pairs (templates that did not resolve, postfilter.go:92-95,145-150) is kept.
+__global__ __launch_bounds__(256) void k_keep(uint32_t k_items, const uint32_t *__restrict__ item_off, const uint8_t *__restrict__ perm, uint8_t *keep_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k_items) return;
+    bool all = true;
+    for (uint32_t j = item_off[i], e = item_off[i + 1]; j < e; j++) all = all && perm[j] == 2;  // PERMISSIONSHIP_HAS_PERMISSION
+    keep_out[i] = all ? 1 : 0;
+}
+
 // ----------------------------------------------------------- reverse expand
 // entry: x = object id, y = lookup request, z = meta (slot | dist << 13 | flags), w unused.
 // dist == 0 marks a seed entry: slot field holds the SUBJECT KEY and the program is rseeds[key].
@@ -615,6 +626,10 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
+}
+void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out) {
+    if (!k_items) return;
+    hipLaunchKernelGGL(k_keep, dim3((k_items + 255) / 256), dim3(256), 0, s, k_items, item_off, perm, keep_out);
 }
 void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase, const DevShard &sh) {
     const dim3 grid(f.nwaves / kWavesPerBlock);

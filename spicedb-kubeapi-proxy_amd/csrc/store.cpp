@@ -89,6 +89,8 @@ Status Store::load_schema(const std::string &text) {
         tables_[slot].assign(schema_.defs[t].members[m].classes.size(), ClassTable());
     }
     revision_++;
+    log_.clear();  // ids of the previous schema mean nothing now
+    log_floor_ = revision_;
     return Status::Ok();
 }
 
@@ -259,6 +261,8 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
         }
     }
     revision_++;
+    for (size_t i = 0; i < updates.size(); i++)
+        log_change(updates[i].op == ACL_OP_DELETE ? ACL_OP_DELETE : ACL_OP_TOUCH, rs[i].slot, rs[i].cls, (uint64_t)rs[i].res << 32 | rs[i].subj);
     if (revision) *revision = revision_;
     return Status::Ok();
 }
@@ -280,9 +284,49 @@ Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t
         ct.expiry.erase(h.key);
     }
     revision_++;
+    for (const Hit &h : hits) log_change(ACL_OP_DELETE, h.slot, h.cls, h.key);
     if (ndeleted) *ndeleted = hits.size();
     if (revision) *revision = revision_;
     return Status::Ok();
+}
+
+RelText Store::rel_text(int slot, int cls, uint64_t key) const {
+    auto [t, m] = schema_.slot_owner[slot];
+    const Member &mem = schema_.defs[t].members[m];
+    const SubjectClass &sc = mem.classes[cls];
+    RelText r;
+    r.rtype = schema_.defs[t].name;
+    const std::string *rn = objects_[t].name((uint32_t)(key >> 32));
+    r.rid = rn ? *rn : "#" + std::to_string((uint32_t)(key >> 32));
+    r.rel = mem.name;
+    r.stype = schema_.defs[sc.stype].name;
+    const std::string *sn = objects_[sc.stype].name((uint32_t)key);
+    r.sid = sn ? *sn : "#" + std::to_string((uint32_t)key);
+    r.srel = sc.srel == kNoRelation ? "" : schema_.defs[sc.stype].members[sc.srel].name;
+    return r;
+}
+
+void Store::log_change(int op, int slot, int cls, uint64_t key) {
+    if (log_.size() >= kLogCap) {
+        const size_t drop = log_.size() / 2;
+        log_floor_ = log_[drop - 1].revision;
+        // never split one revision's updates: drop the rest of that revision too
+        size_t d = drop;
+        while (d < log_.size() && log_[d].revision == log_floor_) d++;
+        log_.erase(log_.begin(), log_.begin() + (long)d);
+    }
+    log_.push_back(Change{revision_, op, slot, cls, key});
+}
+
+bool Store::changes_since(uint64_t after, const std::vector<int> &types, const std::function<void(const Change &, const RelText &)> &fn) const {
+    if (after < log_floor_) return false;
+    auto it = std::upper_bound(log_.begin(), log_.end(), after, [](uint64_t a, const Change &c) { return a < c.revision; });
+    for (; it != log_.end(); ++it) {
+        const int t = schema_.slot_owner[it->slot].first;
+        if (!types.empty() && std::find(types.begin(), types.end(), t) == types.end()) continue;
+        fn(*it, rel_text(it->slot, it->cls, it->key));
+    }
+    return true;
 }
 
 Status Store::read(const FilterText &f, const std::function<void(const RelText &)> &cb) {
@@ -290,18 +334,7 @@ Status Store::read(const FilterText &f, const std::function<void(const RelText &
     Status s = validate_filter(f);
     if (!s.ok()) return s;
     scan(f, now(), [&](int slot, int cls, uint64_t key) {
-        auto [t, m] = schema_.slot_owner[slot];
-        const Member &mem = schema_.defs[t].members[m];
-        const SubjectClass &sc = mem.classes[cls];
-        RelText r;
-        r.rtype = schema_.defs[t].name;
-        const std::string *rn = objects_[t].name((uint32_t)(key >> 32));
-        r.rid = rn ? *rn : "#" + std::to_string((uint32_t)(key >> 32));
-        r.rel = mem.name;
-        r.stype = schema_.defs[sc.stype].name;
-        const std::string *sn = objects_[sc.stype].name((uint32_t)key);
-        r.sid = sn ? *sn : "#" + std::to_string((uint32_t)key);
-        r.srel = sc.srel == kNoRelation ? "" : schema_.defs[sc.stype].members[sc.srel].name;
+        RelText r = rel_text(slot, cls, key);
         auto e = tables_[slot][cls].expiry.find(key);
         r.expires_at = e == tables_[slot][cls].expiry.end() ? 0 : e->second;
         cb(r);

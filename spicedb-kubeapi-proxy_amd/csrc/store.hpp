@@ -107,6 +107,19 @@ class Store {
 
     int class_index(int slot, int stype, int srel) const;
 
+    // ---- change feed (WatchService.Watch, reference pkg/authz/watch.go:29-38): every update committed through
+    // write() / delete_by_filter(), in commit order.  Bulk loads (bootstrap, add_edges) are not part of the feed.
+    struct Change {
+        uint64_t revision;
+        int32_t op;  // ACL_OP_TOUCH (created or touched) / ACL_OP_DELETE
+        int32_t slot, cls;
+        uint64_t key;  // res << 32 | subj
+    };
+    // calls fn for every change with revision > after whose RESOURCE type is in `types` (empty = all); returns false
+    // when `after` is older than the retained window
+    bool changes_since(uint64_t after, const std::vector<int> &types, const std::function<void(const Change &, const RelText &)> &fn) const;
+    RelText rel_text(int slot, int cls, uint64_t key) const;
+
   private:
     struct Resolved {
         int slot, cls, rtype, stype;
@@ -124,6 +137,10 @@ class Store {
     std::vector<std::vector<ClassTable>> tables_;
     uint64_t revision_ = 1;
     int64_t now_override_ = 0;
+    std::vector<Change> log_;       // bounded: the oldest half is dropped when it reaches kLogCap
+    uint64_t log_floor_ = 0;        // changes with revision <= log_floor_ may have been dropped
+    void log_change(int op, int slot, int cls, uint64_t key);
+    static constexpr size_t kLogCap = 1u << 20;
 };
 
 bool parse_relationship_text(const std::string &line, RelText *out);

@@ -1,0 +1,142 @@
+"""GPU tests of the callers either side of the kernels: the PostFilter keep mask
+(pkg/authz/postfilter.go:58-182), the PreFilter IsAllowed over the LookupResources bitmap (lookups.go:25-36),
+the micro-batching front-end for concurrent single checks (check.go:76-94) and the Watch -> re-check loop
+(watch.go:27-111).  Expected answers come from the CPU oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests import kat_runner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aclgpu(aclgpu_lib):
+    import aclgpu as m
+    return m
+
+
+def test_postfilter_keep_mask(aclgpu):
+    """K list items x ragged PostFilter pairs -> keep mask, ids path (AND on the device) and strings path; equals the
+    reference's rule applied to the oracle's per-pair answers."""
+    from aclgpu import workloads
+    w = workloads.c2(scale=0.05, batch=6000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rng = np.random.default_rng(5)
+    K = 2000
+    nper = rng.integers(0, 4, size=K)  # 0..3 pairs per list item (0 = no template resolved -> kept)
+    off = np.concatenate([[0], np.cumsum(nper)]).astype(np.uint32)
+    n = int(off[-1])
+    res, subj = w.res[:n].copy(), w.subj[:n].copy()
+    operm, oerr = o.check_bulk_ids("pod", "view", res, "user", "", subj)
+    want = np.array([all(operm[j] == 2 and oerr[j] == 0 for j in range(off[i], off[i + 1])) for i in range(K)])
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        items = e.make_items("pod", "view", res, "user", "", subj)
+        keep = e.check_bulk_keep_ids(items, off)
+        assert np.array_equal(keep.astype(bool), want)
+        assert 0 < want.sum() < K
+        # an invalid pair (unknown permission index) is a pair error -> its item is dropped
+        bad = items.copy()
+        victim = int(np.flatnonzero((nper > 0) & want)[0])
+        bad["permission"][off[victim]] = 99
+        keep2 = e.check_bulk_keep_ids(bad, off)
+        assert not keep2[victim] and np.array_equal(np.delete(keep2, victim), np.delete(keep, victim))
+        with pytest.raises(aclgpu.AclError):
+            e.check_bulk_keep_ids(items, [0, n + 1])
+
+
+def test_postfilter_and_prefilter_mirror(aclgpu):
+    """The e2e shape (proxy_test.go:474-531): paul's pods are kept, chani's dropped; items whose template did not
+    resolve are kept; prefilter bitmap answers IsAllowed for `ns/name` ids, unknown names are not allowed."""
+    from aclgpu import client as v1
+    b = kat_runner.load_bootstrap()
+    with aclgpu.Engine(b["schema"], "\n".join(b["relationships"])) as e:
+        c = v1.PermissionsServiceClient(e)
+        mk = lambda pod, u: v1.RelationshipUpdate(v1.OPERATION_TOUCH, v1.Relationship(v1.ObjectReference("pod", pod), "creator",  # noqa: E731
+                                                                                       v1.SubjectReference(v1.ObjectReference("user", u))))
+        c.WriteRelationships([mk("ns/p1", "paul"), mk("ns/p2", "chani"), mk("ns/p3", "paul"), mk("other/p1", "paul")])
+        chk = lambda pod, perm="view": v1.CheckPermissionRequest(v1.ObjectReference("pod", pod), perm,  # noqa: E731
+                                                                   v1.SubjectReference(v1.ObjectReference("user", "paul")))
+        resolved = [[chk("ns/p1")], [chk("ns/p2")], [chk("ns/p3"), chk("ns/p3", "edit")], None, [chk("ns/p2"), chk("ns/p1")], [], [chk("ns/unknown")]]
+        assert v1.filter_items_with_bulk_permissions(c, resolved) == [True, False, True, True, False, True, False]
+        pre = v1.PrefilterResult.run_lookup_resources(e, v1.LookupResourcesRequest("pod", "view", v1.SubjectReference(v1.ObjectReference("user", "paul"))))
+        assert pre.filter(["ns/p1", "ns/p2", "ns/p3", "other/p1", "nope/nope"]) == [True, False, True, True, False]
+        assert pre.is_allowed("ns/p3") and not pre.is_allowed("ns/p2")
+
+
+def test_micro_batcher_concurrent_single_checks(aclgpu):
+    """64 threads x 40 single checks each: every answer equals the oracle's, and the batcher needed far fewer device
+    passes than there were calls."""
+    from aclgpu import workloads
+    w = workloads.c1()
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    names = lambda t, n: [f"{t}-{i}" for i in range(n)]  # noqa: E731
+    with aclgpu.Engine(w.schema) as e:
+        # string ids so that acl_check_one has something to intern: object i is named "<type>-<i>"
+        for t, n in w.nobjects.items():
+            for nm in names(t, n):
+                e.intern(t, nm)
+        w.load(e)
+        T, PER = 64, 40
+        rng = np.random.default_rng(3)
+        res = rng.integers(0, w.nobjects["namespace"], size=(T, PER))
+        sub = rng.integers(0, w.nobjects["user"], size=(T, PER))
+        res[:, ::2] = w.res[rng.integers(0, w.res.size, size=(T, PER // 2))]  # half the stream are known hits' resources
+        want, _ = o.check_bulk_ids("namespace", "view", res.reshape(-1), "user", "", sub.reshape(-1))
+        got = np.zeros((T, PER), dtype=np.uint8)
+        errs = []
+        e.batcher_start(max_items=1024, max_wait_us=300)
+        passes0 = e.stats()["check_passes"]
+
+        def worker(t):
+            try:
+                for k in range(PER):
+                    p, er = e.check_one("namespace", f"namespace-{res[t, k]}", "view", "user", f"user-{sub[t, k]}")
+                    assert er == 0
+                    got[t, k] = p
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errs, errs[:1]
+        st = e.batcher_stats()
+        passes = e.stats()["check_passes"] - passes0
+        e.batcher_stop()
+        assert np.array_equal(got.reshape(-1), want)
+        assert st["items"] == T * PER and passes == st["batches"] and st["batches"] < T * PER / 4, st
+        # without the batcher a single check still works (a device pass of its own)
+        assert e.check_one("namespace", f"namespace-{res[0, 0]}", "view", "user", f"user-{sub[0, 0]}")[0] == want[0]
+        assert e.check_one("", "x", "view", "user", "u") == (0, aclgpu.ERR_INVALID_ARGUMENT)
+
+
+def test_watch_then_recheck(aclgpu):
+    """RunWatch (watch.go:27-111): per update of the watched type, ONE check of (updated resource, the request's
+    subject) decides allowed/denied -- here the polled updates are re-checked as one batch."""
+    from aclgpu import client as v1
+    b = kat_runner.load_bootstrap()
+    with aclgpu.Engine(b["schema"], "\n".join(b["relationships"])) as e:
+        c, w = v1.PermissionsServiceClient(e), v1.WatchServiceClient(e)
+        recv = w.Watch(["pod"])
+        mk = lambda op, pod, rel, u: v1.RelationshipUpdate(op, v1.Relationship(v1.ObjectReference("pod", pod), rel,  # noqa: E731
+                                                                                v1.SubjectReference(v1.ObjectReference("user", u))))
+        c.WriteRelationships([mk(v1.OPERATION_CREATE, "ns/a", "creator", "paul"), mk(v1.OPERATION_CREATE, "ns/b", "viewer", "chani")])
+        c.WriteRelationships([mk(v1.OPERATION_DELETE, "ns/a", "creator", "paul"), mk(v1.OPERATION_TOUCH, "ns/c", "viewer", "paul")])
+        events = []
+        for resp in recv():
+            reqs = [v1.CheckPermissionRequest(v1.ObjectReference("pod", u.relationship.resource.object_id), "view",
+                                              v1.SubjectReference(v1.ObjectReference("user", "paul"))) for u in resp.updates]
+            pairs = c.CheckBulkPermissions(reqs).pairs
+            events += [(u.relationship.resource.object_id, v1.is_allowed(p)) for u, p in zip(resp.updates, pairs)]
+        # fully consistent reads: every re-check sees the LATEST state (ns/a's creator is already gone)
+        assert events == [("ns/a", False), ("ns/b", False), ("ns/a", False), ("ns/c", True)]

@@ -107,3 +107,52 @@ def test_bulk_edges_and_text_agree(aclgpu_lib):
     got = sorted((r[1], r[4]) for r in e.read(rtype="doc"))
     assert got == [("#1", "#2"), ("#1", "#9"), ("#3", "#7")]  # anonymous ids print as #n; duplicates collapse (TOUCH)
     assert e.object_count("doc") == 4 and e.object_count("user") == 10
+
+
+def test_watch_feed(aclgpu_lib):
+    """Change feed behind WatchService.Watch (pkg/authz/watch.go:29-38): commit order, type filter, cursor, and the
+    client mirror that groups updates per revision."""
+    import aclgpu
+    from aclgpu import client as v1
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    ups, cur = e.watch_poll(aclgpu.WATCH_FROM_NOW)
+    assert ups == [] and cur == e.revision  # bootstrap relationships are not part of the feed
+    w = v1.WatchServiceClient(e)
+    recv_pods, recv_all = w.Watch(["pod"]), w.Watch()
+    c = v1.PermissionsServiceClient(e)
+    rel = lambda t, i, r, u: v1.Relationship(v1.ObjectReference(t, i), r, v1.SubjectReference(v1.ObjectReference("user", u)))  # noqa: E731
+    c.WriteRelationships([v1.RelationshipUpdate(v1.OPERATION_CREATE, rel("pod", "ns/p1", "creator", "paul")),
+                          v1.RelationshipUpdate(v1.OPERATION_TOUCH, rel("namespace", "ns", "creator", "paul"))])
+    c.WriteRelationships([v1.RelationshipUpdate(v1.OPERATION_DELETE, rel("pod", "ns/p1", "creator", "paul")),
+                          v1.RelationshipUpdate(v1.OPERATION_CREATE, rel("pod", "ns/p1", "creator", "chani"))])
+    got = recv_pods()
+    assert [len(r.updates) for r in got] == [1, 2] and got[0].changes_through < got[1].changes_through
+    assert [(u.operation, u.relationship.resource.object_id, u.relationship.subject.object.object_id) for r in got for u in r.updates] == [
+        (v1.OPERATION_TOUCH, "ns/p1", "paul"), (v1.OPERATION_DELETE, "ns/p1", "paul"), (v1.OPERATION_TOUCH, "ns/p1", "chani")]
+    assert recv_pods() == []  # nothing new
+    assert sum(len(r.updates) for r in recv_all()) == 4
+    assert c.DeleteRelationships(v1.RelationshipFilter("pod", "ns/p1")).relationships_deleted_count == 1
+    (r,) = recv_pods()
+    assert [(u.operation, u.relationship.subject.object.object_id) for u in r.updates] == [(v1.OPERATION_DELETE, "chani")]
+    with pytest.raises(aclgpu.AclError):
+        e.watch_poll(0, ["nosuchtype"])
+    e.load_bootstrap(b["schema"])  # a new schema invalidates old cursors
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.watch_poll(cur)
+    assert ei.value.code == aclgpu.ERR_OUT_OF_RANGE
+    e.close()
+
+
+def test_keep_and_check_one_need_a_gpu(aclgpu_lib):
+    import aclgpu
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], store_only=True)
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.check_bulk_keep([("namespace", "a", "view", "user", "u", "")], [0, 1])
+    assert ei.value.code == aclgpu.ERR_UNAVAILABLE
+    with pytest.raises(aclgpu.AclError):
+        e.check_one("namespace", "a", "view", "user", "u")
+    # an empty request never reaches the device: the pair carries InvalidArgument (options_test.go:101-102)
+    assert e.check_one("", "", "", "", "") == (0, aclgpu.ERR_INVALID_ARGUMENT)
+    e.close()
