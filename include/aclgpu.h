@@ -215,6 +215,12 @@ int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entrie
 /* n rows of bitmap_words words: the resource type's owner returns the result bits, every other shard zeros */
 int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_words);
 
+/* ---- test hook ----
+ * Updates the HOST copy of the snapshot the way the next read would (in-place patch from the change feed when
+ * possible, rebuild otherwise) and verifies it against the relationship store: every live relationship findable,
+ * nothing dead left, rows sorted, no unsound leaf flag.  Store-only engines only (it never touches a device). */
+int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out);
+
 /* ---- measurement ---- */
 typedef struct {
     uint64_t check_items;      /* items answered since open / last reset */
@@ -229,6 +235,7 @@ typedef struct {
     uint64_t snapshot_builds;
     uint64_t overflow_retries;
     uint64_t snapshot_edges_local; /* relationships whose rows THIS engine holds (== snapshot_edges unless sharded) */
+    uint64_t snapshot_patches;     /* times committed writes were patched into the HBM snapshot in place (no rebuild) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

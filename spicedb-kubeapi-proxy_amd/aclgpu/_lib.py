@@ -22,7 +22,7 @@ SYMBOLS = [
     "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
     "acl_shard_lookup_finish",
     "acl_check_bulk_keep", "acl_check_bulk_keep_ids", "acl_check_bulk_keep_ids_device", "acl_bitmap_test_names", "acl_watch_poll",
-    "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one",
+    "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_selfcheck_snapshot",
 ]
 
 
@@ -50,7 +50,7 @@ class CheckItem(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("check_items", C.c_uint64), ("check_passes", C.c_uint64), ("expand_launches", C.c_uint64), ("levels_last", C.c_uint64),
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
-                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64)]
+                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64)]
 
 
 class ShardStep(C.Structure):
@@ -128,6 +128,7 @@ def load():
     L.acl_batcher_stop.argtypes = [H]
     L.acl_batcher_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_check_one.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+    L.acl_selfcheck_snapshot.argtypes = [H, C.POINTER(C.c_int)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]
     L.acl_shard_grow_frontier.argtypes = [H]

@@ -308,6 +308,12 @@ class Engine:
         bms, _ = self.lookup_ids_batch(rtype, perm, stype, srel, [subject_id])
         return np.flatnonzero(np.unpackbits(bms[0].view(np.uint8), bitorder="little")).astype(np.uint32)
 
+    def selfcheck_snapshot(self) -> bool:
+        """Test hook (store-only engines): update + verify the host snapshot; True when the update was an in-place patch."""
+        p = C.c_int()
+        self._check(self._L.acl_selfcheck_snapshot(self._h, C.byref(p)))
+        return bool(p.value)
+
     # ---- measurement
     def stats(self) -> dict:
         s = Stats()

@@ -60,9 +60,16 @@ struct DevArray {
         return e;
     }
     hipError_t upload(const std::vector<T> &v, hipStream_t s) {
-        hipError_t e = ensure(v.size());
+        // headroom: snapshot arrays grow when writes are patched in (plan.cpp patch_forward)
+        hipError_t e = (p && v.size() <= n) ? hipSuccess : ensure(v.size() + v.size() / 4 + 16384);
         if (e != hipSuccess) return e;
         return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    // re-uploads elements [off, off + cnt) of v; false when v outgrew the allocation
+    bool patch(const std::vector<T> &v, size_t off, size_t cnt, hipStream_t s, hipError_t *err) {
+        if (!p || v.size() > n) return false;
+        *err = hipMemcpyAsync(p + off, v.data() + off, cnt * sizeof(T), hipMemcpyHostToDevice, s);
+        return true;
     }
 };
 
@@ -196,6 +203,38 @@ int ensure_snapshot(acl_engine *h) {
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     const int64_t now = h->store.now();
     if (h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi) return ACL_OK;
+    // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
+    if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi && h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
+        std::vector<Patch> patches;
+        if (patch_forward(h->store, now, &h->snap, h->shard, &patches)) {
+            HIP_TRY(hipStreamSynchronize(h->stream));  // nothing may still be reading the rows we overwrite
+            bool fits = true;
+            hipError_t pe = hipSuccess;
+            for (const Patch &p : patches) {
+                hipError_t e1 = hipSuccess;
+                switch (p.array) {
+                    case Patch::META: fits = fits && h->d_meta.patch(h->snap.meta, p.off, p.n, h->stream, &e1); break;
+                    case Patch::EDGES: fits = fits && h->d_edges.patch(h->snap.edges, p.off, p.n, h->stream, &e1); break;
+                    case Patch::BUCKETS: fits = fits && h->d_buckets.patch(h->snap.buckets, p.off, p.n, h->stream, &e1); break;
+                    case Patch::OPS: fits = fits && h->d_ops.patch(h->snap.ops, p.off, p.n, h->stream, &e1); break;
+                }
+                if (e1 != hipSuccess) pe = e1;
+            }
+            if (pe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("snapshot patch upload: ") + hipGetErrorString(pe));
+            if (!fits) {  // an array outgrew its device allocation: the host copy is already exact, upload it whole
+                HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
+                HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
+                HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
+                HIP_TRY(h->d_ops.upload(h->snap.ops, h->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->rev_uploaded = false;
+            h->stats.snapshot_patches++;
+            h->stats.snapshot_edges = h->snap.nedges;
+            h->stats.snapshot_edges_local = h->snap.nedges_local;
+            return ACL_OK;
+        }
+    }
     build_forward(h->store, now, &h->snap, h->shard);
     HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
     HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
@@ -722,7 +761,10 @@ int acl_stats(acl_engine_t *h, acl_stats_t *out) {
 int acl_stats_reset(acl_engine_t *h) {
     std::lock_guard<std::mutex> lk(h->mu);
     uint64_t e = h->stats.snapshot_edges, b = h->stats.snapshot_bytes, el = h->stats.snapshot_edges_local;
+    uint64_t sb = h->stats.snapshot_builds, sp = h->stats.snapshot_patches;
     h->stats = acl_stats_t{};
+    h->stats.snapshot_builds = sb;
+    h->stats.snapshot_patches = sp;
     h->stats.snapshot_edges_local = el;
     h->stats.snapshot_edges = e;
     h->stats.snapshot_bytes = b;
@@ -1030,6 +1072,33 @@ int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, i
         cb(user, c.revision, c.op, &o);
     });
     return ok ? ACL_OK : fail(ACL_ERR_OUT_OF_RANGE, "acl_watch_poll: cursor is older than the retained change feed");
+}
+
+// Test hook: brings the HOST snapshot up to date exactly as a read would (patch if possible, else rebuild) -- without
+// touching a device, so it also works on a store-only engine -- and verifies it against the store.
+// *patched_out = 1 when the update was a patch, 0 when it was a (re)build.
+int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    if (!h->store_only) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_snapshot drives the host snapshot itself: use a store-only engine");
+    const int64_t now = h->store.now();
+    std::vector<Patch> patches;
+    bool patched = false;
+    const bool current = h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi;
+    if (!current) {
+        if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi) patched = patch_forward(h->store, now, &h->snap, h->shard, &patches);
+        if (!patched) build_forward(h->store, now, &h->snap, h->shard);
+        h->snap_valid = true;
+    }
+    for (const Patch &p : patches) {  // every patch region must lie inside its array
+        const size_t sz = p.array == Patch::META ? h->snap.meta.size() : p.array == Patch::EDGES ? h->snap.edges.size()
+                        : p.array == Patch::BUCKETS ? h->snap.buckets.size() : h->snap.ops.size();
+        if (p.off + p.n > sz) return fail(ACL_ERR_INTERNAL, "patch region outside its array");
+    }
+    if (patched_out) *patched_out = patched ? 1 : 0;
+    std::string why;
+    if (!verify_snapshot(h->store, now, h->snap, h->shard, &why)) return fail(ACL_ERR_INTERNAL, "snapshot does not match the store: " + why);
+    return ACL_OK;
 }
 
 // ---- micro-batching front-end: the proxy issues many concurrent 1-item checks (check.go:76-94: one goroutine per

@@ -10,17 +10,8 @@ namespace {
 constexpr uint32_t kMaxOpsPerSlot = 256;
 constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
-struct ClassLayout {
-    bool live = false;    // >= 1 live relationship in this snapshot
-    bool hashed = false;  // membership-only class: subject-indexed hashed rows
-    uint32_t ks = 0;      // sorted-class index inside the relation's row descriptors
-    uint32_t smeta_base = 0, nsubjects = 0;  // hashed: per-subject descriptors (uint2 units) and their count
-};
-struct RelLayout {
-    uint32_t meta_base = 0, nrows = 0, Ks = 0;  // meta_base in uint2 units
-    std::vector<ClassLayout> cls;
-};
-
+// tables are sized for objects that do not exist yet, so that writes naming new objects can be patched in
+inline uint32_t with_headroom(uint32_t n) { return n + n / 4 + 1024; }
 inline uint32_t hash_bucket(uint32_t v, uint32_t nb) { return (uint32_t)(((uint64_t)(v * 0x9E3779B1u) * nb) >> 32); }
 inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }  // load <= 0.75 (<= 1.0 for a single bucket)
 
@@ -160,7 +151,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         const Member &mem = sc.defs[t].members[m];
         if (mem.is_permission) continue;
         RelLayout &l = lay[slot];
-        l.nrows = store.objects(t).count();
+        l.nrows = with_headroom(store.objects(t).count());
         l.cls.resize(mem.classes.size());
         if (s.type_owner[t] != shard.rank) continue;  // another shard holds this type's rows
         for (const ClassTable &ct : tables[slot]) s.nedges_local += ct.keys.size();
@@ -180,7 +171,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             if (!c.live || !c.hashed) continue;
             const ClassTable &ct = tables[slot][k];
             const bool filt = !ct.expiry.empty();
-            const uint32_t ns = store.objects(mem.classes[k].stype).count();
+            const uint32_t ns = with_headroom(store.objects(mem.classes[k].stype).count());
             c.nsubjects = ns;
             c.smeta_base = (uint32_t)(s.meta.size() / 2);
             s.meta.resize(s.meta.size() + 2 * (size_t)ns, 0);
@@ -297,7 +288,288 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             }
         }
     }
+    s.lay = std::move(lay);
     *snap = std::move(s);
+}
+
+
+// ---------------------------------------------------------------------------------------------- patching
+namespace {
+
+constexpr size_t kMaxPatchChanges = 8192;  // beyond this a rebuild is cheaper than row-by-row patching
+
+struct Patcher {
+    Store &store;
+    Snapshot &s;
+    std::vector<Patch> &out;
+    bool ops_dirty = false;
+
+    // ---- hashed rows (subject-indexed): row of `sid` holds resource ids
+    uint32_t *hdesc(const ClassLayout &c, uint32_t sid) { return s.meta.data() + 2 * ((size_t)c.smeta_base + sid); }
+    bool hashed_has(const ClassLayout &c, uint32_t sid, uint32_t res) {
+        const uint32_t *md = hdesc(c, sid);
+        const uint32_t nb = md[1] - md[0];
+        if (!nb) return false;
+        const uint32_t *row = s.buckets.data() + 4 * (size_t)md[0];
+        uint32_t b = hash_bucket(res, nb);
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint32_t *q = row + 4 * (size_t)b;
+            bool empty = false;
+            for (int k = 0; k < 4; k++) {
+                if (q[k] == res) return true;
+                if (q[k] == 0xFFFFFFFFu) empty = true;
+            }
+            if (empty) return false;
+            b = b + 1 == nb ? 0 : b + 1;
+        }
+        return false;
+    }
+    static void hashed_insert(uint32_t *row, uint32_t nb, uint32_t res) {
+        uint32_t bi = hash_bucket(res, nb);
+        for (;;) {
+            uint32_t *q = row + 4 * (size_t)bi;
+            int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
+            if (f >= 0) { q[f] = res; return; }
+            bi = bi + 1 == nb ? 0 : bi + 1;
+        }
+    }
+    // re-hashes the whole row of `sid` with `res` added or removed: no deletion holes, same placement rule as the build
+    void hashed_set(const ClassLayout &c, uint32_t sid, uint32_t res, bool add) {
+        uint32_t *md = hdesc(c, sid);
+        const uint32_t b0 = md[0], nb = md[1] - md[0];
+        std::vector<uint32_t> el;
+        for (size_t i = 4 * (size_t)b0; i < 4 * (size_t)(b0 + nb); i++)
+            if (s.buckets[i] != 0xFFFFFFFFu && (add || s.buckets[i] != res)) el.push_back(s.buckets[i]);
+        if (add) el.push_back(res);
+        const uint32_t need = el.empty() ? 0u : buckets_for((uint32_t)el.size());
+        if (need <= nb) {  // fits where it is (an emptied row keeps its space for the next insert)
+            std::fill(s.buckets.begin() + 4 * (long)b0, s.buckets.begin() + 4 * (long)(b0 + nb), 0xFFFFFFFFu);
+            for (uint32_t r : el) hashed_insert(s.buckets.data() + 4 * (size_t)b0, nb, r);
+            if (nb) out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)b0, 4 * (size_t)nb});
+            return;
+        }
+        const uint32_t nb2 = buckets_for((uint32_t)(el.size() + el.size() / 2 + 1));  // room to grow before the next move
+        const uint32_t nb0 = (uint32_t)(s.buckets.size() / 4);
+        s.buckets.resize(s.buckets.size() + 4 * (size_t)nb2, 0xFFFFFFFFu);
+        for (uint32_t r : el) hashed_insert(s.buckets.data() + 4 * (size_t)nb0, nb2, r);
+        md = hdesc(c, sid);
+        md[0] = nb0;
+        md[1] = nb0 + nb2;
+        s.garbage_words += 4 * (uint64_t)nb;
+        out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)nb0, 4 * (size_t)nb2});
+        out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+    }
+
+    // ---- sorted rows: row of (res, class) holds subject ids ascending (| leaf flag)
+    uint32_t *sdesc(const RelLayout &l, const ClassLayout &c, uint32_t res) { return s.meta.data() + 2 * ((size_t)l.meta_base + (size_t)res * l.Ks + c.ks); }
+    bool sorted_find(const uint32_t *md, uint32_t sid, uint32_t *pos) {
+        uint32_t lo = md[0], hi = md[1];
+        while (lo < hi) {
+            uint32_t mid = (lo + hi) >> 1;
+            if ((s.edges[mid] & kIdMask) < sid) lo = mid + 1;
+            else hi = mid;
+        }
+        *pos = lo;
+        return lo < md[1] && (s.edges[lo] & kIdMask) == sid;
+    }
+    bool row_nonempty(const FwdOp &op, uint32_t id) const {
+        if (id >= op.nrows) return false;
+        const uint32_t *md = s.meta.data() + 2 * ((size_t)op.base + (size_t)id * op.K + op.k);
+        return md[1] > md[0];
+    }
+    // leaf flag of a new userset edge -> child (target slot, child id): nothing left to enumerate there
+    bool child_is_leaf(uint32_t target_slot, uint32_t child) const {
+        const SlotProg &tp = s.progs[target_slot];
+        for (uint32_t j = tp.n_probe; j < tp.n_main; j++) {
+            const FwdOp &op = s.ops[tp.first + j];
+            if (op.flags & OP_PUSH_SAME) return false;
+            if ((op.flags & OP_ENUM) && row_nonempty(op, child)) return false;
+        }
+        return true;
+    }
+    // an object of type t got its first enumerable row: edges elsewhere may still flag it as a leaf.  Leaf flags are
+    // an optimisation; switch their authority off for every op whose children are of type t (the kernel then looks
+    // at the child's rows, which are exact) until the next rebuild recomputes them.
+    void distrust_leaf_flags(int t) {
+        const Schema &sc = store.schema();
+        for (FwdOp &op : s.ops)
+            if ((op.flags & OP_ENUM) && (op.flags & OP_LEAFBIT) && sc.slot_owner[op.key].first == t) {
+                op.flags &= ~(uint32_t)OP_LEAFBIT;
+                ops_dirty = true;
+            }
+    }
+    void sorted_add(int slot, int cls, const RelLayout &l, const ClassLayout &c, uint32_t res, uint32_t sid) {
+        const Schema &sc = store.schema();
+        auto [t, m] = sc.slot_owner[slot];
+        const SubjectClass &k = sc.defs[t].members[m].classes[cls];
+        uint32_t *md = sdesc(l, c, res);
+        uint32_t pos;
+        sorted_find(md, sid, &pos);
+        const uint32_t a = md[0], b = md[1];
+        uint32_t edge = sid;
+        if (k.srel != kNoRelation && s.type_owner[k.stype] == s.type_owner[t] && child_is_leaf((uint32_t)sc.slot(k.stype, k.srel), sid)) edge |= kLeafBit;
+        const uint32_t start = (uint32_t)s.edges.size();
+        std::vector<uint32_t> row(s.edges.begin() + a, s.edges.begin() + b);  // (copy first: the append may reallocate)
+        row.insert(row.begin() + (pos - a), edge);
+        s.edges.insert(s.edges.end(), row.begin(), row.end());
+        md = sdesc(l, c, res);
+        md[0] = start;
+        md[1] = (uint32_t)s.edges.size();
+        s.garbage_words += b - a;
+        out.push_back(Patch{Patch::EDGES, start, (size_t)(md[1] - start)});
+        out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+        if (a == b) distrust_leaf_flags(t);  // `res` may just have stopped being a leaf
+    }
+    void sorted_remove(const RelLayout &l, const ClassLayout &c, uint32_t res, uint32_t sid) {
+        uint32_t *md = sdesc(l, c, res);
+        uint32_t pos;
+        if (!sorted_find(md, sid, &pos)) return;
+        std::copy(s.edges.begin() + pos + 1, s.edges.begin() + md[1], s.edges.begin() + pos);
+        md[1]--;
+        s.garbage_words++;
+        if (md[1] > md[0]) out.push_back(Patch{Patch::EDGES, md[0], (size_t)(md[1] - md[0])});
+        out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+        // a row that became empty leaves stale NON-leaf flags behind: harmless (one wasted frontier entry)
+    }
+};
+
+}  // namespace
+
+bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches) {
+    Snapshot &s = *snap;
+    if (s.lay.empty()) return false;
+    std::vector<Store::Change> ch;
+    if (!store.raw_changes_since(s.revision, &ch) || ch.size() > kMaxPatchChanges) return false;
+    store.settle_all();
+    const Schema &sc = store.schema();
+    // objects created since the build must fit the headroom of every table they index
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        auto [t, m] = sc.slot_owner[slot];
+        const Member &mem = sc.defs[t].members[m];
+        if (mem.is_permission || s.type_owner[t] != shard.rank) continue;
+        const RelLayout &l = s.lay[slot];
+        if (store.objects(t).count() > l.nrows) return false;
+        for (size_t k = 0; k < mem.classes.size(); k++)
+            if (l.cls[k].live && l.cls[k].hashed && store.objects(mem.classes[k].stype).count() > l.cls[k].nsubjects) return false;
+    }
+    std::sort(ch.begin(), ch.end(), [](const Store::Change &a, const Store::Change &b) {
+        return a.slot != b.slot ? a.slot < b.slot : a.cls != b.cls ? a.cls < b.cls : a.key < b.key;
+    });
+    auto &tables = store.tables();
+    Patcher P{store, s, *patches};
+    // first pass: can everything be expressed as a patch?  (nothing is modified before we know)
+    for (const Store::Change &c : ch) {
+        const int t = sc.slot_owner[c.slot].first;
+        if (s.type_owner[t] != shard.rank) continue;
+        const ClassTable &ct = tables[c.slot][c.cls];
+        if (!s.lay[c.slot].cls[c.cls].live && ct.contains(c.key) && store.live(ct, c.key, now)) return false;  // the class has no program op yet
+    }
+    for (size_t i = 0; i < ch.size(); i++) {
+        const Store::Change &c = ch[i];
+        if (i && ch[i - 1].slot == c.slot && ch[i - 1].cls == c.cls && ch[i - 1].key == c.key) continue;  // net effect per relationship
+        const int t = sc.slot_owner[c.slot].first;
+        if (s.type_owner[t] != shard.rank) continue;
+        const RelLayout &l = s.lay[c.slot];
+        const ClassLayout &cl = l.cls[c.cls];
+        if (!cl.live) continue;  // deletions in a class that was already empty
+        const ClassTable &ct = tables[c.slot][c.cls];
+        const bool want = ct.contains(c.key) && store.live(ct, c.key, now);
+        const uint32_t res = (uint32_t)(c.key >> 32), sid = (uint32_t)c.key;
+        if (cl.hashed) {
+            if (want != P.hashed_has(cl, sid, res)) {
+                P.hashed_set(cl, sid, res, want);
+                s.patched++;
+            }
+        } else {
+            uint32_t pos;
+            const bool have = P.sorted_find(P.sdesc(l, cl, res), sid, &pos);
+            if (want && !have) P.sorted_add(c.slot, c.cls, l, cl, res, sid);
+            else if (!want && have) P.sorted_remove(l, cl, res, sid);
+            if (want != have) s.patched++;
+        }
+    }
+    if (P.ops_dirty) patches->push_back(Patch{Patch::OPS, 0, s.ops.size()});
+    store.expiry_window(now, &s.valid_lo, &s.valid_hi);
+    s.revision = store.revision();
+    s.nedges = s.nedges_local = 0;
+    for (int slot = 0; slot < sc.nslots; slot++)
+        for (const ClassTable &ct : tables[slot]) {
+            s.nedges += ct.keys.size();
+            if (s.type_owner[sc.slot_owner[slot].first] == shard.rank) s.nedges_local += ct.keys.size();
+        }
+    for (size_t t = 0; t < sc.defs.size(); t++) s.type_nobjects[t] = store.objects((int)t).count();
+    s.has_reverse = false;
+    return true;
+}
+
+// Test hook (acl_selfcheck_snapshot): does the snapshot -- however it got here, built or patched -- hold exactly the
+// store's live relationships, in rows the kernels can search, with only sound leaf flags?
+bool verify_snapshot(Store &store, int64_t now, const Snapshot &s, ShardSpec shard, std::string *why) {
+    store.settle_all();
+    const Schema &sc = store.schema();
+    auto &tables = store.tables();
+    auto bad = [&](const std::string &m) {
+        if (why) *why = m;
+        return false;
+    };
+    if (s.lay.size() != (size_t)sc.nslots) return bad("layout does not match the schema");
+    Snapshot &ms = const_cast<Snapshot &>(s);
+    std::vector<Patch> none;
+    Patcher P{store, ms, none};
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        auto [t, m] = sc.slot_owner[slot];
+        const Member &mem = sc.defs[t].members[m];
+        if (mem.is_permission || s.type_owner[t] != shard.rank) continue;
+        const RelLayout &l = s.lay[slot];
+        const std::string rel = sc.defs[t].name + "#" + mem.name;
+        for (size_t k = 0; k < mem.classes.size(); k++) {
+            const ClassLayout &c = l.cls[k];
+            const ClassTable &ct = tables[slot][k];
+            std::vector<uint64_t> live;
+            for (uint64_t key : ct.keys)
+                if (store.live(ct, key, now)) live.push_back(key);
+            if (!c.live) {
+                if (!live.empty()) return bad(rel + ": class has relationships but no rows");
+                continue;
+            }
+            size_t stored = 0;
+            if (c.hashed) {
+                for (uint64_t key : live)
+                    if ((uint32_t)key >= c.nsubjects || !P.hashed_has(c, (uint32_t)key, (uint32_t)(key >> 32))) return bad(rel + ": hashed row misses a relationship");
+                for (uint32_t sid = 0; sid < c.nsubjects; sid++) {
+                    const uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
+                    if (md[1] < md[0] || 4 * (size_t)md[1] > s.buckets.size()) return bad(rel + ": hashed descriptor out of range");
+                    for (size_t i = 4 * (size_t)md[0]; i < 4 * (size_t)md[1]; i++)
+                        if (s.buckets[i] != 0xFFFFFFFFu) {
+                            stored++;
+                            if (!std::binary_search(live.begin(), live.end(), (uint64_t)s.buckets[i] << 32 | sid)) return bad(rel + ": hashed row holds a dead relationship");
+                        }
+                }
+            } else {
+                for (uint32_t res = 0; res < l.nrows; res++) {
+                    const uint32_t *md = s.meta.data() + 2 * ((size_t)l.meta_base + (size_t)res * l.Ks + c.ks);
+                    if (md[1] < md[0] || md[1] > s.edges.size()) return bad(rel + ": row descriptor out of range");
+                    for (uint32_t e = md[0]; e < md[1]; e++) {
+                        const uint32_t id = s.edges[e] & kIdMask;
+                        if (e > md[0] && (s.edges[e - 1] & kIdMask) >= id) return bad(rel + ": row not strictly ascending");
+                        if (!std::binary_search(live.begin(), live.end(), (uint64_t)res << 32 | id)) return bad(rel + ": row holds a dead relationship");
+                        stored++;
+                    }
+                }
+            }
+            if (stored != live.size()) return bad(rel + ": " + std::to_string(stored) + " stored vs " + std::to_string(live.size()) + " live relationships");
+        }
+    }
+    // leaf flags: wherever an op still trusts them, a flagged child must really have nothing to enumerate
+    for (const FwdOp &op : s.ops) {
+        if (!(op.flags & OP_ENUM) || !(op.flags & OP_LEAFBIT)) continue;
+        for (uint32_t res = 0; res < op.nrows; res++) {
+            const uint32_t *md = s.meta.data() + 2 * ((size_t)op.base + (size_t)res * op.K + op.k);
+            for (uint32_t e = md[0]; e < md[1]; e++)
+                if ((s.edges[e] & kLeafBit) && !P.child_is_leaf(op.key, s.edges[e] & kIdMask)) return bad("stale leaf flag under an op that trusts leaf flags");
+        }
+    }
+    return true;
 }
 
 }  // namespace acl

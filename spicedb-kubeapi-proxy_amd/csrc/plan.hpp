@@ -11,6 +11,7 @@
 // The kernels (kernels.hip) interpret the programs against the data.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "store.hpp"
@@ -60,6 +61,22 @@ struct RevProg {
 };
 constexpr uint32_t kRevRemoteBit = 0x80000000u;
 
+// ---- host-side layout of one relation's rows (kept with the snapshot so that writes can patch it in place)
+struct ClassLayout {
+    bool live = false;    // >= 1 live relationship when the snapshot was built (decides whether programs hold an op for it)
+    bool hashed = false;  // membership-only class: subject-indexed hashed rows
+    uint32_t ks = 0;      // sorted-class index inside the relation's row descriptors
+    uint32_t smeta_base = 0, nsubjects = 0;  // hashed: per-subject descriptors (uint2 units) and their count (with headroom)
+};
+struct RelLayout {
+    uint32_t meta_base = 0, nrows = 0, Ks = 0;  // meta_base in uint2 units; nrows includes headroom for new objects
+    std::vector<ClassLayout> cls;
+};
+struct Patch {  // a region of a snapshot array that changed on the host and must be re-uploaded
+    enum Array { META = 0, EDGES = 1, BUCKETS = 2, OPS = 3 } array;
+    size_t off, n;  // in elements of that array (u32 words; FwdOp for OPS)
+};
+
 // ---- host-side snapshot ----
 struct Snapshot {
     uint64_t revision = 0;     // store revision it was built from
@@ -73,6 +90,9 @@ struct Snapshot {
     // per type: first slot + member count (request validation on device)
     std::vector<uint32_t> type_slot_base, type_nmembers;
     std::vector<uint32_t> type_nobjects;
+    std::vector<RelLayout> lay;  // [nslots]
+    uint64_t garbage_words = 0;  // edge / bucket words orphaned by row relocations since the build
+    uint64_t patched = 0;        // relationships patched in since the build
     uint32_t nslots = 0, ntypes = 0;
     uint64_t nedges = 0;        // relationships in the store
     uint64_t nedges_local = 0;  // ... whose resource type this shard owns
@@ -96,6 +116,13 @@ struct ShardSpec {
 uint32_t shard_of_type(const std::string &type_name, uint32_t world);
 
 void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
+// Brings a snapshot built at an older store revision up to date IN PLACE from the store's change feed: hashed rows
+// are re-hashed per subject, sorted rows are shrunk in place or relocated to the end of `edges`, leaf flags that
+// may have gone stale are switched off per program op.  Returns false when the change cannot be expressed as a
+// patch (bulk load, a class becoming live, table headroom exhausted, too many changes): rebuild instead.
+// On success `patches` lists the regions to re-upload and the reverse rows (if any) are invalidated.
+bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
+bool verify_snapshot(Store &store, int64_t now, const Snapshot &snap, ShardSpec shard, std::string *why);
 void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
 
 }  // namespace acl

@@ -318,6 +318,13 @@ void Store::log_change(int op, int slot, int cls, uint64_t key) {
     log_.push_back(Change{revision_, op, slot, cls, key});
 }
 
+bool Store::raw_changes_since(uint64_t after, std::vector<Change> *out) const {
+    if (after < log_floor_ || after < bulk_revision_) return false;
+    auto it = std::upper_bound(log_.begin(), log_.end(), after, [](uint64_t a, const Change &c) { return a < c.revision; });
+    out->assign(it, log_.end());
+    return true;
+}
+
 bool Store::changes_since(uint64_t after, const std::vector<int> &types, const std::function<void(const Change &, const RelText &)> &fn) const {
     if (after < log_floor_) return false;
     auto it = std::upper_bound(log_.begin(), log_.end(), after, [](uint64_t a, const Change &c) { return a < c.revision; });
@@ -367,6 +374,7 @@ Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const
         objects_[stype].reserve_ids(maxs + 1);
     }
     revision_++;
+    bulk_revision_ = revision_;  // not in the change feed: snapshots older than this must be rebuilt, not patched
     return Status::Ok();
 }
 

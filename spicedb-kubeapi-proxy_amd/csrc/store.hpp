@@ -119,6 +119,9 @@ class Store {
     // when `after` is older than the retained window
     bool changes_since(uint64_t after, const std::vector<int> &types, const std::function<void(const Change &, const RelText &)> &fn) const;
     RelText rel_text(int slot, int cls, uint64_t key) const;
+    // raw feed for the snapshot patcher (plan.cpp patch_forward): changes with revision > after, or false when some
+    // mutation since `after` is not in the feed (bulk load, schema load, dropped window)
+    bool raw_changes_since(uint64_t after, std::vector<Change> *out) const;
 
   private:
     struct Resolved {
@@ -139,6 +142,7 @@ class Store {
     int64_t now_override_ = 0;
     std::vector<Change> log_;       // bounded: the oldest half is dropped when it reaches kLogCap
     uint64_t log_floor_ = 0;        // changes with revision <= log_floor_ may have been dropped
+    uint64_t bulk_revision_ = 0;    // revision of the last mutation that bypassed the feed (add_edges, bootstrap lines)
     void log_change(int op, int slot, int cls, uint64_t key);
     static constexpr size_t kLogCap = 1u << 20;
 };

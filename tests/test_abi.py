@@ -35,7 +35,7 @@ def test_struct_layouts(aclgpu_lib):
     assert C.sizeof(aclgpu._lib.Update) == 8 + 7 * 8
     assert C.sizeof(aclgpu._lib.Filter) == 8 + 6 * 8
     assert C.sizeof(aclgpu._lib.CheckItem) == 6 * 8
-    assert C.sizeof(aclgpu._lib.Stats) == 12 * 8
+    assert C.sizeof(aclgpu._lib.Stats) == 13 * 8
 
 
 def test_no_gpu_means_no_evaluation(aclgpu_lib):

@@ -1,0 +1,131 @@
+"""CPU tests of the write path's snapshot maintenance: committed writes are patched into the
+HBM snapshot's host copy in place (plan.cpp patch_forward) and the result must describe exactly the store's live
+relationships (verify_snapshot: every relationship findable by the kernels' search, nothing dead left, rows sorted,
+no unsound leaf flag).  Runs on a store-only engine -- the device upload of the patched regions is covered by
+tests/test_write_path_gpu.py."""
+import random
+
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from tests.test_oracle_cross import SCHEMA, tuples_strategy
+from tests.test_sharded_gloo import random_tuples
+
+
+@pytest.fixture(scope="module")
+def aclgpu(aclgpu_lib):
+    import aclgpu as m
+    return m
+
+
+def writes_strategy():
+    return st.lists(st.tuples(st.sampled_from([1, 2, 3]), tuples_strategy().map(lambda ts: ts[:6])), min_size=1, max_size=8)
+
+
+def test_patch_after_every_write_matches_store(aclgpu):
+    @settings(max_examples=60, deadline=None)
+    @given(tuples_strategy(), writes_strategy())
+    def run(initial, writes):
+        e = aclgpu.Engine(SCHEMA, store_only=True)
+        initial = list(dict.fromkeys(initial))
+        if initial:
+            e.write([(aclgpu.OP_TOUCH, t) for t in initial])
+        assert e.selfcheck_snapshot() is False  # first call builds
+        for op, ts in writes:
+            ts = list(dict.fromkeys(ts))
+            if not ts:
+                continue
+            try:
+                e.write([(op, t) for t in ts])
+            except aclgpu.AclError as ex:  # CREATE of an existing relationship: the whole write is refused
+                assert ex.code == aclgpu.ERR_ALREADY_EXISTS
+            e.selfcheck_snapshot()  # patch or rebuild, then verified inside the library (raises on any mismatch)
+        e.close()
+
+    run()
+
+
+def test_patches_are_actually_used_and_leaf_flags_stay_sound(aclgpu):
+    rng = random.Random(7)
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    e.write([(aclgpu.OP_TOUCH, t) for t in random_tuples(rng, 40)])
+    e.selfcheck_snapshot()
+    patched = 0
+    for i in range(200):
+        ts = random_tuples(rng, rng.randint(1, 5))
+        op = rng.choice([aclgpu.OP_TOUCH, aclgpu.OP_TOUCH, aclgpu.OP_DELETE])
+        e.write([(op, t) for t in ts])
+        if i % 3 == 0:  # several writes may accumulate before the next read
+            patched += e.selfcheck_snapshot()
+    assert patched > 30, patched
+    # a group that had no members gains a nested group: everything that flagged it as a leaf must be distrusted or fixed
+    e2 = aclgpu.Engine(SCHEMA, store_only=True)
+    e2.write([(aclgpu.OP_TOUCH, "group:g1#member@user:u1"), (aclgpu.OP_TOUCH, "group:g0#member@group:g1#member"),
+              (aclgpu.OP_TOUCH, "doc:d0#viewer@group:g0#member"), (aclgpu.OP_TOUCH, "group:g2#member@user:u2")])
+    e2.selfcheck_snapshot()
+    e2.write([(aclgpu.OP_TOUCH, "group:g1#member@group:g2#member")])  # g1 was a leaf (only user members) until now
+    assert e2.selfcheck_snapshot() is True
+    e2.write([(aclgpu.OP_DELETE, "group:g1#member@group:g2#member"), (aclgpu.OP_DELETE, "group:g0#member@group:g1#member")])
+    assert e2.selfcheck_snapshot() is True
+    for e_ in (e, e2):
+        e_.close()
+
+
+def test_what_cannot_be_patched_is_rebuilt(aclgpu):
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    e.write([(aclgpu.OP_TOUCH, "doc:d0#viewer@user:u0")])
+    e.selfcheck_snapshot()
+    # first relationship ever in a class: the programs have no op for it yet -> rebuild
+    e.write([(aclgpu.OP_TOUCH, "org:o0#admin@user:u0")])
+    assert e.selfcheck_snapshot() is False
+    e.write([(aclgpu.OP_TOUCH, "org:o1#admin@user:u1")])
+    assert e.selfcheck_snapshot() is True
+    # bulk loads bypass the change feed -> rebuild
+    import numpy as np
+    e.add_edges("doc", "viewer", "user", "", np.array([0], dtype=np.uint32), np.array([1], dtype=np.uint32))
+    assert e.selfcheck_snapshot() is False
+    # more new objects than the tables' headroom (1024 + 25 %) -> rebuild, and the rebuilt tables fit again
+    for base in range(0, 3000, 500):
+        e.write([(aclgpu.OP_TOUCH, f"doc:new{base + i}#viewer@user:u0") for i in range(500)])
+    assert e.selfcheck_snapshot() is False
+    e.write([(aclgpu.OP_TOUCH, "doc:one-more#viewer@user:u0")])
+    assert e.selfcheck_snapshot() is True
+    e.close()
+
+
+def test_expiring_relationships_and_the_patch_window(aclgpu):
+    from tests import kat_runner
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], store_only=True)
+    e.set_now(1000)
+    e.write([(aclgpu.OP_TOUCH, ("workflow", "w1", "idempotency_key", "activity", "a1", ""), 1500)])
+    e.selfcheck_snapshot()
+    e.write([(aclgpu.OP_TOUCH, ("workflow", "w2", "idempotency_key", "activity", "a2", ""), 1200)])
+    assert e.selfcheck_snapshot() is True  # an expiring relationship can be patched in; the window shrinks to 1200
+    e.set_now(1300)  # a2 expired: the snapshot's validity window is over -> rebuild without it
+    assert e.selfcheck_snapshot() is False
+    assert [r[1] for r in e.read(rtype="workflow")] == ["w1"]
+    e.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_patching_a_shard(aclgpu, world):
+    """A shard only patches rows of the types it owns; its snapshot must match the store restricted to those types."""
+    rng = random.Random(11)
+    engines = []
+    for r in range(world):
+        e = aclgpu.Engine(SCHEMA, store_only=True)
+        e._check(e._L.acl_shard_configure(e._h, r, world))
+        engines.append(e)
+    init = random_tuples(rng, 40)
+    for e in engines:
+        e.write([(aclgpu.OP_TOUCH, t) for t in init])
+        e.selfcheck_snapshot()
+    for _ in range(40):
+        ts = random_tuples(rng, 3)
+        op = rng.choice([aclgpu.OP_TOUCH, aclgpu.OP_DELETE])
+        for e in engines:
+            e.write([(op, t) for t in ts])
+            e.selfcheck_snapshot()
+    for e in engines:
+        e.close()
