@@ -20,18 +20,30 @@ def aclgpu(aclgpu_lib):
     return m
 
 
+def acyclic(ts):
+    """Keeps nesting edges that go from a lower to a higher index only.  Long random histories otherwise converge to
+    densely cyclic group graphs whose path count (no visited set, depth 50 -- as in the reference's engine) explodes;
+    cyclic data is covered with small graphs in test_engine_gpu.py / test_sharded_gpu.py."""
+    keep = []
+    for t in ts:
+        if t[0] == t[3] and t[0] in ("group", "org") and int(t[4][1:]) <= int(t[1][1:]):
+            continue
+        keep.append(t)
+    return keep
+
+
 def test_random_write_history_reads_match_oracle(aclgpu):
     rng = random.Random(21)
     subjects = [("user", "u0", ""), ("group", "g0", "member"), ("group", "g1", "manage")]
     with aclgpu.Engine(SCHEMA) as e:
         co = orc.Oracle(SCHEMA)
-        init = random_tuples(rng, 40)
+        init = acyclic(random_tuples(rng, 40))
         for tgt, op in ((e, aclgpu.OP_TOUCH), (co, orc.OP_TOUCH)):
             tgt.write([(op, t) for t in init])
         e.check_bulk(QUERIES)
         builds0 = e.stats()["snapshot_builds"]
         for step in range(120):
-            ts = random_tuples(rng, rng.randint(1, 4))
+            ts = acyclic(random_tuples(rng, rng.randint(1, 4))) or [("doc", "d0", "creator", "user", "u0", "")]
             kind = rng.choice(["touch", "touch", "delete"])
             e.write([(aclgpu.OP_TOUCH if kind == "touch" else aclgpu.OP_DELETE, t) for t in ts])
             co.write([(orc.OP_TOUCH if kind == "touch" else orc.OP_DELETE, t) for t in ts])
@@ -82,8 +94,8 @@ def test_patched_shards_agree_with_oracle(aclgpu):
     """Sharded engines: every shard applies the same writes and patches only the rows it owns."""
     from aclgpu import sharded
     rng = random.Random(5)
-    init = random_tuples(rng, 30)
-    writes = [(rng.choice(["touch", "delete"]), random_tuples(rng, 3)) for _ in range(25)]
+    init = acyclic(random_tuples(rng, 30))
+    writes = [(rng.choice(["touch", "delete"]), acyclic(random_tuples(rng, 3)) or [("doc", "d0", "creator", "user", "u0", "")]) for _ in range(25)]
     co = orc.Oracle(SCHEMA)
     co.write([(orc.OP_TOUCH, t) for t in init])
     want = []
