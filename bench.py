@@ -18,6 +18,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -160,10 +161,6 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
         w.load(e2)
         sh = sharded.GpuShard(e2, rank, world)
         se = sharded.ShardedEngine(sh, sharded.TorchComm(device=f"cuda:{local_rank}"), export_entries=1 << 20)
-        # watchdog: a wedged collective must not take the bench line with it
-        timer = threading.Timer(240.0, lambda: (print(json.dumps({"metric": "check_decisions_per_sec", "error": "sharded leg timed out"}), flush=True) if rank == 0 else None, os._exit(3)))
-        timer.daemon = True
-        timer.start()
         try:
             o = run(se, dist.barrier)
             o["shard_relationships"] = int(_local_edges(e2))
@@ -172,7 +169,6 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
             if rank == 0:
                 done(gathered)
         finally:
-            timer.cancel()
             e2.close()
     else:
         engines = []
@@ -302,10 +298,7 @@ def main():
         host_lat.append(time.perf_counter() - t1)
 
     # ---- extra leg (outside the timed region above): the sharded graph
-    sharded_out = None
-    want_sharded = args.sharded == "on" or (args.sharded == "auto" and world == 8)
-    if want_sharded and (world > 1 or args.logical_shards > 1):
-        sharded_out = sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank)
+    want_sharded = (args.sharded == "on" or (args.sharded == "auto" and world == 8)) and (world > 1 or args.logical_shards > 1)
 
     out = None
     if rank == 0:
@@ -390,8 +383,31 @@ def main():
                     pass
         out["roofline"] = roof
         out["cpu_baseline"] = cpu
-        if sharded_out is not None:
-            out["sharded"] = sharded_out
+    # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
+    # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.
+    if want_sharded:
+        printed = threading.Event()
+
+        def emit(extra):
+            if rank == 0 and not printed.is_set():
+                printed.set()
+                out["sharded"] = extra
+                print(json.dumps(out), flush=True)
+
+        def on_timeout():
+            emit({"error": "sharded leg did not finish within 180 s (collective wedged?)"})
+            os._exit(0)
+
+        timer = threading.Timer(180.0, on_timeout)
+        timer.daemon = True
+        timer.start()
+        try:
+            emit(sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank))
+        except Exception as ex:  # noqa: BLE001
+            emit({"error": f"{type(ex).__name__}: {ex}"})
+        finally:
+            timer.cancel()
+    elif rank == 0:
         print(json.dumps(out))
     eng.close()
     if world > 1:
