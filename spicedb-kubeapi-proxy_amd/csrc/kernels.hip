@@ -40,7 +40,6 @@ constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same o
 constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
 constexpr uint32_t kCountMask = 0x3FFFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
-constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
 
 // entry meta: slot[0:13) | level[13:19) | probed[19] | subject key[20:32)
@@ -123,17 +122,15 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
     return lo < end && (edges[lo] & kIdMask) == key;
 }
 
-// hashed row: nb = b1 - b0 buckets of 4 ids; same placement rule as plan.cpp (hash_bucket + linear probing)
+// hashed row: nb = b1 - b0 buckets of 4 ids, two-choice placement (plan.hpp hashed_row_buckets): the id is in bucket h1
+// or h2 or nowhere -- two INDEPENDENT 16 B gathers in flight together, never a probing chain (with linear probing the
+// slowest of the 64 lanes made almost every wave walk 3-5 dependent buckets; profiles/r01_c4_v5_pmc.md)
 __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
-    const uint32_t nb = b1 - b0;
-    uint32_t b = (uint32_t)(((uint64_t)(want * 0x9E3779B1u) * nb) >> 32);
-    for (uint32_t i = 0; i < nb; i++) {
-        const uint4 q = buckets[b0 + b];
-        if (q.x == want || q.y == want || q.z == want || q.w == want) return true;
-        if (q.x == kEmptySlot || q.y == kEmptySlot || q.z == kEmptySlot || q.w == kEmptySlot) return false;
-        b = b + 1 == nb ? 0 : b + 1;
-    }
-    return false;
+    uint32_t h1, h2;
+    hashed_row_buckets(want, b1 - b0, &h1, &h2);
+    const uint4 p = buckets[b0 + h1];
+    const uint4 q = buckets[b0 + h2];
+    return p.x == want || p.y == want || p.z == want || p.w == want || q.x == want || q.y == want || q.z == want || q.w == want;
 }
 
 // Membership of (resource id, subject sid) in a membership-only class.  The class is stored SUBJECT-indexed:

@@ -12,8 +12,49 @@ constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
 // tables are sized for objects that do not exist yet, so that writes naming new objects can be patched in
 inline uint32_t with_headroom(uint32_t n) { return n + n / 4 + 1024; }
-inline uint32_t hash_bucket(uint32_t v, uint32_t nb) { return (uint32_t)(((uint64_t)(v * 0x9E3779B1u) * nb) >> 32); }
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+// two-choice insertion with random-walk eviction; false when the row is too tight (the caller gives it more buckets)
+bool cuckoo_insert(uint32_t *row, uint32_t nb, uint32_t id) {
+    uint32_t cur = id;
+    for (uint32_t kick = 0; kick < 512; kick++) {
+        uint32_t h1, h2;
+        hashed_row_buckets(cur, nb, &h1, &h2);
+        for (uint32_t b : {h1, h2})
+            for (int k = 0; k < 4; k++)
+                if (row[4 * (size_t)b + k] == kEmpty) {
+                    row[4 * (size_t)b + k] = cur;
+                    return true;
+                }
+        const uint32_t b = (kick & 1u) ? h2 : h1;
+        const uint32_t k = (cur * 2654435761u >> 13 ^ kick) & 3u;
+        std::swap(cur, row[4 * (size_t)b + k]);
+    }
+    // undo is not needed: the caller discards the row
+    return false;
+}
+// builds the row of `ids` at the end of `buckets`; returns {first bucket, end bucket}
+std::pair<uint32_t, uint32_t> append_hashed_row(std::vector<uint32_t> &buckets, const uint32_t *ids, size_t n, uint32_t min_buckets);
+bool hashed_row_has(const uint32_t *row, uint32_t nb, uint32_t id) {
+    if (!nb) return false;
+    uint32_t h1, h2;
+    hashed_row_buckets(id, nb, &h1, &h2);
+    for (uint32_t b : {h1, h2})
+        for (int k = 0; k < 4; k++)
+            if (row[4 * (size_t)b + k] == id) return true;
+    return false;
+}
 inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }  // load <= 0.75 (<= 1.0 for a single bucket)
+std::pair<uint32_t, uint32_t> append_hashed_row(std::vector<uint32_t> &buckets, const uint32_t *ids, size_t n, uint32_t min_buckets) {
+    const uint32_t b0 = (uint32_t)(buckets.size() / 4);
+    if (!n && !min_buckets) return {b0, b0};
+    for (uint32_t nb = std::max(min_buckets, buckets_for((uint32_t)n));; nb += std::max(1u, nb / 4)) {
+        buckets.resize(4 * (size_t)(b0 + nb));
+        std::fill(buckets.begin() + 4 * (long)b0, buckets.end(), kEmpty);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) ok = cuckoo_insert(buckets.data() + 4 * (size_t)b0, nb, ids[i]);
+        if (ok) return {b0, b0 + nb};
+    }
+}
 
 struct Flattener {
     const Schema &sc;
@@ -175,30 +216,20 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             c.nsubjects = ns;
             c.smeta_base = (uint32_t)(s.meta.size() / 2);
             s.meta.resize(s.meta.size() + 2 * (size_t)ns, 0);
-            cnt.assign(ns, 0);
+            // group the class's resource ids by subject (counting sort), then lay the rows out one after the other
+            cnt.assign((size_t)ns + 1, 0);
             for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) cnt[(uint32_t)key]++;
-            uint32_t b = (uint32_t)(s.buckets.size() / 4);
+                if (!filt || store.live(ct, key, now)) cnt[(uint32_t)key + 1]++;
+            for (uint32_t sid = 0; sid < ns; sid++) cnt[sid + 1] += cnt[sid];
+            fill.assign(cnt.begin(), cnt.end() - 1);
+            std::vector<uint32_t> by_subject(cnt[ns]);
+            for (uint64_t key : ct.keys)
+                if (!filt || store.live(ct, key, now)) by_subject[fill[(uint32_t)key]++] = (uint32_t)(key >> 32);
             for (uint32_t sid = 0; sid < ns; sid++) {
+                const auto r = append_hashed_row(s.buckets, by_subject.data() + cnt[sid], cnt[sid + 1] - cnt[sid], 0);
                 uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
-                md[0] = b;
-                if (cnt[sid]) b += buckets_for(cnt[sid]);
-                md[1] = b;
-            }
-            s.buckets.resize(4 * (size_t)b, 0xFFFFFFFFu);
-            for (uint64_t key : ct.keys) {
-                if (filt && !store.live(ct, key, now)) continue;
-                const uint32_t res = (uint32_t)(key >> 32), sid = (uint32_t)key;
-                const uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
-                const uint32_t nb = md[1] - md[0];
-                uint32_t *row = s.buckets.data() + 4 * (size_t)md[0];
-                uint32_t bi = hash_bucket(res, nb);
-                for (;;) {
-                    uint32_t *q = row + 4 * (size_t)bi;
-                    int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
-                    if (f >= 0) { q[f] = res; break; }
-                    bi = bi + 1 == nb ? 0 : bi + 1;
-                }
+                md[0] = r.first;
+                md[1] = r.second;
             }
         }
         // ---- enumerable classes: sorted sub-rows per (object, class)
@@ -308,55 +339,33 @@ struct Patcher {
     uint32_t *hdesc(const ClassLayout &c, uint32_t sid) { return s.meta.data() + 2 * ((size_t)c.smeta_base + sid); }
     bool hashed_has(const ClassLayout &c, uint32_t sid, uint32_t res) {
         const uint32_t *md = hdesc(c, sid);
-        const uint32_t nb = md[1] - md[0];
-        if (!nb) return false;
-        const uint32_t *row = s.buckets.data() + 4 * (size_t)md[0];
-        uint32_t b = hash_bucket(res, nb);
-        for (uint32_t i = 0; i < nb; i++) {
-            const uint32_t *q = row + 4 * (size_t)b;
-            bool empty = false;
-            for (int k = 0; k < 4; k++) {
-                if (q[k] == res) return true;
-                if (q[k] == 0xFFFFFFFFu) empty = true;
-            }
-            if (empty) return false;
-            b = b + 1 == nb ? 0 : b + 1;
-        }
-        return false;
+        return hashed_row_has(s.buckets.data() + 4 * (size_t)md[0], md[1] - md[0], res);
     }
-    static void hashed_insert(uint32_t *row, uint32_t nb, uint32_t res) {
-        uint32_t bi = hash_bucket(res, nb);
-        for (;;) {
-            uint32_t *q = row + 4 * (size_t)bi;
-            int f = q[0] == 0xFFFFFFFFu ? 0 : q[1] == 0xFFFFFFFFu ? 1 : q[2] == 0xFFFFFFFFu ? 2 : q[3] == 0xFFFFFFFFu ? 3 : -1;
-            if (f >= 0) { q[f] = res; return; }
-            bi = bi + 1 == nb ? 0 : bi + 1;
-        }
-    }
-    // re-hashes the whole row of `sid` with `res` added or removed: no deletion holes, same placement rule as the build
+    // rebuilds the row of `sid` with `res` added or removed: in place while it fits its buckets, else at the end of
+    // `buckets` with room to grow before the next move
     void hashed_set(const ClassLayout &c, uint32_t sid, uint32_t res, bool add) {
         uint32_t *md = hdesc(c, sid);
         const uint32_t b0 = md[0], nb = md[1] - md[0];
         std::vector<uint32_t> el;
         for (size_t i = 4 * (size_t)b0; i < 4 * (size_t)(b0 + nb); i++)
-            if (s.buckets[i] != 0xFFFFFFFFu && (add || s.buckets[i] != res)) el.push_back(s.buckets[i]);
+            if (s.buckets[i] != kEmpty && (add || s.buckets[i] != res)) el.push_back(s.buckets[i]);
         if (add) el.push_back(res);
-        const uint32_t need = el.empty() ? 0u : buckets_for((uint32_t)el.size());
-        if (need <= nb) {  // fits where it is (an emptied row keeps its space for the next insert)
-            std::fill(s.buckets.begin() + 4 * (long)b0, s.buckets.begin() + 4 * (long)(b0 + nb), 0xFFFFFFFFu);
-            for (uint32_t r : el) hashed_insert(s.buckets.data() + 4 * (size_t)b0, nb, r);
-            if (nb) out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)b0, 4 * (size_t)nb});
-            return;
+        if (nb && (el.empty() || buckets_for((uint32_t)el.size()) <= nb)) {
+            std::vector<uint32_t> row(4 * (size_t)nb, kEmpty);
+            bool ok = true;
+            for (size_t i = 0; i < el.size() && ok; i++) ok = cuckoo_insert(row.data(), nb, el[i]);
+            if (ok) {
+                std::copy(row.begin(), row.end(), s.buckets.begin() + 4 * (long)b0);
+                out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)b0, 4 * (size_t)nb});
+                return;
+            }
         }
-        const uint32_t nb2 = buckets_for((uint32_t)(el.size() + el.size() / 2 + 1));  // room to grow before the next move
-        const uint32_t nb0 = (uint32_t)(s.buckets.size() / 4);
-        s.buckets.resize(s.buckets.size() + 4 * (size_t)nb2, 0xFFFFFFFFu);
-        for (uint32_t r : el) hashed_insert(s.buckets.data() + 4 * (size_t)nb0, nb2, r);
+        const auto r = append_hashed_row(s.buckets, el.data(), el.size(), buckets_for((uint32_t)(el.size() + el.size() / 2 + 1)));
         md = hdesc(c, sid);
-        md[0] = nb0;
-        md[1] = nb0 + nb2;
+        md[0] = r.first;
+        md[1] = r.second;
         s.garbage_words += 4 * (uint64_t)nb;
-        out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)nb0, 4 * (size_t)nb2});
+        out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)r.first, 4 * (size_t)(r.second - r.first)});
         out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
     }
 

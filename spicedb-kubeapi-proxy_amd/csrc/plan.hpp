@@ -27,6 +27,20 @@ enum : uint32_t {
     OP_PROBE_HASH = 16u, // membership test in a membership-only class: SUBJECT-indexed hashed rows (4-slot buckets)
     OP_LEAFBIT = 32u     // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
 };
+// Hashed rows use two-choice (cuckoo) placement over 4-slot buckets: an id lives in bucket h1 or h2 of its row, so a
+// membership test is exactly two independent 16-byte gathers -- no probing chain whose longest lane stalls the wave.
+#if defined(__HIPCC__)
+#define ACL_HD __host__ __device__
+#else
+#define ACL_HD
+#endif
+ACL_HD inline void hashed_row_buckets(uint32_t id, uint32_t nb, uint32_t *h1, uint32_t *h2) {
+    const uint32_t a = (uint32_t)(((uint64_t)(id * 0x9E3779B1u) * nb) >> 32);
+    uint32_t b = (uint32_t)(((uint64_t)((id ^ 0x5bd1e995u) * 0x85EBCA6Bu) * nb) >> 32);
+    if (b == a) b = a + 1 == nb ? 0 : a + 1;  // nb == 1: both are bucket 0
+    *h1 = a;
+    *h2 = b;
+}
 constexpr uint32_t kLeafBit = 0x80000000u;  // object ids are < 2^31
 constexpr uint32_t kIdMask = 0x7FFFFFFFu;
 
