@@ -322,13 +322,28 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
     WaveOut wo{wave, 0u, 0u};
-    for (uint32_t x = wave; x < C * kSegsPerChunk; x += nwaves) {
-        // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
-        // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
-        // (each segment layer is rotated so that one wave does not keep landing on the same chunk)
-        const uint32_t s = x / C, c = (x % C + s * 509u) % C;
-        const uint32_t cnt = in_counts[c];
-        if (s * 64 >= cnt) continue;
+    // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
+    // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
+    // (each segment layer is rotated so that one wave does not keep landing on the same chunk).
+    // The fill counts of the wave's next 64 segment slots are fetched by its 64 lanes in ONE gather; the loop then
+    // reads them with readlane -- not one dependent load per slot (most slots are empty: 16+ per wave and level).
+    const uint32_t nslot = C * kSegsPerChunk;
+    for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
+        const uint32_t xl = x0 + lane * nwaves;
+        uint32_t lc = 0, lcnt = 0;
+        if (xl < nslot) {
+            const uint32_t ls = xl / C;
+            lc = (xl % C + ls * 509u) % C;
+            lcnt = in_counts[lc];
+            lcnt = lcnt > ls * 64 ? lcnt - ls * 64 : 0u;  // entries of this slot's segment and beyond
+        }
+        uint64_t work = __ballot(lcnt != 0);
+        while (work) {
+        const int wl = __ffsll((unsigned long long)work) - 1;
+        work &= work - 1;
+        const uint32_t x = x0 + (uint32_t)wl * nwaves;
+        const uint32_t s = x / C, c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
         const bool valid = s * 64 + lane < cnt;
         const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
@@ -403,6 +418,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
         if (hit) has[req] = 1;
         else if (depth_err) err[req] = ITEM_ERR_DEPTH;
         if (T) flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
+        }
     }
     if (lane == 0) {
         if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
@@ -457,13 +473,28 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
     const DevGraph nog{};
     WaveOut wo{wave, 0u, 0u};
-    for (uint32_t x = wave; x < C * kSegsPerChunk; x += nwaves) {
-        // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
-        // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
-        // (each segment layer is rotated so that one wave does not keep landing on the same chunk)
-        const uint32_t s = x / C, c = (x % C + s * 509u) % C;
-        const uint32_t cnt = in_counts[c];
-        if (s * 64 >= cnt) continue;
+    // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
+    // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
+    // (each segment layer is rotated so that one wave does not keep landing on the same chunk).
+    // The fill counts of the wave's next 64 segment slots are fetched by its 64 lanes in ONE gather; the loop then
+    // reads them with readlane -- not one dependent load per slot (most slots are empty: 16+ per wave and level).
+    const uint32_t nslot = C * kSegsPerChunk;
+    for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
+        const uint32_t xl = x0 + lane * nwaves;
+        uint32_t lc = 0, lcnt = 0;
+        if (xl < nslot) {
+            const uint32_t ls = xl / C;
+            lc = (xl % C + ls * 509u) % C;
+            lcnt = in_counts[lc];
+            lcnt = lcnt > ls * 64 ? lcnt - ls * 64 : 0u;  // entries of this slot's segment and beyond
+        }
+        uint64_t work = __ballot(lcnt != 0);
+        while (work) {
+        const int wl = __ffsll((unsigned long long)work) - 1;
+        work &= work - 1;
+        const uint32_t x = x0 + (uint32_t)wl * nwaves;
+        const uint32_t s = x / C, c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
         const bool valid = s * 64 + lane < cnt;
         const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z;
@@ -542,6 +573,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
             }
         }
         if (T) flush_tasks<false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr, sh);
+        }
     }
     if (lane == 0) {
         if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;
