@@ -35,6 +35,7 @@ WORKLOAD_DESC = {
     "C2": "C2: 100k-object / 1M-relationship 3-level (cluster->namespace->pod) graph, 64k-batch Check",
     "C3": "C3: C2 graph + 64 power users, Filter/LookupResources(pod, view, user) returning ~10k allowed IDs per user",
     "C4": "C4: 10M-relationship / 1M-object 5-level nested-group graph, 256k-batch Check",
+    "C5": "C5: 100M-relationship graph sharded by object type, mixed stream (90% 256k-batch Check / 10% Filter) with per-level frontier all-gather",
 }
 
 
@@ -102,6 +103,106 @@ def filter_bench(args, w, eng, world, rank):
     eng.close()
     if out.get("parity", {}).get("mismatches"):
         raise SystemExit("PARITY FAILURE: GPU lookup differs from the oracle")
+
+
+def c5_bench(args, w, world, rank, local_rank, t_gen):
+    """BASELINE config 5 (not the headline): the graph sharded by object type over G shards, mixed Check + Filter stream.
+    G = the ranks of a multi-GPU launch (RCCL all-gather), or --logical-shards (default 8) on one GPU -- the latter is an
+    EMULATION of the layout on one device, labelled as such."""
+    import torch
+    import torch.distributed as dist
+
+    import aclgpu
+    from aclgpu import sharded, workloads
+
+    rt, perm_name, st = w.check
+    n = int(w.res.size)
+    G = world if world > 1 else (args.logical_shards or 8)
+    ops = workloads.c5_stream(w, args.steps)
+    nC = sum(1 for o in ops if o == "C")
+    engines = []
+
+    def make(r, g):
+        e = aclgpu.Engine(w.schema, device=local_rank)
+        w.load(e)
+        engines.append(e)
+        return sharded.GpuShard(e, r, g)
+
+    def run(se, barrier):
+        e = se.shard.e
+        se._alloc(1 << 20)
+        items = e.make_items(rt, perm_name, w.res, st, "", w.subj)
+        d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
+        p, er = se.check_bulk_ids(d_items)  # warm-up (also builds + uploads the shard's snapshot)
+        bm = se.lookup_ids_batch(rt, perm_name, st, "", [int(w.lookup_subjects[0])])
+        barrier()
+        t0 = time.perf_counter()
+        tc = tf = 0.0
+        for o in ops:
+            t1 = time.perf_counter()
+            if o == "C":
+                p, er = se.check_bulk_ids(d_items)
+                tc += time.perf_counter() - t1
+            else:
+                bm = se.lookup_ids_batch(rt, perm_name, st, "", [o[1]])
+                tf += time.perf_counter() - t1
+        barrier()
+        el = time.perf_counter() - t0
+        st_ = e.stats()
+        # cross-path property at full size: the last Filter bitmap must agree with sharded Checks of the same subject
+        last_f = [o for o in ops if o != "C"][-1][1]
+        rng = np.random.default_rng(7)
+        pods = rng.integers(0, w.nobjects[rt], size=20000).astype(np.uint32)
+        bm = se.lookup_ids_batch(rt, perm_name, st, "", [last_f])
+        bits = np.unpackbits(bm[0].cpu().numpy().view(np.uint8), bitorder="little")
+        cp, _ = se.check_bulk_ids(e.make_items(rt, perm_name, pods, st, "", np.full(pods.size, last_f, dtype=np.uint32)))
+        cross = int(((cp.cpu().numpy() == 2) != (bits[pods] == 1)).sum())
+        return {"elapsed": el, "check_s": tc, "filter_s": tf, "perm": p.cpu().numpy(), "err": er.cpu().numpy(), "cross_mismatch": cross,
+                "allowed_last_filter": int(bits.sum()), "local_relationships": int(st_["snapshot_edges_local"]), "recv": se.exchanged_entries,
+                "levels": se.levels_last}
+
+    t0 = time.time()
+    if world > 1:
+        se = sharded.ShardedEngine(make(rank, world), sharded.TorchComm(device=f"cuda:{local_rank}"))
+        o = run(se, dist.barrier)
+        outs = [None] * world
+        dist.all_gather_object(outs, {k: v for k, v in o.items() if k not in ("perm", "err")})
+        outs[rank].update(perm=o["perm"], err=o["err"])
+    else:
+        outs = sharded.run_logical_shards(G, make, lambda se: run(se, se.comm.barrier))
+    t_all = time.time() - t0
+    if rank == 0:
+        el = max(o["elapsed"] for o in outs)
+        out = {"metric": "mixed_stream_check_decisions_per_sec", "value": n * nC / el, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+               "warmup": 1, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u32", "data": "synthetic",
+               "config": {"workload": WORKLOAD_DESC["C5"], "shards": G, "scale": args.scale, "relationships": w.ntuples,
+                          "objects": int(sum(w.nobjects.values())), "check_batch": n, "stream": "".join("C" if o == "C" else "F" for o in ops),
+                          "execution": "one shard per GPU, RCCL all-gather" if world > 1 else f"{G} LOGICAL shards on ONE GPU: emulated, not a multi-GPU measurement"},
+               "check_batches": nC, "filter_requests": len(ops) - nC,
+               "ms_per_check_batch": 1e3 * outs[0]["check_s"] / max(1, nC), "ms_per_filter_request": 1e3 * outs[0]["filter_s"] / max(1, len(ops) - nC),
+               "levels": outs[0]["levels"], "shard_relationships": [o["local_relationships"] for o in outs],
+               "recv_entries_by_shard": [o["recv"] for o in outs], "allowed_ids_last_filter": outs[0]["allowed_last_filter"],
+               "setup_s": {"generate": round(t_gen, 1), "load+run": round(t_all, 1)}}
+        parity = {"filter_vs_check_cross_mismatches": int(sum(o["cross_mismatch"] for o in outs)), "cross_checked_pods": 20000}
+        if not args.no_cpu:
+            from oracle import orc
+            o = orc.Oracle(w.schema)
+            w.load(o)
+            o.freeze()
+            m = min(n, 4096)
+            op_, oe_ = o.check_bulk_ids_mt(usable_cores() if usable_cores() <= 16 else 16, rt, perm_name, w.res[:m], st, "", w.subj[:m])
+            parity["checked_against_oracle"] = m
+            parity["mismatches"] = int((op_ != outs[0]["perm"][:m]).sum() + (oe_ != outs[0]["err"][:m]).sum())
+        out["parity"] = parity
+        print(json.dumps(out))
+    for e in engines:
+        e.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and (out["parity"].get("mismatches") or out["parity"]["filter_vs_check_cross_mismatches"]):
+        raise SystemExit("PARITY FAILURE in the sharded mixed stream")
 
 
 def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
@@ -202,7 +303,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4"])
+    ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
@@ -232,7 +333,7 @@ def main():
     from aclgpu import workloads
 
     kw = {}
-    if args.workload in ("C2", "C3", "C4"):
+    if args.workload in ("C2", "C3", "C4", "C5"):
         kw["scale"] = args.scale
         if args.batch:
             kw["batch"] = args.batch
@@ -248,6 +349,8 @@ def main():
     rt, perm_name, st = w.check
     n = int(w.res.size)
 
+    if args.workload == "C5":
+        return c5_bench(args, w, world, rank, local_rank, t_gen)
     eng = aclgpu.Engine(w.schema, device=local_rank)
     t0 = time.time()
     w.load(eng)

@@ -273,5 +273,28 @@ def c4(seed: int = 0x5ACE0004, scale: float = 1.0, batch: int = 262144, n_user: 
     return w
 
 
+def c5(seed: int = 0x5ACE0005, scale: float = 1.0, batch: int = 262144, n_lookups: int = 64, n_user: int = 0) -> Workload:
+    """BASELINE config 5: the C4 generator scaled x10 (100 M relationships / 10 M objects at scale 1.0), for the graph
+    sharded by object type; `stream(k)` yields the mixed request stream: 90 % Check batches, 10 % Filter requests."""
+    w = c4(seed=seed, scale=10.0 * scale, batch=batch, n_user=n_user)
+    w.name = "C5"
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xF17E))
+    w.lookup_subjects = rng.integers(0, w.nobjects["user"], size=n_lookups).astype(np.uint32)
+    w.meta["stream_seed"] = seed
+    return w
+
+
+def c5_stream(w: Workload, steps: int):
+    """['C' | ('F', subject id)] * steps, interleaved by the workload's seed; at least one of each kind when steps >= 2."""
+    rng = np.random.Generator(np.random.PCG64(w.meta.get("stream_seed", 0x5ACE0005)))
+    ops = [("F", int(w.lookup_subjects[i % w.lookup_subjects.size])) if rng.random() < 0.1 else "C" for i in range(steps)]
+    if steps >= 2:
+        if all(o == "C" for o in ops):
+            ops[steps // 2] = ("F", int(w.lookup_subjects[0]))
+        if all(o != "C" for o in ops):
+            ops[0] = "C"
+    return ops
+
+
 def by_name(name: str, **kw) -> Workload:
-    return {"C1": c1, "C2": c2, "C3": c3, "C4": c4}[name.upper()](**kw)
+    return {"C1": c1, "C2": c2, "C3": c3, "C4": c4, "C5": c5}[name.upper()](**kw)

@@ -64,6 +64,50 @@ def test_sharded_workload_parity(name, kw, world, aclgpu):
         assert sum(x[3] for x in outs) > 0, "nothing crossed a shard boundary"
 
 
+def test_c5_mixed_stream_reduced(aclgpu):
+    """BASELINE config 5 at reduced scale (200 k relationships, 8 logical shards): every Check batch and every Filter request
+    of the mixed stream equals the oracle's answer."""
+    from aclgpu import sharded, workloads
+    w = workloads.c5(scale=0.002, batch=8000, n_lookups=6, n_user=4000)
+    ops = workloads.c5_stream(w, 12)
+    assert any(o == "C" for o in ops) and any(o != "C" for o in ops)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rt, perm, st = w.check
+    operms, oerrs = o.check_bulk_ids(rt, perm, w.res, st, "", w.subj)
+    engines = []
+
+    def make(rank, nshards):
+        e = aclgpu.Engine(w.schema)
+        w.load(e)
+        engines.append(e)
+        return sharded.GpuShard(e, rank, nshards)
+
+    def run(se):
+        items = se.shard.e.make_items(rt, perm, w.res, st, "", w.subj)
+        got = []
+        for op in ops:
+            if op == "C":
+                p, er = se.check_bulk_ids(items)
+                got.append((p.cpu().numpy(), er.cpu().numpy()))
+            else:
+                got.append(bits(se.lookup_ids_batch(rt, perm, st, "", [op[1]])[0]))
+        return got
+
+    try:
+        outs = sharded.run_logical_shards(8, make, run)
+    finally:
+        for e in engines:
+            e.close()
+    for got in outs:
+        for op, g in zip(ops, got):
+            if op == "C":
+                assert np.array_equal(g[0], operms) and np.array_equal(g[1], oerrs)
+            else:
+                assert np.array_equal(g, np.sort(o.lookup_ids(rt, perm, st, "", op[1]))), op
+
+
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_random_graphs_and_depth(world, aclgpu):
     """Cyclic nesting, arrows, permission-typed usersets (seeded random graphs) and the depth-50 chain whose every
