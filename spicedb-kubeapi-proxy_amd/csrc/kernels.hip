@@ -31,6 +31,12 @@
 namespace acl {
 namespace {
 
+#ifndef ACL_PERTURB
+#define ACL_PERTURB 0  // cost attribution (tools/perturb.sh, profiles/r01_c4_bottleneck_analysis.md): repeat ONE kind of work, results unchanged.
+                       // 1 has[] read / entry, 2 row-descriptor gather / entry, 3 hashed probe / child, 5 edge gather / child,
+                       // 6 ~60 VALU / child, 7 random bucket gather / child, 8 six LDS reads / child, 9 entry re-read / entry
+#endif
+#define ACL_KEEP(x) asm volatile("" ::"v"(x))
 constexpr int kBlock = kWavesPerBlock * 64;
 #ifndef ACL_MIN_WAVES_PER_SIMD
 #define ACL_MIN_WAVES_PER_SIMD 8  // 8 blocks of 4 waves per CU: the kernels are latency bound, residency is what hides it
@@ -124,7 +130,7 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
 
 // hashed row: nb = b1 - b0 buckets of 4 ids, two-choice placement (plan.hpp hashed_row_buckets): the id is in bucket h1
 // or h2 or nowhere -- two INDEPENDENT 16 B gathers in flight together, never a probing chain (with linear probing the
-// slowest of the 64 lanes made almost every wave walk 3-5 dependent buckets; profiles/r01_c4_v5_pmc.md)
+// slowest of the 64 lanes made almost every wave walk 3-5 dependent buckets; profiles/r01_c4_bottleneck_analysis.md)
 __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
     uint32_t h1, h2;
     hashed_row_buckets(want, b1 - b0, &h1, &h2);
@@ -251,6 +257,24 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                         err[e.y] = ITEM_ERR_DEPTH;
                     }
                     e.z |= kProbedBit;
+                    if (ACL_PERTURB == 3) {
+                        const FwdOp pop = ops[progs[meta_slot(e.z)].first];
+                        if (pop.flags & OP_PROBE_HASH) { const bool x = subject_row_contains(g, pop, child ^ 1u, e.w); ACL_KEEP((uint32_t)x); }
+                    }
+                    if (ACL_PERTURB == 5 && !(c & kSelfBit)) { const uint32_t x = edges[s + ((w - t.scan[j]) ^ 1u)]; ACL_KEEP(x); }
+                    if (ACL_PERTURB == 6) {
+                        uint32_t x = child;
+#pragma unroll
+                        for (int q = 0; q < 20; q++) x = x * 0x9E3779B1u + (x >> 7);
+                        ACL_KEEP(x);
+                    }
+                    if (ACL_PERTURB == 7) { const uint4 x = reinterpret_cast<const uint4 *>(g.buckets)[(child * 0x9E3779B1u) >> 12]; ACL_KEEP(x.x); }
+                    if (ACL_PERTURB == 8) {
+                        uint32_t x = 0;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) x += t.meta[(tj + q * 7 + x) & (kTaskCap - 1)];
+                        ACL_KEEP(x);
+                    }
                 }
             }
             const uint64_t b = __ballot(push);
@@ -349,6 +373,9 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
         const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
         bool active = valid && meta != kDeadMeta;
         if (active && has[req]) active = false;  // request already answered HAS: drop its pending work
+        if (ACL_PERTURB == 1 && valid) { const uint32_t x = has[req ^ 0x5555u]; ACL_KEEP(x); }
+        if (ACL_PERTURB == 2 && active) { const uint2 x = reinterpret_cast<const uint2 *>(g.meta)[(id * 2654435761u) % (g.nops + 100000u)]; ACL_KEEP(x.x); }
+        if (ACL_PERTURB == 9 && valid) { const uint4 x = in[(size_t)c * kChunk + s * 64 + (lane ^ 1u)]; ACL_KEEP(x.x); }
         const uint32_t slot = meta_slot(meta), level = meta_level(meta), key = meta_key(meta);
         const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
         SlotProg p{};
