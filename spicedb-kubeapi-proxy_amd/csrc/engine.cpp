@@ -273,8 +273,12 @@ int ensure_reverse(acl_engine *h) {
 
 // Runs iterations 1.. of a level loop until the frontier is empty.  `launch(iter)` enqueues
 // one expansion.  Returns ACL_OK, or ACL_ERR_RESOURCE_EXHAUSTED when the frontier overflowed.
-template <typename F>
-int level_loop(acl_engine *h, uint32_t max_iter, F launch, uint32_t *levels_out) {
+// `tail()` is enqueued after every burst, BEFORE the host learns whether the burst reached the last level: when it did
+// (the common case -- the burst is sized by the previous batch's depth) the batch's epilogue has already run by the time
+// the status read-back completes, instead of costing another launch + sync round trip; when it did not, the epilogue
+// simply runs again after the next burst (it only reads the final has/err).
+template <typename F, typename T>
+int level_loop(acl_engine *h, uint32_t max_iter, F launch, uint32_t *levels_out, T tail) {
     uint32_t next = 1, burst = std::max<uint32_t>(h->levels_hint, 2);
     for (;;) {
         uint32_t last = std::min(max_iter, next + burst - 1);
@@ -284,6 +288,7 @@ int level_loop(acl_engine *h, uint32_t max_iter, F launch, uint32_t *levels_out)
             ev_end(h);
             h->stats.expand_launches++;
         }
+        tail();
         HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         ev_collect(h);
@@ -314,12 +319,17 @@ int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm,
         }
         DevGraph g = h->dev_graph();
         DevFrontier f = h->dev_frontier();
-        HIP_TRY(hipMemsetAsync(h->d_status.p, 0, kStatusWords * sizeof(uint32_t), h->stream));
         ev_begin(h, 0);
-        launch_seed(h->stream, g, f, d_items, n, h->d_has.p, h->d_err.p);
+        launch_seed(h->stream, g, f, d_items, n, h->d_has.p, h->d_err.p);  // also resets the status block
         ev_end(h);
         uint32_t levels = 0;
-        int rc = level_loop(h, kMaxLevels, [&](uint32_t it) { launch_expand(h->stream, g, f, it, h->d_has.p, h->d_err.p); }, &levels);
+        int rc = level_loop(
+            h, kMaxLevels, [&](uint32_t it) { launch_expand(h->stream, g, f, it, h->d_has.p, h->d_err.p); }, &levels,
+            [&] {
+                ev_begin(h, 0);
+                launch_finalize(h->stream, n, h->d_has.p, h->d_err.p, d_perm, d_errout);
+                ev_end(h);
+            });
         if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
             // frontier out of chunks: grow (up to 2^32 entries) and redo the pass
             h->stats.overflow_retries++;
@@ -332,9 +342,6 @@ int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm,
         if (rc) return rc;
         h->levels_hint = levels;
         h->stats.levels_last = levels;
-        ev_begin(h, 0);
-        launch_finalize(h->stream, n, h->d_has.p, h->d_err.p, d_perm, d_errout);
-        ev_end(h);
         h->stats.check_items += n;
         h->stats.check_passes++;
         return ACL_OK;
@@ -690,7 +697,7 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
             HIP_TRY(hipMemcpyAsync(f.counts[0], cc.data(), cc.size() * 4, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope below
             uint32_t levels = 0;
-            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels);
+            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels, [] {});
             if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
                 h->stats.overflow_retries++;
                 if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
@@ -853,10 +860,9 @@ int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *
         rc = alloc_frontier(h, (uint64_t)n * 4);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemsetAsync(h->d_status.p, 0, kStatusWords * sizeof(uint32_t), h->stream));
     ev_begin(h, 0);
     launch_seed(h->stream, h->dev_graph(), h->dev_frontier(), (const uint4 *)d_items, (uint32_t)n, (uint8_t *)d_has, (uint8_t *)d_err,
-                dev_shard(h, nullptr, 0));
+                dev_shard(h, nullptr, 0));  // also resets the status block
     ev_end(h);
     h->stats.check_items += n;
     h->stats.check_passes++;

@@ -26,6 +26,8 @@
 //   all for the common case); further chunks come from one atomicAdd per 1024 entries.
 //
 // Bound: HBM/L2 transactions (random row gathers); no MFMA anywhere by design.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace acl {
@@ -295,10 +297,9 @@ __global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const u
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t need = (n + kChunk - 1) / kChunk;       // chunks holding seeds: ids [0, need)
     const uint32_t readable = max(need, f.nwaves);          // the reader scans every static chunk
-    if (i == 0) {
-        f.nchunks[0] = need > f.nwaves ? need - f.nwaves : 0u;
-        f.any[0] = 1u;
-    }
+    // status block = nchunks[kLevelSlots] | any[kLevelSlots] | overflow | export count, contiguous from f.nchunks:
+    // reset here (no separate memset launch); slot 0 describes the seeds
+    if (i < kStatusWords) f.nchunks[i] = i == 0 ? (need > f.nwaves ? need - f.nwaves : 0u) : (i == kLevelSlots ? 1u : 0u);
     if (i < readable) f.counts[0][i] = i < need ? min(kChunk, n - i * kChunk) : 0u;
     if (i >= n) return;
     uint4 it = items[i];
@@ -665,7 +666,7 @@ int expand_grid_blocks(int device) {
 }
 
 void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const uint4 *items, uint32_t n, uint8_t *has, uint8_t *err, const DevShard &sh) {
-    const uint32_t threads = n > f.nwaves ? n : f.nwaves;
+    const uint32_t threads = std::max(std::max(n, f.nwaves), kStatusWords);
     hipLaunchKernelGGL(k_seed, dim3((threads + 255) / 256), dim3(256), 0, s, g, f, items, n, has, err, sh);
 }
 void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err, const DevShard &sh) {
