@@ -90,7 +90,7 @@ struct acl_engine {
     DevArray<FwdOp> d_ops;
     DevArray<SlotProg> d_progs;
     // reverse graph
-    DevArray<uint32_t> d_roff, d_redges, d_sbb, d_snobj, d_visited;
+    DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj, d_visited;
     DevArray<RevOp> d_rops;
     DevArray<RevProg> d_rprogs, d_rseeds;
     // frontier
@@ -206,7 +206,10 @@ int ensure_snapshot(acl_engine *h) {
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
     if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi && h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
         std::vector<Patch> patches;
+        const uint64_t from_revision = h->snap.revision;
         if (patch_forward(h->store, now, &h->snap, h->shard, &patches)) {
+            // the reverse rows (LookupResources), if they are on the device, follow the same feed
+            bool rev_ok = h->rev_uploaded && patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches);
             HIP_TRY(hipStreamSynchronize(h->stream));  // nothing may still be reading the rows we overwrite
             bool fits = true;
             hipError_t pe = hipSuccess;
@@ -217,6 +220,8 @@ int ensure_snapshot(acl_engine *h) {
                     case Patch::EDGES: fits = fits && h->d_edges.patch(h->snap.edges, p.off, p.n, h->stream, &e1); break;
                     case Patch::BUCKETS: fits = fits && h->d_buckets.patch(h->snap.buckets, p.off, p.n, h->stream, &e1); break;
                     case Patch::OPS: fits = fits && h->d_ops.patch(h->snap.ops, p.off, p.n, h->stream, &e1); break;
+                    case Patch::RMETA: fits = fits && h->d_rmeta.patch(h->snap.rmeta, p.off, p.n, h->stream, &e1); break;
+                    case Patch::REDGES: fits = fits && h->d_redges.patch(h->snap.redges, p.off, p.n, h->stream, &e1); break;
                 }
                 if (e1 != hipSuccess) pe = e1;
             }
@@ -226,9 +231,16 @@ int ensure_snapshot(acl_engine *h) {
                 HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
                 HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
                 HIP_TRY(h->d_ops.upload(h->snap.ops, h->stream));
+                if (rev_ok) {
+                    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, h->stream));
+                    HIP_TRY(h->d_redges.upload(h->snap.redges, h->stream));
+                }
             }
             HIP_TRY(hipStreamSynchronize(h->stream));
-            h->rev_uploaded = false;
+            if (!rev_ok) {  // not patchable (or never built): rebuilt lazily by the next lookup
+                h->rev_uploaded = false;
+                h->snap.has_reverse = false;
+            }
             h->stats.snapshot_patches++;
             h->stats.snapshot_edges = h->snap.nedges;
             h->stats.snapshot_edges_local = h->snap.nedges_local;
@@ -258,7 +270,7 @@ int ensure_reverse(acl_engine *h) {
     if (rc) return rc;
     if (h->rev_uploaded) return ACL_OK;
     build_reverse(h->store, h->store.now(), &h->snap, h->shard);
-    HIP_TRY(h->d_roff.upload(h->snap.roff, h->stream));
+    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, h->stream));
     HIP_TRY(h->d_redges.upload(h->snap.redges, h->stream));
     HIP_TRY(h->d_rops.upload(h->snap.rops, h->stream));
     HIP_TRY(h->d_rprogs.upload(h->snap.rprogs, h->stream));
@@ -267,7 +279,7 @@ int ensure_reverse(acl_engine *h) {
     HIP_TRY(h->d_snobj.upload(h->snap.slot_nobjects, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->rev_uploaded = true;
-    h->stats.snapshot_bytes += h->snap.roff.size() * 4 + h->snap.redges.size() * 4;
+    h->stats.snapshot_bytes += h->snap.rmeta.size() * 4 + h->snap.redges.size() * 4;
     return ACL_OK;
 }
 
@@ -667,7 +679,7 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
         return fail(ACL_ERR_FAILED_PRECONDITION, "lookup: unknown type, permission or subject relation");
     const uint32_t target = (uint32_t)sc.slot(rtype, perm);
     const uint32_t key = sc.subject_key(stype, srel < 0 ? kNoRelation : srel);
-    const uint32_t nobj = h->snap.slot_nobjects[target];
+    const uint32_t nobj = h->store.objects(rtype).count();  // (the bitmaps on the device also cover the headroom ids)
     const size_t need = (nobj + 31) / 32;
     if (words < need) return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
     const size_t vwords = (size_t)((h->snap.visited_bits + 31) / 32);
@@ -677,7 +689,7 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
         const size_t m = std::min(group, n - b);
         HIP_TRY(h->d_visited.ensure(m * std::max<size_t>(vwords, 1)));
         HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, m * std::max<size_t>(vwords, 1) * 4, h->stream));
-        DevReverse r{h->d_roff.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
+        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
         for (int attempt = 0;; attempt++) {
             if (m > h->frontier_entries) {
                 rc = alloc_frontier(h, m * 4);
@@ -752,9 +764,12 @@ int acl_lookup_resources(acl_engine_t *h, const char *rtype, const char *perm, c
             if (sr < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation `") + srel + "` not found under definition `" + stype + "`");
         }
         // the subject may be new to the store; give it an id so `stype:sid#srel` can be its own member
-        uint32_t before = h->store.objects(st).count();
         sub = h->store.objects(st).intern(sid);
-        if (h->store.objects(st).count() != before) h->snap_valid = false;
+        // a subject the reverse rows have no room for (beyond the headroom ids): they are rebuilt by this lookup
+        if (sr >= 0 && h->snap.has_reverse && h->store.objects(st).count() > h->snap.slot_nobjects[sc.slot(st, sr)]) {
+            h->rev_uploaded = false;
+            h->snap.has_reverse = false;
+        }
     }
     return acl_lookup_resources_batch(h, rt, pm, st, sr, &sub, 1, bitmap, words, count);
 }
@@ -951,7 +966,7 @@ int acl_shard_lookup_step(acl_engine_t *h, uint32_t iter, int phase, void *d_exp
     if (rc) return rc;
     if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_step without acl_shard_lookup_begin");
     const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
-    DevReverse r{h->d_roff.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
+    DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
     HIP_TRY(hipMemsetAsync(h->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), h->stream));
     ev_begin(h, 1);
     launch_rev_expand(h->stream, r, h->dev_frontier(), iter, phase == ACL_SHARD_VISIT ? REV_VISIT : REV_EXPAND, dev_shard(h, d_export, export_cap));
@@ -966,7 +981,7 @@ int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entrie
     int rc = shard_ready(h, iter);
     if (rc) return rc;
     if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_import without acl_shard_lookup_begin");
-    DevReverse r{h->d_roff.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, 0};
+    DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, 0};
     launch_rev_import(h->stream, r, h->dev_frontier(), iter, (const uint4 *)d_entries, (uint32_t)n);
     return ACL_OK;
 }
@@ -976,7 +991,7 @@ int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_
     if (h->store_only) return ensure_snapshot(h);
     if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_finish without acl_shard_lookup_begin");
     HIP_TRY(hipSetDevice(h->device));
-    const uint32_t nobj = h->snap.slot_nobjects[h->lk_target];
+    const uint32_t nobj = h->store.objects(h->store.schema().slot_owner[h->lk_target].first).count();
     const size_t need = (nobj + 31) / 32;
     if (h->lk_n && (!d_bitmaps_out || bitmap_words < need))
         return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
@@ -1092,13 +1107,17 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
     bool patched = false;
     const bool current = h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi;
     if (!current) {
+        const uint64_t from_revision = h->snap.revision;
         if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi) patched = patch_forward(h->store, now, &h->snap, h->shard, &patches);
+        if (patched && h->snap.has_reverse && !patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches)) h->snap.has_reverse = false;
         if (!patched) build_forward(h->store, now, &h->snap, h->shard);
         h->snap_valid = true;
     }
+    if (!h->snap.has_reverse) build_reverse(h->store, now, &h->snap, h->shard);  // the hook always carries reverse rows along
     for (const Patch &p : patches) {  // every patch region must lie inside its array
         const size_t sz = p.array == Patch::META ? h->snap.meta.size() : p.array == Patch::EDGES ? h->snap.edges.size()
-                        : p.array == Patch::BUCKETS ? h->snap.buckets.size() : h->snap.ops.size();
+                        : p.array == Patch::BUCKETS ? h->snap.buckets.size() : p.array == Patch::OPS ? h->snap.ops.size()
+                        : p.array == Patch::RMETA ? h->snap.rmeta.size() : h->snap.redges.size();
         if (p.off + p.n > sz) return fail(ACL_ERR_INTERNAL, "patch region outside its array");
     }
     if (patched_out) *patched_out = patched ? 1 : 0;

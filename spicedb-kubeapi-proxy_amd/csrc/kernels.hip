@@ -573,7 +573,8 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                     tstart = id;
                     tcount = 1u | kSelfBit;
                 } else if (id < op.nrows) {
-                    const uint32_t s0 = r.roff[op.roff_base + id], s1 = r.roff[op.roff_base + id + 1];
+                    const uint2 rd = reinterpret_cast<const uint2 *>(r.rmeta)[op.roff_base + id];
+                    const uint32_t s0 = rd.x, s1 = rd.y;
                     if (s1 - s0 > kMaxRow) *f.overflow = 2u;
                     else if (s1 > s0) {
                         want = true;

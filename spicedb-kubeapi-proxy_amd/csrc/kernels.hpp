@@ -32,7 +32,7 @@ struct DevGraph {
     uint32_t nslots, ntypes, nops;
 };
 struct DevReverse {
-    const uint32_t *roff, *redges;
+    const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids
     const RevOp *rops;
     const RevProg *rprogs, *rseeds;
     const uint32_t *slot_bit_base;  // [nslots]

@@ -10,8 +10,7 @@ namespace {
 constexpr uint32_t kMaxOpsPerSlot = 256;
 constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
-// tables are sized for objects that do not exist yet, so that writes naming new objects can be patched in
-inline uint32_t with_headroom(uint32_t n) { return n + n / 4 + 1024; }
+
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 // two-choice insertion with random-walk eviction; false when the row is too tight (the caller gives it more buckets)
 bool cuckoo_insert(uint32_t *row, uint32_t nb, uint32_t id) {
@@ -154,6 +153,9 @@ void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
 }
 
 }  // namespace
+
+// tables are sized for objects that do not exist yet, so that writes naming new objects can be patched in
+uint32_t with_headroom(uint32_t n) { return n + n / 4 + 1024; }
 
 uint32_t shard_of_type(const std::string &type_name, uint32_t world) {
     uint32_t h = 2166136261u;  // FNV-1a
@@ -507,8 +509,7 @@ bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, s
             if (s.type_owner[sc.slot_owner[slot].first] == shard.rank) s.nedges_local += ct.keys.size();
         }
     for (size_t t = 0; t < sc.defs.size(); t++) s.type_nobjects[t] = store.objects((int)t).count();
-    s.has_reverse = false;
-    return true;
+    return true;  // the reverse rows (if built) are now one feed position behind: patch_reverse or rebuild them
 }
 
 // Test hook (acl_selfcheck_snapshot): does the snapshot -- however it got here, built or patched -- hold exactly the
@@ -567,6 +568,39 @@ bool verify_snapshot(Store &store, int64_t now, const Snapshot &s, ShardSpec sha
                 }
             }
             if (stored != live.size()) return bad(rel + ": " + std::to_string(stored) + " stored vs " + std::to_string(live.size()) + " live relationships");
+        }
+    }
+    // reverse rows (when built): subject -> ascending resource ids, exactly the live relationships
+    if (s.has_reverse) {
+        if (s.rlay.size() != (size_t)sc.nslots) return bad("reverse layout does not match the schema");
+        for (int slot = 0; slot < sc.nslots; slot++) {
+            auto [t, m] = sc.slot_owner[slot];
+            const Member &mem = sc.defs[t].members[m];
+            if (mem.is_permission) continue;
+            const std::string rel = sc.defs[t].name + "#" + mem.name + " (reverse)";
+            if (store.objects(t).count() > s.slot_nobjects[slot]) return bad(rel + ": visited bitmap too small for the type's objects");
+            if (s.type_owner[t] != shard.rank) continue;
+            for (size_t k = 0; k < mem.classes.size(); k++) {
+                const Snapshot::RevLayout &l = s.rlay[slot][k];
+                const ClassTable &ct = tables[slot][k];
+                size_t live = 0, stored = 0;
+                for (uint64_t key : ct.keys) live += store.live(ct, key, now) ? 1 : 0;
+                if (!l.any) {
+                    if (live) return bad(rel + ": class has relationships but no reverse rows");
+                    continue;
+                }
+                for (uint32_t sid = 0; sid < l.nrows; sid++) {
+                    const uint32_t *md = s.rmeta.data() + 2 * ((size_t)l.base + sid);
+                    if (md[1] < md[0] || md[1] > s.redges.size()) return bad(rel + ": descriptor out of range");
+                    for (uint32_t e = md[0]; e < md[1]; e++) {
+                        if (e > md[0] && s.redges[e - 1] >= s.redges[e]) return bad(rel + ": row not strictly ascending");
+                        const uint64_t key = (uint64_t)s.redges[e] << 32 | sid;
+                        if (!ct.contains(key) || !store.live(ct, key, now)) return bad(rel + ": row holds a dead relationship");
+                        stored++;
+                    }
+                }
+                if (stored != live) return bad(rel + ": " + std::to_string(stored) + " stored vs " + std::to_string(live) + " live relationships");
+            }
         }
     }
     // leaf flags: wherever an op still trusts them, a flagged child must really have nothing to enumerate

@@ -66,7 +66,7 @@ struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create
 };
 struct RevOp {          // 16 B
     uint32_t flags;     // OP_ENUM (reverse row) or OP_PUSH_SAME
-    uint32_t roff_base; // index into `roff`
+    uint32_t roff_base; // first row descriptor (uint2 {start, end} per subject id) in `rmeta`
     uint32_t nrows;     // subject id space covered
     uint32_t target;    // slot that becomes true
 };
@@ -87,7 +87,7 @@ struct RelLayout {
     std::vector<ClassLayout> cls;
 };
 struct Patch {  // a region of a snapshot array that changed on the host and must be re-uploaded
-    enum Array { META = 0, EDGES = 1, BUCKETS = 2, OPS = 3 } array;
+    enum Array { META = 0, EDGES = 1, BUCKETS = 2, OPS = 3, RMETA = 4, REDGES = 5 } array;
     size_t off, n;  // in elements of that array (u32 words; FwdOp for OPS)
 };
 
@@ -113,12 +113,14 @@ struct Snapshot {
     std::vector<uint32_t> type_owner;  // [ntypes] shard of each type
     // reverse (built on demand)
     bool has_reverse = false;
-    std::vector<uint32_t> roff, redges;
+    std::vector<uint32_t> rmeta, redges;  // reverse rows: uint2 {start, end} per (relation, class, SUBJECT id) into redges (resource ids)
+    struct RevLayout { bool any = false; uint32_t base = 0, nrows = 0; };  // base in uint2 units; nrows includes headroom
+    std::vector<std::vector<RevLayout>> rlay;  // [slot][class]
     std::vector<RevOp> rops;
     std::vector<RevProg> rprogs;   // [nslots]: parents of a true state
     std::vector<RevProg> rseeds;   // [nkeys]: seeds for a subject key
     std::vector<uint32_t> slot_bit_base;  // [nslots+1] first bit of each slot's visited bitmap (32-bit aligned)
-    std::vector<uint32_t> slot_nobjects;  // [nslots] id space of the slot's type when the reverse rows were built
+    std::vector<uint32_t> slot_nobjects;  // [nslots] id space of the slot's type the visited bitmaps cover (with headroom for new objects)
     uint64_t visited_bits = 0;
 };
 
@@ -136,6 +138,10 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = 
 // patch (bulk load, a class becoming live, table headroom exhausted, too many changes): rebuild instead.
 // On success `patches` lists the regions to re-upload and the reverse rows (if any) are invalidated.
 bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
+// Same for the reverse rows (LookupResources); call after a successful patch_forward with the same feed position
+// (`from_revision` = the snapshot's revision BEFORE patch_forward).  false: rebuild the reverse rows instead.
+bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
+uint32_t with_headroom(uint32_t n);
 bool verify_snapshot(Store &store, int64_t now, const Snapshot &snap, ShardSpec shard, std::string *why);
 void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
 

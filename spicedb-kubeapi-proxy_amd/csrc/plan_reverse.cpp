@@ -25,11 +25,12 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     std::vector<uint32_t> type_owner;
     for (const Definition &d : sc.defs) type_owner.push_back(shard_of_type(d.name, shard.world));
     auto &tables = store.tables();
-    s.roff.clear();
+    s.rmeta.clear();
     s.redges.clear();
     s.rops.clear();
-    // reverse rows per (relation slot, class): subject id -> sorted resource ids
-    struct RevLayout { bool any = false; uint32_t roff_base = 0, nrows = 0; };
+    // reverse rows per (relation slot, class): subject id -> resource ids; one {start, end} descriptor per subject,
+    // sized with headroom so that writes naming new subjects can be patched in (patch_reverse)
+    using RevLayout = Snapshot::RevLayout;
     std::vector<std::vector<RevLayout>> rl(sc.nslots);
     std::vector<uint32_t> cursor;
     for (int slot = 0; slot < sc.nslots; slot++) {
@@ -47,7 +48,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
                 continue;
             }
             const bool filt = !ct.expiry.empty();
-            const uint32_t ns = store.objects(mem.classes[k].stype).count();
+            const uint32_t ns = with_headroom(store.objects(mem.classes[k].stype).count());
             size_t total = 0;
             for (uint64_t key : ct.keys)
                 if (!filt || store.live(ct, key, now)) total++;
@@ -55,25 +56,26 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             RevLayout &l = rl[slot][k];
             l.any = true;
             l.nrows = ns;
-            l.roff_base = (uint32_t)s.roff.size();
-            s.roff.resize(s.roff.size() + ns + 1, 0);
-            uint32_t *ro = s.roff.data() + l.roff_base;
+            l.base = (uint32_t)(s.rmeta.size() / 2);
+            s.rmeta.resize(s.rmeta.size() + 2 * (size_t)ns, 0);
+            cursor.assign((size_t)ns + 1, 0);
             for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) ro[(uint32_t)key]++;
+                if (!filt || store.live(ct, key, now)) cursor[(uint32_t)key + 1]++;
+            uint32_t *rm = s.rmeta.data() + 2 * (size_t)l.base;
             uint32_t run = (uint32_t)s.redges.size();
             for (uint32_t i = 0; i < ns; i++) {
-                uint32_t c = ro[i];
-                ro[i] = run;
+                const uint32_t c = cursor[i + 1];
+                rm[2 * i] = run;
+                cursor[i] = run;
                 run += c;
+                rm[2 * i + 1] = run;
             }
-            ro[ns] = run;
             s.redges.resize(run);
-            cursor.assign(ro, ro + ns);
             for (uint64_t key : ct.keys)  // keys ascend by resource => each reverse row ascends by resource
                 if (!filt || store.live(ct, key, now)) s.redges[cursor[(uint32_t)key]++] = (uint32_t)(key >> 32);
         }
     }
-    if (s.roff.empty()) s.roff.push_back(0);
+    if (s.rmeta.empty()) s.rmeta.assign(2, 0);
     if (s.redges.empty()) s.redges.push_back(0);
     bool remote = false;  // set by enum_op when a live parent row set belongs to another shard
     auto enum_op = [&](int rel_slot, size_t k, int target) {
@@ -85,7 +87,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         }
         RevOp op{};
         op.flags = OP_ENUM;
-        op.roff_base = l.roff_base;
+        op.roff_base = l.base;
         op.nrows = l.nrows;
         op.target = (uint32_t)target;
         s.rops.push_back(op);
@@ -165,12 +167,71 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     uint64_t bits = 0;
     for (int slot = 0; slot < sc.nslots; slot++) {
         s.slot_bit_base[slot] = (uint32_t)bits;
-        s.slot_nobjects[slot] = store.objects(sc.slot_owner[slot].first).count();
+        s.slot_nobjects[slot] = with_headroom(store.objects(sc.slot_owner[slot].first).count());
         bits += ((uint64_t)s.slot_nobjects[slot] + 31) / 32 * 32;
     }
     s.slot_bit_base[sc.nslots] = (uint32_t)bits;
     s.visited_bits = bits;
+    s.rlay = std::move(rl);
     s.has_reverse = true;
+}
+
+
+bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches) {
+    Snapshot &s = *snap;
+    if (!s.has_reverse || s.rlay.empty()) return false;
+    std::vector<Store::Change> ch;
+    if (!store.raw_changes_since(from_revision, &ch)) return false;
+    const Schema &sc = store.schema();
+    // new objects must fit the visited bitmaps and the descriptor tables
+    for (int slot = 0; slot < sc.nslots; slot++)
+        if (store.objects(sc.slot_owner[slot].first).count() > s.slot_nobjects[slot]) return false;
+    std::sort(ch.begin(), ch.end(), [](const Store::Change &a, const Store::Change &b) {
+        return a.slot != b.slot ? a.slot < b.slot : a.cls != b.cls ? a.cls < b.cls : a.key < b.key;
+    });
+    auto &tables = store.tables();
+    for (const Store::Change &c : ch) {  // first pass: nothing is modified before we know everything is patchable
+        const auto &l = s.rlay[c.slot][c.cls];
+        const ClassTable &ct = tables[c.slot][c.cls];
+        const bool want = ct.contains(c.key) && store.live(ct, c.key, now);
+        if (!l.any && want) return false;  // a class became live: parent programs change
+        if (l.any && s.type_owner[sc.slot_owner[c.slot].first] == shard.rank && (uint32_t)c.key >= l.nrows) return false;
+    }
+    for (size_t i = 0; i < ch.size(); i++) {
+        const Store::Change &c = ch[i];
+        if (i && ch[i - 1].slot == c.slot && ch[i - 1].cls == c.cls && ch[i - 1].key == c.key) continue;
+        if (s.type_owner[sc.slot_owner[c.slot].first] != shard.rank) continue;
+        const auto &l = s.rlay[c.slot][c.cls];
+        if (!l.any) continue;
+        const ClassTable &ct = tables[c.slot][c.cls];
+        const bool want = ct.contains(c.key) && store.live(ct, c.key, now);
+        const uint32_t res = (uint32_t)(c.key >> 32), sid = (uint32_t)c.key;
+        uint32_t *md = s.rmeta.data() + 2 * ((size_t)l.base + sid);
+        const uint32_t a = md[0], b = md[1];
+        const auto first = s.redges.begin() + a, last = s.redges.begin() + b;
+        const auto it = std::lower_bound(first, last, res);
+        const bool have = it != last && *it == res;
+        if (want == have) continue;
+        if (want) {  // relocate the row to the end with the resource inserted in order
+            std::vector<uint32_t> row(first, last);
+            row.insert(row.begin() + (it - first), res);
+            const uint32_t start = (uint32_t)s.redges.size();
+            s.redges.insert(s.redges.end(), row.begin(), row.end());
+            md = s.rmeta.data() + 2 * ((size_t)l.base + sid);
+            md[0] = start;
+            md[1] = (uint32_t)s.redges.size();
+            s.garbage_words += b - a;
+            patches->push_back(Patch{Patch::REDGES, start, (size_t)(md[1] - start)});
+        } else {  // shrink in place
+            const uint32_t pos = (uint32_t)(it - s.redges.begin());
+            std::copy(s.redges.begin() + pos + 1, s.redges.begin() + b, s.redges.begin() + pos);
+            md[1]--;
+            s.garbage_words++;
+            if (md[1] > md[0]) patches->push_back(Patch{Patch::REDGES, md[0], (size_t)(md[1] - md[0])});
+        }
+        patches->push_back(Patch{Patch::RMETA, (size_t)(md - s.rmeta.data()), 2});
+    }
+    return true;
 }
 
 }  // namespace acl
