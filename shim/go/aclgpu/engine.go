@@ -1,0 +1,133 @@
+// Package aclgpu binds libaclgpu.so (include/aclgpu.h), the MI355X-native batched ACL-check engine, and implements the
+// authzed v1.PermissionsServiceClient / v1.WatchServiceClient interfaces the proxy holds in proxy.Options
+// (reference pkg/proxy/options.go:81-82).  UNBUILT in this repository: see README.md.
+package aclgpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../../spicedb-kubeapi-proxy_amd/lib -laclgpu -Wl,-rpath,${SRCDIR}/../../../spicedb-kubeapi-proxy_amd/lib
+#include <stdlib.h>
+#include "aclgpu.h"
+
+// cgo cannot take the address of a Go callback directly: trampolines defined in callbacks.go
+extern void goReadCallback(void *user, acl_relationship_t *rel);
+extern void goWatchCallback(void *user, uint64_t revision, int32_t op, acl_relationship_t *rel);
+static inline int acl_read_go(acl_engine_t *h, const acl_filter_t *f, void *user) { return acl_read(h, f, (acl_read_cb)goReadCallback, user); }
+static inline int acl_watch_poll_go(acl_engine_t *h, uint64_t after, const int *types, int n, void *user, uint64_t *rev) {
+	return acl_watch_poll(h, after, types, n, (acl_watch_cb)goWatchCallback, user, rev);
+}
+*/
+import "C"
+
+import (
+	"strconv"
+	"unsafe"
+
+	v1 "github.com/authzed/authzed-go/proto/authzed/api/v1"
+	"google.golang.org/grpc/codes"
+	"google.golang.org/grpc/status"
+)
+
+// Config mirrors acl_config_t plus the micro-batcher settings (acl_batcher_start).
+type Config struct {
+	Device             int32  // HIP device ordinal, -1 = current
+	FrontierEntries    uint64 // 0 = default
+	BatchMaxItems      uint32 // 0 = no micro-batching of single checks
+	BatchMaxWaitMicros uint32
+}
+
+// Engine owns one acl_engine_t.  All methods are safe for concurrent use (the C ABI is).
+type Engine struct{ h *C.acl_engine_t }
+
+func lastError(rc C.int) error {
+	return status.Error(codes.Code(rc), C.GoString(C.acl_last_error())) // return codes ARE gRPC codes (aclgpu.h)
+}
+
+// Open replaces spicedb.NewServer (reference pkg/spicedb/spicedb.go:18-71): schema + bootstrap relationships
+// (pkg/spicedb/bootstrap.yaml) -> a running engine.
+func Open(cfg Config, schema, relationships string) (*Engine, error) {
+	var h *C.acl_engine_t
+	c := C.acl_config_t{device: C.int32_t(cfg.Device), frontier_entries: C.uint64_t(cfg.FrontierEntries)}
+	if rc := C.acl_open(&c, &h); rc != 0 {
+		return nil, lastError(rc)
+	}
+	cs, cr := C.CString(schema), C.CString(relationships)
+	defer C.free(unsafe.Pointer(cs))
+	defer C.free(unsafe.Pointer(cr))
+	if rc := C.acl_load_bootstrap(h, cs, C.size_t(len(schema)), cr, C.size_t(len(relationships))); rc != 0 {
+		C.acl_close(h)
+		return nil, lastError(rc)
+	}
+	if cfg.BatchMaxItems > 0 {
+		if rc := C.acl_batcher_start(h, C.uint32_t(cfg.BatchMaxItems), C.uint32_t(cfg.BatchMaxWaitMicros)); rc != 0 {
+			C.acl_close(h)
+			return nil, lastError(rc)
+		}
+	}
+	return &Engine{h}, nil
+}
+
+func (e *Engine) Close() { C.acl_close(e.h) }
+
+// zedToken: the store revision as an opaque token (activity.go:76 only stores and compares it).
+func (e *Engine) zedToken() *v1.ZedToken {
+	return &v1.ZedToken{Token: "aclgpu-" + strconv.FormatUint(uint64(C.acl_revision(e.h)), 10)}
+}
+
+// cstrings allocates C strings and frees them together.
+type cstrings struct{ ptrs []unsafe.Pointer }
+
+func (c *cstrings) add(s string) *C.char {
+	p := C.CString(s)
+	c.ptrs = append(c.ptrs, unsafe.Pointer(p))
+	return p
+}
+func (c *cstrings) free() {
+	for _, p := range c.ptrs {
+		C.free(p)
+	}
+}
+
+func (c *cstrings) item(resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) C.acl_check_item_t {
+	var it C.acl_check_item_t // nil members (an empty request) stay NULL: the engine answers InvalidArgument (options_test.go:101-102)
+	if resource != nil {
+		it.resource_type, it.resource_id = c.add(resource.ObjectType), c.add(resource.ObjectId)
+	}
+	it.permission = c.add(permission)
+	if subject != nil && subject.Object != nil {
+		it.subject_type, it.subject_id = c.add(subject.Object.ObjectType), c.add(subject.Object.ObjectId)
+		it.subject_relation = c.add(subject.OptionalRelation)
+	}
+	return it
+}
+
+func (c *cstrings) filter(f *v1.RelationshipFilter, op C.int32_t) C.acl_filter_t {
+	out := C.acl_filter_t{op: op, resource_type: c.add(f.ResourceType)}
+	if f.OptionalResourceId != "" {
+		out.resource_id = c.add(f.OptionalResourceId)
+	}
+	if f.OptionalRelation != "" {
+		out.relation = c.add(f.OptionalRelation)
+	}
+	if sf := f.OptionalSubjectFilter; sf != nil {
+		out.subject_type = c.add(sf.SubjectType)
+		if sf.OptionalSubjectId != "" {
+			out.subject_id = c.add(sf.OptionalSubjectId)
+		}
+		if sf.OptionalRelation != nil {
+			out.subject_relation = c.add(sf.OptionalRelation.Relation) // "" = only relationships without a subject relation
+		}
+	}
+	return out
+}
+
+func relationshipFromC(r *C.acl_relationship_t) *v1.Relationship {
+	return &v1.Relationship{
+		Resource: &v1.ObjectReference{ObjectType: C.GoString(r.resource_type), ObjectId: C.GoString(r.resource_id)},
+		Relation: C.GoString(r.relation),
+		Subject: &v1.SubjectReference{
+			Object:           &v1.ObjectReference{ObjectType: C.GoString(r.subject_type), ObjectId: C.GoString(r.subject_id)},
+			OptionalRelation: C.GoString(r.subject_relation),
+		},
+	}
+}

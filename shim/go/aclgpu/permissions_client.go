@@ -1,0 +1,239 @@
+package aclgpu
+
+/*
+#include <stdlib.h>
+#include "aclgpu.h"
+static inline int acl_read_go(acl_engine_t *h, const acl_filter_t *f, void *user);
+*/
+import "C"
+
+import (
+	"context"
+	"io"
+	"math/bits"
+	"runtime/cgo"
+	"unsafe"
+
+	v1 "github.com/authzed/authzed-go/proto/authzed/api/v1"
+	"google.golang.org/grpc"
+	"google.golang.org/grpc/codes"
+	"google.golang.org/grpc/metadata"
+	"google.golang.org/grpc/status"
+)
+
+type permissionsClient struct{ e *Engine }
+
+// NewPermissionsClient is what goes into proxy.Options.PermissionsClient (pkg/proxy/options.go:82).
+func NewPermissionsClient(e *Engine) v1.PermissionsServiceClient { return &permissionsClient{e} }
+
+// CheckPermission: pkg/authz/watch.go:50 and every 1-item check expression (check.go:23-48).  Concurrent callers share
+// one device pass through the micro-batcher (acl_check_one).
+func (p *permissionsClient) CheckPermission(ctx context.Context, in *v1.CheckPermissionRequest, _ ...grpc.CallOption) (*v1.CheckPermissionResponse, error) {
+	var cs cstrings
+	defer cs.free()
+	it := cs.item(in.Resource, in.Permission, in.Subject)
+	var perm C.uint8_t
+	var perr C.int32_t
+	if rc := C.acl_check_one(p.e.h, &it, &perm, &perr); rc != 0 {
+		return nil, lastError(rc)
+	}
+	if perr != 0 {
+		return nil, status.Error(codes.Code(perr), "check failed") // e.g. InvalidArgument for an empty request
+	}
+	return &v1.CheckPermissionResponse{CheckedAt: p.e.zedToken(), Permissionship: v1.CheckPermissionResponse_Permissionship(perm)}, nil
+}
+
+// CheckBulkPermissions: pkg/authz/check.go:48, postfilter.go:134.  Pairs[i] answers Items[i] (check.go:54-57).
+func (p *permissionsClient) CheckBulkPermissions(ctx context.Context, in *v1.CheckBulkPermissionsRequest, _ ...grpc.CallOption) (*v1.CheckBulkPermissionsResponse, error) {
+	n := len(in.Items)
+	out := &v1.CheckBulkPermissionsResponse{CheckedAt: p.e.zedToken(), Pairs: make([]*v1.CheckBulkPermissionsPair, n)}
+	if n == 0 {
+		return out, nil
+	}
+	var cs cstrings
+	defer cs.free()
+	items := make([]C.acl_check_item_t, n)
+	for i, it := range in.Items {
+		items[i] = cs.item(it.Resource, it.Permission, it.Subject)
+	}
+	perm := make([]C.uint8_t, n)
+	errs := make([]C.int32_t, n)
+	if rc := C.acl_check_bulk(p.e.h, &items[0], C.size_t(n), &perm[0], &errs[0]); rc != 0 {
+		return nil, lastError(rc)
+	}
+	for i := range in.Items {
+		pair := &v1.CheckBulkPermissionsPair{Request: in.Items[i]}
+		if errs[i] != 0 {
+			pair.Response = &v1.CheckBulkPermissionsPair_Error{Error: status.New(codes.Code(errs[i]), "check failed").Proto()}
+		} else {
+			pair.Response = &v1.CheckBulkPermissionsPair_Item{Item: &v1.CheckBulkPermissionsResponseItem{
+				Permissionship: v1.CheckPermissionResponse_Permissionship(perm[i])}} // ACL_PERM_* == the proto enum values
+		}
+		out.Pairs[i] = pair
+	}
+	return out, nil
+}
+
+// LookupResources: pkg/authz/lookups.go:65; the proxy drains the stream until io.EOF (lookups.go:75-83).
+func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupResourcesRequest, _ ...grpc.CallOption) (v1.PermissionsService_LookupResourcesClient, error) {
+	var cs cstrings
+	defer cs.free()
+	var st, sid, srel string
+	if in.Subject != nil && in.Subject.Object != nil {
+		st, sid, srel = in.Subject.Object.ObjectType, in.Subject.Object.ObjectId, in.Subject.OptionalRelation
+	}
+	rt := cs.add(in.ResourceObjectType)
+	typeID := C.acl_type_id(p.e.h, rt)
+	words := (uint32(C.acl_object_count(p.e.h, typeID)) + 1 + 31) / 32 + 1 // +1: the call may intern the subject
+	bm := make([]C.uint32_t, words)
+	var count C.uint64_t
+	if rc := C.acl_lookup_resources(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), &bm[0], C.size_t(words), &count); rc != 0 {
+		return nil, lastError(rc)
+	}
+	return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: bm, at: p.e.zedToken()}, nil
+}
+
+// bitmapStream turns the result bitmap into the stream the reference consumes: one HAS_PERMISSION message per set bit.
+type bitmapStream struct {
+	ctx    context.Context
+	e      *Engine
+	typeID C.int
+	bm     []C.uint32_t
+	word   int
+	at     *v1.ZedToken
+}
+
+func (s *bitmapStream) Recv() (*v1.LookupResourcesResponse, error) {
+	if err := s.ctx.Err(); err != nil { // LR uses the HTTP request context (responsefilterer.go:168)
+		return nil, status.FromContextError(err).Err()
+	}
+	for s.word < len(s.bm) && s.bm[s.word] == 0 {
+		s.word++
+	}
+	if s.word == len(s.bm) {
+		return nil, io.EOF
+	}
+	bit := bits.TrailingZeros32(uint32(s.bm[s.word]))
+	s.bm[s.word] &^= 1 << uint(bit)
+	name := C.acl_object_name(s.e.h, s.typeID, C.uint32_t(s.word*32+bit))
+	return &v1.LookupResourcesResponse{LookedUpAt: s.at, ResourceObjectId: C.GoString(name),
+		Permissionship: v1.LookupPermissionship_LOOKUP_PERMISSIONSHIP_HAS_PERMISSION}, nil
+}
+func (s *bitmapStream) Header() (metadata.MD, error) { return nil, nil }
+func (s *bitmapStream) Trailer() metadata.MD         { return nil }
+func (s *bitmapStream) CloseSend() error             { return nil }
+func (s *bitmapStream) Context() context.Context     { return s.ctx }
+func (s *bitmapStream) SendMsg(any) error            { return nil }
+func (s *bitmapStream) RecvMsg(any) error            { return io.EOF }
+
+// WriteRelationships: pkg/authz/distributedtx/activity.go:60.  Atomic; preconditions see the pre-write state; AlreadyExists
+// for a duplicate CREATE and FailedPrecondition for an unmet precondition drive the workflow's conflict logic
+// (workflow.go:187-201); InvalidArgument is unrecoverable during rollback (workflow.go:115-119).
+func (p *permissionsClient) WriteRelationships(ctx context.Context, in *v1.WriteRelationshipsRequest, _ ...grpc.CallOption) (*v1.WriteRelationshipsResponse, error) {
+	var cs cstrings
+	defer cs.free()
+	ups := make([]C.acl_update_t, len(in.Updates)+1)
+	for i, u := range in.Updates {
+		r := u.Relationship
+		rel := C.acl_relationship_t{resource_type: cs.add(r.Resource.ObjectType), resource_id: cs.add(r.Resource.ObjectId), relation: cs.add(r.Relation),
+			subject_type: cs.add(r.Subject.Object.ObjectType), subject_id: cs.add(r.Subject.Object.ObjectId), subject_relation: cs.add(r.Subject.OptionalRelation)}
+		if r.OptionalExpiresAt != nil {
+			rel.expires_at = C.int64_t(r.OptionalExpiresAt.Seconds)
+		}
+		ups[i] = C.acl_update_t{op: C.int32_t(u.Operation), rel: rel} // OPERATION_CREATE/TOUCH/DELETE == ACL_OP_*
+	}
+	pre := make([]C.acl_filter_t, len(in.OptionalPreconditions)+1)
+	for i, pc := range in.OptionalPreconditions {
+		pre[i] = cs.filter(pc.Filter, C.int32_t(pc.Operation)) // OPERATION_MUST_NOT_MATCH/MUST_MATCH == ACL_PRE_*
+	}
+	var rev C.uint64_t
+	if rc := C.acl_write(p.e.h, &ups[0], C.int(len(in.Updates)), &pre[0], C.int(len(in.OptionalPreconditions)), &rev); rc != 0 {
+		return nil, lastError(rc)
+	}
+	return &v1.WriteRelationshipsResponse{WrittenAt: p.e.zedToken()}, nil
+}
+
+// DeleteRelationships: e2e/util_test.go:66.
+func (p *permissionsClient) DeleteRelationships(ctx context.Context, in *v1.DeleteRelationshipsRequest, _ ...grpc.CallOption) (*v1.DeleteRelationshipsResponse, error) {
+	var cs cstrings
+	defer cs.free()
+	f := cs.filter(in.RelationshipFilter, 0)
+	var n, rev C.uint64_t
+	if rc := C.acl_delete_by_filter(p.e.h, &f, &n, &rev); rc != 0 {
+		return nil, lastError(rc)
+	}
+	return &v1.DeleteRelationshipsResponse{DeletedAt: p.e.zedToken(), RelationshipsDeletedCount: uint64(n)}, nil
+}
+
+// ReadRelationships: activity.go:107,154; e2e/util_test.go:27.  The matches are buffered, then streamed.
+func (p *permissionsClient) ReadRelationships(ctx context.Context, in *v1.ReadRelationshipsRequest, _ ...grpc.CallOption) (v1.PermissionsService_ReadRelationshipsClient, error) {
+	var cs cstrings
+	defer cs.free()
+	f := cs.filter(in.RelationshipFilter, 0)
+	sink := &readSink{}
+	hdl := cgo.NewHandle(sink)
+	defer hdl.Delete()
+	if rc := C.acl_read_go(p.e.h, &f, unsafe.Pointer(uintptr(hdl))); rc != 0 {
+		return nil, lastError(rc)
+	}
+	return &relStream{ctx: ctx, rels: sink.rels, at: p.e.zedToken()}, nil
+}
+
+type relStream struct {
+	ctx  context.Context
+	rels []*v1.Relationship
+	at   *v1.ZedToken
+}
+
+func (s *relStream) Recv() (*v1.ReadRelationshipsResponse, error) {
+	if len(s.rels) == 0 {
+		return nil, io.EOF
+	}
+	r := s.rels[0]
+	s.rels = s.rels[1:]
+	return &v1.ReadRelationshipsResponse{ReadAt: s.at, Relationship: r}, nil
+}
+func (s *relStream) Header() (metadata.MD, error) { return nil, nil }
+func (s *relStream) Trailer() metadata.MD         { return nil }
+func (s *relStream) CloseSend() error             { return nil }
+func (s *relStream) Context() context.Context     { return s.ctx }
+func (s *relStream) SendMsg(any) error            { return nil }
+func (s *relStream) RecvMsg(any) error            { return io.EOF }
+
+// Never called by the proxy (SURVEY.md 8(b)): Unimplemented, as a real server without the feature would answer.
+func (p *permissionsClient) LookupSubjects(context.Context, *v1.LookupSubjectsRequest, ...grpc.CallOption) (v1.PermissionsService_LookupSubjectsClient, error) {
+	return nil, status.Error(codes.Unimplemented, "not implemented by the GPU ACL engine")
+}
+func (p *permissionsClient) ExpandPermissionTree(context.Context, *v1.ExpandPermissionTreeRequest, ...grpc.CallOption) (*v1.ExpandPermissionTreeResponse, error) {
+	return nil, status.Error(codes.Unimplemented, "not implemented by the GPU ACL engine")
+}
+func (p *permissionsClient) ExportBulkRelationships(context.Context, *v1.ExportBulkRelationshipsRequest, ...grpc.CallOption) (v1.PermissionsService_ExportBulkRelationshipsClient, error) {
+	return nil, status.Error(codes.Unimplemented, "not implemented by the GPU ACL engine")
+}
+func (p *permissionsClient) ImportBulkRelationships(context.Context, ...grpc.CallOption) (v1.PermissionsService_ImportBulkRelationshipsClient, error) {
+	return nil, status.Error(codes.Unimplemented, "not implemented by the GPU ACL engine")
+}
+
+// KeepMask is the fused form of filterItemsWithBulkPermissions (pkg/authz/postfilter.go:58-182) for callers patched to use
+// it: pairs = the resolved PostFilter checks of all list items, off[i]..off[i+1] = item i's pairs; true = keep the item.
+func (e *Engine) KeepMask(pairs []*v1.CheckBulkPermissionsRequestItem, off []uint32) ([]bool, error) {
+	k := len(off) - 1
+	if k <= 0 {
+		return nil, nil
+	}
+	var cs cstrings
+	defer cs.free()
+	items := make([]C.acl_check_item_t, len(pairs)+1)
+	for i, it := range pairs {
+		items[i] = cs.item(it.Resource, it.Permission, it.Subject)
+	}
+	keep := make([]C.uint8_t, k)
+	if rc := C.acl_check_bulk_keep(e.h, &items[0], C.size_t(len(pairs)), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(k), &keep[0]); rc != 0 {
+		return nil, lastError(rc)
+	}
+	out := make([]bool, k)
+	for i := range out {
+		out[i] = keep[i] != 0
+	}
+	return out, nil
+}
