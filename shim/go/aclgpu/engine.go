@@ -6,16 +6,7 @@ package aclgpu
 /*
 #cgo CFLAGS: -I${SRCDIR}/../../../include
 #cgo LDFLAGS: -L${SRCDIR}/../../../spicedb-kubeapi-proxy_amd/lib -laclgpu -Wl,-rpath,${SRCDIR}/../../../spicedb-kubeapi-proxy_amd/lib
-#include <stdlib.h>
-#include "aclgpu.h"
-
-// cgo cannot take the address of a Go callback directly: trampolines defined in callbacks.go
-extern void goReadCallback(void *user, acl_relationship_t *rel);
-extern void goWatchCallback(void *user, uint64_t revision, int32_t op, acl_relationship_t *rel);
-static inline int acl_read_go(acl_engine_t *h, const acl_filter_t *f, void *user) { return acl_read(h, f, (acl_read_cb)goReadCallback, user); }
-static inline int acl_watch_poll_go(acl_engine_t *h, uint64_t after, const int *types, int n, void *user, uint64_t *rev) {
-	return acl_watch_poll(h, after, types, n, (acl_watch_cb)goWatchCallback, user, rev);
-}
+#include "shim.h"
 */
 import "C"
 

@@ -1,9 +1,7 @@
 package aclgpu
 
 /*
-#include <stdlib.h>
-#include "aclgpu.h"
-static inline int acl_read_go(acl_engine_t *h, const acl_filter_t *f, void *user);
+#include "shim.h"
 */
 import "C"
 

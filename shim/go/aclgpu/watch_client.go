@@ -1,8 +1,7 @@
 package aclgpu
 
 /*
-#include "aclgpu.h"
-static inline int acl_watch_poll_go(acl_engine_t *h, uint64_t after, const int *types, int n, void *user, uint64_t *rev);
+#include "shim.h"
 */
 import "C"
 
