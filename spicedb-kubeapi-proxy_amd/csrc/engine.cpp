@@ -107,7 +107,7 @@ struct acl_engine {
     uint32_t levels_hint = 6;
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
     size_t lk_n = 0;
-    DevArray<uint32_t> d_itemoff;
+    DevArray<uint32_t> d_itemoff, d_sids;
     DevArray<uint8_t> d_keep;
     // micro-batching front-end (acl_check_one): concurrent single checks ride one device pass
     struct Waiter {
@@ -684,11 +684,11 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
     if (words < need) return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
     const size_t vwords = (size_t)((h->snap.visited_bits + 31) / 32);
     const size_t group = std::max<size_t>(1, std::min<size_t>(n ? n : 1, ((size_t)1 << 28) / std::max<size_t>(vwords, 1)));  // <= 1 GiB of visited bits
-    std::vector<uint4> seeds;
     for (size_t b = 0; b < n; b += group) {
         const size_t m = std::min(group, n - b);
         HIP_TRY(h->d_visited.ensure(m * std::max<size_t>(vwords, 1)));
-        HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, m * std::max<size_t>(vwords, 1) * 4, h->stream));
+        HIP_TRY(h->d_sids.ensure(m));
+        HIP_TRY(hipMemcpyAsync(h->d_sids.p, sids + b, m * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));  // pageable source: staged before return
         DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
         for (int attempt = 0;; attempt++) {
             if (m > h->frontier_entries) {
@@ -696,37 +696,24 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, 
                 if (rc) return rc;
             }
             DevFrontier f = h->dev_frontier();
-            seeds.resize(m);
-            for (size_t i = 0; i < m; i++) seeds[i] = make_uint4(sids[b + i], (uint32_t)i, key /* dist 0 */, 0);
-            // seeds fill chunks [0, need); the reader scans every static chunk, so publish counts for all of them
-            const size_t need_chunks = (m + kChunk - 1) / kChunk;
-            std::vector<uint32_t> st(kStatusWords, 0), cc(std::max<size_t>(need_chunks, f.nwaves), 0);
-            st[0] = need_chunks > f.nwaves ? (uint32_t)(need_chunks - f.nwaves) : 0u;  // dynamic chunks of "iteration 0"
-            st[kLevelSlots] = 1;                                                         // any[0]
-            for (size_t c = 0; c < need_chunks; c++) cc[c] = (uint32_t)std::min<size_t>(kChunk, m - c * kChunk);
-            HIP_TRY(hipMemcpyAsync(h->d_status.p, st.data(), st.size() * 4, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(f.buf[0], seeds.data(), m * sizeof(uint4), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemcpyAsync(f.counts[0], cc.data(), cc.size() * 4, hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));  // host staging vectors go out of scope below
+            HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, m * std::max<size_t>(vwords, 1) * 4, h->stream));
+            launch_rev_seed(h->stream, f, h->d_sids.p, (uint32_t)m, key);  // seeds + status block, on the device
             uint32_t levels = 0;
-            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels, [] {});
+            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels, [&] {
+                // speculative epilogue: the result rows of the target slot, one strided copy for all requests
+                if (need) (void)hipMemcpy2DAsync(bitmaps + b * words, words * 4, h->d_visited.p + h->snap.slot_bit_base[target] / 32, std::max<size_t>(vwords, 1) * 4,
+                                                 need * 4, m, hipMemcpyDeviceToHost, h->stream);
+            });
             if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
                 h->stats.overflow_retries++;
                 if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
                 int rc2 = alloc_frontier(h, h->frontier_entries * 4);
                 if (rc2) return rc2;
-                HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, m * std::max<size_t>(vwords, 1) * 4, h->stream));
                 continue;
             }
             if (rc) return rc;
             break;
         }
-        const size_t woff = h->snap.slot_bit_base[target] / 32;
-        for (size_t i = 0; i < m; i++) {
-            uint32_t *dst = bitmaps + (b + i) * words;
-            if (need) HIP_TRY(hipMemcpyAsync(dst, h->d_visited.p + i * vwords + woff, need * 4, hipMemcpyDeviceToHost, h->stream));
-        }
-        HIP_TRY(hipStreamSynchronize(h->stream));
         for (size_t i = 0; i < m; i++) {
             uint32_t *dst = bitmaps + (b + i) * words;
             std::fill(dst + need, dst + words, 0u);

@@ -318,6 +318,17 @@ __global__ __launch_bounds__(256) void k_seed(DevGraph g, DevFrontier f, const u
     f.buf[0][i] = make_uint4(it.y, i, meta, it.w);
 }
 
+// reverse-walk seeds: lookup request i starts from subject sids[i]; entry meta = subject key (dist 0 => program rseeds[key]).
+// Also resets the status block (slot 0 describes the seeds), like k_seed.
+__global__ __launch_bounds__(256) void k_rev_seed(DevFrontier f, const uint32_t *__restrict__ sids, uint32_t n, uint32_t key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t need = (n + kChunk - 1) / kChunk;
+    const uint32_t readable = max(need, f.nwaves);
+    if (i < kStatusWords) f.nchunks[i] = i == 0 ? (need > f.nwaves ? need - f.nwaves : 0u) : (i == kLevelSlots ? (n ? 1u : 0u) : 0u);
+    if (i < readable) f.counts[0][i] = i < need ? min(kChunk, n - i * kChunk) : 0u;
+    if (i < n) f.buf[0][i] = make_uint4(sids[i], i, key, 0);
+}
+
 // ---------------------------------------------------------------- expand
 template <bool LDSPROG, bool SHARDED>
 __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
@@ -684,6 +695,10 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
+}
+void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key) {
+    const uint32_t threads = std::max(std::max(n, f.nwaves), kStatusWords);
+    hipLaunchKernelGGL(k_rev_seed, dim3((threads + 255) / 256), dim3(256), 0, s, f, d_sids, n, key);
 }
 void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out) {
     if (!k_items) return;
