@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -76,7 +77,9 @@ struct DevArray {
 }  // namespace
 
 struct acl_engine {
-    std::mutex mu;
+    std::mutex mu;             // device state, snapshot, relationship tables
+    std::shared_mutex names_mu;  // schema + object-name tables: shared by the callers of acl_check_one (string -> id only reads them),
+                                 // exclusive (together with mu, taken after it) for everything that can add names or reload the schema
     Store store;
     Snapshot snap;
     ShardSpec shard;  // world > 1: this engine holds one shard of the graph and only the acl_shard_* entry points evaluate
@@ -117,9 +120,10 @@ struct acl_engine {
         int rc = 0;
         std::string msg;
         bool done = false;
+        std::condition_variable cv;  // own wake-up: a finished batch does not stampede every parked caller
     };
     std::mutex q_mu;
-    std::condition_variable q_cv, q_done;
+    std::condition_variable q_cv;
     std::vector<Waiter *> queue;
     std::thread batcher;
     bool batcher_on = false, batcher_stop = false;
@@ -461,6 +465,7 @@ void acl_close(acl_engine_t *h) {
 
 int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, const char *rels, size_t rels_len) {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (!schema) return fail(ACL_ERR_INVALID_ARGUMENT, "schema is NULL");
     Status s = h->store.load_schema(std::string(schema, schema_len));
     if (!s.ok()) return fail(s);
@@ -484,6 +489,7 @@ int acl_relation_id(acl_engine_t *h, int type, const char *name) {
 }
 int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
     *id_out = h->store.objects(type).intern(object_id);
@@ -511,6 +517,7 @@ uint32_t acl_object_count(acl_engine_t *h, int type) {
 
 int acl_write(acl_engine_t *h, const acl_update_t *ups, int n, const acl_filter_t *pre, int m, uint64_t *rev) {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (n < 0 || m < 0 || (n && !ups) || (m && !pre)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_write: bad argument");
     std::vector<UpdateText> u(n);
     for (int i = 0; i < n; i++) {
@@ -532,6 +539,7 @@ int acl_write(acl_engine_t *h, const acl_update_t *ups, int n, const acl_filter_
 
 int acl_delete_by_filter(acl_engine_t *h, const acl_filter_t *f, uint64_t *n_deleted, uint64_t *rev) {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (!f) return fail(ACL_ERR_INVALID_ARGUMENT, "filter is NULL");
     Status s = h->store.delete_by_filter(to_filter(f), n_deleted, rev);
     return s.ok() ? ACL_OK : fail(s);
@@ -549,6 +557,7 @@ int acl_read(acl_engine_t *h, const acl_filter_t *f, acl_read_cb cb, void *user)
 
 int acl_add_edges(acl_engine_t *h, int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj) {
     std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     Status s = h->store.add_edges(rtype, rel, stype, srel, n, res, subj);
     return s.ok() ? ACL_OK : fail(s);
 }
@@ -737,6 +746,7 @@ int acl_lookup_resources(acl_engine_t *h, const char *rtype, const char *perm, c
     uint32_t sub;
     {
         std::lock_guard<std::mutex> lk(h->mu);
+        std::unique_lock<std::shared_mutex> nlk(h->names_mu);
         if (empty(rtype) || empty(perm) || empty(stype) || empty(sid)) return fail(ACL_ERR_INVALID_ARGUMENT, "invalid LookupResourcesRequest: empty field");
         if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
         const Schema &sc = h->store.schema();
@@ -1121,12 +1131,14 @@ static void batcher_loop(acl_engine_t *h) {
     std::vector<acl_item_t> items;
     std::vector<uint8_t> perm;
     std::vector<int32_t> err;
+    bool back_to_back = false;  // the previous pass WAS the batching window: whoever arrived during it goes now
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(h->q_mu);
+            if (h->queue.empty()) back_to_back = false;
             h->q_cv.wait(lk, [&] { return h->batcher_stop || !h->queue.empty(); });
             if (h->batcher_stop && h->queue.empty()) return;
-            if (h->queue.size() < h->mb_max_items && h->mb_wait_us)  // let concurrent callers pile on
+            if (!back_to_back && h->queue.size() < h->mb_max_items && h->mb_wait_us)  // idle engine: let concurrent callers pile on
                 h->q_cv.wait_for(lk, std::chrono::microseconds(h->mb_wait_us), [&] { return h->batcher_stop || h->queue.size() >= h->mb_max_items; });
             const size_t take = std::min<size_t>(h->queue.size(), h->mb_max_items);
             batch.assign(h->queue.begin(), h->queue.begin() + (long)take);
@@ -1146,11 +1158,12 @@ static void batcher_loop(acl_engine_t *h) {
                 batch[i]->perm = perm[i];
                 batch[i]->err = err[i];
                 batch[i]->done = true;
+                batch[i]->cv.notify_one();
             }
             h->mb_batches++;
             h->mb_items += batch.size();
         }
-        h->q_done.notify_all();
+        back_to_back = true;
     }
 }
 
@@ -1190,7 +1203,7 @@ int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_o
     if (!item || !perm_out || !err_out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_one: NULL argument");
     acl_engine::Waiter w;
     {
-        std::lock_guard<std::mutex> lk(h->mu);
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);  // string -> id reads only: callers do not serialise on the engine
         if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
         *perm_out = ACL_PERM_UNSPECIFIED;
         *err_out = intern_check_item(h, *item, &w.item);
@@ -1200,8 +1213,8 @@ int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_o
         std::unique_lock<std::mutex> lk(h->q_mu);
         if (h->batcher_on && !h->batcher_stop) {
             h->queue.push_back(&w);
-            h->q_cv.notify_all();
-            h->q_done.wait(lk, [&] { return w.done; });
+            if (h->queue.size() == 1 || h->queue.size() >= h->mb_max_items) h->q_cv.notify_one();  // only the batcher waits on q_cv
+            w.cv.wait(lk, [&] { return w.done; });
             if (w.rc) return fail(w.rc, w.msg);
             *perm_out = w.perm;
             *err_out = w.err;

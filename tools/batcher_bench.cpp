@@ -1,0 +1,78 @@
+// batcher_bench -- the proxy's call shape against the C ABI: T host threads each issuing single CheckPermission calls
+// (pkg/authz/check.go:76-94: one goroutine per check expression; watch.go:50: one per update), with and without the
+// micro-batching front-end (acl_batcher_start).  Plain C++ over include/aclgpu.h, no Python in the timed path.
+//   g++ -O2 -std=c++17 tools/batcher_bench.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -o /tmp/batcher_bench
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "aclgpu.h"
+
+static const char *kSchema =
+    "definition user {}\n"
+    "definition namespace {\n  relation viewer: user\n  relation creator: user\n  permission view = viewer + creator\n}\n"
+    "definition pod {\n  relation namespace: namespace\n  relation viewer: user\n  relation creator: user\n"
+    "  permission view = viewer + creator + namespace->view\n}\n";
+
+int main(int argc, char **argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 64, PER = argc > 2 ? atoi(argv[2]) : 2000, NPOD = 100000, NNS = 1000, NUSER = 10000;
+    acl_engine_t *h = nullptr;
+    acl_config_t cfg{-1, 0, 0, 0};
+    if (acl_open(&cfg, &h)) { fprintf(stderr, "acl_open: %s\n", acl_last_error()); return 1; }
+    std::string rels;
+    unsigned s = 12345;
+    auto rnd = [&](unsigned m) { s = s * 1664525u + 1013904223u; return (s >> 8) % m; };
+    for (int p = 0; p < NPOD; p++) {
+        char b[160];
+        int ns = rnd(NNS);
+        snprintf(b, sizeof b, "pod:ns%d/p%d#namespace@namespace:ns%d\npod:ns%d/p%d#creator@user:u%d\n", ns, p, ns, ns, p, rnd(NUSER));
+        rels += b;
+        const int v0 = rnd(NUSER);
+        for (int k = 0; k < 3; k++) { snprintf(b, sizeof b, "pod:ns%d/p%d#viewer@user:u%d\n", ns, p, (v0 + k * 3331) % NUSER); rels += b; }  // distinct viewers
+    }
+    for (int n = 0; n < NNS; n++) {
+        const int v0 = rnd(NUSER);
+        for (int k = 0; k < 10; k++) { char b[96]; snprintf(b, sizeof b, "namespace:ns%d#viewer@user:u%d\n", n, (v0 + k * 977) % NUSER); rels += b; }
+    }
+    if (acl_load_bootstrap(h, kSchema, std::string(kSchema).size(), rels.data(), rels.size())) { fprintf(stderr, "load: %s\n", acl_last_error()); return 1; }
+    acl_snapshot(h);
+    // request strings prepared up front (the proxy has them from its rule templates)
+    std::vector<std::vector<std::string>> pod(T), usr(T);
+    for (int t = 0; t < T; t++)
+        for (int i = 0; i < PER; i++) {
+            int p = rnd(NPOD);
+            pod[t].push_back("ns" + std::to_string(rnd(NNS)) + "/p" + std::to_string(p));  // mostly unknown ids -> NO, some known
+            usr[t].push_back("u" + std::to_string(rnd(NUSER)));
+        }
+    for (int mode = 0; mode < 2; mode++) {
+        if (mode == 1 && acl_batcher_start(h, 4096, 100)) { fprintf(stderr, "batcher: %s\n", acl_last_error()); return 1; }
+        acl_stats_reset(h);
+        std::atomic<long> has{0}, bad{0};
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                for (int i = 0; i < PER; i++) {
+                    acl_check_item_t it{"pod", pod[t][i].c_str(), "view", "user", usr[t][i].c_str(), ""};
+                    uint8_t perm = 0;
+                    int32_t err = 0;
+                    if (acl_check_one(h, &it, &perm, &err) || err) bad++;
+                    else if (perm == ACL_PERM_HAS_PERMISSION) has++;
+                }
+            });
+        for (auto &x : th) x.join();
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        acl_stats_t st;
+        acl_stats(h, &st);
+        printf("{\"mode\": \"%s\", \"threads\": %d, \"checks\": %ld, \"checks_per_s\": %.0f, \"mean_latency_us\": %.1f, \"device_passes\": %llu, \"has\": %ld, \"errors\": %ld}\n",
+               mode ? "micro-batched (max 4096 items / 100 us)" : "one device pass per call", T, (long)T * PER, T * PER / el, el * 1e6 / PER,
+               (unsigned long long)st.check_passes, has.load(), bad.load());
+    }
+    acl_batcher_stop(h);
+    acl_close(h);
+    return 0;
+}
