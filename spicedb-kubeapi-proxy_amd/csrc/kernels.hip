@@ -27,6 +27,7 @@
 //
 // Bound: HBM/L2 transactions (random row gathers); no MFMA anywhere by design.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.hpp"
 
@@ -672,6 +673,7 @@ int expand_grid_blocks(int device) {
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int per_cu = 8;  // 256-thread blocks, <= 64 VGPRs, ~20 KiB LDS
+    if (const char *e = getenv("ACL_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // A/B knob (tools/ab.sh)
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 0) == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
     return cus * per_cu;

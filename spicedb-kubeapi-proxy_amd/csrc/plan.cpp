@@ -3,6 +3,8 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace acl {
 namespace {
@@ -448,8 +450,8 @@ struct Patcher {
 
 bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches) {
     Snapshot &s = *snap;
-    if (s.lay.empty()) return false;
     std::vector<Store::Change> ch;
+    if (s.lay.empty()) return false;
     if (!store.raw_changes_since(s.revision, &ch) || ch.size() > kMaxPatchChanges) return false;
     store.settle_all();
     const Schema &sc = store.schema();
