@@ -42,7 +42,7 @@ namespace {
 #define ACL_KEEP(x) asm volatile("" ::"v"(x))
 constexpr int kBlock = kWavesPerBlock * 64;
 #ifndef ACL_MIN_WAVES_PER_SIMD
-#define ACL_MIN_WAVES_PER_SIMD 8  // 8 blocks of 4 waves per CU: the kernels are latency bound, residency is what hides it
+#define ACL_MIN_WAVES_PER_SIMD 5  // 84 VGPRs: the multi-child fast path (flush_simple) needs them; spilling at 8 waves/SIMD costs more than the waves give
 #endif
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
@@ -207,6 +207,96 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
     return push;
 }
 
+// Fast path of the expansion for the shape that dominates deep levels: every task's child state is "simple" -- one hashed
+// probe of the request's subject (a plain subject) plus an authoritative leaf flag on the edge, nothing else -- and all
+// tasks agree on (child slot, subject key).  Then there is no program to interpret, and each lane evaluates kSimpleWidth children
+// per step with branch-free loads (dummy in-range addresses for inactive lanes), so the edge, descriptor and bucket
+// gathers of 64 x kSimpleWidth children are in flight together instead of 64 at a time behind three dependent waits.
+// Bit-for-bit the same decisions, the same output entries in the same order as the generic path.
+#ifndef ACL_SIMPLE_WIDTH
+#define ACL_SIMPLE_WIDTH 3  // A/B on C4 (tools/ab.sh): width 2 380 M/s, 3 398 M/s (5 waves/SIMD); 3 or 4 at 4 waves/SIMD 353-369 M/s
+#endif
+constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
+template <bool SHARDED>
+__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+                                              const DevFrontier &f, uint4 *__restrict__ out, uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has,
+                                              uint8_t *err) {
+    const uint32_t *__restrict__ edges = g.edges;
+    const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
+    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
+    for (uint32_t gq = 0; gq < T; gq += 64) {
+        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        t.scan[lane] = incl - cnt;
+        wave_lds_fence();
+        for (uint32_t w0 = 0; w0 < total; w0 += 64 * kSimpleWidth) {
+            bool valid[kSimpleWidth];
+            uint32_t tj[kSimpleWidth], eaddr[kSimpleWidth];
+#pragma unroll
+            for (int k = 0; k < kSimpleWidth; k++) {
+                const uint32_t w = w0 + 64u * k + lane;
+                valid[k] = w < total;
+                const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+                uint32_t j = 0;
+#pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1)
+                    if (t.scan[j + step] <= wv) j += step;
+                tj[k] = gq + j;
+                eaddr[k] = t.start[tj[k]] + (wv - t.scan[j]);
+            }
+            uint32_t edge[kSimpleWidth], sid[kSimpleWidth], req[kSimpleWidth], meta[kSimpleWidth];
+#pragma unroll
+            for (int k = 0; k < kSimpleWidth; k++) {
+                edge[k] = edges[eaddr[k]];
+                sid[k] = t.sid[tj[k]];
+                req[k] = t.req[tj[k]];
+                meta[k] = t.meta[tj[k]];
+            }
+            uint2 d[kSimpleWidth];
+            bool row[kSimpleWidth];
+#pragma unroll
+            for (int k = 0; k < kSimpleWidth; k++) {
+                row[k] = sid[k] < pop.nrows;
+                d[k] = smeta[pop.base + (row[k] ? sid[k] : 0u)];
+                row[k] = row[k] && d[k].y > d[k].x;
+            }
+            uint4 p[kSimpleWidth], q[kSimpleWidth];
+            uint32_t child[kSimpleWidth];
+#pragma unroll
+            for (int k = 0; k < kSimpleWidth; k++) {
+                child[k] = edge[k] & kIdMask;
+                const uint32_t b0 = row[k] ? d[k].x : 0u, nb = row[k] ? d[k].y - d[k].x : 1u;
+                uint32_t h1, h2;
+                hashed_row_buckets(child[k], nb, &h1, &h2);
+                p[k] = buckets[b0 + h1];
+                q[k] = buckets[b0 + h2];
+            }
+#pragma unroll
+            for (int k = 0; k < kSimpleWidth; k++) {
+                const uint32_t c = child[k];
+                const bool contains = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
+                const uint32_t level = meta_level(meta[k]);
+                const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
+                const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
+                bool push = valid[k] && !(edge[k] & kLeafBit);
+                if (hit) {
+                    has[req[k]] = 1;
+                    push = false;
+                } else if (derr) {
+                    err[req[k]] = ITEM_ERR_DEPTH;
+                }
+                const uint64_t b = __ballot(push);
+                if (b) {
+                    const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                    if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(c, req[k], meta[k] | kProbedBit, sid[k]);
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 // Expand the first T tasks of the wave's LDS list.  INLINE: children are probed here and only the ones with
 // remaining enumeration work are written (forward Check); otherwise every child is written (reverse walk).
 // wave-cooperative append of the flagged lanes' entries to the shard's export buffer (one atomic per call)
@@ -224,6 +314,26 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                                             const FwdOp *ops, const uint32_t *__restrict__ edges, const DevFrontier &f, uint4 *__restrict__ out,
                                             uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err, const DevShard &sh) {
     wave_lds_fence();
+    if (INLINE) {  // all tasks lead to the same "simple" child state?  (one hashed probe + authoritative leaf flags, plain subject)
+        const uint32_t m0 = t.meta[0];
+        const uint32_t cs = uniform(meta_slot(m0)), k0 = uniform(meta_key(m0));
+        const SlotProg cp = progs[cs];
+        bool ok = cp.n_probe == 1 && k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank);
+        FwdOp pop{};
+        if (ok) {
+            pop = ops[cp.first];
+            ok = pop.flags == OP_PROBE_HASH && pop.key == k0;
+        }
+        bool agree = true;
+        for (uint32_t i = lane; i < T; i += 64) {
+            const uint32_t mi = t.meta[i], ci = t.count[i];
+            agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
+        }
+        if (ok && !__ballot(!agree)) {
+            flush_simple<SHARDED>(t, T, wo, lane, g, cp, pop, f, out, out_counts, out_nchunks, has, err);
+            return;
+        }
+    }
     for (uint32_t gq = 0; gq < T; gq += 64) {
         const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
         const uint32_t incl = wave_incl_scan(cnt, lane);
