@@ -494,6 +494,61 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
         const bool valid = s * 64 + lane < cnt;
         const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
+        // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
+        // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read and
+        // the row-descriptor gather are issued together (branch-free), not one after the other.
+        {
+            const uint64_t vb = __ballot(valid);
+            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
+            const uint32_t cs = meta_slot(m0);
+            bool simple = m0 != kDeadMeta && !__ballot(valid && (meta == kDeadMeta || !(meta & kProbedBit) || meta_slot(meta) != cs || meta_key(meta) < g.nslots));
+            SlotProg sp{};
+            FwdOp sop{};
+            if (simple) {
+                sp = progs[cs];
+                simple = sp.n_main == sp.n_probe + 1;
+                if (simple) {
+                    sop = ops[sp.first + sp.n_probe];
+                    simple = (sop.flags & OP_ENUM) && !(sop.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH));
+                }
+            }
+            if (simple) {
+                const uint32_t hv = has[valid ? req : 0u];
+                const bool inrow = valid && id < sop.nrows;
+                const uint32_t rid = inrow ? id : 0u;
+                uint2 md;
+                if (sop.K == 2) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
+                    md = sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+                } else {
+                    md = reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
+                }
+                const bool act = valid && !hv;
+                const uint32_t lv = meta_level(meta), L = lv + sop.dlevel;
+                bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
+                if (act && L <= kMaxLevels && inrow && md.y > md.x) {
+                    if (L + 1 > kMaxLevels) derr = true;
+                    else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
+                    else want = true;
+                }
+                if (derr) err[req] = ITEM_ERR_DEPTH;
+                uint32_t T = 0;
+                const uint64_t b = __ballot(want);
+                if (b) {
+                    if (want) {
+                        const uint32_t q = lanes_below(b);
+                        t.start[q] = md.x;
+                        t.count[q] = (md.y - md.x) | ((sop.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
+                        t.req[q] = req;
+                        t.meta[q] = make_meta(sop.key, L + 1, meta_key(meta));
+                        t.sid[q] = sid;
+                    }
+                    T = (uint32_t)__popcll(b);
+                    flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
+                }
+                continue;
+            }
+        }
         bool active = valid && meta != kDeadMeta;
         if (active && has[req]) active = false;  // request already answered HAS: drop its pending work
         if (ACL_PERTURB == 1 && valid) { const uint32_t x = has[req ^ 0x5555u]; ACL_KEEP(x); }
