@@ -513,39 +513,59 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                 }
             }
             if (simple) {
-                const uint32_t hv = has[valid ? req : 0u];
-                const bool inrow = valid && id < sop.nrows;
-                const uint32_t rid = inrow ? id : 0u;
-                uint2 md;
-                if (sop.K == 2) {
-                    const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
-                    md = sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
-                } else {
-                    md = reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
-                }
-                const bool act = valid && !hv;
-                const uint32_t lv = meta_level(meta), L = lv + sop.dlevel;
-                bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
-                if (act && L <= kMaxLevels && inrow && md.y > md.x) {
-                    if (L + 1 > kMaxLevels) derr = true;
-                    else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
-                    else want = true;
-                }
-                if (derr) err[req] = ITEM_ERR_DEPTH;
-                uint32_t T = 0;
-                const uint64_t b = __ballot(want);
-                if (b) {
+                // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
+                auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, bool inrow, uint32_t Tb) -> uint32_t {
+                    const bool act = sv && !hv;
+                    const uint32_t lv = meta_level(se.z), L = lv + sop.dlevel;
+                    bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
+                    if (act && L <= kMaxLevels && inrow && md.y > md.x) {
+                        if (L + 1 > kMaxLevels) derr = true;
+                        else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
+                        else want = true;
+                    }
+                    if (derr) err[se.y] = ITEM_ERR_DEPTH;
+                    const uint64_t b = __ballot(want);
                     if (want) {
-                        const uint32_t q = lanes_below(b);
+                        const uint32_t q = Tb + lanes_below(b);
                         t.start[q] = md.x;
                         t.count[q] = (md.y - md.x) | ((sop.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
-                        t.req[q] = req;
-                        t.meta[q] = make_meta(sop.key, L + 1, meta_key(meta));
-                        t.sid[q] = sid;
+                        t.req[q] = se.y;
+                        t.meta[q] = make_meta(sop.key, L + 1, meta_key(se.z));
+                        t.sid[q] = se.w;
                     }
-                    T = (uint32_t)__popcll(b);
-                    flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
+                    return (uint32_t)__popcll(b);
+                };
+                auto row_desc = [&](uint32_t rid) -> uint2 {
+                    if (sop.K == 2) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
+                        return sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+                    }
+                    return reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
+                };
+                // segment A's gathers and -- when the wave has another slot pending -- segment B's entries, all in flight together
+                const uint32_t hvA = has[valid ? req : 0u];
+                const bool inA = valid && id < sop.nrows;
+                const uint2 mdA = row_desc(inA ? id : 0u);
+                bool validB = false;
+                uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
+                int wlB = -1;
+                if (work) {
+                    wlB = __ffsll((unsigned long long)work) - 1;
+                    const uint32_t xB = x0 + (uint32_t)wlB * nwaves, sB = xB / C;
+                    const uint32_t cB = (uint32_t)__builtin_amdgcn_readlane((int)lc, wlB);
+                    const uint32_t cntB = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wlB) + sB * 64;
+                    validB = sB * 64 + lane < cntB;
+                    if (validB) eB = in[(size_t)cB * kChunk + sB * 64 + lane];
                 }
+                uint32_t T = seg_tasks(e, valid, hvA, mdA, inA, 0u);
+                if (wlB >= 0 && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots))) {
+                    work &= work - 1;  // B is a simple segment of the same slot: taken here
+                    const uint32_t hvB = has[validB ? eB.y : 0u];
+                    const bool inB = validB && eB.x < sop.nrows;
+                    const uint2 mdB = row_desc(inB ? eB.x : 0u);
+                    T += seg_tasks(eB, validB, hvB, mdB, inB, T);
+                }
+                if (T) flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
                 continue;
             }
         }
