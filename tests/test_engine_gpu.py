@@ -189,3 +189,32 @@ def test_frontier_overflow_grows(aclgpu):
         w.load(e2)
         p2, er2 = e2.check_bulk_ids(e2.make_items("pod", "view", w.res, "user", "", w.subj))
         assert np.array_equal(p, p2) and np.array_equal(er, er2)
+
+
+def test_sub_batched_passes(aclgpu):
+    """A batch larger than max_sub_batch is answered in several device passes (each with its own epilogue): same bytes as
+    one pass, for the host-buffer and the device-resident entry points."""
+    import torch
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.02, batch=50000, n_user=20000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    op, oe = o.check_bulk_ids("pod", "view", w.res, "user", "", w.subj)
+    with aclgpu.Engine(w.schema, max_sub_batch=4096) as e:
+        w.load(e)
+        items = e.make_items("pod", "view", w.res, "user", "", w.subj)
+        p, er = e.check_bulk_ids(items)
+        assert np.array_equal(p, op) and np.array_equal(er, oe)
+        assert e.stats()["check_passes"] == (items.size + 4095) // 4096
+        d_items = torch.from_numpy(items.view(np.uint8).copy()).cuda()
+        d_perm = torch.zeros(items.size, dtype=torch.uint8, device="cuda")
+        d_err = torch.zeros(items.size, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        e.check_bulk_ids_device(d_items.data_ptr(), items.size, d_perm.data_ptr(), d_err.data_ptr())
+        e.sync()
+        assert np.array_equal(d_perm.cpu().numpy(), op) and np.array_equal(d_err.cpu().numpy(), oe)
+        # the PostFilter keep mask over a sub-batched check
+        off = np.arange(0, items.size + 1, 5, dtype=np.uint32)
+        keep = e.check_bulk_keep_ids(items[:off[-1]], off)
+        want = (op[:off[-1]].reshape(-1, 5) == 2).all(axis=1)
+        assert np.array_equal(keep.astype(bool), want)
