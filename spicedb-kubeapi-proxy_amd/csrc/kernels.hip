@@ -213,6 +213,9 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 // per step with branch-free loads (dummy in-range addresses for inactive lanes), so the edge, descriptor and bucket
 // gathers of 64 x kSimpleWidth children are in flight together instead of 64 at a time behind three dependent waits.
 // Bit-for-bit the same decisions, the same output entries in the same order as the generic path.
+#ifndef ACL_FLUSH_PER_OP
+#define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
+#endif
 #ifndef ACL_SIMPLE_WIDTH
 #define ACL_SIMPLE_WIDTH 3  // A/B on C4 (tools/ab.sh): width 2 380 M/s, 3 398 M/s (5 waves/SIMD); 3 or 4 at 4 waves/SIMD 353-369 M/s
 #endif
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                     t.sid[q] = sid;
                 }
                 T += (uint32_t)__popcll(b);
-                if (T > kTaskCap - 64) {
+                if (ACL_FLUSH_PER_OP || T > kTaskCap - 64) {  // per op: the tasks of one flush share the child slot -> flush_simple can take them
                     flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
                     T = 0;
                 }
