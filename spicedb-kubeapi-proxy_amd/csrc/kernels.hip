@@ -300,6 +300,91 @@ __device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo
     }
 }
 
+// Second specialised expansion: all tasks lead to one child slot whose program is at most two hashed probes followed by at
+// most two enumerate ops that a child is only LOOKED at for ("does it have anything to enumerate?") -- arrow targets such as
+// `namespace#view = viewer + creator + ...`.  One child per lane; the subject's row descriptors (they depend on the request,
+// not on the child) are fetched together with the edge, then every bucket and every row descriptor of the child together:
+// two dependent trips instead of up to six.  Same decisions and output order as the generic path.
+template <bool SHARDED>
+__device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp *cops,
+                                             uint32_t k0, bool leafauth, const DevFrontier &f, uint4 *__restrict__ out, uint32_t *out_counts,
+                                             uint32_t *out_nchunks, uint8_t *has, uint8_t *err) {
+    const uint32_t *__restrict__ edges = g.edges;
+    const uint2 *__restrict__ meta2 = reinterpret_cast<const uint2 *>(g.meta);
+    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
+    const uint32_t nh = uniform(cp.n_probe), nl = leafauth ? 0u : uniform(cp.n_main - cp.n_probe);
+    const FwdOp *lops = cops + cp.n_probe;
+    for (uint32_t gq = 0; gq < T; gq += 64) {
+        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        t.scan[lane] = incl - cnt;
+        wave_lds_fence();
+        for (uint32_t w0 = 0; w0 < total; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            const bool valid = w < total;
+            const uint32_t wv = valid ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t step = 32; step >= 1; step >>= 1)
+                if (t.scan[j + step] <= wv) j += step;
+            const uint32_t tj = gq + j;
+            const uint32_t sid = t.sid[tj], req = t.req[tj], meta = t.meta[tj];
+            // trip 1: the edge and the subject's row descriptor of every probe
+            const uint32_t edge = edges[t.start[tj] + (wv - t.scan[j])];
+            uint2 hd[2];
+            bool hrow[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const bool hk = (uint32_t)k < nh;
+                hrow[k] = hk && cops[hk ? k : 0].key == k0 && sid < cops[hk ? k : 0].nrows;
+                hd[k] = meta2[(hk ? cops[k].base : 0u) + (hrow[k] ? sid : 0u)];
+            }
+            const uint32_t child = edge & kIdMask;
+            // trip 2: both buckets of every probe and the child's row descriptor of every enumerate op
+            uint4 bp[2], bq[2];
+            uint2 md[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                hrow[k] = hrow[k] && hd[k].y > hd[k].x;
+                const uint32_t b0 = hrow[k] ? hd[k].x : 0u, nb = hrow[k] ? hd[k].y - hd[k].x : 1u;
+                uint32_t h1, h2;
+                hashed_row_buckets(child, nb, &h1, &h2);
+                bp[k] = buckets[b0 + h1];
+                bq[k] = buckets[b0 + h2];
+                const bool lk = (uint32_t)k < nl;
+                const FwdOp &lo = lops[lk ? k : 0];
+                const bool inrow = lk && child < lo.nrows;
+                md[k] = meta2[lk ? lo.base + (size_t)(inrow ? child : 0u) * lo.K + lo.k : 0u];
+                if (!inrow) md[k] = make_uint2(0, 0);
+            }
+            const uint32_t level = meta_level(meta);
+            bool hit = false, push = leafauth && !(edge & kLeafBit);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (hrow[k] && level + cops[(uint32_t)k < nh ? k : 0].dlevel <= kMaxLevels)
+                    hit = hit || bp[k].x == child || bp[k].y == child || bp[k].z == child || bp[k].w == child || bq[k].x == child ||
+                          bq[k].y == child || bq[k].z == child || bq[k].w == child;
+                if ((uint32_t)k < nl && md[k].y > md[k].x && level + lops[k].dlevel <= kMaxLevels) push = true;
+            }
+            hit = hit && valid;
+            push = push && valid;
+            if (hit) {
+                has[req] = 1;
+                push = false;
+            } else if (valid && level + cp.max_dlevel > kMaxLevels) {
+                err[req] = ITEM_ERR_DEPTH;
+            }
+            const uint64_t b = __ballot(push);
+            if (b) {
+                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(child, req, meta | kProbedBit, sid);
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
 // Expand the first T tasks of the wave's LDS list.  INLINE: children are probed here and only the ones with
 // remaining enumeration work are written (forward Check); otherwise every child is written (reverse walk).
 // wave-cooperative append of the flagged lanes' entries to the shard's export buffer (one atomic per call)
@@ -335,6 +420,25 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
         if (ok && !__ballot(!agree)) {
             flush_simple<SHARDED>(t, T, wo, lane, g, cp, pop, f, out, out_counts, out_nchunks, has, err);
             return;
+        }
+        // second shape: <= 2 hashed probes + <= 2 enumerate ops that are only looked at; uniform slot, key and leaf authority
+        if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
+            const FwdOp *cops = ops + cp.first;
+            bool shape = true;
+            for (uint32_t q = 0; q < cp.n_main; q++) {
+                const uint32_t fl = cops[q].flags;
+                shape = shape && (q < cp.n_probe ? fl == OP_PROBE_HASH : ((fl & OP_ENUM) && !(fl & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH)) && cops[q].K != 2));
+            }
+            const bool la0 = (t.count[0] & kLeafAuthBit) != 0;
+            bool agree2 = true;
+            for (uint32_t i = lane; i < T; i += 64) {
+                const uint32_t mi = t.meta[i], ci = t.count[i];
+                agree2 = agree2 && meta_slot(mi) == cs && meta_key(mi) == k0 && ((ci & kLeafAuthBit) != 0) == la0 && !(ci & kSelfBit);
+            }
+            if (shape && !__ballot(!agree2)) {
+                flush_probes<SHARDED>(t, T, wo, lane, g, cp, cops, k0, la0, f, out, out_counts, out_nchunks, has, err);
+                return;
+            }
         }
     }
     for (uint32_t gq = 0; gq < T; gq += 64) {
