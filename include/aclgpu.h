@@ -182,6 +182,12 @@ int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us)
 int acl_batcher_stop(acl_engine_t *h);
 int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items);
 int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out);
+/* the same for Filter requests (lookups.go:65; one LookupResources per list request, each from its own goroutine:
+ * responsefilterer.go:165): concurrent requests with the same (resource type, permission, subject class) share ONE
+ * batched reverse walk.  Arguments as acl_lookup_resources. */
+int acl_lookup_one(acl_engine_t *h, const char *resource_type, const char *permission, const char *subject_type, const char *subject_id,
+                   const char *subject_relation, uint32_t *bitmap_out, size_t bitmap_words, uint64_t *count_out);
+int acl_batcher_lookup_stats(acl_engine_t *h, uint64_t *walks, uint64_t *lookups);
 
 /* ---- sharded graph: the north star's multi-GPU configuration ----
  * One engine per GPU holds the rows of the object types with fnv1a(type name) mod world == rank; the

@@ -85,7 +85,8 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 	words := (uint32(C.acl_object_count(p.e.h, typeID)) + 1 + 31) / 32 + 1 // +1: the call may intern the subject
 	bm := make([]C.uint32_t, words)
 	var count C.uint64_t
-	if rc := C.acl_lookup_resources(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), &bm[0], C.size_t(words), &count); rc != 0 {
+	// acl_lookup_one: concurrent list requests of the same (type, permission, subject class) share one batched reverse walk
+	if rc := C.acl_lookup_one(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), &bm[0], C.size_t(words), &count); rc != 0 {
 		return nil, lastError(rc)
 	}
 	return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: bm, at: p.e.zedToken()}, nil

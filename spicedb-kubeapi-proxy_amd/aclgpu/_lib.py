@@ -22,7 +22,8 @@ SYMBOLS = [
     "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
     "acl_shard_lookup_finish",
     "acl_check_bulk_keep", "acl_check_bulk_keep_ids", "acl_check_bulk_keep_ids_device", "acl_bitmap_test_names", "acl_watch_poll",
-    "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_selfcheck_snapshot",
+    "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
+    "acl_selfcheck_snapshot",
 ]
 
 
@@ -128,6 +129,8 @@ def load():
     L.acl_batcher_stop.argtypes = [H]
     L.acl_batcher_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_check_one.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+    L.acl_lookup_one.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.acl_batcher_lookup_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_selfcheck_snapshot.argtypes = [H, C.POINTER(C.c_int)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]

@@ -280,6 +280,21 @@ class Engine:
         self._check(self._L.acl_check_one(self._h, C.byref(it), C.byref(p), C.byref(e)))
         return p.value, e.value
 
+    def lookup_one(self, rt, perm, st, sid, srel=""):
+        """One LookupResources request (lookups.go:65) -> set of resource ids; concurrent callers with the same (type,
+        permission, subject class) share one batched reverse walk while the batcher runs.  Blocks; releases the GIL."""
+        words = (self.object_count(rt) + 1 + 31) // 32 + 1
+        bm = np.zeros(words, dtype=np.uint32)
+        cnt = C.c_uint64()
+        self._check(self._L.acl_lookup_one(self._h, _b(rt), _b(perm), _b(st), _b(sid), _b(srel or ""), bm.ctypes.data, words, C.byref(cnt)))
+        ids = np.flatnonzero(np.unpackbits(bm.view(np.uint8), bitorder="little"))
+        return {self.object_name(rt, int(i)) for i in ids}
+
+    def batcher_lookup_stats(self):
+        w, n = C.c_uint64(), C.c_uint64()
+        self._check(self._L.acl_batcher_lookup_stats(self._h, C.byref(w), C.byref(n)))
+        return {"walks": w.value, "lookups": n.value}
+
     # ---- lookups
     def lookup_bitmap(self, rt, perm, st, sid, srel=""):
         words = (self.object_count(rt) + 1 + 31) // 32 + 1  # +1: the subject may be interned by the call

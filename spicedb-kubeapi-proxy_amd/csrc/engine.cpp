@@ -565,34 +565,48 @@ int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int perm, int stype, in
     return acl_lookup_resources_batch(h, rtype, perm, stype, srel, &sid, 1, bitmap, words, count);
 }
 
+extern "C++" {
+namespace aclint {
+// LookupResourcesRequest strings -> ids (lookups.go:49-62); the subject is interned so `stype:sid#srel` can be its own member
+int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
+                   int *st_out, int *sr_out, uint32_t *sub_out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    if (empty(rtype) || empty(perm) || empty(stype) || empty(sid)) return fail(ACL_ERR_INVALID_ARGUMENT, "invalid LookupResourcesRequest: empty field");
+    if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    const Schema &sc = h->store.schema();
+    int sr = -1;
+    const int rt = sc.type_of(rtype);
+    if (rt < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + rtype + "` not found");
+    const int pm = sc.defs[rt].find(perm);
+    if (pm < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation/permission `") + perm + "` not found under definition `" + rtype + "`");
+    const int st = sc.type_of(stype);
+    if (st < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + stype + "` not found");
+    if (!empty(srel) && std::strcmp(srel, "...") != 0) {
+        sr = sc.defs[st].find(srel);
+        if (sr < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation `") + srel + "` not found under definition `" + stype + "`");
+    }
+    *sub_out = h->store.objects(st).intern(sid);
+    // a subject the reverse rows have no room for (beyond the headroom ids): they are rebuilt by this lookup
+    if (sr >= 0 && h->snap.has_reverse && h->store.objects(st).count() > h->snap.slot_nobjects[sc.slot(st, sr)]) {
+        h->rev_uploaded = false;
+        h->snap.has_reverse = false;
+    }
+    *rt_out = rt;
+    *pm_out = pm;
+    *st_out = st;
+    *sr_out = sr;
+    return ACL_OK;
+}
+}  // namespace aclint
+}  // extern "C++"
+
 int acl_lookup_resources(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap,
                          size_t words, uint64_t *count) {
-    int rt, pm, st, sr = -1;
+    int rt, pm, st, sr;
     uint32_t sub;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-        if (empty(rtype) || empty(perm) || empty(stype) || empty(sid)) return fail(ACL_ERR_INVALID_ARGUMENT, "invalid LookupResourcesRequest: empty field");
-        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
-        const Schema &sc = h->store.schema();
-        rt = sc.type_of(rtype);
-        if (rt < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + rtype + "` not found");
-        pm = sc.defs[rt].find(perm);
-        if (pm < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation/permission `") + perm + "` not found under definition `" + rtype + "`");
-        st = sc.type_of(stype);
-        if (st < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + stype + "` not found");
-        if (!empty(srel) && std::strcmp(srel, "...") != 0) {
-            sr = sc.defs[st].find(srel);
-            if (sr < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation `") + srel + "` not found under definition `" + stype + "`");
-        }
-        // the subject may be new to the store; give it an id so `stype:sid#srel` can be its own member
-        sub = h->store.objects(st).intern(sid);
-        // a subject the reverse rows have no room for (beyond the headroom ids): they are rebuilt by this lookup
-        if (sr >= 0 && h->snap.has_reverse && h->store.objects(st).count() > h->snap.slot_nobjects[sc.slot(st, sr)]) {
-            h->rev_uploaded = false;
-            h->snap.has_reverse = false;
-        }
-    }
+    int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &rt, &pm, &st, &sr, &sub);
+    if (rc) return rc;
     return acl_lookup_resources_batch(h, rt, pm, st, sr, &sub, 1, bitmap, words, count);
 }
 

@@ -1,5 +1,7 @@
 // engine_callers.cpp -- the callers either side of the kernels: PostFilter keep mask, PreFilter bitmap test,
 // Watch change feed, snapshot self-check hook, micro-batching front-end.
+#include <tuple>
+
 #include "engine_internal.hpp"
 
 // ---------------------------------------------------------------- callers either side of the kernels
@@ -129,6 +131,8 @@ static void batcher_loop(acl_engine_t *h) {
     std::vector<acl_item_t> items;
     std::vector<uint8_t> perm;
     std::vector<int32_t> err;
+    std::vector<uint32_t> sids, bms;
+    std::vector<uint64_t> cnts;
     bool back_to_back = false;  // the previous pass WAS the batching window: whoever arrived during it goes now
     for (;;) {
         {
@@ -142,24 +146,65 @@ static void batcher_loop(acl_engine_t *h) {
             batch.assign(h->queue.begin(), h->queue.begin() + (long)take);
             h->queue.erase(h->queue.begin(), h->queue.begin() + (long)take);
         }
-        items.resize(batch.size());
-        perm.assign(batch.size(), 0);
-        err.assign(batch.size(), 0);
-        for (size_t i = 0; i < batch.size(); i++) items[i] = batch[i]->item;
-        int rc = acl_check_bulk_ids(h, items.data(), items.size(), perm.data(), err.data());
+        // Checks of the batch: one device pass
+        items.clear();
+        for (acl_engine::Waiter *w : batch)
+            if (w->kind == 0) items.push_back(w->item);
+        perm.assign(items.size(), 0);
+        err.assign(items.size(), 0);
+        int rc = items.empty() ? ACL_OK : acl_check_bulk_ids(h, items.data(), items.size(), perm.data(), err.data());
         const std::string msg = rc ? acl_last_error() : "";
+        // LookupResources of the batch: one batched reverse walk per (resource type, permission, subject class)
+        std::vector<acl_engine::Waiter *> lks;
+        for (acl_engine::Waiter *w : batch)
+            if (w->kind == 1) lks.push_back(w);
+        std::sort(lks.begin(), lks.end(), [](const acl_engine::Waiter *a, const acl_engine::Waiter *b) {
+            return std::tie(a->lk_rtype, a->lk_perm, a->lk_stype, a->lk_srel, a->lk_words) < std::tie(b->lk_rtype, b->lk_perm, b->lk_stype, b->lk_srel, b->lk_words);
+        });
+        uint64_t walks = 0;
+        for (size_t g0 = 0; g0 < lks.size();) {
+            size_t g1 = g0 + 1;
+            while (g1 < lks.size() && std::tie(lks[g1]->lk_rtype, lks[g1]->lk_perm, lks[g1]->lk_stype, lks[g1]->lk_srel, lks[g1]->lk_words) ==
+                                          std::tie(lks[g0]->lk_rtype, lks[g0]->lk_perm, lks[g0]->lk_stype, lks[g0]->lk_srel, lks[g0]->lk_words))
+                g1++;
+            const size_t m = g1 - g0, words = lks[g0]->lk_words;
+            sids.resize(m);
+            bms.assign(m * words, 0);
+            cnts.assign(m, 0);
+            for (size_t i = 0; i < m; i++) sids[i] = lks[g0 + i]->lk_sid;
+            const int lrc = acl_lookup_resources_batch(h, lks[g0]->lk_rtype, lks[g0]->lk_perm, lks[g0]->lk_stype, lks[g0]->lk_srel, sids.data(), m, bms.data(),
+                                                       words, cnts.data());
+            const std::string lmsg = lrc ? acl_last_error() : "";
+            for (size_t i = 0; i < m; i++) {
+                acl_engine::Waiter *w = lks[g0 + i];
+                w->rc = lrc;
+                w->msg = lmsg;
+                if (!lrc) {
+                    std::memcpy(w->lk_bitmap, bms.data() + i * words, words * sizeof(uint32_t));
+                    w->lk_count = cnts[i];
+                }
+            }
+            walks++;
+            g0 = g1;
+        }
         {
             std::lock_guard<std::mutex> lk(h->q_mu);
-            for (size_t i = 0; i < batch.size(); i++) {
-                batch[i]->rc = rc;
-                batch[i]->msg = msg;
-                batch[i]->perm = perm[i];
-                batch[i]->err = err[i];
-                batch[i]->done = true;
-                batch[i]->cv.notify_one();
+            size_t ci = 0;
+            for (acl_engine::Waiter *w : batch) {
+                if (w->kind == 0) {
+                    w->rc = rc;
+                    w->msg = msg;
+                    w->perm = perm[ci];
+                    w->err = err[ci];
+                    ci++;
+                }
+                w->done = true;
+                w->cv.notify_one();
             }
-            h->mb_batches++;
-            h->mb_items += batch.size();
+            if (!items.empty()) h->mb_batches++;
+            h->mb_items += items.size();
+            h->mb_lookup_walks += walks;
+            h->mb_lookups += lks.size();
         }
         back_to_back = true;
     }
@@ -194,6 +239,39 @@ int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items) {
     if (batches) *batches = h->mb_batches;
     if (items) *items = h->mb_items;
     return ACL_OK;
+}
+
+int acl_batcher_lookup_stats(acl_engine_t *h, uint64_t *walks, uint64_t *lookups) {
+    std::lock_guard<std::mutex> lk(h->q_mu);
+    if (walks) *walks = h->mb_lookup_walks;
+    if (lookups) *lookups = h->mb_lookups;
+    return ACL_OK;
+}
+
+// One LookupResources request (lookups.go:65; one per list request, issued from its own goroutine: responsefilterer.go:165).
+// While the batcher runs, concurrent requests for the same (resource type, permission, subject class) share ONE batched
+// reverse walk.  Blocks until answered; bitmap_out as for acl_lookup_resources.
+int acl_lookup_one(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
+                   size_t bitmap_words, uint64_t *count_out) {
+    if (!bitmap_out && bitmap_words) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_one: NULL bitmap");
+    acl_engine::Waiter w;
+    w.kind = 1;
+    int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &w.lk_rtype, &w.lk_perm, &w.lk_stype, &w.lk_srel, &w.lk_sid);
+    if (rc) return rc;
+    w.lk_bitmap = bitmap_out;
+    w.lk_words = bitmap_words;
+    {
+        std::unique_lock<std::mutex> lk(h->q_mu);
+        if (h->batcher_on && !h->batcher_stop) {
+            h->queue.push_back(&w);
+            if (h->queue.size() == 1 || h->queue.size() >= h->mb_max_items) h->q_cv.notify_one();
+            w.cv.wait(lk, [&] { return w.done; });
+            if (w.rc) return fail(w.rc, w.msg);
+            if (count_out) *count_out = w.lk_count;
+            return ACL_OK;
+        }
+    }
+    return acl_lookup_resources_batch(h, w.lk_rtype, w.lk_perm, w.lk_stype, w.lk_srel, &w.lk_sid, 1, bitmap_out, bitmap_words, count_out);
 }
 
 // CheckPermission (watch.go:50) / a 1-item CheckBulkPermissions (check.go:23-48).  Blocks until answered.

@@ -113,9 +113,15 @@ struct acl_engine {
     DevArray<uint8_t> d_keep;
     // micro-batching front-end (acl_check_one): concurrent single checks ride one device pass
     struct Waiter {
+        int kind = 0;  // 0: one Check item; 1: one LookupResources request
         acl_item_t item;
         uint8_t perm = 0;
         int32_t err = 0;
+        int lk_rtype = 0, lk_perm = 0, lk_stype = 0, lk_srel = -1;  // kind 1
+        uint32_t lk_sid = 0;
+        uint32_t *lk_bitmap = nullptr;
+        size_t lk_words = 0;
+        uint64_t lk_count = 0;
         int rc = 0;
         std::string msg;
         bool done = false;
@@ -127,7 +133,7 @@ struct acl_engine {
     std::thread batcher;
     bool batcher_on = false, batcher_stop = false;
     uint32_t mb_max_items = 4096, mb_wait_us = 200;
-    uint64_t mb_batches = 0, mb_items = 0;
+    uint64_t mb_batches = 0, mb_items = 0, mb_lookup_walks = 0, mb_lookups = 0;
     // measurement
     acl_stats_t stats{};
     bool timing = false;
@@ -168,6 +174,8 @@ bool empty(const char *s);
 FilterText to_filter(const acl_filter_t *f);
 // strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55)
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
+int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
+                   int *st_out, int *sr_out, uint32_t *sub_out);
 
 // Runs iterations 1.. of a level loop until the frontier is empty.  `launch(iter)` enqueues
 // one expansion.  Returns ACL_OK, or ACL_ERR_RESOURCE_EXHAUSTED when the frontier overflowed.

@@ -122,6 +122,44 @@ def test_micro_batcher_concurrent_single_checks(aclgpu):
         assert e.check_one("", "x", "view", "user", "u") == (0, aclgpu.ERR_INVALID_ARGUMENT)
 
 
+def test_micro_batcher_coalesces_lookups(aclgpu):
+    """Concurrent LookupResources requests (one per list request in the proxy) of the same (type, permission, subject class)
+    share batched reverse walks; every set equals the oracle's; requests of another class are walked separately."""
+    from tests.test_oracle_cross import SCHEMA
+    from tests.test_sharded_gloo import random_tuples
+    import random
+    tuples = [t for t in random_tuples(random.Random(4), 40) if not (t[0] == t[3] and int(t[4][1:]) <= int(t[1][1:]))]
+    co = orc.Oracle(SCHEMA)
+    co.write([(orc.OP_TOUCH, t) for t in tuples])
+    with aclgpu.Engine(SCHEMA) as e:
+        e.write([(aclgpu.OP_TOUCH, t) for t in tuples])
+        e.batcher_start(256, 2000)
+        reqs = [("doc", "view", "user", f"u{i % 4}", "") for i in range(24)] + [("org", "view", "user", f"u{i % 4}", "") for i in range(8)] + [
+            ("doc", "view", "group", "g0", "member")] * 4
+        got, errs = [None] * len(reqs), []
+
+        def worker(i):
+            try:
+                got[i] = e.lookup_one(*reqs[i])
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(len(reqs))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs[:1]
+        for r, g in zip(reqs, got):
+            assert g == co.lookup(*r), r
+        st = e.batcher_lookup_stats()
+        assert st["lookups"] == len(reqs) and 3 <= st["walks"] < len(reqs) / 2, st
+        e.batcher_stop()
+        assert e.lookup_one("doc", "view", "user", "u1") == co.lookup("doc", "view", "user", "u1")  # no batcher: a walk of its own
+        with pytest.raises(aclgpu.AclError):
+            e.lookup_one("nosuch", "view", "user", "u1")
+
+
 def test_watch_then_recheck(aclgpu):
     """RunWatch (watch.go:27-111): per update of the watched type, ONE check of (updated resource, the request's
     subject) decides allowed/denied -- here the polled updates are re-checked as one batch."""
