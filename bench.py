@@ -226,36 +226,48 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
     result = {}
     box = {}
 
+    modes = ["allgather", "alltoall"] if args.exchange == "both" else [args.exchange]
+
     def run(se, comm_barrier):
         d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
-        p = e = None
-        for _ in range(2):
-            p, e = se.check_bulk_ids(d_items)
-        x0, c0 = se.exchanged_entries, se.exchanges
-        comm_barrier()
-        t0 = time.perf_counter()
-        lat = []
-        for _ in range(steps):
-            t1 = time.perf_counter()
-            p, e = se.check_bulk_ids(d_items)
-            lat.append(time.perf_counter() - t1)
-        comm_barrier()
-        el = time.perf_counter() - t0
-        mism = int((p.cpu().numpy() != want_p).sum() + (e.cpu().numpy() != want_e).sum())
-        return {"elapsed": el, "lat": lat, "mismatches": mism, "levels": se.levels_last, "recv_entries_per_batch": (se.exchanged_entries - x0) / steps,
-                "exchanges_per_batch": (se.exchanges - c0) / steps, "shard_relationships": None, "export_cap": se.cap}
+        res_by_mode = {}
+        for mode in modes:
+            se.exchange = mode
+            se._alloc(max(se.cap, 1 << 20))
+            p = e = None
+            for _ in range(2):
+                p, e = se.check_bulk_ids(d_items)
+            x0, c0 = se.exchanged_entries, se.exchanges
+            comm_barrier()
+            t0 = time.perf_counter()
+            lat = []
+            for _ in range(steps):
+                t1 = time.perf_counter()
+                p, e = se.check_bulk_ids(d_items)
+                lat.append(time.perf_counter() - t1)
+            comm_barrier()
+            el = time.perf_counter() - t0
+            mism = int((p.cpu().numpy() != want_p).sum() + (e.cpu().numpy() != want_e).sum())
+            res_by_mode[mode] = {"elapsed": el, "lat": lat, "mismatches": mism, "levels": se.levels_last,
+                                 "recv_entries_per_batch": (se.exchanged_entries - x0) / steps, "exchanges_per_batch": (se.exchanges - c0) / steps}
+        return {"modes": res_by_mode, "shard_relationships": None}
 
     def done(outs):
-        el = max(o["elapsed"] for o in outs)
         result.update({
-            "layout": f"fnv1a(object type) mod {G}; per-level all-gather of 16 B frontier entries",
-            "collective": "RCCL all_gather_into_tensor over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
-            "shards": G, "batch": n, "steps": steps, "decisions_per_s": n * steps / el, "ms_per_batch": 1e3 * el / steps,
-            "p50_batch_ms": 1e3 * float(np.median(outs[0]["lat"])), "levels": outs[0]["levels"],
-            "exchanges_per_batch": outs[0]["exchanges_per_batch"], "recv_entries_per_batch_by_shard": [o["recv_entries_per_batch"] for o in outs],
-            "shard_relationships": [o["shard_relationships"] for o in outs],
-            "mismatches_vs_replica": int(sum(o["mismatches"] for o in outs)),
-        })
+            "layout": f"fnv1a(object type) mod {G}; 16 B frontier entries cross shards once per level",
+            "transport": "RCCL over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
+            "shards": G, "batch": n, "steps": steps, "shard_relationships": [o["shard_relationships"] for o in outs]})
+        for mode in modes:
+            ms = [o["modes"][mode] for o in outs]
+            el = max(m["elapsed"] for m in ms)
+            result[mode] = {"collective": "all_gather_into_tensor of every export buffer, each rank keeps what it owns" if mode == "allgather"
+                            else "exports grouped by owner on the device, batch_isend_irecv (grouped send/recv) to the owners only",
+                            "decisions_per_s": n * steps / el, "ms_per_batch": 1e3 * el / steps, "p50_batch_ms": 1e3 * float(np.median(ms[0]["lat"])),
+                            "levels": ms[0]["levels"], "exchanges_per_batch": ms[0]["exchanges_per_batch"],
+                            "recv_entries_per_batch_by_shard": [m["recv_entries_per_batch"] for m in ms],
+                            "mismatches_vs_replica": int(sum(m["mismatches"] for m in ms))}
+        result["decisions_per_s"] = result[modes[0]]["decisions_per_s"]
+        result["mismatches_vs_replica"] = int(sum(result[m]["mismatches_vs_replica"] for m in modes))
 
     if world > 1:
         e2 = aclgpu.Engine(w.schema, device=local_rank)
@@ -281,7 +293,6 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
             return sharded.GpuShard(e2, r, g)
 
         def fn(se):
-            se._alloc(1 << 20)
             o = run(se, se.comm.barrier)
             o["shard_relationships"] = int(_local_edges(se.shard.e))
             return o
@@ -312,6 +323,8 @@ def main():
                     help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "
                          "frontiers (north star's 8-GPU layout).  auto = on at 8 ranks.  Reported beside `value`, never as `value`.")
     ap.add_argument("--logical-shards", type=int, default=0, help="with 1 GPU: run the sharded leg as G logical shards on this device (emulated)")
+    ap.add_argument("--exchange", default="both", choices=["allgather", "alltoall", "both"],
+                    help="sharded leg: how Check frontiers cross shards (allgather = the north star's form; alltoall moves G x fewer bytes)")
     args = ap.parse_args()
 
     import torch

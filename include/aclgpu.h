@@ -210,6 +210,11 @@ int acl_shard_grow_frontier(acl_engine_t *h);
 int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *d_has, void *d_err);
 int acl_shard_check_step(acl_engine_t *h, uint32_t level /* 1..50 */, void *d_has, void *d_err, void *d_export, size_t export_cap,
                          acl_shard_step_t *out);
+/* all-to-all form: d_export is `world` buffers of cap_per_dest entries, buffer d holds the entries owned by shard d;
+ * exported_by_dest[d] counts them (out->exported = the largest).  The host sends buffer d to rank d and imports what it
+ * receives; G times fewer bytes than the all-gather form. */
+int acl_shard_check_step_by_dest(acl_engine_t *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t cap_per_dest,
+                                 acl_shard_step_t *out, uint64_t *exported_by_dest /* [world] */);
 int acl_shard_check_import(acl_engine_t *h, uint32_t level, const void *d_entries, size_t n);
 int acl_shard_check_finish(acl_engine_t *h, const void *d_has, const void *d_err, size_t n, void *d_perm_out, void *d_err_out);
 /* LookupResources (lookups.go:65) for n subjects of one class.  Iteration 1 expands the seeds (ACL_SHARD_EXPAND);

@@ -19,7 +19,7 @@ SYMBOLS = [
     "acl_set_now", "acl_snapshot", "acl_check_bulk", "acl_check_bulk_ids", "acl_check_bulk_ids_device", "acl_stream", "acl_sync",
     "acl_lookup_resources", "acl_lookup_resources_ids", "acl_lookup_resources_batch", "acl_stats", "acl_stats_reset", "acl_set_timing",
     "acl_shard_configure", "acl_shard_of_type", "acl_shard_grow_frontier", "acl_shard_check_begin", "acl_shard_check_step",
-    "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
+    "acl_shard_check_step_by_dest", "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
     "acl_shard_lookup_finish",
     "acl_check_bulk_keep", "acl_check_bulk_keep_ids", "acl_check_bulk_keep_ids_device", "acl_bitmap_test_names", "acl_watch_poll",
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
@@ -137,6 +137,7 @@ def load():
     L.acl_shard_grow_frontier.argtypes = [H]
     L.acl_shard_check_begin.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_shard_check_step.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ShardStep)]
+    L.acl_shard_check_step_by_dest.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ShardStep), C.POINTER(C.c_uint64)]
     L.acl_shard_check_import.argtypes = [H, C.c_uint32, C.c_void_p, C.c_size_t]
     L.acl_shard_check_finish.argtypes = [H, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_shard_lookup_begin.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]

@@ -58,6 +58,24 @@ class TorchComm:
     def all_gather(self, out, inp):  # flat views: gloo's all-gather only takes 1-D tensors
         self.dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
 
+    def all_to_all(self, recv, send):
+        """recv[r] <- rank r's send[self.rank]; tensors of any (matching) sizes, empty ones skipped.  Point-to-point pairs
+        (batch_isend_irecv: grouped ncclSend/ncclRecv on RCCL; also available on gloo)."""
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                if send[r].numel():
+                    recv[r].copy_(send[r])
+                continue
+            peer = self.dist.get_global_rank(self.group, r) if self.group is not None else r
+            if send[r].numel():
+                ops.append(self.dist.P2POp(self.dist.isend, send[r].view(-1), peer, self.group))
+            if recv[r].numel():
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[r].view(-1), peer, self.group))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
     def all_reduce_max(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
 
@@ -108,6 +126,17 @@ class ThreadComm:
         if inp.is_cuda:
             torch.cuda.current_stream().synchronize()
         self._s.barrier.wait()  # nobody overwrites its buffer before every peer has copied it
+
+    def all_to_all(self, recv, send):
+        if any(x.is_cuda for x in send):
+            torch.cuda.current_stream().synchronize()
+        parts = self._exchange(send)  # parts[r] = rank r's send list
+        for r in range(self.world):
+            if recv[r].numel():
+                recv[r].copy_(parts[r][self.rank])
+        if any(x.is_cuda for x in recv):
+            torch.cuda.current_stream().synchronize()
+        self._s.barrier.wait()
 
     def all_reduce_max(self, t):
         if t.is_cuda:
@@ -175,6 +204,13 @@ class GpuShard:
     def check_step(self, level, has, err, export):
         return self._step(self._L.acl_shard_check_step, level, has.data_ptr(), err.data_ptr(), export.data_ptr(), export.shape[0])
 
+    def check_step_by_dest(self, level, has, err, export, cap_per_dest):
+        """all-to-all form: `export` holds `world` buffers of cap_per_dest entries -> ((largest count, produced, overflow), counts[world])"""
+        st = _lib.ShardStep()
+        counts = (C.c_uint64 * self.world)()
+        self.e._check(self._L.acl_shard_check_step_by_dest(self._h, level, has.data_ptr(), err.data_ptr(), export.data_ptr(), cap_per_dest, C.byref(st), counts))
+        return (int(st.exported), int(st.produced), int(st.overflow)), [int(c) for c in counts]
+
     def check_import(self, level, entries, n):
         self.e._check(self._L.acl_shard_check_import(self._h, level, entries.data_ptr(), n))
 
@@ -208,9 +244,14 @@ class _Redo(Exception):
 class ShardedEngine:
     """SPMD driver: call the same method with the same arguments on every rank."""
 
-    def __init__(self, shard, comm, export_entries: int = 1 << 16):
+    def __init__(self, shard, comm, export_entries: int = 1 << 16, exchange: str = "allgather"):
+        """exchange: how Check frontiers cross shards -- "allgather" (the north star's form: every rank receives every export
+        buffer and keeps what it owns) or "alltoall" (exports grouped by owner on the device, each rank receives only its own:
+        G times fewer bytes).  LookupResources always all-gathers (a visited state goes to every shard that
+        holds parent rows for it)."""
         assert shard.rank == comm.rank and shard.world == comm.world
-        self.shard, self.comm = shard, comm
+        assert exchange in ("allgather", "alltoall")
+        self.shard, self.comm, self.exchange = shard, comm, exchange
         self.cap = 0
         self._alloc(export_entries)
         self.levels_last = 0
@@ -219,6 +260,9 @@ class ShardedEngine:
 
     def _alloc(self, entries):
         entries = max(8, (int(entries) + 7) // 8 * 8)  # multiples of 8 entries (128 B)
+        if getattr(self, "exchange", "allgather") == "alltoall":  # one buffer of >= 8 entries per destination
+            entries = max(entries, 8 * self.comm.world)
+            entries = (entries + 8 * self.comm.world - 1) // (8 * self.comm.world) * (8 * self.comm.world)
         dev = self.shard.device
         self.export = torch.empty((entries, ENTRY_WORDS), dtype=torch.int32, device=dev)
         self.gather = torch.empty((entries * self.comm.world, ENTRY_WORDS), dtype=torch.int32, device=dev)
@@ -283,6 +327,8 @@ class ShardedEngine:
             return perm[:n], errout[:n]
 
     def _check_levels(self, items, has, err):
+        if self.exchange == "alltoall":
+            return self._check_levels_a2a(items, has, err)
         sh = self.shard
         sh.check_begin(items, has, err)
         for level in range(1, MAX_LEVELS + 1):
@@ -294,6 +340,44 @@ class ShardedEngine:
                 break
             if mx:
                 self._exchange(info, mx, sh.check_import, level)
+
+    def _check_levels_a2a(self, items, has, err):
+        """Same level loop with exports grouped by destination: export = world buffers of `cap // world` entries."""
+        sh, w, me = self.shard, self.comm.world, self.comm.rank
+        per = self.cap // w  # _alloc keeps cap a multiple of 8 * world
+        sh.check_begin(items, has, err)
+        for level in range(1, MAX_LEVELS + 1):
+            rep, counts = sh.check_step_by_dest(level, has, err, self.export, per)
+            info = self.comm.all_gather_small(list(rep) + counts)  # [r] = (largest, produced, overflow, count to 0, ..., count to w-1)
+            if (info[:, 2] == 2).any():
+                raise AclError(ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit")
+            redo = False
+            if (info[:, 2] == 1).any():
+                if info[me, 2] == 1:
+                    sh.grow_frontier()
+                redo = True
+            mx = int(info[:, 3:].max())
+            if mx > per:
+                self._alloc(2 * mx * w)
+                redo = True
+            if redo:
+                raise _Redo()
+            self.levels_last = level
+            total = int(info[:, 3:].sum())
+            if total == 0 and not info[:, 1].any():
+                break
+            if total:
+                send = [self.export[d * per:d * per + int(info[me, 3 + d])] for d in range(w)]
+                off = np.concatenate([[0], np.cumsum(info[:, 3 + me])]).astype(np.int64)
+                if int(off[-1]) > self.gather.shape[0]:
+                    self.gather = torch.empty((int(off[-1]) * 2, ENTRY_WORDS), dtype=torch.int32, device=sh.device)
+                recv = [self.gather[int(off[r]):int(off[r + 1])] for r in range(w)]
+                self.comm.all_to_all(recv, send)
+                self.exchanges += 1
+                n_in = int(off[-1])
+                if n_in:
+                    sh.check_import(level, self.gather[:n_in], n_in)
+                    self.exchanged_entries += n_in - int(info[me, 3 + me])
 
     # ---- LookupResources
     def lookup_ids_batch(self, rtype, perm, stype, srel, subject_ids):
@@ -341,6 +425,7 @@ def run_logical_shards(world: int, make_shard, fn):
     make_shard(rank, world) -> shard object.  Returns the per-rank results; re-raises the first failure."""
     comms = ThreadComm.create(world)
     out, errs = [None] * world, [None] * world
+    exchange = getattr(fn, "exchange", "allgather")
     dev = torch.cuda.current_device() if torch.cuda.is_available() else None
 
     def work(r):
@@ -348,7 +433,7 @@ def run_logical_shards(world: int, make_shard, fn):
             if dev is not None:
                 torch.cuda.set_device(dev)
             sh = make_shard(r, world)
-            out[r] = fn(ShardedEngine(sh, comms[r]))
+            out[r] = fn(ShardedEngine(sh, comms[r], exchange=exchange))
         except BaseException as ex:  # noqa: BLE001
             errs[r] = ex
             comms[r]._s.barrier.abort()

@@ -17,6 +17,8 @@ DevShard dev_shard(acl_engine *h, void *d_export, size_t cap) {
     return sh;
 }
 
+int check_step(acl_engine *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t cap, bool by_dest, acl_shard_step_t *out, uint64_t *by_dest_out);
+
 // reads back the status block after a level and fills the step report
 int shard_report(acl_engine *h, uint32_t iter, acl_shard_step_t *out) {
     HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -33,6 +35,38 @@ int shard_ready(acl_engine *h, uint32_t iter) {
     if (iter == 0 || iter >= kLevelSlots) return fail(ACL_ERR_INVALID_ARGUMENT, "shard step: iteration out of range");
     if (!h->snap_valid) return fail(ACL_ERR_FAILED_PRECONDITION, "shard step without acl_shard_*_begin");
     HIP_TRY(hipSetDevice(h->device));
+    return ACL_OK;
+}
+
+}  // namespace
+
+namespace {
+
+int check_step(acl_engine *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t cap, bool by_dest, acl_shard_step_t *out, uint64_t *by_dest_out) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!out || !d_has || !d_err || (cap && !d_export)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: NULL buffer");
+    int rc = shard_ready(h, level);
+    if (rc) return rc;
+    if (level > kMaxLevels) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: level beyond the dispatch depth limit");
+    if (by_dest && h->shard.world > kMaxShards) return fail(ACL_ERR_INVALID_ARGUMENT, "per-destination export supports at most 64 shards");
+    HIP_TRY(hipMemsetAsync(h->d_status.p + 2 * kLevelSlots + 1, 0, (1 + kMaxShards) * sizeof(uint32_t), h->stream));
+    DevShard sh = dev_shard(h, d_export, cap);
+    sh.by_dest = by_dest ? 1u : 0u;
+    ev_begin(h, 1);
+    launch_expand(h->stream, h->dev_graph(), h->dev_frontier(), level, (uint8_t *)d_has, (uint8_t *)d_err, sh);
+    ev_end(h);
+    h->stats.expand_launches++;
+    h->stats.levels_last = level;
+    rc = shard_report(h, level, out);
+    if (rc) return rc;
+    if (by_dest) {
+        uint64_t mx = 0;
+        for (uint32_t d = 0; d < h->shard.world; d++) {
+            by_dest_out[d] = h->h_status[2 * kLevelSlots + 2 + d];
+            mx = std::max(mx, by_dest_out[d]);
+        }
+        out->exported = mx;  // the largest per-destination count: what the caller sizes a retry by
+    }
     return ACL_OK;
 }
 
@@ -87,18 +121,13 @@ int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *
 }
 
 int acl_shard_check_step(acl_engine_t *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t export_cap, acl_shard_step_t *out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (!out || !d_has || !d_err || (export_cap && !d_export)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: NULL buffer");
-    int rc = shard_ready(h, level);
-    if (rc) return rc;
-    if (level > kMaxLevels) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step: level beyond the dispatch depth limit");
-    HIP_TRY(hipMemsetAsync(h->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), h->stream));
-    ev_begin(h, 1);
-    launch_expand(h->stream, h->dev_graph(), h->dev_frontier(), level, (uint8_t *)d_has, (uint8_t *)d_err, dev_shard(h, d_export, export_cap));
-    ev_end(h);
-    h->stats.expand_launches++;
-    h->stats.levels_last = level;
-    return shard_report(h, level, out);
+    return check_step(h, level, d_has, d_err, d_export, export_cap, false, out, nullptr);
+}
+
+int acl_shard_check_step_by_dest(acl_engine_t *h, uint32_t level, void *d_has, void *d_err, void *d_export, size_t cap_per_dest, acl_shard_step_t *out,
+                                 uint64_t *exported_by_dest) {
+    if (!exported_by_dest) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_step_by_dest: NULL counts");
+    return check_step(h, level, d_has, d_err, d_export, cap_per_dest, true, out, exported_by_dest);
 }
 
 int acl_shard_check_import(acl_engine_t *h, uint32_t level, const void *d_entries, size_t n) {

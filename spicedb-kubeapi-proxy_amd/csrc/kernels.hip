@@ -387,14 +387,29 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
 
 // Expand the first T tasks of the wave's LDS list.  INLINE: children are probed here and only the ones with
 // remaining enumeration work are written (forward Check); otherwise every child is written (reverse walk).
-// wave-cooperative append of the flagged lanes' entries to the shard's export buffer (one atomic per call)
-__device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint32_t lane, const DevShard &sh) {
-    const uint64_t bx = __ballot(xport);
-    if (!bx) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(sh.exp_count, (uint32_t)__popcll(bx));
-    const uint32_t at = uniform(base) + lanes_below(bx);
-    if (xport && at < sh.cap) sh.exp[at] = e;
+// wave-cooperative append of the flagged lanes' entries to the shard's export buffer (one atomic per call and destination).
+// sh.by_dest: one buffer per destination shard (`dest` = owner of the entry's slot) for an all-to-all exchange; otherwise
+// one buffer that every shard receives (all-gather; also the reverse walk's broadcast of visited states).
+__device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint32_t dest, uint32_t lane, const DevShard &sh) {
+    uint64_t todo = __ballot(xport);
+    if (!todo) return;
+    if (!sh.by_dest) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(sh.exp_count, (uint32_t)__popcll(todo));
+        const uint32_t at = uniform(base) + lanes_below(todo);
+        if (xport && at < sh.cap) sh.exp[at] = e;
+        return;
+    }
+    while (todo) {
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dest, (int)(__ffsll((unsigned long long)todo) - 1));
+        const bool mine = xport && dest == d;
+        const uint64_t m = __ballot(mine);
+        todo &= ~m;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(sh.exp_count + 1 + d, (uint32_t)__popcll(m));
+        const uint32_t at = uniform(base) + lanes_below(m);
+        if (mine && at < sh.cap) sh.exp[(size_t)d * sh.cap + at] = e;
+    }
 }
 
 template <bool INLINE, bool SHARDED>
@@ -502,7 +517,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                 const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
                 if (push && base != kNoSpace) out[base + lanes_below(b)] = e;
             }
-            if (INLINE && SHARDED) export_entries(xport, e, lane, sh);
+            if (INLINE && SHARDED) export_entries(xport, e, xport ? progs[meta_slot(e.z)].owner : 0u, lane, sh);
         }
         wave_lds_fence();
     }
@@ -861,7 +876,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                 const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
                 if (active && base != kNoSpace) out[base + lanes_below(b)] = o;
             }
-            export_entries(first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels, make_uint4(id, req, meta | kRevForeign, 0), lane, sh);
+            export_entries(first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels, make_uint4(id, req, meta | kRevForeign, 0), 0u, lane, sh);
             continue;
         }
         const uint32_t nops = (active && dist < kMaxLevels) ? (p.n & ~kRevRemoteBit) : 0u;  // parents of a dist-50 state would need 51 levels

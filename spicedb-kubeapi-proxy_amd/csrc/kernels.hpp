@@ -13,7 +13,8 @@ constexpr uint32_t kChunk = 1024;         // entries per frontier chunk (16 KiB)
 constexpr uint32_t kSegsPerChunk = kChunk / 64;
 constexpr uint32_t kMaxLevels = 50;       // dispatch max depth, reference pkg/spicedb/spicedb.go:34
 constexpr uint32_t kLevelSlots = 128;     // per-iteration counters (the sharded reverse walk runs two iterations per level)
-constexpr uint32_t kStatusWords = 2 * kLevelSlots + 2;  // nchunks[] | any[] | overflow | export count
+constexpr uint32_t kMaxShards = 64;      // per-destination export counters (all-to-all exchange)
+constexpr uint32_t kStatusWords = 2 * kLevelSlots + 2 + kMaxShards;  // nchunks[] | any[] | overflow | export count | export count per destination
 constexpr uint32_t kDeadMeta = 0xFFFFFFFFu;
 constexpr int kWavesPerBlock = 4;
 constexpr uint32_t kProgLdsEntries = 256;  // ops + progs (32 B each) cached in LDS when they fit
@@ -57,7 +58,8 @@ struct DevFrontier {
 // `exp_count` keeps counting past `cap` (entries beyond it are dropped) so the host can size a retry.
 struct DevShard {
     uint4 *exp = nullptr;
-    uint32_t *exp_count = nullptr;
+    uint32_t *exp_count = nullptr;   // [1] all-gather form; followed by [kMaxShards] per-destination counters (all-to-all form)
+    uint32_t by_dest = 0;            // != 0: `exp` is `world` buffers of `cap` entries, entry -> the buffer of the shard that owns its slot
     uint32_t cap = 0;
     uint32_t rank = 0;
     uint32_t world = 1;

@@ -156,9 +156,23 @@ class CpuShard:
                 else:
                     exports.append(self._enc(ct, cname, cm, lv + 1, req))
         self.frontier = nxt
+        self._last_exports = exports
         for i, row in enumerate(exports[:export.shape[0]]):
             export[i] = torch.tensor(row, dtype=torch.int64).to(torch.int32)
         return len(exports), 1 if nxt else 0, 0
+
+    def check_step_by_dest(self, level, has, err, export, cap_per_dest):
+        tmp = torch.zeros((max(1, export.shape[0]), 4), dtype=torch.int32)
+        n, produced, ov = self.check_step(level, has, err, tmp[:0])  # count only; entries regrouped below
+        rows = self._last_exports
+        counts = [0] * self.world
+        for row in rows:
+            t, _m = self.u.slots[row[2] & 0x1FFF]
+            d = self.owner[t]
+            if counts[d] < cap_per_dest:
+                export[d * cap_per_dest + counts[d]] = torch.tensor(row, dtype=torch.int64).to(torch.int32)
+            counts[d] += 1
+        return (max(counts) if counts else 0, produced, ov), counts
 
     def check_import(self, level, entries, n):
         for row in entries[:n].tolist():

@@ -32,7 +32,7 @@ def main():
         for (_rt, _pm, st, sid, _sr) in case["lookups"]:
             u.ensure(st, sid)
         sh = CpuShard(u, rank, world)
-        eng = ShardedEngine(sh, comm, export_entries=case.get("export_entries", 1 << 12))
+        eng = ShardedEngine(sh, comm, export_entries=case.get("export_entries", 1 << 12), exchange=os.environ.get("ACL_EXCHANGE", "allgather"))
         perm, err = eng.check_bulk_ids(items)
         res = {"perm": perm.tolist(), "err": err.tolist(), "levels": eng.levels_last, "exchanges": eng.exchanges, "lookups": [],
                "owners": {t: sh.owner_of_type(t) for t in u.types}, "cap": eng.cap}

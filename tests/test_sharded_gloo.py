@@ -73,7 +73,7 @@ def make_cases():
     return cases
 
 
-def run_world(world, cases, tmp_path):
+def run_world(world, cases, tmp_path, exchange="allgather"):
     cf, of = tmp_path / "cases.json", tmp_path / "out.json"
     cf.write_text(json.dumps(cases))
     with socket.socket() as s:
@@ -81,7 +81,7 @@ def run_world(world, cases, tmp_path):
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", ACL_EXCHANGE=exchange)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(cf), str(of)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -97,10 +97,10 @@ def run_world(world, cases, tmp_path):
     return json.loads(of.read_text())
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_protocol_matches_unsharded_oracle(world, tmp_path):
+@pytest.mark.parametrize("world,exchange", [(2, "allgather"), (3, "allgather"), (2, "alltoall"), (3, "alltoall")])
+def test_sharded_protocol_matches_unsharded_oracle(world, exchange, tmp_path):
     cases = make_cases()
-    results = run_world(world, cases, tmp_path)
+    results = run_world(world, cases, tmp_path, exchange)
     crossed = 0
     for case, res in zip(cases, results):
         o = PyOracle(case["schema"])

@@ -21,10 +21,10 @@ def bits(row):
     return np.flatnonzero(np.unpackbits(row.cpu().numpy().view(np.uint8), bitorder="little")).astype(np.uint32)
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world,exchange", [(2, "allgather"), (8, "allgather"), (3, "alltoall"), (8, "alltoall")])
 @pytest.mark.parametrize("name,kw", [("C2", dict(scale=0.05, batch=20000)), ("C3", dict(scale=0.05, batch=4000, power_users=8)),
                                      ("C4", dict(scale=0.02, batch=30000, n_user=20000))], ids=["C2", "C3", "C4"])
-def test_sharded_workload_parity(name, kw, world, aclgpu):
+def test_sharded_workload_parity(name, kw, world, exchange, aclgpu):
     from aclgpu import sharded, workloads
     w = workloads.by_name(name, **kw)
     o = orc.Oracle(w.schema)
@@ -51,6 +51,7 @@ def test_sharded_workload_parity(name, kw, world, aclgpu):
         owners = {se.shard.owner_of_type(t) for t in w.nobjects if t != st}  # the types that hold relationships
         return p.cpu().numpy(), er.cpu().numpy(), bm.cpu(), se.exchanged_entries, owners, se.levels_last
 
+    run.exchange = exchange
     try:
         outs = sharded.run_logical_shards(world, make, run)
     finally:
@@ -155,6 +156,7 @@ def test_sharded_random_graphs_and_depth(world, aclgpu):
                 got.append({e.object_name(rt, int(b)) for b in bits(bm[0])})
             return list(zip(p.cpu().tolist(), er.cpu().tolist())), got
 
+        run.exchange = "alltoall" if world % 2 else "allgather"
         try:
             outs = sharded.run_logical_shards(world, make, run)
         finally:
