@@ -205,7 +205,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
         raise SystemExit("PARITY FAILURE in the sharded mixed stream")
 
 
-def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
+def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
     """The north star's multi-GPU layout: rows partitioned by fnv1a(object type) mod G, one shard per
     rank, per-level all-gather of cross-shard frontier entries over RCCL.  All ranks answer ONE batch together; the
     answers are compared with the replica engine's.  world == 1: G logical shards (threads) on this device -- emulated."""
@@ -223,12 +223,10 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
     items = replica.make_items(rt, perm_name, res, st, "", subj)
     want_p, want_e = replica.check_bulk_ids(items)
     G = world if world > 1 else args.logical_shards
-    result = {}
-    box = {}
 
     modes = ["allgather", "alltoall"] if args.exchange == "both" else [args.exchange]
 
-    def run(se, comm_barrier):
+    def run(se, comm_barrier, after_mode=None):
         d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
         res_by_mode = {}
         for mode in modes:
@@ -250,16 +248,18 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
             mism = int((p.cpu().numpy() != want_p).sum() + (e.cpu().numpy() != want_e).sum())
             res_by_mode[mode] = {"elapsed": el, "lat": lat, "mismatches": mism, "levels": se.levels_last,
                                  "recv_entries_per_batch": (se.exchanged_entries - x0) / steps, "exchanges_per_batch": (se.exchanges - c0) / steps}
+            if after_mode:
+                after_mode(mode, res_by_mode[mode])
         return {"modes": res_by_mode, "shard_relationships": None}
 
-    def done(outs):
-        result.update({
-            "layout": f"fnv1a(object type) mod {G}; 16 B frontier entries cross shards once per level",
-            "transport": "RCCL over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
-            "shards": G, "batch": n, "steps": steps, "shard_relationships": [o["shard_relationships"] for o in outs]})
-        for mode in modes:
-            ms = [o["modes"][mode] for o in outs]
-            el = max(m["elapsed"] for m in ms)
+    result.update({
+        "layout": f"fnv1a(object type) mod {G}; 16 B frontier entries cross shards once per level",
+        "transport": "RCCL over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
+        "shards": G, "batch": n, "steps": steps})
+
+    def mode_done(mode, ms):  # ms: every rank's record of one exchange form (filled in as soon as that form has run)
+        el = max(m["elapsed"] for m in ms)
+        if True:
             result[mode] = {"collective": "all_gather_into_tensor of every export buffer, each rank keeps what it owns" if mode == "allgather"
                             else "exports grouped by owner on the device, batch_isend_irecv (grouped send/recv) to the owners only",
                             "decisions_per_s": n * steps / el, "ms_per_batch": 1e3 * el / steps, "p50_batch_ms": 1e3 * float(np.median(ms[0]["lat"])),
@@ -267,20 +267,29 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
                             "recv_entries_per_batch_by_shard": [m["recv_entries_per_batch"] for m in ms],
                             "mismatches_vs_replica": int(sum(m["mismatches"] for m in ms))}
         result["decisions_per_s"] = result[modes[0]]["decisions_per_s"]
-        result["mismatches_vs_replica"] = int(sum(result[m]["mismatches_vs_replica"] for m in modes))
+        result["mismatches_vs_replica"] = int(sum(result[m]["mismatches_vs_replica"] for m in modes if m in result))
+
+    def done(outs):
+        result["shard_relationships"] = [o["shard_relationships"] for o in outs]
+        for mode in modes:
+            mode_done(mode, [o["modes"][mode] for o in outs])
 
     if world > 1:
         e2 = aclgpu.Engine(w.schema, device=local_rank)
         w.load(e2)
         sh = sharded.GpuShard(e2, rank, world)
         se = sharded.ShardedEngine(sh, sharded.TorchComm(device=f"cuda:{local_rank}"), export_entries=1 << 20)
-        try:
-            o = run(se, dist.barrier)
-            o["shard_relationships"] = int(_local_edges(e2))
-            gathered = [None] * world
-            dist.all_gather_object(gathered, {k: v for k, v in o.items()})
+        def after_mode(mode, rec):  # the all-gather form's numbers survive whatever the all-to-all form does on real RCCL
+            g = [None] * world
+            dist.all_gather_object(g, rec)
             if rank == 0:
-                done(gathered)
+                mode_done(mode, g)
+
+        try:
+            o = run(se, dist.barrier, after_mode)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, int(_local_edges(e2)))
+            result["shard_relationships"] = gathered
         finally:
             e2.close()
     else:
@@ -302,7 +311,7 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank):
         finally:
             for _r, e2 in engines:
                 e2.close()
-    return result if rank == 0 else None
+    return result
 
 
 def _local_edges(engine):
@@ -510,17 +519,21 @@ def main():
                 out["sharded"] = extra
                 print(json.dumps(out), flush=True)
 
+        sharded_result = {}
+
         def on_timeout():
-            emit({"error": "sharded leg did not finish within 180 s (collective wedged?)"})
+            sharded_result["error"] = "sharded leg did not finish within 180 s (collective wedged?)"
+            emit(sharded_result)
             os._exit(0)
 
         timer = threading.Timer(180.0, on_timeout)
         timer.daemon = True
         timer.start()
         try:
-            emit(sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank))
+            emit(sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank, sharded_result))
         except Exception as ex:  # noqa: BLE001
-            emit({"error": f"{type(ex).__name__}: {ex}"})
+            sharded_result["error"] = f"{type(ex).__name__}: {ex}"
+            emit(sharded_result)
         finally:
             timer.cancel()
     elif rank == 0:
