@@ -1,0 +1,65 @@
+"""CPU tests of the BASELINE workload generators (spicedb-kubeapi-proxy_amd/aclgpu/workloads.py) that bench.py and the parity
+tests share: sizes as SURVEY.md 8(d) specifies them, determinism per seed, acyclic group nesting (so that no request's answer
+hinges on the depth limit), and the oracle agreeing with the generator's own intent for the request mix."""
+import importlib.util
+import os
+
+import numpy as np
+
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c4_shape_and_determinism():
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.05, batch=5000)
+    w2 = workloads.c4(scale=0.05, batch=5000)
+    assert w.ntuples == w2.ntuples and np.array_equal(w.res, w2.res) and np.array_equal(w.subj, w2.subj)
+    assert abs(w.ntuples - 500_000) < 5_000  # 10 M * scale, after de-duplication
+    assert sum(w.nobjects.values()) == 50_000
+    # nesting is acyclic by construction: a level-l group only contains level-(l+1) groups
+    per = w.meta["groups_per_level"]
+    gg = next(e for e in w.edges if e[0] == "group" and e[3] == "member")
+    assert (gg[5] // per == gg[4] // per + 1).all()
+    # the request mix really contains deep hits: most requests are allowed, none errors (no depth-limit ambiguity)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    perm, err = o.check_bulk_ids("pod", "view", w.res[:1500], "user", "", w.subj[:1500])
+    assert (err == 0).all() and (perm == 2).mean() > 0.5  # (0.88 at full scale; denser -- more hits -- at reduced scale)
+
+
+def test_c2_c3_shape():
+    from aclgpu import workloads
+    w = workloads.c2(scale=0.1, batch=2000)
+    assert abs(w.ntuples - 100_000) < 3_000 and w.check == ("pod", "view", "user")
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    perm, err = o.check_bulk_ids("pod", "view", w.res, "user", "", w.subj)
+    assert (err == 0).all() and 0.3 < (perm == 2).mean() < 0.9  # hits at pod, namespace and cluster level + ~40 % misses
+    w3 = workloads.c3(scale=0.1, batch=100, power_users=4)
+    n = o2 = None
+    o2 = orc.Oracle(w3.schema)
+    w3.load(o2)
+    n = o2.lookup_ids("pod", "view", "user", "", int(w3.lookup_subjects[0])).size
+    assert 500 < n < 2000  # ~10 k allowed pods per power user at scale 1.0
+
+
+def test_c5_stream_is_the_mixed_stream():
+    from aclgpu import workloads
+    w = workloads.c5(scale=0.001, batch=100, n_lookups=8, n_user=500)
+    ops = workloads.c5_stream(w, 200)
+    f = sum(1 for o in ops if o != "C")
+    assert ops == workloads.c5_stream(w, 200) and 8 <= f <= 35  # ~10 % Filter requests, seeded
+    assert all(o == "C" or (o[0] == "F" and o[1] in set(int(x) for x in w.lookup_subjects)) for o in ops)
+    two = workloads.c5_stream(w, 2)
+    assert any(o == "C" for o in two) and any(o != "C" for o in two)
+
+
+def test_bench_helpers_import_without_gpu():
+    """bench.py must be importable on a box without a GPU (the driver's CPU checks import it) and usable_cores() must be sane."""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert 1 <= m.usable_cores() <= os.cpu_count()
+    assert set(m.WORKLOAD_DESC) == {"C1", "C2", "C3", "C4", "C5"}
