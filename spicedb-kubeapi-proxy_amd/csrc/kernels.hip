@@ -9,8 +9,9 @@
 //   frontier entry = (request, object#relation state)                16 B
 //   k_expand: every lane takes one entry and interprets the state's flattened
 //             program (plan.hpp, cached in LDS): probes of the request's subject in
-//             hashed 4-slot bucket rows (one 16 B gather) or sorted rows (binary
-//             search), and "enumerate" operations whose child states are produced by
+//             hashed rows (two-choice placement over 4-slot buckets: two independent
+//             16 B gathers, never a probing chain) or sorted rows (binary search), and
+//             "enumerate" operations whose child states are produced by
 //             a wave-cooperative, load-balanced expansion:
 //               - per-lane tasks (row start, degree) are compacted into LDS with
 //                 wave64 ballot + mbcnt,
@@ -22,10 +23,15 @@
 //                 children that still have something to enumerate are written, compacted
 //                 with a second ballot, as consecutive 16 B entries (coalesced).  Leaf
 //                 states therefore never enter the frontier.
+//   Where the frontier is uniform (deep levels) the interpreter is bypassed: flush_simple evaluates three
+//   children per lane per step with branch-free loads, flush_probes handles arrow-target states, and
+//   segments of already-probed single-op parents fetch has[] and the row descriptor together, two
+//   segments per step.  Same entries, same order as the generic path.
 //   Output space: every wave owns one static 16 KiB chunk per level (no allocation at
 //   all for the common case); further chunks come from one atomicAdd per 1024 entries.
 //
-// Bound: HBM/L2 transactions (random row gathers); no MFMA anywhere by design.
+// Bound: the vector L1's tag-lookup rate and per-level latency chains of divergent 4-16 B gathers (DESIGN.md 4,
+// profiles/r01_c4_bottleneck_analysis.md); no MFMA anywhere by design.
 #include <algorithm>
 #include <cstdlib>
 
