@@ -63,3 +63,12 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "acl_oracle" not in text and "orc_" not in text, f
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/aclgpu.h must compile as C99 (what cgo's C compiler sees), no C++ or HIP types."""
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "aclgpu.h"\nint main(void) { acl_item_t it; (void)it; return sizeof(acl_stats_t) == 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
