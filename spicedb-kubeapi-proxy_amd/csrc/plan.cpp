@@ -191,6 +191,10 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     std::vector<RelLayout> lay(sc.nslots);
     auto &tables = store.tables();
     std::vector<uint32_t> cnt, fill;
+    // pass A: which classes are live / hashed.  Sorted classes are numbered per TYPE: the row descriptors of all relations of
+    // one object sit side by side ({start, end} pairs), so a state that touches two of them (`pod#view`: the group viewers and
+    // the namespace arrow) finds both in one 16-byte record -- one cold line instead of two at level 1.
+    std::vector<uint32_t> type_ks(sc.defs.size(), 0), type_base(sc.defs.size(), 0);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
         const Member &mem = sc.defs[t].members[m];
@@ -208,8 +212,22 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             else
                 for (uint64_t key : ct.keys)
                     if (store.live(ct, key, now)) { c.live = true; break; }
-            if (c.live && !c.hashed) c.ks = l.Ks++;
+            if (c.live && !c.hashed) c.ks = type_ks[t]++;
         }
+    }
+    for (size_t t = 0; t < sc.defs.size(); t++) {
+        if (!type_ks[t]) continue;
+        if (s.meta.size() % 4) s.meta.resize(s.meta.size() + 2, 0);  // 16-byte alignment: K == 2 rows load as one dwordx4
+        type_base[t] = (uint32_t)(s.meta.size() / 2);
+        s.meta.resize(s.meta.size() + 2 * (size_t)with_headroom(store.objects((int)t).count()) * type_ks[t], 0);
+    }
+    for (int slot = 0; slot < sc.nslots; slot++) {
+        auto [t, m] = sc.slot_owner[slot];
+        const Member &mem = sc.defs[t].members[m];
+        if (mem.is_permission || s.type_owner[t] != shard.rank) continue;
+        RelLayout &l = lay[slot];
+        l.Ks = type_ks[t];
+        l.meta_base = type_base[t];
         // ---- membership-only classes: one hashed row of RESOURCE ids per SUBJECT
         for (size_t k = 0; k < mem.classes.size(); k++) {
             ClassLayout &c = l.cls[k];
@@ -238,9 +256,6 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         }
         // ---- enumerable classes: sorted sub-rows per (object, class)
         if (!l.Ks) continue;
-        if (s.meta.size() % 4) s.meta.resize(s.meta.size() + 2, 0);  // 16-byte alignment: Ks == 2 rows load as one dwordx4
-        l.meta_base = (uint32_t)(s.meta.size() / 2);
-        s.meta.resize(s.meta.size() + 2 * (size_t)l.nrows * l.Ks, 0);
         for (size_t k = 0; k < mem.classes.size(); k++) {
             const ClassLayout &c = l.cls[k];
             if (!c.live || c.hashed) continue;
