@@ -120,6 +120,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
     G = world if world > 1 else (args.logical_shards or 8)
     ops = workloads.c5_stream(w, args.steps)
     nC = sum(1 for o in ops if o == "C")
+    c5_exchange = "alltoall" if args.exchange == "alltoall" else "allgather"  # Check frontiers; LookupResources always all-gathers
     engines = []
 
     def make(r, g):
@@ -163,13 +164,16 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
 
     t0 = time.time()
     if world > 1:
-        se = sharded.ShardedEngine(make(rank, world), sharded.TorchComm(device=f"cuda:{local_rank}"))
+        se = sharded.ShardedEngine(make(rank, world), sharded.TorchComm(device=f"cuda:{local_rank}"), exchange=c5_exchange)
         o = run(se, dist.barrier)
         outs = [None] * world
         dist.all_gather_object(outs, {k: v for k, v in o.items() if k not in ("perm", "err")})
         outs[rank].update(perm=o["perm"], err=o["err"])
     else:
-        outs = sharded.run_logical_shards(G, make, lambda se: run(se, se.comm.barrier))
+        def fn(se):
+            return run(se, se.comm.barrier)
+        fn.exchange = c5_exchange
+        outs = sharded.run_logical_shards(G, make, fn)
     t_all = time.time() - t0
     if rank == 0:
         el = max(o["elapsed"] for o in outs)
@@ -177,7 +181,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
                "warmup": 1, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "u32", "data": "synthetic",
                "config": {"workload": WORKLOAD_DESC["C5"], "shards": G, "scale": args.scale, "relationships": w.ntuples,
-                          "objects": int(sum(w.nobjects.values())), "check_batch": n, "stream": "".join("C" if o == "C" else "F" for o in ops),
+                          "objects": int(sum(w.nobjects.values())), "check_batch": n, "stream": "".join("C" if o == "C" else "F" for o in ops), "check_exchange": c5_exchange,
                           "execution": "one shard per GPU, RCCL all-gather" if world > 1 else f"{G} LOGICAL shards on ONE GPU: emulated, not a multi-GPU measurement"},
                "check_batches": nC, "filter_requests": len(ops) - nC,
                "ms_per_check_batch": 1e3 * outs[0]["check_s"] / max(1, nC), "ms_per_filter_request": 1e3 * outs[0]["filter_s"] / max(1, len(ops) - nC),
