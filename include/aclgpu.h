@@ -18,8 +18,10 @@
  *    reference inspects: codes.InvalidArgument pkg/authz/distributedtx/workflow.go:115,
  *    precondition / already-exists failures activity.go:62-74); the message is
  *    available from acl_last_error() (thread-local).
- *  - all entry points are thread-safe (the proxy calls the seam from arbitrary
- *    goroutines: pkg/authz/check.go:77-93, responsefilterer.go:165).
+ *  - all entry points are thread-safe and concurrent (the proxy calls the seam from arbitrary
+ *    goroutines: pkg/authz/check.go:77-93, responsefilterer.go:165): evaluations share the
+ *    relationship store and the HBM snapshot and run on separate device contexts (HIP
+ *    streams); writes are exclusive and visible to every call that starts after them.
  *  - there is NO CPU evaluation path in this library: if no gfx950 device is
  *    usable acl_open() fails with ACL_ERR_UNAVAILABLE.
  */
@@ -38,7 +40,9 @@ typedef struct acl_engine acl_engine_t;
 /* gRPC status codes used as return values */
 enum {
     ACL_OK = 0,
+    ACL_ERR_CANCELLED = 1,           /* codes.Canceled: the caller's cancel flag was raised (responsefilterer.go:168-170) */
     ACL_ERR_INVALID_ARGUMENT = 3,    /* codes.InvalidArgument   */
+    ACL_ERR_DEADLINE_EXCEEDED = 4,   /* codes.DeadlineExceeded: acl_call_opts_t.timeout_ns elapsed (responsefilterer.go:44,196-204) */
     ACL_ERR_NOT_FOUND = 5,           /* codes.NotFound          */
     ACL_ERR_ALREADY_EXISTS = 6,      /* codes.AlreadyExists: CREATE of an existing relationship */
     ACL_ERR_RESOURCE_EXHAUSTED = 8,  /* codes.ResourceExhausted: frontier capacity exceeded */
@@ -64,6 +68,9 @@ typedef struct {
     uint64_t frontier_entries;   /* capacity of EACH of the two frontier buffers, in 16-byte entries; 0 = default */
     uint32_t max_sub_batch;      /* Check items evaluated per device pass; 0 = default */
     uint32_t flags;              /* ACL_FLAG_* */
+    uint32_t contexts;           /* evaluations that may be in flight on the device at once (each has its own HIP stream,
+                                    frontier and staging buffers; created on demand); 0 = default (4), max 16 */
+    uint32_t reserved;
 } acl_config_t;
 /* open only the relationship store (writes, reads, preconditions) without touching a GPU: every entry
  * point that evaluates permissions then fails with ACL_ERR_UNAVAILABLE.  For tooling and CPU-side tests. */
@@ -110,6 +117,9 @@ int acl_write(acl_engine_t *h, const acl_update_t *updates, int n_updates, const
               uint64_t *revision_out);
 /* DeleteRelationships (e2e/util_test.go:66) */
 int acl_delete_by_filter(acl_engine_t *h, const acl_filter_t *filter, uint64_t *n_deleted, uint64_t *revision_out);
+/* ... with DeleteRelationshipsRequest.OptionalPreconditions: evaluated against the pre-delete state, atomically with it */
+int acl_delete_by_filter_pre(acl_engine_t *h, const acl_filter_t *filter, const acl_filter_t *preconditions, int n_pre, uint64_t *n_deleted,
+                             uint64_t *revision_out);
 /* ReadRelationships (activity.go:107, e2e/util_test.go:27): cb per matching relationship */
 typedef void (*acl_read_cb)(void *user, const acl_relationship_t *rel);
 int acl_read(acl_engine_t *h, const acl_filter_t *filter, acl_read_cb cb, void *user);
@@ -139,11 +149,34 @@ typedef struct {
     uint32_t subject_id;
 } acl_item_t;
 int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
-/* same, but items / outputs are DEVICE pointers (HBM-resident batch; asynchronous on acl_stream()
- * until acl_sync()); err_out may be NULL */
+
+/* Cancellation / deadline of one call -- the C side of a Go context.Context.  The reference runs LookupResources on the
+ * HTTP request's ctx and abandons it when that is cancelled (responsefilterer.go:165-170); the prefilter join gives up
+ * after 10 s (responsefilterer.go:44,196-204).  The shim points `cancel` at an int32 it sets from a goroutine watching
+ * ctx.Done(); the engine polls it while the call waits for a device context / the micro-batcher and between level
+ * bursts of the walk, and returns ACL_ERR_CANCELLED / ACL_ERR_DEADLINE_EXCEEDED.  NULL opts = neither. */
+typedef struct {
+    const volatile int32_t *cancel; /* NULL or a flag: != 0 abandons the call */
+    int64_t timeout_ns;             /* <= 0: none; else relative to the call's start */
+} acl_call_opts_t;
+int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
+
+/* Pipelined form of acl_check_bulk_ids: submit returns at once, the batch is answered by one of the engine's evaluation
+ * contexts (own HIP stream: the H2D copy of batch N+1 and the D2H copy of batch N-1 overlap the kernels of batch N);
+ * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
+ * Buffers must stay valid until the wait returns. */
+typedef struct acl_ticket acl_ticket_t;
+int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
+int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);
+/* Page-locked host memory for request / answer arrays: buffers from here are DMA'd directly by the host-buffer entry
+ * points; any other host pointer is staged through the context's own pinned buffers (one extra memcpy). */
+int acl_host_alloc(acl_engine_t *h, size_t bytes, void **out);
+int acl_host_free(acl_engine_t *h, void *p);
+/* same, but items / outputs are DEVICE pointers (HBM-resident batch).  The inputs must be complete before the call
+ * (they are read on one of the engine's own streams); the answers are complete when it returns.  err_out may be NULL */
 int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out);
-void *acl_stream(acl_engine_t *h); /* hipStream_t the engine launches on */
-int acl_sync(acl_engine_t *h);
+void *acl_stream(acl_engine_t *h); /* hipStream_t of the engine's first evaluation context */
+int acl_sync(acl_engine_t *h);     /* waits for every evaluation context's stream */
 
 /* ---- Filter: LookupResources (lookups.go:49-65) ----
  * Result = dense bitmap over the resource type's local ids (bit id set <=> HAS_PERMISSION);
@@ -153,6 +186,13 @@ int acl_lookup_resources(acl_engine_t *h, const char *resource_type, const char 
                          uint64_t *count_out);
 int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int permission, int stype, int srel /* -1 none */, uint32_t subject_id,
                              uint32_t *bitmap_out, size_t bitmap_words, uint64_t *count_out);
+/* Engine-owned result: *bitmap_out (release with acl_free) is sized by the engine when the walk runs, so objects interned
+ * by a racing WriteRelationships can never make a caller-sized buffer "too small".  Rides the micro-batcher like
+ * acl_lookup_one when it is running.  opts may be NULL. */
+int acl_lookup_resources_alloc(acl_engine_t *h, const char *resource_type, const char *permission, const char *subject_type,
+                               const char *subject_id, const char *subject_relation, const acl_call_opts_t *opts, uint32_t **bitmap_out,
+                               size_t *bitmap_words_out, uint64_t *count_out);
+void acl_free(void *p);
 /* batched form: n subjects of one (stype, srel) against one (rtype, permission); bitmaps_out is n * bitmap_words */
 int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int stype, int srel, const uint32_t *subject_ids, size_t n,
                                uint32_t *bitmaps_out, size_t bitmap_words, uint64_t *counts_out);
@@ -182,11 +222,14 @@ int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us)
 int acl_batcher_stop(acl_engine_t *h);
 int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items);
 int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out);
+int acl_check_one_opts(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
 /* the same for Filter requests (lookups.go:65; one LookupResources per list request, each from its own goroutine:
  * responsefilterer.go:165): concurrent requests with the same (resource type, permission, subject class) share ONE
  * batched reverse walk.  Arguments as acl_lookup_resources. */
 int acl_lookup_one(acl_engine_t *h, const char *resource_type, const char *permission, const char *subject_type, const char *subject_id,
                    const char *subject_relation, uint32_t *bitmap_out, size_t bitmap_words, uint64_t *count_out);
+int acl_lookup_one_opts(acl_engine_t *h, const char *resource_type, const char *permission, const char *subject_type, const char *subject_id,
+                        const char *subject_relation, uint32_t *bitmap_out, size_t bitmap_words, uint64_t *count_out, const acl_call_opts_t *opts);
 int acl_batcher_lookup_stats(acl_engine_t *h, uint64_t *walks, uint64_t *lookups);
 
 /* ---- sharded graph: the north star's multi-GPU configuration ----
@@ -247,10 +290,13 @@ typedef struct {
     uint64_t overflow_retries;
     uint64_t snapshot_edges_local; /* relationships whose rows THIS engine holds (== snapshot_edges unless sharded) */
     uint64_t snapshot_patches;     /* times committed writes were patched into the HBM snapshot in place (no rebuild) */
+    double local_ms;               /* HIP-event time of the single-launch small-batch kernel (k_check_local) */
+    uint64_t local_passes;         /* device passes answered by that kernel (one launch for all levels) */
+    uint64_t snapshot_compactions; /* snapshots rebuilt in the background and swapped in */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);
-int acl_set_timing(acl_engine_t *h, int on); /* bracket every kernel with HIP events on acl_stream() */
+int acl_set_timing(acl_engine_t *h, int on); /* bracket every kernel with HIP events on its context's stream */
 
 #ifdef __cplusplus
 }

@@ -24,11 +24,19 @@ SYMBOLS = [
     "acl_check_bulk_keep", "acl_check_bulk_keep_ids", "acl_check_bulk_keep_ids_device", "acl_bitmap_test_names", "acl_watch_poll",
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
     "acl_selfcheck_snapshot",
+    "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
+    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts",
 ]
 
 
 class Config(C.Structure):
-    _fields_ = [("device", C.c_int32), ("frontier_entries", C.c_uint64), ("max_sub_batch", C.c_uint32), ("flags", C.c_uint32)]
+    _fields_ = [("device", C.c_int32), ("frontier_entries", C.c_uint64), ("max_sub_batch", C.c_uint32), ("flags", C.c_uint32),
+                ("contexts", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class CallOpts(C.Structure):
+    """acl_call_opts_t: `cancel` points at an int32 the caller raises to abandon the call; timeout_ns <= 0 = none."""
+    _fields_ = [("cancel", C.POINTER(C.c_int32)), ("timeout_ns", C.c_int64)]
 
 
 class Relationship(C.Structure):
@@ -51,7 +59,8 @@ class CheckItem(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("check_items", C.c_uint64), ("check_passes", C.c_uint64), ("expand_launches", C.c_uint64), ("levels_last", C.c_uint64),
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
-                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64)]
+                ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64),
+                ("local_ms", C.c_double), ("local_passes", C.c_uint64), ("snapshot_compactions", C.c_uint64)]
 
 
 class ShardStep(C.Structure):
@@ -132,6 +141,19 @@ def load():
     L.acl_lookup_one.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.acl_batcher_lookup_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_selfcheck_snapshot.argtypes = [H, C.POINTER(C.c_int)]
+    L.acl_delete_by_filter_pre.argtypes = [H, C.POINTER(Filter), C.POINTER(Filter), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.acl_check_bulk_ids_opts.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(CallOpts)]
+    L.acl_check_bulk_ids_submit.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.acl_ticket_wait.argtypes = [H, C.c_void_p]
+    L.acl_host_alloc.argtypes = [H, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.acl_host_free.argtypes = [H, C.c_void_p]
+    L.acl_lookup_resources_alloc.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CallOpts),
+                                             C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    L.acl_free.argtypes = [C.c_void_p]
+    L.acl_free.restype = None
+    L.acl_check_one_opts.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(CallOpts)]
+    L.acl_lookup_one_opts.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
+                                      C.POINTER(CallOpts)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]
     L.acl_shard_grow_frontier.argtypes = [H]

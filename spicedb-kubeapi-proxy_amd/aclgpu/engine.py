@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
+from ._lib import CallOpts, CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
 
 PERM_UNSPECIFIED, PERM_NO, PERM_HAS, PERM_CONDITIONAL = 0, 1, 2, 3
 OP_CREATE, OP_TOUCH, OP_DELETE = 1, 2, 3
@@ -19,6 +19,7 @@ PRE_MUST_NOT_MATCH, PRE_MUST_MATCH = 1, 2
 ERR_INVALID_ARGUMENT, ERR_NOT_FOUND, ERR_ALREADY_EXISTS, ERR_RESOURCE_EXHAUSTED, ERR_FAILED_PRECONDITION = 3, 5, 6, 8, 9
 ERR_INTERNAL, ERR_UNAVAILABLE, ERR_DEPTH = 13, 14, 100
 ERR_OUT_OF_RANGE = 11
+ERR_CANCELLED, ERR_DEADLINE_EXCEEDED = 1, 4
 WATCH_FROM_NOW = 0xFFFFFFFFFFFFFFFF
 NO_RELATION = 0xFFFF
 
@@ -42,9 +43,9 @@ def _b(s):
 
 class Engine:
     def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
-                 max_sub_batch: int = 0, store_only: bool = False):
+                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0):
         self._L = _lib.load()
-        cfg = Config(device, frontier_entries, max_sub_batch, 1 if store_only else 0)
+        cfg = Config(device, frontier_entries, max_sub_batch, 1 if store_only else 0, contexts, 0)
         h = C.c_void_p()
         rc = self._L.acl_open(C.byref(cfg), C.byref(h))
         self._h = h if rc == 0 else None
@@ -130,10 +131,14 @@ class Engine:
     def touch(self, *rels):
         return self.write([(OP_TOUCH, r) for r in rels])
 
-    def delete_by_filter(self, **f):
+    def delete_by_filter(self, preconditions=(), **f):
+        """DeleteRelationships; preconditions [(op, {filter kwargs})] are evaluated against the pre-delete state."""
         n, rev = C.c_uint64(), C.c_uint64()
         flt = self._mkfilter(0, **f)
-        self._check(self._L.acl_delete_by_filter(self._h, C.byref(flt), C.byref(n), C.byref(rev)))
+        pre = (Filter * max(1, len(preconditions)))()
+        for i, (op, pf) in enumerate(preconditions):
+            pre[i] = self._mkfilter(op, **pf)
+        self._check(self._L.acl_delete_by_filter_pre(self._h, C.byref(flt), pre, len(preconditions), C.byref(n), C.byref(rev)))
         return n.value
 
     def read(self, **f):
@@ -201,6 +206,48 @@ class Engine:
         err = np.zeros(max(1, n), dtype=np.int32)
         self._check(self._L.acl_check_bulk_ids(self._h, items.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
         return perm[:n], err[:n]
+
+    @staticmethod
+    def _opts(cancel=None, timeout_s=None):
+        """cancel: a ctypes.c_int32 the caller sets non-zero to abandon the call (the C side of ctx.Done())."""
+        if cancel is None and not timeout_s:
+            return None
+        return CallOpts(C.pointer(cancel) if cancel is not None else None, int((timeout_s or 0) * 1e9))
+
+    def check_bulk_ids_opts(self, items: np.ndarray, cancel=None, timeout_s=None):
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        n = items.size
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        o = self._opts(cancel, timeout_s)
+        self._check(self._L.acl_check_bulk_ids_opts(self._h, items.ctypes.data, n, perm.ctypes.data, err.ctypes.data, C.byref(o) if o else None))
+        return perm[:n], err[:n]
+
+    # ---- pipelined host-buffer path: pinned request / answer arrays + submit / wait
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Page-locked host memory as a uint8 array (free with host_free): DMA'd directly by check_bulk_ids / submit."""
+        p = C.c_void_p()
+        self._check(self._L.acl_host_alloc(self._h, int(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * int(nbytes)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=np.uint8)
+        a.flags.writeable = True
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p is not None and self._h:
+            self._check(self._L.acl_host_free(self._h, p))
+
+    def submit_ids(self, items: np.ndarray, perm: np.ndarray, err: np.ndarray):
+        """acl_check_bulk_ids_submit: returns a ticket; the arrays must stay alive (and untouched) until wait()."""
+        t = C.c_void_p()
+        self._check(self._L.acl_check_bulk_ids_submit(self._h, items.ctypes.data, items.size, perm.ctypes.data, err.ctypes.data, C.byref(t)))
+        return t
+
+    def wait(self, ticket):
+        self._check(self._L.acl_ticket_wait(self._h, ticket))
 
     def check_bulk_ids_device(self, d_items: int, n: int, d_perm: int, d_err: int = 0):
         """Device pointers (ints); asynchronous after return only w.r.t. the output buffers' readers on acl_stream."""
@@ -273,21 +320,27 @@ class Engine:
         self._check(self._L.acl_batcher_stats(self._h, C.byref(b), C.byref(i)))
         return {"batches": b.value, "items": i.value}
 
-    def check_one(self, rt, rid, perm, st, sid, srel=""):
+    def check_one(self, rt, rid, perm, st, sid, srel="", cancel=None, timeout_s=None):
         """One CheckPermission (watch.go:50); rides the micro-batcher when it is running.  Blocks; releases the GIL."""
         it = CheckItem(*[_b(x if x is not None else "") for x in (rt, rid, perm, st, sid, srel)])
         p, e = C.c_uint8(), C.c_int32()
-        self._check(self._L.acl_check_one(self._h, C.byref(it), C.byref(p), C.byref(e)))
+        o = self._opts(cancel, timeout_s)
+        self._check(self._L.acl_check_one_opts(self._h, C.byref(it), C.byref(p), C.byref(e), C.byref(o) if o else None))
         return p.value, e.value
 
-    def lookup_one(self, rt, perm, st, sid, srel=""):
+    def lookup_one(self, rt, perm, st, sid, srel="", cancel=None, timeout_s=None):
         """One LookupResources request (lookups.go:65) -> set of resource ids; concurrent callers with the same (type,
-        permission, subject class) share one batched reverse walk while the batcher runs.  Blocks; releases the GIL."""
-        words = (self.object_count(rt) + 1 + 31) // 32 + 1
-        bm = np.zeros(words, dtype=np.uint32)
-        cnt = C.c_uint64()
-        self._check(self._L.acl_lookup_one(self._h, _b(rt), _b(perm), _b(st), _b(sid), _b(srel or ""), bm.ctypes.data, words, C.byref(cnt)))
-        ids = np.flatnonzero(np.unpackbits(bm.view(np.uint8), bitorder="little"))
+        permission, subject class) share one batched reverse walk while the batcher runs.  Blocks; releases the GIL.
+        The result bitmap is engine-owned (acl_lookup_resources_alloc): no caller-side sizing race with concurrent writes."""
+        bm, words, cnt = C.POINTER(C.c_uint32)(), C.c_size_t(), C.c_uint64()
+        o = self._opts(cancel, timeout_s)
+        self._check(self._L.acl_lookup_resources_alloc(self._h, _b(rt), _b(perm), _b(st), _b(sid), _b(srel or ""), C.byref(o) if o else None,
+                                                       C.byref(bm), C.byref(words), C.byref(cnt)))
+        try:
+            a = np.ctypeslib.as_array(bm, shape=(words.value,)).copy()
+        finally:
+            self._L.acl_free(bm)
+        ids = np.flatnonzero(np.unpackbits(a.view(np.uint8), bitorder="little"))
         return {self.object_name(rt, int(i)) for i in ids}
 
     def batcher_lookup_stats(self):

@@ -7,119 +7,180 @@
 //   LookupResources      : set of ids with HAS_PERMISSION, order irrelevant (lookups.go:85-88,129)
 //   every read is fully consistent (check.go:41-46): a write is visible to the next call.
 // There is no CPU evaluation path: without a GPU acl_open() fails.
+// Threading: engine_internal.hpp (state_mu / names_mu / PassCtx pool).
 #include "engine_internal.hpp"
 
 namespace aclint {
 
 thread_local std::string g_last_error;
 
+int64_t mono_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int alloc_frontier(acl_engine *h, uint64_t entries) {
+int check_opts(const CallOpts &o) {
+    if (o.cancel && *o.cancel) return fail(ACL_ERR_CANCELLED, "call cancelled by the caller");
+    if (o.deadline_ns && mono_ns() >= o.deadline_ns) return fail(ACL_ERR_DEADLINE_EXCEEDED, "deadline exceeded");
+    return ACL_OK;
+}
+
+PassCtx::~PassCtx() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (h_status) (void)hipHostFree(h_status);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int alloc_frontier(acl_engine *h, PassCtx *c, uint64_t entries) {
     // every wave of an expand launch owns one static chunk; at least one dynamic chunk on top
     entries = std::max<uint64_t>(entries, ((uint64_t)h->grid_blocks * kWavesPerBlock + 1) * kChunk);
     uint64_t chunks = (entries + kChunk - 1) / kChunk;
     if (chunks > 0x3FFFFFu) chunks = 0x3FFFFFu;  // entry indices stay below 2^32
     for (int i = 0; i < 2; i++) {
-        h->d_fbuf[i].release();
-        h->d_fcounts[i].release();
-        HIP_TRY(h->d_fbuf[i].ensure(chunks * kChunk));
-        HIP_TRY(h->d_fcounts[i].ensure(chunks));
+        c->d_fbuf[i].release();
+        c->d_fcounts[i].release();
+        HIP_TRY(c->d_fbuf[i].ensure(chunks * kChunk));
+        HIP_TRY(c->d_fcounts[i].ensure(chunks));
     }
-    h->max_chunks = (uint32_t)chunks;
-    h->frontier_entries = chunks * kChunk;
+    c->max_chunks = (uint32_t)chunks;
+    c->frontier_entries = chunks * kChunk;
     return ACL_OK;
 }
 
-// ---- timing helpers: one HIP event pair per kernel launch, on the engine's stream
-void ev_begin(acl_engine *h, int kind) {
-    if (!h->timing) return;
-    if (h->ev_used + 2 > h->ev.size()) {
+int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index) {
+    auto c = std::make_unique<PassCtx>();
+    c->index = index;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c->d_status.ensure(kStatusWords));
+    HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
+    int rc = alloc_frontier(h, c.get(),
+                            h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(16u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));
+    if (rc) return rc;
+    *out = std::move(c);
+    return ACL_OK;
+}
+
+// ---- timing helpers: one HIP event pair per kernel launch, on the context's stream
+void ev_begin(PassCtx *c, int kind) {
+    if (!c->timing) return;
+    if (c->ev_used + 2 > c->ev.size()) {
         for (int i = 0; i < 2; i++) {
             hipEvent_t e;
             (void)hipEventCreate(&e);
-            h->ev.push_back(e);
+            c->ev.push_back(e);
         }
-        h->ev_kind.push_back(0);
+        c->ev_kind.push_back(0);
     }
-    h->ev_kind[h->ev_used / 2] = kind;
-    (void)hipEventRecord(h->ev[h->ev_used], h->stream);
+    c->ev_kind[c->ev_used / 2] = kind;
+    (void)hipEventRecord(c->ev[c->ev_used], c->stream);
 }
-void ev_end(acl_engine *h) {
-    if (!h->timing) return;
-    (void)hipEventRecord(h->ev[h->ev_used + 1], h->stream);
-    h->ev_used += 2;
+void ev_end(PassCtx *c) {
+    if (!c->timing) return;
+    (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+    c->ev_used += 2;
 }
-void ev_collect(acl_engine *h) {  // stream must be synchronized
-    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+void ev_collect(PassCtx *c) {  // stream must be synchronized
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) {
-            h->stats.kernel_ms += ms;
-            if (h->ev_kind[i / 2] == 1) h->stats.expand_ms += ms;
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) {
+            c->stats.kernel_ms += ms;
+            if (c->ev_kind[i / 2] == 1) c->stats.expand_ms += ms;
+            else if (c->ev_kind[i / 2] == 2) c->stats.local_ms += ms;
         }
     }
-    h->ev_used = 0;
+    c->ev_used = 0;
 }
 
+void merge_stats(acl_engine *h, PassCtx *c) {
+    std::lock_guard<std::mutex> lk(h->stats_mu);
+    acl_stats_t &a = h->stats, &b = c->stats;
+    a.check_items += b.check_items;
+    a.check_passes += b.check_passes;
+    a.expand_launches += b.expand_launches;
+    if (b.check_passes) a.levels_last = b.levels_last;
+    a.frontier_entries += b.frontier_entries;
+    a.kernel_ms += b.kernel_ms;
+    a.expand_ms += b.expand_ms;
+    a.local_ms += b.local_ms;
+    a.local_passes += b.local_passes;
+    a.overflow_retries += b.overflow_retries;
+    b = acl_stats_t{};
+}
+
+bool snapshot_current(acl_engine *h, bool need_reverse) {
+    if (!h->snap_valid || !h->dev_valid || h->snap.revision != h->store.revision()) return false;
+    const int64_t now = h->store.now();
+    if (now < h->snap.valid_lo || now >= h->snap.valid_hi) return false;
+    return !need_reverse || h->rev_uploaded;
+}
+
+// caller holds state_mu EXCLUSIVE: no evaluation is reading the device arrays
 int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    if (snapshot_current(h, false)) return ACL_OK;
     const int64_t now = h->store.now();
-    if (h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi) return ACL_OK;
+    hipStream_t s = h->up_stream;
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
-    if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi && h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
+    if (h->snap_valid && h->dev_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi &&
+        h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
         std::vector<Patch> patches;
         const uint64_t from_revision = h->snap.revision;
         if (patch_forward(h->store, now, &h->snap, h->shard, &patches)) {
+            h->dev_valid = false;  // until every region below has reached the device
             // the reverse rows (LookupResources), if they are on the device, follow the same feed
             bool rev_ok = h->rev_uploaded && patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches);
-            HIP_TRY(hipStreamSynchronize(h->stream));  // nothing may still be reading the rows we overwrite
+            const bool had_rev = h->rev_uploaded;
+            h->rev_uploaded = false;
             bool fits = true;
             hipError_t pe = hipSuccess;
             for (const Patch &p : patches) {
                 hipError_t e1 = hipSuccess;
                 switch (p.array) {
-                    case Patch::META: fits = fits && h->d_meta.patch(h->snap.meta, p.off, p.n, h->stream, &e1); break;
-                    case Patch::EDGES: fits = fits && h->d_edges.patch(h->snap.edges, p.off, p.n, h->stream, &e1); break;
-                    case Patch::BUCKETS: fits = fits && h->d_buckets.patch(h->snap.buckets, p.off, p.n, h->stream, &e1); break;
-                    case Patch::OPS: fits = fits && h->d_ops.patch(h->snap.ops, p.off, p.n, h->stream, &e1); break;
-                    case Patch::RMETA: fits = fits && h->d_rmeta.patch(h->snap.rmeta, p.off, p.n, h->stream, &e1); break;
-                    case Patch::REDGES: fits = fits && h->d_redges.patch(h->snap.redges, p.off, p.n, h->stream, &e1); break;
+                    case Patch::META: fits = fits && h->d_meta.patch(h->snap.meta, p.off, p.n, s, &e1); break;
+                    case Patch::EDGES: fits = fits && h->d_edges.patch(h->snap.edges, p.off, p.n, s, &e1); break;
+                    case Patch::BUCKETS: fits = fits && h->d_buckets.patch(h->snap.buckets, p.off, p.n, s, &e1); break;
+                    case Patch::OPS: fits = fits && h->d_ops.patch(h->snap.ops, p.off, p.n, s, &e1); break;
+                    case Patch::RMETA: fits = fits && h->d_rmeta.patch(h->snap.rmeta, p.off, p.n, s, &e1); break;
+                    case Patch::REDGES: fits = fits && h->d_redges.patch(h->snap.redges, p.off, p.n, s, &e1); break;
                 }
                 if (e1 != hipSuccess) pe = e1;
             }
             if (pe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("snapshot patch upload: ") + hipGetErrorString(pe));
             if (!fits) {  // an array outgrew its device allocation: the host copy is already exact, upload it whole
-                HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
-                HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
-                HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
-                HIP_TRY(h->d_ops.upload(h->snap.ops, h->stream));
+                HIP_TRY(h->d_meta.upload(h->snap.meta, s));
+                HIP_TRY(h->d_edges.upload(h->snap.edges, s));
+                HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
+                HIP_TRY(h->d_ops.upload(h->snap.ops, s));
                 if (rev_ok) {
-                    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, h->stream));
-                    HIP_TRY(h->d_redges.upload(h->snap.redges, h->stream));
+                    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, s));
+                    HIP_TRY(h->d_redges.upload(h->snap.redges, s));
                 }
             }
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (!rev_ok) {  // not patchable (or never built): rebuilt lazily by the next lookup
-                h->rev_uploaded = false;
-                h->snap.has_reverse = false;
-            }
+            HIP_TRY(hipStreamSynchronize(s));
+            h->dev_valid = true;
+            h->rev_uploaded = had_rev && rev_ok;
+            if (!h->rev_uploaded) h->snap.has_reverse = false;  // not patchable (or never built): rebuilt lazily by the next lookup
+            std::lock_guard<std::mutex> lk(h->stats_mu);
             h->stats.snapshot_patches++;
             h->stats.snapshot_edges = h->snap.nedges;
             h->stats.snapshot_edges_local = h->snap.nedges_local;
             return ACL_OK;
         }
     }
-    build_forward(h->store, now, &h->snap, h->shard);
-    HIP_TRY(h->d_meta.upload(h->snap.meta, h->stream));
-    HIP_TRY(h->d_edges.upload(h->snap.edges, h->stream));
-    HIP_TRY(h->d_buckets.upload(h->snap.buckets, h->stream));
-    HIP_TRY(h->d_ops.upload(h->snap.ops, h->stream));
-    HIP_TRY(h->d_progs.upload(h->snap.progs, h->stream));
-    HIP_TRY(h->d_tsb.upload(h->snap.type_slot_base, h->stream));
-    HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->snap_valid = true;
+    h->snap_valid = false;
+    h->dev_valid = false;
     h->rev_uploaded = false;
+    build_forward(h->store, now, &h->snap, h->shard);
+    h->snap_valid = true;
+    HIP_TRY(h->d_meta.upload(h->snap.meta, s));
+    HIP_TRY(h->d_edges.upload(h->snap.edges, s));
+    HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
+    HIP_TRY(h->d_ops.upload(h->snap.ops, s));
+    HIP_TRY(h->d_progs.upload(h->snap.progs, s));
+    HIP_TRY(h->d_tsb.upload(h->snap.type_slot_base, s));
+    HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->dev_valid = true;
+    std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
     h->stats.snapshot_edges_local = h->snap.nedges_local;
@@ -127,61 +188,175 @@ int ensure_snapshot(acl_engine *h) {
     return ACL_OK;
 }
 
+// do the reverse rows' visited bitmaps cover every id a walk could mark?  Ids are interned without a revision bump
+// (acl_intern, a lookup's subject, a LookupResources on a new object), so "same revision" does not imply it.
+static bool reverse_covers(acl_engine *h) {
+    const Schema &sc = h->store.schema();
+    if (h->snap.slot_nobjects.size() != (size_t)sc.nslots) return false;
+    for (int slot = 0; slot < sc.nslots; slot++)
+        if (h->store.objects(sc.slot_owner[slot].first).count() > h->snap.slot_nobjects[slot]) return false;
+    return true;
+}
+
 int ensure_reverse(acl_engine *h) {
     int rc = ensure_snapshot(h);
     if (rc) return rc;
-    if (h->rev_uploaded) return ACL_OK;
+    if (h->rev_uploaded && reverse_covers(h)) return ACL_OK;
+    hipStream_t s = h->up_stream;
+    h->rev_uploaded = false;
     build_reverse(h->store, h->store.now(), &h->snap, h->shard);
-    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, h->stream));
-    HIP_TRY(h->d_redges.upload(h->snap.redges, h->stream));
-    HIP_TRY(h->d_rops.upload(h->snap.rops, h->stream));
-    HIP_TRY(h->d_rprogs.upload(h->snap.rprogs, h->stream));
-    HIP_TRY(h->d_rseeds.upload(h->snap.rseeds, h->stream));
-    HIP_TRY(h->d_sbb.upload(h->snap.slot_bit_base, h->stream));
-    HIP_TRY(h->d_snobj.upload(h->snap.slot_nobjects, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, s));
+    HIP_TRY(h->d_redges.upload(h->snap.redges, s));
+    HIP_TRY(h->d_rops.upload(h->snap.rops, s));
+    HIP_TRY(h->d_rprogs.upload(h->snap.rprogs, s));
+    HIP_TRY(h->d_rseeds.upload(h->snap.rseeds, s));
+    HIP_TRY(h->d_sbb.upload(h->snap.slot_bit_base, s));
+    HIP_TRY(h->d_snobj.upload(h->snap.slot_nobjects, s));
+    HIP_TRY(hipStreamSynchronize(s));
     h->rev_uploaded = true;
+    std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_bytes += h->snap.rmeta.size() * 4 + h->snap.redges.size() * 4;
     return ACL_OK;
 }
 
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot) {
+    h = h_;
+    if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = check_opts(opts);
+    if (rc) return rc;
+    for (;;) {
+        h->state_mu.lock_shared();
+        bool ok = snapshot_current(h, need_reverse);
+        // a `type#relation` lookup subject is itself a state of the walk: its id must lie inside the visited bitmap
+        if (ok && need_reverse && rev_key_slot >= 0 &&
+            h->store.objects(h->store.schema().slot_owner[rev_key_slot].first).count() > h->snap.slot_nobjects[rev_key_slot])
+            ok = false;
+        if (ok) {
+            locked = true;
+            break;
+        }
+        h->state_mu.unlock_shared();
+        std::lock_guard<RwLock> lk(h->state_mu);
+        rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
+        if (rc) return rc;
+    }
+    // a context from the pool (created on demand up to max_ctx)
+    std::unique_lock<std::mutex> lk(h->pool_mu);
+    for (;;) {
+        if (!h->free_ctxs.empty()) {
+            c = h->free_ctxs.back();
+            h->free_ctxs.pop_back();
+            break;
+        }
+        if (h->ctxs.size() < h->max_ctx) {
+            std::unique_ptr<PassCtx> nc;
+            rc = new_ctx(h, &nc, (int)h->ctxs.size());
+            if (rc) return rc;
+            c = nc.get();
+            h->ctxs.push_back(std::move(nc));
+            break;
+        }
+        if (opts.cancel || opts.deadline_ns) {
+            h->pool_cv.wait_for(lk, std::chrono::microseconds(500));
+            rc = check_opts(opts);
+            if (rc) return rc;
+        } else {
+            h->pool_cv.wait(lk);
+        }
+    }
+    c->opts = opts;
+    c->timing = h->timing.load(std::memory_order_relaxed);
+    return ACL_OK;
+}
+
+void Eval::end() {
+    if (c) {
+        merge_stats(h, c);
+        c->opts = CallOpts();
+        {
+            std::lock_guard<std::mutex> lk(h->pool_mu);
+            h->free_ctxs.push_back(c);
+        }
+        h->pool_cv.notify_one();
+        c = nullptr;
+    }
+    if (locked) {
+        h->state_mu.unlock_shared();
+        locked = false;
+    }
+}
+
+// Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
+// batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
+// the context's frontier buffers.
+int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+    const uint32_t max_waves = (uint32_t)h->grid_blocks * kWavesPerBlock;  // what is resident at once
+    uint32_t rpw = (n + max_waves - 1) / max_waves;
+    rpw = std::min<uint32_t>(std::max<uint32_t>(rpw, 1), 64);
+    const uint32_t nwaves = (n + rpw - 1) / rpw;
+    const uint64_t cap64 = c->frontier_entries / std::max<uint32_t>(nwaves, 1);
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 1u << 20);
+    if (cap < 256) return ACL_ERR_RESOURCE_EXHAUSTED;
+    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;
+    HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(uint32_t), c->stream));
+    ev_begin(c, 2);
+    launch_check_local(c->stream, g, d_items, n, rpw, c->d_fbuf[0].p, c->d_fbuf[1].p, cap, d_over, c->d_has.p, c->d_err.p, d_perm, d_errout);
+    ev_end(c);
+    HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+    if (c->h_status[0]) return ACL_ERR_RESOURCE_EXHAUSTED;
+    c->stats.check_items += n;
+    c->stats.check_passes++;
+    c->stats.local_passes++;
+    return ACL_OK;
+}
 
 // one device pass over n (<= max_sub_batch) interned items already in HBM
-int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
-    HIP_TRY(h->d_has.ensure(h->max_sub_batch));
-    HIP_TRY(h->d_err.ensure(h->max_sub_batch));
+int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+    DevGraph g = h->dev_graph();
+    // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
+    // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
+    if (n <= h->local_max_items) {
+        int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
+        if (rc != ACL_ERR_RESOURCE_EXHAUSTED || std::string(acl_last_error()).find("enumeration limit") != std::string::npos) return rc;
+        // a wave ran out of private frontier: the level-synchronous path takes the batch
+    }
     for (int attempt = 0;; attempt++) {
-        if ((uint64_t)n > h->frontier_entries) {
-            int rc = alloc_frontier(h, (uint64_t)n * 4);
+        if ((uint64_t)n > c->frontier_entries) {
+            int rc = alloc_frontier(h, c, (uint64_t)n * 4);
             if (rc) return rc;
         }
-        DevGraph g = h->dev_graph();
-        DevFrontier f = h->dev_frontier();
-        ev_begin(h, 0);
-        launch_seed(h->stream, g, f, d_items, n, h->d_has.p, h->d_err.p);  // also resets the status block
-        ev_end(h);
+        DevFrontier f = h->dev_frontier(*c);
+        ev_begin(c, 0);
+        launch_seed(c->stream, g, f, d_items, n, c->d_has.p, c->d_err.p);  // also resets the status block
+        ev_end(c);
         uint32_t levels = 0;
         int rc = level_loop(
-            h, kMaxLevels, [&](uint32_t it) { launch_expand(h->stream, g, f, it, h->d_has.p, h->d_err.p); }, &levels,
+            h, c, kMaxLevels, [&](uint32_t it) { launch_expand(c->stream, g, f, it, c->d_has.p, c->d_err.p); }, &levels,
             [&] {
-                ev_begin(h, 0);
-                launch_finalize(h->stream, n, h->d_has.p, h->d_err.p, d_perm, d_errout);
-                ev_end(h);
+                ev_begin(c, 0);
+                launch_finalize(c->stream, n, c->d_has.p, c->d_err.p, d_perm, d_errout);
+                ev_end(c);
             });
-        if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
+        if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
             // frontier out of chunks: grow (up to 2^32 entries) and redo the pass
-            h->stats.overflow_retries++;
-            if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8)
-                return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded (" + std::to_string(h->frontier_entries) + " entries); lower max_sub_batch");
-            int rc2 = alloc_frontier(h, h->frontier_entries * 4);
+            c->stats.overflow_retries++;
+            if (c->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8)
+                return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded (" + std::to_string(c->frontier_entries) + " entries); lower max_sub_batch");
+            int rc2 = alloc_frontier(h, c, c->frontier_entries * 4);
             if (rc2) return rc2;
             continue;
         }
         if (rc) return rc;
-        h->levels_hint = levels;
-        h->stats.levels_last = levels;
-        h->stats.check_items += n;
-        h->stats.check_passes++;
+        c->levels_hint = levels;
+        c->stats.levels_last = levels;
+        c->stats.check_items += n;
+        c->stats.check_passes++;
         return ACL_OK;
     }
 }
@@ -192,16 +367,47 @@ int not_sharded(acl_engine *h) {
     return ACL_OK;
 }
 
-int check_device(acl_engine *h, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout) {
+int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout) {
     int rc = not_sharded(h);
-    if (rc) return rc;
-    rc = ensure_snapshot(h);
     if (rc) return rc;
     for (size_t b = 0; b < n; b += h->max_sub_batch) {
         uint32_t m = (uint32_t)std::min<size_t>(h->max_sub_batch, n - b);
-        rc = check_pass(h, d_items + b, m, d_perm + b, d_errout ? d_errout + b : nullptr);
+        rc = check_pass(h, c, d_items + b, m, d_perm + b, d_errout ? d_errout + b : nullptr);
         if (rc) return rc;
     }
+    return ACL_OK;
+}
+
+// Host items in, host answers out (SURVEY.md 8(d) timing variant (ii)): H2D, kernels, D2H on the context's stream.
+// Buffers from acl_host_alloc are pinned and are DMA'd directly; anything else is staged through the context's pinned
+// buffers (an async copy from pageable memory would be staged by the runtime anyway, synchronously).
+int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    HIP_TRY(c->d_items.ensure(n));
+    HIP_TRY(c->d_perm.ensure(n));
+    HIP_TRY(c->d_errout.ensure(n));
+    const void *src = items;
+    if (!h->is_pinned(items, n * sizeof(acl_item_t))) {
+        HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
+        std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
+        src = c->h_in.p;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
+    int rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);
+    if (rc) return rc;
+    const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
+    uint8_t *hp = perm_out;
+    int32_t *he = err_out;
+    if (!pin_p || !pin_e) {
+        HIP_TRY(c->h_out.ensure(n * 5 + 64));
+        if (!pin_e) he = (int32_t *)c->h_out.p;
+        if (!pin_p) hp = (uint8_t *)c->h_out.p + n * 4;
+    }
+    HIP_TRY(hipMemcpyAsync(hp, c->d_perm.p, n, hipMemcpyDeviceToHost, c->stream));
+    if (err_out) HIP_TRY(hipMemcpyAsync(he, c->d_errout.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    if (!pin_p) std::memcpy(perm_out, hp, n);
+    if (err_out && !pin_e) std::memcpy(err_out, he, n * sizeof(int32_t));
     return ACL_OK;
 }
 
@@ -219,226 +425,6 @@ FilterText to_filter(const acl_filter_t *f) {
     return o;
 }
 
-}  // namespace aclint
-
-extern "C" {
-
-const char *acl_last_error(void) { return g_last_error.c_str(); }
-
-int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
-    if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: out is NULL");
-    *out = nullptr;
-    if (cfg && (cfg->flags & ACL_FLAG_STORE_ONLY)) {
-        auto *so = new acl_engine();
-        so->store_only = true;
-        so->device = -1;
-        *out = so;
-        return ACL_OK;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(ACL_ERR_UNAVAILABLE, "acl_open: no HIP device available (this engine has no CPU evaluation path)");
-    auto *h = new acl_engine();
-    int dev = cfg ? cfg->device : -1;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    }
-    if (dev >= ndev) {
-        delete h;
-        return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: device ordinal out of range");
-    }
-    h->device = dev;
-    hipError_t e = hipSetDevice(dev);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = h->d_status.ensure(kStatusWords);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault);
-    if (e != hipSuccess) {
-        std::string m = std::string("acl_open: ") + hipGetErrorString(e);
-        delete h;
-        return fail(ACL_ERR_UNAVAILABLE, m);
-    }
-    h->grid_blocks = expand_grid_blocks(dev);
-    if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
-    int rc = alloc_frontier(h, cfg && cfg->frontier_entries ? cfg->frontier_entries
-                                                            : std::max<uint64_t>(16u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));
-    if (rc) {
-        delete h;
-        return rc;
-    }
-    *out = h;
-    return ACL_OK;
-}
-
-void acl_close(acl_engine_t *h) {
-    if (!h) return;
-    (void)acl_batcher_stop(h);
-    if (h->store_only) {
-        delete h;
-        return;
-    }
-    (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
-    if (h->h_status) (void)hipHostFree(h->h_status);
-    hipStream_t s = h->stream;
-    delete h;
-    if (s) (void)hipStreamDestroy(s);
-}
-
-int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, const char *rels, size_t rels_len) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-    if (!schema) return fail(ACL_ERR_INVALID_ARGUMENT, "schema is NULL");
-    Status s = h->store.load_schema(std::string(schema, schema_len));
-    if (!s.ok()) return fail(s);
-    h->snap_valid = false;
-    if (rels && rels_len) {
-        s = h->store.load_relationship_lines(std::string(rels, rels_len));
-        if (!s.ok()) return fail(s);
-    }
-    return ACL_OK;
-}
-
-int acl_type_id(acl_engine_t *h, const char *type) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    return type ? h->store.schema().type_of(type) : -1;
-}
-int acl_relation_id(acl_engine_t *h, int type, const char *name) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    const Schema &sc = h->store.schema();
-    if (!name || type < 0 || type >= (int)sc.defs.size()) return -1;
-    return sc.defs[type].find(name);
-}
-int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-    const Schema &sc = h->store.schema();
-    if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
-    *id_out = h->store.objects(type).intern(object_id);
-    return ACL_OK;
-}
-int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    const Schema &sc = h->store.schema();
-    if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_find: bad argument");
-    return h->store.objects(type).find(object_id, id_out) ? ACL_OK : fail(ACL_ERR_NOT_FOUND, "object not found");
-}
-const char *acl_object_name(acl_engine_t *h, int type, uint32_t id) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    const Schema &sc = h->store.schema();
-    if (type < 0 || type >= (int)sc.defs.size()) return nullptr;
-    const std::string *n = h->store.objects(type).name(id);
-    return n ? n->c_str() : nullptr;
-}
-uint32_t acl_object_count(acl_engine_t *h, int type) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    const Schema &sc = h->store.schema();
-    if (type < 0 || type >= (int)sc.defs.size()) return 0;
-    return h->store.objects(type).count();
-}
-
-int acl_write(acl_engine_t *h, const acl_update_t *ups, int n, const acl_filter_t *pre, int m, uint64_t *rev) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-    if (n < 0 || m < 0 || (n && !ups) || (m && !pre)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_write: bad argument");
-    std::vector<UpdateText> u(n);
-    for (int i = 0; i < n; i++) {
-        const acl_relationship_t &r = ups[i].rel;
-        u[i].op = ups[i].op;
-        u[i].rel.rtype = r.resource_type ? r.resource_type : "";
-        u[i].rel.rid = r.resource_id ? r.resource_id : "";
-        u[i].rel.rel = r.relation ? r.relation : "";
-        u[i].rel.stype = r.subject_type ? r.subject_type : "";
-        u[i].rel.sid = r.subject_id ? r.subject_id : "";
-        u[i].rel.srel = r.subject_relation ? r.subject_relation : "";
-        u[i].rel.expires_at = r.expires_at;
-    }
-    std::vector<FilterText> p(m);
-    for (int i = 0; i < m; i++) p[i] = to_filter(&pre[i]);
-    Status s = h->store.write(u, p, rev);
-    return s.ok() ? ACL_OK : fail(s);
-}
-
-int acl_delete_by_filter(acl_engine_t *h, const acl_filter_t *f, uint64_t *n_deleted, uint64_t *rev) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-    if (!f) return fail(ACL_ERR_INVALID_ARGUMENT, "filter is NULL");
-    Status s = h->store.delete_by_filter(to_filter(f), n_deleted, rev);
-    return s.ok() ? ACL_OK : fail(s);
-}
-
-int acl_read(acl_engine_t *h, const acl_filter_t *f, acl_read_cb cb, void *user) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (!f || !cb) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_read: bad argument");
-    Status s = h->store.read(to_filter(f), [&](const RelText &r) {
-        acl_relationship_t o{r.rtype.c_str(), r.rid.c_str(), r.rel.c_str(), r.stype.c_str(), r.sid.c_str(), r.srel.c_str(), r.expires_at};
-        cb(user, &o);
-    });
-    return s.ok() ? ACL_OK : fail(s);
-}
-
-int acl_add_edges(acl_engine_t *h, int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
-    Status s = h->store.add_edges(rtype, rel, stype, srel, n, res, subj);
-    return s.ok() ? ACL_OK : fail(s);
-}
-
-uint64_t acl_revision(acl_engine_t *h) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    return h->store.revision();
-}
-int acl_set_now(acl_engine_t *h, int64_t t) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->store.set_now(t);
-    return ACL_OK;
-}
-int acl_snapshot(acl_engine_t *h) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    return ensure_snapshot(h);
-}
-
-void *acl_stream(acl_engine_t *h) { return (void *)h->stream; }
-int acl_sync(acl_engine_t *h) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    ev_collect(h);
-    return ACL_OK;
-}
-
-int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids_device: NULL buffer");
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    return check_device(h, (const uint4 *)d_items, n, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
-}
-
-int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (n && (!items || !perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids: NULL buffer");
-    if (!n) return ACL_OK;
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(h->d_items.ensure(n));
-    HIP_TRY(h->d_perm.ensure(n));
-    HIP_TRY(h->d_errout.ensure(n));
-    HIP_TRY(hipMemcpyAsync(h->d_items.p, items, n * sizeof(acl_item_t), hipMemcpyHostToDevice, h->stream));
-    int rc = check_device(h, h->d_items.p, n, h->d_perm.p, h->d_errout.p);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(perm_out, h->d_perm.p, n, hipMemcpyDeviceToHost, h->stream));
-    if (err_out) HIP_TRY(hipMemcpyAsync(err_out, h->d_errout.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    ev_collect(h);
-    return ACL_OK;
-}
-
-extern "C++" {
-namespace aclint {
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out) {
     const Schema &sc = h->store.schema();
     if (empty(it.resource_type) || empty(it.resource_id) || empty(it.permission) || empty(it.subject_type) || empty(it.subject_id))
@@ -464,115 +450,146 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
     *out = acl_item_t{(uint16_t)rt, (uint16_t)pm, res, (uint16_t)st, (uint16_t)(sr == kNoRelation ? ACL_NO_RELATION : sr), sub};
     return 0;
 }
-}  // namespace aclint
-}  // extern "C++"
 
-int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
-    if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk: NULL buffer");
-    std::vector<acl_item_t> ids;
-    std::vector<size_t> where;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
-        ids.reserve(n);
-        where.reserve(n);
-        for (size_t i = 0; i < n; i++) {
-            perm_out[i] = ACL_PERM_UNSPECIFIED;
-            acl_item_t o;
-            err_out[i] = intern_check_item(h, items[i], &o);
-            if (err_out[i]) continue;
-            ids.push_back(o);
-            where.push_back(i);
+// The string entry point's host half (SURVEY.md 7 "the GPU is not the bottleneck; the host is"): type / permission names
+// repeat across a bulk request (check.go:23-39 resolves one rule template per item), so the last resolved
+// (type, permission, subject type, subject relation) is remembered per thread; object ids are two hash probes over the
+// caller's bytes.  Large batches are split over host threads (lookups only read the tables: names_mu is held shared by the caller).
+struct NameMemo {
+    const char *rt = nullptr, *pm = nullptr, *st = nullptr, *sr = nullptr;
+    std::string rts, pms, sts, srs;
+    int rti = -1, pmi = -1, sti = -1, sri = kNoRelation;
+    bool bad = true;
+};
+
+static int32_t intern_fast(acl_engine_t *h, const Schema &sc, const acl_check_item_t &it, NameMemo &m, acl_item_t *out) {
+    if (empty(it.resource_type) || empty(it.resource_id) || empty(it.permission) || empty(it.subject_type) || empty(it.subject_id))
+        return ACL_ERR_INVALID_ARGUMENT;
+    const char *srel = (empty(it.subject_relation) || std::strcmp(it.subject_relation, "...") == 0) ? "" : it.subject_relation;
+    if (!(m.rt && m.rts == it.resource_type && m.pms == it.permission && m.sts == it.subject_type && m.srs == srel)) {
+        m.rt = it.resource_type;
+        m.rts = it.resource_type;
+        m.pms = it.permission;
+        m.sts = it.subject_type;
+        m.srs = srel;
+        m.rti = sc.type_of(m.rts);
+        m.sti = sc.type_of(m.sts);
+        m.pmi = m.rti < 0 ? -1 : sc.defs[m.rti].find(m.pms);
+        m.sri = kNoRelation;
+        m.bad = m.rti < 0 || m.sti < 0 || m.pmi < 0;
+        if (!m.bad && *srel) {
+            m.sri = sc.defs[m.sti].find(m.srs);
+            m.bad = m.sri < 0;
         }
     }
-    if (ids.empty()) return ACL_OK;
-    std::vector<uint8_t> p(ids.size());
-    std::vector<int32_t> e(ids.size());
-    int rc = acl_check_bulk_ids(h, ids.data(), ids.size(), p.data(), e.data());
-    if (rc) return rc;
-    for (size_t k = 0; k < ids.size(); k++) {
-        perm_out[where[k]] = p[k];
-        err_out[where[k]] = e[k];
+    if (m.bad) return ACL_ERR_FAILED_PRECONDITION;
+    uint32_t res, sub;
+    const bool kr = h->store.objects(m.rti).find(it.resource_id, &res), ks = h->store.objects(m.sti).find(it.subject_id, &sub);
+    if (!kr && !ks && m.rti == m.sti && std::strcmp(it.resource_id, it.subject_id) == 0) res = sub = 0xFFFFFFFEu;
+    else {
+        if (!kr) res = 0xFFFFFFFDu;
+        if (!ks) sub = 0xFFFFFFFCu;
     }
-    return ACL_OK;
+    *out = acl_item_t{(uint16_t)m.rti, (uint16_t)m.pmi, res, (uint16_t)m.sti, (uint16_t)(m.sri == kNoRelation ? ACL_NO_RELATION : m.sri), sub};
+    return 0;
 }
 
-int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps,
-                               size_t words, uint64_t *counts) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (n && (!sids || !bitmaps)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_resources_batch: NULL buffer");
-    if (h->store_only) return ensure_snapshot(h);
+void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out) {
+    const Schema &sc = h->store.schema();
+    auto run = [&](size_t a, size_t b) {
+        NameMemo m;
+        for (size_t i = a; i < b; i++) {
+            out[i] = acl_item_t{};
+            err_out[i] = intern_fast(h, sc, items[i], m, &out[i]);
+        }
+    };
+    unsigned nt = n >= 32768 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
+    if (nt > 1) nt = (unsigned)std::min<size_t>(nt, n / 8192);
+    if (nt <= 1) {
+        run(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(run, n * t / nt, n * (t + 1) / nt);
+    run(0, n / nt);
+    for (auto &t : th) t.join();
+}
+
+// one batched reverse walk: n subjects of one class against one (type, permission); bitmaps in host memory
+int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
+                 uint64_t *counts) {
     int rc = not_sharded(h);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(h->device));
-    rc = ensure_reverse(h);
-    if (rc) return rc;
     const Schema &sc = h->store.schema();
-    if (rtype < 0 || rtype >= (int)sc.defs.size() || stype < 0 || stype >= (int)sc.defs.size() || perm < 0 ||
-        perm >= (int)sc.defs[rtype].members.size() || srel >= (int)sc.defs[stype].members.size())
-        return fail(ACL_ERR_FAILED_PRECONDITION, "lookup: unknown type, permission or subject relation");
     const uint32_t target = (uint32_t)sc.slot(rtype, perm);
     const uint32_t key = sc.subject_key(stype, srel < 0 ? kNoRelation : srel);
-    const uint32_t nobj = h->store.objects(rtype).count();  // (the bitmaps on the device also cover the headroom ids)
+    const uint32_t nobj = h->store.objects(rtype).count();
     const size_t need = (nobj + 31) / 32;
     if (words < need) return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
-    const size_t vwords = (size_t)((h->snap.visited_bits + 31) / 32);
-    const size_t group = std::max<size_t>(1, std::min<size_t>(n ? n : 1, ((size_t)1 << 28) / std::max<size_t>(vwords, 1)));  // <= 1 GiB of visited bits
+    // the walk can only mark the ids the snapshot's bitmap slot covers (the build-time count plus headroom); ids interned
+    // since then have no relationship in this snapshot, so their bits are zero -- never copy past the slot (advice r1)
+    const size_t slot_words = ((size_t)h->snap.slot_nobjects[target] + 31) / 32;
+    const size_t cw = std::min(need, slot_words);
+    const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
+    const size_t group = std::max<size_t>(1, std::min<size_t>(n ? n : 1, ((size_t)1 << 28) / vwords));  // <= 1 GiB of visited bits
     for (size_t b = 0; b < n; b += group) {
         const size_t m = std::min(group, n - b);
-        HIP_TRY(h->d_visited.ensure(m * std::max<size_t>(vwords, 1)));
-        HIP_TRY(h->d_sids.ensure(m));
-        HIP_TRY(hipMemcpyAsync(h->d_sids.p, sids + b, m * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));  // pageable source: staged before return
-        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, h->d_visited.p, (uint32_t)vwords};
+        HIP_TRY(c->d_visited.ensure(m * vwords));
+        HIP_TRY(c->d_sids.ensure(m));
+        HIP_TRY(c->h_in.ensure(m * sizeof(uint32_t)));
+        std::memcpy(c->h_in.p, sids + b, m * sizeof(uint32_t));
+        HIP_TRY(hipMemcpyAsync(c->d_sids.p, c->h_in.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords};
+        HIP_TRY(c->h_out.ensure(m * std::max<size_t>(cw, 1) * 4));
         for (int attempt = 0;; attempt++) {
-            if (m > h->frontier_entries) {
-                rc = alloc_frontier(h, m * 4);
+            if (m > c->frontier_entries) {
+                rc = alloc_frontier(h, c, m * 4);
                 if (rc) return rc;
             }
-            DevFrontier f = h->dev_frontier();
-            HIP_TRY(hipMemsetAsync(h->d_visited.p, 0, m * std::max<size_t>(vwords, 1) * 4, h->stream));
-            launch_rev_seed(h->stream, f, h->d_sids.p, (uint32_t)m, key);  // seeds + status block, on the device
+            DevFrontier f = h->dev_frontier(*c);
+            HIP_TRY(hipMemsetAsync(c->d_visited.p, 0, m * vwords * 4, c->stream));
+            launch_rev_seed(c->stream, f, c->d_sids.p, (uint32_t)m, key);  // seeds + status block, on the device
             uint32_t levels = 0;
-            rc = level_loop(h, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(h->stream, r, f, it); }, &levels, [&] {
+            hipError_t cpe = hipSuccess;
+            rc = level_loop(h, c, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(c->stream, r, f, it); }, &levels, [&] {
                 // speculative epilogue: the result rows of the target slot, one strided copy for all requests
-                if (need) (void)hipMemcpy2DAsync(bitmaps + b * words, words * 4, h->d_visited.p + h->snap.slot_bit_base[target] / 32, std::max<size_t>(vwords, 1) * 4,
-                                                 need * 4, m, hipMemcpyDeviceToHost, h->stream);
+                if (cw) {
+                    hipError_t e = hipMemcpy2DAsync(c->h_out.p, cw * 4, c->d_visited.p + h->snap.slot_bit_base[target] / 32, vwords * 4, cw * 4, m,
+                                                    hipMemcpyDeviceToHost, c->stream);
+                    if (e != hipSuccess) cpe = e;
+                }
             });
-            if (rc == ACL_ERR_RESOURCE_EXHAUSTED && h->h_status[2 * kLevelSlots] == 1) {
-                h->stats.overflow_retries++;
-                if (h->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
-                int rc2 = alloc_frontier(h, h->frontier_entries * 4);
+            if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
+                c->stats.overflow_retries++;
+                if (c->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
+                int rc2 = alloc_frontier(h, c, c->frontier_entries * 4);
                 if (rc2) return rc2;
                 continue;
             }
             if (rc) return rc;
+            if (cpe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("lookup result copy: ") + hipGetErrorString(cpe));
             break;
         }
         for (size_t i = 0; i < m; i++) {
             uint32_t *dst = bitmaps + (b + i) * words;
-            std::fill(dst + need, dst + words, 0u);
+            if (cw) std::memcpy(dst, (const uint32_t *)c->h_out.p + i * cw, cw * 4);
+            std::fill(dst + cw, dst + words, 0u);
             if (counts) {
-                uint64_t c = 0;
-                for (size_t w = 0; w < need; w++) c += (uint64_t)__builtin_popcount(dst[w]);
-                counts[b + i] = c;
+                uint64_t cnt = 0;
+                for (size_t w = 0; w < cw; w++) cnt += (uint64_t)__builtin_popcount(dst[w]);
+                counts[b + i] = cnt;
             }
         }
     }
     return ACL_OK;
 }
 
-int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int perm, int stype, int srel, uint32_t sid, uint32_t *bitmap, size_t words, uint64_t *count) {
-    return acl_lookup_resources_batch(h, rtype, perm, stype, srel, &sid, 1, bitmap, words, count);
-}
-
-extern "C++" {
-namespace aclint {
 // LookupResourcesRequest strings -> ids (lookups.go:49-62); the subject is interned so `stype:sid#srel` can be its own member
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (empty(rtype) || empty(perm) || empty(stype) || empty(sid)) return fail(ACL_ERR_INVALID_ARGUMENT, "invalid LookupResourcesRequest: empty field");
+    std::shared_lock<RwLock> slk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     const Schema &sc = h->store.schema();
     int sr = -1;
@@ -587,37 +604,386 @@ int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const c
         if (sr < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation `") + srel + "` not found under definition `" + stype + "`");
     }
     *sub_out = h->store.objects(st).intern(sid);
-    // a subject the reverse rows have no room for (beyond the headroom ids): they are rebuilt by this lookup
-    if (sr >= 0 && h->snap.has_reverse && h->store.objects(st).count() > h->snap.slot_nobjects[sc.slot(st, sr)]) {
-        h->rev_uploaded = false;
-        h->snap.has_reverse = false;
-    }
     *rt_out = rt;
     *pm_out = pm;
     *st_out = st;
     *sr_out = sr;
     return ACL_OK;
 }
-}  // namespace aclint
-}  // extern "C++"
 
-int acl_lookup_resources(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap,
-                         size_t words, uint64_t *count) {
+static int lookup_args_ok(acl_engine *h, int rtype, int perm, int stype, int srel) {
+    const Schema &sc = h->store.schema();
+    if (rtype < 0 || rtype >= (int)sc.defs.size() || stype < 0 || stype >= (int)sc.defs.size() || perm < 0 ||
+        perm >= (int)sc.defs[rtype].members.size() || srel >= (int)sc.defs[stype].members.size())
+        return fail(ACL_ERR_FAILED_PRECONDITION, "lookup: unknown type, permission or subject relation");
+    return ACL_OK;
+}
+
+int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
+                             uint64_t *counts, const CallOpts &opts) {
+    if (n && (!sids || !bitmaps)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_resources_batch: NULL buffer");
+    int key_slot = -1;
+    {
+        std::shared_lock<RwLock> slk(h->state_mu);
+        if (!h->store_only) {
+            if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+            int rc = lookup_args_ok(h, rtype, perm, stype, srel);
+            if (rc) return rc;
+            if (srel >= 0) key_slot = h->store.schema().slot(stype, srel);
+        }
+    }
+    Eval ev;
+    int rc = ev.begin(h, true, opts, key_slot);
+    if (rc) return rc;
+    rc = lookup_args_ok(h, rtype, perm, stype, srel);  // (the schema may have been reloaded in between)
+    if (rc) return rc;
+    return lookup_batch(h, ev.c, rtype, perm, stype, srel, sids, n, bitmaps, words, counts);
+}
+
+int lookup_opts_call(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
+                     size_t bitmap_words, uint64_t *count_out, const CallOpts &opts) {
     int rt, pm, st, sr;
     uint32_t sub;
     int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &rt, &pm, &st, &sr, &sub);
     if (rc) return rc;
-    return acl_lookup_resources_batch(h, rt, pm, st, sr, &sub, 1, bitmap, words, count);
+    return lookup_batch_call(h, rt, pm, st, sr, &sub, 1, bitmap_out, bitmap_words, count_out, opts);
 }
 
+}  // namespace aclint
+
+bool acl_engine::is_pinned(const void *p, size_t bytes) {
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(pinned_mu);
+    const uintptr_t a = (uintptr_t)p;
+    for (const auto &r : pinned)
+        if (a >= r.first && a + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+extern "C" {
+
+const char *acl_last_error(void) { return g_last_error.c_str(); }
+
+int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
+    if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: out is NULL");
+    *out = nullptr;
+    if (cfg && (cfg->flags & ACL_FLAG_STORE_ONLY)) {
+        auto *so = new acl_engine();
+        so->store_only = true;
+        so->device = -1;
+        batcher_create(so);
+        *out = so;
+        return ACL_OK;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(ACL_ERR_UNAVAILABLE, "acl_open: no HIP device available (this engine has no CPU evaluation path)");
+    auto h = std::make_unique<acl_engine>();
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: device ordinal out of range");
+    h->device = dev;
+    hipError_t e = hipSetDevice(dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
+    h->grid_blocks = expand_grid_blocks(dev);
+    if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
+    if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;
+    if (cfg && cfg->contexts) h->max_ctx = std::min<uint32_t>(cfg->contexts, 16);
+    if (const char *ev = getenv("ACL_LOCAL_MAX")) h->local_max_items = (uint32_t)atoi(ev);  // A/B knob: 0 disables the single-launch path
+    // the first context is created here, so that "out of device memory" surfaces at open
+    std::unique_ptr<PassCtx> c0;
+    int rc = new_ctx(h.get(), &c0, 0);
+    if (rc) return rc;
+    h->free_ctxs.push_back(c0.get());
+    h->ctxs.push_back(std::move(c0));
+    batcher_create(h.get());
+    *out = h.release();
+    return ACL_OK;
+}
+
+void acl_close(acl_engine_t *h) {
+    if (!h) return;
+    (void)acl_batcher_stop(h);
+    async_shutdown(h);
+    batcher_destroy(h);
+    if (h->store_only) {
+        delete h;
+        return;
+    }
+    (void)hipSetDevice(h->device);
+    {
+        std::lock_guard<RwLock> lk(h->state_mu);  // waits for evaluations in flight
+        h->ctxs.clear();
+        h->shard_ctx.reset();
+        std::lock_guard<std::mutex> plk(h->pinned_mu);
+        for (auto &r : h->pinned) (void)hipHostFree((void *)r.first);
+        h->pinned.clear();
+    }
+    hipStream_t s = h->up_stream;
+    delete h;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, const char *rels, size_t rels_len) {
+    std::lock_guard<RwLock> lk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    if (!schema) return fail(ACL_ERR_INVALID_ARGUMENT, "schema is NULL");
+    Status s = h->store.load_schema(std::string(schema, schema_len));
+    if (!s.ok()) return fail(s);
+    h->snap_valid = false;
+    h->dev_valid = false;
+    h->rev_uploaded = false;
+    if (rels && rels_len) {
+        s = h->store.load_relationship_lines(std::string(rels, rels_len));
+        if (!s.ok()) return fail(s);
+    }
+    return ACL_OK;
+}
+
+int acl_type_id(acl_engine_t *h, const char *type) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    return type ? h->store.schema().type_of(type) : -1;
+}
+int acl_relation_id(acl_engine_t *h, int type, const char *name) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (!name || type < 0 || type >= (int)sc.defs.size()) return -1;
+    return sc.defs[type].find(name);
+}
+int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
+    std::shared_lock<RwLock> slk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
+    *id_out = h->store.objects(type).intern(object_id);
+    return ACL_OK;
+}
+int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_find: bad argument");
+    return h->store.objects(type).find(object_id, id_out) ? ACL_OK : fail(ACL_ERR_NOT_FOUND, "object not found");
+}
+const char *acl_object_name(acl_engine_t *h, int type, uint32_t id) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return nullptr;
+    const std::string *n = h->store.objects(type).name(id);
+    return n ? n->c_str() : nullptr;
+}
+uint32_t acl_object_count(acl_engine_t *h, int type) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return 0;
+    return h->store.objects(type).count();
+}
+
+int acl_write(acl_engine_t *h, const acl_update_t *ups, int n, const acl_filter_t *pre, int m, uint64_t *rev) {
+    if (n < 0 || m < 0 || (n && !ups) || (m && !pre)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_write: bad argument");
+    std::vector<UpdateText> u(n);
+    for (int i = 0; i < n; i++) {
+        const acl_relationship_t &r = ups[i].rel;
+        u[i].op = ups[i].op;
+        u[i].rel.rtype = r.resource_type ? r.resource_type : "";
+        u[i].rel.rid = r.resource_id ? r.resource_id : "";
+        u[i].rel.rel = r.relation ? r.relation : "";
+        u[i].rel.stype = r.subject_type ? r.subject_type : "";
+        u[i].rel.sid = r.subject_id ? r.subject_id : "";
+        u[i].rel.srel = r.subject_relation ? r.subject_relation : "";
+        u[i].rel.expires_at = r.expires_at;
+    }
+    std::vector<FilterText> p(m);
+    for (int i = 0; i < m; i++) p[i] = to_filter(&pre[i]);
+    std::lock_guard<RwLock> lk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    Status s = h->store.write(u, p, rev);
+    return s.ok() ? ACL_OK : fail(s);
+}
+
+int acl_delete_by_filter(acl_engine_t *h, const acl_filter_t *f, uint64_t *n_deleted, uint64_t *rev) {
+    return acl_delete_by_filter_pre(h, f, nullptr, 0, n_deleted, rev);
+}
+
+// DeleteRelationships with OptionalPreconditions: evaluated against the pre-delete state, atomically with the delete
+int acl_delete_by_filter_pre(acl_engine_t *h, const acl_filter_t *f, const acl_filter_t *pre, int n_pre, uint64_t *n_deleted, uint64_t *rev) {
+    if (!f) return fail(ACL_ERR_INVALID_ARGUMENT, "filter is NULL");
+    if (n_pre < 0 || (n_pre && !pre)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_delete_by_filter_pre: bad argument");
+    std::vector<FilterText> p(n_pre);
+    for (int i = 0; i < n_pre; i++) p[i] = to_filter(&pre[i]);
+    std::lock_guard<RwLock> lk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    if (n_pre) {
+        Status ps = h->store.check_preconditions(p);
+        if (!ps.ok()) return fail(ps);
+    }
+    Status s = h->store.delete_by_filter(to_filter(f), n_deleted, rev);
+    return s.ok() ? ACL_OK : fail(s);
+}
+
+int acl_read(acl_engine_t *h, const acl_filter_t *f, acl_read_cb cb, void *user) {
+    if (!f || !cb) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_read: bad argument");
+    std::lock_guard<RwLock> lk(h->state_mu);  // the scan settles pending bulk appends: exclusive
+    Status s = h->store.read(to_filter(f), [&](const RelText &r) {
+        acl_relationship_t o{r.rtype.c_str(), r.rid.c_str(), r.rel.c_str(), r.stype.c_str(), r.sid.c_str(), r.srel.c_str(), r.expires_at};
+        cb(user, &o);
+    });
+    return s.ok() ? ACL_OK : fail(s);
+}
+
+int acl_add_edges(acl_engine_t *h, int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj) {
+    std::lock_guard<RwLock> lk(h->state_mu);
+    std::unique_lock<std::shared_mutex> nlk(h->names_mu);
+    Status s = h->store.add_edges(rtype, rel, stype, srel, n, res, subj);
+    return s.ok() ? ACL_OK : fail(s);
+}
+
+uint64_t acl_revision(acl_engine_t *h) {
+    std::shared_lock<RwLock> lk(h->state_mu);
+    return h->store.revision();
+}
+int acl_set_now(acl_engine_t *h, int64_t t) {
+    std::lock_guard<RwLock> lk(h->state_mu);
+    h->store.set_now(t);
+    return ACL_OK;
+}
+int acl_snapshot(acl_engine_t *h) {
+    std::lock_guard<RwLock> lk(h->state_mu);
+    if (h->store_only) return ensure_snapshot(h);
+    HIP_TRY(hipSetDevice(h->device));
+    return ensure_snapshot(h);
+}
+
+void *acl_stream(acl_engine_t *h) { return h->ctxs.empty() ? nullptr : (void *)h->ctxs[0]->stream; }
+int acl_sync(acl_engine_t *h) {
+    if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
+    HIP_TRY(hipSetDevice(h->device));
+    std::vector<hipStream_t> ss;
+    {
+        std::lock_guard<std::mutex> lk(h->pool_mu);
+        for (auto &c : h->ctxs) ss.push_back(c->stream);
+    }
+    for (hipStream_t s : ss) HIP_TRY(hipStreamSynchronize(s));
+    return ACL_OK;
+}
+
+int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out) {
+    if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids_device: NULL buffer");
+    Eval ev;
+    int rc = ev.begin(h, false);
+    if (rc) return rc;
+    rc = check_device(h, ev.c, (const uint4 *)d_items, n, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ev.c->stream));
+    ev_collect(ev.c);
+    return ACL_OK;
+}
+
+int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    return acl_check_bulk_ids_opts(h, items, n, perm_out, err_out, nullptr);
+}
+
+int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o) {
+    if (n && (!items || !perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids: NULL buffer");
+    CallOpts opts;
+    if (o) {
+        opts.cancel = o->cancel;
+        if (o->timeout_ns > 0) opts.deadline_ns = mono_ns() + o->timeout_ns;
+    }
+    if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
+    Eval ev;
+    int rc = ev.begin(h, false, opts);
+    if (rc) return rc;
+    return check_ids_host(h, ev.c, items, n, perm_out, err_out);
+}
+
+int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk: NULL buffer");
+    std::vector<acl_item_t> all(n), ids;
+    std::vector<uint32_t> where;
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);  // string -> id only reads the tables: concurrent callers intern in parallel
+        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+        intern_check_items(h, items, n, all.data(), err_out);
+    }
+    ids.reserve(n);
+    where.reserve(n);
+    for (size_t i = 0; i < n; i++) {
+        perm_out[i] = ACL_PERM_UNSPECIFIED;
+        if (err_out[i]) continue;
+        ids.push_back(all[i]);
+        where.push_back((uint32_t)i);
+    }
+    if (ids.empty()) return ACL_OK;
+    if (ids.size() == n) return acl_check_bulk_ids(h, ids.data(), n, perm_out, err_out);
+    std::vector<uint8_t> p(ids.size());
+    std::vector<int32_t> e(ids.size());
+    int rc = acl_check_bulk_ids(h, ids.data(), ids.size(), p.data(), e.data());
+    if (rc) return rc;
+    for (size_t k = 0; k < ids.size(); k++) {
+        perm_out[where[k]] = p[k];
+        err_out[where[k]] = e[k];
+    }
+    return ACL_OK;
+}
+
+int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps,
+                               size_t words, uint64_t *counts) {
+    return lookup_batch_call(h, rtype, perm, stype, srel, sids, n, bitmaps, words, counts, CallOpts());
+}
+
+int acl_lookup_resources_ids(acl_engine_t *h, int rtype, int perm, int stype, int srel, uint32_t sid, uint32_t *bitmap, size_t words, uint64_t *count) {
+    return acl_lookup_resources_batch(h, rtype, perm, stype, srel, &sid, 1, bitmap, words, count);
+}
+
+int acl_lookup_resources(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap,
+                         size_t words, uint64_t *count) {
+    return lookup_opts_call(h, rtype, perm, stype, sid, srel, bitmap, words, count, CallOpts());
+}
+
+// LookupResources with an engine-owned result: the bitmap is sized by the engine at the moment of the walk, so a racing
+// WriteRelationships that interns new objects of the type cannot make the caller's buffer "too small" (advice r1).
+int acl_lookup_resources_alloc(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel,
+                               const acl_call_opts_t *o, uint32_t **bitmap_out, size_t *words_out, uint64_t *count_out) {
+    if (!bitmap_out || !words_out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_resources_alloc: NULL output");
+    *bitmap_out = nullptr;
+    *words_out = 0;
+    CallOpts opts;
+    if (o) {
+        opts.cancel = o->cancel;
+        if (o->timeout_ns > 0) opts.deadline_ns = mono_ns() + o->timeout_ns;
+    }
+    int rt, pm, st, sr;
+    uint32_t sub;
+    int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &rt, &pm, &st, &sr, &sub);
+    if (rc) return rc;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        const size_t words = ((size_t)acl_object_count(h, rt) + 31) / 32 + 64;  // slack: objects interned while the walk runs
+        uint32_t *bm = (uint32_t *)std::malloc(std::max<size_t>(words, 1) * sizeof(uint32_t));
+        if (!bm) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory for the result bitmap");
+        rc = lookup_one_routed(h, rt, pm, st, sr, sub, bm, words, count_out, opts);
+        if (rc == ACL_OK) {
+            *bitmap_out = bm;
+            *words_out = words;
+            return ACL_OK;
+        }
+        std::free(bm);
+        if (rc != ACL_ERR_INVALID_ARGUMENT || std::string(acl_last_error()).find("bitmap too small") == std::string::npos) return rc;
+    }
+    return fail(ACL_ERR_UNAVAILABLE, "lookup: the object table kept growing faster than the result bitmap");
+}
+void acl_free(void *p) { std::free(p); }
+
 int acl_stats(acl_engine_t *h, acl_stats_t *out) {
-    std::lock_guard<std::mutex> lk(h->mu);
     if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "out is NULL");
+    std::lock_guard<std::mutex> lk(h->stats_mu);
     *out = h->stats;
     return ACL_OK;
 }
 int acl_stats_reset(acl_engine_t *h) {
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk(h->stats_mu);
     uint64_t e = h->stats.snapshot_edges, b = h->stats.snapshot_bytes, el = h->stats.snapshot_edges_local;
     uint64_t sb = h->stats.snapshot_builds, sp = h->stats.snapshot_patches;
     h->stats = acl_stats_t{};
@@ -629,8 +995,7 @@ int acl_stats_reset(acl_engine_t *h) {
     return ACL_OK;
 }
 int acl_set_timing(acl_engine_t *h, int on) {
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->timing = on != 0;
+    h->timing.store(on != 0);
     return ACL_OK;
 }
 

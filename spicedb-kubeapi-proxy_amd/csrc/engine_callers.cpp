@@ -1,28 +1,281 @@
 // engine_callers.cpp -- the callers either side of the kernels: PostFilter keep mask, PreFilter bitmap test,
 // Watch change feed, snapshot self-check hook, micro-batching front-end.
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <climits>
 #include <tuple>
 
 #include "engine_internal.hpp"
+
+// ---------------------------------------------------------------- micro-batching front-end
+// The proxy issues many concurrent 1-item checks (check.go:76-94: one goroutine per check expression; watch.go:50: one
+// per update) and one LookupResources per list request (responsefilterer.go:165).  Callers append to the OPEN batch (a
+// few dozen nanoseconds under one mutex) and sleep on that batch's own futex word; dispatcher threads -- one per
+// evaluation context, so passes overlap on the device -- close the open batch, answer it with one device pass and wake
+// exactly its callers with ONE futex call.  (Round 1 woke every caller through its own condition variable while holding
+// the queue lock: 263 k checks/s at 64 threads, collapsing to 46 k/s at 1 024.)
+namespace {
+
+inline long futex(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec *ts) {
+    return syscall(SYS_futex, reinterpret_cast<uint32_t *>(addr), op, val, ts, nullptr, 0);
+}
+
+struct LookupReq {
+    int rtype, perm, stype, srel;
+    uint32_t sid;
+    size_t words;
+    // filled by the dispatcher
+    int rc = 0;
+    std::string msg;
+    std::vector<uint32_t> bitmap;
+    uint64_t count = 0;
+};
+
+struct Batch {
+    std::atomic<uint32_t> done{0};
+    std::atomic<uint32_t> refs{1};  // the queue's own reference + one per caller
+    std::vector<acl_item_t> items;
+    std::vector<uint8_t> perm;
+    std::vector<int32_t> err;
+    std::vector<LookupReq> lookups;
+    int rc = 0;
+    std::string msg;
+    int64_t opened_ns = 0;
+    void unref() {
+        if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
+    }
+};
+
+}  // namespace
+
+struct acl_engine::Batcher {
+    std::mutex mu;
+    std::condition_variable cv;  // dispatchers only
+    Batch *open = nullptr;
+    uint32_t idle = 0;      // dispatchers parked on cv
+    uint32_t in_flight = 0;  // passes on the device
+    bool stop = false;
+    std::vector<std::thread> threads;
+    uint32_t max_items = 4096, wait_us = 200;
+    std::atomic<uint64_t> batches{0}, items{0}, lookup_walks{0}, lookups{0};
+    std::atomic<uint32_t> sleepers{0};
+    unsigned cores = 1;
+};
+
+namespace {
+
+void answer_batch(acl_engine_t *h, Batch *b) {
+    if (!b->items.empty()) {
+        b->perm.assign(b->items.size(), 0);
+        b->err.assign(b->items.size(), 0);
+        b->rc = acl_check_bulk_ids(h, b->items.data(), b->items.size(), b->perm.data(), b->err.data());
+        if (b->rc) b->msg = acl_last_error();
+    }
+    // LookupResources of the batch: one batched reverse walk per (resource type, permission, subject class)
+    uint64_t walks = 0;
+    if (!b->lookups.empty()) {
+        std::vector<LookupReq *> lks;
+        for (LookupReq &l : b->lookups) lks.push_back(&l);
+        auto key = [](const LookupReq *a) { return std::tie(a->rtype, a->perm, a->stype, a->srel, a->words); };
+        std::stable_sort(lks.begin(), lks.end(), [&](const LookupReq *a, const LookupReq *c) { return key(a) < key(c); });
+        std::vector<uint32_t> sids, bms;
+        std::vector<uint64_t> cnts;
+        for (size_t g0 = 0; g0 < lks.size();) {
+            size_t g1 = g0 + 1;
+            while (g1 < lks.size() && key(lks[g1]) == key(lks[g0])) g1++;
+            const size_t m = g1 - g0, words = lks[g0]->words;
+            sids.resize(m);
+            bms.assign(m * std::max<size_t>(words, 1), 0);
+            cnts.assign(m, 0);
+            for (size_t i = 0; i < m; i++) sids[i] = lks[g0 + i]->sid;
+            const int lrc = acl_lookup_resources_batch(h, lks[g0]->rtype, lks[g0]->perm, lks[g0]->stype, lks[g0]->srel, sids.data(), m, bms.data(), words, cnts.data());
+            const std::string lmsg = lrc ? acl_last_error() : "";
+            for (size_t i = 0; i < m; i++) {
+                LookupReq *w = lks[g0 + i];
+                w->rc = lrc;
+                w->msg = lmsg;
+                if (!lrc) {
+                    w->bitmap.assign(bms.begin() + (long)(i * words), bms.begin() + (long)((i + 1) * words));
+                    w->count = cnts[i];
+                }
+            }
+            walks++;
+            g0 = g1;
+        }
+    }
+    acl_engine::Batcher &B = *h->batcher;
+    if (!b->items.empty()) B.batches++;
+    B.items += b->items.size();
+    B.lookup_walks += walks;
+    B.lookups += b->lookups.size();
+    b->done.store(1, std::memory_order_release);
+    futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this batch's callers, one system call
+    b->unref();
+}
+
+void dispatcher_loop(acl_engine_t *h) {
+    acl_engine::Batcher &B = *h->batcher;
+    for (;;) {
+        Batch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(B.mu);
+            B.idle++;
+            B.cv.wait(lk, [&] { return B.stop || (B.open && (!B.open->items.empty() || !B.open->lookups.empty())); });
+            B.idle--;
+            if (!B.open || (B.open->items.empty() && B.open->lookups.empty())) {
+                if (B.stop) return;
+                continue;
+            }
+            // idle device and a small batch: let concurrent callers pile on for at most wait_us.  When a pass is already in
+            // flight, that pass WAS the batching window: whoever arrived during it goes now.
+            if (!B.stop && B.in_flight == 0 && B.wait_us && B.open->items.size() + B.open->lookups.size() < B.max_items) {
+                const int64_t until = B.open->opened_ns + (int64_t)B.wait_us * 1000;
+                while (!B.stop && B.open && B.open->items.size() + B.open->lookups.size() < B.max_items) {
+                    const int64_t now = mono_ns();
+                    if (now >= until) break;
+                    B.cv.wait_for(lk, std::chrono::nanoseconds(until - now));
+                }
+                if (!B.open) continue;  // another dispatcher took it meanwhile
+            }
+            b = B.open;
+            B.open = nullptr;
+            B.in_flight++;
+        }
+        answer_batch(h, b);
+        {
+            std::lock_guard<std::mutex> lk(B.mu);
+            B.in_flight--;
+        }
+    }
+}
+
+// appends to the open batch; returns the batch (one reference for the caller) and the caller's index in it
+Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, size_t *index) {
+    acl_engine::Batcher *B = h->batcher;
+    if (!B) return nullptr;
+    std::unique_lock<std::mutex> g(B->mu);
+    if (B->stop || B->threads.empty()) return nullptr;  // no batcher running
+    if (!B->open) {
+        B->open = new Batch();
+        B->open->opened_ns = mono_ns();
+    }
+    Batch *b = B->open;
+    const bool was_empty = b->items.empty() && b->lookups.empty();
+    if (item) {
+        *index = b->items.size();
+        b->items.push_back(*item);
+    } else {
+        *index = b->lookups.size();
+        b->lookups.push_back(*lk);
+    }
+    b->refs.fetch_add(1, std::memory_order_relaxed);
+    const bool full = b->items.size() + b->lookups.size() >= B->max_items;
+    const bool wake = (was_empty || full) && B->idle > 0;
+    g.unlock();
+    if (wake) B->cv.notify_one();
+    return b;
+}
+
+// parks the caller until its batch is answered: a short spin first when cores are to spare (a pass takes tens of
+// microseconds, a futex sleep + wake about as long), then the batch's futex
+int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
+    acl_engine::Batcher &B = *h->batcher;
+    const bool watched = opts.cancel || opts.deadline_ns;
+    if (B.sleepers.load(std::memory_order_relaxed) * 2 < B.cores) {
+        const int64_t spin_until = mono_ns() + 30000;
+        B.sleepers.fetch_add(1, std::memory_order_relaxed);
+        while (!b->done.load(std::memory_order_acquire) && mono_ns() < spin_until) {
+            for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+        }
+        B.sleepers.fetch_sub(1, std::memory_order_relaxed);
+    }
+    if (!b->done.load(std::memory_order_acquire)) {
+        B.sleepers.fetch_add(1, std::memory_order_relaxed);
+        while (!b->done.load(std::memory_order_acquire)) {
+            if (watched) {
+                int rc = check_opts(opts);
+                if (rc) {
+                    B.sleepers.fetch_sub(1, std::memory_order_relaxed);
+                    return rc;  // the batch still answers the abandoned slot; nobody reads it
+                }
+                timespec ts{0, 500000};
+                futex(&b->done, FUTEX_WAIT_PRIVATE, 0, &ts);
+            } else {
+                futex(&b->done, FUTEX_WAIT_PRIVATE, 0, nullptr);
+            }
+        }
+        B.sleepers.fetch_sub(1, std::memory_order_relaxed);
+    }
+    return ACL_OK;
+}
+
+CallOpts to_opts(const acl_call_opts_t *o) {
+    CallOpts opts;
+    if (o) {
+        opts.cancel = o->cancel;
+        if (o->timeout_ns > 0) opts.deadline_ns = mono_ns() + o->timeout_ns;
+    }
+    return opts;
+}
+
+}  // namespace
+
+namespace aclint {
+
+void batcher_create(acl_engine_t *h) { h->batcher = new acl_engine::Batcher(); }
+void batcher_destroy(acl_engine_t *h) {
+    if (h->batcher && h->batcher->open) h->batcher->open->unref();
+    delete h->batcher;
+    h->batcher = nullptr;
+}
+
+// one LookupResources with interned arguments: rides the micro-batcher when it runs, else a walk of its own
+int lookup_one_routed(acl_engine_t *h, int rt, int pm, int st, int sr, uint32_t sub, uint32_t *bitmap_out, size_t words, uint64_t *count_out,
+                      const CallOpts &opts) {
+    LookupReq lk{rt, pm, st, sr, sub, words};
+    size_t idx = 0;
+    Batch *b = enqueue(h, nullptr, &lk, &idx);
+    if (!b) return lookup_batch_call(h, rt, pm, st, sr, &sub, 1, bitmap_out, words, count_out, opts);
+    int rc = await_batch(h, b, opts);
+    if (rc == ACL_OK) {
+        LookupReq &r = b->lookups[idx];
+        if (r.rc) rc = fail(r.rc, r.msg);
+        else {
+            if (words) std::memcpy(bitmap_out, r.bitmap.data(), words * sizeof(uint32_t));
+            if (count_out) *count_out = r.count;
+        }
+    }
+    b->unref();
+    return rc;
+}
+
+}  // namespace aclint
 
 // ---------------------------------------------------------------- callers either side of the kernels
 extern "C" {
 
 // filterItemsWithBulkPermissions (postfilter.go:58-182) fused: ONE bulk check of the K*F resolved pairs and the
 // per-list-item AND, on the device; only K bytes come back.
-static int keep_device_locked(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out) {
-    HIP_TRY(h->d_perm.ensure(std::max<size_t>(n, 1)));
-    int rc = check_device(h, (const uint4 *)d_items, n, h->d_perm.p, nullptr);
+static int keep_device(acl_engine_t *h, PassCtx *c, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out) {
+    HIP_TRY(c->d_perm.ensure(std::max<size_t>(n, 1)));
+    int rc = check_device(h, c, (const uint4 *)d_items, n, c->d_perm.p, nullptr);
     if (rc) return rc;
-    launch_keep(h->stream, (uint32_t)k_items, (const uint32_t *)d_item_off, h->d_perm.p, (uint8_t *)d_keep_out);
+    launch_keep(c->stream, (uint32_t)k_items, (const uint32_t *)d_item_off, c->d_perm.p, (uint8_t *)d_keep_out);
     return ACL_OK;
 }
 
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
     if ((n && !d_items) || (k_items && (!d_item_off || !d_keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_ids_device: NULL buffer");
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    return keep_device_locked(h, d_items, n, d_item_off, k_items, d_keep_out);
+    Eval ev;
+    int rc = ev.begin(h, false);
+    if (rc) return rc;
+    rc = keep_device(h, ev.c, d_items, n, d_item_off, k_items, d_keep_out);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ev.c->stream));
+    ev_collect(ev.c);
+    return ACL_OK;
 }
 
 int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
@@ -30,19 +283,26 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
     if (!k_items) return ACL_OK;
     for (size_t i = 0; i < k_items; i++)
         if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_ids: item_off must ascend and end within n");
-    std::lock_guard<std::mutex> lk(h->mu);
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(h->d_items.ensure(std::max<size_t>(n, 1)));
-    HIP_TRY(h->d_itemoff.ensure(k_items + 1));
-    HIP_TRY(h->d_keep.ensure(k_items));
-    if (n) HIP_TRY(hipMemcpyAsync(h->d_items.p, items, n * sizeof(acl_item_t), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->d_itemoff.p, item_off, (k_items + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    int rc = keep_device_locked(h, h->d_items.p, n, h->d_itemoff.p, k_items, h->d_keep.p);
+    Eval ev;
+    int rc = ev.begin(h, false);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(keep_out, h->d_keep.p, k_items, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    ev_collect(h);
+    PassCtx *c = ev.c;
+    HIP_TRY(c->d_items.ensure(std::max<size_t>(n, 1)));
+    HIP_TRY(c->d_itemoff.ensure(k_items + 1));
+    HIP_TRY(c->d_keep.ensure(k_items));
+    HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t) + (k_items + 1) * sizeof(uint32_t)));
+    std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
+    uint32_t *h_off = (uint32_t *)((char *)c->h_in.p + n * sizeof(acl_item_t));
+    std::memcpy(h_off, item_off, (k_items + 1) * sizeof(uint32_t));
+    if (n) HIP_TRY(hipMemcpyAsync(c->d_items.p, c->h_in.p, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_itemoff.p, h_off, (k_items + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    rc = keep_device(h, c, c->d_items.p, n, c->d_itemoff.p, k_items, c->d_keep.p);
+    if (rc) return rc;
+    HIP_TRY(c->h_out.ensure(k_items));
+    HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_keep.p, k_items, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    std::memcpy(keep_out, c->h_out.p, k_items);
     return ACL_OK;
 }
 
@@ -63,7 +323,7 @@ int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n
 
 // prefilterResult.IsAllowed (lookups.go:25-36) over a LookupResources bitmap instead of a set of NamespacedNames
 int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t words, const char *const *object_ids, size_t n, uint8_t *allowed_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     if (type < 0 || type >= (int)sc.defs.size() || (n && (!bitmap || !object_ids || !allowed_out)))
         return fail(ACL_ERR_INVALID_ARGUMENT, "acl_bitmap_test_names: bad argument");
@@ -77,8 +337,9 @@ int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, siz
 
 // WatchService.Watch (watch.go:29-38) as a poll over the store's change feed
 int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, int ntypes, acl_watch_cb cb, void *user, uint64_t *revision_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
     if (ntypes < 0 || (ntypes && !types)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_watch_poll: bad argument");
+    std::shared_lock<RwLock> lk(h->state_mu);
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     std::vector<int> tv(types, types + ntypes);
     for (int t : tv)
@@ -96,7 +357,7 @@ int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, i
 // touching a device, so it also works on a store-only engine -- and verifies it against the store.
 // *patched_out = 1 when the update was a patch, 0 when it was a (re)build.
 int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
-    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<RwLock> lk(h->state_mu);
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     if (!h->store_only) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_snapshot drives the host snapshot itself: use a store-only engine");
     const int64_t now = h->store.now();
@@ -123,182 +384,97 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
     return ACL_OK;
 }
 
-// ---- micro-batching front-end: the proxy issues many concurrent 1-item checks (check.go:76-94: one goroutine per
-// check expression; watch.go:50: one per update).  acl_check_one() parks the caller, a batcher thread drains the
-// queue into ONE device pass (after at most max_wait_us, or as soon as max_items are waiting) and wakes everyone.
-static void batcher_loop(acl_engine_t *h) {
-    std::vector<acl_engine::Waiter *> batch;
-    std::vector<acl_item_t> items;
-    std::vector<uint8_t> perm;
-    std::vector<int32_t> err;
-    std::vector<uint32_t> sids, bms;
-    std::vector<uint64_t> cnts;
-    bool back_to_back = false;  // the previous pass WAS the batching window: whoever arrived during it goes now
-    for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(h->q_mu);
-            if (h->queue.empty()) back_to_back = false;
-            h->q_cv.wait(lk, [&] { return h->batcher_stop || !h->queue.empty(); });
-            if (h->batcher_stop && h->queue.empty()) return;
-            if (!back_to_back && h->queue.size() < h->mb_max_items && h->mb_wait_us)  // idle engine: let concurrent callers pile on
-                h->q_cv.wait_for(lk, std::chrono::microseconds(h->mb_wait_us), [&] { return h->batcher_stop || h->queue.size() >= h->mb_max_items; });
-            const size_t take = std::min<size_t>(h->queue.size(), h->mb_max_items);
-            batch.assign(h->queue.begin(), h->queue.begin() + (long)take);
-            h->queue.erase(h->queue.begin(), h->queue.begin() + (long)take);
-        }
-        // Checks of the batch: one device pass
-        items.clear();
-        for (acl_engine::Waiter *w : batch)
-            if (w->kind == 0) items.push_back(w->item);
-        perm.assign(items.size(), 0);
-        err.assign(items.size(), 0);
-        int rc = items.empty() ? ACL_OK : acl_check_bulk_ids(h, items.data(), items.size(), perm.data(), err.data());
-        const std::string msg = rc ? acl_last_error() : "";
-        // LookupResources of the batch: one batched reverse walk per (resource type, permission, subject class)
-        std::vector<acl_engine::Waiter *> lks;
-        for (acl_engine::Waiter *w : batch)
-            if (w->kind == 1) lks.push_back(w);
-        std::sort(lks.begin(), lks.end(), [](const acl_engine::Waiter *a, const acl_engine::Waiter *b) {
-            return std::tie(a->lk_rtype, a->lk_perm, a->lk_stype, a->lk_srel, a->lk_words) < std::tie(b->lk_rtype, b->lk_perm, b->lk_stype, b->lk_srel, b->lk_words);
-        });
-        uint64_t walks = 0;
-        for (size_t g0 = 0; g0 < lks.size();) {
-            size_t g1 = g0 + 1;
-            while (g1 < lks.size() && std::tie(lks[g1]->lk_rtype, lks[g1]->lk_perm, lks[g1]->lk_stype, lks[g1]->lk_srel, lks[g1]->lk_words) ==
-                                          std::tie(lks[g0]->lk_rtype, lks[g0]->lk_perm, lks[g0]->lk_stype, lks[g0]->lk_srel, lks[g0]->lk_words))
-                g1++;
-            const size_t m = g1 - g0, words = lks[g0]->lk_words;
-            sids.resize(m);
-            bms.assign(m * words, 0);
-            cnts.assign(m, 0);
-            for (size_t i = 0; i < m; i++) sids[i] = lks[g0 + i]->lk_sid;
-            const int lrc = acl_lookup_resources_batch(h, lks[g0]->lk_rtype, lks[g0]->lk_perm, lks[g0]->lk_stype, lks[g0]->lk_srel, sids.data(), m, bms.data(),
-                                                       words, cnts.data());
-            const std::string lmsg = lrc ? acl_last_error() : "";
-            for (size_t i = 0; i < m; i++) {
-                acl_engine::Waiter *w = lks[g0 + i];
-                w->rc = lrc;
-                w->msg = lmsg;
-                if (!lrc) {
-                    std::memcpy(w->lk_bitmap, bms.data() + i * words, words * sizeof(uint32_t));
-                    w->lk_count = cnts[i];
-                }
-            }
-            walks++;
-            g0 = g1;
-        }
-        {
-            std::lock_guard<std::mutex> lk(h->q_mu);
-            size_t ci = 0;
-            for (acl_engine::Waiter *w : batch) {
-                if (w->kind == 0) {
-                    w->rc = rc;
-                    w->msg = msg;
-                    w->perm = perm[ci];
-                    w->err = err[ci];
-                    ci++;
-                }
-                w->done = true;
-                w->cv.notify_one();
-            }
-            if (!items.empty()) h->mb_batches++;
-            h->mb_items += items.size();
-            h->mb_lookup_walks += walks;
-            h->mb_lookups += lks.size();
-        }
-        back_to_back = true;
-    }
-}
-
 int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us) {
-    std::lock_guard<std::mutex> lk(h->q_mu);
-    if (h->batcher_on) return fail(ACL_ERR_FAILED_PRECONDITION, "batcher already running");
-    h->mb_max_items = max_items ? max_items : 4096;
-    h->mb_wait_us = max_wait_us;
-    h->batcher_stop = false;
-    h->batcher = std::thread(batcher_loop, h);
-    h->batcher_on = true;
+    std::lock_guard<std::mutex> lk(h->batcher_mu);
+    acl_engine::Batcher &B = *h->batcher;
+    std::lock_guard<std::mutex> g(B.mu);
+    if (!B.threads.empty()) return fail(ACL_ERR_FAILED_PRECONDITION, "batcher already running");
+    B.max_items = max_items ? max_items : 4096;
+    B.wait_us = max_wait_us;
+    B.cores = std::max(1u, std::thread::hardware_concurrency());
+    B.stop = false;
+    // one dispatcher per evaluation context the engine may open (store-only engines: one, it only reports the error)
+    const uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>(h->max_ctx, 4));
+    for (uint32_t i = 0; i < nd; i++) B.threads.emplace_back(dispatcher_loop, h);
     return ACL_OK;
 }
 
 int acl_batcher_stop(acl_engine_t *h) {
+    std::lock_guard<std::mutex> lk(h->batcher_mu);
+    if (!h->batcher) return ACL_OK;
+    acl_engine::Batcher &B = *h->batcher;
+    std::vector<std::thread> threads;
     {
-        std::lock_guard<std::mutex> lk(h->q_mu);
-        if (!h->batcher_on) return ACL_OK;
-        h->batcher_stop = true;
+        std::lock_guard<std::mutex> g(B.mu);
+        if (B.threads.empty()) return ACL_OK;
+        B.stop = true;  // enqueue() refuses from here on: callers fall back to passes of their own
+        threads.swap(B.threads);
     }
-    h->q_cv.notify_all();
-    h->batcher.join();
-    std::lock_guard<std::mutex> lk(h->q_mu);
-    h->batcher_on = false;
+    B.cv.notify_all();
+    for (auto &t : threads) t.join();  // dispatchers leave only when nothing is queued
     return ACL_OK;
 }
 
 int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items) {
-    std::lock_guard<std::mutex> lk(h->q_mu);
-    if (batches) *batches = h->mb_batches;
-    if (items) *items = h->mb_items;
+    std::lock_guard<std::mutex> lk(h->batcher_mu);
+    if (batches) *batches = h->batcher->batches.load();
+    if (items) *items = h->batcher->items.load();
     return ACL_OK;
 }
 
 int acl_batcher_lookup_stats(acl_engine_t *h, uint64_t *walks, uint64_t *lookups) {
-    std::lock_guard<std::mutex> lk(h->q_mu);
-    if (walks) *walks = h->mb_lookup_walks;
-    if (lookups) *lookups = h->mb_lookups;
+    std::lock_guard<std::mutex> lk(h->batcher_mu);
+    if (walks) *walks = h->batcher->lookup_walks.load();
+    if (lookups) *lookups = h->batcher->lookups.load();
     return ACL_OK;
 }
 
 // One LookupResources request (lookups.go:65; one per list request, issued from its own goroutine: responsefilterer.go:165).
 // While the batcher runs, concurrent requests for the same (resource type, permission, subject class) share ONE batched
-// reverse walk.  Blocks until answered; bitmap_out as for acl_lookup_resources.
+// reverse walk.  Blocks until answered, cancelled or timed out; bitmap_out as for acl_lookup_resources.
+int acl_lookup_one_opts(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
+                        size_t bitmap_words, uint64_t *count_out, const acl_call_opts_t *o) {
+    if (!bitmap_out && bitmap_words) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_one: NULL bitmap");
+    const CallOpts opts = to_opts(o);
+    int rt, pm, st, sr;
+    uint32_t sub;
+    int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &rt, &pm, &st, &sr, &sub);
+    if (rc) return rc;
+    return lookup_one_routed(h, rt, pm, st, sr, sub, bitmap_out, bitmap_words, count_out, opts);
+}
 int acl_lookup_one(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
                    size_t bitmap_words, uint64_t *count_out) {
-    if (!bitmap_out && bitmap_words) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_lookup_one: NULL bitmap");
-    acl_engine::Waiter w;
-    w.kind = 1;
-    int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &w.lk_rtype, &w.lk_perm, &w.lk_stype, &w.lk_srel, &w.lk_sid);
-    if (rc) return rc;
-    w.lk_bitmap = bitmap_out;
-    w.lk_words = bitmap_words;
-    {
-        std::unique_lock<std::mutex> lk(h->q_mu);
-        if (h->batcher_on && !h->batcher_stop) {
-            h->queue.push_back(&w);
-            if (h->queue.size() == 1 || h->queue.size() >= h->mb_max_items) h->q_cv.notify_one();
-            w.cv.wait(lk, [&] { return w.done; });
-            if (w.rc) return fail(w.rc, w.msg);
-            if (count_out) *count_out = w.lk_count;
-            return ACL_OK;
-        }
-    }
-    return acl_lookup_resources_batch(h, w.lk_rtype, w.lk_perm, w.lk_stype, w.lk_srel, &w.lk_sid, 1, bitmap_out, bitmap_words, count_out);
+    return acl_lookup_one_opts(h, rtype, perm, stype, sid, srel, bitmap_out, bitmap_words, count_out, nullptr);
 }
 
 // CheckPermission (watch.go:50) / a 1-item CheckBulkPermissions (check.go:23-48).  Blocks until answered.
-int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out) {
+int acl_check_one_opts(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o) {
     if (!item || !perm_out || !err_out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_one: NULL argument");
-    acl_engine::Waiter w;
+    acl_item_t it;
     {
         std::shared_lock<std::shared_mutex> nlk(h->names_mu);  // string -> id reads only: callers do not serialise on the engine
         if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
         *perm_out = ACL_PERM_UNSPECIFIED;
-        *err_out = intern_check_item(h, *item, &w.item);
+        *err_out = intern_check_item(h, *item, &it);
         if (*err_out) return ACL_OK;
     }
-    {
-        std::unique_lock<std::mutex> lk(h->q_mu);
-        if (h->batcher_on && !h->batcher_stop) {
-            h->queue.push_back(&w);
-            if (h->queue.size() == 1 || h->queue.size() >= h->mb_max_items) h->q_cv.notify_one();  // only the batcher waits on q_cv
-            w.cv.wait(lk, [&] { return w.done; });
-            if (w.rc) return fail(w.rc, w.msg);
-            *perm_out = w.perm;
-            *err_out = w.err;
-            return ACL_OK;
+    const CallOpts opts = to_opts(o);
+    size_t idx = 0;
+    Batch *b = enqueue(h, &it, nullptr, &idx);
+    if (!b) return acl_check_bulk_ids_opts(h, &it, 1, perm_out, err_out, o);  // no batcher: a device pass of its own
+    int rc = await_batch(h, b, opts);
+    if (rc == ACL_OK) {
+        if (b->rc) rc = fail(b->rc, b->msg);
+        else {
+            *perm_out = b->perm[idx];
+            *err_out = b->err[idx];
         }
     }
-    return acl_check_bulk_ids(h, &w.item, 1, perm_out, err_out);  // no batcher: a device pass of its own
+    b->unref();
+    return rc;
+}
+int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out) {
+    return acl_check_one_opts(h, item, perm_out, err_out, nullptr);
 }
 
 }  // extern "C"
-

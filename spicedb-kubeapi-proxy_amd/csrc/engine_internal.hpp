@@ -1,19 +1,36 @@
 // engine_internal.hpp -- shared by the translation units behind the C ABI (engine.cpp: core + Check/Filter,
-// engine_shard.cpp: acl_shard_*, engine_callers.cpp: keep mask / bitmap test / watch / micro-batcher).
+// engine_shard.cpp: acl_shard_*, engine_callers.cpp: keep mask / bitmap test / watch / micro-batcher,
+// engine_async.cpp: submit/wait + pinned host buffers).
+//
+// Threading model (the seam is called from arbitrary goroutines: reference pkg/authz/check.go:77-93,
+// responsefilterer.go:165, watch.go:50):
+//   state_mu  writer-preferring RW lock over the relationship store AND the snapshot (host copy + device arrays).
+//             Evaluations (Check / LookupResources) hold it SHARED for the whole call; writes and snapshot
+//             maintenance (patch / rebuild / upload) hold it EXCLUSIVE -- so a patch never overwrites rows a kernel reads.
+//   names_mu  schema + object-name tables.  string -> id lookups take it shared (and nothing else: callers of the string
+//             entry points intern in parallel, outside any evaluation lock); whatever adds names takes it exclusive
+//             while holding state_mu (shared or exclusive).  Lock order: state_mu, then names_mu.
+//   PassCtx   everything ONE in-flight evaluation needs on the device: its own stream, frontier buffers, status block,
+//             per-batch scratch, pinned staging.  A pool of them lets concurrent callers overlap: while one call waits
+//             for its level burst, another's H2D copy, kernels or D2H copy run (verdict r1: one engine-wide mutex
+//             serialised everything).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
-#include <thread>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aclgpu.h"
@@ -24,7 +41,6 @@
 using namespace acl;
 
 namespace aclint {
-
 
 extern thread_local std::string g_last_error;  // engine.cpp
 
@@ -40,15 +56,45 @@ inline int fail(const Status &s) { return fail(s.code, s.msg); }
         if (e_ != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// pthread rwlock with writer preference: a WriteRelationships must not starve behind a stream of Checks
+// (glibc's default policy prefers readers; std::shared_mutex cannot select another one)
+class RwLock {
+  public:
+    RwLock() {
+        pthread_rwlockattr_t a;
+        pthread_rwlockattr_init(&a);
+        pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
+        pthread_rwlock_init(&l_, &a);
+        pthread_rwlockattr_destroy(&a);
+    }
+    ~RwLock() { pthread_rwlock_destroy(&l_); }
+    RwLock(const RwLock &) = delete;
+    RwLock &operator=(const RwLock &) = delete;
+    void lock() { pthread_rwlock_wrlock(&l_); }
+    void unlock() { pthread_rwlock_unlock(&l_); }
+    void lock_shared() { pthread_rwlock_rdlock(&l_); }
+    void unlock_shared() { pthread_rwlock_unlock(&l_); }
+
+  private:
+    pthread_rwlock_t l_;
+};
+
 template <typename T>
 struct DevArray {
     T *p = nullptr;
     size_t n = 0;
+    DevArray() = default;
+    DevArray(const DevArray &) = delete;
+    DevArray &operator=(const DevArray &) = delete;
     ~DevArray() { release(); }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+    }
+    void swap(DevArray &o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
     }
     hipError_t ensure(size_t count) {  // grow-only, contents discarded
         if (count <= n && p) return hipSuccess;
@@ -71,111 +117,207 @@ struct DevArray {
     }
 };
 
+// pinned host staging (grow-only)
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= n && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 64), hipHostMallocDefault);
+        if (e == hipSuccess) n = bytes;
+        return e;
+    }
+};
 
-}  // namespace aclint
-using namespace aclint;
+// per-call cancellation / deadline (reference: LookupResources runs on the HTTP request's ctx and is abandoned when it is
+// cancelled, responsefilterer.go:165-170; the prefilter join times out after 10 s, responsefilterer.go:44,196-204)
+struct CallOpts {
+    const volatile int32_t *cancel = nullptr;  // *cancel != 0: abandon the call
+    int64_t deadline_ns = 0;                   // CLOCK_MONOTONIC nanoseconds; 0 = none
+};
+int64_t mono_ns();
+// ACL_OK, ACL_ERR_CANCELLED or ACL_ERR_DEADLINE_EXCEEDED
+int check_opts(const CallOpts &o);
 
-struct acl_engine {
-    std::mutex mu;             // device state, snapshot, relationship tables
-    std::shared_mutex names_mu;  // schema + object-name tables: shared by the callers of acl_check_one (string -> id only reads them),
-                                 // exclusive (together with mu, taken after it) for everything that can add names or reload the schema
-    Store store;
-    Snapshot snap;
-    ShardSpec shard;  // world > 1: this engine holds one shard of the graph and only the acl_shard_* entry points evaluate
-    bool snap_valid = false, rev_uploaded = false;
-    int device = 0;
-    bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
+// Device state of ONE in-flight evaluation.
+struct PassCtx {
+    int index = 0;
     hipStream_t stream = nullptr;
-    int grid_blocks = 2048;
-    // forward graph
-    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
-    DevArray<FwdOp> d_ops;
-    DevArray<SlotProg> d_progs;
-    // reverse graph
-    DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj, d_visited;
-    DevArray<RevOp> d_rops;
-    DevArray<RevProg> d_rprogs, d_rseeds;
     // frontier
     DevArray<uint4> d_fbuf[2];
-    DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow
+    DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow | export counters
     uint64_t frontier_entries = 0;
     uint32_t max_chunks = 0;
     uint32_t *h_status = nullptr;  // pinned
     // batch scratch
-    DevArray<uint8_t> d_has, d_err, d_perm;
+    DevArray<uint8_t> d_has, d_err, d_perm, d_keep;
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
-    uint32_t max_sub_batch = 1u << 20;
+    DevArray<uint32_t> d_itemoff, d_sids, d_visited;
+    PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     uint32_t levels_hint = 6;
-    uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
-    size_t lk_n = 0;
-    DevArray<uint32_t> d_itemoff, d_sids;
-    DevArray<uint8_t> d_keep;
-    // micro-batching front-end (acl_check_one): concurrent single checks ride one device pass
-    struct Waiter {
-        int kind = 0;  // 0: one Check item; 1: one LookupResources request
-        acl_item_t item;
-        uint8_t perm = 0;
-        int32_t err = 0;
-        int lk_rtype = 0, lk_perm = 0, lk_stype = 0, lk_srel = -1;  // kind 1
-        uint32_t lk_sid = 0;
-        uint32_t *lk_bitmap = nullptr;
-        size_t lk_words = 0;
-        uint64_t lk_count = 0;
-        int rc = 0;
-        std::string msg;
-        bool done = false;
-        std::condition_variable cv;  // own wake-up: a finished batch does not stampede every parked caller
-    };
-    std::mutex q_mu;
-    std::condition_variable q_cv;
-    std::vector<Waiter *> queue;
-    std::thread batcher;
-    bool batcher_on = false, batcher_stop = false;
-    uint32_t mb_max_items = 4096, mb_wait_us = 200;
-    uint64_t mb_batches = 0, mb_items = 0, mb_lookup_walks = 0, mb_lookups = 0;
-    // measurement
+    CallOpts opts;  // of the call that holds this context
+    // measurement (merged into the engine's stats when the context is released)
     acl_stats_t stats{};
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs
     size_t ev_used = 0;
     std::vector<int> ev_kind;  // per pair: 0 other, 1 expand
 
+    ~PassCtx();
+};
+
+}  // namespace aclint
+using namespace aclint;
+
+struct AsyncPool;  // engine_async.cpp
+
+struct acl_engine {
+    RwLock state_mu;             // store + snapshot (see the header comment)
+    std::shared_mutex names_mu;  // schema + object-name tables
+    Store store;
+    Snapshot snap;
+    ShardSpec shard;  // world > 1: this engine holds one shard of the graph and only the acl_shard_* entry points evaluate
+    // snap_valid: the HOST snapshot matches `snap.revision`; dev_valid: the device arrays hold exactly the host snapshot.
+    // Both are cleared before the snapshot is touched and set again only after every upload succeeded (advice r1: a failed
+    // upload used to leave a "valid" snapshot behind).
+    bool snap_valid = false, dev_valid = false, rev_uploaded = false;
+    int device = 0;
+    bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
+    hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
+    int grid_blocks = 2048;
+    uint64_t cfg_frontier_entries = 0;
+    // forward graph
+    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
+    DevArray<FwdOp> d_ops;
+    DevArray<SlotProg> d_progs;
+    // reverse graph
+    DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj;
+    DevArray<RevOp> d_rops;
+    DevArray<RevProg> d_rprogs, d_rseeds;
+    // evaluation contexts
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    std::vector<std::unique_ptr<PassCtx>> ctxs;  // created lazily up to max_ctx
+    std::vector<PassCtx *> free_ctxs;
+    uint32_t max_ctx = 4;
+    std::unique_ptr<PassCtx> shard_ctx;  // the acl_shard_* protocol keeps state across calls: its own context, never pooled
+    std::mutex shard_mu;
+    uint32_t max_sub_batch = 1u << 20;
+    uint32_t local_max_items = 8192;  // batches up to this size take the single-launch path (k_check_local); 0 = never
+    uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
+    size_t lk_n = 0;
+    // micro-batching front-end (engine_callers.cpp)
+    struct Batcher;
+    Batcher *batcher = nullptr;  // lives from acl_open to acl_close (batcher_create / batcher_destroy); start / stop only toggle its threads
+    std::mutex batcher_mu;       // start / stop
+    // async submit / wait (engine_async.cpp)
+    AsyncPool *async = nullptr;  // created by the first submit, destroyed by async_shutdown
+    std::mutex async_mu;
+    // pinned buffers handed out by acl_host_alloc: [base, base + bytes)
+    std::mutex pinned_mu;
+    std::vector<std::pair<uintptr_t, size_t>> pinned;
+    // measurement
+    std::mutex stats_mu;
+    acl_stats_t stats{};
+    std::atomic<bool> timing{false};
+
+
     DevGraph dev_graph() const {
         return DevGraph{d_meta.p, d_edges.p, d_buckets.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
     }
-    DevFrontier dev_frontier() const {
+    DevFrontier dev_frontier(const PassCtx &c) const {
         DevFrontier f;
-        f.buf[0] = d_fbuf[0].p;
-        f.buf[1] = d_fbuf[1].p;
-        f.counts[0] = d_fcounts[0].p;
-        f.counts[1] = d_fcounts[1].p;
-        f.nchunks = d_status.p;
-        f.any = d_status.p + kLevelSlots;
-        f.overflow = d_status.p + 2 * kLevelSlots;  // [+1]: the level's export counter (sharded graph)
+        f.buf[0] = c.d_fbuf[0].p;
+        f.buf[1] = c.d_fbuf[1].p;
+        f.counts[0] = c.d_fcounts[0].p;
+        f.counts[1] = c.d_fcounts[1].p;
+        f.nchunks = c.d_status.p;
+        f.any = c.d_status.p + kLevelSlots;
+        f.overflow = c.d_status.p + 2 * kLevelSlots;  // [+1]: the level's export counter (sharded graph)
         f.nwaves = (uint32_t)grid_blocks * kWavesPerBlock;
-        f.max_chunks = max_chunks;
+        f.max_chunks = c.max_chunks;
         return f;
     }
+    bool is_pinned(const void *p, size_t bytes);
 };
 
 namespace aclint {
 
-int alloc_frontier(acl_engine *h, uint64_t entries);
-void ev_begin(acl_engine *h, int kind);
-void ev_end(acl_engine *h);
-void ev_collect(acl_engine *h);  // stream must be synchronized
+int alloc_frontier(acl_engine *h, PassCtx *c, uint64_t entries);
+void ev_begin(PassCtx *c, int kind);
+void ev_end(PassCtx *c);
+void ev_collect(PassCtx *c);  // stream must be synchronized
+// snapshot maintenance; caller holds state_mu EXCLUSIVE
 int ensure_snapshot(acl_engine *h);
 int ensure_reverse(acl_engine *h);
-int check_pass(acl_engine *h, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
+// true when the device snapshot answers for the store as it is now (caller holds state_mu at least shared)
+bool snapshot_current(acl_engine *h, bool need_reverse);
+
+// RAII for one evaluating call: state_mu shared (snapshot brought up to date first) + a PassCtx from the pool.
+struct Eval {
+    acl_engine *h = nullptr;
+    PassCtx *c = nullptr;
+    bool locked = false;
+    Eval() = default;
+    Eval(const Eval &) = delete;
+    Eval &operator=(const Eval &) = delete;
+    ~Eval() { end(); }
+    // rev_key_slot >= 0: the lookup's subject is `type#relation` of that slot -- the reverse rows must cover its id space
+    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1);
+    void end();
+};
+
+// one call of the acl_shard_* step protocol (engine_shard.cpp): shard_mu + state_mu shared + the shard's own context
+struct ShardCall {
+    acl_engine *h = nullptr;
+    PassCtx *c = nullptr;
+    bool locked = false, have_mu = false;
+    ShardCall() = default;
+    ShardCall(const ShardCall &) = delete;
+    ShardCall &operator=(const ShardCall &) = delete;
+    ~ShardCall();
+    int begin(acl_engine *h_, bool fresh, bool need_reverse);
+};
+DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap);
+int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index);
+void merge_stats(acl_engine *h, PassCtx *c);
+
+int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
+// every level in ONE launch, wave-private frontiers; ACL_ERR_RESOURCE_EXHAUSTED when a wave's private frontier overflowed
+int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
 int not_sharded(acl_engine *h);
-int check_device(acl_engine *h, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout);
+int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout);
+// host items -> answers in host buffers through context c (pinned staging unless the caller's buffers are pinned)
+int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
+int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
+                 uint64_t *counts);
 bool empty(const char *s);
 FilterText to_filter(const acl_filter_t *f);
-// strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55)
+// strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55).  Caller holds names_mu shared.
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
+// many items: split over host threads when the batch is large
+void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
+int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
+                      uint64_t *counts, const CallOpts &opts);
+int lookup_one_routed(acl_engine_t *h, int rt, int pm, int st, int sr, uint32_t sub, uint32_t *bitmap_out, size_t words, uint64_t *count_out,
+                      const CallOpts &opts);
+void async_shutdown(acl_engine_t *h);
+void batcher_create(acl_engine_t *h);
+void batcher_destroy(acl_engine_t *h);  // after acl_batcher_stop
+int lookup_opts_call(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
+                     size_t bitmap_words, uint64_t *count_out, const CallOpts &opts);
 
 // Runs iterations 1.. of a level loop until the frontier is empty.  `launch(iter)` enqueues
 // one expansion.  Returns ACL_OK, or ACL_ERR_RESOURCE_EXHAUSTED when the frontier overflowed.
@@ -183,34 +325,44 @@ int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const c
 // (the common case -- the burst is sized by the previous batch's depth) the batch's epilogue has already run by the time
 // the status read-back completes, instead of costing another launch + sync round trip; when it did not, the epilogue
 // simply runs again after the next burst (it only reads the final has/err).
+// Cancellation / deadline (PassCtx::opts) is honoured between bursts.
 template <typename F, typename T>
-int level_loop(acl_engine *h, uint32_t max_iter, F launch, uint32_t *levels_out, T tail) {
-    uint32_t next = 1, burst = std::max<uint32_t>(h->levels_hint, 2);
+int level_loop(acl_engine *h, PassCtx *c, uint32_t max_iter, F launch, uint32_t *levels_out, T tail) {
+    const bool watched = c->opts.cancel || c->opts.deadline_ns;
+    uint32_t next = 1, burst = std::max<uint32_t>(c->levels_hint, 2);
+    if (watched) burst = std::min<uint32_t>(burst, 2);  // a watched call learns about its cancellation every two levels
     for (;;) {
+        if (watched) {
+            int rc = check_opts(c->opts);
+            if (rc) {
+                (void)hipStreamSynchronize(c->stream);
+                return rc;
+            }
+        }
         uint32_t last = std::min(max_iter, next + burst - 1);
         for (uint32_t it = next; it <= last; it++) {
-            ev_begin(h, 1);
+            ev_begin(c, 1);
             launch(it);
-            ev_end(h);
-            h->stats.expand_launches++;
+            ev_end(c);
+            c->stats.expand_launches++;
         }
         tail();
-        HIP_TRY(hipMemcpyAsync(h->h_status, h->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        ev_collect(h);
-        if (h->h_status[2 * kLevelSlots] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
-        if (h->h_status[2 * kLevelSlots]) return ACL_ERR_RESOURCE_EXHAUSTED;
+        HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status.p, kStatusWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ev_collect(c);
+        if (c->h_status[2 * kLevelSlots] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+        if (c->h_status[2 * kLevelSlots]) return ACL_ERR_RESOURCE_EXHAUSTED;
         uint32_t done_at = 0;
         for (uint32_t it = next; it <= last; it++)
-            if (h->h_status[kLevelSlots + it] == 0) { done_at = it; break; }  // any[it]: iteration `it` produced nothing
+            if (c->h_status[kLevelSlots + it] == 0) { done_at = it; break; }  // any[it]: iteration `it` produced nothing
         if (done_at || last == max_iter) {
             uint32_t lv = done_at ? done_at : max_iter;
-            for (uint32_t it = 0; it < lv; it++) h->stats.frontier_entries += (uint64_t)h->h_status[it] * kChunk;  // dynamic chunks only (lower bound)
+            for (uint32_t it = 0; it < lv; it++) c->stats.frontier_entries += (uint64_t)c->h_status[it] * kChunk;  // dynamic chunks only (lower bound)
             *levels_out = lv;
             return ACL_OK;
         }
         next = last + 1;
-        burst = 4;
+        burst = watched ? 2 : 4;
     }
 }
 

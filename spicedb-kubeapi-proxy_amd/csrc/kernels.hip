@@ -53,9 +53,18 @@ constexpr int kBlock = kWavesPerBlock * 64;
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
 constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
-constexpr uint32_t kCountMask = 0x3FFFFFFFu;
+constexpr uint32_t kRowSlotShift = 26;          // task: which staged subject row its children probe (flush_simple), 4 bits
+constexpr uint32_t kCountMask = 0x03FFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
 constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
+// LDS-staged subject rows (flush_simple): the hashed row of the request's subject -- the resources it is directly related
+// to -- is copied into LDS once per flush and every child of that request probes it there.  A wave's tasks belong to a
+// handful of requests, so 64 x 3 children per step that used to cost one descriptor gather + two bucket gathers EACH now
+// cost one coalesced row load per distinct subject.
+constexpr uint32_t kRowSlots = 8;      // distinct subjects staged per flush; further ones probe in global memory
+constexpr uint32_t kRowCap = 16;       // buckets (16 B) per staged row; longer rows probe in global memory
+constexpr uint32_t kNoRowSlot = 15;    // task marker: not staged
+constexpr uint32_t kRowGlobal = 0xFFFFFFFFu;  // rnb[] marker: row too long for LDS
 
 // entry meta: slot[0:13) | level[13:19) | probed[19] | subject key[20:32)
 constexpr uint32_t kProbedBit = 1u << 19;
@@ -91,29 +100,48 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // LDS-staged task list of one wave.
 struct TaskLds {
     uint32_t start[kTaskCap];  // first edge (absolute index) -- or the object id for a "self" task
-    uint32_t count[kTaskCap];  // degree (| kSelfBit)
+    uint32_t count[kTaskCap];  // degree (| kSelfBit | kLeafAuthBit | staged row slot << kRowSlotShift)
     uint32_t req[kTaskCap];
     uint32_t meta[kTaskCap];   // child meta
     uint32_t sid[kTaskCap];
     uint32_t scan[64];
+    uint4 rows[kRowSlots][kRowCap];  // staged subject rows (flush_simple)
+    uint32_t rnb[kRowSlots];         // buckets of each staged row; 0 = the subject has no row; kRowGlobal = too long
 };
 
-// Wave-private output cursor.  The wave starts on its static chunk (id = wave index); when that is full it
-// closes it (count store) and takes a dynamic chunk.  All fields wave-uniform.
+// Wave-private output cursor, all fields wave-uniform.
+//   chunked (k_expand, k_rev_expand): the wave starts on its static chunk (id = wave index); when that is full it closes it
+//            (count store) and takes a dynamic chunk from the level's counter;
+//   LOCAL   (k_check_local): a linear wave-private region [cur, cur + cap) of the frontier buffer.
 struct WaveOut {
+    uint4 *buf;
     uint32_t cur, fill, produced;
+    uint32_t *counts, *nchunks, *overflow;
+    uint32_t nwaves, max_chunks, cap;
 };
 
 // room for `need` (<= 64) consecutive entries; returns the first entry index
-__device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane, const DevFrontier &f, uint32_t *out_counts, uint32_t *out_nchunks) {
+template <bool LOCAL>
+__device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane) {
     if (wo.cur == kNoSpace) return kNoSpace;
+    if (LOCAL) {
+        if (wo.fill + need > wo.cap) {
+            if (lane == 0) *wo.overflow = 1u;
+            wo.cur = kNoSpace;
+            return kNoSpace;
+        }
+        const uint32_t base = wo.cur + wo.fill;
+        wo.fill += need;
+        wo.produced += need;
+        return base;
+    }
     if (wo.fill + need > kChunk) {
-        if (lane == 0) out_counts[wo.cur] = wo.fill;
+        if (lane == 0) wo.counts[wo.cur] = wo.fill;
         uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(out_nchunks, 1u);
-        c = uniform(c) + f.nwaves;
-        if (c >= f.max_chunks) {
-            if (lane == 0) *f.overflow = 1u;
+        if (lane == 0) c = atomicAdd(wo.nchunks, 1u);
+        c = uniform(c) + wo.nwaves;
+        if (c >= wo.max_chunks) {
+            if (lane == 0) *wo.overflow = 1u;
             wo.cur = kNoSpace;
             return kNoSpace;
         }
@@ -159,18 +187,12 @@ __device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const Fw
 }
 
 // Row descriptor {start, end} of (object id, sorted class op.k).  Relations with two sorted classes keep both
-// descriptors in one aligned 16 B record, fetched once per state and reused by the state's next op.
-struct RowCache {
-    uint32_t base = 0xFFFFFFFFu;
-    uint4 v;
-};
-__device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, uint32_t id, RowCache &rc) {
+// descriptors in one aligned 16 B record: the state's second op re-reads the same line (an L1 hit) rather than carrying
+// the record in five VGPRs across the expansions -- that cache was what kept the kernel above 96 VGPRs.
+__device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, uint32_t id) {
     if (op.K == 2) {
-        if (rc.base != op.base) {
-            rc.v = reinterpret_cast<const uint4 *>(g.meta)[(op.base >> 1) + id];
-            rc.base = op.base;
-        }
-        return op.k ? make_uint2(rc.v.z, rc.v.w) : make_uint2(rc.v.x, rc.v.y);
+        const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(op.base >> 1) + id];
+        return op.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
     }
     return reinterpret_cast<const uint2 *>(g.meta)[op.base + (size_t)id * op.K + op.k];
 }
@@ -187,7 +209,6 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
     // plain subjects with a known leaf flag only need the probe-only ops
     const uint32_t nops = userset_subject ? p.n_total : (leaf_known ? p.n_probe : p.n_main);
     bool push = leaf_known && !leaf;
-    RowCache rc;
     for (uint32_t j = 0; j < nops; j++) {
         const FwdOp op = ops[p.first + j];
         const uint32_t L = level + op.dlevel;
@@ -202,7 +223,7 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
             const bool probe = (op.flags & OP_PROBE) && key == op.key;
             const bool look = (op.flags & OP_ENUM) && !leaf_known;
             if (probe || look) {
-                const uint2 md = row_meta(g, op, id, rc);
+                const uint2 md = row_meta(g, op, id);
                 if (md.y > md.x) {
                     if (probe) hit |= row_contains(g.edges, md.x, md.y, sid);
                     if (look) push = true;
@@ -226,84 +247,128 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_SIMPLE_WIDTH 3  // A/B on C4 (tools/ab.sh): width 2 380 M/s, 3 398 M/s (5 waves/SIMD); 3 or 4 at 4 waves/SIMD 353-369 M/s
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
-template <bool SHARDED>
-__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
-                                              const DevFrontier &f, uint4 *__restrict__ out, uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has,
-                                              uint8_t *err) {
+// Returns the number of tasks it did NOT expand (their subject's row does not fit an LDS slot: rare), compacted to the front of
+// the task list for the generic path.
+template <bool SHARDED, bool LOCAL>
+__device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+                                                  uint8_t *has, uint8_t *err) {
     const uint32_t *__restrict__ edges = g.edges;
     const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
-    for (uint32_t gq = 0; gq < T; gq += 64) {
-        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
-        const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = uniform(__shfl(incl, 63, 64));
-        t.scan[lane] = incl - cnt;
-        wave_lds_fence();
-        for (uint32_t w0 = 0; w0 < total; w0 += 64 * kSimpleWidth) {
-            bool valid[kSimpleWidth];
-            uint32_t tj[kSimpleWidth], eaddr[kSimpleWidth];
-#pragma unroll
-            for (int k = 0; k < kSimpleWidth; k++) {
-                const uint32_t w = w0 + 64u * k + lane;
-                valid[k] = w < total;
-                const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
-                uint32_t j = 0;
-#pragma unroll
-                for (uint32_t step = 32; step >= 1; step >>= 1)
-                    if (t.scan[j + step] <= wv) j += step;
-                tj[k] = gq + j;
-                eaddr[k] = t.start[tj[k]] + (wv - t.scan[j]);
-            }
-            uint32_t edge[kSimpleWidth], sid[kSimpleWidth], req[kSimpleWidth], meta[kSimpleWidth];
-#pragma unroll
-            for (int k = 0; k < kSimpleWidth; k++) {
-                edge[k] = edges[eaddr[k]];
-                sid[k] = t.sid[tj[k]];
-                req[k] = t.req[tj[k]];
-                meta[k] = t.meta[tj[k]];
-            }
-            uint2 d[kSimpleWidth];
-            bool row[kSimpleWidth];
-#pragma unroll
-            for (int k = 0; k < kSimpleWidth; k++) {
-                row[k] = sid[k] < pop.nrows;
-                d[k] = smeta[pop.base + (row[k] ? sid[k] : 0u)];
-                row[k] = row[k] && d[k].y > d[k].x;
-            }
-            uint4 p[kSimpleWidth], q[kSimpleWidth];
-            uint32_t child[kSimpleWidth];
-#pragma unroll
-            for (int k = 0; k < kSimpleWidth; k++) {
-                child[k] = edge[k] & kIdMask;
-                const uint32_t b0 = row[k] ? d[k].x : 0u, nb = row[k] ? d[k].y - d[k].x : 1u;
-                uint32_t h1, h2;
-                hashed_row_buckets(child[k], nb, &h1, &h2);
-                p[k] = buckets[b0 + h1];
-                q[k] = buckets[b0 + h2];
-            }
-#pragma unroll
-            for (int k = 0; k < kSimpleWidth; k++) {
-                const uint32_t c = child[k];
-                const bool contains = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
-                const uint32_t level = meta_level(meta[k]);
-                const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
-                const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
-                bool push = valid[k] && !(edge[k] & kLeafBit);
-                if (hit) {
-                    has[req[k]] = 1;
-                    push = false;
-                } else if (derr) {
-                    err[req[k]] = ITEM_ERR_DEPTH;
-                }
-                const uint64_t b = __ballot(push);
-                if (b) {
-                    const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
-                    if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(c, req[k], meta[k] | kProbedBit, sid[k]);
-                }
+    uint4 *__restrict__ out = wo.buf;
+    // task i is looked after by lane i (A half) or lane i - 64 (B half)
+    const bool inA = lane < T, inB = lane + 64 < T;
+    const uint32_t sidA = inA ? t.sid[lane] : 0u, sidB = inB ? t.sid[lane + 64] : 0u;
+    uint64_t todoA = __ballot(inA), todoB = __ballot(inB);  // tasks not expanded yet
+    uint64_t leftA = 0, leftB = 0;                          // tasks left to the generic path
+    // Rounds: each stages the hashed rows of up to kRowSlots distinct subjects in LDS and expands the tasks of those subjects.
+    // A wave's tasks belong to a handful of requests (children of one request are neighbours in the frontier): usually one round.
+    while (todoA | todoB) {
+        uint32_t slotA = kNoRowSlot, slotB = kNoRowSlot, mysid = 0, ns = 0;
+        {
+            uint64_t pa = todoA, pb = todoB;
+            while ((pa | pb) && ns < kRowSlots) {
+                const uint32_t s0 = pa ? (uint32_t)__builtin_amdgcn_readlane((int)sidA, __ffsll((unsigned long long)pa) - 1)
+                                       : (uint32_t)__builtin_amdgcn_readlane((int)sidB, __ffsll((unsigned long long)pb) - 1);
+                const bool mA = ((pa >> lane) & 1ull) && sidA == s0, mB = ((pb >> lane) & 1ull) && sidB == s0;
+                if (mA) slotA = ns;
+                if (mB) slotB = ns;
+                pa &= ~__ballot(mA);
+                pb &= ~__ballot(mB);
+                if (lane == ns) mysid = s0;
+                ns++;
             }
         }
-        wave_lds_fence();
+        // trip 1: the subjects' row descriptors (lane k holds subject k)
+        const bool own = lane < ns && mysid < pop.nrows;
+        uint2 d = smeta[pop.base + (own ? mysid : 0u)];
+        if (!own) d = make_uint2(0, 0);
+        const uint32_t nb = d.y > d.x ? d.y - d.x : 0u;
+        if (lane < ns) t.rnb[lane] = nb;
+        // trip 2: the rows themselves, four subjects per load instruction (16 lanes x 16 B each, coalesced)
+#pragma unroll
+        for (uint32_t pass = 0; pass < kRowSlots / 4; pass++) {
+            const uint32_t k = pass * 4 + (lane >> 4), i = lane & 15u;
+            const uint32_t b0 = (uint32_t)__shfl((int)d.x, (int)k, 64), n = (uint32_t)__shfl((int)nb, (int)k, 64);
+            const bool ld = k < ns && n <= kRowCap && i < n;
+            const uint4 v = buckets[ld ? b0 + i : 0u];
+            if (ld) t.rows[k][i] = v;
+        }
+        // this round's tasks; the ones whose row is too long for a slot go to the generic path
+        const uint32_t nbA = (uint32_t)__shfl((int)nb, (int)(slotA & 7u), 64), nbB = (uint32_t)__shfl((int)nb, (int)(slotB & 7u), 64);
+        const bool asgA = slotA != kNoRowSlot, asgB = slotB != kNoRowSlot;
+        const bool actA = asgA && nbA <= kRowCap, actB = asgB && nbB <= kRowCap;
+        leftA |= __ballot(asgA && !actA);
+        leftB |= __ballot(asgB && !actB);
+        todoA &= ~__ballot(asgA);
+        todoB &= ~__ballot(asgB);
+        if (actA) t.count[lane] = (t.count[lane] & ~(15u << kRowSlotShift)) | (slotA << kRowSlotShift);
+        if (actB) t.count[lane + 64] = (t.count[lane + 64] & ~(15u << kRowSlotShift)) | (slotB << kRowSlotShift);
+        for (uint32_t gq = 0; gq < T; gq += 64) {
+            const bool act = gq ? actB : actA;
+            const uint32_t cnt = act ? (t.count[gq + lane] & kCountMask) : 0u;
+            const uint32_t incl = wave_incl_scan(cnt, lane);
+            const uint32_t total = uniform(__shfl(incl, 63, 64));
+            if (!total) continue;
+            t.scan[lane] = incl - cnt;
+            wave_lds_fence();
+            for (uint32_t w0 = 0; w0 < total; w0 += 64 * kSimpleWidth) {
+                bool valid[kSimpleWidth];
+                uint32_t tj[kSimpleWidth], edge[kSimpleWidth];
+#pragma unroll
+                for (int k = 0; k < kSimpleWidth; k++) {
+                    const uint32_t w = w0 + 64u * k + lane;
+                    valid[k] = w < total;
+                    const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+                    uint32_t j = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step >= 1; step >>= 1)
+                        if (t.scan[j + step] <= wv) j += step;
+                    tj[k] = gq + j;
+                    edge[k] = edges[t.start[tj[k]] + (wv - t.scan[j])];
+                }
+#pragma unroll
+                for (int k = 0; k < kSimpleWidth; k++) {  // the subject's row is in LDS: two 16 B LDS reads per child
+                    const uint32_t c = edge[k] & kIdMask;
+                    const uint32_t rs = (t.count[tj[k]] >> kRowSlotShift) & 7u;
+                    const uint32_t rnb = t.rnb[rs];
+                    uint32_t h1, h2;
+                    hashed_row_buckets(c, rnb ? rnb : 1u, &h1, &h2);
+                    const uint4 p = t.rows[rs][rnb ? h1 : 0u], q = t.rows[rs][rnb ? h2 : 0u];
+                    const bool contains = rnb && (p.x == c || p.y == c || p.z == c || p.w == c || q.x == c || q.y == c || q.z == c || q.w == c);
+                    const uint32_t req = t.req[tj[k]], meta = t.meta[tj[k]];
+                    const uint32_t level = meta_level(meta);
+                    const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
+                    const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
+                    bool push = valid[k] && !(edge[k] & kLeafBit);
+                    if (hit) {
+                        has[req] = 1;
+                        push = false;
+                    } else if (derr) {
+                        err[req] = ITEM_ERR_DEPTH;
+                    }
+                    const uint64_t b = __ballot(push);
+                    if (b) {
+                        const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
+                        if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(c, req, meta | kProbedBit, t.sid[tj[k]]);
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
     }
+    if (!(leftA | leftB)) return 0u;
+    // compact the leftover tasks to the front of the list
+    uint32_t f0[5] = {0, 0, 0, 0, 0}, f1[5] = {0, 0, 0, 0, 0};
+    const bool la = (leftA >> lane) & 1ull, lb = (leftB >> lane) & 1ull;
+    if (la) { f0[0] = t.start[lane]; f0[1] = t.count[lane]; f0[2] = t.req[lane]; f0[3] = t.meta[lane]; f0[4] = t.sid[lane]; }
+    if (lb) { f1[0] = t.start[lane + 64]; f1[1] = t.count[lane + 64]; f1[2] = t.req[lane + 64]; f1[3] = t.meta[lane + 64]; f1[4] = t.sid[lane + 64]; }
+    wave_lds_fence();
+    const uint32_t na = (uint32_t)__popcll(leftA);
+    if (la) { const uint32_t q = lanes_below(leftA); t.start[q] = f0[0]; t.count[q] = f0[1] & ~(15u << kRowSlotShift); t.req[q] = f0[2]; t.meta[q] = f0[3]; t.sid[q] = f0[4]; }
+    if (lb) { const uint32_t q = na + lanes_below(leftB); t.start[q] = f1[0]; t.count[q] = f1[1] & ~(15u << kRowSlotShift); t.req[q] = f1[2]; t.meta[q] = f1[3]; t.sid[q] = f1[4]; }
+    wave_lds_fence();
+    return na + (uint32_t)__popcll(leftB);
 }
 
 // Second specialised expansion: all tasks lead to one child slot whose program is at most two hashed probes followed by at
@@ -311,10 +376,10 @@ __device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo
 // `namespace#view = viewer + creator + ...`.  One child per lane; the subject's row descriptors (they depend on the request,
 // not on the child) are fetched together with the edge, then every bucket and every row descriptor of the child together:
 // two dependent trips instead of up to six.  Same decisions and output order as the generic path.
-template <bool SHARDED>
+template <bool SHARDED, bool LOCAL>
 __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp *cops,
-                                             uint32_t k0, bool leafauth, const DevFrontier &f, uint4 *__restrict__ out, uint32_t *out_counts,
-                                             uint32_t *out_nchunks, uint8_t *has, uint8_t *err) {
+                                             uint32_t k0, bool leafauth, uint8_t *has, uint8_t *err) {
+    uint4 *__restrict__ out = wo.buf;
     const uint32_t *__restrict__ edges = g.edges;
     const uint2 *__restrict__ meta2 = reinterpret_cast<const uint2 *>(g.meta);
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
@@ -335,7 +400,8 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             for (uint32_t step = 32; step >= 1; step >>= 1)
                 if (t.scan[j + step] <= wv) j += step;
             const uint32_t tj = gq + j;
-            const uint32_t sid = t.sid[tj], req = t.req[tj], meta = t.meta[tj];
+            const uint32_t sid = t.sid[tj];
+            const uint32_t level = meta_level(t.meta[tj]);
             // trip 1: the edge and the subject's row descriptor of every probe
             const uint32_t edge = edges[t.start[tj] + (wv - t.scan[j])];
             uint2 hd[2];
@@ -347,32 +413,37 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                 hd[k] = meta2[(hk ? cops[k].base : 0u) + (hrow[k] ? sid : 0u)];
             }
             const uint32_t child = edge & kIdMask;
-            // trip 2: both buckets of every probe and the child's row descriptor of every enumerate op
-            uint4 bp[2], bq[2];
-            uint2 md[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                hrow[k] = hrow[k] && hd[k].y > hd[k].x;
-                const uint32_t b0 = hrow[k] ? hd[k].x : 0u, nb = hrow[k] ? hd[k].y - hd[k].x : 1u;
+            // trips 2 and 3: both buckets of the first probe, then of the second (two-probe programs only).  One probe's
+            // buckets at a time: four 16 B gathers in flight at once cost 16 VGPRs, which is what pushed this kernel into
+            // scratch at 5 waves/SIMD.
+            bool hit = false, push = leafauth && !(edge & kLeafBit);
+            auto probe = [&](const uint2 &hdk, bool hrk, uint32_t dl) {
+                const bool hr = hrk && hdk.y > hdk.x;
+                const uint32_t b0 = hr ? hdk.x : 0u, nb = hr ? hdk.y - hdk.x : 1u;
                 uint32_t h1, h2;
                 hashed_row_buckets(child, nb, &h1, &h2);
-                bp[k] = buckets[b0 + h1];
-                bq[k] = buckets[b0 + h2];
-                const bool lk = (uint32_t)k < nl;
-                const FwdOp &lo = lops[lk ? k : 0];
-                const bool inrow = lk && child < lo.nrows;
-                md[k] = meta2[lk ? lo.base + (size_t)(inrow ? child : 0u) * lo.K + lo.k : 0u];
-                if (!inrow) md[k] = make_uint2(0, 0);
-            }
-            const uint32_t level = meta_level(meta);
-            bool hit = false, push = leafauth && !(edge & kLeafBit);
+                const uint4 bp = buckets[b0 + h1], bq = buckets[b0 + h2];
+                if (hr && level + dl <= kMaxLevels)
+                    hit = hit || bp.x == child || bp.y == child || bp.z == child || bp.w == child || bq.x == child || bq.y == child || bq.z == child ||
+                          bq.w == child;
+            };
+            if (nh > 0) probe(hd[0], hrow[0], cops[0].dlevel);
+            asm volatile("" ::: "memory");  // keep the second probe's gathers behind the first's (register budget, see above)
+            if (nh > 1) probe(hd[1], hrow[1], cops[1].dlevel);
+            asm volatile("" ::: "memory");
+            // the child's own rows are looked at only where the edge carries no authoritative leaf flag (after a patch
+            // made an op distrust them): one more trip, rare
+            if (nl) {
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (hrow[k] && level + cops[(uint32_t)k < nh ? k : 0].dlevel <= kMaxLevels)
-                    hit = hit || bp[k].x == child || bp[k].y == child || bp[k].z == child || bp[k].w == child || bq[k].x == child ||
-                          bq[k].y == child || bq[k].z == child || bq[k].w == child;
-                if ((uint32_t)k < nl && md[k].y > md[k].x && level + lops[k].dlevel <= kMaxLevels) push = true;
+                for (int k = 0; k < 2; k++) {
+                    const bool lk = (uint32_t)k < nl;
+                    const FwdOp &lo = lops[lk ? k : 0];
+                    const bool inrow = lk && child < lo.nrows;
+                    const uint2 md = meta2[lk ? lo.base + (size_t)(inrow ? child : 0u) * lo.K + lo.k : 0u];
+                    if (inrow && md.y > md.x && level + lo.dlevel <= kMaxLevels) push = true;
+                }
             }
+            const uint32_t req = t.req[tj], meta = t.meta[tj];
             hit = hit && valid;
             push = push && valid;
             if (hit) {
@@ -383,7 +454,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             }
             const uint64_t b = __ballot(push);
             if (b) {
-                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
                 if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(child, req, meta | kProbedBit, sid);
             }
         }
@@ -418,10 +489,10 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
     }
 }
 
-template <bool INLINE, bool SHARDED>
+template <bool INLINE, bool SHARDED, bool LOCAL>
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
-                                            const FwdOp *ops, const uint32_t *__restrict__ edges, const DevFrontier &f, uint4 *__restrict__ out,
-                                            uint32_t *out_counts, uint32_t *out_nchunks, uint8_t *has, uint8_t *err, const DevShard &sh) {
+                                            const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh) {
+    uint4 *__restrict__ out = wo.buf;
     wave_lds_fence();
     if (INLINE) {  // all tasks lead to the same "simple" child state?  (one hashed probe + authoritative leaf flags, plain subject)
         const uint32_t m0 = t.meta[0];
@@ -438,12 +509,14 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             const uint32_t mi = t.meta[i], ci = t.count[i];
             agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
         }
+        bool leftovers = false;
         if (ok && !__ballot(!agree)) {
-            flush_simple<SHARDED>(t, T, wo, lane, g, cp, pop, f, out, out_counts, out_nchunks, has, err);
-            return;
+            T = flush_simple<SHARDED, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
+            if (!T) return;
+            leftovers = true;  // subjects whose rows do not fit LDS: the generic loop below takes them
         }
         // second shape: <= 2 hashed probes + <= 2 enumerate ops that are only looked at; uniform slot, key and leaf authority
-        if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
+        if (!leftovers && k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
             const FwdOp *cops = ops + cp.first;
             bool shape = true;
             for (uint32_t q = 0; q < cp.n_main; q++) {
@@ -457,7 +530,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                 agree2 = agree2 && meta_slot(mi) == cs && meta_key(mi) == k0 && ((ci & kLeafAuthBit) != 0) == la0 && !(ci & kSelfBit);
             }
             if (shape && !__ballot(!agree2)) {
-                flush_probes<SHARDED>(t, T, wo, lane, g, cp, cops, k0, la0, f, out, out_counts, out_nchunks, has, err);
+                flush_probes<SHARDED, LOCAL>(t, T, wo, lane, g, cp, cops, k0, la0, has, err);
                 return;
             }
         }
@@ -520,7 +593,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             }
             const uint64_t b = __ballot(push);
             if (b) {
-                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
                 if (push && base != kNoSpace) out[base + lanes_below(b)] = e;
             }
             if (INLINE && SHARDED) export_entries(xport, e, xport ? progs[meta_slot(e.z)].owner : 0u, lane, sh);
@@ -569,139 +642,98 @@ __global__ __launch_bounds__(256) void k_rev_seed(DevFrontier f, const uint32_t 
 }
 
 // ---------------------------------------------------------------- expand
-template <bool LDSPROG, bool SHARDED>
-__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
-                                                                           DevShard sh) {
-    __shared__ TaskLds lds[kWavesPerBlock];
-    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
-    const SlotProg *progs = g.progs;
-    const FwdOp *ops = g.ops;
-    if (LDSPROG) {  // the whole program table (a few hundred bytes for real schemas) lives in LDS
-        const uint32_t np = g.nslots * 2, no = g.nops * 2;
-        for (uint32_t i = threadIdx.x; i < np; i += kBlock) s_prog[i] = reinterpret_cast<const uint4 *>(g.progs)[i];
-        for (uint32_t i = threadIdx.x; i < no; i += kBlock) s_prog[np + i] = reinterpret_cast<const uint4 *>(g.ops)[i];
-        __syncthreads();
-        progs = reinterpret_cast<const SlotProg *>(s_prog);
-        ops = reinterpret_cast<const FwdOp *>(s_prog + np);
+// One 64-entry segment of the frontier: every lane holds one pending sub-check.  Shared by the level-synchronous kernel
+// (k_expand: segments come from the chunked global frontier) and the single-launch kernel (k_check_local: segments
+// come from the wave's private region).  `next` lets the simple-parent fast path pull the following segment in early:
+//   bool peek(uint4 &e, bool &valid)  loads the next segment's entries if there is one (not consumed yet)
+//   void take()                       consumes it
+template <bool SHARDED, bool LOCAL, typename Next>
+__device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next &next, TaskLds &t, WaveOut &wo, uint32_t lane, const DevGraph &g,
+                                                const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh) {
+    const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
+    // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
+    // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read and
+    // the row-descriptor gather are issued together (branch-free), not one after the other.
+    {
+        const uint64_t vb = __ballot(valid);
+        if (!vb) return;
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
+        const uint32_t cs = meta_slot(m0);
+        bool simple = m0 != kDeadMeta && !__ballot(valid && (meta == kDeadMeta || !(meta & kProbedBit) || meta_slot(meta) != cs || meta_key(meta) < g.nslots));
+        SlotProg sp{};
+        FwdOp sop{};
+        if (simple) {
+            sp = progs[cs];
+            simple = sp.n_main == sp.n_probe + 1;
+            if (simple) {
+                sop = ops[sp.first + sp.n_probe];
+                simple = (sop.flags & OP_ENUM) && !(sop.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH));
+            }
+        }
+        if (simple) {
+            // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
+            auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, bool inrow, uint32_t Tb) -> uint32_t {
+                const bool act = sv && !hv;
+                const uint32_t lv = meta_level(se.z), L = lv + sop.dlevel;
+                bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
+                if (act && L <= kMaxLevels && inrow && md.y > md.x) {
+                    if (L + 1 > kMaxLevels) derr = true;
+                    else if (md.y - md.x > kMaxRow) *wo.overflow = 2u;
+                    else want = true;
+                }
+                if (derr) err[se.y] = ITEM_ERR_DEPTH;
+                const uint64_t b = __ballot(want);
+                if (want) {
+                    const uint32_t q = Tb + lanes_below(b);
+                    t.start[q] = md.x;
+                    t.count[q] = (md.y - md.x) | ((sop.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
+                    t.req[q] = se.y;
+                    t.meta[q] = make_meta(sop.key, L + 1, meta_key(se.z));
+                    t.sid[q] = se.w;
+                }
+                return (uint32_t)__popcll(b);
+            };
+            auto row_desc = [&](uint32_t rid) -> uint2 {
+                if (sop.K == 2) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
+                    return sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
+                }
+                return reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
+            };
+            // segment A's gathers and -- when the wave has another segment pending -- segment B's entries, all in flight together
+            const uint32_t hvA = has[valid ? req : 0u];
+            const bool inA = valid && id < sop.nrows;
+            const uint2 mdA = row_desc(inA ? id : 0u);
+            bool validB = false;
+            uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
+            const bool haveB = next.peek(eB, validB);
+            uint32_t T = seg_tasks(e, valid, hvA, mdA, inA, 0u);
+            if (haveB && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots))) {
+                next.take();  // B is a simple segment of the same slot: taken here
+                const uint32_t hvB = has[validB ? eB.y : 0u];
+                const bool inB = validB && eB.x < sop.nrows;
+                const uint2 mdB = row_desc(inB ? eB.x : 0u);
+                T += seg_tasks(eB, validB, hvB, mdB, inB, T);
+            }
+            if (T) flush_tasks<true, SHARDED, LOCAL>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            return;
+        }
     }
-    const uint32_t lane = lane_id();
-    const uint32_t wib = threadIdx.x >> 6;
-    TaskLds &t = lds[wib];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
-    const uint32_t pin = (iter + 1) & 1u, pout = iter & 1u;  // iteration i reads parity (i-1)&1
-    const uint4 *__restrict__ in = f.buf[pin];
-    const uint32_t *__restrict__ in_counts = f.counts[pin];
-    uint4 *__restrict__ out = f.buf[pout];
-    uint32_t *out_counts = f.counts[pout];
-    uint32_t *out_nchunks = f.nchunks + iter;
-    const bool live = !*f.overflow && f.any[iter - 1];
-    const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
-    WaveOut wo{wave, 0u, 0u};
-    // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
-    // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
-    // (each segment layer is rotated so that one wave does not keep landing on the same chunk).
-    // The fill counts of the wave's next 64 segment slots are fetched by its 64 lanes in ONE gather; the loop then
-    // reads them with readlane -- not one dependent load per slot (most slots are empty: 16+ per wave and level).
-    const uint32_t nslot = C * kSegsPerChunk;
-    for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
-        const uint32_t xl = x0 + lane * nwaves;
-        uint32_t lc = 0, lcnt = 0;
-        if (xl < nslot) {
-            const uint32_t ls = xl / C;
-            lc = (xl % C + ls * 509u) % C;
-            lcnt = in_counts[lc];
-            lcnt = lcnt > ls * 64 ? lcnt - ls * 64 : 0u;  // entries of this slot's segment and beyond
-        }
-        uint64_t work = __ballot(lcnt != 0);
-        while (work) {
-        const int wl = __ffsll((unsigned long long)work) - 1;
-        work &= work - 1;
-        const uint32_t x = x0 + (uint32_t)wl * nwaves;
-        const uint32_t s = x / C, c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
-        const bool valid = s * 64 + lane < cnt;
-        const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
-        const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
-        // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
-        // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read and
-        // the row-descriptor gather are issued together (branch-free), not one after the other.
-        {
-            const uint64_t vb = __ballot(valid);
-            const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
-            const uint32_t cs = meta_slot(m0);
-            bool simple = m0 != kDeadMeta && !__ballot(valid && (meta == kDeadMeta || !(meta & kProbedBit) || meta_slot(meta) != cs || meta_key(meta) < g.nslots));
-            SlotProg sp{};
-            FwdOp sop{};
-            if (simple) {
-                sp = progs[cs];
-                simple = sp.n_main == sp.n_probe + 1;
-                if (simple) {
-                    sop = ops[sp.first + sp.n_probe];
-                    simple = (sop.flags & OP_ENUM) && !(sop.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH));
-                }
-            }
-            if (simple) {
-                // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
-                auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, bool inrow, uint32_t Tb) -> uint32_t {
-                    const bool act = sv && !hv;
-                    const uint32_t lv = meta_level(se.z), L = lv + sop.dlevel;
-                    bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
-                    if (act && L <= kMaxLevels && inrow && md.y > md.x) {
-                        if (L + 1 > kMaxLevels) derr = true;
-                        else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
-                        else want = true;
-                    }
-                    if (derr) err[se.y] = ITEM_ERR_DEPTH;
-                    const uint64_t b = __ballot(want);
-                    if (want) {
-                        const uint32_t q = Tb + lanes_below(b);
-                        t.start[q] = md.x;
-                        t.count[q] = (md.y - md.x) | ((sop.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
-                        t.req[q] = se.y;
-                        t.meta[q] = make_meta(sop.key, L + 1, meta_key(se.z));
-                        t.sid[q] = se.w;
-                    }
-                    return (uint32_t)__popcll(b);
-                };
-                auto row_desc = [&](uint32_t rid) -> uint2 {
-                    if (sop.K == 2) {
-                        const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
-                        return sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
-                    }
-                    return reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
-                };
-                // segment A's gathers and -- when the wave has another slot pending -- segment B's entries, all in flight together
-                const uint32_t hvA = has[valid ? req : 0u];
-                const bool inA = valid && id < sop.nrows;
-                const uint2 mdA = row_desc(inA ? id : 0u);
-                bool validB = false;
-                uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
-                int wlB = -1;
-                if (work) {
-                    wlB = __ffsll((unsigned long long)work) - 1;
-                    const uint32_t xB = x0 + (uint32_t)wlB * nwaves, sB = xB / C;
-                    const uint32_t cB = (uint32_t)__builtin_amdgcn_readlane((int)lc, wlB);
-                    const uint32_t cntB = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wlB) + sB * 64;
-                    validB = sB * 64 + lane < cntB;
-                    if (validB) eB = in[(size_t)cB * kChunk + sB * 64 + lane];
-                }
-                uint32_t T = seg_tasks(e, valid, hvA, mdA, inA, 0u);
-                if (wlB >= 0 && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots))) {
-                    work &= work - 1;  // B is a simple segment of the same slot: taken here
-                    const uint32_t hvB = has[validB ? eB.y : 0u];
-                    const bool inB = validB && eB.x < sop.nrows;
-                    const uint2 mdB = row_desc(inB ? eB.x : 0u);
-                    T += seg_tasks(eB, validB, hvB, mdB, inB, T);
-                }
-                if (T) flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
-                continue;
-            }
-        }
+    // ---- generic path: interpret the state's program.  Tasks are only RECORDED while the ops run (one segment of the LDS
+    // list per enumerating op) and expanded afterwards, segment by segment, when the interpreter's per-lane state is dead:
+    // the expansions (flush_simple / flush_probes) are the register-hungry part and no longer stack on top of it.
+    // (Per-op segments keep the tasks of one flush uniform in child slot, which is what the fast paths need.)
+    constexpr uint32_t kMaxSeg = 4;
+    uint4 ee = e;
+    uint32_t jstart = 0;
+    bool hit = false;
+    for (;;) {
+        // (re)derive everything from the entry: nothing but `ee`, `hit` and `jstart` lives across the expansions below
+        asm volatile("" : "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(ee.w));
+        const uint32_t id = ee.x, req = ee.y, meta = ee.z, sid = ee.w;
         bool active = valid && meta != kDeadMeta;
-        if (active && has[req]) active = false;  // request already answered HAS: drop its pending work
-        if (ACL_PERTURB == 1 && valid) { const uint32_t x = has[req ^ 0x5555u]; ACL_KEEP(x); }
-        if (ACL_PERTURB == 2 && active) { const uint2 x = reinterpret_cast<const uint2 *>(g.meta)[(id * 2654435761u) % (g.nops + 100000u)]; ACL_KEEP(x.x); }
-        if (ACL_PERTURB == 9 && valid) { const uint4 x = in[(size_t)c * kChunk + s * 64 + (lane ^ 1u)]; ACL_KEEP(x.x); }
+        if (active && !jstart && has[req]) active = false;  // request already answered HAS: drop its pending work
+        if (jstart && hit) active = false;
         const uint32_t slot = meta_slot(meta), level = meta_level(meta), key = meta_key(meta);
         const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
         SlotProg p{};
@@ -709,11 +741,10 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
         const uint32_t j0 = probed ? p.n_probe : 0u;
         const uint32_t j1 = active ? ((probed || key >= g.nslots) ? p.n_main : p.n_total) : 0u;
         bool depth_err = active && level + p.max_dlevel > kMaxLevels;
-        bool hit = false;
-        uint32_t T = 0;
-        RowCache rc;
-        const uint32_t maxops = uniform(wave_max(j1 > j0 ? j1 - j0 : 0u));
-        for (uint32_t jj = 0; jj < maxops; jj++) {
+        uint32_t T = 0, nseg = 0, seg_end[kMaxSeg] = {0, 0, 0, 0};
+            const uint32_t maxops = uniform(wave_max(j1 > j0 ? j1 - j0 : 0u));
+        uint32_t jj = jstart;
+        for (; jj < maxops; jj++) {
             const uint32_t j = j0 + jj;
             bool want = false;
             uint32_t tstart = 0, tcount = 0, tmeta = 0;
@@ -734,12 +765,12 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                     } else if (op.flags & OP_PROBE_HASH) {
                         if (key == op.key) hit |= subject_row_contains(g, op, id, sid);
                     } else if (id < op.nrows) {
-                        const uint2 md = row_meta(g, op, id, rc);
+                        const uint2 md = row_meta(g, op, id);
                         if (md.y > md.x) {
                             if ((op.flags & OP_PROBE) && key == op.key) hit |= row_contains(g.edges, md.x, md.y, sid);
                             if (op.flags & OP_ENUM) {
                                 if (L + 1 > kMaxLevels) depth_err = true;
-                                else if (md.y - md.x > kMaxRow) *f.overflow = 2u;
+                                else if (md.y - md.x > kMaxRow) *wo.overflow = 2u;
                                 else if (!hit) {
                                     want = true;
                                     tstart = md.x;
@@ -762,20 +793,243 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                     t.sid[q] = sid;
                 }
                 T += (uint32_t)__popcll(b);
-                if (ACL_FLUSH_PER_OP || T > kTaskCap - 64) {  // per op: the tasks of one flush share the child slot -> flush_simple can take them
-                    flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
-                    T = 0;
+                seg_end[nseg++] = T;
+                if (nseg == kMaxSeg || T > kTaskCap - 64) {  // list (nearly) full: expand what is recorded, then resume with the next op
+                    jj++;
+                    break;
                 }
             }
         }
-        if (hit) has[req] = 1;
-        else if (depth_err) err[req] = ITEM_ERR_DEPTH;
-        if (T) flush_tasks<true, SHARDED>(t, T, wo, lane, g, progs, ops, g.edges, f, out, out_counts, out_nchunks, has, err, sh);
+        jstart = jj;
+        if (active) {
+            if (hit) has[req] = 1;
+            else if (depth_err) err[req] = ITEM_ERR_DEPTH;
+        }
+        const bool more = jstart < maxops;
+        // ---- expand the recorded segments (the interpreter's state is dead from here to the loop's top)
+        uint32_t a = 0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < nseg; k++) {
+            const uint32_t bnd = seg_end[k], cnt = bnd - a;  // cnt <= 64
+            if (a) {  // bring the segment to the front of the list (expansions address tasks from 0)
+                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+                if (lane < cnt) { c0 = t.start[a + lane]; c1 = t.count[a + lane]; c2 = t.req[a + lane]; c3 = t.meta[a + lane]; c4 = t.sid[a + lane]; }
+                wave_lds_fence();
+                if (lane < cnt) { t.start[lane] = c0; t.count[lane] = c1; t.req[lane] = c2; t.meta[lane] = c3; t.sid[lane] = c4; }
+            }
+            flush_tasks<true, SHARDED, LOCAL>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            a = bnd;
+        }
+        if (!more) break;
+    }
+}
+
+// the program table (a few hundred bytes for real schemas) is copied into LDS when it fits
+template <bool LDSPROG>
+__device__ __forceinline__ void load_programs(const DevGraph &g, uint4 *s_prog, const SlotProg *&progs, const FwdOp *&ops, uint32_t nthreads) {
+    progs = g.progs;
+    ops = g.ops;
+    if (LDSPROG) {
+        const uint32_t np = g.nslots * 2, no = g.nops * 2;
+        for (uint32_t i = threadIdx.x; i < np; i += nthreads) s_prog[i] = reinterpret_cast<const uint4 *>(g.progs)[i];
+        for (uint32_t i = threadIdx.x; i < no; i += nthreads) s_prog[np + i] = reinterpret_cast<const uint4 *>(g.ops)[i];
+        __syncthreads();
+        progs = reinterpret_cast<const SlotProg *>(s_prog);
+        ops = reinterpret_cast<const FwdOp *>(s_prog + np);
+    }
+}
+
+__device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t iter, uint32_t wave) {
+    WaveOut wo;
+    wo.buf = f.buf[iter & 1u];
+    wo.cur = wave;
+    wo.fill = 0;
+    wo.produced = 0;
+    wo.counts = f.counts[iter & 1u];
+    wo.nchunks = f.nchunks + iter;
+    wo.overflow = f.overflow;
+    wo.nwaves = f.nwaves;
+    wo.max_chunks = f.max_chunks;
+    wo.cap = 0;
+    return wo;
+}
+
+// Segment-major walk over the chunks iteration `iter - 1` produced.  Chunks are mostly part-filled, so their low segments
+// carry the work; walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves (each segment
+// layer is rotated so that one wave does not keep landing on the same chunk).  The fill counts of the wave's next 64
+// segment slots are fetched by its 64 lanes in ONE gather; the loop then reads them with readlane -- not one dependent
+// load per slot (most slots are empty: 16+ per wave and level).
+struct ChunkWalk {
+    const uint4 *__restrict__ in;
+    uint32_t C, nwaves, lane, x0;
+    uint32_t lc, lcnt;
+    uint64_t work;
+    __device__ __forceinline__ void load(int wl, uint4 &e, bool &valid) const {
+        const uint32_t x = x0 + (uint32_t)wl * nwaves, s = x / C;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
+        valid = s * 64 + lane < cnt;
+        e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+    }
+    __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
+        if (!work) return false;
+        load(__ffsll((unsigned long long)work) - 1, e, valid);
+        return true;
+    }
+    __device__ __forceinline__ void take() { work &= work - 1; }
+};
+
+template <bool LDSPROG, bool SHARDED>
+__global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
+                                                                           DevShard sh) {
+    __shared__ TaskLds lds[kWavesPerBlock];
+    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
+    const SlotProg *progs;
+    const FwdOp *ops;
+    load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
+    const uint32_t lane = lane_id();
+    const uint32_t wib = threadIdx.x >> 6;
+    TaskLds &t = lds[wib];
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
+    const uint32_t pin = (iter + 1) & 1u;  // iteration i reads parity (i-1)&1
+    const uint32_t *__restrict__ in_counts = f.counts[pin];
+    const bool live = !*f.overflow && f.any[iter - 1];
+    const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
+    WaveOut wo = chunked_out(f, iter, wave);
+    ChunkWalk cw{f.buf[pin], C, nwaves, lane, 0u, 0u, 0u, 0ull};
+    const uint32_t nslot = C * kSegsPerChunk;
+    for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
+        const uint32_t xl = x0 + lane * nwaves;
+        uint32_t lc = 0, lcnt = 0;
+        if (xl < nslot) {
+            const uint32_t ls = xl / C;
+            lc = (xl % C + ls * 509u) % C;
+            lcnt = in_counts[lc];
+            lcnt = lcnt > ls * 64 ? lcnt - ls * 64 : 0u;  // entries of this slot's segment and beyond
+        }
+        cw.x0 = x0;
+        cw.lc = lc;
+        cw.lcnt = lcnt;
+        cw.work = __ballot(lcnt != 0);
+        while (cw.work) {
+            const int wl = __ffsll((unsigned long long)cw.work) - 1;
+            cw.work &= cw.work - 1;
+            uint4 e;
+            bool valid;
+            cw.load(wl, e, valid);
+            process_segment<SHARDED, false>(e, valid, cw, t, wo, lane, g, progs, ops, has, err, sh);
         }
     }
     if (lane == 0) {
-        if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
+        if (wo.cur != kNoSpace) wo.counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
         if (wo.produced) f.any[iter] = 1u;
+    }
+}
+
+// ------------------------------------------------------------ single launch
+// Small batches -- the proxy's own call shape: one item per check expression (reference pkg/authz/check.go:76-94), one per
+// watch update (watch.go:50), a few thousand after micro-batching.  The level-synchronous path costs a launch (and part of
+// a host round trip) per dispatch level, ~17 us each whatever the batch size; here ONE launch answers the batch: every wave
+// takes `rpw` requests, seeds them in registers, and walks them through all levels itself with a wave-private frontier
+// (two regions of the frontier buffers, ping-pong), then writes the answers (k_seed + k_expand x levels + k_finalize fused).
+// No wave ever reads another wave's entries, so there is no grid barrier and no inter-level visibility to arrange beyond
+// the wave's own release/acquire.  A wave that outgrows its region raises `overflow`; the host redoes the batch on the
+// level-synchronous path.  Same segment processor, same decisions.
+struct LocalWalk {
+    const uint4 *__restrict__ in;
+    uint32_t n, s, lane;  // entries in the input region, current segment
+    __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
+        if ((s + 1) * 64 >= n) return false;
+        valid = (s + 1) * 64 + lane < n;
+        e = valid ? in[(s + 1) * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        return true;
+    }
+    __device__ __forceinline__ void take() { s++; }
+};
+struct NoNext {
+    __device__ __forceinline__ bool peek(uint4 &, bool &) const { return false; }
+    __device__ __forceinline__ void take() {}
+};
+
+template <bool LDSPROG>
+__global__ __launch_bounds__(64) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1,
+                                                    uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+    __shared__ TaskLds t;
+    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
+    const SlotProg *progs;
+    const FwdOp *ops;
+    load_programs<LDSPROG>(g, s_prog, progs, ops, 64);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = blockIdx.x;
+    const uint32_t first = wave * rpw;
+    if (first >= n) return;
+    const uint32_t mine = min(rpw, n - first);
+    const DevShard nosh{};
+    // ---- seeds (k_seed's validation), in registers
+    const bool valid = lane < mine;
+    const uint32_t req = first + lane;
+    uint4 e = make_uint4(0, 0, kDeadMeta, 0);
+    if (valid) {
+        const uint4 it = items[req];
+        const uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
+        const bool ok = rtype < g.ntypes && stype < g.ntypes && perm < g.type_nmembers[rtype < g.ntypes ? rtype : 0] &&
+                        (srel == 0xFFFFu || srel < g.type_nmembers[stype < g.ntypes ? stype : 0]);
+        has[req] = 0;
+        err[req] = ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID;
+        uint32_t meta = kDeadMeta;
+        if (ok) {
+            const uint32_t slot = g.type_slot_base[rtype] + perm;
+            const uint32_t key = srel == 0xFFFFu ? g.nslots + stype : g.type_slot_base[stype] + srel;
+            meta = make_meta(slot, 1u, key);
+        }
+        e = make_uint4(it.y, req, meta, it.w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint4 *bufs[2] = {buf0 + (size_t)wave * cap, buf1 + (size_t)wave * cap};
+    WaveOut wo;
+    wo.buf = bufs[0];
+    wo.cur = 0;
+    wo.fill = 0;
+    wo.produced = 0;
+    wo.counts = nullptr;
+    wo.nchunks = nullptr;
+    wo.overflow = overflow;
+    wo.nwaves = 0;
+    wo.max_chunks = 0;
+    wo.cap = cap;
+    {
+        NoNext nn;
+        process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
+    }
+    uint32_t parity = 0;
+    for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
+        if (wo.cur == kNoSpace) break;  // overflow: the host redoes the batch
+        const uint32_t cnt = wo.fill;
+        if (!cnt) break;
+        // the wave's own stores of this level must be visible to its own loads of the next
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        LocalWalk lw{bufs[parity], cnt, 0u, lane};
+        parity ^= 1u;
+        wo.buf = bufs[parity];
+        wo.cur = 0;
+        wo.fill = 0;
+        for (; lw.s * 64 < cnt; lw.s++) {
+            const bool v = lw.s * 64 + lane < cnt;
+            const uint4 en = v ? lw.in[lw.s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+            process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+        }
+    }
+    // ---- answers (k_finalize)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (valid) {
+        const bool h = __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        perm_out[req] = h ? 2 : (er ? 0 : 1);
+        if (err_out) err_out[req] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
     }
 }
 
@@ -816,21 +1070,15 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
     const uint32_t wib = threadIdx.x >> 6;
     TaskLds &t = lds[wib];
     const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
-    const uint32_t pin = (iter + 1) & 1u, pout = iter & 1u;
+    const uint32_t pin = (iter + 1) & 1u;
     const uint4 *__restrict__ in = f.buf[pin];
     const uint32_t *__restrict__ in_counts = f.counts[pin];
-    uint4 *__restrict__ out = f.buf[pout];
-    uint32_t *out_counts = f.counts[pout];
-    uint32_t *out_nchunks = f.nchunks + iter;
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
     const DevGraph nog{};
-    WaveOut wo{wave, 0u, 0u};
-    // segment-major work order: chunks are mostly part-filled, so their low segments carry the work;
-    // walking all chunks' segment 0 first, then segment 1, ... spreads it evenly over the waves
-    // (each segment layer is rotated so that one wave does not keep landing on the same chunk).
-    // The fill counts of the wave's next 64 segment slots are fetched by its 64 lanes in ONE gather; the loop then
-    // reads them with readlane -- not one dependent load per slot (most slots are empty: 16+ per wave and level).
+    WaveOut wo = chunked_out(f, iter, wave);
+    uint4 *__restrict__ out = wo.buf;
+    // segment-major work order, as in k_expand (ChunkWalk)
     const uint32_t nslot = C * kSegsPerChunk;
     for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
         const uint32_t xl = x0 + lane * nwaves;
@@ -879,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
             const uint4 o = make_uint4(id, req, first_visit ? (meta | kRevVisited) : meta, 0);
             const uint64_t b = __ballot(active);
             if (b) {
-                const uint32_t base = reserve(wo, (uint32_t)__popcll(b), lane, f, out_counts, out_nchunks);
+                const uint32_t base = reserve<false>(wo, (uint32_t)__popcll(b), lane);
                 if (active && base != kNoSpace) out[base + lanes_below(b)] = o;
             }
             export_entries(first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels, make_uint4(id, req, meta | kRevForeign, 0), 0u, lane, sh);
@@ -921,16 +1169,16 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                 }
                 T += (uint32_t)__popcll(b);
                 if (T > kTaskCap - 64) {
-                    flush_tasks<false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr, sh);
+                    flush_tasks<false, false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, nullptr, nullptr, sh);
                     T = 0;
                 }
             }
         }
-        if (T) flush_tasks<false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, f, out, out_counts, out_nchunks, nullptr, nullptr, sh);
+        if (T) flush_tasks<false, false, false>(t, T, wo, lane, nog, nullptr, nullptr, r.redges, nullptr, nullptr, sh);
         }
     }
     if (lane == 0) {
-        if (wo.cur != kNoSpace) out_counts[wo.cur] = wo.fill;
+        if (wo.cur != kNoSpace) wo.counts[wo.cur] = wo.fill;
         if (wo.produced) f.any[iter] = 1u;
     }
 }
@@ -1006,6 +1254,14 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
         if (lds) hipLaunchKernelGGL((k_expand<true, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
+}
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1, uint32_t cap,
+                        uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+    const dim3 grid((n + rpw - 1) / rpw);
+    if (g.nslots + g.nops <= kProgLdsEntries)
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(64), 0, s, g, items, n, rpw, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+    else
+        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(64), 0, s, g, items, n, rpw, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;

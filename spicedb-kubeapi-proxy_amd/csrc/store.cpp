@@ -11,23 +11,59 @@
 namespace acl {
 
 // ---------------------------------------------------------------- ObjectTable
-uint32_t ObjectTable::intern(const std::string &name) {
-    auto it = by_name_.find(name);
-    if (it != by_name_.end()) return it->second;
-    uint32_t id = count_++;
-    by_name_.emplace(name, id);
-    names_.emplace(id, name);
+uint64_t ObjectTable::hash(std::string_view s) {  // FNV-1a folded through a 64-bit finaliser
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull;
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+void ObjectTable::grow() {
+    std::vector<Slot> old;
+    old.swap(slots_);
+    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu});
+    const size_t mask = slots_.size() - 1;
+    for (const Slot &s : old) {
+        if (s.id == 0xFFFFFFFFu) continue;
+        size_t i = hash(names_[name_of_[s.id]]) & mask;
+        while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+        slots_[i] = s;
+    }
+}
+bool ObjectTable::find(std::string_view name, uint32_t *id) const {
+    if (slots_.empty()) return false;
+    const uint64_t h = hash(name);
+    const uint32_t tag = (uint32_t)(h >> 32);
+    const size_t mask = slots_.size() - 1;
+    for (size_t i = h & mask;; i = (i + 1) & mask) {
+        const Slot &s = slots_[i];
+        if (s.id == 0xFFFFFFFFu) return false;
+        if (s.tag == tag && names_[name_of_[s.id]] == name) {
+            *id = s.id;
+            return true;
+        }
+    }
+}
+uint32_t ObjectTable::intern(std::string_view name) {
+    uint32_t id;
+    if (find(name, &id)) return id;
+    if ((used_ + 1) * 2 > slots_.size()) grow();
+    id = count();
+    if (name_of_.size() <= id) name_of_.resize((size_t)id + 1, 0xFFFFFFFFu);
+    name_of_[id] = (uint32_t)names_.size();
+    names_.emplace_back(name);
+    const uint64_t h = hash(name);
+    const size_t mask = slots_.size() - 1;
+    size_t i = h & mask;
+    while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+    slots_[i] = Slot{(uint32_t)(h >> 32), id};
+    used_++;
+    count_.store(id + 1, std::memory_order_release);
     return id;
 }
-bool ObjectTable::find(const std::string &name, uint32_t *id) const {
-    auto it = by_name_.find(name);
-    if (it == by_name_.end()) return false;
-    *id = it->second;
-    return true;
-}
 const std::string *ObjectTable::name(uint32_t id) const {
-    auto it = names_.find(id);
-    return it == names_.end() ? nullptr : &it->second;
+    if (id >= name_of_.size() || name_of_[id] == 0xFFFFFFFFu) return nullptr;
+    return &names_[name_of_[id]];
 }
 
 // ----------------------------------------------------------------- ClassTable
@@ -150,8 +186,9 @@ Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
     if (create_ids) {
         out->res = objects_[rt].intern(r.rid);
         out->subj = objects_[st].intern(r.sid);
-    } else {
-        if (!objects_[rt].find(r.rid, &out->res) || !objects_[st].find(r.sid, &out->subj)) return Status::Err(ACL_ERR_NOT_FOUND, "unknown object");
+    } else {  // unknown objects resolve to kUnknownId: they take part in no relationship yet
+        if (!objects_[rt].find(r.rid, &out->res)) out->res = kUnknownId;
+        if (!objects_[st].find(r.sid, &out->subj)) out->subj = kUnknownId;
     }
     out->expires = r.expires_at;
     return Status::Ok();
@@ -212,41 +249,43 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
     if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     // limits pinned by the reference's engine config: pkg/spicedb/spicedb.go:35-36
     if (updates.size() > 1000) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "update count of " + std::to_string(updates.size()) + " is greater than maximum allowed of 1000");
-    if (pre.size() > 1000) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "precondition count of " + std::to_string(pre.size()) + " is greater than maximum allowed of 1000");
-    for (const FilterText &f : pre) {
-        if (f.op != ACL_PRE_MUST_MATCH && f.op != ACL_PRE_MUST_NOT_MATCH) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid precondition operation");
-        Status s = validate_filter(f);
-        if (!s.ok()) return s;
-    }
+    Status vs = validate_preconditions(pre);
+    if (!vs.ok()) return vs;
+    // Validation resolves WITHOUT creating ids: a rejected write (failed precondition, CREATE conflict -- the normal
+    // conflict path of the dual-write workflow, workflow.go:187-201) must not grow the dense id space.
     std::vector<Resolved> rs(updates.size());
     for (size_t i = 0; i < updates.size(); i++) {
         if (updates[i].op < ACL_OP_CREATE || updates[i].op > ACL_OP_DELETE) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid update operation");
-        Status s = resolve(updates[i].rel, true, &rs[i]);
+        Status s = resolve(updates[i].rel, false, &rs[i]);
         if (!s.ok()) return s;
         for (size_t j = 0; j < i; j++)
-            if (rs[j].slot == rs[i].slot && rs[j].cls == rs[i].cls && rs[j].res == rs[i].res && rs[j].subj == rs[i].subj)
+            if (rs[j].slot == rs[i].slot && rs[j].cls == rs[i].cls && updates[j].rel.rid == updates[i].rel.rid && updates[j].rel.sid == updates[i].rel.sid)
                 return Status::Err(ACL_ERR_INVALID_ARGUMENT, "found more than one update with relationship `" + updates[i].rel.rtype + ":" + updates[i].rel.rid + "#" + updates[i].rel.rel + "` in this request");
     }
     const int64_t t = now();
     // all preconditions see the pre-write state (workflow.go:452-462)
-    for (const FilterText &f : pre) {
-        bool any = false;
-        scan(f, t, [&](int, int, uint64_t) {
-            any = true;
-            return false;
-        });
-        if ((f.op == ACL_PRE_MUST_MATCH && !any) || (f.op == ACL_PRE_MUST_NOT_MATCH && any))
-            return Status::Err(ACL_ERR_FAILED_PRECONDITION, "unable to satisfy write precondition");
-    }
+    Status ps = eval_preconditions(pre, t);
+    if (!ps.ok()) return ps;
     for (size_t i = 0; i < updates.size(); i++) {
         ClassTable &ct = tables_[rs[i].slot][rs[i].cls];
         ct.settle();
-        if (updates[i].op != ACL_OP_CREATE) continue;
+        if (updates[i].op != ACL_OP_CREATE || rs[i].res == kUnknownId || rs[i].subj == kUnknownId) continue;
         uint64_t key = (uint64_t)rs[i].res << 32 | rs[i].subj;
         if (ct.contains(key) && live(ct, key, t))
             return Status::Err(ACL_ERR_ALREADY_EXISTS, "could not CREATE relationship `" + updates[i].rel.rtype + ":" + updates[i].rel.rid + "#" + updates[i].rel.rel + "@" + updates[i].rel.stype + ":" + updates[i].rel.sid + "`, as it already existed");
     }
+    // accepted: from here on nothing fails.  New objects get their ids now (a DELETE of an unknown object is a no-op).
+    std::vector<char> skip(updates.size(), 0);
     for (size_t i = 0; i < updates.size(); i++) {
+        if (updates[i].op == ACL_OP_DELETE) {
+            skip[i] = rs[i].res == kUnknownId || rs[i].subj == kUnknownId;
+            continue;
+        }
+        if (rs[i].res == kUnknownId) rs[i].res = objects_[rs[i].rtype].intern(updates[i].rel.rid);
+        if (rs[i].subj == kUnknownId) rs[i].subj = objects_[rs[i].stype].intern(updates[i].rel.sid);
+    }
+    for (size_t i = 0; i < updates.size(); i++) {
+        if (skip[i]) continue;
         ClassTable &ct = tables_[rs[i].slot][rs[i].cls];
         uint64_t key = (uint64_t)rs[i].res << 32 | rs[i].subj;
         auto it = std::lower_bound(ct.keys.begin(), ct.keys.end(), key);
@@ -262,9 +301,38 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
     }
     revision_++;
     for (size_t i = 0; i < updates.size(); i++)
-        log_change(updates[i].op == ACL_OP_DELETE ? ACL_OP_DELETE : ACL_OP_TOUCH, rs[i].slot, rs[i].cls, (uint64_t)rs[i].res << 32 | rs[i].subj);
+        if (!skip[i]) log_change(updates[i].op == ACL_OP_DELETE ? ACL_OP_DELETE : ACL_OP_TOUCH, rs[i].slot, rs[i].cls, (uint64_t)rs[i].res << 32 | rs[i].subj);
     if (revision) *revision = revision_;
     return Status::Ok();
+}
+
+Status Store::validate_preconditions(const std::vector<FilterText> &pre) const {
+    if (pre.size() > 1000) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "precondition count of " + std::to_string(pre.size()) + " is greater than maximum allowed of 1000");
+    for (const FilterText &f : pre) {
+        if (f.op != ACL_PRE_MUST_MATCH && f.op != ACL_PRE_MUST_NOT_MATCH) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid precondition operation");
+        Status s = validate_filter(f);
+        if (!s.ok()) return s;
+    }
+    return Status::Ok();
+}
+
+Status Store::eval_preconditions(const std::vector<FilterText> &pre, int64_t t) {
+    for (const FilterText &f : pre) {
+        bool any = false;
+        scan(f, t, [&](int, int, uint64_t) {
+            any = true;
+            return false;
+        });
+        if ((f.op == ACL_PRE_MUST_MATCH && !any) || (f.op == ACL_PRE_MUST_NOT_MATCH && any))
+            return Status::Err(ACL_ERR_FAILED_PRECONDITION, "unable to satisfy write precondition");
+    }
+    return Status::Ok();
+}
+
+Status Store::check_preconditions(const std::vector<FilterText> &pre) {
+    if (!schema_loaded_) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    Status s = validate_preconditions(pre);
+    return s.ok() ? eval_preconditions(pre, now()) : s;
 }
 
 Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t *revision) {

@@ -12,9 +12,12 @@
 // inside a class is the 64-bit key (resource_id << 32 | subject_id); tables are
 // kept sorted, i.e. already in CSR order (rows = resources, columns sorted).
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <deque>
 #include <functional>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -50,20 +53,39 @@ struct FilterText {  // authzed.api.v1.RelationshipFilter (+ precondition op)
     std::string rid, rel, stype, sid, srel;  // srel: "" means "only relationships without subject relation"
 };
 
-class ObjectTable {  // dense local ids of one object type
+// Dense local ids of one object type.  string -> id is an open-addressing table of (32-bit hash tag, id) pairs over
+// names kept in stable storage: a lookup hashes the caller's bytes in place (no std::string is built) -- this is the
+// per-item cost of the string entry points (acl_check_bulk: reference pkg/authz/check.go:23-39 builds 5 strings per
+// item).  Threading (engine_internal.hpp): mutated only under the names lock held exclusively, read under it shared.
+class ObjectTable {
   public:
-    uint32_t intern(const std::string &name);
-    bool find(const std::string &name, uint32_t *id) const;
+    uint32_t intern(std::string_view name);
+    bool find(std::string_view name, uint32_t *id) const;
     const std::string *name(uint32_t id) const;  // nullptr for anonymous ids
-    uint32_t count() const { return count_; }
+    uint32_t count() const { return count_.load(std::memory_order_acquire); }
     void reserve_ids(uint32_t n) {  // numeric bulk loads: ids < n exist (anonymous)
-        if (n > count_) count_ = n;
+        if (n > count()) count_.store(n, std::memory_order_release);
+    }
+    ObjectTable() = default;
+    ObjectTable(const ObjectTable &o) : names_(o.names_), name_of_(o.name_of_), slots_(o.slots_), used_(o.used_), count_(o.count()) {}
+    ObjectTable &operator=(const ObjectTable &o) {
+        names_ = o.names_;
+        name_of_ = o.name_of_;
+        slots_ = o.slots_;
+        used_ = o.used_;
+        count_.store(o.count());
+        return *this;
     }
 
   private:
-    std::unordered_map<std::string, uint32_t> by_name_;
-    std::unordered_map<uint32_t, std::string> names_;
-    uint32_t count_ = 0;
+    struct Slot { uint32_t tag, id; };  // id == 0xFFFFFFFF: empty
+    static uint64_t hash(std::string_view s);
+    void grow();
+    std::deque<std::string> names_;      // stable addresses (acl_object_name hands out c_str())
+    std::vector<uint32_t> name_of_;      // id -> index in names_ (0xFFFFFFFF anonymous); covers ids < name_of_.size()
+    std::vector<Slot> slots_;            // power-of-two capacity, load <= 0.5
+    size_t used_ = 0;
+    std::atomic<uint32_t> count_{0};
 };
 
 struct ClassTable {
@@ -87,6 +109,8 @@ class Store {
 
     Status write(const std::vector<UpdateText> &updates, const std::vector<FilterText> &preconditions, uint64_t *revision);
     Status delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t *revision);
+    // DeleteRelationshipsRequest.OptionalPreconditions: evaluated by the caller under the same lock as the delete
+    Status check_preconditions(const std::vector<FilterText> &preconditions);
     Status read(const FilterText &f, const std::function<void(const RelText &)> &cb);
     Status add_edges(int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj);
     Status load_relationship_lines(const std::string &text);
@@ -124,6 +148,7 @@ class Store {
     bool raw_changes_since(uint64_t after, std::vector<Change> *out) const;
 
   private:
+    static constexpr uint32_t kUnknownId = 0xFFFFFFFFu;  // resolve(create_ids = false): the object has no id (yet)
     struct Resolved {
         int slot, cls, rtype, stype;
         uint32_t res, subj;
@@ -131,6 +156,8 @@ class Store {
     };
     Status resolve(const RelText &r, bool create_ids, Resolved *out);
     Status validate_filter(const FilterText &f) const;
+    Status validate_preconditions(const std::vector<FilterText> &pre) const;
+    Status eval_preconditions(const std::vector<FilterText> &pre, int64_t now);
     // calls fn(slot, class, key) for every live relationship matching f; stops when fn returns false
     void scan(const FilterText &f, int64_t now, const std::function<bool(int, int, uint64_t)> &fn);
 

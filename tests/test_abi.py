@@ -27,15 +27,30 @@ def test_header_symbols_exported(aclgpu_lib):
     assert sorted(aclgpu._lib.SYMBOLS) == names  # the binding covers exactly the header
 
 
-def test_struct_layouts(aclgpu_lib):
+def test_struct_layouts(aclgpu_lib, tmp_path):
+    """Every struct of the ctypes binding has exactly the size and field offsets gcc gives the header's struct."""
+    import subprocess
     import aclgpu
     assert aclgpu.ITEM_DTYPE.itemsize == 16  # acl_item_t: the 16-byte interned request
-    assert C.sizeof(aclgpu._lib.Config) == 24
-    assert C.sizeof(aclgpu._lib.Relationship) == 7 * 8
-    assert C.sizeof(aclgpu._lib.Update) == 8 + 7 * 8
-    assert C.sizeof(aclgpu._lib.Filter) == 8 + 6 * 8
-    assert C.sizeof(aclgpu._lib.CheckItem) == 6 * 8
-    assert C.sizeof(aclgpu._lib.Stats) == 13 * 8
+    pairs = {"acl_config_t": aclgpu._lib.Config, "acl_relationship_t": aclgpu._lib.Relationship, "acl_update_t": aclgpu._lib.Update,
+             "acl_filter_t": aclgpu._lib.Filter, "acl_check_item_t": aclgpu._lib.CheckItem, "acl_stats_t": aclgpu._lib.Stats,
+             "acl_shard_step_t": aclgpu._lib.ShardStep, "acl_call_opts_t": aclgpu._lib.CallOpts}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "aclgpu.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _t in ct._fields_:
+            lines.append(f'printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('printf("\\n");')
+    lines.append('printf("acl_item_t %zu\\n", sizeof(acl_item_t)); return 0; }')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.dirname(HEADER), "-o", str(exe), str(src)])
+    out = dict((ln.split()[0], [int(x) for x in ln.split()[1:]]) for ln in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert out["acl_item_t"] == [16]
+    for cname, ct in pairs.items():
+        assert out[cname][0] == C.sizeof(ct), cname
+        assert out[cname][1:] == [getattr(ct, f).offset for f, _t in ct._fields_], cname
 
 
 def test_no_gpu_means_no_evaluation(aclgpu_lib):
