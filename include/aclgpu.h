@@ -248,6 +248,9 @@ enum { ACL_SHARD_VISIT = 1, ACL_SHARD_EXPAND = 2 };
 int acl_shard_configure(acl_engine_t *h, uint32_t rank, uint32_t world); /* world == 1 restores the single-GPU engine */
 int acl_shard_of_type(acl_engine_t *h, int type);                        /* shard holding the type's rows; -1 if unknown */
 int acl_shard_grow_frontier(acl_engine_t *h);
+/* hipStream_t every acl_shard_* call launches on (the protocol's own evaluation context): the host orders its
+ * collectives after / before the steps on this stream.  NULL without a GPU. */
+void *acl_shard_stream(acl_engine_t *h);
 /* Check (check.go:48): d_items = the WHOLE batch on every shard (each seeds the items whose resource type it owns);
  * d_has / d_err = n bytes each, per shard; after the last level the host MAX-reduces both across shards. */
 int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *d_has, void *d_err);

@@ -1056,8 +1056,10 @@ static unsigned clog2(uint64_t x) { unsigned b = 0; while ((1ull << b) < x) b++;
 
 typedef struct { uint16_t type, rel; uint32_t id; } state_t;
 
-uint64_t orc_check_bytes(orc_t *o, int rtype, int perm, uint32_t res, int stype, int srel, uint32_t subj, int *result) {
-    ensure_sorted(o);
+/* lvl_bytes[L] / lvl_states[L] (L = 1..ORC_MAX_DEPTH, may be NULL): bytes charged while level L was evaluated and the
+ * number of distinct states that level held (level 1 = the request itself; its 17 request/answer bytes are charged there). */
+static uint64_t check_bytes_core(orc_t *o, int rtype, int perm, uint32_t res, int stype, int srel, uint32_t subj, int *result, uint64_t *lvl_bytes,
+                                 uint64_t *lvl_states) {
     subject_t s = {stype, srel < 0 ? ELLIPSIS : (unsigned)srel, subj};
     uint64_t bytes = 17;
     u64set_t seen_states = {0}, seen_rows = {0};
@@ -1073,8 +1075,10 @@ uint64_t orc_check_bytes(orc_t *o, int rtype, int perm, uint32_t res, int stype,
             next[nn++] = (state_t){(uint16_t)(T), (uint16_t)(R), (I)};                                              \
         }                                                                                                           \
     } while (0)
+    uint64_t charged = 0;
     for (int level = 1; level <= ORC_MAX_DEPTH && fn && !found; level++) {
         nn = 0;
+        if (lvl_states) lvl_states[level] += fn;
         for (size_t fi = 0; fi < fn; fi++) {
             state_t st = front[fi];
             if (s.stype == st.type && s.srel == st.rel && s.sid == st.id) found = 1;
@@ -1140,11 +1144,62 @@ uint64_t orc_check_bytes(orc_t *o, int rtype, int perm, uint32_t res, int stype,
         }
         state_t *tmp = front; front = next; next = tmp;
         fn = nn;
+        if (lvl_bytes) lvl_bytes[level] += bytes - charged;
+        charged = bytes;
     }
 #undef PUSH_NEXT
     free(front); free(next); free(seen_states.k); free(seen_rows.k);
     if (result) *result = found ? ORC_PERM_HAS : ORC_PERM_NO;
     return bytes;
+}
+
+uint64_t orc_check_bytes(orc_t *o, int rtype, int perm, uint32_t res, int stype, int srel, uint32_t subj, int *result) {
+    ensure_sorted(o);
+    return check_bytes_core(o, rtype, perm, res, stype, srel, subj, result, NULL, NULL);
+}
+
+/* The byte model over a WHOLE batch, split over host threads (the model only reads the sorted tuple table).
+ * Returns the batch's algorithmic bytes; lvl_bytes / lvl_states: [ORC_MAX_DEPTH + 1] totals per level (may be NULL). */
+typedef struct {
+    orc_t *o;
+    size_t lo, hi;
+    int rtype, perm, stype, srel;
+    const uint32_t *res, *subj;
+    uint64_t total, lvl_bytes[ORC_MAX_DEPTH + 1], lvl_states[ORC_MAX_DEPTH + 1];
+} bytes_job_t;
+static void *bytes_run(void *arg) {
+    bytes_job_t *j = arg;
+    for (size_t i = j->lo; i < j->hi; i++)
+        j->total += check_bytes_core(j->o, j->rtype, j->perm, j->res[i], j->stype, j->srel, j->subj[i], NULL, j->lvl_bytes, j->lvl_states);
+    return NULL;
+}
+uint64_t orc_check_bytes_bulk_mt(orc_t *o, int nthreads, size_t n, int rtype, int perm, const uint32_t *res, int stype, int srel, const uint32_t *subj,
+                                 uint64_t *lvl_bytes, uint64_t *lvl_states) {
+    ensure_sorted(o);
+    if (nthreads < 1) nthreads = 1;
+    if ((size_t)nthreads > n && n) nthreads = (int)n;
+    bytes_job_t *jobs = calloc((size_t)nthreads, sizeof *jobs);
+    pthread_t *th = calloc((size_t)nthreads, sizeof *th);
+    for (int t = 0; t < nthreads; t++) {
+        bytes_job_t *j = &jobs[t];
+        j->o = o;
+        j->lo = n * (size_t)t / (size_t)nthreads;
+        j->hi = n * (size_t)(t + 1) / (size_t)nthreads;
+        j->rtype = rtype; j->perm = perm; j->stype = stype; j->srel = srel;
+        j->res = res; j->subj = subj;
+        pthread_create(&th[t], NULL, bytes_run, j);
+    }
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        total += jobs[t].total;
+        for (int l = 0; l <= ORC_MAX_DEPTH; l++) {
+            if (lvl_bytes) lvl_bytes[l] += jobs[t].lvl_bytes[l];
+            if (lvl_states) lvl_states[l] += jobs[t].lvl_states[l];
+        }
+    }
+    free(jobs); free(th);
+    return total;
 }
 
 /* multi-threaded helper for the cpu_baseline leg is deliberately absent: the

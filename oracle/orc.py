@@ -78,6 +78,8 @@ def lib():
         L.orc_lookup_result.argtypes = [C.c_void_p]
         L.orc_check_bytes.restype = C.c_uint64
         L.orc_check_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_int)]
+        L.orc_check_bytes_bulk_mt.restype = C.c_uint64
+        L.orc_check_bytes_bulk_mt.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -253,6 +255,16 @@ class Oracle:
         b = self._L.orc_check_bytes(self._h, self.type_id(rtype), self.rel_id(rtype, perm), int(res), self.type_id(stype),
                                     self.rel_id(stype, srel), int(subj), C.byref(r))
         return b, r.value
+
+    def check_bytes_bulk(self, nthreads, rtype, perm, res, stype, srel, subj):
+        """SURVEY.md 8(d) algorithmic bytes of a whole batch (multi-threaded) -> (total bytes, bytes per level [51], distinct states per level [51])"""
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        subj = np.ascontiguousarray(subj, dtype=np.uint32)
+        lb = np.zeros(51, dtype=np.uint64)
+        ls = np.zeros(51, dtype=np.uint64)
+        tot = self._L.orc_check_bytes_bulk_mt(self._h, int(nthreads), res.size, self.type_id(rtype), self.rel_id(rtype, perm), res.ctypes.data,
+                                              self.type_id(stype), self.rel_id(stype, srel), subj.ctypes.data, lb.ctypes.data, ls.ctypes.data)
+        return int(tot), lb, ls
 
     def counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -25,7 +25,7 @@ SYMBOLS = [
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
-    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts",
+    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream",
 ]
 
 
@@ -157,6 +157,8 @@ def load():
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]
     L.acl_shard_grow_frontier.argtypes = [H]
+    L.acl_shard_stream.argtypes = [H]
+    L.acl_shard_stream.restype = C.c_void_p
     L.acl_shard_check_begin.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_shard_check_step.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ShardStep)]
     L.acl_shard_check_step_by_dest.argtypes = [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ShardStep), C.POINTER(C.c_uint64)]

@@ -181,7 +181,7 @@ class GpuShard:
 
     @contextlib.contextmanager
     def stream(self):
-        ext = torch.cuda.ExternalStream(self.e.stream, device=self.device)
+        ext = torch.cuda.ExternalStream(self._L.acl_shard_stream(self._h) or 0, device=self.device)
         with torch.cuda.stream(ext):
             yield
 

@@ -127,6 +127,12 @@ int acl_shard_of_type(acl_engine_t *h, int type) {
     return (int)shard_of_type(sc.defs[type].name, h->shard.world);
 }
 
+void *acl_shard_stream(acl_engine_t *h) {
+    ShardCall sc;
+    if (sc.begin(h, false, false)) return nullptr;
+    return (void *)sc.c->stream;
+}
+
 int acl_shard_grow_frontier(acl_engine_t *h) {
     ShardCall sc;
     int rc = sc.begin(h, false, false);

@@ -732,8 +732,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         asm volatile("" : "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(ee.w));
         const uint32_t id = ee.x, req = ee.y, meta = ee.z, sid = ee.w;
         bool active = valid && meta != kDeadMeta;
-        if (active && !jstart && has[req]) active = false;  // request already answered HAS: drop its pending work
-        if (jstart && hit) active = false;
+        if (active && (hit || has[req])) active = false;  // request already answered HAS: drop its pending work
         const uint32_t slot = meta_slot(meta), level = meta_level(meta), key = meta_key(meta);
         const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
         SlotProg p{};

@@ -1,0 +1,119 @@
+"""Deterministic request/response cases for pinning the oracle (and the engine) against the REAL embedded SpiceDB.
+
+The reference's arithmetic is the third-party Go module github.com/authzed/spicedb (go.mod:9); neither it nor a Go
+toolchain exists in this build environment, and no reference test holds a vector for arrows, nested usersets or the
+depth limit (last row).  These cases are the inputs of oracle/ref_spicedb/ (a small Go program around
+the reference's own spicedb.NewServer, pkg/spicedb/spicedb.go:18-71): `python tools/dump_ref_inputs.py` writes them under
+oracle/_ref/inputs/, the Go program replays them through CheckBulkPermissions / LookupResources (check.go:48,
+lookups.go:65) and writes tests/golden/ref_<case>.json, and tests/test_ref_fixtures.py compares the oracle (CPU) and
+the engine (GPU) with those fixtures.  Until the fixtures exist the tests report PARITY UNPINNED, loudly.
+
+A case: name, schema text, relationships [6-tuples], checks [6-tuples rt, rid, perm, st, sid, srel],
+lookups [5-tuples rt, perm, st, sid, srel].  Everything below is seeded; ids of the numeric workloads are decimal strings.
+"""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _workload_case(name, w, max_checks, n_lookups=4):
+    rels = []
+    for rt, rel, st, srel, r, s in w.edges:
+        rels += [(rt, str(int(a)), rel, st, str(int(b)), srel) for a, b in zip(r, s)]
+    rt, perm, st = w.check
+    m = min(max_checks, w.res.size)
+    checks = [(rt, str(int(a)), perm, st, str(int(b)), "") for a, b in zip(w.res[:m], w.subj[:m])]
+    rng = np.random.default_rng(7)
+    subs = [int(x) for x in rng.integers(0, w.nobjects[st], size=n_lookups)]
+    if w.lookup_subjects is not None:
+        subs += [int(x) for x in w.lookup_subjects[:n_lookups]]
+    lookups = [(rt, perm, st, str(s), "") for s in subs]
+    return {"name": name, "schema": w.schema, "relationships": rels, "checks": checks, "lookups": lookups}
+
+
+def _shapes_case():
+    """The shapes no reference test pins: arrows (incl. recursive parent->view), usersets with permissions as subject
+    relations, subject-with-relation requests, a userset that is its own member, the depth limit on a 60-long chain,
+    cycles (deny or depth error -- the proxy denies either way, check.go:55-69), unknown ids, relation-name checks."""
+    from tests.test_oracle_cross import SCHEMA
+    rels = [
+        ("group", "eng", "member", "user", "alice", ""), ("group", "eng", "owner", "user", "olga", ""),
+        ("group", "all", "member", "group", "eng", "member"), ("group", "all", "member", "user", "bob", ""),
+        ("group", "loop-a", "member", "group", "loop-b", "member"), ("group", "loop-b", "member", "group", "loop-a", "member"),
+        ("group", "loop-b", "member", "user", "carol", ""),
+        ("group", "self", "member", "group", "self", "member"),
+        ("org", "root", "admin", "group", "all", "member"), ("org", "mid", "parent", "org", "root", ""),
+        ("org", "leaf", "parent", "org", "mid", ""), ("org", "cyc-a", "parent", "org", "cyc-b", ""), ("org", "cyc-b", "parent", "org", "cyc-a", ""),
+        ("org", "cyc-b", "admin", "user", "dave", ""),
+        ("doc", "readme", "org", "org", "leaf", ""), ("doc", "readme", "creator", "user", "erin", ""),
+        ("doc", "plan", "viewer", "group", "eng", "manage"), ("doc", "plan", "viewer", "group", "loop-a", "member"),
+        ("doc", "notes", "viewer", "user", "frank", ""), ("doc", "orphan", "org", "org", "cyc-a", ""),
+    ]
+    n = 60
+    rels += [("group", f"chain{i}", "member", "group", f"chain{i + 1}", "member") for i in range(n)]
+    rels.append(("group", f"chain{n}", "member", "user", "deep", ""))
+    users = ["alice", "bob", "carol", "dave", "erin", "frank", "olga", "deep", "nobody"]
+    checks = []
+    for u in users:
+        for d in ("readme", "plan", "notes", "orphan", "missing"):
+            for p in ("view", "edit", "viewer", "nothing"):
+                checks.append(("doc", d, p, "user", u, ""))
+        for o in ("root", "mid", "leaf", "cyc-a", "cyc-b"):
+            checks.append(("org", o, "view", "user", u, ""))
+        for g in ("eng", "all", "loop-a", "loop-b", "self"):
+            for p in ("member", "manage"):
+                checks.append(("group", g, p, "user", u, ""))
+    for k in range(0, n + 1):
+        checks.append(("group", f"chain{k}", "member", "user", "deep", ""))
+    for s in (("group", "eng", "member"), ("group", "eng", "manage"), ("group", "self", "member"), ("group", "loop-a", "member"), ("group", "chain30", "member")):
+        for d in ("readme", "plan"):
+            checks.append(("doc", d, "view") + s)
+        for g in ("eng", "all", "self", "loop-b", "chain0", "chain30"):
+            checks.append(("group", g, "member") + s)
+        checks.append(("org", "leaf", "view") + s)
+    lookups = [("doc", "view", "user", u, "") for u in ("alice", "bob", "carol", "dave", "erin", "olga", "nobody")]
+    lookups += [("org", "view", "user", "alice", ""), ("group", "member", "user", "deep", ""), ("group", "member", "user", "carol", ""),
+                ("group", "manage", "user", "olga", ""), ("doc", "view", "group", "eng", "member"), ("group", "member", "group", "self", "member"),
+                ("doc", "nothing", "user", "alice", "")]
+    return {"name": "shapes", "schema": SCHEMA, "relationships": rels, "checks": checks, "lookups": lookups}
+
+
+def _bootstrap_case():
+    b = json.load(open(os.path.join(HERE, "golden", "bootstrap.json")))
+    rels = []
+    from tests import kat_runner
+    for line in b["relationships"]:
+        rels.append(kat_runner.parse_rel(line))
+    rels += [("namespace", "paul-ns", "creator", "user", "paul", ""), ("pod", "paul-ns/p1", "creator", "user", "paul", ""),
+             ("pod", "paul-ns/p1", "namespace", "namespace", "paul-ns", ""), ("pod", "paul-ns/p2", "viewer", "user", "chani", "")]
+    checks = []
+    for u in ("rakis", "paul", "chani", "nobody"):
+        for ns in ("spicedb-kubeapi-proxy", "paul-ns", "missing"):
+            for p in ("view", "edit", "admin", "no_one_at_all", "creator", "viewer"):
+                checks.append(("namespace", ns, p, "user", u, ""))
+        for pod in ("paul-ns/p1", "paul-ns/p2", "x/y"):
+            for p in ("view", "edit"):
+                checks.append(("pod", pod, p, "user", u, ""))
+    lookups = [("namespace", "view", "user", u, "") for u in ("rakis", "paul", "chani")] + [("pod", "view", "user", u, "") for u in ("paul", "chani")]
+    return {"name": "bootstrap", "schema": b["schema"], "relationships": rels, "checks": checks, "lookups": lookups}
+
+
+def cases():
+    import sys
+    pkg = os.path.join(os.path.dirname(HERE), "spicedb-kubeapi-proxy_amd")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    from aclgpu import workloads
+    out = [_bootstrap_case(), _shapes_case(),
+           _workload_case("c1", workloads.c1(), 100),
+           _workload_case("c2_s005", workloads.c2(scale=0.05, batch=20000), 20000),
+           _workload_case("c3_s005", workloads.c3(scale=0.05, batch=4000, power_users=8), 4000),
+           _workload_case("c4_s002", workloads.c4(scale=0.02, batch=30000, n_user=20000), 30000)]
+    return out
+
+
+def fixture_path(name):
+    return os.path.join(HERE, "golden", f"ref_{name}.json")
