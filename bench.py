@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Check decisions/s of the MI355X ACL engine on BASELINE.json's headline workload.
 
-A "step" = one pass of the hot path (bulk Check through the C ABI, acl_check_bulk_ids_device)
-over one HBM-resident batch of interned requests.  Default workload: C4 (10 M relationships /
-1 M objects, 5-level nested groups, 256 k-item batch) -- the configuration BASELINE.json's
-metric is quoted on.  N > 1: one process per GPU (torchrun), every rank holds a full replica of
-the graph and answers its own batch (weak scaling, no data-path collective: requests are
-independent -- SURVEY.md 8(e)); the timed region is bracketed by barrier + synchronize and the
-MAX over ranks is reported.
+A "step" = one pass of the hot path (bulk Check through the C ABI) over one batch of interned requests.  Default
+workload: C4 (10 M relationships / 1 M objects, 5-level nested groups, 256 k-item batch) -- the configuration
+BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic bytes / HIP-event kernel
-time vs HBM peak) and `cpu_baseline` (the CPU oracle, a single-thread restatement of SpiceDB's
-dispatch -- NOT the embedded SpiceDB, which cannot be built here -- timed on a bounded sample of
-the same batch on this box's host cores, and used at the same time to verify the GPU answers).
+  value             (ii) the ABI call that takes HOST ids -- H2D + kernels + D2H -- PIPELINED: K steps over 8 distinct
+                    pre-generated batches in pinned host memory, submitted through acl_check_bulk_ids_submit so that the copies
+                    of one batch overlap the kernels of another (the engine's evaluation contexts, one HIP stream each)
+  device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
+                    per-launch kernel time comes from HIP events in THIS leg (pipelined launches overlap each other)
+  latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")
+  string_path       (iii) acl_check_bulk with strings (5 strings interned per item), reported separately
+
+N > 1: one process per GPU (torchrun), every rank holds a full replica of the graph and answers its own batches (weak
+scaling, no data-path collective: requests are independent -- SURVEY.md 8(e)); the timed region is bracketed by barrier +
+synchronize and the MAX over ranks is reported.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic bytes of the WHOLE batch from the oracle's byte model,
+multi-threaded, with its per-level split / HIP-event kernel time vs HBM peak), `cpu_baseline` (the CPU oracle, a restatement of
+SpiceDB's dispatch -- NOT the embedded SpiceDB, which cannot be built here -- timed on a bounded sample of the same batch on
+this box's host cores and used at the same time to verify the GPU answers), and `configs` = {C2, C3}: the other single-GPU
+BASELINE configurations measured in the same run, each with its own roofline / cpu_baseline / parity.
 """
 import argparse
 import json
@@ -51,20 +60,58 @@ def usable_cores():
     return c
 
 
-def filter_bench(args, w, eng, world, rank):
-    """BASELINE config 3 (not the headline): one step = LookupResources(pod, view, user:U) for the 64 power users as ONE
-    batched reverse walk (acl_lookup_resources_batch: bitmaps come back to the host, as the Go side consumes them)."""
+def c3_lookup_bytes(w, subjects):
+    """SURVEY.md 8(d) LookupResources formula, evaluated on the generator's arrays for C3's schema:
+    17 + sum over the reverse rows the walk touches of (8 + 4 * deg) + ceil(N_pod / 8) for the result bitmap."""
+    E = {(e[0], e[1]): (e[4], e[5]) for e in w.edges}
+
+    def by_subject(key, n):
+        r, s_ = E[key]
+        o = np.argsort(s_, kind="stable")
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, s_.astype(np.int64) + 1, 1)
+        return np.cumsum(ptr), r[o]
+
+    nu, nns, ncl, npod = w.nobjects["user"], w.nobjects["namespace"], w.nobjects["cluster"], w.nobjects["pod"]
+    user_rows = {k: by_subject(k, nu) for k in [("pod", "viewer"), ("pod", "creator"), ("namespace", "viewer"), ("namespace", "creator"), ("cluster", "viewer"), ("cluster", "admin")]}
+    ns_of_cl = by_subject(("namespace", "cluster"), ncl)
+    pod_of_ns = by_subject(("pod", "namespace"), nns)
+    out = []
+    for u in subjects:
+        u = int(u)
+        b = 17 + (npod + 7) // 8
+        reach = {}
+        for k, (ptr, col) in user_rows.items():
+            d = int(ptr[u + 1] - ptr[u])
+            b += 8 + 4 * d
+            reach.setdefault(k[0], []).append(col[ptr[u]:ptr[u + 1]])
+        cls = np.unique(np.concatenate(reach["cluster"])) if reach.get("cluster") else np.zeros(0, dtype=np.int64)
+        nss = [np.concatenate(reach["namespace"])] if reach.get("namespace") else []
+        for c in cls:
+            d = int(ns_of_cl[0][c + 1] - ns_of_cl[0][c])
+            b += 8 + 4 * d
+            nss.append(ns_of_cl[1][ns_of_cl[0][c]:ns_of_cl[0][c + 1]])
+        nss = np.unique(np.concatenate(nss)) if nss else np.zeros(0, dtype=np.int64)
+        deg = pod_of_ns[0][nss.astype(np.int64) + 1] - pod_of_ns[0][nss.astype(np.int64)]
+        b += int(8 * nss.size + 4 * deg.sum())
+        out.append(b)
+    return np.asarray(out, dtype=np.int64)
+
+
+def filter_bench(args, w, eng, steps, warmup):
+    """BASELINE config 3: one step = LookupResources(pod, view, user:U) for the 64 power users as ONE batched reverse walk
+    (acl_lookup_resources_batch: bitmaps come back to the host, as the Go side consumes them).  Returns the C3 record."""
     import torch
     rt, perm_name, st = w.check
     subs = np.asarray(w.lookup_subjects, dtype=np.uint32)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.lookup_ids_batch(rt, perm_name, st, "", subs)
     eng.stats_reset()
     eng.set_timing(True)
     torch.cuda.synchronize()
     lat = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         t1 = time.perf_counter()
         bms, counts = eng.lookup_ids_batch(rt, perm_name, st, "", subs)
         lat.append(time.perf_counter() - t1)
@@ -73,36 +120,47 @@ def filter_bench(args, w, eng, world, rank):
     stats = eng.stats()
     # single-request latency (the proxy's shape: one prefilter per list request)
     one = []
-    for s_ in subs[:16]:
+    for s_ in np.tile(subs, 4)[:200]:
         t1 = time.perf_counter()
         eng.lookup_ids_batch(rt, perm_name, st, "", [int(s_)])
         one.append(time.perf_counter() - t1)
-    out = {"metric": "lookup_resources_per_sec", "value": subs.size * args.steps / el, "unit": "lookups/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "u32", "data": "synthetic",
-           "config": {"workload": WORKLOAD_DESC["C3"], "lookups_per_step": int(subs.size), "relationships": w.ntuples,
-                      "objects": int(sum(w.nobjects.values())), "scale": args.scale},
-           "allowed_ids_per_lookup": float(np.mean(counts)), "allowed_ids_per_sec": float(np.sum(counts)) * args.steps / el,
-           "p50_batch_ms": 1e3 * float(np.median(lat)), "p50_single_lookup_ms": 1e3 * float(np.median(one)),
-           "kernel_ms_per_step": stats["kernel_ms"] / args.steps, "rev_expand_launches_per_step": stats["expand_launches"] / args.steps,
-           "bitmap_bytes_per_lookup": int(bms.shape[1] * 4)}
+    launches = max(1, stats["expand_launches"])
+    lb = c3_lookup_bytes(w, subs)
+    batch_bytes = float(lb.sum())
+    ach = batch_bytes * steps / (stats["expand_ms"] * 1e-3) / 1e9 if stats["expand_ms"] > 0 else None
+    out = {"metric": "lookup_resources_per_sec", "value": subs.size * steps / el, "unit": "lookups/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * el / steps, "workload": WORKLOAD_DESC["C3"], "lookups_per_step": int(subs.size), "relationships": w.ntuples,
+           "objects": int(sum(w.nobjects.values())),
+           "allowed_ids_per_lookup": float(np.mean(counts)), "allowed_ids_per_sec": float(np.sum(counts)) * steps / el,
+           "p50_batch_ms": 1e3 * float(np.median(lat)), "p50_single_lookup_ms": 1e3 * float(np.median(one)), "p95_single_lookup_ms": 1e3 * float(np.percentile(one, 95)),
+           "kernel_ms_per_step": stats["kernel_ms"] / steps, "rev_expand_launches_per_step": launches / steps,
+           "bitmap_bytes_per_lookup": int(bms.shape[1] * 4),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                        "kernel": "k_rev_expand", "kernel_avg_us": 1e3 * stats["expand_ms"] / launches,
+                        "algorithmic_bytes_per_lookup": batch_bytes / subs.size, "algorithmic_bytes_per_launch": batch_bytes * steps / launches,
+                        "model": "SURVEY.md 8(d) LookupResources formula on the generator's arrays: 17 + sum over reverse rows (8 + 4 deg) + N_pod / 8"}}
     if not args.no_cpu:
         from oracle import orc
         o = orc.Oracle(w.schema)
         w.load(o)
         o.freeze()
+        nt = min(usable_cores(), 32)
+        npod = w.nobjects[rt]
+        pods = np.arange(npod, dtype=np.uint32)
+        mism = 0
         t1 = time.perf_counter()
-        want = [np.sort(o.lookup_ids(rt, perm_name, st, "", int(s_))) for s_ in subs[:2]]
+        for i, s_ in enumerate(subs):  # the DEFINITION {id : Check == HAS} over every pod, multi-threaded bulk check: all 64 users
+            op, _oe = o.check_bulk_ids_mt(nt, rt, perm_name, pods, st, "", np.full(npod, s_, dtype=np.uint32))
+            want = np.flatnonzero(op == 2)
+            got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little"))
+            mism += int(not np.array_equal(got, want))
         t_cpu = time.perf_counter() - t1
-        mism = sum(int(not np.array_equal(np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little")).astype(np.uint32), want[i])) for i in range(2))
-        out["parity"] = {"lookups_checked_against_oracle": 2, "mismatches": mism}
-        out["cpu_baseline"] = {"value": 2 / t_cpu, "unit": "lookups/s", "cores": 1, "kind": "port",
-                               "sample": "2 power users, brute-force definition {id : Check == HAS} over every pod, restated CPU oracle", "seconds": round(t_cpu, 2)}
-    if rank == 0:
-        print(json.dumps(out))
-    eng.close()
-    if out.get("parity", {}).get("mismatches"):
-        raise SystemExit("PARITY FAILURE: GPU lookup differs from the oracle")
+        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism}
+        out["cpu_baseline"] = {"value": subs.size / t_cpu, "unit": "lookups/s", "cores": nt, "kind": "port",
+                               "sample": f"all {subs.size} power users, by DEFINITION {{id : Check == HAS}} over every pod ({subs.size * npod} oracle checks over {nt} "
+                                         "threads); the restated oracle has no reverse walk, so this is a brute-force checker rather than a tuned CPU LookupResources",
+                               "seconds": round(t_cpu, 2)}
+    return out
 
 
 def c5_bench(args, w, world, rank, local_rank, t_gen):
@@ -322,6 +380,193 @@ def _local_edges(engine):
     return engine.stats().get("snapshot_edges_local", 0)
 
 
+def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None):
+    """All Check legs of one workload on one engine.  Returns (record, gpu_perm, gpu_err) -- the answers of batch 0."""
+    import torch
+    rt, perm_name, st = w.check
+    n = int(w.res.size)
+    NB = 8  # distinct pre-generated batches: rotations of the request stream (same mix, different items in every lane)
+    items0 = eng.make_items(rt, perm_name, w.res, st, "", w.subj)
+    rec = {"workload": WORKLOAD_DESC[label], "batch": n, "relationships": w.ntuples, "objects": int(sum(w.nobjects.values()))}
+
+    # ---------------- (i) device-resident, sequential, HIP events on: the roofline's kernel time
+    d_batches = [torch.from_numpy(np.roll(items0, b * 4099).view(np.uint8).copy()).cuda() for b in range(NB)]
+    d_perm = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    d_err = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for k in range(warmup):
+        eng.check_bulk_ids_device(d_batches[k % NB].data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
+    eng.stats_reset()
+    eng.set_timing(True)
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for k in range(steps):
+        t1 = time.perf_counter()
+        eng.check_bulk_ids_device(d_batches[(k + 1) % NB].data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
+        lat.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    el_dev = time.perf_counter() - t0
+    eng.set_timing(False)
+    st_dev = eng.stats()
+    eng.check_bulk_ids_device(d_batches[0].data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
+    gpu_perm, gpu_err = d_perm.cpu().numpy(), d_err.cpu().numpy()
+    launches = max(1, st_dev["expand_launches"])
+    rec["device_resident"] = {"decisions_per_s": n * steps / el_dev, "ms_per_batch": 1e3 * el_dev / steps, "p50_batch_ms": 1e3 * float(np.median(lat)),
+                              "kernel_ms_per_batch": st_dev["kernel_ms"] / steps, "expand_launches_per_batch": launches / steps,
+                              "note": "acl_check_bulk_ids_device: batch already in HBM, one call at a time"}
+    rec["levels"] = int(st_dev["levels_last"])
+    rec["has_fraction"] = float((gpu_perm == 2).mean())
+    if "device" == legs:
+        rec["value"] = rec["device_resident"]["decisions_per_s"]
+        rec["elapsed"] = el_dev
+        rec["kernel"] = {"expand_ms": st_dev["expand_ms"], "launches": launches}
+        return rec, gpu_perm, gpu_err
+
+    # ---------------- (ii) host ids, pipelined: THE timed region (`value`)
+    hb = eng.host_alloc(NB * n * 21)
+    h_items = hb[:NB * n * 16].view(aclgpu_item_dtype()).reshape(NB, n)
+    h_perm = hb[NB * n * 16:NB * n * 17].reshape(NB, n)
+    h_err = hb[NB * n * 17:].view(np.int32).reshape(NB, n)
+    for b in range(NB):
+        h_items[b] = np.roll(items0, b * 4099)
+    window = max(2, min(args.window, NB))
+
+    def pipelined(k_steps):
+        q = []
+        for k in range(k_steps):
+            if len(q) == window:
+                eng.wait(q.pop(0))
+            b = k % NB
+            q.append(eng.submit_ids(h_items[b], h_perm[b], h_err[b]))
+        for t in q:
+            eng.wait(t)
+
+    pipelined(max(warmup, window))
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipelined(steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    host_ok = bool(np.array_equal(h_perm[0], gpu_perm) and np.array_equal(h_err[0], gpu_err))
+    rec["value"] = n * steps / elapsed
+    rec["elapsed"] = elapsed
+    rec["pipelined_host_ids"] = {"decisions_per_s": n * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "window": window, "distinct_batches": NB,
+                                 "answers_equal_device_leg": host_ok,
+                                 "note": "acl_check_bulk_ids_submit/wait over pinned buffers: H2D + kernels + D2H, copies overlap other batches' kernels"}
+    # ---------------- batch latency: >= 200 single unpipelined host-id calls (SURVEY.md 8(d) "p50 over >= 200 batches after 20 warm-ups")
+    nl = max(200, steps)
+    lat = []
+    for k in range(20 + nl):
+        b = k % NB
+        t1 = time.perf_counter()
+        eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+        if k >= 20:
+            lat.append(time.perf_counter() - t1)
+    rec["latency"] = {"p50_batch_ms": 1e3 * float(np.median(lat)), "p95_batch_ms": 1e3 * float(np.percentile(lat, 95)), "batches": nl,
+                      "decisions_per_s_unpipelined": n / float(np.median(lat)), "note": "one acl_check_bulk_ids call at a time, pinned buffers (PCIe inclusive)"}
+    pg = [time.perf_counter()]
+    for _ in range(5):
+        eng.check_bulk_ids(items0)
+        pg.append(time.perf_counter())
+    rec["latency"]["pageable_buffers_p50_ms"] = 1e3 * float(np.median(np.diff(pg)))
+    eng.host_free(hb)
+    # ---------------- (iii) string path: named objects needed -> a NAMED copy of a slice would not be this graph; the engine's
+    # bulk loads are anonymous ids, so the string leg names the ids it asks about through acl_intern-free decimal names:
+    # unknown names resolve to "no relationships" -- what is timed is the host half (5 strings per item -> ids) + one pass.
+    m = min(n, 65536)
+    strs = eng.make_check_strings(rt, perm_name, w.res[:m], st, w.subj[:m])
+    t1 = time.perf_counter()
+    eng.check_bulk_prepared(strs)
+    t_str = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    eng.check_bulk_prepared(strs)
+    t_str = min(t_str, time.perf_counter() - t1)
+    rec["string_path"] = {"decisions_per_s": m / t_str, "ms_per_batch": 1e3 * t_str, "items": m,
+                          "note": "acl_check_bulk: 5 C strings per item interned on the host (parallel over host threads), then one pass; "
+                                  "object names are the decimal ids (bulk-loaded ids are anonymous: every name resolves to 'no relationships')"}
+    rec["kernel"] = {"expand_ms": st_dev["expand_ms"], "launches": launches}
+    return rec, gpu_perm, gpu_err
+
+
+def aclgpu_item_dtype():
+    import aclgpu
+    return aclgpu.ITEM_DTYPE
+
+
+def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
+    """CPU oracle on the same batch (parity + baseline) and the roofline from the oracle's byte model over the WHOLE batch."""
+    from oracle import orc
+    rt, perm_name, st = w.check
+    n = int(w.res.size)
+    t0 = time.time()
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    t_oload = time.time() - t0
+    # single thread: calibrate, then a bounded sample (prefix of the SAME batch)
+    m0 = min(n, 512)
+    t0 = time.perf_counter()
+    o.check_bulk_ids(rt, perm_name, w.res[:m0], st, "", w.subj[:m0])
+    per = (time.perf_counter() - t0) / m0
+    m = int(min(n, max(m0, min(args.cpu_seconds, 4.0) / max(per, 1e-9))))
+    t0 = time.perf_counter()
+    operm, oerr = o.check_bulk_ids(rt, perm_name, w.res[:m], st, "", w.subj[:m])
+    t_cpu = time.perf_counter() - t0
+    mism = int((operm != gpu_perm[:m]).sum() + (oerr != gpu_err[:m]).sum())
+    # all host cores: the whole batch split statically over threads (SURVEY.md 8(d) "CPU baseline beside it" (b));
+    # the box may expose more hardware threads than this container may use: keep the thread count that is fastest
+    cores = usable_cores()
+    best = (0.0, 1)
+    cm = min(n, 16384)
+    c_try = 4
+    while c_try <= cores:
+        t0 = time.perf_counter()
+        o.check_bulk_ids_mt(c_try, rt, perm_name, w.res[:cm], st, "", w.subj[:cm])
+        r_ = cm / (time.perf_counter() - t0)
+        if r_ > best[0]:
+            best = (r_, c_try)
+        c_try *= 2
+    cores = best[1]
+    t0 = time.perf_counter()
+    mperm, merr = o.check_bulk_ids_mt(cores, rt, perm_name, w.res, st, "", w.subj)  # EVERY answer of the batch is checked
+    t_mt = time.perf_counter() - t0
+    mism_mt = int((mperm != gpu_perm).sum() + (merr != gpu_err).sum())
+    rec["parity"] = {"checked_against_oracle": n, "mismatches": mism + mism_mt}
+    rec["cpu_baseline"] = {"value": n / t_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
+                           "sample": f"the whole {n}-item batch split statically over {cores} host threads, restated CPU oracle (not embedded SpiceDB)",
+                           "seconds": round(t_mt, 2), "load_s": round(t_oload, 2),
+                           "single_thread": {"value": m / t_cpu, "sample": f"first {m} items", "seconds": round(t_cpu, 2)}}
+    # algorithmic bytes (SURVEY.md 8(d) model) over the WHOLE batch, multi-threaded, with the per-level split
+    t0 = time.perf_counter()
+    tot, lvl_b, lvl_s = o.check_bytes_bulk(max(cores, 4), rt, perm_name, w.res, st, "", w.subj)
+    t_bytes = time.perf_counter() - t0
+    k = rec.pop("kernel")
+    steps = rec["_steps"]
+    ach = tot * steps / (k["expand_ms"] * 1e-3) / 1e9 if k["expand_ms"] > 0 else None
+    nz = int(np.flatnonzero(lvl_b)[-1]) + 1 if lvl_b.any() else 1
+    traffic = None
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            t_ = json.load(open(tr)).get(label)
+            if t_:
+                traffic = dict(t_, source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, NOT measured in this run")
+        except Exception:  # noqa: BLE001
+            pass
+    rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                       "kernel": "k_expand", "kernel_avg_us": 1e3 * k["expand_ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
+                       "measured_in": "device_resident leg (sequential launches, HIP events on the launching stream)",
+                       "algorithmic_bytes_per_check": tot / n, "algorithmic_bytes_per_batch": tot, "algorithmic_bytes_per_launch": tot * steps / k["launches"],
+                       "algorithmic_bytes_by_model_level": [int(x) for x in lvl_b[1:nz]], "distinct_states_by_model_level": [int(x) for x in lvl_s[1:nz]],
+                       "model": "oracle byte counter over all items (level-synchronous, sorted-row probes; the model's levels count every computed "
+                                "userset as a dispatch, the kernels inline them)", "model_seconds": round(t_bytes, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -332,6 +577,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
+                    "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
+    ap.add_argument("--window", type=int, default=4, help="batches in flight in the pipelined leg (<= the engine's evaluation contexts)")
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="also measure C2 and C3 in the same run (auto: at N=1 with the default workload)")
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "
                          "frontiers (north star's 8-GPU layout).  auto = on at 8 ranks.  Reported beside `value`, never as `value`.")
@@ -372,59 +621,34 @@ def main():
         w.res = w.res[perm]
         w.subj = np.roll(w.subj[perm], rank * 7919) if rank else w.subj[perm]
     t_gen = time.time() - t0
-    rt, perm_name, st = w.check
     n = int(w.res.size)
 
     if args.workload == "C5":
         return c5_bench(args, w, world, rank, local_rank, t_gen)
-    eng = aclgpu.Engine(w.schema, device=local_rank)
+    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window))
     t0 = time.time()
     w.load(eng)
     eng.snapshot()
     t_load = time.time() - t0
     if args.workload == "C3":
-        return filter_bench(args, w, eng, world, rank)
-    items = eng.make_items(rt, perm_name, w.res, st, "", w.subj)
-    d_items = torch.from_numpy(items.view(np.uint8).copy()).cuda()
-    d_perm = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    d_err = torch.zeros(n, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
+        out = filter_bench(args, w, eng, args.steps, args.warmup)
+        out.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": out.pop("workload"), "lookups_per_step": out.pop("lookups_per_step"), "relationships": out.pop("relationships"),
+                               "objects": out.pop("objects"), "scale": args.scale}})
+        if rank == 0:
+            print(json.dumps(out))
+        eng.close()
+        if out.get("parity", {}).get("mismatches"):
+            raise SystemExit("PARITY FAILURE: GPU lookup differs from the oracle")
+        return
 
-    def step():
-        eng.check_bulk_ids_device(d_items.data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
-        eng.sync()
-
-    for _ in range(args.warmup):
-        step()
-    eng.stats_reset()
-    eng.set_timing(True)  # HIP events around every engine kernel, on the engine's own stream
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lat = []
-    t_begin = time.perf_counter()
-    for _ in range(args.steps):
-        t1 = time.perf_counter()
-        step()
-        lat.append(time.perf_counter() - t1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_begin
-    eng.set_timing(False)
-    stats = eng.stats()
+    rec, gpu_perm, gpu_err = check_bench(args, w, eng, args.steps, args.warmup, world, rank, args.workload, args.legs, dist if world > 1 else None)
+    elapsed = rec.pop("elapsed")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    gpu_perm = d_perm.cpu().numpy()
-    gpu_err = d_err.cpu().numpy()
-    # (ii) of SURVEY.md 8(d): the ABI call that takes HOST buffers -- H2D of the items, kernels, D2H of perm/err (never `value`)
-    host_lat = []
-    for _ in range(5):
-        t1 = time.perf_counter()
-        eng.check_bulk_ids(items)
-        host_lat.append(time.perf_counter() - t1)
+    stats = eng.stats()
 
     # ---- extra leg (outside the timed region above): the sharded graph
     want_sharded = (args.sharded == "on" or (args.sharded == "auto" and world == 8)) and (world > 1 or args.logical_shards > 1)
@@ -432,86 +656,62 @@ def main():
     out = None
     if rank == 0:
         total = n * args.steps * world
-        launches = max(1, stats["expand_launches"])
+        rec.pop("value")
         out = {
             "metric": "check_decisions_per_sec", "value": total / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_DESC[args.workload], "batch_per_gpu": n, "relationships": w.ntuples,
-                       "objects": int(sum(w.nobjects.values())), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)"},
-            "p50_batch_ms": 1e3 * float(np.median(lat)), "p95_batch_ms": 1e3 * float(np.percentile(lat, 95)),
-            "has_fraction": float((gpu_perm == 2).mean()), "levels": int(stats["levels_last"]),
-            "expand_launches_per_batch": launches / args.steps, "kernel_ms_per_batch": stats["kernel_ms"] / args.steps,
+            "config": {"workload": rec.pop("workload"), "batch_per_gpu": rec.pop("batch"), "relationships": rec.pop("relationships"),
+                       "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)",
+                       "timed": "host-id ABI calls (H2D + kernels + D2H), pipelined over 8 distinct pinned batches" if args.legs == "all"
+                                else "device-resident calls only (--legs device)"},
+            "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
             "setup_s": {"generate": round(t_gen, 2), "load+snapshot": round(t_load, 2)},
             "snapshot_bytes": int(stats["snapshot_bytes"]),
-            "host_buffer_path": {"p50_batch_ms": 1e3 * float(np.median(host_lat)), "decisions_per_s": n / float(np.median(host_lat)),
-                                 "note": "acl_check_bulk_ids: pageable host items in, perm+err out (PCIe inclusive)"},
         }
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "k_expand", "kernel_avg_us": 1e3 * stats["expand_ms"] / launches}
-        cpu = None
+        kernel = rec.get("kernel")
+        out.update(rec)
         if world == 1 and not args.no_cpu:
-            from oracle import orc
-            t0 = time.time()
-            o = orc.Oracle(w.schema)
-            w.load(o)
-            o.freeze()
-            t_oload = time.time() - t0
-            # calibrate, then time a bounded sample of the SAME batch (prefix), single thread
-            m0 = min(n, 512)
-            t0 = time.perf_counter()
-            o.check_bulk_ids(rt, perm_name, w.res[:m0], st, "", w.subj[:m0])
-            per = (time.perf_counter() - t0) / m0
-            m = int(min(n, max(m0, args.cpu_seconds / max(per, 1e-9))))
-            t0 = time.perf_counter()
-            operm, oerr = o.check_bulk_ids(rt, perm_name, w.res[:m], st, "", w.subj[:m])
-            t_cpu = time.perf_counter() - t0
-            mism = int((operm != gpu_perm[:m]).sum() + (oerr != gpu_err[:m]).sum())
-            out["parity"] = {"checked_against_oracle": m, "mismatches": mism}
-            # all host cores: the same oracle, the whole batch split statically over threads (SURVEY.md 8(d) "CPU baseline beside it" (b))
-            cores = usable_cores()
-            # the box may expose more hardware threads than this container may use: keep the thread count that is fastest
-            best = (0.0, 1)
-            cm = min(n, 16384)
-            c_try = 4
-            while c_try <= cores:
-                t0 = time.perf_counter()
-                o.check_bulk_ids_mt(c_try, rt, perm_name, w.res[:cm], st, "", w.subj[:cm])
-                r_ = cm / (time.perf_counter() - t0)
-                if r_ > best[0]:
-                    best = (r_, c_try)
-                c_try *= 2
-            cores = best[1]
-            mm = int(min(n, max(m, best[0] * args.cpu_seconds)))
-            t0 = time.perf_counter()
-            mperm, merr = o.check_bulk_ids_mt(cores, rt, perm_name, w.res[:mm], st, "", w.subj[:mm])
-            t_mt = time.perf_counter() - t0
-            mism_mt = int((mperm != gpu_perm[:mm]).sum() + (merr != gpu_err[:mm]).sum())
-            out["parity"]["checked_against_oracle"] = max(m, mm)
-            out["parity"]["mismatches"] = mism + mism_mt
-            cpu = {"value": mm / t_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
-                   "sample": f"first {mm} of the {n}-item batch split statically over {cores} host threads, restated CPU oracle (not embedded SpiceDB)",
-                   "seconds": round(t_mt, 2), "load_s": round(t_oload, 2),
-                   "single_thread": {"value": m / t_cpu, "sample": f"first {m} items", "seconds": round(t_cpu, 2)}}
-            # algorithmic bytes per Check (SURVEY.md 8(d) model) from the oracle's counter on a sub-sample
-            mb = min(m, 4096)
-            tot = 0
-            for i in range(mb):
-                b, _r = o.check_bytes(rt, perm_name, int(w.res[i]), st, "", int(w.subj[i]))
-                tot += b
-            bytes_per_check = tot / mb
-            batch_bytes = bytes_per_check * n
-            ach = batch_bytes * args.steps / (stats["expand_ms"] * 1e-3) / 1e9 if stats["expand_ms"] > 0 else None
-            roof.update({"achieved": ach, "frac": (ach / HBM_PEAK_GBS) if ach else None, "algorithmic_bytes_per_check": bytes_per_check,
-                         "algorithmic_bytes_per_launch": batch_bytes * args.steps / launches})
-            tr = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tr):
-                try:
-                    roof["traffic"] = json.load(open(tr)).get(args.workload)
-                except Exception:  # noqa: BLE001
-                    pass
-        out["roofline"] = roof
-        out["cpu_baseline"] = cpu
+            out["_steps"] = args.steps
+            cpu_and_roofline(args, w, out, gpu_perm, gpu_err, args.workload)
+            out.pop("_steps")
+        else:
+            out.pop("kernel", None)
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_expand",
+                               "kernel_avg_us": 1e3 * kernel["expand_ms"] / kernel["launches"] if kernel else None,
+                               "note": "algorithmic bytes need the CPU oracle's byte model: rank 0 at N=1 only"}
+            out["cpu_baseline"] = None
+    eng.close()
+
+    # ---- the other single-GPU BASELINE configurations, same run (never part of `value`)
+    if rank == 0 and world == 1 and args.legs == "all" and (args.configs == "on" or (args.configs == "auto" and args.workload == "C4" and args.scale == 1.0 and not args.batch)):
+        cfgs = {}
+        try:
+            w2 = workloads.c2()
+            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window))
+            w2.load(e2)
+            e2.snapshot()
+            r2, p2, er2 = check_bench(args, w2, e2, max(args.steps, 50), args.warmup, 1, 0, "C2", "all")
+            r2.pop("elapsed")
+            r2["metric"], r2["unit"] = "check_decisions_per_sec", "decisions/s"
+            if not args.no_cpu:
+                r2["_steps"] = max(args.steps, 50)
+                cpu_and_roofline(args, w2, r2, p2, er2, "C2")
+                r2.pop("_steps")
+            else:
+                r2.pop("kernel", None)
+            e2.close()
+            cfgs["C2"] = r2
+            w3 = workloads.c3()
+            e3 = aclgpu.Engine(w3.schema, device=local_rank)
+            w3.load(e3)
+            e3.snapshot()
+            cfgs["C3"] = filter_bench(args, w3, e3, max(args.steps, 20), args.warmup)
+            e3.close()
+        except Exception as ex:  # noqa: BLE001 -- the headline line is printed whatever happens here
+            cfgs["error"] = f"{type(ex).__name__}: {ex}"
+        out["configs"] = cfgs
+
     # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
     # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.
     if want_sharded:
@@ -533,20 +733,23 @@ def main():
         timer = threading.Timer(180.0, on_timeout)
         timer.daemon = True
         timer.start()
+        eng_r = aclgpu.Engine(w.schema, device=local_rank)
+        w.load(eng_r)
         try:
-            emit(sharded_leg(args, w, eng, canon_res, canon_subj, world, rank, local_rank, sharded_result))
+            emit(sharded_leg(args, w, eng_r, canon_res, canon_subj, world, rank, local_rank, sharded_result))
         except Exception as ex:  # noqa: BLE001
             sharded_result["error"] = f"{type(ex).__name__}: {ex}"
             emit(sharded_result)
         finally:
             timer.cancel()
+            eng_r.close()
     elif rank == 0:
         print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if out and out.get("parity", {}).get("mismatches"):
+    bad = out and (out.get("parity", {}).get("mismatches") or any(isinstance(c, dict) and c.get("parity", {}).get("mismatches") for c in out.get("configs", {}).values()))
+    if bad:
         raise SystemExit("PARITY FAILURE: GPU answers differ from the oracle")
 
 

@@ -207,6 +207,30 @@ class Engine:
         self._check(self._L.acl_check_bulk_ids(self._h, items.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
         return perm[:n], err[:n]
 
+    def check_bulk_ids_into(self, items: np.ndarray, perm: np.ndarray, err: np.ndarray):
+        """acl_check_bulk_ids into caller-owned arrays (e.g. views of host_alloc memory: no staging copy)."""
+        self._check(self._L.acl_check_bulk_ids(self._h, items.ctypes.data, items.size, perm.ctypes.data, err.ctypes.data))
+
+    def make_check_strings(self, rtype, perm, res, stype, subj, srel=""):
+        """A prepared acl_check_item_t array whose object ids are the DECIMAL numeric ids (bench.py's string leg)."""
+        n = len(res)
+        arr = (CheckItem * max(1, n))()
+        rt, pm, st, sr = _b(rtype), _b(perm), _b(stype), _b(srel)
+        keep = []
+        for i in range(n):
+            a, b = str(int(res[i])).encode(), str(int(subj[i])).encode()
+            keep.append(a)
+            keep.append(b)
+            arr[i] = CheckItem(rt, a, pm, st, b, sr)
+        return arr, n, keep
+
+    def check_bulk_prepared(self, prepared):
+        arr, n, _keep = prepared
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_check_bulk(self._h, arr, n, perm.ctypes.data, err.ctypes.data))
+        return perm[:n], err[:n]
+
     @staticmethod
     def _opts(cancel=None, timeout_s=None):
         """cancel: a ctypes.c_int32 the caller sets non-zero to abandon the call (the C side of ctx.Done())."""
