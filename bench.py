@@ -579,7 +579,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
-    ap.add_argument("--window", type=int, default=4, help="batches in flight in the pipelined leg (<= the engine's evaluation contexts)")
+    ap.add_argument("--window", type=int, default=2, help="batches in flight in the pipelined leg (<= the engine's evaluation contexts)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="also measure C2 and C3 in the same run (auto: at N=1 with the default workload)")
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "

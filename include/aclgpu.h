@@ -205,6 +205,16 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int s
 int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);
+/* PostFilter at LIST level: filterListResponse (postfilter.go:17-55).  body = the kube list response (JSON).  Every element
+ * of its "items" array gets one check per template, rendered from the item's metadata: placeholders {{name}}, {{namespace}},
+ * {{namespacedName}} (namespace/name, or name when cluster scoped) and {{user.name}} inside `type:id#perm@type:id[#rel]`
+ * (the form of deploy/rules.yaml:68; richer rule expressions resolve in Go and use acl_check_bulk_keep).  A template that
+ * does not resolve for an item contributes no check (postfilter.go:92-95); an item is kept iff all its checks are
+ * HAS_PERMISSION (postfilter.go:144-178).  *out_body (release with acl_free) is the ORIGINAL document with the dropped
+ * items' bytes cut out ("items": null when none is left, as the reference's nil slice marshals); a body without an
+ * "items" array, or with an empty one, comes back unchanged (postfilter.go:26-35).  Invalid JSON: ACL_ERR_INVALID_ARGUMENT. */
+int acl_filter_list_response(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates,
+                             const char *user_name, char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out);
 /* PreFilter: prefilterResult.IsAllowed (lookups.go:25-36; consumers responsefilterer.go:349-415) over the bitmap of
  * acl_lookup_resources*: allowed_out[i] = 1 iff object_ids[i] (the rule's `ns/name` object id text) is set. */
 int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *const *object_ids, size_t n,

@@ -25,7 +25,7 @@ SYMBOLS = [
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
-    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream",
+    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response",
 ]
 
 
@@ -149,6 +149,8 @@ def load():
     L.acl_host_free.argtypes = [H, C.c_void_p]
     L.acl_lookup_resources_alloc.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CallOpts),
                                              C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    L.acl_filter_list_response.argtypes = [H, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_free.argtypes = [C.c_void_p]
     L.acl_free.restype = None
     L.acl_check_one_opts.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(CallOpts)]

@@ -33,7 +33,7 @@ int alloc_frontier(acl_engine *h, PassCtx *c, uint64_t entries) {
     // every wave of an expand launch owns one static chunk; at least one dynamic chunk on top
     entries = std::max<uint64_t>(entries, ((uint64_t)h->grid_blocks * kWavesPerBlock + 1) * kChunk);
     uint64_t chunks = (entries + kChunk - 1) / kChunk;
-    if (chunks > 0x3FFFFFu) chunks = 0x3FFFFFu;  // entry indices stay below 2^32
+    if (chunks > kMaxFrontierChunks) chunks = kMaxFrontierChunks;  // byte offsets of entries stay below 2^32 (kernels.hip gld / gst)
     for (int i = 0; i < 2; i++) {
         c->d_fbuf[i].release();
         c->d_fcounts[i].release();
@@ -145,6 +145,8 @@ int ensure_snapshot(acl_engine *h) {
                 if (e1 != hipSuccess) pe = e1;
             }
             if (pe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("snapshot patch upload: ") + hipGetErrorString(pe));
+            if (std::max({h->snap.meta.size(), h->snap.edges.size(), h->snap.buckets.size()}) >= ((size_t)1 << 30))
+                return fail(ACL_ERR_RESOURCE_EXHAUSTED, "snapshot array beyond 4 GiB (more than ~1 G relationships in one array): shard the graph (acl_shard_configure)");
             if (!fits) {  // an array outgrew its device allocation: the host copy is already exact, upload it whole
                 HIP_TRY(h->d_meta.upload(h->snap.meta, s));
                 HIP_TRY(h->d_edges.upload(h->snap.edges, s));
@@ -171,6 +173,9 @@ int ensure_snapshot(acl_engine *h) {
     h->rev_uploaded = false;
     build_forward(h->store, now, &h->snap, h->shard);
     h->snap_valid = true;
+    // the kernels address every snapshot array as base + 32-bit byte offset (kernels.hip gld): refuse what does not fit
+    if (std::max({h->snap.meta.size(), h->snap.edges.size(), h->snap.buckets.size()}) >= ((size_t)1 << 30))
+        return fail(ACL_ERR_RESOURCE_EXHAUSTED, "snapshot array beyond 4 GiB (more than ~1 G relationships in one array): shard the graph (acl_shard_configure)");
     HIP_TRY(h->d_meta.upload(h->snap.meta, s));
     HIP_TRY(h->d_edges.upload(h->snap.edges, s));
     HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
@@ -346,7 +351,7 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
         if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
             // frontier out of chunks: grow (up to 2^32 entries) and redo the pass
             c->stats.overflow_retries++;
-            if (c->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8)
+            if (c->frontier_entries >= (uint64_t)kMaxFrontierChunks * kChunk || attempt > 8)
                 return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded (" + std::to_string(c->frontier_entries) + " entries); lower max_sub_batch");
             int rc2 = alloc_frontier(h, c, c->frontier_entries * 4);
             if (rc2) return rc2;
@@ -561,7 +566,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
             });
             if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
                 c->stats.overflow_retries++;
-                if (c->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
+                if (c->frontier_entries >= (uint64_t)kMaxFrontierChunks * kChunk || attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded in lookup");
                 int rc2 = alloc_frontier(h, c, c->frontier_entries * 4);
                 if (rc2) return rc2;
                 continue;

@@ -4,6 +4,8 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <sched.h>
+
 #include <climits>
 #include <tuple>
 
@@ -183,7 +185,7 @@ Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, siz
 int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
     acl_engine::Batcher &B = *h->batcher;
     const bool watched = opts.cancel || opts.deadline_ns;
-    if (B.sleepers.load(std::memory_order_relaxed) * 2 < B.cores) {
+    if ((B.sleepers.load(std::memory_order_relaxed) + 4) * 2 < B.cores) {  // (+ the dispatchers, which spin in their stream syncs)
         const int64_t spin_until = mono_ns() + 30000;
         B.sleepers.fetch_add(1, std::memory_order_relaxed);
         while (!b->done.load(std::memory_order_acquire) && mono_ns() < spin_until) {
@@ -209,6 +211,21 @@ int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
         B.sleepers.fetch_sub(1, std::memory_order_relaxed);
     }
     return ACL_OK;
+}
+
+// hardware threads this process may actually use: affinity mask, capped by the cgroup CPU quota (a container on a
+// 256-thread box may be allowed 16 cores' worth of time: spinning there burns the quota every thread shares)
+unsigned usable_cores() {
+    unsigned c = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) c = std::min<unsigned>(c, (unsigned)std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long per = 0;
+        if (std::fscanf(f, "%31s %ld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) c = std::min<unsigned>(c, (unsigned)std::max(1L, (std::atol(q) + per / 2) / per));
+        std::fclose(f);
+    }
+    return c;
 }
 
 CallOpts to_opts(const acl_call_opts_t *o) {
@@ -391,10 +408,11 @@ int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us)
     if (!B.threads.empty()) return fail(ACL_ERR_FAILED_PRECONDITION, "batcher already running");
     B.max_items = max_items ? max_items : 4096;
     B.wait_us = max_wait_us;
-    B.cores = std::max(1u, std::thread::hardware_concurrency());
+    B.cores = usable_cores();
     B.stop = false;
-    // one dispatcher per evaluation context the engine may open (store-only engines: one, it only reports the error)
-    const uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>(h->max_ctx, 4));
+    // one dispatcher per evaluation context the engine may open, but no more than a quarter of the usable cores (a
+    // dispatcher's stream synchronisation spins); store-only engines: one, it only reports the error
+    const uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({h->max_ctx, 4u, std::max(1u, B.cores / 4)}));
     for (uint32_t i = 0; i < nd; i++) B.threads.emplace_back(dispatcher_loop, h);
     return ACL_OK;
 }

@@ -1,0 +1,349 @@
+// engine_list.cpp -- PostFilter at LIST level: the reference's filterListResponse (pkg/authz/postfilter.go:17-55) over the
+// kube list response's bytes.
+//
+// Reference flow: json.Unmarshal(body) -> items[] -> for every item and every PostFilter template resolve
+// `type:id#perm@type:id` from the item's metadata.name / metadata.namespace (postfilter.go:73-119) -> ONE
+// CheckBulkPermissions (postfilter.go:134) -> keep the items whose pairs are all HAS_PERMISSION (postfilter.go:144-178)
+// -> json.Marshal.  Here the body is scanned once for the item spans and their metadata, the K x F resolved pairs go
+// through acl_check_bulk_keep (one device pass), and the answer is the ORIGINAL bytes with the dropped items' spans cut
+// out -- no generic decode / re-encode of a body that can be many megabytes.  (The reference's re-marshal sorts object
+// keys; the spliced document is the same JSON value for every key order, which is what kube clients parse.)
+//
+// Templates: the general rule language (Bloblang / CEL, pkg/rules) stays in Go (out of scope); this entry
+// point renders the placeholder form every shipped rule uses (deploy/rules.yaml:68 `pod:{{namespacedName}}#view@user:{{user.name}}`):
+// {{name}} {{namespace}} {{namespacedName}} {{user.name}}.  Rules that need more resolve in Go and call acl_check_bulk_keep.
+#include "engine_internal.hpp"
+
+namespace {
+
+struct Scanner {
+    const char *p, *e;
+    bool ok = true;
+    void ws() {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++;
+    }
+    bool fail() {
+        ok = false;
+        return false;
+    }
+    static void utf8(std::string *o, uint32_t c) {
+        if (c < 0x80) o->push_back((char)c);
+        else if (c < 0x800) { o->push_back((char)(0xC0 | (c >> 6))); o->push_back((char)(0x80 | (c & 0x3F))); }
+        else if (c < 0x10000) { o->push_back((char)(0xE0 | (c >> 12))); o->push_back((char)(0x80 | ((c >> 6) & 0x3F))); o->push_back((char)(0x80 | (c & 0x3F))); }
+        else { o->push_back((char)(0xF0 | (c >> 18))); o->push_back((char)(0x80 | ((c >> 12) & 0x3F))); o->push_back((char)(0x80 | ((c >> 6) & 0x3F))); o->push_back((char)(0x80 | (c & 0x3F))); }
+    }
+    bool hex4(uint32_t *v) {
+        if (e - p < 4) return fail();
+        uint32_t x = 0;
+        for (int i = 0; i < 4; i++) {
+            const char c = p[i];
+            x <<= 4;
+            if (c >= '0' && c <= '9') x |= (uint32_t)(c - '0');
+            else if (c >= 'a' && c <= 'f') x |= (uint32_t)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') x |= (uint32_t)(c - 'A' + 10);
+            else return fail();
+        }
+        p += 4;
+        *v = x;
+        return true;
+    }
+    // at '"'; decodes into out when not null
+    bool string(std::string *out) {
+        if (p >= e || *p != '"') return fail();
+        p++;
+        while (p < e && *p != '"') {
+            if ((unsigned char)*p < 0x20) return fail();
+            if (*p != '\\') {
+                if (out) out->push_back(*p);
+                p++;
+                continue;
+            }
+            if (++p >= e) return fail();
+            const char c = *p++;
+            uint32_t u = 0;
+            switch (c) {
+                case '"': case '\\': case '/': if (out) out->push_back(c); break;
+                case 'b': if (out) out->push_back('\b'); break;
+                case 'f': if (out) out->push_back('\f'); break;
+                case 'n': if (out) out->push_back('\n'); break;
+                case 'r': if (out) out->push_back('\r'); break;
+                case 't': if (out) out->push_back('\t'); break;
+                case 'u':
+                    if (!hex4(&u)) return false;
+                    if (u >= 0xD800 && u < 0xDC00 && e - p >= 6 && p[0] == '\\' && p[1] == 'u') {  // surrogate pair
+                        const char *save = p;
+                        p += 2;
+                        uint32_t lo = 0;
+                        if (!hex4(&lo)) return false;
+                        if (lo >= 0xDC00 && lo < 0xE000) u = 0x10000 + ((u - 0xD800) << 10) + (lo - 0xDC00);
+                        else { p = save; u = 0xFFFD; }
+                    } else if (u >= 0xD800 && u < 0xE000) u = 0xFFFD;  // lone surrogate: Go substitutes U+FFFD
+                    if (out) utf8(out, u);
+                    break;
+                default: return fail();
+            }
+        }
+        if (p >= e) return fail();
+        p++;
+        return true;
+    }
+    bool literal(const char *w) {
+        const size_t n = std::strlen(w);
+        if ((size_t)(e - p) < n || std::memcmp(p, w, n) != 0) return fail();
+        p += n;
+        return true;
+    }
+    bool number() {
+        const char *s = p;
+        if (p < e && *p == '-') p++;
+        while (p < e && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
+        return p > s ? true : fail();
+    }
+    // skips any value; depth-limited like encoding/json (10000)
+    bool skip(int depth = 0) {
+        ws();
+        if (p >= e || depth > 10000) return fail();
+        switch (*p) {
+            case '"': return string(nullptr);
+            case '{': {
+                p++;
+                ws();
+                if (p < e && *p == '}') { p++; return true; }
+                for (;;) {
+                    ws();
+                    if (!string(nullptr)) return false;
+                    ws();
+                    if (p >= e || *p++ != ':') return fail();
+                    if (!skip(depth + 1)) return false;
+                    ws();
+                    if (p < e && *p == ',') { p++; continue; }
+                    if (p < e && *p == '}') { p++; return true; }
+                    return fail();
+                }
+            }
+            case '[': {
+                p++;
+                ws();
+                if (p < e && *p == ']') { p++; return true; }
+                for (;;) {
+                    if (!skip(depth + 1)) return false;
+                    ws();
+                    if (p < e && *p == ',') { p++; continue; }
+                    if (p < e && *p == ']') { p++; return true; }
+                    return fail();
+                }
+            }
+            case 't': return literal("true");
+            case 'f': return literal("false");
+            case 'n': return literal("null");
+            default: return number();
+        }
+    }
+    // at '{': calls on_key(key) positioned at the value; on_key must consume the value
+    template <typename F>
+    bool object(F on_key) {
+        if (p >= e || *p != '{') return fail();
+        p++;
+        ws();
+        if (p < e && *p == '}') { p++; return true; }
+        for (;;) {
+            ws();
+            std::string key;
+            if (!string(&key)) return false;
+            ws();
+            if (p >= e || *p++ != ':') return fail();
+            ws();
+            if (!on_key(key)) return false;
+            ws();
+            if (p < e && *p == ',') { p++; continue; }
+            if (p < e && *p == '}') { p++; return true; }
+            return fail();
+        }
+    }
+};
+
+struct Item {
+    size_t b, e;  // span of the element in the body
+    bool is_object = false, has_meta = false;
+    std::string name, ns;
+};
+
+// the item's metadata.name / metadata.namespace when they are strings (postfilter.go:73-85); later duplicates win, as in Go's map decode
+bool scan_item(Scanner &s, Item *it) {
+    s.ws();
+    if (s.p < s.e && *s.p == '{') {
+        it->is_object = true;
+        return s.object([&](const std::string &k) {
+            if (k != "metadata" || s.p >= s.e || *s.p != '{') {
+                if (k == "metadata") it->has_meta = false;  // a later non-object "metadata" replaces an earlier object
+                return s.skip();
+            }
+            it->has_meta = true;
+            it->name.clear();
+            it->ns.clear();
+            return s.object([&](const std::string &mk) {
+                if ((mk == "name" || mk == "namespace") && s.p < s.e && *s.p == '"') {
+                    std::string v;
+                    if (!s.string(&v)) return false;
+                    (mk == "name" ? it->name : it->ns) = v;
+                    return true;
+                }
+                if (mk == "name") it->name.clear();
+                if (mk == "namespace") it->ns.clear();
+                return s.skip();
+            });
+        });
+    }
+    return s.skip();
+}
+
+// renders one template for one item; false = "failed to resolve" (the item then gets no check from this template: postfilter.go:92-95)
+bool render(const std::string &tpl, const Item &it, const std::string &user, std::string *out) {
+    out->clear();
+    size_t i = 0;
+    while (i < tpl.size()) {
+        const size_t o = tpl.find("{{", i);
+        if (o == std::string::npos) {
+            out->append(tpl, i, std::string::npos);
+            break;
+        }
+        out->append(tpl, i, o - i);
+        const size_t c = tpl.find("}}", o + 2);
+        if (c == std::string::npos) return false;
+        std::string var = tpl.substr(o + 2, c - o - 2);
+        const size_t a = var.find_first_not_of(" \t"), z = var.find_last_not_of(" \t");
+        var = a == std::string::npos ? "" : var.substr(a, z - a + 1);
+        if (var == "name") out->append(it.name);
+        else if (var == "namespace") out->append(it.ns);
+        else if (var == "namespacedName") out->append(it.ns.empty() ? it.name : it.ns + "/" + it.name);
+        else if (var == "user.name") out->append(user);
+        else return false;  // anything richer is the Go rule engine's business
+        i = c + 2;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int acl_filter_list_response(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates, const char *user_name,
+                             char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out) {
+    if (!body || !out_body || !out_len || (n_templates && !templates)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_filter_list_response: NULL argument");
+    *out_body = nullptr;
+    *out_len = 0;
+    auto unchanged = [&](uint64_t n) {
+        char *o = (char *)std::malloc(std::max<size_t>(body_len, 1));
+        if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
+        std::memcpy(o, body, body_len);
+        *out_body = o;
+        *out_len = body_len;
+        if (kept_out) *kept_out = n;
+        if (total_out) *total_out = n;
+        return (int)ACL_OK;
+    };
+    // ---- one scan: the top-level object's "items" array and its elements
+    Scanner s{body, body + body_len};
+    s.ws();
+    std::vector<Item> items;
+    bool have_items = false;
+    size_t arr_open = 0, arr_close = 0;  // positions of '[' and ']'
+    if (s.p >= s.e || *s.p != '{') return fail(ACL_ERR_INVALID_ARGUMENT, "failed to parse list response: not a JSON object");
+    const bool parsed = s.object([&](const std::string &k) {
+        if (k != "items" || s.p >= s.e || *s.p != '[') {
+            if (k == "items") have_items = false;
+            return s.skip();
+        }
+        have_items = true;
+        items.clear();
+        arr_open = (size_t)(s.p - body);
+        s.p++;
+        s.ws();
+        if (s.p < s.e && *s.p == ']') {
+            arr_close = (size_t)(s.p - body);
+            s.p++;
+            return true;
+        }
+        for (;;) {
+            s.ws();
+            Item it;
+            const char *b0 = s.p;
+            if (!scan_item(s, &it)) return false;
+            it.b = (size_t)(b0 - body);
+            it.e = (size_t)(s.p - body);
+            items.push_back(std::move(it));
+            s.ws();
+            if (s.p < s.e && *s.p == ',') { s.p++; continue; }
+            if (s.p < s.e && *s.p == ']') {
+                arr_close = (size_t)(s.p - body);
+                s.p++;
+                return true;
+            }
+            return s.fail();
+        }
+    });
+    s.ws();
+    if (!parsed || !s.ok || s.p != s.e) return fail(ACL_ERR_INVALID_ARGUMENT, "failed to parse list response: invalid JSON");
+    if (!have_items || items.empty()) return unchanged(0);  // postfilter.go:26-35: nothing to filter, the body stays as it is
+    // ---- resolve K x F pairs
+    const std::string user = user_name ? user_name : "";
+    std::vector<std::string> tpls(templates, templates + n_templates);
+    std::vector<RelText> rels;
+    std::vector<uint32_t> off(items.size() + 1, 0);
+    std::string text;
+    for (size_t i = 0; i < items.size(); i++) {
+        off[i] = (uint32_t)rels.size();
+        if (!items[i].is_object) continue;  // postfilter.go:68-71
+        for (const std::string &t : tpls) {
+            RelText r;
+            if (!render(t, items[i], user, &text) || !parse_relationship_text(text, &r)) continue;  // resolution failed: no check (postfilter.go:92-95)
+            rels.push_back(std::move(r));
+        }
+    }
+    off[items.size()] = (uint32_t)rels.size();
+    if (rels.empty()) return unchanged(items.size());  // postfilter.go:122-125
+    std::vector<acl_check_item_t> ci(rels.size());
+    for (size_t k = 0; k < rels.size(); k++)
+        ci[k] = acl_check_item_t{rels[k].rtype.c_str(), rels[k].rid.c_str(), rels[k].rel.c_str(), rels[k].stype.c_str(), rels[k].sid.c_str(), rels[k].srel.c_str()};
+    std::vector<uint8_t> keep(items.size());
+    int rc = acl_check_bulk_keep(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
+    if (rc) return rc;
+    // ---- splice: the original bytes minus the dropped items
+    size_t kept = 0, bytes = arr_open + 1 + (body_len - arr_close);
+    for (size_t i = 0; i < items.size(); i++)
+        if (keep[i]) {
+            kept++;
+            bytes += items[i].e - items[i].b + 1;
+        }
+    char *o = (char *)std::malloc(std::max<size_t>(bytes, 1) + 8), *w = o;
+    if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
+    if (!kept) {
+        // the reference appends to a nil slice (postfilter.go:142): with nothing allowed, "items" marshals as null
+        std::memcpy(w, body, arr_open);
+        w += arr_open;
+        std::memcpy(w, "null", 4);
+        w += 4;
+        std::memcpy(w, body + arr_close + 1, body_len - arr_close - 1);
+        w += body_len - arr_close - 1;
+    } else {
+        std::memcpy(w, body, arr_open + 1);
+        w += arr_open + 1;
+        bool first = true;
+        for (size_t i = 0; i < items.size(); i++) {
+            if (!keep[i]) continue;
+            if (!first) *w++ = ',';
+            first = false;
+            std::memcpy(w, body + items[i].b, items[i].e - items[i].b);
+            w += items[i].e - items[i].b;
+        }
+        std::memcpy(w, body + arr_close, body_len - arr_close);
+        w += body_len - arr_close;
+    }
+    *out_body = o;
+    *out_len = (size_t)(w - o);
+    if (kept_out) *kept_out = kept;
+    if (total_out) *total_out = items.size();
+    return ACL_OK;
+}
+
+}  // extern "C"

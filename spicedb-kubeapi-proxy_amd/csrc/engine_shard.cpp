@@ -137,7 +137,7 @@ int acl_shard_grow_frontier(acl_engine_t *h) {
     ShardCall sc;
     int rc = sc.begin(h, false, false);
     if (rc) return rc;
-    if (sc.c->frontier_entries >= (uint64_t)0x3FFFFFu * kChunk) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded");
+    if (sc.c->frontier_entries >= (uint64_t)kMaxFrontierChunks * kChunk) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded");
     sc.c->stats.overflow_retries++;
     return alloc_frontier(h, sc.c, sc.c->frontier_entries * 4);
 }

@@ -113,11 +113,14 @@ struct TaskLds {
 //   chunked (k_expand, k_rev_expand): the wave starts on its static chunk (id = wave index); when that is full it closes it
 //            (count store) and takes a dynamic chunk from the level's counter;
 //   LOCAL   (k_check_local): a linear wave-private region [cur, cur + cap) of the frontier buffer.
+struct WaveOutCold {  // what only the chunk switch / overflow paths need: kept in LDS, not in ~10 SGPRs for the whole kernel
+    uint32_t *counts, *nchunks, *overflow;
+    uint32_t nwaves, max_chunks, cap;
+};
 struct WaveOut {
     uint4 *buf;
     uint32_t cur, fill, produced;
-    uint32_t *counts, *nchunks, *overflow;
-    uint32_t nwaves, max_chunks, cap;
+    WaveOutCold *cold;  // LDS
 };
 
 // room for `need` (<= 64) consecutive entries; returns the first entry index
@@ -125,8 +128,8 @@ template <bool LOCAL>
 __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane) {
     if (wo.cur == kNoSpace) return kNoSpace;
     if (LOCAL) {
-        if (wo.fill + need > wo.cap) {
-            if (lane == 0) *wo.overflow = 1u;
+        if (wo.fill + need > wo.cold->cap) {
+            if (lane == 0) *wo.cold->overflow = 1u;
             wo.cur = kNoSpace;
             return kNoSpace;
         }
@@ -136,12 +139,13 @@ __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t
         return base;
     }
     if (wo.fill + need > kChunk) {
-        if (lane == 0) wo.counts[wo.cur] = wo.fill;
+        const WaveOutCold k = *wo.cold;
+        if (lane == 0) k.counts[wo.cur] = wo.fill;
         uint32_t c = 0;
-        if (lane == 0) c = atomicAdd(wo.nchunks, 1u);
-        c = uniform(c) + wo.nwaves;
-        if (c >= wo.max_chunks) {
-            if (lane == 0) *wo.overflow = 1u;
+        if (lane == 0) c = atomicAdd(k.nchunks, 1u);
+        c = uniform(c) + k.nwaves;
+        if (c >= k.max_chunks) {
+            if (lane == 0) *k.overflow = 1u;
             wo.cur = kNoSpace;
             return kNoSpace;
         }
@@ -154,15 +158,27 @@ __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t
     return base;
 }
 
+// Gathers address their tables as `scalar base + 32-bit byte offset` (global_load ... v_off, s[base:base+1]): one address VGPR
+// per load in flight instead of a 64-bit pair.  The host guarantees every snapshot array and frontier buffer stays below
+// 4 GiB (plan.cpp / alloc_frontier fail loudly beyond), which is > 1 G relationships per sorted array.
+template <typename T>
+__device__ __forceinline__ T gld(const T *__restrict__ base, uint32_t idx) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ void gst(T *__restrict__ base, uint32_t idx, const T &v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (uint32_t)(idx * (uint32_t)sizeof(T))) = v;
+}
+
 // sorted sub-row (ids ascending; bit 31 of an edge is the leaf flag, not part of the id)
 __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges, uint32_t lo, uint32_t hi, uint32_t key) {
     uint32_t end = hi;
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        if ((edges[mid] & kIdMask) < key) lo = mid + 1;
+        if ((gld(edges, mid) & kIdMask) < key) lo = mid + 1;
         else hi = mid;
     }
-    return lo < end && (edges[lo] & kIdMask) == key;
+    return lo < end && (gld(edges, lo) & kIdMask) == key;
 }
 
 // hashed row: nb = b1 - b0 buckets of 4 ids, two-choice placement (plan.hpp hashed_row_buckets): the id is in bucket h1
@@ -171,8 +187,8 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
 __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
     uint32_t h1, h2;
     hashed_row_buckets(want, b1 - b0, &h1, &h2);
-    const uint4 p = buckets[b0 + h1];
-    const uint4 q = buckets[b0 + h2];
+    const uint4 p = gld(buckets, b0 + h1);
+    const uint4 q = gld(buckets, b0 + h2);
     return p.x == want || p.y == want || p.z == want || p.w == want || q.x == want || q.y == want || q.z == want || q.w == want;
 }
 
@@ -182,7 +198,7 @@ __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ bu
 // and the same few bucket lines instead of 64 different resource rows.
 __device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const FwdOp &op, uint32_t id, uint32_t sid) {
     if (sid >= op.nrows) return false;
-    const uint2 md = reinterpret_cast<const uint2 *>(g.meta)[op.base + sid];
+    const uint2 md = gld(reinterpret_cast<const uint2 *>(g.meta), op.base + sid);
     return md.y > md.x && bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, id);
 }
 
@@ -191,10 +207,10 @@ __device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const Fw
 // the record in five VGPRs across the expansions -- that cache was what kept the kernel above 96 VGPRs.
 __device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, uint32_t id) {
     if (op.K == 2) {
-        const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(op.base >> 1) + id];
+        const uint4 v = gld(reinterpret_cast<const uint4 *>(g.meta), (op.base >> 1) + id);
         return op.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
     }
-    return reinterpret_cast<const uint2 *>(g.meta)[op.base + (size_t)id * op.K + op.k];
+    return gld(reinterpret_cast<const uint2 *>(g.meta), op.base + id * op.K + op.k);
 }
 
 // Child mode: evaluate every probe of state (slot, id) at `level` for subject (key, sid) without creating tasks.
@@ -247,128 +263,152 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_SIMPLE_WIDTH 3  // A/B on C4 (tools/ab.sh): width 2 380 M/s, 3 398 M/s (5 waves/SIMD); 3 or 4 at 4 waves/SIMD 353-369 M/s
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
-// Returns the number of tasks it did NOT expand (their subject's row does not fit an LDS slot: rare), compacted to the front of
-// the task list for the generic path.
-template <bool SHARDED, bool LOCAL>
-__device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
-                                                  uint8_t *has, uint8_t *err) {
+// The children steps of flush_simple.  STAGED: every task's subject row sits in an LDS slot (two 16 B LDS reads per child);
+// otherwise descriptor + two bucket gathers per child in global memory, branch-free, W children per lane in flight.
+template <bool STAGED, int W, bool LOCAL>
+__device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+                                              uint8_t *has, uint8_t *err) {
     const uint32_t *__restrict__ edges = g.edges;
     const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     uint4 *__restrict__ out = wo.buf;
-    // task i is looked after by lane i (A half) or lane i - 64 (B half)
-    const bool inA = lane < T, inB = lane + 64 < T;
-    const uint32_t sidA = inA ? t.sid[lane] : 0u, sidB = inB ? t.sid[lane + 64] : 0u;
-    uint64_t todoA = __ballot(inA), todoB = __ballot(inB);  // tasks not expanded yet
-    uint64_t leftA = 0, leftB = 0;                          // tasks left to the generic path
-    // Rounds: each stages the hashed rows of up to kRowSlots distinct subjects in LDS and expands the tasks of those subjects.
-    // A wave's tasks belong to a handful of requests (children of one request are neighbours in the frontier): usually one round.
-    while (todoA | todoB) {
-        uint32_t slotA = kNoRowSlot, slotB = kNoRowSlot, mysid = 0, ns = 0;
-        {
-            uint64_t pa = todoA, pb = todoB;
-            while ((pa | pb) && ns < kRowSlots) {
-                const uint32_t s0 = pa ? (uint32_t)__builtin_amdgcn_readlane((int)sidA, __ffsll((unsigned long long)pa) - 1)
-                                       : (uint32_t)__builtin_amdgcn_readlane((int)sidB, __ffsll((unsigned long long)pb) - 1);
-                const bool mA = ((pa >> lane) & 1ull) && sidA == s0, mB = ((pb >> lane) & 1ull) && sidB == s0;
-                if (mA) slotA = ns;
-                if (mB) slotB = ns;
-                pa &= ~__ballot(mA);
-                pb &= ~__ballot(mB);
-                if (lane == ns) mysid = s0;
-                ns++;
+    for (uint32_t gq = 0; gq < T; gq += 64) {
+        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        t.scan[lane] = incl - cnt;
+        wave_lds_fence();
+        for (uint32_t w0 = 0; w0 < total; w0 += 64 * W) {
+            bool valid[W];
+            uint32_t tj[W], edge[W];
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const uint32_t w = w0 + 64u * k + lane;
+                valid[k] = w < total;
+                const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+                uint32_t j = 0;
+#pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1)
+                    if (t.scan[j + step] <= wv) j += step;
+                tj[k] = gq + j;
+                edge[k] = gld(edges, t.start[tj[k]] + (wv - t.scan[j]));
             }
-        }
-        // trip 1: the subjects' row descriptors (lane k holds subject k)
-        const bool own = lane < ns && mysid < pop.nrows;
-        uint2 d = smeta[pop.base + (own ? mysid : 0u)];
-        if (!own) d = make_uint2(0, 0);
-        const uint32_t nb = d.y > d.x ? d.y - d.x : 0u;
-        if (lane < ns) t.rnb[lane] = nb;
-        // trip 2: the rows themselves, four subjects per load instruction (16 lanes x 16 B each, coalesced)
+            bool contains[W];
+            if (STAGED) {
 #pragma unroll
-        for (uint32_t pass = 0; pass < kRowSlots / 4; pass++) {
-            const uint32_t k = pass * 4 + (lane >> 4), i = lane & 15u;
-            const uint32_t b0 = (uint32_t)__shfl((int)d.x, (int)k, 64), n = (uint32_t)__shfl((int)nb, (int)k, 64);
-            const bool ld = k < ns && n <= kRowCap && i < n;
-            const uint4 v = buckets[ld ? b0 + i : 0u];
-            if (ld) t.rows[k][i] = v;
-        }
-        // this round's tasks; the ones whose row is too long for a slot go to the generic path
-        const uint32_t nbA = (uint32_t)__shfl((int)nb, (int)(slotA & 7u), 64), nbB = (uint32_t)__shfl((int)nb, (int)(slotB & 7u), 64);
-        const bool asgA = slotA != kNoRowSlot, asgB = slotB != kNoRowSlot;
-        const bool actA = asgA && nbA <= kRowCap, actB = asgB && nbB <= kRowCap;
-        leftA |= __ballot(asgA && !actA);
-        leftB |= __ballot(asgB && !actB);
-        todoA &= ~__ballot(asgA);
-        todoB &= ~__ballot(asgB);
-        if (actA) t.count[lane] = (t.count[lane] & ~(15u << kRowSlotShift)) | (slotA << kRowSlotShift);
-        if (actB) t.count[lane + 64] = (t.count[lane + 64] & ~(15u << kRowSlotShift)) | (slotB << kRowSlotShift);
-        for (uint32_t gq = 0; gq < T; gq += 64) {
-            const bool act = gq ? actB : actA;
-            const uint32_t cnt = act ? (t.count[gq + lane] & kCountMask) : 0u;
-            const uint32_t incl = wave_incl_scan(cnt, lane);
-            const uint32_t total = uniform(__shfl(incl, 63, 64));
-            if (!total) continue;
-            t.scan[lane] = incl - cnt;
-            wave_lds_fence();
-            for (uint32_t w0 = 0; w0 < total; w0 += 64 * kSimpleWidth) {
-                bool valid[kSimpleWidth];
-                uint32_t tj[kSimpleWidth], edge[kSimpleWidth];
-#pragma unroll
-                for (int k = 0; k < kSimpleWidth; k++) {
-                    const uint32_t w = w0 + 64u * k + lane;
-                    valid[k] = w < total;
-                    const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
-                    uint32_t j = 0;
-#pragma unroll
-                    for (uint32_t step = 32; step >= 1; step >>= 1)
-                        if (t.scan[j + step] <= wv) j += step;
-                    tj[k] = gq + j;
-                    edge[k] = edges[t.start[tj[k]] + (wv - t.scan[j])];
-                }
-#pragma unroll
-                for (int k = 0; k < kSimpleWidth; k++) {  // the subject's row is in LDS: two 16 B LDS reads per child
+                for (int k = 0; k < W; k++) {
                     const uint32_t c = edge[k] & kIdMask;
                     const uint32_t rs = (t.count[tj[k]] >> kRowSlotShift) & 7u;
                     const uint32_t rnb = t.rnb[rs];
                     uint32_t h1, h2;
                     hashed_row_buckets(c, rnb ? rnb : 1u, &h1, &h2);
                     const uint4 p = t.rows[rs][rnb ? h1 : 0u], q = t.rows[rs][rnb ? h2 : 0u];
-                    const bool contains = rnb && (p.x == c || p.y == c || p.z == c || p.w == c || q.x == c || q.y == c || q.z == c || q.w == c);
-                    const uint32_t req = t.req[tj[k]], meta = t.meta[tj[k]];
-                    const uint32_t level = meta_level(meta);
-                    const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
-                    const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
-                    bool push = valid[k] && !(edge[k] & kLeafBit);
-                    if (hit) {
-                        has[req] = 1;
-                        push = false;
-                    } else if (derr) {
-                        err[req] = ITEM_ERR_DEPTH;
-                    }
-                    const uint64_t b = __ballot(push);
-                    if (b) {
-                        const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
-                        if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(c, req, meta | kProbedBit, t.sid[tj[k]]);
-                    }
+                    contains[k] = rnb && (p.x == c || p.y == c || p.z == c || p.w == c || q.x == c || q.y == c || q.z == c || q.w == c);
+                }
+            } else {
+                uint2 d[W];
+                bool row[W];
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint32_t sidk = t.sid[tj[k]];
+                    row[k] = sidk < pop.nrows;
+                    d[k] = gld(smeta, pop.base + (row[k] ? sidk : 0u));
+                    row[k] = row[k] && d[k].y > d[k].x;
+                }
+                uint4 p[W], q[W];
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint32_t b0 = row[k] ? d[k].x : 0u, nbk = row[k] ? d[k].y - d[k].x : 1u;
+                    uint32_t h1, h2;
+                    hashed_row_buckets(edge[k] & kIdMask, nbk, &h1, &h2);
+                    p[k] = gld(buckets, b0 + h1);
+                    q[k] = gld(buckets, b0 + h2);
+                }
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint32_t c = edge[k] & kIdMask;
+                    contains[k] = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
                 }
             }
-            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const uint32_t c = edge[k] & kIdMask;
+                const uint32_t req = t.req[tj[k]], meta = t.meta[tj[k]];
+                const uint32_t level = meta_level(meta);
+                const bool hit = valid[k] && contains[k] && level + pop.dlevel <= kMaxLevels;
+                const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
+                bool push = valid[k] && !(edge[k] & kLeafBit);
+                if (hit) {
+                    has[req] = 1;
+                    push = false;
+                } else if (derr) {
+                    err[req] = ITEM_ERR_DEPTH;
+                }
+                const uint64_t b = __ballot(push);
+                if (b) {
+                    const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
+                    if (push && base != kNoSpace) gst(out, base + lanes_below(b), make_uint4(c, req, meta | kProbedBit, t.sid[tj[k]]));
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// Subject rows in LDS: when the flush's tasks belong to at most kRowSlots distinct subjects (deep levels: tens of entries per
+// request) whose hashed rows fit a slot, the rows are staged once -- two trips, the second a coalesced load per subject -- and
+// every child probes LDS: 64 x kStagedWidth children per step cost one edge gather each.  Otherwise (shallow levels: a wave's
+// 64-128 tasks are as many requests) staging would be two trips for nothing and the children probe global memory as before.
+#ifndef ACL_STAGED_WIDTH
+#define ACL_STAGED_WIDTH 4
+#endif
+constexpr int kStagedWidth = ACL_STAGED_WIDTH;
+template <bool SHARDED, bool LOCAL>
+__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+                                              uint8_t *has, uint8_t *err) {
+    const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
+    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
+    // ---- distinct subjects of the flush (tasks i and 64 + i are looked after by lane i)
+    const bool inA = lane < T, inB = lane + 64 < T;
+    const uint32_t sidA = inA ? t.sid[lane] : 0u, sidB = inB ? t.sid[lane + 64] : 0u;
+    uint32_t slotA = kNoRowSlot, slotB = kNoRowSlot, mysid = 0, ns = 0;
+    uint64_t pa = __ballot(inA), pb = __ballot(inB);
+    while ((pa | pb) && ns < kRowSlots) {
+        const uint32_t s0 = pa ? (uint32_t)__builtin_amdgcn_readlane((int)sidA, __ffsll((unsigned long long)pa) - 1)
+                               : (uint32_t)__builtin_amdgcn_readlane((int)sidB, __ffsll((unsigned long long)pb) - 1);
+        const bool mA = inA && sidA == s0, mB = inB && sidB == s0;
+        if (mA) slotA = ns;
+        if (mB) slotB = ns;
+        pa &= ~__ballot(mA);
+        pb &= ~__ballot(mB);
+        if (lane == ns) mysid = s0;
+        ns++;
+    }
+    bool staged = !(pa | pb);  // every task's subject got a slot
+    if (staged) {
+        // trip 1: the subjects' row descriptors (lane k holds subject k)
+        const bool own = lane < ns && mysid < pop.nrows;
+        uint2 d = gld(smeta, pop.base + (own ? mysid : 0u));
+        if (!own) d = make_uint2(0, 0);
+        const uint32_t nb = d.y > d.x ? d.y - d.x : 0u;
+        staged = !__ballot(nb > kRowCap);  // a row too long for its slot (rare): the whole flush probes global memory
+        if (staged) {
+            if (lane < ns) t.rnb[lane] = nb;
+            // trip 2: the rows themselves, four subjects per load instruction (16 lanes x 16 B each, coalesced)
+#pragma unroll
+            for (uint32_t pass = 0; pass < kRowSlots / 4; pass++) {
+                const uint32_t k = pass * 4 + (lane >> 4), i = lane & 15u;
+                const uint32_t b0 = (uint32_t)__shfl((int)d.x, (int)k, 64), n = (uint32_t)__shfl((int)nb, (int)k, 64);
+                const bool ld = k < ns && i < n;
+                const uint4 v = gld(buckets, ld ? b0 + i : 0u);
+                if (ld) t.rows[k][i] = v;
+            }
+            if (inA) t.count[lane] |= slotA << kRowSlotShift;
+            if (inB) t.count[lane + 64] |= slotB << kRowSlotShift;
         }
     }
-    if (!(leftA | leftB)) return 0u;
-    // compact the leftover tasks to the front of the list
-    uint32_t f0[5] = {0, 0, 0, 0, 0}, f1[5] = {0, 0, 0, 0, 0};
-    const bool la = (leftA >> lane) & 1ull, lb = (leftB >> lane) & 1ull;
-    if (la) { f0[0] = t.start[lane]; f0[1] = t.count[lane]; f0[2] = t.req[lane]; f0[3] = t.meta[lane]; f0[4] = t.sid[lane]; }
-    if (lb) { f1[0] = t.start[lane + 64]; f1[1] = t.count[lane + 64]; f1[2] = t.req[lane + 64]; f1[3] = t.meta[lane + 64]; f1[4] = t.sid[lane + 64]; }
-    wave_lds_fence();
-    const uint32_t na = (uint32_t)__popcll(leftA);
-    if (la) { const uint32_t q = lanes_below(leftA); t.start[q] = f0[0]; t.count[q] = f0[1] & ~(15u << kRowSlotShift); t.req[q] = f0[2]; t.meta[q] = f0[3]; t.sid[q] = f0[4]; }
-    if (lb) { const uint32_t q = na + lanes_below(leftB); t.start[q] = f1[0]; t.count[q] = f1[1] & ~(15u << kRowSlotShift); t.req[q] = f1[2]; t.meta[q] = f1[3]; t.sid[q] = f1[4]; }
-    wave_lds_fence();
-    return na + (uint32_t)__popcll(leftB);
+    if (staged) simple_steps<true, kStagedWidth, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
+    else simple_steps<false, kSimpleWidth, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
 }
 
 // Second specialised expansion: all tasks lead to one child slot whose program is at most two hashed probes followed by at
@@ -403,14 +443,14 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             const uint32_t sid = t.sid[tj];
             const uint32_t level = meta_level(t.meta[tj]);
             // trip 1: the edge and the subject's row descriptor of every probe
-            const uint32_t edge = edges[t.start[tj] + (wv - t.scan[j])];
+            const uint32_t edge = gld(edges, t.start[tj] + (wv - t.scan[j]));
             uint2 hd[2];
             bool hrow[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const bool hk = (uint32_t)k < nh;
                 hrow[k] = hk && cops[hk ? k : 0].key == k0 && sid < cops[hk ? k : 0].nrows;
-                hd[k] = meta2[(hk ? cops[k].base : 0u) + (hrow[k] ? sid : 0u)];
+                hd[k] = gld(meta2, (hk ? cops[k].base : 0u) + (hrow[k] ? sid : 0u));
             }
             const uint32_t child = edge & kIdMask;
             // trips 2 and 3: both buckets of the first probe, then of the second (two-probe programs only).  One probe's
@@ -422,7 +462,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                 const uint32_t b0 = hr ? hdk.x : 0u, nb = hr ? hdk.y - hdk.x : 1u;
                 uint32_t h1, h2;
                 hashed_row_buckets(child, nb, &h1, &h2);
-                const uint4 bp = buckets[b0 + h1], bq = buckets[b0 + h2];
+                const uint4 bp = gld(buckets, b0 + h1), bq = gld(buckets, b0 + h2);
                 if (hr && level + dl <= kMaxLevels)
                     hit = hit || bp.x == child || bp.y == child || bp.z == child || bp.w == child || bq.x == child || bq.y == child || bq.z == child ||
                           bq.w == child;
@@ -439,7 +479,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                     const bool lk = (uint32_t)k < nl;
                     const FwdOp &lo = lops[lk ? k : 0];
                     const bool inrow = lk && child < lo.nrows;
-                    const uint2 md = meta2[lk ? lo.base + (size_t)(inrow ? child : 0u) * lo.K + lo.k : 0u];
+                    const uint2 md = gld(meta2, lk ? lo.base + (inrow ? child : 0u) * lo.K + lo.k : 0u);
                     if (inrow && md.y > md.x && level + lo.dlevel <= kMaxLevels) push = true;
                 }
             }
@@ -455,7 +495,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             const uint64_t b = __ballot(push);
             if (b) {
                 const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
-                if (push && base != kNoSpace) out[base + lanes_below(b)] = make_uint4(child, req, meta | kProbedBit, sid);
+                if (push && base != kNoSpace) gst(out, base + lanes_below(b), make_uint4(child, req, meta | kProbedBit, sid));
             }
         }
         wave_lds_fence();
@@ -509,14 +549,12 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             const uint32_t mi = t.meta[i], ci = t.count[i];
             agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
         }
-        bool leftovers = false;
         if (ok && !__ballot(!agree)) {
-            T = flush_simple<SHARDED, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
-            if (!T) return;
-            leftovers = true;  // subjects whose rows do not fit LDS: the generic loop below takes them
+            flush_simple<SHARDED, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
+            return;
         }
         // second shape: <= 2 hashed probes + <= 2 enumerate ops that are only looked at; uniform slot, key and leaf authority
-        if (!leftovers && k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
+        if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
             const FwdOp *cops = ops + cp.first;
             bool shape = true;
             for (uint32_t q = 0; q < cp.n_main; q++) {
@@ -552,7 +590,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     if (t.scan[j + step] <= w) j += step;
                 const uint32_t tj = gq + j;
                 const uint32_t c = t.count[tj], s = t.start[tj];
-                const uint32_t edge = (c & kSelfBit) ? s : edges[s + (w - t.scan[j])];
+                const uint32_t edge = (c & kSelfBit) ? s : gld(edges, s + (w - t.scan[j]));
                 const uint32_t child = INLINE ? (edge & kIdMask) : edge;
                 e = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
                 push = true;
@@ -594,7 +632,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             const uint64_t b = __ballot(push);
             if (b) {
                 const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
-                if (push && base != kNoSpace) out[base + lanes_below(b)] = e;
+                if (push && base != kNoSpace) gst(out, base + lanes_below(b), e);
             }
             if (INLINE && SHARDED) export_entries(xport, e, xport ? progs[meta_slot(e.z)].owner : 0u, lane, sh);
         }
@@ -678,7 +716,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
                 if (act && L <= kMaxLevels && inrow && md.y > md.x) {
                     if (L + 1 > kMaxLevels) derr = true;
-                    else if (md.y - md.x > kMaxRow) *wo.overflow = 2u;
+                    else if (md.y - md.x > kMaxRow) *wo.cold->overflow = 2u;
                     else want = true;
                 }
                 if (derr) err[se.y] = ITEM_ERR_DEPTH;
@@ -695,13 +733,13 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             };
             auto row_desc = [&](uint32_t rid) -> uint2 {
                 if (sop.K == 2) {
-                    const uint4 v = reinterpret_cast<const uint4 *>(g.meta)[(sop.base >> 1) + rid];
+                    const uint4 v = gld(reinterpret_cast<const uint4 *>(g.meta), (sop.base >> 1) + rid);
                     return sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
                 }
-                return reinterpret_cast<const uint2 *>(g.meta)[sop.base + (size_t)rid * sop.K + sop.k];
+                return gld(reinterpret_cast<const uint2 *>(g.meta), sop.base + rid * sop.K + sop.k);
             };
             // segment A's gathers and -- when the wave has another segment pending -- segment B's entries, all in flight together
-            const uint32_t hvA = has[valid ? req : 0u];
+            const uint32_t hvA = gld(has, valid ? req : 0u);
             const bool inA = valid && id < sop.nrows;
             const uint2 mdA = row_desc(inA ? id : 0u);
             bool validB = false;
@@ -710,7 +748,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             uint32_t T = seg_tasks(e, valid, hvA, mdA, inA, 0u);
             if (haveB && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots))) {
                 next.take();  // B is a simple segment of the same slot: taken here
-                const uint32_t hvB = has[validB ? eB.y : 0u];
+                const uint32_t hvB = gld(has, validB ? eB.y : 0u);
                 const bool inB = validB && eB.x < sop.nrows;
                 const uint2 mdB = row_desc(inB ? eB.x : 0u);
                 T += seg_tasks(eB, validB, hvB, mdB, inB, T);
@@ -769,7 +807,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                             if ((op.flags & OP_PROBE) && key == op.key) hit |= row_contains(g.edges, md.x, md.y, sid);
                             if (op.flags & OP_ENUM) {
                                 if (L + 1 > kMaxLevels) depth_err = true;
-                                else if (md.y - md.x > kMaxRow) *wo.overflow = 2u;
+                                else if (md.y - md.x > kMaxRow) *wo.cold->overflow = 2u;
                                 else if (!hit) {
                                     want = true;
                                     tstart = md.x;
@@ -838,18 +876,22 @@ __device__ __forceinline__ void load_programs(const DevGraph &g, uint4 *s_prog, 
     }
 }
 
-__device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t iter, uint32_t wave) {
+__device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t iter, uint32_t wave, WaveOutCold *cold, uint32_t lane) {
+    if (lane == 0) {
+        cold->counts = f.counts[iter & 1u];
+        cold->nchunks = f.nchunks + iter;
+        cold->overflow = f.overflow;
+        cold->nwaves = f.nwaves;
+        cold->max_chunks = f.max_chunks;
+        cold->cap = 0;
+    }
+    wave_lds_fence();
     WaveOut wo;
     wo.buf = f.buf[iter & 1u];
     wo.cur = wave;
     wo.fill = 0;
     wo.produced = 0;
-    wo.counts = f.counts[iter & 1u];
-    wo.nchunks = f.nchunks + iter;
-    wo.overflow = f.overflow;
-    wo.nwaves = f.nwaves;
-    wo.max_chunks = f.max_chunks;
-    wo.cap = 0;
+    wo.cold = cold;
     return wo;
 }
 
@@ -868,7 +910,7 @@ struct ChunkWalk {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
         valid = s * 64 + lane < cnt;
-        e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        e = valid ? gld(in, c * kChunk + s * 64 + lane) : make_uint4(0, 0, kDeadMeta, 0);
     }
     __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
         if (!work) return false;
@@ -882,6 +924,7 @@ template <bool LDSPROG, bool SHARDED>
 __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
                                                                            DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
+    __shared__ WaveOutCold s_cold[kWavesPerBlock];
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs;
     const FwdOp *ops;
@@ -894,7 +937,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     const uint32_t *__restrict__ in_counts = f.counts[pin];
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
-    WaveOut wo = chunked_out(f, iter, wave);
+    WaveOut wo = chunked_out(f, iter, wave, &s_cold[wib], lane);
     ChunkWalk cw{f.buf[pin], C, nwaves, lane, 0u, 0u, 0u, 0ull};
     const uint32_t nslot = C * kSegsPerChunk;
     for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
@@ -920,7 +963,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
         }
     }
     if (lane == 0) {
-        if (wo.cur != kNoSpace) wo.counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
+        if (wo.cur != kNoSpace) wo.cold->counts[wo.cur] = wo.fill;  // also publishes 0 for an unused static chunk
         if (wo.produced) f.any[iter] = 1u;
     }
 }
@@ -954,6 +997,7 @@ template <bool LDSPROG>
 __global__ __launch_bounds__(64) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1,
                                                     uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     __shared__ TaskLds t;
+    __shared__ WaveOutCold s_cold;
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs;
     const FwdOp *ops;
@@ -990,12 +1034,9 @@ __global__ __launch_bounds__(64) void k_check_local(DevGraph g, const uint4 *__r
     wo.cur = 0;
     wo.fill = 0;
     wo.produced = 0;
-    wo.counts = nullptr;
-    wo.nchunks = nullptr;
-    wo.overflow = overflow;
-    wo.nwaves = 0;
-    wo.max_chunks = 0;
-    wo.cap = cap;
+    if (lane == 0) s_cold = WaveOutCold{nullptr, nullptr, overflow, 0u, 0u, cap};
+    wave_lds_fence();
+    wo.cold = &s_cold;
     {
         NoNext nn;
         process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
@@ -1065,6 +1106,7 @@ __global__ __launch_bounds__(256) void k_keep(uint32_t k_items, const uint32_t *
 template <uint32_t PHASE>
 __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(DevReverse r, DevFrontier f, uint32_t iter, DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
+    __shared__ WaveOutCold s_cold[kWavesPerBlock];
     const uint32_t lane = lane_id();
     const uint32_t wib = threadIdx.x >> 6;
     TaskLds &t = lds[wib];
@@ -1075,7 +1117,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
     const DevGraph nog{};
-    WaveOut wo = chunked_out(f, iter, wave);
+    WaveOut wo = chunked_out(f, iter, wave, &s_cold[wib], lane);
     uint4 *__restrict__ out = wo.buf;
     // segment-major work order, as in k_expand (ChunkWalk)
     const uint32_t nslot = C * kSegsPerChunk;
@@ -1096,7 +1138,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
         const uint32_t s = x / C, c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
         const bool valid = s * 64 + lane < cnt;
-        const uint4 e = valid ? in[(size_t)c * kChunk + s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        const uint4 e = valid ? gld(in, c * kChunk + s * 64 + lane) : make_uint4(0, 0, kDeadMeta, 0);
         const uint32_t id = e.x, req = e.y, meta = e.z;
         bool active = valid && meta != kDeadMeta;
         const uint32_t slot = meta & 0x1FFFu, dist = (meta >> 13) & 63u;
@@ -1177,7 +1219,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
         }
     }
     if (lane == 0) {
-        if (wo.cur != kNoSpace) wo.counts[wo.cur] = wo.fill;
+        if (wo.cur != kNoSpace) wo.cold->counts[wo.cur] = wo.fill;
         if (wo.produced) f.any[iter] = 1u;
     }
 }

@@ -11,6 +11,7 @@ namespace acl {
 // frontier geometry
 constexpr uint32_t kChunk = 1024;         // entries per frontier chunk (16 KiB)
 constexpr uint32_t kSegsPerChunk = kChunk / 64;
+constexpr uint32_t kMaxFrontierChunks = (1u << 18) - 1;  // 16 B entries of a frontier buffer stay below 4 GiB: the kernels address with 32-bit byte offsets
 constexpr uint32_t kMaxLevels = 50;       // dispatch max depth, reference pkg/spicedb/spicedb.go:34
 constexpr uint32_t kLevelSlots = 128;     // per-iteration counters (the sharded reverse walk runs two iterations per level)
 constexpr uint32_t kMaxShards = 64;      // per-destination export counters (all-to-all exchange)

@@ -1,0 +1,150 @@
+"""List-level PostFilter: acl_filter_list_response, the reference's filterListResponse
+(pkg/authz/postfilter.go:17-55), fed with the reference's own test vectors (pkg/authz/postfilter_test.go:181-317) and checked
+against a line-by-line Python restatement of the reference algorithm (json decode -> per-item checks -> json encode) whose
+checks are answered by the CPU oracle."""
+import json
+import random
+
+import pytest
+
+from oracle import orc
+
+SCHEMA = """
+definition user {}
+definition namespace { relation viewer: user
+  permission view = viewer }
+definition pod {
+  relation namespace: namespace
+  relation viewer: user
+  relation creator: user
+  permission view = viewer + creator + namespace->view
+  permission edit = creator
+}
+"""
+
+
+def reference_filter_list_response(body: bytes, templates, user, check):
+    """postfilter.go:17-182 restated: returns the filtered body as a JSON VALUE (None = body unchanged)."""
+    doc = json.loads(body)
+    items = doc.get("items") if isinstance(doc, dict) else None
+    if not isinstance(items, list) or not items:
+        return None
+    bulk, item_reqs = [], {}
+    for i, item in enumerate(items):
+        if not isinstance(item, dict):
+            continue
+        name = ns = ""
+        md = item.get("metadata")
+        if isinstance(md, dict):
+            if isinstance(md.get("name"), str):
+                name = md["name"]
+            if isinstance(md.get("namespace"), str):
+                ns = md["namespace"]
+        for t in templates:
+            text = t.replace("{{name}}", name).replace("{{namespace}}", ns).replace("{{namespacedName}}", f"{ns}/{name}" if ns else name).replace("{{user.name}}", user)
+            if "{{" in text:
+                continue  # failed to resolve: no check (postfilter.go:92-95)
+            try:
+                rel = orc.parse_rel(text)
+            except ValueError:
+                continue
+            item_reqs.setdefault(i, []).append(len(bulk))
+            bulk.append(rel)
+    if not bulk:
+        return None
+    answers = [check(*r) for r in bulk]
+    allowed = [it for i, it in enumerate(items) if i not in item_reqs or all(answers[k] == (2, 0) for k in item_reqs[i])]
+    doc["items"] = allowed if allowed else None  # appending to a nil slice: nothing allowed marshals as null
+    return doc
+
+
+def pods(names, ns="default"):
+    return {"apiVersion": "v1", "kind": "PodList", "items": [{"metadata": {"name": n, "namespace": ns}} for n in names]}
+
+
+@pytest.mark.gpu
+def test_reference_vectors(aclgpu_lib):
+    """TestFilterListResponse (postfilter_test.go:181-243) and TestFilterItemsWithBulkPermissions (:248-317): the mock client
+    answers HAS for pod1 / testpod1 and NO for pod2 / testpod2; here the relationships say the same."""
+    import aclgpu
+    with aclgpu.Engine(SCHEMA) as e:
+        e.touch(("pod", "pod1", "viewer", "user", "testuser", ""), ("pod", "testpod1", "creator", "user", "testuser", ""))
+        tpl = ["pod:{{name}}#view@user:{{user.name}}"]
+        out, kept, total = e.filter_list_response(json.dumps(pods(["pod1", "pod2"])).encode(), tpl, "testuser")
+        doc = json.loads(out)
+        assert (kept, total) == (1, 2) and [i["metadata"]["name"] for i in doc["items"]] == ["pod1"]
+        assert doc["apiVersion"] == "v1" and doc["kind"] == "PodList"
+        out, kept, total = e.filter_list_response(json.dumps(pods(["testpod1", "testpod2"])).encode(), tpl, "testuser")
+        assert [i["metadata"]["name"] for i in json.loads(out)["items"]] == ["testpod1"]
+        # empty items / no items array: the body comes back untouched (postfilter.go:26-35)
+        for body in (b'{"kind":"PodList","items":[]}', b'{"kind":"Status","code":404}', b'{"items":"nope"}'):
+            out, _k, _t = e.filter_list_response(body, tpl, "testuser")
+            assert out == body
+        # nothing allowed: the reference's nil slice marshals as null
+        out, kept, _t = e.filter_list_response(json.dumps(pods(["pod2"])).encode(), tpl, "testuser")
+        assert kept == 0 and json.loads(out)["items"] is None
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.filter_list_response(b'{"items": [', tpl, "testuser")
+        assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_matches_reference_algorithm_on_random_lists(aclgpu_lib):
+    import aclgpu
+    rng = random.Random(0x5ACE)
+    o = orc.Oracle(SCHEMA)
+    with aclgpu.Engine(SCHEMA) as e:
+        rels = []
+        for n in range(8):
+            rels.append(("namespace", f"ns{n}", "viewer", "user", f"u{n % 3}", ""))
+        for p in range(300):
+            ns = f"ns{rng.randrange(8)}"
+            rels.append(("pod", f"{ns}/p{p}", "namespace", "namespace", ns, ""))
+            rels.append(("pod", f"{ns}/p{p}", "creator", "user", f"u{rng.randrange(6)}", ""))
+            if rng.random() < 0.3:
+                rels.append(("pod", f"{ns}/p{p}", "viewer", "user", f"u{rng.randrange(6)}", ""))
+        for i in range(0, len(rels), 500):
+            o.write([(orc.OP_TOUCH, r) for r in rels[i:i + 500]])
+            e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 500]])
+        pod_ids = [r[1] for r in rels if r[0] == "pod" and r[2] == "namespace"]
+        weird = [7, "str", None, {"no": "metadata"}, {"metadata": "not-an-object"}, {"metadata": {"name": 5}}, {"metadata": {"name": "qé\"x\\y", "namespace": "ns1"}},
+                 {"metadata": {"name": "dup", "namespace": "ns0"}, "spec": {"containers": [{"image": "a:b", "ports": [1, 2.5, -3e2]}], "x": [[], {}, [[]]]}}]
+        for trial in range(40):
+            items = []
+            for _ in range(rng.randrange(0, 60)):
+                if rng.random() < 0.15:
+                    items.append(rng.choice(weird))
+                else:
+                    ns, name = rng.choice(pod_ids).split("/")
+                    items.append({"metadata": {"name": name, "namespace": ns, "labels": {"a": "b"}}, "status": {"phase": "Running"}})
+            doc = {"kind": "PodList", "metadata": {"resourceVersion": str(trial)}, "items": items, "apiVersion": "v1"}
+            body = json.dumps(doc, indent=rng.choice([None, 1]), ensure_ascii=rng.random() < 0.5).encode()
+            tpls = rng.choice([["pod:{{namespacedName}}#view@user:{{user.name}}"], ["pod:{{namespacedName}}#view@user:{{user.name}}", "pod:{{namespacedName}}#edit@user:{{user.name}}"],
+                               ["namespace:{{namespace}}#view@user:{{user.name}}"], ["pod:{{ namespacedName }}#view@user:{{user.name}}", "pod:{{unknownVar}}#view@user:x"], []])
+            user = f"u{rng.randrange(6)}"
+            want = reference_filter_list_response(body, [t.replace("{{ namespacedName }}", "{{namespacedName}}") for t in tpls], user, o.check)
+            out, kept, total = e.filter_list_response(body, tpls, user)
+            if want is None:
+                assert out == body, (trial, tpls)
+            else:
+                assert json.loads(out) == want, (trial, tpls, user)
+                assert kept == len(want["items"] or []) and total == len(items)
+
+
+def test_unchanged_and_invalid_bodies_need_no_gpu(aclgpu_lib):
+    """The scan half runs anywhere: bodies the reference returns untouched, and bodies json.Unmarshal rejects."""
+    import aclgpu
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    tpl = ["pod:{{name}}#view@user:{{user.name}}"]
+    for body in (b'{"kind":"PodList","items":[]}', b' { "a" : [1, {"b": null}], "items" : 3 } ', b'{"items":[1],"items":{}}'):
+        out, _k, _t = e.filter_list_response(body, tpl, "u")
+        assert out == body
+    for bad in (b'', b'[1,2]', b'{"items": [}', b'{"a": tru}', b'{"a": "\\q"}', b'{"a":1} trailing', b'{"a":"\x01"}'):
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.filter_list_response(bad, tpl, "u")
+        assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
+    # a list with items but a store-only engine: the check itself is what needs the device
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.filter_list_response(b'{"items":[{"metadata":{"name":"p"}}]}', tpl, "u")
+    assert ei.value.code == aclgpu.ERR_UNAVAILABLE
+    e.close()
