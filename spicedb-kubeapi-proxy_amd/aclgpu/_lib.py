@@ -25,7 +25,8 @@ SYMBOLS = [
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
-    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response",
+    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
+    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl",
 ]
 
 
@@ -61,6 +62,19 @@ class Stats(C.Structure):
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
                 ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64),
                 ("local_ms", C.c_double), ("local_passes", C.c_uint64), ("snapshot_compactions", C.c_uint64)]
+
+
+ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class ShardComm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_CB), ("all_reduce_max_u8", ALL_REDUCE_CB)]
+
+
+class ShardBulkStats(C.Structure):
+    _fields_ = [("levels", C.c_uint32), ("exchanges", C.c_uint32), ("host_syncs", C.c_uint32), ("retries", C.c_uint32),
+                ("exchanged_bytes", C.c_uint64), ("entries_exchanged", C.c_uint64), ("export_capacity", C.c_uint64)]
 
 
 class ShardStep(C.Structure):
@@ -159,6 +173,11 @@ def load():
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_shard_of_type.argtypes = [H, C.c_int]
     L.acl_shard_grow_frontier.argtypes = [H]
+    L.acl_shard_check_bulk.argtypes = [H, C.POINTER(ShardComm), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(ShardBulkStats)]
+    L.acl_shard_rccl_unique_id.argtypes = [C.c_void_p]
+    L.acl_shard_rccl_init.argtypes = [H, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.acl_shard_rccl_destroy.argtypes = [H]
+    L.acl_shard_check_bulk_rccl.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(ShardBulkStats)]
     L.acl_shard_stream.argtypes = [H]
     L.acl_shard_stream.restype = C.c_void_p
     L.acl_shard_check_begin.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

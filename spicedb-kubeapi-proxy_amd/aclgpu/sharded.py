@@ -165,6 +165,85 @@ class ThreadComm:
         self._s.barrier.wait()
 
 
+# ----------------------------------------------------------------------------- communicators of the NATIVE loop
+# acl_shard_check_bulk (csrc/engine_shard_native.cpp) runs the whole level loop inside libaclgpu.so and calls back only
+# for the collective itself.  Production: RCCL inside the library (acl_shard_rccl_*; `RcclNative` hands the ncclUniqueId
+# around through torch.distributed).  Single-GPU tests: `ThreadNative`, device-to-device copies between the logical
+# shards of one process -- the loop, the kernels and every decision are the same code as with RCCL.
+_hip = None
+
+
+def _hiprt():
+    global _hip
+    if _hip is None:
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+            try:
+                _hip = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if _hip is None:
+            raise ImportError("libamdhip64.so not loadable")
+        _hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    return _hip
+
+
+class ThreadNative:
+    """acl_shard_comm_t over a ThreadComm: the all-gather is `world` device-to-device copies on the caller's stream."""
+
+    def __init__(self, comm: "ThreadComm"):
+        self.comm = comm
+        hip = _hiprt()
+
+        def all_gather(_user, d_send, d_recv, nbytes, stream):
+            try:
+                hip.hipStreamSynchronize(stream)  # my block is complete before any peer copies it
+                sends = comm._exchange(int(d_send))
+                for r, src in enumerate(sends):
+                    if hip.hipMemcpyAsync(d_recv + r * nbytes, src, nbytes, 3, stream):
+                        return 13
+                hip.hipStreamSynchronize(stream)
+                comm._s.barrier.wait()  # nobody overwrites its send block before every peer has copied it
+                return 0
+            except Exception:  # noqa: BLE001  (a broken barrier: another logical shard failed)
+                return 13
+
+        def all_reduce_max(_user, d_buf, n, stream):
+            try:
+                hip.hipStreamSynchronize(stream)
+                mine = np.empty(n, dtype=np.uint8)
+                hip.hipMemcpy(mine.ctypes.data, d_buf, n, 2)
+                parts = comm._exchange(mine)
+                red = np.maximum.reduce(parts)
+                hip.hipMemcpy(d_buf, red.ctypes.data, n, 1)
+                comm._s.barrier.wait()
+                return 0
+            except Exception:  # noqa: BLE001
+                return 13
+
+        self._cbs = (_lib.ALL_GATHER_CB(all_gather), _lib.ALL_REDUCE_CB(all_reduce_max))  # keep the trampolines alive
+        self.struct = _lib.ShardComm(None, self._cbs[0], self._cbs[1])
+
+
+class RcclNative:
+    """The library's own RCCL communicator: rank 0 makes the ncclUniqueId, torch.distributed (any backend) hands it around."""
+
+    def __init__(self, shard: "GpuShard", comm: "TorchComm"):
+        L, h = shard._L, shard._h
+        idb = np.zeros(128, dtype=np.uint8)
+        if comm.rank == 0:
+            shard.e._check(L.acl_shard_rccl_unique_id(idb.ctypes.data))
+        t = torch.from_numpy(idb)
+        if comm.device is not None:
+            t = t.to(comm.device)
+        comm.broadcast(t, 0)
+        idb = t.cpu().numpy().copy()
+        shard.e._check(L.acl_shard_rccl_init(h, idb.ctypes.data, comm.rank, comm.world))
+        self.struct = None  # acl_shard_check_bulk_rccl uses the engine's communicator
+
+
 # ----------------------------------------------------------------------------- one shard on one GPU
 class GpuShard:
     """One shard of the graph on one MI355X: an Engine configured with (rank, world), stepped through the
@@ -325,6 +404,29 @@ class ShardedEngine:
             if perm.is_cuda:
                 torch.cuda.current_stream().synchronize()
             return perm[:n], errout[:n]
+
+    def check_bulk_ids_native(self, items):
+        """The same answers through acl_shard_check_bulk: the whole level loop inside libaclgpu.so -- one fixed-capacity all-gather
+        per level, decisions on the device, one host synchronisation per burst of levels.  -> (perm, err, stats dict)."""
+        sh = self.shard
+        if getattr(self, "_native", None) is None:
+            self._native = RcclNative(sh, self.comm) if isinstance(self.comm, TorchComm) else ThreadNative(self.comm)
+        with sh.stream():
+            if isinstance(items, np.ndarray):
+                items = torch.from_numpy(np.ascontiguousarray(items).view(np.uint8).reshape(-1).copy())
+            items = items.to(sh.device).contiguous()
+            n = items.numel() * items.element_size() // 16
+            perm = torch.zeros(max(n, 1), dtype=torch.uint8, device=sh.device)
+            errout = torch.zeros(max(n, 1), dtype=torch.int32, device=sh.device)
+            torch.cuda.current_stream().synchronize()
+            st = _lib.ShardBulkStats()
+            if self._native.struct is None:
+                rc = sh._L.acl_shard_check_bulk_rccl(sh._h, items.data_ptr(), n, perm.data_ptr(), errout.data_ptr(), C.byref(st))
+            else:
+                rc = sh._L.acl_shard_check_bulk(sh._h, C.byref(self._native.struct), items.data_ptr(), n, perm.data_ptr(), errout.data_ptr(), C.byref(st))
+            sh.e._check(rc)
+            self.levels_last = int(st.levels)
+            return perm[:n], errout[:n], {f: int(getattr(st, f)) for f, _t in _lib.ShardBulkStats._fields_}
 
     def _check_levels(self, items, has, err):
         if self.exchange == "alltoall":

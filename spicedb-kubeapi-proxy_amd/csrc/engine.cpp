@@ -714,6 +714,7 @@ void acl_close(acl_engine_t *h) {
     (void)acl_batcher_stop(h);
     async_shutdown(h);
     batcher_destroy(h);
+    (void)acl_shard_rccl_destroy(h);
     if (h->store_only) {
         delete h;
         return;

@@ -13,11 +13,15 @@
 
 // ---------------------------------------------------------------- micro-batching front-end
 // The proxy issues many concurrent 1-item checks (check.go:76-94: one goroutine per check expression; watch.go:50: one
-// per update) and one LookupResources per list request (responsefilterer.go:165).  Callers append to the OPEN batch (a
-// few dozen nanoseconds under one mutex) and sleep on that batch's own futex word; dispatcher threads -- one per
-// evaluation context, so passes overlap on the device -- close the open batch, answer it with one device pass and wake
-// exactly its callers with ONE futex call.  (Round 1 woke every caller through its own condition variable while holding
-// the queue lock: 263 k checks/s at 64 threads, collapsing to 46 k/s at 1 024.)
+// per update) and one LookupResources per list request (responsefilterer.go:165).  Design, from what broke before:
+//   * round 1 woke every caller through its own condition variable while holding the one queue lock: 263 k checks/s at 64
+//     threads, 46 k/s at 1 024;
+//   * one open batch behind one mutex + one futex per batch (first cut of this round): the callers a pass wakes all
+//     re-enqueue at once and convoy on that mutex: 420 k/s at 64 threads, 56 k/s at 1 024.
+// Now: kQueues independent queues (a caller uses the one its thread hashes to: a few dozen nanoseconds under a lock it
+// shares with 1/16 of the callers), each holding an open sub-batch with its own futex word.  Dispatcher threads -- one
+// per evaluation context, so passes overlap on the device -- sleep on a counter of queued requests, sweep all queues,
+// answer what they found with ONE device pass and wake every sub-batch's callers with one futex call each.
 namespace {
 
 inline long futex(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec *ts) {
@@ -35,7 +39,7 @@ struct LookupReq {
     uint64_t count = 0;
 };
 
-struct Batch {
+struct Batch {  // the callers of one queue between two sweeps
     std::atomic<uint32_t> done{0};
     std::atomic<uint32_t> refs{1};  // the queue's own reference + one per caller
     std::vector<acl_item_t> items;
@@ -44,21 +48,26 @@ struct Batch {
     std::vector<LookupReq> lookups;
     int rc = 0;
     std::string msg;
-    int64_t opened_ns = 0;
     void unref() {
         if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
     }
 };
 
+constexpr uint32_t kQueues = 16;
+struct alignas(64) Queue {
+    std::mutex mu;
+    Batch *open = nullptr;
+};
+
 }  // namespace
 
 struct acl_engine::Batcher {
-    std::mutex mu;
-    std::condition_variable cv;  // dispatchers only
-    Batch *open = nullptr;
-    uint32_t idle = 0;      // dispatchers parked on cv
-    uint32_t in_flight = 0;  // passes on the device
-    bool stop = false;
+    Queue q[kQueues];
+    std::atomic<uint32_t> pending{0};  // requests queued and not yet swept; dispatchers sleep on it (futex) while it is 0
+    std::atomic<uint32_t> in_flight{0};  // passes on the device
+    std::atomic<int64_t> oldest_ns{0};   // when the oldest unswept request arrived (0: none)
+    std::atomic<bool> running{false}, stop{false};
+    std::mutex mu;  // start / stop
     std::vector<std::thread> threads;
     uint32_t max_items = 4096, wait_us = 200;
     std::atomic<uint64_t> batches{0}, items{0}, lookup_walks{0}, lookups{0};
@@ -68,22 +77,44 @@ struct acl_engine::Batcher {
 
 namespace {
 
-void answer_batch(acl_engine_t *h, Batch *b) {
-    if (!b->items.empty()) {
-        b->perm.assign(b->items.size(), 0);
-        b->err.assign(b->items.size(), 0);
-        b->rc = acl_check_bulk_ids(h, b->items.data(), b->items.size(), b->perm.data(), b->err.data());
-        if (b->rc) b->msg = acl_last_error();
+// answers the swept sub-batches with one device pass (+ one batched reverse walk per lookup class) and wakes their callers
+void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
+    acl_engine::Batcher &B = *h->batcher;
+    size_t n = 0, nl = 0;
+    for (Batch *b : subs) {
+        n += b->items.size();
+        nl += b->lookups.size();
     }
-    // LookupResources of the batch: one batched reverse walk per (resource type, permission, subject class)
-    uint64_t walks = 0;
-    if (!b->lookups.empty()) {
+    if (n) {
+        std::vector<acl_item_t> items;
+        items.reserve(n);
+        for (Batch *b : subs) items.insert(items.end(), b->items.begin(), b->items.end());
+        std::vector<uint8_t> perm(n);
+        std::vector<int32_t> err(n);
+        const int rc = acl_check_bulk_ids(h, items.data(), n, perm.data(), err.data());
+        const std::string msg = rc ? acl_last_error() : "";
+        size_t o = 0;
+        for (Batch *b : subs) {
+            const size_t k = b->items.size();
+            b->rc = rc;
+            b->msg = msg;
+            b->perm.assign(perm.begin() + (long)o, perm.begin() + (long)(o + k));
+            b->err.assign(err.begin() + (long)o, err.begin() + (long)(o + k));
+            o += k;
+        }
+        B.batches++;
+        B.items += n;
+    }
+    // LookupResources: one batched reverse walk per (resource type, permission, subject class)
+    if (nl) {
         std::vector<LookupReq *> lks;
-        for (LookupReq &l : b->lookups) lks.push_back(&l);
+        for (Batch *b : subs)
+            for (LookupReq &l : b->lookups) lks.push_back(&l);
         auto key = [](const LookupReq *a) { return std::tie(a->rtype, a->perm, a->stype, a->srel, a->words); };
         std::stable_sort(lks.begin(), lks.end(), [&](const LookupReq *a, const LookupReq *c) { return key(a) < key(c); });
         std::vector<uint32_t> sids, bms;
         std::vector<uint64_t> cnts;
+        uint64_t walks = 0;
         for (size_t g0 = 0; g0 < lks.size();) {
             size_t g1 = g0 + 1;
             while (g1 < lks.size() && key(lks[g1]) == key(lks[g0])) g1++;
@@ -106,111 +137,115 @@ void answer_batch(acl_engine_t *h, Batch *b) {
             walks++;
             g0 = g1;
         }
+        B.lookup_walks += walks;
+        B.lookups += nl;
     }
-    acl_engine::Batcher &B = *h->batcher;
-    if (!b->items.empty()) B.batches++;
-    B.items += b->items.size();
-    B.lookup_walks += walks;
-    B.lookups += b->lookups.size();
-    b->done.store(1, std::memory_order_release);
-    futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this batch's callers, one system call
-    b->unref();
+    for (Batch *b : subs) {
+        b->done.store(1, std::memory_order_release);
+        futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this sub-batch's callers
+        b->unref();
+    }
 }
 
-void dispatcher_loop(acl_engine_t *h) {
+void dispatcher_loop(acl_engine_t *h, uint32_t me) {
     acl_engine::Batcher &B = *h->batcher;
+    std::vector<Batch *> subs;
     for (;;) {
-        Batch *b = nullptr;
-        {
-            std::unique_lock<std::mutex> lk(B.mu);
-            B.idle++;
-            B.cv.wait(lk, [&] { return B.stop || (B.open && (!B.open->items.empty() || !B.open->lookups.empty())); });
-            B.idle--;
-            if (!B.open || (B.open->items.empty() && B.open->lookups.empty())) {
-                if (B.stop) return;
-                continue;
-            }
-            // idle device and a small batch: let concurrent callers pile on for at most wait_us.  When a pass is already in
-            // flight, that pass WAS the batching window: whoever arrived during it goes now.
-            if (!B.stop && B.in_flight == 0 && B.wait_us && B.open->items.size() + B.open->lookups.size() < B.max_items) {
-                const int64_t until = B.open->opened_ns + (int64_t)B.wait_us * 1000;
-                while (!B.stop && B.open && B.open->items.size() + B.open->lookups.size() < B.max_items) {
-                    const int64_t now = mono_ns();
-                    if (now >= until) break;
-                    B.cv.wait_for(lk, std::chrono::nanoseconds(until - now));
-                }
-                if (!B.open) continue;  // another dispatcher took it meanwhile
-            }
-            b = B.open;
-            B.open = nullptr;
-            B.in_flight++;
+        while (B.pending.load(std::memory_order_acquire) == 0) {
+            if (B.stop.load(std::memory_order_acquire)) return;
+            timespec ts{0, 2000000};  // (bounded: a stop request is noticed within 2 ms even if its wake-up is missed)
+            futex(&B.pending, FUTEX_WAIT_PRIVATE, 0, &ts);
         }
-        answer_batch(h, b);
-        {
-            std::lock_guard<std::mutex> lk(B.mu);
-            B.in_flight--;
+        // idle device and few requests: let concurrent callers pile on for at most wait_us.  When a pass is already in
+        // flight, that pass WAS the batching window: whoever arrived during it goes now.
+        if (B.wait_us && B.in_flight.load(std::memory_order_relaxed) == 0 && B.pending.load(std::memory_order_relaxed) < B.max_items) {
+            const int64_t first = B.oldest_ns.load(std::memory_order_relaxed);
+            const int64_t until = (first ? first : mono_ns()) + (int64_t)B.wait_us * 1000;
+            while (!B.stop.load(std::memory_order_relaxed) && B.pending.load(std::memory_order_relaxed) < B.max_items) {
+                const int64_t now = mono_ns();
+                if (now >= until) break;
+                timespec ts{0, (long)std::min<int64_t>(until - now, 50000)};
+                nanosleep(&ts, nullptr);
+            }
         }
+        // sweep every queue (starting at a different one per dispatcher so that two sweeps do not chase each other)
+        subs.clear();
+        uint32_t taken = 0;
+        for (uint32_t k = 0; k < kQueues && taken < B.max_items; k++) {
+            Queue &q = B.q[(me * 5 + k) % kQueues];
+            Batch *b = nullptr;
+            {
+                std::lock_guard<std::mutex> g(q.mu);
+                b = q.open;
+                q.open = nullptr;
+            }
+            if (!b) continue;
+            taken += (uint32_t)(b->items.size() + b->lookups.size());
+            subs.push_back(b);
+        }
+        if (!taken) continue;  // another dispatcher swept them first
+        B.oldest_ns.store(0, std::memory_order_relaxed);
+        B.pending.fetch_sub(taken, std::memory_order_acq_rel);
+        B.in_flight.fetch_add(1, std::memory_order_relaxed);
+        answer(h, subs);
+        B.in_flight.fetch_sub(1, std::memory_order_relaxed);
     }
 }
 
-// appends to the open batch; returns the batch (one reference for the caller) and the caller's index in it
+// appends to the caller's queue; returns the sub-batch (one reference for the caller) and the caller's index in it
 Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, size_t *index) {
     acl_engine::Batcher *B = h->batcher;
-    if (!B) return nullptr;
-    std::unique_lock<std::mutex> g(B->mu);
-    if (B->stop || B->threads.empty()) return nullptr;  // no batcher running
-    if (!B->open) {
-        B->open = new Batch();
-        B->open->opened_ns = mono_ns();
+    if (!B || !B->running.load(std::memory_order_acquire)) return nullptr;  // no batcher running
+    static std::atomic<uint32_t> next_thread{0};
+    static thread_local uint32_t my_queue = next_thread.fetch_add(1, std::memory_order_relaxed) % kQueues;
+    Queue &q = B->q[my_queue];
+    Batch *b;
+    {
+        std::lock_guard<std::mutex> g(q.mu);
+        if (!B->running.load(std::memory_order_relaxed)) return nullptr;
+        if (!q.open) q.open = new Batch();
+        b = q.open;
+        if (item) {
+            *index = b->items.size();
+            b->items.push_back(*item);
+        } else {
+            *index = b->lookups.size();
+            b->lookups.push_back(*lk);
+        }
+        b->refs.fetch_add(1, std::memory_order_relaxed);
     }
-    Batch *b = B->open;
-    const bool was_empty = b->items.empty() && b->lookups.empty();
-    if (item) {
-        *index = b->items.size();
-        b->items.push_back(*item);
-    } else {
-        *index = b->lookups.size();
-        b->lookups.push_back(*lk);
+    if (B->pending.fetch_add(1, std::memory_order_acq_rel) == 0) {
+        B->oldest_ns.store(mono_ns(), std::memory_order_relaxed);
+        futex(&B->pending, FUTEX_WAKE_PRIVATE, 1, nullptr);  // dispatchers only sleep while nothing is queued
     }
-    b->refs.fetch_add(1, std::memory_order_relaxed);
-    const bool full = b->items.size() + b->lookups.size() >= B->max_items;
-    const bool wake = (was_empty || full) && B->idle > 0;
-    g.unlock();
-    if (wake) B->cv.notify_one();
     return b;
 }
 
-// parks the caller until its batch is answered: a short spin first when cores are to spare (a pass takes tens of
-// microseconds, a futex sleep + wake about as long), then the batch's futex
+// parks the caller until its sub-batch is answered: a short spin first when cores are to spare (a pass takes tens of
+// microseconds, a futex sleep + wake about as long), then the sub-batch's futex
 int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
     acl_engine::Batcher &B = *h->batcher;
     const bool watched = opts.cancel || opts.deadline_ns;
-    if ((B.sleepers.load(std::memory_order_relaxed) + 4) * 2 < B.cores) {  // (+ the dispatchers, which spin in their stream syncs)
+    const uint32_t parked = B.sleepers.fetch_add(1, std::memory_order_relaxed);
+    if ((parked + 4) * 2 < B.cores) {  // (+ the dispatchers, which spin in their stream syncs)
         const int64_t spin_until = mono_ns() + 30000;
-        B.sleepers.fetch_add(1, std::memory_order_relaxed);
         while (!b->done.load(std::memory_order_acquire) && mono_ns() < spin_until) {
             for (int i = 0; i < 32; i++) __builtin_ia32_pause();
         }
-        B.sleepers.fetch_sub(1, std::memory_order_relaxed);
     }
-    if (!b->done.load(std::memory_order_acquire)) {
-        B.sleepers.fetch_add(1, std::memory_order_relaxed);
-        while (!b->done.load(std::memory_order_acquire)) {
-            if (watched) {
-                int rc = check_opts(opts);
-                if (rc) {
-                    B.sleepers.fetch_sub(1, std::memory_order_relaxed);
-                    return rc;  // the batch still answers the abandoned slot; nobody reads it
-                }
-                timespec ts{0, 500000};
-                futex(&b->done, FUTEX_WAIT_PRIVATE, 0, &ts);
-            } else {
-                futex(&b->done, FUTEX_WAIT_PRIVATE, 0, nullptr);
-            }
+    int rc = ACL_OK;
+    while (!b->done.load(std::memory_order_acquire)) {
+        if (watched) {
+            rc = check_opts(opts);
+            if (rc) break;  // the pass still answers the abandoned slot; nobody reads it
+            timespec ts{0, 500000};
+            futex(&b->done, FUTEX_WAIT_PRIVATE, 0, &ts);
+        } else {
+            futex(&b->done, FUTEX_WAIT_PRIVATE, 0, nullptr);
         }
-        B.sleepers.fetch_sub(1, std::memory_order_relaxed);
     }
-    return ACL_OK;
+    B.sleepers.fetch_sub(1, std::memory_order_relaxed);
+    return rc;
 }
 
 // hardware threads this process may actually use: affinity mask, capped by the cgroup CPU quota (a container on a
@@ -243,7 +278,9 @@ namespace aclint {
 
 void batcher_create(acl_engine_t *h) { h->batcher = new acl_engine::Batcher(); }
 void batcher_destroy(acl_engine_t *h) {
-    if (h->batcher && h->batcher->open) h->batcher->open->unref();
+    if (h->batcher)
+        for (Queue &q : h->batcher->q)
+            if (q.open) q.open->unref();
     delete h->batcher;
     h->batcher = nullptr;
 }
@@ -251,7 +288,7 @@ void batcher_destroy(acl_engine_t *h) {
 // one LookupResources with interned arguments: rides the micro-batcher when it runs, else a walk of its own
 int lookup_one_routed(acl_engine_t *h, int rt, int pm, int st, int sr, uint32_t sub, uint32_t *bitmap_out, size_t words, uint64_t *count_out,
                       const CallOpts &opts) {
-    LookupReq lk{rt, pm, st, sr, sub, words};
+    LookupReq lk{rt, pm, st, sr, sub, words, 0, std::string(), std::vector<uint32_t>(), 0};
     size_t idx = 0;
     Batch *b = enqueue(h, nullptr, &lk, &idx);
     if (!b) return lookup_batch_call(h, rt, pm, st, sr, &sub, 1, bitmap_out, words, count_out, opts);
@@ -409,11 +446,12 @@ int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us)
     B.max_items = max_items ? max_items : 4096;
     B.wait_us = max_wait_us;
     B.cores = usable_cores();
-    B.stop = false;
+    B.stop.store(false);
     // one dispatcher per evaluation context the engine may open, but no more than a quarter of the usable cores (a
     // dispatcher's stream synchronisation spins); store-only engines: one, it only reports the error
     const uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({h->max_ctx, 4u, std::max(1u, B.cores / 4)}));
-    for (uint32_t i = 0; i < nd; i++) B.threads.emplace_back(dispatcher_loop, h);
+    for (uint32_t i = 0; i < nd; i++) B.threads.emplace_back(dispatcher_loop, h, i);
+    B.running.store(true, std::memory_order_release);
     return ACL_OK;
 }
 
@@ -425,10 +463,12 @@ int acl_batcher_stop(acl_engine_t *h) {
     {
         std::lock_guard<std::mutex> g(B.mu);
         if (B.threads.empty()) return ACL_OK;
-        B.stop = true;  // enqueue() refuses from here on: callers fall back to passes of their own
+        B.running.store(false, std::memory_order_release);  // enqueue() refuses from here on: callers fall back to passes of their own
+        for (Queue &q : B.q) std::lock_guard<std::mutex> qg(q.mu);  // callers already inside enqueue() have finished appending
+        B.stop.store(true, std::memory_order_release);
         threads.swap(B.threads);
     }
-    B.cv.notify_all();
+    futex(&B.pending, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);
     for (auto &t : threads) t.join();  // dispatchers leave only when nothing is queued
     return ACL_OK;
 }

@@ -164,6 +164,11 @@ struct PassCtx {
     DevArray<uint4> d_items;
     DevArray<uint32_t> d_itemoff, d_sids, d_visited;
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
+    // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
+    DevArray<uint4> d_xsend, d_xrecv;
+    DevArray<uint32_t> d_xctrl;
+    PinnedBuf h_xctrl;
+    uint32_t xcap = 0;
     uint32_t levels_hint = 6;
     CallOpts opts;  // of the call that holds this context
     // measurement (merged into the engine's stats when the context is released)
@@ -211,6 +216,7 @@ struct acl_engine {
     std::vector<PassCtx *> free_ctxs;
     uint32_t max_ctx = 4;
     std::unique_ptr<PassCtx> shard_ctx;  // the acl_shard_* protocol keeps state across calls: its own context, never pooled
+    void *rccl_comm = nullptr;           // ncclComm_t of acl_shard_rccl_init
     std::mutex shard_mu;
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 8192;  // batches up to this size take the single-launch path (k_check_local); 0 = never

@@ -384,7 +384,10 @@ __device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo
         if (lane == ns) mysid = s0;
         ns++;
     }
-    bool staged = !(pa | pb);  // every task's subject got a slot
+#ifndef ACL_STAGE
+#define ACL_STAGE 1  // A/B knob (tools/build_variant.sh): 0 = never stage subject rows in LDS
+#endif
+    bool staged = ACL_STAGE && !(pa | pb);  // every task's subject got a slot
     if (staged) {
         // trip 1: the subjects' row descriptors (lane k holds subject k)
         const bool own = lane < ns && mysid < pop.nrows;
@@ -1268,6 +1271,86 @@ __global__ __launch_bounds__(256) void k_import(DevFrontier f, uint32_t iter, co
     }
 }
 
+// ---------------------------------------------------------------- native sharded loop (engine_shard_native.cpp)
+// One exchange block per shard and level: [header][cap entries].  header = {entries exported (may exceed cap: the surplus was
+// dropped), this shard's any[iter] before imports, its overflow code, level}.  Written on the device, so the host never
+// waits between levels.
+__global__ __launch_bounds__(64) void k_xhdr(uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level) {
+    if (threadIdx.x == 0) *hdr = make_uint4(*exp_count, *any_iter, *overflow, level);
+}
+
+// After the all-gather: blockIdx.y = source shard.  Rows of other shards import the entries this shard owns (as k_import
+// does, the count read from the gathered header); the own row's first wave folds all headers into the level's control
+// record {total exported, any shard produced, any overflow, largest export} -- identical on every shard, so all of them take
+// the same decisions (done / redo) without talking to each other or to the host.
+__global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t iter, const uint4 *__restrict__ recv, uint32_t world, uint32_t rank,
+                                                         uint32_t cap, const SlotProg *progs, uint32_t *ctrl) {
+    const uint32_t lane = lane_id();
+    const uint32_t src = blockIdx.y;
+    if (src == rank) {
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            uint32_t total = 0, anyp = 0, over = 0, mx = 0;
+            for (uint32_t r = lane; r < world; r += 64) {
+                const uint4 h = recv[(size_t)r * (cap + 1)];
+                total += h.x;
+                anyp |= h.y;
+                over |= h.z | (h.x > cap ? 1u : 0u);
+                mx = max(mx, h.x);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                total += (uint32_t)__shfl_xor((int)total, d, 64);
+                anyp |= (uint32_t)__shfl_xor((int)anyp, d, 64);
+                over |= (uint32_t)__shfl_xor((int)over, d, 64);
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+            }
+            if (lane == 0) {
+                ctrl[0] = total;
+                ctrl[1] = anyp;
+                ctrl[2] = over;
+                ctrl[3] = mx;
+            }
+        }
+        return;
+    }
+    const uint4 *__restrict__ in = recv + (size_t)src * (cap + 1) + 1;
+    const uint32_t n = min(recv[(size_t)src * (cap + 1)].x, cap);
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    uint4 *__restrict__ out = f.buf[iter & 1u];
+    uint32_t *out_counts = f.counts[iter & 1u];
+    uint32_t *out_nchunks = f.nchunks + iter;
+    uint32_t cur = kNoSpace, fill = kChunk, produced = 0;
+    for (uint32_t x = wave; (uint64_t)x * 64 < n; x += nw) {
+        const uint32_t i = x * 64 + lane;
+        const uint4 e = i < n ? in[i] : make_uint4(0, 0, kDeadMeta, 0);
+        bool mine = i < n && e.z != kDeadMeta;
+        if (mine) mine = progs[meta_slot(e.z)].owner == rank;
+        const uint64_t b = __ballot(mine);
+        if (!b) continue;
+        const uint32_t need = (uint32_t)__popcll(b);
+        if (fill + need > kChunk) {
+            if (lane == 0 && cur != kNoSpace) out_counts[cur] = fill;
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(out_nchunks, 1u);
+            c = uniform(c) + f.nwaves;
+            if (c >= f.max_chunks) {
+                if (lane == 0) *f.overflow = 1u;
+                cur = kNoSpace;
+                break;
+            }
+            cur = c;
+            fill = 0;
+        }
+        if (mine) out[(size_t)cur * kChunk + fill + lanes_below(b)] = e;
+        fill += need;
+        produced += need;
+    }
+    if (lane == 0) {
+        if (cur != kNoSpace) out_counts[cur] = fill;
+        if (produced) f.any[iter] = 1u;
+    }
+}
+
 }  // namespace
 
 int expand_grid_blocks(int device) {
@@ -1329,6 +1412,14 @@ static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input p
 void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n, const DevShard &sh) {
     if (!n) return;
     hipLaunchKernelGGL(k_import<true>, dim3(import_blocks(n)), dim3(256), 0, s, f, iter, in, n, g.progs, (const RevProg *)nullptr, sh.rank);
+}
+void launch_xhdr(hipStream_t s, uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level) {
+    hipLaunchKernelGGL(k_xhdr, dim3(1), dim3(64), 0, s, hdr, exp_count, any_iter, overflow, level);
+}
+void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *recv, uint32_t world, uint32_t rank, uint32_t cap,
+                            uint32_t *ctrl) {
+    const uint32_t bx = std::max<uint32_t>(1, std::min<uint32_t>(64, (cap + 4095) / 4096));
+    hipLaunchKernelGGL(k_import_gathered, dim3(bx, world), dim3(256), 0, s, f, iter, recv, world, rank, cap, g.progs, ctrl);
 }
 void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n) {
     if (!n) return;

@@ -77,6 +77,10 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 // appends the entries of `in` (an all-gathered export buffer) whose slot this shard owns to the frontier that
 // iteration `iter` produced
 void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n, const DevShard &sh);
+// native sharded loop: exchange-block header written on the device; import of an all-gathered set of blocks + the level's control record
+void launch_xhdr(hipStream_t s, uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level);
+void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *recv, uint32_t world, uint32_t rank, uint32_t cap,
+                            uint32_t *ctrl);
 void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n);
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key);
 void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out);

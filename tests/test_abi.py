@@ -34,7 +34,8 @@ def test_struct_layouts(aclgpu_lib, tmp_path):
     assert aclgpu.ITEM_DTYPE.itemsize == 16  # acl_item_t: the 16-byte interned request
     pairs = {"acl_config_t": aclgpu._lib.Config, "acl_relationship_t": aclgpu._lib.Relationship, "acl_update_t": aclgpu._lib.Update,
              "acl_filter_t": aclgpu._lib.Filter, "acl_check_item_t": aclgpu._lib.CheckItem, "acl_stats_t": aclgpu._lib.Stats,
-             "acl_shard_step_t": aclgpu._lib.ShardStep, "acl_call_opts_t": aclgpu._lib.CallOpts}
+             "acl_shard_step_t": aclgpu._lib.ShardStep, "acl_call_opts_t": aclgpu._lib.CallOpts,
+             "acl_shard_comm_t": aclgpu._lib.ShardComm, "acl_shard_bulk_stats_t": aclgpu._lib.ShardBulkStats}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "aclgpu.h"', 'int main(void) {']
     for cname, ct in pairs.items():
         lines.append(f'printf("{cname} %zu", sizeof({cname}));')

@@ -168,6 +168,85 @@ def test_sharded_random_graphs_and_depth(world, aclgpu):
                 assert ids == co.lookup(*l), (ci, world, l)
 
 
+@pytest.mark.parametrize("world,xcap", [(2, 0), (8, 0), (5, 8)])
+def test_native_loop_logical_shards(world, xcap, aclgpu, monkeypatch):
+    """acl_shard_check_bulk -- the whole level loop inside libaclgpu.so, one fixed-capacity all-gather per level, decisions on the
+    device -- on G logical shards of one GPU (the collective is a device-to-device copy between them; with RCCL it is
+    ncclAllGather, same loop): answers equal the oracle's and the host-driven protocol's; xcap=8 forces grow-and-redo."""
+    from aclgpu import sharded, workloads
+    if xcap:
+        monkeypatch.setenv("ACL_SHARD_XCAP", str(xcap))
+    w = workloads.c4(scale=0.02, batch=30000, n_user=20000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rt, perm, st = w.check
+    operms, oerrs = o.check_bulk_ids(rt, perm, w.res, st, "", w.subj)
+    engines = []
+
+    def make(rank, nshards):
+        e = aclgpu.Engine(w.schema, contexts=1)
+        w.load(e)
+        engines.append(e)
+        return sharded.GpuShard(e, rank, nshards)
+
+    def run(se):
+        items = se.shard.e.make_items(rt, perm, w.res, st, "", w.subj)
+        p, er, stats = se.check_bulk_ids_native(items)
+        p2, er2, stats2 = se.check_bulk_ids_native(items)  # second batch: the burst is sized by the first one's depth
+        return p.cpu().numpy(), er.cpu().numpy(), stats, p2.cpu().numpy(), er2.cpu().numpy(), stats2
+
+    try:
+        outs = sharded.run_logical_shards(world, make, run)
+    finally:
+        for e in engines:
+            e.close()
+    for p, er, stats, p2, er2, stats2 in outs:
+        assert np.array_equal(p, operms) and np.array_equal(er, oerrs)
+        assert np.array_equal(p2, operms) and np.array_equal(er2, oerrs)
+        assert stats["levels"] == outs[0][2]["levels"] and stats["exchanges"] >= stats["levels"]
+        assert stats2["host_syncs"] <= 3  # one per burst (the burst now covers the whole depth) + the final one
+        if xcap:
+            assert stats["retries"] >= 1 and stats["export_capacity"] > xcap
+
+
+def test_native_loop_depth_chain(aclgpu):
+    """The depth-50 chain whose every hop crosses shards, through the native loop: HAS at 50 dispatches, depth error at 51."""
+    from aclgpu import sharded
+    for hops in (49, 50):
+        tuples = chain_case(hops)
+        queries = [("team", "t0", "member", "user", "deep", ""), ("team", "t0", "member", "user", "nobody", ""), ("crew", "c0", "member", "user", "deep", "")]
+        co = orc.Oracle(CHAIN_SCHEMA)
+        co.write([(orc.OP_TOUCH, t) for t in tuples])
+        want = [co.check(*q) for q in queries]
+        engines = []
+
+        def make(rank, nshards):
+            e = aclgpu.Engine(CHAIN_SCHEMA, contexts=1)
+            e.write([(aclgpu.OP_TOUCH, t) for t in tuples])
+            for q in queries:
+                e.intern(q[0], q[1])
+                e.intern(q[3], q[4])
+            engines.append(e)
+            return sharded.GpuShard(e, rank, nshards)
+
+        def run(se):
+            e = se.shard.e
+            items = np.zeros(len(queries), dtype=aclgpu.ITEM_DTYPE)
+            for i, (rt, rid, pm, st, sid, sr) in enumerate(queries):
+                items[i] = (e.type_id(rt), e.relation_id(rt, pm), e.find(rt, rid), e.type_id(st), aclgpu.NO_RELATION, e.find(st, sid))
+            p, er, _s = se.check_bulk_ids_native(items)
+            return list(zip(p.cpu().tolist(), er.cpu().tolist()))
+
+        try:
+            outs = sharded.run_logical_shards(3, make, run)
+        finally:
+            for e in engines:
+                e.close()
+        for got in outs:
+            assert got == want, (hops, got, want)
+
+
 def test_sharded_engine_refuses_unsharded_entry_points(aclgpu):
     from aclgpu import sharded
     with aclgpu.Engine(SCHEMA) as e:
@@ -201,7 +280,10 @@ with se.shard.stream():
     se.comm.all_gather(se.gather[:64], se.export[:64])
     h = torch.ones(8, dtype=torch.uint8, device="cuda"); se.comm.all_reduce_max(h)
     se.comm.broadcast(bm, 0)
-print(json.dumps({"ok": ok, "levels": se.levels_last}))
+# the native loop over the library's OWN RCCL communicator (ncclCommInitRank / ncclAllGather / ncclAllReduce inside libaclgpu.so)
+pn, en, stn = se.check_bulk_ids_native(items)
+ok_native = bool(np.array_equal(pn.cpu().numpy(), want[0]) and np.array_equal(en.cpu().numpy(), want[1]))
+print(json.dumps({"ok": ok, "ok_native": ok_native, "native": stn, "levels": se.levels_last}))
 e.close(); dist.destroy_process_group()
 """
 
@@ -222,4 +304,5 @@ def test_protocol_over_rccl_world1(aclgpu, tmp_path):
     r = subprocess.run([sys.executable, "-c", NCCL_WORLD1], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out["ok"], out
+    assert out["ok"] and out["ok_native"], out
+    assert out["native"]["exchanges"] >= out["native"]["levels"] >= 1

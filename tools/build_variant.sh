@@ -6,5 +6,5 @@ TAG=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)/spicedb-kubeapi-proxy_amd
 make -s -C $R -j8 lib/libaclgpu.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $R/csrc/kernels.hip -o $R/build/kernels_$TAG.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $R/lib/libaclgpu_$TAG.so $(ls $R/build/*.cpp.o) $R/build/kernels_$TAG.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $R/lib/libaclgpu_$TAG.so $(ls $R/build/*.cpp.o) $R/build/kernels_$TAG.o -ldl
 echo built $R/lib/libaclgpu_$TAG.so
