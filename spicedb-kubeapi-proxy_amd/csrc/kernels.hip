@@ -53,18 +53,9 @@ constexpr int kBlock = kWavesPerBlock * 64;
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
 constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
-constexpr uint32_t kRowSlotShift = 26;          // task: which staged subject row its children probe (flush_simple), 4 bits
-constexpr uint32_t kCountMask = 0x03FFFFFFu;
+constexpr uint32_t kCountMask = 0x3FFFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
 constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
-// LDS-staged subject rows (flush_simple): the hashed row of the request's subject -- the resources it is directly related
-// to -- is copied into LDS once per flush and every child of that request probes it there.  A wave's tasks belong to a
-// handful of requests, so 64 x 3 children per step that used to cost one descriptor gather + two bucket gathers EACH now
-// cost one coalesced row load per distinct subject.
-constexpr uint32_t kRowSlots = 8;      // distinct subjects staged per flush; further ones probe in global memory
-constexpr uint32_t kRowCap = 16;       // buckets (16 B) per staged row; longer rows probe in global memory
-constexpr uint32_t kNoRowSlot = 15;    // task marker: not staged
-constexpr uint32_t kRowGlobal = 0xFFFFFFFFu;  // rnb[] marker: row too long for LDS
 
 // entry meta: slot[0:13) | level[13:19) | probed[19] | subject key[20:32)
 constexpr uint32_t kProbedBit = 1u << 19;
@@ -100,13 +91,11 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // LDS-staged task list of one wave.
 struct TaskLds {
     uint32_t start[kTaskCap];  // first edge (absolute index) -- or the object id for a "self" task
-    uint32_t count[kTaskCap];  // degree (| kSelfBit | kLeafAuthBit | staged row slot << kRowSlotShift)
+    uint32_t count[kTaskCap];  // degree (| kSelfBit | kLeafAuthBit)
     uint32_t req[kTaskCap];
     uint32_t meta[kTaskCap];   // child meta
     uint32_t sid[kTaskCap];
     uint32_t scan[64];
-    uint4 rows[kRowSlots][kRowCap];  // staged subject rows (flush_simple)
-    uint32_t rnb[kRowSlots];         // buckets of each staged row; 0 = the subject has no row; kRowGlobal = too long
 };
 
 // Wave-private output cursor, all fields wave-uniform.
@@ -260,14 +249,14 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
 #endif
 #ifndef ACL_SIMPLE_WIDTH
-#define ACL_SIMPLE_WIDTH 3  // A/B on C4 (tools/ab.sh): width 2 380 M/s, 3 398 M/s (5 waves/SIMD); 3 or 4 at 4 waves/SIMD 353-369 M/s
+#define ACL_SIMPLE_WIDTH 2  // round 2 A/B on one box (profiles/r02_kernel_ab.md): width 3 is 3 % faster (508 vs 525 us per batch) but needs 97 VGPRs -- 7
+                            // spilled at the 96 that 5 waves/SIMD allow; width 2 fits with ScratchSize 0
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
-// The children steps of flush_simple.  STAGED: every task's subject row sits in an LDS slot (two 16 B LDS reads per child);
-// otherwise descriptor + two bucket gathers per child in global memory, branch-free, W children per lane in flight.
-template <bool STAGED, int W, bool LOCAL>
-__device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+template <bool SHARDED, bool LOCAL>
+__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
                                               uint8_t *has, uint8_t *err) {
+    constexpr int W = kSimpleWidth;
     const uint32_t *__restrict__ edges = g.edges;
     const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
@@ -293,49 +282,32 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t T, WaveOut &wo
                 tj[k] = gq + j;
                 edge[k] = gld(edges, t.start[tj[k]] + (wv - t.scan[j]));
             }
-            bool contains[W];
-            if (STAGED) {
+            // the subject's row descriptor goes out in the same trip as the edge: it depends on the task, not on the child
+            uint2 d[W];
+            bool row[W];
 #pragma unroll
-                for (int k = 0; k < W; k++) {
-                    const uint32_t c = edge[k] & kIdMask;
-                    const uint32_t rs = (t.count[tj[k]] >> kRowSlotShift) & 7u;
-                    const uint32_t rnb = t.rnb[rs];
-                    uint32_t h1, h2;
-                    hashed_row_buckets(c, rnb ? rnb : 1u, &h1, &h2);
-                    const uint4 p = t.rows[rs][rnb ? h1 : 0u], q = t.rows[rs][rnb ? h2 : 0u];
-                    contains[k] = rnb && (p.x == c || p.y == c || p.z == c || p.w == c || q.x == c || q.y == c || q.z == c || q.w == c);
-                }
-            } else {
-                uint2 d[W];
-                bool row[W];
+            for (int k = 0; k < W; k++) {
+                const uint32_t sidk = t.sid[tj[k]];
+                row[k] = sidk < pop.nrows;
+                d[k] = gld(smeta, pop.base + (row[k] ? sidk : 0u));
+                row[k] = row[k] && d[k].y > d[k].x;
+            }
+            uint4 p[W], q[W];
 #pragma unroll
-                for (int k = 0; k < W; k++) {
-                    const uint32_t sidk = t.sid[tj[k]];
-                    row[k] = sidk < pop.nrows;
-                    d[k] = gld(smeta, pop.base + (row[k] ? sidk : 0u));
-                    row[k] = row[k] && d[k].y > d[k].x;
-                }
-                uint4 p[W], q[W];
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    const uint32_t b0 = row[k] ? d[k].x : 0u, nbk = row[k] ? d[k].y - d[k].x : 1u;
-                    uint32_t h1, h2;
-                    hashed_row_buckets(edge[k] & kIdMask, nbk, &h1, &h2);
-                    p[k] = gld(buckets, b0 + h1);
-                    q[k] = gld(buckets, b0 + h2);
-                }
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    const uint32_t c = edge[k] & kIdMask;
-                    contains[k] = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
-                }
+            for (int k = 0; k < W; k++) {
+                const uint32_t b0 = row[k] ? d[k].x : 0u, nbk = row[k] ? d[k].y - d[k].x : 1u;
+                uint32_t h1, h2;
+                hashed_row_buckets(edge[k] & kIdMask, nbk, &h1, &h2);
+                p[k] = gld(buckets, b0 + h1);
+                q[k] = gld(buckets, b0 + h2);
             }
 #pragma unroll
             for (int k = 0; k < W; k++) {
                 const uint32_t c = edge[k] & kIdMask;
+                const bool contains = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
                 const uint32_t req = t.req[tj[k]], meta = t.meta[tj[k]];
                 const uint32_t level = meta_level(meta);
-                const bool hit = valid[k] && contains[k] && level + pop.dlevel <= kMaxLevels;
+                const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
                 const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
                 bool push = valid[k] && !(edge[k] & kLeafBit);
                 if (hit) {
@@ -353,65 +325,6 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t T, WaveOut &wo
         }
         wave_lds_fence();
     }
-}
-
-// Subject rows in LDS: when the flush's tasks belong to at most kRowSlots distinct subjects (deep levels: tens of entries per
-// request) whose hashed rows fit a slot, the rows are staged once -- two trips, the second a coalesced load per subject -- and
-// every child probes LDS: 64 x kStagedWidth children per step cost one edge gather each.  Otherwise (shallow levels: a wave's
-// 64-128 tasks are as many requests) staging would be two trips for nothing and the children probe global memory as before.
-#ifndef ACL_STAGED_WIDTH
-#define ACL_STAGED_WIDTH 4
-#endif
-constexpr int kStagedWidth = ACL_STAGED_WIDTH;
-template <bool SHARDED, bool LOCAL>
-__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
-                                              uint8_t *has, uint8_t *err) {
-    const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
-    const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
-    // ---- distinct subjects of the flush (tasks i and 64 + i are looked after by lane i)
-    const bool inA = lane < T, inB = lane + 64 < T;
-    const uint32_t sidA = inA ? t.sid[lane] : 0u, sidB = inB ? t.sid[lane + 64] : 0u;
-    uint32_t slotA = kNoRowSlot, slotB = kNoRowSlot, mysid = 0, ns = 0;
-    uint64_t pa = __ballot(inA), pb = __ballot(inB);
-    while ((pa | pb) && ns < kRowSlots) {
-        const uint32_t s0 = pa ? (uint32_t)__builtin_amdgcn_readlane((int)sidA, __ffsll((unsigned long long)pa) - 1)
-                               : (uint32_t)__builtin_amdgcn_readlane((int)sidB, __ffsll((unsigned long long)pb) - 1);
-        const bool mA = inA && sidA == s0, mB = inB && sidB == s0;
-        if (mA) slotA = ns;
-        if (mB) slotB = ns;
-        pa &= ~__ballot(mA);
-        pb &= ~__ballot(mB);
-        if (lane == ns) mysid = s0;
-        ns++;
-    }
-#ifndef ACL_STAGE
-#define ACL_STAGE 1  // A/B knob (tools/build_variant.sh): 0 = never stage subject rows in LDS
-#endif
-    bool staged = ACL_STAGE && !(pa | pb);  // every task's subject got a slot
-    if (staged) {
-        // trip 1: the subjects' row descriptors (lane k holds subject k)
-        const bool own = lane < ns && mysid < pop.nrows;
-        uint2 d = gld(smeta, pop.base + (own ? mysid : 0u));
-        if (!own) d = make_uint2(0, 0);
-        const uint32_t nb = d.y > d.x ? d.y - d.x : 0u;
-        staged = !__ballot(nb > kRowCap);  // a row too long for its slot (rare): the whole flush probes global memory
-        if (staged) {
-            if (lane < ns) t.rnb[lane] = nb;
-            // trip 2: the rows themselves, four subjects per load instruction (16 lanes x 16 B each, coalesced)
-#pragma unroll
-            for (uint32_t pass = 0; pass < kRowSlots / 4; pass++) {
-                const uint32_t k = pass * 4 + (lane >> 4), i = lane & 15u;
-                const uint32_t b0 = (uint32_t)__shfl((int)d.x, (int)k, 64), n = (uint32_t)__shfl((int)nb, (int)k, 64);
-                const bool ld = k < ns && i < n;
-                const uint4 v = gld(buckets, ld ? b0 + i : 0u);
-                if (ld) t.rows[k][i] = v;
-            }
-            if (inA) t.count[lane] |= slotA << kRowSlotShift;
-            if (inB) t.count[lane + 64] |= slotB << kRowSlotShift;
-        }
-    }
-    if (staged) simple_steps<true, kStagedWidth, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
-    else simple_steps<false, kSimpleWidth, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
 }
 
 // Second specialised expansion: all tasks lead to one child slot whose program is at most two hashed probes followed by at
