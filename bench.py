@@ -45,6 +45,7 @@ WORKLOAD_DESC = {
     "C3": "C3: C2 graph + 64 power users, Filter/LookupResources(pod, view, user) returning ~10k allowed IDs per user",
     "C4": "C4: 10M-relationship / 1M-object 5-level nested-group graph, 256k-batch Check",
     "C5": "C5: 100M-relationship graph sharded by object type, mixed stream (90% 256k-batch Check / 10% Filter) with per-level frontier all-gather",
+    "C5R": "C5-size graph (100M relationships / 10M objects, ~0.7 GB snapshot: beyond the 256 MiB Infinity Cache) as ONE single-GPU replica, 256k-batch Check",
 }
 
 
@@ -577,6 +578,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
     ap.add_argument("--window", type=int, default=2, help="batches in flight in the pipelined leg (<= the engine's evaluation contexts)")
@@ -623,8 +625,9 @@ def main():
     t_gen = time.time() - t0
     n = int(w.res.size)
 
-    if args.workload == "C5":
+    if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
+    label = "C5R" if args.workload == "C5" else args.workload
     eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window))
     t0 = time.time()
     w.load(eng)
@@ -642,7 +645,7 @@ def main():
             raise SystemExit("PARITY FAILURE: GPU lookup differs from the oracle")
         return
 
-    rec, gpu_perm, gpu_err = check_bench(args, w, eng, args.steps, args.warmup, world, rank, args.workload, args.legs, dist if world > 1 else None)
+    rec, gpu_perm, gpu_err = check_bench(args, w, eng, args.steps, args.warmup, world, rank, label, args.legs, dist if world > 1 else None)
     elapsed = rec.pop("elapsed")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -673,7 +676,7 @@ def main():
         out.update(rec)
         if world == 1 and not args.no_cpu:
             out["_steps"] = args.steps
-            cpu_and_roofline(args, w, out, gpu_perm, gpu_err, args.workload)
+            cpu_and_roofline(args, w, out, gpu_perm, gpu_err, label)
             out.pop("_steps")
         else:
             out.pop("kernel", None)

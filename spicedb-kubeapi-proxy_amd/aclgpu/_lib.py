@@ -26,7 +26,7 @@ SYMBOLS = [
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
-    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl",
+    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_selfcheck_compaction",
 ]
 
 
@@ -155,6 +155,7 @@ def load():
     L.acl_lookup_one.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.acl_batcher_lookup_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_selfcheck_snapshot.argtypes = [H, C.POINTER(C.c_int)]
+    L.acl_selfcheck_compaction.argtypes = [H, C.c_int, C.POINTER(C.c_int)]
     L.acl_delete_by_filter_pre.argtypes = [H, C.POINTER(Filter), C.POINTER(Filter), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_check_bulk_ids_opts.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(CallOpts)]
     L.acl_check_bulk_ids_submit.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]

@@ -417,6 +417,13 @@ class Engine:
         self._check(self._L.acl_selfcheck_snapshot(self._h, C.byref(p)))
         return bool(p.value)
 
+    def selfcheck_compaction(self, phase: int) -> bool:
+        """Test hook (store-only engines): phase 0 = build from a copy-on-write view; phase 1 = catch up, adopt, verify.
+        Returns True when phase 1 adopted the background build."""
+        a = C.c_int(1)
+        self._check(self._L.acl_selfcheck_compaction(self._h, int(phase), C.byref(a)))
+        return bool(a.value)
+
     # ---- measurement
     def stats(self) -> dict:
         s = Stats()

@@ -112,6 +112,126 @@ bool snapshot_current(acl_engine *h, bool need_reverse) {
     return !need_reverse || h->rev_uploaded;
 }
 
+// ---- background compaction (engine_internal.hpp Compaction); everything here runs under state_mu EXCLUSIVE except the worker
+static bool compaction_due(acl_engine *h) {
+    const Snapshot &s = h->snap;
+    if (s.garbage_words * 8 > s.edges.size() + s.buckets.size() + 65536) return true;  // half of the 25 % that forces a rebuild
+    const Schema &sc = h->store.schema();
+    for (int slot = 0; slot < sc.nslots && slot < (int)s.lay.size(); slot++) {  // half of a table's headroom for new objects used up
+        const RelLayout &l = s.lay[slot];
+        if (l.nrows && (uint64_t)h->store.objects(sc.slot_owner[slot].first).count() * 10 > (uint64_t)l.nrows * 9) return true;
+        for (size_t k = 0; k < l.cls.size(); k++) {
+            const auto [t, m] = sc.slot_owner[slot];
+            if (l.cls[k].hashed && l.cls[k].nsubjects &&
+                (uint64_t)h->store.objects(sc.defs[t].members[m].classes[k].stype).count() * 10 > (uint64_t)l.cls[k].nsubjects * 9)
+                return true;
+        }
+    }
+    return false;
+}
+
+static void compaction_start(acl_engine *h) {
+    if (!h->compaction_enabled || h->store_only) return;
+    if (!h->compaction) h->compaction = std::make_unique<Compaction>();
+    Compaction *c = h->compaction.get();
+    if (c->state.load() == 1) return;  // one at a time
+    if (c->worker.joinable()) c->worker.join();
+    if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
+    auto view = std::make_shared<Store>(h->store.view());  // tables shared copy-on-write: O(#tables), not O(#relationships)
+    c->shard = h->shard;
+    c->with_reverse = h->rev_uploaded;
+    c->now = h->store.now();
+    c->error.clear();
+    c->state.store(1);
+    const int device = h->device;
+    c->worker = std::thread([c, view, device] {
+        auto up = [&](auto &dev, const auto &host) { return dev.upload(host, c->stream) == hipSuccess; };
+        bool ok = hipSetDevice(device) == hipSuccess;
+        if (ok) {
+            build_forward(*view, c->now, &c->snap, c->shard);
+            if (c->with_reverse) build_reverse(*view, c->now, &c->snap, c->shard);
+            const Snapshot &s = c->snap;
+            ok = std::max({s.meta.size(), s.edges.size(), s.buckets.size()}) < ((size_t)1 << 30) && up(c->d_meta, s.meta) && up(c->d_edges, s.edges) &&
+                 up(c->d_buckets, s.buckets) && up(c->d_ops, s.ops) && up(c->d_progs, s.progs) && up(c->d_tsb, s.type_slot_base) && up(c->d_tnm, s.type_nmembers);
+            if (ok && c->with_reverse)
+                ok = up(c->d_rmeta, s.rmeta) && up(c->d_redges, s.redges) && up(c->d_rops, s.rops) && up(c->d_rprogs, s.rprogs) && up(c->d_rseeds, s.rseeds) &&
+                     up(c->d_sbb, s.slot_bit_base) && up(c->d_snobj, s.slot_nobjects);
+            ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+        }
+        c->state.store(ok ? 2 : 3);
+    });
+}
+
+void compaction_join(acl_engine *h) {
+    if (!h->compaction) return;
+    if (h->compaction->worker.joinable()) h->compaction->worker.join();
+    h->compaction->state.store(0);
+}
+
+// A finished build: bring it from the view's revision to the store's with the ordinary patcher, then swap it in.
+// Returns true when the engine's snapshot is now the compacted one (and current).
+static bool compaction_adopt(acl_engine *h, int64_t now) {
+    Compaction *c = h->compaction.get();
+    if (!c || c->state.load() != 2) {
+        if (c && c->state.load() == 3) c->state.store(0);
+        return false;
+    }
+    c->state.store(0);
+    if (c->worker.joinable()) c->worker.join();
+    if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world || now < c->snap.valid_lo || now >= c->snap.valid_hi) return false;
+    std::vector<Patch> patches;
+    const uint64_t from = c->snap.revision;
+    if (!patch_forward(h->store, now, &c->snap, h->shard, &patches)) return false;  // (a bulk load or > 8192 changes meanwhile: the synchronous path decides)
+    bool rev_ok = c->with_reverse && patch_reverse(h->store, now, from, &c->snap, h->shard, &patches);
+    hipStream_t s = h->up_stream;
+    bool fits = true;
+    hipError_t pe = hipSuccess;
+    for (const Patch &p : patches) {
+        hipError_t e1 = hipSuccess;
+        switch (p.array) {
+            case Patch::META: fits = fits && c->d_meta.patch(c->snap.meta, p.off, p.n, s, &e1); break;
+            case Patch::EDGES: fits = fits && c->d_edges.patch(c->snap.edges, p.off, p.n, s, &e1); break;
+            case Patch::BUCKETS: fits = fits && c->d_buckets.patch(c->snap.buckets, p.off, p.n, s, &e1); break;
+            case Patch::OPS: fits = fits && c->d_ops.patch(c->snap.ops, p.off, p.n, s, &e1); break;
+            case Patch::RMETA: fits = fits && (!rev_ok || c->d_rmeta.patch(c->snap.rmeta, p.off, p.n, s, &e1)); break;
+            case Patch::REDGES: fits = fits && (!rev_ok || c->d_redges.patch(c->snap.redges, p.off, p.n, s, &e1)); break;
+        }
+        if (e1 != hipSuccess) pe = e1;
+    }
+    if (pe != hipSuccess || !fits || hipStreamSynchronize(s) != hipSuccess) return false;
+    // swap: the old arrays go to the compaction object and are freed (or reused) by its next run
+    h->dev_valid = false;
+    h->snap = std::move(c->snap);
+    c->snap = Snapshot();
+    h->d_meta.swap(c->d_meta);
+    h->d_edges.swap(c->d_edges);
+    h->d_buckets.swap(c->d_buckets);
+    h->d_ops.swap(c->d_ops);
+    h->d_progs.swap(c->d_progs);
+    h->d_tsb.swap(c->d_tsb);
+    h->d_tnm.swap(c->d_tnm);
+    if (rev_ok) {
+        h->d_rmeta.swap(c->d_rmeta);
+        h->d_redges.swap(c->d_redges);
+        h->d_rops.swap(c->d_rops);
+        h->d_rprogs.swap(c->d_rprogs);
+        h->d_rseeds.swap(c->d_rseeds);
+        h->d_sbb.swap(c->d_sbb);
+        h->d_snobj.swap(c->d_snobj);
+    }
+    h->rev_uploaded = rev_ok;
+    if (!rev_ok) h->snap.has_reverse = false;
+    h->snap_valid = true;
+    h->dev_valid = true;
+    std::lock_guard<std::mutex> lk(h->stats_mu);
+    h->stats.snapshot_compactions++;
+    h->stats.snapshot_edges = h->snap.nedges;
+    h->stats.snapshot_edges_local = h->snap.nedges_local;
+    h->stats.snapshot_bytes = h->snap.meta.size() * 4 + h->snap.edges.size() * 4 + h->snap.buckets.size() * 4 + h->snap.ops.size() * sizeof(FwdOp) +
+                              h->snap.progs.size() * sizeof(SlotProg) + (rev_ok ? h->snap.rmeta.size() * 4 + h->snap.redges.size() * 4 : 0);
+    return true;
+}
+
 // caller holds state_mu EXCLUSIVE: no evaluation is reading the device arrays
 int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
@@ -119,6 +239,7 @@ int ensure_snapshot(acl_engine *h) {
     if (snapshot_current(h, false)) return ACL_OK;
     const int64_t now = h->store.now();
     hipStream_t s = h->up_stream;
+    if (h->snap_valid && h->dev_valid && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
     if (h->snap_valid && h->dev_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi &&
         h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
@@ -161,10 +282,13 @@ int ensure_snapshot(acl_engine *h) {
             h->dev_valid = true;
             h->rev_uploaded = had_rev && rev_ok;
             if (!h->rev_uploaded) h->snap.has_reverse = false;  // not patchable (or never built): rebuilt lazily by the next lookup
-            std::lock_guard<std::mutex> lk(h->stats_mu);
-            h->stats.snapshot_patches++;
-            h->stats.snapshot_edges = h->snap.nedges;
-            h->stats.snapshot_edges_local = h->snap.nedges_local;
+            {
+                std::lock_guard<std::mutex> lk(h->stats_mu);
+                h->stats.snapshot_patches++;
+                h->stats.snapshot_edges = h->snap.nedges;
+                h->stats.snapshot_edges_local = h->snap.nedges_local;
+            }
+            if (compaction_due(h)) compaction_start(h);  // garbage / headroom half used: build the next snapshot in the background
             return ACL_OK;
         }
     }
@@ -292,6 +416,8 @@ void Eval::end() {
     }
 }
 
+constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path declines the batch (never leaves this file)
+
 // Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
 // batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
 // the context's frontier buffers.
@@ -302,7 +428,7 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
     const uint32_t nwaves = (n + rpw - 1) / rpw;
     const uint64_t cap64 = c->frontier_entries / std::max<uint32_t>(nwaves, 1);
     const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 1u << 20);
-    if (cap < 256) return ACL_ERR_RESOURCE_EXHAUSTED;
+    if (cap < 256) return kTakeLevelLoop;
     uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;
     HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(uint32_t), c->stream));
     ev_begin(c, 2);
@@ -312,7 +438,45 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
-    if (c->h_status[0]) return ACL_ERR_RESOURCE_EXHAUSTED;
+    if (c->h_status[0]) return kTakeLevelLoop;
+    c->stats.check_items += n;
+    c->stats.check_passes++;
+    c->stats.local_passes++;
+    return ACL_OK;
+}
+
+// The same for a batch in HOST memory, with no copy engine in the path: the kernel reads the items from pinned host memory
+// and writes the answers (and its overflow flag) straight back into pinned host memory, so a pass is ONE launch and ONE
+// stream synchronisation -- no H2D, no flag memset, no D2H copies, each of which costs a few microseconds of API time that a
+// 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
+static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out) {
+    const uint32_t max_waves = (uint32_t)h->grid_blocks * kWavesPerBlock;
+    uint32_t rpw = std::min<uint32_t>(std::max<uint32_t>((n + max_waves - 1) / max_waves, 1), 64);
+    const uint32_t nwaves = (n + rpw - 1) / rpw;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / std::max<uint32_t>(nwaves, 1), 1u << 20);
+    if (cap < 256) return kTakeLevelLoop;
+    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+    HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
+    HIP_TRY(c->h_out.ensure(64 + (size_t)n * 5));
+    std::memcpy(c->h_in.p, items, (size_t)n * sizeof(acl_item_t));
+    uint32_t *flag = (uint32_t *)c->h_out.p;
+    int32_t *h_err = (int32_t *)((char *)c->h_out.p + 64);
+    uint8_t *h_perm = (uint8_t *)(h_err + n);
+    *flag = 0;
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_in, c->h_in.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
+    ev_begin(c, 2);
+    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, rpw, c->d_fbuf[0].p, c->d_fbuf[1].p, cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
+                       (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64));
+    ev_end(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+    if (*flag) return kTakeLevelLoop;
+    std::memcpy(perm_out, h_perm, n);
+    if (err_out) std::memcpy(err_out, h_err, (size_t)n * sizeof(int32_t));
     c->stats.check_items += n;
     c->stats.check_passes++;
     c->stats.local_passes++;
@@ -328,8 +492,7 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
     // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
     if (n <= h->local_max_items) {
         int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
-        if (rc != ACL_ERR_RESOURCE_EXHAUSTED || std::string(acl_last_error()).find("enumeration limit") != std::string::npos) return rc;
-        // a wave ran out of private frontier: the level-synchronous path takes the batch
+        if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a wave ran out of private frontier, the level-synchronous path takes the batch
     }
     for (int attempt = 0;; attempt++) {
         if ((uint64_t)n > c->frontier_entries) {
@@ -387,6 +550,11 @@ int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint
 // Buffers from acl_host_alloc are pinned and are DMA'd directly; anything else is staged through the context's pinned
 // buffers (an async copy from pageable memory would be staged by the runtime anyway, synchronously).
 int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    if (n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1) {
+        int rc = check_pass_local_host(h, c, items, (uint32_t)n, perm_out, err_out);
+        if (rc != kTakeLevelLoop) return rc;
+        // a wave ran out of private frontier: the level-synchronous path below takes the batch
+    }
     HIP_TRY(c->d_items.ensure(n));
     HIP_TRY(c->d_perm.ensure(n));
     HIP_TRY(c->d_errout.ensure(n));
@@ -397,7 +565,18 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         src = c->h_in.p;
     }
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
-    int rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);
+    int rc;
+    if (n >= kComputeTokenItems) {
+        // A batch this size fills every wave slot of the chip by itself: two such batches' kernels running at once only
+        // take turns (measured: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
+        // copies with ANOTHER batch's kernels: the H2D above is already under way when we queue for the compute token,
+        // and the D2H below runs after it is handed on.
+        HIP_TRY(hipStreamSynchronize(c->stream));  // items are on the device before the kernels' turn starts
+        std::lock_guard<std::mutex> tk(h->compute_mu);
+        rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);  // (ends with the context's stream synchronised)
+    } else {
+        rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);
+    }
     if (rc) return rc;
     const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
     uint8_t *hp = perm_out;
@@ -715,6 +894,7 @@ void acl_close(acl_engine_t *h) {
     async_shutdown(h);
     batcher_destroy(h);
     (void)acl_shard_rccl_destroy(h);
+    compaction_join(h);
     if (h->store_only) {
         delete h;
         return;
@@ -724,6 +904,8 @@ void acl_close(acl_engine_t *h) {
         std::lock_guard<RwLock> lk(h->state_mu);  // waits for evaluations in flight
         h->ctxs.clear();
         h->shard_ctx.reset();
+        if (h->compaction && h->compaction->stream) (void)hipStreamDestroy(h->compaction->stream);
+        h->compaction.reset();
         std::lock_guard<std::mutex> plk(h->pinned_mu);
         for (auto &r : h->pinned) (void)hipHostFree((void *)r.first);
         h->pinned.clear();

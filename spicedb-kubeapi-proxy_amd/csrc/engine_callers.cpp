@@ -438,6 +438,43 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
     return ACL_OK;
 }
 
+// Test hook for the background compaction's HOST half (store-only engines): phase 0 takes the copy-on-write view of the
+// store and builds a snapshot from it (what the worker thread does); phase 1 brings that snapshot up to the store's
+// present revision with the ordinary patcher, makes it the engine's snapshot (what the adopting reader does) and
+// verifies it against the store.  Writes issued between the two phases are exactly the case the design must get right.
+int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out) {
+    std::lock_guard<RwLock> lk(h->state_mu);
+    if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    if (!h->store_only) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_compaction drives the host snapshot itself: use a store-only engine");
+    const int64_t now = h->store.now();
+    if (!h->compaction) h->compaction = std::make_unique<Compaction>();
+    Compaction *c = h->compaction.get();
+    if (phase == 0) {
+        Store view = h->store.view();
+        c->shard = h->shard;
+        c->now = now;
+        build_forward(view, now, &c->snap, c->shard);
+        build_reverse(view, now, &c->snap, c->shard);
+        c->state.store(2);
+        return ACL_OK;
+    }
+    if (c->state.load() != 2) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_compaction: phase 1 without phase 0");
+    c->state.store(0);
+    std::vector<Patch> patches;
+    const uint64_t from = c->snap.revision;
+    bool ok = now >= c->snap.valid_lo && now < c->snap.valid_hi && patch_forward(h->store, now, &c->snap, h->shard, &patches);
+    if (ok && !patch_reverse(h->store, now, from, &c->snap, h->shard, &patches)) c->snap.has_reverse = false;
+    if (adopted_out) *adopted_out = ok ? 1 : 0;
+    if (!ok) return ACL_OK;  // not adoptable (bulk load, too many changes, an expiry passed): the engine would rebuild instead
+    h->snap = std::move(c->snap);
+    c->snap = Snapshot();
+    h->snap_valid = true;
+    if (!h->snap.has_reverse) build_reverse(h->store, now, &h->snap, h->shard);
+    std::string why;
+    if (!verify_snapshot(h->store, now, h->snap, h->shard, &why)) return fail(ACL_ERR_INTERNAL, "compacted snapshot does not match the store: " + why);
+    return ACL_OK;
+}
+
 int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us) {
     std::lock_guard<std::mutex> lk(h->batcher_mu);
     acl_engine::Batcher &B = *h->batcher;

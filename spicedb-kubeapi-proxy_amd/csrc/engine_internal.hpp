@@ -138,6 +138,8 @@ struct PinnedBuf {
     }
 };
 
+constexpr size_t kComputeTokenItems = 32768;  // host-buffer batches at least this large run their kernels one batch at a time
+
 // per-call cancellation / deadline (reference: LookupResources runs on the HTTP request's ctx and is abandoned when it is
 // cancelled, responsefilterer.go:165-170; the prefilter join times out after 10 s, responsefilterer.go:44,196-204)
 struct CallOpts {
@@ -186,6 +188,27 @@ using namespace aclint;
 
 struct AsyncPool;  // engine_async.cpp
 
+// Background snapshot compaction (engine.cpp).  Patching writes into the HBM snapshot leaves garbage behind (relocated
+// rows) and eats the tables' headroom; once either passes a threshold the next snapshot is built from a copy-on-write view
+// of the store on a worker thread and uploaded to fresh device arrays on the worker's own stream, while reads keep
+// patching and using the old one.  The next reader adopts it under the lock: catch-up patch from the view's revision,
+// pointer swap.  (Round 1 rebuilt synchronously: the first read after the threshold paid 100-140 ms on the 10 M graph.)
+struct Compaction {
+    std::thread worker;
+    std::atomic<int> state{0};  // 0 idle, 1 building, 2 ready, 3 failed
+    Snapshot snap;
+    ShardSpec shard;
+    bool with_reverse = false;
+    int64_t now = 0;
+    hipStream_t stream = nullptr;
+    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm, d_rmeta, d_redges, d_sbb, d_snobj;
+    DevArray<FwdOp> d_ops;
+    DevArray<SlotProg> d_progs;
+    DevArray<RevOp> d_rops;
+    DevArray<RevProg> d_rprogs, d_rseeds;
+    std::string error;
+};
+
 struct acl_engine {
     RwLock state_mu;             // store + snapshot (see the header comment)
     std::shared_mutex names_mu;  // schema + object-name tables
@@ -217,7 +240,10 @@ struct acl_engine {
     uint32_t max_ctx = 4;
     std::unique_ptr<PassCtx> shard_ctx;  // the acl_shard_* protocol keeps state across calls: its own context, never pooled
     void *rccl_comm = nullptr;           // ncclComm_t of acl_shard_rccl_init
+    std::unique_ptr<Compaction> compaction;  // touched only under state_mu exclusive (the worker owns its innards while state == 1)
+    bool compaction_enabled = true;
     std::mutex shard_mu;
+    std::mutex compute_mu;  // turn-taking of chip-filling batches (check_ids_host)
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 8192;  // batches up to this size take the single-launch path (k_check_local); 0 = never
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
@@ -268,6 +294,7 @@ int ensure_snapshot(acl_engine *h);
 int ensure_reverse(acl_engine *h);
 // true when the device snapshot answers for the store as it is now (caller holds state_mu at least shared)
 bool snapshot_current(acl_engine *h, bool need_reverse);
+void compaction_join(acl_engine *h);  // acl_close / schema reload: waits for a build in flight and drops its result
 
 // RAII for one evaluating call: state_mu shared (snapshot brought up to date first) + a PassCtx from the pool.
 struct Eval {
@@ -299,7 +326,7 @@ int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index);
 void merge_stats(acl_engine *h, PassCtx *c);
 
 int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
-// every level in ONE launch, wave-private frontiers; ACL_ERR_RESOURCE_EXHAUSTED when a wave's private frontier overflowed
+// every level in ONE launch, wave-private frontiers; an internal negative code when a wave's private frontier overflowed (engine.cpp)
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
 int not_sharded(acl_engine *h);
 int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout);

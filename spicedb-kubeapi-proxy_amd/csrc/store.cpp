@@ -72,12 +72,12 @@ void ClassTable::settle() {
     std::sort(pending.begin(), pending.end());
     pending.erase(std::unique(pending.begin(), pending.end()), pending.end());
     if (keys.empty()) {
-        keys.swap(pending);
+        keys.mut().swap(pending);
     } else {
         std::vector<uint64_t> merged;
         merged.reserve(keys.size() + pending.size());
         std::set_union(keys.begin(), keys.end(), pending.begin(), pending.end(), std::back_inserter(merged));
-        keys.swap(merged);
+        keys.mut().swap(merged);
     }
     pending.clear();
     pending.shrink_to_fit();
@@ -141,6 +141,21 @@ int Store::class_index(int slot, int stype, int srel) const {
     for (size_t k = 0; k < cls.size(); k++)
         if (cls[k].stype == stype && cls[k].srel == srel) return (int)k;
     return -1;
+}
+
+Store Store::view() {
+    settle_all();
+    Store v;
+    v.schema_ = schema_;
+    v.schema_loaded_ = schema_loaded_;
+    v.objects_.resize(objects_.size());
+    for (size_t t = 0; t < objects_.size(); t++) v.objects_[t].reserve_ids(objects_[t].count());
+    v.tables_ = tables_;  // CowKeys copies share their vectors; the (small) expiry maps are copied
+    v.revision_ = revision_;
+    v.now_override_ = now_override_;
+    v.log_floor_ = revision_;
+    v.bulk_revision_ = bulk_revision_;
+    return v;
 }
 
 void Store::settle_all() {
@@ -288,13 +303,18 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
         if (skip[i]) continue;
         ClassTable &ct = tables_[rs[i].slot][rs[i].cls];
         uint64_t key = (uint64_t)rs[i].res << 32 | rs[i].subj;
-        auto it = std::lower_bound(ct.keys.begin(), ct.keys.end(), key);
-        bool present = it != ct.keys.end() && *it == key;
+        const bool present = ct.contains(key);
         if (updates[i].op == ACL_OP_DELETE) {
-            if (present) ct.keys.erase(it);
+            if (present) {
+                auto &kv = ct.keys.mut();
+                kv.erase(std::lower_bound(kv.begin(), kv.end(), key));
+            }
             ct.expiry.erase(key);
         } else {
-            if (!present) ct.keys.insert(it, key);
+            if (!present) {
+                auto &kv = ct.keys.mut();
+                kv.insert(std::lower_bound(kv.begin(), kv.end(), key), key);
+            }
             if (rs[i].expires) ct.expiry[key] = rs[i].expires;
             else ct.expiry.erase(key);
         }
@@ -347,8 +367,10 @@ Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t
     });
     for (const Hit &h : hits) {
         ClassTable &ct = tables_[h.slot][h.cls];
-        auto it = std::lower_bound(ct.keys.begin(), ct.keys.end(), h.key);
-        if (it != ct.keys.end() && *it == h.key) ct.keys.erase(it);
+        if (ct.contains(h.key)) {
+            auto &kv = ct.keys.mut();
+            kv.erase(std::lower_bound(kv.begin(), kv.end(), h.key));
+        }
         ct.expiry.erase(h.key);
     }
     revision_++;

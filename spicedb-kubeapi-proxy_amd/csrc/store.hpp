@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -88,8 +89,27 @@ class ObjectTable {
     std::atomic<uint32_t> count_{0};
 };
 
+// Sorted unique relationship keys behind a shared pointer (copy on write): a background snapshot build (engine.cpp, snapshot
+// compaction) keeps iterating the vector it took under the lock while writers clone a table before their first change to it.
+class CowKeys {
+  public:
+    using const_iterator = std::vector<uint64_t>::const_iterator;
+    const_iterator begin() const { return v_->begin(); }
+    const_iterator end() const { return v_->end(); }
+    size_t size() const { return v_->size(); }
+    bool empty() const { return v_->empty(); }
+    uint64_t operator[](size_t i) const { return (*v_)[i]; }
+    std::vector<uint64_t> &mut() {  // writers only (store lock held exclusively)
+        if (v_.use_count() > 1) v_ = std::make_shared<std::vector<uint64_t>>(*v_);
+        return *v_;
+    }
+
+  private:
+    std::shared_ptr<std::vector<uint64_t>> v_ = std::make_shared<std::vector<uint64_t>>();
+};
+
 struct ClassTable {
-    std::vector<uint64_t> keys;     // sorted unique (res << 32 | subj)
+    CowKeys keys;                   // sorted unique (res << 32 | subj)
     std::vector<uint64_t> pending;  // unsorted bulk appends, merged by settle()
     std::unordered_map<uint64_t, int64_t> expiry;  // only relationships with an expiration
     void settle();
@@ -117,6 +137,9 @@ class Store {
 
     uint64_t revision() const { return revision_; }
     void settle_all();
+    // A read-only twin for a background snapshot build: same schema, revision and clock, relationship tables SHARED
+    // (copy on write), object tables reduced to their id counts, no change feed.  Take it with the store lock held.
+    Store view();
 
     // expiration clock (unix seconds).  now_override_ == 0 -> wall clock.
     void set_now(int64_t t) { now_override_ = t; }

@@ -129,3 +129,48 @@ def test_patching_a_shard(aclgpu, world):
             e.selfcheck_snapshot()
     for e in engines:
         e.close()
+
+
+def test_background_compaction_host_half(aclgpu):
+    """Snapshot compaction (engine.cpp): a snapshot built from a COPY-ON-WRITE view of the store while writes keep landing,
+    then caught up with the ordinary patcher and adopted, must describe exactly the store -- including writes that hit the very
+    tables the build was reading (they clone the table first) and deletes of relationships the view still held."""
+    rng = random.Random(11)
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    e.write([(aclgpu.OP_TOUCH, t) for t in random_tuples(rng, 60)])
+    e.selfcheck_snapshot()
+    adopted = 0
+    for round_ in range(30):
+        e.selfcheck_compaction(0)  # the worker's part: view + build
+        for _ in range(rng.randint(0, 12)):  # writes racing with the "build": they must not disturb the view and must all be caught up
+            ts = random_tuples(rng, rng.randint(1, 6))
+            e.write([(rng.choice([aclgpu.OP_TOUCH, aclgpu.OP_TOUCH, aclgpu.OP_DELETE]), t) for t in ts])
+            if rng.random() < 0.3:
+                e.selfcheck_snapshot()  # reads in between keep patching the OLD snapshot
+        adopted += e.selfcheck_compaction(1)  # the adopting reader's part: catch up, swap, verify (raises on any mismatch)
+        e.selfcheck_snapshot()
+    assert adopted >= 25, adopted
+    # a bulk load between the phases is not in the change feed: the build must be discarded, not adopted
+    e.selfcheck_compaction(0)
+    e.add_edges("doc", "creator", "user", "", [0], [0])
+    assert e.selfcheck_compaction(1) is False
+    e.selfcheck_snapshot()
+    e.close()
+
+
+def test_view_is_isolated_from_writes(aclgpu):
+    """Copy-on-write tables: after the view is taken, 2 000 inserts and deletes in the live store leave a later adoption
+    exact (the view's rows were never touched) -- on a table big enough that an in-place edit would shift thousands of keys."""
+    rng = random.Random(3)
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    big = [("doc", f"d{i}", "viewer", "user", f"u{i % 97}", "") for i in range(4000)]
+    for i in range(0, len(big), 1000):
+        e.write([(aclgpu.OP_TOUCH, t) for t in big[i:i + 1000]])
+    e.selfcheck_snapshot()
+    e.selfcheck_compaction(0)
+    for i in range(0, 2000, 500):
+        e.write([(aclgpu.OP_DELETE, t) for t in big[i:i + 500]])
+        e.write([(aclgpu.OP_TOUCH, ("doc", f"n{i + k}", "viewer", "user", f"u{k % 13}", "")) for k in range(500)])
+    assert e.selfcheck_compaction(1) is True
+    assert len(e.read(rtype="doc", rel="viewer")) == 4000
+    e.close()

@@ -62,4 +62,4 @@ def test_bench_helpers_import_without_gpu():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert 1 <= m.usable_cores() <= os.cpu_count()
-    assert set(m.WORKLOAD_DESC) == {"C1", "C2", "C3", "C4", "C5"}
+    assert set(m.WORKLOAD_DESC) == {"C1", "C2", "C3", "C4", "C5", "C5R"}  # C5R: the C5-size graph as one replica (beyond-L3 data point)
