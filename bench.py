@@ -628,7 +628,7 @@ def main():
     if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
     label = "C5R" if args.workload == "C5" else args.workload
-    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window))
+    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window) + 1)
     t0 = time.time()
     w.load(eng)
     eng.snapshot()
@@ -691,7 +691,7 @@ def main():
         cfgs = {}
         try:
             w2 = workloads.c2()
-            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window))
+            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window) + 1)
             w2.load(e2)
             e2.snapshot()
             r2, p2, er2 = check_bench(args, w2, e2, max(args.steps, 50), args.warmup, 1, 0, "C2", "all")

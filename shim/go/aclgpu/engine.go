@@ -25,6 +25,7 @@ type Config struct {
 	FrontierEntries    uint64 // 0 = default
 	BatchMaxItems      uint32 // 0 = no micro-batching of single checks
 	BatchMaxWaitMicros uint32
+	Contexts           uint32 // evaluations in flight on the device at once (own HIP stream each); 0 = default (4)
 }
 
 // Engine owns one acl_engine_t.  All methods are safe for concurrent use (the C ABI is).
@@ -38,7 +39,7 @@ func lastError(rc C.int) error {
 // (pkg/spicedb/bootstrap.yaml) -> a running engine.
 func Open(cfg Config, schema, relationships string) (*Engine, error) {
 	var h *C.acl_engine_t
-	c := C.acl_config_t{device: C.int32_t(cfg.Device), frontier_entries: C.uint64_t(cfg.FrontierEntries)}
+	c := C.acl_config_t{device: C.int32_t(cfg.Device), frontier_entries: C.uint64_t(cfg.FrontierEntries), contexts: C.uint32_t(cfg.Contexts)}
 	if rc := C.acl_open(&c, &h); rc != 0 {
 		return nil, lastError(rc)
 	}

@@ -10,6 +10,8 @@ import (
 	"io"
 	"math/bits"
 	"runtime/cgo"
+	"sync/atomic"
+	"time"
 	"unsafe"
 
 	v1 "github.com/authzed/authzed-go/proto/authzed/api/v1"
@@ -32,11 +34,13 @@ func (p *permissionsClient) CheckPermission(ctx context.Context, in *v1.CheckPer
 	it := cs.item(in.Resource, in.Permission, in.Subject)
 	var perm C.uint8_t
 	var perr C.int32_t
-	if rc := C.acl_check_one(p.e.h, &it, &perm, &perr); rc != 0 {
+	opts, stop := callOpts(ctx) // ctx cancellation / deadline reach the engine through acl_call_opts_t
+	defer stop()
+	if rc := C.acl_check_one_opts(p.e.h, &it, &perm, &perr, opts); rc != 0 {
 		return nil, lastError(rc)
 	}
 	if perr != 0 {
-		return nil, status.Error(codes.Code(perr), "check failed") // e.g. InvalidArgument for an empty request
+		return nil, status.Error(itemCode(perr), "check failed") // e.g. InvalidArgument for an empty request
 	}
 	return &v1.CheckPermissionResponse{CheckedAt: p.e.zedToken(), Permissionship: v1.CheckPermissionResponse_Permissionship(perm)}, nil
 }
@@ -62,7 +66,7 @@ func (p *permissionsClient) CheckBulkPermissions(ctx context.Context, in *v1.Che
 	for i := range in.Items {
 		pair := &v1.CheckBulkPermissionsPair{Request: in.Items[i]}
 		if errs[i] != 0 {
-			pair.Response = &v1.CheckBulkPermissionsPair_Error{Error: status.New(codes.Code(errs[i]), "check failed").Proto()}
+			pair.Response = &v1.CheckBulkPermissionsPair_Error{Error: status.New(itemCode(errs[i]), "check failed").Proto()}
 		} else {
 			pair.Response = &v1.CheckBulkPermissionsPair_Item{Item: &v1.CheckBulkPermissionsResponseItem{
 				Permissionship: v1.CheckPermissionResponse_Permissionship(perm[i])}} // ACL_PERM_* == the proto enum values
@@ -82,13 +86,21 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 	}
 	rt := cs.add(in.ResourceObjectType)
 	typeID := C.acl_type_id(p.e.h, rt)
-	words := (uint32(C.acl_object_count(p.e.h, typeID)) + 1 + 31) / 32 + 1 // +1: the call may intern the subject
-	bm := make([]C.uint32_t, words)
+	// The result bitmap is engine-owned (acl_lookup_resources_alloc): it is sized when the walk runs, so objects interned by a
+	// racing WriteRelationships can never make a caller-sized buffer "too small".  Concurrent list requests of the same
+	// (type, permission, subject class) share one batched reverse walk (the micro-batcher); the HTTP request's ctx
+	// (responsefilterer.go:165-170) cancels the call while it queues and between level bursts of the walk.
+	var bmp *C.uint32_t
+	var words C.size_t
 	var count C.uint64_t
-	// acl_lookup_one: concurrent list requests of the same (type, permission, subject class) share one batched reverse walk
-	if rc := C.acl_lookup_one(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), &bm[0], C.size_t(words), &count); rc != 0 {
+	opts, stop := callOpts(ctx)
+	defer stop()
+	if rc := C.acl_lookup_resources_alloc(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), opts, &bmp, &words, &count); rc != 0 {
 		return nil, lastError(rc)
 	}
+	bm := make([]C.uint32_t, int(words))
+	copy(bm, unsafe.Slice(bmp, int(words)))
+	C.acl_free(unsafe.Pointer(bmp))
 	return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: bm, at: p.e.zedToken()}, nil
 }
 
@@ -133,6 +145,9 @@ func (p *permissionsClient) WriteRelationships(ctx context.Context, in *v1.Write
 	defer cs.free()
 	ups := make([]C.acl_update_t, len(in.Updates)+1)
 	for i, u := range in.Updates {
+		if u == nil || u.Relationship == nil || u.Relationship.Resource == nil || u.Relationship.Subject == nil || u.Relationship.Subject.Object == nil {
+			return nil, status.Error(codes.InvalidArgument, "invalid WriteRelationshipsRequest: update without relationship, resource or subject")
+		}
 		r := u.Relationship
 		rel := C.acl_relationship_t{resource_type: cs.add(r.Resource.ObjectType), resource_id: cs.add(r.Resource.ObjectId), relation: cs.add(r.Relation),
 			subject_type: cs.add(r.Subject.Object.ObjectType), subject_id: cs.add(r.Subject.Object.ObjectId), subject_relation: cs.add(r.Subject.OptionalRelation)}
@@ -143,6 +158,9 @@ func (p *permissionsClient) WriteRelationships(ctx context.Context, in *v1.Write
 	}
 	pre := make([]C.acl_filter_t, len(in.OptionalPreconditions)+1)
 	for i, pc := range in.OptionalPreconditions {
+		if pc == nil || pc.Filter == nil {
+			return nil, status.Error(codes.InvalidArgument, "invalid WriteRelationshipsRequest: precondition without filter")
+		}
 		pre[i] = cs.filter(pc.Filter, C.int32_t(pc.Operation)) // OPERATION_MUST_NOT_MATCH/MUST_MATCH == ACL_PRE_*
 	}
 	var rev C.uint64_t
@@ -152,13 +170,27 @@ func (p *permissionsClient) WriteRelationships(ctx context.Context, in *v1.Write
 	return &v1.WriteRelationshipsResponse{WrittenAt: p.e.zedToken()}, nil
 }
 
-// DeleteRelationships: e2e/util_test.go:66.
+// DeleteRelationships: e2e/util_test.go:66.  OptionalPreconditions are evaluated against the pre-delete state, atomically
+// with the delete (acl_delete_by_filter_pre); a limit / partial deletion is not something the engine offers: refused.
 func (p *permissionsClient) DeleteRelationships(ctx context.Context, in *v1.DeleteRelationshipsRequest, _ ...grpc.CallOption) (*v1.DeleteRelationshipsResponse, error) {
+	if in.RelationshipFilter == nil {
+		return nil, status.Error(codes.InvalidArgument, "invalid DeleteRelationshipsRequest: no filter")
+	}
+	if in.OptionalLimit != 0 || in.OptionalAllowPartialDeletions {
+		return nil, status.Error(codes.Unimplemented, "DeleteRelationships with a limit / partial deletions is not implemented by the GPU ACL engine")
+	}
 	var cs cstrings
 	defer cs.free()
 	f := cs.filter(in.RelationshipFilter, 0)
+	pre := make([]C.acl_filter_t, len(in.OptionalPreconditions)+1)
+	for i, pc := range in.OptionalPreconditions {
+		if pc == nil || pc.Filter == nil {
+			return nil, status.Error(codes.InvalidArgument, "invalid DeleteRelationshipsRequest: precondition without filter")
+		}
+		pre[i] = cs.filter(pc.Filter, C.int32_t(pc.Operation))
+	}
 	var n, rev C.uint64_t
-	if rc := C.acl_delete_by_filter(p.e.h, &f, &n, &rev); rc != 0 {
+	if rc := C.acl_delete_by_filter_pre(p.e.h, &f, &pre[0], C.int(len(in.OptionalPreconditions)), &n, &rev); rc != 0 {
 		return nil, lastError(rc)
 	}
 	return &v1.DeleteRelationshipsResponse{DeletedAt: p.e.zedToken(), RelationshipsDeletedCount: uint64(n)}, nil
@@ -235,4 +267,74 @@ func (e *Engine) KeepMask(pairs []*v1.CheckBulkPermissionsRequestItem, off []uin
 		out[i] = keep[i] != 0
 	}
 	return out, nil
+}
+
+// itemCode maps a per-item error of the engine to the gRPC code the pair carries: the engine's codes ARE gRPC codes except
+// ACL_ERR_DEPTH (100), SpiceDB's "max depth exceeded" -- a ResourceExhausted there.
+func itemCode(c C.int32_t) codes.Code {
+	if c == C.ACL_ERR_DEPTH {
+		return codes.ResourceExhausted
+	}
+	return codes.Code(c)
+}
+
+// callOpts turns a context into acl_call_opts_t: a deadline becomes timeout_ns, cancellation raises an int32 flag the engine
+// polls (while the call waits for a device context or the micro-batcher, and between level bursts of a walk).  The flag
+// lives in C memory: the engine reads it while the goroutine is blocked in cgo.  stop() releases it.
+func callOpts(ctx context.Context) (*C.acl_call_opts_t, func()) {
+	done := ctx.Done()
+	dl, hasDL := ctx.Deadline()
+	if done == nil && !hasDL {
+		return nil, func() {}
+	}
+	o := (*C.acl_call_opts_t)(C.calloc(1, C.size_t(unsafe.Sizeof(C.acl_call_opts_t{}))))
+	flag := (*C.int32_t)(C.calloc(1, 4))
+	o.cancel = flag
+	if hasDL {
+		if d := time.Until(dl); d > 0 {
+			o.timeout_ns = C.int64_t(d.Nanoseconds())
+		} else {
+			o.timeout_ns = 1
+		}
+	}
+	quit := make(chan struct{})
+	finished := make(chan struct{})
+	go func() {
+		defer close(finished)
+		select {
+		case <-done:
+			atomic.StoreInt32((*int32)(unsafe.Pointer(flag)), 1)
+		case <-quit:
+		}
+	}()
+	return o, func() {
+		close(quit)
+		<-finished
+		C.free(unsafe.Pointer(flag))
+		C.free(unsafe.Pointer(o))
+	}
+}
+
+// FilterListResponse is filterListResponse (pkg/authz/postfilter.go:17-55) on the list response's bytes for rules whose
+// PostFilter templates are plain placeholders ({{name}}, {{namespace}}, {{namespacedName}}, {{user.name}} -- the form of
+// deploy/rules.yaml:68): one scan of the body, one device pass for all K x F pairs, the original bytes with the dropped
+// items cut out.  Rules that need the full Bloblang / CEL environment keep resolving in Go and call KeepMask.
+func (e *Engine) FilterListResponse(body []byte, templates []string, userName string) ([]byte, error) {
+	if len(body) == 0 {
+		return body, nil
+	}
+	var cs cstrings
+	defer cs.free()
+	tp := make([]*C.char, len(templates)+1)
+	for i, t := range templates {
+		tp[i] = cs.add(t)
+	}
+	var out *C.char
+	var n C.size_t
+	if rc := C.acl_filter_list_response(e.h, (*C.char)(unsafe.Pointer(&body[0])), C.size_t(len(body)), &tp[0], C.size_t(len(templates)), cs.add(userName),
+		&out, &n, nil, nil); rc != 0 {
+		return nil, lastError(rc)
+	}
+	defer C.acl_free(unsafe.Pointer(out))
+	return C.GoBytes(unsafe.Pointer(out), C.int(n)), nil
 }

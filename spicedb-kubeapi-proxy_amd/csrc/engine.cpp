@@ -181,7 +181,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world || now < c->snap.valid_lo || now >= c->snap.valid_hi) return false;
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
-    if (!patch_forward(h->store, now, &c->snap, h->shard, &patches)) return false;  // (a bulk load or > 8192 changes meanwhile: the synchronous path decides)
+    if (!patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19)) return false;  // (a bulk load meanwhile: the synchronous path decides)
     bool rev_ok = c->with_reverse && patch_reverse(h->store, now, from, &c->snap, h->shard, &patches);
     hipStream_t s = h->up_stream;
     bool fits = true;

@@ -12,6 +12,11 @@ struct acl_ticket {
     size_t n = 0;
     uint8_t *perm = nullptr;
     int32_t *err = nullptr;
+    // pipelined (large) batches: the evaluation context is held from submit to wait
+    bool staged_pipeline = false;
+    Eval ev;
+    uint8_t *hp = nullptr;  // where the D2H copies land (the caller's pinned buffers or the context's staging)
+    int32_t *he = nullptr;
     int rc = 0;
     std::string msg;
     bool done = false;
@@ -22,12 +27,25 @@ struct acl_ticket {
 struct AsyncPool {
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<acl_ticket *> queue;
+    std::deque<acl_ticket *> queue;     // small batches: any worker runs the whole call
+    std::deque<acl_ticket *> compute;   // chip-filling batches: ONE worker runs their kernels, one batch at a time, in order
     std::vector<std::thread> workers;
+    std::thread compute_worker;
     bool stop = false;
 };
 
 namespace {
+
+void finish(acl_ticket *t, int rc) {
+    std::string msg = rc ? acl_last_error() : "";
+    {
+        std::lock_guard<std::mutex> lk(t->mu);
+        t->rc = rc;
+        t->msg = std::move(msg);
+        t->done = true;
+    }
+    t->cv.notify_one();
+}
 
 void worker_loop(acl_engine_t *h, AsyncPool *P) {
     for (;;) {
@@ -39,15 +57,37 @@ void worker_loop(acl_engine_t *h, AsyncPool *P) {
             t = P->queue.front();
             P->queue.pop_front();
         }
-        const int rc = acl_check_bulk_ids(h, t->items, t->n, t->perm, t->err);
-        std::string msg = rc ? acl_last_error() : "";
+        finish(t, acl_check_bulk_ids(h, t->items, t->n, t->perm, t->err));
+    }
+}
+
+// The pipeline of chip-filling batches.  submit (caller's thread) has already taken a context and enqueued the H2D copy on
+// its stream; here the kernels of one batch after the other run (a batch this size fills every wave slot: two at once
+// only take turns), each followed by its D2H copies -- enqueued, NOT waited for: the next batch's kernels start while
+// they drain, and the next batch's H2D was under way before its turn came.
+void compute_loop(acl_engine_t *h, AsyncPool *P) {
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        acl_ticket *t = nullptr;
         {
-            std::lock_guard<std::mutex> lk(t->mu);
-            t->rc = rc;
-            t->msg = std::move(msg);
-            t->done = true;
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->cv.wait(lk, [&] { return P->stop || !P->compute.empty(); });
+            if (P->compute.empty()) return;
+            t = P->compute.front();
+            P->compute.pop_front();
         }
-        t->cv.notify_one();
+        PassCtx *c = t->ev.c;
+        int rc;
+        {
+            std::lock_guard<std::mutex> tk(h->compute_mu);  // (blocking callers with chip-filling batches take turns with the pipeline)
+            rc = check_device(h, c, c->d_items.p, t->n, c->d_perm.p, c->d_errout.p);  // (the stream already carries the H2D)
+        }
+        if (!rc) {
+            hipError_t e = hipMemcpyAsync(t->hp, c->d_perm.p, t->n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && t->err) e = hipMemcpyAsync(t->he, c->d_errout.p, t->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) rc = fail(ACL_ERR_INTERNAL, std::string("result copy: ") + hipGetErrorString(e));
+        }
+        finish(t, rc);
     }
 }
 
@@ -69,6 +109,7 @@ void async_shutdown(acl_engine_t *h) {
     }
     P->cv.notify_all();
     for (auto &t : P->workers) t.join();  // drains what is queued first
+    if (P->compute_worker.joinable()) P->compute_worker.join();
     delete P;
 }
 
@@ -86,26 +127,54 @@ int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n
         if (!h->async) {
             h->async = new AsyncPool();
             for (uint32_t i = 0; i < std::max<uint32_t>(1, h->max_ctx); i++) h->async->workers.emplace_back(worker_loop, h, h->async);
+            h->async->compute_worker = std::thread(compute_loop, h, h->async);
         }
         P = h->async;
     }
-    auto *t = new acl_ticket();
+    auto t = std::make_unique<acl_ticket>();
     t->items = items;
     t->n = n;
     t->perm = perm_out;
     t->err = err_out;
-    {
+    if (n >= kComputeTokenItems && n <= h->max_sub_batch && h->shard.world == 1) {
+        // take a context now (this is the pipeline's window: submit blocks while every context is busy) and start the H2D
+        int rc = t->ev.begin(h, false);
+        if (rc) return rc;
+        PassCtx *c = t->ev.c;
+        HIP_TRY(c->d_items.ensure(n));
+        HIP_TRY(c->d_perm.ensure(n));
+        HIP_TRY(c->d_errout.ensure(n));
+        const void *src = items;
+        if (!h->is_pinned(items, n * sizeof(acl_item_t))) {
+            HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
+            std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
+            src = c->h_in.p;
+        }
+        const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
+        t->hp = perm_out;
+        t->he = err_out;
+        if (!pin_p || !pin_e) {
+            HIP_TRY(c->h_out.ensure(n * 5 + 64));
+            if (!pin_e) t->he = (int32_t *)c->h_out.p;
+            if (!pin_p) t->hp = (uint8_t *)c->h_out.p + n * 4;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
+        t->staged_pipeline = true;
         std::lock_guard<std::mutex> lk(P->mu);
-        P->queue.push_back(t);
+        P->compute.push_back(t.get());
+    } else {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->queue.push_back(t.get());
     }
-    P->cv.notify_one();
-    *ticket_out = t;
+    P->cv.notify_all();
+    *ticket_out = t.release();
     return ACL_OK;
 }
 
-int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *t) {
+int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *tp) {
     (void)h;
-    if (!t) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_ticket_wait: NULL ticket");
+    if (!tp) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_ticket_wait: NULL ticket");
+    std::unique_ptr<acl_ticket> t(tp);
     int rc;
     std::string msg;
     {
@@ -114,7 +183,20 @@ int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *t) {
         rc = t->rc;
         msg = t->msg;
     }
-    delete t;
+    if (t->staged_pipeline) {
+        PassCtx *c = t->ev.c;
+        hipError_t e = hipStreamSynchronize(c->stream);  // the D2H copies (everything else on this stream finished before them)
+        ev_collect(c);
+        if (!rc && e != hipSuccess) {
+            rc = ACL_ERR_INTERNAL;
+            msg = std::string("result copy: ") + hipGetErrorString(e);
+        }
+        if (!rc) {
+            if (t->hp != t->perm) std::memcpy(t->perm, t->hp, t->n);
+            if (t->err && t->he != t->err) std::memcpy(t->err, t->he, t->n * sizeof(int32_t));
+        }
+        t->ev.end();
+    }
     return rc ? fail(rc, msg) : ACL_OK;
 }
 

@@ -462,7 +462,7 @@ int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out) {
     c->state.store(0);
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
-    bool ok = now >= c->snap.valid_lo && now < c->snap.valid_hi && patch_forward(h->store, now, &c->snap, h->shard, &patches);
+    bool ok = now >= c->snap.valid_lo && now < c->snap.valid_hi && patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19);
     if (ok && !patch_reverse(h->store, now, from, &c->snap, h->shard, &patches)) c->snap.has_reverse = false;
     if (adopted_out) *adopted_out = ok ? 1 : 0;
     if (!ok) return ACL_OK;  // not adoptable (bulk load, too many changes, an expiry passed): the engine would rebuild instead

@@ -463,11 +463,11 @@ struct Patcher {
 
 }  // namespace
 
-bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches) {
+bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches, size_t max_changes) {
     Snapshot &s = *snap;
     std::vector<Store::Change> ch;
     if (s.lay.empty()) return false;
-    if (!store.raw_changes_since(s.revision, &ch) || ch.size() > kMaxPatchChanges) return false;
+    if (!store.raw_changes_since(s.revision, &ch) || ch.size() > (max_changes ? max_changes : kMaxPatchChanges)) return false;
     store.settle_all();
     const Schema &sc = store.schema();
     // objects created since the build must fit the headroom of every table they index

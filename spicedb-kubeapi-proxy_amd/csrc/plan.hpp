@@ -137,7 +137,9 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = 
 // may have gone stale are switched off per program op.  Returns false when the change cannot be expressed as a
 // patch (bulk load, a class becoming live, table headroom exhausted, too many changes): rebuild instead.
 // On success `patches` lists the regions to re-upload and the reverse rows (if any) are invalidated.
-bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
+// max_changes: how many feed entries a patch may carry (0 = the default bound beyond which a rebuild is cheaper; the adoption of
+// a background-built snapshot passes a larger one: there the alternative is not a rebuild but throwing a finished build away).
+bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches, size_t max_changes = 0);
 // Same for the reverse rows (LookupResources); call after a successful patch_forward with the same feed position
 // (`from_revision` = the snapshot's revision BEFORE patch_forward).  false: rebuild the reverse rows instead.
 bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
