@@ -164,10 +164,10 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
 /* Pipelined form of acl_check_bulk_ids: submit returns at once, the batch is answered by one of the engine's evaluation
  * contexts (own HIP stream: the H2D copy of batch N+1 and the D2H copy of batch N-1 overlap the kernels of batch N);
  * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
- * Buffers must stay valid until the wait returns; wait from the thread that submitted.  Batches that fill the chip
- * (>= 32 768 items) form a pipeline: submit takes a context (blocking while all are busy -- the window is the
- * engine's `contexts`) and starts the H2D at once, one worker runs the batches' kernels strictly one after the other,
- * each batch's D2H drains while the next one's kernels run.  Smaller batches simply run concurrently. */
+ * Buffers must stay valid until the wait returns; a batch keeps its evaluation context until it is waited for, so wait in
+ * submission order.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up to
+ * three batches ahead (context + H2D) while contexts are free, runs the batches' kernels strictly one after the other,
+ * and each batch's D2H drains while the next one's kernels run.  Smaller batches simply run concurrently. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);

@@ -348,7 +348,7 @@ int ensure_reverse(acl_engine *h) {
     return ACL_OK;
 }
 
-int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot) {
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     HIP_TRY(hipSetDevice(h->device));
@@ -385,6 +385,11 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
             c = nc.get();
             h->ctxs.push_back(std::move(nc));
             break;
+        }
+        if (try_only) {
+            lk.unlock();
+            end();  // gives the shared lock back
+            return kNoContextFree;
         }
         if (opts.cancel || opts.deadline_ns) {
             h->pool_cv.wait_for(lk, std::chrono::microseconds(500));

@@ -61,21 +61,67 @@ void worker_loop(acl_engine_t *h, AsyncPool *P) {
     }
 }
 
-// The pipeline of chip-filling batches.  submit (caller's thread) has already taken a context and enqueued the H2D copy on
-// its stream; here the kernels of one batch after the other run (a batch this size fills every wave slot: two at once
-// only take turns), each followed by its D2H copies -- enqueued, NOT waited for: the next batch's kernels start while
-// they drain, and the next batch's H2D was under way before its turn came.
+// The pipeline of chip-filling batches, owned by ONE worker: it takes a context for a batch and starts its H2D copy as early as
+// a context is free (up to two batches ahead of the one whose kernels run), runs the batches' kernels strictly one after the
+// other (a batch this size fills every wave slot: two at once only take turns), and enqueues each batch's D2H copies without
+// waiting for them -- they drain under the next batch's kernels.  The waiter synchronises the batch's stream, copies
+// out of staging if the caller's buffers are not pinned, and gives the context back.
+int stage(acl_engine_t *h, acl_ticket *t, bool may_block) {
+    int rc = t->ev.begin(h, false, CallOpts(), -1, !may_block);
+    if (rc) return rc;
+    PassCtx *c = t->ev.c;
+    const size_t n = t->n;
+    HIP_TRY(c->d_items.ensure(n));
+    HIP_TRY(c->d_perm.ensure(n));
+    HIP_TRY(c->d_errout.ensure(n));
+    const void *src = t->items;
+    if (!h->is_pinned(t->items, n * sizeof(acl_item_t))) {
+        HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
+        std::memcpy(c->h_in.p, t->items, n * sizeof(acl_item_t));
+        src = c->h_in.p;
+    }
+    const bool pin_p = h->is_pinned(t->perm, n), pin_e = !t->err || h->is_pinned(t->err, n * sizeof(int32_t));
+    t->hp = t->perm;
+    t->he = t->err;
+    if (!pin_p || !pin_e) {
+        HIP_TRY(c->h_out.ensure(n * 5 + 64));
+        if (!pin_e) t->he = (int32_t *)c->h_out.p;
+        if (!pin_p) t->hp = (uint8_t *)c->h_out.p + n * 4;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
+    t->staged_pipeline = true;
+    return ACL_OK;
+}
+
 void compute_loop(acl_engine_t *h, AsyncPool *P) {
     (void)hipSetDevice(h->device);
+    std::deque<acl_ticket *> staged;  // context taken, H2D under way
     for (;;) {
-        acl_ticket *t = nullptr;
-        {
+        // look ahead: stage queued batches while contexts are free (never waiting for one)
+        for (;;) {
+            acl_ticket *t = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(P->mu);
+                if (staged.size() >= 3 || P->compute.empty()) break;
+                t = P->compute.front();
+            }
+            const int rc = stage(h, t, staged.empty());  // with nothing staged there is nothing else to do: wait for a context
+            if (rc == kNoContextFree) break;
+            {
+                std::lock_guard<std::mutex> lk(P->mu);
+                P->compute.pop_front();
+            }
+            if (rc) finish(t, rc);
+            else staged.push_back(t);
+        }
+        if (staged.empty()) {
             std::unique_lock<std::mutex> lk(P->mu);
             P->cv.wait(lk, [&] { return P->stop || !P->compute.empty(); });
             if (P->compute.empty()) return;
-            t = P->compute.front();
-            P->compute.pop_front();
+            continue;
         }
+        acl_ticket *t = staged.front();
+        staged.pop_front();
         PassCtx *c = t->ev.c;
         int rc;
         {
@@ -136,35 +182,10 @@ int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n
     t->n = n;
     t->perm = perm_out;
     t->err = err_out;
-    if (n >= kComputeTokenItems && n <= h->max_sub_batch && h->shard.world == 1) {
-        // take a context now (this is the pipeline's window: submit blocks while every context is busy) and start the H2D
-        int rc = t->ev.begin(h, false);
-        if (rc) return rc;
-        PassCtx *c = t->ev.c;
-        HIP_TRY(c->d_items.ensure(n));
-        HIP_TRY(c->d_perm.ensure(n));
-        HIP_TRY(c->d_errout.ensure(n));
-        const void *src = items;
-        if (!h->is_pinned(items, n * sizeof(acl_item_t))) {
-            HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
-            std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
-            src = c->h_in.p;
-        }
-        const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
-        t->hp = perm_out;
-        t->he = err_out;
-        if (!pin_p || !pin_e) {
-            HIP_TRY(c->h_out.ensure(n * 5 + 64));
-            if (!pin_e) t->he = (int32_t *)c->h_out.p;
-            if (!pin_p) t->hp = (uint8_t *)c->h_out.p + n * 4;
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
-        t->staged_pipeline = true;
+    {
         std::lock_guard<std::mutex> lk(P->mu);
-        P->compute.push_back(t.get());
-    } else {
-        std::lock_guard<std::mutex> lk(P->mu);
-        P->queue.push_back(t.get());
+        if (n >= kComputeTokenItems && n <= h->max_sub_batch && h->shard.world == 1) P->compute.push_back(t.get());
+        else P->queue.push_back(t.get());
     }
     P->cv.notify_all();
     *ticket_out = t.release();

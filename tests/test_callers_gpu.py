@@ -258,3 +258,60 @@ def test_concurrent_mixed_calls_are_safe_and_consistent(aclgpu):
         for u in users:
             assert e.lookup("doc", "view", "user", u) == co.lookup("doc", "view", "user", u)
         assert len(applied) == 180 and e.stats()["snapshot_patches"] > 0
+
+
+def test_cancellation_and_deadline(aclgpu):
+    """LookupResources runs on the HTTP request's context and is abandoned when that is cancelled
+    (responsefilterer.go:165-170); the prefilter join gives up after 10 s (responsefilterer.go:44,196-204).  The C side of a
+    context.Context is acl_call_opts_t: a cancel flag the engine polls and a timeout."""
+    import ctypes as C
+    import threading
+    import time
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.02, batch=20000, n_user=20000)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        items = e.make_items("pod", "view", w.res, "user", "", w.subj)
+        want = e.check_bulk_ids(items)
+        # already cancelled / already past its deadline: refused before any device work, with the gRPC codes the shim forwards
+        flag = C.c_int32(1)
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.check_bulk_ids_opts(items, cancel=flag)
+        assert ei.value.code == aclgpu.ERR_CANCELLED
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.check_bulk_ids_opts(items, timeout_s=1e-9)
+        assert ei.value.code == aclgpu.ERR_DEADLINE_EXCEEDED
+        e.intern("user", "somebody")
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.lookup_one("pod", "view", "user", "somebody", cancel=flag)
+        assert ei.value.code == aclgpu.ERR_CANCELLED
+        # not cancelled, generous deadline: same answers
+        flag.value = 0
+        p, er = e.check_bulk_ids_opts(items, cancel=flag, timeout_s=30.0)
+        assert np.array_equal(p, want[0]) and np.array_equal(er, want[1])
+        # cancelled while parked behind the micro-batcher's window: the caller returns, the batch still completes for the others
+        e.batcher_start(max_items=1 << 20, max_wait_us=200_000)
+        try:
+            out = {}
+
+            def blocked():
+                try:
+                    out["r"] = e.check_one("pod", "nope", "view", "user", "nobody", cancel=flag)
+                except aclgpu.AclError as ex:
+                    out["code"] = ex.code
+                out["t"] = time.perf_counter()
+
+            t0 = time.perf_counter()
+            th = threading.Thread(target=blocked)
+            th.start()
+            time.sleep(0.02)
+            flag.value = 1  # ctx.Done()
+            th.join(5)
+            assert out.get("code") == aclgpu.ERR_CANCELLED and out["t"] - t0 < 0.15, out  # well before the 200 ms window closes
+            flag.value = 0
+            assert e.check_one("pod", "nope", "view", "user", "nobody", timeout_s=5.0) == (1, 0)
+            with pytest.raises(aclgpu.AclError) as ei:
+                e.check_one("pod", "nope", "view", "user", "nobody", timeout_s=0.01)  # deadline inside the 200 ms window
+            assert ei.value.code == aclgpu.ERR_DEADLINE_EXCEEDED
+        finally:
+            e.batcher_stop()

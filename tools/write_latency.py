@@ -34,12 +34,15 @@ for i in range(3):
     t1 = time.perf_counter()
     e.check("pod", "ns/p0", "view", "user", "paul0")
     reb.append(time.perf_counter() - t1)
-# ---- background compaction.  Phase A (untimed): bulk creates (1 000 updates per write) until the pod tables' headroom is
-# 88 % used.  Phase B (timed): kube-style creates -- 2 relationships naming a new pod, then a Check right after -- across the
-# 90 % mark that starts a background build and on past its adoption.  Round 1 paid a synchronous rebuild (100-140 ms) at
-# such thresholds; now the build runs on a worker thread and the read that adopts it pays a catch-up patch.
+# ---- background compaction.  Phase A (untimed): bulk creates (1 000 updates per write, each followed by a read so that every
+# patch stays small and the snapshot is never rebuilt) until the pod tables' headroom is 88 % used.  Phase B (timed):
+# kube-style creates -- 2 relationships naming a new pod, then a Check right after -- across the 90 % mark that starts a
+# background build and on past its adoption.  Round 1 paid a synchronous rebuild (100-140 ms) at such thresholds; now the
+# build runs on a worker thread and the read that adopts it pays a catch-up patch.
 npod0 = e.object_count("pod")
-nrows = int(w.nobjects["pod"] * 1.25) + 1024  # plan.cpp with_headroom
+nrows = int(w.nobjects["pod"] * 1.25) + 1024  # plan.cpp with_headroom, as built by the forced rebuilds above
+e.check("pod", "ns/p0", "view", "user", "paul0")
+builds_a0 = e.stats()["snapshot_builds"]
 target_a = int(nrows * 0.88)
 k = 0
 while e.object_count("pod") < target_a:
@@ -50,7 +53,8 @@ while e.object_count("pod") < target_a:
         ups.append((aclgpu.OP_TOUCH, ("pod", f"cmp/a{k}", "namespace", "namespace", "ns", "")))
         k += 1
     e.write(ups)
-e.check("pod", "cmp/a0", "view", "user", "paul0")
+    e.check("pod", "cmp/a0", "view", "user", "paul0")
+assert e.stats()["snapshot_builds"] == builds_a0, "phase A must be patched in, not rebuilt (the headroom marks would move)"
 st_a = e.stats()
 clat = []
 nb = int(nrows * 0.035)
