@@ -436,16 +436,30 @@ struct Patcher {
         const uint32_t a = md[0], b = md[1];
         uint32_t edge = sid;
         if (k.srel != kNoRelation && s.type_owner[k.stype] == s.type_owner[t] && child_is_leaf((uint32_t)sc.slot(k.stype, k.srel), sid)) edge |= kLeafBit;
-        const uint32_t start = (uint32_t)s.edges.size();
-        std::vector<uint32_t> row(s.edges.begin() + a, s.edges.begin() + b);  // (copy first: the append may reallocate)
-        row.insert(row.begin() + (pos - a), edge);
-        s.edges.insert(s.edges.end(), row.begin(), row.end());
-        md = sdesc(l, c, res);
-        md[0] = start;
-        md[1] = (uint32_t)s.edges.size();
-        s.garbage_words += b - a;
-        out.push_back(Patch{Patch::EDGES, start, (size_t)(md[1] - start)});
-        out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+        const uint32_t len = b - a, ipos = pos - a;
+        auto capit = s.edge_cap.find(a);
+        const uint32_t cap = capit == s.edge_cap.end() ? len : capit->second;
+        if (len && len + 1 <= cap) {  // the row was moved before and has room: insert in place
+            std::copy_backward(s.edges.begin() + pos, s.edges.begin() + b, s.edges.begin() + b + 1);
+            s.edges[pos] = edge;
+            md[1] = b + 1;
+            out.push_back(Patch{Patch::EDGES, pos, (size_t)(b + 1 - pos)});
+            out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+        } else {  // move it to the end of `edges` with the subject inserted and room for half as many again
+            const uint32_t start = (uint32_t)s.edges.size(), ncap = std::max<uint32_t>(4, (len + 1) + (len + 1) / 2);
+            std::vector<uint32_t> row(s.edges.begin() + a, s.edges.begin() + b);  // (copy first: the append may reallocate)
+            row.insert(row.begin() + ipos, edge);
+            s.edges.insert(s.edges.end(), row.begin(), row.end());
+            s.edges.resize((size_t)start + ncap, 0u);
+            if (capit != s.edge_cap.end()) s.edge_cap.erase(capit);
+            s.edge_cap[start] = ncap;
+            md = sdesc(l, c, res);
+            md[0] = start;
+            md[1] = start + len + 1;
+            s.garbage_words += cap;
+            out.push_back(Patch{Patch::EDGES, start, (size_t)(len + 1)});
+            out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+        }
         if (a == b) distrust_leaf_flags(t);  // `res` may just have stopped being a leaf
     }
     void sorted_remove(const RelLayout &l, const ClassLayout &c, uint32_t res, uint32_t sid) {

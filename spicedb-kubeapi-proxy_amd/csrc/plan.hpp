@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "store.hpp"
@@ -106,6 +107,10 @@ struct Snapshot {
     std::vector<uint32_t> type_nobjects;
     std::vector<RelLayout> lay;  // [nslots]
     uint64_t garbage_words = 0;  // edge / bucket words orphaned by row relocations since the build
+    // Rows that a patch had to move get room to grow (1.5x): start offset -> capacity in words.  Host-only: the kernels read
+    // [start, end) of a descriptor and never see the slack behind it.  Without it a namespace that gains pods one write at a
+    // time (or a group that gains members) would be copied whole, and orphan its old copy, on every single write.
+    std::unordered_map<uint32_t, uint32_t> edge_cap, redge_cap;
     uint64_t patched = 0;        // relationships patched in since the build
     uint32_t nslots = 0, ntypes = 0;
     uint64_t nedges = 0;        // relationships in the store

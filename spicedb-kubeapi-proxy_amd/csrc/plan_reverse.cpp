@@ -27,6 +27,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     auto &tables = store.tables();
     s.rmeta.clear();
     s.redges.clear();
+    s.redge_cap.clear();
     s.rops.clear();
     // reverse rows per (relation slot, class): subject id -> resource ids; one {start, end} descriptor per subject,
     // sized with headroom so that writes naming new subjects can be patched in (patch_reverse)
@@ -212,16 +213,29 @@ bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *
         const auto it = std::lower_bound(first, last, res);
         const bool have = it != last && *it == res;
         if (want == have) continue;
-        if (want) {  // relocate the row to the end with the resource inserted in order
-            std::vector<uint32_t> row(first, last);
-            row.insert(row.begin() + (it - first), res);
-            const uint32_t start = (uint32_t)s.redges.size();
-            s.redges.insert(s.redges.end(), row.begin(), row.end());
-            md = s.rmeta.data() + 2 * ((size_t)l.base + sid);
-            md[0] = start;
-            md[1] = (uint32_t)s.redges.size();
-            s.garbage_words += b - a;
-            patches->push_back(Patch{Patch::REDGES, start, (size_t)(md[1] - start)});
+        if (want) {
+            const uint32_t len = b - a, ipos = (uint32_t)(it - first);
+            auto capit = s.redge_cap.find(a);
+            const uint32_t cap = capit == s.redge_cap.end() ? len : capit->second;
+            if (len && len + 1 <= cap) {  // the row was moved before and has room: insert in place
+                std::copy_backward(s.redges.begin() + a + ipos, s.redges.begin() + b, s.redges.begin() + b + 1);
+                s.redges[a + ipos] = res;
+                md[1] = b + 1;
+                patches->push_back(Patch{Patch::REDGES, (size_t)a + ipos, (size_t)(len + 1 - ipos)});
+            } else {  // move the row to the end with the resource inserted in order and room for half as many again
+                std::vector<uint32_t> row(first, last);
+                row.insert(row.begin() + ipos, res);
+                const uint32_t start = (uint32_t)s.redges.size(), ncap = std::max<uint32_t>(4, (len + 1) + (len + 1) / 2);
+                s.redges.insert(s.redges.end(), row.begin(), row.end());
+                s.redges.resize((size_t)start + ncap, 0u);
+                if (capit != s.redge_cap.end()) s.redge_cap.erase(capit);
+                s.redge_cap[start] = ncap;
+                md = s.rmeta.data() + 2 * ((size_t)l.base + sid);
+                md[0] = start;
+                md[1] = start + len + 1;
+                s.garbage_words += cap;
+                patches->push_back(Patch{Patch::REDGES, start, (size_t)(len + 1)});
+            }
         } else {  // shrink in place
             const uint32_t pos = (uint32_t)(it - s.redges.begin());
             std::copy(s.redges.begin() + pos + 1, s.redges.begin() + b, s.redges.begin() + pos);
