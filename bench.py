@@ -431,9 +431,10 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     h_err = hb[NB * n * 17:].view(np.int32).reshape(NB, n)
     for b in range(NB):
         h_items[b] = np.roll(items0, b * 4099)
-    window = max(2, min(args.window, NB))
+    window = max(1, min(args.window, NB))
+    callers = max(1, args.callers)
 
-    def pipelined(k_steps):
+    def submit_wait(k_steps):  # acl_check_bulk_ids_submit / acl_ticket_wait: `window` batches in flight from ONE host thread
         q = []
         for k in range(k_steps):
             if len(q) == window:
@@ -443,7 +444,34 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         for t in q:
             eng.wait(t)
 
-    pipelined(max(warmup, window))
+    def blocking(k_steps):  # `callers` host threads, each in a blocking acl_check_bulk_ids (what goroutines behind the cgo shim do)
+        if callers == 1:
+            for k in range(k_steps):
+                b = k % NB
+                eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+            return
+        nxt = [0]
+        lk = threading.Lock()
+
+        def run():
+            while True:
+                with lk:
+                    k = nxt[0]
+                    nxt[0] += 1
+                if k >= k_steps:
+                    return
+                b = k % NB if callers <= NB else k % NB
+                eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+
+        # (two callers never share a batch's output buffers at the same time: steps are handed out in order, NB >= callers)
+        ts = [threading.Thread(target=run) for _ in range(callers)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    pipelined = submit_wait if args.pipeline == "submit" else blocking
+    pipelined(max(warmup, window, callers))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -456,9 +484,10 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     host_ok = bool(np.array_equal(h_perm[0], gpu_perm) and np.array_equal(h_err[0], gpu_err))
     rec["value"] = n * steps / elapsed
     rec["elapsed"] = elapsed
-    rec["pipelined_host_ids"] = {"decisions_per_s": n * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "window": window, "distinct_batches": NB,
-                                 "answers_equal_device_leg": host_ok,
-                                 "note": "acl_check_bulk_ids_submit/wait over pinned buffers: H2D + kernels + D2H, copies overlap other batches' kernels"}
+    rec["host_ids"] = {"decisions_per_s": n * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "distinct_batches": NB, "answers_equal_device_leg": host_ok,
+                       "mode": (f"acl_check_bulk_ids_submit/wait, {window} in flight" if args.pipeline == "submit" else f"{callers} caller thread(s) in blocking acl_check_bulk_ids"),
+                       "note": "pinned host buffers: H2D + kernels + D2H per batch; with several callers a batch's copies overlap another batch's kernels "
+                               "(chip-filling batches run their kernels one batch at a time)"}
     # ---------------- batch latency: >= 200 single unpipelined host-id calls (SURVEY.md 8(d) "p50 over >= 200 batches after 20 warm-ups")
     nl = max(200, steps)
     lat = []
@@ -581,7 +610,9 @@ def main():
     ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
-    ap.add_argument("--window", type=int, default=2, help="batches in flight in the pipelined leg (<= the engine's evaluation contexts)")
+    ap.add_argument("--pipeline", default="blocking", choices=["blocking", "submit"], help="how the timed host-id leg keeps batches in flight")
+    ap.add_argument("--callers", type=int, default=2, help="--pipeline blocking: host threads issuing blocking acl_check_bulk_ids calls")
+    ap.add_argument("--window", type=int, default=2, help="--pipeline submit: batches in flight (<= the engine's evaluation contexts)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="also measure C2 and C3 in the same run (auto: at N=1 with the default workload)")
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "
@@ -628,7 +659,7 @@ def main():
     if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
     label = "C5R" if args.workload == "C5" else args.workload
-    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window) + 1)
+    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
     t0 = time.time()
     w.load(eng)
     eng.snapshot()
@@ -666,7 +697,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec.pop("workload"), "batch_per_gpu": rec.pop("batch"), "relationships": rec.pop("relationships"),
                        "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)",
-                       "timed": "host-id ABI calls (H2D + kernels + D2H), pipelined over 8 distinct pinned batches" if args.legs == "all"
+                       "timed": "host-id ABI calls (H2D + kernels + D2H) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
                                 else "device-resident calls only (--legs device)"},
             "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
             "setup_s": {"generate": round(t_gen, 2), "load+snapshot": round(t_load, 2)},
@@ -691,7 +722,7 @@ def main():
         cfgs = {}
         try:
             w2 = workloads.c2()
-            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window) + 1)
+            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
             w2.load(e2)
             e2.snapshot()
             r2, p2, er2 = check_bench(args, w2, e2, max(args.steps, 50), args.warmup, 1, 0, "C2", "all")
