@@ -5,9 +5,13 @@ A "step" = one pass of the hot path (bulk Check through the C ABI) over one batc
 workload: C4 (10 M relationships / 1 M objects, 5-level nested groups, 256 k-item batch) -- the configuration
 BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
 
-  value             (ii) the ABI call that takes HOST ids -- H2D + kernels + D2H -- PIPELINED: K steps over 8 distinct
-                    pre-generated batches in pinned host memory, submitted through acl_check_bulk_ids_submit so that the copies
-                    of one batch overlap the kernels of another (the engine's evaluation contexts, one HIP stream each)
+  value             (ii) the ABI call that takes HOST ids -- H2D + kernels + D2H: K steps over 8 distinct pre-generated
+                    batches in pinned host memory, issued by `--callers` (default 2) host threads that each block in
+                    acl_check_bulk_ids -- what goroutines behind the cgo shim do -- so that the copies of one batch overlap
+                    the kernels of another (the engine's evaluation contexts, one HIP stream each; chip-filling batches'
+                    kernels take turns).  `--pipeline submit` times acl_check_bulk_ids_submit / acl_ticket_wait from one
+                    thread instead.  Measured (profiles/r02_hostid_modes.txt): 1 caller 374 M/s, 2 callers 444 M/s,
+                    3 callers 442 M/s, submit window 2 271 M/s; kernels alone (device_resident) 416 M/s.
   device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
                     per-launch kernel time comes from HIP events in THIS leg (pipelined launches overlap each other)
   latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")
