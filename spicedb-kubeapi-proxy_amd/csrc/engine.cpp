@@ -444,18 +444,35 @@ constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path decli
 // Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
 // batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
 // the context's frontier buffers.
+// Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, whether units are handed out dynamically.
+struct LocalGeom {
+    uint32_t rpw, nblocks, nunits, cap;
+    bool dynamic;
+};
+static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
+    const uint32_t max_waves = (uint32_t)h->local_blocks * kWavesPerBlock;  // what is resident at once
+    LocalGeom G{};
+    if (n <= max_waves) G.rpw = 1;  // latency: every request its own wave
+    else {
+        // throughput: every level of a unit costs a chain of dependent trips whatever the unit's size, so units are as large as
+        // balance allows: `upw` units per resident wave, handed out dynamically (a wave that drew cheap requests takes more)
+        G.rpw = std::min<uint32_t>(std::max<uint32_t>((n + max_waves * h->local_upw - 1) / (max_waves * h->local_upw), 1), 64);
+    }
+    G.nunits = (n + G.rpw - 1) / G.rpw;
+    G.nblocks = std::min<uint32_t>((G.nunits + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->local_blocks);
+    G.dynamic = G.nunits > G.nblocks * kWavesPerBlock;
+    G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / ((uint64_t)G.nblocks * kWavesPerBlock), 1u << 20);
+    return G;
+}
+
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
-    const uint32_t max_waves = (uint32_t)h->grid_blocks * kWavesPerBlock;  // what is resident at once
-    uint32_t rpw = (n + max_waves - 1) / max_waves;
-    rpw = std::min<uint32_t>(std::max<uint32_t>(rpw, 1), 64);
-    const uint32_t nwaves = (n + rpw - 1) / rpw;
-    const uint64_t cap64 = c->frontier_entries / std::max<uint32_t>(nwaves, 1);
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(cap64, 1u << 20);
-    if (cap < 256) return kTakeLevelLoop;
-    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;
-    HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(uint32_t), c->stream));
+    const LocalGeom G = local_geom(h, c, n);
+    if (G.cap < 256) return kTakeLevelLoop;
+    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
+    HIP_TRY(hipMemsetAsync(d_over, 0, 2 * sizeof(uint32_t), c->stream));
     ev_begin(c, 2);
-    launch_check_local(c->stream, g, d_items, n, rpw, c->d_fbuf[0].p, c->d_fbuf[1].p, cap, d_over, c->d_has.p, c->d_err.p, d_perm, d_errout);
+    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.dynamic ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
+                       c->d_err.p, d_perm, d_errout);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -473,11 +490,8 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
 // stream synchronisation -- no H2D, no flag memset, no D2H copies, each of which costs a few microseconds of API time that a
 // 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
 static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out) {
-    const uint32_t max_waves = (uint32_t)h->grid_blocks * kWavesPerBlock;
-    uint32_t rpw = std::min<uint32_t>(std::max<uint32_t>((n + max_waves - 1) / max_waves, 1), 64);
-    const uint32_t nwaves = (n + rpw - 1) / rpw;
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / std::max<uint32_t>(nwaves, 1), 1u << 20);
-    if (cap < 256) return kTakeLevelLoop;
+    const LocalGeom G = local_geom(h, c, n);
+    if (G.cap < 256 || G.dynamic) return kTakeLevelLoop;  // (the unit counter lives in device memory: large batches go through check_pass_local)
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
@@ -491,7 +505,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     HIP_TRY(hipHostGetDevicePointer(&d_in, c->h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
     ev_begin(c, 2);
-    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, rpw, c->d_fbuf[0].p, c->d_fbuf[1].p, cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
+    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
                        (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64));
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -896,6 +910,8 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
+    h->local_blocks = local_grid_blocks(dev);
+    if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
     if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;
     if (cfg && cfg->contexts) h->max_ctx = std::min<uint32_t>(cfg->contexts, 16);

@@ -140,6 +140,9 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
         B.lookup_walks += walks;
         B.lookups += nl;
     }
+    // the device is idle again BEFORE the callers learn their answers: a caller that comes straight back with its next request must
+    // find the batching window open, not a stale "a pass is in flight, go now"
+    B.in_flight.fetch_sub(1, std::memory_order_relaxed);
     for (Batch *b : subs) {
         b->done.store(1, std::memory_order_release);
         futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this sub-batch's callers
@@ -161,12 +164,18 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
         if (B.wait_us && B.in_flight.load(std::memory_order_relaxed) == 0 && B.pending.load(std::memory_order_relaxed) < B.max_items) {
             const int64_t first = B.oldest_ns.load(std::memory_order_relaxed);
             const int64_t until = (first ? first : mono_ns()) + (int64_t)B.wait_us * 1000;
+            bool stale = false;  // another dispatcher swept the requests this window was opened for: whatever is queued now has a window of its own
             while (!B.stop.load(std::memory_order_relaxed) && B.pending.load(std::memory_order_relaxed) < B.max_items) {
+                if (B.pending.load(std::memory_order_relaxed) == 0 || B.oldest_ns.load(std::memory_order_relaxed) != first) {
+                    stale = true;
+                    break;
+                }
                 const int64_t now = mono_ns();
                 if (now >= until) break;
                 timespec ts{0, (long)std::min<int64_t>(until - now, 50000)};
                 nanosleep(&ts, nullptr);
             }
+            if (stale) continue;
         }
         // sweep every queue (starting at a different one per dispatcher so that two sweeps do not chase each other)
         subs.clear();
@@ -187,8 +196,7 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
         B.oldest_ns.store(0, std::memory_order_relaxed);
         B.pending.fetch_sub(taken, std::memory_order_acq_rel);
         B.in_flight.fetch_add(1, std::memory_order_relaxed);
-        answer(h, subs);
-        B.in_flight.fetch_sub(1, std::memory_order_relaxed);
+        answer(h, subs);  // (decrements in_flight itself, between the device pass and the wake-ups)
     }
 }
 

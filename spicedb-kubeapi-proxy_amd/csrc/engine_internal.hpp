@@ -224,6 +224,8 @@ struct acl_engine {
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
     hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
     int grid_blocks = 2048;
+    int local_blocks = 1024;   // resident blocks of the single-launch kernel
+    uint32_t local_upw = 2;    // single-launch pass over a large batch: work units per resident wave
     uint64_t cfg_frontier_entries = 0;
     // forward graph
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
@@ -246,7 +248,8 @@ struct acl_engine {
     std::mutex shard_mu;
     std::mutex compute_mu;  // turn-taking of chip-filling batches (check_ids_host)
     uint32_t max_sub_batch = 1u << 20;
-    uint32_t local_max_items = 8192;  // batches up to this size take the single-launch path (k_check_local); 0 = never
+    uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
+                                          // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
     size_t lk_n = 0;
     // micro-batching front-end (engine_callers.cpp)

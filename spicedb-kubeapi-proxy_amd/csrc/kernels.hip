@@ -51,6 +51,7 @@ constexpr int kBlock = kWavesPerBlock * 64;
 #define ACL_MIN_WAVES_PER_SIMD 5  // 84 VGPRs: the multi-child fast path (flush_simple) needs them; spilling at 8 waves/SIMD costs more than the waves give
 #endif
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
+constexpr uint32_t kHeadWords = 32;  // flush_simple maps work items to tasks through head bits: rounds of <= 64 * kHeadWords children
 constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
 constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
 constexpr uint32_t kCountMask = 0x3FFFFFFFu;
@@ -69,23 +70,41 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Everything above this line is issued before anything below it.  Placed between "issue every load of this trip" and "first use":
+// left alone, the compiler sinks a load next to its use and waits for it before it issues the next one -- a wave's independent
+// gathers then travel one after the other instead of together (seen in the ISA of every multi-load step of this file).
+__device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += o;
-    }
+// Wave64 scan / reduction on the DPP lane network: six v_add / v_max with a DPP source operand, no LDS traffic (ds_bpermute)
+// and -- what mattered more here -- no per-distance lane-address VGPRs that the compiler hoists and keeps alive across the
+// whole kernel.  row_shr:n shifts within a row of 16 lanes (lanes without a source add 0), row_bcast:15 / :31 carry a
+// row's / a half's total into the rows above (gfx9 family incl. gfx950).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t) {
+    v += dpp_or0<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_or0<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_or0<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_or0<0x118, 0xf>(v);  // row_shr:8  -> inclusive within each row of 16
+    v += dpp_or0<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or0<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, 64));
-    return v;
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // same network with max (0 is neutral for unsigned); lane 63 ends up with the maximum
+    v = max(v, dpp_or0<0x111, 0xf>(v));
+    v = max(v, dpp_or0<0x112, 0xf>(v));
+    v = max(v, dpp_or0<0x114, 0xf>(v));
+    v = max(v, dpp_or0<0x118, 0xf>(v));
+    v = max(v, dpp_or0<0x142, 0xa>(v));
+    v = max(v, dpp_or0<0x143, 0xc>(v));
+    return wave_last(v);
 }
 
 // LDS-staged task list of one wave.
@@ -95,7 +114,10 @@ struct TaskLds {
     uint32_t req[kTaskCap];
     uint32_t meta[kTaskCap];   // child meta
     uint32_t sid[kTaskCap];
+    uint32_t b0[kTaskCap];     // flush_simple: the hashed row the children are probed in (the request subject's row of the child's one probe op):
+    uint32_t nb[kTaskCap];     //   first bucket and bucket count; {0, 1} = the reserved empty bucket when the subject has no row
     uint32_t scan[64];
+    uint64_t heads[kHeadWords];  // flush_simple: bit (w & 63) of word (w >> 6) set <=> a task's children start at work item w
 };
 
 // Wave-private output cursor, all fields wave-uniform.
@@ -112,7 +134,7 @@ struct WaveOut {
     WaveOutCold *cold;  // LDS
 };
 
-// room for `need` (<= 64) consecutive entries; returns the first entry index
+// room for `need` (<= kChunk) consecutive entries; returns the first entry index
 template <bool LOCAL>
 __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane) {
     if (wo.cur == kNoSpace) return kNoSpace;
@@ -173,12 +195,21 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
 // hashed row: nb = b1 - b0 buckets of 4 ids, two-choice placement (plan.hpp hashed_row_buckets): the id is in bucket h1
 // or h2 or nowhere -- two INDEPENDENT 16 B gathers in flight together, never a probing chain (with linear probing the
 // slowest of the 64 lanes made almost every wave walk 3-5 dependent buckets; profiles/r01_c4_bottleneck_analysis.md)
+// is `want` one of the eight ids of two buckets?  Written as xor + min3: 8 v_xor + 3 v_min3 + v_min + v_cmp.  The obvious
+// `p.x == want || ...` compiles to ~35 VALU instructions (the compiler packs the eight i1 results into a 16-bit vector), and
+// the deep levels of a large batch are bound by VALU issue (profiles/r02_pmc_issue_breakdown.txt).
+__device__ __forceinline__ bool bucket_pair_has(const uint4 &p, const uint4 &q, uint32_t want) {
+    uint32_t m = min(min(p.x ^ want, p.y ^ want), p.z ^ want);
+    m = min(min(m, p.w ^ want), q.x ^ want);
+    m = min(min(m, q.y ^ want), q.z ^ want);
+    return min(m, q.w ^ want) == 0u;
+}
 __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
     uint32_t h1, h2;
     hashed_row_buckets(want, b1 - b0, &h1, &h2);
     const uint4 p = gld(buckets, b0 + h1);
     const uint4 q = gld(buckets, b0 + h2);
-    return p.x == want || p.y == want || p.z == want || p.w == want || q.x == want || q.y == want || q.z == want || q.w == want;
+    return bucket_pair_has(p, q, want);
 }
 
 // Membership of (resource id, subject sid) in a membership-only class.  The class is stored SUBJECT-indexed:
@@ -249,82 +280,112 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
 #endif
 #ifndef ACL_SIMPLE_WIDTH
-#define ACL_SIMPLE_WIDTH 2  // round 2 A/B on one box (profiles/r02_kernel_ab.md): width 3 is 3 % faster (508 vs 525 us per batch) but needs 97 VGPRs -- 7
-                            // spilled at the 96 that 5 waves/SIMD allow; width 2 fits with ScratchSize 0
+#define ACL_SIMPLE_WIDTH 2  // children per lane and step.  Same-box A/B (profiles/r02_kernel_ab.md): 2 and 3 are within 2 % of each other on the level loop; 2 keeps the single-launch kernel out of scratch
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
-template <bool SHARDED, bool LOCAL>
-__device__ __forceinline__ void flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
-                                              uint8_t *has, uint8_t *err) {
+// Returns a bit mask of the 64-task rounds it did NOT handle (the caller expands those the generic way): a round whose rows
+// together exceed the head-bit window (a row of thousands of ids) or with a task at the dispatch-depth limit.
+//
+// Instruction count is what bounds this loop (the deep levels of a large batch keep the vector ALU busy 60 % of the launch,
+// profiles/r02_pmc_issue_breakdown.txt), so everything that is a property of the TASK is done once per task, not per child:
+//   - the subject's row {first bucket, count} sits in the task (DESC: fetched by the parent lane together with its has[] byte
+//     and row descriptor; otherwise fetched here, one gather per 64 tasks) -- no per-child descriptor gather;
+//   - depth limits are checked per task (above);
+//   - work item -> task without a search: every task owns >= 1 consecutive work items, so task lanes set ONE head bit each
+//     (LDS atomic or) at their first work item; a lane's task is then `tasks before this 64-item window` + the head bits at or
+//     below its lane (two v_mbcnt) -- the 6-step binary search over the LDS prefix array cost ~30 VALU + 6 LDS reads per child;
+//   - one output reservation per step for the W x 64 children, not one per 64.
+template <bool SHARDED, bool LOCAL, bool DESC>
+__device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
+                                                  uint8_t *has, uint8_t *err) {
     constexpr int W = kSimpleWidth;
     const uint32_t *__restrict__ edges = g.edges;
-    const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     uint4 *__restrict__ out = wo.buf;
+    uint32_t skipped = 0;
     for (uint32_t gq = 0; gq < T; gq += 64) {
-        const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
+        const bool mine = gq + lane < T;
+        const uint32_t cnt = mine ? (t.count[gq + lane] & kCountMask) : 0u;
         const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = uniform(__shfl(incl, 63, 64));
-        t.scan[lane] = incl - cnt;
+        const uint32_t total = wave_last(incl);
+        const uint32_t lvl = mine ? meta_level(t.meta[gq + lane]) : 0u;
+        if (total > 64u * kHeadWords || __ballot(lvl + pop.dlevel > kMaxLevels || lvl + cp.max_dlevel > kMaxLevels)) {
+            skipped |= 1u << (gq >> 6);
+            continue;
+        }
+        const uint32_t excl = incl - cnt;
+        if (!DESC && mine) {
+            const uint32_t sidt = t.sid[gq + lane];
+            const uint2 d = gld(reinterpret_cast<const uint2 *>(g.meta), pop.base + (sidt < pop.nrows ? sidt : 0u));
+            const bool row = sidt < pop.nrows && d.y > d.x;
+            t.b0[gq + lane] = row ? d.x : 0u;
+            t.nb[gq + lane] = row ? d.y - d.x : 1u;
+        }
+        if (lane < kHeadWords) t.heads[lane] = 0ull;
+        t.scan[lane] = (mine ? t.start[gq + lane] : 0u) - excl;  // first edge of the task minus its first work item: edge index = this + work item
         wave_lds_fence();
+        if (mine) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl >> 6]), 1ull << (excl & 63u));
+        wave_lds_fence();
+        uint32_t before = 0;  // tasks that start before the current 64-item window
         for (uint32_t w0 = 0; w0 < total; w0 += 64 * W) {
             bool valid[W];
             uint32_t tj[W], edge[W];
 #pragma unroll
             for (int k = 0; k < W; k++) {
+                const uint32_t win = (w0 >> 6) + (uint32_t)k;
+                const uint64_t hw = win < kHeadWords ? t.heads[win] : 0ull;
+                const uint32_t hlo = uniform((uint32_t)hw), hhi = uniform((uint32_t)(hw >> 32));
                 const uint32_t w = w0 + 64u * k + lane;
                 valid[k] = w < total;
                 const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
-                uint32_t j = 0;
-#pragma unroll
-                for (uint32_t step = 32; step >= 1; step >>= 1)
-                    if (t.scan[j + step] <= wv) j += step;
+                // tasks starting at or before this lane's work item, minus one (beyond `total` there are no head bits: the last task)
+                const uint32_t j = before + __builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, 0u)) + (uint32_t)((hw >> lane) & 1ull) - 1u;
+                before += (uint32_t)__popc(hlo) + (uint32_t)__popc(hhi);
                 tj[k] = gq + j;
-                edge[k] = gld(edges, t.start[tj[k]] + (wv - t.scan[j]));
+                edge[k] = gld(edges, t.scan[j] + wv);
             }
-            // the subject's row descriptor goes out in the same trip as the edge: it depends on the task, not on the child
-            uint2 d[W];
-            bool row[W];
-#pragma unroll
-            for (int k = 0; k < W; k++) {
-                const uint32_t sidk = t.sid[tj[k]];
-                row[k] = sidk < pop.nrows;
-                d[k] = gld(smeta, pop.base + (row[k] ? sidk : 0u));
-                row[k] = row[k] && d[k].y > d[k].x;
-            }
+            issue_fence();  // trip 1: the W edges
             uint4 p[W], q[W];
 #pragma unroll
             for (int k = 0; k < W; k++) {
-                const uint32_t b0 = row[k] ? d[k].x : 0u, nbk = row[k] ? d[k].y - d[k].x : 1u;
                 uint32_t h1, h2;
-                hashed_row_buckets(edge[k] & kIdMask, nbk, &h1, &h2);
+                hashed_row_buckets(edge[k] & kIdMask, t.nb[tj[k]], &h1, &h2);
+                const uint32_t b0 = t.b0[tj[k]];
                 p[k] = gld(buckets, b0 + h1);
                 q[k] = gld(buckets, b0 + h2);
             }
+            issue_fence();  // trip 2: the 2 x W buckets
+            bool hit[W], push[W];
+            uint64_t pb[W];
+            uint32_t pre[W], np = 0;
 #pragma unroll
             for (int k = 0; k < W; k++) {
-                const uint32_t c = edge[k] & kIdMask;
-                const bool contains = row[k] && (p[k].x == c || p[k].y == c || p[k].z == c || p[k].w == c || q[k].x == c || q[k].y == c || q[k].z == c || q[k].w == c);
-                const uint32_t req = t.req[tj[k]], meta = t.meta[tj[k]];
-                const uint32_t level = meta_level(meta);
-                const bool hit = valid[k] && contains && level + pop.dlevel <= kMaxLevels;
-                const bool derr = valid[k] && level + cp.max_dlevel > kMaxLevels;
-                bool push = valid[k] && !(edge[k] & kLeafBit);
-                if (hit) {
-                    has[req] = 1;
-                    push = false;
-                } else if (derr) {
-                    err[req] = ITEM_ERR_DEPTH;
-                }
-                const uint64_t b = __ballot(push);
-                if (b) {
-                    const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
-                    if (push && base != kNoSpace) gst(out, base + lanes_below(b), make_uint4(c, req, meta | kProbedBit, t.sid[tj[k]]));
+                // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
+                //  loads at the end of every step; depth limits were checked per task above)
+                hit[k] = valid[k] & bucket_pair_has(p[k], q[k], edge[k] & kIdMask);
+                push[k] = valid[k] & !hit[k] & ((edge[k] & kLeafBit) == 0u);
+                pb[k] = __ballot(push[k]);
+                pre[k] = np;
+                np += (uint32_t)__popcll(pb[k]);
+            }
+            // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
+            // (vmcnt counts stores too, and the compiler must assume the store was not issued)
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                if (hit[k]) has[t.req[tj[k]]] = 1;
+            if (np) {
+                const uint32_t base = reserve<LOCAL>(wo, np, lane);
+                if (base != kNoSpace) {
+#pragma unroll
+                    for (int k = 0; k < W; k++)
+                        if (push[k])
+                            gst(out, base + pre[k] + lanes_below(pb[k]), make_uint4(edge[k] & kIdMask, t.req[tj[k]], t.meta[tj[k]] | kProbedBit, t.sid[tj[k]]));
                 }
             }
         }
         wave_lds_fence();
     }
+    return skipped;
 }
 
 // Second specialised expansion: all tasks lead to one child slot whose program is at most two hashed probes followed by at
@@ -344,7 +405,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
     for (uint32_t gq = 0; gq < T; gq += 64) {
         const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
         const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        const uint32_t total = wave_last(incl);
         t.scan[lane] = incl - cnt;
         wave_lds_fence();
         for (uint32_t w0 = 0; w0 < total; w0 += 64) {
@@ -379,9 +440,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                 uint32_t h1, h2;
                 hashed_row_buckets(child, nb, &h1, &h2);
                 const uint4 bp = gld(buckets, b0 + h1), bq = gld(buckets, b0 + h2);
-                if (hr && level + dl <= kMaxLevels)
-                    hit = hit || bp.x == child || bp.y == child || bp.z == child || bp.w == child || bq.x == child || bq.y == child || bq.z == child ||
-                          bq.w == child;
+                if (hr && level + dl <= kMaxLevels) hit = hit || bucket_pair_has(bp, bq, child);
             };
             if (nh > 0) probe(hd[0], hrow[0], cops[0].dlevel);
             asm volatile("" ::: "memory");  // keep the second probe's gathers behind the first's (register budget, see above)
@@ -445,10 +504,11 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
     }
 }
 
-template <bool INLINE, bool SHARDED, bool LOCAL>
+template <bool INLINE, bool SHARDED, bool LOCAL, bool DESC = false>  // DESC: the tasks carry the subject's hashed row (TaskLds b0 / nb)
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
                                             const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh) {
     uint4 *__restrict__ out = wo.buf;
+    uint32_t only = ~0u;  // rounds of 64 tasks left for the generic loop
     wave_lds_fence();
     if (INLINE) {  // all tasks lead to the same "simple" child state?  (one hashed probe + authoritative leaf flags, plain subject)
         const uint32_t m0 = t.meta[0];
@@ -466,9 +526,9 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
         }
         if (ok && !__ballot(!agree)) {
-            flush_simple<SHARDED, LOCAL>(t, T, wo, lane, g, cp, pop, has, err);
-            return;
-        }
+            only = flush_simple<SHARDED, LOCAL, DESC>(t, T, wo, lane, g, cp, pop, has, err);
+            if (!only) return;
+        } else
         // second shape: <= 2 hashed probes + <= 2 enumerate ops that are only looked at; uniform slot, key and leaf authority
         if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
             const FwdOp *cops = ops + cp.first;
@@ -490,9 +550,10 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
         }
     }
     for (uint32_t gq = 0; gq < T; gq += 64) {
+        if (!(only & (1u << (gq >> 6)))) continue;
         const uint32_t cnt = (gq + lane < T) ? (t.count[gq + lane] & kCountMask) : 0u;
         const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = uniform(__shfl(incl, 63, 64));
+        const uint32_t total = wave_last(incl);
         t.scan[lane] = incl - cnt;
         wave_lds_fence();
         for (uint32_t w0 = 0; w0 < total; w0 += 64) {
@@ -611,6 +672,12 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
     {
         const uint64_t vb = __ballot(valid);
         if (!vb) return;
+        // the wave's NEXT segment (B) is loaded right behind this one (A): if both turn out to be simple segments of one slot they
+        // are expanded as a pair, and then their entries arrive in one trip and their gathers go out in one trip
+        bool validB = false;
+        uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
+        const bool haveB = next.peek(eB, validB);
+        issue_fence();
         const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
         const uint32_t cs = meta_slot(m0);
         bool simple = m0 != kDeadMeta && !__ballot(valid && (meta == kDeadMeta || !(meta & kProbedBit) || meta_slot(meta) != cs || meta_key(meta) < g.nslots));
@@ -625,8 +692,24 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             }
         }
         if (simple) {
+            // The child state every task of this segment leads to: when it is "one hashed probe" (the shape flush_simple expands),
+            // the parent lane fetches the request subject's row descriptor of that probe right here -- in the same trip as its
+            // has[] byte and its own row descriptor -- and the task carries {first bucket, count}: once per parent, not per child.
+            const SlotProg ccp = progs[sop.key];
+            FwdOp cpop{};
+            bool cfast = ccp.n_probe == 1;
+            if (cfast) {
+                cpop = ops[ccp.first];
+                cfast = cpop.flags == OP_PROBE_HASH;
+            }
+            const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
+            auto subj_desc = [&](const uint4 &se, bool sv) -> uint2 {
+                const bool ok = cfast && sv && meta_key(se.z) == cpop.key && se.w < cpop.nrows;
+                const uint2 d = gld(smeta, cpop.base + (ok ? se.w : 0u));
+                return (ok && d.y > d.x) ? make_uint2(d.x, d.y - d.x) : make_uint2(0u, 1u);  // no row: the reserved empty bucket
+            };
             // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
-            auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, bool inrow, uint32_t Tb) -> uint32_t {
+            auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, uint2 sd, bool inrow, uint32_t Tb) -> uint32_t {
                 const bool act = sv && !hv;
                 const uint32_t lv = meta_level(se.z), L = lv + sop.dlevel;
                 bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
@@ -644,6 +727,8 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                     t.req[q] = se.y;
                     t.meta[q] = make_meta(sop.key, L + 1, meta_key(se.z));
                     t.sid[q] = se.w;
+                    t.b0[q] = sd.x;
+                    t.nb[q] = sd.y;
                 }
                 return (uint32_t)__popcll(b);
             };
@@ -654,22 +739,26 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 }
                 return gld(reinterpret_cast<const uint2 *>(g.meta), sop.base + rid * sop.K + sop.k);
             };
-            // segment A's gathers and -- when the wave has another segment pending -- segment B's entries, all in flight together
+            // B joins when it is a simple segment of the same slot; then all six gathers are in flight together
+            const bool pairB = haveB && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots));
+            if (pairB) next.take();
+            else validB = false;
             const uint32_t hvA = gld(has, valid ? req : 0u);
             const bool inA = valid && id < sop.nrows;
             const uint2 mdA = row_desc(inA ? id : 0u);
-            bool validB = false;
-            uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
-            const bool haveB = next.peek(eB, validB);
-            uint32_t T = seg_tasks(e, valid, hvA, mdA, inA, 0u);
-            if (haveB && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots))) {
-                next.take();  // B is a simple segment of the same slot: taken here
-                const uint32_t hvB = gld(has, validB ? eB.y : 0u);
-                const bool inB = validB && eB.x < sop.nrows;
-                const uint2 mdB = row_desc(inB ? eB.x : 0u);
-                T += seg_tasks(eB, validB, hvB, mdB, inB, T);
+            const uint2 sdA = subj_desc(e, valid);
+            uint32_t hvB = 0;
+            uint2 mdB = make_uint2(0, 0), sdB = make_uint2(0, 1);
+            const bool inB = validB && eB.x < sop.nrows;
+            if (pairB) {
+                hvB = gld(has, validB ? eB.y : 0u);
+                mdB = row_desc(inB ? eB.x : 0u);
+                sdB = subj_desc(eB, validB);
             }
-            if (T) flush_tasks<true, SHARDED, LOCAL>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            issue_fence();
+            uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, 0u);
+            if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, T);
+            if (T) flush_tasks<true, SHARDED, LOCAL, true>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh);
             return;
         }
     }
@@ -818,15 +907,14 @@ __device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t it
 // load per slot (most slots are empty: 16+ per wave and level).
 struct ChunkWalk {
     const uint4 *__restrict__ in;
-    uint32_t C, nwaves, lane, x0;
-    uint32_t lc, lcnt;
+    uint32_t lane;
+    const uint32_t *slots;  // LDS, wave-private, of the wave's next 64 segment slots: [0, 64) first entry of the segment (chunk * kChunk + segment * 64),
+                            // [64, 128) entries the chunk holds from that segment on -- in LDS, not in two VGPRs that live across every expansion
     uint64_t work;
     __device__ __forceinline__ void load(int wl, uint4 &e, bool &valid) const {
-        const uint32_t x = x0 + (uint32_t)wl * nwaves, s = x / C;
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)lc, wl);
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)lcnt, wl) + s * 64;
-        valid = s * 64 + lane < cnt;
-        e = valid ? gld(in, c * kChunk + s * 64 + lane) : make_uint4(0, 0, kDeadMeta, 0);
+        const uint32_t at = uniform(slots[wl]), left = uniform(slots[64 + wl]);  // left >= 1: the slot's work bit is set
+        valid = lane < left;
+        e = gld(in, at + (valid ? lane : 0u));  // unconditional (a load under `if` is waited for where the branch rejoins); the caller masks by `valid`
     }
     __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
         if (!work) return false;
@@ -841,12 +929,13 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
                                                                            DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
+    __shared__ uint32_t s_slots[kWavesPerBlock][128];
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs;
     const FwdOp *ops;
     load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
     const uint32_t lane = lane_id();
-    const uint32_t wib = threadIdx.x >> 6;
+    const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
     const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
     const uint32_t pin = (iter + 1) & 1u;  // iteration i reads parity (i-1)&1
@@ -854,21 +943,26 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     const bool live = !*f.overflow && f.any[iter - 1];
     const uint32_t C = live ? nwaves + min(f.nchunks[iter - 1], f.max_chunks - nwaves) : 0u;
     WaveOut wo = chunked_out(f, iter, wave, &s_cold[wib], lane);
-    ChunkWalk cw{f.buf[pin], C, nwaves, lane, 0u, 0u, 0u, 0ull};
+    uint32_t *slots = s_slots[wib];
+    ChunkWalk cw{f.buf[pin], lane, slots, 0ull};
     const uint32_t nslot = C * kSegsPerChunk;
     for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
+        // (once per 64 slots: keep the division's precomputed reciprocal out of a VGPR that would live across every expansion)
+        uint32_t Cl = C;
+        asm volatile("" : "+s"(Cl));
         const uint32_t xl = x0 + lane * nwaves;
-        uint32_t lc = 0, lcnt = 0;
+        uint32_t lat = 0, lcnt = 0;
         if (xl < nslot) {
-            const uint32_t ls = xl / C;
-            lc = (xl % C + ls * 509u) % C;
+            const uint32_t ls = xl / Cl, lc = (xl % Cl + ls * 509u) % Cl;
             lcnt = in_counts[lc];
             lcnt = lcnt > ls * 64 ? lcnt - ls * 64 : 0u;  // entries of this slot's segment and beyond
+            lat = lc * kChunk + ls * 64;
         }
-        cw.x0 = x0;
-        cw.lc = lc;
-        cw.lcnt = lcnt;
+        wave_lds_fence();  // (the previous round's readers are done)
+        slots[lane] = lat;
+        slots[64 + lane] = lcnt;
         cw.work = __ballot(lcnt != 0);
+        wave_lds_fence();
         while (cw.work) {
             const int wl = __ffsll((unsigned long long)cw.work) - 1;
             cw.work &= cw.work - 1;
@@ -899,7 +993,7 @@ struct LocalWalk {
     __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
         if ((s + 1) * 64 >= n) return false;
         valid = (s + 1) * 64 + lane < n;
-        e = valid ? in[(s + 1) * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
+        e = in[valid ? (s + 1) * 64 + lane : (s + 1) * 64];  // unconditional, like ChunkWalk::load
         return true;
     }
     __device__ __forceinline__ void take() { s++; }
@@ -909,83 +1003,100 @@ struct NoNext {
     __device__ __forceinline__ void take() {}
 };
 
+// Work = units of `rpw` consecutive requests.  Wave w starts on unit w; when there are more units than waves the rest is handed
+// out through `next_unit` (one atomic per unit), so a wave that drew cheap requests takes more of them.
+#ifndef ACL_LOCAL_WAVES_PER_SIMD
+#define ACL_LOCAL_WAVES_PER_SIMD 6
+#endif
 template <bool LDSPROG>
-__global__ __launch_bounds__(64) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1,
-                                                    uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
-    __shared__ TaskLds t;
-    __shared__ WaveOutCold s_cold;
+__global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
+                                                                                uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap,
+                                                                                uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
+                                                                                int32_t *err_out) {
+    __shared__ TaskLds lds[kWavesPerBlock];
+    __shared__ WaveOutCold s_cold[kWavesPerBlock];
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs;
     const FwdOp *ops;
-    load_programs<LDSPROG>(g, s_prog, progs, ops, 64);
+    load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
     const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x;
-    const uint32_t first = wave * rpw;
-    if (first >= n) return;
-    const uint32_t mine = min(rpw, n - first);
+    const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
+    TaskLds &t = lds[wib];
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = gridDim.x * kWavesPerBlock;
     const DevShard nosh{};
-    // ---- seeds (k_seed's validation), in registers
-    const bool valid = lane < mine;
-    const uint32_t req = first + lane;
-    uint4 e = make_uint4(0, 0, kDeadMeta, 0);
-    if (valid) {
-        const uint4 it = items[req];
-        const uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
-        const bool ok = rtype < g.ntypes && stype < g.ntypes && perm < g.type_nmembers[rtype < g.ntypes ? rtype : 0] &&
-                        (srel == 0xFFFFu || srel < g.type_nmembers[stype < g.ntypes ? stype : 0]);
-        has[req] = 0;
-        err[req] = ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID;
-        uint32_t meta = kDeadMeta;
-        if (ok) {
-            const uint32_t slot = g.type_slot_base[rtype] + perm;
-            const uint32_t key = srel == 0xFFFFu ? g.nslots + stype : g.type_slot_base[stype] + srel;
-            meta = make_meta(slot, 1u, key);
-        }
-        e = make_uint4(it.y, req, meta, it.w);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     uint4 *bufs[2] = {buf0 + (size_t)wave * cap, buf1 + (size_t)wave * cap};
-    WaveOut wo;
-    wo.buf = bufs[0];
-    wo.cur = 0;
-    wo.fill = 0;
-    wo.produced = 0;
-    if (lane == 0) s_cold = WaveOutCold{nullptr, nullptr, overflow, 0u, 0u, cap};
+    if (lane == 0) s_cold[wib] = WaveOutCold{nullptr, nullptr, overflow, 0u, 0u, cap};
     wave_lds_fence();
-    wo.cold = &s_cold;
-    {
-        NoNext nn;
-        process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
-    }
-    uint32_t parity = 0;
-    for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
-        if (wo.cur == kNoSpace) break;  // overflow: the host redoes the batch
-        const uint32_t cnt = wo.fill;
-        if (!cnt) break;
-        // the wave's own stores of this level must be visible to its own loads of the next
+    for (uint32_t unit = uniform(wave); unit < nunits;) {
+        const uint32_t first = unit * rpw;
+        const uint32_t mine = min(rpw, n - first);
+        // ---- seeds (k_seed's validation), in registers
+        const bool valid = lane < mine;
+        const uint32_t req = first + lane;
+        uint4 e = make_uint4(0, 0, kDeadMeta, 0);
+        if (valid) {
+            const uint4 it = gld(items, req);
+            const uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
+            const bool tok = rtype < g.ntypes && stype < g.ntypes;
+            const uint32_t rt = tok ? rtype : 0u, st = tok ? stype : 0u;
+            const uint32_t rmem = gld(g.type_nmembers, rt), smem = gld(g.type_nmembers, st), rbase = gld(g.type_slot_base, rt), sbase = gld(g.type_slot_base, st);
+            const bool ok = tok && perm < rmem && (srel == 0xFFFFu || srel < smem);
+            gst(has, req, (uint8_t)0);
+            gst(err, req, (uint8_t)(ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID));
+            const uint32_t meta = ok ? make_meta(rbase + perm, 1u, srel == 0xFFFFu ? g.nslots + stype : sbase + srel) : kDeadMeta;
+            e = make_uint4(it.y, req, meta, it.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        WaveOut wo;
+        wo.buf = bufs[0];
+        wo.cur = 0;
+        wo.fill = 0;
+        wo.produced = 0;
+        wo.cold = &s_cold[wib];
+        {
+            NoNext nn;
+            process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
+        }
+        uint32_t parity = 0;
+        for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
+            if (wo.cur == kNoSpace) break;  // overflow: the host redoes the batch
+            const uint32_t cnt = wo.fill;
+            if (!cnt) break;
+            // the wave's own stores of this level must be visible to its own loads of the next
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            LocalWalk lw{bufs[parity], cnt, 0u, lane};
+            parity ^= 1u;
+            wo.buf = bufs[parity];
+            wo.cur = 0;
+            wo.fill = 0;
+            for (; lw.s * 64 < cnt; lw.s++) {
+                const bool v = lw.s * 64 + lane < cnt;
+                const uint4 en = lw.in[v ? lw.s * 64 + lane : lw.s * 64];  // unconditional; process_segment masks by `v`
+                process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+            }
+        }
+        // ---- answers (k_finalize)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        LocalWalk lw{bufs[parity], cnt, 0u, lane};
-        parity ^= 1u;
-        wo.buf = bufs[parity];
-        wo.cur = 0;
-        wo.fill = 0;
-        for (; lw.s * 64 < cnt; lw.s++) {
-            const bool v = lw.s * 64 + lane < cnt;
-            const uint4 en = v ? lw.in[lw.s * 64 + lane] : make_uint4(0, 0, kDeadMeta, 0);
-            process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+        {
+            // (request index and validity are re-derived from the unit number: two VGPRs that would otherwise live across the whole walk)
+            uint32_t u2 = uniform(unit);
+            asm volatile("" : "+s"(u2));
+            const uint32_t first2 = u2 * rpw, rq = first2 + lane;
+            if (lane < min(rpw, n - first2)) {
+                const bool h = __hip_atomic_load(has + rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                perm_out[rq] = h ? 2 : (er ? 0 : 1);
+                if (err_out) err_out[rq] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
+            }
         }
-    }
-    // ---- answers (k_finalize)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (valid) {
-        const bool h = __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        perm_out[req] = h ? 2 : (er ? 0 : 1);
-        if (err_out) err_out[req] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
+        if (wo.cur == kNoSpace || !next_unit) break;
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(next_unit, 1u);
+        unit = nwaves + uniform(nx);
     }
 }
 
@@ -1024,7 +1135,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
     const uint32_t lane = lane_id();
-    const uint32_t wib = threadIdx.x >> 6;
+    const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
     const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
     const uint32_t pin = (iter + 1) & 1u;
@@ -1292,13 +1403,22 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
 }
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1, uint32_t cap,
-                        uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
-    const dim3 grid((n + rpw - 1) / rpw);
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+    const uint32_t nunits = (n + rpw - 1) / rpw;
+    const dim3 grid(nblocks);
     if (g.nslots + g.nops <= kProgLdsEntries)
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(64), 0, s, g, items, n, rpw, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
     else
-        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(64), 0, s, g, items, n, rpw, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+}
+int local_grid_blocks(int device) {
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, 0) != hipSuccess || occ <= 0) occ = 4;
+    return cus * occ;
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;

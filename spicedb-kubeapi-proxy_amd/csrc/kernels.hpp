@@ -86,8 +86,10 @@ void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids
 void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out);
 // single-launch Check for small batches: wave w answers requests [w * rpw, (w + 1) * rpw) through every level with a private
 // frontier of `cap` entries in each of buf0 / buf1 (regions w * cap); *overflow != 0 afterwards: redo on the level loop
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint4 *buf0, uint4 *buf1, uint32_t cap,
-                        uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
+// blocks of the single-launch kernel that are resident at once on this device
+int local_grid_blocks(int device);
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
 void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase = REV_FUSED,
                        const DevShard &sh = DevShard());

@@ -191,6 +191,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     std::vector<RelLayout> lay(sc.nslots);
     auto &tables = store.tables();
     std::vector<uint32_t> cnt, fill;
+    s.buckets.assign(4, kEmpty);  // bucket 0 is nobody's and stays empty: the kernels point a subject WITHOUT a row at {0, 1} and probe branch-free
     // pass A: which classes are live / hashed.  Sorted classes are numbered per TYPE: the row descriptors of all relations of
     // one object sit side by side ({start, end} pairs), so a state that touches two of them (`pod#view`: the group viewers and
     // the namespace arrow) finds both in one 16-byte record -- one cold line instead of two at level 1.
@@ -280,7 +281,6 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         for (const auto &ct : slot) s.nedges += ct.keys.size();
     if (s.meta.empty()) s.meta.assign(4, 0);
     if (s.edges.empty()) s.edges.push_back(0);
-    if (s.buckets.empty()) s.buckets.assign(4, 0xFFFFFFFFu);
     // ---- programs
     s.progs.resize(sc.nslots);
     for (int slot = 0; slot < sc.nslots; slot++) {
