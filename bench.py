@@ -416,16 +416,22 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     st_dev = eng.stats()
     eng.check_bulk_ids_device(d_batches[0].data_ptr(), n, d_perm.data_ptr(), d_err.data_ptr())
     gpu_perm, gpu_err = d_perm.cpu().numpy(), d_err.cpu().numpy()
-    launches = max(1, st_dev["expand_launches"])
+    # the dominant kernel: the single-launch walk (k_check_local: every level of the batch in ONE launch) unless the batch took the
+    # level loop (k_expand: one launch per level) -- frontier overflow, sharded graph, ACL_LOCAL_MAX=0
+    if st_dev.get("local_ms", 0.0) >= st_dev["expand_ms"]:
+        kern = {"name": "k_check_local", "ms": st_dev["local_ms"], "launches": max(1, st_dev["local_passes"])}
+    else:
+        kern = {"name": "k_expand", "ms": st_dev["expand_ms"], "launches": max(1, st_dev["expand_launches"])}
     rec["device_resident"] = {"decisions_per_s": n * steps / el_dev, "ms_per_batch": 1e3 * el_dev / steps, "p50_batch_ms": 1e3 * float(np.median(lat)),
-                              "kernel_ms_per_batch": st_dev["kernel_ms"] / steps, "expand_launches_per_batch": launches / steps,
+                              "kernel_ms_per_batch": st_dev["kernel_ms"] / steps, "dominant_kernel": kern["name"],
+                              "launches_per_batch": kern["launches"] / steps, "level_loop_launches_per_batch": st_dev["expand_launches"] / steps,
                               "note": "acl_check_bulk_ids_device: batch already in HBM, one call at a time"}
     rec["levels"] = int(st_dev["levels_last"])
     rec["has_fraction"] = float((gpu_perm == 2).mean())
     if "device" == legs:
         rec["value"] = rec["device_resident"]["decisions_per_s"]
         rec["elapsed"] = el_dev
-        rec["kernel"] = {"expand_ms": st_dev["expand_ms"], "launches": launches}
+        rec["kernel"] = kern
         return rec, gpu_perm, gpu_err
 
     # ---------------- (ii) host ids, pipelined: THE timed region (`value`)
@@ -523,7 +529,7 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     rec["string_path"] = {"decisions_per_s": m / t_str, "ms_per_batch": 1e3 * t_str, "items": m,
                           "note": "acl_check_bulk: 5 C strings per item interned on the host (parallel over host threads), then one pass; "
                                   "object names are the decimal ids (bulk-loaded ids are anonymous: every name resolves to 'no relationships')"}
-    rec["kernel"] = {"expand_ms": st_dev["expand_ms"], "launches": launches}
+    rec["kernel"] = kern
     return rec, gpu_perm, gpu_err
 
 
@@ -581,19 +587,23 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
     t_bytes = time.perf_counter() - t0
     k = rec.pop("kernel")
     steps = rec["_steps"]
-    ach = tot * steps / (k["expand_ms"] * 1e-3) / 1e9 if k["expand_ms"] > 0 else None
+    ach = tot * steps / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else None
     nz = int(np.flatnonzero(lvl_b)[-1]) + 1 if lvl_b.any() else 1
     traffic = None
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
-            t_ = json.load(open(tr)).get(label)
-            if t_:
-                traffic = dict(t_, source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, NOT measured in this run")
+            tj = json.load(open(tr))
+            det = tj.get(label + "_detail") or {}
+            if tj.get(label) and det.get("kernel") == k["name"]:  # (only a profile of the SAME kernel says anything about this run's launches)
+                traffic = {"bytes_per_launch": tj[label], "fetch_bytes_raw": det.get("fetch_bytes_per_launch_raw"), "write_bytes": det.get("write_bytes_per_launch"),
+                           "profile": det.get("tag"),
+                           "source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (gfx950 x2 FETCH "
+                                     "correction applied), NOT measured in this run"}
         except Exception:  # noqa: BLE001
             pass
     rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                       "kernel": "k_expand", "kernel_avg_us": 1e3 * k["expand_ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
+                       "kernel": k["name"], "kernel_avg_us": 1e3 * k["ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
                        "measured_in": "device_resident leg (sequential launches, HIP events on the launching stream)",
                        "algorithmic_bytes_per_check": tot / n, "algorithmic_bytes_per_batch": tot, "algorithmic_bytes_per_launch": tot * steps / k["launches"],
                        "algorithmic_bytes_by_model_level": [int(x) for x in lvl_b[1:nz]], "distinct_states_by_model_level": [int(x) for x in lvl_s[1:nz]],
@@ -715,8 +725,8 @@ def main():
             out.pop("_steps")
         else:
             out.pop("kernel", None)
-            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "k_expand",
-                               "kernel_avg_us": 1e3 * kernel["expand_ms"] / kernel["launches"] if kernel else None,
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                               "kernel": kernel["name"] if kernel else None, "kernel_avg_us": 1e3 * kernel["ms"] / kernel["launches"] if kernel else None,
                                "note": "algorithmic bytes need the CPU oracle's byte model: rank 0 at N=1 only"}
             out["cpu_baseline"] = None
     eng.close()

@@ -225,7 +225,8 @@ struct acl_engine {
     hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
     int grid_blocks = 2048;
     int local_blocks = 1024;   // resident blocks of the single-launch kernel
-    uint32_t local_upw = 2;    // single-launch pass over a large batch: work units per resident wave
+    uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
+                               // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round
     uint64_t cfg_frontier_entries = 0;
     // forward graph
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;

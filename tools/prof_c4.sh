@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/stats.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/write.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats -d $O/stats -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/stats.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/fetch.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o r -- python $R/bench.py --steps 5 --warmup 2 --no-cpu --legs device --configs off "$@" > $O/write.log 2>&1
 grep -h '^{' $O/stats.log | tail -1
