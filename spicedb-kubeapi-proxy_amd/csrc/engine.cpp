@@ -444,10 +444,9 @@ constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path decli
 // Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
 // batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
 // the context's frontier buffers.
-// Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, whether units are handed out dynamically.
+// Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, private frontier entries per wave.
 struct LocalGeom {
     uint32_t rpw, nblocks, nunits, cap;
-    bool dynamic;
 };
 static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     const uint32_t max_waves = (uint32_t)h->local_blocks * kWavesPerBlock;  // what is resident at once
@@ -455,23 +454,23 @@ static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     if (n <= max_waves) G.rpw = 1;  // latency: every request its own wave
     else {
         // throughput: every level of a unit costs a chain of dependent trips whatever the unit's size, so units are as large as
-        // balance allows: `upw` units per resident wave, handed out dynamically (a wave that drew cheap requests takes more)
+        // the lanes allow: `upw` units per resident wave (1: no second round of chains)
         G.rpw = std::min<uint32_t>(std::max<uint32_t>((n + max_waves * h->local_upw - 1) / (max_waves * h->local_upw), 1), 64);
     }
     G.nunits = (n + G.rpw - 1) / G.rpw;
     G.nblocks = std::min<uint32_t>((G.nunits + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->local_blocks);
-    G.dynamic = G.nunits > G.nblocks * kWavesPerBlock;
-    G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / ((uint64_t)G.nblocks * kWavesPerBlock), 1u << 20);
+    // (a wave that needs more than 64 K entries is walking something the whole chip should walk: the level loop takes the batch)
+    G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / ((uint64_t)G.nblocks * kWavesPerBlock), 1u << 16);
     return G;
 }
 
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
-    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
-    HIP_TRY(hipMemsetAsync(d_over, 0, 2 * sizeof(uint32_t), c->stream));
+    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;
+    HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(uint32_t), c->stream));
     ev_begin(c, 2);
-    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.dynamic ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
+    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
                        c->d_err.p, d_perm, d_errout);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -491,7 +490,7 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
 // 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
 static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out) {
     const LocalGeom G = local_geom(h, c, n);
-    if (G.cap < 256 || G.dynamic) return kTakeLevelLoop;  // (the unit counter lives in device memory: large batches go through check_pass_local)
+    if (G.cap < 256 || n > 8192) return kTakeLevelLoop;  // (a large batch is better copied than read across PCIe by the kernel)
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
@@ -505,7 +504,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     HIP_TRY(hipHostGetDevicePointer(&d_in, c->h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
     ev_begin(c, 2);
-    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
+    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
                        (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64));
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -520,21 +519,19 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     return ACL_OK;
 }
 
-// one device pass over n (<= max_sub_batch) interned items already in HBM
-int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
-    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
-    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    DevGraph g = h->dev_graph();
-    // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
-    // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
-    if (n <= h->local_max_items) {
-        int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
-        if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a wave ran out of private frontier, the level-synchronous path takes the batch
-    }
+constexpr int kRetryMerging = -1002;  // internal: the level loop ran out of frontier on its first attempt
+
+// the level-synchronous pass (one k_expand launch per dispatch level); `merging`: duplicate entries are struck after every level
+static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool merging) {
     for (int attempt = 0;; attempt++) {
         if ((uint64_t)n > c->frontier_entries) {
             int rc = alloc_frontier(h, c, (uint64_t)n * 4);
             if (rc) return rc;
+        }
+        uint32_t bits = 0;
+        if (merging) {
+            while ((1ull << bits) < 2 * c->frontier_entries) bits++;
+            HIP_TRY(c->d_dedup.ensure((size_t)1 << bits));
         }
         DevFrontier f = h->dev_frontier(*c);
         ev_begin(c, 0);
@@ -542,14 +539,20 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
         ev_end(c);
         uint32_t levels = 0;
         int rc = level_loop(
-            h, c, kMaxLevels, [&](uint32_t it) { launch_expand(c->stream, g, f, it, c->d_has.p, c->d_err.p); }, &levels,
+            h, c, kMaxLevels,
+            [&](uint32_t it) {
+                launch_expand(c->stream, g, f, it, c->d_has.p, c->d_err.p);
+                if (merging) launch_dedup(c->stream, f, it, c->d_dedup.p, bits);
+            },
+            &levels,
             [&] {
                 ev_begin(c, 0);
                 launch_finalize(c->stream, n, c->d_has.p, c->d_err.p, d_perm, d_errout);
                 ev_end(c);
             });
         if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
-            // frontier out of chunks: grow (up to 2^32 entries) and redo the pass
+            if (!merging) return kRetryMerging;
+            // out of chunks even with duplicates merged: grow (up to 2^28 entries) and redo the pass
             c->stats.overflow_retries++;
             if (c->frontier_entries >= (uint64_t)kMaxFrontierChunks * kChunk || attempt > 8)
                 return fail(ACL_ERR_RESOURCE_EXHAUSTED, "frontier capacity exceeded (" + std::to_string(c->frontier_entries) + " entries); lower max_sub_batch");
@@ -564,6 +567,30 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
         c->stats.check_passes++;
         return ACL_OK;
     }
+}
+
+// one device pass over n (<= max_sub_batch) interned items already in HBM
+int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+    DevGraph g = h->dev_graph();
+    // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
+    // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
+    if (n <= h->local_max_items) {
+        int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
+        if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a wave ran out of private frontier, the level-synchronous path takes the batch
+    }
+    int rc = levels_pass(h, c, g, d_items, n, d_perm, d_errout, false);
+    if (rc != kRetryMerging) return rc;
+    // The frontier outgrew its buffers.  Before growing them: merge identical (request, state, level) entries after every level
+    // (k_dedup) -- nested groups with branching cycles double the frontier per level otherwise -- on slices the dedup key can hold.
+    c->stats.overflow_retries++;
+    for (uint32_t off = 0; off < n; off += kDedupBatch) {
+        const uint32_t m = std::min<uint32_t>(kDedupBatch, n - off);
+        rc = levels_pass(h, c, g, d_items + off, m, d_perm + off, d_errout ? d_errout + off : nullptr, true);
+        if (rc) return rc;
+    }
+    return ACL_OK;
 }
 
 int not_sharded(acl_engine *h) {

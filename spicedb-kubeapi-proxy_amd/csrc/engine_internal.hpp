@@ -166,6 +166,7 @@ struct PassCtx {
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
     DevArray<uint32_t> d_itemoff, d_sids, d_visited;
+    DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
     DevArray<uint4> d_xsend, d_xrecv;

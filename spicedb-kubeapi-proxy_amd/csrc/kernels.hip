@@ -1003,14 +1003,15 @@ struct NoNext {
     __device__ __forceinline__ void take() {}
 };
 
-// Work = units of `rpw` consecutive requests.  Wave w starts on unit w; when there are more units than waves the rest is handed
-// out through `next_unit` (one atomic per unit), so a wave that drew cheap requests takes more of them.
+// Work = units of `rpw` consecutive requests.  Wave w takes units w, w + nwaves, ... -- statically: handing units out through one
+// atomic counter cost ~12 ns per unit in same-address contention (C2, 65 536 items: 137 us with two units per wave against
+// 20 us with one; profiles/r02_walk_units_per_wave.txt), which is more than dynamic balance ever gave back (3 % on C4).
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
 #define ACL_LOCAL_WAVES_PER_SIMD 6
 #endif
 template <bool LDSPROG>
 __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
-                                                                                uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap,
+                                                                                uint32_t nunits, uint4 *buf0, uint4 *buf1, uint32_t cap,
                                                                                 uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
                                                                                 int32_t *err_out) {
     __shared__ TaskLds lds[kWavesPerBlock];
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
     uint4 *bufs[2] = {buf0 + (size_t)wave * cap, buf1 + (size_t)wave * cap};
     if (lane == 0) s_cold[wib] = WaveOutCold{nullptr, nullptr, overflow, 0u, 0u, cap};
     wave_lds_fence();
-    for (uint32_t unit = uniform(wave); unit < nunits;) {
+    for (uint32_t unit = uniform(wave); unit < nunits; unit += nwaves) {
         const uint32_t first = unit * rpw;
         const uint32_t mine = min(rpw, n - first);
         // ---- seeds (k_seed's validation), in registers
@@ -1093,10 +1094,41 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
                 if (err_out) err_out[rq] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
             }
         }
-        if (wo.cur == kNoSpace || !next_unit) break;
-        uint32_t nx = 0;
-        if (lane == 0) nx = atomicAdd(next_unit, 1u);
-        unit = nwaves + uniform(nx);
+        if (wo.cur == kNoSpace) break;
+    }
+}
+
+// Merges identical pending sub-checks of one level: two frontier entries with the same (request, state, level) have identical
+// subtrees, so all but one are struck (meta = dead) -- answers cannot change.  Only run when a pass outgrew its frontier: on
+// sane graphs duplicates are rare (1.8 % on C4, profiles/r02_c4_duplicate_ratio.txt) and the walk is faster without it, but group
+// nesting with BRANCHING cycles (g0 -> {g0, g1}, g1 -> g0) doubles the frontier every level for 50 levels; SpiceDB's
+// dispatcher cuts the same recursion at depth 50, and the oracle memoises on exactly this key.
+// key = request[14] | level[6] | slot[13] | object id[31] (dedup passes run on slices of <= 16 384 requests); table: open
+// addressing over u64, empty = ~0.
+__global__ __launch_bounds__(256) void k_dedup(DevFrontier f, uint32_t iter, unsigned long long *table, uint32_t bits) {
+    uint4 *buf = f.buf[iter & 1u];
+    const uint32_t *counts = f.counts[iter & 1u];
+    if (*f.overflow) return;
+    const uint32_t C = f.nwaves + min(f.nchunks[iter], f.max_chunks - f.nwaves);
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint32_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const uint32_t cnt = counts[c];
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const uint4 e = buf[(size_t)c * kChunk + i];
+            if (e.z == kDeadMeta) continue;
+            const unsigned long long key = ((unsigned long long)(e.y & 0x3FFFu) << 50) | ((unsigned long long)meta_level(e.z) << 44) |
+                                           ((unsigned long long)meta_slot(e.z) << 31) | (unsigned long long)(e.x & kIdMask);
+            uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+            for (;;) {
+                const unsigned long long old = atomicCAS(table + h, ~0ull, key);
+                if (old == ~0ull) break;  // first of its kind
+                if (old == key) {
+                    buf[(size_t)c * kChunk + i].z = kDeadMeta;
+                    break;
+                }
+                h = (h + 1u) & mask;
+            }
+        }
     }
 }
 
@@ -1403,14 +1435,14 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
 }
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
-                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint4 *buf0, uint4 *buf1,
+                        uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     const uint32_t nunits = (n + rpw - 1) / rpw;
     const dim3 grid(nblocks);
     if (g.nslots + g.nops <= kProgLdsEntries)
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
     else
-        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
 }
 int local_grid_blocks(int device) {
     hipDeviceProp_t prop;
@@ -1419,6 +1451,10 @@ int local_grid_blocks(int device) {
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, 0) != hipSuccess || occ <= 0) occ = 4;
     return cus * occ;
+}
+void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {
+    (void)hipMemsetAsync(table, 0xFF, sizeof(uint64_t) << bits, s);
+    hipLaunchKernelGGL(k_dedup, dim3(f.nwaves / kWavesPerBlock), dim3(256), 0, s, f, iter, reinterpret_cast<unsigned long long *>(table), bits);
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;

@@ -69,6 +69,27 @@ def test_depth_limit_chain(aclgpu):
         assert e.lookup("group", "member", "user", "deep") == o.lookup("group", "member", "user", "deep")
 
 
+def test_branching_cycles_stay_polynomial(aclgpu):
+    """Group nesting with BRANCHING cycles (g0 -> {g0, g1}, g1 -> g0: found by the hypothesis test below) doubles the number of
+    pending sub-checks per dispatch level for 50 levels unless identical (request, state, level) entries are merged.  The engine
+    merges them once a pass outgrows its frontier; the answers are the oracle's (which memoises on the same key): depth error for
+    subjects that are nowhere, HAS where a member is reachable."""
+    schema = "definition user {}\ndefinition group { relation member: user | group#member }"
+    rels = ["group:g0#member@group:g0#member", "group:g0#member@group:g1#member", "group:g1#member@group:g0#member",
+            "group:g1#member@group:g2#member", "group:g2#member@group:g0#member", "group:g2#member@group:g1#member", "group:g2#member@user:deep"]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        for g in ("g0", "g1", "g2"):
+            for u in ("deep", "nobody"):
+                assert e.check("group", g, "member", "user", u) == o.check("group", g, "member", "user", u), (g, u)
+        assert e.check("group", "g0", "member", "user", "nobody")[0] != 2
+        qs = [("group", g, "member", "user", u, "") for g in ("g0", "g1", "g2") for u in ("deep", "nobody")] * 50
+        perms, errs = e.check_bulk(qs)
+        assert list(zip(perms, errs)) == [o.check(*q) for q in qs]
+        assert e.stats()["overflow_retries"] >= 1  # (the merging pass was what answered)
+
+
 def test_engine_matches_oracle_hypothesis(aclgpu):
     """Random small graphs incl. cyclic group nesting, arrows, usersets with permissions as subject
     relations: every query's (permissionship, error) and every lookup set equal the oracle's."""
