@@ -444,33 +444,30 @@ constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path decli
 // Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
 // batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
 // the context's frontier buffers.
-// Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, private frontier entries per wave.
+// Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, private frontier entries per block.
 struct LocalGeom {
     uint32_t rpw, nblocks, nunits, cap;
 };
 static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
-    const uint32_t max_waves = (uint32_t)h->local_blocks * kWavesPerBlock;  // what is resident at once
+    const uint32_t blocks = (uint32_t)h->local_blocks;  // what is resident at once; a unit is walked by one block (4 waves)
     LocalGeom G{};
-    if (n <= max_waves) G.rpw = 1;  // latency: every request its own wave
-    else {
-        // throughput: every level of a unit costs a chain of dependent trips whatever the unit's size, so units are as large as
-        // the lanes allow: `upw` units per resident wave (1: no second round of chains)
-        G.rpw = std::min<uint32_t>(std::max<uint32_t>((n + max_waves * h->local_upw - 1) / (max_waves * h->local_upw), 1), 64);
-    }
+    // latency: while the batch has fewer requests than the chip has blocks, every request gets a block of its own; beyond that
+    // every block gets ONE unit of n / blocks requests (`upw` > 1: several smaller ones, a second round of per-level chains)
+    G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), kWavesPerBlock * 64u);
     G.nunits = (n + G.rpw - 1) / G.rpw;
-    G.nblocks = std::min<uint32_t>((G.nunits + kWavesPerBlock - 1) / kWavesPerBlock, (uint32_t)h->local_blocks);
-    // (a wave that needs more than 64 K entries is walking something the whole chip should walk: the level loop takes the batch)
-    G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / ((uint64_t)G.nblocks * kWavesPerBlock), 1u << 16);
+    G.nblocks = std::min<uint32_t>(G.nunits, blocks);
+    // (a block that needs more than 256 K entries is walking something the whole chip should walk: the level loop takes the batch)
+    G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / G.nblocks, 1u << 18);
     return G;
 }
 
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
-    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;
-    HIP_TRY(hipMemsetAsync(d_over, 0, sizeof(uint32_t), c->stream));
+    uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
+    HIP_TRY(hipMemsetAsync(d_over, 0, 2 * sizeof(uint32_t), c->stream));
     ev_begin(c, 2);
-    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
+    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
                        c->d_err.p, d_perm, d_errout);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -490,7 +487,7 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
 // 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
 static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out) {
     const LocalGeom G = local_geom(h, c, n);
-    if (G.cap < 256 || n > 8192) return kTakeLevelLoop;  // (a large batch is better copied than read across PCIe by the kernel)
+    if (G.cap < 256 || n > 8192 || G.nunits > G.nblocks) return kTakeLevelLoop;  // (a large batch is better copied than read across PCIe by the kernel)
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
@@ -504,7 +501,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     HIP_TRY(hipHostGetDevicePointer(&d_in, c->h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
     ev_begin(c, 2);
-    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
+    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
                        (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64));
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));

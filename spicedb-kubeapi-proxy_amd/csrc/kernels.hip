@@ -107,6 +107,27 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // same network with
     return wave_last(v);
 }
 
+// Phase timing (variant builds only, tools/phases.sh): every wave adds the shader-clock time between two marks to the phase named by
+// the second one; loads are waited for AT the mark, so a "wait" phase is the exposed latency of that trip.  ~10 % slower.
+#ifndef ACL_PROFILE_PHASES
+#define ACL_PROFILE_PHASES 0
+#endif
+enum { PH_OTHER = 0, PH_ENTRIES, PH_GATHERS, PH_TASKS, PH_PROLOGUE, PH_EDGES, PH_BUCKETS, PH_PUSH, PH_GENERIC, PH_BARRIER, PH_SEED, PH_COUNT };
+#if ACL_PROFILE_PHASES
+__device__ unsigned long long acl_phase_cycles[16];
+#define ACL_MARK(wo, ph)                                                                  \
+    do {                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                       \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();                     \
+        if (lane_id() == 0) {                                                             \
+            (wo).cold->prof[ph] += now_ - (wo).cold->last;                                \
+            (wo).cold->last = now_;                                                       \
+        }                                                                                 \
+    } while (0)
+#else
+#define ACL_MARK(wo, ph) do {} while (0)
+#endif
+
 // LDS-staged task list of one wave.
 struct TaskLds {
     uint32_t start[kTaskCap];  // first edge (absolute index) -- or the object id for a "self" task
@@ -127,11 +148,15 @@ struct TaskLds {
 struct WaveOutCold {  // what only the chunk switch / overflow paths need: kept in LDS, not in ~10 SGPRs for the whole kernel
     uint32_t *counts, *nchunks, *overflow;
     uint32_t nwaves, max_chunks, cap;
+#if ACL_PROFILE_PHASES
+    uint32_t last, prof[16];
+#endif
 };
 struct WaveOut {
     uint4 *buf;
     uint32_t cur, fill, produced;
     WaveOutCold *cold;  // LDS
+    uint32_t *lfill;    // LOCAL: the block's output cursor (LDS) -- the block's waves append to one region
 };
 
 // room for `need` (<= kChunk) consecutive entries; returns the first entry index
@@ -139,13 +164,14 @@ template <bool LOCAL>
 __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t lane) {
     if (wo.cur == kNoSpace) return kNoSpace;
     if (LOCAL) {
-        if (wo.fill + need > wo.cold->cap) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(wo.lfill, need);
+        base = uniform(base);
+        if (base + need > wo.cold->cap) {
             if (lane == 0) *wo.cold->overflow = 1u;
             wo.cur = kNoSpace;
             return kNoSpace;
         }
-        const uint32_t base = wo.cur + wo.fill;
-        wo.fill += need;
         wo.produced += need;
         return base;
     }
@@ -280,7 +306,7 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
 #endif
 #ifndef ACL_SIMPLE_WIDTH
-#define ACL_SIMPLE_WIDTH 2  // children per lane and step.  Same-box A/B (profiles/r02_kernel_ab.md): 2 and 3 are within 2 % of each other on the level loop; 2 keeps the single-launch kernel out of scratch
+#define ACL_SIMPLE_WIDTH 3  // children per lane and step.  Same-box A/B (profiles/r02_kernel_ab.md): 3 is 3-5 % faster than 2 on both the walk and the level loop, and fits 6 waves/SIMD
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
 // Returns a bit mask of the 64-task rounds it did NOT handle (the caller expands those the generic way): a round whose rows
@@ -327,6 +353,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
         if (mine) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl >> 6]), 1ull << (excl & 63u));
         wave_lds_fence();
         uint32_t before = 0;  // tasks that start before the current 64-item window
+        ACL_MARK(wo, PH_PROLOGUE);
         for (uint32_t w0 = 0; w0 < total; w0 += 64 * W) {
             bool valid[W];
             uint32_t tj[W], edge[W];
@@ -345,6 +372,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 edge[k] = gld(edges, t.scan[j] + wv);
             }
             issue_fence();  // trip 1: the W edges
+            ACL_MARK(wo, PH_EDGES);
             uint4 p[W], q[W];
 #pragma unroll
             for (int k = 0; k < W; k++) {
@@ -355,6 +383,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 q[k] = gld(buckets, b0 + h2);
             }
             issue_fence();  // trip 2: the 2 x W buckets
+            ACL_MARK(wo, PH_BUCKETS);
             bool hit[W], push[W];
             uint64_t pb[W];
             uint32_t pre[W], np = 0;
@@ -382,6 +411,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                             gst(out, base + pre[k] + lanes_below(pb[k]), make_uint4(edge[k] & kIdMask, t.req[tj[k]], t.meta[tj[k]] | kProbedBit, t.sid[tj[k]]));
                 }
             }
+            ACL_MARK(wo, PH_PUSH);
         }
         wave_lds_fence();
     }
@@ -667,54 +697,69 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                                                 const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
     // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
-    // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read and
-    // the row-descriptor gather are issued together (branch-free), not one after the other.
+    // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read, the
+    // row-descriptor gather and the subject's row of the child's probe are issued together (branch-free), for this segment (A)
+    // and the wave's next one (B) at once.  The slots may differ from lane to lane (level 2 of a pod check holds `namespace#view`
+    // and `group#member` states side by side): each lane reads ITS program from the LDS copy; a segment of one slot (the deep
+    // levels) reads it once, through the scalar path.
     {
         const uint64_t vb = __ballot(valid);
         if (!vb) return;
-        // the wave's NEXT segment (B) is loaded right behind this one (A): if both turn out to be simple segments of one slot they
-        // are expanded as a pair, and then their entries arrive in one trip and their gathers go out in one trip
+        // B is loaded right behind A: their entries arrive in one trip
         bool validB = false;
         uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
         const bool haveB = next.peek(eB, validB);
         issue_fence();
-        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
-        const uint32_t cs = meta_slot(m0);
-        bool simple = m0 != kDeadMeta && !__ballot(valid && (meta == kDeadMeta || !(meta & kProbedBit) || meta_slot(meta) != cs || meta_key(meta) < g.nslots));
-        SlotProg sp{};
-        FwdOp sop{};
-        if (simple) {
-            sp = progs[cs];
-            simple = sp.n_main == sp.n_probe + 1;
-            if (simple) {
-                sop = ops[sp.first + sp.n_probe];
-                simple = (sop.flags & OP_ENUM) && !(sop.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH));
+        ACL_MARK(wo, PH_ENTRIES);
+        struct LaneOp {  // the lane's one remaining op + what its tasks need to know about the child state
+            uint32_t flags, dlevel, base, nrows, Kk, key, maxd;  // Kk = K | k << 16
+            uint32_t cbase, cnrows, ckey;                        // child's hashed probe (cnrows == 0: the child is not "one hashed probe")
+        };
+        auto lane_op = [&](uint32_t m, LaneOp &L) -> bool {  // false: not a simple parent
+            if (m == kDeadMeta || !(m & kProbedBit) || meta_key(m) < g.nslots) return false;
+            const SlotProg sp = progs[meta_slot(m)];
+            if (sp.n_main != sp.n_probe + 1) return false;
+            const FwdOp o = ops[sp.first + sp.n_probe];
+            if (!(o.flags & OP_ENUM) || (o.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH))) return false;
+            L.flags = o.flags; L.dlevel = o.dlevel; L.base = o.base; L.nrows = o.nrows; L.Kk = o.K | (o.k << 16); L.key = o.key; L.maxd = sp.max_dlevel;
+            const SlotProg cp = progs[o.key];
+            L.cbase = 0; L.cnrows = 0; L.ckey = 0;
+            if (cp.n_probe == 1) {
+                const FwdOp co = ops[cp.first];
+                if (co.flags == OP_PROBE_HASH) { L.cbase = co.base; L.cnrows = co.nrows; L.ckey = co.key; }
             }
+            return true;
+        };
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)meta, (int)(__ffsll((unsigned long long)vb) - 1));
+        LaneOp LA{}, LB{};
+        bool simple;
+        const uint64_t vbB = haveB ? __ballot(validB) : 0ull;
+        const bool oneslot = !__ballot(valid && meta != m0) && !(vbB && __ballot(validB && eB.z != m0));  // (same slot, level, key: the deep levels)
+        if (oneslot) {
+            simple = lane_op(m0, LA);  // wave-uniform argument: scalar loads
+            LB = LA;
+        } else {
+            simple = !__ballot(valid && !lane_op(meta, LA));
         }
         if (simple) {
-            // The child state every task of this segment leads to: when it is "one hashed probe" (the shape flush_simple expands),
-            // the parent lane fetches the request subject's row descriptor of that probe right here -- in the same trip as its
-            // has[] byte and its own row descriptor -- and the task carries {first bucket, count}: once per parent, not per child.
-            const SlotProg ccp = progs[sop.key];
-            FwdOp cpop{};
-            bool cfast = ccp.n_probe == 1;
-            if (cfast) {
-                cpop = ops[ccp.first];
-                cfast = cpop.flags == OP_PROBE_HASH;
-            }
-            const uint2 *__restrict__ smeta = reinterpret_cast<const uint2 *>(g.meta);
-            auto subj_desc = [&](const uint4 &se, bool sv) -> uint2 {
-                const bool ok = cfast && sv && meta_key(se.z) == cpop.key && se.w < cpop.nrows;
-                const uint2 d = gld(smeta, cpop.base + (ok ? se.w : 0u));
+            bool pairB = vbB != 0;
+            if (pairB && !oneslot) pairB = !__ballot(validB && !lane_op(eB.z, LB));
+            if (pairB) next.take();
+            else validB = false;
+            const uint2 *__restrict__ meta2 = reinterpret_cast<const uint2 *>(g.meta);
+            auto subj_desc = [&](const uint4 &se, bool sv, const LaneOp &L) -> uint2 {
+                const bool ok = sv && meta_key(se.z) == L.ckey && se.w < L.cnrows;
+                const uint2 d = gld(meta2, L.cbase + (ok ? se.w : 0u));
                 return (ok && d.y > d.x) ? make_uint2(d.x, d.y - d.x) : make_uint2(0u, 1u);  // no row: the reserved empty bucket
             };
+            auto row_desc = [&](uint32_t rid, bool in, const LaneOp &L) -> uint2 { return gld(meta2, L.base + (in ? rid * (L.Kk & 0xFFFFu) + (L.Kk >> 16) : 0u)); };
             // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
-            auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, uint2 sd, bool inrow, uint32_t Tb) -> uint32_t {
+            auto seg_tasks = [&](const uint4 &se, bool sv, uint32_t hv, uint2 md, uint2 sd, bool inrow, const LaneOp &L, uint32_t Tb) -> uint32_t {
                 const bool act = sv && !hv;
-                const uint32_t lv = meta_level(se.z), L = lv + sop.dlevel;
-                bool derr = act && lv + sp.max_dlevel > kMaxLevels, want = false;
-                if (act && L <= kMaxLevels && inrow && md.y > md.x) {
-                    if (L + 1 > kMaxLevels) derr = true;
+                const uint32_t lv = meta_level(se.z), Lv = lv + L.dlevel;
+                bool derr = act && lv + L.maxd > kMaxLevels, want = false;
+                if (act && Lv <= kMaxLevels && inrow && md.y > md.x) {
+                    if (Lv + 1 > kMaxLevels) derr = true;
                     else if (md.y - md.x > kMaxRow) *wo.cold->overflow = 2u;
                     else want = true;
                 }
@@ -723,42 +768,35 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 if (want) {
                     const uint32_t q = Tb + lanes_below(b);
                     t.start[q] = md.x;
-                    t.count[q] = (md.y - md.x) | ((sop.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
+                    t.count[q] = (md.y - md.x) | ((L.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
                     t.req[q] = se.y;
-                    t.meta[q] = make_meta(sop.key, L + 1, meta_key(se.z));
+                    t.meta[q] = make_meta(L.key, Lv + 1, meta_key(se.z));
                     t.sid[q] = se.w;
                     t.b0[q] = sd.x;
                     t.nb[q] = sd.y;
                 }
                 return (uint32_t)__popcll(b);
             };
-            auto row_desc = [&](uint32_t rid) -> uint2 {
-                if (sop.K == 2) {
-                    const uint4 v = gld(reinterpret_cast<const uint4 *>(g.meta), (sop.base >> 1) + rid);
-                    return sop.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
-                }
-                return gld(reinterpret_cast<const uint2 *>(g.meta), sop.base + rid * sop.K + sop.k);
-            };
-            // B joins when it is a simple segment of the same slot; then all six gathers are in flight together
-            const bool pairB = haveB && !__ballot(validB && (eB.z == kDeadMeta || !(eB.z & kProbedBit) || meta_slot(eB.z) != cs || meta_key(eB.z) < g.nslots));
-            if (pairB) next.take();
-            else validB = false;
+            // all six gathers in flight together
             const uint32_t hvA = gld(has, valid ? req : 0u);
-            const bool inA = valid && id < sop.nrows;
-            const uint2 mdA = row_desc(inA ? id : 0u);
-            const uint2 sdA = subj_desc(e, valid);
+            const bool inA = valid && id < LA.nrows;
+            const uint2 mdA = row_desc(id, inA, LA);
+            const uint2 sdA = subj_desc(e, valid, LA);
             uint32_t hvB = 0;
             uint2 mdB = make_uint2(0, 0), sdB = make_uint2(0, 1);
-            const bool inB = validB && eB.x < sop.nrows;
+            const bool inB = validB && eB.x < LB.nrows;
             if (pairB) {
                 hvB = gld(has, validB ? eB.y : 0u);
-                mdB = row_desc(inB ? eB.x : 0u);
-                sdB = subj_desc(eB, validB);
+                mdB = row_desc(eB.x, inB, LB);
+                sdB = subj_desc(eB, validB, LB);
             }
             issue_fence();
-            uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, 0u);
-            if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, T);
+            ACL_MARK(wo, PH_GATHERS);
+            uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, LA, 0u);
+            if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, LB, T);
+            ACL_MARK(wo, PH_TASKS);
             if (T) flush_tasks<true, SHARDED, LOCAL, true>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            ACL_MARK(wo, PH_PUSH);
             return;
         }
     }
@@ -864,6 +902,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         }
         if (!more) break;
     }
+    ACL_MARK(wo, PH_GENERIC);
 }
 
 // the program table (a few hundred bytes for real schemas) is copied into LDS when it fits
@@ -989,33 +1028,42 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
 // level-synchronous path.  Same segment processor, same decisions.
 struct LocalWalk {
     const uint4 *__restrict__ in;
-    uint32_t n, s, lane;  // entries in the input region, current segment
+    uint32_t n, s, lane;  // entries in the input region; the segment being processed (segments are claimed in pairs: s even)
+    bool second;          // the pair's second segment is still to be taken
     __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
-        if ((s + 1) * 64 >= n) return false;
+        if (!second || (s + 1) * 64 >= n) return false;
         valid = (s + 1) * 64 + lane < n;
         e = in[valid ? (s + 1) * 64 + lane : (s + 1) * 64];  // unconditional, like ChunkWalk::load
         return true;
     }
-    __device__ __forceinline__ void take() { s++; }
+    __device__ __forceinline__ void take() { second = false; }
 };
 struct NoNext {
     __device__ __forceinline__ bool peek(uint4 &, bool &) const { return false; }
     __device__ __forceinline__ void take() {}
 };
 
-// Work = units of `rpw` consecutive requests.  Wave w takes units w, w + nwaves, ... -- statically: handing units out through one
-// atomic counter cost ~12 ns per unit in same-address contention (C2, 65 536 items: 137 us with two units per wave against
-// 20 us with one; profiles/r02_walk_units_per_wave.txt), which is more than dynamic balance ever gave back (3 % on C4).
+// Work = units of `rpw` (<= 256) consecutive requests, one unit per BLOCK at a time (block b takes units b, b + nblocks, ...).
+// The block's four waves walk the unit together, level by level, inside the block's private frontier region: a level's
+// segments are claimed pair by pair through an LDS counter, children are appended through an LDS cursor, and one block
+// barrier separates the levels.  Sharing a unit between four waves is what keeps the launch's tail short: requests differ
+// 100-fold in work (a first-level hit against a full five-level miss), and a wave that walked its own 43 requests alone
+// finished anywhere between 0.5x and 1.6x the mean -- a third of the wave-time was idle waiting for the slowest
+// (profiles/r02_pmc_walk.txt); a unit of 4 x 43 requests varies half as much, and inside it the work is shared per level.
+// Block b starts on unit b; further units (batches beyond 256 requests per resident block, or `upw` > 1) are handed out through
+// `next_unit`, one atomic per BLOCK-unit -- per wave-unit the same counter cost ~12 ns per unit in same-address contention
+// (profiles/r02_walk_units_per_wave.txt).
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
 #define ACL_LOCAL_WAVES_PER_SIMD 6
 #endif
 template <bool LDSPROG>
 __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
-                                                                                uint32_t nunits, uint4 *buf0, uint4 *buf1, uint32_t cap,
-                                                                                uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
-                                                                                int32_t *err_out) {
+                                                                                  uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap,
+                                                                                  uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
+                                                                                  int32_t *err_out) {
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
+    __shared__ uint32_t s_fill, s_next, s_stop, s_unit;
     __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
     const SlotProg *progs;
     const FwdOp *ops;
@@ -1023,17 +1071,34 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
     const uint32_t lane = lane_id();
     const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
-    const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = gridDim.x * kWavesPerBlock;
     const DevShard nosh{};
-    uint4 *bufs[2] = {buf0 + (size_t)wave * cap, buf1 + (size_t)wave * cap};
-    if (lane == 0) s_cold[wib] = WaveOutCold{nullptr, nullptr, overflow, 0u, 0u, cap};
-    wave_lds_fence();
-    for (uint32_t unit = uniform(wave); unit < nunits; unit += nwaves) {
+    uint4 *bufs[2] = {buf0 + (size_t)blockIdx.x * cap, buf1 + (size_t)blockIdx.x * cap};
+    if (lane == 0) {
+        s_cold[wib] = WaveOutCold{};
+        s_cold[wib].overflow = overflow;
+        s_cold[wib].cap = cap;
+#if ACL_PROFILE_PHASES
+        s_cold[wib].last = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+    }
+    if (threadIdx.x == 0) s_stop = 0;
+    WaveOut wo;
+    wo.cur = 0;
+    wo.fill = 0;
+    wo.produced = 0;
+    wo.cold = &s_cold[wib];
+    wo.lfill = &s_fill;
+    for (uint32_t unit = blockIdx.x; unit < nunits;) {
         const uint32_t first = unit * rpw;
-        const uint32_t mine = min(rpw, n - first);
-        // ---- seeds (k_seed's validation), in registers
-        const bool valid = lane < mine;
-        const uint32_t req = first + lane;
+        const uint32_t mine = min(rpw, n - first);  // <= 256: thread i seeds and answers request first + i
+        if (threadIdx.x == 0) {
+            s_fill = 0;
+            s_next = 0;
+        }
+        __syncthreads();
+        // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit
+        const bool valid = threadIdx.x < mine;
+        const uint32_t req = first + threadIdx.x;
         uint4 e = make_uint4(0, 0, kDeadMeta, 0);
         if (valid) {
             const uint4 it = gld(items, req);
@@ -1048,54 +1113,62 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
             e = make_uint4(it.y, req, meta, it.w);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        WaveOut wo;
         wo.buf = bufs[0];
         wo.cur = 0;
-        wo.fill = 0;
-        wo.produced = 0;
-        wo.cold = &s_cold[wib];
+        ACL_MARK(wo, PH_SEED);
         {
             NoNext nn;
             process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
         }
         uint32_t parity = 0;
         for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
-            if (wo.cur == kNoSpace) break;  // overflow: the host redoes the batch
-            const uint32_t cnt = wo.fill;
-            if (!cnt) break;
-            // the wave's own stores of this level must be visible to its own loads of the next
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            LocalWalk lw{bufs[parity], cnt, 0u, lane};
+            // ---- level boundary: everybody's children are written, the cursors turn over
+            if (wo.cur == kNoSpace && lane == 0) s_stop = 1;  // overflow: the host redoes the batch
+            __syncthreads();
+            const uint32_t cnt = s_fill;
+            const bool stop = s_stop != 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                s_fill = 0;
+                s_next = 0;
+            }
+            __syncthreads();
+            ACL_MARK(wo, PH_BARRIER);
+            if (stop || !cnt) break;
+            LocalWalk lw{bufs[parity], cnt, 0u, lane, false};
             parity ^= 1u;
             wo.buf = bufs[parity];
-            wo.cur = 0;
-            wo.fill = 0;
-            for (; lw.s * 64 < cnt; lw.s++) {
-                const bool v = lw.s * 64 + lane < cnt;
-                const uint4 en = lw.in[v ? lw.s * 64 + lane : lw.s * 64];  // unconditional; process_segment masks by `v`
-                process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+            for (;;) {
+                uint32_t sg = 0;
+                if (lane == 0) sg = atomicAdd(&s_next, 2u);
+                sg = uniform(sg);
+                if (sg * 64 >= cnt) break;
+                for (lw.s = sg, lw.second = true; lw.s < sg + 2 && lw.s * 64 < cnt; lw.s++) {
+                    if (lw.s > sg && !lw.second) break;  // the pair's second segment went with the first
+                    const bool v = lw.s * 64 + lane < cnt;
+                    const uint4 en = lw.in[v ? lw.s * 64 + lane : lw.s * 64];  // unconditional; process_segment masks by `v`
+                    if (lw.s > sg) lw.second = false;
+                    process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+                }
             }
         }
-        // ---- answers (k_finalize)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        {
-            // (request index and validity are re-derived from the unit number: two VGPRs that would otherwise live across the whole walk)
-            uint32_t u2 = uniform(unit);
-            asm volatile("" : "+s"(u2));
-            const uint32_t first2 = u2 * rpw, rq = first2 + lane;
-            if (lane < min(rpw, n - first2)) {
-                const bool h = __hip_atomic_load(has + rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                perm_out[rq] = h ? 2 : (er ? 0 : 1);
-                if (err_out) err_out[rq] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
-            }
+        // ---- answers (k_finalize): every wave's has[] / err[] stores are behind a block barrier
+        __syncthreads();
+        if (valid) {
+            const bool h = __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            perm_out[req] = h ? 2 : (er ? 0 : 1);
+            if (err_out) err_out[req] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
         }
-        if (wo.cur == kNoSpace) break;
+        if (s_stop || !next_unit) break;
+        if (threadIdx.x == 0) s_unit = gridDim.x + atomicAdd(next_unit, 1u);
+        __syncthreads();
+        unit = s_unit;
     }
+#if ACL_PROFILE_PHASES
+    ACL_MARK(wo, PH_OTHER);
+    if (lane < PH_COUNT) atomicAdd(&acl_phase_cycles[lane], (unsigned long long)s_cold[wib].prof[lane]);
+#endif
 }
 
 // Merges identical pending sub-checks of one level: two frontier entries with the same (request, state, level) have identical
@@ -1409,6 +1482,24 @@ __global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t
 
 }  // namespace
 
+#if ACL_PROFILE_PHASES
+}  // namespace acl
+extern "C" int acl_debug_phase_cycles(unsigned long long *out16) {  // variant builds only (tools/phases.sh): reads and resets the counters
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(acl::acl_phase_cycles), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(acl::acl_phase_cycles), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+namespace acl {
+#endif
+// A/B knob: ACL_PROG_LDS=0 runs the instantiations that read the program table from global memory (8 KiB less LDS per block)
+static bool prog_in_lds() {
+    static const bool on = [] {
+        const char *e = getenv("ACL_PROG_LDS");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 int expand_grid_blocks(int device) {
     hipDeviceProp_t prop;
     int cus = 256;
@@ -1416,7 +1507,9 @@ int expand_grid_blocks(int device) {
     int per_cu = 8;  // 256-thread blocks, <= 64 VGPRs, ~20 KiB LDS
     if (const char *e = getenv("ACL_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // A/B knob (tools/ab.sh)
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 0) == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
+    const hipError_t oe = prog_in_lds() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<false, false>, kBlock, 0);
+    if (oe == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
     return cus * per_cu;
 }
 
@@ -1426,7 +1519,7 @@ void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const u
 }
 void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const dim3 grid(f.nwaves / kWavesPerBlock);
-    const bool lds = g.nslots + g.nops <= kProgLdsEntries;
+    const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
     if (sh.world > 1) {
         if (lds) hipLaunchKernelGGL((k_expand<true, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
@@ -1435,21 +1528,23 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
 }
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint4 *buf0, uint4 *buf1,
-                        uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     const uint32_t nunits = (n + rpw - 1) / rpw;
     const dim3 grid(nblocks);
-    if (g.nslots + g.nops <= kProgLdsEntries)
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+    if (g.nslots + g.nops <= kProgLdsEntries && prog_in_lds())
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
     else
-        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
 }
 int local_grid_blocks(int device) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, 0) != hipSuccess || occ <= 0) occ = 4;
+    const hipError_t oe = prog_in_lds() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, 0)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false>, kBlock, 0);
+    if (oe != hipSuccess || occ <= 0) occ = 4;
     return cus * occ;
 }
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {

@@ -84,10 +84,10 @@ void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier 
 void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n);
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key);
 void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out);
-// single-launch Check: units of rpw consecutive requests; wave w (of nblocks * 4) walks units w, w + nwaves, ... through every level
-// with a private frontier of `cap` entries in each of buf0 / buf1 (regions w * cap); *overflow != 0 afterwards: redo on the level loop
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint4 *buf0, uint4 *buf1,
-                        uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
+// single-launch Check: units of rpw (<= 256) consecutive requests; block b (of nblocks) walks units b, b + nblocks, ... through every
+// level with a private frontier of `cap` entries in each of buf0 / buf1 (regions b * cap); next_unit: zeroed device counter, needed when there are more units than blocks; *overflow != 0 afterwards: redo on the level loop
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
 // blocks of the single-launch kernel that are resident at once on this device
 int local_grid_blocks(int device);
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)

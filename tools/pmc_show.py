@@ -2,7 +2,7 @@
 """print per-launch PMC values of the last N k_expand launches from a rocprofv3 rocpd db"""
 import sqlite3, sys, collections
 db, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 7
-kern = sys.argv[3] if len(sys.argv) > 3 else "k_expand"
+kern = sys.argv[3] if len(sys.argv) > 3 else "k_"
 con = sqlite3.connect(db)
 rows = con.execute(f"select dispatch_id, counter_name, value, duration from counters_collection where kernel_name like '%{kern}%' order by dispatch_id").fetchall()
 by = collections.OrderedDict()
