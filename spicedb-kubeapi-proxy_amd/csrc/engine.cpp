@@ -248,6 +248,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     if (!rev_ok) h->snap.has_reverse = false;
     h->snap_valid = true;
     h->dev_valid = true;
+    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_compactions++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -327,6 +328,7 @@ int ensure_snapshot(acl_engine *h) {
     HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->dev_valid = true;
+    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);  // (the single-launch kernel's LDS depends on the schema)
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -934,7 +936,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
-    h->local_blocks = local_grid_blocks(dev);
+    h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
     if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;

@@ -48,7 +48,7 @@ namespace {
 #define ACL_KEEP(x) asm volatile("" ::"v"(x))
 constexpr int kBlock = kWavesPerBlock * 64;
 #ifndef ACL_MIN_WAVES_PER_SIMD
-#define ACL_MIN_WAVES_PER_SIMD 5  // 84 VGPRs: the multi-child fast path (flush_simple) needs them; spilling at 8 waves/SIMD costs more than the waves give
+#define ACL_MIN_WAVES_PER_SIMD 6  // (k_expand, k_rev_expand; the single-launch kernel has its own bound below)
 #endif
 constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kHeadWords = 32;  // flush_simple maps work items to tasks through head bits: rounds of <= 64 * kHeadWords children
@@ -306,7 +306,7 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
 #endif
 #ifndef ACL_SIMPLE_WIDTH
-#define ACL_SIMPLE_WIDTH 3  // children per lane and step.  Same-box A/B (profiles/r02_kernel_ab.md): 3 is 3-5 % faster than 2 on both the walk and the level loop, and fits 6 waves/SIMD
+#define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
 // Returns a bit mask of the 64-task rounds it did NOT handle (the caller expands those the generic way): a round whose rows
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
     __shared__ uint32_t s_slots[kWavesPerBlock][128];
-    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
+    extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
     load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
@@ -1054,7 +1054,7 @@ struct NoNext {
 // `next_unit`, one atomic per BLOCK-unit -- per wave-unit the same counter cost ~12 ns per unit in same-address contention
 // (profiles/r02_walk_units_per_wave.txt).
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
-#define ACL_LOCAL_WAVES_PER_SIMD 6
+#define ACL_LOCAL_WAVES_PER_SIMD 8
 #endif
 template <bool LDSPROG>
 __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
     __shared__ uint32_t s_fill, s_next, s_stop, s_unit;
-    __shared__ uint4 s_prog[LDSPROG ? kProgLdsEntries * 2 : 1];
+    extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
     load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
@@ -1491,6 +1491,7 @@ extern "C" int acl_debug_phase_cycles(unsigned long long *out16) {  // variant b
 }
 namespace acl {
 #endif
+static size_t prog_lds_bytes(const DevGraph &g) { return ((size_t)g.nslots + g.nops) * 32; }
 // A/B knob: ACL_PROG_LDS=0 runs the instantiations that read the program table from global memory (8 KiB less LDS per block)
 static bool prog_in_lds() {
     static const bool on = [] {
@@ -1507,7 +1508,8 @@ int expand_grid_blocks(int device) {
     int per_cu = 8;  // 256-thread blocks, <= 64 VGPRs, ~20 KiB LDS
     if (const char *e = getenv("ACL_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;  // A/B knob (tools/ab.sh)
     int occ = 0;
-    const hipError_t oe = prog_in_lds() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 0)
+    // (the program table's LDS copy is dynamic; 2 KiB covers schemas of ~60 slots + ops -- a larger one only means some blocks of a launch queue)
+    const hipError_t oe = prog_in_lds() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<true, false>, kBlock, 2048)
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_expand<false, false>, kBlock, 0);
     if (oe == hipSuccess && occ > 0) per_cu = occ < per_cu ? occ : per_cu;
     return cus * per_cu;
@@ -1521,10 +1523,10 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
     const dim3 grid(f.nwaves / kWavesPerBlock);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
     if (sh.world > 1) {
-        if (lds) hipLaunchKernelGGL((k_expand<true, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+        if (lds) hipLaunchKernelGGL((k_expand<true, true>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     } else {
-        if (lds) hipLaunchKernelGGL((k_expand<true, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+        if (lds) hipLaunchKernelGGL((k_expand<true, false>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
 }
@@ -1533,17 +1535,18 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
     const uint32_t nunits = (n + rpw - 1) / rpw;
     const dim3 grid(nblocks);
     if (g.nslots + g.nops <= kProgLdsEntries && prog_in_lds())
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), prog_lds_bytes(g), s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
     else
         hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
 }
-int local_grid_blocks(int device) {
+int local_grid_blocks(int device, size_t prog_bytes) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     int occ = 0;
-    const hipError_t oe = prog_in_lds() ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, 0)
-                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false>, kBlock, 0);
+    const bool lds = prog_in_lds() && prog_bytes <= (size_t)kProgLdsEntries * 32;
+    const hipError_t oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, prog_bytes)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false>, kBlock, 0);
     if (oe != hipSuccess || occ <= 0) occ = 4;
     return cus * occ;
 }

@@ -89,7 +89,7 @@ void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, cons
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
                         uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
 // blocks of the single-launch kernel that are resident at once on this device
-int local_grid_blocks(int device);
+int local_grid_blocks(int device, size_t prog_bytes);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits);
 constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key holds 14 request bits)

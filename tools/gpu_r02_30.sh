@@ -1,0 +1,11 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+O=$R/gpurun_out
+for SET in "tcp:TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_PENDING_STALL_CYCLES_sum" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "grbm:GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  N=${SET%%:*}; C=${SET#*:}
+  PMC_TIMEOUT=60 bash tools/pmc.sh r02_pmc_walk3/$N "$C" > /dev/null 2>&1
+  DB=$(ls $O/prof/r02_pmc_walk3/$N/*.db 2>/dev/null | head -1)
+  echo "== $N: $C"
+  if [ -n "$DB" ]; then python tools/pmc_show.py $DB 4; else tail -3 $O/prof/r02_pmc_walk3/$N/run.log; fi
+done 2>&1 | tee $O/r02_30_pmc_walk3.txt
