@@ -52,7 +52,7 @@ int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index) {
     HIP_TRY(c->d_status.ensure(kStatusWords));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
     int rc = alloc_frontier(h, c.get(),
-                            h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(16u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));
+                            h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(32u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));  // 2 x 512 MiB: the single-launch walk carves its blocks' private regions out of these
     if (rc) return rc;
     *out = std::move(c);
     return ACL_OK;

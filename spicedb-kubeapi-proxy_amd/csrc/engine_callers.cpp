@@ -164,9 +164,11 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
         if (B.wait_us && B.in_flight.load(std::memory_order_relaxed) == 0 && B.pending.load(std::memory_order_relaxed) < B.max_items) {
             const int64_t first = B.oldest_ns.load(std::memory_order_relaxed);
             const int64_t until = (first ? first : mono_ns()) + (int64_t)B.wait_us * 1000;
-            bool stale = false;  // another dispatcher swept the requests this window was opened for: whatever is queued now has a window of its own
+            bool stale = false;  // another dispatcher swept everything this window was opened for
             while (!B.stop.load(std::memory_order_relaxed) && B.pending.load(std::memory_order_relaxed) < B.max_items) {
-                if (B.pending.load(std::memory_order_relaxed) == 0 || B.oldest_ns.load(std::memory_order_relaxed) != first) {
+                // (requests that arrived after such a sweep are NOT made to wait for a window of their own: wait_us is an upper bound
+                //  on the wait, and going early costs nothing -- a second full window did cost 64 callers 40 % of their throughput)
+                if (B.pending.load(std::memory_order_relaxed) == 0) {
                     stale = true;
                     break;
                 }

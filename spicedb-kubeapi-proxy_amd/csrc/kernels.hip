@@ -1,37 +1,29 @@
 // kernels.hip -- gfx950 (CDNA4) frontier-expansion kernels of the batched ACL-check engine.
 //
-// What they replace: the per-item recursive dispatch SpiceDB runs for
-// CheckBulkPermissions (reached from reference pkg/authz/check.go:48 and
-// pkg/authz/postfilter.go:134) and the reverse walk behind LookupResources
-// (pkg/authz/lookups.go:65).  Here a whole request batch advances together, one
-// dispatch level per launch:
+// What they replace: the per-item recursive dispatch SpiceDB runs for CheckBulkPermissions (reached from reference
+// pkg/authz/check.go:48 and pkg/authz/postfilter.go:134) and the reverse walk behind LookupResources (pkg/authz/lookups.go:65).
+// A pending sub-check is a 16-byte frontier entry (object id, request, slot | level | flags, subject id); a SEGMENT is 64 of them,
+// one per lane.  process_segment() advances a segment by one dispatch level:
+//   - every lane interprets its state's flattened program (plan.hpp, cached in LDS): probes of the request's subject in hashed rows
+//     (two-choice placement over 4-slot buckets: two independent 16 B gathers, never a probing chain) or sorted rows (binary
+//     search), and "enumerate" operations whose child states are produced by a wave-cooperative, load-balanced expansion:
+//       - per-lane tasks (row start, degree, the subject's hashed row) are compacted into LDS with wave64 ballot + mbcnt,
+//       - a DPP prefix sum over task degrees sizes the work, and every task marks its first work item with a head bit,
+//       - lanes take consecutive work items, find their task from the head bits (two v_mbcnt) and load consecutive edges of a row,
+//       - each child's own probes are evaluated RIGHT THERE; only children that still have something to enumerate are written,
+//         compacted with a second ballot, as consecutive entries.  Leaf states never enter the frontier.
+//   - where a segment is uniform enough the interpreter is bypassed: already-probed single-op parents (the deep levels) fetch has[],
+//     their row descriptor and the subject's row of the child's probe in ONE trip, two segments at a time; flush_simple expands
+//     their tasks kSimpleWidth children per lane and step; flush_probes handles arrow-target states.
+//   Loads are pinned into trips (issue_fence): all loads of a trip are issued before the first of them is waited for.
+// Two drivers call it:
+//   k_check_local  ONE launch per batch: a block walks its share of the requests through every level inside a block-private
+//                  frontier region (LDS cursors, one barrier per level).  The default for every batch size.
+//   k_expand       one launch per level over a chunked global frontier (every wave owns one static 16 KiB chunk per level, further
+//                  chunks from one atomicAdd per 1024 entries): the sharded graph, and batches that outgrow the private regions.
+// k_rev_expand is the reverse walk (LookupResources); k_dedup merges duplicate entries of a level when a frontier explodes.
 //
-//   frontier entry = (request, object#relation state)                16 B
-//   k_expand: every lane takes one entry and interprets the state's flattened
-//             program (plan.hpp, cached in LDS): probes of the request's subject in
-//             hashed rows (two-choice placement over 4-slot buckets: two independent
-//             16 B gathers, never a probing chain) or sorted rows (binary search), and
-//             "enumerate" operations whose child states are produced by
-//             a wave-cooperative, load-balanced expansion:
-//               - per-lane tasks (row start, degree) are compacted into LDS with
-//                 wave64 ballot + mbcnt,
-//               - a wave prefix-sum over task degrees sizes the work,
-//               - lanes then take consecutive work items, find their task by binary
-//                 search in the LDS prefix array and load consecutive edges of a row
-//                 (coalesced),
-//               - each child's own probes are evaluated RIGHT THERE (child mode); only
-//                 children that still have something to enumerate are written, compacted
-//                 with a second ballot, as consecutive 16 B entries (coalesced).  Leaf
-//                 states therefore never enter the frontier.
-//   Where the frontier is uniform (deep levels) the interpreter is bypassed: flush_simple evaluates three
-//   children per lane per step with branch-free loads, flush_probes handles arrow-target states, and
-//   segments of already-probed single-op parents fetch has[] and the row descriptor together, two
-//   segments per step.  Same entries, same order as the generic path.
-//   Output space: every wave owns one static 16 KiB chunk per level (no allocation at
-//   all for the common case); further chunks come from one atomicAdd per 1024 entries.
-//
-// Bound: the vector L1's tag-lookup rate and per-level latency chains of divergent 4-16 B gathers (DESIGN.md 4,
-// profiles/r01_c4_bottleneck_analysis.md); no MFMA anywhere by design.
+// Bound (profiles/r02_*): instruction issue and the vector L1, not HBM -- no MFMA anywhere by design.
 #include <algorithm>
 #include <cstdlib>
 
