@@ -292,11 +292,37 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
     G = world if world > 1 else args.logical_shards
 
     modes = ["allgather", "alltoall"] if args.exchange == "both" else [args.exchange]
+    if args.native_loop == "on":
+        modes = modes + ["native"]  # last: whatever it does on a real communicator, the host-driven forms' numbers are already out
 
     def run(se, comm_barrier, after_mode=None):
         d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
         res_by_mode = {}
         for mode in modes:
+            if mode == "native":  # the whole level loop inside libaclgpu.so (acl_shard_check_bulk[_rccl]): one fixed-capacity all-gather per level
+                try:
+                    nstat = {}
+                    for _ in range(2):
+                        p, e, nstat = se.check_bulk_ids_native(d_items)
+                    comm_barrier()
+                    t0 = time.perf_counter()
+                    lat = []
+                    for _ in range(steps):
+                        t1 = time.perf_counter()
+                        p, e, nstat = se.check_bulk_ids_native(d_items)
+                        lat.append(time.perf_counter() - t1)
+                    comm_barrier()
+                    el = time.perf_counter() - t0
+                    mism = int((p.cpu().numpy() != want_p).sum() + (e.cpu().numpy() != want_e).sum())
+                    res_by_mode[mode] = {"elapsed": el, "lat": lat, "mismatches": mism, "levels": nstat.get("levels"),
+                                         "recv_entries_per_batch": nstat.get("entries_exchanged"), "exchanges_per_batch": nstat.get("exchanges"),
+                                         "host_syncs_per_batch": nstat.get("host_syncs")}
+                except Exception as ex:  # noqa: BLE001
+                    res_by_mode[mode] = {"elapsed": float("inf"), "lat": [0.0], "mismatches": 0, "levels": None, "recv_entries_per_batch": None,
+                                         "exchanges_per_batch": None, "error": f"{type(ex).__name__}: {ex}"}
+                if after_mode:
+                    after_mode(mode, res_by_mode[mode])
+                continue
             se.exchange = mode
             se._alloc(max(se.cap, 1 << 20))
             p = e = None
@@ -327,14 +353,20 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
     def mode_done(mode, ms):  # ms: every rank's record of one exchange form (filled in as soon as that form has run)
         el = max(m["elapsed"] for m in ms)
         if True:
+            if any(m.get("error") for m in ms):
+                result[mode] = {"error": next(m["error"] for m in ms if m.get("error"))}
+                return
             result[mode] = {"collective": "all_gather_into_tensor of every export buffer, each rank keeps what it owns" if mode == "allgather"
-                            else "exports grouped by owner on the device, batch_isend_irecv (grouped send/recv) to the owners only",
+                            else "exports grouped by owner on the device, batch_isend_irecv (grouped send/recv) to the owners only" if mode == "alltoall"
+                            else "level loop inside libaclgpu.so: ONE fixed-capacity all-gather per level ([header | entries] per shard), decisions on the device, "
+                                 "one host sync per burst of levels (ncclAllGather / ncclAllReduce from the library when world > 1)",
                             "decisions_per_s": n * steps / el, "ms_per_batch": 1e3 * el / steps, "p50_batch_ms": 1e3 * float(np.median(ms[0]["lat"])),
                             "levels": ms[0]["levels"], "exchanges_per_batch": ms[0]["exchanges_per_batch"],
                             "recv_entries_per_batch_by_shard": [m["recv_entries_per_batch"] for m in ms],
                             "mismatches_vs_replica": int(sum(m["mismatches"] for m in ms))}
-        result["decisions_per_s"] = result[modes[0]]["decisions_per_s"]
-        result["mismatches_vs_replica"] = int(sum(result[m]["mismatches_vs_replica"] for m in modes if m in result))
+        if "decisions_per_s" in result.get(modes[0], {}):
+            result["decisions_per_s"] = result[modes[0]]["decisions_per_s"]
+        result["mismatches_vs_replica"] = int(sum(result[m].get("mismatches_vs_replica", 0) for m in modes if m in result))
 
     def done(outs):
         result["shard_relationships"] = [o["shard_relationships"] for o in outs]
@@ -624,6 +656,7 @@ def main():
     ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
+    ap.add_argument("--native-loop", default="on", choices=["on", "off"], help="sharded leg: also time the level loop inside libaclgpu.so (acl_shard_check_bulk)")
     ap.add_argument("--pipeline", default="blocking", choices=["blocking", "submit"], help="how the timed host-id leg keeps batches in flight")
     ap.add_argument("--callers", type=int, default=2, help="--pipeline blocking: host threads issuing blocking acl_check_bulk_ids calls")
     ap.add_argument("--window", type=int, default=2, help="--pipeline submit: batches in flight (<= the engine's evaluation contexts)")
