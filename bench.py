@@ -9,9 +9,10 @@ BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
                     batches in pinned host memory, issued by `--callers` (default 2) host threads that each block in
                     acl_check_bulk_ids -- what goroutines behind the cgo shim do -- so that the copies of one batch overlap
                     the kernels of another (the engine's evaluation contexts, one HIP stream each; chip-filling batches'
-                    kernels take turns).  `--pipeline submit` times acl_check_bulk_ids_submit / acl_ticket_wait from one
-                    thread instead.  Measured (profiles/r02_hostid_modes.txt): 1 caller 374 M/s, 2 callers 444 M/s,
-                    3 callers 442 M/s, submit window 2 271 M/s; kernels alone (device_resident) 416 M/s.
+                    kernels follow each other on the device: each waits for the previous one's event).  `--pipeline submit`
+                    times acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead.  Measured
+                    (profiles/r02_hostid_modes_chained.txt): 1 caller 570 M/s, 2 callers 750 M/s, 3 callers 745 M/s
+                    (4: 306 M/s -- keep it at 2-3); kernels alone (device_resident) 770 M/s.
   device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
                     per-launch kernel time comes from HIP events in THIS leg (pipelined launches overlap each other)
   latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")

@@ -26,6 +26,7 @@ PassCtx::~PassCtx() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     if (h_status) (void)hipHostFree(h_status);
+    if (chain_ev) (void)hipEventDestroy(chain_ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -49,6 +50,7 @@ int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index) {
     auto c = std::make_unique<PassCtx>();
     c->index = index;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->chain_ev, hipEventDisableTiming));
     HIP_TRY(c->d_status.ensure(kStatusWords));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
     int rc = alloc_frontier(h, c.get(),
@@ -463,7 +465,8 @@ static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     return G;
 }
 
-int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+// enqueue-only half (memset of the flag, the launch, the flag's read-back): what check_ids_host chains on the device
+static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
     uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
@@ -473,6 +476,10 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
                        c->d_err.p, d_perm, d_errout);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    return ACL_OK;
+}
+static int local_finish(acl_engine *h, PassCtx *c, uint32_t n) {
+    (void)h;
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
@@ -481,6 +488,10 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
     c->stats.check_passes++;
     c->stats.local_passes++;
     return ACL_OK;
+}
+int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+    const int rc = local_enqueue(h, c, g, d_items, n, d_perm, d_errout);
+    return rc ? rc : local_finish(h, c, n);
 }
 
 // The same for a batch in HOST memory, with no copy engine in the path: the kernel reads the items from pinned host memory
@@ -569,15 +580,15 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4
 }
 
 // one device pass over n (<= max_sub_batch) interned items already in HBM
-int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local) {
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     DevGraph g = h->dev_graph();
     // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
     // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
-    if (n <= h->local_max_items) {
+    if (try_local && n <= h->local_max_items) {
         int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
-        if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a wave ran out of private frontier, the level-synchronous path takes the batch
+        if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a block ran out of private frontier, the level-synchronous path takes the batch
     }
     int rc = levels_pass(h, c, g, d_items, n, d_perm, d_errout, false);
     if (rc != kRetryMerging) return rc;
@@ -598,12 +609,12 @@ int not_sharded(acl_engine *h) {
     return ACL_OK;
 }
 
-int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout) {
+int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local) {
     int rc = not_sharded(h);
     if (rc) return rc;
     for (size_t b = 0; b < n; b += h->max_sub_batch) {
         uint32_t m = (uint32_t)std::min<size_t>(h->max_sub_batch, n - b);
-        rc = check_pass(h, c, d_items + b, m, d_perm + b, d_errout ? d_errout + b : nullptr);
+        rc = check_pass(h, c, d_items + b, m, d_perm + b, d_errout ? d_errout + b : nullptr, try_local);
         if (rc) return rc;
     }
     return ACL_OK;
@@ -628,15 +639,49 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         src = c->h_in.p;
     }
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
-    int rc;
+    int rc = kTakeLevelLoop;
     if (n >= kComputeTokenItems) {
         // A batch this size fills every wave slot of the chip by itself: two such batches' kernels running at once only
         // take turns (measured: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
-        // copies with ANOTHER batch's kernels: the H2D above is already under way when we queue for the compute token,
-        // and the D2H below runs after it is handed on.
-        HIP_TRY(hipStreamSynchronize(c->stream));  // items are on the device before the kernels' turn starts
-        std::lock_guard<std::mutex> tk(h->compute_mu);
-        rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);  // (ends with the context's stream synchronised)
+        // copies with ANOTHER batch's kernel -- and the kernels themselves should follow each other without a gap.  So the
+        // turn-taking happens ON THE DEVICE: this context's stream waits for the event the previous batch's kernel recorded,
+        // the single-launch kernel is enqueued behind it (the H2D above is already under way and is not held up), and its
+        // own event becomes the one the next caller waits for.  No host thread waits for another one: a mutex around
+        // "launch + synchronise" left the chip idle for a wake-up and a launch (~10 % of a C4 batch) between two kernels.
+        // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
+        //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
+        if (n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1) {
+            HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+            HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+            {
+                // at most three chained passes in flight: the runtime multiplexes streams onto 4 hardware queues, and a fourth waiter
+                // halves the throughput of all of them (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3)
+                std::unique_lock<std::mutex> ck(h->chain_mu);
+                h->chain_cv.wait(ck, [&] { return h->chain_inflight < 3; });
+                h->chain_inflight++;
+                hipError_t he = h->chain_prev ? hipStreamWaitEvent(c->stream, h->chain_prev, 0) : hipSuccess;
+                rc = he == hipSuccess ? local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p)
+                                      : fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
+                if (!rc) {
+                    he = hipEventRecord(c->chain_ev, c->stream);
+                    if (he == hipSuccess) h->chain_prev = c->chain_ev;
+                    else rc = fail(ACL_ERR_INTERNAL, std::string("hipEventRecord: ") + hipGetErrorString(he));
+                }
+            }
+            if (!rc) rc = local_finish(h, c, (uint32_t)n);
+            else if (rc != kTakeLevelLoop) (void)hipStreamSynchronize(c->stream);
+            {
+                std::lock_guard<std::mutex> ck(h->chain_mu);
+                h->chain_inflight--;
+            }
+            h->chain_cv.notify_one();
+        }
+        if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time
+            const bool tried = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+            HIP_TRY(hipStreamSynchronize(c->stream));  // items are on the device before the kernels' turn starts
+            std::lock_guard<std::mutex> tk(h->compute_mu);
+            rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p, !tried);  // (ends with the context's stream synchronised)
+        }
     } else {
         rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);
     }

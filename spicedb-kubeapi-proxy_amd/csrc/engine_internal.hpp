@@ -140,6 +140,7 @@ struct PinnedBuf {
 
 constexpr int kNoContextFree = -1001;  // internal (Eval::begin with try_only)
 constexpr size_t kComputeTokenItems = 32768;  // host-buffer batches at least this large run their kernels one batch at a time
+constexpr size_t kChainItems = 131072;         // ... and from here on they are chained on the device instead of taking turns through a host mutex
 
 // per-call cancellation / deadline (reference: LookupResources runs on the HTTP request's ctx and is abandoned when it is
 // cancelled, responsefilterer.go:165-170; the prefilter join times out after 10 s, responsefilterer.go:44,196-204)
@@ -155,6 +156,7 @@ int check_opts(const CallOpts &o);
 struct PassCtx {
     int index = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t chain_ev = nullptr;  // recorded behind this context's single-launch kernel (engine::chain_prev)
     // frontier
     DevArray<uint4> d_fbuf[2];
     DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow | export counters
@@ -248,7 +250,11 @@ struct acl_engine {
     std::unique_ptr<Compaction> compaction;  // touched only under state_mu exclusive (the worker owns its innards while state == 1)
     bool compaction_enabled = true;
     std::mutex shard_mu;
-    std::mutex compute_mu;  // turn-taking of chip-filling batches (check_ids_host)
+    std::mutex compute_mu;  // turn-taking of chip-filling batches on the level loop (check_ids_host's fallback, the submit/wait pipeline)
+    std::mutex chain_mu;    // chip-filling single-launch passes follow each other ON THE DEVICE: each waits for the previous one's event
+    hipEvent_t chain_prev = nullptr;  // (a context's chain_ev; contexts live until acl_close)
+    std::condition_variable chain_cv;
+    uint32_t chain_inflight = 0;
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
@@ -332,11 +338,11 @@ DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap);
 int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index);
 void merge_stats(acl_engine *h, PassCtx *c);
 
-int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
+int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local = true);
 // every level in ONE launch, wave-private frontiers; an internal negative code when a wave's private frontier overflowed (engine.cpp)
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
 int not_sharded(acl_engine *h);
-int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout);
+int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local = true);  // try_local: the single-launch walk first
 // host items -> answers in host buffers through context c (pinned staging unless the caller's buffers are pinned)
 int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
 int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
