@@ -104,6 +104,48 @@ def c3_lookup_bytes(w, subjects):
     return np.asarray(out, dtype=np.int64)
 
 
+def c3_cpu_reverse_walk(w, subjects):
+    """CPU LookupResources for C3's schema: the same reverse walk the device runs (subject -> the rows that name it -> down the
+    cluster -> namespace -> pod arrows), over CSR-by-subject arrays in numpy -- the tuned CPU baseline VERDICT r1 asked for next to
+    the brute-force definition.  Returns (list of allowed-pod id arrays, seconds for the walks alone: index building is setup)."""
+    E = {(e[0], e[1]): (e[4], e[5]) for e in w.edges}
+
+    def by_subject(key, n):
+        r, s_ = E[key]
+        o = np.argsort(s_, kind="stable")
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, s_.astype(np.int64) + 1, 1)
+        return np.cumsum(ptr), r[o].astype(np.int64)
+
+    nu, nns, ncl, npod = w.nobjects["user"], w.nobjects["namespace"], w.nobjects["cluster"], w.nobjects["pod"]
+    rows = {k: by_subject(k, nu) for k in [("pod", "viewer"), ("pod", "creator"), ("namespace", "viewer"), ("namespace", "creator"), ("cluster", "viewer"), ("cluster", "admin")]}
+    ns_of_cl = by_subject(("namespace", "cluster"), ncl)
+    pod_of_ns = by_subject(("pod", "namespace"), nns)
+
+    def expand(csr, ids):  # all resources of the rows of `ids`
+        ptr, col = csr
+        if not ids.size:
+            return np.zeros(0, dtype=np.int64)
+        st_, en = ptr[ids], ptr[ids + 1]
+        tot = int((en - st_).sum())
+        if not tot:
+            return np.zeros(0, dtype=np.int64)
+        idx = np.repeat(st_ - np.concatenate(([0], np.cumsum(en - st_)[:-1])), en - st_) + np.arange(tot)
+        return col[idx]
+
+    outs = []
+    t0 = time.perf_counter()
+    for u in subjects:
+        one = np.asarray([int(u)], dtype=np.int64)
+        cl = np.unique(np.concatenate([expand(rows[("cluster", "viewer")], one), expand(rows[("cluster", "admin")], one)]))
+        ns = np.unique(np.concatenate([expand(rows[("namespace", "viewer")], one), expand(rows[("namespace", "creator")], one), expand(ns_of_cl, cl)]))
+        seen = np.zeros(npod, dtype=bool)
+        for part in (expand(rows[("pod", "viewer")], one), expand(rows[("pod", "creator")], one), expand(pod_of_ns, ns)):
+            seen[part] = True
+        outs.append(np.flatnonzero(seen))
+    return outs, time.perf_counter() - t0
+
+
 def filter_bench(args, w, eng, steps, warmup):
     """BASELINE config 3: one step = LookupResources(pod, view, user:U) for the 64 power users as ONE batched reverse walk
     (acl_lookup_resources_batch: bitmaps come back to the host, as the Go side consumes them).  Returns the C3 record."""
@@ -161,11 +203,18 @@ def filter_bench(args, w, eng, steps, warmup):
             got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little"))
             mism += int(not np.array_equal(got, want))
         t_cpu = time.perf_counter() - t1
-        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism}
-        out["cpu_baseline"] = {"value": subs.size / t_cpu, "unit": "lookups/s", "cores": nt, "kind": "port",
-                               "sample": f"all {subs.size} power users, by DEFINITION {{id : Check == HAS}} over every pod ({subs.size * npod} oracle checks over {nt} "
-                                         "threads); the restated oracle has no reverse walk, so this is a brute-force checker rather than a tuned CPU LookupResources",
-                               "seconds": round(t_cpu, 2)}
+        # the CPU baseline proper: the same reverse walk on the host (numpy over CSR-by-subject rows); its id sets are checked too
+        walks, t_walk = c3_cpu_reverse_walk(w, subs)
+        for i in range(subs.size):
+            got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little"))
+            mism += int(not np.array_equal(got, walks[i]))
+        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism,
+                         "checkers": "the DEFINITION {id : Check == HAS} over every pod (multi-threaded oracle) AND a CPU reverse walk"}
+        out["cpu_baseline"] = {"value": subs.size / t_walk, "unit": "lookups/s", "cores": 1, "kind": "port",
+                               "sample": f"all {subs.size} power users: reverse walk over CSR-by-subject rows in numpy (one thread; the algorithm the device runs, specialised "
+                                         "to C3's schema; index building not timed)", "seconds": round(t_walk, 3),
+                               "by_definition": {"value": subs.size / t_cpu, "cores": nt, "seconds": round(t_cpu, 2),
+                                                 "sample": f"{{id : Check == HAS}} over every pod: {subs.size * npod} oracle checks"}}
     return out
 
 

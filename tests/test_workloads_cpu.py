@@ -63,3 +63,20 @@ def test_bench_helpers_import_without_gpu():
     spec.loader.exec_module(m)
     assert 1 <= m.usable_cores() <= os.cpu_count()
     assert set(m.WORKLOAD_DESC) == {"C1", "C2", "C3", "C4", "C5", "C5R"}  # C5R: the C5-size graph as one replica (beyond-L3 data point)
+
+
+def test_c3_cpu_reverse_walk_matches_definition():
+    """bench.py's CPU baseline for C3 (a reverse walk over CSR-by-subject rows) returns exactly {id : Check == HAS}."""
+    import bench
+    from oracle import orc
+    w = workloads.c3(scale=0.05, power_users=4)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    subs = np.asarray(w.lookup_subjects, dtype=np.uint32)
+    walks, _t = bench.c3_cpu_reverse_walk(w, subs)
+    rt, perm, st = w.check
+    pods = np.arange(w.nobjects[rt], dtype=np.uint32)
+    for i, s_ in enumerate(subs):
+        op, _oe = o.check_bulk_ids_mt(2, rt, perm, pods, st, "", np.full(pods.size, s_, dtype=np.uint32))
+        assert np.array_equal(np.flatnonzero(op == 2), walks[i]), i
