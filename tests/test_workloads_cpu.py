@@ -67,8 +67,10 @@ def test_bench_helpers_import_without_gpu():
 
 def test_c3_cpu_reverse_walk_matches_definition():
     """bench.py's CPU baseline for C3 (a reverse walk over CSR-by-subject rows) returns exactly {id : Check == HAS}."""
-    import bench
-    from oracle import orc
+    from aclgpu import workloads
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
     w = workloads.c3(scale=0.05, power_users=4)
     o = orc.Oracle(w.schema)
     w.load(o)
