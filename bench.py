@@ -12,7 +12,7 @@ BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
                     kernels follow each other on the device: each waits for the previous one's event).  `--pipeline submit`
                     times acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead.  Measured
                     (profiles/r02_hostid_modes_chained.txt): 1 caller 570 M/s, 2 callers 750 M/s, 3 callers 745 M/s
-                    (4: 306 M/s -- keep it at 2-3); kernels alone (device_resident) 770 M/s.
+                    (4: 566 M/s: at most three chained batches in flight); kernels alone (device_resident) 755-770 M/s.
   device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
                     per-launch kernel time comes from HIP events in THIS leg (pipelined launches overlap each other)
   latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")

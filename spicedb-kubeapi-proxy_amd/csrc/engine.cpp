@@ -638,6 +638,31 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
         src = c->h_in.p;
     }
+    // Chained (chip-filling) batches: at most three contexts' streams carry such a batch at a time, copies included -- the runtime multiplexes
+    // streams onto 4 hardware queues, and a fourth busy stream sharing a queue with one that waits for an event halves everybody's
+    // throughput (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3).  Further callers queue here.
+    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+    struct ChainSlot {
+        acl_engine *h;
+        bool held = false;
+        void acquire() {
+            std::unique_lock<std::mutex> ck(h->chain_mu);
+            h->chain_cv.wait(ck, [&] { return h->chain_inflight < 3; });
+            h->chain_inflight++;
+            held = true;
+        }
+        void release() {
+            if (!held) return;
+            {
+                std::lock_guard<std::mutex> ck(h->chain_mu);
+                h->chain_inflight--;
+            }
+            h->chain_cv.notify_one();
+            held = false;
+        }
+        ~ChainSlot() { release(); }
+    } slot{h};
+    if (chained) slot.acquire();
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
     int rc = kTakeLevelLoop;
     if (n >= kComputeTokenItems) {
@@ -650,15 +675,11 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         // "launch + synchronise" left the chip idle for a wake-up and a launch (~10 % of a C4 batch) between two kernels.
         // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
         //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
-        if (n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1) {
+        if (chained) {
             HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
             HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
             {
-                // at most three chained passes in flight: the runtime multiplexes streams onto 4 hardware queues, and a fourth waiter
-                // halves the throughput of all of them (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3)
-                std::unique_lock<std::mutex> ck(h->chain_mu);
-                h->chain_cv.wait(ck, [&] { return h->chain_inflight < 3; });
-                h->chain_inflight++;
+                std::lock_guard<std::mutex> ck(h->chain_mu);
                 hipError_t he = h->chain_prev ? hipStreamWaitEvent(c->stream, h->chain_prev, 0) : hipSuccess;
                 rc = he == hipSuccess ? local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p)
                                       : fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
@@ -670,14 +691,10 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
             }
             if (!rc) rc = local_finish(h, c, (uint32_t)n);
             else if (rc != kTakeLevelLoop) (void)hipStreamSynchronize(c->stream);
-            {
-                std::lock_guard<std::mutex> ck(h->chain_mu);
-                h->chain_inflight--;
-            }
-            h->chain_cv.notify_one();
+            slot.release();
         }
         if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time
-            const bool tried = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+            const bool tried = chained;
             HIP_TRY(hipStreamSynchronize(c->stream));  // items are on the device before the kernels' turn starts
             std::lock_guard<std::mutex> tk(h->compute_mu);
             rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p, !tried);  // (ends with the context's stream synchronised)
