@@ -118,6 +118,22 @@ def test_c4_full_every_entry_point(aclgpu):
             e.wait(t)
         for b in range(k):
             assert np.array_equal(h_perm[b], np.roll(op, b * 4099)) and np.array_equal(h_err[b], np.roll(oe, b * 4099)), b
+        # chip-filling batches from several threads at once (goroutines behind the cgo shim): their kernels are chained on the
+        # device, each stream waiting for the event behind the previous batch's kernel; four callers exercise the in-flight cap
+        import threading
+        for b in range(k):
+            h_perm[b][:] = 255
+            h_err[b][:] = -1
+        def caller(mine):
+            for b in mine:
+                e.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+        ths = [threading.Thread(target=caller, args=(range(t, k, 4),)) for t in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for b in range(k):
+            assert np.array_equal(h_perm[b], np.roll(op, b * 4099)) and np.array_equal(h_err[b], np.roll(oe, b * 4099)), b
         e.host_free(hb)
         # (iii) string path (anonymous numeric ids have no names: name a slice of the objects first)
         m = 16384
