@@ -459,7 +459,7 @@ static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     // every block gets ONE unit of n / blocks requests (`upw` > 1: several smaller ones, a second round of per-level chains)
     G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), kWavesPerBlock * 64u);
     G.nunits = (n + G.rpw - 1) / G.rpw;
-    G.nblocks = std::min<uint32_t>(G.nunits, blocks);
+    G.nblocks = std::max<uint32_t>(std::min<uint32_t>(G.nunits, blocks), 1);
     // (a block that needs more than 256 K entries is walking something the whole chip should walk: the level loop takes the batch)
     G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / G.nblocks, 1u << 18);
     return G;

@@ -528,7 +528,8 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
 
 template <bool INLINE, bool SHARDED, bool LOCAL, bool DESC = false>  // DESC: the tasks carry the subject's hashed row (TaskLds b0 / nb)
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
-                                            const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh) {
+                                            const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh,
+                                            bool same = false /* the caller made every task from ONE op: child slot, key and flags agree */) {
     uint4 *__restrict__ out = wo.buf;
     uint32_t only = ~0u;  // rounds of 64 tasks left for the generic loop
     wave_lds_fence();
@@ -543,9 +544,13 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             ok = pop.flags == OP_PROBE_HASH && pop.key == k0;
         }
         bool agree = true;
-        for (uint32_t i = lane; i < T; i += 64) {
-            const uint32_t mi = t.meta[i], ci = t.count[i];
-            agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
+        if (same) {
+            agree = (t.count[0] & (kLeafAuthBit | kSelfBit)) == kLeafAuthBit;
+        } else {
+            for (uint32_t i = lane; i < T; i += 64) {
+                const uint32_t mi = t.meta[i], ci = t.count[i];
+                agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
+            }
         }
         if (ok && !__ballot(!agree)) {
             only = flush_simple<SHARDED, LOCAL, DESC>(t, T, wo, lane, g, cp, pop, has, err);
@@ -787,7 +792,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, LA, 0u);
             if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, LB, T);
             ACL_MARK(wo, PH_TASKS);
-            if (T) flush_tasks<true, SHARDED, LOCAL, true>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            if (T) flush_tasks<true, SHARDED, LOCAL, true>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh, oneslot);
             ACL_MARK(wo, PH_PUSH);
             return;
         }
@@ -1055,7 +1060,9 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
                                                                                   int32_t *err_out) {
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
-    __shared__ uint32_t s_fill, s_next, s_stop, s_unit;
+    // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
+    // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
+    __shared__ uint32_t s_fill[3], s_next[3], s_stop, s_unit;
     extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
@@ -1079,13 +1086,13 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
     wo.fill = 0;
     wo.produced = 0;
     wo.cold = &s_cold[wib];
-    wo.lfill = &s_fill;
+    wo.lfill = &s_fill[1];
     for (uint32_t unit = blockIdx.x; unit < nunits;) {
         const uint32_t first = unit * rpw;
         const uint32_t mine = min(rpw, n - first);  // <= 256: thread i seeds and answers request first + i
-        if (threadIdx.x == 0) {
-            s_fill = 0;
-            s_next = 0;
+        if (threadIdx.x < 3) {
+            s_fill[threadIdx.x] = 0;
+            s_next[threadIdx.x] = 0;
         }
         __syncthreads();
         // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit
@@ -1107,6 +1114,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wo.buf = bufs[0];
         wo.cur = 0;
+        wo.lfill = &s_fill[1];  // level 1
         ACL_MARK(wo, PH_SEED);
         {
             NoNext nn;
@@ -1117,22 +1125,22 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
             // ---- level boundary: everybody's children are written, the cursors turn over
             if (wo.cur == kNoSpace && lane == 0) s_stop = 1;  // overflow: the host redoes the batch
             __syncthreads();
-            const uint32_t cnt = s_fill;
+            const uint32_t cnt = s_fill[(level - 1) % 3];
             const bool stop = s_stop != 0;
-            __syncthreads();
             if (threadIdx.x == 0) {
-                s_fill = 0;
-                s_next = 0;
+                s_fill[(level + 1) % 3] = 0;
+                s_next[(level + 1) % 3] = 0;
             }
-            __syncthreads();
             ACL_MARK(wo, PH_BARRIER);
             if (stop || !cnt) break;
+            wo.lfill = &s_fill[level % 3];
+            uint32_t *const next_seg = &s_next[level % 3];
             LocalWalk lw{bufs[parity], cnt, 0u, lane, false};
             parity ^= 1u;
             wo.buf = bufs[parity];
             for (;;) {
                 uint32_t sg = 0;
-                if (lane == 0) sg = atomicAdd(&s_next, 2u);
+                if (lane == 0) sg = atomicAdd(next_seg, 2u);
                 sg = uniform(sg);
                 if (sg * 64 >= cnt) break;
                 for (lw.s = sg, lw.second = true; lw.s < sg + 2 && lw.s * 64 < cnt; lw.s++) {
