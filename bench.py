@@ -696,8 +696,8 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--batch", type=int, default=0)

@@ -88,6 +88,20 @@ def test_branching_cycles_stay_polynomial(aclgpu):
         perms, errs = e.check_bulk(qs)
         assert list(zip(perms, errs)) == [o.check(*q) for q in qs]
         assert e.stats()["overflow_retries"] >= 1  # (the merging pass was what answered)
+        # more requests than one merging pass holds (its key has 14 request bits): the batch is answered in slices
+        import numpy as np
+        base = e.make_items("group", "member", np.zeros(1, dtype=np.uint32), "user", "", np.zeros(1, dtype=np.uint32))
+        ids = {g: int(e.intern("group", g)) for g in ("g0", "g1", "g2")}
+        us = {u: int(e.intern("user", u)) for u in ("deep", "nobody")}
+        combos = [(g, u) for g in ("g0", "g1", "g2") for u in ("deep", "nobody")]
+        big = np.repeat(base, 20000)
+        for i, (g, u) in enumerate(combos):
+            big["resource_id"][i::6] = ids[g]
+            big["subject_id"][i::6] = us[u]
+        bp, be = e.check_bulk_ids(big)
+        for i, (g, u) in enumerate(combos):
+            want = o.check("group", g, "member", "user", u)
+            assert set(zip(bp[i::6].tolist(), be[i::6].tolist())) == {want}, (g, u)
 
 
 def test_engine_matches_oracle_hypothesis(aclgpu):
