@@ -129,7 +129,7 @@ struct TaskLds {
     uint32_t sid[kTaskCap];
     uint32_t b0[kTaskCap];     // flush_simple: the hashed row the children are probed in (the request subject's row of the child's one probe op):
     uint32_t nb[kTaskCap];     //   first bucket and bucket count; {0, 1} = the reserved empty bucket when the subject has no row
-    uint32_t scan[64];
+    uint32_t scan[kTaskCap];   // generic expansion: exclusive prefix of a round's 64 degrees; flush_simple: first edge minus first work item, per task
     uint64_t heads[kHeadWords];  // flush_simple: bit (w & 63) of word (w >> 6) set <=> a task's children start at work item w
 };
 
@@ -300,7 +300,11 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #ifndef ACL_SIMPLE_WIDTH
 #define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
 #endif
-constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane and step
+constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane whose buckets are in flight together
+#ifndef ACL_EDGES_AHEAD
+#define ACL_EDGES_AHEAD 2  // = the width.  4 and 6 (all edges of a pair of segments in ONE trip) measured the same 305 us: one more sign that the walk is not waiting on trips
+#endif
+constexpr int kEdgesAhead = ACL_EDGES_AHEAD;    // children per lane whose edges are fetched in one trip
 // Returns a bit mask of the 64-task rounds it did NOT handle (the caller expands those the generic way): a round whose rows
 // together exceed the head-bit window (a row of thousands of ids) or with a task at the dispatch-depth limit.
 //
@@ -321,36 +325,53 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     uint4 *__restrict__ out = wo.buf;
     uint32_t skipped = 0;
-    for (uint32_t gq = 0; gq < T; gq += 64) {
-        const bool mine = gq + lane < T;
-        const uint32_t cnt = mine ? (t.count[gq + lane] & kCountMask) : 0u;
-        const uint32_t incl = wave_incl_scan(cnt, lane);
-        const uint32_t total = wave_last(incl);
-        const uint32_t lvl = mine ? meta_level(t.meta[gq + lane]) : 0u;
-        if (total > 64u * kHeadWords || __ballot(lvl + pop.dlevel > kMaxLevels || lvl + cp.max_dlevel > kMaxLevels)) {
-            skipped |= 1u << (gq >> 6);
-            continue;
-        }
-        const uint32_t excl = incl - cnt;
-        if (!DESC && mine) {
-            const uint32_t sidt = t.sid[gq + lane];
-            const uint2 d = gld(reinterpret_cast<const uint2 *>(g.meta), pop.base + (sidt < pop.nrows ? sidt : 0u));
-            const bool row = sidt < pop.nrows && d.y > d.x;
-            t.b0[gq + lane] = row ? d.x : 0u;
-            t.nb[gq + lane] = row ? d.y - d.x : 1u;
+    // ONE round for the whole list (<= kTaskCap = 128 tasks): every lane owns tasks `lane` and `64 + lane`.  Two rounds of 64 paid this
+    // prologue -- a chain of dependent LDS round trips: counts, scan, head bits, fences -- twice per pair of segments
+    // (17 % of the walk's wave-time, profiles/r02_walk_phase_breakdown.txt).
+    {
+        constexpr uint32_t gq = 0;
+        const bool mine0 = lane < T, mine1 = 64u + lane < T;
+        const uint32_t cnt0 = mine0 ? (t.count[lane] & kCountMask) : 0u, cnt1 = mine1 ? (t.count[64u + lane] & kCountMask) : 0u;
+        const uint32_t incl0 = wave_incl_scan(cnt0, lane);
+        const uint32_t tot0 = wave_last(incl0);
+        const uint32_t incl1 = wave_incl_scan(cnt1, lane) + tot0;
+        const uint32_t total = wave_last(incl1);
+        const uint32_t lvl0 = mine0 ? meta_level(t.meta[lane]) : 0u, lvl1 = mine1 ? meta_level(t.meta[64u + lane]) : 0u;
+        const uint32_t lvl = max(lvl0, lvl1);
+        if (total > 64u * kHeadWords || __ballot(lvl + pop.dlevel > kMaxLevels || lvl + cp.max_dlevel > kMaxLevels)) return ~0u;
+        const uint32_t excl0 = incl0 - cnt0, excl1 = incl1 - cnt1;
+        if (!DESC) {
+#pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t i = h * 64u + lane;
+                if (i < T) {
+                    const uint32_t sidt = t.sid[i];
+                    const uint2 d = gld(reinterpret_cast<const uint2 *>(g.meta), pop.base + (sidt < pop.nrows ? sidt : 0u));
+                    const bool row = sidt < pop.nrows && d.y > d.x;
+                    t.b0[i] = row ? d.x : 0u;
+                    t.nb[i] = row ? d.y - d.x : 1u;
+                }
+            }
         }
         if (lane < kHeadWords) t.heads[lane] = 0ull;
-        t.scan[lane] = (mine ? t.start[gq + lane] : 0u) - excl;  // first edge of the task minus its first work item: edge index = this + work item
+        // first edge of the task minus its first work item: edge index = this + work item
+        t.scan[lane] = (mine0 ? t.start[lane] : 0u) - excl0;
+        t.scan[64u + lane] = (mine1 ? t.start[64u + lane] : 0u) - excl1;
         wave_lds_fence();
-        if (mine) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl >> 6]), 1ull << (excl & 63u));
+        if (mine0) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl0 >> 6]), 1ull << (excl0 & 63u));
+        if (mine1) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl1 >> 6]), 1ull << (excl1 & 63u));
         wave_lds_fence();
         uint32_t before = 0;  // tasks that start before the current 64-item window
         ACL_MARK(wo, PH_PROLOGUE);
-        for (uint32_t w0 = 0; w0 < total; w0 += 64 * W) {
-            bool valid[W];
-            uint32_t tj[W], edge[W];
+        // A step = kEdgesAhead windows of 64 children: their edges go out in one trip (one VGPR each), then the buckets follow W windows
+        // at a time (8 VGPRs per child).
+        constexpr int E = kEdgesAhead;
+        static_assert(E % W == 0, "the bucket stage walks the fetched windows W at a time");
+        for (uint32_t w0 = 0; w0 < total; w0 += 64 * E) {
+            bool valid[E];
+            uint32_t tj[E], edge[E];
 #pragma unroll
-            for (int k = 0; k < W; k++) {
+            for (int k = 0; k < E; k++) {
                 const uint32_t win = (w0 >> 6) + (uint32_t)k;
                 const uint64_t hw = win < kHeadWords ? t.heads[win] : 0ull;
                 const uint32_t hlo = uniform((uint32_t)hw), hhi = uniform((uint32_t)(hw >> 32));
@@ -363,47 +384,52 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 tj[k] = gq + j;
                 edge[k] = gld(edges, t.scan[j] + wv);
             }
-            issue_fence();  // trip 1: the W edges
+            issue_fence();  // trip 1: every edge of the step
             ACL_MARK(wo, PH_EDGES);
-            uint4 p[W], q[W];
 #pragma unroll
-            for (int k = 0; k < W; k++) {
-                uint32_t h1, h2;
-                hashed_row_buckets(edge[k] & kIdMask, t.nb[tj[k]], &h1, &h2);
-                const uint32_t b0 = t.b0[tj[k]];
-                p[k] = gld(buckets, b0 + h1);
-                q[k] = gld(buckets, b0 + h2);
-            }
-            issue_fence();  // trip 2: the 2 x W buckets
-            ACL_MARK(wo, PH_BUCKETS);
-            bool hit[W], push[W];
-            uint64_t pb[W];
-            uint32_t pre[W], np = 0;
+            for (int k0 = 0; k0 < E; k0 += W) {
+                if (w0 + 64u * k0 >= total) break;  // (uniform)
+                uint4 p[W], q[W];
 #pragma unroll
-            for (int k = 0; k < W; k++) {
-                // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
-                //  loads at the end of every step; depth limits were checked per task above)
-                hit[k] = valid[k] & bucket_pair_has(p[k], q[k], edge[k] & kIdMask);
-                push[k] = valid[k] & !hit[k] & ((edge[k] & kLeafBit) == 0u);
-                pb[k] = __ballot(push[k]);
-                pre[k] = np;
-                np += (uint32_t)__popcll(pb[k]);
-            }
-            // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
-            // (vmcnt counts stores too, and the compiler must assume the store was not issued)
-#pragma unroll
-            for (int k = 0; k < W; k++)
-                if (hit[k]) has[t.req[tj[k]]] = 1;
-            if (np) {
-                const uint32_t base = reserve<LOCAL>(wo, np, lane);
-                if (base != kNoSpace) {
-#pragma unroll
-                    for (int k = 0; k < W; k++)
-                        if (push[k])
-                            gst(out, base + pre[k] + lanes_below(pb[k]), make_uint4(edge[k] & kIdMask, t.req[tj[k]], t.meta[tj[k]] | kProbedBit, t.sid[tj[k]]));
+                for (int k = 0; k < W; k++) {
+                    uint32_t h1, h2;
+                    hashed_row_buckets(edge[k0 + k] & kIdMask, t.nb[tj[k0 + k]], &h1, &h2);
+                    const uint32_t b0 = t.b0[tj[k0 + k]];
+                    p[k] = gld(buckets, b0 + h1);
+                    q[k] = gld(buckets, b0 + h2);
                 }
+                issue_fence();  // trip 2: the 2 x W buckets
+                ACL_MARK(wo, PH_BUCKETS);
+                bool hit[W], push[W];
+                uint64_t pb[W];
+                uint32_t pre[W], np = 0;
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
+                    //  loads at the end of every step; depth limits were checked per task above)
+                    hit[k] = valid[k0 + k] & bucket_pair_has(p[k], q[k], edge[k0 + k] & kIdMask);
+                    push[k] = valid[k0 + k] & !hit[k] & ((edge[k0 + k] & kLeafBit) == 0u);
+                    pb[k] = __ballot(push[k]);
+                    pre[k] = np;
+                    np += (uint32_t)__popcll(pb[k]);
+                }
+                // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
+                // (vmcnt counts stores too, and the compiler must assume the store was not issued)
+#pragma unroll
+                for (int k = 0; k < W; k++)
+                    if (hit[k]) has[t.req[tj[k0 + k]]] = 1;
+                if (np) {
+                    const uint32_t base = reserve<LOCAL>(wo, np, lane);
+                    if (base != kNoSpace) {
+#pragma unroll
+                        for (int k = 0; k < W; k++)
+                            if (push[k])
+                                gst(out, base + pre[k] + lanes_below(pb[k]),
+                                    make_uint4(edge[k0 + k] & kIdMask, t.req[tj[k0 + k]], t.meta[tj[k0 + k]] | kProbedBit, t.sid[tj[k0 + k]]));
+                    }
+                }
+                ACL_MARK(wo, PH_PUSH);
             }
-            ACL_MARK(wo, PH_PUSH);
         }
         wave_lds_fence();
     }
