@@ -224,6 +224,17 @@ class Engine:
             arr[i] = CheckItem(rt, a, pm, st, b, sr)
         return arr, n, keep
 
+    def make_check_strings_named(self, items):
+        """A prepared acl_check_item_t array of [(rt, rid, perm, st, sid, srel)] (the ctypes marshalling done once, outside any timing)."""
+        n = len(items)
+        arr = (CheckItem * max(1, n))()
+        keep = []
+        for i, it in enumerate(items):
+            bs = [_b(x if x is not None else "") for x in it]
+            keep.append(bs)
+            arr[i] = CheckItem(*bs)
+        return arr, n, keep
+
     def check_bulk_prepared(self, prepared):
         arr, n, _keep = prepared
         perm = np.zeros(max(1, n), dtype=np.uint8)

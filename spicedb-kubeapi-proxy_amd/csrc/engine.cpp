@@ -771,9 +771,12 @@ struct NameMemo {
     bool bad = true;
 };
 
-static int32_t intern_fast(acl_engine_t *h, const Schema &sc, const acl_check_item_t &it, NameMemo &m, acl_item_t *out) {
-    if (empty(it.resource_type) || empty(it.resource_id) || empty(it.permission) || empty(it.subject_type) || empty(it.subject_id))
-        return ACL_ERR_INVALID_ARGUMENT;
+// names -> indices of one item (memoised per thread); false: *err says why the item cannot be checked
+static bool intern_names(const Schema &sc, const acl_check_item_t &it, NameMemo &m, int32_t *err) {
+    if (empty(it.resource_type) || empty(it.resource_id) || empty(it.permission) || empty(it.subject_type) || empty(it.subject_id)) {
+        *err = ACL_ERR_INVALID_ARGUMENT;
+        return false;
+    }
     const char *srel = (empty(it.subject_relation) || std::strcmp(it.subject_relation, "...") == 0) ? "" : it.subject_relation;
     if (!(m.rt && m.rts == it.resource_type && m.pms == it.permission && m.sts == it.subject_type && m.srs == srel)) {
         m.rt = it.resource_type;
@@ -791,37 +794,137 @@ static int32_t intern_fast(acl_engine_t *h, const Schema &sc, const acl_check_it
             m.bad = m.sri < 0;
         }
     }
-    if (m.bad) return ACL_ERR_FAILED_PRECONDITION;
-    uint32_t res, sub;
-    const bool kr = h->store.objects(m.rti).find(it.resource_id, &res), ks = h->store.objects(m.sti).find(it.subject_id, &sub);
-    if (!kr && !ks && m.rti == m.sti && std::strcmp(it.resource_id, it.subject_id) == 0) res = sub = 0xFFFFFFFEu;
-    else {
-        if (!kr) res = 0xFFFFFFFDu;
-        if (!ks) sub = 0xFFFFFFFCu;
+    if (m.bad) {
+        *err = ACL_ERR_FAILED_PRECONDITION;
+        return false;
     }
-    *out = acl_item_t{(uint16_t)m.rti, (uint16_t)m.pmi, res, (uint16_t)m.sti, (uint16_t)(m.sri == kNoRelation ? ACL_NO_RELATION : m.sri), sub};
-    return 0;
+    return true;
+}
+
+// Host threads of the string entry points' interning: persistent (spawning 15 threads costs 0.2-2 ms per call -- more than interning a
+// 64 k-item batch), woken per batch; the caller works too.
+struct InternPool {
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::vector<std::thread> threads;
+    const std::function<void(size_t, size_t)> *job = nullptr;
+    size_t n = 0, chunk = 1;
+    std::atomic<size_t> next{0};
+    size_t outstanding = 0;  // workers that have not yet passed through the current batch (every worker passes through every batch)
+    uint64_t gen = 0;
+    bool stop = false;
+    std::mutex call_mu;  // one batch at a time
+
+    void work() {
+        for (;;) {
+            const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (a >= n) return;
+            (*job)(a, std::min(n, a + chunk));
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                outstanding--;
+            }
+            done_cv.notify_one();
+        }
+    }
+    explicit InternPool(unsigned nthreads) {
+        for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this] { loop(); });
+    }
+    ~InternPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
+    void run(size_t total, size_t chunk_items, const std::function<void(size_t, size_t)> &fn) {
+        std::lock_guard<std::mutex> one(call_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = &fn;
+            n = total;
+            chunk = chunk_items;
+            next.store(0, std::memory_order_relaxed);
+            outstanding = threads.size();
+            gen++;
+        }
+        cv.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return outstanding == 0; });  // no worker is still inside (or yet to enter) this batch: `fn` may go out of scope
+    }
+};
+
+void intern_pool_destroy(acl_engine_t *h) {
+    delete h->intern_pool;
+    h->intern_pool = nullptr;
 }
 
 void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out) {
     const Schema &sc = h->store.schema();
-    auto run = [&](size_t a, size_t b) {
+    // Object ids: two hash probes per item into tables of up to millions of names -- one DRAM miss each.  Items go in groups of
+    // kGroup: hash every id and prefetch its slot, then probe; the misses of a group are in flight together.
+    constexpr size_t kGroup = 16;
+    const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
         NameMemo m;
-        for (size_t i = a; i < b; i++) {
-            out[i] = acl_item_t{};
-            err_out[i] = intern_fast(h, sc, items[i], m, &out[i]);
+        struct Pending {
+            uint64_t hr, hs;
+            int rt, st, pm, sr;
+            bool ok;
+        } pend[kGroup];
+        for (size_t g0 = a; g0 < b; g0 += kGroup) {
+            const size_t g1 = std::min(b, g0 + kGroup);
+            for (size_t i = g0; i < g1; i++) {
+                Pending &p = pend[i - g0];
+                out[i] = acl_item_t{};
+                err_out[i] = 0;
+                p.ok = intern_names(sc, items[i], m, &err_out[i]);
+                if (!p.ok) continue;
+                p.rt = m.rti; p.st = m.sti; p.pm = m.pmi; p.sr = m.sri;
+                p.hr = ObjectTable::hash_of(items[i].resource_id);
+                p.hs = ObjectTable::hash_of(items[i].subject_id);
+                h->store.objects(p.rt).prefetch(p.hr);
+                h->store.objects(p.st).prefetch(p.hs);
+            }
+            for (size_t i = g0; i < g1; i++) {
+                const Pending &p = pend[i - g0];
+                if (!p.ok) continue;
+                const acl_check_item_t &it = items[i];
+                // unknown object ids have no relationships: sentinels above every dense id, equal only when
+                // resource and subject are the same (unknown) object
+                uint32_t res, sub;
+                const bool kr = h->store.objects(p.rt).find_hashed(it.resource_id, p.hr, &res), ks = h->store.objects(p.st).find_hashed(it.subject_id, p.hs, &sub);
+                if (!kr && !ks && p.rt == p.st && std::strcmp(it.resource_id, it.subject_id) == 0) res = sub = 0xFFFFFFFEu;
+                else {
+                    if (!kr) res = 0xFFFFFFFDu;
+                    if (!ks) sub = 0xFFFFFFFCu;
+                }
+                out[i] = acl_item_t{(uint16_t)p.rt, (uint16_t)p.pm, res, (uint16_t)p.st, (uint16_t)(p.sr == kNoRelation ? ACL_NO_RELATION : p.sr), sub};
+            }
         }
     };
-    unsigned nt = n >= 32768 ? std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u) : 1u;
-    if (nt > 1) nt = (unsigned)std::min<size_t>(nt, n / 8192);
-    if (nt <= 1) {
+    if (n < 4096) {  // ~90 ns per item on one thread: below this the pool's wake-up costs more than it saves
         run(0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(run, n * t / nt, n * (t + 1) / nt);
-    run(0, n / nt);
-    for (auto &t : th) t.join();
+    {
+        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+        if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), 16u) - 1);
+    }
+    h->intern_pool->run(n, n >= 32768 ? 2048 : 512, run);
 }
 
 // one batched reverse walk: n subjects of one class against one (type, permission); bitmaps in host memory
@@ -1020,6 +1123,7 @@ void acl_close(acl_engine_t *h) {
     (void)acl_batcher_stop(h);
     async_shutdown(h);
     batcher_destroy(h);
+    intern_pool_destroy(h);
     (void)acl_shard_rccl_destroy(h);
     compaction_join(h);
     if (h->store_only) {

@@ -190,7 +190,10 @@ struct PassCtx {
 }  // namespace aclint
 using namespace aclint;
 
-struct AsyncPool;  // engine_async.cpp
+struct AsyncPool;
+namespace aclint {
+struct InternPool;  // engine.cpp
+}  // engine_async.cpp
 
 // Background snapshot compaction (engine.cpp).  Patching writes into the HBM snapshot leaves garbage behind (relocated
 // rows) and eats the tables' headroom; once either passes a threshold the next snapshot is built from a copy-on-write view
@@ -266,6 +269,8 @@ struct acl_engine {
     std::mutex batcher_mu;       // start / stop
     // async submit / wait (engine_async.cpp)
     AsyncPool *async = nullptr;  // created by the first submit, destroyed by async_shutdown
+    aclint::InternPool *intern_pool = nullptr;  // host threads of bulk string interning (engine.cpp), created by the first large string batch
+    std::mutex intern_pool_mu;
     std::mutex async_mu;
     // pinned buffers handed out by acl_host_alloc: [base, base + bytes)
     std::mutex pinned_mu;
@@ -353,6 +358,7 @@ FilterText to_filter(const acl_filter_t *f);
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
 // many items: split over host threads when the batch is large
 void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out);
+void intern_pool_destroy(acl_engine_t *h);
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
 int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,

@@ -30,9 +30,9 @@ void ObjectTable::grow() {
         slots_[i] = s;
     }
 }
-bool ObjectTable::find(std::string_view name, uint32_t *id) const {
+bool ObjectTable::find(std::string_view name, uint32_t *id) const { return find_hashed(name, hash(name), id); }
+bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) const {
     if (slots_.empty()) return false;
-    const uint64_t h = hash(name);
     const uint32_t tag = (uint32_t)(h >> 32);
     const size_t mask = slots_.size() - 1;
     for (size_t i = h & mask;; i = (i + 1) & mask) {

@@ -62,6 +62,13 @@ class ObjectTable {
   public:
     uint32_t intern(std::string_view name);
     bool find(std::string_view name, uint32_t *id) const;
+    // two-step form for bulk interning: hash first and pull the slot's line towards the core, probe a few items later --
+    // a lookup in a table of millions of names is one DRAM miss, and eight of them in flight cost about as much as one
+    static uint64_t hash_of(std::string_view s) { return hash(s); }
+    void prefetch(uint64_t h) const {
+        if (!slots_.empty()) __builtin_prefetch(&slots_[h & (slots_.size() - 1)]);
+    }
+    bool find_hashed(std::string_view name, uint64_t h, uint32_t *id) const;
     const std::string *name(uint32_t id) const;  // nullptr for anonymous ids
     uint32_t count() const { return count_.load(std::memory_order_acquire); }
     void reserve_ids(uint32_t n) {  // numeric bulk loads: ids < n exist (anonymous)
