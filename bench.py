@@ -537,38 +537,47 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
             eng.wait(t)
 
     def blocking(k_steps):  # `callers` host threads, each in a blocking acl_check_bulk_ids (what goroutines behind the cgo shim do)
+        """-> fire(): the caller threads exist and are parked before the clock starts (a server's callers are not created per request)"""
         if callers == 1:
-            for k in range(k_steps):
-                b = k % NB
-                eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
-            return
+            def fire1():
+                for k in range(k_steps):
+                    b = k % NB
+                    eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+            return fire1
         nxt = [0]
         lk = threading.Lock()
+        go = threading.Event()
 
         def run():
+            go.wait()
             while True:
                 with lk:
                     k = nxt[0]
                     nxt[0] += 1
                 if k >= k_steps:
                     return
-                b = k % NB if callers <= NB else k % NB
+                b = k % NB
                 eng.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
 
         # (two callers never share a batch's output buffers at the same time: steps are handed out in order, NB >= callers)
         ts = [threading.Thread(target=run) for _ in range(callers)]
         for t in ts:
             t.start()
-        for t in ts:
-            t.join()
 
-    pipelined = submit_wait if args.pipeline == "submit" else blocking
-    pipelined(max(warmup, window, callers))
+        def fire():
+            go.set()
+            for t in ts:
+                t.join()
+        return fire
+
+    pipelined = (lambda k_: (lambda: submit_wait(k_))) if args.pipeline == "submit" else blocking
+    pipelined(max(warmup, window, callers))()
+    fire = pipelined(steps)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pipelined(steps)
+    fire()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

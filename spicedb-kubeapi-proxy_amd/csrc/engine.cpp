@@ -470,12 +470,12 @@ static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g, const uin
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
     uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
-    HIP_TRY(hipMemsetAsync(d_over, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(d_over, 0, 3 * sizeof(uint32_t), c->stream));  // [2]: deepest level (a per-destination export counter of the sharded walk: unused here)
     ev_begin(c, 2);
     launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
-                       c->d_err.p, d_perm, d_errout);
+                       c->d_err.p, d_perm, d_errout, d_over + 2);
     ev_end(c);
-    HIP_TRY(hipMemcpyAsync(c->h_status, d_over, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_status, d_over, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return ACL_OK;
 }
 static int local_finish(acl_engine *h, PassCtx *c, uint32_t n) {
@@ -484,6 +484,7 @@ static int local_finish(acl_engine *h, PassCtx *c, uint32_t n) {
     ev_collect(c);
     if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     if (c->h_status[0]) return kTakeLevelLoop;
+    c->stats.levels_last = c->h_status[2];
     c->stats.check_items += n;
     c->stats.check_passes++;
     c->stats.local_passes++;

@@ -1083,7 +1083,7 @@ template <bool LDSPROG>
 __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
                                                                                   uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap,
                                                                                   uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
-                                                                                  int32_t *err_out) {
+                                                                                  int32_t *err_out, uint32_t *max_level) {
     __shared__ TaskLds lds[kWavesPerBlock];
     __shared__ WaveOutCold s_cold[kWavesPerBlock];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
             NoNext nn;
             process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
         }
-        uint32_t parity = 0;
+        uint32_t parity = 0, level_reached = 1;
         for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
             // ---- level boundary: everybody's children are written, the cursors turn over
             if (wo.cur == kNoSpace && lane == 0) s_stop = 1;  // overflow: the host redoes the batch
@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
             }
             ACL_MARK(wo, PH_BARRIER);
             if (stop || !cnt) break;
+            level_reached = level;
             wo.lfill = &s_fill[level % 3];
             uint32_t *const next_seg = &s_next[level % 3];
             LocalWalk lw{bufs[parity], cnt, 0u, lane, false};
@@ -1178,6 +1179,7 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
                 }
             }
         }
+        if (max_level && threadIdx.x == 0) atomicMax(max_level, level_reached);  // (statistics: dispatch levels the deepest request of the batch needed)
         // ---- answers (k_finalize): every wave's has[] / err[] stores are behind a block barrier
         __syncthreads();
         if (valid) {
@@ -1557,13 +1559,13 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
     }
 }
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
-                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level) {
     const uint32_t nunits = (n + rpw - 1) / rpw;
     const dim3 grid(nblocks);
     if (g.nslots + g.nops <= kProgLdsEntries && prog_in_lds())
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), prog_lds_bytes(g), s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), prog_lds_bytes(g), s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
     else
-        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out);
+        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
 }
 int local_grid_blocks(int device, size_t prog_bytes) {
     hipDeviceProp_t prop;

@@ -87,7 +87,8 @@ void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, cons
 // single-launch Check: units of rpw (<= 256) consecutive requests; block b (of nblocks) walks units b, b + nblocks, ... through every
 // level with a private frontier of `cap` entries in each of buf0 / buf1 (regions b * cap); next_unit: zeroed device counter, needed when there are more units than blocks; *overflow != 0 afterwards: redo on the level loop
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
-                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out);
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
+                        uint32_t *max_level = nullptr /* device word (zeroed): atomicMax of the dispatch levels the units needed */);
 // blocks of the single-launch kernel that are resident at once on this device
 int local_grid_blocks(int device, size_t prog_bytes);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
