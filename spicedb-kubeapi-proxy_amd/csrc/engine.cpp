@@ -462,6 +462,7 @@ static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     G.nblocks = std::max<uint32_t>(std::min<uint32_t>(G.nunits, blocks), 1);
     // (a block that needs more than 256 K entries is walking something the whole chip should walk: the level loop takes the batch)
     G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / G.nblocks, 1u << 18);
+    if (h->local_cap_limit) G.cap = std::min(G.cap, h->local_cap_limit);
     return G;
 }
 
@@ -530,6 +531,18 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     return ACL_OK;
 }
 
+// A graph whose walks keep outgrowing the blocks' private regions should not pay for a failed walk before every level loop: after an
+// overflow the walk sits out 2, 4, ... 64 large passes before it is tried again.
+static bool walk_allowed(acl_engine *h, size_t n) {
+    if (n < kComputeTokenItems) return true;
+    return !(h->local_skip.load(std::memory_order_relaxed) > 0 && h->local_skip.fetch_sub(1, std::memory_order_relaxed) > 0);
+}
+static void walk_outcome(acl_engine *h, size_t n, int rc) {
+    if (n < kComputeTokenItems) return;
+    if (rc == kTakeLevelLoop) h->local_skip.store(1 << std::min(6, 1 + h->local_fail_streak.fetch_add(1, std::memory_order_relaxed)), std::memory_order_relaxed);
+    else if (!rc) h->local_fail_streak.store(0, std::memory_order_relaxed);
+}
+
 constexpr int kRetryMerging = -1002;  // internal: the level loop ran out of frontier on its first attempt
 
 // the level-synchronous pass (one k_expand launch per dispatch level); `merging`: duplicate entries are struck after every level
@@ -587,8 +600,9 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
     DevGraph g = h->dev_graph();
     // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
     // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
-    if (try_local && n <= h->local_max_items) {
+    if (try_local && n <= h->local_max_items && walk_allowed(h, n)) {
         int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
+        walk_outcome(h, n, rc);
         if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a block ran out of private frontier, the level-synchronous path takes the batch
     }
     int rc = levels_pass(h, c, g, d_items, n, d_perm, d_errout, false);
@@ -642,7 +656,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     // Chained (chip-filling) batches: at most three contexts' streams carry such a batch at a time, copies included -- the runtime multiplexes
     // streams onto 4 hardware queues, and a fourth busy stream sharing a queue with one that waits for an event halves everybody's
     // throughput (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3).  Further callers queue here.
-    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && walk_allowed(h, n);
     struct ChainSlot {
         acl_engine *h;
         bool held = false;
@@ -692,6 +706,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
             }
             if (!rc) rc = local_finish(h, c, (uint32_t)n);
             else if (rc != kTakeLevelLoop) (void)hipStreamSynchronize(c->stream);
+            walk_outcome(h, n, rc);
             slot.release();
         }
         if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time
@@ -1103,6 +1118,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
     h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
+    if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
     if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;

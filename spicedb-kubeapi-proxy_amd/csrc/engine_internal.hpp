@@ -230,6 +230,8 @@ struct acl_engine {
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
     hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
     int grid_blocks = 2048;
+    std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
+    uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
     int local_blocks = 1024;   // resident blocks of the single-launch kernel
     uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
                                // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round

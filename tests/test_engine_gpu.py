@@ -206,6 +206,31 @@ def test_edge_cases(aclgpu):
         assert e.check_bulk_ids(far)[0].tolist() == [1]
 
 
+def test_walk_overflow_falls_back_and_backs_off(aclgpu, monkeypatch):
+    """A block of the single-launch walk that outgrows its private frontier region hands the batch to the level loop (same answers);
+    after such an overflow large batches skip the walk for 2, 4, ... passes instead of paying for a failed walk every time."""
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.05, batch=40000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rt, perm, st = w.check
+    op, oe = o.check_bulk_ids_mt(4, rt, perm, w.res, st, "", w.subj)
+    monkeypatch.setenv("ACL_LOCAL_CAP", "256")  # (read at acl_open)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        items = e.make_items(rt, perm, w.res, st, "", w.subj)
+        e.stats_reset()
+        for _ in range(7):
+            p, er = e.check_bulk_ids(items)
+            assert np.array_equal(p, op) and np.array_equal(er, oe)
+        s_ = e.stats()
+        assert s_["check_passes"] == 7 and s_["local_passes"] == 0 and s_["expand_launches"] > 0
+        # small batches still try the walk (and fall back) every time: nothing to back off from at their cost
+        p, er = e.check_bulk_ids(items[:64])
+        assert np.array_equal(p, op[:64]) and np.array_equal(er, oe[:64])
+
+
 def test_frontier_overflow_grows(aclgpu):
     """A frontier too small for the batch is grown and the pass redone -- same answers."""
     from aclgpu import workloads
