@@ -294,9 +294,6 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 // per step with branch-free loads (dummy in-range addresses for inactive lanes), so the edge, descriptor and bucket
 // gathers of 64 x kSimpleWidth children are in flight together instead of 64 at a time behind three dependent waits.
 // Bit-for-bit the same decisions, the same output entries in the same order as the generic path.
-#ifndef ACL_FLUSH_PER_OP
-#define ACL_FLUSH_PER_OP 1  // A/B on C4: level 1 87 -> 75 us (its group-viewer children take flush_simple), 435 -> 439 M/s
-#endif
 #ifndef ACL_SIMPLE_WIDTH
 #define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
 #endif
