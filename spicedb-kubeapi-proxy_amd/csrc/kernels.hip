@@ -122,14 +122,13 @@ __device__ unsigned long long acl_phase_cycles[16];
 
 // LDS-staged task list of one wave.
 struct TaskLds {
-    uint32_t start[kTaskCap];  // first edge (absolute index) -- or the object id for a "self" task
+    uint4 a[kTaskCap];         // x: first edge (absolute index) -- or the object id for a "self" task; flush_simple turns it into "first edge minus
+                               //    first work item" (edge index = x + work item).  y, z: the hashed row the children are probed in (first bucket,
+                               //    bucket count; {0, 1} = the reserved empty bucket).  w: the request.  One 16-byte read per child instead of four.
     uint32_t count[kTaskCap];  // degree (| kSelfBit | kLeafAuthBit)
-    uint32_t req[kTaskCap];
     uint32_t meta[kTaskCap];   // child meta
     uint32_t sid[kTaskCap];
-    uint32_t b0[kTaskCap];     // flush_simple: the hashed row the children are probed in (the request subject's row of the child's one probe op):
-    uint32_t nb[kTaskCap];     //   first bucket and bucket count; {0, 1} = the reserved empty bucket when the subject has no row
-    uint32_t scan[kTaskCap];   // generic expansion: exclusive prefix of a round's 64 degrees; flush_simple: first edge minus first work item, per task
+    uint32_t scan[64];         // generic expansion / flush_probes: exclusive prefix of a round's 64 degrees
     uint64_t heads[kHeadWords];  // flush_simple: bit (w & 63) of word (w >> 6) set <=> a task's children start at work item w
 };
 
@@ -345,15 +344,15 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                     const uint32_t sidt = t.sid[i];
                     const uint2 d = gld(reinterpret_cast<const uint2 *>(g.meta), pop.base + (sidt < pop.nrows ? sidt : 0u));
                     const bool row = sidt < pop.nrows && d.y > d.x;
-                    t.b0[i] = row ? d.x : 0u;
-                    t.nb[i] = row ? d.y - d.x : 1u;
+                    t.a[i].y = row ? d.x : 0u;
+                    t.a[i].z = row ? d.y - d.x : 1u;
                 }
             }
         }
         if (lane < kHeadWords) t.heads[lane] = 0ull;
         // first edge of the task minus its first work item: edge index = this + work item
-        t.scan[lane] = (mine0 ? t.start[lane] : 0u) - excl0;
-        t.scan[64u + lane] = (mine1 ? t.start[64u + lane] : 0u) - excl1;
+        if (mine0) t.a[lane].x -= excl0;
+        if (mine1) t.a[64u + lane].x -= excl1;
         wave_lds_fence();
         if (mine0) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl0 >> 6]), 1ull << (excl0 & 63u));
         if (mine1) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl1 >> 6]), 1ull << (excl1 & 63u));
@@ -379,7 +378,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 const uint32_t j = before + __builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, 0u)) + (uint32_t)((hw >> lane) & 1ull) - 1u;
                 before += (uint32_t)__popc(hlo) + (uint32_t)__popc(hhi);
                 tj[k] = gq + j;
-                edge[k] = gld(edges, t.scan[j] + wv);
+                edge[k] = gld(edges, t.a[j].x + wv);
             }
             issue_fence();  // trip 1: every edge of the step
             ACL_MARK(wo, PH_EDGES);
@@ -387,11 +386,14 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
             for (int k0 = 0; k0 < E; k0 += W) {
                 if (w0 + 64u * k0 >= total) break;  // (uniform)
                 uint4 p[W], q[W];
+                uint32_t rq[W];
 #pragma unroll
                 for (int k = 0; k < W; k++) {
+                    const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, bucket count, request} in one 16-byte read
+                    rq[k] = ta.w;
                     uint32_t h1, h2;
-                    hashed_row_buckets(edge[k0 + k] & kIdMask, t.nb[tj[k0 + k]], &h1, &h2);
-                    const uint32_t b0 = t.b0[tj[k0 + k]];
+                    hashed_row_buckets(edge[k0 + k] & kIdMask, ta.z, &h1, &h2);
+                    const uint32_t b0 = ta.y;
                     p[k] = gld(buckets, b0 + h1);
                     q[k] = gld(buckets, b0 + h2);
                 }
@@ -414,7 +416,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 // (vmcnt counts stores too, and the compiler must assume the store was not issued)
 #pragma unroll
                 for (int k = 0; k < W; k++)
-                    if (hit[k]) has[t.req[tj[k0 + k]]] = 1;
+                    if (hit[k]) has[rq[k]] = 1;
                 if (np) {
                     const uint32_t base = reserve<LOCAL>(wo, np, lane);
                     if (base != kNoSpace) {
@@ -422,7 +424,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                         for (int k = 0; k < W; k++)
                             if (push[k])
                                 gst(out, base + pre[k] + lanes_below(pb[k]),
-                                    make_uint4(edge[k0 + k] & kIdMask, t.req[tj[k0 + k]], t.meta[tj[k0 + k]] | kProbedBit, t.sid[tj[k0 + k]]));
+                                    make_uint4(edge[k0 + k] & kIdMask, rq[k], t.meta[tj[k0 + k]] | kProbedBit, t.sid[tj[k0 + k]]));
                     }
                 }
                 ACL_MARK(wo, PH_PUSH);
@@ -465,7 +467,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             const uint32_t sid = t.sid[tj];
             const uint32_t level = meta_level(t.meta[tj]);
             // trip 1: the edge and the subject's row descriptor of every probe
-            const uint32_t edge = gld(edges, t.start[tj] + (wv - t.scan[j]));
+            const uint32_t edge = gld(edges, t.a[tj].x + (wv - t.scan[j]));
             uint2 hd[2];
             bool hrow[2];
 #pragma unroll
@@ -503,7 +505,7 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                     if (inrow && md.y > md.x && level + lo.dlevel <= kMaxLevels) push = true;
                 }
             }
-            const uint32_t req = t.req[tj], meta = t.meta[tj];
+            const uint32_t req = t.a[tj].w, meta = t.meta[tj];
             hit = hit && valid;
             push = push && valid;
             if (hit) {
@@ -616,10 +618,10 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                 for (uint32_t step = 32; step >= 1; step >>= 1)
                     if (t.scan[j + step] <= w) j += step;
                 const uint32_t tj = gq + j;
-                const uint32_t c = t.count[tj], s = t.start[tj];
+                const uint32_t c = t.count[tj], s = t.a[tj].x;
                 const uint32_t edge = (c & kSelfBit) ? s : gld(edges, s + (w - t.scan[j]));
                 const uint32_t child = INLINE ? (edge & kIdMask) : edge;
-                e = make_uint4(child, t.req[tj], t.meta[tj], t.sid[tj]);
+                e = make_uint4(child, t.a[tj].w, t.meta[tj], t.sid[tj]);
                 push = true;
                 if (INLINE && SHARDED && progs[meta_slot(e.z)].owner != sh.rank) {
                     // the child's rows live on another shard: it leaves unprobed and is evaluated by its owner
@@ -787,13 +789,10 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 const uint64_t b = __ballot(want);
                 if (want) {
                     const uint32_t q = Tb + lanes_below(b);
-                    t.start[q] = md.x;
+                    t.a[q] = make_uint4(md.x, sd.x, sd.y, se.y);
                     t.count[q] = (md.y - md.x) | ((L.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
-                    t.req[q] = se.y;
                     t.meta[q] = make_meta(L.key, Lv + 1, meta_key(se.z));
                     t.sid[q] = se.w;
-                    t.b0[q] = sd.x;
-                    t.nb[q] = sd.y;
                 }
                 return (uint32_t)__popcll(b);
             };
@@ -886,9 +885,8 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             if (b) {
                 if (want) {
                     const uint32_t q = T + lanes_below(b);
-                    t.start[q] = tstart;
+                    t.a[q] = make_uint4(tstart, 0u, 1u, req);  // (the subject's row is looked up by the expansion that needs it)
                     t.count[q] = tcount;
-                    t.req[q] = req;
                     t.meta[q] = tmeta;
                     t.sid[q] = sid;
                 }
@@ -912,10 +910,11 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         for (uint32_t k = 0; k < nseg; k++) {
             const uint32_t bnd = seg_end[k], cnt = bnd - a;  // cnt <= 64
             if (a) {  // bring the segment to the front of the list (expansions address tasks from 0)
-                uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-                if (lane < cnt) { c0 = t.start[a + lane]; c1 = t.count[a + lane]; c2 = t.req[a + lane]; c3 = t.meta[a + lane]; c4 = t.sid[a + lane]; }
+                uint4 c0 = make_uint4(0, 0, 0, 0);
+                uint32_t c1 = 0, c3 = 0, c4 = 0;
+                if (lane < cnt) { c0 = t.a[a + lane]; c1 = t.count[a + lane]; c3 = t.meta[a + lane]; c4 = t.sid[a + lane]; }
                 wave_lds_fence();
-                if (lane < cnt) { t.start[lane] = c0; t.count[lane] = c1; t.req[lane] = c2; t.meta[lane] = c3; t.sid[lane] = c4; }
+                if (lane < cnt) { t.a[lane] = c0; t.count[lane] = c1; t.meta[lane] = c3; t.sid[lane] = c4; }
             }
             flush_tasks<true, SHARDED, LOCAL>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh);
             a = bnd;
@@ -1176,7 +1175,9 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
                 }
             }
         }
-        if (max_level && threadIdx.x == 0) atomicMax(max_level, level_reached);  // (statistics: dispatch levels the deepest request of the batch needed)
+        // (statistics: dispatch levels the deepest request of the batch needed.  Test before the atomic: 2 048 blocks ending together on
+        //  one address serialise at ~12 ns each -- C2's 18 us kernel took 38 us with an unconditional atomicMax.)
+        if (max_level && threadIdx.x == 0 && level_reached > __hip_atomic_load(max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_level, level_reached);
         // ---- answers (k_finalize): every wave's has[] / err[] stores are behind a block barrier
         __syncthreads();
         if (valid) {
@@ -1359,9 +1360,8 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
             if (b) {
                 if (want) {
                     const uint32_t q = T + lanes_below(b);
-                    t.start[q] = tstart;
+                    t.a[q] = make_uint4(tstart, 0u, 1u, req);
                     t.count[q] = tcount;
-                    t.req[q] = req;
                     t.meta[q] = tmeta;
                     t.sid[q] = 0;
                 }
