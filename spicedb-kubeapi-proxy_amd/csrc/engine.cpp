@@ -496,6 +496,34 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
     return rc ? rc : local_finish(h, c, n);
 }
 
+static bool walk_allowed(acl_engine *h, size_t n);
+static void walk_outcome(acl_engine *h, size_t n, int rc);
+
+// Chip-filling single-launch passes follow each other ON THE DEVICE: the context's stream waits for the event behind the previous
+// such kernel, the kernel is enqueued (context buffers d_items -> d_perm / d_errout), its own event becomes the one the next pass
+// waits for.  Nothing is synchronised here.  kChainDeclined: take the turn-taking path instead (batch too small, walk switched off / backing off).
+int chained_enqueue(acl_engine *h, PassCtx *c, size_t n) {
+    if (!(n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && walk_allowed(h, n))) return kChainDeclined;
+    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+    std::lock_guard<std::mutex> ck(h->chain_mu);
+    hipError_t he = h->chain_prev ? hipStreamWaitEvent(c->stream, h->chain_prev, 0) : hipSuccess;
+    if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
+    int rc = local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
+    if (rc == kTakeLevelLoop) return kChainDeclined;
+    if (rc) return rc;
+    he = hipEventRecord(c->chain_ev, c->stream);
+    if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipEventRecord: ") + hipGetErrorString(he));
+    h->chain_prev = c->chain_ev;
+    return ACL_OK;
+}
+// ... and its other half: synchronises the context's stream.  kChainDeclined: a block ran out of private frontier -- redo on the level loop.
+int chained_finish(acl_engine *h, PassCtx *c, size_t n) {
+    int rc = local_finish(h, c, (uint32_t)n);
+    walk_outcome(h, n, rc);
+    return rc == kTakeLevelLoop ? kChainDeclined : rc;
+}
+
 // The same for a batch in HOST memory, with no copy engine in the path: the kernel reads the items from pinned host memory
 // and writes the answers (and its overflow flag) straight back into pinned host memory, so a pass is ONE launch and ONE
 // stream synchronisation -- no H2D, no flag memset, no D2H copies, each of which costs a few microseconds of API time that a
@@ -656,7 +684,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     // Chained (chip-filling) batches: at most three contexts' streams carry such a batch at a time, copies included -- the runtime multiplexes
     // streams onto 4 hardware queues, and a fourth busy stream sharing a queue with one that waits for an event halves everybody's
     // throughput (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3).  Further callers queue here.
-    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && walk_allowed(h, n);
+    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
     struct ChainSlot {
         acl_engine *h;
         bool held = false;
@@ -691,22 +719,10 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
         //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
         if (chained) {
-            HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
-            HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-            {
-                std::lock_guard<std::mutex> ck(h->chain_mu);
-                hipError_t he = h->chain_prev ? hipStreamWaitEvent(c->stream, h->chain_prev, 0) : hipSuccess;
-                rc = he == hipSuccess ? local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p)
-                                      : fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
-                if (!rc) {
-                    he = hipEventRecord(c->chain_ev, c->stream);
-                    if (he == hipSuccess) h->chain_prev = c->chain_ev;
-                    else rc = fail(ACL_ERR_INTERNAL, std::string("hipEventRecord: ") + hipGetErrorString(he));
-                }
-            }
-            if (!rc) rc = local_finish(h, c, (uint32_t)n);
-            else if (rc != kTakeLevelLoop) (void)hipStreamSynchronize(c->stream);
-            walk_outcome(h, n, rc);
+            rc = chained_enqueue(h, c, n);
+            if (!rc) rc = chained_finish(h, c, n);
+            else if (rc != kChainDeclined) (void)hipStreamSynchronize(c->stream);
+            if (rc == kChainDeclined) rc = kTakeLevelLoop;
             slot.release();
         }
         if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time

@@ -361,6 +361,9 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
 // many items: split over host threads when the batch is large
 void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 void intern_pool_destroy(acl_engine_t *h);
+constexpr int kChainDeclined = -1003;  // internal: chained_enqueue / chained_finish hand the batch to the turn-taking path
+int chained_enqueue(acl_engine *h, PassCtx *c, size_t n);  // context buffers d_items -> d_perm / d_errout; nothing synchronised
+int chained_finish(acl_engine *h, PassCtx *c, size_t n);
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
 int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
