@@ -10,7 +10,7 @@ BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
                     acl_check_bulk_ids -- what goroutines behind the cgo shim do -- so that the copies of one batch overlap
                     the kernels of another (the engine's evaluation contexts, one HIP stream each; chip-filling batches'
                     kernels follow each other on the device: each waits for the previous one's event).  `--pipeline submit`
-                    times acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead.  Measured
+                    times acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead (window 2: the same rate).  Measured
                     (profiles/r02_hostid_modes_chained.txt): 1 caller 570 M/s, 2 callers 750 M/s, 3 callers 745 M/s
                     (4: 566 M/s: at most three chained batches in flight); kernels alone (device_resident) 755-770 M/s.
   device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
