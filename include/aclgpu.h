@@ -65,7 +65,7 @@ enum { ACL_PRE_MUST_NOT_MATCH = 1, ACL_PRE_MUST_MATCH = 2 };
 
 typedef struct {
     int32_t device;              /* HIP device ordinal; -1 = current (LOCAL_RANK for one-process-per-GPU) */
-    uint64_t frontier_entries;   /* capacity of EACH of the two frontier buffers, in 16-byte entries; 0 = default */
+    uint64_t frontier_entries;   /* capacity of EACH of the two frontier buffers, in 16-byte entries; 0 = default (32 M: 512 MiB each, per context) */
     uint32_t max_sub_batch;      /* Check items evaluated per device pass; 0 = default */
     uint32_t flags;              /* ACL_FLAG_* */
     uint32_t contexts;           /* evaluations that may be in flight on the device at once (each has its own HIP stream,
@@ -166,8 +166,10 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
  * Buffers must stay valid until the wait returns; a batch keeps its evaluation context until it is waited for, so wait in
  * submission order.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up to
- * three batches ahead (context + H2D) while contexts are free, runs the batches' kernels strictly one after the other,
- * and each batch's D2H drains while the next one's kernels run.  Smaller batches simply run concurrently. */
+ * three batches ahead (context + H2D) while contexts are free, runs the batches' kernels strictly one after the other
+ * (from 131 072 items on they are chained ON THE DEVICE -- each stream waits for the event behind the previous kernel -- and
+ * the waiter completes the pass), and each batch's D2H drains while the next one's kernel runs.  Keep two tickets in flight:
+ * measured 785 M decisions/s on C4 against 566 M/s for one and 395 M/s for three.  Smaller batches simply run concurrently. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);
