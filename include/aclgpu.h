@@ -238,6 +238,23 @@ int acl_batcher_stop(acl_engine_t *h);
 int acl_batcher_stats(acl_engine_t *h, uint64_t *batches, uint64_t *items);
 int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out);
 int acl_check_one_opts(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
+/* The same check without an OS thread blocked per request -- the form a cgo shim should bind: the goroutine that issues
+ * check.go:48 / watch.go:50 parks on a Go channel and ONE poller goroutine drains the completions.  With
+ * acl_check_one every check costs the host a futex sleep + wake-up (~17 us of kernel time per check on the measured hosts:
+ * a ~0.9 M checks/s ceiling on 16 cores, whatever the device does); here a wake-up is paid per device pass.
+ * acl_check_one_submit returns at once (needs a running batcher; `tag` is the caller's); acl_check_completions takes up to
+ * `max` finished checks, blocking while there are none (timeout_ns < 0: until one arrives, 0: never, > 0: at most that
+ * long).  rc / err / perm are what acl_check_one would have returned / stored.  Any number of threads may submit and poll;
+ * each completion is delivered once; completions not yet collected when the batcher stops stay collectable. */
+typedef struct {
+    uint64_t tag;
+    int32_t rc;   /* ACL_OK, or the status of the device pass that carried the item */
+    int32_t err;  /* per-item error (0 = none), as acl_check_one's err_out */
+    uint8_t perm; /* ACL_PERM_* */
+    uint8_t pad[3];
+} acl_completion_t;
+int acl_check_one_submit(acl_engine_t *h, const acl_check_item_t *item, uint64_t tag);
+int acl_check_completions(acl_engine_t *h, acl_completion_t *out, size_t max, int64_t timeout_ns, size_t *n_out);
 /* the same for Filter requests (lookups.go:65; one LookupResources per list request, each from its own goroutine:
  * responsefilterer.go:165): concurrent requests with the same (resource type, permission, subject class) share ONE
  * batched reverse walk.  Arguments as acl_lookup_resources. */

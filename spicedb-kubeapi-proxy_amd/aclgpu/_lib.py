@@ -26,7 +26,7 @@ SYMBOLS = [
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
-    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_selfcheck_compaction",
+    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
 ]
 
 
@@ -55,6 +55,11 @@ class Filter(C.Structure):
 
 class CheckItem(C.Structure):
     _fields_ = [(n, C.c_char_p) for n in ("resource_type", "resource_id", "permission", "subject_type", "subject_id", "subject_relation")]
+
+
+class Completion(C.Structure):
+    """acl_completion_t: one answered acl_check_one_submit."""
+    _fields_ = [("tag", C.c_uint64), ("rc", C.c_int32), ("err", C.c_int32), ("perm", C.c_uint8), ("pad", C.c_uint8 * 3)]
 
 
 class Stats(C.Structure):
@@ -169,6 +174,8 @@ def load():
     L.acl_free.argtypes = [C.c_void_p]
     L.acl_free.restype = None
     L.acl_check_one_opts.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(CallOpts)]
+    L.acl_check_one_submit.argtypes = [H, C.POINTER(CheckItem), C.c_uint64]
+    L.acl_check_completions.argtypes = [H, C.POINTER(Completion), C.c_size_t, C.c_int64, C.POINTER(C.c_size_t)]
     L.acl_lookup_one_opts.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                       C.POINTER(CallOpts)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CallOpts, CheckItem, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
+from ._lib import CallOpts, CheckItem, Completion, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
 
 PERM_UNSPECIFIED, PERM_NO, PERM_HAS, PERM_CONDITIONAL = 0, 1, 2, 3
 OP_CREATE, OP_TOUCH, OP_DELETE = 1, 2, 3
@@ -373,6 +373,21 @@ class Engine:
         o = self._opts(cancel, timeout_s)
         self._check(self._L.acl_check_one_opts(self._h, C.byref(it), C.byref(p), C.byref(e), C.byref(o) if o else None))
         return p.value, e.value
+
+    def check_one_submit(self, rt, rid, perm, st, sid, srel="", tag=0):
+        """acl_check_one without a blocked thread: returns at once; the answer arrives, tagged, through check_completions().
+        This is the form a cgo shim binds (a goroutine parks on a channel, one poller drains the queue).  Needs a running batcher."""
+        it = CheckItem(*[_b(x if x is not None else "") for x in (rt, rid, perm, st, sid, srel)])
+        self._check(self._L.acl_check_one_submit(self._h, C.byref(it), int(tag)))
+
+    def check_completions(self, max_items=256, timeout_s=-1.0):
+        """Up to max_items answered submissions as (tag, rc, err, perm); blocks while there are none (timeout_s < 0: until one
+        arrives, 0: never).  Releases the GIL."""
+        buf = (Completion * max(1, max_items))()
+        n = C.c_size_t()
+        t = -1 if timeout_s < 0 else int(timeout_s * 1e9)
+        self._check(self._L.acl_check_completions(self._h, buf, max_items, t, C.byref(n)))
+        return [(int(buf[i].tag), int(buf[i].rc), int(buf[i].err), int(buf[i].perm)) for i in range(n.value)]
 
     def lookup_one(self, rt, perm, st, sid, srel="", cancel=None, timeout_s=None):
         """One LookupResources request (lookups.go:65) -> set of resource ids; concurrent callers with the same (type,

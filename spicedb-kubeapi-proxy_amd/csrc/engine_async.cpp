@@ -39,12 +39,12 @@ namespace {
 
 void finish(acl_ticket *t, int rc) {
     std::string msg = rc ? acl_last_error() : "";
-    {
-        std::lock_guard<std::mutex> lk(t->mu);
-        t->rc = rc;
-        t->msg = std::move(msg);
-        t->done = true;
-    }
+    // (notified under the lock: the waiter deletes the ticket as soon as it has seen `done`, so nothing of *t may be touched
+    //  once the lock is gone)
+    std::lock_guard<std::mutex> lk(t->mu);
+    t->rc = rc;
+    t->msg = std::move(msg);
+    t->done = true;
     t->cv.notify_one();
 }
 

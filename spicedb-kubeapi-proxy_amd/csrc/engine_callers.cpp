@@ -20,8 +20,14 @@
 //     re-enqueue at once and convoy on that mutex: 420 k/s at 64 threads, 56 k/s at 1 024.
 // Now: kQueues independent queues (a caller uses the one its thread hashes to: a few dozen nanoseconds under a lock it
 // shares with 1/16 of the callers), each holding an open sub-batch with its own futex word.  Dispatcher threads -- one
-// per evaluation context, so passes overlap on the device -- sleep on a counter of queued requests, sweep all queues,
-// answer what they found with ONE device pass and wake every sub-batch's callers with one futex call each.
+// per evaluation context, so passes overlap on the device -- sleep on a counter of queued requests, sweep all queues and
+// answer what they found with ONE device pass.
+//   * waking every caller from the dispatcher (one FUTEX_WAKE of INT_MAX per sub-batch) made the DISPATCHERS the limit: a wake-up of a
+//     sleeping thread costs the waker 4-9 us on these (virtualised) hosts, so four dispatchers could release at most ~0.8 M callers
+//     per second whatever the device did (64 / 256 / 1 024 threads all sat at dispatchers / wake cost).
+// Now the dispatcher wakes ONE sleeper per sub-batch and every caller that leaves a finished sub-batch wakes up to `fanout` (2) more of
+// its sleepers: the wake-ups run on the callers' cores, in a tree (profiles/r02_batcher_ab.txt: 256 threads 0.70-0.80 -> 0.90 M/s, 1 024
+// threads 0.38 -> 0.46 M/s; fewer queues for small passes -- more callers per tree -- lost more to lock convoys than the trees won).
 namespace {
 
 inline long futex(std::atomic<uint32_t> *addr, int op, uint32_t val, const timespec *ts) {
@@ -39,8 +45,15 @@ struct LookupReq {
     uint64_t count = 0;
 };
 
+struct AsyncRef {  // an item submitted through acl_check_one_submit: nobody sleeps on it, its answer goes to the completion queue
+    uint32_t idx;
+    uint64_t tag;
+};
+
 struct Batch {  // the callers of one queue between two sweeps
     std::atomic<uint32_t> done{0};
+    std::atomic<uint32_t> sleeping{0};  // callers inside (or about to enter) futex_wait on `done`
+    std::vector<AsyncRef> async_items;
     std::atomic<uint32_t> refs{1};  // the queue's own reference + one per caller
     std::vector<acl_item_t> items;
     std::vector<uint8_t> perm;
@@ -73,6 +86,23 @@ struct acl_engine::Batcher {
     std::atomic<uint64_t> batches{0}, items{0}, lookup_walks{0}, lookups{0};
     std::atomic<uint32_t> sleepers{0};
     unsigned cores = 1;
+    // wake-up tree (see the top of this file); knobs for A/B runs: ACL_BATCHER_CHAIN=0 restores "the dispatcher wakes everybody",
+    // ACL_BATCHER_FANOUT, ACL_BATCHER_QUEUES (queues in use, <= 16), ACL_BATCHER_DISPATCHERS, ACL_BATCHER_SPINNERS
+    bool chain = true;
+    uint32_t fanout = 2, max_spinners = 0;
+    // a sleep + wake-up of a thread costs 20-100 us of latency on these hosts, more than a pass: dispatchers and completion pollers spin
+    // this long before they go to sleep (ACL_BATCHER_IDLE_SPIN_US, ACL_BATCHER_POLL_SPIN_US), and the batching window (<= 100 us) is spun
+    uint32_t idle_spin_us = 0, poll_spin_us = 0;
+    uint32_t active_queues = kQueues;
+    // host-side tuning aid, store-only engines only: their passes are refused (UNAVAILABLE: no GPU, no evaluation -- never an answer)
+    // at once; ACL_BATCHER_SIM_PASS_US makes the refusal take as long as a device pass would, so that the queueing / wake-up
+    // machinery can be timed on a box without a GPU (tools/batcher_bench with that variable set)
+    uint32_t sim_pass_us = 0;
+    // completion queue of acl_check_one_submit (see there)
+    std::mutex cq_mu;
+    std::deque<acl_completion_t> cq;
+    alignas(64) std::atomic<uint32_t> cq_seq{0};  // bumped on every push; pollers sleep on it (futex)
+    std::atomic<uint32_t> cq_waiters{0};
 };
 
 namespace {
@@ -91,6 +121,10 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
         for (Batch *b : subs) items.insert(items.end(), b->items.begin(), b->items.end());
         std::vector<uint8_t> perm(n);
         std::vector<int32_t> err(n);
+        if (h->store_only && B.sim_pass_us) {  // (timing aid: the refusal below arrives after what a device pass would take)
+            const int64_t until = mono_ns() + (int64_t)B.sim_pass_us * 1000;
+            while (mono_ns() < until) __builtin_ia32_pause();
+        }
         const int rc = acl_check_bulk_ids(h, items.data(), n, perm.data(), err.data());
         const std::string msg = rc ? acl_last_error() : "";
         size_t o = 0;
@@ -104,6 +138,19 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
         }
         B.batches++;
         B.items += n;
+        // answers nobody waits for in person: one push, one poller woken (it wakes the next if it leaves work behind)
+        size_t na = 0;
+        for (Batch *b : subs) na += b->async_items.size();
+        if (na) {
+            {
+                std::lock_guard<std::mutex> g(B.cq_mu);
+                for (Batch *b : subs)
+                    for (const AsyncRef &a : b->async_items)
+                        B.cq.push_back(acl_completion_t{a.tag, rc, rc ? 0 : b->err[a.idx], rc ? (uint8_t)ACL_PERM_UNSPECIFIED : b->perm[a.idx], {0, 0, 0}});
+            }
+            B.cq_seq.fetch_add(1, std::memory_order_seq_cst);
+            if (B.cq_waiters.load(std::memory_order_seq_cst)) futex(&B.cq_seq, FUTEX_WAKE_PRIVATE, 1, nullptr);
+        }
     }
     // LookupResources: one batched reverse walk per (resource type, permission, subject class)
     if (nl) {
@@ -144,8 +191,10 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
     // find the batching window open, not a stale "a pass is in flight, go now"
     B.in_flight.fetch_sub(1, std::memory_order_relaxed);
     for (Batch *b : subs) {
-        b->done.store(1, std::memory_order_release);
-        futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this sub-batch's callers
+        // (sequentially consistent on both sides: either this thread sees the sleeper's count or the sleeper's futex_wait sees `done`)
+        b->done.store(1, std::memory_order_seq_cst);
+        if (!B.chain) futex(&b->done, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr);  // exactly this sub-batch's callers
+        else if (b->sleeping.load(std::memory_order_seq_cst)) futex(&b->done, FUTEX_WAKE_PRIVATE, 1, nullptr);  // the root of its wake-up tree
         b->unref();
     }
 }
@@ -154,6 +203,11 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
     acl_engine::Batcher &B = *h->batcher;
     std::vector<Batch *> subs;
     for (;;) {
+        if (B.idle_spin_us && B.pending.load(std::memory_order_acquire) == 0) {
+            const int64_t until = mono_ns() + (int64_t)B.idle_spin_us * 1000;
+            while (B.pending.load(std::memory_order_acquire) == 0 && mono_ns() < until)
+                for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+        }
         while (B.pending.load(std::memory_order_acquire) == 0) {
             if (B.stop.load(std::memory_order_acquire)) return;
             timespec ts{0, 2000000};  // (bounded: a stop request is noticed within 2 ms even if its wake-up is missed)
@@ -174,7 +228,11 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
                 }
                 const int64_t now = mono_ns();
                 if (now >= until) break;
-                timespec ts{0, (long)std::min<int64_t>(until - now, 50000)};
+                if (until - now <= 100000) {  // (a nanosleep of 50 us returns after 100-150 us here)
+                    for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+                    continue;
+                }
+                timespec ts{0, (long)std::min<int64_t>(until - now - 60000, 50000)};
                 nanosleep(&ts, nullptr);
             }
             if (stale) continue;
@@ -203,12 +261,12 @@ void dispatcher_loop(acl_engine_t *h, uint32_t me) {
 }
 
 // appends to the caller's queue; returns the sub-batch (one reference for the caller) and the caller's index in it
-Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, size_t *index) {
+Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, size_t *index, const uint64_t *async_tag = nullptr) {
     acl_engine::Batcher *B = h->batcher;
     if (!B || !B->running.load(std::memory_order_acquire)) return nullptr;  // no batcher running
     static std::atomic<uint32_t> next_thread{0};
-    static thread_local uint32_t my_queue = next_thread.fetch_add(1, std::memory_order_relaxed) % kQueues;
-    Queue &q = B->q[my_queue];
+    static thread_local uint32_t my_slot = next_thread.fetch_add(1, std::memory_order_relaxed);
+    Queue &q = B->q[my_slot % B->active_queues];
     Batch *b;
     {
         std::lock_guard<std::mutex> g(q.mu);
@@ -218,11 +276,12 @@ Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, siz
         if (item) {
             *index = b->items.size();
             b->items.push_back(*item);
+            if (async_tag) b->async_items.push_back(AsyncRef{(uint32_t)*index, *async_tag});
         } else {
             *index = b->lookups.size();
             b->lookups.push_back(*lk);
         }
-        b->refs.fetch_add(1, std::memory_order_relaxed);
+        if (!async_tag) b->refs.fetch_add(1, std::memory_order_relaxed);  // (a submitted item has no caller holding on to the sub-batch)
     }
     if (B->pending.fetch_add(1, std::memory_order_acq_rel) == 0) {
         B->oldest_ns.store(mono_ns(), std::memory_order_relaxed);
@@ -237,7 +296,7 @@ int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
     acl_engine::Batcher &B = *h->batcher;
     const bool watched = opts.cancel || opts.deadline_ns;
     const uint32_t parked = B.sleepers.fetch_add(1, std::memory_order_relaxed);
-    if ((parked + 4) * 2 < B.cores) {  // (+ the dispatchers, which spin in their stream syncs)
+    if (parked < B.max_spinners) {  // (cores / 2 less the dispatchers, which spin in their stream syncs)
         const int64_t spin_until = mono_ns() + 30000;
         while (!b->done.load(std::memory_order_acquire) && mono_ns() < spin_until) {
             for (int i = 0; i < 32; i++) __builtin_ia32_pause();
@@ -248,13 +307,18 @@ int await_batch(acl_engine_t *h, Batch *b, const CallOpts &opts) {
         if (watched) {
             rc = check_opts(opts);
             if (rc) break;  // the pass still answers the abandoned slot; nobody reads it
-            timespec ts{0, 500000};
-            futex(&b->done, FUTEX_WAIT_PRIVATE, 0, &ts);
-        } else {
-            futex(&b->done, FUTEX_WAIT_PRIVATE, 0, nullptr);
         }
+        // (bounded even for unwatched callers: the wake-up tree hands every sleeper's wake-up to another caller, and a missed one
+        //  must cost a hiccup, not a hang)
+        timespec ts{0, watched ? 500000 : 5000000};
+        b->sleeping.fetch_add(1, std::memory_order_seq_cst);
+        futex(&b->done, FUTEX_WAIT_PRIVATE, 0, &ts);
+        b->sleeping.fetch_sub(1, std::memory_order_seq_cst);
     }
     B.sleepers.fetch_sub(1, std::memory_order_relaxed);
+    // this caller's share of the wake-up tree: a sleeper can only have counted itself before `done` was set, and every caller that
+    // sees `done` comes through here, so as long as one sleeps somebody is still on the way to wake it
+    if (!rc && B.chain && b->sleeping.load(std::memory_order_seq_cst)) futex(&b->done, FUTEX_WAKE_PRIVATE, (uint32_t)B.fanout, nullptr);
     return rc;
 }
 
@@ -496,7 +560,20 @@ int acl_batcher_start(acl_engine_t *h, uint32_t max_items, uint32_t max_wait_us)
     B.stop.store(false);
     // one dispatcher per evaluation context the engine may open, but no more than a quarter of the usable cores (a
     // dispatcher's stream synchronisation spins); store-only engines: one, it only reports the error
-    const uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({h->max_ctx, 4u, std::max(1u, B.cores / 4)}));
+    uint32_t nd = h->store_only ? 1u : std::max<uint32_t>(1, std::min<uint32_t>({h->max_ctx, 4u, std::max(1u, B.cores / 4)}));
+    auto knob = [](const char *name, uint32_t dflt) {
+        const char *e = std::getenv(name);
+        return e && *e ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
+    };
+    B.chain = knob("ACL_BATCHER_CHAIN", 1) != 0;
+    B.fanout = std::max<uint32_t>(1, knob("ACL_BATCHER_FANOUT", 2));
+    B.active_queues = std::max<uint32_t>(1, std::min<uint32_t>(kQueues, knob("ACL_BATCHER_QUEUES", kQueues)));
+    B.max_spinners = knob("ACL_BATCHER_SPINNERS", B.cores / 2 > 4 ? B.cores / 2 - 4 : 0);
+    B.idle_spin_us = knob("ACL_BATCHER_IDLE_SPIN_US", 0);
+    B.poll_spin_us = knob("ACL_BATCHER_POLL_SPIN_US", 0);
+    B.sim_pass_us = h->store_only ? knob("ACL_BATCHER_SIM_PASS_US", 0) : 0;
+    if (B.sim_pass_us) nd = std::max<uint32_t>(1, std::min<uint32_t>(4u, std::max(1u, B.cores / 4)));
+    nd = std::max<uint32_t>(1, knob("ACL_BATCHER_DISPATCHERS", nd));
     for (uint32_t i = 0; i < nd; i++) B.threads.emplace_back(dispatcher_loop, h, i);
     B.running.store(true, std::memory_order_release);
     return ACL_OK;
@@ -580,6 +657,79 @@ int acl_check_one_opts(acl_engine_t *h, const acl_check_item_t *item, uint8_t *p
 }
 int acl_check_one(acl_engine_t *h, const acl_check_item_t *item, uint8_t *perm_out, int32_t *err_out) {
     return acl_check_one_opts(h, item, perm_out, err_out, nullptr);
+}
+
+// The same request WITHOUT a blocked OS thread per check: submit returns at once and the answer arrives, tagged, through
+// acl_check_completions.  This is the form a cgo shim wants -- the calling goroutine parks on a Go channel (a user-space switch) and
+// one poller goroutine drains the completions -- because with acl_check_one every check costs the host a futex sleep and a futex
+// wake-up: ~17 us of kernel time on the measured (virtualised, 16-core quota) hosts, i.e. a ceiling of ~0.9 M checks/s whatever the
+// device does (profiles/r02_batcher_ab.txt).  Needs a running batcher.
+int acl_check_one_submit(acl_engine_t *h, const acl_check_item_t *item, uint64_t tag) {
+    if (!item) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_one_submit: NULL item");
+    acl_engine::Batcher *B = h->batcher;
+    if (!B || !B->running.load(std::memory_order_acquire)) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_check_one_submit: no batcher running (acl_batcher_start)");
+    acl_item_t it;
+    int32_t err;
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+        err = intern_check_item(h, *item, &it);
+    }
+    if (err) {  // the pair carries its error (check.go:55), no device work: straight to the completion queue
+        {
+            std::lock_guard<std::mutex> g(B->cq_mu);
+            B->cq.push_back(acl_completion_t{tag, ACL_OK, err, (uint8_t)ACL_PERM_UNSPECIFIED, {0, 0, 0}});
+        }
+        B->cq_seq.fetch_add(1, std::memory_order_seq_cst);
+        if (B->cq_waiters.load(std::memory_order_seq_cst)) futex(&B->cq_seq, FUTEX_WAKE_PRIVATE, 1, nullptr);
+        return ACL_OK;
+    }
+    size_t idx = 0;
+    if (!enqueue(h, &it, nullptr, &idx, &tag)) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_check_one_submit: the batcher was stopped");
+    return ACL_OK;
+}
+
+// Takes up to `max` finished checks off the completion queue; blocks while it is empty (timeout_ns < 0: until something arrives,
+// 0: never, > 0: at most that long).  Any number of threads may poll; each completion is delivered once.
+int acl_check_completions(acl_engine_t *h, acl_completion_t *out, size_t max, int64_t timeout_ns, size_t *n_out) {
+    if (!n_out || (max && !out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_completions: NULL argument");
+    *n_out = 0;
+    acl_engine::Batcher *B = h->batcher;
+    if (!B) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_check_completions: engine is closing");
+    if (!max) return ACL_OK;
+    const int64_t until = timeout_ns > 0 ? mono_ns() + timeout_ns : 0;
+    for (;;) {
+        const uint32_t seq = B->cq_seq.load(std::memory_order_seq_cst);
+        bool more = false;
+        {
+            std::lock_guard<std::mutex> g(B->cq_mu);
+            size_t k = std::min(max, B->cq.size());
+            std::copy(B->cq.begin(), B->cq.begin() + (long)k, out);
+            B->cq.erase(B->cq.begin(), B->cq.begin() + (long)k);
+            *n_out = k;
+            more = !B->cq.empty();
+        }
+        if (*n_out) {
+            if (more && B->cq_waiters.load(std::memory_order_seq_cst)) futex(&B->cq_seq, FUTEX_WAKE_PRIVATE, 1, nullptr);  // work left behind: the next poller
+            return ACL_OK;
+        }
+        if (timeout_ns == 0) return ACL_OK;
+        if (B->poll_spin_us) {
+            const int64_t spin_until = mono_ns() + (int64_t)B->poll_spin_us * 1000;
+            while (B->cq_seq.load(std::memory_order_acquire) == seq && mono_ns() < spin_until)
+                for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+            if (B->cq_seq.load(std::memory_order_acquire) != seq) continue;
+        }
+        timespec ts{0, 2000000};  // (bounded: a missed wake-up costs 2 ms, not a hang)
+        if (timeout_ns > 0) {
+            const int64_t left = until - mono_ns();
+            if (left <= 0) return ACL_OK;
+            if (left < 2000000) ts.tv_nsec = (long)left;
+        }
+        B->cq_waiters.fetch_add(1, std::memory_order_seq_cst);
+        futex(&B->cq_seq, FUTEX_WAIT_PRIVATE, seq, &ts);  // returns at once if something was pushed since `seq` was read
+        B->cq_waiters.fetch_sub(1, std::memory_order_seq_cst);
+    }
 }
 
 }  // extern "C"

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_rev_seed(DevFrontier f, const uint32_t 
 template <bool SHARDED, bool LOCAL, typename Next>
 __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next &next, TaskLds &t, WaveOut &wo, uint32_t lane, const DevGraph &g,
                                                 const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh) {
-    const uint32_t id = e.x, req = e.y, meta = e.z, sid = e.w;
+    const uint32_t id = e.x, req = e.y, meta = e.z;
     // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
     // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read, the
     // row-descriptor gather and the subject's row of the child's probe are issued together (branch-free), for this segment (A)

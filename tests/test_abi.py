@@ -35,7 +35,8 @@ def test_struct_layouts(aclgpu_lib, tmp_path):
     pairs = {"acl_config_t": aclgpu._lib.Config, "acl_relationship_t": aclgpu._lib.Relationship, "acl_update_t": aclgpu._lib.Update,
              "acl_filter_t": aclgpu._lib.Filter, "acl_check_item_t": aclgpu._lib.CheckItem, "acl_stats_t": aclgpu._lib.Stats,
              "acl_shard_step_t": aclgpu._lib.ShardStep, "acl_call_opts_t": aclgpu._lib.CallOpts,
-             "acl_shard_comm_t": aclgpu._lib.ShardComm, "acl_shard_bulk_stats_t": aclgpu._lib.ShardBulkStats}
+             "acl_shard_comm_t": aclgpu._lib.ShardComm, "acl_shard_bulk_stats_t": aclgpu._lib.ShardBulkStats,
+             "acl_completion_t": aclgpu._lib.Completion}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "aclgpu.h"', 'int main(void) {']
     for cname, ct in pairs.items():
         lines.append(f'printf("{cname} %zu", sizeof({cname}));')
@@ -70,6 +71,51 @@ def test_no_gpu_means_no_evaluation(aclgpu_lib):
         with pytest.raises(aclgpu.AclError) as ei:
             call()
         assert ei.value.code == aclgpu.ERR_UNAVAILABLE
+
+
+def test_completion_queue_without_gpu(aclgpu_lib):
+    """acl_check_one_submit / acl_check_completions on a store-only engine: the queueing works, and every completion carries the
+    REFUSAL of the pass (no GPU => UNAVAILABLE), never an answer; each tag arrives exactly once; a pair that fails interning
+    completes with its own error; submitting without a batcher is refused."""
+    import threading
+    import aclgpu
+    e = aclgpu.Engine("definition user {}\ndefinition doc { relation viewer: user\n permission view = viewer }", store_only=True)
+    for i in range(50):
+        e.touch(("doc", f"d{i}", "viewer", "user", f"u{i}", ""))
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.check_one_submit("doc", "d0", "view", "user", "u0", tag=1)
+    assert ei.value.code == aclgpu.ERR_FAILED_PRECONDITION
+    e.batcher_start(max_items=64, max_wait_us=50)
+    N, M = 400, 4
+    got, errs = [[] for _ in range(M)], []
+
+    def worker(m):
+        try:
+            for k in range(m, N, M):
+                e.check_one_submit("doc", f"d{k % 50}", "view", "user", f"u{k % 50}", tag=k)
+            while True:
+                c = e.check_completions(32, timeout_s=0.2)
+                if not c:
+                    return
+                got[m] += c
+        except BaseException as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ths = [threading.Thread(target=worker, args=(m,)) for m in range(M)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs[:1]
+    allc = [c for g in got for c in g]
+    assert sorted(c[0] for c in allc) == list(range(N))
+    assert all(rc == aclgpu.ERR_UNAVAILABLE and perm == 0 for _t, rc, _e, perm in allc)
+    e.check_one_submit("nosuchtype", "x", "view", "user", "u", tag=9)
+    (tag, rc, err, perm), = e.check_completions(8, timeout_s=2.0)
+    assert (tag, rc, perm) == (9, 0, 0) and err != 0
+    assert e.check_completions(8, timeout_s=0) == []
+    e.batcher_stop()
+    e.close()
 
 
 def test_product_never_imports_oracle():

@@ -122,6 +122,80 @@ def test_micro_batcher_concurrent_single_checks(aclgpu):
         assert e.check_one("", "x", "view", "user", "u") == (0, aclgpu.ERR_INVALID_ARGUMENT)
 
 
+def test_check_one_submit_and_completions(aclgpu):
+    """The non-blocking form of acl_check_one (what a cgo shim binds): 256 logical callers, each with one check outstanding, multiplexed
+    over 4 threads that submit and poll.  Every tagged answer equals the oracle's, each completion arrives exactly once, an item that
+    fails interning completes with its error, and submitting without a batcher is refused."""
+    from aclgpu import workloads
+    w = workloads.c1()
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    with aclgpu.Engine(w.schema) as e:
+        for t, n in w.nobjects.items():
+            for i in range(n):
+                e.intern(t, f"{t}-{i}")
+        w.load(e)
+        with pytest.raises(aclgpu.AclError):
+            e.check_one_submit("namespace", "namespace-0", "view", "user", "user-0", tag=1)
+        L, PER, M = 256, 12, 4
+        rng = np.random.default_rng(11)
+        res = rng.integers(0, w.nobjects["namespace"], size=(L, PER))
+        sub = rng.integers(0, w.nobjects["user"], size=(L, PER))
+        res[:, ::2] = w.res[rng.integers(0, w.res.size, size=(L, PER // 2))]
+        want, _ = o.check_bulk_ids("namespace", "view", res.reshape(-1), "user", "", sub.reshape(-1))
+        got = np.zeros((L, PER), dtype=np.uint8)
+        seen = np.zeros((L, PER), dtype=np.int32)
+        progress = np.zeros(L, dtype=np.int64)
+        finished = [0]
+        lock = threading.Lock()
+        errs = []
+        e.batcher_start(max_items=1024, max_wait_us=100)
+
+        def submit(t):
+            k = int(progress[t])
+            progress[t] += 1
+            e.check_one_submit("namespace", f"namespace-{res[t, k]}", "view", "user", f"user-{sub[t, k]}", tag=t * 1000 + k)
+
+        def worker(m):
+            try:
+                for t in range(m, L, M):
+                    submit(t)
+                while True:
+                    with lock:
+                        if finished[0] >= L:
+                            return
+                    for tag, rc, er, p in e.check_completions(64, timeout_s=0.05):
+                        t, k = divmod(tag, 1000)
+                        assert rc == 0 and er == 0
+                        got[t, k] = p
+                        seen[t, k] += 1
+                        if progress[t] < PER:
+                            submit(t)
+                        else:
+                            with lock:
+                                finished[0] += 1
+            except BaseException as ex:  # noqa: BLE001
+                errs.append(ex)
+                with lock:
+                    finished[0] = L
+
+        ths = [threading.Thread(target=worker, args=(m,)) for m in range(M)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errs, errs[:1]
+        assert (seen == 1).all()
+        assert np.array_equal(got.reshape(-1), want)
+        st = e.batcher_stats()
+        assert st["items"] == L * PER and st["batches"] < L * PER, st
+        # a pair that fails interning completes with its error and never reaches the device
+        e.check_one_submit("", "x", "view", "user", "u", tag=77)
+        assert e.check_completions(8, timeout_s=2.0) == [(77, 0, aclgpu.ERR_INVALID_ARGUMENT, 0)]
+        assert e.check_completions(8, timeout_s=0) == []
+        e.batcher_stop()
+
+
 def test_micro_batcher_coalesces_lookups(aclgpu):
     """Concurrent LookupResources requests (one per list request in the proxy) of the same (type, permission, subject class)
     share batched reverse walks; every set equals the oracle's; requests of another class are walked separately."""
