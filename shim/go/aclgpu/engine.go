@@ -29,7 +29,10 @@ type Config struct {
 }
 
 // Engine owns one acl_engine_t.  All methods are safe for concurrent use (the C ABI is).
-type Engine struct{ h *C.acl_engine_t }
+type Engine struct {
+	h  *C.acl_engine_t
+	cq *completions // non-nil while the micro-batcher runs: single checks go through the completion queue (completions.go)
+}
 
 func lastError(rc C.int) error {
 	return status.Error(codes.Code(rc), C.GoString(C.acl_last_error())) // return codes ARE gRPC codes (aclgpu.h)
@@ -55,11 +58,17 @@ func Open(cfg Config, schema, relationships string) (*Engine, error) {
 			C.acl_close(h)
 			return nil, lastError(rc)
 		}
+		e := &Engine{h: h}
+		e.startPoller()
+		return e, nil
 	}
-	return &Engine{h}, nil
+	return &Engine{h: h}, nil
 }
 
-func (e *Engine) Close() { C.acl_close(e.h) }
+func (e *Engine) Close() {
+	e.stopPoller()
+	C.acl_close(e.h)
+}
 
 // zedToken: the store revision as an opaque token (activity.go:76 only stores and compares it).
 func (e *Engine) zedToken() *v1.ZedToken {

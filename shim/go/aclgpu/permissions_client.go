@@ -27,17 +27,30 @@ type permissionsClient struct{ e *Engine }
 func NewPermissionsClient(e *Engine) v1.PermissionsServiceClient { return &permissionsClient{e} }
 
 // CheckPermission: pkg/authz/watch.go:50 and every 1-item check expression (check.go:23-48).  Concurrent callers share
-// one device pass through the micro-batcher (acl_check_one).
+// one device pass through the micro-batcher.  With a batcher running the goroutine parks on a channel and the engine's
+// completion queue answers it (completions.go: no OS thread blocked in C per check); without one it falls back to the
+// blocking acl_check_one_opts (a device pass of its own).
 func (p *permissionsClient) CheckPermission(ctx context.Context, in *v1.CheckPermissionRequest, _ ...grpc.CallOption) (*v1.CheckPermissionResponse, error) {
 	var cs cstrings
 	defer cs.free()
 	it := cs.item(in.Resource, in.Permission, in.Subject)
 	var perm C.uint8_t
 	var perr C.int32_t
-	opts, stop := callOpts(ctx) // ctx cancellation / deadline reach the engine through acl_call_opts_t
-	defer stop()
-	if rc := C.acl_check_one_opts(p.e.h, &it, &perm, &perr, opts); rc != 0 {
-		return nil, lastError(rc)
+	if p.e.cq != nil {
+		c, err := p.e.checkOne(ctx, &it)
+		if err != nil {
+			return nil, err
+		}
+		if c.rc != 0 {
+			return nil, status.Error(codes.Code(c.rc), "check failed")
+		}
+		perm, perr = C.uint8_t(c.perm), C.int32_t(c.err)
+	} else {
+		opts, stop := callOpts(ctx) // ctx cancellation / deadline reach the engine through acl_call_opts_t
+		defer stop()
+		if rc := C.acl_check_one_opts(p.e.h, &it, &perm, &perr, opts); rc != 0 {
+			return nil, lastError(rc)
+		}
 	}
 	if perr != 0 {
 		return nil, status.Error(itemCode(perr), "check failed") // e.g. InvalidArgument for an empty request
