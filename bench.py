@@ -26,11 +26,13 @@ Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic bytes of 
 multi-threaded, with its per-level split / HIP-event kernel time vs HBM peak), `cpu_baseline` (the CPU oracle, a restatement of
 SpiceDB's dispatch -- NOT the embedded SpiceDB, which cannot be built here -- timed on a bounded sample of the same batch on
 this box's host cores and used at the same time to verify the GPU answers), and `configs` = {C2, C3}: the other single-GPU
-BASELINE configurations measured in the same run, each with its own roofline / cpu_baseline / parity.
+BASELINE configurations measured in the same run, each with its own roofline / cpu_baseline / parity; `single_checks` = the proxy's own
+call shape (64 / 256 / 1 024 concurrent single CheckPermission calls through the micro-batcher), from tools/bin/batcher_bench.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -463,6 +465,36 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
     return result
 
 
+def single_checks_leg():
+    """The proxy's own call shape (check.go:76-94, watch.go:50): T concurrent callers issuing single CheckPermission calls through the
+    micro-batcher.  Native threads are needed to load it, so the leg runs tools/bin/batcher_bench (C++ over include/aclgpu.h, built by
+    __graft_entry__.build()) on a 3-level pod graph of 500 k relationships and reports both call forms: one OS thread blocked per check
+    (acl_check_one) and the completion queue (acl_check_one_submit / acl_check_completions: T logical callers over 8 OS threads)."""
+    exe = os.path.join(ROOT, "tools", "bin", "batcher_bench")
+    if not os.path.exists(exe):
+        return {"skipped": "tools/bin/batcher_bench is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    try:
+        pr = subprocess.run([exe, "1000", "64", "256", "1024"], capture_output=True, text=True, timeout=150)
+    except Exception as ex:  # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"}
+    if pr.returncode:
+        return {"error": f"batcher_bench exited {pr.returncode}: {pr.stderr.strip()[-200:]}"}
+    txt = pr.stdout
+    res = {"graph": "3-level pod graph, 500 k relationships; 1000 checks per caller", "unit": "checks/s", "blocking_threads": {}, "completion_queue": {}, "small_batch_p50_us": {}}
+    for ln in txt.splitlines():
+        try:
+            r = json.loads(ln)
+        except ValueError:
+            continue
+        if "small_batch_items" in r:
+            res["small_batch_p50_us"][str(r["small_batch_items"])] = r["p50_us"]
+        elif "logical_callers" in r:
+            res["completion_queue"][str(r["logical_callers"])] = {"checks_per_s": r["checks_per_s"], "mean_latency_us": r["mean_latency_us"], "os_threads": r["threads"], "errors": r["errors"]}
+        elif r.get("mode", "").startswith("micro-batched"):
+            res["blocking_threads"][str(r["threads"])] = {"checks_per_s": r["checks_per_s"], "mean_latency_us": r["mean_latency_us"], "errors": r["errors"]}
+    return res
+
+
 def _local_edges(engine):
     return engine.stats().get("snapshot_edges_local", 0)
 
@@ -851,6 +883,7 @@ def main():
         except Exception as ex:  # noqa: BLE001 -- the headline line is printed whatever happens here
             cfgs["error"] = f"{type(ex).__name__}: {ex}"
         out["configs"] = cfgs
+        out["single_checks"] = single_checks_leg()
 
     # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
     # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.
