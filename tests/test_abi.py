@@ -118,6 +118,27 @@ def test_completion_queue_without_gpu(aclgpu_lib):
     e.close()
 
 
+def test_batcher_wakeups_with_native_threads_without_gpu(aclgpu_lib, tmp_path):
+    """The micro-batcher's queueing and wake-up tree under native threads (tools/batcher_bench.cpp: 256 OS threads blocked in
+    acl_check_one, then 256 logical callers on the completion queue) on a store-only engine whose passes are refused after 20 us:
+    every caller returns (no lost wake-up), every check is refused (no GPU => never an answer)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = tmp_path / "batcher_bench"
+    lib = os.path.join(root, "spicedb-kubeapi-proxy_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", os.path.join(root, "tools", "batcher_bench.cpp"), "-I", os.path.join(root, "include"), "-L", lib,
+                           "-laclgpu", "-lpthread", f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    env = dict(os.environ, ACL_BATCHER_SIM_PASS_US="20")
+    out = subprocess.run([str(exe), "150", "64", "256"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    recs = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(recs) == 4  # two thread counts x (blocking, completion queue)
+    for r in recs:
+        assert r["errors"] == r["checks"] and r["has"] == 0, r
+        assert r["batcher_passes"] < r["checks"], r  # calls were coalesced
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(os.path.dirname(HERE), "spicedb-kubeapi-proxy_amd")
     for root, _d, files in os.walk(pkg):
