@@ -78,6 +78,7 @@ typedef struct {
 
 /* replaces spicedb.NewServer (pkg/spicedb/spicedb.go:18-71): builds the engine. */
 int acl_open(const acl_config_t *cfg, acl_engine_t **out);
+/* no other call on the handle may be in flight (a poller blocked in acl_check_completions included: stop it first) */
 void acl_close(acl_engine_t *h);
 const char *acl_last_error(void);
 
