@@ -18,6 +18,10 @@ BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
   latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")
   string_path       (iii) acl_check_bulk with strings (5 strings interned per item), reported separately
 
+Sharded leg (8 ranks, or --sharded on): the SAME graph partitioned by type hash, answered by all ranks together; with more than one
+rank it runs in child processes with a process group of their own (isolated_sharded_leg), so that nothing an RCCL path does on a real
+multi-GPU node can take the headline line with it.
+
 N > 1: one process per GPU (torchrun), every rank holds a full replica of the graph and answers its own batches (weak
 scaling, no data-path collective: requests are independent -- SURVEY.md 8(e)); the timed region is bracketed by barrier +
 synchronize and the MAX over ranks is reported.
@@ -324,6 +328,52 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
         raise SystemExit("PARITY FAILURE in the sharded mixed stream")
 
 
+SHARDED_CHECKPOINT = None  # set in the isolated child: called on rank 0 after every exchange form with the results so far
+
+
+def isolated_sharded_leg(rank, world, timeout_s=300.0):
+    """Runs the sharded leg of this very command line in CHILD processes (one per rank, a process group of their own on another port)
+    and returns rank 0's result.  The leg drives RCCL paths that the one-GPU development boxes cannot exercise for real (grouped
+    send/recv, the library's own communicator): whatever they do on a real 8-GPU node -- a crash, a wedged collective -- the parent
+    still owns the measured headline line and prints it exactly once, with what the child got to before it died."""
+    import signal
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"aclgpu_sharded_{os.getpid()}.json")
+    errp = path + ".err"
+    for f in (path, errp):
+        if os.path.exists(f):
+            os.remove(f)
+    env = dict(os.environ)
+    if world > 1:
+        env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 101)
+        env["TORCHELASTIC_USE_AGENT_STORE"] = "False"  # rank 0 of the children hosts the rendezvous store itself
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--sharded-child", path]
+    note = None
+    with open(errp, "w") as ef:
+        pr = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=ef, start_new_session=True)
+        try:
+            pr.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(pr.pid, signal.SIGKILL)  # (the session this call started: nothing else is in it)
+            pr.wait()
+            note = f"sharded leg did not finish within {timeout_s:.0f} s (collective wedged?)"
+    if rank != 0:
+        return None
+    res = {}
+    if os.path.exists(path):
+        try:
+            res = json.load(open(path))
+        except ValueError:
+            res = {}
+    if pr.returncode and not note:
+        tail = open(errp).read().strip().splitlines()[-3:]
+        note = f"sharded leg child exited with {pr.returncode}: " + " | ".join(tail)[-300:]
+    if note:
+        res["error"] = note
+    res["isolated"] = "ran in child processes with a process group of their own"
+    return res
+
+
 def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
     """The north star's multi-GPU layout: rows partitioned by fnv1a(object type) mod G, one shard per
     rank, per-level all-gather of cross-shard frontier entries over RCCL.  All ranks answer ONE batch together; the
@@ -435,6 +485,8 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
             dist.all_gather_object(g, rec)
             if rank == 0:
                 mode_done(mode, g)
+                if SHARDED_CHECKPOINT:
+                    SHARDED_CHECKPOINT(result)
 
         try:
             o = run(se, dist.barrier, after_mode)
@@ -755,6 +807,8 @@ def main():
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
                     help="extra leg: the SAME graph partitioned by type hash over the ranks, per-level RCCL all-gather of cross-shard "
                          "frontiers (north star's 8-GPU layout).  auto = on at 8 ranks.  Reported beside `value`, never as `value`.")
+    ap.add_argument("--sharded-isolate", default="auto", choices=["auto", "on", "off"], help="run the sharded leg in child processes (auto: when there is more than one rank)")
+    ap.add_argument("--sharded-child", default="", help=argparse.SUPPRESS)  # internal: this process IS such a child; rank 0 writes its result there
     ap.add_argument("--logical-shards", type=int, default=0, help="with 1 GPU: run the sharded leg as G logical shards on this device (emulated)")
     ap.add_argument("--exchange", default="both", choices=["allgather", "alltoall", "both"],
                     help="sharded leg: how Check frontiers cross shards (allgather = the north star's form; alltoall moves G x fewer bytes)")
@@ -793,6 +847,33 @@ def main():
         w.subj = np.roll(w.subj[perm], rank * 7919) if rank else w.subj[perm]
     t_gen = time.time() - t0
     n = int(w.res.size)
+
+    if args.sharded_child:  # the isolated sharded leg (isolated_sharded_leg): nothing else, no stdout
+        global SHARDED_CHECKPOINT
+        res = {}
+
+        def save(r):
+            tmp = args.sharded_child + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump(r, f)
+            os.replace(tmp, args.sharded_child)
+
+        if rank == 0:
+            SHARDED_CHECKPOINT = save
+        eng_r = aclgpu.Engine(w.schema, device=local_rank)
+        w.load(eng_r)
+        try:
+            sharded_leg(args, w, eng_r, canon_res, canon_subj, world, rank, local_rank, res)
+        except Exception as ex:  # noqa: BLE001
+            res["error"] = f"{type(ex).__name__}: {ex}"
+        finally:
+            eng_r.close()
+        if rank == 0:
+            save(res)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
@@ -887,7 +968,12 @@ def main():
 
     # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
     # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.
-    if want_sharded:
+    if want_sharded and (args.sharded_isolate == "on" or (args.sharded_isolate == "auto" and world > 1)):
+        sh = isolated_sharded_leg(rank, world)
+        if rank == 0:
+            out["sharded"] = sh
+            print(json.dumps(out), flush=True)
+    elif want_sharded:
         printed = threading.Event()
 
         def emit(extra):
