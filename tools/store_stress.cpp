@@ -1,0 +1,145 @@
+// store_stress -- the host side of the engine under concurrent callers, for ThreadSanitizer (no GPU: a store-only engine).
+// Writers (WriteRelationships with TOUCH / DELETE / CREATE + preconditions, activity.go:47-149), readers (ReadRelationships, name lookups,
+// the Watch feed), the snapshot self-checks (in-place patch, background compaction) and single checks through the micro-batcher (refused:
+// no GPU) all at once.  Exit code 0 = every call returned what it must; run under TSan for the races:
+//   hipcc/clang++ -fsanitize=thread over csrc/*.cpp and this file (tools/tsan.sh)
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "aclgpu.h"
+
+static const char *kSchema =
+    "definition user {}\n"
+    "definition group {\n  relation member: user | group#member\n}\n"
+    "definition namespace {\n  relation viewer: user | group#member\n  relation creator: user\n  permission view = viewer + creator\n}\n"
+    "definition pod {\n  relation namespace: namespace\n  relation viewer: user | group#member\n  relation creator: user\n"
+    "  permission view = viewer + creator + namespace->view\n}\n";
+
+int main(int argc, char **argv) {
+    const int ROUNDS = argc > 1 ? atoi(argv[1]) : 300;
+    acl_engine_t *h = nullptr;
+    acl_config_t cfg{-1, 0, 0, ACL_FLAG_STORE_ONLY, 0, 0};
+    if (acl_open(&cfg, &h)) return 1;
+    std::string rels;
+    for (int p = 0; p < 2000; p++) {
+        char b[200];
+        snprintf(b, sizeof b, "pod:ns%d/p%d#namespace@namespace:ns%d\npod:ns%d/p%d#viewer@user:u%d\n", p % 50, p, p % 50, p % 50, p, p % 300);
+        rels += b;
+    }
+    for (int g = 0; g < 100; g++) {
+        char b[160];
+        snprintf(b, sizeof b, "group:g%d#member@user:u%d\ngroup:g%d#member@group:g%d#member\nnamespace:ns%d#viewer@group:g%d#member\n", g, g, g, (g + 1) % 100, g % 50, g);
+        rels += b;
+    }
+    if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) { fprintf(stderr, "load: %s\n", acl_last_error()); return 1; }
+    if (acl_batcher_start(h, 256, 50)) return 1;
+    std::atomic<int> bad{0};
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> th;
+    // writers
+    for (int wtr = 0; wtr < 2; wtr++)
+        th.emplace_back([&, wtr] {
+            unsigned s = 77u + wtr;
+            auto rnd = [&](unsigned m) { s = s * 1664525u + 1013904223u; return (s >> 8) % m; };
+            for (int r = 0; r < ROUNDS; r++) {
+                char rid[64], sid[32];
+                const int p = (int)rnd(4000);  // half of them new pods
+                snprintf(rid, sizeof rid, "ns%d/p%d", p % 50, p);
+                snprintf(sid, sizeof sid, "u%d", (int)rnd(400));
+                acl_update_t u[2] = {{(int32_t)(r % 3 == 2 ? ACL_OP_DELETE : ACL_OP_TOUCH), {"pod", rid, "viewer", "user", sid, "", 0}},
+                                     {ACL_OP_TOUCH, {"pod", rid, "creator", "user", sid, "", 0}}};
+                uint64_t rev = 0;
+                if (acl_write(h, u, 2, nullptr, 0, &rev) || !rev) bad++;
+                if (r % 16 == 0) {  // CREATE of something that exists must fail, atomically (activity.go:62-74)
+                    acl_update_t c{ACL_OP_CREATE, {"pod", rid, "creator", "user", sid, "", 0}};
+                    if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS) bad++;
+                    acl_filter_t pre{ACL_PRE_MUST_MATCH, "pod", rid, "creator", "user", sid, nullptr};
+                    acl_update_t t{ACL_OP_TOUCH, {"pod", rid, "viewer", "group", "g1", "member", 0}};
+                    if (acl_write(h, &t, 1, &pre, 1, &rev)) bad++;
+                }
+            }
+        });
+    // readers: ReadRelationships, name lookups, the Watch feed
+    for (int rd = 0; rd < 2; rd++)
+        th.emplace_back([&, rd] {
+            uint64_t cursor = 0;
+            acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
+            const int tp = acl_type_id(h, "pod"), tu = acl_type_id(h, "user");
+            unsigned s = 5u + rd;
+            while (!stop.load()) {
+                s = s * 1664525u + 1013904223u;
+                char rid[64];
+                const int p = (int)((s >> 8) % 2000);
+                snprintf(rid, sizeof rid, "ns%d/p%d", p % 50, p);
+                acl_filter_t f{0, "pod", rid, nullptr, nullptr, nullptr, nullptr};
+                long n = 0;
+                if (acl_read(h, &f, [](void *u, const acl_relationship_t *r) { if (r->resource_id) ++*(long *)u; }, &n) || n < 1) bad++;  // (its namespace row is never deleted)
+                uint32_t id = 0;
+                if (acl_find(h, tp, rid, &id)) bad++;
+                else if (const char *nm = acl_object_name(h, tp, id)) { if (strcmp(nm, rid) != 0) bad++; }
+                acl_intern(h, tu, ("fresh" + std::to_string(s % 5000)).c_str(), &id);
+                uint64_t next = 0;
+                long seen = 0;
+                const int rc = acl_watch_poll(h, cursor, &tp, 1, [](void *u, uint64_t, int32_t, const acl_relationship_t *) { ++*(long *)u; }, &seen, &next);
+                if (rc == ACL_OK) cursor = next;
+                else if (rc == ACL_ERR_OUT_OF_RANGE) acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
+                else bad++;
+            }
+        });
+    // snapshot maintenance: the patcher and the background compaction's two halves, verified against the store each time
+    th.emplace_back([&] {
+        int k = 0;
+        while (!stop.load()) {
+            int patched = 0, adopted = 0;
+            if (acl_selfcheck_snapshot(h, &patched)) { fprintf(stderr, "selfcheck: %s\n", acl_last_error()); bad++; }
+            if (++k % 4 == 0) {
+                if (acl_selfcheck_compaction(h, 0, &adopted)) { fprintf(stderr, "compaction 0: %s\n", acl_last_error()); bad++; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                if (acl_selfcheck_compaction(h, 1, &adopted)) { fprintf(stderr, "compaction 1: %s\n", acl_last_error()); bad++; }
+            }
+        }
+    });
+    // single checks: strings interned under the shared name lock, queued, refused by the pass (no GPU)
+    for (int c = 0; c < 4; c++)
+        th.emplace_back([&, c] {
+            unsigned s = 1000u + c;
+            acl_completion_t comp[16];
+            while (!stop.load()) {
+                s = s * 1664525u + 1013904223u;
+                char rid[64], sid[32];
+                const int p = (int)((s >> 8) % 2000);
+                snprintf(rid, sizeof rid, "ns%d/p%d", p % 50, p);
+                snprintf(sid, sizeof sid, "u%d", (int)((s >> 12) % 300));
+                acl_check_item_t it{"pod", rid, "view", "user", sid, ""};
+                uint8_t perm = 9;
+                int32_t err = 0;
+                if (c & 1) {
+                    if (acl_check_one(h, &it, &perm, &err) != ACL_ERR_UNAVAILABLE) bad++;
+                } else {
+                    if (acl_check_one_submit(h, &it, s)) bad++;
+                    size_t k = 0;
+                    if (acl_check_completions(h, comp, 16, 1000000, &k)) bad++;
+                    for (size_t j = 0; j < k; j++)
+                        if (comp[j].rc != ACL_ERR_UNAVAILABLE || comp[j].perm != ACL_PERM_UNSPECIFIED) bad++;
+                }
+                uint8_t pb[4];
+                int32_t eb[4];
+                acl_check_item_t four[4] = {it, it, it, it};
+                if (acl_check_bulk(h, four, 4, pb, eb) != ACL_ERR_UNAVAILABLE) bad++;
+            }
+        });
+    for (int i = 0; i < 2; i++) th[i].join();
+    stop = true;
+    for (size_t i = 2; i < th.size(); i++) th[i].join();
+    acl_batcher_stop(h);
+    int patched = 0;
+    if (acl_selfcheck_snapshot(h, &patched)) bad++;
+    acl_close(h);
+    printf("store_stress: %d rounds per writer, %d failed expectations\n", ROUNDS, bad.load());
+    return bad.load() ? 1 : 0;
+}

@@ -1,0 +1,27 @@
+#!/bin/bash
+# ThreadSanitizer over the host side of libaclgpu.so (no GPU needed: store-only engines).  Builds an instrumented copy of the library
+# under /tmp/aclgpu_tsan (the kernels' object is reused uninstrumented), then runs
+#   tools/store_stress.cpp   writers + readers + watch + snapshot patch / compaction self-checks + single checks, all at once
+#   tools/batcher_bench.cpp  the micro-batcher's wake-up tree and completion queue under 32-64 native threads (passes refused after 20 us)
+# usage: bash tools/tsan.sh [rounds]      prints the number of TSan reports (0 expected) per program
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+P=$R/spicedb-kubeapi-proxy_amd
+T=/tmp/aclgpu_tsan
+mkdir -p $T
+make -C $P -j8 lib/libaclgpu.so > /dev/null
+for f in schema store plan plan_reverse engine engine_shard engine_shard_native engine_callers engine_async engine_list; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=thread -Wno-option-ignored -x hip -c $P/csrc/$f.cpp -o $T/$f.o 2> /dev/null &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fsanitize=thread -Wno-option-ignored -shared -o $T/libaclgpu.so $T/*.o $P/build/kernels.hip.o -ldl 2> /dev/null
+CXX=/opt/rocm/lib/llvm/bin/clang++
+$CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/store_stress.cpp -I$R/include -L$T -laclgpu -lpthread -Wl,-rpath,$T -o $T/store_stress
+$CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/batcher_bench.cpp -I$R/include -L$T -laclgpu -lpthread -Wl,-rpath,$T -o $T/batcher_bench
+export TSAN_OPTIONS="halt_on_error=0"
+set +e
+timeout 900 $T/store_stress ${1:-150} > $T/store_stress.out 2> $T/store_stress.err; rc1=$?
+ACL_BATCHER_SIM_PASS_US=20 timeout 900 $T/batcher_bench 100 32 64 > $T/batcher_bench.out 2> $T/batcher_bench.err; rc2=$?
+echo "store_stress rc=$rc1: $(cat $T/store_stress.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_stress.err)"
+echo "batcher_bench rc=$rc2 ($(grep -c '"mode"' $T/batcher_bench.out) runs); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/batcher_bench.err)"
+grep -h "SUMMARY" $T/store_stress.err $T/batcher_bench.err | sort | uniq -c | sort -rn | head -20
