@@ -377,7 +377,14 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
     int rc = check_opts(opts);
     if (rc) return rc;
     for (;;) {
-        h->state_mu.lock_shared();
+        // try_only (the submit pipeline staging a batch AHEAD of the one it is about to run): never wait for the state lock either.  The
+        // batches already staged hold it shared until they are waited for; a writer queued behind them keeps new readers out (writer
+        // preference), and the pipeline blocking here could then never run the batches whose locks the writer is waiting for.
+        if (try_only) {
+            if (!h->state_mu.try_lock_shared()) return kNoContextFree;
+        } else {
+            h->state_mu.lock_shared();
+        }
         bool ok = snapshot_current(h, need_reverse);
         // a `type#relation` lookup subject is itself a state of the walk: its id must lie inside the visited bitmap
         if (ok && need_reverse && rev_key_slot >= 0 &&
@@ -388,6 +395,7 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
             break;
         }
         h->state_mu.unlock_shared();
+        if (try_only) return kNoContextFree;  // (the snapshot needs maintenance -- exclusive work: not while batches of this pipeline hold the lock)
         std::lock_guard<RwLock> lk(h->state_mu);
         rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;

@@ -74,6 +74,7 @@ class RwLock {
     void lock() { pthread_rwlock_wrlock(&l_); }
     void unlock() { pthread_rwlock_unlock(&l_); }
     void lock_shared() { pthread_rwlock_rdlock(&l_); }
+    bool try_lock_shared() { return pthread_rwlock_tryrdlock(&l_) == 0; }  // (fails while a writer holds the lock or waits for it)
     void unlock_shared() { pthread_rwlock_unlock(&l_); }
 
   private:

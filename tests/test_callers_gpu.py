@@ -390,3 +390,20 @@ def test_cancellation_and_deadline(aclgpu):
             assert ei.value.code == aclgpu.ERR_DEADLINE_EXCEEDED
         finally:
             e.batcher_stop()
+
+
+def test_every_call_shape_at_once_native_threads(aclgpu, tmp_path):
+    """tools/engine_stress.cpp: three blocking callers with chip-filling batches (chained on the device), a submit/wait window, 64-item
+    batches, single checks (blocking and completion queue), LookupResources and a writer that forces snapshot patches -- all at once on one
+    engine, every answer compared with the same call made alone.  (Found the pipeline's look-ahead staging deadlocking against a queued
+    writer: Eval::begin with try_only must not wait for the state lock.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "spicedb-kubeapi-proxy_amd", "lib")
+    exe = tmp_path / "engine_stress"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tools", "engine_stress.cpp"), "-I", os.path.join(root, "include"), "-L", lib,
+                           "-laclgpu", "-lpthread", f"-Wl,-rpath,{lib}", "-o", str(exe)])
+    pr = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=120)
+    assert pr.returncode == 0, (pr.stdout + pr.stderr)[-600:]
+    assert " 0 wrong or failed" in pr.stdout, pr.stdout

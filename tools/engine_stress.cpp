@@ -1,0 +1,177 @@
+// engine_stress -- every concurrent call shape of the seam at once against ONE engine on a GPU, answers compared with the same calls made
+// alone: chip-filling batches from three blocking callers (the chained path), a submit/wait window, 64-item batches, single checks through
+// the micro-batcher (blocking and completion queue), LookupResources, and a writer whose relationships touch only pods no request names
+// (so every answer must stay what it was) but force snapshot patches and background compactions under the readers.
+//   g++ -O2 -std=c++17 tools/engine_stress.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -o tools/bin/engine_stress
+// Also the program tools/tsan.sh --gpu runs under ThreadSanitizer.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "aclgpu.h"
+
+static const char *kSchema =
+    "definition user {}\n"
+    "definition namespace {\n  relation viewer: user\n  relation creator: user\n  permission view = viewer + creator\n}\n"
+    "definition pod {\n  relation namespace: namespace\n  relation viewer: user\n  relation creator: user\n"
+    "  permission view = viewer + creator + namespace->view\n}\n";
+
+int main(int argc, char **argv) {
+    const double SECONDS = argc > 1 ? atof(argv[1]) : 3.0;
+    const int NPOD = 100000, NREQ_POD = 90000 /* requests name pods below this; the writer works above it */, NNS = 1000, NUSER = 10000;
+    acl_engine_t *h = nullptr;
+    acl_config_t cfg{-1, 0, 0, 0, 6, 0};
+    if (acl_open(&cfg, &h)) { fprintf(stderr, "acl_open: %s\n", acl_last_error()); return 2; }
+    std::string rels;
+    unsigned s = 4242;
+    auto rnd = [&](unsigned m) { s = s * 1664525u + 1013904223u; return (s >> 8) % m; };
+    for (int p = 0; p < NPOD; p++) {
+        char b[200];
+        const int ns = p % NNS;
+        snprintf(b, sizeof b, "pod:ns%d/p%d#namespace@namespace:ns%d\npod:ns%d/p%d#creator@user:u%d\npod:ns%d/p%d#viewer@user:u%d\n", ns, p, ns, ns, p, (int)rnd(NUSER), ns, p, (int)rnd(NUSER));
+        rels += b;
+    }
+    for (int n = 0; n < NNS; n++)
+        for (int k = 0; k < 10; k++) { char b[96]; snprintf(b, sizeof b, "namespace:ns%d#viewer@user:u%d\n", n, (int)((n * 31 + k * 977) % NUSER)); rels += b; }
+    if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) { fprintf(stderr, "load: %s\n", acl_last_error()); return 2; }
+    if (acl_snapshot(h)) { fprintf(stderr, "snapshot: %s\n", acl_last_error()); return 2; }
+    const int tp = acl_type_id(h, "pod"), tu = acl_type_id(h, "user"), pv = acl_relation_id(h, tp, "view");
+    std::vector<uint32_t> pod_id(NREQ_POD), user_id(NUSER);
+    for (int p = 0; p < NREQ_POD; p++) { char nm[64]; snprintf(nm, sizeof nm, "ns%d/p%d", p % NNS, p); if (acl_find(h, tp, nm, &pod_id[p])) return 2; }
+    for (int u = 0; u < NUSER; u++) { char nm[32]; snprintf(nm, sizeof nm, "u%d", u); if (acl_intern(h, tu, nm, &user_id[u])) return 2; }
+    auto make = [&](size_t n, unsigned seed) {
+        std::vector<acl_item_t> v(n);
+        unsigned q = seed;
+        for (auto &it : v) {
+            q = q * 1664525u + 1013904223u;
+            const uint32_t p = (q >> 8) % NREQ_POD;
+            q = q * 1664525u + 1013904223u;
+            it = acl_item_t{(uint16_t)tp, (uint16_t)pv, pod_id[p], (uint16_t)tu, ACL_NO_RELATION, user_id[(q >> 8) % NUSER]};
+        }
+        return v;
+    };
+    struct Job { std::vector<acl_item_t> items; std::vector<uint8_t> want; };
+    auto job = [&](size_t n, unsigned seed) {
+        Job j{make(n, seed), std::vector<uint8_t>(n)};
+        std::vector<int32_t> err(n);
+        if (acl_check_bulk_ids(h, j.items.data(), n, j.want.data(), err.data())) { fprintf(stderr, "reference pass: %s\n", acl_last_error()); exit(2); }
+        return j;
+    };
+    std::vector<Job> big, mid, small;
+    for (int i = 0; i < 3; i++) big.push_back(job(200000, 11 + i));
+    for (int i = 0; i < 2; i++) mid.push_back(job(65536, 21 + i));
+    for (int i = 0; i < 2; i++) small.push_back(job(64, 31 + i));
+    // LookupResources of one user, alone
+    const size_t words = (acl_object_count(h, tp) + 31) / 32 + 64;
+    std::vector<uint32_t> bm0(words);
+    uint64_t cnt0 = 0;
+    if (acl_lookup_resources_ids(h, tp, pv, tu, -1, user_id[7], bm0.data(), words, &cnt0)) { fprintf(stderr, "lookup: %s\n", acl_last_error()); return 2; }
+    if (acl_batcher_start(h, 1024, 50)) return 2;
+
+    std::atomic<long> bad{0}, calls{0};
+    std::atomic<bool> stop{false};
+    auto check = [&](const Job &j, const std::vector<uint8_t> &got) {
+        if (memcmp(j.want.data(), got.data(), got.size()) != 0) bad++;
+        calls++;
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < 3; i++)  // chip-filling batches, blocking (>= 131 072 items: chained on the device)
+        th.emplace_back([&, i] {
+            std::vector<uint8_t> p(big[i].items.size());
+            std::vector<int32_t> e(p.size());
+            while (!stop.load()) {
+                if (acl_check_bulk_ids(h, big[i].items.data(), p.size(), p.data(), e.data())) { bad++; break; }
+                check(big[i], p);
+            }
+        });
+    th.emplace_back([&] {  // a submit / wait window of two
+        std::vector<uint8_t> p[2] = {std::vector<uint8_t>(65536), std::vector<uint8_t>(65536)};
+        std::vector<int32_t> e[2] = {std::vector<int32_t>(65536), std::vector<int32_t>(65536)};
+        while (!stop.load()) {
+            acl_ticket_t *t[2] = {nullptr, nullptr};
+            for (int k = 0; k < 2; k++)
+                if (acl_check_bulk_ids_submit(h, mid[k].items.data(), 65536, p[k].data(), e[k].data(), &t[k])) bad++;
+            for (int k = 0; k < 2; k++) {
+                if (t[k] && acl_ticket_wait(h, t[k])) bad++;
+                else check(mid[k], p[k]);
+            }
+        }
+    });
+    for (int i = 0; i < 2; i++)  // the proxy's own batch size
+        th.emplace_back([&, i] {
+            std::vector<uint8_t> p(64);
+            std::vector<int32_t> e(64);
+            while (!stop.load()) {
+                if (acl_check_bulk_ids(h, small[i].items.data(), 64, p.data(), e.data())) { bad++; break; }
+                check(small[i], p);
+            }
+        });
+    for (int i = 0; i < 4; i++)  // single checks by name: blocking and through the completion queue
+        th.emplace_back([&, i] {
+            unsigned q = 900 + i;
+            acl_completion_t comp[32];
+            while (!stop.load()) {
+                q = q * 1664525u + 1013904223u;
+                const int k = (q >> 8) % 64;
+                const acl_item_t &it0 = small[0].items[k];
+                const char *pn = acl_object_name(h, tp, it0.resource_id), *un = acl_object_name(h, tu, it0.subject_id);
+                if (!pn || !un) { bad++; break; }
+                std::string pns(pn), uns(un);  // (engine-owned strings are only good until the next mutating call)
+                acl_check_item_t it{"pod", pns.c_str(), "view", "user", uns.c_str(), ""};
+                if (i & 1) {
+                    uint8_t perm = 0;
+                    int32_t err = 0;
+                    if (acl_check_one(h, &it, &perm, &err) || err || perm != small[0].want[k]) bad++;
+                    calls++;
+                } else {
+                    if (acl_check_one_submit(h, &it, (uint64_t)k)) bad++;
+                    size_t n = 0;
+                    if (acl_check_completions(h, comp, 32, 2000000, &n)) bad++;
+                    for (size_t j = 0; j < n; j++)
+                        if (comp[j].rc || comp[j].err || comp[j].perm != small[0].want[comp[j].tag]) bad++;
+                    calls += (long)n;
+                }
+            }
+        });
+    th.emplace_back([&] {  // LookupResources
+        std::vector<uint32_t> bm(words);
+        while (!stop.load()) {
+            uint64_t cnt = 0;
+            if (acl_lookup_resources_ids(h, tp, pv, tu, -1, user_id[7], bm.data(), words, &cnt)) { bad++; break; }
+            // the writer only adds viewers u7 never is, on pods above NREQ_POD ... of other users: this user's set must not change
+            if (cnt != cnt0 || memcmp(bm.data(), bm0.data(), (NREQ_POD / 32) * 4) != 0) bad++;
+            calls++;
+        }
+    });
+    th.emplace_back([&] {  // the writer: pods nobody asks about, users other than u7
+        unsigned q = 5;
+        long w = 0;
+        while (!stop.load()) {
+            q = q * 1664525u + 1013904223u;
+            const int p = NREQ_POD + (int)((q >> 8) % (NPOD - NREQ_POD));
+            char rid[64], sid[32];
+            snprintf(rid, sizeof rid, "ns%d/p%d", p % NNS, p);
+            snprintf(sid, sizeof sid, "u%d", 8 + (int)((q >> 12) % (NUSER - 8)));
+            acl_update_t u{(int32_t)(w % 3 == 2 ? ACL_OP_DELETE : ACL_OP_TOUCH), {"pod", rid, "viewer", "user", sid, "", 0}};
+            uint64_t rev = 0;
+            if (acl_write(h, &u, 1, nullptr, 0, &rev)) bad++;
+            w++;
+            std::this_thread::sleep_for(std::chrono::microseconds(300));
+        }
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds((long)(SECONDS * 1000)));
+    stop = true;
+    for (auto &t : th) t.join();
+    acl_batcher_stop(h);
+    acl_stats_t st;
+    acl_stats(h, &st);
+    printf("engine_stress: %.1f s, %ld calls checked, %ld wrong or failed; snapshot patches %llu, compactions %llu, single-launch passes %llu\n", SECONDS, calls.load(), bad.load(),
+           (unsigned long long)st.snapshot_patches, (unsigned long long)st.snapshot_compactions, (unsigned long long)st.local_passes);
+    acl_close(h);
+    return bad.load() ? 1 : 0;
+}

@@ -3,12 +3,15 @@
 # under /tmp/aclgpu_tsan (the kernels' object is reused uninstrumented), then runs
 #   tools/store_stress.cpp   writers + readers + watch + snapshot patch / compaction self-checks + single checks, all at once
 #   tools/batcher_bench.cpp  the micro-batcher's wake-up tree and completion queue under 32-64 native threads (passes refused after 20 us)
-# usage: bash tools/tsan.sh [rounds]      prints the number of TSan reports (0 expected) per program
+#   tools/engine_stress.cpp  (built only: needs a GPU) every concurrent call shape of the seam at once, answers compared; run it on a GPU box
+#                            as $T/engine_stress [seconds] -- set T=tools/bin/tsan before building so that it travels with gpurun
+# usage: [T=dir] bash tools/tsan.sh [rounds]      prints the number of TSan reports (0 expected) per program
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 P=$R/spicedb-kubeapi-proxy_amd
-T=/tmp/aclgpu_tsan
+T=${T:-/tmp/aclgpu_tsan}
 mkdir -p $T
+T=$(cd $T && pwd)
 make -C $P -j8 lib/libaclgpu.so > /dev/null
 for f in schema store plan plan_reverse engine engine_shard engine_shard_native engine_callers engine_async engine_list; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=thread -Wno-option-ignored -x hip -c $P/csrc/$f.cpp -o $T/$f.o 2> /dev/null &
@@ -18,6 +21,7 @@ wait
 CXX=/opt/rocm/lib/llvm/bin/clang++
 $CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/store_stress.cpp -I$R/include -L$T -laclgpu -lpthread -Wl,-rpath,$T -o $T/store_stress
 $CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/batcher_bench.cpp -I$R/include -L$T -laclgpu -lpthread -Wl,-rpath,$T -o $T/batcher_bench
+$CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/engine_stress.cpp -I$R/include -L$T -laclgpu -lpthread -Wl,-rpath,'$ORIGIN' -o $T/engine_stress
 export TSAN_OPTIONS="halt_on_error=0"
 set +e
 timeout 900 $T/store_stress ${1:-150} > $T/store_stress.out 2> $T/store_stress.err; rc1=$?
