@@ -4,6 +4,7 @@
 // no GPU) all at once.  Exit code 0 = every call returned what it must; run under TSan for the races:
 //   hipcc/clang++ -fsanitize=thread over csrc/*.cpp and this file (tools/tsan.sh)
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,9 @@ static const char *kSchema =
 
 int main(int argc, char **argv) {
     const int ROUNDS = argc > 1 ? atoi(argv[1]) : 300;
+    // "reload": a thread re-runs acl_load_bootstrap (same schema and relationships) under everybody else; the expectations that a reload
+    // between two calls of one thread can void are then not counted -- the run is for crashes and ThreadSanitizer reports
+    const bool reload = argc > 2 && !strcmp(argv[2], "reload");
     acl_engine_t *h = nullptr;
     acl_config_t cfg{-1, 0, 0, ACL_FLAG_STORE_ONLY, 0, 0};
     if (acl_open(&cfg, &h)) return 1;
@@ -57,10 +61,10 @@ int main(int argc, char **argv) {
                 if (acl_write(h, u, 2, nullptr, 0, &rev) || !rev) bad++;
                 if (r % 16 == 0) {  // CREATE of something that exists must fail, atomically (activity.go:62-74)
                     acl_update_t c{ACL_OP_CREATE, {"pod", rid, "creator", "user", sid, "", 0}};
-                    if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS) bad++;
+                    if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS && !reload) bad++;
                     acl_filter_t pre{ACL_PRE_MUST_MATCH, "pod", rid, "creator", "user", sid, nullptr};
                     acl_update_t t{ACL_OP_TOUCH, {"pod", rid, "viewer", "group", "g1", "member", 0}};
-                    if (acl_write(h, &t, 1, &pre, 1, &rev)) bad++;
+                    if (acl_write(h, &t, 1, &pre, 1, &rev) && !reload) bad++;
                 }
             }
         });
@@ -81,7 +85,9 @@ int main(int argc, char **argv) {
                 if (acl_read(h, &f, [](void *u, const acl_relationship_t *r) { if (r->resource_id) ++*(long *)u; }, &n) || n < 1) bad++;  // (its namespace row is never deleted)
                 uint32_t id = 0;
                 if (acl_find(h, tp, rid, &id)) bad++;
-                else if (const char *nm = acl_object_name(h, tp, id)) { if (strcmp(nm, rid) != 0) bad++; }
+                else if (!reload) {  // (a reload renumbers: the id may name another object by the time the name is asked for)
+                    if (const char *nm = acl_object_name(h, tp, id)) { if (strcmp(nm, rid) != 0) bad++; }
+                }
                 acl_intern(h, tu, ("fresh" + std::to_string(s % 5000)).c_str(), &id);
                 uint64_t next = 0;
                 long seen = 0;
@@ -104,6 +110,13 @@ int main(int argc, char **argv) {
             }
         }
     });
+    if (reload)
+        th.emplace_back([&] {
+            while (!stop.load()) {
+                if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) bad++;
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        });
     // single checks: strings interned under the shared name lock, queued, refused by the pass (no GPU)
     for (int c = 0; c < 4; c++)
         th.emplace_back([&, c] {

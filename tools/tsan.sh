@@ -2,6 +2,7 @@
 # ThreadSanitizer over the host side of libaclgpu.so (no GPU needed: store-only engines).  Builds an instrumented copy of the library
 # under /tmp/aclgpu_tsan (the kernels' object is reused uninstrumented), then runs
 #   tools/store_stress.cpp   writers + readers + watch + snapshot patch / compaction self-checks + single checks, all at once
+#                            (a second time with a thread that re-runs acl_load_bootstrap under everybody else)
 #   tools/batcher_bench.cpp  the micro-batcher's wake-up tree and completion queue under 32-64 native threads (passes refused after 20 us)
 #   tools/engine_stress.cpp  (built only: needs a GPU) every concurrent call shape of the seam at once, answers compared; run it on a GPU box
 #                            as $T/engine_stress [seconds] -- set T=tools/bin/tsan before building so that it travels with gpurun
@@ -25,7 +26,9 @@ $CXX -O1 -g -std=c++17 -fsanitize=thread $R/tools/engine_stress.cpp -I$R/include
 export TSAN_OPTIONS="halt_on_error=0"
 set +e
 timeout 900 $T/store_stress ${1:-150} > $T/store_stress.out 2> $T/store_stress.err; rc1=$?
+timeout 900 $T/store_stress ${1:-150} reload > $T/store_reload.out 2> $T/store_reload.err; rc3=$?
 ACL_BATCHER_SIM_PASS_US=20 timeout 900 $T/batcher_bench 100 32 64 > $T/batcher_bench.out 2> $T/batcher_bench.err; rc2=$?
 echo "store_stress rc=$rc1: $(cat $T/store_stress.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_stress.err)"
+echo "store_stress with bootstrap reloads rc=$rc3: $(cat $T/store_reload.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_reload.err)"
 echo "batcher_bench rc=$rc2 ($(grep -c '"mode"' $T/batcher_bench.out) runs); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/batcher_bench.err)"
-grep -h "SUMMARY" $T/store_stress.err $T/batcher_bench.err | sort | uniq -c | sort -rn | head -20
+grep -h "SUMMARY" $T/store_stress.err $T/store_reload.err $T/batcher_bench.err | sort | uniq -c | sort -rn | head -20
