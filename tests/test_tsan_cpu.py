@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_host_side_is_race_free_under_tsan(aclgpu_lib):
     if not (os.path.exists("/opt/rocm/bin/hipcc") and os.path.exists("/opt/rocm/lib/llvm/bin/clang++") and shutil.which("make")):
         pytest.skip("no ROCm clang here")
-    pr = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan.sh"), "60"], capture_output=True, text=True, timeout=600)
+    pr = subprocess.run(["bash", os.path.join(ROOT, "tools", "tsan.sh"), "20"], capture_output=True, text=True, timeout=600)
     if pr.returncode:
         pytest.skip("the instrumented build did not link here: " + pr.stderr.strip()[-300:])
     out = pr.stdout
