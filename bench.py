@@ -764,21 +764,22 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
     steps = rec["_steps"]
     ach = tot * steps / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else None
     nz = int(np.flatnonzero(lvl_b)[-1]) + 1 if lvl_b.any() else 1
-    traffic = None
+    traffic = traffic_detail = None  # `traffic`: HBM bytes per launch (a number, as the bench contract defines it); the label rides beside it
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
             tj = json.load(open(tr))
             det = tj.get(label + "_detail") or {}
             if tj.get(label) and det.get("kernel") == k["name"]:  # (only a profile of the SAME kernel says anything about this run's launches)
-                traffic = {"bytes_per_launch": tj[label], "fetch_bytes_raw": det.get("fetch_bytes_per_launch_raw"), "write_bytes": det.get("write_bytes_per_launch"),
+                traffic = float(tj[label])
+                traffic_detail = {"bytes_per_launch": tj[label], "fetch_bytes_raw": det.get("fetch_bytes_per_launch_raw"), "write_bytes": det.get("write_bytes_per_launch"),
                            "profile": det.get("tag"),
                            "source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (gfx950 x2 FETCH "
                                      "correction applied), NOT measured in this run"}
         except Exception:  # noqa: BLE001
             pass
     rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                       "kernel": k["name"], "kernel_avg_us": 1e3 * k["ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
+                       "traffic_detail": traffic_detail, "kernel": k["name"], "kernel_avg_us": 1e3 * k["ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
                        "measured_in": "device_resident leg (sequential launches, HIP events on the launching stream)",
                        "algorithmic_bytes_per_check": tot / n, "algorithmic_bytes_per_batch": tot, "algorithmic_bytes_per_launch": tot * steps / k["launches"],
                        "algorithmic_bytes_by_model_level": [int(x) for x in lvl_b[1:nz]], "distinct_states_by_model_level": [int(x) for x in lvl_s[1:nz]],
