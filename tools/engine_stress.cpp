@@ -3,7 +3,8 @@
 // the micro-batcher (blocking and completion queue), LookupResources, and a writer whose relationships touch only pods no request names
 // (so every answer must stay what it was) but force snapshot patches and background compactions under the readers.
 //   g++ -O2 -std=c++17 tools/engine_stress.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -o tools/bin/engine_stress
-// Also the program tools/tsan.sh --gpu runs under ThreadSanitizer.
+// (tools/tsan.sh also builds it instrumented, but ThreadSanitizer on a GPU box only reports the uninstrumented HIP / HSA runtimes' own
+// accesses -- profiles/r02_engine_stress.txt; the host side is covered on store-only engines.)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
