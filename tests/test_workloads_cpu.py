@@ -82,3 +82,20 @@ def test_c3_cpu_reverse_walk_matches_definition():
     for i, s_ in enumerate(subs):
         op, _oe = o.check_bulk_ids_mt(2, rt, perm, pods, st, "", np.full(pods.size, s_, dtype=np.uint32))
         assert np.array_equal(np.flatnonzero(op == 2), walks[i]), i
+
+
+def test_isolated_sharded_leg_survives_a_dying_child(monkeypatch):
+    """bench.py runs the sharded leg of multi-rank runs in child processes so that nothing RCCL does there can take the headline line
+    with it.  Here the child dies at once (no GPU in this container): the parent gets an error record, not an exception."""
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible: the child would run the real leg")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--sharded", "on", "--logical-shards", "2"])
+    r = bench.isolated_sharded_leg(0, 1, timeout_s=300)
+    assert "exited with" in r["error"] and "isolated" in r
+    assert bench.isolated_sharded_leg(1, 1, timeout_s=300) is None  # only rank 0 reports
