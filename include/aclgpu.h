@@ -339,7 +339,7 @@ int acl_shard_check_bulk_rccl(acl_engine_t *h, const void *d_items, size_t n, vo
  * Updates the HOST copy of the snapshot the way the next read would (in-place patch from the change feed when
  * possible, rebuild otherwise) and verifies it against the relationship store: every live relationship findable,
  * nothing dead left, rows sorted, no unsound leaf flag.  Store-only engines only (it never touches a device). */
-int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out);
+int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out); /* *patched_out: 1 patched in place, 0 rebuilt, 2 was current */
 /* The host half of the background snapshot compaction in two steps (store-only engines): phase 0 builds a snapshot from a
  * copy-on-write view of the store, phase 1 catches it up with the writes since (the ordinary patcher), adopts and verifies it.
  * *adopted_out = 0 when the catch-up was not expressible as a patch (the engine then rebuilds synchronously). */

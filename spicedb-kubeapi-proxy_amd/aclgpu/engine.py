@@ -439,9 +439,13 @@ class Engine:
 
     def selfcheck_snapshot(self) -> bool:
         """Test hook (store-only engines): update + verify the host snapshot; True when the update was an in-place patch."""
+        return self.selfcheck_snapshot_code() == 1
+
+    def selfcheck_snapshot_code(self) -> int:
+        """... 1: patched in place, 0: rebuilt, 2: the snapshot was current already."""
         p = C.c_int()
         self._check(self._L.acl_selfcheck_snapshot(self._h, C.byref(p)))
-        return bool(p.value)
+        return int(p.value)
 
     def selfcheck_compaction(self, phase: int) -> bool:
         """Test hook (store-only engines): phase 0 = build from a copy-on-write view; phase 1 = catch up, adopt, verify.

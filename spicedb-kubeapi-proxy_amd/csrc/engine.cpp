@@ -217,7 +217,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     }
     c->state.store(0);
     if (c->worker.joinable()) c->worker.join();
-    if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world || now < c->snap.valid_lo || now >= c->snap.valid_hi) return false;
+    if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world) return false;
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
     if (!patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19)) return false;  // (a bulk load meanwhile: the synchronous path decides)
@@ -269,7 +269,8 @@ int ensure_snapshot(acl_engine *h) {
     hipStream_t s = h->up_stream;
     if (h->snap_valid && h->dev_valid && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
-    if (h->snap_valid && h->dev_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi &&
+    // (... or an expiration passed: the relationships that ran out are part of the patcher's feed)
+    if (h->snap_valid && h->dev_valid &&
         h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
         std::vector<Patch> patches;
         const uint64_t from_revision = h->snap.revision;

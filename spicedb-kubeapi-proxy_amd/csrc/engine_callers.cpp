@@ -494,7 +494,7 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
     const bool current = h->snap_valid && h->snap.revision == h->store.revision() && now >= h->snap.valid_lo && now < h->snap.valid_hi;
     if (!current) {
         const uint64_t from_revision = h->snap.revision;
-        if (h->snap_valid && now >= h->snap.valid_lo && now < h->snap.valid_hi) patched = patch_forward(h->store, now, &h->snap, h->shard, &patches);
+        if (h->snap_valid) patched = patch_forward(h->store, now, &h->snap, h->shard, &patches);
         if (patched && h->snap.has_reverse && !patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches)) h->snap.has_reverse = false;
         if (!patched) build_forward(h->store, now, &h->snap, h->shard);
         h->snap_valid = true;
@@ -506,7 +506,7 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out) {
                         : p.array == Patch::RMETA ? h->snap.rmeta.size() : h->snap.redges.size();
         if (p.off + p.n > sz) return fail(ACL_ERR_INTERNAL, "patch region outside its array");
     }
-    if (patched_out) *patched_out = patched ? 1 : 0;
+    if (patched_out) *patched_out = patched ? 1 : current ? 2 : 0;  // 1: patched in place, 0: rebuilt, 2: was current already
     std::string why;
     if (!verify_snapshot(h->store, now, h->snap, h->shard, &why)) return fail(ACL_ERR_INTERNAL, "snapshot does not match the store: " + why);
     return ACL_OK;
@@ -536,7 +536,7 @@ int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out) {
     c->state.store(0);
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
-    bool ok = now >= c->snap.valid_lo && now < c->snap.valid_hi && patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19);
+    bool ok = patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19);
     if (ok && !patch_reverse(h->store, now, from, &c->snap, h->shard, &patches)) c->snap.has_reverse = false;
     if (adopted_out) *adopted_out = ok ? 1 : 0;
     if (!ok) return ACL_OK;  // not adoptable (bulk load, too many changes, an expiry passed): the engine would rebuild instead

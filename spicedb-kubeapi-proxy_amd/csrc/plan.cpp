@@ -477,11 +477,24 @@ struct Patcher {
 
 }  // namespace
 
+void expiry_crossings(const Store &store, int64_t lo, int64_t hi, int64_t now, std::vector<Store::Change> *ch) {
+    if (now >= lo && now < hi) return;
+    // the snapshot held exactly the relationships expiring at or after `hi` (Store::expiry_window: nothing expires inside the window);
+    // at `now` those expiring after `now` are alive
+    const auto &tables = store.tables();
+    for (size_t slot = 0; slot < tables.size(); slot++)
+        for (size_t cls = 0; cls < tables[slot].size(); cls++)
+            for (const auto &kv : tables[slot][cls].expiry)
+                if ((kv.second >= hi) != (kv.second > now)) ch->push_back(Store::Change{0, 0 /* op: the patchers look the relationship up */, (int32_t)slot, (int32_t)cls, kv.first});
+}
+
 bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches, size_t max_changes) {
     Snapshot &s = *snap;
     std::vector<Store::Change> ch;
     if (s.lay.empty()) return false;
-    if (!store.raw_changes_since(s.revision, &ch) || ch.size() > (max_changes ? max_changes : kMaxPatchChanges)) return false;
+    if (!store.raw_changes_since(s.revision, &ch)) return false;
+    expiry_crossings(store, s.valid_lo, s.valid_hi, now, &ch);
+    if (ch.size() > (max_changes ? max_changes : kMaxPatchChanges)) return false;
     store.settle_all();
     const Schema &sc = store.schema();
     // objects created since the build must fit the headroom of every table they index
@@ -531,6 +544,8 @@ bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, s
         }
     }
     if (P.ops_dirty) patches->push_back(Patch{Patch::OPS, 0, s.ops.size()});
+    s.patch_lo = s.valid_lo;
+    s.patch_hi = s.valid_hi;
     store.expiry_window(now, &s.valid_lo, &s.valid_hi);
     s.revision = store.revision();
     s.nedges = s.nedges_local = 0;

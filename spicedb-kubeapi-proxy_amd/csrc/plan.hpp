@@ -96,6 +96,7 @@ struct Patch {  // a region of a snapshot array that changed on the host and mus
 struct Snapshot {
     uint64_t revision = 0;     // store revision it was built from
     int64_t valid_lo = 0, valid_hi = 0;  // expiration window of `now`
+    int64_t patch_lo = 0, patch_hi = 0;  // ... as it was before the last patch_forward (patch_reverse replays the same expiry crossings)
     // forward
     std::vector<uint32_t> meta;     // uint2 {start, end}: per (object, sorted class) into edges; per (hashed class, SUBJECT) into buckets
     std::vector<uint32_t> edges;    // SORTED sub-rows: subject ids ascending (| kLeafBit, see OP_LEAFBIT)
@@ -144,7 +145,12 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = 
 // On success `patches` lists the regions to re-upload and the reverse rows (if any) are invalidated.
 // max_changes: how many feed entries a patch may carry (0 = the default bound beyond which a rebuild is cheaper; the adoption of
 // a background-built snapshot passes a larger one: there the alternative is not a rebuild but throwing a finished build away).
+// A `now` outside the snapshot's expiration window is part of the feed: the relationships whose expiry lies between the window and
+// `now` are patched out (or, for a clock set back, in) like deletions -- an idempotency key running out (bootstrap.yaml:34-36) is not
+// a reason to rebuild 10 M relationships.
 bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches, size_t max_changes = 0);
+// the relationships whose liveness differs between a snapshot valid for [lo, hi) and `now` (appended to *ch; nothing when now is inside)
+void expiry_crossings(const Store &store, int64_t lo, int64_t hi, int64_t now, std::vector<Store::Change> *ch);
 // Same for the reverse rows (LookupResources); call after a successful patch_forward with the same feed position
 // (`from_revision` = the snapshot's revision BEFORE patch_forward).  false: rebuild the reverse rows instead.
 bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);

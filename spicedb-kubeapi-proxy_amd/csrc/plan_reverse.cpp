@@ -183,6 +183,7 @@ bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *
     if (!s.has_reverse || s.rlay.empty()) return false;
     std::vector<Store::Change> ch;
     if (!store.raw_changes_since(from_revision, &ch)) return false;
+    expiry_crossings(store, s.patch_lo, s.patch_hi, now, &ch);  // (the window patch_forward started from)
     const Schema &sc = store.schema();
     // new objects must fit the visited bitmaps and the descriptor tables
     for (int slot = 0; slot < sc.nslots; slot++)

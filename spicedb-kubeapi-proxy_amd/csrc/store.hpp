@@ -133,6 +133,7 @@ class Store {
     const ObjectTable &objects(int type) const { return objects_[type]; }
     // tables[slot][class]
     std::vector<std::vector<ClassTable>> &tables() { return tables_; }
+    const std::vector<std::vector<ClassTable>> &tables() const { return tables_; }
 
     Status write(const std::vector<UpdateText> &updates, const std::vector<FilterText> &preconditions, uint64_t *revision);
     Status delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t *revision);

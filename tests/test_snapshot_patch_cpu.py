@@ -102,9 +102,56 @@ def test_expiring_relationships_and_the_patch_window(aclgpu):
     e.selfcheck_snapshot()
     e.write([(aclgpu.OP_TOUCH, ("workflow", "w2", "idempotency_key", "activity", "a2", ""), 1200)])
     assert e.selfcheck_snapshot() is True  # an expiring relationship can be patched in; the window shrinks to 1200
-    e.set_now(1300)  # a2 expired: the snapshot's validity window is over -> rebuild without it
-    assert e.selfcheck_snapshot() is False
+    e.set_now(1300)  # a2 ran out: the relationship is patched OUT (an idempotency key expiring must not rebuild the graph)
+    assert e.selfcheck_snapshot() is True
     assert [r[1] for r in e.read(rtype="workflow")] == ["w1"]
+    e.set_now(1100)  # a clock set back (test clocks only): a2 is alive again, patched back in
+    assert e.selfcheck_snapshot() is True
+    assert sorted(r[1] for r in e.read(rtype="workflow")) == ["w1", "w2"]
+    e.set_now(2000)  # both gone
+    assert e.selfcheck_snapshot() is True
+    assert e.read(rtype="workflow") == []
+    e.close()
+
+
+def test_expiry_crossings_mixed_with_writes_and_compaction(aclgpu):
+    """Random walk of the clock over many expiring idempotency keys, interleaved with writes, deletes and a background compaction's two
+    halves: after every step the patched snapshot (forward and reverse rows) equals the store at that instant (acl_selfcheck_*)."""
+    from tests import kat_runner
+    b = kat_runner.load_bootstrap()
+    rng = random.Random(23)
+    e = aclgpu.Engine(b["schema"], store_only=True)
+    now = 10_000
+    e.set_now(now)
+    e.write([(aclgpu.OP_TOUCH, ("workflow", "w-seed", "idempotency_key", "activity", "a-seed", ""), now + 50)])
+    e.selfcheck_snapshot()
+    patched = rebuilt = 0
+    for step in range(160):
+        k = rng.random()
+        if k < 0.45:
+            ups = []
+            for i in rng.sample(range(41), rng.randint(1, 3)):  # (one update per relationship in a request)
+                ups.append((rng.choice([aclgpu.OP_TOUCH, aclgpu.OP_TOUCH, aclgpu.OP_DELETE]), ("workflow", f"w{i}", "idempotency_key", "activity", f"a{i % 7}", ""),
+                            now + rng.randint(1, 400)))
+            e.write([(op, t, exp) if op != aclgpu.OP_DELETE else (op, t) for op, t, exp in ups])
+        elif k < 0.55:
+            e.write([(aclgpu.OP_TOUCH, ("namespace", f"n{rng.randint(0, 9)}", "viewer", "user", f"u{rng.randint(0, 9)}", ""))])
+        elif k < 0.9:
+            now += rng.choice([1, 5, 30, 120, 400])
+            e.set_now(now)
+        else:
+            now -= rng.choice([1, 20, 200])  # (test clocks may run backwards)
+            e.set_now(now)
+        if step % 17 == 5:
+            e.selfcheck_compaction(0)
+            now += 60
+            e.set_now(now)
+            e.write([(aclgpu.OP_TOUCH, ("workflow", f"wc{step}", "idempotency_key", "activity", "ac", ""), now + 10)])
+            e.selfcheck_compaction(1)
+        code = e.selfcheck_snapshot_code()
+        patched += code == 1
+        rebuilt += code == 0
+    assert patched > 60 and rebuilt <= 2, (patched, rebuilt)  # (a rebuild is only allowed when a class comes alive for the first time)
     e.close()
 
 
