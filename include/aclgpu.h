@@ -166,8 +166,9 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * contexts (own HIP stream: the H2D copy of batch N+1 and the D2H copy of batch N-1 overlap the kernels of batch N);
  * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
  * Buffers must stay valid until the wait returns; a batch keeps its evaluation context -- and the engine's state lock, shared --
- * until it is waited for, so wait in submission order, and never call a WRITING entry point (acl_write, acl_delete_by_filter*,
- * acl_load_bootstrap) from the thread that still holds unwaited tickets: the write waits for them.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up to
+ * until it is waited for, so wait in submission order.  A thread that holds unwaited tickets must not make any other BLOCKING call
+ * on the engine before waiting for them: a write (acl_write, acl_delete_by_filter*, acl_load_bootstrap) waits for the tickets, and
+ * once a writer queues, every new evaluation queues behind it (the state lock prefers writers) -- only acl_ticket_wait gets out.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up to
  * three batches ahead (context + H2D) while contexts are free, runs the batches' kernels strictly one after the other
  * (from 131 072 items on they are chained ON THE DEVICE -- each stream waits for the event behind the previous kernel -- and
  * the waiter completes the pass), and each batch's D2H drains while the next one's kernel runs.  Keep two tickets in flight:
