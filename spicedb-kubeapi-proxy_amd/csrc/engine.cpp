@@ -1027,11 +1027,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
             uint32_t *dst = bitmaps + (b + i) * words;
             if (cw) std::memcpy(dst, (const uint32_t *)c->h_out.p + i * cw, cw * 4);
             std::fill(dst + cw, dst + words, 0u);
-            if (counts) {
-                uint64_t cnt = 0;
-                for (size_t w = 0; w < cw; w++) cnt += (uint64_t)__builtin_popcount(dst[w]);
-                counts[b + i] = cnt;
-            }
+            if (counts) counts[b + i] = popcount_words(dst, cw);
         }
     }
     return ACL_OK;

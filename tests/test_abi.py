@@ -155,3 +155,37 @@ def test_header_is_plain_c99(tmp_path):
     src.write_text('#include "aclgpu.h"\nint main(void) { acl_item_t it; (void)it; return sizeof(acl_stats_t) == 0; }\n')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+
+
+def test_popcount_words_matches_the_portable_loop(tmp_path):
+    """engine_internal.hpp's popcount_words (the LookupResources id counts: popcnt over 64-bit words when the CPU has it) against the
+    portable per-word loop, on every length around its unrolling and on random data."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    src = tmp_path / "pc.cpp"
+    src.write_text(r'''
+#include "engine_internal.hpp"
+#include <cstdio>
+#include <random>
+int main() {
+    std::mt19937 rng(7);
+    std::vector<uint32_t> v(5000);
+    for (auto &x : v) x = rng();
+    v[3] = 0; v[4] = 0xFFFFFFFFu;
+    for (size_t off = 0; off < 3; off++)
+        for (size_t n = 0; n + off <= v.size(); n = n < 70 ? n + 1 : n * 2 + 1) {
+            const uint64_t a = aclint::popcount_words(v.data() + off, n), b = aclint::popcount_words_portable(v.data() + off, n);
+            if (a != b || a != aclint::popcount_words_hw(v.data() + off, n)) { printf("mismatch at n=%zu off=%zu\n", n, off); return 1; }
+        }
+    printf("ok\n");
+    return 0;
+}
+''')
+    root = os.path.dirname(HERE)
+    exe = tmp_path / "pc"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", str(src), "-I", os.path.join(root, "spicedb-kubeapi-proxy_amd", "csrc"),
+                           "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).decode().strip() == "ok"
