@@ -189,3 +189,20 @@ int main() {
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-x", "hip", str(src), "-I", os.path.join(root, "spicedb-kubeapi-proxy_amd", "csrc"),
                            "-o", str(exe)])
     assert subprocess.check_output([str(exe)]).decode().strip() == "ok"
+
+
+def test_docs_and_go_shim_name_only_declared_entry_points():
+    """Every acl_* name INTEGRATION.md, README.md and the (unbuilt) Go shim mention is declared in include/aclgpu.h -- or in the shim's
+    own shim.h for its two callback trampolines."""
+    import glob
+    import re
+    root = os.path.dirname(HERE)
+    hdr = open(HEADER).read()
+    decl = set(re.findall(r"\b(acl_[a-z0-9_]+)\s*\(", hdr)) | set(re.findall(r"\b(acl_[a-z0-9_]+_t)\b", hdr)) | set(re.findall(r"\(\*(acl_[a-z0-9_]+)\)", hdr))
+    shim_local = {"acl_read_go", "acl_watch_poll_go"}
+    files = [os.path.join(root, f) for f in ("INTEGRATION.md", "README.md")] + glob.glob(os.path.join(root, "shim", "go", "aclgpu", "*"))
+    assert len(files) > 6
+    for f in files:
+        used = set(re.findall(r"\b(acl_[a-z0-9_]+)\b", open(f).read()))
+        missing = sorted(u for u in used if u not in decl and u not in shim_local and not any(d.startswith(u) for d in decl))
+        assert not missing, (f, missing)
