@@ -690,6 +690,12 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         eng.check_bulk_ids(items0)
         pg.append(time.perf_counter())
     rec["latency"]["pageable_buffers_p50_ms"] = 1e3 * float(np.median(np.diff(pg)))
+    # every one of the NB rotations has been answered by now (timed leg + 220 latency calls): batch b must hold batch 0's answers rotated
+    # the same way -- cpu_and_roofline compares batch 0 with the oracle item by item, so this extends the oracle check to all NB batches
+    rot_bad = 0
+    for b in range(NB):
+        rot_bad += int((h_perm[b] != np.roll(gpu_perm, b * 4099)).sum() + (h_err[b] != np.roll(gpu_err, b * 4099)).sum())
+    rec["rotations"] = {"batches": NB, "items": NB * n, "mismatches_vs_rotated_batch0": rot_bad}
     eng.host_free(hb)
     # ---------------- (iii) string path: named objects needed -> a NAMED copy of a slice would not be this graph; the engine's
     # bulk loads are anonymous ids, so the string leg names the ids it asks about through acl_intern-free decimal names:
@@ -752,7 +758,11 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
     mperm, merr = o.check_bulk_ids_mt(cores, rt, perm_name, w.res, st, "", w.subj)  # EVERY answer of the batch is checked
     t_mt = time.perf_counter() - t0
     mism_mt = int((mperm != gpu_perm).sum() + (merr != gpu_err).sum())
+    rot = rec.pop("rotations", None)
     rec["parity"] = {"checked_against_oracle": n, "mismatches": mism + mism_mt}
+    if rot:  # all 8 distinct batches of the timed leg: batch b == oracle answers rotated by b * 4099 (the oracle's answers equal batch 0's item by item)
+        rec["parity"].update({"checked_against_oracle": rot["items"], "distinct_batches_checked": rot["batches"],
+                              "mismatches": mism + mism_mt + rot["mismatches_vs_rotated_batch0"]})
     rec["cpu_baseline"] = {"value": n / t_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
                            "sample": f"the whole {n}-item batch split statically over {cores} host threads, restated CPU oracle (not embedded SpiceDB)",
                            "seconds": round(t_mt, 2), "load_s": round(t_oload, 2),
@@ -788,9 +798,51 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
                                 "userset as a dispatch, the kernels inline them)", "model_seconds": round(t_bytes, 2)}
 
 
+def launch_ranks(n, dry):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks here (python -m torch.distributed.run, one process per GPU,
+    rendezvous on 127.0.0.1 -- the container's hostname may not resolve) and hand their exit code back.  Rank 0 prints the line."""
+    import socket
+    if not dry:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py: {n} GPUs requested, {have} visible -- refusing to run fewer ranks and call it n_gpus={n}")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
+def dry_spawn(world, rank, local_rank):
+    """--dry-spawn: the launch path without a GPU (tests/test_bench_spawn.py).  The ranks meet over gloo, agree on who is there, rank 0
+    prints ONE line."""
+    import torch
+    import torch.distributed as dist
+    seen = [rank]
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = 1 + local_rank
+        dist.all_reduce(t)
+        seen = [int(x) - 1 for x in t]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_spawn": True, "n_gpus": world, "local_ranks_seen": seen, "metric": "check_decisions_per_sec", "value": None}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (one process per GPU).  Under torchrun it must equal WORLD_SIZE; "
+                    "without torchrun and N > 1 this process launches the N ranks itself (torch.distributed.run, 127.0.0.1)")
+    ap.add_argument("--dry-spawn", action="store_true", help="launch plumbing only (no GPU): the N ranks rendezvous over gloo and rank 0 prints one line")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
@@ -816,17 +868,27 @@ def main():
                     help="sharded leg: how Check frontiers cross shards (allgather = the north star's form; alltoall moves G x fewer bytes)")
     args = ap.parse_args()
 
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not under_launcher and (args.gpus or 1) > 1:
+        return launch_ranks(args.gpus, args.dry_spawn)  # this process is the launcher: the ranks print, it forwards their exit code
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a line whose n_gpus is not what was asked for")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_spawn:
+        return dry_spawn(world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU evaluation path")
+    if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} GPUs requested, {torch.cuda.device_count()} visible (one process per GPU: rank {rank} has no device)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -842,11 +904,12 @@ def main():
     t0 = time.time()
     w = workloads.by_name(args.workload, **kw)
     canon_res, canon_subj = w.res.copy(), w.subj.copy()  # the sharded leg answers ONE stream with all ranks together
-    if world > 1:  # every rank answers a different request stream against the same graph
-        rng = np.random.default_rng(0x5ACE0000 + rank)
-        perm = rng.permutation(w.res.size)
-        w.res = w.res[perm]
-        w.subj = np.roll(w.subj[perm], rank * 7919) if rank else w.subj[perm]
+    if world > 1 and rank:
+        # every rank answers its own request stream against its replica: the SAME request mix in a different order (the (resource,
+        # subject) pairs rotated together -- rotating one column against the other would turn every engineered hit into a random
+        # pair, a different workload).  Same multiset of requests on every rank => rank 0's algorithmic bytes are every rank's.
+        shift = (rank * 32749) % max(1, int(w.res.size))
+        w.res, w.subj = np.roll(w.res, shift), np.roll(w.subj, shift)
     t_gen = time.time() - t0
     n = int(w.res.size)
 
@@ -899,9 +962,15 @@ def main():
 
     rec, gpu_perm, gpu_err = check_bench(args, w, eng, args.steps, args.warmup, world, rank, label, args.legs, dist if world > 1 else None)
     elapsed = rec.pop("elapsed")
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world  # every rank's own clock and kernel time: the roofline is per GPU
+        k_ = rec.get("kernel") or {}
+        dist.all_gather_object(per_rank, {"rank": rank, "elapsed_s": elapsed, "decisions_per_s": n * args.steps / elapsed,
+                                          "kernel": k_.get("name"), "kernel_avg_us": 1e3 * k_["ms"] / k_["launches"] if k_.get("launches") else None,
+                                          "device_resident_decisions_per_s": rec["device_resident"]["decisions_per_s"]})
         elapsed = float(tt.item())
     stats = eng.stats()
 
@@ -926,15 +995,36 @@ def main():
         }
         kernel = rec.get("kernel")
         out.update(rec)
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu:
+            # at EVERY N: rank 0 times the CPU oracle on its own batch and prices the roofline from the oracle's byte model (the other ranks
+            # wait at the barrier below -- outside every timed region)
             out["_steps"] = args.steps
             cpu_and_roofline(args, w, out, gpu_perm, gpu_err, label)
             out.pop("_steps")
+            if per_rank:
+                rf = out["roofline"]
+                bpl = rf["algorithmic_bytes_per_launch"]
+                gl = []
+                for pr_ in per_rank:  # same request multiset on every rank (rotated): rank 0's bytes per launch are every rank's
+                    a_ = bpl / (pr_["kernel_avg_us"] * 1e-6) / 1e9 if pr_.get("kernel_avg_us") else None
+                    gl.append({"rank": pr_["rank"], "kernel": pr_["kernel"], "kernel_avg_us": pr_["kernel_avg_us"], "achieved": a_,
+                               "frac": a_ / HBM_PEAK_GBS if a_ else None, "host_id_decisions_per_s": pr_["decisions_per_s"],
+                               "device_resident_decisions_per_s": pr_["device_resident_decisions_per_s"]})
+                ok_ = [g_["achieved"] for g_ in gl if g_["achieved"]]
+                rf["per_gpu"] = gl
+                rf["achieved"] = float(np.mean(ok_)) if ok_ else None  # per GPU (mean over ranks) against ONE GPU's peak
+                rf["frac"] = rf["achieved"] / HBM_PEAK_GBS if ok_ else None
+                rf["frac_min_over_gpus"] = min(ok_) / HBM_PEAK_GBS if ok_ else None
+                rf["aggregate_achieved"] = float(np.sum(ok_)) if ok_ else None
+                rf["note"] = "achieved / frac are PER GPU (mean over the ranks' own HIP-event kernel times); every rank runs the same request multiset"
         else:
             out.pop("kernel", None)
+            rot = out.pop("rotations", None)
+            if rot:
+                out["parity"] = {"checked_against_oracle": 0, "distinct_batches_checked": rot["batches"], "mismatches_vs_rotated_batch0": rot["mismatches_vs_rotated_batch0"]}
             out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                "kernel": kernel["name"] if kernel else None, "kernel_avg_us": 1e3 * kernel["ms"] / kernel["launches"] if kernel else None,
-                               "note": "algorithmic bytes need the CPU oracle's byte model: rank 0 at N=1 only"}
+                               "note": "--no-cpu: algorithmic bytes need the CPU oracle's byte model"}
             out["cpu_baseline"] = None
     eng.close()
 

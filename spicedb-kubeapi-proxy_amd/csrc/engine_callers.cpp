@@ -82,22 +82,23 @@ struct acl_engine::Batcher {
     std::atomic<bool> running{false}, stop{false};
     std::mutex mu;  // start / stop
     std::vector<std::thread> threads;
-    uint32_t max_items = 4096, wait_us = 200;
+    // (knobs: written by acl_batcher_start, read by callers and pollers that may run across a stop + restart -- relaxed atomics)
+    std::atomic<uint32_t> max_items{4096}, wait_us{200};
     std::atomic<uint64_t> batches{0}, items{0}, lookup_walks{0}, lookups{0};
     std::atomic<uint32_t> sleepers{0};
-    unsigned cores = 1;
+    std::atomic<unsigned> cores{1};
     // wake-up tree (see the top of this file); knobs for A/B runs: ACL_BATCHER_CHAIN=0 restores "the dispatcher wakes everybody",
     // ACL_BATCHER_FANOUT, ACL_BATCHER_QUEUES (queues in use, <= 16), ACL_BATCHER_DISPATCHERS, ACL_BATCHER_SPINNERS
-    bool chain = true;
-    uint32_t fanout = 2, max_spinners = 0;
+    std::atomic<bool> chain{true};
+    std::atomic<uint32_t> fanout{2}, max_spinners{0};
     // a sleep + wake-up of a thread costs 20-100 us of latency on these hosts, more than a pass: dispatchers and completion pollers spin
     // this long before they go to sleep (ACL_BATCHER_IDLE_SPIN_US, ACL_BATCHER_POLL_SPIN_US), and the batching window (<= 100 us) is spun
-    uint32_t idle_spin_us = 0, poll_spin_us = 0;
-    uint32_t active_queues = kQueues;
+    std::atomic<uint32_t> idle_spin_us{0}, poll_spin_us{0};
+    std::atomic<uint32_t> active_queues{kQueues};
     // host-side tuning aid, store-only engines only: their passes are refused (UNAVAILABLE: no GPU, no evaluation -- never an answer)
     // at once; ACL_BATCHER_SIM_PASS_US makes the refusal take as long as a device pass would, so that the queueing / wake-up
     // machinery can be timed on a box without a GPU (tools/batcher_bench with that variable set)
-    uint32_t sim_pass_us = 0;
+    std::atomic<uint32_t> sim_pass_us{0};
     // completion queue of acl_check_one_submit (see there)
     std::mutex cq_mu;
     std::deque<acl_completion_t> cq;
@@ -268,6 +269,7 @@ Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, siz
     static thread_local uint32_t my_slot = next_thread.fetch_add(1, std::memory_order_relaxed);
     Queue &q = B->q[my_slot % B->active_queues];
     Batch *b;
+    bool first = false;
     {
         std::lock_guard<std::mutex> g(q.mu);
         if (!B->running.load(std::memory_order_relaxed)) return nullptr;
@@ -282,11 +284,13 @@ Batch *enqueue(acl_engine_t *h, const acl_item_t *item, const LookupReq *lk, siz
             b->lookups.push_back(*lk);
         }
         if (!async_tag) b->refs.fetch_add(1, std::memory_order_relaxed);  // (a submitted item has no caller holding on to the sub-batch)
+        // counted UNDER the queue lock: acl_batcher_stop's barrier -- lock + unlock of every queue -- then covers the count as
+        // well as the append, so a dispatcher that sees `stop && pending == 0` has really answered everything; and a sweep can never
+        // subtract an item it took before the item was counted (the counter used to wrap through 0xFFFFFFFF for a moment)
+        first = B->pending.fetch_add(1, std::memory_order_acq_rel) == 0;
+        if (first) B->oldest_ns.store(mono_ns(), std::memory_order_relaxed);
     }
-    if (B->pending.fetch_add(1, std::memory_order_acq_rel) == 0) {
-        B->oldest_ns.store(mono_ns(), std::memory_order_relaxed);
-        futex(&B->pending, FUTEX_WAKE_PRIVATE, 1, nullptr);  // dispatchers only sleep while nothing is queued
-    }
+    if (first) futex(&B->pending, FUTEX_WAKE_PRIVATE, 1, nullptr);  // dispatchers only sleep while nothing is queued
     return b;
 }
 

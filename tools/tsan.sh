@@ -27,8 +27,10 @@ export TSAN_OPTIONS="halt_on_error=0"
 set +e
 timeout 900 $T/store_stress ${1:-150} > $T/store_stress.out 2> $T/store_stress.err; rc1=$?
 timeout 900 $T/store_stress ${1:-150} reload > $T/store_reload.out 2> $T/store_reload.err; rc3=$?
+ACL_BATCHER_SIM_PASS_US=20 timeout 300 $T/store_stress ${1:-150} restart > $T/store_restart.out 2> $T/store_restart.err; rc4=$?
 ACL_BATCHER_SIM_PASS_US=20 timeout 900 $T/batcher_bench 100 32 64 > $T/batcher_bench.out 2> $T/batcher_bench.err; rc2=$?
 echo "store_stress rc=$rc1: $(cat $T/store_stress.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_stress.err)"
 echo "store_stress with bootstrap reloads rc=$rc3: $(cat $T/store_reload.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_reload.err)"
+echo "store_stress with batcher restarts rc=$rc4: $(cat $T/store_restart.out | tail -1); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/store_restart.err)"
 echo "batcher_bench rc=$rc2 ($(grep -c '"mode"' $T/batcher_bench.out) runs); ThreadSanitizer reports: $(grep -c 'WARNING: ThreadSanitizer' $T/batcher_bench.err)"
-grep -h "SUMMARY" $T/store_stress.err $T/store_reload.err $T/batcher_bench.err | sort | uniq -c | sort -rn | head -20
+grep -h "SUMMARY" $T/store_stress.err $T/store_reload.err $T/store_restart.err $T/batcher_bench.err | sort | uniq -c | sort -rn | head -20
