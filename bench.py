@@ -158,9 +158,13 @@ def filter_bench(args, w, eng, steps, warmup):
     import torch
     rt, perm_name, st = w.check
     subs = np.asarray(w.lookup_subjects, dtype=np.uint32)
-    bufs = None  # (result buffers reused across steps, as a Go caller would: a fresh 0.8 MB array per call is ~200 page faults)
+    # result buffers: allocated once with acl_host_alloc (pinned) and reused across steps, as the Go shim does -- the single-launch walk then
+    # writes the result rows straight into them; `pageable` below is the same call with ordinary numpy arrays (staged through the context)
+    words = max(1, (eng.object_count(rt) + 31) // 32)
+    hb = eng.host_alloc(subs.size * words * 4 + subs.size * 8)
+    bufs = (hb[:subs.size * words * 4].view(np.uint32).reshape(subs.size, words), hb[subs.size * words * 4:].view(np.uint64))
     for _ in range(max(1, warmup)):
-        bufs = eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=bufs)
+        eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=bufs)
     eng.stats_reset()
     eng.set_timing(True)
     torch.cuda.synchronize()
@@ -168,32 +172,59 @@ def filter_bench(args, w, eng, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         t1 = time.perf_counter()
-        bms, counts = bufs = eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=bufs)
+        bms, counts = eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=bufs)
         lat.append(time.perf_counter() - t1)
     el = time.perf_counter() - t0
     eng.set_timing(False)
     stats = eng.stats()
+    assert bms is bufs[0]
+    pg_bufs = None
+    pg = []
+    for _ in range(max(5, warmup)):
+        t1 = time.perf_counter()
+        pg_bufs = eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=pg_bufs)
+        pg.append(time.perf_counter() - t1)
+    pageable_equal = bool(np.array_equal(pg_bufs[0], bms) and np.array_equal(pg_bufs[1], counts))
     # single-request latency (the proxy's shape: one prefilter per list request)
     one = []
+    one_buf = (bufs[0][:1], bufs[1][:1])
+    keep = (bms.copy(), counts.copy())
     for s_ in np.tile(subs, 4)[:200]:
         t1 = time.perf_counter()
-        eng.lookup_ids_batch(rt, perm_name, st, "", [int(s_)])
+        eng.lookup_ids_batch(rt, perm_name, st, "", [int(s_)], out=one_buf)
         one.append(time.perf_counter() - t1)
-    launches = max(1, stats["expand_launches"])
+    bms, counts = keep
+    eng.host_free(hb)
+    if stats.get("rev_local_passes"):
+        kname, kms, launches = "k_rev_local", stats["rev_local_ms"], max(1, stats["rev_local_passes"])
+    else:
+        kname, kms, launches = "k_rev_expand", stats["expand_ms"], max(1, stats["expand_launches"])
     lb = c3_lookup_bytes(w, subs)
     batch_bytes = float(lb.sum())
-    ach = batch_bytes * steps / (stats["expand_ms"] * 1e-3) / 1e9 if stats["expand_ms"] > 0 else None
+    ach = batch_bytes * steps / (kms * 1e-3) / 1e9 if kms > 0 else None
+    traffic = None
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            tj = json.load(open(tr))
+            if tj.get("C3") and (tj.get("C3_detail") or {}).get("kernel") == kname:
+                traffic = float(tj["C3"])
+        except Exception:  # noqa: BLE001
+            pass
     out = {"metric": "lookup_resources_per_sec", "value": subs.size * steps / el, "unit": "lookups/s", "steps": steps, "warmup": warmup,
            "ms_per_step": 1e3 * el / steps, "workload": WORKLOAD_DESC["C3"], "lookups_per_step": int(subs.size), "relationships": w.ntuples,
            "objects": int(sum(w.nobjects.values())),
            "allowed_ids_per_lookup": float(np.mean(counts)), "allowed_ids_per_sec": float(np.sum(counts)) * steps / el,
            "p50_batch_ms": 1e3 * float(np.median(lat)), "p50_single_lookup_ms": 1e3 * float(np.median(one)), "p95_single_lookup_ms": 1e3 * float(np.percentile(one, 95)),
-           "kernel_ms_per_step": stats["kernel_ms"] / steps, "rev_expand_launches_per_step": launches / steps,
+           "pageable_result_buffers": {"p50_batch_ms": 1e3 * float(np.median(pg)), "lookups_per_s": subs.size / float(np.median(pg)), "equal_to_pinned_run": pageable_equal},
+           "kernel_ms_per_step": stats["kernel_ms"] / steps, "launches_per_step": launches / steps, "reverse_levels": int(stats.get("levels_last", 0)),
            "bitmap_bytes_per_lookup": int(bms.shape[1] * 4),
-           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
-                        "kernel": "k_rev_expand", "kernel_avg_us": 1e3 * stats["expand_ms"] / launches,
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                        "kernel": kname, "kernel_avg_us": 1e3 * kms / launches,
                         "algorithmic_bytes_per_lookup": batch_bytes / subs.size, "algorithmic_bytes_per_launch": batch_bytes * steps / launches,
                         "model": "SURVEY.md 8(d) LookupResources formula on the generator's arrays: 17 + sum over reverse rows (8 + 4 deg) + N_pod / 8"}}
+    if not pageable_equal:
+        out.setdefault("parity", {})["pageable_vs_pinned_mismatch"] = True
     if not args.no_cpu:
         from oracle import orc
         o = orc.Oracle(w.schema)
@@ -215,7 +246,7 @@ def filter_bench(args, w, eng, steps, warmup):
         for i in range(subs.size):
             got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little"))
             mism += int(not np.array_equal(got, walks[i]))
-        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism,
+        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism + int(not pageable_equal),
                          "checkers": "the DEFINITION {id : Check == HAS} over every pod (multi-threaded oracle) AND a CPU reverse walk"}
         out["cpu_baseline"] = {"value": subs.size / t_walk, "unit": "lookups/s", "cores": 1, "kind": "port",
                                "sample": f"all {subs.size} power users: reverse walk over CSR-by-subject rows in numpy (one thread; the algorithm the device runs, specialised "

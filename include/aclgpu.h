@@ -364,6 +364,9 @@ typedef struct {
     double local_ms;               /* HIP-event time of the single-launch small-batch kernel (k_check_local) */
     uint64_t local_passes;         /* device passes answered by that kernel (one launch for all levels) */
     uint64_t snapshot_compactions; /* snapshots rebuilt in the background and swapped in */
+    double rev_local_ms;           /* HIP-event time of the single-launch LookupResources kernel (k_rev_local) */
+    uint64_t rev_local_passes;     /* LookupResources groups answered by that kernel (one launch for all reverse levels) */
+    uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

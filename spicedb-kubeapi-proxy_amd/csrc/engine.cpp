@@ -86,6 +86,7 @@ void ev_collect(PassCtx *c) {  // stream must be synchronized
             c->stats.kernel_ms += ms;
             if (c->ev_kind[i / 2] == 1) c->stats.expand_ms += ms;
             else if (c->ev_kind[i / 2] == 2) c->stats.local_ms += ms;
+            else if (c->ev_kind[i / 2] == 3) c->stats.rev_local_ms += ms;
         }
     }
     c->ev_used = 0;
@@ -97,12 +98,15 @@ void merge_stats(acl_engine *h, PassCtx *c) {
     a.check_items += b.check_items;
     a.check_passes += b.check_passes;
     a.expand_launches += b.expand_launches;
-    if (b.check_passes) a.levels_last = b.levels_last;
+    if (b.check_passes || b.lookup_requests) a.levels_last = b.levels_last;
     a.frontier_entries += b.frontier_entries;
     a.kernel_ms += b.kernel_ms;
     a.expand_ms += b.expand_ms;
     a.local_ms += b.local_ms;
     a.local_passes += b.local_passes;
+    a.rev_local_ms += b.rev_local_ms;
+    a.rev_local_passes += b.rev_local_passes;
+    a.lookup_requests += b.lookup_requests;
     a.overflow_retries += b.overflow_retries;
     b = acl_stats_t{};
 }
@@ -968,6 +972,55 @@ void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n
     h->intern_pool->run(n, n >= 32768 ? 2048 : 512, run);
 }
 
+// Single-launch LookupResources over m subjects already staged in c->h_in (pinned).  Result rows go to `bitmaps` directly when the
+// caller's buffer is pinned (acl_host_alloc), else through the context's pinned staging.  kTakeLevelLoop: a block outgrew its share.
+static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uint32_t key, uint32_t target, size_t m, uint32_t *bitmaps, size_t words, size_t cw,
+                             uint64_t *counts) {
+    // private frontier regions: 8-byte entries carved from the context's two frontier buffers (16 B per entry there)
+    uint64_t cap64 = std::min<uint64_t>(c->frontier_entries * 2 / std::max<size_t>(m, 1), 1u << 22);
+    if (h->local_cap_limit) cap64 = std::min<uint64_t>(cap64, h->local_cap_limit);
+    if (cap64 < 64 || words > 0xFFFFFFFFull || m > 0x7FFFFFFFull || r.nslots > kRevLdsSlots || r.nrops > kRevLdsOps) return kTakeLevelLoop;
+    const bool direct = words && h->is_pinned(bitmaps, m * words * sizeof(uint32_t));
+    const size_t ostride = direct ? words : cw;
+    // staging: [flag (64 B)] [counts m x 8] [rows m x cw x 4]
+    const size_t rows_off = 64 + m * sizeof(uint64_t);
+    HIP_TRY(c->h_out.ensure(rows_off + (direct ? 0 : m * std::max<size_t>(cw, 1) * 4)));
+    uint32_t *flag = (uint32_t *)c->h_out.p;
+    uint64_t *h_counts = (uint64_t *)((char *)c->h_out.p + 64);
+    uint32_t *h_rows = (uint32_t *)((char *)c->h_out.p + rows_off);
+    *flag = 0;
+    void *d_sids = nullptr, *d_out = nullptr, *d_rows = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_sids, c->h_in.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
+    if (direct) HIP_TRY(hipHostGetDevicePointer(&d_rows, bitmaps, 0));
+    else d_rows = (char *)d_out + rows_off;
+    ev_begin(c, 3);
+    launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target, c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
+                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out);
+    ev_end(c);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+    if (*flag) {
+        c->stats.overflow_retries++;
+        return kTakeLevelLoop;
+    }
+    uint32_t levels = 0;
+    for (size_t i = 0; i < m; i++) {  // count | levels walked << 56
+        levels = std::max<uint32_t>(levels, (uint32_t)(h_counts[i] >> 56));
+        if (counts) counts[i] = h_counts[i] & 0x00FFFFFFFFFFFFFFull;
+        if (!direct) {
+            uint32_t *dst = bitmaps + i * words;
+            if (cw) std::memcpy(dst, h_rows + i * cw, cw * 4);
+            std::fill(dst + cw, dst + words, 0u);
+        }
+    }
+    c->stats.levels_last = levels;
+    c->stats.rev_local_passes++;
+    c->stats.lookup_requests += m;
+    return ACL_OK;
+}
+
 // one batched reverse walk: n subjects of one class against one (type, permission); bitmaps in host memory
 int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
                  uint64_t *counts) {
@@ -991,8 +1044,18 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
         HIP_TRY(c->d_sids.ensure(m));
         HIP_TRY(c->h_in.ensure(m * sizeof(uint32_t)));
         std::memcpy(c->h_in.p, sids + b, m * sizeof(uint32_t));
+        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords,
+                     (uint32_t)h->snap.rprogs.size(), (uint32_t)h->snap.rops.size()};
+        // ONE launch for the whole group (k_rev_local: a block per lookup walks every reverse level, marks the result bits where they are
+        // produced, and writes the result rows + id counts straight into host memory): no per-level launches, no status round trips, no
+        // memset, no D2H copies.  A lookup that outgrows its block (private frontier region, children per level) sends the group to the
+        // level loop below, which spreads it over the chip.
+        if (h->rev_local) {
+            rc = lookup_pass_local(h, c, r, key, target, m, bitmaps + b * words, words, cw, counts ? counts + b : nullptr);
+            if (rc == ACL_OK) continue;
+            if (rc != kTakeLevelLoop) return rc;
+        }
         HIP_TRY(hipMemcpyAsync(c->d_sids.p, c->h_in.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords};
         HIP_TRY(c->h_out.ensure(m * std::max<size_t>(cw, 1) * 4));
         for (int attempt = 0;; attempt++) {
             if (m > c->frontier_entries) {
@@ -1023,6 +1086,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
             if (cpe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("lookup result copy: ") + hipGetErrorString(cpe));
             break;
         }
+        c->stats.lookup_requests += m;
         for (size_t i = 0; i < m; i++) {
             uint32_t *dst = bitmaps + (b + i) * words;
             if (cw) std::memcpy(dst, (const uint32_t *)c->h_out.p + i * cw, cw * 4);
@@ -1139,6 +1203,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
     h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
+    if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;

@@ -291,6 +291,7 @@ struct acl_engine {
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
+    bool rev_local = true;  // LookupResources: the single-launch reverse walk (k_rev_local) first; ACL_REV_LOCAL=0 = always the level loop (A/B)
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
     size_t lk_n = 0;
     // micro-batching front-end (engine_callers.cpp)

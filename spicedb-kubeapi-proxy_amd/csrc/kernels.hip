@@ -1381,6 +1381,235 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
     }
 }
 
+// ------------------------------------------------------- reverse walk, single launch
+// LookupResources as the proxy issues it: one request per list call (reference pkg/authz/lookups.go:49-83), a few dozen in flight
+// (one goroutine per request: responsefilterer.go:165-204).  The level loop above costs one k_rev_expand launch per reverse level plus a
+// status round trip, whatever the batch size, and writes every result id through the frontier once more before the next launch sets
+// its bit (the level that produces the ~10 k result pods of a C3 lookup is the children of ~100 namespace entries).  Here ONE launch
+// answers the batch: block b walks lookup b through every reverse level by itself.
+//   * entries of a level = true states (object id, slot); their distance is the level: uniform, not stored;
+//   * phase A: every thread takes an entry and turns its program's ops into tasks (row start, degree, target) in an LDS list
+//     (computed-userset parents -- PUSH_SAME -- are visited right there);
+//   * phase B: a block-wide prefix sum over the degrees, then the 1024 lanes walk the OUTPUT index space: lane -> task by a binary
+//     search over the LDS prefix array, consecutive lanes read consecutive resource ids of a reverse row (coalesced), four children
+//     per lane in flight;
+//   * a child is VISITED WHERE IT IS PRODUCED: test-and-set of its bit in the request's visited bitmap (first visit wins; everything
+//     produced in one level has the same distance, so "first" is still "nearest" -- the depth-50 cut depends on it).  Children whose
+//     slot has no parents (the lookup's own result slot, typically) need no answer from the atomic and are never written anywhere
+//     else: the bit IS the result.  Only first visits of states that do have parents enter the block's private frontier region.
+//   * the block zeroes its own bitmap at the start and, at the end, copies the result slot's words to the caller's rows (device,
+//     or pinned host memory: no separate D2H copy) and counts the ids.
+// A block that outgrows its region or meets a level of more than kRevLocalBudget children raises `overflow`: the host redoes the
+// batch on the level loop, which spreads one huge lookup over the whole chip.
+constexpr int kRevLocalThreads = 1024;
+constexpr uint32_t kRevTaskCap = kRevLocalThreads;  // one (state, op) pair per thread and round => at most one task per thread
+constexpr uint32_t kRevLocalBudget = 1u << 22;      // children of one round a single block may enumerate
+constexpr uint32_t kRevTerminal = 0x80000000u;      // task target flag: children are only marked, never expanded
+struct RevTaskLds {
+    uint32_t start[kRevTaskCap];       // first resource id of the row in `redges`
+    uint32_t prefix[kRevTaskCap + 1];  // exclusive prefix of the degrees (a thread without a task: degree 0)
+    uint32_t target[kRevTaskCap];      // child slot | kRevTerminal
+};
+struct RevProgLds {  // the reverse programs, staged once per block (the host only takes this path when they fit)
+    RevOp ops[kRevLdsOps];
+    RevProg progs[kRevLdsSlots];
+    uint2 slot[kRevLdsSlots];  // {first bit of the slot's visited rows, id space they cover}
+};
+
+__global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_slot,
+                                                                 uint2 *buf0, uint2 *buf1, uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride,
+                                                                 uint32_t copy_words, unsigned long long *out_counts, uint32_t *status) {
+    __shared__ RevTaskLds t;
+    __shared__ RevProgLds pl;
+    // s_fill[L % 3]: output cursor of level L (cleared during level L - 1, read at the end of level L)
+    __shared__ uint32_t s_fill[3], s_wave_tot[kRevLocalThreads / 64], s_stop, s_maxops, s_count[kRevLocalThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wib = tid >> 6;
+    const uint32_t req = blockIdx.x;
+    uint32_t *__restrict__ visited = r.visited + (size_t)req * r.visited_words;
+    uint2 *bufs[2] = {buf0 + (size_t)req * cap, buf1 + (size_t)req * cap};
+    const uint2 *__restrict__ rmeta2 = reinterpret_cast<const uint2 *>(r.rmeta);
+    const uint32_t *__restrict__ redges = r.redges;
+    if (tid < 3) s_fill[tid] = 0;
+    if (tid == 0) {
+        s_stop = 0;
+        s_maxops = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < r.nrops; i += kRevLocalThreads) pl.ops[i] = r.rops[i];
+    for (uint32_t i = tid; i < r.nslots; i += kRevLocalThreads) {
+        const RevProg p = r.rprogs[i];
+        pl.progs[i] = p;
+        pl.slot[i] = make_uint2(r.slot_bit_base[i], r.slot_nobjects[i]);
+        atomicMax(&s_maxops, p.n & ~kRevRemoteBit);
+    }
+    const RevProg seed = r.rseeds[key];
+    const uint32_t sid = sids[req];
+    for (uint32_t i = tid; i < r.visited_words; i += kRevLocalThreads) visited[i] = 0u;
+    __threadfence();  // the zeroes are in the L2 before the first atomic of any wave of this block
+    __syncthreads();
+
+    // marks child (slot, id); returns true when it was a first visit of a state that has parents of its own
+    auto visit = [&](uint32_t id, uint32_t tgt, bool valid) -> bool {
+        const uint2 si = pl.slot[tgt & ~kRevTerminal];
+        const bool ok = valid && id < si.y;
+        const uint32_t bit = si.x + (ok ? id : 0u);
+        uint32_t *w = visited + (bit >> 5);
+        const uint32_t m = 1u << (bit & 31u);
+        bool push = false;
+        if (ok) {
+            if (tgt & kRevTerminal) (void)__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: no return trip)
+            else push = !(__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m);
+        }
+        return push;
+    };
+    // wave-cooperative append to the block's output region (call in wave-uniform control flow)
+    auto append = [&](bool push, uint32_t id, uint32_t slot, uint2 *out, uint32_t *fill) {
+        const uint64_t b = __ballot(push);
+        if (!b) return;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(fill, (uint32_t)__popcll(b));
+        base = uniform(base);
+        if (base + (uint32_t)__popcll(b) > cap) {
+            if (lane == 0) s_stop = 1u;
+            return;
+        }
+        if (push) out[base + lanes_below(b)] = make_uint2(id, slot);
+    };
+
+    uint32_t parity = 0, cnt = 1, level = 1;
+    int stop = 0;  // block-uniform copy of s_stop (taken through a barrier: s_stop itself may be raised by a faster wave at any time)
+    for (; level <= kMaxLevels; level++) {  // level L: states at distance L - 1 (all of them: uniform) produce children at distance L
+        const uint2 *__restrict__ fin = bufs[parity];
+        uint2 *fout = bufs[parity ^ 1u];
+        uint32_t *fill = &s_fill[level % 3];
+        if (tid == 0) s_fill[(level + 1) % 3] = 0;
+        // a child at distance 50 is marked but never expanded (its parents would sit at 51): terminal whatever its slot
+        const uint32_t term_all = level >= kMaxLevels ? kRevTerminal : 0u;
+        // work items of a level = (state, op) pairs, one per thread and round: a seed's six rows, or the one or two parent ops of a
+        // few hundred states, are fetched side by side instead of one after the other by the state's thread
+        const uint32_t W = level == 1 ? (seed.n & ~kRevRemoteBit) : s_maxops;
+        const uint32_t npairs = cnt * W;
+        for (uint32_t pb = 0; pb < npairs; pb += kRevLocalThreads) {
+            // ---- phase A: this thread's op -> at most one task (start, degree, target), kept in registers
+            const uint32_t q = pb + tid;
+            uint32_t deg = 0, start = 0, tgt = 0;
+            bool same = false;  // computed-userset parent: the child is the same object
+            uint32_t id = 0;
+            if (q < npairs) {
+                const uint32_t e = q / W, j = q - e * W;
+                RevProg p = seed;
+                id = sid;
+                if (level > 1) {
+                    const uint2 en = fin[e];
+                    id = en.x;
+                    p = pl.progs[en.y];
+                }
+                if (j < (p.n & ~kRevRemoteBit)) {
+                    const RevOp op = pl.ops[p.first + j];
+                    const uint32_t np = pl.progs[op.target].n & ~kRevRemoteBit;
+                    tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all;
+                    if (op.flags & OP_PUSH_SAME) {
+                        same = true;
+                    } else if (id < op.nrows) {
+                        const uint2 rd = rmeta2[op.roff_base + id];
+                        if (rd.y - rd.x > kMaxRow) s_stop = 2u;
+                        else if (rd.y > rd.x) {
+                            start = rd.x;
+                            deg = rd.y - rd.x;
+                        }
+                    }
+                }
+            }
+            {  // same-object parents are visited right here (wave-uniform control flow: the append ballots)
+                const bool push = visit(id, tgt, same);
+                append(push, id, tgt & ~kRevTerminal, fout, fill);
+            }
+            // ---- block-wide exclusive prefix of the degrees
+            const uint32_t incl = wave_incl_scan(deg, lane);
+            if (lane == 63) s_wave_tot[wib] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kRevLocalThreads / 64; w++) {
+                const uint32_t wt = s_wave_tot[w];
+                before += w < wib ? wt : 0u;
+                total += wt;
+            }
+            if (total) {  // (block-uniform)
+                t.prefix[tid] = before + incl - deg;
+                t.start[tid] = start;
+                t.target[tid] = tgt;
+                if (tid == 0 && total > kRevLocalBudget) s_stop = 1u;  // one block should not enumerate this alone: the level loop takes the batch
+                __syncthreads();
+                // ---- phase B: the lanes walk the output index space; lane -> task by binary search (threads without a task have degree 0:
+                // "the last task whose prefix is <= w" is always the one that owns w)
+                if (total <= kRevLocalBudget) {
+                    constexpr int U = 4;  // children per lane in flight
+                    for (uint32_t wb = 0; wb < total; wb += U * kRevLocalThreads) {  // (block-uniform trip count)
+                        uint32_t edge[U], tj[U];
+                        bool valid[U];
+#pragma unroll
+                        for (int k = 0; k < U; k++) {
+                            const uint32_t w = wb + (uint32_t)k * kRevLocalThreads + tid;
+                            valid[k] = w < total;
+                            const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+                            uint32_t jt = 0;
+#pragma unroll
+                            for (uint32_t step = kRevTaskCap / 2; step >= 1; step >>= 1)
+                                if (t.prefix[jt + step] <= wv) jt += step;
+                            tj[k] = jt;
+                            edge[k] = gld(redges, t.start[jt] + (wv - t.prefix[jt]));
+                        }
+                        issue_fence();  // the U gathers travel together
+#pragma unroll
+                        for (int k = 0; k < U; k++) {
+                            if (!__ballot(valid[k])) break;  // (wave-uniform)
+                            const uint32_t tg = t.target[tj[k]];
+                            const bool push = visit(edge[k], tg, valid[k]);
+                            append(push, edge[k], tg & ~kRevTerminal, fout, fill);
+                        }
+                    }
+                }
+            }
+            // (also the barrier behind phase B: every lane is done with the task list before the next round overwrites it)
+            stop = __syncthreads_or(s_stop != 0u);
+            if (stop) break;
+        }
+        if (stop) break;
+        const uint32_t produced = *fill;  // (every append of this level is behind the round's closing barrier; <= cap, or `stop` were set)
+        if (!produced) break;
+        cnt = produced;
+        parity ^= 1u;
+    }
+    if (stop) {
+        // 1: redo on the level loop, 2: a row beyond the per-task enumeration limit.  A plain store (the flag may live in pinned host
+        // memory): blocks that race write non-zero either way, and a 2 lost to a 1 is found again by the level loop.
+        if (tid == 0) *status = s_stop;
+        return;
+    }
+    // ---- result rows: the target slot's words (every one of them was last written by an L2 atomic or by this block's zeroes)
+    __threadfence();
+    const uint32_t w0 = pl.slot[target_slot].x >> 5;
+    uint32_t *orow = out_bitmaps + (size_t)req * out_stride;
+    uint32_t c32 = 0;  // (a row holds < 2^31 ids)
+    for (uint32_t i = tid; i < out_stride; i += kRevLocalThreads) {
+        uint32_t v = 0;
+        if (i < copy_words) v = __hip_atomic_load(visited + w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        orow[i] = v;
+        c32 += (uint32_t)__popc(v);
+    }
+    if (out_counts) {
+        c32 = wave_last(wave_incl_scan(c32, lane));
+        if (lane == 0) s_count[wib] = c32;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+            for (uint32_t w = 0; w < kRevLocalThreads / 64; w++) tot += s_count[w];
+            out_counts[req] = tot | ((unsigned long long)min(level, kMaxLevels) << 56);  // + the reverse levels this lookup walked (statistics)
+        }
+    }
+}
+
 // ------------------------------------------------------------------ import
 // Appends entries of an exchanged export buffer to the frontier iteration `iter` produced (dynamic chunks only:
 // the static chunks belong to that iteration's expand waves).  FWD: keep the entries whose slot this shard owns.
@@ -1596,6 +1825,12 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
     if (phase == REV_VISIT) hipLaunchKernelGGL(k_rev_expand<REV_VISIT>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
     else if (phase == REV_EXPAND) hipLaunchKernelGGL(k_rev_expand<REV_EXPAND>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
     else hipLaunchKernelGGL(k_rev_expand<REV_FUSED>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
+}
+void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
+                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), 0, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps, out_stride,
+                       copy_words, (unsigned long long *)out_counts, status);
 }
 static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input per wave, at most 256 blocks
     const uint32_t b = (n + 4095) / 4096;

@@ -41,7 +41,9 @@ struct DevReverse {
     const uint32_t *slot_nobjects;  // [nslots] id space of the slot's type
     uint32_t *visited;              // [nreq][visited_words]
     uint32_t visited_words;
+    uint32_t nslots = 0, nrops = 0;  // sizes of rprogs / rops (the single-launch walk stages them in LDS when they fit)
 };
+constexpr uint32_t kRevLdsSlots = 256, kRevLdsOps = 384;  // what k_rev_local's LDS copy of the reverse programs holds
 // Chunk ids: [0, nwaves) are the waves' static first chunks (no allocation), ids >= nwaves come from the
 // level's dynamic counter nchunks[iter].  counts[] holds every readable chunk's fill.
 struct DevFrontier {
@@ -97,6 +99,13 @@ constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key 
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
 void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase = REV_FUSED,
                        const DevShard &sh = DevShard());
+// single-launch LookupResources: block b walks lookup b (subject sids[b] of class `key`) through every reverse level; visited rows r.visited
+// (zeroed by the kernel), private frontier regions of `cap` 8-byte entries per block in buf0 / buf1; the result slot's first `copy_words`
+// words go to out_bitmaps + b * out_stride (device or pinned host memory; the rest of the row is zeroed), the id counts to out_counts.
+// *status != 0 afterwards (the caller zeroes it; it may live in pinned host memory): redo on the level loop (1) / a row beyond the enumeration limit (2);
+// out_counts[b] = ids in the row | reverse levels walked << 56
+void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
+                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status);
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 

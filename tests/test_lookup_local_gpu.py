@@ -1,0 +1,126 @@
+"""Single-launch LookupResources (k_rev_local) on the GPU: the reverse walk behind pkg/authz/lookups.go:49-83 in ONE launch per batch.
+Every bitmap must equal the level loop's (k_rev_expand, ACL_REV_LOCAL=0) AND the oracle's id set; the kernel must really be the one
+that ran (stats), pinned result buffers and staged ones must agree, and a lookup that outgrows its block must fall back."""
+import numpy as np
+import pytest
+
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aclgpu(aclgpu_lib):
+    import aclgpu as m
+    return m
+
+
+def ids_of(row):
+    return np.flatnonzero(np.unpackbits(row.view(np.uint8), bitorder="little")).astype(np.uint32)
+
+
+def test_nested_groups_equal_level_loop_and_oracle(aclgpu, monkeypatch):
+    """C4's shape (5-level nested groups, arrows, userset subjects): non-terminal states are pushed through several reverse levels."""
+    from aclgpu import workloads
+    w = workloads.c4(scale=0.02, batch=1000, n_user=5000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rng = np.random.default_rng(11)
+    users = rng.integers(0, w.nobjects["user"], size=40).astype(np.uint32)
+    groups = rng.integers(0, w.nobjects["group"], size=24).astype(np.uint32)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        e.stats_reset()
+        got = {}
+        for rt, perm in (("pod", "view"), ("namespace", "view"), ("group", "member")):
+            got[(rt, perm, "user")] = e.lookup_ids_batch(rt, perm, "user", "", users)
+            got[(rt, perm, "group")] = e.lookup_ids_batch(rt, perm, "group", "member", groups)  # subject with a relation: it is its own member
+        st = e.stats()
+        assert st["rev_local_passes"] == 6 and st["expand_launches"] == 0 and st["lookup_requests"] == 3 * (40 + 24)
+        assert st["levels_last"] >= 2
+    monkeypatch.setenv("ACL_REV_LOCAL", "0")  # (read at acl_open)
+    with aclgpu.Engine(w.schema) as e2:
+        w.load(e2)
+        e2.stats_reset()
+        for (rt, perm, stype), (bms, counts) in got.items():
+            subs, srel = (users, "") if stype == "user" else (groups, "member")
+            b2, c2 = e2.lookup_ids_batch(rt, perm, stype, srel, subs)
+            assert np.array_equal(bms, b2) and np.array_equal(counts, c2), (rt, perm, stype)
+            for i in range(0, subs.size, 5):
+                want = np.sort(o.lookup_ids(rt, perm, stype, srel, int(subs[i])))
+                assert np.array_equal(ids_of(bms[i]), want), (rt, perm, stype, int(subs[i]))
+                assert counts[i] == want.size
+        s2 = e2.stats()
+        assert s2["rev_local_passes"] == 0 and s2["expand_launches"] > 0
+    assert max(int(c.max()) for _b, c in got.values()) > 50  # (the graph is not degenerate)
+
+
+def test_pinned_and_pageable_result_rows_agree(aclgpu):
+    from aclgpu import workloads
+    w = workloads.c3(scale=0.1, batch=256, power_users=16)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        rt, perm, st = w.check
+        subs = np.concatenate([w.lookup_subjects, np.arange(5, dtype=np.uint32)])
+        words = max(1, (e.object_count(rt) + 31) // 32)
+        hb = e.host_alloc(subs.size * words * 4 + subs.size * 8)
+        hb[:] = 0xFF
+        pinned = (hb[:subs.size * words * 4].view(np.uint32).reshape(subs.size, words), hb[subs.size * words * 4:].view(np.uint64))
+        b1, c1 = e.lookup_ids_batch(rt, perm, st, "", subs, out=pinned)
+        assert b1 is pinned[0]
+        b2, c2 = e.lookup_ids_batch(rt, perm, st, "", subs)
+        assert np.array_equal(b1, b2) and np.array_equal(c1, c2)
+        assert c1[:16].min() > 100 and int(c1.sum()) == int(sum(ids_of(r).size for r in b1))
+        # a row wider than the type's id space (the caller's `words` may exceed what the snapshot covers): the tail is zeroed
+        wide = np.full((3, words + 7), 0xFFFFFFFF, dtype=np.uint32)
+        cnt = np.zeros(3, dtype=np.uint64)
+        e._check(e._L.acl_lookup_resources_batch(e._h, e.type_id(rt), e.relation_id(rt, perm), e.type_id(st), e.relation_id(st, ""),
+                                                 subs[:3].ctypes.data, 3, wide.ctypes.data, words + 7, cnt.ctypes.data))
+        assert np.array_equal(wide[:, :words], b1[:3]) and not wide[:, words:].any() and np.array_equal(cnt, c1[:3])
+        e.host_free(hb)
+
+
+def test_depth_limit_and_cycles_reverse(aclgpu):
+    """first visit wins at the level it is produced: a 60-long chain is cut at distance 50 exactly as the level loop and the oracle cut it;
+    cyclic nesting terminates"""
+    schema = "definition user {}\ndefinition group { relation member: user | group#member }"
+    n = 60
+    rels = [f"group:g{i}#member@group:g{i+1}#member" for i in range(n)] + [f"group:g{n}#member@user:deep"]
+    rels += ["group:c0#member@group:c1#member", "group:c1#member@group:c2#member", "group:c2#member@group:c0#member", "group:c1#member@user:loop"]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        e.stats_reset()
+        deep = e.lookup("group", "member", "user", "deep")
+        assert deep == o.lookup("group", "member", "user", "deep") and len(deep) == 50
+        assert e.lookup("group", "member", "user", "loop") == o.lookup("group", "member", "user", "loop") == {"c0", "c1", "c2"}
+        assert e.lookup("group", "member", "group", "g30", "member") == o.lookup("group", "member", "group", "g30", "member")
+        assert e.stats()["rev_local_passes"] == 3
+
+
+def test_block_that_outgrows_its_region_falls_back(aclgpu, monkeypatch):
+    from aclgpu import workloads
+    w = workloads.c3(scale=0.2, batch=256, power_users=8)
+    big = 7  # an ordinary user made a direct viewer of 700 pods: 700 first-level states
+    w.edges.append(("pod", "viewer", "user", "", np.arange(100, 800, dtype=np.uint32), np.full(700, big, dtype=np.uint32)))
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    monkeypatch.setenv("ACL_LOCAL_CAP", "256")  # private frontier region of 256 entries per lookup (read at acl_open)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        rt, perm, st = w.check
+        subs = np.concatenate([w.lookup_subjects[:4], np.asarray([big], dtype=np.uint32)])
+        e.stats_reset()
+        bms, counts = e.lookup_ids_batch(rt, perm, st, "", subs)  # one lookup of the group overflows: the whole group takes the level loop
+        s_ = e.stats()
+        assert s_["overflow_retries"] >= 1 and s_["expand_launches"] > 0 and s_["rev_local_passes"] == 0
+        for i, s in enumerate(subs):
+            want = np.sort(o.lookup_ids(rt, perm, st, "", int(s)))
+            assert np.array_equal(ids_of(bms[i]), want) and counts[i] == want.size
+        assert counts[-1] >= 700
+        # the others fit: the single launch answers
+        e.stats_reset()
+        b4, c4 = e.lookup_ids_batch(rt, perm, st, "", subs[:4])
+        assert e.stats()["rev_local_passes"] == 1 and np.array_equal(b4, bms[:4]) and np.array_equal(c4, counts[:4])
