@@ -992,12 +992,19 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
     void *d_sids = nullptr, *d_out = nullptr, *d_rows = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_sids, c->h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
-    if (direct) HIP_TRY(hipHostGetDevicePointer(&d_rows, bitmaps, 0));
+    // Result rows: written by the kernel straight into host memory (each block as it finishes), or -- rev_rows_device, A/B knob
+    // ACL_REV_ROWS=device -- into a device buffer that one DMA copy brings over afterwards.
+    const bool via_device = h->rev_rows_device && ostride;
+    if (via_device) {
+        HIP_TRY(c->d_rows.ensure(m * ostride));
+        d_rows = c->d_rows.p;
+    } else if (direct) HIP_TRY(hipHostGetDevicePointer(&d_rows, bitmaps, 0));
     else d_rows = (char *)d_out + rows_off;
     ev_begin(c, 3);
     launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target, c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
-                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out);
+                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u);
     ev_end(c);
+    if (via_device) HIP_TRY(hipMemcpyAsync(direct ? (void *)bitmaps : (void *)h_rows, c->d_rows.p, m * ostride * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
@@ -1204,6 +1211,8 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     h->grid_blocks = expand_grid_blocks(dev);
     h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
+    if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;

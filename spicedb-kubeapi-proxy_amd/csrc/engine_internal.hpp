@@ -195,7 +195,7 @@ struct PassCtx {
     DevArray<uint8_t> d_has, d_err, d_perm, d_keep;
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
-    DevArray<uint32_t> d_itemoff, d_sids, d_visited;
+    DevArray<uint32_t> d_itemoff, d_sids, d_visited, d_rows;
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
@@ -291,6 +291,8 @@ struct acl_engine {
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
+    bool rev_rows_device = false;  // k_rev_local's result rows through a device buffer + one DMA copy instead of kernel writes to host memory (A/B)
+    bool rev_lds_rows = true;  // k_rev_local keeps the result slot's rows in LDS when they fit (ACL_REV_LDS_ROWS=0: always in HBM; A/B and tests)
     bool rev_local = true;  // LookupResources: the single-launch reverse walk (k_rev_local) first; ACL_REV_LOCAL=0 = always the level loop (A/B)
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
     size_t lk_n = 0;

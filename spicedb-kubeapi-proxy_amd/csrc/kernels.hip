@@ -1418,9 +1418,13 @@ struct RevProgLds {  // the reverse programs, staged once per block (the host on
 
 __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_slot,
                                                                  uint2 *buf0, uint2 *buf1, uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride,
-                                                                 uint32_t copy_words, unsigned long long *out_counts, uint32_t *status) {
+                                                                 uint32_t copy_words, unsigned long long *out_counts, uint32_t *status, uint32_t lds_words) {
     __shared__ RevTaskLds t;
     __shared__ RevProgLds pl;
+    // lds_words != 0: the RESULT slot's rows live here, not in `visited` -- the level that produces a lookup's ids (thousands of pods under
+    // a few hundred namespaces) then marks them with LDS atomics instead of L2 atomics, and the result row is copied out of LDS.  The
+    // launcher sizes it to the slot's id space (up to 128 KiB = 1 M objects; beyond that, lds_words == 0 and the rows stay in HBM).
+    extern __shared__ uint32_t s_row[];
     // s_fill[L % 3]: output cursor of level L (cleared during level L - 1, read at the end of level L)
     __shared__ uint32_t s_fill[3], s_wave_tot[kRevLocalThreads / 64], s_stop, s_maxops, s_count[kRevLocalThreads / 64];
     const uint32_t tid = threadIdx.x, lane = lane_id(), wib = tid >> 6;
@@ -1444,21 +1448,34 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     }
     const RevProg seed = r.rseeds[key];
     const uint32_t sid = sids[req];
-    for (uint32_t i = tid; i < r.visited_words; i += kRevLocalThreads) visited[i] = 0u;
-    __threadfence();  // the zeroes are in the L2 before the first atomic of any wave of this block
+    const uint32_t row_w0 = r.slot_bit_base[target_slot] >> 5;  // first word of the result slot's rows in `visited`
+    for (uint32_t i = tid; i < lds_words; i += kRevLocalThreads) s_row[i] = 0u;
+    for (uint32_t i = tid; i < r.visited_words; i += kRevLocalThreads)
+        if (i - row_w0 >= lds_words) visited[i] = 0u;  // (unsigned: also true below row_w0)
+    // The bitmap is private to this block: WORKGROUP scope everywhere.  The zeroes are write-through stores, acknowledged by this XCD's L2
+    // before the barrier; the atomics below execute in that same L2.  (Agent scope here was the kernel's whole cost beyond 16 lookups: an
+    // agent-scope atomic on gfx950 is a fabric transaction that drops the line from the L2, and __threadfence() walks the L2's dirty lines.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
 
     // marks child (slot, id); returns true when it was a first visit of a state that has parents of its own
     auto visit = [&](uint32_t id, uint32_t tgt, bool valid) -> bool {
-        const uint2 si = pl.slot[tgt & ~kRevTerminal];
+        const uint32_t slot = tgt & ~kRevTerminal;
+        const uint2 si = pl.slot[slot];
         const bool ok = valid && id < si.y;
+        bool push = false;
+        if (ok && lds_words && slot == target_slot) {
+            const uint32_t m = 1u << (id & 31u);
+            if (tgt & kRevTerminal) (void)atomicOr(&s_row[id >> 5], m);
+            else push = !(atomicOr(&s_row[id >> 5], m) & m);
+            return push;
+        }
         const uint32_t bit = si.x + (ok ? id : 0u);
         uint32_t *w = visited + (bit >> 5);
         const uint32_t m = 1u << (bit & 31u);
-        bool push = false;
         if (ok) {
-            if (tgt & kRevTerminal) (void)__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (result unused: no return trip)
-            else push = !(__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m);
+            if (tgt & kRevTerminal) (void)__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (result unused: no return trip)
+            else push = !(__hip_atomic_fetch_or(w, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & m);
         }
         return push;
     };
@@ -1587,14 +1604,15 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         if (tid == 0) *status = s_stop;
         return;
     }
-    // ---- result rows: the target slot's words (every one of them was last written by an L2 atomic or by this block's zeroes)
-    __threadfence();
-    const uint32_t w0 = pl.slot[target_slot].x >> 5;
+    // ---- result rows: the target slot's words (every one of them was last written by an L2 atomic or by this block's zeroes; the
+    // loads below are served by that L2 -- sc1 loads bypass the vector L1, which atomics never update)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
     uint32_t *orow = out_bitmaps + (size_t)req * out_stride;
     uint32_t c32 = 0;  // (a row holds < 2^31 ids)
     for (uint32_t i = tid; i < out_stride; i += kRevLocalThreads) {
         uint32_t v = 0;
-        if (i < copy_words) v = __hip_atomic_load(visited + w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i < copy_words) v = lds_words ? s_row[i] : __hip_atomic_load(visited + row_w0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         orow[i] = v;
         c32 += (uint32_t)__popc(v);
     }
@@ -1827,10 +1845,12 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
     else hipLaunchKernelGGL(k_rev_expand<REV_FUSED>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
 }
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
-                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status) {
+                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status, uint32_t lds_row_words) {
     if (!n) return;
-    hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), 0, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps, out_stride,
-                       copy_words, (unsigned long long *)out_counts, status);
+    static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rev_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRevLdsRowBytes) == hipSuccess;
+    if (lds_row_words * 4u > (big_lds ? kRevLdsRowBytes : 32768u)) lds_row_words = 0;  // rows stay in HBM
+    hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), (size_t)lds_row_words * 4, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps,
+                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words);
 }
 static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input per wave, at most 256 blocks
     const uint32_t b = (n + 4095) / 4096;

@@ -43,6 +43,7 @@ struct DevReverse {
     uint32_t visited_words;
     uint32_t nslots = 0, nrops = 0;  // sizes of rprogs / rops (the single-launch walk stages them in LDS when they fit)
 };
+constexpr uint32_t kRevLdsRowBytes = 128u << 10;  // the result slot's rows live in LDS up to this size (1 M objects)
 constexpr uint32_t kRevLdsSlots = 256, kRevLdsOps = 384;  // what k_rev_local's LDS copy of the reverse programs holds
 // Chunk ids: [0, nwaves) are the waves' static first chunks (no allocation), ids >= nwaves come from the
 // level's dynamic counter nchunks[iter].  counts[] holds every readable chunk's fill.
@@ -105,7 +106,8 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
 // *status != 0 afterwards (the caller zeroes it; it may live in pinned host memory): redo on the level loop (1) / a row beyond the enumeration limit (2);
 // out_counts[b] = ids in the row | reverse levels walked << 56
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
-                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status);
+                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status,
+                      uint32_t lds_row_words /* words covering the result slot's id space: kept in LDS when <= kRevLdsRowBytes, else (or 0) in r.visited */);
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 

@@ -54,6 +54,17 @@ def test_nested_groups_equal_level_loop_and_oracle(aclgpu, monkeypatch):
         s2 = e2.stats()
         assert s2["rev_local_passes"] == 0 and s2["expand_launches"] > 0
     assert max(int(c.max()) for _b, c in got.values()) > 50  # (the graph is not degenerate)
+    # the result slot's rows in HBM (what a type of more than 1 M objects gets) instead of LDS: same rows
+    monkeypatch.delenv("ACL_REV_LOCAL")
+    monkeypatch.setenv("ACL_REV_LDS_ROWS", "0")
+    with aclgpu.Engine(w.schema) as e3:
+        w.load(e3)
+        e3.stats_reset()
+        for (rt, perm, stype), (bms, counts) in got.items():
+            subs, srel = (users, "") if stype == "user" else (groups, "member")
+            b3, c3 = e3.lookup_ids_batch(rt, perm, stype, srel, subs)
+            assert np.array_equal(bms, b3) and np.array_equal(counts, c3), (rt, perm, stype)
+        assert e3.stats()["rev_local_passes"] == 6
 
 
 def test_pinned_and_pageable_result_rows_agree(aclgpu):
