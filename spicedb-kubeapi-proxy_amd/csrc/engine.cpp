@@ -160,14 +160,15 @@ static bool compaction_due(acl_engine *h) {
     const Snapshot &s = h->snap;
     if (s.garbage_words * 8 > s.edges.size() + s.buckets.size() + 65536) return true;  // half of the 25 % that forces a rebuild
     const Schema &sc = h->store.schema();
-    for (int slot = 0; slot < sc.nslots && slot < (int)s.lay.size(); slot++) {  // half of a table's headroom for new objects used up
+    // a table's spare ids running low: fewer left than a tenth of the table, or than 8 192 (half of the smallest headroom) -- the build
+    // must finish before they are gone, and a small table of a fast-growing type (lock / workflow / activity ids) has no "last 10 %" to speak of
+    auto low = [](uint64_t used, uint64_t cap) { return cap && used + std::max<uint64_t>(cap / 10, 8192) > cap; };
+    for (int slot = 0; slot < sc.nslots && slot < (int)s.lay.size(); slot++) {
         const RelLayout &l = s.lay[slot];
-        if (l.nrows && (uint64_t)h->store.objects(sc.slot_owner[slot].first).count() * 10 > (uint64_t)l.nrows * 9) return true;
+        if (low(h->store.objects(sc.slot_owner[slot].first).count(), l.nrows)) return true;
         for (size_t k = 0; k < l.cls.size(); k++) {
             const auto [t, m] = sc.slot_owner[slot];
-            if (l.cls[k].hashed && l.cls[k].nsubjects &&
-                (uint64_t)h->store.objects(sc.defs[t].members[m].classes[k].stype).count() * 10 > (uint64_t)l.cls[k].nsubjects * 9)
-                return true;
+            if (l.cls[k].hashed && low(h->store.objects(sc.defs[t].members[m].classes[k].stype).count(), l.cls[k].nsubjects)) return true;
         }
     }
     return false;
@@ -177,7 +178,11 @@ static void compaction_start(acl_engine *h) {
     if (!h->compaction_enabled || h->store_only) return;
     if (!h->compaction) h->compaction = std::make_unique<Compaction>();
     Compaction *c = h->compaction.get();
-    if (c->state.load() == 1) return;  // one at a time
+    // one at a time -- and a FINISHED build (2) waits for the next reader to adopt it: starting another one here threw it away.  That was not
+    // rare: the worker's last uploads and this thread's patch upload meet in the runtime, so the build tended to finish exactly between this
+    // read's adoption check and this call (4 of 5 builds were dropped in the dual-write run, and the tables ran out of spare ids meanwhile).
+    if (c->state.load() == 1 || c->state.load() == 2) return;
+    if (getenv("ACL_DEBUG_REBUILD")) fprintf(stderr, "[aclgpu] background build starts at revision %llu (previous state %d)\n", (unsigned long long)h->store.revision(), c->state.load());
     if (c->worker.joinable()) c->worker.join();
     if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
     auto view = std::make_shared<Store>(h->store.view());  // tables shared copy-on-write: O(#tables), not O(#relationships)
@@ -216,7 +221,10 @@ void compaction_join(acl_engine *h) {
 static bool compaction_adopt(acl_engine *h, int64_t now) {
     Compaction *c = h->compaction.get();
     if (!c || c->state.load() != 2) {
-        if (c && c->state.load() == 3) c->state.store(0);
+        if (c && c->state.load() == 3) {
+            if (getenv("ACL_DEBUG_REBUILD")) fprintf(stderr, "[aclgpu] background build failed: %s\n", c->error.c_str());
+            c->state.store(0);
+        }
         return false;
     }
     c->state.store(0);
@@ -224,6 +232,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world) return false;
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
+    if (getenv("ACL_DEBUG_REBUILD")) fprintf(stderr, "[aclgpu] adopting the background build of revision %llu at revision %llu\n", (unsigned long long)from, (unsigned long long)h->store.revision());
     if (!patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19)) return false;  // (a bulk load meanwhile: the synchronous path decides)
     bool rev_ok = c->with_reverse && patch_reverse(h->store, now, from, &c->snap, h->shard, &patches);
     hipStream_t s = h->up_stream;

@@ -77,7 +77,7 @@ struct Flattener {
     void row_op(uint32_t flags, int rel_slot, int k, uint32_t d, uint32_t key) {
         const RelLayout &l = lay[rel_slot];
         const ClassLayout &c = l.cls[k];
-        if (!c.live) return;  // empty class: nothing to probe or enumerate in this snapshot
+        if (!c.live) return;  // rows held by another shard and referenced from here only through exports (sharded graph)
         FwdOp op{};
         op.dlevel = d;
         op.key = key;
@@ -157,7 +157,11 @@ void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
 }  // namespace
 
 // tables are sized for objects that do not exist yet, so that writes naming new objects can be patched in
-uint32_t with_headroom(uint32_t n) { return n + n / 4 + 1024; }
+// A quarter more than there is, and never fewer than 16 384 spare ids: the dual-write workflow names a new lock, a new workflow and two new
+// activities per kube write (workflow.go:392-418, activity.go:81-102), so types that START empty grow by thousands of ids between two
+// compactions -- with 1 024 spare ids the tables of `activity` were outgrown every ~500 kube writes, faster than a background build of the
+// 10 M graph finishes (9 synchronous rebuilds in 37 k kube writes, profiles/r03_dual_write_before.json).  8 B per spare id and class.
+uint32_t with_headroom(uint32_t n) { return n + n / 4 + 16384; }
 
 uint32_t shard_of_type(const std::string &type_name, uint32_t world) {
     uint32_t h = 2166136261u;  // FNV-1a
@@ -209,11 +213,15 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             ClassLayout &c = l.cls[k];
             const ClassTable &ct = tables[slot][k];
             c.hashed = mem.classes[k].srel == kNoRelation && !is_tupleset[slot];
-            if (ct.expiry.empty()) c.live = !ct.keys.empty();
-            else
-                for (uint64_t key : ct.keys)
-                    if (store.live(ct, key, now)) { c.live = true; break; }
-            if (c.live && !c.hashed) c.ks = type_ks[t]++;
+            // Every class the schema DECLARES gets descriptors and program ops, relationships or not.  A class that
+            // was skipped while empty made its first relationship unpatchable -- the parents' programs had no op for it -- and the next
+            // fully-consistent read (check.go:41-46) rebuilt the whole snapshot: 100-140 ms on the 10 M graph.  The dual-write path hits
+            // exactly that: `lock:<hash>#workflow@workflow:<id>` is created and deleted around every kube write (workflow.go:392-418), so on a
+            // quiet proxy the class is empty at every build.  An empty class costs 8 B per object / subject of descriptors pointing at
+            // nothing and one op per program that walks it.
+            (void)ct;
+            c.live = true;
+            if (!c.hashed) c.ks = type_ks[t]++;
         }
     }
     for (size_t t = 0; t < sc.defs.size(); t++) {
@@ -477,24 +485,22 @@ struct Patcher {
 
 }  // namespace
 
-void expiry_crossings(const Store &store, int64_t lo, int64_t hi, int64_t now, std::vector<Store::Change> *ch) {
-    if (now >= lo && now < hi) return;
-    // the snapshot held exactly the relationships expiring at or after `hi` (Store::expiry_window: nothing expires inside the window);
-    // at `now` those expiring after `now` are alive
-    const auto &tables = store.tables();
-    for (size_t slot = 0; slot < tables.size(); slot++)
-        for (size_t cls = 0; cls < tables[slot].size(); cls++)
-            for (const auto &kv : tables[slot][cls].expiry)
-                if ((kv.second >= hi) != (kv.second > now)) ch->push_back(Store::Change{0, 0 /* op: the patchers look the relationship up */, (int32_t)slot, (int32_t)cls, kv.first});
+void expiry_crossings(const Store &store, int64_t lo, int64_t hi, int64_t now, std::vector<Store::Change> *ch) { store.expiry_crossings(lo, hi, now, ch); }
+
+// ACL_DEBUG_REBUILD: say why a snapshot could not be patched (the caller then rebuilds, or drops a background build)
+static bool unpatchable(const char *why, uint64_t a = 0, uint64_t b = 0) {
+    static const bool on = getenv("ACL_DEBUG_REBUILD") != nullptr;
+    if (on) fprintf(stderr, "[aclgpu] patch_forward declines: %s (%llu, %llu)\n", why, (unsigned long long)a, (unsigned long long)b);
+    return false;
 }
 
 bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches, size_t max_changes) {
     Snapshot &s = *snap;
     std::vector<Store::Change> ch;
-    if (s.lay.empty()) return false;
-    if (!store.raw_changes_since(s.revision, &ch)) return false;
+    if (s.lay.empty()) return unpatchable("no layout");
+    if (!store.raw_changes_since(s.revision, &ch)) return unpatchable("change feed does not reach back to the snapshot's revision (bulk load / dropped window)", s.revision, store.revision());
     expiry_crossings(store, s.valid_lo, s.valid_hi, now, &ch);
-    if (ch.size() > (max_changes ? max_changes : kMaxPatchChanges)) return false;
+    if (ch.size() > (max_changes ? max_changes : kMaxPatchChanges)) return unpatchable("too many changes", ch.size(), max_changes ? max_changes : kMaxPatchChanges);
     store.settle_all();
     const Schema &sc = store.schema();
     // objects created since the build must fit the headroom of every table they index
@@ -503,9 +509,10 @@ bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, s
         const Member &mem = sc.defs[t].members[m];
         if (mem.is_permission || s.type_owner[t] != shard.rank) continue;
         const RelLayout &l = s.lay[slot];
-        if (store.objects(t).count() > l.nrows) return false;
+        if (store.objects(t).count() > l.nrows) return unpatchable("objects of a relation's type outgrew its row table", store.objects(t).count(), l.nrows);
         for (size_t k = 0; k < mem.classes.size(); k++)
-            if (l.cls[k].live && l.cls[k].hashed && store.objects(mem.classes[k].stype).count() > l.cls[k].nsubjects) return false;
+            if (l.cls[k].live && l.cls[k].hashed && store.objects(mem.classes[k].stype).count() > l.cls[k].nsubjects)
+                return unpatchable("subjects of a hashed class outgrew its descriptor table", store.objects(mem.classes[k].stype).count(), l.cls[k].nsubjects);
     }
     std::sort(ch.begin(), ch.end(), [](const Store::Change &a, const Store::Change &b) {
         return a.slot != b.slot ? a.slot < b.slot : a.cls != b.cls ? a.cls < b.cls : a.key < b.key;
@@ -517,7 +524,7 @@ bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, s
         const int t = sc.slot_owner[c.slot].first;
         if (s.type_owner[t] != shard.rank) continue;
         const ClassTable &ct = tables[c.slot][c.cls];
-        if (!s.lay[c.slot].cls[c.cls].live && ct.contains(c.key) && store.live(ct, c.key, now)) return false;  // the class has no program op yet
+        if (!s.lay[c.slot].cls[c.cls].live && ct.contains(c.key) && store.live(ct, c.key, now)) return unpatchable("relationship in a class without rows");  // (cannot happen for a class of an owned type: all are live)
     }
     for (size_t i = 0; i < ch.size(); i++) {
         const Store::Change &c = ch[i];

@@ -42,18 +42,14 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             const ClassTable &ct = tables[slot][k];
             // `any` is a property of the whole graph (it decides which shards a true state must be sent to);
             // the rows themselves are only built on the shard that owns the relation's type
+            // every declared class counts as live, with or without relationships (as in build_forward: the first relationship of a class
+            // must be a patch, not a reason to rebuild the parents' programs)
             if (type_owner[t] != shard.rank) {
-                const bool f2 = !ct.expiry.empty();
-                for (uint64_t key : ct.keys)
-                    if (!f2 || store.live(ct, key, now)) { rl[slot][k].any = true; break; }
+                rl[slot][k].any = true;
                 continue;
             }
             const bool filt = !ct.expiry.empty();
             const uint32_t ns = with_headroom(store.objects(mem.classes[k].stype).count());
-            size_t total = 0;
-            for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) total++;
-            if (!total) continue;
             RevLayout &l = rl[slot][k];
             l.any = true;
             l.nrows = ns;
@@ -196,7 +192,7 @@ bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *
         const auto &l = s.rlay[c.slot][c.cls];
         const ClassTable &ct = tables[c.slot][c.cls];
         const bool want = ct.contains(c.key) && store.live(ct, c.key, now);
-        if (!l.any && want) return false;  // a class became live: parent programs change
+        if (!l.any && want) return false;  // (cannot happen: every declared class has reverse rows)
         if (l.any && s.type_owner[sc.slot_owner[c.slot].first] == shard.rank && (uint32_t)c.key >= l.nrows) return false;
     }
     for (size_t i = 0; i < ch.size(); i++) {

@@ -120,6 +120,7 @@ Status Store::load_schema(const std::string &text) {
     schema_loaded_ = true;
     objects_.assign(schema_.defs.size(), ObjectTable());
     tables_.assign(schema_.nslots, {});
+    expiry_index_.clear();
     for (int slot = 0; slot < schema_.nslots; slot++) {
         auto [t, m] = schema_.slot_owner[slot];
         tables_[slot].assign(schema_.defs[t].members[m].classes.size(), ClassTable());
@@ -150,7 +151,8 @@ Store Store::view() {
     v.schema_loaded_ = schema_loaded_;
     v.objects_.resize(objects_.size());
     for (size_t t = 0; t < objects_.size(); t++) v.objects_[t].reserve_ids(objects_[t].count());
-    v.tables_ = tables_;  // CowKeys copies share their vectors; the (small) expiry maps are copied
+    v.tables_ = tables_;  // CowKeys copies share their vectors; the expiry maps and their index are copied
+    v.expiry_index_ = expiry_index_;
     v.revision_ = revision_;
     v.now_override_ = now_override_;
     v.log_floor_ = revision_;
@@ -166,12 +168,56 @@ void Store::settle_all() {
 void Store::expiry_window(int64_t now, int64_t *lo, int64_t *hi) const {
     *lo = LLONG_MIN;
     *hi = LLONG_MAX;
-    for (const auto &slot : tables_)
-        for (const auto &ct : slot)
-            for (const auto &kv : ct.expiry) {
-                if (kv.second <= now) *lo = std::max(*lo, kv.second);
-                else *hi = std::min(*hi, kv.second);
-            }
+    // first entry expiring after `now`; the one before it is the last that expired at or before `now`
+    auto it = expiry_index_.upper_bound(ExpiryEntry{now, INT32_MAX, INT32_MAX, UINT64_MAX});
+    if (it != expiry_index_.end()) *hi = it->at;
+    if (it != expiry_index_.begin()) *lo = std::prev(it)->at;
+}
+
+void Store::expiry_crossings(int64_t lo, int64_t hi, int64_t now, std::vector<Change> *out) const {
+    if (now >= lo && now < hi) return;
+    // the snapshot held exactly the relationships expiring at or after `hi` (nothing expires inside its window); at `now` those expiring
+    // after `now` are alive: the two differ on hi <= at <= now (clock moved on) or now < at < hi (a test clock set back)
+    const int64_t a = now >= hi ? hi : now + 1, b = now >= hi ? now : hi - 1;
+    for (auto it = expiry_index_.lower_bound(ExpiryEntry{a, INT32_MIN, INT32_MIN, 0}); it != expiry_index_.end() && it->at <= b; ++it)
+        out->push_back(Change{0, 0 /* op: the patchers look the relationship up */, it->slot, it->cls, it->key});
+}
+
+void Store::set_expiry(int slot, int cls, uint64_t key, int64_t at) {
+    ClassTable &ct = tables_[slot][cls];
+    auto it = ct.expiry.find(key);
+    if (it != ct.expiry.end()) {
+        if (it->second == at) return;
+        expiry_index_.erase(ExpiryEntry{it->second, slot, cls, key});
+        if (at) it->second = at;
+        else ct.expiry.erase(it);
+    } else if (at) {
+        ct.expiry.emplace(key, at);
+    }
+    if (at) expiry_index_.insert(ExpiryEntry{at, slot, cls, key});
+}
+
+size_t Store::gc_expired(int64_t now) {
+    size_t n = 0;
+    bool bumped = false;
+    while (!expiry_index_.empty() && expiry_index_.begin()->at <= now - kGcWindowSeconds) {
+        const ExpiryEntry e = *expiry_index_.begin();
+        ClassTable &ct = tables_[e.slot][e.cls];
+        ct.settle();
+        if (ct.contains(e.key)) {
+            auto &kv = ct.keys.mut();
+            kv.erase(std::lower_bound(kv.begin(), kv.end(), e.key));
+        }
+        ct.expiry.erase(e.key);
+        expiry_index_.erase(expiry_index_.begin());
+        if (!bumped) {
+            revision_++;
+            bumped = true;
+        }
+        log_change(0, e.slot, e.cls, e.key);
+        n++;
+    }
+    return n;
 }
 
 Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
@@ -309,19 +355,19 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
                 auto &kv = ct.keys.mut();
                 kv.erase(std::lower_bound(kv.begin(), kv.end(), key));
             }
-            ct.expiry.erase(key);
+            set_expiry(rs[i].slot, rs[i].cls, key, 0);
         } else {
             if (!present) {
                 auto &kv = ct.keys.mut();
                 kv.insert(std::lower_bound(kv.begin(), kv.end(), key), key);
             }
-            if (rs[i].expires) ct.expiry[key] = rs[i].expires;
-            else ct.expiry.erase(key);
+            set_expiry(rs[i].slot, rs[i].cls, key, rs[i].expires);
         }
     }
     revision_++;
     for (size_t i = 0; i < updates.size(); i++)
         if (!skip[i]) log_change(updates[i].op == ACL_OP_DELETE ? ACL_OP_DELETE : ACL_OP_TOUCH, rs[i].slot, rs[i].cls, (uint64_t)rs[i].res << 32 | rs[i].subj);
+    if (!expiry_index_.empty()) gc_expired(t);  // (its removals get a revision of their own: the API write's updates stay one Watch event)
     if (revision) *revision = revision_;
     return Status::Ok();
 }
@@ -371,7 +417,7 @@ Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t
             auto &kv = ct.keys.mut();
             kv.erase(std::lower_bound(kv.begin(), kv.end(), h.key));
         }
-        ct.expiry.erase(h.key);
+        set_expiry(h.slot, h.cls, h.key, 0);
     }
     revision_++;
     for (const Hit &h : hits) log_change(ACL_OP_DELETE, h.slot, h.cls, h.key);
@@ -419,6 +465,7 @@ bool Store::changes_since(uint64_t after, const std::vector<int> &types, const s
     if (after < log_floor_) return false;
     auto it = std::upper_bound(log_.begin(), log_.end(), after, [](uint64_t a, const Change &c) { return a < c.revision; });
     for (; it != log_.end(); ++it) {
+        if (!it->op) continue;  // garbage collection of a long-expired relationship: not an API write
         const int t = schema_.slot_owner[it->slot].first;
         if (!types.empty() && std::find(types.begin(), types.end(), t) == types.end()) continue;
         fn(*it, rel_text(it->slot, it->cls, it->key));

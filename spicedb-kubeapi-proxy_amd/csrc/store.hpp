@@ -17,6 +17,7 @@
 #include <deque>
 #include <functional>
 #include <memory>
+#include <set>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -159,6 +160,17 @@ class Store {
     }
     // interval of `now` values for which a snapshot built at `now` stays exact: [lo, hi)
     void expiry_window(int64_t now, int64_t *lo, int64_t *hi) const;
+    // the relationships whose liveness differs between a snapshot valid for [lo, hi) and `now` (appended; nothing when now is inside).
+    // Both are range queries on an index ordered by expiry time: every dual write leaves two expiring idempotency keys behind
+    // (activity.go:81-102), and a scan over all of them per snapshot update cost 1 ms per read after 100 k kube writes.
+    struct Change;
+    void expiry_crossings(int64_t lo, int64_t hi, int64_t now, std::vector<Change> *out) const;
+    // Drops relationships that expired more than kGcWindowSeconds ago (the reference's engine collects garbage after 24 h,
+    // pkg/spicedb/spicedb.go:66).  They have been invisible since their expiry; each removal still enters the change feed as a
+    // "look it up" entry (op 0) so that a snapshot which was idle across the expiry patches the row out.  Runs inside write().
+    size_t gc_expired(int64_t now);
+    static constexpr int64_t kGcWindowSeconds = 24 * 3600;
+    size_t expiring_relationships() const { return expiry_index_.size(); }
 
     int class_index(int slot, int stype, int srel) const;
 
@@ -166,7 +178,7 @@ class Store {
     // write() / delete_by_filter(), in commit order.  Bulk loads (bootstrap, add_edges) are not part of the feed.
     struct Change {
         uint64_t revision;
-        int32_t op;  // ACL_OP_TOUCH (created or touched) / ACL_OP_DELETE
+        int32_t op;  // ACL_OP_TOUCH (created or touched) / ACL_OP_DELETE / 0 = not an API write (expiry crossing, garbage collection): never shown to Watch
         int32_t slot, cls;
         uint64_t key;  // res << 32 | subj
     };
@@ -191,6 +203,17 @@ class Store {
     Status eval_preconditions(const std::vector<FilterText> &pre, int64_t now);
     // calls fn(slot, class, key) for every live relationship matching f; stops when fn returns false
     void scan(const FilterText &f, int64_t now, const std::function<bool(int, int, uint64_t)> &fn);
+
+    struct ExpiryEntry {
+        int64_t at;
+        int32_t slot, cls;
+        uint64_t key;
+        bool operator<(const ExpiryEntry &o) const {
+            return at != o.at ? at < o.at : slot != o.slot ? slot < o.slot : cls != o.cls ? cls < o.cls : key < o.key;
+        }
+    };
+    std::set<ExpiryEntry> expiry_index_;  // every entry of every ClassTable::expiry, ordered by expiry time
+    void set_expiry(int slot, int cls, uint64_t key, int64_t at);  // at == 0: the relationship does not expire (any more)
 
     Schema schema_;
     bool schema_loaded_ = false;

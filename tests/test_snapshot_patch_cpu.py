@@ -75,17 +75,18 @@ def test_what_cannot_be_patched_is_rebuilt(aclgpu):
     e = aclgpu.Engine(SCHEMA, store_only=True)
     e.write([(aclgpu.OP_TOUCH, "doc:d0#viewer@user:u0")])
     e.selfcheck_snapshot()
-    # first relationship ever in a class: the programs have no op for it yet -> rebuild
+    # first relationship ever in a class: every DECLARED class has descriptors and program ops from the build on, so this is a patch
+    # (it used to rebuild the whole snapshot: the dual-write's lock tuple hits an empty class on every quiet proxy, workflow.go:392-418)
     e.write([(aclgpu.OP_TOUCH, "org:o0#admin@user:u0")])
-    assert e.selfcheck_snapshot() is False
+    assert e.selfcheck_snapshot() is True
     e.write([(aclgpu.OP_TOUCH, "org:o1#admin@user:u1")])
     assert e.selfcheck_snapshot() is True
     # bulk loads bypass the change feed -> rebuild
     import numpy as np
     e.add_edges("doc", "viewer", "user", "", np.array([0], dtype=np.uint32), np.array([1], dtype=np.uint32))
     assert e.selfcheck_snapshot() is False
-    # more new objects than the tables' headroom (1024 + 25 %) -> rebuild, and the rebuilt tables fit again
-    for base in range(0, 3000, 500):
+    # more new objects than the tables' headroom (16 384 + 25 %) -> rebuild, and the rebuilt tables fit again
+    for base in range(0, 18000, 500):
         e.write([(aclgpu.OP_TOUCH, f"doc:new{base + i}#viewer@user:u0") for i in range(500)])
     assert e.selfcheck_snapshot() is False
     e.write([(aclgpu.OP_TOUCH, "doc:one-more#viewer@user:u0")])
@@ -111,6 +112,31 @@ def test_expiring_relationships_and_the_patch_window(aclgpu):
     e.set_now(2000)  # both gone
     assert e.selfcheck_snapshot() is True
     assert e.read(rtype="workflow") == []
+    e.close()
+
+
+def test_expired_relationships_are_collected_after_the_gc_window(aclgpu):
+    """Idempotency keys (activity.go:81-102) pile up at two per kube write; the store drops them 24 h after they expired (the reference engine's
+    GC window, pkg/spicedb/spicedb.go:66).  A snapshot that slept through both the expiry and the collection still patches the rows out, and
+    Watch never reports the collection (it is not an API write)."""
+    from tests import kat_runner
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], store_only=True)
+    t0 = 1_000_000
+    e.set_now(t0)
+    e.write([(aclgpu.OP_TOUCH, ("workflow", f"w{i}", "idempotency_key", "activity", f"a{i}", ""), t0 + 10 + i) for i in range(50)])
+    e.write([(aclgpu.OP_TOUCH, ("namespace", "n0", "viewer", "user", "u0", ""))])
+    e.selfcheck_snapshot()  # the snapshot holds all 50 keys
+    _, cursor = e.watch_poll(aclgpu.WATCH_FROM_NOW)
+    e.set_now(t0 + 24 * 3600 + 30)  # keys 0..20 expired at least 24 h ago, the rest less
+    e.write([(aclgpu.OP_TOUCH, ("namespace", "n1", "viewer", "user", "u1", ""))])  # any write collects
+    assert e.read(rtype="workflow") == []  # (all 50 have been invisible since their expiry)
+    assert e.selfcheck_snapshot() is True  # patched: expiry crossings for the 29 still stored, feed entries for the 21 collected; verified inside
+    events, cursor = e.watch_poll(cursor)
+    assert [(ev[1], ev[2][0]) for ev in events] == [(aclgpu.OP_TOUCH, "namespace")], events
+    e.set_now(t0 + 20)  # a test clock set back: what was collected stays gone, what was merely expired comes back
+    assert sorted(r[1] for r in e.read(rtype="workflow")) == sorted(f"w{i}" for i in range(21, 50))  # (at <= now - 24 h: keys 0..20 were collected)
+    assert e.selfcheck_snapshot() is True
     e.close()
 
 
@@ -151,7 +177,7 @@ def test_expiry_crossings_mixed_with_writes_and_compaction(aclgpu):
         code = e.selfcheck_snapshot_code()
         patched += code == 1
         rebuilt += code == 0
-    assert patched > 60 and rebuilt <= 2, (patched, rebuilt)  # (a rebuild is only allowed when a class comes alive for the first time)
+    assert patched > 60 and rebuilt == 0, (patched, rebuilt)  # (not even a class coming alive for the first time rebuilds)
     e.close()
 
 
