@@ -264,6 +264,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     h->snap_valid = true;
     h->dev_valid = true;
     h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
+    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_compactions++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -344,7 +345,8 @@ int ensure_snapshot(acl_engine *h) {
     HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->dev_valid = true;
-    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);  // (the single-launch kernel's LDS depends on the schema)
+    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
+    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);  // (the single-launch kernel's LDS depends on the schema)
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -473,15 +475,29 @@ constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path decli
 // Geometry of a single-launch pass over n requests: requests per unit, blocks to launch, private frontier entries per block.
 struct LocalGeom {
     uint32_t rpw, nblocks, nunits, cap;
+    uint32_t nstatic = 0, rdyn = 0;  // != 0: static units for the head of the batch, small hand-out units for its tail
+    bool wide = false;               // 16 waves per block and unit (chip-filling batches) instead of 4
 };
 static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
-    const uint32_t blocks = (uint32_t)h->local_blocks;  // what is resident at once; a unit is walked by one block (4 waves)
     LocalGeom G{};
+    G.wide = n >= h->local_wide_min;
+    const uint32_t blocks = (uint32_t)(G.wide ? h->local_blocks_wide : h->local_blocks);  // what is resident at once; a unit is walked by one block (4 or 16 waves)
     // latency: while the batch has fewer requests than the chip has blocks, every request gets a block of its own; beyond that
     // every block gets ONE unit of n / blocks requests (`upw` > 1: several smaller ones, a second round of per-level chains)
-    G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), kWavesPerBlock * 64u);
+    G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), local_unit_max(G.wide));
     G.nunits = (n + G.rpw - 1) / G.rpw;
     G.nblocks = std::max<uint32_t>(std::min<uint32_t>(G.nunits, blocks), 1);
+    // Chip-filling batches: requests differ 100-fold in work, a block's unit is the sum of ~128 of them, and the slowest of 2 048 such sums sets
+    // the launch (waves resident 76 % of it, profiles/r02_pmc_walk_final.txt).  So only `local_static_pct` of the batch goes out as one big unit
+    // per resident block; the rest is cut into units of `local_dyn_unit` requests that blocks draw from a counter as they finish -- spread over
+    // the tail, so the counter's same-address cost (~12 ns per draw) never sees all blocks at once.
+    if (h->local_static_pct < 100 && h->local_upw == 1 && G.nunits == blocks && G.rpw >= 2 * h->local_dyn_unit) {
+        const uint32_t rs = std::max<uint32_t>(h->local_dyn_unit, (uint32_t)((uint64_t)G.rpw * h->local_static_pct / 100));
+        G.rpw = rs;
+        G.nstatic = blocks;
+        G.rdyn = h->local_dyn_unit;
+        G.nunits = G.nstatic + (n - G.nstatic * rs + G.rdyn - 1) / G.rdyn;
+    }
     // (a block that needs more than 256 K entries is walking something the whole chip should walk: the level loop takes the batch)
     G.cap = (uint32_t)std::min<uint64_t>(c->frontier_entries / G.nblocks, 1u << 18);
     if (h->local_cap_limit) G.cap = std::min(G.cap, h->local_cap_limit);
@@ -496,7 +512,7 @@ static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g, const uin
     HIP_TRY(hipMemsetAsync(d_over, 0, 3 * sizeof(uint32_t), c->stream));  // [2]: deepest level (a per-destination export counter of the sharded walk: unused here)
     ev_begin(c, 2);
     launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
-                       c->d_err.p, d_perm, d_errout, d_over + 2);
+                       c->d_err.p, d_perm, d_errout, d_over + 2, G.nstatic, G.rdyn, G.wide);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return ACL_OK;
@@ -567,7 +583,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
     ev_begin(c, 2);
     launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
-                       (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64));
+                       (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64), nullptr, 0, 0, G.wide);
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
@@ -1219,11 +1235,15 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
     h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
+    h->local_blocks_wide = local_grid_blocks(dev, 2048, true);
+    if (const char *ev = getenv("ACL_LOCAL_WIDE_MIN")) h->local_wide_min = (uint32_t)std::max(0, atoi(ev));  // A/B knob
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
+    if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch
+    if (const char *ev = getenv("ACL_LOCAL_DYN_UNIT")) h->local_dyn_unit = (uint32_t)std::min(256, std::max(1, atoi(ev)));       // in static units; size of the hand-out units
     if (cfg && cfg->max_sub_batch) h->max_sub_batch = cfg->max_sub_batch;
     if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;
     if (cfg && cfg->contexts) h->max_ctx = std::min<uint32_t>(cfg->contexts, 16);

@@ -260,9 +260,12 @@ struct acl_engine {
     int grid_blocks = 2048;
     std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
-    int local_blocks = 1024;   // resident blocks of the single-launch kernel
+    int local_blocks = 1024;   // resident blocks of the single-launch kernel (4 waves per block)
+    int local_blocks_wide = 512;  // ... of its 16-wave instantiation
+    uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)
     uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
                                // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round
+    uint32_t local_static_pct = 100, local_dyn_unit = 32;  // chip-filling single-launch passes: share of the batch in static (one per block) units; hand-out unit size
     uint64_t cfg_frontier_entries = 0;
     // forward graph
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;

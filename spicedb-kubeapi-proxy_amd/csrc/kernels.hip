@@ -1075,20 +1075,26 @@ struct NoNext {
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
 #define ACL_LOCAL_WAVES_PER_SIMD 8
 #endif
-template <bool LDSPROG>
-__global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
-                                                                                  uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap,
+// Waves per block = waves that share one unit.  Two instantiations: kLocalNarrow for batches that do not fill the chip (a unit is a handful of
+// requests: more, smaller blocks) and kLocalWide for chip-filling ones -- requests differ 100-fold in work, so the more requests (and waves) a
+// unit pools, the less the slowest block's sum sticks out: C4's 262 144-item batch 303 us with 4 waves per block (2 048 units of 128 requests),
+// 286 us with 8, 276 us with 16 (512 units of 512), same-box A/B in profiles/r03_waves_per_block_ab.txt.
+constexpr int kLocalNarrow = 4, kLocalWide = 16;
+template <bool LDSPROG, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
+                                                                                  uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
+                                                                                  uint32_t cap,
                                                                                   uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
                                                                                   int32_t *err_out, uint32_t *max_level) {
-    __shared__ TaskLds lds[kWavesPerBlock];
-    __shared__ WaveOutCold s_cold[kWavesPerBlock];
+    __shared__ TaskLds lds[WAVES];
+    __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
     // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
     __shared__ uint32_t s_fill[3], s_next[3], s_stop, s_unit;
     extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
-    load_programs<LDSPROG>(g, s_prog, progs, ops, kBlock);
+    load_programs<LDSPROG>(g, s_prog, progs, ops, WAVES * 64);
     const uint32_t lane = lane_id();
     const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
@@ -1109,9 +1115,12 @@ __global__ __launch_bounds__(kBlock, ACL_LOCAL_WAVES_PER_SIMD) void k_check_loca
     wo.produced = 0;
     wo.cold = &s_cold[wib];
     wo.lfill = &s_fill[1];
+    // units [0, nstatic) hold rpw requests each (block b starts on unit b: no hand-out); the requests behind them come in SMALL units of rdyn,
+    // handed out through `next_unit` as blocks finish -- the launch's tail is then a small unit's walk, not the slowest big unit's
+    const uint32_t nstat_req = min(n, nstatic * rpw);
     for (uint32_t unit = blockIdx.x; unit < nunits;) {
-        const uint32_t first = unit * rpw;
-        const uint32_t mine = min(rpw, n - first);  // <= 256: thread i seeds and answers request first + i
+        const uint32_t first = unit < nstatic ? unit * rpw : nstat_req + (unit - nstatic) * rdyn;
+        const uint32_t mine = unit < nstatic ? min(rpw, nstat_req - first) : min(rdyn, n - first);  // <= 256: thread i seeds and answers request first + i
         if (threadIdx.x < 3) {
             s_fill[threadIdx.x] = 0;
             s_next[threadIdx.x] = 0;
@@ -1802,26 +1811,42 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
         else hipLaunchKernelGGL((k_expand<false, false>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
     }
 }
-void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
-                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level) {
-    const uint32_t nunits = (n + rpw - 1) / rpw;
+template <int WAVES>
+static void launch_check_local_w(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t nunits, uint32_t nstatic, uint32_t rdyn,
+                                 uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
+                                 uint32_t *max_level) {
     const dim3 grid(nblocks);
     if (g.nslots + g.nops <= kProgLdsEntries && prog_in_lds())
-        hipLaunchKernelGGL(k_check_local<true>, grid, dim3(kBlock), prog_lds_bytes(g), s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
+        hipLaunchKernelGGL((k_check_local<true, WAVES>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
+                           perm_out, err_out, max_level);
     else
-        hipLaunchKernelGGL(k_check_local<false>, grid, dim3(kBlock), 0, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
+        hipLaunchKernelGGL((k_check_local<false, WAVES>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out,
+                           err_out, max_level);
 }
-int local_grid_blocks(int device, size_t prog_bytes) {
+void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
+                        uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level,
+                        uint32_t nstatic, uint32_t rdyn, bool wide) {
+    uint32_t nunits = (n + rpw - 1) / rpw;
+    if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) nunits = nstatic + (n - nstatic * rpw + rdyn - 1) / rdyn;  // static units, then small ones
+    else nstatic = nunits, rdyn = rpw;
+    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
+    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
+}
+template <int WAVES>
+static int local_occupancy(bool lds, size_t prog_bytes) {
+    int occ = 0;
+    const hipError_t oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true, WAVES>, WAVES * 64, prog_bytes)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false, WAVES>, WAVES * 64, 0);
+    return (oe != hipSuccess || occ <= 0) ? std::max(1, 16 / WAVES) : occ;
+}
+int local_grid_blocks(int device, size_t prog_bytes, bool wide) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    int occ = 0;
     const bool lds = prog_in_lds() && prog_bytes <= (size_t)kProgLdsEntries * 32;
-    const hipError_t oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true>, kBlock, prog_bytes)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false>, kBlock, 0);
-    if (oe != hipSuccess || occ <= 0) occ = 4;
-    return cus * occ;
+    return cus * (wide ? local_occupancy<kLocalWide>(lds, prog_bytes) : local_occupancy<kLocalNarrow>(lds, prog_bytes));
 }
+uint32_t local_unit_max(bool wide) { return (uint32_t)(wide ? kLocalWide : kLocalNarrow) * 64u; }
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {
     (void)hipMemsetAsync(table, 0xFF, sizeof(uint64_t) << bits, s);
     hipLaunchKernelGGL(k_dedup, dim3(f.nwaves / kWavesPerBlock), dim3(256), 0, s, f, iter, reinterpret_cast<unsigned long long *>(table), bits);

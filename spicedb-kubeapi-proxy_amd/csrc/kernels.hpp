@@ -91,9 +91,13 @@ void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, cons
 // level with a private frontier of `cap` entries in each of buf0 / buf1 (regions b * cap); next_unit: zeroed device counter, needed when there are more units than blocks; *overflow != 0 afterwards: redo on the level loop
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
                         uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
-                        uint32_t *max_level = nullptr /* device word (zeroed): atomicMax of the dispatch levels the units needed */);
+                        uint32_t *max_level = nullptr /* device word (zeroed): atomicMax of the dispatch levels the units needed */,
+                        uint32_t nstatic = 0, uint32_t rdyn = 0 /* != 0: only the first nstatic units hold rpw requests, the rest of the batch is cut into units of rdyn
+                                                                   handed out through next_unit (which must then be given) */,
+                        bool wide = false /* 16 waves per block (and unit) instead of 4: chip-filling batches */);
 // blocks of the single-launch kernel that are resident at once on this device
-int local_grid_blocks(int device, size_t prog_bytes);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS
+int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
+uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= threads per block of the single-launch kernel: thread i seeds request i of the unit)
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits);
 constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key holds 14 request bits)
