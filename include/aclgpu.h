@@ -165,14 +165,15 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
 /* Pipelined form of acl_check_bulk_ids: submit returns at once, the batch is answered by one of the engine's evaluation
  * contexts (own HIP stream: the H2D copy of batch N+1 and the D2H copy of batch N-1 overlap the kernels of batch N);
  * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
- * Buffers must stay valid until the wait returns; a batch keeps its evaluation context -- and the engine's state lock, shared --
- * until it is waited for, so wait in submission order.  A thread that holds unwaited tickets must not make any other BLOCKING call
- * on the engine before waiting for them: a write (acl_write, acl_delete_by_filter*, acl_load_bootstrap) waits for the tickets, and
- * once a writer queues, every new evaluation queues behind it (the state lock prefers writers) -- only acl_ticket_wait gets out.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up to
- * three batches ahead (context + H2D) while contexts are free, runs the batches' kernels strictly one after the other
- * (from 131 072 items on they are chained ON THE DEVICE -- each stream waits for the event behind the previous kernel -- and
- * the waiter completes the pass), and each batch's D2H drains while the next one's kernel runs.  Keep two tickets in flight:
- * measured 785 M decisions/s on C4 against 566 M/s for one and 395 M/s for three.  Smaller batches simply run concurrently. */
+ * Buffers must stay valid until the wait returns.  Tickets complete by themselves, in submission order: a completer thread inside the
+ * engine waits for each batch's device work, copies the answers out and gives the batch's evaluation context and its (shared) hold on
+ * the engine's state back -- a ticket nobody has waited for yet pins nothing, so the holder of tickets may make any other call on the
+ * engine (writes included) before it waits.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up
+ * to three batches ahead (context + H2D), runs the batches' kernels strictly one after the other (from 131 072 items on they are chained
+ * ON THE DEVICE -- each stream waits for the event behind the previous kernel), and each batch's D2H drains while the next one's kernel
+ * runs.  Such batches -- submitted or issued by blocking callers -- only ever use three of the engine's contexts: further ones queue for a
+ * lane.  Measured on C4 (profiles/r03_hostid_modes.txt): 2 ... 16 blocking callers 865-882 M decisions/s (one caller 622), a window of two
+ * or of six tickets 870 M/s.  Smaller batches simply run concurrently. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);

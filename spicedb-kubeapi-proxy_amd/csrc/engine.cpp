@@ -386,7 +386,7 @@ int ensure_reverse(acl_engine *h) {
     return ACL_OK;
 }
 
-int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only) {
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, bool chain_lane) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     HIP_TRY(hipSetDevice(h->device));
@@ -416,15 +416,30 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
         rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;
     }
-    // a context from the pool (created on demand up to max_ctx)
+    // a context from the pool (created on demand up to max_ctx).  Chip-filling host batches (chain_lane) only ever run on the first kChainLanes
+    // contexts: that is the admission queue of the chained-kernel pipeline -- callers 4 ... N wait HERE for a lane, before they have put a
+    // byte on any stream, and hold it until their results are back.  The runtime multiplexes streams onto 4 hardware queues; a fourth
+    // stream carrying such a batch (even only its D2H copies) shares a queue with one that waits for an event and halved everybody's
+    // throughput (4 callers 566 M/s against 748 M/s for 2-3, profiles/r02_hostid_modes_chained.txt).  Everything else prefers the other contexts.
+    const uint32_t lanes = std::min<uint32_t>(kChainLanes, h->max_ctx);
     std::unique_lock<std::mutex> lk(h->pool_mu);
     for (;;) {
-        if (!h->free_ctxs.empty()) {
-            c = h->free_ctxs.back();
-            h->free_ctxs.pop_back();
+        int pick = -1;
+        for (int i = 0; i < (int)h->free_ctxs.size(); i++) {
+            const int idx = h->free_ctxs[i]->index;
+            if (chain_lane ? (idx < (int)lanes && (pick < 0 || idx < h->free_ctxs[pick]->index))
+                           : (pick < 0 || (idx >= (int)lanes) > (h->free_ctxs[pick]->index >= (int)lanes) ||
+                              ((idx >= (int)lanes) == (h->free_ctxs[pick]->index >= (int)lanes) && idx > h->free_ctxs[pick]->index)))
+                pick = i;
+        }
+        const bool may_create = h->ctxs.size() < (chain_lane ? lanes : h->max_ctx);
+        // (a free lane is the last resort of a call that is not chained: a new context first)
+        if (pick >= 0 && (chain_lane || h->free_ctxs[pick]->index >= (int)lanes || !may_create)) {
+            c = h->free_ctxs[pick];
+            h->free_ctxs.erase(h->free_ctxs.begin() + pick);
             break;
         }
-        if (h->ctxs.size() < h->max_ctx) {
+        if (may_create) {
             std::unique_ptr<PassCtx> nc;
             rc = new_ctx(h, &nc, (int)h->ctxs.size());
             if (rc) return rc;
@@ -540,8 +555,9 @@ static void walk_outcome(acl_engine *h, size_t n, int rc);
 // Chip-filling single-launch passes follow each other ON THE DEVICE: the context's stream waits for the event behind the previous
 // such kernel, the kernel is enqueued (context buffers d_items -> d_perm / d_errout), its own event becomes the one the next pass
 // waits for.  Nothing is synchronised here.  kChainDeclined: take the turn-taking path instead (batch too small, walk switched off / backing off).
+bool chains(acl_engine *h, size_t n) { return n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1; }
 int chained_enqueue(acl_engine *h, PassCtx *c, size_t n) {
-    if (!(n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && walk_allowed(h, n))) return kChainDeclined;
+    if (!(chains(h, n) && walk_allowed(h, n))) return kChainDeclined;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     std::lock_guard<std::mutex> ck(h->chain_mu);
@@ -719,31 +735,9 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
         src = c->h_in.p;
     }
-    // Chained (chip-filling) batches: at most three contexts' streams carry such a batch at a time, copies included -- the runtime multiplexes
-    // streams onto 4 hardware queues, and a fourth busy stream sharing a queue with one that waits for an event halves everybody's
-    // throughput (profiles/r02_hostid_modes_chained.txt: 4 callers 306 M/s against 750 M/s for 2 or 3).  Further callers queue here.
-    const bool chained = n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
-    struct ChainSlot {
-        acl_engine *h;
-        bool held = false;
-        void acquire() {
-            std::unique_lock<std::mutex> ck(h->chain_mu);
-            h->chain_cv.wait(ck, [&] { return h->chain_inflight < 3; });
-            h->chain_inflight++;
-            held = true;
-        }
-        void release() {
-            if (!held) return;
-            {
-                std::lock_guard<std::mutex> ck(h->chain_mu);
-                h->chain_inflight--;
-            }
-            h->chain_cv.notify_one();
-            held = false;
-        }
-        ~ChainSlot() { release(); }
-    } slot{h};
-    if (chained) slot.acquire();
+    // Chained (chip-filling) batches run on one of kChainLanes contexts: the caller was admitted to a lane in Eval::begin and keeps it until
+    // its results are back (callers beyond the lanes wait there).
+    const bool chained = chains(h, n) && (uint32_t)c->index < std::min<uint32_t>(kChainLanes, h->max_ctx);  // (a caller that did not ask for a lane takes turns instead)
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
     int rc = kTakeLevelLoop;
     if (n >= kComputeTokenItems) {
@@ -761,7 +755,6 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
             if (!rc) rc = chained_finish(h, c, n);
             else if (rc != kChainDeclined) (void)hipStreamSynchronize(c->stream);
             if (rc == kChainDeclined) rc = kTakeLevelLoop;
-            slot.release();
         }
         if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time
             const bool tried = chained;
@@ -1454,7 +1447,7 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
     }
     if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
     Eval ev;
-    int rc = ev.begin(h, false, opts);
+    int rc = ev.begin(h, false, opts, -1, false, chains(h, n));
     if (rc) return rc;
     return check_ids_host(h, ev.c, items, n, perm_out, err_out);
 }

@@ -30,9 +30,11 @@ struct AsyncPool {
     std::condition_variable cv;
     std::deque<acl_ticket *> queue;     // small batches: any worker runs the whole call
     std::deque<acl_ticket *> compute;   // chip-filling batches: ONE worker runs their kernels, one batch at a time, in order
+    std::deque<acl_ticket *> completing;  // ... enqueued on the device: the completer waits for each in turn, finishes the pass and gives lock + context back
+    std::condition_variable ccv;
     std::vector<std::thread> workers;
-    std::thread compute_worker;
-    bool stop = false;
+    std::thread compute_worker, completer;
+    bool stop = false, compute_done = false;
 };
 
 namespace {
@@ -67,9 +69,15 @@ void worker_loop(acl_engine_t *h, AsyncPool *P) {
 // other (a batch this size fills every wave slot: two at once only take turns), and enqueues each batch's D2H copies without
 // waiting for them -- they drain under the next batch's kernels.  The waiter synchronises the batch's stream, copies
 // out of staging if the caller's buffers are not pinned, and gives the context back.
+int stage_copies(acl_engine_t *h, acl_ticket *t);
 int stage(acl_engine_t *h, acl_ticket *t, bool may_block) {
-    int rc = t->ev.begin(h, false, CallOpts(), -1, !may_block);
+    int rc = t->ev.begin(h, false, CallOpts(), -1, !may_block, chains(h, t->n));
     if (rc) return rc;
+    rc = stage_copies(h, t);
+    if (rc) t->ev.end();  // (a batch that failed to stage kept the shared state lock and its context until the caller waited)
+    return rc;
+}
+int stage_copies(acl_engine_t *h, acl_ticket *t) {
     PassCtx *c = t->ev.c;
     const size_t n = t->n;
     HIP_TRY(c->d_items.ensure(n));
@@ -127,7 +135,7 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
         // The kernel goes behind the previous batch's ON THE DEVICE (an event between the two contexts' streams) and this thread moves on
         // to the next batch without waiting for it: launching batch N + 1 only after synchronising batch N left the chip idle for a
         // wake-up and a launch between two kernels.  The waiter synchronises, and redoes the pass on the level loop if a block overflowed.
-        // (Keep the window at 2: three tickets in flight measured 395 M/s against 785 M/s for two, whatever was capped inside -- profiles/r02_hostid_modes_chained.txt.)
+        // (profiles/r03_hostid_modes.txt: windows of 2 and of 6 tickets 870 M/s; 3 and 4 measure 630 M/s -- a resonance of the user / completer / staging hand-offs not yet understood.)
         int rc = chained_enqueue(h, c, t->n);
         if (rc == ACL_OK) {
             t->chained = true;
@@ -140,6 +148,61 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
             if (e == hipSuccess && t->err) e = hipMemcpyAsync(t->he, c->d_errout.p, t->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
             if (e != hipSuccess) rc = fail(ACL_ERR_INTERNAL, std::string("result copy: ") + hipGetErrorString(e));
         }
+        if (rc) {
+            (void)hipStreamSynchronize(c->stream);
+            t->ev.end();
+            finish(t, rc);
+            continue;
+        }
+        {  // everything is enqueued: the completer takes it from here, this thread moves on to the next batch
+            std::lock_guard<std::mutex> lk(P->mu);
+            P->completing.push_back(t);
+        }
+        P->ccv.notify_one();
+    }
+}
+
+// Completes pipelined batches in the order their kernels were enqueued: waits for the batch's stream, redoes the pass on the level loop if a block
+// of the walk ran out of private frontier, copies out of staging when the caller's buffers are not pinned, and gives the shared state lock and
+// the context back -- WITHOUT the caller: a ticket nobody waits for no longer pins the engine's state lock (a writer used to starve behind
+// it) or a context, and acl_ticket_wait is a plain wait for the ticket's answer.
+void completer_loop(acl_engine_t *h, AsyncPool *P) {
+    (void)hipSetDevice(h->device);
+    for (;;) {
+        acl_ticket *t = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(P->mu);
+            P->ccv.wait(lk, [&] { return !P->completing.empty() || P->compute_done; });
+            if (P->completing.empty()) return;
+            t = P->completing.front();
+            P->completing.pop_front();
+        }
+        PassCtx *c = t->ev.c;
+        int rc = ACL_OK;
+        hipError_t e = hipSuccess;
+        if (t->chained) {
+            rc = chained_finish(h, c, t->n);  // synchronises the stream (kernel + result copies)
+            if (rc == kChainDeclined) {       // a block ran out of private frontier: the level loop, and the copies once more
+                {
+                    std::lock_guard<std::mutex> tk(h->compute_mu);
+                    rc = check_device(h, c, c->d_items.p, t->n, c->d_perm.p, c->d_errout.p, false);
+                }
+                if (!rc) {
+                    e = hipMemcpyAsync(t->hp, c->d_perm.p, t->n, hipMemcpyDeviceToHost, c->stream);
+                    if (e == hipSuccess && t->err) e = hipMemcpyAsync(t->he, c->d_errout.p, t->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                }
+            }
+        } else {
+            e = hipStreamSynchronize(c->stream);  // the D2H copies (everything else on this stream finished before them)
+            ev_collect(c);
+        }
+        if (!rc && e != hipSuccess) rc = fail(ACL_ERR_INTERNAL, std::string("result copy: ") + hipGetErrorString(e));
+        if (!rc) {
+            if (t->hp != t->perm) std::memcpy(t->perm, t->hp, t->n);
+            if (t->err && t->he != t->err) std::memcpy(t->err, t->he, t->n * sizeof(int32_t));
+        }
+        t->ev.end();
         finish(t, rc);
     }
 }
@@ -163,6 +226,12 @@ void async_shutdown(acl_engine_t *h) {
     P->cv.notify_all();
     for (auto &t : P->workers) t.join();  // drains what is queued first
     if (P->compute_worker.joinable()) P->compute_worker.join();
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        P->compute_done = true;  // (nothing more will be handed to the completer)
+    }
+    P->ccv.notify_all();
+    if (P->completer.joinable()) P->completer.join();
     delete P;
 }
 
@@ -181,6 +250,7 @@ int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n
             h->async = new AsyncPool();
             for (uint32_t i = 0; i < std::max<uint32_t>(1, h->max_ctx); i++) h->async->workers.emplace_back(worker_loop, h, h->async);
             h->async->compute_worker = std::thread(compute_loop, h, h->async);
+            h->async->completer = std::thread(completer_loop, h, h->async);
         }
         P = h->async;
     }
@@ -209,40 +279,6 @@ int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *tp) {
         t->cv.wait(lk, [&] { return t->done; });
         rc = t->rc;
         msg = t->msg;
-    }
-    if (t->staged_pipeline) {
-        PassCtx *c = t->ev.c;
-        hipError_t e = hipSuccess;
-        if (t->chained && !rc) {
-            int rc2 = chained_finish(h, c, t->n);  // synchronises the stream (kernel + result copies)
-            if (rc2 == kChainDeclined) {           // a block ran out of private frontier: the level loop, and the copies once more
-                {
-                    std::lock_guard<std::mutex> tk(h->compute_mu);
-                    rc2 = check_device(h, c, c->d_items.p, t->n, c->d_perm.p, c->d_errout.p, false);
-                }
-                if (!rc2) {
-                    e = hipMemcpyAsync(t->hp, c->d_perm.p, t->n, hipMemcpyDeviceToHost, c->stream);
-                    if (e == hipSuccess && t->err) e = hipMemcpyAsync(t->he, c->d_errout.p, t->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-                }
-            }
-            if (rc2) {
-                rc = rc2;
-                msg = acl_last_error();
-            }
-        } else {
-            e = hipStreamSynchronize(c->stream);  // the D2H copies (everything else on this stream finished before them)
-            ev_collect(c);
-        }
-        if (!rc && e != hipSuccess) {
-            rc = ACL_ERR_INTERNAL;
-            msg = std::string("result copy: ") + hipGetErrorString(e);
-        }
-        if (!rc) {
-            if (t->hp != t->perm) std::memcpy(t->perm, t->hp, t->n);
-            if (t->err && t->he != t->err) std::memcpy(t->err, t->he, t->n * sizeof(int32_t));
-        }
-        t->ev.end();
     }
     return rc ? fail(rc, msg) : ACL_OK;
 }

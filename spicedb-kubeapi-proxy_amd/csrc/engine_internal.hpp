@@ -16,7 +16,6 @@
 //             serialised everything).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -57,28 +56,55 @@ inline int fail(const Status &s) { return fail(s.code, s.msg); }
         if (e_ != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// pthread rwlock with writer preference: a WriteRelationships must not starve behind a stream of Checks
-// (glibc's default policy prefers readers; std::shared_mutex cannot select another one)
+// Reader/writer lock with writer preference (a WriteRelationships must not starve behind a stream of Checks) whose SHARED side is a plain
+// count: whoever finishes an evaluation may release it, not only the thread that took it.  Pipelined tickets take the lock on the staging
+// thread and give it back on the thread that completes the batch (engine_async.cpp); with a pthread rwlock that hand-over was undefined
+// behaviour that glibc happened to tolerate.  One mutex acquisition per call -- calls are device passes, not single loads.
 class RwLock {
   public:
-    RwLock() {
-        pthread_rwlockattr_t a;
-        pthread_rwlockattr_init(&a);
-        pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
-        pthread_rwlock_init(&l_, &a);
-        pthread_rwlockattr_destroy(&a);
-    }
-    ~RwLock() { pthread_rwlock_destroy(&l_); }
+    RwLock() = default;
     RwLock(const RwLock &) = delete;
     RwLock &operator=(const RwLock &) = delete;
-    void lock() { pthread_rwlock_wrlock(&l_); }
-    void unlock() { pthread_rwlock_unlock(&l_); }
-    void lock_shared() { pthread_rwlock_rdlock(&l_); }
-    bool try_lock_shared() { return pthread_rwlock_tryrdlock(&l_) == 0; }  // (fails while a writer holds the lock or waits for it)
-    void unlock_shared() { pthread_rwlock_unlock(&l_); }
+    void lock() {
+        std::unique_lock<std::mutex> lk(m_);
+        waiting_writers_++;
+        wcv_.wait(lk, [&] { return !writer_ && readers_ == 0; });
+        waiting_writers_--;
+        writer_ = true;
+    }
+    void unlock() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            writer_ = false;
+        }
+        wcv_.notify_one();
+        rcv_.notify_all();
+    }
+    void lock_shared() {
+        std::unique_lock<std::mutex> lk(m_);
+        rcv_.wait(lk, [&] { return !writer_ && waiting_writers_ == 0; });
+        readers_++;
+    }
+    bool try_lock_shared() {  // (fails while a writer holds the lock or waits for it)
+        std::lock_guard<std::mutex> lk(m_);
+        if (writer_ || waiting_writers_) return false;
+        readers_++;
+        return true;
+    }
+    void unlock_shared() {
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            last = --readers_ == 0;
+        }
+        if (last) wcv_.notify_one();
+    }
 
   private:
-    pthread_rwlock_t l_;
+    std::mutex m_;
+    std::condition_variable rcv_, wcv_;
+    uint32_t readers_ = 0, waiting_writers_ = 0;
+    bool writer_ = false;
 };
 
 // Bits set in n 32-bit words.  LookupResources counts the ids of every result bitmap on the host (64 lookups x 12 KB per C3 step): the
@@ -360,7 +386,8 @@ struct Eval {
     ~Eval() { end(); }
     // rev_key_slot >= 0: the lookup's subject is `type#relation` of that slot -- the reverse rows must cover its id space
     // try_only: never wait for a context -- kNoContextFree when every one is taken
-    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false);
+    // chain_lane: the call carries a chip-filling host batch: only the first kChainLanes contexts will do (the chained pipeline's admission queue)
+    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, bool chain_lane = false);
     void end();
 };
 
@@ -395,6 +422,8 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
 // many items: split over host threads when the batch is large
 void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 void intern_pool_destroy(acl_engine_t *h);
+constexpr uint32_t kChainLanes = 3;  // contexts (streams) that carry chip-filling host batches
+bool chains(acl_engine *h, size_t n);  // does a host batch of n items take the chained-kernel pipeline?
 constexpr int kChainDeclined = -1003;  // internal: chained_enqueue / chained_finish hand the batch to the turn-taking path
 int chained_enqueue(acl_engine *h, PassCtx *c, size_t n);  // context buffers d_items -> d_perm / d_errout; nothing synchronised
 int chained_finish(acl_engine *h, PassCtx *c, size_t n);
