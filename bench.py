@@ -584,6 +584,28 @@ def single_checks_leg():
     return res
 
 
+def name_objects(eng, w):
+    """Gives every object of the check stream's resource and subject types a NAME, in id order, BEFORE the numeric bulk load: the engine's dense ids are
+    handed out in interning order, so name k gets id k and the bulk-loaded (anonymous-id) relationships are relationships of these named objects.
+    pods are `ns<namespace>/pod-<id>` (the proxy's `{{namespacedName}}` shape, deploy/rules.yaml:68), users `user-<id>`."""
+    rt, _p, st = w.check
+    pod_ns = None
+    for e_ in w.edges:
+        if e_[0] == rt and e_[1] == "namespace":
+            pod_ns = np.zeros(w.nobjects[rt], dtype=np.int64)
+            pod_ns[e_[4]] = e_[5]
+    names = {rt: [f"ns{int(pod_ns[i]) if pod_ns is not None else 0}/pod-{i}" for i in range(w.nobjects[rt])], st: [f"user-{i}" for i in range(w.nobjects[st])]}
+    import ctypes
+    out = ctypes.c_uint32()
+    for t_, ns_ in names.items():
+        tid = eng.type_id(t_)
+        for k, nm in enumerate(ns_):
+            eng._check(eng._L.acl_intern(eng._h, tid, nm.encode(), ctypes.byref(out)))
+        if ns_ and out.value != len(ns_) - 1:
+            raise SystemExit("name_objects must run on an empty engine (ids follow interning order)")
+    w.names = names
+
+
 def _local_edges(engine):
     return engine.stats().get("snapshot_edges_local", 0)
 
@@ -733,20 +755,38 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         rot_bad += int((h_perm[b] != np.roll(gpu_perm, b * 4099)).sum() + (h_err[b] != np.roll(gpu_err, b * 4099)).sum())
     rec["rotations"] = {"batches": NB, "items": NB * n, "mismatches_vs_rotated_batch0": rot_bad}
     eng.host_free(hb)
-    # ---------------- (iii) string path: named objects needed -> a NAMED copy of a slice would not be this graph; the engine's
-    # bulk loads are anonymous ids, so the string leg names the ids it asks about through acl_intern-free decimal names:
-    # unknown names resolve to "no relationships" -- what is timed is the host half (5 strings per item -> ids) + one pass.
-    m = min(n, 65536)
-    strs = eng.make_check_strings(rt, perm_name, w.res[:m], st, w.subj[:m])
-    t1 = time.perf_counter()
-    eng.check_bulk_prepared(strs)
-    t_str = time.perf_counter() - t1
-    t1 = time.perf_counter()
-    eng.check_bulk_prepared(strs)
-    t_str = min(t_str, time.perf_counter() - t1)
-    rec["string_path"] = {"decisions_per_s": m / t_str, "ms_per_batch": 1e3 * t_str, "items": m,
-                          "note": "acl_check_bulk: 5 C strings per item interned on the host (parallel over host threads), then one pass; "
-                                  "object names are the decimal ids (bulk-loaded ids are anonymous: every name resolves to 'no relationships')"}
+    # ---------------- (iii) string path on NAMED objects: every pod and user of the graph was given a name before the load (name_objects), so the strings
+    # below resolve to the very ids of the batch and the answers must equal the id path's (which the oracle checks item by item).  Timed: the whole
+    # ABI call -- strings -> ids on the host (parallel, straight into pinned staging), one device pass, answers back.  Two item forms: NUL-terminated
+    # fields (acl_check_bulk) and {pointer, length} fields (acl_check_bulk_v: what a cgo shim points at Go strings without copying).
+    names = getattr(w, "names", None)
+    if names:
+        sp = {"note": "acl_check_bulk_v / acl_check_bulk on named objects (every pod and user of the graph has a name; tables of "
+                      f"{len(names[rt])} + {len(names[st])} names); answers compared with the id path's", "sizes": {}}
+        ok_all = True
+        for m in (1024, 16384, 65536):
+            m = min(m, n)
+            qs = [(rt, names[rt][int(r_)], perm_name, st, names[st][int(s_)], "") for r_, s_ in zip(w.res[:m], w.subj[:m])]
+            pv, pc = eng.make_check_views(qs), eng.make_check_strings_named(qs)
+            row = {}
+            for form, call, prep in (("views", eng.check_bulk_views, pv), ("c_strings", eng.check_bulk_prepared, pc)):
+                got = call(prep)
+                ok = bool(np.array_equal(got[0], gpu_perm[:m]) and np.array_equal(got[1], gpu_err[:m]))
+                ok_all = ok_all and ok
+                ts = []
+                for _ in range(12):
+                    t1 = time.perf_counter()
+                    call(prep)
+                    ts.append(time.perf_counter() - t1)
+                row[form] = {"decisions_per_s": m / min(ts), "ms_per_batch": 1e3 * min(ts), "p50_ms": 1e3 * float(np.median(ts)), "answers_equal_id_path": ok}
+            sp["sizes"][str(m)] = row
+        big = sp["sizes"][str(min(65536, n))]
+        sp.update({"decisions_per_s": big["views"]["decisions_per_s"], "ms_per_batch": big["views"]["ms_per_batch"], "items": min(65536, n), "answers_equal_id_path": ok_all})
+        rec["string_path"] = sp
+        if not ok_all:
+            rec["string_path_mismatch"] = True
+    else:
+        rec["string_path"] = {"skipped": "objects of this run have no names (--legs / workload without name_objects)"}
     rec["kernel"] = kern
     return rec, gpu_perm, gpu_err
 
@@ -795,7 +835,8 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
     t_mt = time.perf_counter() - t0
     mism_mt = int((mperm != gpu_perm).sum() + (merr != gpu_err).sum())
     rot = rec.pop("rotations", None)
-    rec["parity"] = {"checked_against_oracle": n, "mismatches": mism + mism_mt}
+    str_bad = int(bool(rec.pop("string_path_mismatch", False)))  # named-object strings answered differently from the ids they name
+    rec["parity"] = {"checked_against_oracle": n, "mismatches": mism + mism_mt + str_bad}
     if rot:  # all 8 distinct batches of the timed leg: batch b == oracle answers rotated by b * 4099 (the oracle's answers equal batch 0's item by item)
         rec["parity"].update({"checked_against_oracle": rot["items"], "distinct_batches_checked": rot["batches"],
                               "mismatches": mism + mism_mt + rot["mismatches_vs_rotated_batch0"]})
@@ -886,6 +927,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--strings", default="on", choices=["on", "off"], help="name every pod and user (string-path leg on named objects); off: ids only")
     ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
@@ -981,6 +1023,10 @@ def main():
     label = "C5R" if args.workload == "C5" else args.workload
     eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
     t0 = time.time()
+    if args.legs == "all" and rank == 0 and args.workload != "C3" and args.strings != "off":
+        name_objects(eng, w)  # (before the load: ids follow interning order)
+    t_names = time.time() - t0
+    t0 = time.time()
     w.load(eng)
     eng.snapshot()
     t_load = time.time() - t0
@@ -1026,7 +1072,7 @@ def main():
                        "timed": "host-id ABI calls (H2D + kernels + D2H) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
                                 else "device-resident calls only (--legs device)"},
             "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
-            "setup_s": {"generate": round(t_gen, 2), "load+snapshot": round(t_load, 2)},
+            "setup_s": {"generate": round(t_gen, 2), "name_objects": round(t_names, 2), "load+snapshot": round(t_load, 2)},
             "snapshot_bytes": int(stats["snapshot_bytes"]),
         }
         kernel = rec.get("kernel")
@@ -1070,6 +1116,8 @@ def main():
         try:
             w2 = workloads.c2()
             e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
+            if args.strings != "off":
+                name_objects(e2, w2)
             w2.load(e2)
             e2.snapshot()
             r2, p2, er2 = check_bench(args, w2, e2, max(args.steps, 50), args.warmup, 1, 0, "C2", "all")

@@ -141,6 +141,16 @@ typedef struct {
 /* order preserving: perm_out[i] / err_out[i] answer items[i] (check.go:54-57).
  * err_out[i] != 0 is that pair's Error (check.go:55); perm_out[i] is then UNSPECIFIED. */
 int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
+/* The same request with {pointer, length} fields: no NUL behind the bytes, no strlen per field.  A cgo shim points these at the Go strings'
+ * own bytes (pinned for the call) instead of C.CString-copying six strings per item; an absent subject relation is {NULL, 0}. */
+typedef struct {
+    const char *p;
+    size_t n;
+} acl_str_t;
+typedef struct {
+    acl_str_t resource_type, resource_id, permission, subject_type, subject_id, subject_relation;
+} acl_check_item_v_t;
+int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
 
 /* 16-byte interned request (SURVEY 8(a) a3 "interned it is 16 B") */
 typedef struct {
@@ -259,6 +269,20 @@ typedef struct {
 } acl_completion_t;
 int acl_check_one_submit(acl_engine_t *h, const acl_check_item_t *item, uint64_t tag);
 int acl_check_completions(acl_engine_t *h, acl_completion_t *out, size_t max, int64_t timeout_ns, size_t *n_out);
+/* LookupResources in the same form (responsefilterer.go:165-204: every prefilter runs in a goroutine of its own next to the upstream call):
+ * submit returns at once, the answer arrives tagged through acl_lookup_completions.  `bitmap` is an engine-allocated row over the result type's
+ * ids (`words` 32-bit words, sized when the walk runs -- objects created after the submit are covered); the receiver releases it with acl_free.
+ * rc != 0: the lookup failed (bitmap NULL).  Concurrent submissions of one (resource type, permission, subject class) share one reverse walk. */
+typedef struct {
+    uint64_t tag;
+    int32_t rc;
+    uint32_t reserved;
+    uint64_t count; /* ids in the row */
+    size_t words;
+    uint32_t *bitmap;
+} acl_lookup_completion_t;
+int acl_lookup_one_submit(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint64_t tag);
+int acl_lookup_completions(acl_engine_t *h, acl_lookup_completion_t *out, size_t max, int64_t timeout_ns, size_t *n_out);
 /* the same for Filter requests (lookups.go:65; one LookupResources per list request, each from its own goroutine:
  * responsefilterer.go:165): concurrent requests with the same (resource type, permission, subject class) share ONE
  * batched reverse walk.  Arguments as acl_lookup_resources. */

@@ -10,6 +10,7 @@ import (
 	"runtime"
 	"sync"
 	"sync/atomic"
+	"unsafe"
 
 	"google.golang.org/grpc/codes"
 	"google.golang.org/grpc/status"
@@ -27,16 +28,24 @@ type completion struct {
 	perm    uint8
 }
 
+type lookupCompletion struct {
+	rc int32
+	bm []C.uint32_t // the result row, copied out of the engine's allocation
+}
+
 type completions struct {
-	mu      sync.Mutex
-	waiting map[uint64]chan completion
-	next    uint64
-	closed  int32
-	done    chan struct{}
+	mu       sync.Mutex
+	waiting  map[uint64]chan completion
+	lwaiting map[uint64]chan lookupCompletion
+	next     uint64
+	closed   int32
+	done     chan struct{}
+	ldone    chan struct{}
 }
 
 func (e *Engine) startPoller() {
-	e.cq = &completions{waiting: make(map[uint64]chan completion), done: make(chan struct{})}
+	e.cq = &completions{waiting: make(map[uint64]chan completion), lwaiting: make(map[uint64]chan lookupCompletion), done: make(chan struct{}), ldone: make(chan struct{})}
+	go e.pollLookups()
 	go func() {
 		runtime.LockOSThread() // blocks in C between passes: keep it off the scheduler's shared threads
 		defer close(e.cq.done)
@@ -62,12 +71,68 @@ func (e *Engine) startPoller() {
 	}()
 }
 
+// pollLookups drains acl_lookup_completions: every finished LookupResources arrives as an engine-allocated row that is copied into Go memory
+// and released (acl_free) here -- also the rows of requests whose caller's ctx ended first.
+func (e *Engine) pollLookups() {
+	runtime.LockOSThread()
+	defer close(e.cq.ldone)
+	buf := make([]C.acl_lookup_completion_t, 64)
+	for atomic.LoadInt32(&e.cq.closed) == 0 {
+		var n C.size_t
+		if rc := C.acl_lookup_completions(e.h, &buf[0], C.size_t(len(buf)), 100_000_000 /* ns: notices Close */, &n); rc != 0 {
+			return
+		}
+		for i := 0; i < int(n); i++ {
+			c := lookupCompletion{rc: int32(buf[i].rc)}
+			if buf[i].bitmap != nil {
+				c.bm = make([]C.uint32_t, int(buf[i].words))
+				copy(c.bm, unsafe.Slice(buf[i].bitmap, int(buf[i].words)))
+				C.acl_free(unsafe.Pointer(buf[i].bitmap))
+			}
+			tag := uint64(buf[i].tag)
+			e.cq.mu.Lock()
+			ch, ok := e.cq.lwaiting[tag]
+			delete(e.cq.lwaiting, tag)
+			e.cq.mu.Unlock()
+			if ok {
+				ch <- c // buffered: never blocks the poller
+			}
+		}
+	}
+}
+
+// lookupOne submits one LookupResources and waits for its row or for ctx (the HTTP request's: responsefilterer.go:165-170).
+func (e *Engine) lookupOne(ctx context.Context, rt, perm, st, sid, srel *C.char) (lookupCompletion, error) {
+	ch := make(chan lookupCompletion, 1)
+	e.cq.mu.Lock()
+	e.cq.next++
+	tag := e.cq.next
+	e.cq.lwaiting[tag] = ch
+	e.cq.mu.Unlock()
+	if rc := C.acl_lookup_one_submit(e.h, rt, perm, st, sid, srel, C.uint64_t(tag)); rc != 0 { // (the strings are interned before it returns)
+		e.cq.mu.Lock()
+		delete(e.cq.lwaiting, tag)
+		e.cq.mu.Unlock()
+		return lookupCompletion{}, lastError(rc)
+	}
+	select {
+	case c := <-ch:
+		return c, nil
+	case <-ctx.Done():
+		e.cq.mu.Lock()
+		delete(e.cq.lwaiting, tag) // the poller frees the row when it arrives
+		e.cq.mu.Unlock()
+		return lookupCompletion{}, ctxError(ctx)
+	}
+}
+
 func (e *Engine) stopPoller() {
 	if e.cq == nil {
 		return
 	}
 	atomic.StoreInt32(&e.cq.closed, 1)
 	<-e.cq.done
+	<-e.cq.ldone
 }
 
 // checkOne submits one check and waits for its answer or for ctx (responsefilterer.go:168: the HTTP request's ctx ends a

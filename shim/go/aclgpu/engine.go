@@ -89,6 +89,70 @@ func (c *cstrings) free() {
 	}
 }
 
+// viewItems builds an acl_check_item_v_t array in C memory over ONE C blob holding every distinct string of the request.
+type viewItems struct {
+	items *C.acl_check_item_v_t
+	n     int
+	blob  []byte            // staged in Go, copied to C once (finish)
+	at    map[string]int    // string -> offset in blob
+	refs  [][6][2]int       // per item and field: {offset, length}; offset -1 = absent
+	cblob unsafe.Pointer
+}
+
+func newViewItems(n int) *viewItems {
+	return &viewItems{n: n, at: make(map[string]int), refs: make([][6][2]int, n)}
+}
+func (v *viewItems) ref(s string, present bool) [2]int {
+	if !present {
+		return [2]int{-1, 0}
+	}
+	off, ok := v.at[s]
+	if !ok {
+		off = len(v.blob)
+		v.at[s] = off
+		v.blob = append(v.blob, s...)
+	}
+	return [2]int{off, len(s)}
+}
+func (v *viewItems) set(i int, resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) {
+	r := &v.refs[i] // nil members (an empty request) stay absent: the engine answers InvalidArgument (options_test.go:101-102)
+	for f := range r {
+		r[f] = [2]int{-1, 0}
+	}
+	if resource != nil {
+		r[0], r[1] = v.ref(resource.ObjectType, true), v.ref(resource.ObjectId, true)
+	}
+	r[2] = v.ref(permission, true)
+	if subject != nil && subject.Object != nil {
+		r[3], r[4] = v.ref(subject.Object.ObjectType, true), v.ref(subject.Object.ObjectId, true)
+		r[5] = v.ref(subject.OptionalRelation, subject.OptionalRelation != "")
+	}
+	if i == v.n-1 {
+		v.finish()
+	}
+}
+func (v *viewItems) finish() {
+	v.cblob = C.malloc(C.size_t(len(v.blob) + 1))
+	if len(v.blob) > 0 {
+		copy(unsafe.Slice((*byte)(v.cblob), len(v.blob)), v.blob)
+	}
+	v.items = (*C.acl_check_item_v_t)(C.calloc(C.size_t(v.n), C.size_t(unsafe.Sizeof(C.acl_check_item_v_t{}))))
+	out := unsafe.Slice(v.items, v.n)
+	for i := range out {
+		fields := (*[6]C.acl_str_t)(unsafe.Pointer(&out[i])) // six consecutive {p, n} views (aclgpu.h)
+		for f, rf := range v.refs[i] {
+			if rf[0] >= 0 {
+				fields[f].p = (*C.char)(unsafe.Add(v.cblob, rf[0]))
+				fields[f].n = C.size_t(rf[1])
+			}
+		}
+	}
+}
+func (v *viewItems) free() {
+	C.free(unsafe.Pointer(v.items))
+	C.free(v.cblob)
+}
+
 func (c *cstrings) item(resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) C.acl_check_item_t {
 	var it C.acl_check_item_t // nil members (an empty request) stay NULL: the engine answers InvalidArgument (options_test.go:101-102)
 	if resource != nil {

@@ -65,15 +65,17 @@ func (p *permissionsClient) CheckBulkPermissions(ctx context.Context, in *v1.Che
 	if n == 0 {
 		return out, nil
 	}
-	var cs cstrings
-	defer cs.free()
-	items := make([]C.acl_check_item_t, n)
+	// {pointer, length} items (acl_check_bulk_v): every string of the request is copied ONCE into one C blob -- two allocations per call instead
+	// of six C.CString mallocs per item -- and equal strings (the rule template's type / permission names) share their bytes, which is also
+	// what lets the engine recognise them by pointer.
+	vi := newViewItems(n)
+	defer vi.free()
 	for i, it := range in.Items {
-		items[i] = cs.item(it.Resource, it.Permission, it.Subject)
+		vi.set(i, it.Resource, it.Permission, it.Subject)
 	}
 	perm := make([]C.uint8_t, n)
 	errs := make([]C.int32_t, n)
-	if rc := C.acl_check_bulk(p.e.h, &items[0], C.size_t(n), &perm[0], &errs[0]); rc != 0 {
+	if rc := C.acl_check_bulk_v(p.e.h, vi.items, C.size_t(n), &perm[0], &errs[0]); rc != 0 {
 		return nil, lastError(rc)
 	}
 	for i := range in.Items {
@@ -103,6 +105,18 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 	// racing WriteRelationships can never make a caller-sized buffer "too small".  Concurrent list requests of the same
 	// (type, permission, subject class) share one batched reverse walk (the micro-batcher); the HTTP request's ctx
 	// (responsefilterer.go:165-170) cancels the call while it queues and between level bursts of the walk.
+	if p.e.cq != nil {
+		// no OS thread blocked in C per prefilter (responsefilterer.go:165-183 starts one goroutine per list request): submit, park on a
+		// channel, the lookup poller hands the row over (completions.go)
+		c, err := p.e.lookupOne(ctx, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel))
+		if err != nil {
+			return nil, err
+		}
+		if c.rc != 0 {
+			return nil, status.Error(codes.Code(c.rc), "lookup failed")
+		}
+		return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: c.bm, at: p.e.zedToken()}, nil
+	}
 	var bmp *C.uint32_t
 	var words C.size_t
 	var count C.uint64_t

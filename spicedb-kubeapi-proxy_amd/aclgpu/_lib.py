@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("ACLGPU_LIB") or os.path.join(_PKG, "lib", "libaclgpu.
 SYMBOLS = [
     "acl_open", "acl_close", "acl_last_error", "acl_load_bootstrap", "acl_type_id", "acl_relation_id", "acl_intern", "acl_find",
     "acl_object_name", "acl_object_count", "acl_write", "acl_delete_by_filter", "acl_read", "acl_add_edges", "acl_revision",
-    "acl_set_now", "acl_snapshot", "acl_check_bulk", "acl_check_bulk_ids", "acl_check_bulk_ids_device", "acl_stream", "acl_sync",
+    "acl_set_now", "acl_snapshot", "acl_check_bulk", "acl_check_bulk_v", "acl_check_bulk_ids", "acl_check_bulk_ids_device", "acl_stream", "acl_sync",
     "acl_lookup_resources", "acl_lookup_resources_ids", "acl_lookup_resources_batch", "acl_stats", "acl_stats_reset", "acl_set_timing",
     "acl_shard_configure", "acl_shard_of_type", "acl_shard_grow_frontier", "acl_shard_check_begin", "acl_shard_check_step",
     "acl_shard_check_step_by_dest", "acl_shard_check_import", "acl_shard_check_finish", "acl_shard_lookup_begin", "acl_shard_lookup_step", "acl_shard_lookup_import",
@@ -27,6 +27,7 @@ SYMBOLS = [
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
+    "acl_lookup_one_submit", "acl_lookup_completions",
 ]
 
 
@@ -60,6 +61,11 @@ class CheckItem(C.Structure):
 class Completion(C.Structure):
     """acl_completion_t: one answered acl_check_one_submit."""
     _fields_ = [("tag", C.c_uint64), ("rc", C.c_int32), ("err", C.c_int32), ("perm", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class LookupCompletion(C.Structure):
+    """acl_lookup_completion_t: one answered acl_lookup_one_submit; `bitmap` is the receiver's (acl_free)."""
+    _fields_ = [("tag", C.c_uint64), ("rc", C.c_int32), ("reserved", C.c_uint32), ("count", C.c_uint64), ("words", C.c_size_t), ("bitmap", C.POINTER(C.c_uint32))]
 
 
 class Stats(C.Structure):
@@ -138,6 +144,7 @@ def load():
     L.acl_set_now.argtypes = [H, C.c_int64]
     L.acl_snapshot.argtypes = [H]
     L.acl_check_bulk.argtypes = [H, C.POINTER(CheckItem), C.c_size_t, C.c_void_p, C.c_void_p]
+    L.acl_check_bulk_v.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_check_bulk_ids.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_check_bulk_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_stream.argtypes = [H]
@@ -177,6 +184,8 @@ def load():
     L.acl_check_one_opts.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(CallOpts)]
     L.acl_check_one_submit.argtypes = [H, C.POINTER(CheckItem), C.c_uint64]
     L.acl_check_completions.argtypes = [H, C.POINTER(Completion), C.c_size_t, C.c_int64, C.POINTER(C.c_size_t)]
+    L.acl_lookup_one_submit.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+    L.acl_lookup_completions.argtypes = [H, C.POINTER(LookupCompletion), C.c_size_t, C.c_int64, C.POINTER(C.c_size_t)]
     L.acl_lookup_one_opts.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64),
                                       C.POINTER(CallOpts)]
     L.acl_shard_configure.argtypes = [H, C.c_uint32, C.c_uint32]

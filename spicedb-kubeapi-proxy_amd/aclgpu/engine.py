@@ -235,6 +235,37 @@ class Engine:
             arr[i] = CheckItem(*bs)
         return arr, n, keep
 
+    def make_check_views(self, items):
+        """A prepared acl_check_item_v_t array ({pointer, length} x 6 per item) of [(rt, rid, perm, st, sid, srel)]: every distinct string is
+        stored once in one blob WITHOUT a NUL behind it, and equal strings share their bytes -- as a cgo shim pointing at Go strings would."""
+        n = len(items)
+        blob = bytearray()
+        where = {}
+        views = np.zeros((max(1, n), 6, 2), dtype=np.uint64)
+        offs = np.zeros((max(1, n), 6), dtype=np.int64)
+        for i, it in enumerate(items):
+            for f, x in enumerate(it):
+                b = _b(x if x is not None else "") or b""
+                if f == 5 and not b:
+                    offs[i, f] = -1  # an absent subject relation is {NULL, 0}
+                    continue
+                at = where.get(b)
+                if at is None:
+                    at = where[b] = len(blob)
+                    blob += b
+                offs[i, f] = at
+                views[i, f, 1] = len(b)
+        buf = np.frombuffer(bytes(blob) or b"\0", dtype=np.uint8).copy()
+        views[:, :, 0] = np.where(offs >= 0, buf.ctypes.data + offs, 0).astype(np.uint64)
+        return views, n, buf
+
+    def check_bulk_views(self, prepared):
+        views, n, _blob = prepared
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_check_bulk_v(self._h, views.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
+        return perm[:n], err[:n]
+
     def check_bulk_prepared(self, prepared):
         arr, n, _keep = prepared
         perm = np.zeros(max(1, n), dtype=np.uint8)
@@ -388,6 +419,31 @@ class Engine:
         t = -1 if timeout_s < 0 else int(timeout_s * 1e9)
         self._check(self._L.acl_check_completions(self._h, buf, max_items, t, C.byref(n)))
         return [(int(buf[i].tag), int(buf[i].rc), int(buf[i].err), int(buf[i].perm)) for i in range(n.value)]
+
+    def lookup_one_submit(self, rt, perm, st, sid, srel="", tag=0):
+        """One LookupResources request WITHOUT a blocked thread (acl_lookup_one_submit): its answer arrives through lookup_completions."""
+        self._check(self._L.acl_lookup_one_submit(self._h, _b(rt), _b(perm), _b(st), _b(sid), _b(srel or ""), int(tag)))
+
+    def lookup_completions(self, rtype=None, max_items=64, timeout_s=-1.0):
+        """Up to max_items answered lookups as (tag, rc, count, ids) -- ids = set of resource names when `rtype` is given, else the raw u32 bitmap;
+        blocks while there are none (timeout_s < 0: until one arrives, 0: never).  Releases the GIL; frees the engine's rows."""
+        from ._lib import LookupCompletion
+        buf = (LookupCompletion * max(1, max_items))()
+        n = C.c_size_t()
+        t = -1 if timeout_s < 0 else int(timeout_s * 1e9)
+        self._check(self._L.acl_lookup_completions(self._h, buf, max_items, t, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            c = buf[i]
+            row = None
+            if c.bitmap:
+                row = np.ctypeslib.as_array(c.bitmap, shape=(max(1, c.words),)).copy()[:c.words]
+                self._L.acl_free(c.bitmap)
+            if row is not None and rtype is not None:
+                ids = np.flatnonzero(np.unpackbits(row.view(np.uint8), bitorder="little"))
+                row = {self.object_name(rtype, int(k)) for k in ids}
+            out.append((int(c.tag), int(c.rc), int(c.count), row))
+        return out
 
     def lookup_one(self, rt, perm, st, sid, srel="", cancel=None, timeout_s=None):
         """One LookupResources request (lookups.go:65) -> set of resource ids; concurrent callers with the same (type,

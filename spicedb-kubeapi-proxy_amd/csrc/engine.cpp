@@ -587,9 +587,11 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     if (G.cap < 256 || n > 8192 || G.nunits > G.nblocks) return kTakeLevelLoop;  // (a large batch is better copied than read across PCIe by the kernel)
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
+    if ((const void *)items != c->h_in.p) {
+        HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
+        std::memcpy(c->h_in.p, items, (size_t)n * sizeof(acl_item_t));
+    }
     HIP_TRY(c->h_out.ensure(64 + (size_t)n * 5));
-    std::memcpy(c->h_in.p, items, (size_t)n * sizeof(acl_item_t));
     uint32_t *flag = (uint32_t *)c->h_out.p;
     int32_t *h_err = (int32_t *)((char *)c->h_out.p + 64);
     uint8_t *h_perm = (uint8_t *)(h_err + n);
@@ -730,7 +732,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     HIP_TRY(c->d_perm.ensure(n));
     HIP_TRY(c->d_errout.ensure(n));
     const void *src = items;
-    if (!h->is_pinned(items, n * sizeof(acl_item_t))) {
+    if ((const void *)items != c->h_in.p && !h->is_pinned(items, n * sizeof(acl_item_t))) {  // (the string entry points intern straight into the staging buffer)
         HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
         std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
         src = c->h_in.p;
@@ -739,33 +741,6 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     // its results are back (callers beyond the lanes wait there).
     const bool chained = chains(h, n) && (uint32_t)c->index < std::min<uint32_t>(kChainLanes, h->max_ctx);  // (a caller that did not ask for a lane takes turns instead)
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
-    int rc = kTakeLevelLoop;
-    if (n >= kComputeTokenItems) {
-        // A batch this size fills every wave slot of the chip by itself: two such batches' kernels running at once only
-        // take turns (measured: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
-        // copies with ANOTHER batch's kernel -- and the kernels themselves should follow each other without a gap.  So the
-        // turn-taking happens ON THE DEVICE: this context's stream waits for the event the previous batch's kernel recorded,
-        // the single-launch kernel is enqueued behind it (the H2D above is already under way and is not held up), and its
-        // own event becomes the one the next caller waits for.  No host thread waits for another one: a mutex around
-        // "launch + synchronise" left the chip idle for a wake-up and a launch (~10 % of a C4 batch) between two kernels.
-        // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
-        //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
-        if (chained) {
-            rc = chained_enqueue(h, c, n);
-            if (!rc) rc = chained_finish(h, c, n);
-            else if (rc != kChainDeclined) (void)hipStreamSynchronize(c->stream);
-            if (rc == kChainDeclined) rc = kTakeLevelLoop;
-        }
-        if (rc == kTakeLevelLoop) {  // smaller batches; a block that ran out of private frontier; the walk switched off: one batch at a time
-            const bool tried = chained;
-            HIP_TRY(hipStreamSynchronize(c->stream));  // items are on the device before the kernels' turn starts
-            std::lock_guard<std::mutex> tk(h->compute_mu);
-            rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p, !tried);  // (ends with the context's stream synchronised)
-        }
-    } else {
-        rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p);
-    }
-    if (rc) return rc;
     const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
     uint8_t *hp = perm_out;
     int32_t *he = err_out;
@@ -774,10 +749,68 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         if (!pin_e) he = (int32_t *)c->h_out.p;
         if (!pin_p) hp = (uint8_t *)c->h_out.p + n * 4;
     }
-    HIP_TRY(hipMemcpyAsync(hp, c->d_perm.p, n, hipMemcpyDeviceToHost, c->stream));
-    if (err_out) HIP_TRY(hipMemcpyAsync(he, c->d_errout.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ev_collect(c);
+    auto results_d2h = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(hp, c->d_perm.p, n, hipMemcpyDeviceToHost, c->stream));
+        if (err_out) HIP_TRY(hipMemcpyAsync(he, c->d_errout.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        return ACL_OK;
+    };
+    // The common case is ONE launch (the single-launch walk): H2D, kernel, overflow-flag read-back and result copies all go onto the stream
+    // and the host synchronises ONCE (three synchronisations -- after the H2D, after the kernel, after the D2H -- cost a 65 536-item call
+    // 30-40 us of wake-ups, a third of its kernel).  Only a walk that overflowed its private regions comes back for the level loop.
+    int rc = kTakeLevelLoop;
+    bool tried = false;  // the single-launch walk has had its go at this batch
+    const bool walk = n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+    if (chained) {
+        tried = true;
+        // A batch this size fills every wave slot of the chip by itself: two such batches' kernels running at once only
+        // take turns (measured: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
+        // copies with ANOTHER batch's kernel -- and the kernels themselves should follow each other without a gap.  So the
+        // turn-taking happens ON THE DEVICE: this context's stream waits for the event the previous batch's kernel recorded,
+        // the single-launch kernel is enqueued behind it (the H2D above is already under way and is not held up), and its
+        // own event becomes the one the next caller waits for; the result copies follow the event, under the next batch's kernel.
+        // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
+        //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
+        rc = chained_enqueue(h, c, n);
+        if (!rc) {
+            rc = results_d2h();
+            if (rc) return rc;
+            rc = chained_finish(h, c, n);
+        } else if (rc != kChainDeclined) {
+            (void)hipStreamSynchronize(c->stream);
+        }
+        if (rc == kChainDeclined) rc = kTakeLevelLoop;
+    } else if (walk && walk_allowed(h, n)) {
+        tried = true;
+        HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
+        HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
+        // chip-filling batches of several callers: kernels one at a time (host mutex, held from the launch to the one synchronisation); the
+        // next caller's H2D, already enqueued on its own stream, runs meanwhile
+        std::unique_lock<std::mutex> tk(h->compute_mu, std::defer_lock);
+        if (n >= kComputeTokenItems) tk.lock();
+        rc = local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
+        if (!rc) {
+            rc = results_d2h();
+            if (rc) return rc;
+            rc = local_finish(h, c, (uint32_t)n);
+        } else if (rc != kTakeLevelLoop) {
+            (void)hipStreamSynchronize(c->stream);
+        }
+        walk_outcome(h, n, rc);
+    }
+    if (rc == kTakeLevelLoop) {  // a block ran out of private frontier, or the walk is switched off / backing off: the level loop, one batch at a time
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        {
+            std::unique_lock<std::mutex> tk(h->compute_mu, std::defer_lock);
+            if (n >= kComputeTokenItems) tk.lock();
+            rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p, !tried);  // (ends with the context's stream synchronised; a batch the walk has not tried -- sub-batched ones -- tries it per pass)
+        }
+        if (rc) return rc;
+        rc = results_d2h();
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ev_collect(c);
+    }
+    if (rc) return rc;
     if (!pin_p) std::memcpy(perm_out, hp, n);
     if (err_out && !pin_e) std::memcpy(err_out, he, n * sizeof(int32_t));
     return ACL_OK;
@@ -823,39 +856,74 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
     return 0;
 }
 
-// The string entry point's host half (SURVEY.md 7 "the GPU is not the bottleneck; the host is"): type / permission names
-// repeat across a bulk request (check.go:23-39 resolves one rule template per item), so the last resolved
-// (type, permission, subject type, subject relation) is remembered per thread; object ids are two hash probes over the
-// caller's bytes.  Large batches are split over host threads (lookups only read the tables: names_mu is held shared by the caller).
+// The string entry points' host half (SURVEY.md 7 "the GPU is not the bottleneck; the host is").  Two item forms share one core:
+// NUL-terminated fields (acl_check_item_t) and {pointer, length} fields (acl_check_item_v_t -- what a cgo shim can point at Go string
+// data without copying).  Type / permission names repeat across a bulk request (check.go:23-39 resolves one rule template per item), so
+// the last resolved (type, permission, subject type, subject relation) is remembered per thread and recognised BY POINTER first: the
+// same template hands over the same string.  Object ids: hash, then the table's three-stage pipelined lookup over groups of items.
+struct CStrItems {
+    const acl_check_item_t *it;
+    static constexpr bool kHasLen = false;
+    const char *ptr(size_t i, int f) const { return (&it[i].resource_type)[f]; }
+    size_t len(size_t i, int f) const {
+        const char *p = ptr(i, f);
+        return p ? std::strlen(p) : 0;
+    }
+};
+struct ViewItems {
+    const acl_check_item_v_t *it;
+    static constexpr bool kHasLen = true;
+    const char *ptr(size_t i, int f) const { return (&it[i].resource_type)[f].p; }
+    size_t len(size_t i, int f) const { return (&it[i].resource_type)[f].p ? (&it[i].resource_type)[f].n : 0; }
+};
+enum { F_RT = 0, F_RID = 1, F_PM = 2, F_ST = 3, F_SID = 4, F_SR = 5 };
+static_assert(offsetof(acl_check_item_t, subject_relation) == 5 * sizeof(const char *), "acl_check_item_t: six consecutive pointers");
+static_assert(offsetof(acl_check_item_v_t, subject_relation) == 5 * sizeof(acl_str_t), "acl_check_item_v_t: six consecutive views");
+
 struct NameMemo {
-    const char *rt = nullptr, *pm = nullptr, *st = nullptr, *sr = nullptr;
-    std::string rts, pms, sts, srs;
+    const char *p[4] = {nullptr, nullptr, nullptr, nullptr};  // resource type, permission, subject type, subject relation: as last seen
+    size_t n[4] = {0, 0, 0, 0};
+    std::string s[4];
     int rti = -1, pmi = -1, sti = -1, sri = kNoRelation;
-    bool bad = true;
+    bool bad = true, valid = false;
 };
 
-// names -> indices of one item (memoised per thread); false: *err says why the item cannot be checked
-static bool intern_names(const Schema &sc, const acl_check_item_t &it, NameMemo &m, int32_t *err) {
-    if (empty(it.resource_type) || empty(it.resource_id) || empty(it.permission) || empty(it.subject_type) || empty(it.subject_id)) {
+// names -> indices of item i (memoised per thread); false: *err says why the item cannot be checked
+template <class Items>
+static bool intern_names(const Schema &sc, const Items &its, size_t i, NameMemo &m, int32_t *err) {
+    static const int kF[4] = {F_RT, F_PM, F_ST, F_SR};
+    bool same = m.valid;
+    for (int k = 0; k < 4 && same; k++) same = its.ptr(i, kF[k]) == m.p[k] && (!Items::kHasLen || its.len(i, kF[k]) == m.n[k]);
+    if (!same) {
+        std::string_view v[4];
+        for (int k = 0; k < 4; k++) {
+            const char *q = its.ptr(i, kF[k]);
+            v[k] = q ? std::string_view(q, its.len(i, kF[k])) : std::string_view();
+        }
+        if (v[3] == "...") v[3] = std::string_view();
+        const bool content = m.valid && v[0] == m.s[0] && v[1] == m.s[1] && v[2] == m.s[2] && v[3] == m.s[3];
+        for (int k = 0; k < 4; k++) {
+            m.p[k] = its.ptr(i, kF[k]);
+            m.n[k] = Items::kHasLen ? its.len(i, kF[k]) : 0;
+        }
+        if (!content) {
+            for (int k = 0; k < 4; k++) m.s[k].assign(v[k].data() ? v[k].data() : "", v[k].size());
+            m.rti = sc.type_of(m.s[0]);
+            m.sti = sc.type_of(m.s[2]);
+            m.pmi = m.rti < 0 ? -1 : sc.defs[m.rti].find(m.s[1]);
+            m.sri = kNoRelation;
+            m.bad = m.rti < 0 || m.sti < 0 || m.pmi < 0;
+            if (!m.bad && !m.s[3].empty()) {
+                m.sri = sc.defs[m.sti].find(m.s[3]);
+                m.bad = m.sri < 0;
+            }
+        }
+        m.valid = true;
+    }
+    // empty request fields: pkg/proxy/options_test.go:101-102 (the subject relation may be empty)
+    if (m.s[0].empty() || m.s[1].empty() || m.s[2].empty()) {
         *err = ACL_ERR_INVALID_ARGUMENT;
         return false;
-    }
-    const char *srel = (empty(it.subject_relation) || std::strcmp(it.subject_relation, "...") == 0) ? "" : it.subject_relation;
-    if (!(m.rt && m.rts == it.resource_type && m.pms == it.permission && m.sts == it.subject_type && m.srs == srel)) {
-        m.rt = it.resource_type;
-        m.rts = it.resource_type;
-        m.pms = it.permission;
-        m.sts = it.subject_type;
-        m.srs = srel;
-        m.rti = sc.type_of(m.rts);
-        m.sti = sc.type_of(m.sts);
-        m.pmi = m.rti < 0 ? -1 : sc.defs[m.rti].find(m.pms);
-        m.sri = kNoRelation;
-        m.bad = m.rti < 0 || m.sti < 0 || m.pmi < 0;
-        if (!m.bad && *srel) {
-            m.sri = sc.defs[m.sti].find(m.srs);
-            m.bad = m.sri < 0;
-        }
     }
     if (m.bad) {
         *err = ACL_ERR_FAILED_PRECONDITION;
@@ -936,15 +1004,24 @@ void intern_pool_destroy(acl_engine_t *h) {
     h->intern_pool = nullptr;
 }
 
-void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out) {
+// Interns n items into `out` (the evaluation context's pinned staging: what the H2D copy reads).  An item that cannot be checked -- empty
+// field, unknown type / permission / relation: the pair carries an error, check.go:55 -- becomes a DEAD item (the kernel answers it
+// "invalid" without touching the graph) and is listed in *bad with its error; the batch is never compacted or copied again.
+constexpr uint16_t kDeadType = 0xFFFFu;
+template <class Items>
+static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t *out, std::vector<std::pair<uint32_t, int32_t>> *bad) {
     const Schema &sc = h->store.schema();
-    // Object ids: two hash probes per item into tables of up to millions of names -- one DRAM miss each.  Items go in groups of
-    // kGroup: hash every id and prefetch its slot, then probe; the misses of a group are in flight together.
+    std::mutex bad_mu;
+    // Object ids: two lookups per item in tables of up to millions of names -- two dependent DRAM misses each (slot, then the name's
+    // bytes).  Items go in groups of kGroup through three stages: hash + prefetch the slots; walk to the tag match + prefetch the names;
+    // compare.  The misses of a group are in flight together.
     constexpr size_t kGroup = 16;
     const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
         NameMemo m;
+        std::vector<std::pair<uint32_t, int32_t>> mybad;
         struct Pending {
             uint64_t hr, hs;
+            std::string_view rid, sid;
             int rt, st, pm, sr;
             bool ok;
         } pend[kGroup];
@@ -952,25 +1029,40 @@ void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n
             const size_t g1 = std::min(b, g0 + kGroup);
             for (size_t i = g0; i < g1; i++) {
                 Pending &p = pend[i - g0];
-                out[i] = acl_item_t{};
-                err_out[i] = 0;
-                p.ok = intern_names(sc, items[i], m, &err_out[i]);
-                if (!p.ok) continue;
+                int32_t err = 0;
+                const char *r = its.ptr(i, F_RID), *u = its.ptr(i, F_SID);
+                p.rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
+                p.sid = u ? std::string_view(u, its.len(i, F_SID)) : std::string_view();
+                p.ok = intern_names(sc, its, i, m, &err);
+                if (err != ACL_ERR_INVALID_ARGUMENT && (p.rid.empty() || p.sid.empty())) {  // an empty field beats an unknown name
+                    p.ok = false;
+                    err = ACL_ERR_INVALID_ARGUMENT;
+                }
+                if (!p.ok) {
+                    out[i] = acl_item_t{kDeadType, 0, 0, kDeadType, 0, 0};
+                    mybad.emplace_back((uint32_t)i, err);
+                    continue;
+                }
                 p.rt = m.rti; p.st = m.sti; p.pm = m.pmi; p.sr = m.sri;
-                p.hr = ObjectTable::hash_of(items[i].resource_id);
-                p.hs = ObjectTable::hash_of(items[i].subject_id);
+                p.hr = ObjectTable::hash_of(p.rid);
+                p.hs = ObjectTable::hash_of(p.sid);
                 h->store.objects(p.rt).prefetch(p.hr);
                 h->store.objects(p.st).prefetch(p.hs);
             }
             for (size_t i = g0; i < g1; i++) {
                 const Pending &p = pend[i - g0];
                 if (!p.ok) continue;
-                const acl_check_item_t &it = items[i];
+                h->store.objects(p.rt).prefetch_name(p.hr);
+                h->store.objects(p.st).prefetch_name(p.hs);
+            }
+            for (size_t i = g0; i < g1; i++) {
+                const Pending &p = pend[i - g0];
+                if (!p.ok) continue;
                 // unknown object ids have no relationships: sentinels above every dense id, equal only when
                 // resource and subject are the same (unknown) object
                 uint32_t res, sub;
-                const bool kr = h->store.objects(p.rt).find_hashed(it.resource_id, p.hr, &res), ks = h->store.objects(p.st).find_hashed(it.subject_id, p.hs, &sub);
-                if (!kr && !ks && p.rt == p.st && std::strcmp(it.resource_id, it.subject_id) == 0) res = sub = 0xFFFFFFFEu;
+                const bool kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &res), ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &sub);
+                if (!kr && !ks && p.rt == p.st && p.rid == p.sid) res = sub = 0xFFFFFFFEu;
                 else {
                     if (!kr) res = 0xFFFFFFFDu;
                     if (!ks) sub = 0xFFFFFFFCu;
@@ -978,8 +1070,12 @@ void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n
                 out[i] = acl_item_t{(uint16_t)p.rt, (uint16_t)p.pm, res, (uint16_t)p.st, (uint16_t)(p.sr == kNoRelation ? ACL_NO_RELATION : p.sr), sub};
             }
         }
+        if (!mybad.empty()) {
+            std::lock_guard<std::mutex> lk(bad_mu);
+            bad->insert(bad->end(), mybad.begin(), mybad.end());
+        }
     };
-    if (n < 4096) {  // ~90 ns per item on one thread: below this the pool's wake-up costs more than it saves
+    if (n < 4096) {  // tens of nanoseconds per item on one thread: below this the pool's wake-up costs more than it saves
         run(0, n);
         return;
     }
@@ -988,6 +1084,35 @@ void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n
         if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), 16u) - 1);
     }
     h->intern_pool->run(n, n >= 32768 ? 2048 : 512, run);
+}
+
+// acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
+template <class Items>
+static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
+    Eval ev;
+    int rc = ev.begin(h, false, CallOpts(), -1, false, chains(h, n));
+    if (rc) return rc;
+    PassCtx *c = ev.c;
+    HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
+    acl_item_t *staged = (acl_item_t *)c->h_in.p;
+    std::vector<std::pair<uint32_t, int32_t>> bad;
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);  // string -> id only reads the tables: concurrent callers intern in parallel
+        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+        intern_items(h, its, n, staged, &bad);
+    }
+    if (bad.size() == n) {  // nothing to ask the device
+        std::memset(perm_out, ACL_PERM_UNSPECIFIED, n);
+    } else {
+        rc = check_ids_host(h, c, staged, n, perm_out, err_out);
+        if (rc) return rc;
+    }
+    for (const auto &be : bad) {
+        perm_out[be.first] = ACL_PERM_UNSPECIFIED;
+        err_out[be.first] = be.second;
+    }
+    return ACL_OK;
 }
 
 // Single-launch LookupResources over m subjects already staged in c->h_in (pinned).  Result rows go to `bitmaps` directly when the
@@ -1454,32 +1579,13 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
 
 int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk: NULL buffer");
-    std::vector<acl_item_t> all(n), ids;
-    std::vector<uint32_t> where;
-    {
-        std::shared_lock<std::shared_mutex> nlk(h->names_mu);  // string -> id only reads the tables: concurrent callers intern in parallel
-        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
-        intern_check_items(h, items, n, all.data(), err_out);
-    }
-    ids.reserve(n);
-    where.reserve(n);
-    for (size_t i = 0; i < n; i++) {
-        perm_out[i] = ACL_PERM_UNSPECIFIED;
-        if (err_out[i]) continue;
-        ids.push_back(all[i]);
-        where.push_back((uint32_t)i);
-    }
-    if (ids.empty()) return ACL_OK;
-    if (ids.size() == n) return acl_check_bulk_ids(h, ids.data(), n, perm_out, err_out);
-    std::vector<uint8_t> p(ids.size());
-    std::vector<int32_t> e(ids.size());
-    int rc = acl_check_bulk_ids(h, ids.data(), ids.size(), p.data(), e.data());
-    if (rc) return rc;
-    for (size_t k = 0; k < ids.size(); k++) {
-        perm_out[where[k]] = p[k];
-        err_out[where[k]] = e[k];
-    }
-    return ACL_OK;
+    return check_bulk_strings(h, CStrItems{items}, n, perm_out, err_out);
+}
+
+// the same with {pointer, length} fields: no strlen per field, and no NUL needed behind the bytes -- a cgo shim points at Go string data
+int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
+    if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v: NULL buffer");
+    return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
 }
 
 int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps,

@@ -419,8 +419,6 @@ bool empty(const char *s);
 FilterText to_filter(const acl_filter_t *f);
 // strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55).  Caller holds names_mu shared.
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
-// many items: split over host threads when the batch is large
-void intern_check_items(acl_engine_t *h, const acl_check_item_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 void intern_pool_destroy(acl_engine_t *h);
 constexpr uint32_t kChainLanes = 3;  // contexts (streams) that carry chip-filling host batches
 bool chains(acl_engine *h, size_t n);  // does a host batch of n items take the chained-kernel pipeline?

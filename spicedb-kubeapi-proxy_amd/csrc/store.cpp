@@ -5,23 +5,42 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstring>
 
 #include "../../include/aclgpu.h"
 
 namespace acl {
 
 // ---------------------------------------------------------------- ObjectTable
-uint64_t ObjectTable::hash(std::string_view s) {  // FNV-1a folded through a 64-bit finaliser
-    uint64_t h = 0xcbf29ce484222325ull;
-    for (unsigned char c : s) h = (h ^ c) * 0x100000001b3ull;
-    h ^= h >> 32;
-    h *= 0x9E3779B97F4A7C15ull;
-    return h ^ (h >> 29);
+// 8 bytes per step through a 64 x 64 -> 128-bit multiply-fold (the construction of wyhash / rapidhash): a 15-byte object id is two steps and
+// a finaliser, where byte-at-a-time FNV-1a was a chain of 15 dependent multiplies -- two ids per item made that half of the string entry
+// point's host time.  (The function is internal to the table: nothing outside depends on its values.)
+static inline uint64_t mulfold(uint64_t a, uint64_t b) {
+    const __uint128_t r = (__uint128_t)a * b;
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+uint64_t ObjectTable::hash(std::string_view s) {
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(s.data());
+    size_t n = s.size();
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+    while (n >= 8) {
+        uint64_t v;
+        std::memcpy(&v, p, 8);
+        h = mulfold(h ^ v, 0xE7037ED1A0B428DBull);
+        p += 8;
+        n -= 8;
+    }
+    if (n) {
+        uint64_t v = 0;
+        std::memcpy(&v, p, n);  // (little-endian tail, zero-padded: the length is mixed in above)
+        h = mulfold(h ^ v, 0x8EBC6AF09C88C6E3ull);
+    }
+    return mulfold(h, 0x589965CC75374CC3ull) ^ h;
 }
 void ObjectTable::grow() {
     std::vector<Slot> old;
     old.swap(slots_);
-    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu});
+    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu, nullptr});
     const size_t mask = slots_.size() - 1;
     for (const Slot &s : old) {
         if (s.id == 0xFFFFFFFFu) continue;
@@ -38,9 +57,15 @@ bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) c
     for (size_t i = h & mask;; i = (i + 1) & mask) {
         const Slot &s = slots_[i];
         if (s.id == 0xFFFFFFFFu) return false;
-        if (s.tag == tag && names_[name_of_[s.id]] == name) {
-            *id = s.id;
-            return true;
+        if (s.tag == tag) {  // (stored names are NUL-terminated; never read past that NUL: a longer query must not run off a shorter name)
+            const char *a = s.name, *b = name.data();
+            const size_t n = name.size();
+            size_t k = 0;
+            while (k < n && a[k] == b[k] && a[k] != 0) k++;
+            if (k == n && a[n] == 0) {
+                *id = s.id;
+                return true;
+            }
         }
     }
 }
@@ -56,7 +81,7 @@ uint32_t ObjectTable::intern(std::string_view name) {
     const size_t mask = slots_.size() - 1;
     size_t i = h & mask;
     while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
-    slots_[i] = Slot{(uint32_t)(h >> 32), id};
+    slots_[i] = Slot{(uint32_t)(h >> 32), id, names_.back().c_str()};
     used_++;
     count_.store(id + 1, std::memory_order_release);
     return id;

@@ -69,6 +69,22 @@ class ObjectTable {
     void prefetch(uint64_t h) const {
         if (!slots_.empty()) __builtin_prefetch(&slots_[h & (slots_.size() - 1)]);
     }
+    // second stage of a pipelined lookup: walks to the first slot whose tag matches (slot lines: prefetched by the first stage) and pulls
+    // the line of that NAME towards the core; the third stage (find_hashed) then compares bytes that are already in cache.  A lookup in a
+    // table of millions of names is two dependent DRAM misses (slot, name); staged over a group of items they overlap instead of adding up.
+    void prefetch_name(uint64_t h) const {
+        if (slots_.empty()) return;
+        const uint32_t tag = (uint32_t)(h >> 32);
+        const size_t mask = slots_.size() - 1;
+        for (size_t i = h & mask;; i = (i + 1) & mask) {
+            const Slot &s = slots_[i];
+            if (s.id == 0xFFFFFFFFu) return;
+            if (s.tag == tag) {
+                __builtin_prefetch(s.name);
+                return;
+            }
+        }
+    }
     bool find_hashed(std::string_view name, uint64_t h, uint32_t *id) const;
     const std::string *name(uint32_t id) const;  // nullptr for anonymous ids
     uint32_t count() const { return count_.load(std::memory_order_acquire); }
@@ -76,20 +92,27 @@ class ObjectTable {
         if (n > count()) count_.store(n, std::memory_order_release);
     }
     ObjectTable() = default;
-    ObjectTable(const ObjectTable &o) : names_(o.names_), name_of_(o.name_of_), slots_(o.slots_), used_(o.used_), count_(o.count()) {}
+    ObjectTable(const ObjectTable &o) : names_(o.names_), name_of_(o.name_of_), slots_(o.slots_), used_(o.used_), count_(o.count()) { repoint(); }
     ObjectTable &operator=(const ObjectTable &o) {
         names_ = o.names_;
         name_of_ = o.name_of_;
         slots_ = o.slots_;
         used_ = o.used_;
         count_.store(o.count());
+        repoint();
         return *this;
     }
 
   private:
-    struct Slot { uint32_t tag, id; };  // id == 0xFFFFFFFF: empty
+    // tag = high half of the hash; `name` points at the NUL-terminated bytes of the name inside names_ (stable: a deque never moves its
+    // elements): a probe compares the caller's bytes with them directly -- no id -> index -> deque block -> string chase (three more misses)
+    struct Slot { uint32_t tag, id; const char *name; };  // id == 0xFFFFFFFF: empty
     static uint64_t hash(std::string_view s);
     void grow();
+    void repoint() {  // after a copy: the slots must point into THIS table's names
+        for (Slot &s : slots_)
+            if (s.id != 0xFFFFFFFFu) s.name = names_[name_of_[s.id]].c_str();
+    }
     std::deque<std::string> names_;      // stable addresses (acl_object_name hands out c_str())
     std::vector<uint32_t> name_of_;      // id -> index in names_ (0xFFFFFFFF anonymous); covers ids < name_of_.size()
     std::vector<Slot> slots_;            // power-of-two capacity, load <= 0.5

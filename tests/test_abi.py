@@ -114,7 +114,23 @@ def test_completion_queue_without_gpu(aclgpu_lib):
     (tag, rc, err, perm), = e.check_completions(8, timeout_s=2.0)
     assert (tag, rc, perm) == (9, 0, 0) and err != 0
     assert e.check_completions(8, timeout_s=0) == []
+    # the same for LookupResources (acl_lookup_one_submit / acl_lookup_completions): refused passes complete with the refusal and no row
+    for k in range(20):
+        e.lookup_one_submit("doc", "view", "user", f"u{k % 5}", tag=1000 + k)
+    seen = []
+    while len(seen) < 20:
+        c = e.lookup_completions(max_items=8, timeout_s=2.0)
+        assert c, "lookup completions stopped arriving"
+        seen += c
+    assert sorted(t for t, _rc, _n, _row in seen) == list(range(1000, 1020))
+    assert all(rc == aclgpu.ERR_UNAVAILABLE and row is None and cnt == 0 for _t, rc, cnt, row in seen)
+    with pytest.raises(aclgpu.AclError) as ei:  # a malformed request is reported by the submit itself
+        e.lookup_one_submit("nosuchtype", "view", "user", "u0", tag=1)
+    assert ei.value.code == aclgpu.ERR_FAILED_PRECONDITION
+    assert e.lookup_completions(timeout_s=0) == []
     e.batcher_stop()
+    with pytest.raises(aclgpu.AclError):
+        e.lookup_one_submit("doc", "view", "user", "u0", tag=2)  # needs a running batcher
     e.close()
 
 

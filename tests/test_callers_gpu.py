@@ -228,6 +228,28 @@ def test_micro_batcher_coalesces_lookups(aclgpu):
             assert g == co.lookup(*r), r
         st = e.batcher_lookup_stats()
         assert st["lookups"] == len(reqs) and 3 <= st["walks"] < len(reqs), st
+        # the same requests WITHOUT a blocked thread each (acl_lookup_one_submit / acl_lookup_completions: responsefilterer.go:165-204 starts every
+        # prefilter in a goroutine next to the upstream call): tagged answers, engine-allocated rows, one walk per class and sweep
+        for i, r in enumerate(reqs):
+            e.lookup_one_submit(*r, tag=500 + i)
+        e.write([(aclgpu.OP_TOUCH, ("doc", "d-late", "viewer", "user", "u0", ""))])  # objects created after the submits: the rows are sized when the walk runs
+        co.write([(orc.OP_TOUCH, ("doc", "d-late", "viewer", "user", "u0", ""))])
+        e.lookup_one_submit("doc", "view", "user", "u0", tag=999)
+        done = {}
+        while len(done) < len(reqs) + 1:
+            c = e.lookup_completions(max_items=16, timeout_s=5.0)
+            assert c, "lookup completions stopped arriving"
+            for tag, rc, cnt, row in c:
+                assert rc == 0 and tag not in done
+                rt = "doc" if tag == 999 else reqs[tag - 500][0]
+                ids = np.flatnonzero(np.unpackbits(row.view(np.uint8), bitorder="little"))
+                done[tag] = ({e.object_name(rt, int(k)) for k in ids}, cnt)
+        for i, r in enumerate(reqs):
+            want = co.lookup(*r)
+            assert done[500 + i][0] - {"d-late"} == want - {"d-late"} and done[500 + i][1] == len(done[500 + i][0]), r
+        assert done[999][0] == co.lookup("doc", "view", "user", "u0") and "d-late" in done[999][0]
+        st2 = e.batcher_lookup_stats()
+        assert st2["lookups"] == 2 * len(reqs) + 1 and st2["walks"] - st["walks"] < len(reqs), (st, st2)
         e.batcher_stop()
         assert e.lookup_one("doc", "view", "user", "u1") == co.lookup("doc", "view", "user", "u1")  # no batcher: a walk of its own
         with pytest.raises(aclgpu.AclError):

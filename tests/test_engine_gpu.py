@@ -278,3 +278,44 @@ def test_sub_batched_passes(aclgpu):
         keep = e.check_bulk_keep_ids(items[:off[-1]], off)
         want = (op[:off[-1]].reshape(-1, 5) == 2).all(axis=1)
         assert np.array_equal(keep.astype(bool), want)
+
+
+def test_string_entry_points_agree(aclgpu):
+    """acl_check_bulk (NUL-terminated fields) and acl_check_bulk_v ({pointer, length} fields, no NUL behind the bytes) against single checks and the
+    oracle: named objects, unknown names, `...` and real subject relations, and items that carry an error (check.go:55) in the middle of the batch --
+    they are answered in place (order preserved, check.go:54-57), not compacted away."""
+    schema = """definition user {}
+definition group { relation member: user | group#member }
+definition namespace { relation viewer: user | group#member
+ relation creator: user
+ permission view = viewer + creator }
+definition pod { relation namespace: namespace
+ relation creator: user
+ permission view = creator + namespace->view }"""
+    rels = [f"pod:ns{i % 7}/p{i}#namespace@namespace:ns{i % 7}" for i in range(300)] + [f"pod:ns{i % 7}/p{i}#creator@user:u{i % 31}" for i in range(300)]
+    rels += [f"namespace:ns{i}#viewer@group:g{i}#member" for i in range(7)] + [f"group:g{i}#member@user:u{i + 40}" for i in range(7)] + ["group:g0#member@group:g1#member"]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    rng = np.random.default_rng(5)
+    qs = []
+    for k in range(6000):
+        i, u = int(rng.integers(0, 330)), int(rng.integers(0, 60))
+        qs.append(("pod", f"ns{i % 7}/p{i}", "view", "user", f"u{u}", "" if k % 3 else "..."))
+    qs[10] = ("pod", "ns0/p0", "view", "group", "g0", "member")       # a subject with a relation
+    qs[11] = ("namespace", "ns1", "view", "group", "g1", "member")
+    qs[12] = ("nosuchtype", "x", "view", "user", "u1", "")            # FAILED_PRECONDITION
+    qs[13] = ("pod", "ns0/p0", "nosuchperm", "user", "u1", "")
+    qs[14] = ("pod", "", "view", "user", "u1", "")                    # INVALID_ARGUMENT (options_test.go:101-102)
+    qs[15] = ("pod", "ns0/p0", "view", "user", "u1", "nosuchrel")
+    qs[16] = ("pod", "same", "view", "pod", "same", "")               # unknown object that is its own subject
+    qs[5000] = ("", "", "", "", "", "")
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        want = [o.check(*q) if all(q[:5]) else (0, aclgpu.ERR_INVALID_ARGUMENT) for q in qs]
+        for idx in (10, 11, 12, 13, 14, 15, 16, 5000):
+            assert e.check(*qs[idx]) == want[idx], (idx, qs[idx])
+        for form, prep, call in (("c strings", e.make_check_strings_named(qs), e.check_bulk_prepared), ("views", e.make_check_views(qs), e.check_bulk_views)):
+            p, er = call(prep)
+            assert list(zip(p.tolist(), er.tolist())) == want, form
+            p2, er2 = call((prep[0], 100, prep[2]))  # a small batch takes the single-thread path
+            assert list(zip(p2.tolist(), er2.tolist())) == want[:100], form
+        assert {w_[1] for w_ in want} >= {0, aclgpu.ERR_INVALID_ARGUMENT, aclgpu.ERR_FAILED_PRECONDITION} and 0 < sum(w_[0] == 2 for w_ in want) < len(want)
