@@ -285,23 +285,37 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
         engines.append(e)
         return sharded.GpuShard(e, r, g)
 
+    native = args.native_loop == "on"  # the level loops inside libaclgpu.so (acl_shard_check_bulk / acl_shard_lookup_bulk) instead of the host-driven step protocol
+
     def run(se, barrier):
         e = se.shard.e
         se._alloc(1 << 20)
         items = e.make_items(rt, perm_name, w.res, st, "", w.subj)
         d_items = torch.from_numpy(items.view(np.uint8).copy()).to(se.shard.device)
-        p, er = se.check_bulk_ids(d_items)  # warm-up (also builds + uploads the shard's snapshot)
-        bm = se.lookup_ids_batch(rt, perm_name, st, "", [int(w.lookup_subjects[0])])
+
+        def check():
+            if native:
+                p_, e_, _s = se.check_bulk_ids_native(d_items)
+                return p_, e_
+            return se.check_bulk_ids(d_items)
+
+        def lookup(sub):
+            if native:
+                return se.lookup_ids_batch_native(rt, perm_name, st, "", [sub])[0]
+            return se.lookup_ids_batch(rt, perm_name, st, "", [sub])
+
+        p, er = check()  # warm-up (also builds + uploads the shard's snapshot)
+        bm = lookup(int(w.lookup_subjects[0]))
         barrier()
         t0 = time.perf_counter()
         tc = tf = 0.0
         for o in ops:
             t1 = time.perf_counter()
             if o == "C":
-                p, er = se.check_bulk_ids(d_items)
+                p, er = check()
                 tc += time.perf_counter() - t1
             else:
-                bm = se.lookup_ids_batch(rt, perm_name, st, "", [o[1]])
+                bm = lookup(o[1])
                 tf += time.perf_counter() - t1
         barrier()
         el = time.perf_counter() - t0
@@ -310,7 +324,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
         last_f = [o for o in ops if o != "C"][-1][1]
         rng = np.random.default_rng(7)
         pods = rng.integers(0, w.nobjects[rt], size=20000).astype(np.uint32)
-        bm = se.lookup_ids_batch(rt, perm_name, st, "", [last_f])
+        bm = lookup(last_f)
         bits = np.unpackbits(bm[0].cpu().numpy().view(np.uint8), bitorder="little")
         cp, _ = se.check_bulk_ids(e.make_items(rt, perm_name, pods, st, "", np.full(pods.size, last_f, dtype=np.uint32)))
         cross = int(((cp.cpu().numpy() == 2) != (bits[pods] == 1)).sum())
@@ -338,6 +352,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
                "dtype": "u32", "data": "synthetic",
                "config": {"workload": WORKLOAD_DESC["C5"], "shards": G, "scale": args.scale, "relationships": w.ntuples,
                           "objects": int(sum(w.nobjects.values())), "check_batch": n, "stream": "".join("C" if o == "C" else "F" for o in ops), "check_exchange": c5_exchange,
+                          "level_loop": "inside libaclgpu.so (acl_shard_check_bulk / acl_shard_lookup_bulk: headers every level, entry blocks where the previous batch exported)" if native else "host-driven step protocol (aclgpu/sharded.py)",
                           "execution": "one shard per GPU, RCCL all-gather" if world > 1 else f"{G} LOGICAL shards on ONE GPU: emulated, not a multi-GPU measurement"},
                "check_batches": nC, "filter_requests": len(ops) - nC,
                "ms_per_check_batch": 1e3 * outs[0]["check_s"] / max(1, nC), "ms_per_filter_request": 1e3 * outs[0]["filter_s"] / max(1, len(ops) - nC),

@@ -332,34 +332,46 @@ int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entrie
 /* n rows of bitmap_words words: the resource type's owner returns the result bits, every other shard zeros */
 int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_words);
 
-/* ---- native sharded loop: the whole level loop of a sharded Check inside the library ----
- * SPMD: every shard makes the same call with the same batch.  Per level ONE fixed-capacity all-gather moves
- * [header | entries] blocks (the counts ride in the header, written on the device); imports, termination and retry
- * decisions are computed on the device from the gathered headers, identically on every shard; the host synchronises
- * once per burst of levels.  has / err are MAX-reduced across shards once per batch.  The collective is two callbacks:
- * acl_shard_rccl_* below supply RCCL (ncclAllGather / ncclAllReduce over xGMI); a host with its own ncclComm_t (the cgo
- * shim) or a test double plugs in the same way.  Callbacks enqueue on `hip_stream` and return 0 or an ACL_ERR_* code. */
+/* ---- native sharded loop: the whole level loop of a sharded Check / LookupResources inside the library ----
+ * SPMD: every shard makes the same call with the same batch.  Per level the shards exchange 16-byte HEADERS (entries exported, produced flag,
+ * overflow code: written on the device) and -- on the levels the previous batch exported something, or on all of them -- fixed-capacity blocks
+ * of frontier ENTRIES; imports, termination and retry decisions are computed on the device from the headers, identically on every shard; the
+ * host synchronises once per burst of levels.  A level that exports where none was expected makes every shard redo the batch with entries on
+ * every level.  Check results (has / err) and LookupResources rows are MAX-reduced across shards once per batch.  The collective is a set of
+ * callbacks: acl_shard_rccl_* below supply RCCL (ncclAllGather / ncclAllReduce, grouped ncclSend / ncclRecv over xGMI); a host with its own
+ * ncclComm_t (the cgo shim) or a test double plugs in the same way.  Callbacks enqueue on `hip_stream` and return 0 or an ACL_ERR_* code.
+ * all_to_all may be NULL: Check then exchanges one block per shard through all_gather (every shard receives everything and keeps what it
+ * owns) instead of one block per (shard, destination) -- `world` times the bytes.  LookupResources always all-gathers (a visited state goes
+ * to every shard that holds parent rows for it). */
 typedef struct {
     void *user;
     int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);
     int (*all_reduce_max_u8)(void *user, void *d_buf, size_t n_bytes, void *hip_stream); /* in place */
+    int (*all_to_all)(void *user, const void *d_send, void *d_recv, size_t bytes_per_peer, void *hip_stream); /* block r of send -> rank r; block r of recv <- rank r */
 } acl_shard_comm_t;
 typedef struct {
     uint32_t levels;            /* dispatch levels the batch needed (max over shards) */
-    uint32_t exchanges;         /* all-gathers issued (includes the burst's levels past the end) */
+    uint32_t exchanges;         /* header exchanges issued (includes the burst's levels past the end) */
     uint32_t host_syncs;        /* stream synchronisations: bursts + the final one */
-    uint32_t retries;           /* batch redone after an export block / frontier overflow */
-    uint64_t exchanged_bytes;   /* bytes this shard received in all-gathers */
+    uint32_t retries;           /* batch redone after an export block / frontier overflow, or an export on a level planned without entries */
+    uint64_t exchanged_bytes;   /* bytes this shard received in the exchanges */
     uint64_t entries_exchanged; /* frontier entries exported by all shards */
     uint64_t export_capacity;   /* entries per exchange block at the end */
+    uint32_t data_exchanges;    /* ... of which also moved entry blocks */
+    uint32_t reserved;
 } acl_shard_bulk_stats_t;
 int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const void *d_items, size_t n, void *d_perm_out, void *d_err_out,
                          acl_shard_bulk_stats_t *stats_out);
+/* LookupResources for n subjects (host array) of one class: n rows of bitmap_words words in device memory, the same on every shard afterwards */
+int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rtype, int permission, int stype, int srel /* -1 none */, const uint32_t *subject_ids,
+                          size_t n, void *d_bitmaps_out, size_t bitmap_words, acl_shard_bulk_stats_t *stats_out);
 #define ACL_RCCL_UNIQUE_ID_BYTES 128
 int acl_shard_rccl_unique_id(void *id_out /* ACL_RCCL_UNIQUE_ID_BYTES; rank 0 makes it, the host hands it to every rank */);
 int acl_shard_rccl_init(acl_engine_t *h, const void *unique_id, uint32_t rank, uint32_t world); /* also acl_shard_configure(rank, world) */
 int acl_shard_rccl_destroy(acl_engine_t *h);
 int acl_shard_check_bulk_rccl(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out, acl_shard_bulk_stats_t *stats_out);
+int acl_shard_lookup_bulk_rccl(acl_engine_t *h, int rtype, int permission, int stype, int srel, const uint32_t *subject_ids, size_t n, void *d_bitmaps_out,
+                               size_t bitmap_words, acl_shard_bulk_stats_t *stats_out);
 
 /* ---- test hook ----
  * Updates the HOST copy of the snapshot the way the next read would (in-place patch from the change feed when

@@ -26,7 +26,7 @@ SYMBOLS = [
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
-    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
+    "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions",
 ]
 
@@ -80,13 +80,17 @@ ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_siz
 ALL_REDUCE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
+ALL_TO_ALL_CB = ALL_GATHER_CB  # (user, d_send, d_recv, bytes per peer, stream)
+
+
 class ShardComm(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_CB), ("all_reduce_max_u8", ALL_REDUCE_CB)]
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_CB), ("all_reduce_max_u8", ALL_REDUCE_CB), ("all_to_all", ALL_TO_ALL_CB)]
 
 
 class ShardBulkStats(C.Structure):
     _fields_ = [("levels", C.c_uint32), ("exchanges", C.c_uint32), ("host_syncs", C.c_uint32), ("retries", C.c_uint32),
-                ("exchanged_bytes", C.c_uint64), ("entries_exchanged", C.c_uint64), ("export_capacity", C.c_uint64)]
+                ("exchanged_bytes", C.c_uint64), ("entries_exchanged", C.c_uint64), ("export_capacity", C.c_uint64),
+                ("data_exchanges", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ShardStep(C.Structure):
@@ -196,6 +200,8 @@ def load():
     L.acl_shard_rccl_init.argtypes = [H, C.c_void_p, C.c_uint32, C.c_uint32]
     L.acl_shard_rccl_destroy.argtypes = [H]
     L.acl_shard_check_bulk_rccl.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(ShardBulkStats)]
+    L.acl_shard_lookup_bulk.argtypes = [H, C.POINTER(ShardComm), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(ShardBulkStats)]
+    L.acl_shard_lookup_bulk_rccl.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(ShardBulkStats)]
     L.acl_shard_stream.argtypes = [H]
     L.acl_shard_stream.restype = C.c_void_p
     L.acl_shard_check_begin.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -193,7 +193,7 @@ def _hiprt():
 class ThreadNative:
     """acl_shard_comm_t over a ThreadComm: the all-gather is `world` device-to-device copies on the caller's stream."""
 
-    def __init__(self, comm: "ThreadComm"):
+    def __init__(self, comm: "ThreadComm", with_all_to_all: bool = True):
         self.comm = comm
         hip = _hiprt()
 
@@ -223,8 +223,21 @@ class ThreadNative:
             except Exception:  # noqa: BLE001
                 return 13
 
-        self._cbs = (_lib.ALL_GATHER_CB(all_gather), _lib.ALL_REDUCE_CB(all_reduce_max))  # keep the trampolines alive
-        self.struct = _lib.ShardComm(None, self._cbs[0], self._cbs[1])
+        def all_to_all(_user, d_send, d_recv, nbytes, stream):  # block r of my send -> rank r's recv block `me`
+            try:
+                hip.hipStreamSynchronize(stream)
+                sends = comm._exchange(int(d_send))
+                for r, src in enumerate(sends):
+                    if hip.hipMemcpyAsync(d_recv + r * nbytes, src + comm.rank * nbytes, nbytes, 3, stream):
+                        return 13
+                hip.hipStreamSynchronize(stream)
+                comm._s.barrier.wait()
+                return 0
+            except Exception:  # noqa: BLE001
+                return 13
+
+        self._cbs = (_lib.ALL_GATHER_CB(all_gather), _lib.ALL_REDUCE_CB(all_reduce_max), _lib.ALL_TO_ALL_CB(all_to_all))  # keep the trampolines alive
+        self.struct = _lib.ShardComm(None, self._cbs[0], self._cbs[1], self._cbs[2] if with_all_to_all else _lib.ALL_TO_ALL_CB())
 
 
 class RcclNative:
@@ -427,6 +440,27 @@ class ShardedEngine:
             sh.e._check(rc)
             self.levels_last = int(st.levels)
             return perm[:n], errout[:n], {f: int(getattr(st, f)) for f, _t in _lib.ShardBulkStats._fields_}
+
+    def lookup_ids_batch_native(self, rtype, perm, stype, srel, subject_ids):
+        """LookupResources through acl_shard_lookup_bulk: the whole reverse level loop inside libaclgpu.so.  -> (int32 tensor [n, words], stats)"""
+        sh = self.shard
+        if getattr(self, "_native", None) is None:
+            self._native = RcclNative(sh, self.comm) if isinstance(self.comm, TorchComm) else ThreadNative(self.comm)
+        sids = np.ascontiguousarray(subject_ids, dtype=np.uint32)
+        e = sh.e
+        with sh.stream():
+            words = sh.lookup_words(rtype)
+            bitmaps = torch.zeros((max(1, sids.size), words), dtype=torch.int32, device=sh.device)
+            torch.cuda.current_stream().synchronize()
+            st = _lib.ShardBulkStats()
+            args = (e.type_id(rtype), e.relation_id(rtype, perm), e.type_id(stype), e.relation_id(stype, srel), sids.ctypes.data, sids.size, bitmaps.data_ptr(), words,
+                    C.byref(st))
+            if self._native.struct is None:
+                rc = sh._L.acl_shard_lookup_bulk_rccl(sh._h, *args)
+            else:
+                rc = sh._L.acl_shard_lookup_bulk(sh._h, C.byref(self._native.struct), *args)
+            e._check(rc)
+            return bitmaps[:sids.size], {f: int(getattr(st, f)) for f, _t in _lib.ShardBulkStats._fields_}
 
     def _check_levels(self, items, has, err):
         if self.exchange == "alltoall":

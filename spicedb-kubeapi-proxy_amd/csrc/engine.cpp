@@ -1358,6 +1358,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch

@@ -225,10 +225,12 @@ struct PassCtx {
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
-    DevArray<uint4> d_xsend, d_xrecv;
+    DevArray<uint4> d_xsend, d_xrecv, d_xhsend, d_xhrecv;  // entries (cap per block) and their 16-byte headers
     DevArray<uint32_t> d_xctrl;
     PinnedBuf h_xctrl;
     uint32_t xcap = 0;
+    std::vector<uint8_t> xplan_fwd, xplan_rev;  // [iteration] the previous batch exported something there: exchange entries (empty: always)
+    uint32_t rev_levels_hint = 4;
     uint32_t levels_hint = 6;
     CallOpts opts;  // of the call that holds this context
     // measurement (merged into the engine's stats when the context is released)
@@ -321,6 +323,7 @@ struct acl_engine {
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
     bool rev_rows_device = false;  // k_rev_local's result rows through a device buffer + one DMA copy instead of kernel writes to host memory (A/B)
+    bool shard_a2a = true;  // native sharded Check: per-destination blocks through the communicator's all_to_all when it has one (ACL_SHARD_A2A=0: all-gather)
     bool rev_lds_rows = true;  // k_rev_local keeps the result slot's rows in LDS when they fit (ACL_REV_LDS_ROWS=0: always in HBM; A/B and tests)
     bool rev_local = true;  // LookupResources: the single-launch reverse walk (k_rev_local) first; ACL_REV_LOCAL=0 = always the level loop (A/B)
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests

@@ -27,6 +27,12 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    // (optional: the all-to-all form of the exchange)
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -60,6 +66,11 @@ Rccl *rccl() {
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+        r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
     });
     return &r;
 }
@@ -74,8 +85,128 @@ int rccl_all_reduce_max(void *user, void *buf, size_t n, void *stream) {
     ncclResult_t e = r->AllReduce(buf, buf, n, ncclUint8, ncclMax, (ncclComm_t)user, (hipStream_t)stream);
     return e == ncclSuccess ? ACL_OK : fail(ACL_ERR_INTERNAL, std::string("ncclAllReduce: ") + r->GetErrorString(e));
 }
+// block r of `send` goes to rank r, block r of `recv` comes from rank r: one grouped ncclSend / ncclRecv pair per peer (xGMI is point to point:
+// this IS the native shape of an all-to-all there)
+int rccl_all_to_all(void *user, const void *send, void *recv, size_t bytes, void *stream) {
+    Rccl *r = rccl();
+    if (!r->Send || !r->Recv || !r->GroupStart || !r->GroupEnd || !r->CommCount) return fail(ACL_ERR_UNAVAILABLE, "librccl.so lacks ncclSend / ncclRecv / ncclGroupStart");
+    int world = 0;
+    ncclResult_t e = r->CommCount((ncclComm_t)user, &world);
+    if (e == ncclSuccess) e = r->GroupStart();
+    for (int p = 0; p < world && e == ncclSuccess; p++) {
+        e = r->Send((const char *)send + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)user, (hipStream_t)stream);
+        if (e == ncclSuccess) e = r->Recv((char *)recv + (size_t)p * bytes, bytes, ncclUint8, p, (ncclComm_t)user, (hipStream_t)stream);
+    }
+    if (e == ncclSuccess) e = r->GroupEnd();
+    return e == ncclSuccess ? ACL_OK : fail(ACL_ERR_INTERNAL, std::string("all-to-all (ncclSend / ncclRecv): ") + r->GetErrorString(e));
+}
 
-constexpr uint32_t kCtrlWords = 4;  // per level: total exported, any produced, overflow, largest export
+constexpr uint32_t kCtrlWords = 4;  // per level: total exported, any produced, overflow code, largest block
+
+// One batch's exchange machinery: buffers, the per-level "are entries expected?" plan, the collectives.
+//   headers  ALWAYS travel (16 bytes per peer): they carry the counts, the produced flag and the overflow code, so termination and
+//            retry decisions are taken on the device, identically on every shard;
+//   entries  travel only on levels the PLAN expects to export something.  The plan is the previous batch's record (the proxy's request
+//            streams repeat their shape: pods -> namespaces / groups cross shards on the first levels, nested groups stay on theirs): a
+//            fixed-capacity collective over world x cap entries per level was the price of deciding on the device, and most levels paid
+//            it for nothing.  A level that exports after all raises code 4 in every shard's control record and the batch is redone with
+//            entries on every level.
+struct Exchange {
+    acl_engine *h;
+    PassCtx *c;
+    const acl_shard_comm_t *comm;
+    uint32_t world, rank, cap = 0;
+    bool a2a = false;     // per-destination blocks through comm->all_to_all (Check only); else one block per shard through all_gather
+    acl_shard_bulk_stats_t *st;
+    std::vector<uint8_t> *plan;  // [level] 1 = exchange entries; empty = always
+
+    uint32_t nblk() const { return a2a ? world : 1u; }
+    // c->xcap is what a shard may export per level IN ALL: the all-gather form moves it whole to every shard, the all-to-all form cuts it into
+    // one block per destination -- `world` times fewer bytes on the wire for the same capacity
+    void size_blocks() { cap = a2a ? std::max<uint32_t>(8, c->xcap / world) : c->xcap; }
+    int alloc() {
+        HIP_TRY(c->d_xsend.ensure((size_t)nblk() * cap));
+        HIP_TRY(c->d_xrecv.ensure((size_t)world * cap));
+        HIP_TRY(c->d_xhsend.ensure(std::max<uint32_t>(world, 64)));
+        HIP_TRY(c->d_xhrecv.ensure(std::max<uint32_t>(world, 64)));
+        HIP_TRY(c->d_xctrl.ensure((size_t)kLevelSlots * kCtrlWords));
+        if (!c->h_xctrl.p) HIP_TRY(c->h_xctrl.ensure((size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t)));
+        return ACL_OK;
+    }
+    DevShard shard() const {
+        DevShard sh = dev_shard(h, c, c->d_xsend.p, cap);
+        sh.by_dest = a2a ? 1u : 0u;
+        return sh;
+    }
+    bool wants_data(uint32_t it) const { return plan->empty() || it >= plan->size() || (*plan)[it]; }
+    // after iteration `it` wrote its exports: headers, (entries), import + control record.  `import`: (hdrs, data, have_data, ctrl)
+    template <typename Import>
+    int run(uint32_t it, Import import) {
+        const uint32_t *status = c->d_status.p;
+        launch_xhdr(c->stream, c->d_xhsend.p, nblk(), status + 2 * kLevelSlots + 1, status + kLevelSlots + it, status + 2 * kLevelSlots);
+        int rc = a2a ? comm->all_to_all(comm->user, c->d_xhsend.p, c->d_xhrecv.p, sizeof(uint4), (void *)c->stream)
+                     : comm->all_gather(comm->user, c->d_xhsend.p, c->d_xhrecv.p, sizeof(uint4), (void *)c->stream);
+        if (rc) return rc;
+        const bool data = wants_data(it);
+        if (data) {
+            rc = a2a ? comm->all_to_all(comm->user, c->d_xsend.p, c->d_xrecv.p, (size_t)cap * sizeof(uint4), (void *)c->stream)
+                     : comm->all_gather(comm->user, c->d_xsend.p, c->d_xrecv.p, (size_t)cap * sizeof(uint4), (void *)c->stream);
+            if (rc) return rc;
+            st->exchanged_bytes += (uint64_t)world * cap * sizeof(uint4);
+            st->data_exchanges++;
+        }
+        st->exchanged_bytes += (uint64_t)world * sizeof(uint4);
+        st->exchanges++;
+        import(c->d_xhrecv.p, c->d_xrecv.p, data, c->d_xctrl.p + (size_t)it * kCtrlWords);
+        return ACL_OK;
+    }
+    // reads the control records of iterations [first, last] (step 1 or 2) after a burst; returns 0 = go on, 1 = done at *done_at, 2 = redo
+    int settle(uint32_t first, uint32_t last, uint32_t step, uint32_t *done_at, uint32_t *redo_code, uint32_t *redo_max, std::vector<uint8_t> *seen) {
+        const uint32_t *hc = (const uint32_t *)c->h_xctrl.p;
+        for (uint32_t it = first; it <= last; it += step) {
+            const uint32_t *k = hc + (size_t)it * kCtrlWords;
+            st->entries_exchanged += k[0];
+            if (seen->size() <= it) seen->resize(it + 1, 0);
+            (*seen)[it] = k[0] ? 1 : 0;
+            if (k[2]) {  // some shard overflowed (frontier, export block, a row beyond the enumeration limit) or exported on a level planned without entries
+                *redo_code = (k[2] & 2u) ? 2u : (k[2] & 1u) ? 1u : 4u;
+                *redo_max = std::max(*redo_max, k[3]);
+                return 2;
+            }
+            if (k[0] == 0 && k[1] == 0) {
+                *done_at = it;
+                return 1;
+            }
+        }
+        return 0;
+    }
+    // every shard saw the same control records, so every shard grows the same things and redoes the batch
+    int grow(uint32_t redo_code, uint32_t redo_max, int attempt) {
+        if (redo_code == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+        st->retries++;
+        if (attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "sharded frontier / export capacity exceeded after 8 retries");
+        c->stats.overflow_retries++;
+        if (redo_code == 4) {
+            plan->clear();  // exports where none were expected: entries on every level from now on
+            return ACL_OK;
+        }
+        if (redo_max > cap) {
+            uint32_t nc = cap;
+            while (nc < redo_max + redo_max / 4 && nc < (1u << 27)) nc <<= 1;
+            c->xcap = a2a ? (uint32_t)std::min<uint64_t>((uint64_t)nc * world, 1u << 30) : nc;  // (xcap = entries a shard may export per level in all)
+            return ACL_OK;
+        }
+        return alloc_frontier(h, c, c->frontier_entries * 4);
+    }
+};
+
+uint32_t first_xcap(PassCtx *c) {
+    if (!c->xcap) {
+        const char *e = getenv("ACL_SHARD_XCAP");  // test knob: a tiny first export block forces the grow-and-redo path
+        c->xcap = e && atoi(e) > 0 ? (uint32_t)std::max(8, atoi(e)) : 1u << 16;
+    }
+    return c->xcap;
+}
 
 }  // namespace
 
@@ -90,90 +221,64 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
     int rc = sc.begin(h, true, false);
     if (rc) return rc;
     PassCtx *c = sc.c;
-    const uint32_t world = h->shard.world, rank = h->shard.rank;
     acl_shard_bulk_stats_t st{};
+    Exchange X{h, c, comm, h->shard.world, h->shard.rank, 0, comm->all_to_all != nullptr && h->shard.world <= kMaxShards && h->shard_a2a, &st, &c->xplan_fwd};
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    HIP_TRY(c->d_xctrl.ensure((size_t)kLevelSlots * kCtrlWords));
-    if (!c->h_xctrl.p) HIP_TRY(c->h_xctrl.ensure((size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t)));
-    uint32_t *hc = (uint32_t *)c->h_xctrl.p;
     if ((uint64_t)n > c->frontier_entries) {
         rc = alloc_frontier(h, c, (uint64_t)n * 4);
         if (rc) return rc;
     }
-    if (!c->xcap) {
-        const char *e = getenv("ACL_SHARD_XCAP");  // test knob: a tiny first export block forces the grow-and-redo path
-        c->xcap = e && atoi(e) > 0 ? (uint32_t)std::max(8, atoi(e)) : 1u << 16;
-    }
+    first_xcap(c);
+    std::vector<uint8_t> seen;
     for (int attempt = 0;; attempt++) {
-        const uint32_t cap = c->xcap;
-        HIP_TRY(c->d_xsend.ensure((size_t)cap + 1));
-        HIP_TRY(c->d_xrecv.ensure((size_t)world * ((size_t)cap + 1)));
+        X.size_blocks();
+        rc = X.alloc();
+        if (rc) return rc;
+        uint32_t *hc = (uint32_t *)c->h_xctrl.p;
         DevGraph g = h->dev_graph();
         DevFrontier f = h->dev_frontier(*c);
-        DevShard sh = dev_shard(h, c, c->d_xsend.p + 1, cap);
+        DevShard sh = X.shard();
         HIP_TRY(hipMemsetAsync(c->d_xctrl.p, 0, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), c->stream));
         ev_begin(c, 0);
         launch_seed(c->stream, g, f, (const uint4 *)d_items, (uint32_t)n, c->d_has.p, c->d_err.p, sh);  // also resets the status block
         ev_end(c);
-        uint32_t next = 1, burst = std::max<uint32_t>(c->levels_hint, 2), done_at = 0;
-        bool redo = false;
-        uint32_t redo_max = 0, redo_code = 0;
-        while (!done_at && !redo) {
+        uint32_t next = 1, burst = std::max<uint32_t>(c->levels_hint, 2), done_at = 0, redo_max = 0, redo_code = 0;
+        int verdict = 0;
+        seen.clear();
+        while (!verdict) {
             const uint32_t last = std::min<uint32_t>(kMaxLevels, next + burst - 1);
             for (uint32_t it = next; it <= last; it++) {
-                HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, (1 + kMaxShards) * sizeof(uint32_t), c->stream));
                 ev_begin(c, 1);
                 launch_expand(c->stream, g, f, it, c->d_has.p, c->d_err.p, sh);
                 ev_end(c);
-                launch_xhdr(c->stream, c->d_xsend.p, c->d_status.p + 2 * kLevelSlots + 1, c->d_status.p + kLevelSlots + it, c->d_status.p + 2 * kLevelSlots, it);
-                rc = comm->all_gather(comm->user, c->d_xsend.p, c->d_xrecv.p, ((size_t)cap + 1) * sizeof(uint4), (void *)c->stream);
+                rc = X.run(it, [&](const uint4 *hdrs, const uint4 *data, bool have, uint32_t *ctrl) {
+                    launch_import_gathered(c->stream, g, f, it, hdrs, data, X.world, X.rank, X.cap, have, ctrl);
+                });
                 if (rc) return rc;
-                launch_import_gathered(c->stream, g, f, it, c->d_xrecv.p, world, rank, cap, c->d_xctrl.p + (size_t)it * kCtrlWords);
                 c->stats.expand_launches++;
-                st.exchanges++;
-                st.exchanged_bytes += (uint64_t)world * ((uint64_t)cap + 1) * sizeof(uint4);
             }
             HIP_TRY(hipMemcpyAsync(hc, c->d_xctrl.p, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             ev_collect(c);
             st.host_syncs++;
-            for (uint32_t it = next; it <= last; it++) {
-                const uint32_t *k = hc + (size_t)it * kCtrlWords;
-                st.entries_exchanged += k[0];
-                if (k[2]) {  // some shard overflowed (its frontier, its export block, or a row beyond the enumeration limit)
-                    redo = true;
-                    redo_code = k[2] == 2 ? 2 : 1;
-                    redo_max = std::max(redo_max, k[3]);
-                    break;
-                }
-                if (k[0] == 0 && k[1] == 0) {
-                    done_at = it;
-                    break;
-                }
+            verdict = X.settle(next, last, 1, &done_at, &redo_code, &redo_max, &seen);
+            if (!verdict && last == kMaxLevels) {
+                done_at = kMaxLevels;
+                verdict = 1;
             }
-            if (!done_at && !redo && last == kMaxLevels) done_at = kMaxLevels;
             next = last + 1;
             burst = 4;
         }
-        if (redo) {
-            if (redo_code == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
-            // every shard saw the same control records, so every shard grows the same things and redoes the batch
-            st.retries++;
-            if (attempt > 8) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "sharded frontier / export capacity exceeded after 8 retries");
-            if (redo_max > cap) {
-                uint32_t nc = cap;
-                while (nc < redo_max + redo_max / 4 && nc < (1u << 27)) nc <<= 1;
-                c->xcap = nc;
-            } else {
-                rc = alloc_frontier(h, c, c->frontier_entries * 4);
-                if (rc) return rc;
-            }
-            c->stats.overflow_retries++;
+        if (verdict == 2) {
+            rc = X.grow(redo_code, redo_max, attempt);
+            if (rc) return rc;
             continue;
         }
         c->levels_hint = done_at;
         st.levels = done_at;
+        c->xplan_fwd = seen;  // the next batch exchanges entries where this one exported some (levels beyond: always)
         break;
     }
     // HAS beats error beats NO: a byte-wise max across shards, then the answers on every shard
@@ -189,9 +294,123 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     st.host_syncs++;
-    st.export_capacity = c->xcap;
+    st.export_capacity = X.cap;
     c->stats.check_items += n;
     c->stats.check_passes++;
+    c->stats.levels_last = st.levels;
+    if (stats_out) *stats_out = st;
+    return ACL_OK;
+}
+
+// LookupResources (pkg/authz/lookups.go:49-83) for n subjects of one class on the sharded graph, the whole reverse level loop inside the
+// library.  Iteration 1 expands the seeds; then pairs (VISIT: first visits marked, states whose parents' rows also live on other shards
+// exported -> exchange -> import of the foreign states this shard holds parent rows for | EXPAND) until a visit step neither produced nor
+// exported anything on any shard.  A visited state goes to every shard that may hold parent rows for it: always the all-gather form.
+// d_bitmaps_out: n rows of bitmap_words words on the device, the same on every shard afterwards (the rows exist on the resource type's owner
+// only; a byte-wise max hands them to everybody).
+int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n,
+                          void *d_bitmaps_out, size_t bitmap_words, acl_shard_bulk_stats_t *stats_out) {
+    if (!comm || !comm->all_gather || !comm->all_reduce_max_u8) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_bulk: communicator callbacks missing");
+    if (n && (!sids || !d_bitmaps_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_bulk: NULL buffer");
+    ShardCall scall;
+    int rc = scall.begin(h, true, true);
+    if (rc) return rc;
+    PassCtx *c = scall.c;
+    const Schema &sc = h->store.schema();
+    if (rtype < 0 || rtype >= (int)sc.defs.size() || stype < 0 || stype >= (int)sc.defs.size() || perm < 0 || perm >= (int)sc.defs[rtype].members.size() ||
+        srel >= (int)sc.defs[stype].members.size())
+        return fail(ACL_ERR_FAILED_PRECONDITION, "lookup: unknown type, permission or subject relation");
+    const uint32_t target = (uint32_t)sc.slot(rtype, perm);
+    const uint32_t key = sc.subject_key(stype, srel < 0 ? kNoRelation : srel);
+    const size_t need = ((size_t)h->store.objects(rtype).count() + 31) / 32;
+    if (n && bitmap_words < need) return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
+    const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
+    if (n * vwords > ((size_t)1 << 30)) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "lookup batch too large for one pass (visited bitmaps > 4 GiB)");
+    acl_shard_bulk_stats_t st{};
+    Exchange X{h, c, comm, h->shard.world, h->shard.rank, 0, false, &st, &c->xplan_rev};
+    if (n > c->frontier_entries) {
+        rc = alloc_frontier(h, c, n * 4);
+        if (rc) return rc;
+    }
+    HIP_TRY(c->d_visited.ensure(std::max<size_t>(n, 1) * vwords));
+    HIP_TRY(c->d_sids.ensure(std::max<size_t>(n, 1)));
+    HIP_TRY(c->h_in.ensure(std::max<size_t>(n, 1) * sizeof(uint32_t)));
+    if (n) std::memcpy(c->h_in.p, sids, n * sizeof(uint32_t));
+    HIP_TRY(hipMemcpyAsync(c->d_sids.p, c->h_in.p, std::max<size_t>(n, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    first_xcap(c);
+    std::vector<uint8_t> seen;
+    constexpr uint32_t kMaxIter = 2 * (kMaxLevels + 1);  // (iteration slots: kLevelSlots = 128)
+    for (int attempt = 0;; attempt++) {
+        X.size_blocks();
+        rc = X.alloc();
+        if (rc) return rc;
+        uint32_t *hc = (uint32_t *)c->h_xctrl.p;
+        DevFrontier f = h->dev_frontier(*c);
+        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords};
+        DevShard sh = X.shard();
+        HIP_TRY(hipMemsetAsync(c->d_xctrl.p, 0, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_visited.p, 0, std::max<size_t>(n, 1) * vwords * 4, c->stream));
+        launch_rev_seed(c->stream, f, c->d_sids.p, (uint32_t)n, key);  // seeds + status block
+        ev_begin(c, 1);
+        launch_rev_expand(c->stream, r, f, 1, REV_EXPAND, sh);  // iteration 1: the seeds
+        ev_end(c);
+        c->stats.expand_launches++;
+        uint32_t next = 2, pairs = std::max<uint32_t>(c->rev_levels_hint, 2), done_at = 0, redo_max = 0, redo_code = 0;
+        int verdict = 0;
+        seen.clear();
+        while (!verdict) {
+            const uint32_t last = std::min<uint32_t>(kMaxIter, next + 2 * pairs - 2);  // VISIT iterations next, next + 2, ..., last
+            for (uint32_t it = next; it <= last; it += 2) {
+                HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), c->stream));
+                ev_begin(c, 1);
+                launch_rev_expand(c->stream, r, f, it, REV_VISIT, sh);
+                ev_end(c);
+                rc = X.run(it, [&](const uint4 *hdrs, const uint4 *data, bool have, uint32_t *ctrl) {
+                    launch_rev_import_gathered(c->stream, r, f, it, hdrs, data, X.world, X.rank, X.cap, have, ctrl);
+                });
+                if (rc) return rc;
+                ev_begin(c, 1);
+                launch_rev_expand(c->stream, r, f, it + 1, REV_EXPAND, sh);
+                ev_end(c);
+                c->stats.expand_launches += 2;
+            }
+            HIP_TRY(hipMemcpyAsync(hc, c->d_xctrl.p, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            ev_collect(c);
+            st.host_syncs++;
+            verdict = X.settle(next, last, 2, &done_at, &redo_code, &redo_max, &seen);
+            if (!verdict && last >= kMaxIter) {
+                done_at = kMaxIter;
+                verdict = 1;
+            }
+            next = last + 2;
+            pairs = 3;
+        }
+        if (verdict == 2) {
+            rc = X.grow(redo_code, redo_max, attempt);
+            if (rc) return rc;
+            continue;
+        }
+        c->rev_levels_hint = std::max<uint32_t>(1, done_at / 2);
+        st.levels = done_at / 2;
+        c->xplan_rev = seen;
+        break;
+    }
+    // result rows: the resource type's owner holds them; everybody else contributes zeros to a byte-wise max
+    if (n) {
+        const size_t woff = h->snap.slot_bit_base[target] / 32;
+        const size_t cw = std::min(need, ((size_t)h->snap.slot_nobjects[target] + 31) / 32);  // only the ids the snapshot's slot covers can be marked
+        HIP_TRY(hipMemsetAsync(d_bitmaps_out, 0, n * bitmap_words * 4, c->stream));
+        if (cw && shard_of_type(sc.defs[rtype].name, h->shard.world) == h->shard.rank)
+            HIP_TRY(hipMemcpy2DAsync(d_bitmaps_out, bitmap_words * 4, c->d_visited.p + woff, vwords * 4, cw * 4, n, hipMemcpyDeviceToDevice, c->stream));
+        rc = comm->all_reduce_max_u8(comm->user, d_bitmaps_out, n * bitmap_words * 4, (void *)c->stream);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ev_collect(c);
+    st.host_syncs++;
+    st.export_capacity = c->xcap;
+    c->stats.lookup_requests += n;
     c->stats.levels_last = st.levels;
     if (stats_out) *stats_out = st;
     return ACL_OK;
@@ -243,8 +462,15 @@ int acl_shard_rccl_destroy(acl_engine_t *h) {
 
 int acl_shard_check_bulk_rccl(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out, acl_shard_bulk_stats_t *stats_out) {
     if (!h->rccl_comm) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_check_bulk_rccl without acl_shard_rccl_init");
-    acl_shard_comm_t comm{h->rccl_comm, rccl_all_gather, rccl_all_reduce_max};
+    acl_shard_comm_t comm{h->rccl_comm, rccl_all_gather, rccl_all_reduce_max, rccl_all_to_all};
     return acl_shard_check_bulk(h, &comm, d_items, n, d_perm_out, d_err_out, stats_out);
+}
+
+int acl_shard_lookup_bulk_rccl(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, void *d_bitmaps_out, size_t bitmap_words,
+                               acl_shard_bulk_stats_t *stats_out) {
+    if (!h->rccl_comm) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_bulk_rccl without acl_shard_rccl_init");
+    acl_shard_comm_t comm{h->rccl_comm, rccl_all_gather, rccl_all_reduce_max, rccl_all_to_all};
+    return acl_shard_lookup_bulk(h, &comm, rtype, perm, stype, srel, sids, n, d_bitmaps_out, bitmap_words, stats_out);
 }
 
 }  // extern "C"

@@ -547,7 +547,7 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(sh.exp_count + 1 + d, (uint32_t)__popcll(m));
         const uint32_t at = uniform(base) + lanes_below(m);
-        if (mine && at < sh.cap) sh.exp[(size_t)d * sh.cap + at] = e;
+        if (mine && at < sh.cap) sh.exp[(size_t)d * (sh.stride ? sh.stride : sh.cap) + at] = e;
     }
 }
 
@@ -1682,30 +1682,49 @@ __global__ __launch_bounds__(256) void k_import(DevFrontier f, uint32_t iter, co
 }
 
 // ---------------------------------------------------------------- native sharded loop (engine_shard_native.cpp)
-// One exchange block per shard and level: [header][cap entries].  header = {entries exported (may exceed cap: the surplus was
-// dropped), this shard's any[iter] before imports, its overflow code, level}.  Written on the device, so the host never
-// waits between levels.
-__global__ __launch_bounds__(64) void k_xhdr(uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level) {
-    if (threadIdx.x == 0) *hdr = make_uint4(*exp_count, *any_iter, *overflow, level);
+// Exchange blocks, one per (shard, level) in the all-gather form and one per (shard, destination, level) in the all-to-all form: a 16-byte
+// HEADER and up to `cap` entries.  header = {x: entries in this block, y: this shard produced local work | overflow code << 1,
+// z: the largest block this shard filled this level, w: entries this shard exported this level in all}.  Written on the device, so the host
+// never waits between levels; headers and entries travel in separate collectives (the entries' one is skipped on levels that are known
+// to export nothing).  exp_count = [0] all-gather form; [1 + d] per destination.
+__global__ __launch_bounds__(64) void k_xhdr(uint4 *hdr, uint32_t nblocks, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow) {
+    const uint32_t d = threadIdx.x;
+    if (d >= nblocks) return;
+    const uint32_t flags = (*any_iter ? 1u : 0u) | (*overflow << 1);
+    if (nblocks == 1) {
+        const uint32_t c = exp_count[0];
+        hdr[0] = make_uint4(c, flags, c, c);
+        return;
+    }
+    uint32_t mx = 0, tot = 0;
+    for (uint32_t k = 0; k < nblocks; k++) {
+        const uint32_t c = exp_count[1 + k];
+        mx = max(mx, c);
+        tot += c;
+    }
+    hdr[d] = make_uint4(exp_count[1 + d], flags, mx, tot);
 }
 
-// After the all-gather: blockIdx.y = source shard.  Rows of other shards import the entries this shard owns (as k_import
-// does, the count read from the gathered header); the own row's first wave folds all headers into the level's control
-// record {total exported, any shard produced, any overflow, largest export} -- identical on every shard, so all of them take
-// the same decisions (done / redo) without talking to each other or to the host.
-__global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t iter, const uint4 *__restrict__ recv, uint32_t world, uint32_t rank,
-                                                         uint32_t cap, const SlotProg *progs, uint32_t *ctrl) {
+// After the exchange: blockIdx.y = source shard.  Rows of other shards import what they sent (FWD: the entries whose slot this shard owns;
+// reverse: foreign states for which this shard holds parent rows), the count read from the source's header; the own row's first wave folds all
+// headers into the level's control record {total exported, any shard produced, overflow code, largest block} -- identical on every shard, so
+// all of them take the same decisions (done / redo) without talking to each other or to the host.  have_data == 0: the entries were not
+// exchanged this level (planned: nothing was expected); headers that announce entries then raise overflow code 4 = "redo with the data".
+template <bool FWD>
+__global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t iter, const uint4 *__restrict__ hdrs, const uint4 *__restrict__ data, uint32_t world,
+                                                         uint32_t rank, uint32_t cap, uint32_t have_data, const SlotProg *progs, const RevProg *rprogs,
+                                                         uint32_t *ctrl) {
     const uint32_t lane = lane_id();
     const uint32_t src = blockIdx.y;
     if (src == rank) {
         if (blockIdx.x == 0 && threadIdx.x < 64) {
             uint32_t total = 0, anyp = 0, over = 0, mx = 0;
             for (uint32_t r = lane; r < world; r += 64) {
-                const uint4 h = recv[(size_t)r * (cap + 1)];
-                total += h.x;
-                anyp |= h.y;
-                over |= h.z | (h.x > cap ? 1u : 0u);
-                mx = max(mx, h.x);
+                const uint4 h = hdrs[r];
+                total += h.w;
+                anyp |= h.y & 1u;
+                over |= (h.y >> 1) | (h.z > cap ? 1u : 0u) | ((!have_data && h.w) ? 4u : 0u);  // (h.w, every shard's own included: the same verdict on every shard)
+                mx = max(mx, h.z);
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
@@ -1723,8 +1742,9 @@ __global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t
         }
         return;
     }
-    const uint4 *__restrict__ in = recv + (size_t)src * (cap + 1) + 1;
-    const uint32_t n = min(recv[(size_t)src * (cap + 1)].x, cap);
+    if (!have_data) return;
+    const uint4 *__restrict__ in = data + (size_t)src * cap;
+    const uint32_t n = min(hdrs[src].x, cap);
     const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     uint4 *__restrict__ out = f.buf[iter & 1u];
     uint32_t *out_counts = f.counts[iter & 1u];
@@ -1734,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_import_gathered(DevFrontier f, uint32_t
         const uint32_t i = x * 64 + lane;
         const uint4 e = i < n ? in[i] : make_uint4(0, 0, kDeadMeta, 0);
         bool mine = i < n && e.z != kDeadMeta;
-        if (mine) mine = progs[meta_slot(e.z)].owner == rank;
+        if (mine) mine = FWD ? progs[meta_slot(e.z)].owner == rank : (rprogs[e.z & 0x1FFFu].n & ~kRevRemoteBit) != 0;
         const uint64_t b = __ballot(mine);
         if (!b) continue;
         const uint32_t need = (uint32_t)__popcll(b);
@@ -1885,13 +1905,18 @@ void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
     if (!n) return;
     hipLaunchKernelGGL(k_import<true>, dim3(import_blocks(n)), dim3(256), 0, s, f, iter, in, n, g.progs, (const RevProg *)nullptr, sh.rank);
 }
-void launch_xhdr(hipStream_t s, uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level) {
-    hipLaunchKernelGGL(k_xhdr, dim3(1), dim3(64), 0, s, hdr, exp_count, any_iter, overflow, level);
+void launch_xhdr(hipStream_t s, uint4 *hdr, uint32_t nblocks, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow) {
+    hipLaunchKernelGGL(k_xhdr, dim3(1), dim3(64), 0, s, hdr, nblocks, exp_count, any_iter, overflow);
 }
-void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *recv, uint32_t world, uint32_t rank, uint32_t cap,
-                            uint32_t *ctrl) {
-    const uint32_t bx = std::max<uint32_t>(1, std::min<uint32_t>(64, (cap + 4095) / 4096));
-    hipLaunchKernelGGL(k_import_gathered, dim3(bx, world), dim3(256), 0, s, f, iter, recv, world, rank, cap, g.progs, ctrl);
+void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *hdrs, const uint4 *data, uint32_t world, uint32_t rank,
+                            uint32_t cap, bool have_data, uint32_t *ctrl) {
+    const uint32_t bx = have_data ? std::max<uint32_t>(1, std::min<uint32_t>(64, (cap + 4095) / 4096)) : 1u;
+    hipLaunchKernelGGL(k_import_gathered<true>, dim3(bx, world), dim3(256), 0, s, f, iter, hdrs, data, world, rank, cap, have_data ? 1u : 0u, g.progs, (const RevProg *)nullptr, ctrl);
+}
+void launch_rev_import_gathered(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *hdrs, const uint4 *data, uint32_t world, uint32_t rank,
+                                uint32_t cap, bool have_data, uint32_t *ctrl) {
+    const uint32_t bx = have_data ? std::max<uint32_t>(1, std::min<uint32_t>(64, (cap + 4095) / 4096)) : 1u;
+    hipLaunchKernelGGL(k_import_gathered<false>, dim3(bx, world), dim3(256), 0, s, f, iter, hdrs, data, world, rank, cap, have_data ? 1u : 0u, (const SlotProg *)nullptr, r.rprogs, ctrl);
 }
 void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n) {
     if (!n) return;

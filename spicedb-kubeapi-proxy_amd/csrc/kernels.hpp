@@ -67,6 +67,7 @@ struct DevShard {
     uint32_t cap = 0;
     uint32_t rank = 0;
     uint32_t world = 1;
+    uint32_t stride = 0;             // by_dest: entries between two destinations' buffers (0 = cap: the buffers are contiguous)
 };
 // reverse-walk entry flags (meta = slot[0:13) | dist[13:19) | flags)
 constexpr uint32_t kRevForeign = 1u << 19;  // state visited on its owner shard: expand it here, do not touch `visited`
@@ -80,10 +81,14 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 // appends the entries of `in` (an all-gathered export buffer) whose slot this shard owns to the frontier that
 // iteration `iter` produced
 void launch_import(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n, const DevShard &sh);
-// native sharded loop: exchange-block header written on the device; import of an all-gathered set of blocks + the level's control record
-void launch_xhdr(hipStream_t s, uint4 *hdr, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow, uint32_t level);
-void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *recv, uint32_t world, uint32_t rank, uint32_t cap,
-                            uint32_t *ctrl);
+// native sharded loop: exchange-block headers written on the device (nblocks = 1: all-gather form, exp_count[0]; = world: one per destination,
+// exp_count[1 + d]); import of the exchanged blocks + the level's control record {total exported, any produced, overflow code, largest block}.
+// hdrs: `world` headers (one per source), data: `world` blocks of `cap` entries; have_data false: the entries were not exchanged this level
+void launch_xhdr(hipStream_t s, uint4 *hdr, uint32_t nblocks, const uint32_t *exp_count, const uint32_t *any_iter, const uint32_t *overflow);
+void launch_import_gathered(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, const uint4 *hdrs, const uint4 *data, uint32_t world, uint32_t rank,
+                            uint32_t cap, bool have_data, uint32_t *ctrl);
+void launch_rev_import_gathered(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *hdrs, const uint4 *data, uint32_t world, uint32_t rank,
+                                uint32_t cap, bool have_data, uint32_t *ctrl);
 void launch_rev_import(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, const uint4 *in, uint32_t n);
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key);
 void launch_keep(hipStream_t s, uint32_t k_items, const uint32_t *item_off, const uint8_t *perm, uint8_t *keep_out);
