@@ -234,6 +234,17 @@ int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t 
  * "items" array, or with an empty one, comes back unchanged (postfilter.go:26-35).  Invalid JSON: ACL_ERR_INVALID_ARGUMENT. */
 int acl_filter_list_response(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates,
                              const char *user_name, char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out);
+/* ... with the kube request the list answers: every item's placeholders are resolved as rules.NewResolveInput does (pkg/rules/rules.go:315-342) --
+ * the item's own metadata.name / metadata.namespace first, the request's where the item has none, and no namespace at all when the request's
+ * resource is `namespaces`.  NULL req (or NULL members) = the item's metadata only. */
+typedef struct {
+    const char *name;       /* RequestInfo.Name */
+    const char *namespace_; /* RequestInfo.Namespace */
+    const char *resource;   /* RequestInfo.Resource, e.g. "pods", "namespaces" */
+} acl_list_request_t;
+int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates,
+                                 const char *user_name, const acl_list_request_t *req, char **out_body, size_t *out_len, uint64_t *kept_out,
+                                 uint64_t *total_out);
 /* PreFilter: prefilterResult.IsAllowed (lookups.go:25-36; consumers responsefilterer.go:349-415) over the bitmap of
  * acl_lookup_resources*: allowed_out[i] = 1 iff object_ids[i] (the rule's `ns/name` object id text) is set. */
 int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *const *object_ids, size_t n,

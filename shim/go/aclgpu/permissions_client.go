@@ -347,8 +347,16 @@ func callOpts(ctx context.Context) (*C.acl_call_opts_t, func()) {
 // deploy/rules.yaml:68): one scan of the body, one device pass for all K x F pairs, the original bytes with the dropped
 // items cut out.  Rules that need the full Bloblang / CEL environment keep resolving in Go and call KeepMask.
 func (e *Engine) FilterListResponse(body []byte, templates []string, userName string) ([]byte, error) {
+	return e.FilterListResponseReq(body, templates, userName, "", "", "")
+}
+
+// FilterListResponseReq also hands over the kube request the list answers (input.Request: RequestInfo.Name / .Namespace / .Resource), so that
+// every item's placeholders resolve as rules.NewResolveInput resolves them (pkg/rules/rules.go:315-342): the item's own metadata first, the
+// request's name / namespace where the item has none, and no namespace for the `namespaces` resource.
+func (e *Engine) FilterListResponseReq(body []byte, templates []string, userName, reqName, reqNamespace, reqResource string) ([]byte, error) {
 	if len(body) == 0 {
-		return body, nil
+		// the reference fails to parse an empty body (postfilter.go:21-24): so does the engine -- let it say so
+		body = []byte{}
 	}
 	var cs cstrings
 	defer cs.free()
@@ -356,10 +364,18 @@ func (e *Engine) FilterListResponse(body []byte, templates []string, userName st
 	for i, t := range templates {
 		tp[i] = cs.add(t)
 	}
+	req := (*C.acl_list_request_t)(C.calloc(1, C.size_t(unsafe.Sizeof(C.acl_list_request_t{}))))
+	defer C.free(unsafe.Pointer(req))
+	req.name, req.namespace_, req.resource = cs.add(reqName), cs.add(reqNamespace), cs.add(reqResource)
+	var bp *C.char
+	if len(body) > 0 {
+		bp = (*C.char)(unsafe.Pointer(&body[0]))
+	} else {
+		bp = cs.add("")
+	}
 	var out *C.char
 	var n C.size_t
-	if rc := C.acl_filter_list_response(e.h, (*C.char)(unsafe.Pointer(&body[0])), C.size_t(len(body)), &tp[0], C.size_t(len(templates)), cs.add(userName),
-		&out, &n, nil, nil); rc != 0 {
+	if rc := C.acl_filter_list_response_req(e.h, bp, C.size_t(len(body)), &tp[0], C.size_t(len(templates)), cs.add(userName), req, &out, &n, nil, nil); rc != 0 {
 		return nil, lastError(rc)
 	}
 	defer C.acl_free(unsafe.Pointer(out))

@@ -25,7 +25,7 @@ SYMBOLS = [
     "acl_batcher_start", "acl_batcher_stop", "acl_batcher_stats", "acl_check_one", "acl_lookup_one", "acl_batcher_lookup_stats",
     "acl_selfcheck_snapshot",
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
-    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
+    "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions",
 ]
@@ -61,6 +61,11 @@ class CheckItem(C.Structure):
 class Completion(C.Structure):
     """acl_completion_t: one answered acl_check_one_submit."""
     _fields_ = [("tag", C.c_uint64), ("rc", C.c_int32), ("err", C.c_int32), ("perm", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class ListRequest(C.Structure):
+    """acl_list_request_t: the kube request a list response answers (RequestInfo.Name / .Namespace / .Resource)."""
+    _fields_ = [("name", C.c_char_p), ("namespace_", C.c_char_p), ("resource", C.c_char_p)]
 
 
 class LookupCompletion(C.Structure):
@@ -181,6 +186,8 @@ def load():
     L.acl_host_free.argtypes = [H, C.c_void_p]
     L.acl_lookup_resources_alloc.argtypes = [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(CallOpts),
                                              C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    L.acl_filter_list_response_req.argtypes = [H, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.POINTER(ListRequest), C.POINTER(C.c_void_p),
+                                               C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_filter_list_response.argtypes = [H, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_free.argtypes = [C.c_void_p]

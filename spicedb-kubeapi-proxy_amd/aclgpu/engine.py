@@ -349,12 +349,19 @@ class Engine:
     def check_bulk_keep_ids_device(self, d_items: int, n: int, d_item_off: int, k_items: int, d_keep: int):
         self._check(self._L.acl_check_bulk_keep_ids_device(self._h, d_items, n, d_item_off, k_items, d_keep))
 
-    def filter_list_response(self, body: bytes, templates, user_name: str):
-        """filterListResponse (postfilter.go:17-55) on the list response's bytes -> (filtered body, kept, total)."""
+    def filter_list_response(self, body: bytes, templates, user_name: str, request=None):
+        """filterListResponse (postfilter.go:17-55) on the list response's bytes -> (filtered body, kept, total).
+        request = (name, namespace, resource) of the kube request (rules.NewResolveInput's fallbacks, rules.go:315-342), or None."""
+        from ._lib import ListRequest
         arr = (C.c_char_p * max(1, len(templates)))(*[_b(t) for t in templates])
         out, n, kept, total = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint64()
-        self._check(self._L.acl_filter_list_response(self._h, body, len(body), arr, len(templates), _b(user_name), C.byref(out), C.byref(n),
-                                                     C.byref(kept), C.byref(total)))
+        if request is not None:
+            rq = ListRequest(_b(request[0] or ""), _b(request[1] or ""), _b(request[2] or ""))
+            self._check(self._L.acl_filter_list_response_req(self._h, body, len(body), arr, len(templates), _b(user_name), C.byref(rq), C.byref(out), C.byref(n),
+                                                             C.byref(kept), C.byref(total)))
+        else:
+            self._check(self._L.acl_filter_list_response(self._h, body, len(body), arr, len(templates), _b(user_name), C.byref(out), C.byref(n),
+                                                         C.byref(kept), C.byref(total)))
         try:
             return C.string_at(out, n.value), kept.value, total.value
         finally:

@@ -13,6 +13,7 @@
 namespace aclint {
 
 thread_local std::string g_last_error;
+thread_local int g_last_detail = 0;
 
 int64_t mono_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1181,7 +1182,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
     const uint32_t key = sc.subject_key(stype, srel < 0 ? kNoRelation : srel);
     const uint32_t nobj = h->store.objects(rtype).count();
     const size_t need = (nobj + 31) / 32;
-    if (words < need) return fail(ACL_ERR_INVALID_ARGUMENT, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
+    if (words < need) return fail_detail(ACL_ERR_INVALID_ARGUMENT, kDetailBitmapTooSmall, "lookup: bitmap too small (" + std::to_string(need) + " words needed)");
     // the walk can only mark the ids the snapshot's bitmap slot covers (the build-time count plus headroom); ids interned
     // since then have no relationship in this snapshot, so their bits are zero -- never copy past the slot (advice r1)
     const size_t slot_words = ((size_t)h->snap.slot_nobjects[target] + 31) / 32;
@@ -1410,6 +1411,7 @@ int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, c
     std::lock_guard<RwLock> lk(h->state_mu);
     std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     if (!schema) return fail(ACL_ERR_INVALID_ARGUMENT, "schema is NULL");
+    compaction_join(h);  // a background build of the OLD schema's graph: wait for it and drop it (its ids mean nothing from here on)
     Status s = h->store.load_schema(std::string(schema, schema_len));
     if (!s.ok()) return fail(s);
     h->snap_valid = false;
@@ -1630,7 +1632,7 @@ int acl_lookup_resources_alloc(acl_engine_t *h, const char *rtype, const char *p
             return ACL_OK;
         }
         std::free(bm);
-        if (rc != ACL_ERR_INVALID_ARGUMENT || std::string(acl_last_error()).find("bitmap too small") == std::string::npos) return rc;
+        if (rc != ACL_ERR_INVALID_ARGUMENT || g_last_detail != kDetailBitmapTooSmall) return rc;  // (a typed detail, not the message's wording: ADVICE r2)
     }
     return fail(ACL_ERR_UNAVAILABLE, "lookup: the object table kept growing faster than the result bitmap");
 }

@@ -43,6 +43,7 @@ struct LookupReq {
     std::string msg;
     std::vector<uint32_t> bitmap;
     uint64_t count = 0;
+    int detail = 0;  // g_last_detail of the failed walk (travels with rc / msg to the caller's thread)
     // acl_lookup_one_submit: nobody sleeps on it, the answer (an engine-allocated row) goes to the lookup completion queue
     bool async = false;
     uint64_t tag = 0;
@@ -185,7 +186,7 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
             cnts.assign(m, 0);
             for (size_t i = 0; i < m; i++) sids[i] = lks[g0 + i]->sid;
             int lrc = acl_lookup_resources_batch(h, lks[g0]->rtype, lks[g0]->perm, lks[g0]->stype, lks[g0]->srel, sids.data(), m, bms.data(), std::max<size_t>(words, 1), cnts.data());
-            if (lrc == ACL_ERR_INVALID_ARGUMENT && !lks[g0]->words) {  // objects were created between the sizing and the walk: once more with the new size
+            if (lrc == ACL_ERR_INVALID_ARGUMENT && g_last_detail == kDetailBitmapTooSmall && !lks[g0]->words) {  // objects were created between the sizing and the walk: once more with the new size
                 {
                     std::shared_lock<RwLock> slk(h->state_mu);
                     words = ((size_t)h->store.objects(lks[g0]->rtype).count() + 31) / 32;
@@ -194,11 +195,13 @@ void answer(acl_engine_t *h, std::vector<Batch *> &subs) {
                 lrc = acl_lookup_resources_batch(h, lks[g0]->rtype, lks[g0]->perm, lks[g0]->stype, lks[g0]->srel, sids.data(), m, bms.data(), std::max<size_t>(words, 1), cnts.data());
             }
             const std::string lmsg = lrc ? acl_last_error() : "";
+            const int ldetail = lrc ? g_last_detail : 0;
             size_t nasync = 0;
             for (size_t i = 0; i < m; i++) {
                 LookupReq *w = lks[g0 + i];
                 w->rc = lrc;
                 w->msg = lmsg;
+                w->detail = ldetail;
                 nasync += w->async;
                 if (!lrc && !w->async) {
                     w->bitmap.assign(bms.begin() + (long)(i * words), bms.begin() + (long)((i + 1) * words));
@@ -415,14 +418,14 @@ void batcher_destroy(acl_engine_t *h) {
 // one LookupResources with interned arguments: rides the micro-batcher when it runs, else a walk of its own
 int lookup_one_routed(acl_engine_t *h, int rt, int pm, int st, int sr, uint32_t sub, uint32_t *bitmap_out, size_t words, uint64_t *count_out,
                       const CallOpts &opts) {
-    LookupReq lk{rt, pm, st, sr, sub, words, 0, std::string(), std::vector<uint32_t>(), 0};
+    LookupReq lk{rt, pm, st, sr, sub, words, 0, std::string(), std::vector<uint32_t>(), 0, 0};
     size_t idx = 0;
     Batch *b = enqueue(h, nullptr, &lk, &idx);
     if (!b) return lookup_batch_call(h, rt, pm, st, sr, &sub, 1, bitmap_out, words, count_out, opts);
     int rc = await_batch(h, b, opts);
     if (rc == ACL_OK) {
         LookupReq &r = b->lookups[idx];
-        if (r.rc) rc = fail(r.rc, r.msg);
+        if (r.rc) rc = fail_detail(r.rc, r.detail, r.msg);
         else {
             if (words) std::memcpy(bitmap_out, r.bitmap.data(), words * sizeof(uint32_t));
             if (count_out) *count_out = r.count;
@@ -798,7 +801,7 @@ int acl_lookup_one_submit(acl_engine_t *h, const char *rtype, const char *perm, 
     uint32_t sub;
     int rc = resolve_lookup(h, rtype, perm, stype, sid, srel, &rt, &pm, &st, &sr, &sub);
     if (rc) return rc;  // (a malformed request is the caller's error, reported here and not through the queue)
-    LookupReq lk{rt, pm, st, sr, sub, 0, 0, std::string(), std::vector<uint32_t>(), 0, true, tag};
+    LookupReq lk{rt, pm, st, sr, sub, 0, 0, std::string(), std::vector<uint32_t>(), 0, 0, true, tag};
     size_t idx = 0;
     if (!enqueue(h, nullptr, &lk, &idx)) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_lookup_one_submit: the batcher was stopped");
     return ACL_OK;

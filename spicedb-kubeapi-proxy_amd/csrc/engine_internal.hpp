@@ -43,9 +43,17 @@ using namespace acl;
 namespace aclint {
 
 extern thread_local std::string g_last_error;  // engine.cpp
+extern thread_local int g_last_detail;          // what KIND of failure the last fail() was, for callers inside the library that react to one (0: nothing special)
+constexpr int kDetailBitmapTooSmall = 1;        // a lookup's caller-sized row no longer covers the type's ids: acl_lookup_resources_alloc sizes again and retries
 
 inline int fail(int code, const std::string &msg) {
     g_last_error = msg;
+    g_last_detail = 0;
+    return code;
+}
+inline int fail_detail(int code, int detail, const std::string &msg) {
+    g_last_error = msg;
+    g_last_detail = detail;
     return code;
 }
 inline int fail(const Status &s) { return fail(s.code, s.msg); }

@@ -93,11 +93,29 @@ struct Scanner {
         p += n;
         return true;
     }
+    // -? (0 | [1-9][0-9]*) (\.[0-9]+)? ([eE][+-]?[0-9]+)?  -- what encoding/json accepts: "+1", "1.2.3", "--", "1e", "01" fail the parse
+    // ('failed to parse list response', postfilter.go:21-24), they are not spliced through
     bool number() {
-        const char *s = p;
+        auto digits = [&] {
+            const char *s0 = p;
+            while (p < e && *p >= '0' && *p <= '9') p++;
+            return p > s0;
+        };
         if (p < e && *p == '-') p++;
-        while (p < e && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
-        return p > s ? true : fail();
+        if (p >= e) return fail();
+        if (*p == '0') p++;
+        else if (*p >= '1' && *p <= '9') digits();
+        else return fail();
+        if (p < e && *p == '.') {
+            p++;
+            if (!digits()) return fail();
+        }
+        if (p < e && (*p == 'e' || *p == 'E')) {
+            p++;
+            if (p < e && (*p == '+' || *p == '-')) p++;
+            if (!digits()) return fail();
+        }
+        return true;
     }
     // skips any value; depth-limited like encoding/json (10000)
     bool skip(int depth = 0) {
@@ -229,6 +247,11 @@ extern "C" {
 
 int acl_filter_list_response(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates, const char *user_name,
                              char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out) {
+    return acl_filter_list_response_req(h, body, body_len, templates, n_templates, user_name, nullptr, out_body, out_len, kept_out, total_out);
+}
+
+int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_len, const char *const *templates, size_t n_templates, const char *user_name,
+                                 const acl_list_request_t *req, char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out) {
     if (!body || !out_body || !out_len || (n_templates && !templates)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_filter_list_response: NULL argument");
     *out_body = nullptr;
     *out_len = 0;
@@ -291,9 +314,17 @@ int acl_filter_list_response(acl_engine_t *h, const char *body, size_t body_len,
     std::vector<RelText> rels;
     std::vector<uint32_t> off(items.size() + 1, 0);
     std::string text;
+    // every item's template input is rules.NewResolveInput(input.Request, ...) (postfilter.go:88, rules.go:315-342): the item's own metadata first,
+    // the REQUEST's name / namespace where the item has none, and no namespace at all for the `namespaces` resource (its requests carry the
+    // namespace name in both fields)
+    const std::string req_name = req && req->name ? req->name : "", req_ns = req && req->namespace_ ? req->namespace_ : "";
+    const bool cluster_scoped = req && req->resource && std::strcmp(req->resource, "namespaces") == 0;
     for (size_t i = 0; i < items.size(); i++) {
         off[i] = (uint32_t)rels.size();
         if (!items[i].is_object) continue;  // postfilter.go:68-71
+        if (items[i].name.empty()) items[i].name = req_name;
+        if (items[i].ns.empty()) items[i].ns = req_ns;
+        if (cluster_scoped) items[i].ns.clear();
         for (const std::string &t : tpls) {
             RelText r;
             if (!render(t, items[i], user, &text) || !parse_relationship_text(text, &r)) continue;  // resolution failed: no check (postfilter.go:92-95)

@@ -150,6 +150,45 @@ def test_c4_full_every_entry_point(aclgpu):
         assert e.stats()["local_passes"] >= 1
 
 
+def test_c4_full_named_objects_through_strings(aclgpu):
+    """The string entry points at FULL size on named objects ("the full-size string path is only exercised with unknown names"):
+    every pod and user of the 10 M-relationship graph gets a name (ids follow interning order, so the bulk-loaded relationships are theirs), and the
+    whole 262 144-item batch goes through acl_check_bulk_v ({pointer, length} fields) and a 65 536-item slice through acl_check_bulk (C strings):
+    every answer equals the oracle's answer for the ids those names stand for."""
+    import ctypes
+    from aclgpu import workloads
+    w = workloads.c4()
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    rt, perm, st = w.check
+    op, oe = o.check_bulk_ids_mt(host_threads(), rt, perm, w.res, st, "", w.subj)
+    pod_ns = np.zeros(w.nobjects["pod"], dtype=np.int64)
+    for e_ in w.edges:
+        if e_[0] == "pod" and e_[1] == "namespace":
+            pod_ns[e_[4]] = e_[5]
+    names = {"pod": [f"ns{int(pod_ns[i])}/pod-{i}" for i in range(w.nobjects["pod"])], "user": [f"user-{i}" for i in range(w.nobjects["user"])]}
+    with aclgpu.Engine(w.schema) as e:
+        out = ctypes.c_uint32()
+        for t_, ns_ in names.items():
+            tid = e.type_id(t_)
+            for nm in ns_:
+                e._check(e._L.acl_intern(e._h, tid, nm.encode(), ctypes.byref(out)))
+            assert out.value == len(ns_) - 1
+        w.load(e)
+        qs = [("pod", names["pod"][int(r)], "view", "user", names["user"][int(s_)], "") for r, s_ in zip(w.res, w.subj)]
+        pv, ev = e.check_bulk_views(e.make_check_views(qs))
+        assert np.array_equal(pv, op) and np.array_equal(ev, oe)
+        m = 65536
+        pc, ec = e.check_bulk_prepared(e.make_check_strings_named(qs[:m]))
+        assert np.array_equal(pc, op[:m]) and np.array_equal(ec, oe[:m])
+        assert 0.5 < (pv == 2).mean() < 0.95
+        # LookupResources by name on the same graph: the ids of the result row are the named pods the oracle finds
+        u = int(w.subj[0])
+        got = e.lookup("pod", "view", "user", names["user"][u])
+        assert got == {names["pod"][int(i)] for i in o.lookup_ids("pod", "view", "user", "", u)}
+
+
 @pytest.mark.skipif(os.environ.get("ACL_SKIP_C5_FULL") == "1", reason="ACL_SKIP_C5_FULL=1")
 def test_c5_full_emulated_8_shards(aclgpu):
     """100 M relationships / 10 M objects, hash(type) mod 8 on ONE device (emulated layout): all 262 144

@@ -86,6 +86,19 @@ def test_reference_vectors(aclgpu_lib):
         with pytest.raises(aclgpu.AclError) as ei:
             e.filter_list_response(b'{"items": [', tpl, "testuser")
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
+        # rules.NewResolveInput's fallbacks (rules.go:315-342): an item WITHOUT metadata.namespace in a namespaced list takes the request's namespace;
+        # without the request it resolves to another id and is dropped
+        e.touch(("pod", "team-a/web", "creator", "user", "testuser", ""), ("namespace", "team-a", "viewer", "user", "testuser", ""))
+        tpl2 = ["pod:{{namespacedName}}#view@user:{{user.name}}"]
+        body = json.dumps({"kind": "PodList", "items": [{"metadata": {"name": "web"}}, {"metadata": {"name": "web", "namespace": "team-b"}}]}).encode()
+        out, kept, total = e.filter_list_response(body, tpl2, "testuser", request=("", "team-a", "pods"))
+        assert (kept, total) == (1, 2) and json.loads(out)["items"] == [{"metadata": {"name": "web"}}]
+        out, kept, _t = e.filter_list_response(body, tpl2, "testuser")
+        assert kept == 0
+        # ... and a request on the `namespaces` resource carries the namespace name in BOTH fields: the namespace is cleared (cluster scoped)
+        nsl = json.dumps({"kind": "NamespaceList", "items": [{"metadata": {"name": "team-a"}}, {"metadata": {"name": "team-z"}}]}).encode()
+        out, kept, _t = e.filter_list_response(nsl, ["namespace:{{namespacedName}}#view@user:{{user.name}}"], "testuser", request=("team-a", "team-a", "namespaces"))
+        assert kept == 1 and [i["metadata"]["name"] for i in json.loads(out)["items"]] == ["team-a"]
 
 
 @pytest.mark.gpu
@@ -139,7 +152,12 @@ def test_unchanged_and_invalid_bodies_need_no_gpu(aclgpu_lib):
     for body in (b'{"kind":"PodList","items":[]}', b' { "a" : [1, {"b": null}], "items" : 3 } ', b'{"items":[1],"items":{}}'):
         out, _k, _t = e.filter_list_response(body, tpl, "u")
         assert out == body
-    for bad in (b'', b'[1,2]', b'{"items": [}', b'{"a": tru}', b'{"a": "\\q"}', b'{"a":1} trailing', b'{"a":"\x01"}'):
+    for ok_numbers in (b'{"a":[0,-0,1,-12,3.5,1e9,1E+9,2.5e-3,0.0,10.01],"items":[]}',):
+        out, _k, _t = e.filter_list_response(ok_numbers, tpl, "u")
+        assert out == ok_numbers
+    for bad in (b'', b'[1,2]', b'{"items": [}', b'{"a": tru}', b'{"a": "\\q"}', b'{"a":1} trailing', b'{"a":"\x01"}',
+                # numbers encoding/json rejects (they used to be spliced through)
+                b'{"a":+1}', b'{"a":1.2.3}', b'{"a":--1}', b'{"a":1e}', b'{"a":01}', b'{"a":.5}', b'{"a":1.}', b'{"a":-}', b'{"a":1e+}', b'{"items":[{"x":1.2.3}]}'):
         with pytest.raises(aclgpu.AclError) as ei:
             e.filter_list_response(bad, tpl, "u")
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
