@@ -109,7 +109,8 @@ int main(int argc, char **argv) {
             if (++k % 4 == 0) {
                 if (acl_selfcheck_compaction(h, 0, &adopted)) { fprintf(stderr, "compaction 0: %s\n", acl_last_error()); bad++; }
                 std::this_thread::sleep_for(std::chrono::milliseconds(2));
-                if (acl_selfcheck_compaction(h, 1, &adopted)) { fprintf(stderr, "compaction 1: %s\n", acl_last_error()); bad++; }
+                const int rc1 = acl_selfcheck_compaction(h, 1, &adopted);  // (a bootstrap reload in between drops the build: "phase 1 without phase 0")
+                if (rc1 && !(reload && rc1 == ACL_ERR_FAILED_PRECONDITION)) { fprintf(stderr, "compaction 1: %s\n", acl_last_error()); bad++; }
             }
         }
     });
