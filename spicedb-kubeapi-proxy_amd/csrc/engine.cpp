@@ -264,8 +264,8 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     if (!rev_ok) h->snap.has_reverse = false;
     h->snap_valid = true;
     h->dev_valid = true;
-    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, false, h->local_queue);
-    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true, h->local_queue);
+    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
+    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_compactions++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -346,8 +346,8 @@ int ensure_snapshot(acl_engine *h) {
     HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->dev_valid = true;
-    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, false, h->local_queue);
-    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true, h->local_queue);  // (the single-launch kernel's LDS depends on the schema)
+    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
+    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);  // (the single-launch kernel's LDS depends on the schema)
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -527,17 +527,8 @@ static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g, const uin
     uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
     HIP_TRY(hipMemsetAsync(d_over, 0, 3 * sizeof(uint32_t), c->stream));  // [2]: deepest level (a per-destination export counter of the sharded walk: unused here)
     ev_begin(c, 2);
-    if (h->debug_geom) {
-        h->debug_geom = false;
-        std::fprintf(stderr, "aclgpu: single-launch walk n=%u rpw=%u units=%u blocks=%u cap=%u wide=%d queue=%d resident blocks %d / %d\n", n, G.rpw, G.nunits, G.nblocks, G.cap, (int)G.wide,
-                     (int)h->local_queue, h->local_blocks, h->local_blocks_wide);
-    }
-    if (h->local_queue && !G.nstatic)
-        launch_check_queue(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p, c->d_err.p,
-                           d_perm, d_errout, d_over + 2, G.wide);
-    else
-        launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
-                           c->d_err.p, d_perm, d_errout, d_over + 2, G.nstatic, G.rdyn, G.wide);
+    launch_check_local(c->stream, g, d_items, n, G.rpw, G.nblocks, G.nunits > G.nblocks ? d_over + 1 : nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, d_over, c->d_has.p,
+                       c->d_err.p, d_perm, d_errout, d_over + 2, G.nstatic, G.rdyn, G.wide);
     ev_end(c);
     HIP_TRY(hipMemcpyAsync(c->h_status, d_over, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     return ACL_OK;
@@ -1362,10 +1353,8 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
     h->grid_blocks = expand_grid_blocks(dev);
-    h->debug_geom = getenv("ACL_DEBUG_GEOM") != nullptr;
-    if (const char *ev = getenv("ACL_LOCAL_QUEUE")) h->local_queue = atoi(ev) != 0;  // A/B knob: the single-launch walk without level barriers (k_check_queue)
-    h->local_blocks = local_grid_blocks(dev, 2048, false, h->local_queue);  // (refined per snapshot: ensure_snapshot)
-    h->local_blocks_wide = local_grid_blocks(dev, 2048, true, h->local_queue);
+    h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
+    h->local_blocks_wide = local_grid_blocks(dev, 2048, true);
     if (const char *ev = getenv("ACL_LOCAL_WIDE_MIN")) h->local_wide_min = (uint32_t)std::max(0, atoi(ev));  // A/B knob
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");

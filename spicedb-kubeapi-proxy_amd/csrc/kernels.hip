@@ -71,9 +71,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// polled LDS words (cursors and counters other waves of the block update): never hoisted out of a loop, never torn
-__device__ __forceinline__ uint32_t lds_ld(const uint32_t *p) { return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
-__device__ __forceinline__ void lds_st(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // Wave64 scan / reduction on the DPP lane network: six v_add / v_max with a DPP source operand, no LDS traffic (ds_bpermute)
 // and -- what mattered more here -- no per-distance lane-address VGPRs that the compiler hoists and keeps alive across the
 // whole kernel.  row_shr:n shifts within a row of 16 lanes (lanes without a source add 0), row_bcast:15 / :31 carry a
@@ -142,7 +139,6 @@ struct TaskLds {
 struct WaveOutCold {  // what only the chunk switch / overflow paths need: kept in LDS, not in ~10 SGPRs for the whole kernel
     uint32_t *counts, *nchunks, *overflow;
     uint32_t nwaves, max_chunks, cap;
-    uint32_t *done;  // QUEUE walk (k_check_queue): LDS counters, entries committed per 128-entry pair of the block's log
 #if ACL_PROFILE_PHASES
     uint32_t last, prof[16];
 #endif
@@ -152,57 +148,7 @@ struct WaveOut {
     uint32_t cur, fill, produced;
     WaveOutCold *cold;  // LDS
     uint32_t *lfill;    // LOCAL: the block's output cursor (LDS) -- the block's waves append to one region
-    uint32_t *pend;     // LOCAL, queue walk only (else nullptr): this wave's reserved-but-uncommitted ranges, LDS: [0] = count, then {base, need} pairs
 };
-#ifndef ACL_QUEUE_FULL_INLINE
-#define ACL_QUEUE_FULL_INLINE __noinline__
-#endif
-#ifndef ACL_QUEUE_PEND
-#define ACL_QUEUE_PEND 15
-#endif
-#ifndef ACL_QUEUE_SLEEP
-#define ACL_QUEUE_SLEEP 2
-#endif
-constexpr uint32_t kPendMax = ACL_QUEUE_PEND;  // ranges a wave may have written but not yet committed (a commit waits for the wave's stores: it is done per pair, not per group)
-
-// QUEUE walk: makes the entries of this wave's reserved ranges visible to the block's other waves and counts them into their pairs' counters
-// (one BYTE per pair, four pairs to an LDS word: a pair holds 128 entries, the byte never carries)
-__device__ __forceinline__ void commit_pending(WaveOut &wo, uint32_t lane) {
-    wave_lds_fence();
-    const uint32_t cnt = uniform(wo.pend[0]);
-    if (!cnt) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's entry stores have reached the L2 before anybody is told about them
-    if (lane < cnt) {
-        const uint32_t base = wo.pend[1 + 2 * lane], need = wo.pend[2 + 2 * lane];
-        uint32_t *done = wo.cold->done;
-        for (uint32_t at = base, left = need; left;) {  // (a range is at most a chunk long: it touches two or three pairs)
-            const uint32_t in = min(left, 128u - (at & 127u)), pr = at >> 7;
-            atomicAdd(&done[pr >> 2], in << (8u * (pr & 3u)));
-            at += in;
-            left -= in;
-        }
-    }
-    wave_lds_fence();
-    if (lane == 0) wo.pend[0] = 0;
-    wave_lds_fence();
-}
-__device__ ACL_QUEUE_FULL_INLINE void commit_pending_full(uint32_t *pend, uint32_t *done, uint32_t lane) {  // the list is full in the middle of a pair (rare: kept out of line, reserve is inlined at every expansion step)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane < kPendMax) {
-        const uint32_t base = pend[1 + 2 * lane], need = pend[2 + 2 * lane];
-        for (uint32_t at = base, left = need; left;) {
-            const uint32_t in = min(left, 128u - (at & 127u)), pr = at >> 7;
-            atomicAdd(&done[pr >> 2], in << (8u * (pr & 3u)));
-            at += in;
-            left -= in;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) pend[0] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // room for `need` (<= kChunk) consecutive entries; returns the first entry index
 template <bool LOCAL>
@@ -218,15 +164,6 @@ __device__ __forceinline__ uint32_t reserve(WaveOut &wo, uint32_t need, uint32_t
             return kNoSpace;
         }
         wo.produced += need;
-        if (wo.pend) {  // queue walk: the range is committed (counted into its pairs) once its stores are done -- at the latest when the list is full
-            if (uniform(wo.pend[0]) == kPendMax) commit_pending_full(wo.pend, wo.cold->done, lane);  // (covers the ranges recorded so far: their stores were issued before this point)
-            if (lane == 0) {
-                const uint32_t c = wo.pend[0];
-                wo.pend[1 + 2 * c] = base;
-                wo.pend[2 + 2 * c] = need;
-                wo.pend[0] = c + 1;
-            }
-        }
         return base;
     }
     if (wo.fill + need > kChunk) {
@@ -1018,8 +955,6 @@ __device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t it
     wo.fill = 0;
     wo.produced = 0;
     wo.cold = cold;
-    wo.lfill = nullptr;
-    wo.pend = nullptr;
     return wo;
 }
 
@@ -1180,7 +1115,6 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     wo.produced = 0;
     wo.cold = &s_cold[wib];
     wo.lfill = &s_fill[1];
-    wo.pend = nullptr;
     // units [0, nstatic) hold rpw requests each (block b starts on unit b: no hand-out); the requests behind them come in SMALL units of rdyn,
     // handed out through `next_unit` as blocks finish -- the launch's tail is then a small unit's walk, not the slowest big unit's
     const uint32_t nstat_req = min(n, nstatic * rpw);
@@ -1270,186 +1204,6 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     ACL_MARK(wo, PH_OTHER);
     if (lane < PH_COUNT) atomicAdd(&acl_phase_cycles[lane], (unsigned long long)s_cold[wib].prof[lane]);
 #endif
-}
-
-// ------------------------------------------------------------ single launch, no level barrier
-// The walk above keeps the block's waves in step: one barrier per dispatch level, at which every wave waits for the slowest one of the level
-// (~18 % of the wave-time, profiles/r02_walk_phase_breakdown_v2.txt).  Forward Check needs no level order: an entry carries its level, and
-// has[] / err[] are order-free (HAS beats error beats NO whatever came first).  So here the block's frontier is ONE append-only LOG of
-// 128-entry PAIRS in the block's private region, and the waves are a pool of workers on it:
-//   * producers append as before (an LDS cursor reserves a range, the lanes store their children); a wave COMMITS the ranges it wrote once per
-//     pair it processed -- a release fence, then the ranges' sizes are added to their pairs' LDS counters (done[pair]);
-//   * a worker claims the next pair index from an LDS counter and waits until that pair's counter says 128: it never reads an entry that is not
-//     written, and pairs are consumed in the order they fill, deep levels and shallow ones mixed;
-//   * when every wave of the block waits and no claimed pair is complete, nothing is being produced: the pair that holds the log's tail is
-//     PARTIAL -- its claimant seals it (the cursor jumps to the pair's end) and processes what is there -- or, if the tail sits on a pair
-//     boundary at or below every claim, the unit is finished.
-// Same segment processor, same decisions; the answers do not depend on the order the log is consumed in.
-template <bool LDSPROG, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_queue(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
-                                                                                      uint32_t nunits, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
-                                                                                      uint32_t cap2 /* entries of a block's log: a multiple of 128 */,
-                                                                                      uint32_t prog_words4 /* uint4s of the program table in front of the counters */,
-                                                                                      uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
-                                                                                      uint32_t *max_level) {
-    __shared__ TaskLds lds[WAVES];
-    __shared__ WaveOutCold s_cold[WAVES];
-    __shared__ uint32_t s_pend[WAVES][2 * kPendMax + 2];
-    __shared__ uint32_t s_tail, s_head, s_state, s_stop, s_unit, s_level;
-    extern __shared__ uint4 s_prog[];  // [program table (LDSPROG)][done counters: cap2 / 128 bytes]
-    const SlotProg *progs;
-    const FwdOp *ops;
-    load_programs<LDSPROG>(g, s_prog, progs, ops, WAVES * 64);
-    uint32_t *done = reinterpret_cast<uint32_t *>(s_prog + prog_words4);
-    const uint32_t npairs = cap2 >> 7;
-    auto pair_done = [&](uint32_t k) { return (lds_ld(&done[k >> 2]) >> (8u * (k & 3u))) & 255u; };
-    const uint32_t lane = lane_id();
-    const uint32_t wib = uniform(threadIdx.x >> 6);
-    TaskLds &t = lds[wib];
-    const DevShard nosh{};
-    // the block's log: 2 x cap entries in ONE of the two frontier buffers (blocks of the lower half of the grid in buf0, the others in buf1)
-    const uint32_t half = (gridDim.x + 1) >> 1;
-    uint4 *log = blockIdx.x < half ? buf0 + (size_t)blockIdx.x * cap2 : buf1 + (size_t)(blockIdx.x - half) * cap2;
-    if (lane == 0) {
-        s_cold[wib] = WaveOutCold{};
-        s_cold[wib].overflow = overflow;
-        s_cold[wib].cap = cap2;
-        s_cold[wib].done = done;
-    }
-    WaveOut wo;
-    wo.buf = log;
-    wo.cur = 0;
-    wo.fill = 0;
-    wo.produced = 0;
-    wo.cold = &s_cold[wib];
-    wo.lfill = &s_tail;
-    wo.pend = s_pend[wib];
-    for (uint32_t unit = blockIdx.x; unit < nunits;) {
-        const uint32_t first = unit * rpw;
-        const uint32_t mine = min(rpw, n - first);  // <= WAVES * 64: thread i seeds and answers request first + i
-        for (uint32_t i = threadIdx.x; i < (npairs + 3) >> 2; i += WAVES * 64) done[i] = 0;
-        if (threadIdx.x == 0) {
-            s_tail = 0;
-            s_head = 0;
-            s_state = 0;
-            s_stop = 0;
-            s_level = 1;
-        }
-        if (lane == 0) s_pend[wib][0] = 0;
-        __syncthreads();
-        // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit
-        const bool valid = threadIdx.x < mine;
-        const uint32_t req = first + threadIdx.x;
-        uint4 e = make_uint4(0, 0, kDeadMeta, 0);
-        if (valid) {
-            const uint4 it = gld(items, req);
-            const uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
-            const bool tok = rtype < g.ntypes && stype < g.ntypes;
-            const uint32_t rt = tok ? rtype : 0u, st = tok ? stype : 0u;
-            const uint32_t rmem = gld(g.type_nmembers, rt), smem = gld(g.type_nmembers, st), rbase = gld(g.type_slot_base, rt), sbase = gld(g.type_slot_base, st);
-            const bool ok = tok && perm < rmem && (srel == 0xFFFFu || srel < smem);
-            gst(has, req, (uint8_t)0);
-            gst(err, req, (uint8_t)(ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID));
-            const uint32_t meta = ok ? make_meta(rbase + perm, 1u, srel == 0xFFFFu ? g.nslots + stype : sbase + srel) : kDeadMeta;
-            e = make_uint4(it.y, req, meta, it.w);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        wo.cur = 0;
-        {
-            NoNext nn;
-            process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
-        }
-        commit_pending(wo, lane);
-        // ---- worker loop
-        for (;;) {
-            if (wo.cur == kNoSpace && lane == 0) lds_st(&s_stop, 1u);  // the log is full: the host redoes the batch on the level loop
-            uint32_t k = 0;
-            if (lane == 0) k = atomicAdd(&s_head, 1u);
-            k = uniform(k);
-            const uint32_t base = k << 7;
-            uint32_t cnt = 0;
-            bool waiting = false, finished = false;
-            // What this wave wrote while it walked its last pair is committed (a release fence = a wait for its stores) where that wait is free:
-            // behind the load of the next pair's entries if that pair is ready -- the stores are long done by then, the load is waited for anyway --
-            // or, if the wave has to wait for its pair, before it starts waiting.
-            const bool ready = !lds_ld(&s_stop) && k < npairs && pair_done(k) == 128u;
-            if (ready) cnt = 128;
-            else commit_pending(wo, lane);
-            while (!ready) {
-                if (lds_ld(&s_stop)) {
-                    finished = true;
-                    break;
-                }
-                if (k < npairs && pair_done(k) == 128u) {
-                    cnt = 128;
-                    break;
-                }
-                if (!waiting) {
-                    if (lane == 0) atomicAdd(&s_state, 1u);
-                    waiting = true;
-                }
-                // s_state = exits << 8 | waves waiting.  Read twice around the cursors: equal and full means that between the two reads every
-                // wave of the block waited -- nobody reserved, committed or claimed, and everything reserved before is committed.
-                const uint32_t s1 = lds_ld(&s_state);
-                if ((s1 & 255u) == (uint32_t)WAVES) {
-                    const uint32_t tl = lds_ld(&s_tail), hd = lds_ld(&s_head), dk = k < npairs ? pair_done(k) : 0u;
-                    if (lds_ld(&s_state) == s1) {
-                        if (dk == 128u) {
-                            cnt = 128;
-                            break;
-                        }
-                        if (tl > base && tl < base + 128u) {  // the log ends inside MY pair: seal it (the cursor jumps to the pair's end) and take what is there
-                            uint32_t old = 0;
-                            if (lane == 0) old = atomicCAS(&s_tail, tl, base + 128u);
-                            if (uniform(old) == tl) {
-                                cnt = tl - base;
-                                break;
-                            }
-                        } else if (tl <= ((hd - (uint32_t)WAVES) << 7)) {  // the log ends at or below every claimed pair: the unit is done
-                            finished = true;
-                            break;
-                        }
-                    }
-                }
-                __builtin_amdgcn_s_sleep(ACL_QUEUE_SLEEP);
-            }
-            if (finished) break;  // (a finished wave stays counted as waiting: the others must see the same stand-still)
-            if (waiting && lane == 0) atomicAdd(&s_state, 255u);  // one more exit, one wave less waiting
-            while (cnt < 128u && pair_done(k) != cnt && !lds_ld(&s_stop)) __builtin_amdgcn_s_sleep(1);  // (a sealed pair: every entry below the seal is committed already)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            LocalWalk lw{log + base, cnt, 0u, lane, true};
-            uint4 en = lw.in[lane < cnt ? lane : 0u];  // unconditional; process_segment masks by `v`
-            if (ready) commit_pending(wo, lane);
-            for (lw.s = 0; lw.s < 2 && lw.s * 64 < cnt; lw.s++) {
-                if (lw.s > 0 && !lw.second) break;  // the pair's second segment went with the first
-                const bool v = lw.s * 64 + lane < cnt;
-                if (lw.s > 0) {
-                    en = lw.in[v ? 64 + lane : 64];
-                    lw.second = false;
-                }
-                {  // (statistics: the deepest dispatch level among the entries; kept in LDS, not in a register across the expansion)
-                    const uint32_t lv = wave_max((v && en.z != kDeadMeta) ? meta_level(en.z) : 0u);
-                    if (lane == 0 && lv > lds_ld(&s_level)) atomicMax(&s_level, lv);
-                }
-                process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
-            }
-        }
-        commit_pending(wo, lane);  // (nothing is left to commit after a finished unit; an overflowed one is abandoned anyway)
-        __syncthreads();
-        if (max_level && threadIdx.x == 0 && s_level > __hip_atomic_load(max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_level, s_level);
-        // ---- answers (k_finalize): every wave's has[] / err[] stores are behind the barrier above
-        if (valid) {
-            const bool h = __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            perm_out[req] = h ? 2 : (er ? 0 : 1);
-            if (err_out) err_out[req] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
-        }
-        if (s_stop || !next_unit) break;
-        __syncthreads();
-        if (threadIdx.x == 0) s_unit = gridDim.x + atomicAdd(next_unit, 1u);
-        __syncthreads();
-        unit = s_unit;
-    }
 }
 
 // Merges identical pending sub-checks of one level: two frontier entries with the same (request, state, level) have identical
@@ -2098,52 +1852,19 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
     if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
     else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
 }
-// the walk without level barriers (k_check_queue): a block's log is 2 x cap entries (at most kQueueLogMax) in one of the two buffers
-uint32_t queue_log_entries(uint32_t cap, uint32_t nblocks) {
-    uint64_t c2 = (nblocks & 1u) ? (uint64_t)2 * cap * nblocks / (nblocks + 1) : (uint64_t)2 * cap;
-    if (nblocks == 1) c2 = cap;
-    return (uint32_t)std::min<uint64_t>(c2, kQueueLogMax) & ~127u;
-}
 template <int WAVES>
-static void launch_check_queue_w(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
-                                 uint32_t cap2, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level) {
-    const uint32_t nunits = (n + rpw - 1) / rpw;
-    const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
-    const uint32_t prog_words4 = lds ? (uint32_t)(prog_lds_bytes(g) / 16) : 0u;
-    const size_t dyn = (size_t)prog_words4 * 16 + (size_t)(((cap2 >> 7) + 15) & ~15u);
-    if (lds)
-        hipLaunchKernelGGL((k_check_queue<true, WAVES>), dim3(nblocks), dim3(WAVES * 64), dyn, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap2, prog_words4, overflow, has, err,
-                           perm_out, err_out, max_level);
-    else
-        hipLaunchKernelGGL((k_check_queue<false, WAVES>), dim3(nblocks), dim3(WAVES * 64), dyn, s, g, items, n, rpw, nunits, next_unit, buf0, buf1, cap2, prog_words4, overflow, has, err,
-                           perm_out, err_out, max_level);
-}
-void launch_check_queue(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
-                        uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level, bool wide) {
-    const uint32_t cap2 = queue_log_entries(cap, nblocks);
-    if (wide) launch_check_queue_w<kLocalWide>(s, g, items, n, rpw, nblocks, next_unit, buf0, buf1, cap2, overflow, has, err, perm_out, err_out, max_level);
-    else launch_check_queue_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, next_unit, buf0, buf1, cap2, overflow, has, err, perm_out, err_out, max_level);
-}
-template <int WAVES>
-static int local_occupancy(bool lds, size_t prog_bytes, bool queue) {
+static int local_occupancy(bool lds, size_t prog_bytes) {
     int occ = 0;
-    hipError_t oe;
-    if (queue) {  // (+ the pair counters of the largest log)
-        const size_t dyn = (lds ? prog_bytes : 0) + (size_t)(kQueueLogMax >> 7);
-        oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_queue<true, WAVES>, WAVES * 64, dyn)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_queue<false, WAVES>, WAVES * 64, dyn);
-    } else {
-        oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true, WAVES>, WAVES * 64, prog_bytes)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false, WAVES>, WAVES * 64, 0);
-    }
+    const hipError_t oe = lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<true, WAVES>, WAVES * 64, prog_bytes)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_check_local<false, WAVES>, WAVES * 64, 0);
     return (oe != hipSuccess || occ <= 0) ? std::max(1, 16 / WAVES) : occ;
 }
-int local_grid_blocks(int device, size_t prog_bytes, bool wide, bool queue) {
+int local_grid_blocks(int device, size_t prog_bytes, bool wide) {
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     const bool lds = prog_in_lds() && prog_bytes <= (size_t)kProgLdsEntries * 32;
-    return cus * (wide ? local_occupancy<kLocalWide>(lds, prog_bytes, queue) : local_occupancy<kLocalNarrow>(lds, prog_bytes, queue));
+    return cus * (wide ? local_occupancy<kLocalWide>(lds, prog_bytes) : local_occupancy<kLocalNarrow>(lds, prog_bytes));
 }
 uint32_t local_unit_max(bool wide) { return (uint32_t)(wide ? kLocalWide : kLocalNarrow) * 64u; }
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {

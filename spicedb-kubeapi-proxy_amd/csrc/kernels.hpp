@@ -101,11 +101,7 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
                                                                    handed out through next_unit (which must then be given) */,
                         bool wide = false /* 16 waves per block (and unit) instead of 4: chip-filling batches */);
 // blocks of the single-launch kernel that are resident at once on this device
-int local_grid_blocks(int device, size_t prog_bytes, bool wide = false, bool queue = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
-// the same batch through the walk WITHOUT level barriers (k_check_queue: the block's frontier is a log of 128-entry pairs that idle waves take as they fill)
-constexpr uint32_t kQueueLogMax = 1u << 18;  // entries of a block's log, at most (2 048 pair counters, a byte each, in LDS)
-void launch_check_queue(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
-                        uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level, bool wide);
+int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
 uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= threads per block of the single-launch kernel: thread i seeds request i of the unit)
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits);
