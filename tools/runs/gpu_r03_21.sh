@@ -1,18 +1,20 @@
 #!/bin/bash
-# round 3, call 21: the default bench line (what the driver runs) + test durations
+# round 3, call 21: k_check_queue variants (geometry print, commit list size, sleep, inline) against k_check_local on C4
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=$R/gpurun_out
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r03_21_bench.json 2> $O/r03_21_bench.err; echo "bench rc=$?"
-python - <<'P'
-import json
-d=json.loads(open('gpurun_out/r03_21_bench.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ('metric','value','n_gpus','ms_per_step','p50_batch_ms','setup_s')})
-print('roofline', {k:v for k,v in d['roofline'].items() if k in ('achieved','frac','traffic','kernel','kernel_avg_us')}, 'parity', d['parity'], 'cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
-print('device', d['device_resident']['decisions_per_s'], 'strings', d['string_path']['decisions_per_s'], d['string_path']['answers_equal_id_path'])
-for k,c in d['configs'].items():
-    if isinstance(c, dict): print(k, c.get('value'), c.get('roofline',{}).get('frac'), c.get('roofline',{}).get('traffic'), c.get('parity'), c.get('cpu_baseline',{}).get('value'))
-    else: print(k, c)
-P
-
-timeout 400 python -m pytest tests/test_fullscale_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider --durations=5 2>&1 | grep -E "s call|passed|failed" | head
+ACL_LOCAL_QUEUE=1 timeout -s KILL 300 python -m pytest tests/test_engine_gpu.py -m gpu -q -x --tb=short -p no:cacheprovider > $O/r03_21_tests.log 2>&1; rc=$?; echo "tests rc=$rc"
+tail -3 $O/r03_21_tests.log
+[ $rc -ne 0 ] && exit 0
+run() {
+  timeout -s KILL 200 python bench.py --workload C4 --no-cpu --legs device --configs off --strings off --steps 30 2>$O/r03_21_err.txt | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print('$1 value', round(d['value']/1e6,1), 'M/s kernel us', round(d['roofline']['kernel_avg_us'],1))"
+  grep "single-launch walk" $O/r03_21_err.txt | head -2
+}
+ACL_DEBUG_GEOM=1 ACL_LOCAL_QUEUE=0 run local
+ACL_DEBUG_GEOM=1 ACL_LOCAL_QUEUE=1 run queue
+for v in qinl qsl8 qp31; do ACLGPU_LIB=$R/spicedb-kubeapi-proxy_amd/lib/libaclgpu_$v.so ACL_LOCAL_QUEUE=1 run $v; done
+ACL_LOCAL_WIDE_MIN=100000000 ACL_DEBUG_GEOM=1 ACL_LOCAL_QUEUE=1 run queue_narrow
+ACL_LOCAL_WIDE_MIN=100000000 ACL_LOCAL_QUEUE=0 run local_narrow
