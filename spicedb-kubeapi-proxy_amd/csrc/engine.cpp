@@ -942,9 +942,14 @@ struct InternPool {
     const std::function<void(size_t, size_t)> *job = nullptr;
     size_t n = 0, chunk = 1;
     std::atomic<size_t> next{0};
+    std::atomic<unsigned> limit{0};  // workers that take chunks of the current batch
     size_t outstanding = 0;  // workers that have not yet passed through the current batch (every worker passes through every batch)
     uint64_t gen = 0;
     bool stop = false;
+    std::atomic<uint64_t> gen_a{0};  // = gen, for the workers that poll instead of sleeping
+    std::atomic<bool> stop_a{false};
+    unsigned sleepers = 0;
+    static constexpr int64_t kSpinNs = 150000;
     std::mutex call_mu;  // one batch at a time
 
     void work() {
@@ -954,16 +959,30 @@ struct InternPool {
             (*job)(a, std::min(n, a + chunk));
         }
     }
-    void loop() {
+    void loop(unsigned me) {
         uint64_t seen = 0;
         for (;;) {
+            // A sleep + wake-up costs a thread 20-100 us on these hosts, about what interning a 16 384-item slice takes: a worker that has just
+            // finished a batch polls for the next one for kSpinNs before it goes to sleep (large string batches come slice after slice, and
+            // a busy proxy's bulk calls follow each other closely).
+            bool got = false;
+            for (const auto t0 = std::chrono::steady_clock::now(); seen && !got && std::chrono::steady_clock::now() - t0 < std::chrono::nanoseconds(kSpinNs);) {
+                for (int i = 0; i < 64 && !got; i++) {
+                    got = gen_a.load(std::memory_order_acquire) != seen || stop_a.load(std::memory_order_relaxed);
+                    if (!got) __builtin_ia32_pause();
+                }
+            }
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (!got) {
+                    sleepers++;
+                    cv.wait(lk, [&] { return stop || gen != seen; });
+                    sleepers--;
+                }
                 if (stop) return;
                 seen = gen;
             }
-            work();
+            if (me < limit.load(std::memory_order_relaxed)) work();  // (every worker passes through every batch; the ones beyond the batch's limit only sign off)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 outstanding--;
@@ -972,28 +991,33 @@ struct InternPool {
         }
     }
     explicit InternPool(unsigned nthreads) {
-        for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this] { loop(); });
+        for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this, i] { loop(i); });
     }
     ~InternPool() {
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
+            stop_a.store(true, std::memory_order_relaxed);
         }
         cv.notify_all();
         for (auto &t : threads) t.join();
     }
-    void run(size_t total, size_t chunk_items, const std::function<void(size_t, size_t)> &fn) {
+    void run(size_t total, size_t chunk_items, unsigned workers, const std::function<void(size_t, size_t)> &fn) {
         std::lock_guard<std::mutex> one(call_mu);
+        bool wake;
         {
             std::lock_guard<std::mutex> lk(mu);
             job = &fn;
             n = total;
             chunk = chunk_items;
             next.store(0, std::memory_order_relaxed);
+            limit.store(workers, std::memory_order_relaxed);
             outstanding = threads.size();
             gen++;
+            gen_a.store(gen, std::memory_order_release);
+            wake = sleepers != 0;
         }
-        cv.notify_all();
+        if (wake) cv.notify_all();
         work();
         std::unique_lock<std::mutex> lk(mu);
         done_cv.wait(lk, [&] { return outstanding == 0; });  // no worker is still inside (or yet to enter) this batch: `fn` may go out of scope
@@ -1082,9 +1106,11 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
     }
     {
         std::lock_guard<std::mutex> lk(h->intern_pool_mu);
-        if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), 16u) - 1);
+        if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
     }
-    h->intern_pool->run(n, n >= 32768 ? 2048 : 512, run);
+    // threads per batch: 16 up to 32 767 items, 32 beyond (same-box A/B on a 256-thread host, profiles/r03_string_path_ab.txt: 65 536 named
+    // items 135 -> 170 M decisions/s with 32; 16 384 items the same with either, 48 threads slower at both sizes)
+    h->intern_pool->run(n, n >= 32768 ? 1024 : 512, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1, run);
 }
 
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
@@ -1360,6 +1386,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch

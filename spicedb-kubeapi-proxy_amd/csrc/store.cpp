@@ -40,7 +40,7 @@ uint64_t ObjectTable::hash(std::string_view s) {
 void ObjectTable::grow() {
     std::vector<Slot> old;
     old.swap(slots_);
-    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu, nullptr});
+    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
     const size_t mask = slots_.size() - 1;
     for (const Slot &s : old) {
         if (s.id == 0xFFFFFFFFu) continue;
@@ -57,17 +57,31 @@ bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) c
     for (size_t i = h & mask;; i = (i + 1) & mask) {
         const Slot &s = slots_[i];
         if (s.id == 0xFFFFFFFFu) return false;
-        if (s.tag == tag) {  // (stored names are NUL-terminated; never read past that NUL: a longer query must not run off a shorter name)
-            const char *a = s.name, *b = name.data();
+        if (s.tag == tag) {
             const size_t n = name.size();
-            size_t k = 0;
-            while (k < n && a[k] == b[k] && a[k] != 0) k++;
-            if (k == n && a[n] == 0) {
-                *id = s.id;
-                return true;
+            if (n <= kInline) {
+                if (s.len == n && !std::memcmp(s.inl, name.data(), n)) {
+                    *id = s.id;
+                    return true;
+                }
+            } else if (s.len == std::min<size_t>(n, 0xFFFFu) && !std::memcmp(s.inl, name.data(), kInline)) {
+                // (the stored name is NUL-terminated; never read past that NUL: a longer query must not run off a shorter name)
+                const char *a = s.far, *b = name.data();
+                size_t k = kInline;
+                while (k < n && a[k] == b[k] && a[k] != 0) k++;
+                if (k == n && a[n] == 0) {
+                    *id = s.id;
+                    return true;
+                }
             }
         }
     }
+}
+ObjectTable::Slot ObjectTable::make_slot(uint64_t h, uint32_t id, const std::string &stored) {
+    Slot s{(uint32_t)(h >> 32), id, (uint16_t)std::min<size_t>(stored.size(), 0xFFFFu), {}, nullptr};
+    std::memcpy(s.inl, stored.data(), std::min<size_t>(stored.size(), kInline));
+    if (stored.size() > kInline) s.far = stored.c_str();
+    return s;
 }
 uint32_t ObjectTable::intern(std::string_view name) {
     uint32_t id;
@@ -81,7 +95,7 @@ uint32_t ObjectTable::intern(std::string_view name) {
     const size_t mask = slots_.size() - 1;
     size_t i = h & mask;
     while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
-    slots_[i] = Slot{(uint32_t)(h >> 32), id, names_.back().c_str()};
+    slots_[i] = make_slot(h, id, names_.back());
     used_++;
     count_.store(id + 1, std::memory_order_release);
     return id;

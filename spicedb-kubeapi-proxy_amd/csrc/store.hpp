@@ -69,9 +69,9 @@ class ObjectTable {
     void prefetch(uint64_t h) const {
         if (!slots_.empty()) __builtin_prefetch(&slots_[h & (slots_.size() - 1)]);
     }
-    // second stage of a pipelined lookup: walks to the first slot whose tag matches (slot lines: prefetched by the first stage) and pulls
-    // the line of that NAME towards the core; the third stage (find_hashed) then compares bytes that are already in cache.  A lookup in a
-    // table of millions of names is two dependent DRAM misses (slot, name); staged over a group of items they overlap instead of adding up.
+    // second stage of a pipelined lookup: names longer than a slot holds (kInline bytes) live outside the slot -- walk to the first slot whose
+    // tag matches (slot lines: prefetched by the first stage) and pull that name's line towards the core.  Short names (the usual case) need
+    // no second stage: their bytes are in the slot's own cache line, a lookup is ONE miss.
     void prefetch_name(uint64_t h) const {
         if (slots_.empty()) return;
         const uint32_t tag = (uint32_t)(h >> 32);
@@ -80,7 +80,7 @@ class ObjectTable {
             const Slot &s = slots_[i];
             if (s.id == 0xFFFFFFFFu) return;
             if (s.tag == tag) {
-                __builtin_prefetch(s.name);
+                if (s.len > kInline) __builtin_prefetch(s.far);
                 return;
             }
         }
@@ -104,14 +104,24 @@ class ObjectTable {
     }
 
   private:
-    // tag = high half of the hash; `name` points at the NUL-terminated bytes of the name inside names_ (stable: a deque never moves its
-    // elements): a probe compares the caller's bytes with them directly -- no id -> index -> deque block -> string chase (three more misses)
-    struct Slot { uint32_t tag, id; const char *name; };  // id == 0xFFFFFFFF: empty
+    // One slot = one 64-byte cache line: tag = high half of the hash, the id, the name's length and its first kInline bytes.  A name that
+    // fits is compared inside the line the probe already pulled in; a longer one continues at `far` (the NUL-terminated bytes inside names_,
+    // stable: a deque never moves its elements).  A slot that held only {tag, id, pointer} cost every lookup a second dependent miss for the
+    // name's bytes -- half of a bulk string call's interning time in tables of millions of names.
+    static constexpr uint32_t kInline = 46;
+    struct alignas(64) Slot {
+        uint32_t tag, id;  // id == 0xFFFFFFFF: empty
+        uint16_t len;      // of the whole name (names longer than 65 535 bytes are stored with len = 0xFFFF and compared at `far`)
+        char inl[kInline];
+        const char *far;   // the whole name (len > kInline), else nullptr
+    };
+    static_assert(sizeof(Slot) == 64, "a slot is a cache line");
+    static Slot make_slot(uint64_t h, uint32_t id, const std::string &stored);
     static uint64_t hash(std::string_view s);
     void grow();
     void repoint() {  // after a copy: the slots must point into THIS table's names
         for (Slot &s : slots_)
-            if (s.id != 0xFFFFFFFFu) s.name = names_[name_of_[s.id]].c_str();
+            if (s.id != 0xFFFFFFFFu && s.far) s.far = names_[name_of_[s.id]].c_str();
     }
     std::deque<std::string> names_;      // stable addresses (acl_object_name hands out c_str())
     std::vector<uint32_t> name_of_;      // id -> index in names_ (0xFFFFFFFF anonymous); covers ids < name_of_.size()

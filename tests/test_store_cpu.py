@@ -156,3 +156,23 @@ def test_keep_and_check_one_need_a_gpu(aclgpu_lib):
     # an empty request never reaches the device: the pair carries InvalidArgument (options_test.go:101-102)
     assert e.check_one("", "", "", "", "") == (0, aclgpu.ERR_INVALID_ARGUMENT)
     e.close()
+
+
+def test_object_names_of_every_length_round_trip(aclgpu_lib):
+    """The name table keeps a name's first 46 bytes inside its hash slot and the rest outside (store.hpp ObjectTable::Slot): names around
+    that length, names that share a 46-byte prefix, prefixes of stored names and one far beyond 65 535 bytes (the slot's length field
+    saturates) must all intern to distinct ids, be found again, and come back byte for byte -- across the table's growth steps."""
+    import aclgpu
+    e = aclgpu.Engine("definition user {}", store_only=True)
+    base = "ns-0123456789/pod-abcdefghijklmnopqrstuvwxyz-0123456789-ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    names = [base[:k] for k in (1, 2, 15, 16, 45, 46, 47, 48, 63, 64, 65, len(base))]
+    names += [base[:46] + s for s in ("x", "y", "xx", "x" * 30)]          # same inline prefix, different tails
+    names += ["é" * 23, "é" * 24, "z" * 65535, "z" * 65536, "z" * 70000]  # multi-byte; around the saturating length
+    names += [f"filler-{i}" for i in range(3000)]                          # several growth steps: slots are re-hashed with their names
+    ids = [e.intern("user", n) for n in names]
+    assert ids == list(range(len(names)))
+    assert [e.intern("user", n) for n in names] == ids  # idempotent
+    assert [e.find("user", n) for n in names] == ids
+    for n in (base[:44], base[:46] + "z", base + "!", "z" * 65534, "z" * 69999, "filler-3000", ""):
+        assert e.find("user", n) is None, n[:60]
+    assert [e.object_name("user", i) for i in ids[:21]] == names[:21]
