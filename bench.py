@@ -731,7 +731,10 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         return fire
 
     pipelined = (lambda k_: (lambda: submit_wait(k_))) if args.pipeline == "submit" else blocking
-    pipelined(max(warmup, window, callers))()
+    # warm-up long enough to reach the steady state of the mode: the HIP runtime sets up its copy paths lazily -- the first time a 2nd, then a
+    # 3rd host<->device copy is in flight at once, hipMemcpyAsync blocks ~7 ms (profiles/r03_submit_window_trace.txt); a `window`-ticket
+    # warm-up left the second of them for the timed region (the "630 M/s at windows 3-4" of earlier runs was that one stall averaged over 40 steps)
+    pipelined(max(warmup, 3 * window, 3 * callers, 12))()
     fire = pipelined(steps)
     if dist is not None:
         dist.barrier()

@@ -7,7 +7,30 @@
 // this form is for single-threaded hosts (bench.py) and for callers that want to keep a window of batches in flight.
 #include "engine_internal.hpp"
 
+// ACL_TRACE_PIPELINE=1: every hand-off of the submit / wait pipeline with its time, printed when the pool shuts down (debugging aid)
+namespace {
+struct PipeTrace {
+    bool on = getenv("ACL_TRACE_PIPELINE") != nullptr;
+    std::mutex mu;
+    std::vector<std::tuple<uint64_t, const char *, int64_t>> ev;
+    std::atomic<uint64_t> seq{0};
+    void mark(uint64_t id, const char *what) {
+        if (!on) return;
+        const int64_t t = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        std::lock_guard<std::mutex> lk(mu);
+        ev.emplace_back(id, what, t);
+    }
+    void dump() {
+        if (!on || ev.empty()) return;
+        const int64_t t0 = std::get<2>(ev.front());
+        for (auto &e : ev) std::fprintf(stderr, "aclgpu-pipeline %llu %s %.1f\n", (unsigned long long)std::get<0>(e), std::get<1>(e), (std::get<2>(e) - t0) / 1e3);
+        ev.clear();
+    }
+} g_trace;
+}  // namespace
+
 struct acl_ticket {
+    uint64_t seq = 0;
     const acl_item_t *items = nullptr;
     size_t n = 0;
     uint8_t *perm = nullptr;
@@ -71,9 +94,12 @@ void worker_loop(acl_engine_t *h, AsyncPool *P) {
 // out of staging if the caller's buffers are not pinned, and gives the context back.
 int stage_copies(acl_engine_t *h, acl_ticket *t);
 int stage(acl_engine_t *h, acl_ticket *t, bool may_block) {
+    g_trace.mark(t->seq, may_block ? "stage_begin_blocking" : "stage_begin");
     int rc = t->ev.begin(h, false, CallOpts(), -1, !may_block, chains(h, t->n));
     if (rc) return rc;
+    g_trace.mark(t->seq, "context");
     rc = stage_copies(h, t);
+    g_trace.mark(t->seq, "h2d_enqueued");
     if (rc) t->ev.end();  // (a batch that failed to stage kept the shared state lock and its context until the caller waited)
     return rc;
 }
@@ -83,6 +109,7 @@ int stage_copies(acl_engine_t *h, acl_ticket *t) {
     HIP_TRY(c->d_items.ensure(n));
     HIP_TRY(c->d_perm.ensure(n));
     HIP_TRY(c->d_errout.ensure(n));
+    g_trace.mark(t->seq, "ensured");
     const void *src = t->items;
     if (!h->is_pinned(t->items, n * sizeof(acl_item_t))) {
         HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
@@ -97,6 +124,7 @@ int stage_copies(acl_engine_t *h, acl_ticket *t) {
         if (!pin_e) t->he = (int32_t *)c->h_out.p;
         if (!pin_p) t->hp = (uint8_t *)c->h_out.p + n * 4;
     }
+    g_trace.mark(t->seq, "before_h2d");
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
     t->staged_pipeline = true;
     return ACL_OK;
@@ -135,8 +163,11 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
         // The kernel goes behind the previous batch's ON THE DEVICE (an event between the two contexts' streams) and this thread moves on
         // to the next batch without waiting for it: launching batch N + 1 only after synchronising batch N left the chip idle for a
         // wake-up and a launch between two kernels.  The waiter synchronises, and redoes the pass on the level loop if a block overflowed.
-        // (profiles/r03_hostid_modes.txt: windows of 2 and of 6 tickets 870 M/s; 3 and 4 measure 630 M/s -- a resonance of the user / completer / staging hand-offs not yet understood.)
+        // (Windows of 3-4 tickets once measured 630 M/s against 870 M/s at 2 and 6: not the pipeline -- the HIP runtime sets up its copy paths lazily, the
+        //  first hipMemcpyAsync that finds two other copies in flight blocks ~7 ms, once per process, and a short warm-up left that for the timed region:
+        //  profiles/r03_submit_window_trace.txt.  Copies issued at open did not pre-empt it.)
         int rc = chained_enqueue(h, c, t->n);
+        g_trace.mark(t->seq, "kernel_enqueued");
         if (rc == ACL_OK) {
             t->chained = true;
         } else if (rc == kChainDeclined) {
@@ -154,6 +185,7 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
             finish(t, rc);
             continue;
         }
+        g_trace.mark(t->seq, "d2h_enqueued");
         {  // everything is enqueued: the completer takes it from here, this thread moves on to the next batch
             std::lock_guard<std::mutex> lk(P->mu);
             P->completing.push_back(t);
@@ -180,8 +212,10 @@ void completer_loop(acl_engine_t *h, AsyncPool *P) {
         PassCtx *c = t->ev.c;
         int rc = ACL_OK;
         hipError_t e = hipSuccess;
+        g_trace.mark(t->seq, "completer_takes");
         if (t->chained) {
             rc = chained_finish(h, c, t->n);  // synchronises the stream (kernel + result copies)
+            g_trace.mark(t->seq, "stream_synchronised");
             if (rc == kChainDeclined) {       // a block ran out of private frontier: the level loop, and the copies once more
                 {
                     std::lock_guard<std::mutex> tk(h->compute_mu);
@@ -203,6 +237,7 @@ void completer_loop(acl_engine_t *h, AsyncPool *P) {
             if (t->err && t->he != t->err) std::memcpy(t->err, t->he, t->n * sizeof(int32_t));
         }
         t->ev.end();
+        g_trace.mark(t->seq, "finished");
         finish(t, rc);
     }
 }
@@ -233,6 +268,7 @@ void async_shutdown(acl_engine_t *h) {
     P->ccv.notify_all();
     if (P->completer.joinable()) P->completer.join();
     delete P;
+    g_trace.dump();
 }
 
 }  // namespace aclint
@@ -255,6 +291,8 @@ int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n
         P = h->async;
     }
     auto t = std::make_unique<acl_ticket>();
+    t->seq = g_trace.seq.fetch_add(1, std::memory_order_relaxed);
+    g_trace.mark(t->seq, "submit");
     t->items = items;
     t->n = n;
     t->perm = perm_out;
@@ -274,9 +312,11 @@ int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *tp) {
     std::unique_ptr<acl_ticket> t(tp);
     int rc;
     std::string msg;
+    g_trace.mark(t->seq, "wait_begin");
     {
         std::unique_lock<std::mutex> lk(t->mu);
         t->cv.wait(lk, [&] { return t->done; });
+        g_trace.mark(t->seq, "wait_returns");
         rc = t->rc;
         msg = t->msg;
     }
