@@ -45,6 +45,7 @@ enum {
     ACL_ERR_DEADLINE_EXCEEDED = 4,   /* codes.DeadlineExceeded: acl_call_opts_t.timeout_ns elapsed (responsefilterer.go:44,196-204) */
     ACL_ERR_NOT_FOUND = 5,           /* codes.NotFound          */
     ACL_ERR_ALREADY_EXISTS = 6,      /* codes.AlreadyExists: CREATE of an existing relationship */
+    ACL_ERR_PERMISSION_DENIED = 7,   /* codes.PermissionDenied: acl_prefilter_response on a single object outside the allowed set ("unauthorized") */
     ACL_ERR_RESOURCE_EXHAUSTED = 8,  /* codes.ResourceExhausted: frontier capacity exceeded */
     ACL_ERR_FAILED_PRECONDITION = 9, /* codes.FailedPrecondition: precondition failed, unknown type/relation */
     ACL_ERR_OUT_OF_RANGE = 11,       /* codes.OutOfRange: watch cursor older than the retained change feed */
@@ -249,6 +250,20 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
  * acl_lookup_resources*: allowed_out[i] = 1 iff object_ids[i] (the rule's `ns/name` object id text) is set. */
 int acl_bitmap_test_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *const *object_ids, size_t n,
                           uint8_t *allowed_out);
+/* PreFilter consumers over the kube response's BYTES (responsefilterer.go:349-372 filterTable, :374-399 filterList, :401-416 filterObject):
+ * keeps the elements prefilterResult.IsAllowed(namespace, name) admits.  The reference maps every LookupResources id to a NamespacedName with
+ * the rule's fromObjectIDNameExpr / fromObjectIDNamespaceExpr (lookups.go:98-131) and tests set membership; here `id_template` is that mapping
+ * read the other way -- the object id of an item's (namespace, name), in the placeholder form of acl_filter_list_response: "{{name}}" for
+ * deploy/rules.yaml:51 (`{{resourceId}}`), "{{namespacedName}}" for rules.yaml:105-106 (split_namespace / split_name) -- and the id's bit in the
+ * bitmap of acl_lookup_resources* decides.  ACL_BODY_LIST: "items" (each item's metadata); ACL_BODY_TABLE: "rows" (each row's
+ * object.metadata; a row without a decodable object: ACL_ERR_INVALID_ARGUMENT, as the reference's decode error); an array without survivors
+ * becomes [] (both consumers start from an empty, non-nil slice).  ACL_BODY_OBJECT: the body comes back unchanged when its object is allowed,
+ * else ACL_ERR_PERMISSION_DENIED ("unauthorized": writeResp makes a 401 of it, responsefilterer.go:716-727).  The answer is the original
+ * bytes minus the dropped elements (release with acl_free); a body without the array comes back unchanged.  Needs no GPU.  (split_name /
+ * split_namespace cut at the first '/', pkg/rules/env.go:18-56: the one id shape the forward reading cannot reach is an id that BEGINS with '/'.) */
+typedef enum { ACL_BODY_LIST = 0, ACL_BODY_TABLE = 1, ACL_BODY_OBJECT = 2 } acl_body_kind_t;
+int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *id_template, int kind, const char *body,
+                           size_t body_len, char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out);
 /* Watch (watch.go:29-38): every update committed by acl_write / acl_delete_by_filter with revision > after_revision
  * whose resource type is in `types` (ntypes == 0: all), in commit order; op = ACL_OP_TOUCH or ACL_OP_DELETE.
  * after_revision == UINT64_MAX or cb == NULL only reports the head revision ("start from now").  *revision_out

@@ -381,3 +381,58 @@ func (e *Engine) FilterListResponseReq(body []byte, templates []string, userName
 	defer C.acl_free(unsafe.Pointer(out))
 	return C.GoBytes(unsafe.Pointer(out), C.int(n)), nil
 }
+
+// Allowed is a LookupResources result kept as the engine produced it: the allowed-id bitmap of one (resource type, permission, subject).  The
+// reference drains the stream into a set of NamespacedNames (pkg/authz/lookups.go:65-131); a caller that only wants the kube response filtered
+// keeps the bitmap and hands the response's bytes to FilterResponse.
+type Allowed struct {
+	e      *Engine
+	typeID C.int
+	bm     []C.uint32_t
+}
+
+// LookupAllowed runs the LookupResources of a PreFilter (lookups.go:49-83) and keeps its result as a bitmap.
+func (p *PermissionsClient) LookupAllowed(ctx context.Context, in *v1.LookupResourcesRequest) (*Allowed, error) {
+	st, err := p.LookupResources(ctx, in)
+	if err != nil {
+		return nil, err
+	}
+	bs := st.(*bitmapStream)
+	return &Allowed{e: p.e, typeID: bs.typeID, bm: bs.bm}, nil
+}
+
+// BodyKind says what the kube response holds: a list ("items"), a Table ("rows", Accept: ...;as=Table) or one object.
+type BodyKind int
+
+const (
+	BodyList BodyKind = iota
+	BodyTable
+	BodyObject
+)
+
+// FilterResponse is filterList / filterTable / filterObject (pkg/authz/responsefilterer.go:349-416) on the response's bytes: the elements
+// whose (namespace, name) the PreFilter admits stay, the others are cut out of the original bytes; a single object outside the set is the
+// reference's "unauthorized" (codes.PermissionDenied here; writeResp turns it into a 401, responsefilterer.go:716-727).  idTemplate is the
+// rule's fromObjectID mapping read forwards: "{{name}}" for `fromObjectIDNameExpr: {{resourceId}}` (deploy/rules.yaml:51),
+// "{{namespacedName}}" for split_namespace / split_name (rules.yaml:105-106).  Rules with other expressions keep using the stream.
+func (a *Allowed) FilterResponse(body []byte, kind BodyKind, idTemplate string) ([]byte, error) {
+	var cs cstrings
+	defer cs.free()
+	var bp *C.char
+	if len(body) > 0 {
+		bp = (*C.char)(unsafe.Pointer(&body[0]))
+	} else {
+		bp = cs.add("")
+	}
+	var bm *C.uint32_t
+	if len(a.bm) > 0 {
+		bm = &a.bm[0]
+	}
+	var out *C.char
+	var n C.size_t
+	if rc := C.acl_prefilter_response(a.e.h, a.typeID, bm, C.size_t(len(a.bm)), cs.add(idTemplate), C.int(kind), bp, C.size_t(len(body)), &out, &n, nil, nil); rc != 0 {
+		return nil, lastError(rc)
+	}
+	defer C.acl_free(unsafe.Pointer(out))
+	return C.GoBytes(unsafe.Pointer(out), C.int(n)), nil
+}

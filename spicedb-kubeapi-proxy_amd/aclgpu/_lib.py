@@ -27,7 +27,7 @@ SYMBOLS = [
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
-    "acl_lookup_one_submit", "acl_lookup_completions",
+    "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response",
 ]
 
 
@@ -190,6 +190,8 @@ def load():
                                                C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_filter_list_response.argtypes = [H, C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.acl_prefilter_response.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_free.argtypes = [C.c_void_p]
     L.acl_free.restype = None
     L.acl_check_one_opts.argtypes = [H, C.POINTER(CheckItem), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(CallOpts)]

@@ -367,6 +367,20 @@ class Engine:
         finally:
             self._L.acl_free(out)
 
+    BODY_LIST, BODY_TABLE, BODY_OBJECT = 0, 1, 2
+
+    def prefilter_response(self, rtype: str, bitmap: np.ndarray, id_template: str, kind: int, body: bytes):
+        """filterList / filterTable / filterObject (responsefilterer.go:349-416) on the kube response's bytes, with the LookupResources bitmap
+        as the allowed set -> (filtered body, kept, total).  A single object outside the set raises AclError(code 7, "unauthorized")."""
+        bm = np.ascontiguousarray(bitmap, dtype=np.uint32)
+        out, n, kept, total = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.acl_prefilter_response(self._h, self.type_id(rtype), bm.ctypes.data, bm.size, _b(id_template), kind, body, len(body), C.byref(out), C.byref(n),
+                                                   C.byref(kept), C.byref(total)))
+        try:
+            return C.string_at(out, n.value), kept.value, total.value
+        finally:
+            self._L.acl_free(out)
+
     def bitmap_test_names(self, rtype: str, bitmap: np.ndarray, object_ids):
         """prefilterResult.IsAllowed (lookups.go:25-36) over a LookupResources bitmap -> bool array."""
         bm = np.ascontiguousarray(bitmap, dtype=np.uint32)

@@ -12,6 +12,10 @@
 // Templates: the general rule language (Bloblang / CEL, pkg/rules) stays in Go (out of scope); this entry
 // point renders the placeholder form every shipped rule uses (deploy/rules.yaml:68 `pod:{{namespacedName}}#view@user:{{user.name}}`):
 // {{name}} {{namespace}} {{namespacedName}} {{user.name}}.  Rules that need more resolve in Go and call acl_check_bulk_keep.
+//
+// PreFilter consumers (acl_prefilter_response): the reference's filterList / filterTable / filterObject (pkg/authz/responsefilterer.go:
+// 349-416) keep what prefilterResult.IsAllowed(namespace, name) admits (lookups.go:25-36) -- here the LookupResources bitmap tested by the
+// object id the rule's inverse mapping gives an item, over the same scanned spans.
 #include "engine_internal.hpp"
 
 namespace {
@@ -241,6 +245,63 @@ bool render(const std::string &tpl, const Item &it, const std::string &user, std
     return true;
 }
 
+// a table row (metav1.TableRow): its "object" is the row's PartialObjectMetadata (responsefilterer.go:359-364); absent, null or not an object
+// = "error decoding partial object metadata from table row"
+bool scan_row(Scanner &s, Item *it, bool *decodable) {
+    *decodable = false;
+    s.ws();
+    if (s.p >= s.e || *s.p != '{') return s.skip();
+    it->is_object = true;
+    return s.object([&](const std::string &k) {
+        if (k != "object") return s.skip();
+        s.ws();
+        Item inner;
+        const bool obj = s.p < s.e && *s.p == '{';
+        if (!scan_item(s, &inner)) return false;
+        *decodable = obj;  // (a later duplicate "object" wins, as in Go's struct decode)
+        it->name = inner.name;
+        it->ns = inner.ns;
+        return true;
+    });
+}
+
+// the body with only the kept elements of the array at [arr_open, arr_close] ('[' and ']'); `none` = what an array without survivors becomes
+char *splice_kept(const char *body, size_t body_len, size_t arr_open, size_t arr_close, const std::vector<Item> &items, const std::vector<uint8_t> &keep, const char *none,
+                  size_t *out_len, size_t *kept_out) {
+    size_t kept = 0, bytes = arr_open + 1 + (body_len - arr_close) + std::strlen(none);
+    for (size_t i = 0; i < items.size(); i++)
+        if (keep[i]) {
+            kept++;
+            bytes += items[i].e - items[i].b + 1;
+        }
+    char *o = (char *)std::malloc(std::max<size_t>(bytes, 1) + 8), *w = o;
+    if (!o) return nullptr;
+    if (!kept) {
+        std::memcpy(w, body, arr_open);
+        w += arr_open;
+        std::memcpy(w, none, std::strlen(none));
+        w += std::strlen(none);
+        std::memcpy(w, body + arr_close + 1, body_len - arr_close - 1);
+        w += body_len - arr_close - 1;
+    } else {
+        std::memcpy(w, body, arr_open + 1);
+        w += arr_open + 1;
+        bool first = true;
+        for (size_t i = 0; i < items.size(); i++) {
+            if (!keep[i]) continue;
+            if (!first) *w++ = ',';
+            first = false;
+            std::memcpy(w, body + items[i].b, items[i].e - items[i].b);
+            w += items[i].e - items[i].b;
+        }
+        std::memcpy(w, body + arr_close, body_len - arr_close);
+        w += body_len - arr_close;
+    }
+    *out_len = (size_t)(w - o);
+    *kept_out = kept;
+    return o;
+}
+
 }  // namespace
 
 extern "C" {
@@ -339,39 +400,112 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     std::vector<uint8_t> keep(items.size());
     int rc = acl_check_bulk_keep(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
     if (rc) return rc;
-    // ---- splice: the original bytes minus the dropped items
-    size_t kept = 0, bytes = arr_open + 1 + (body_len - arr_close);
-    for (size_t i = 0; i < items.size(); i++)
-        if (keep[i]) {
-            kept++;
-            bytes += items[i].e - items[i].b + 1;
-        }
-    char *o = (char *)std::malloc(std::max<size_t>(bytes, 1) + 8), *w = o;
+    // ---- splice: the original bytes minus the dropped items (the reference appends to a nil slice, postfilter.go:142: with nothing allowed, "items" marshals as null)
+    size_t kept = 0;
+    char *o = splice_kept(body, body_len, arr_open, arr_close, items, keep, "null", out_len, &kept);
     if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
-    if (!kept) {
-        // the reference appends to a nil slice (postfilter.go:142): with nothing allowed, "items" marshals as null
-        std::memcpy(w, body, arr_open);
-        w += arr_open;
-        std::memcpy(w, "null", 4);
-        w += 4;
-        std::memcpy(w, body + arr_close + 1, body_len - arr_close - 1);
-        w += body_len - arr_close - 1;
-    } else {
-        std::memcpy(w, body, arr_open + 1);
-        w += arr_open + 1;
-        bool first = true;
-        for (size_t i = 0; i < items.size(); i++) {
-            if (!keep[i]) continue;
-            if (!first) *w++ = ',';
-            first = false;
-            std::memcpy(w, body + items[i].b, items[i].e - items[i].b);
-            w += items[i].e - items[i].b;
-        }
-        std::memcpy(w, body + arr_close, body_len - arr_close);
-        w += body_len - arr_close;
-    }
     *out_body = o;
-    *out_len = (size_t)(w - o);
+    if (kept_out) *kept_out = kept;
+    if (total_out) *total_out = items.size();
+    return ACL_OK;
+}
+
+int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, size_t bitmap_words, const char *id_template, int kind, const char *body, size_t body_len,
+                           char **out_body, size_t *out_len, uint64_t *kept_out, uint64_t *total_out) {
+    if (!body || !out_body || !out_len || !id_template || (bitmap_words && !bitmap) || kind < ACL_BODY_LIST || kind > ACL_BODY_OBJECT)
+        return fail(ACL_ERR_INVALID_ARGUMENT, "acl_prefilter_response: bad argument");
+    *out_body = nullptr;
+    *out_len = 0;
+    const std::string tpl = id_template;
+    auto unchanged = [&](uint64_t kept, uint64_t total) {
+        char *o = (char *)std::malloc(std::max<size_t>(body_len, 1));
+        if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
+        std::memcpy(o, body, body_len);
+        *out_body = o;
+        *out_len = body_len;
+        if (kept_out) *kept_out = kept;
+        if (total_out) *total_out = total;
+        return (int)ACL_OK;
+    };
+    Scanner s{body, body + body_len};
+    s.ws();
+    if (s.p >= s.e || *s.p != '{') return fail(ACL_ERR_INVALID_ARGUMENT, "failed to decode response body: not a JSON object");
+    std::vector<Item> items;
+    std::vector<uint8_t> decodable;  // tables: the row's object could be decoded
+    bool have = false;
+    size_t arr_open = 0, arr_close = 0;
+    Item single;
+    bool parsed;
+    if (kind == ACL_BODY_OBJECT) {
+        parsed = scan_item(s, &single);
+    } else {
+        const char *const key = kind == ACL_BODY_TABLE ? "rows" : "items";
+        parsed = s.object([&](const std::string &k) {
+            if (k != key || s.p >= s.e || *s.p != '[') {
+                if (k == key) have = false;
+                return s.skip();
+            }
+            have = true;
+            items.clear();
+            decodable.clear();
+            arr_open = (size_t)(s.p - body);
+            s.p++;
+            s.ws();
+            if (s.p < s.e && *s.p == ']') {
+                arr_close = (size_t)(s.p - body);
+                s.p++;
+                return true;
+            }
+            for (;;) {
+                s.ws();
+                Item it;
+                bool dec = true;
+                const char *b0 = s.p;
+                if (!(kind == ACL_BODY_TABLE ? scan_row(s, &it, &dec) : scan_item(s, &it))) return false;
+                it.b = (size_t)(b0 - body);
+                it.e = (size_t)(s.p - body);
+                decodable.push_back(dec && it.is_object);
+                items.push_back(std::move(it));
+                s.ws();
+                if (s.p < s.e && *s.p == ',') { s.p++; continue; }
+                if (s.p < s.e && *s.p == ']') {
+                    arr_close = (size_t)(s.p - body);
+                    s.p++;
+                    return true;
+                }
+                return s.fail();
+            }
+        });
+    }
+    s.ws();
+    if (!parsed || !s.ok || s.p != s.e) return fail(ACL_ERR_INVALID_ARGUMENT, "failed to decode response body: invalid JSON");
+    // ---- IsAllowed(namespace, name): the object id the rule maps this (namespace, name) to, looked up, its bit tested
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_prefilter_response: unknown object type");
+    const ObjectTable &ot = h->store.objects(type);
+    std::string idtext;
+    auto allowed = [&](const Item &it) {
+        uint32_t id;
+        return render(tpl, it, std::string(), &idtext) && ot.find(idtext, &id) && (size_t)(id >> 5) < bitmap_words && ((bitmap[id >> 5] >> (id & 31u)) & 1u);
+    };
+    if (kind == ACL_BODY_OBJECT) {  // responsefilterer.go:401-416: the object itself, or "unauthorized" (writeResp turns that into a 401 body)
+        if (!allowed(single)) return fail(ACL_ERR_PERMISSION_DENIED, "unauthorized");
+        return unchanged(1, 1);
+    }
+    if (!have) return unchanged(0, 0);  // (nothing to cut; the reference's re-encode would add an empty array)
+    for (size_t i = 0; i < items.size(); i++)
+        if (!decodable[i])
+            return fail(ACL_ERR_INVALID_ARGUMENT, kind == ACL_BODY_TABLE ? "error decoding partial object metadata from table row" : "failed to decode response body: list item is not an object");
+    std::vector<uint8_t> keep(items.size());
+    for (size_t i = 0; i < items.size(); i++) keep[i] = allowed(items[i]);
+    nlk.unlock();
+    // both consumers start from make([]T, 0): an array without survivors is [], not null (responsefilterer.go:358,375)
+    size_t kept = 0;
+    char *o = items.empty() ? nullptr : splice_kept(body, body_len, arr_open, arr_close, items, keep, "[]", out_len, &kept);
+    if (items.empty()) return unchanged(0, 0);
+    if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
+    *out_body = o;
     if (kept_out) *kept_out = kept;
     if (total_out) *total_out = items.size();
     return ACL_OK;

@@ -69,6 +69,21 @@ def test_postfilter_and_prefilter_mirror(aclgpu):
         pre = v1.PrefilterResult.run_lookup_resources(e, v1.LookupResourcesRequest("pod", "view", v1.SubjectReference(v1.ObjectReference("user", "paul"))))
         assert pre.filter(["ns/p1", "ns/p2", "ns/p3", "other/p1", "nope/nope"]) == [True, False, True, True, False]
         assert pre.is_allowed("ns/p3") and not pre.is_allowed("ns/p2")
+        # the same result applied to the kube response's bytes (responsefilterer.go:349-416): list, `kubectl get`'s Table, single object
+        import json
+        pods = ["ns/p1", "ns/p2", "ns/p3", "other/p1", "nope/nope"]
+        md = lambda p: {"namespace": p.split("/")[0], "name": p.split("/")[1]}  # noqa: E731
+        body = json.dumps({"kind": "PodList", "items": [{"metadata": md(p), "spec": {}} for p in pods]}).encode()
+        out, kept, total = e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_LIST, body)
+        assert [f'{i["metadata"]["namespace"]}/{i["metadata"]["name"]}' for i in json.loads(out)["items"]] == ["ns/p1", "ns/p3", "other/p1"] and (kept, total) == (3, 5)
+        table = json.dumps({"kind": "Table", "rows": [{"cells": [p], "object": {"kind": "PartialObjectMetadata", "metadata": md(p)}} for p in pods]}).encode()
+        out, kept, _ = e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_TABLE, table)
+        assert [r["cells"][0] for r in json.loads(out)["rows"]] == ["ns/p1", "ns/p3", "other/p1"] and kept == 3
+        one = json.dumps({"kind": "Pod", "metadata": md("ns/p3")}).encode()
+        assert e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_OBJECT, one)[0] == one
+        with pytest.raises(Exception) as x:
+            e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_OBJECT, json.dumps({"metadata": md("ns/p2")}).encode())
+        assert x.value.code == 7
 
 
 def test_micro_batcher_concurrent_single_checks(aclgpu):
