@@ -265,7 +265,6 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     h->snap_valid = true;
     h->dev_valid = true;
     h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
-    h->filter_op = pick_filter_op(h->snap);
     h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_compactions++;
@@ -348,7 +347,6 @@ int ensure_snapshot(acl_engine *h) {
     HIP_TRY(hipStreamSynchronize(s));
     h->dev_valid = true;
     h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
-    h->filter_op = pick_filter_op(h->snap);
     h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);  // (the single-launch kernel's LDS depends on the schema)
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
@@ -1388,7 +1386,6 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
-    if (const char *ev = getenv("ACL_LOCAL_FILTER")) h->local_filter = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave

@@ -298,8 +298,6 @@ struct acl_engine {
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
     int local_blocks = 1024;   // resident blocks of the single-launch kernel (4 waves per block)
     int local_blocks_wide = 512;  // ... of its 16-wave instantiation
-    bool local_filter = true;     // k_check_local keeps a membership filter per request (ACL_LOCAL_FILTER=0: off, A/B knob)
-    uint32_t filter_op = 0xFFFFFFFFu;  // ... over this hashed probe of the current device snapshot (plan.hpp pick_filter_op)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
     uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)
     uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
@@ -358,7 +356,7 @@ struct acl_engine {
 
 
     DevGraph dev_graph() const {
-        return DevGraph{d_meta.p, d_edges.p, d_buckets.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size(), local_filter ? filter_op : 0xFFFFFFFFu};
+        return DevGraph{d_meta.p, d_edges.p, d_buckets.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
     }
     DevFrontier dev_frontier(const PassCtx &c) const {
         DevFrontier f;

@@ -139,7 +139,6 @@ struct TaskLds {
 struct WaveOutCold {  // what only the chunk switch / overflow paths need: kept in LDS, not in ~10 SGPRs for the whole kernel
     uint32_t *counts, *nchunks, *overflow;
     uint32_t nwaves, max_chunks, cap;
-    uint32_t filt_base, req0;  // membership filters: `base` of the hashed probe they summarise (~0: none), the unit's first request
 #if ACL_PROFILE_PHASES
     uint32_t last, prof[16];
 #endif
@@ -149,7 +148,6 @@ struct WaveOut {
     uint32_t cur, fill, produced;
     WaveOutCold *cold;  // LDS
     uint32_t *lfill;    // LOCAL: the block's output cursor (LDS) -- the block's waves append to one region
-    const uint32_t *filt;  // LOCAL, 16-wave blocks: the unit's membership filters (LDS, 4 words per request; see k_check_local), or nullptr
 };
 
 // room for `need` (<= kChunk) consecutive entries; returns the first entry index
@@ -223,11 +221,6 @@ __device__ __forceinline__ bool bucket_pair_has(const uint4 &p, const uint4 &q, 
     m = min(min(m, q.y ^ want), q.z ^ want);
     return min(m, q.w ^ want) == 0u;
 }
-// Bloom bits of an id in a request's 128-bit membership filter (k_check_local): the top 7 bits of the two products the bucket hashes use
-__device__ __forceinline__ uint32_t filter_bit1(uint32_t id) { return (id * 0x9E3779B1u) >> 25; }
-__device__ __forceinline__ uint32_t filter_bit2(uint32_t id) { return ((id ^ 0x5bd1e995u) * 0x85EBCA6Bu) >> 25; }
-constexpr uint32_t kLocalWideUnit = 512;  // requests of a 16-wave block's unit, at most (its filters: 512 x 16 B of LDS)
-constexpr uint32_t kFilterBuckets = 32;  // rows up to 32 buckets (128 ids) are summarised; a longer one would saturate 128 bits anyway
 __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
     uint32_t h1, h2;
     hashed_row_buckets(want, b1 - b0, &h1, &h2);
@@ -328,8 +321,6 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     uint4 *__restrict__ out = wo.buf;
     uint32_t skipped = 0;
-    const uint32_t *filt = (LOCAL && wo.filt && pop.base == uniform(wo.cold->filt_base)) ? wo.filt : nullptr;
-    const uint32_t req0 = filt ? uniform(wo.cold->req0) : 0u;
     // ONE round for the whole list (<= kTaskCap = 128 tasks): every lane owns tasks `lane` and `64 + lane`.  Two rounds of 64 paid this
     // prologue -- a chain of dependent LDS round trips: counts, scan, head bits, fences -- twice per pair of segments
     // (17 % of the walk's wave-time, profiles/r02_walk_phase_breakdown.txt).
@@ -401,18 +392,10 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                     const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, bucket count, request} in one 16-byte read
                     rq[k] = ta.w;
                     uint32_t h1, h2;
-                    const uint32_t cid = edge[k0 + k] & kIdMask;
-                    hashed_row_buckets(cid, ta.z, &h1, &h2);
-                    uint32_t a1 = ta.y + h1, a2 = ta.y + h2;
-                    if (LOCAL && filt) {  // (wave-uniform) a child that misses its request's filter is not in the row: both gathers go to the reserved empty bucket
-                        const uint32_t x1 = filter_bit1(cid), x2 = filter_bit2(cid);
-                        const uint32_t *f = filt + (ta.w - req0) * 4u;
-                        const bool maybe = ((f[x1 >> 5] >> (x1 & 31u)) & (f[x2 >> 5] >> (x2 & 31u)) & 1u) != 0u;
-                        a1 = maybe ? a1 : 0u;
-                        a2 = maybe ? a2 : 0u;
-                    }
-                    p[k] = gld(buckets, a1);
-                    q[k] = gld(buckets, a2);
+                    hashed_row_buckets(edge[k0 + k] & kIdMask, ta.z, &h1, &h2);
+                    const uint32_t b0 = ta.y;
+                    p[k] = gld(buckets, b0 + h1);
+                    q[k] = gld(buckets, b0 + h2);
                 }
                 issue_fence();  // trip 2: the 2 x W buckets
                 ACL_MARK(wo, PH_BUCKETS);
@@ -972,8 +955,6 @@ __device__ __forceinline__ WaveOut chunked_out(const DevFrontier &f, uint32_t it
     wo.fill = 0;
     wo.produced = 0;
     wo.cold = cold;
-    wo.lfill = nullptr;
-    wo.filt = nullptr;
     return wo;
 }
 
@@ -1111,14 +1092,6 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
     __shared__ uint32_t s_fill[3], s_next[3], s_stop, s_unit;
     extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
-    // Membership filters (16-wave blocks; a 4-wave block's LDS budget has no room for them): 128 bits per request of the unit, a Bloom
-    // summary (two bits per id) of the SUBJECT's hashed row in the class that the walk keeps probing -- `group#member@user` under nested
-    // groups: every group a request reaches asks "is the user in it?", 150-400 times per request, against the same 2-4 cache lines.  Those
-    // lines do not survive in the L2 from one level to the next (32 k requests in flight per XCD x 128-256 B > 4 MB), so every level
-    // fetched them again: beyond the Infinity Cache that is most of the launch's traffic (profiles/r03_c5r_levels_pmc.txt).  A child whose
-    // id misses the filter is not in the row -- no false negatives -- and sends both of its bucket gathers to the reserved empty bucket instead.
-    constexpr bool FILT = WAVES == kLocalWide;
-    __shared__ uint4 s_filt[FILT ? kLocalWideUnit : 1];  // (8 KB: a 16-wave block's units are capped at 512 requests so that two blocks still share a CU's 160 KB)
     const SlotProg *progs;
     const FwdOp *ops;
     load_programs<LDSPROG>(g, s_prog, progs, ops, WAVES * 64);
@@ -1127,13 +1100,10 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     TaskLds &t = lds[wib];
     const DevShard nosh{};
     uint4 *bufs[2] = {buf0 + (size_t)blockIdx.x * cap, buf1 + (size_t)blockIdx.x * cap};
-    const bool filt_on = FILT && g.filter_op != 0xFFFFFFFFu;
-    const FwdOp fop = filt_on ? ops[g.filter_op] : FwdOp{};
     if (lane == 0) {
         s_cold[wib] = WaveOutCold{};
         s_cold[wib].overflow = overflow;
         s_cold[wib].cap = cap;
-        s_cold[wib].filt_base = filt_on ? fop.base : 0xFFFFFFFFu;
 #if ACL_PROFILE_PHASES
         s_cold[wib].last = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -1145,7 +1115,6 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     wo.produced = 0;
     wo.cold = &s_cold[wib];
     wo.lfill = &s_fill[1];
-    wo.filt = filt_on ? reinterpret_cast<const uint32_t *>(s_filt) : nullptr;
     // units [0, nstatic) hold rpw requests each (block b starts on unit b: no hand-out); the requests behind them come in SMALL units of rdyn,
     // handed out through `next_unit` as blocks finish -- the launch's tail is then a small unit's walk, not the slowest big unit's
     const uint32_t nstat_req = min(n, nstatic * rpw);
@@ -1173,36 +1142,6 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             const uint32_t meta = ok ? make_meta(rbase + perm, 1u, srel == 0xFFFFu ? g.nslots + stype : sbase + srel) : kDeadMeta;
             e = make_uint4(it.y, req, meta, it.w);
         }
-        if (filt_on && valid && threadIdx.x < kLocalWideUnit) {  // this request's filter (valid: thread < the unit's requests <= kLocalWideUnit): every id of its subject's row, or all ones (= always probe) where the row is long or not this class's
-            uint4 f = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (e.z != kDeadMeta && meta_key(e.z) == fop.key) {
-                const uint2 d = e.w < fop.nrows ? gld(reinterpret_cast<const uint2 *>(g.meta), fop.base + e.w) : make_uint2(0u, 0u);
-                const uint32_t nb = d.y > d.x ? d.y - d.x : 0u;
-                if (nb <= kFilterBuckets) {
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    const uint4 *__restrict__ bk = reinterpret_cast<const uint4 *>(g.buckets);
-                    for (uint32_t b = 0; b < nb; b += 4) {  // four buckets in flight
-                        uint4 v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) v[q] = gld(bk, d.x + min(b + q, nb - 1));
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const uint32_t ids[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                if (ids[c] == 0xFFFFFFFFu) continue;  // empty slot
-                                const uint32_t x1 = filter_bit1(ids[c]), x2 = filter_bit2(ids[c]);
-#pragma unroll
-                                for (int k = 0; k < 4; k++) w[k] |= ((x1 >> 5) == (uint32_t)k ? 1u << (x1 & 31u) : 0u) | ((x2 >> 5) == (uint32_t)k ? 1u << (x2 & 31u) : 0u);
-                            }
-                        }
-                    }
-                    f = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            }
-            s_filt[threadIdx.x] = f;
-        }
-        if (filt_on && lane == 0) s_cold[wib].req0 = first;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         wo.buf = bufs[0];
         wo.cur = 0;
@@ -1927,7 +1866,7 @@ int local_grid_blocks(int device, size_t prog_bytes, bool wide) {
     const bool lds = prog_in_lds() && prog_bytes <= (size_t)kProgLdsEntries * 32;
     return cus * (wide ? local_occupancy<kLocalWide>(lds, prog_bytes) : local_occupancy<kLocalNarrow>(lds, prog_bytes));
 }
-uint32_t local_unit_max(bool wide) { return wide ? kLocalWideUnit : (uint32_t)kLocalNarrow * 64u; }
+uint32_t local_unit_max(bool wide) { return (uint32_t)(wide ? kLocalWide : kLocalNarrow) * 64u; }
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {
     (void)hipMemsetAsync(table, 0xFF, sizeof(uint64_t) << bits, s);
     hipLaunchKernelGGL(k_dedup, dim3(f.nwaves / kWavesPerBlock), dim3(256), 0, s, f, iter, reinterpret_cast<unsigned long long *>(table), bits);

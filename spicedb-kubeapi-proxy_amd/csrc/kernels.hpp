@@ -32,7 +32,6 @@ struct DevGraph {
     const SlotProg *progs;
     const uint32_t *type_slot_base, *type_nmembers;
     uint32_t nslots, ntypes, nops;
-    uint32_t filter_op = 0xFFFFFFFFu;  // k_check_local's per-request membership filter: index of the hashed probe it summarises (plan.hpp pick_filter_op); ~0: none
 };
 struct DevReverse {
     const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids

@@ -161,34 +161,6 @@ void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
 // activities per kube write (workflow.go:392-418, activity.go:81-102), so types that START empty grow by thousands of ids between two
 // compactions -- with 1 024 spare ids the tables of `activity` were outgrown every ~500 kube writes, faster than a background build of the
 // 10 M graph finishes (9 synchronous rebuilds in 37 k kube writes, profiles/r03_dual_write_before.json).  8 B per spare id and class.
-uint32_t pick_filter_op(const Snapshot &s) {
-    const uint32_t n = (uint32_t)s.progs.size();
-    auto children = [&](uint32_t slot, std::vector<uint32_t> *out) {
-        const SlotProg &p = s.progs[slot];
-        for (uint32_t j = p.first; j < p.first + p.n_total && j < s.ops.size(); j++)
-            if ((s.ops[j].flags & (OP_ENUM | OP_PUSH_SAME)) && s.ops[j].key < n) out->push_back(s.ops[j].key);
-    };
-    uint32_t best = 0xFFFFFFFFu;
-    for (uint32_t slot = 0; slot < n; slot++) {
-        const SlotProg &p = s.progs[slot];
-        if (p.n_probe != 1 || p.first >= s.ops.size() || s.ops[p.first].flags != OP_PROBE_HASH) continue;  // (what flush_simple expands)
-        std::vector<uint8_t> seen(n, 0);
-        std::vector<uint32_t> todo;
-        children(slot, &todo);
-        bool back = false;
-        while (!todo.empty() && !back) {
-            const uint32_t c = todo.back();
-            todo.pop_back();
-            if (c == slot) back = true;
-            else if (!seen[c]) {
-                seen[c] = 1;
-                children(c, &todo);
-            }
-        }
-        if (back && (best == 0xFFFFFFFFu || s.ops[p.first].nrows > s.ops[best].nrows)) best = p.first;
-    }
-    return best;
-}
 uint32_t with_headroom(uint32_t n) { return n + n / 4 + 16384; }
 
 uint32_t shard_of_type(const std::string &type_name, uint32_t world) {

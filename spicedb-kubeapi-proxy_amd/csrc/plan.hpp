@@ -155,10 +155,6 @@ void expiry_crossings(const Store &store, int64_t lo, int64_t hi, int64_t now, s
 // (`from_revision` = the snapshot's revision BEFORE patch_forward).  false: rebuild the reverse rows instead.
 bool patch_reverse(Store &store, int64_t now, uint64_t from_revision, Snapshot *snap, ShardSpec shard, std::vector<Patch> *patches);
 uint32_t with_headroom(uint32_t n);
-// The hashed probe k_check_local summarises per request (kernels.hip, membership filters): the one probe of a state the walk comes back to --
-// a slot that reaches itself through its enumerating ops (`group#member` under nested groups), whose program is exactly that probe plus
-// what creates children.  Several: the one over the most subjects.  ~0: the schema has no such state (no filter, nothing changes).
-uint32_t pick_filter_op(const Snapshot &snap);
 bool verify_snapshot(Store &store, int64_t now, const Snapshot &snap, ShardSpec shard, std::string *why);
 void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard = ShardSpec());
 
