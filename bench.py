@@ -385,7 +385,7 @@ def c5_bench(args, w, world, rank, local_rank, t_gen):
 SHARDED_CHECKPOINT = None  # set in the isolated child: called on rank 0 after every exchange form with the results so far
 
 
-def isolated_sharded_leg(rank, world, timeout_s=300.0):
+def isolated_sharded_leg(rank, world, timeout_s=180.0):
     """Runs the sharded leg of this very command line in CHILD processes (one per rank, a process group of their own on another port)
     and returns rank 0's result.  The leg drives RCCL paths that the one-GPU development boxes cannot exercise for real (grouped
     send/recv, the library's own communicator): whatever they do on a real 8-GPU node -- a crash, a wedged collective -- the parent

@@ -231,12 +231,14 @@ def test_walk_overflow_falls_back_and_backs_off(aclgpu, monkeypatch):
         assert np.array_equal(p, op[:64]) and np.array_equal(er, oe[:64])
 
 
-def test_frontier_overflow_grows(aclgpu):
-    """A frontier too small for the batch is grown and the pass redone -- same answers."""
+def test_frontier_overflow_grows(aclgpu, monkeypatch):
+    """A frontier too small for the batch is grown and the pass redone -- same answers.  (The LEVEL LOOP's frontier: the single-launch walk,
+    whose blocks may or may not fit their regions at this size, is switched off for the first engine.)"""
     from aclgpu import workloads
     w = workloads.c4(scale=0.02, batch=600000, n_user=20000)
     o = orc.Oracle(w.schema)
     w.load(o)
+    monkeypatch.setenv("ACL_LOCAL_MAX", "0")  # (read at acl_open)
     # the smallest legal frontier: one static chunk per wave + 1 dynamic chunk -> the deep levels overflow it
     with aclgpu.Engine(w.schema, frontier_entries=4096) as e:
         w.load(e)
@@ -245,7 +247,8 @@ def test_frontier_overflow_grows(aclgpu):
         op, oe = o.check_bulk_ids("pod", "view", w.res[:m], "user", "", w.subj[:m])
         assert np.array_equal(p[:m], op) and np.array_equal(er[:m], oe)
         assert e.stats()["overflow_retries"] >= 1
-    with aclgpu.Engine(w.schema) as e2:  # same batch with the default frontier: identical bytes
+    monkeypatch.delenv("ACL_LOCAL_MAX")
+    with aclgpu.Engine(w.schema) as e2:  # same batch with the default frontier (and the single-launch walk): identical bytes
         w.load(e2)
         p2, er2 = e2.check_bulk_ids(e2.make_items("pod", "view", w.res, "user", "", w.subj))
         assert np.array_equal(p, p2) and np.array_equal(er, er2)
