@@ -27,7 +27,9 @@ scaling, no data-path collective: requests are independent -- SURVEY.md 8(e)); t
 synchronize and the MAX over ranks is reported.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` (algorithmic bytes of the WHOLE batch from the oracle's byte model,
-multi-threaded, with its per-level split / HIP-event kernel time vs HBM peak), `cpu_baseline` (the CPU oracle, a restatement of
+multi-threaded, with its per-level split / HIP-event kernel time vs HBM peak; `traffic` = HBM bytes per launch MEASURED IN THE RUN at N=1 --
+the device leg of this very command re-run under two rocprofv3 --pmc passes, ~5 s -- or, for the other configurations and N > 1, the
+figure of profiles/traffic.json from an earlier run's passes, labelled), `cpu_baseline` (the CPU oracle, a restatement of
 SpiceDB's dispatch -- NOT the embedded SpiceDB, which cannot be built here -- timed on a bounded sample of the same batch on
 this box's host cores and used at the same time to verify the GPU answers), and `configs` = {C2, C3}: the other single-GPU
 BASELINE configurations measured in the same run, each with its own roofline / cpu_baseline / parity; `single_checks` = the proxy's own
@@ -887,6 +889,12 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
                                      "correction applied), NOT measured in this run"}
         except Exception:  # noqa: BLE001
             pass
+    if getattr(args, "traffic", "static") == "measure":
+        m = measure_traffic(args, label, k["name"])
+        if m.get("bytes_per_launch"):
+            traffic, traffic_detail = float(m["bytes_per_launch"]), m
+        elif traffic_detail is not None:
+            traffic_detail["live_measurement_failed"] = m.get("error")
     rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                        "traffic_detail": traffic_detail, "kernel": k["name"], "kernel_avg_us": 1e3 * k["ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
                        "measured_in": "device_resident leg (sequential launches, HIP events on the launching stream)",
@@ -894,6 +902,65 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
                        "algorithmic_bytes_by_model_level": [int(x) for x in lvl_b[1:nz]], "distinct_states_by_model_level": [int(x) for x in lvl_s[1:nz]],
                        "model": "oracle byte counter over all items (level-synchronous, sorted-row probes; the model's levels count every computed "
                                 "userset as a dispatch, the kernels inline them)", "model_seconds": round(t_bytes, 2)}
+
+
+def measure_traffic(args, label, kernel):
+    """HBM traffic of `kernel` per launch, measured NOW: this command's device-resident leg re-run twice under `rocprofv3 --kernel-trace --pmc`
+    (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; no other trace domain), mean over the
+    child's launches; reads x2 for gfx950's FETCH_SIZE under-count (the guide's correction; raw figures beside it).  {"error": ...} when
+    rocprofv3 is missing or a pass fails -- the caller then keeps the figure of profiles/traffic.json, labelled as such."""
+    import glob
+    import shutil
+    import signal
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--scale", str(args.scale), "--steps", "3", "--warmup", "1", "--no-cpu", "--legs", "device",
+             "--configs", "off", "--strings", "off", "--traffic", "static"]
+    if label == "C2":
+        child[child.index("--workload") + 1] = "C2"
+    if args.batch and label != "C2":
+        child += ["--batch", str(args.batch)]
+    if label == "C5R":
+        child += ["--replica"]
+    per = {}
+    t0 = time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="aclgpu_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k_, None)
+            pr = subprocess.Popen([exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "r", "--"] + child, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                                  stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)  # (the session this call started: nothing else is in it)
+                pr.wait()
+                return {"error": f"rocprofv3 --pmc {ctr} pass did not finish within 150 s"}
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if pr.returncode or not dbs:
+                return {"error": f"rocprofv3 --pmc {ctr} pass failed (rc {pr.returncode})"}
+            con = sqlite3.connect(dbs[0])
+            try:
+                rows = con.execute("select value from counters_collection where counter_name=? and kernel_name like ?", (ctr, f"%{kernel}%")).fetchall()
+            finally:
+                con.close()
+            if not rows:
+                return {"error": f"no {ctr} samples of {kernel}"}
+            per[ctr] = (sum(r[0] for r in rows) / len(rows) * 1024.0, len(rows))  # KiB -> bytes
+        except Exception as ex:  # noqa: BLE001
+            return {"error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w_ = per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    return {"bytes_per_launch": 2 * f + w_, "fetch_bytes_raw": f, "write_bytes": w_, "bytes_per_launch_raw": f + w_, "launches_sampled": per["FETCH_SIZE"][1],
+            "seconds": round(time.time() - t0, 1),
+            "source": "measured in THIS run: the device-resident leg of this command re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE "
+                      "(separate passes, mean over the launches; gfx950 x2 FETCH correction applied, raw figures beside it)"}
 
 
 def launch_ranks(n, dry):
@@ -949,6 +1016,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--strings", default="on", choices=["on", "off"], help="name every pod and user (string-path leg on named objects); off: ids only")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "static"],
+                    help="roofline.traffic: measure = two rocprofv3 --pmc passes of this command's device leg, now (about 25 s); static = profiles/traffic.json "
+                         "(an earlier run's passes, labelled); auto = measure for the headline workload at N=1 with the CPU legs on")
     ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
@@ -984,6 +1054,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dry_spawn:
         return dry_spawn(world, rank, local_rank)
+    if args.traffic == "auto":  # (every rank of an N > 1 run would need a profiler pass of its own; the other configurations keep the committed figures)
+        args.traffic = "measure" if (world == 1 and not args.no_cpu and args.legs == "all" and not args.sharded_child) else "static"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU evaluation path")
     if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
@@ -1146,7 +1218,9 @@ def main():
             r2["metric"], r2["unit"] = "check_decisions_per_sec", "decisions/s"
             if not args.no_cpu:
                 r2["_steps"] = max(args.steps, 50)
+                tmode, args.traffic = args.traffic, "static"
                 cpu_and_roofline(args, w2, r2, p2, er2, "C2")
+                args.traffic = tmode
                 r2.pop("_steps")
             else:
                 r2.pop("kernel", None)
