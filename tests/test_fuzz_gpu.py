@@ -1,0 +1,20 @@
+"""A short run of tools/fuzz_gpu.py as a regression test: the engine and the CPU oracle mutate the same nested-group / arrow graph step by step
+(write batches with every update kind, filter deletes) and answer the same Check batches (1 ... 70 000 items), single checks through the
+micro-batcher and LookupResources requests in between -- every answer, error code and id set equal.  The long campaigns are run by hand
+(tools/fuzz_gpu.py --seed S --steps N [--burst B --universe U]); profiles/r03_fuzz.txt holds this round's."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(burst=300, universe=3))], ids=["small-universe", "write-bursts"])
+def test_differential_fuzz(seed, kw, aclgpu_lib):
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    st = fz.run(seed, 120 if not kw else 60, verbose=False, **kw)  # (the oracle's brute-force lookups are what takes the time: ~10 s and ~20 s)
+    assert st["writes"] > 10 and st["checks"] > 1000 and st["lookups"] > 5 and st["snapshot_patches"] > 5
