@@ -10,6 +10,9 @@
 // Threading: engine_internal.hpp (state_mu / names_mu / PassCtx pool).
 #include "engine_internal.hpp"
 
+#include <pthread.h>
+#include <sched.h>
+
 namespace aclint {
 
 thread_local std::string g_last_error;
@@ -990,8 +993,55 @@ struct InternPool {
             done_cv.notify_one();
         }
     }
+    // The workers stay on the NUMA node of the thread that creates the pool (the first large string batch's caller): the name tables were
+    // filled from that side, and on a two-socket host a worker that lands on the other socket pays a remote access for every slot it probes --
+    // the same binary measured 0.34 ms or 0.55 ms per 65 536-item call depending on where the scheduler had put the threads
+    // (profiles/r03_string_path_ab.txt).  ACL_INTERN_PIN=0: leave them to the scheduler.
+    static bool node_cpus(cpu_set_t *out) {
+        const int cpu = sched_getcpu();
+        if (cpu < 0) return false;
+        cpu_set_t allowed;
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+        for (int node = 0; node < 64; node++) {
+            char path[96];
+            std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+            FILE *f = std::fopen(path, "r");
+            if (!f) break;
+            char buf[4096];
+            const bool got = std::fgets(buf, sizeof(buf), f) != nullptr;
+            std::fclose(f);
+            if (!got) continue;
+            CPU_ZERO(out);
+            bool mine = false;
+            int n = 0;
+            for (const char *q = buf; *q && *q != '\n';) {  // "0-63,128-191"
+                char *end = nullptr;
+                const long a = std::strtol(q, &end, 10);
+                if (end == q) break;
+                long b = a;
+                q = end;
+                if (*q == '-') {
+                    b = std::strtol(q + 1, &end, 10);
+                    q = end;
+                }
+                for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+                    if (CPU_ISSET((int)c, &allowed)) {
+                        CPU_SET((int)c, out);
+                        n++;
+                        mine = mine || c == cpu;
+                    }
+                if (*q == ',') q++;
+            }
+            if (mine && n >= 2) return true;
+        }
+        return false;
+    }
     explicit InternPool(unsigned nthreads) {
         for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this, i] { loop(i); });
+        const char *ev = getenv("ACL_INTERN_PIN");
+        cpu_set_t set;
+        if (!(ev && atoi(ev) == 0) && node_cpus(&set))
+            for (auto &t : threads) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
     }
     ~InternPool() {
         {
