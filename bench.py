@@ -5,7 +5,7 @@ A "step" = one pass of the hot path (bulk Check through the C ABI) over one batc
 workload: C4 (10 M relationships / 1 M objects, 5-level nested groups, 256 k-item batch) -- the configuration
 BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
 
-  value             (ii) the ABI call that takes HOST ids -- H2D + kernels + D2H: K steps over 8 distinct pre-generated
+  value             (ii) the ABI call that takes HOST ids -- items and answers cross PCIe inside the call: K steps over 8 distinct pre-generated
                     batches in pinned host memory, issued by `--callers` (default 2) host threads that each block in
                     acl_check_bulk_ids -- what goroutines behind the cgo shim do -- so that the copies of one batch overlap
                     the kernels of another (the engine's evaluation contexts, one HIP stream each; chip-filling batches'
@@ -752,8 +752,7 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     rec["elapsed"] = elapsed
     rec["host_ids"] = {"decisions_per_s": n * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "distinct_batches": NB, "answers_equal_device_leg": host_ok,
                        "mode": (f"acl_check_bulk_ids_submit/wait, {window} in flight" if args.pipeline == "submit" else f"{callers} caller thread(s) in blocking acl_check_bulk_ids"),
-                       "note": "pinned host buffers: H2D + kernels + D2H per batch; with several callers a batch's copies overlap another batch's kernels "
-                               "(chip-filling batches run their kernels one batch at a time)"}
+                       "note": "pinned host buffers in, pinned host buffers out: the items and the answers cross PCIe inside every call -- read and written by the kernel itself where the single-launch walk takes the batch (no copies), H2D + kernels + D2H otherwise"}
     # ---------------- batch latency: >= 200 single unpipelined host-id calls (SURVEY.md 8(d) "p50 over >= 200 batches after 20 warm-ups")
     nl = max(200, steps)
     lat = []
@@ -1162,7 +1161,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec.pop("workload"), "batch_per_gpu": rec.pop("batch"), "relationships": rec.pop("relationships"),
                        "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)",
-                       "timed": "host-id ABI calls (H2D + kernels + D2H) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
+                       "timed": "host-id ABI calls (host buffers in, host buffers out: PCIe both ways inside the call) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
                                 else "device-resident calls only (--legs device)"},
             "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
             "setup_s": {"generate": round(t_gen, 2), "name_objects": round(t_names, 2), "load+snapshot": round(t_load, 2)},

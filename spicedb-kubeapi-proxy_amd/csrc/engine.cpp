@@ -586,33 +586,45 @@ int chained_finish(acl_engine *h, PassCtx *c, size_t n) {
 // and writes the answers (and its overflow flag) straight back into pinned host memory, so a pass is ONE launch and ONE
 // stream synchronisation -- no H2D, no flag memset, no D2H copies, each of which costs a few microseconds of API time that a
 // 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
-static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out) {
+static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out, bool *attempted) {
+    *attempted = false;
     const LocalGeom G = local_geom(h, c, n);
-    if (G.cap < 256 || n > 8192 || G.nunits > G.nblocks) return kTakeLevelLoop;  // (a large batch is better copied than read across PCIe by the kernel)
+    if (G.cap < 256 || n > h->hostmap_max || G.nunits > G.nblocks) return kTakeLevelLoop;  // (units handed out through a device counter: the copying path)
+    *attempted = true;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    if ((const void *)items != c->h_in.p) {
+    // the caller's own buffers where they are pinned (acl_host_alloc), else the context's pinned staging
+    const void *src = items;
+    if ((const void *)items != c->h_in.p && !h->is_pinned(items, (size_t)n * sizeof(acl_item_t))) {
         HIP_TRY(c->h_in.ensure((size_t)n * sizeof(acl_item_t)));
         std::memcpy(c->h_in.p, items, (size_t)n * sizeof(acl_item_t));
+        src = c->h_in.p;
     }
+    const bool pin_p = h->is_pinned(perm_out, n), pin_e = err_out && h->is_pinned(err_out, (size_t)n * sizeof(int32_t));
     HIP_TRY(c->h_out.ensure(64 + (size_t)n * 5));
     uint32_t *flag = (uint32_t *)c->h_out.p;
-    int32_t *h_err = (int32_t *)((char *)c->h_out.p + 64);
-    uint8_t *h_perm = (uint8_t *)(h_err + n);
+    int32_t *h_err = pin_e ? err_out : (int32_t *)((char *)c->h_out.p + 64);
+    uint8_t *h_perm = pin_p ? perm_out : (uint8_t *)c->h_out.p + 64 + (size_t)n * 4;
     *flag = 0;
-    void *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&d_in, c->h_in.p, 0));
-    HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
+    void *d_in = nullptr, *d_flag = nullptr, *d_perm = nullptr, *d_errp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_in, const_cast<void *>(src), 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_flag, c->h_out.p, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_perm, h_perm, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_errp, h_err, 0));
+    // (No turn-taking between callers here, whatever the batch size: two single-launch kernels on the chip at once do not get in each other's
+    //  way -- the second one's blocks move in as the first one's finish, which fills the tail a lone launch leaves idle: 2 / 4 / 8 / 16 callers
+    //  with 262 144-item batches measure 886 / 890 / 914 / 916 M decisions/s, ABOVE the 873 M/s of back-to-back device-resident launches, and a
+    //  host mutex around launch + synchronise costs a third of that; profiles/r03_hostmapped_batches.txt.)
     ev_begin(c, 2);
-    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_out, c->d_has.p, c->d_err.p,
-                       (uint8_t *)d_out + 64 + (size_t)n * 4, (int32_t *)((char *)d_out + 64), nullptr, 0, 0, G.wide);
+    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_flag, c->d_has.p, c->d_err.p,
+                       (uint8_t *)d_perm, (int32_t *)d_errp, nullptr, 0, 0, G.wide);
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     if (*flag) return kTakeLevelLoop;
-    std::memcpy(perm_out, h_perm, n);
-    if (err_out) std::memcpy(err_out, h_err, (size_t)n * sizeof(int32_t));
+    if (!pin_p) std::memcpy(perm_out, h_perm, n);
+    if (err_out && !pin_e) std::memcpy(err_out, h_err, (size_t)n * sizeof(int32_t));
     c->stats.check_items += n;
     c->stats.check_passes++;
     c->stats.local_passes++;
@@ -727,10 +739,16 @@ int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint
 // Buffers from acl_host_alloc are pinned and are DMA'd directly; anything else is staged through the context's pinned
 // buffers (an async copy from pageable memory would be staged by the runtime anyway, synchronously).
 int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
-    if (n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1) {
-        int rc = check_pass_local_host(h, c, items, (uint32_t)n, perm_out, err_out);
+    const bool walk = n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
+    const bool allowed = walk && walk_allowed(h, n);  // (asked once per call: it counts down the back-off after an overflow)
+    bool tried = false;  // the single-launch walk has had its go at this batch
+    if (allowed) {
+        // first choice at every size: the kernel reads the items from, and writes the answers to, pinned host memory itself -- one launch, one
+        // synchronisation, no copy engine, no turn-taking between callers
+        int rc = check_pass_local_host(h, c, items, (uint32_t)n, perm_out, err_out, &tried);
+        if (tried) walk_outcome(h, n, rc);
         if (rc != kTakeLevelLoop) return rc;
-        // a wave ran out of private frontier: the level-synchronous path below takes the batch
+        // a block ran out of private frontier (-> the level loop below), or the batch needs more units than blocks (-> the copying walk below)
     }
     HIP_TRY(c->d_items.ensure(n));
     HIP_TRY(c->d_perm.ensure(n));
@@ -762,12 +780,11 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     // and the host synchronises ONCE (three synchronisations -- after the H2D, after the kernel, after the D2H -- cost a 65 536-item call
     // 30-40 us of wake-ups, a third of its kernel).  Only a walk that overflowed its private regions comes back for the level loop.
     int rc = kTakeLevelLoop;
-    bool tried = false;  // the single-launch walk has had its go at this batch
-    const bool walk = n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1;
-    if (chained) {
+    if (chained && !tried && allowed) {
         tried = true;
-        // A batch this size fills every wave slot of the chip by itself: two such batches' kernels running at once only
-        // take turns (measured: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
+        // (The copying pipeline: what a batch takes when it needs more units than the chip holds blocks -- beyond 262 144 items -- and what
+        //  submitted tickets use.)  With copies in the picture two such batches' kernels running at once only took turns (round 1's chunked
+        //  kernels: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
         // copies with ANOTHER batch's kernel -- and the kernels themselves should follow each other without a gap.  So the
         // turn-taking happens ON THE DEVICE: this context's stream waits for the event the previous batch's kernel recorded,
         // the single-launch kernel is enqueued behind it (the H2D above is already under way and is not held up), and its
@@ -783,7 +800,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
             (void)hipStreamSynchronize(c->stream);
         }
         if (rc == kChainDeclined) rc = kTakeLevelLoop;
-    } else if (walk && walk_allowed(h, n)) {
+    } else if (allowed && !tried) {
         tried = true;
         HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
         HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
@@ -1436,6 +1453,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_HOSTMAP_MAX")) h->hostmap_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob: batches up to this size are read / answered across PCIe by the kernel itself
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
