@@ -183,10 +183,10 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * to three batches ahead (context + H2D), runs the batches' kernels strictly one after the other (from 131 072 items on they are chained
  * ON THE DEVICE -- each stream waits for the event behind the previous kernel), and each batch's D2H drains while the next one's kernel
  * runs.  Such batches -- submitted or issued by blocking callers -- only ever use three of the engine's contexts: further ones queue for a
- * lane.  Measured on C4: a window of two to six tickets 863-878 M decisions/s (profiles/r03_hostid_modes.txt, r03_submit_window_trace.txt).
- * BLOCKING callers do not go through this pipeline for batches the single-launch walk takes (<= 262 144 items on an MI355X): there the
- * kernel itself reads the items from, and writes the answers to, the (pinned) host buffers across PCIe -- no copies, no turn-taking: 2 ... 16
- * callers 884-912 M decisions/s, one caller 692 (profiles/r03_hostmapped_batches.txt). */
+ * lane.  That pipeline is for batches that have to be COPIED (beyond 262 144 items on an MI355X).  A batch the single-launch walk takes is
+ * answered by the kernel itself across PCIe -- it reads the items from, and writes the answers to, the (pinned) host buffers: no copies, no
+ * turn-taking -- whether a blocking caller brings it or a ticket (then a whole call on one of the pool's workers): 2 ... 16 callers 884-912 M
+ * decisions/s on C4, one caller 692, windows of 2 ... 6 tickets 899-945 (profiles/r03_hostmapped_batches.txt). */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);

@@ -631,6 +631,13 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     return ACL_OK;
 }
 
+// would check_pass_local_host take a batch of n items?  (what the submit pipeline asks before it decides who runs a ticket)
+bool hostmap_takes(acl_engine *h, size_t n) {
+    if (!(n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && n <= h->hostmap_max)) return false;
+    const bool wide = n >= h->local_wide_min;
+    return n <= (uint64_t)(wide ? h->local_blocks_wide : h->local_blocks) * local_unit_max(wide);  // (one unit per resident block)
+}
+
 // A graph whose walks keep outgrowing the blocks' private regions should not pay for a failed walk before every level loop: after an
 // overflow the walk sits out 2, 4, ... 64 large passes before it is tried again.
 static bool walk_allowed(acl_engine *h, size_t n) {

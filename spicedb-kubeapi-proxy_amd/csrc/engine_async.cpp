@@ -299,7 +299,10 @@ int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n
     t->err = err_out;
     {
         std::lock_guard<std::mutex> lk(P->mu);
-        if (n >= kComputeTokenItems && n <= h->max_sub_batch && h->shard.world == 1) P->compute.push_back(t.get());
+        // chip-filling batches that have to be COPIED go through the one-worker pipeline (look-ahead H2D, kernels chained on the device); everything
+        // else -- also every batch the kernel answers across PCIe itself, whatever its size -- is a whole blocking call on any worker: such
+        // calls need no turn-taking (profiles/r03_hostmapped_batches.txt)
+        if (n >= kComputeTokenItems && n <= h->max_sub_batch && h->shard.world == 1 && !hostmap_takes(h, n)) P->compute.push_back(t.get());
         else P->queue.push_back(t.get());
     }
     P->cv.notify_all();

@@ -433,6 +433,7 @@ FilterText to_filter(const acl_filter_t *f);
 // strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55).  Caller holds names_mu shared.
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
 void intern_pool_destroy(acl_engine_t *h);
+bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n items is answered by the kernel across PCIe (no copies)
 constexpr uint32_t kChainLanes = 3;  // contexts (streams) that carry chip-filling host batches
 bool chains(acl_engine *h, size_t n);  // does a host batch of n items take the chained-kernel pipeline?
 constexpr int kChainDeclined = -1003;  // internal: chained_enqueue / chained_finish hand the batch to the turn-taking path
