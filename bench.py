@@ -6,13 +6,12 @@ workload: C4 (10 M relationships / 1 M objects, 5-level nested groups, 256 k-ite
 BASELINE.json's metric is quoted on.  What is timed follows SURVEY.md 8(d):
 
   value             (ii) the ABI call that takes HOST ids -- items and answers cross PCIe inside the call: K steps over 8 distinct pre-generated
-                    batches in pinned host memory, issued by `--callers` (default 2) host threads that each block in
-                    acl_check_bulk_ids -- what goroutines behind the cgo shim do -- so that the copies of one batch overlap
-                    the kernels of another (the engine's evaluation contexts, one HIP stream each; chip-filling batches'
-                    kernels follow each other on the device: each waits for the previous one's event).  `--pipeline submit`
-                    times acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead (window 2: the same rate).  Measured
-                    (profiles/r02_hostid_modes_chained.txt): 1 caller 570 M/s, 2 callers 750 M/s, 3 callers 745 M/s
-                    (4: 566 M/s: at most three chained batches in flight); kernels alone (device_resident) 755-770 M/s.
+                    batches in pinned host memory, issued by `--callers` (default 3) host threads that each block in
+                    acl_check_bulk_ids -- what goroutines behind the cgo shim do.  The kernel reads the items from, and writes the
+                    answers to, that pinned memory itself (no copies); the engine admits three chip-filling batches at once and their
+                    kernels fill each other's tails (profiles/r03_hostmapped_batches.txt: 1 / 2 / 3 / 4 / 8 / 16 callers
+                    692 / 884 / 912 / 893 / 909 / 901 M/s; kernels alone, back to back: 873-889).  `--pipeline submit` times
+                    acl_check_bulk_ids_submit / acl_ticket_wait from one thread instead (windows 2-6: 899-945 M/s).
   device_resident   (i) kernels only: the batch is already in HBM (acl_check_bulk_ids_device), sequential; the roofline's
                     per-launch kernel time comes from HIP events in THIS leg (pipelined launches overlap each other)
   latency           p50 / p95 of >= 200 single, unpipelined host-id calls ("batch latency")
@@ -1023,7 +1022,7 @@ def main():
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
     ap.add_argument("--native-loop", default="on", choices=["on", "off"], help="sharded leg: also time the level loop inside libaclgpu.so (acl_shard_check_bulk)")
     ap.add_argument("--pipeline", default="blocking", choices=["blocking", "submit"], help="how the timed host-id leg keeps batches in flight")
-    ap.add_argument("--callers", type=int, default=2, help="--pipeline blocking: host threads issuing blocking acl_check_bulk_ids calls")
+    ap.add_argument("--callers", type=int, default=3, help="--pipeline blocking: host threads issuing blocking acl_check_bulk_ids calls (default 3 = the batches the engine admits at once: its chain lanes; Python threads, so a native caller needs fewer)")
     ap.add_argument("--window", type=int, default=2, help="--pipeline submit: batches in flight (<= the engine's evaluation contexts)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="also measure C2 and C3 in the same run (auto: at N=1 with the default workload)")
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
