@@ -989,9 +989,8 @@ struct InternPool {
     void loop(unsigned me) {
         uint64_t seen = 0;
         for (;;) {
-            // A sleep + wake-up costs a thread 20-100 us on these hosts, about what interning a 16 384-item slice takes: a worker that has just
-            // finished a batch polls for the next one for kSpinNs before it goes to sleep (large string batches come slice after slice, and
-            // a busy proxy's bulk calls follow each other closely).
+            // A sleep + wake-up costs a thread 20-100 us on these hosts, about what its share of a 16 384-item batch takes: a worker that has just
+            // finished a batch polls for the next one for kSpinNs before it goes to sleep (a busy proxy's bulk calls follow each other closely).
             bool got = false;
             for (const auto t0 = std::chrono::steady_clock::now(); seen && !got && std::chrono::steady_clock::now() - t0 < std::chrono::nanoseconds(kSpinNs);) {
                 for (int i = 0; i < 64 && !got; i++) {
