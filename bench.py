@@ -73,6 +73,34 @@ def usable_cores():
     return c
 
 
+def bind_to_gpu_numa_node(device: int):
+    """Runs this rank on the NUMA node its GPU hangs off (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node): the kernels read
+    the request arrays from, and write the answers to, pinned HOST memory, and the bulk string interning walks host tables -- both are
+    allocated first-touch by this process's threads.  On a two-socket node half the ranks would otherwise sit across the socket link from
+    their GPU.  Returns the node, or None when anything about it cannot be found out (nothing is changed then)."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        bus = buf.value.decode().strip().lower()
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 2:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def c3_lookup_bytes(w, subjects):
     """SURVEY.md 8(d) LookupResources formula, evaluated on the generator's arrays for C3's schema:
     17 + sum over the reverse rows the walk touches of (8 + 4 * deg) + ceil(N_pod / 8) for the result bitmap."""
@@ -1014,6 +1042,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-oracle sample time (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--strings", default="on", choices=["on", "off"], help="name every pod and user (string-path leg on named objects); off: ids only")
+    ap.add_argument("--numa", default="gpu", choices=["gpu", "off"], help="gpu: every rank runs on the NUMA node of its GPU (pinned request / answer arrays and name tables are then local to it)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "static"],
                     help="roofline.traffic: measure = two rocprofv3 --pmc passes of this command's device leg, now (about 25 s); static = profiles/traffic.json "
                          "(an earlier run's passes, labelled); auto = measure for the headline workload at N=1 with the CPU legs on")
@@ -1059,6 +1088,7 @@ def main():
     if torch.cuda.device_count() < world or local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: {world} GPUs requested, {torch.cuda.device_count()} visible (one process per GPU: rank {rank} has no device)")
     torch.cuda.set_device(local_rank)
+    numa_node = bind_to_gpu_numa_node(local_rank) if args.numa == "gpu" else None
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -1159,7 +1189,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec.pop("workload"), "batch_per_gpu": rec.pop("batch"), "relationships": rec.pop("relationships"),
-                       "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)",
+                       "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)", "numa_node_of_rank0": numa_node,
                        "timed": "host-id ABI calls (host buffers in, host buffers out: PCIe both ways inside the call) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
                                 else "device-resident calls only (--legs device)"},
             "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
