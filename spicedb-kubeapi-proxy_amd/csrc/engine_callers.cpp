@@ -467,26 +467,25 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
     if (!k_items) return ACL_OK;
     for (size_t i = 0; i < k_items; i++)
         if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_ids: item_off must ascend and end within n");
-    Eval ev;
-    int rc = ev.begin(h, false);
-    if (rc) return rc;
-    PassCtx *c = ev.c;
-    HIP_TRY(c->d_items.ensure(std::max<size_t>(n, 1)));
-    HIP_TRY(c->d_itemoff.ensure(k_items + 1));
-    HIP_TRY(c->d_keep.ensure(k_items));
-    HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t) + (k_items + 1) * sizeof(uint32_t)));
-    std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
-    uint32_t *h_off = (uint32_t *)((char *)c->h_in.p + n * sizeof(acl_item_t));
-    std::memcpy(h_off, item_off, (k_items + 1) * sizeof(uint32_t));
-    if (n) HIP_TRY(hipMemcpyAsync(c->d_items.p, c->h_in.p, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_itemoff.p, h_off, (k_items + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    rc = keep_device(h, c, c->d_items.p, n, c->d_itemoff.p, k_items, c->d_keep.p);
-    if (rc) return rc;
-    HIP_TRY(c->h_out.ensure(k_items));
-    HIP_TRY(hipMemcpyAsync(c->h_out.p, c->d_keep.p, k_items, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    ev_collect(c);
-    std::memcpy(keep_out, c->h_out.p, k_items);
+    // the host form: one pass of the host-id path (the kernel reads the pairs from, and answers into, pinned host memory: no copies), then the
+    // AND over each item's pairs on the host -- K bytes of work.  (k_keep, the same reduction on the device, serves the *_device form, whose
+    // answers never leave the HBM.)
+    std::vector<uint8_t> perm(std::max<size_t>(n, 1));
+    std::vector<int32_t> err(std::max<size_t>(n, 1));
+    if (n) {
+        Eval ev;
+        int rc = ev.begin(h, false, CallOpts(), -1, false, chains(h, n));
+        if (rc) return rc;
+        rc = check_ids_host(h, ev.c, items, n, perm.data(), err.data());
+        if (rc) return rc;
+    } else if (h->store_only) {
+        return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
+    }
+    for (size_t i = 0; i < k_items; i++) {
+        bool all = true;  // pair error or anything but HAS_PERMISSION drops the item: postfilter.go:162-172
+        for (uint32_t j = item_off[i]; j < item_off[i + 1]; j++) all = all && !err[j] && perm[j] == ACL_PERM_HAS_PERMISSION;
+        keep_out[i] = all ? 1 : 0;
+    }
     return ACL_OK;
 }
 

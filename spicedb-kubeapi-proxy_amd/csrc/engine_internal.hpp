@@ -226,10 +226,10 @@ struct PassCtx {
     uint32_t max_chunks = 0;
     uint32_t *h_status = nullptr;  // pinned
     // batch scratch
-    DevArray<uint8_t> d_has, d_err, d_perm, d_keep;
+    DevArray<uint8_t> d_has, d_err, d_perm;
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
-    DevArray<uint32_t> d_itemoff, d_sids, d_visited, d_rows;
+    DevArray<uint32_t> d_sids, d_visited, d_rows;
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
