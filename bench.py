@@ -228,6 +228,33 @@ def filter_bench(args, w, eng, steps, warmup):
     if only_batched:
         one = [float("nan")]
     bms, counts = keep
+    # the reference runs every list request's prefilter in a goroutine of its own (responsefilterer.go:165): three callers, each with result
+    # buffers of its own, each step one batched walk -- their kernels fill each other's gaps
+    conc = None
+    if not only_batched:
+        ncall = 3
+        hbs = [eng.host_alloc(subs.size * words * 4 + subs.size * 8) for _ in range(ncall)]
+        cb = [(b_[:subs.size * words * 4].view(np.uint32).reshape(subs.size, words), b_[subs.size * words * 4:].view(np.uint64)) for b_ in hbs]
+        go = threading.Event()
+
+        def caller(i):
+            go.wait()
+            for _ in range(steps):
+                eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=cb[i])
+
+        for i in range(ncall):
+            eng.lookup_ids_batch(rt, perm_name, st, "", subs, out=cb[i])
+        ts = [threading.Thread(target=caller, args=(i,)) for i in range(ncall)]
+        for t_ in ts:
+            t_.start()
+        tc = time.perf_counter()
+        go.set()
+        for t_ in ts:
+            t_.join()
+        elc = time.perf_counter() - tc
+        conc = {"callers": ncall, "lookups_per_s": ncall * steps * subs.size / elc, "equal_to_sequential_run": bool(all(np.array_equal(c_[0], bms) and np.array_equal(c_[1], counts) for c_ in cb))}
+        for b_ in hbs:
+            eng.host_free(b_)
     eng.host_free(hb)
     if stats.get("rev_local_passes"):
         kname, kms, launches = "k_rev_local", stats["rev_local_ms"], max(1, stats["rev_local_passes"])
@@ -251,14 +278,15 @@ def filter_bench(args, w, eng, steps, warmup):
            "allowed_ids_per_lookup": float(np.mean(counts)), "allowed_ids_per_sec": float(np.sum(counts)) * steps / el,
            "p50_batch_ms": 1e3 * float(np.median(lat)), "p50_single_lookup_ms": 1e3 * float(np.median(one)), "p95_single_lookup_ms": 1e3 * float(np.percentile(one, 95)),
            "pageable_result_buffers": {"p50_batch_ms": 1e3 * float(np.median(pg)), "lookups_per_s": subs.size / float(np.median(pg)), "equal_to_pinned_run": pageable_equal},
+           "concurrent_callers": conc,
            "kernel_ms_per_step": stats["kernel_ms"] / steps, "launches_per_step": launches / steps, "reverse_levels": int(stats.get("levels_last", 0)),
            "bitmap_bytes_per_lookup": int(bms.shape[1] * 4),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                         "kernel": kname, "kernel_avg_us": 1e3 * kms / launches,
                         "algorithmic_bytes_per_lookup": batch_bytes / subs.size, "algorithmic_bytes_per_launch": batch_bytes * steps / launches,
                         "model": "SURVEY.md 8(d) LookupResources formula on the generator's arrays: 17 + sum over reverse rows (8 + 4 deg) + N_pod / 8"}}
-    if not pageable_equal:
-        out.setdefault("parity", {})["pageable_vs_pinned_mismatch"] = True
+    if not pageable_equal or (conc and not conc["equal_to_sequential_run"]):
+        out.setdefault("parity", {})["pageable_vs_pinned_mismatch" if not pageable_equal else "concurrent_vs_sequential_mismatch"] = True
     if not args.no_cpu:
         from oracle import orc
         o = orc.Oracle(w.schema)
@@ -280,7 +308,7 @@ def filter_bench(args, w, eng, steps, warmup):
         for i in range(subs.size):
             got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little"))
             mism += int(not np.array_equal(got, walks[i]))
-        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism + int(not pageable_equal),
+        out["parity"] = {"lookups_checked_against_oracle": int(subs.size), "mismatches": mism + int(not pageable_equal) + int(bool(conc) and not conc["equal_to_sequential_run"]),
                          "checkers": "the DEFINITION {id : Check == HAS} over every pod (multi-threaded oracle) AND a CPU reverse walk"}
         # cpu_baseline = the oracle through its own ABI, as for the Check configs: the restated engine answers LookupResources by its DEFINITION
         # ({id : Check == HAS} over every pod, here split over the host threads).  The numpy reverse walk -- the algorithm the device runs,
