@@ -727,6 +727,30 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
                               "note": "acl_check_bulk_ids_device: batch already in HBM, one call at a time"}
     rec["levels"] = int(st_dev["levels_last"])
     rec["has_fraction"] = float((gpu_perm == 2).mean())
+    if legs != "device":
+        # ... and the same device-resident calls from `callers` threads at once (own answer buffers each): launches of different batches overlap --
+        # one's blocks move in as the other's finish -- which is what the host-id leg below gets too; the sequential figure above is what
+        # prices the roofline (one launch at a time, HIP events)
+        ncall = max(1, args.callers)
+        outs_c = [(torch.zeros(n, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")) for _ in range(ncall)]
+        go = threading.Event()
+
+        def dev_caller(i):
+            go.wait()
+            for k in range(i, steps, ncall):
+                eng.check_bulk_ids_device(d_batches[k % NB].data_ptr(), n, outs_c[i][0].data_ptr(), outs_c[i][1].data_ptr())
+
+        ts = [threading.Thread(target=dev_caller, args=(i,)) for i in range(ncall)]
+        for t_ in ts:
+            t_.start()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        go.set()
+        for t_ in ts:
+            t_.join()
+        torch.cuda.synchronize()
+        rec["device_resident"]["concurrent"] = {"callers": ncall, "decisions_per_s": n * steps / (time.perf_counter() - tc)}
+        del outs_c
     if "device" == legs:
         rec["value"] = rec["device_resident"]["decisions_per_s"]
         rec["elapsed"] = el_dev
