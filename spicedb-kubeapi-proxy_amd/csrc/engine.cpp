@@ -162,7 +162,7 @@ static hipError_t upload_patches(const Snapshot &sn, const std::vector<Patch> &p
 // ---- background compaction (engine_internal.hpp Compaction); everything here runs under state_mu EXCLUSIVE except the worker
 static bool compaction_due(acl_engine *h) {
     const Snapshot &s = h->snap;
-    if (s.garbage_words * 8 > s.edges.size() + s.buckets.size() + 65536) return true;  // half of the 25 % that forces a rebuild
+    if (s.garbage_words * 8 > s.edges.size() + s.buckets.size() + h->compaction_slack) return true;  // half of the 25 % that forces a rebuild
     const Schema &sc = h->store.schema();
     // a table's spare ids running low: fewer left than a tenth of the table, or than 8 192 (half of the smallest headroom) -- the build
     // must finish before they are gone, and a small table of a fast-growing type (lock / workflow / activity ids) has no "last 10 %" to speak of
@@ -1459,6 +1459,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_COMPACTION_SLACK")) h->compaction_slack = (uint64_t)std::max(0, atoi(ev));  // test knob (tools/fuzz_gpu.py --compact-early): small graphs compact too
     if (const char *ev = getenv("ACL_HOSTMAP_MAX")) h->hostmap_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob: batches up to this size are read / answered across PCIe by the kernel itself
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow

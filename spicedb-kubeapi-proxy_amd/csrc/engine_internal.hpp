@@ -298,6 +298,7 @@ struct acl_engine {
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
     int local_blocks = 1024;   // resident blocks of the single-launch kernel (4 waves per block)
     int local_blocks_wide = 512;  // ... of its 16-wave instantiation
+    uint64_t compaction_slack = 65536;  // words of garbage a snapshot may hold on top of an eighth of its rows before a background build starts
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
     uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "spicedb-kubeapi-proxy_amd")]
 
 
-def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1) -> dict:
+def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False) -> dict:
     import aclgpu
     from aclgpu import workloads
     from oracle import orc
@@ -48,7 +48,12 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
         if k < 9: return ("group", rng.choice(groups), "member", "user", u, "")
         return ("pod", rng.choice(pods), "view", "group", rng.choice(groups), "member")  # a userset as the subject
 
-    e = aclgpu.Engine(workloads.SCHEMA_C4)
+    if compact_early:
+        os.environ["ACL_COMPACTION_SLACK"] = "0"  # (read at acl_open) background compactions, adopted with the writes since replayed, on this small graph too
+    try:
+        e = aclgpu.Engine(workloads.SCHEMA_C4)
+    finally:
+        os.environ.pop("ACL_COMPACTION_SLACK", None)
     o = orc.Oracle(workloads.SCHEMA_C4)
     live = set()
     init = list(dict.fromkeys(rand_tuple() for _ in range(2500 * universe)))
@@ -134,10 +139,11 @@ if __name__ == "__main__":
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--burst", type=int, default=25, help="updates per write, at most (<= 1000: the reference's limit, spicedb.go:35)")
+    ap.add_argument("--compact-early", action="store_true", help="ACL_COMPACTION_SLACK=0: background compactions (and their adoption with the writes since replayed) happen on this small graph too")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
-        print(run(a.seed, a.steps, burst=a.burst, universe=a.universe))
+        print(run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)
