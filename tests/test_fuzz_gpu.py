@@ -20,3 +20,15 @@ def test_differential_fuzz(seed, kw, aclgpu_lib):
     assert st["writes"] > 5 and st["checks"] > 100 and st["lookups"] >= 1 and st["snapshot_patches"] >= 1  # (the run itself asserts every answer)
     if kw.get("compact_early"):
         assert st["snapshot_compactions"] >= 1  # background builds were adopted in mid-stream, the writes since their start replayed onto them
+
+
+@pytest.mark.gpu
+def test_differential_fuzz_expiring_keys(aclgpu_lib):
+    """The reference's bootstrap schema under the dual write's shapes (lock CREATE behind MUST_NOT_MATCH, lock DELETE, expiring idempotency keys:
+    workflow.go:392-462, activity.go:81-102) with a clock that moves seconds to days per step: checks on live / expired / unwritten keys, locks and
+    payloads and the read-back of the expiring class equal the oracle's after every step."""
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    st = fz.run_expiry(14, 400, verbose=False)
+    assert st["writes"] > 100 and st["write_errors"] > 5 and st["clock_moves"] > 20 and st["snapshot_patches"] > 20

@@ -134,16 +134,96 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     return stats
 
 
+def run_expiry(seed: int, steps: int, verbose: bool = True) -> dict:
+    """The reference's own schema (pkg/spicedb/bootstrap.yaml) under the dual write's shapes: lock tuples created behind MUST_NOT_MATCH and deleted
+    again (workflow.go:392-462), idempotency keys that EXPIRE (activity.go:81-102), payload relationships -- while the clock moves forwards in
+    random steps (seconds to days: keys run out in between, expired ones are collected after 24 h).  After every step a batch of checks on live,
+    expired and never-written keys, locks and payloads, and ReadRelationships of the expiring class, must equal the oracle's."""
+    import json
+
+    import aclgpu
+    from oracle import orc
+
+    rng = random.Random(seed)
+    b = json.load(open(os.path.join(ROOT, "tests", "golden", "bootstrap.json")))
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]))
+    o = orc.Oracle(b["schema"])
+    o.write([(orc.OP_TOUCH, r) for r in b["relationships"]])
+    now = 1_700_000_000
+    e.set_now(now)
+    o.set_now(now)
+    wfs = [f"wf{i}" for i in range(40)]
+    acts = [f"act{i:x}" for i in range(120)]
+    locks = [f"lk{i:x}" for i in range(30)]
+    users = [f"u{i}" for i in range(20)]
+    nss = [f"ns{i}" for i in range(12)]
+    stats = {"writes": 0, "write_errors": 0, "clock_moves": 0, "checks": 0, "reads": 0}
+    OPS = {aclgpu.OP_TOUCH: orc.OP_TOUCH, aclgpu.OP_CREATE: orc.OP_CREATE, aclgpu.OP_DELETE: orc.OP_DELETE}
+    for step in range(steps):
+        r = rng.random()
+        if r < 0.5:
+            ups, pre = [], []
+            k = rng.random()
+            if k < 0.45:    # the pessimistic dual write's first request: payload + lock CREATE behind MUST_NOT_MATCH + an expiring idempotency key
+                lk, wf = rng.choice(locks), rng.choice(wfs)
+                pre = [(aclgpu.PRE_MUST_NOT_MATCH, dict(rtype="lock", rid=lk, rel="workflow"))]
+                ups = [(aclgpu.OP_TOUCH, f"namespace:{rng.choice(nss)}#creator@user:{rng.choice(users)}"),
+                       (aclgpu.OP_CREATE, f"lock:{lk}#workflow@workflow:{wf}"),
+                       (aclgpu.OP_TOUCH, f"workflow:{wf}#idempotency_key@activity:{rng.choice(acts)}", now + rng.choice([1, 5, 60, 3600, 86400, 200000]))]
+            elif k < 0.8:   # ... and its second: the lock goes away
+                ups = [(aclgpu.OP_DELETE, f"lock:{rng.choice(locks)}#workflow@workflow:{rng.choice(wfs)}")]
+            else:           # keys rewritten with a new expiry, or none
+                ups = [(aclgpu.OP_TOUCH, f"workflow:{rng.choice(wfs)}#idempotency_key@activity:{rng.choice(acts)}", rng.choice([0, now + 2, now + 30, now - 5]))
+                       for _ in range(rng.randrange(1, 6))]
+                ups = list({u[1]: u for u in ups}.values())
+            eo = ee = None
+            try:
+                o.write([(OPS[u[0]],) + tuple(u[1:]) for u in ups], [({aclgpu.PRE_MUST_NOT_MATCH: orc.PRE_MUST_NOT_MATCH}[p[0]], p[1]) for p in pre])
+            except orc.OracleError as x:
+                eo = x.code
+            try:
+                e.write(ups, pre)
+            except aclgpu.AclError as x:
+                ee = x.code
+            assert eo == ee, f"step {step}: write outcome differs: oracle {eo}, engine {ee}: {ups} {pre}"
+            stats["writes"] += 1
+            stats["write_errors"] += eo is not None
+        elif r < 0.7:
+            now += rng.choice([1, 1, 3, 10, 61, 3601, 50000, 90000])
+            e.set_now(now)
+            o.set_now(now)
+            stats["clock_moves"] += 1
+        qs = [("workflow", rng.choice(wfs), "idempotency_key", "activity", rng.choice(acts), "") for _ in range(150)] + \
+             [("lock", rng.choice(locks), "workflow", "workflow", rng.choice(wfs), "") for _ in range(40)] + \
+             [("namespace", rng.choice(nss), rng.choice(["view", "edit", "admin", "no_one_at_all"]), "user", rng.choice(users + ["rakis"]), "") for _ in range(40)] + \
+             [("namespace", "spicedb-kubeapi-proxy", "view", "user", "rakis", "")]
+        perms, errs = e.check_bulk(qs)
+        for i, q in enumerate(qs):
+            assert (perms[i], errs[i]) == tuple(o.check(*q)), f"step {step} (now {now}): check {q}: engine {(perms[i], errs[i])}, oracle {o.check(*q)}"
+        stats["checks"] += len(qs)
+        if step % 5 == 0:  # ReadRelationships of the expiring class (activity.go:107-149 reads the keys back): expired ones are gone on both sides
+            a, b2 = sorted(e.read(rtype="workflow")), sorted(o.read(rtype="workflow"))
+            assert [x[:6] for x in a] == [x[:6] for x in b2], f"step {step} (now {now}): workflow relationships differ: {set(a) ^ set(b2)}"
+            stats["reads"] += 1
+        if verbose and step % 100 == 99:
+            print(f"step {step + 1}/{steps}: {stats}, now +{now - 1_700_000_000} s", file=sys.stderr, flush=True)
+    st = e.stats()
+    stats.update({k: int(st[k]) for k in ("snapshot_builds", "snapshot_patches", "snapshot_compactions") if k in st})
+    e.close()
+    return stats
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--burst", type=int, default=25, help="updates per write, at most (<= 1000: the reference's limit, spicedb.go:35)")
     ap.add_argument("--compact-early", action="store_true", help="ACL_COMPACTION_SLACK=0: background compactions (and their adoption with the writes since replayed) happen on this small graph too")
+    ap.add_argument("--expiry", action="store_true", help="the other campaign: the reference's bootstrap schema, dual-write shapes, expiring idempotency keys, a moving clock")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
-        print(run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
+        print(run_expiry(a.seed, a.steps) if a.expiry else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)
