@@ -247,3 +247,17 @@ def test_view_is_isolated_from_writes(aclgpu):
     assert e.selfcheck_compaction(1) is True
     assert len(e.read(rtype="doc", rel="viewer")) == 4000
     e.close()
+
+
+def test_long_random_write_streams_keep_the_snapshot_exact(aclgpu):
+    """tools/fuzz_gpu.py --patcher: 1 500 write batches / filter deletes on the nested-group schema (and 300 large bursts on a wider universe), the
+    host snapshot updated and verified against the store after every one."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    codes = fz.run_patcher(5, 1500)
+    assert codes[1] > 1400  # patched in place, not rebuilt
+    codes = fz.run_patcher(6, 300, universe=8, burst=400)
+    assert codes[0] + codes[1] + codes[2] == 300

@@ -134,6 +134,48 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     return stats
 
 
+def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25) -> dict:
+    """No GPU: the same kind of write stream on a STORE-ONLY engine, and after every write the host snapshot is brought up to date the way a read
+    would (patched in place, or rebuilt) and verified against the store (acl_selfcheck_snapshot: every relationship findable by the kernels'
+    search, nothing dead left, rows sorted, no unsound leaf flag).  -> how often it was patched (1), rebuilt (0) or current (2)."""
+    import aclgpu
+    from aclgpu import workloads
+
+    rng = random.Random(seed)
+    users = [f"u{i}" for i in range(160 * universe)]
+    groups = [f"g{i}" for i in range(48 * universe)]
+    nss = [f"n{i}" for i in range(8 * universe)]
+    pods = [f"{rng.choice(nss)}/p{i}" for i in range(240 * universe)]
+    shapes = [lambda: f"group:{rng.choice(groups)}#member@group:{rng.choice(groups)}#member", lambda: f"group:{rng.choice(groups)}#member@user:{rng.choice(users)}",
+              lambda: f"pod:{rng.choice(pods)}#namespace@namespace:{rng.choice(nss)}", lambda: f"pod:{rng.choice(pods)}#creator@user:{rng.choice(users)}",
+              lambda: f"namespace:{rng.choice(nss)}#creator@user:{rng.choice(users)}", lambda: f"pod:{rng.choice(pods)}#viewer@user:{rng.choice(users)}",
+              lambda: f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#member", lambda: f"namespace:{rng.choice(nss)}#viewer@user:{rng.choice(users)}",
+              lambda: f"namespace:{rng.choice(nss)}#viewer@group:{rng.choice(groups)}#member"]
+    e = aclgpu.Engine(workloads.SCHEMA_C4, store_only=True)
+    live = set(dict.fromkeys(rng.choice(shapes)() for _ in range(2500 * universe)))
+    init = sorted(live)
+    for i in range(0, len(init), 500):
+        e.write([(aclgpu.OP_TOUCH, t) for t in init[i:i + 500]])
+    e.selfcheck_snapshot_code()
+    codes = {0: 0, 1: 0, 2: 0}
+    for _ in range(steps):
+        if rng.random() < 0.9:
+            pool = sorted(live)
+            ups = {}
+            for _u in range(rng.randrange(1, burst)):
+                t = rng.choice(shapes)() if rng.random() < 0.55 or not pool else rng.choice(pool)
+                ups[t] = (aclgpu.OP_TOUCH if t not in live or rng.random() < 0.3 else aclgpu.OP_DELETE, t)
+            e.write(list(ups.values()))
+            for op, t in ups.values():
+                (live.discard if op == aclgpu.OP_DELETE else live.add)(t)
+        else:
+            e.delete_by_filter(**rng.choice([dict(rtype="pod", rid=rng.choice(pods)), dict(rtype="group", rel="member", stype="user", sid=rng.choice(users))]))
+            live = set(f"{a}:{b}#{c}@{d}:{x}" + (f"#{y}" if y else "") for t in ("group", "namespace", "pod") for a, b, c, d, x, y, *_ in e.read(rtype=t))
+        codes[e.selfcheck_snapshot_code()] += 1  # (raises when the snapshot does not describe the store)
+    e.close()
+    return codes
+
+
 def run_expiry(seed: int, steps: int, verbose: bool = True) -> dict:
     """The reference's own schema (pkg/spicedb/bootstrap.yaml) under the dual write's shapes: lock tuples created behind MUST_NOT_MATCH and deleted
     again (workflow.go:392-462), idempotency keys that EXPIRE (activity.go:81-102), payload relationships -- while the clock moves forwards in
@@ -219,11 +261,12 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--burst", type=int, default=25, help="updates per write, at most (<= 1000: the reference's limit, spicedb.go:35)")
     ap.add_argument("--compact-early", action="store_true", help="ACL_COMPACTION_SLACK=0: background compactions (and their adoption with the writes since replayed) happen on this small graph too")
+    ap.add_argument("--patcher", action="store_true", help="no GPU: a store-only engine whose host snapshot is verified against the store after every write")
     ap.add_argument("--expiry", action="store_true", help="the other campaign: the reference's bootstrap schema, dual-write shapes, expiring idempotency keys, a moving clock")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
-        print(run_expiry(a.seed, a.steps) if a.expiry else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
+        print(run_patcher(a.seed, a.steps, a.universe, a.burst) if a.patcher else run_expiry(a.seed, a.steps) if a.expiry else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)
