@@ -157,7 +157,8 @@ def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25) -> di
     for i in range(0, len(init), 500):
         e.write([(aclgpu.OP_TOUCH, t) for t in init[i:i + 500]])
     e.selfcheck_snapshot_code()
-    codes = {0: 0, 1: 0, 2: 0}
+    codes = {0: 0, 1: 0, 2: 0, "adopted": 0, "dropped": 0}
+    pending_build = None
     for _ in range(steps):
         if rng.random() < 0.9:
             pool = sorted(live)
@@ -172,6 +173,16 @@ def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25) -> di
             e.delete_by_filter(**rng.choice([dict(rtype="pod", rid=rng.choice(pods)), dict(rtype="group", rel="member", stype="user", sid=rng.choice(users))]))
             live = set(f"{a}:{b}#{c}@{d}:{x}" + (f"#{y}" if y else "") for t in ("group", "namespace", "pod") for a, b, c, d, x, y, *_ in e.read(rtype=t))
         codes[e.selfcheck_snapshot_code()] += 1  # (raises when the snapshot does not describe the store)
+        # a background compaction's two halves around the writes in between: build from a copy-on-write view now, adopt it some writes later
+        if pending_build is None and rng.random() < 0.02:
+            e.selfcheck_compaction(0)
+            pending_build = rng.randrange(0, 30)
+        elif pending_build is not None:
+            if pending_build == 0:
+                codes["adopted" if e.selfcheck_compaction(1) else "dropped"] += 1  # (phase 1 verifies the adopted snapshot against the store)
+                pending_build = None
+            else:
+                pending_build -= 1
     e.close()
     return codes
 
