@@ -282,6 +282,12 @@ class PrefilterResult:
     def is_allowed(self, object_id: str) -> bool:
         return self.filter([object_id])[0]
 
+    def filter_response(self, body: bytes, kind: str = "list", id_template: str = "{{namespacedName}}") -> bytes:
+        """filterList / filterTable / filterObject (pkg/authz/responsefilterer.go:349-416) on the kube response's bytes: kind = "list" | "table" |
+        "object"; a single object outside the allowed set raises AclError("unauthorized", code 7)."""
+        k = {"list": Engine.BODY_LIST, "table": Engine.BODY_TABLE, "object": Engine.BODY_OBJECT}[kind]
+        return self.engine.prefilter_response(self.resource_type, self.bitmap, id_template, k, body)[0]
+
 
 def is_allowed(pair: CheckBulkPermissionsPair) -> bool:
     """The reference's allow rule: no error and HAS_PERMISSION (pkg/authz/check.go:55-69)."""

@@ -79,6 +79,7 @@ def test_postfilter_and_prefilter_mirror(aclgpu):
         table = json.dumps({"kind": "Table", "rows": [{"cells": [p], "object": {"kind": "PartialObjectMetadata", "metadata": md(p)}} for p in pods]}).encode()
         out, kept, _ = e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_TABLE, table)
         assert [r["cells"][0] for r in json.loads(out)["rows"]] == ["ns/p1", "ns/p3", "other/p1"] and kept == 3
+        assert pre.filter_response(table, "table") == out and pre.filter_response(body) == e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_LIST, body)[0]
         one = json.dumps({"kind": "Pod", "metadata": md("ns/p3")}).encode()
         assert e.prefilter_response("pod", pre.bitmap, "{{namespacedName}}", e.BODY_OBJECT, one)[0] == one
         with pytest.raises(Exception) as x:
