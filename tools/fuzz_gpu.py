@@ -134,7 +134,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     return stats
 
 
-def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25) -> dict:
+def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25, shard=None) -> dict:
     """No GPU: the same kind of write stream on a STORE-ONLY engine, and after every write the host snapshot is brought up to date the way a read
     would (patched in place, or rebuilt) and verified against the store (acl_selfcheck_snapshot: every relationship findable by the kernels'
     search, nothing dead left, rows sorted, no unsound leaf flag).  -> how often it was patched (1), rebuilt (0) or current (2)."""
@@ -152,6 +152,8 @@ def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25) -> di
               lambda: f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#member", lambda: f"namespace:{rng.choice(nss)}#viewer@user:{rng.choice(users)}",
               lambda: f"namespace:{rng.choice(nss)}#viewer@group:{rng.choice(groups)}#member"]
     e = aclgpu.Engine(workloads.SCHEMA_C4, store_only=True)
+    if shard:  # (rank, world): the snapshot of ONE shard of the type-hash layout -- it holds, and patches, only the rows of the types it owns
+        e._check(e._L.acl_shard_configure(e._h, shard[0], shard[1]))
     live = set(dict.fromkeys(rng.choice(shapes)() for _ in range(2500 * universe)))
     init = sorted(live)
     for i in range(0, len(init), 500):
