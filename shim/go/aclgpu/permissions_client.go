@@ -392,13 +392,13 @@ type Allowed struct {
 }
 
 // LookupAllowed runs the LookupResources of a PreFilter (lookups.go:49-83) and keeps its result as a bitmap.
-func (p *PermissionsClient) LookupAllowed(ctx context.Context, in *v1.LookupResourcesRequest) (*Allowed, error) {
-	st, err := p.LookupResources(ctx, in)
+func (e *Engine) LookupAllowed(ctx context.Context, in *v1.LookupResourcesRequest) (*Allowed, error) {
+	st, err := (&permissionsClient{e: e}).LookupResources(ctx, in)
 	if err != nil {
 		return nil, err
 	}
 	bs := st.(*bitmapStream)
-	return &Allowed{e: p.e, typeID: bs.typeID, bm: bs.bm}, nil
+	return &Allowed{e: e, typeID: bs.typeID, bm: bs.bm}, nil
 }
 
 // BodyKind says what the kube response holds: a list ("items"), a Table ("rows", Accept: ...;as=Table) or one object.
