@@ -223,7 +223,7 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int s
  * PostFilter: filterItemsWithBulkPermissions (postfilter.go:58-182).  The K list items' resolved pairs are ONE bulk
  * check; pairs [item_off[i], item_off[i+1]) belong to list item i (itemToRequestMap, postfilter.go:65,117-119);
  * keep_out[i] = 1 iff all of them are HAS_PERMISSION without error (postfilter.go:152-178); an item without pairs
- * is kept (postfilter.go:145-150).  The *_ids forms do the AND on the device and return K bytes. */
+ * is kept (postfilter.go:145-150).  K bytes come back; the *_device form does the AND on the device (its answers never leave the HBM). */
 int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);
