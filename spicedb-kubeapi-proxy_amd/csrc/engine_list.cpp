@@ -55,14 +55,24 @@ struct Scanner {
     bool string(std::string *out) {
         if (p >= e || *p != '"') return fail();
         p++;
-        while (p < e && *p != '"') {
-            if ((unsigned char)*p < 0x20) return fail();
-            if (*p != '\\') {
+        for (;;) {
+            // eight bytes at a time while none of them is '"', '\\' or a control character (most of a kube response is string content)
+            while (e - p >= 8) {
+                uint64_t w;
+                std::memcpy(&w, p, 8);
+                const uint64_t q = w ^ 0x2222222222222222ull, b = w ^ 0x5C5C5C5C5C5C5C5Cull;
+                const uint64_t hit = ((q - 0x0101010101010101ull) & ~q) | ((b - 0x0101010101010101ull) & ~b) | ((w - 0x2020202020202020ull) & ~w);
+                if (hit & 0x8080808080808080ull) break;  // (may over-report above a true hit: the byte loop below decides)
+                if (out) out->append(p, 8);
+                p += 8;
+            }
+            while (p < e && *p != '"' && *p != '\\' && (unsigned char)*p >= 0x20) {  // (the rest of a window with a hit, or the last < 8 bytes)
                 if (out) out->push_back(*p);
                 p++;
-                continue;
             }
-            if (++p >= e) return fail();
+            if (!(p < e && *p != '"')) break;
+            if ((unsigned char)*p < 0x20) return fail();
+            if (++p >= e) return fail();  // (*p was the backslash)
             const char c = *p++;
             uint32_t u = 0;
             switch (c) {

@@ -139,3 +139,33 @@ def test_cluster_scoped_ids_and_edge_bodies(eng):
     with pytest.raises(Exception) as x:  # a template the engine does not render
         eng.prefilter_response("namespace", bm, "{{metadata.labels.x}}", eng.BODY_OBJECT, b'{"metadata":{"name":"default"}}')
     assert x.value.code == 7
+
+
+def test_string_scanning_fast_path_decodes_what_json_decodes(eng):
+    """The scanner walks string content eight bytes at a time until a quote, a backslash or a control character shows up (engine_list.cpp
+    Scanner::string): names with those bytes at every offset of a window, escapes after long plain runs, multi-byte UTF-8 and \\u escapes must
+    decode to exactly what encoding/json (here: Python's json) decodes -- the item is found under that name or it is not."""
+    rng = random.Random(3)
+    alphabet = ['a', 'B', '7', '-', '.', '"', '\\', '/', '\t', '\n', 'é', 'ß', '漢', '😀', ' ', '\x7f']
+    names = set()
+    for length in list(range(0, 20)) + [31, 32, 33, 63, 64, 65, 200]:
+        for _ in range(12):
+            names.add("".join(rng.choice(alphabet) for _ in range(length)))
+    for pos in range(0, 18):  # one special byte at every offset of a run of plain bytes
+        for ch in ('"', '\\', '\n', '😀'):
+            names.add("x" * pos + ch + "y" * 9)
+    names.discard("")
+    names = sorted(names)
+    for nm in names:
+        eng.intern("pod", nm)
+    allowed = set(rng.sample(names, len(names) // 2))
+    bm = bitmap_of(eng, "pod", allowed)
+    for ensure_ascii in (True, False):
+        items = [{"metadata": {"name": nm}, "pad": nm * 2} for nm in names] + [{"metadata": {"name": nm + "?"}} for nm in names[:50]]
+        body = json.dumps({"items": items}, ensure_ascii=ensure_ascii).encode()
+        out, kept, total = eng.prefilter_response("pod", bm, "{{name}}", eng.BODY_LIST, body)
+        assert [it["metadata"]["name"] for it in json.loads(out)["items"]] == [nm for nm in names if nm in allowed] and total == len(items)
+    for bad in (b'{"items":[{"metadata":{"name":"abcdefgh\x01ijkl"}}]}', b'{"items":[{"metadata":{"name":"abcdefghijklmnop\\q"}}]}', b'{"items":[{"metadata":{"name":"abcdefghijkl'):
+        with pytest.raises(Exception) as x:  # a raw control character, an unknown escape, an unterminated string: invalid JSON
+            eng.prefilter_response("pod", bm, "{{name}}", eng.BODY_LIST, bad)
+        assert x.value.code == 3
