@@ -477,7 +477,9 @@ void Eval::end() {
             std::lock_guard<std::mutex> lk(h->pool_mu);
             h->free_ctxs.push_back(c);
         }
-        h->pool_cv.notify_one();
+        // every waiter: chain_lane callers can only take contexts 0..kChainLanes-1 and ordinary callers prefer the others -- a single wake-up
+        // that lands on a waiter who cannot use THIS context is consumed while another waiter sleeps next to a free context
+        h->pool_cv.notify_all();
         c = nullptr;
     }
     if (locked) {
@@ -560,8 +562,9 @@ static void walk_outcome(acl_engine *h, size_t n, int rc);
 // such kernel, the kernel is enqueued (context buffers d_items -> d_perm / d_errout), its own event becomes the one the next pass
 // waits for.  Nothing is synchronised here.  kChainDeclined: take the turn-taking path instead (batch too small, walk switched off / backing off).
 bool chains(acl_engine *h, size_t n) { return n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1; }
-int chained_enqueue(acl_engine *h, PassCtx *c, size_t n) {
-    if (!(chains(h, n) && walk_allowed(h, n))) return kChainDeclined;
+int chained_enqueue(acl_engine *h, PassCtx *c, size_t n, bool asked) {
+    // asked: the caller already drew this batch's walk_allowed() -- the question counts the back-off down, so it is put ONCE per batch
+    if (!(chains(h, n) && (asked || walk_allowed(h, n)))) return kChainDeclined;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     std::lock_guard<std::mutex> ck(h->chain_mu);
@@ -798,7 +801,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         // own event becomes the one the next caller waits for; the result copies follow the event, under the next batch's kernel.
         // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
         //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
-        rc = chained_enqueue(h, c, n);
+        rc = chained_enqueue(h, c, n, true);
         if (!rc) {
             rc = results_d2h();
             if (rc) return rc;

@@ -438,7 +438,7 @@ bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n i
 constexpr uint32_t kChainLanes = 3;  // contexts (streams) that carry chip-filling host batches
 bool chains(acl_engine *h, size_t n);  // does a host batch of n items take the chained-kernel pipeline?
 constexpr int kChainDeclined = -1003;  // internal: chained_enqueue / chained_finish hand the batch to the turn-taking path
-int chained_enqueue(acl_engine *h, PassCtx *c, size_t n);  // context buffers d_items -> d_perm / d_errout; nothing synchronised
+int chained_enqueue(acl_engine *h, PassCtx *c, size_t n, bool asked = false);  // context buffers d_items -> d_perm / d_errout; nothing synchronised
 int chained_finish(acl_engine *h, PassCtx *c, size_t n);
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
