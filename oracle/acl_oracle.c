@@ -18,8 +18,28 @@
  * (pkg/spicedb/bootstrap.yaml:1-40; e2e rules): direct relations, userset
  * subjects (`group#member`), union `+`, `nil`, arrows `a->b`, dispatch depth
  * limit 50 (pkg/spicedb/spicedb.go:34), relationship expiration
- * (pkg/spicedb/spicedb.go:60).  Caveats, wildcards, `&`, `-` and `.all()` are
- * REJECTED at schema load.
+ * (pkg/spicedb/spicedb.go:60), and -- round 4, because the reference boots ARBITRARY
+ * schemas (pkg/spicedb/spicedb.go:19-24, pkg/proxy/options.go:313-316,
+ * e2e/embedded_integration_test.go:34-250) -- intersection `&`, exclusion `-` and
+ * wildcard subjects `type:*`.  Caveats and `.all()` are REJECTED at schema load.
+ *
+ * Intersection / exclusion (EXTERNAL: SpiceDB internal/graph/check.go `all` /
+ * `difference`, restated from memory, unverified):
+ *   - operator precedence of the schema language, loosest to tightest: `-`, `&`, `+`
+ *     (`a + b - c` is `(a + b) - c`, `a - b + c` is `a - (b + c)`); same-operator
+ *     chains associate to the left; parentheses override;
+ *   - neither operator dispatches: their operands (references, arrows) do, exactly as
+ *     under a union, so the depth limit counts the same dispatches;
+ *   - results are three-valued per item.  SpiceDB evaluates operands concurrently and
+ *     takes the first DECISIVE result, so which of an error and a decisive result wins
+ *     is a race there; this restatement fixes the order a short-circuiting evaluator
+ *     would most often see: union HAS > ERR > NO; intersection NO > ERR > HAS;
+ *     exclusion: base ERR -> ERR, base NO -> NO, then subtracted ERR -> ERR,
+ *     subtracted HAS -> NO, else HAS.  Generators keep data acyclic so that ERR only
+ *     arises where a test asks for it.
+ * Wildcards (EXTERNAL, same caveat): a relationship `res#rel@T:*` makes every subject
+ * `T:x` WITHOUT a subject relation a member of res#rel; it is never a userset, arrows
+ * may not walk a relation that allows wildcards, `*` cannot carry a relation.
  *
  * PARITY STATUS: the oracle is pinned against every golden vector the
  * reference's own tests hold for this path (see
@@ -60,18 +80,19 @@ enum {
 };
 
 #define ELLIPSIS 0xFFFFu
+#define WILDCARD 0xFFFEu /* tuple_t.srel of `T:*` subjects (subj = the interned id of "*", never compared) */
 
 /* ------------------------------------------------------------------ schema */
-enum { EX_UNION, EX_REF, EX_ARROW, EX_NIL };
+enum { EX_UNION, EX_REF, EX_ARROW, EX_NIL, EX_INTERSECT, EX_EXCLUDE };
 typedef struct expr {
     int kind;
-    struct expr *l, *r; /* union */
+    struct expr *l, *r; /* union, intersection; exclusion: l minus r */
     char *a, *b;        /* ref: a ; arrow: a->b */
 } expr_t;
 
 typedef struct {
     int stype;      /* subject type index */
-    unsigned srel;  /* relation index in subject type, or ELLIPSIS */
+    unsigned srel;  /* relation index in subject type, ELLIPSIS, or WILDCARD (`T:*`) */
     int expiring;   /* `with expiration` */
 } allowed_t;
 
@@ -82,7 +103,7 @@ typedef struct {
     int nallowed;
     /* unresolved allowed refs (names) until all types are parsed */
     char **a_type, **a_rel;
-    int *a_exp;
+    int *a_exp, *a_wild;
     expr_t *expr;
 } rel_t;
 
@@ -282,20 +303,24 @@ static expr_t *parse_term(lex_t *L) {
     e->a = strdup(a);
     return e;
 }
-static expr_t *parse_expr(lex_t *L) {
-    expr_t *l = parse_term(L);
+/* one binary level: operands from `sub`, joined by operator character `op` into nodes of `kind`, left-associative */
+static expr_t *parse_level(lex_t *L, int op, int kind, expr_t *(*sub)(lex_t *)) {
+    expr_t *l = sub(L);
     if (!l) return NULL;
-    while (L->tok == '+' || L->tok == '&' || L->tok == '-') {
-        if (L->tok != '+') { lx_fail(L, "unsupported: intersection/exclusion operators"); ex_free(l); return NULL; }
+    while (L->tok == op) {
         lx_next(L);
-        expr_t *r = parse_term(L);
+        expr_t *r = sub(L);
         if (!r) { ex_free(l); return NULL; }
-        expr_t *u = ex_new(EX_UNION);
+        expr_t *u = ex_new(kind);
         u->l = l; u->r = r;
         l = u;
     }
     return l;
 }
+/* precedence, loosest first: exclusion, intersection, union (EXTERNAL, see the header) */
+static expr_t *parse_union(lex_t *L) { return parse_level(L, '+', EX_UNION, parse_term); }
+static expr_t *parse_inter(lex_t *L) { return parse_level(L, '&', EX_INTERSECT, parse_union); }
+static expr_t *parse_expr(lex_t *L) { return parse_level(L, '-', EX_EXCLUDE, parse_inter); }
 
 static int type_index(orc_t *o, const char *name) {
     for (int i = 0; i < o->ntypes; i++)
@@ -354,17 +379,22 @@ static int parse_schema(orc_t *o, const char *text) {
                     r->a_type = realloc(r->a_type, sizeof(char *) * r->nallowed);
                     r->a_rel = realloc(r->a_rel, sizeof(char *) * r->nallowed);
                     r->a_exp = realloc(r->a_exp, sizeof(int) * r->nallowed);
+                    r->a_wild = realloc(r->a_wild, sizeof(int) * r->nallowed);
                     r->a_type[k] = strdup(L.text);
                     r->a_rel[k] = NULL;
                     r->a_exp[k] = 0;
+                    r->a_wild[k] = 0;
                     lx_next(&L);
                     if (L.tok == '#') {
                         lx_next(&L);
                         if (L.tok != 'i') return lx_fail(&L, "expected relation after '#'");
                         r->a_rel[k] = strdup(L.text);
                         lx_next(&L);
-                    } else if (L.tok == ':') {
-                        return lx_fail(&L, "unsupported: wildcard subjects");
+                    } else if (L.tok == ':') { /* `T:*` */
+                        lx_next(&L);
+                        if (L.tok != '*') return lx_fail(&L, "expected '*' after ':'");
+                        r->a_wild[k] = 1;
+                        lx_next(&L);
                     }
                     if (L.tok == 'i' && strcmp(L.text, "with") == 0) {
                         lx_next(&L);
@@ -392,7 +422,7 @@ static int parse_schema(orc_t *o, const char *text) {
             for (int k = 0; k < r->nallowed; k++) {
                 int st = type_index(o, r->a_type[k]);
                 if (st < 0) { seterr(o, "schema: unknown subject type '%s' in %s#%s", r->a_type[k], t->name, r->name); return 0; }
-                unsigned sr = ELLIPSIS;
+                unsigned sr = r->a_wild[k] ? WILDCARD : ELLIPSIS;
                 if (r->a_rel[k]) {
                     int x = rel_index(&o->types[st], r->a_rel[k]);
                     if (x < 0) { seterr(o, "schema: unknown relation '%s#%s'", r->a_type[k], r->a_rel[k]); return 0; }
@@ -415,12 +445,14 @@ static int parse_schema(orc_t *o, const char *text) {
             stack[sp++] = r->expr;
             while (sp) {
                 expr_t *e = stack[--sp];
-                if (e->kind == EX_UNION) { stack[sp++] = e->l; stack[sp++] = e->r; }
+                if (e->kind == EX_UNION || e->kind == EX_INTERSECT || e->kind == EX_EXCLUDE) { stack[sp++] = e->l; stack[sp++] = e->r; }
                 else if (e->kind == EX_REF) {
                     if (rel_index(t, e->a) < 0) { seterr(o, "schema: %s#%s references unknown '%s'", t->name, r->name, e->a); return 0; }
                 } else if (e->kind == EX_ARROW) {
                     int x = rel_index(t, e->a);
                     if (x < 0 || t->rels[x].is_perm) { seterr(o, "schema: %s#%s arrow over non-relation '%s'", t->name, r->name, e->a); return 0; }
+                    for (int k = 0; k < t->rels[x].nallowed; k++)
+                        if (t->rels[x].allowed[k].srel == WILDCARD) { seterr(o, "schema: %s#%s arrow over '%s', which allows wildcard subjects", t->name, r->name, e->a); return 0; }
                 }
             }
         }
@@ -488,8 +520,8 @@ static size_t row_find(const orc_t *o, size_t lo, size_t hi, int stype, unsigned
  * depth_remaining follows dispatch.CheckDepth: a dispatch entered with 0
  * remaining fails with "max depth exceeded"; every nested dispatch (computed
  * userset, arrow target, userset subject) passes depth_remaining-1.
- * Result lattice (deterministic restatement of SpiceDB's racing union):
- * HAS beats ERR beats NO.
+ * Result lattice (deterministic restatement of SpiceDB's racing set operations, see the
+ * header): union HAS > ERR > NO; intersection NO > ERR > HAS; exclusion base first.
  */
 typedef struct { int stype; unsigned srel; uint32_t sid; } subject_t;
 enum { R_NO = 0, R_HAS = 1, R_ERR = 2 };
@@ -548,6 +580,19 @@ static int eval_expr(orc_t *o, int type, const expr_t *e, uint32_t id, const sub
     type_t *t = &o->types[type];
     switch (e->kind) {
     case EX_NIL: return R_NO;
+    case EX_INTERSECT: { /* `all`: the first empty operand decides; neither operand is a dispatch of its own */
+        int a = eval_expr(o, type, e->l, id, s, depth_remaining);
+        if (a == R_NO) return R_NO;
+        int b = eval_expr(o, type, e->r, id, s, depth_remaining);
+        if (b == R_NO) return R_NO;
+        return (a == R_ERR || b == R_ERR) ? R_ERR : R_HAS;
+    }
+    case EX_EXCLUDE: { /* `difference`: the base is waited for first; an empty base decides without the subtracted set */
+        int a = eval_expr(o, type, e->l, id, s, depth_remaining);
+        if (a != R_HAS) return a;
+        int b = eval_expr(o, type, e->r, id, s, depth_remaining);
+        return b == R_ERR ? R_ERR : (b == R_HAS ? R_NO : R_HAS);
+    }
     case EX_UNION: {
         int a = eval_expr(o, type, e->l, id, s, depth_remaining);
         if (a == R_HAS) return R_HAS;
@@ -603,10 +648,14 @@ static int check_rel_body(orc_t *o, int type, int rel, uint32_t id, const subjec
         size_t p = row_find(o, lo, hi, s->stype, s->srel, s->sid);
         o->cnt_edges += hi - lo;
         if (p < hi && tup_live(o, &o->tup[p])) return R_HAS;
+        if (s->srel == ELLIPSIS) { /* `T:*` on the row: every plain subject of type T is a member */
+            for (size_t i = lo; i < hi; i++)
+                if (o->tup[i].stype == s->stype && o->tup[i].srel == WILDCARD && tup_live(o, &o->tup[i])) return R_HAS;
+        }
     }
     for (size_t i = lo; i < hi; i++) { /* userset subjects: dispatch */
         const tuple_t *tp = &o->tup[i];
-        if (!tup_live(o, tp) || tp->srel == ELLIPSIS) continue;
+        if (!tup_live(o, tp) || tp->srel == ELLIPSIS || tp->srel == WILDCARD) continue;
         int x = check_rel(o, tp->stype, (int)tp->srel, tp->subj, s, depth_remaining - 1);
         if (x == R_HAS) return R_HAS;
         acc = join_union(acc, x);
@@ -636,7 +685,7 @@ void orc_free(orc_t *o) {
         for (int j = 0; j < t->nrels; j++) {
             rel_t *r = &t->rels[j];
             for (int k = 0; k < r->nallowed; k++) { free(r->a_type[k]); free(r->a_rel[k]); }
-            free(r->a_type); free(r->a_rel); free(r->a_exp); free(r->allowed);
+            free(r->a_type); free(r->a_rel); free(r->a_exp); free(r->a_wild); free(r->allowed);
             ex_free(r->expr);
             free(r->name);
         }
@@ -681,7 +730,7 @@ static const allowed_t *allowed_subject(orc_t *o, int rtype, int rel, int stype,
 /* Bulk numeric load: object ids are caller-chosen dense integers (no strings).
  * Appends; call orc_freeze() (or any read) afterwards. */
 int orc_add_edges(orc_t *o, int rtype, int rel, int stype, int srel, size_t n, const uint32_t *res, const uint32_t *subj) {
-    unsigned sr = srel < 0 ? ELLIPSIS : (unsigned)srel;
+    unsigned sr = srel == -2 ? WILDCARD : (srel < 0 ? ELLIPSIS : (unsigned)srel); /* -2: `stype:*` relationships (subj[] is ignored) */
     if (rtype < 0 || rtype >= o->ntypes || rel < 0 || rel >= o->types[rtype].nrels || o->types[rtype].rels[rel].is_perm ||
         !allowed_subject(o, rtype, rel, stype, sr)) {
         seterr(o, "add_edges: subject type not allowed on relation");
@@ -694,7 +743,7 @@ int orc_add_edges(orc_t *o, int rtype, int rel, int stype, int srel, size_t n, c
     for (size_t i = 0; i < n; i++) {
         tuple_t *t = &o->tup[o->ntup++];
         t->rtype = (uint16_t)rtype; t->rel = (uint16_t)rel; t->res = res[i];
-        t->stype = (uint16_t)stype; t->srel = (uint16_t)sr; t->subj = subj[i];
+        t->stype = (uint16_t)stype; t->srel = (uint16_t)sr; t->subj = sr == WILDCARD ? 0u : subj[i];
         t->expires = 0;
     }
     o->sorted = 0;
@@ -736,13 +785,17 @@ static int resolve_rel(orc_t *o, const orc_rel_t *r, tuple_t *out, int intern) {
         if (x < 0) { seterr(o, "relation/permission `%s` not found under definition `%s`", r->srel, r->stype); return ORC_ERR_FAILED_PRECONDITION; }
         sr = (unsigned)x;
     }
+    if (strcmp(r->sid, "*") == 0) { /* `T:*`: a class of its own; never with a subject relation */
+        if (sr != ELLIPSIS) { seterr(o, "invalid relationship: wildcard subject with a relation"); return ORC_ERR_INVALID_ARGUMENT; }
+        sr = WILDCARD;
+    }
     out->rtype = (uint16_t)rt; out->rel = (uint16_t)rl; out->stype = (uint16_t)st; out->srel = (uint16_t)sr;
     if (intern) {
         out->res = st_intern(&o->types[rt].objs, r->rid);
-        out->subj = st_intern(&o->types[st].objs, r->sid);
+        out->subj = sr == WILDCARD ? 0u : st_intern(&o->types[st].objs, r->sid);
     } else {
         out->res = st_find(&o->types[rt].objs, r->rid);
-        out->subj = st_find(&o->types[st].objs, r->sid);
+        out->subj = sr == WILDCARD ? 0u : st_find(&o->types[st].objs, r->sid);
     }
     out->expires = r->expires_at;
     return ORC_OK;
@@ -755,11 +808,11 @@ static int filter_match(orc_t *o, const orc_filter_t *f, const tuple_t *t) {
     if (f->rel && *f->rel && strcmp(o->types[t->rtype].rels[t->rel].name, f->rel) != 0) return 0;
     if (f->stype) {
         if (strcmp(o->types[t->stype].name, f->stype) != 0) return 0;
-        if (f->sid && *f->sid && strcmp(o->types[t->stype].objs.strs[t->subj], f->sid) != 0) return 0;
+        if (f->sid && *f->sid && strcmp(t->srel == WILDCARD ? "*" : o->types[t->stype].objs.strs[t->subj], f->sid) != 0) return 0;
         if (f->srel) {
-            if (!*f->srel || strcmp(f->srel, "...") == 0) { if (t->srel != ELLIPSIS) return 0; }
+            if (!*f->srel || strcmp(f->srel, "...") == 0) { if (t->srel != ELLIPSIS && t->srel != WILDCARD) return 0; }
             else {
-                if (t->srel == ELLIPSIS) return 0;
+                if (t->srel == ELLIPSIS || t->srel == WILDCARD) return 0;
                 if (strcmp(o->types[t->stype].rels[t->srel].name, f->srel) != 0) return 0;
             }
         }
@@ -804,7 +857,7 @@ int orc_write(orc_t *o, const orc_update_t *ups, int nups, const orc_filter_t *p
         if (!a) {
             free(res);
             seterr(o, "subjects of type `%s%s%s` are not allowed on relation `%s#%s`", ups[i].rel.stype,
-                   t->srel == ELLIPSIS ? "" : "#", t->srel == ELLIPSIS ? "" : ups[i].rel.srel, ups[i].rel.rtype, ups[i].rel.rel);
+                   t->srel == WILDCARD ? ":*" : (t->srel == ELLIPSIS ? "" : "#"), t->srel >= WILDCARD ? "" : ups[i].rel.srel, ups[i].rel.rtype, ups[i].rel.rel);
             return ORC_ERR_INVALID_ARGUMENT;
         }
         if (t->expires && !a->expiring) { free(res); seterr(o, "relation does not allow expiration"); return ORC_ERR_INVALID_ARGUMENT; }
@@ -872,8 +925,8 @@ int orc_read(orc_t *o, const orc_filter_t *f, orc_read_cb cb, void *user) {
         const tuple_t *t = &o->tup[i];
         if (!filter_match(o, f, t)) continue;
         cb(user, o->types[t->rtype].name, o->types[t->rtype].objs.strs[t->res], o->types[t->rtype].rels[t->rel].name,
-           o->types[t->stype].name, o->types[t->stype].objs.strs[t->subj],
-           t->srel == ELLIPSIS ? "" : o->types[t->stype].rels[t->srel].name, t->expires);
+           o->types[t->stype].name, t->srel == WILDCARD ? "*" : o->types[t->stype].objs.strs[t->subj],
+           t->srel >= WILDCARD ? "" : o->types[t->stype].rels[t->srel].name, t->expires);
     }
     return ORC_OK;
 }
@@ -1097,7 +1150,7 @@ static uint64_t check_bytes_core(orc_t *o, int rtype, int perm, uint32_t res, in
                     int fresh = set_add(&seen_rows, rowkey);
                     if (fresh) bytes += 8;
                     int is_member_class = a->stype == s.stype && a->srel == s.srel;
-                    if (a->srel != ELLIPSIS) { /* userset class: enumerate */
+                    if (a->srel < WILDCARD) { /* userset class: enumerate */
                         if (fresh) bytes += 4 * deg;
                         for (size_t i = lo; i < hi; i++) {
                             const tuple_t *tp = &o->tup[i];
@@ -1117,7 +1170,7 @@ static uint64_t check_bytes_core(orc_t *o, int rtype, int perm, uint32_t res, in
                 stack[sp++] = r->expr;
                 while (sp) {
                     const expr_t *e = stack[--sp];
-                    if (e->kind == EX_UNION) { stack[sp++] = e->l; stack[sp++] = e->r; }
+                    if (e->kind == EX_UNION || e->kind == EX_INTERSECT || e->kind == EX_EXCLUDE) { stack[sp++] = e->l; stack[sp++] = e->r; }
                     else if (e->kind == EX_REF) PUSH_NEXT(st.type, rel_index(&o->types[st.type], e->a), st.id);
                     else if (e->kind == EX_ARROW) {
                         int ts = rel_index(&o->types[st.type], e->a);

@@ -217,8 +217,9 @@ class Oracle:
         res = np.ascontiguousarray(res, dtype=np.uint32)
         subj = np.ascontiguousarray(subj, dtype=np.uint32)
         assert res.shape == subj.shape
+        # srel "*": `stype:*` relationships (one per entry of res; subj is ignored)
         rc = self._L.orc_add_edges(self._h, self.type_id(rtype), self.rel_id(rtype, rel), self.type_id(stype),
-                                   self.rel_id(stype, srel), res.size, res.ctypes.data, subj.ctypes.data)
+                                   -2 if srel == "*" else self.rel_id(stype, srel), res.size, res.ctypes.data, subj.ctypes.data)
         if rc:
             raise self._err(rc)
 

@@ -10,6 +10,12 @@ written restatements arbitrate each other under hypothesis-generated graphs.
 Written in a different style on purpose: regex schema parser, dict-of-sets
 store, recursive evaluation returning a 3-valued result.
 Pure-Python loops: small cases only.
+
+Round 4: intersection `&`, exclusion `-` (precedence loosest to tightest `-`, `&`, `+`;
+three-valued results: union HAS > ERR > NO, intersection NO > ERR > HAS, exclusion
+base-first) and wildcard subjects `T:*` -- the same EXTERNAL, unverified restatement
+of SpiceDB's `all` / `difference` as the C oracle's header describes, written here as
+a precedence-climbing parser and table lookups instead of nested ifs.
 """
 from __future__ import annotations
 
@@ -34,7 +40,7 @@ class Relation:
 @dataclass
 class Permission:
     name: str
-    expr: tuple  # ('union', a, b) | ('ref', name) | ('arrow', tupleset, computed) | ('nil',)
+    expr: tuple  # ('union' | 'inter' | 'excl', a, b) | ('ref', name) | ('arrow', tupleset, computed) | ('nil',)
 
 
 @dataclass
@@ -68,13 +74,20 @@ def _parse_expr(tokens: list, pos: int):
             return ("arrow", t, tokens[p + 4]), p + 6
         return ("ref", t), p + 1
 
-    left, pos = term(pos)
-    while pos < len(tokens) and tokens[pos] in "+&-" and tokens[pos] != "->":
-        if tokens[pos] != "+":
-            raise SchemaError("unsupported: intersection/exclusion")
-        right, pos = term(pos + 1)
-        left = ("union", left, right)
-    return left, pos
+    # precedence climbing: a level's operands are the next-tighter level's expressions
+    levels = [("-", "excl"), ("&", "inter"), ("+", "union")]
+
+    def level(i, p):
+        if i == len(levels):
+            return term(p)
+        op, name = levels[i]
+        left, p = level(i + 1, p)
+        while p < len(tokens) and tokens[p] == op:
+            right, p = level(i + 1, p + 1)
+            left = (name, left, right)
+        return left, p
+
+    return level(0, pos)
 
 
 def parse_schema(text: str) -> dict:
@@ -98,15 +111,17 @@ def parse_schema(text: str) -> dict:
                 allowed = []
                 for alt in rest.split("|"):
                     alt = alt.strip()
-                    mm = re.fullmatch(r"([\w/]+)(?:#(\w+))?(\s+with\s+expiration)?", alt)
+                    mm = re.fullmatch(r"([\w/]+)(?:#(\w+)|(:\*))?(\s+with\s+expiration)?", alt)
                     if not mm:
                         raise SchemaError(f"unsupported subject reference {alt!r}")
-                    allowed.append((mm.group(1), mm.group(2), bool(mm.group(3))))
+                    allowed.append((mm.group(1), "*" if mm.group(3) else mm.group(2), bool(mm.group(4))))
                 d.members[name] = Relation(name, allowed)
             else:
                 if sep != "=":
                     raise SchemaError("permission needs '='")
                 toks = re.findall(r"->|[A-Za-z_][\w/]*|[()+&\-.]", rest)
+                if re.sub(r"->|[A-Za-z_][\w/]*|[()+&\-.]|\s", "", rest):
+                    raise SchemaError(f"unexpected characters in permission expression {rest!r}")
                 expr, pos = _parse_expr(toks, 0)
                 if pos != len(toks):
                     raise SchemaError("trailing tokens in permission expression")
@@ -119,7 +134,7 @@ def parse_schema(text: str) -> dict:
         for mem in d.members.values():
             if isinstance(mem, Relation):
                 for (st, sr, _e) in mem.allowed:
-                    if st not in defs or (sr and sr not in defs[st].members):
+                    if st not in defs or (sr and sr != "*" and sr not in defs[st].members):
                         raise SchemaError(f"unknown subject reference {st}#{sr}")
             else:
                 _validate(defs, d, mem.expr)
@@ -127,13 +142,22 @@ def parse_schema(text: str) -> dict:
 
 
 def _validate(defs, d, e):
-    if e[0] == "union":
+    if e[0] in ("union", "inter", "excl"):
         _validate(defs, d, e[1])
         _validate(defs, d, e[2])
     elif e[0] == "ref" and e[1] not in d.members:
         raise SchemaError(f"unknown reference {e[1]}")
-    elif e[0] == "arrow" and not isinstance(d.members.get(e[1]), Relation):
-        raise SchemaError(f"arrow over non-relation {e[1]}")
+    elif e[0] == "arrow":
+        ts = d.members.get(e[1])
+        if not isinstance(ts, Relation):
+            raise SchemaError(f"arrow over non-relation {e[1]}")
+        if any(a[1] == "*" for a in ts.allowed):
+            raise SchemaError(f"arrow over {e[1]}, which allows wildcard subjects")
+
+
+# intersection: an empty operand decides (NO), then an error, then HAS; exclusion with a HAS base: by the subtracted operand
+_INTER = {(a, b): (NO if NO in (a, b) else ERR if ERR in (a, b) else HAS) for a in (NO, HAS, ERR) for b in (NO, HAS, ERR)}
+_MINUS = {NO: HAS, HAS: NO, ERR: ERR}
 
 
 class PyOracle:
@@ -149,7 +173,10 @@ class PyOracle:
     def touch(self, rtype, rid, rel, stype, sid, srel="", expires=0):
         mem = self.defs[rtype].members[rel]
         assert isinstance(mem, Relation)
-        assert any(a[0] == stype and (a[1] or "") == srel for a in mem.allowed), "subject not allowed"
+        if sid == "*":  # `T:*`: its own allowed form, stored as the subject (T, "*", "")
+            assert srel == "" and any(a[0] == stype and a[1] == "*" for a in mem.allowed), "wildcard not allowed"
+        else:
+            assert any(a[0] == stype and a[1] != "*" and (a[1] or "") == srel for a in mem.allowed), "subject not allowed"
         self.rows.setdefault((rtype, rid, rel), {})[(stype, sid, srel)] = expires
 
     def delete(self, rtype, rid, rel, stype, sid, srel=""):
@@ -178,6 +205,8 @@ class PyOracle:
             subs = self._subjects(rtype, rid, rel)
             if subject in subs:
                 return HAS
+            if subject[2] == "" and (subject[0], "*", "") in subs:
+                return HAS  # a wildcard covers every plain subject of its type
             for (st, sid, sr) in subs:
                 if sr:
                     results.append(self._check(st, sid, sr, subject, depth - 1))
@@ -188,6 +217,13 @@ class PyOracle:
     def _eval(self, rtype, rid, e, subject, depth):
         if e[0] == "nil":
             return NO
+        if e[0] == "inter":
+            a = self._eval(rtype, rid, e[1], subject, depth)
+            b = NO if a == NO else self._eval(rtype, rid, e[2], subject, depth)
+            return _INTER[a, b]
+        if e[0] == "excl":
+            a = self._eval(rtype, rid, e[1], subject, depth)
+            return a if a != HAS else _MINUS[self._eval(rtype, rid, e[2], subject, depth)]
         if e[0] == "union":
             rs = [self._eval(rtype, rid, e[1], subject, depth), self._eval(rtype, rid, e[2], subject, depth)]
         elif e[0] == "ref":

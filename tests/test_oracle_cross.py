@@ -106,3 +106,139 @@ def test_bytes_model_result_agrees_with_check():
         uid = [i for i in range(8) if L.orc_object_name(co._h, tid("user"), i) == u.encode()][0]
         b, r = co.check_bytes("doc", "view", did, "user", "", uid)
         assert r == want and b > 17
+
+
+# ---- round 4: intersection, exclusion, wildcards.  Group nesting may be cyclic, so depth errors meet `&` and
+# `-` from both sides; arrows reach permissions that are themselves non-monotone; wildcards sit in positive and in subtracted operands.
+SCHEMA_NM = """
+definition user {}
+definition group {
+  relation member: user | group#member | user:*
+  relation banned: user | group#member
+  permission active = member - banned
+}
+definition folder {
+  relation parent: folder
+  relation viewer: user | group#member | group#active | user:*
+  relation banned: user | user:*
+  relation auditor: user | group#member
+  permission view = (viewer - banned) + parent->view
+  permission audit = auditor & view
+}
+definition doc {
+  relation folder: folder
+  relation viewer: user | group#active
+  relation editor: user | group#member
+  relation banned: user | group#member
+  permission edit = editor - banned
+  permission view = viewer + edit + folder->view - banned
+  permission strict = viewer & editor & folder->audit
+  permission odd = (viewer - (editor & folder->view)) + (edit & folder->view)
+  permission nothing = nil & viewer
+}
+"""
+FOLDERS = [f"f{i}" for i in range(3)]
+
+
+def nm_tuples_strategy():
+    user = st.sampled_from(USERS + ["*"])
+    plain = st.sampled_from(USERS)
+    group = st.sampled_from(GROUPS)
+    folder = st.sampled_from(FOLDERS)
+    doc = st.sampled_from(DOCS)
+    j = st.just
+    one = st.one_of(
+        st.tuples(j("group"), group, j("member"), j("user"), user, j("")),
+        st.tuples(j("group"), group, j("member"), j("group"), group, j("member")),
+        st.tuples(j("group"), group, j("banned"), j("user"), plain, j("")),
+        st.tuples(j("group"), group, j("banned"), j("group"), group, j("member")),
+        st.tuples(j("folder"), folder, j("parent"), j("folder"), folder, j("")),
+        st.tuples(j("folder"), folder, j("viewer"), j("user"), user, j("")),
+        st.tuples(j("folder"), folder, j("viewer"), j("group"), group, st.sampled_from(["member", "active"])),
+        st.tuples(j("folder"), folder, j("banned"), j("user"), user, j("")),
+        st.tuples(j("folder"), folder, j("auditor"), j("user"), plain, j("")),
+        st.tuples(j("folder"), folder, j("auditor"), j("group"), group, j("member")),
+        st.tuples(j("doc"), doc, j("folder"), j("folder"), folder, j("")),
+        st.tuples(j("doc"), doc, j("viewer"), j("user"), plain, j("")),
+        st.tuples(j("doc"), doc, j("viewer"), j("group"), group, j("active")),
+        st.tuples(j("doc"), doc, j("editor"), j("user"), plain, j("")),
+        st.tuples(j("doc"), doc, j("editor"), j("group"), group, j("member")),
+        st.tuples(j("doc"), doc, j("banned"), j("user"), plain, j("")),
+        st.tuples(j("doc"), doc, j("banned"), j("group"), group, j("member")),
+    )
+    return st.lists(one, min_size=0, max_size=30)
+
+
+def nm_queries():
+    qs = []
+    subjects = [("user", u, "") for u in USERS] + [("group", GROUPS[0], "member"), ("group", GROUPS[1], "active")]
+    for s in subjects:
+        for d in DOCS:
+            for p in ("view", "edit", "strict", "odd", "nothing", "viewer"):
+                qs.append(("doc", d, p) + s)
+        for f in FOLDERS:
+            for p in ("view", "audit"):
+                qs.append(("folder", f, p) + s)
+        for g in GROUPS:
+            for p in ("member", "active"):
+                qs.append(("group", g, p) + s)
+    return qs
+
+
+NM_QUERIES = nm_queries()
+
+
+@settings(max_examples=200, deadline=None)
+@given(nm_tuples_strategy())
+def test_c_oracle_matches_python_oracle_nonmonotone(tuples):
+    co = orc.Oracle(SCHEMA_NM)
+    po = PyOracle(SCHEMA_NM)
+    if tuples:
+        co.write([(orc.OP_TOUCH, t) for t in dict.fromkeys(tuples)])
+    for t in tuples:
+        po.touch(*t)
+    for q in NM_QUERIES:
+        assert co.check(*q) == PY2C[po.check(*q)], q
+    for s in [("user", USERS[0], ""), ("group", GROUPS[0], "member")]:
+        for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("folder", "audit"), ("group", "active")]:
+            assert co.lookup(rt, p, *s) == po.lookup_resources(rt, p, *s), (rt, p, s)
+
+
+def test_precedence_and_three_valued_rules():
+    """The restated operator precedence (`-` loosest, then `&`, then `+`) and the fixed order of the three-valued rules, on both oracles."""
+    schema = """
+    definition user {}
+    definition g { relation member: user | g#member }
+    definition d {
+      relation a: user | g#member
+      relation b: user | g#member
+      relation c: user | g#member
+      permission p1 = a + b - c
+      permission p2 = a - b + c
+      permission p3 = a & b + c
+      permission p4 = a - b & c
+      permission p5 = a - b - c
+      permission deny_err = a - b
+      permission and_err = a & b
+    }
+    """
+    co, po = orc.Oracle(schema), PyOracle(schema)
+    rels = [("d", "x", "a", "user", "u", ""), ("d", "x", "c", "user", "u", ""), ("d", "y", "a", "user", "u", ""), ("d", "y", "b", "user", "u", ""),
+            # a 60-long membership chain: g0 <- g1 <- ... (checking g59#member for a user in g0 crosses the depth limit)
+            ("g", "g0", "member", "user", "deep", "")] + [("g", f"g{i + 1}", "member", "g", f"g{i}", "member") for i in range(60)] + [
+            ("d", "e1", "a", "user", "deep", ""), ("d", "e1", "b", "g", "g59", "member"),   # base HAS, subtracted ERR -> ERR ; a & b: HAS & ERR -> ERR
+            ("d", "e2", "b", "g", "g59", "member"),                                          # base NO: the subtracted error is never looked at -> NO ; NO & ERR -> NO
+            ("d", "e3", "a", "g", "g59", "member"), ("d", "e3", "b", "user", "deep", "")]    # base ERR -> ERR ; ERR & HAS -> ERR
+    co.write([(orc.OP_TOUCH, r) for r in rels])
+    for r in rels:
+        po.touch(*r)
+    H, N, E = (orc.PERM_HAS, 0), (orc.PERM_NO, 0), (orc.PERM_UNSPEC, orc.ERR_DEPTH)
+    want = {("x", "p1"): N,   # (a + b) - c
+            ("x", "p2"): N,   # a - (b + c)
+            ("x", "p3"): H,   # a & (b + c)
+            ("x", "p4"): H,   # a - (b & c): b is empty
+            ("y", "p4"): H, ("y", "p5"): N, ("x", "p5"): N, ("y", "p1"): H, ("y", "p2"): N, ("y", "p3"): H}
+    for (obj, perm), w in want.items():
+        assert co.check("d", obj, perm, "user", "u") == w == PY2C[po.check("d", obj, perm, "user", "u")], (obj, perm)
+    for obj, perm, w in [("e1", "deny_err", E), ("e1", "and_err", E), ("e2", "deny_err", N), ("e2", "and_err", N), ("e3", "deny_err", E), ("e3", "and_err", E)]:
+        assert co.check("d", obj, perm, "user", "deep") == w == PY2C[po.check("d", obj, perm, "user", "deep")], (obj, perm)
