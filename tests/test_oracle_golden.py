@@ -23,10 +23,20 @@ def test_oracle_kat(kat):
     kat_runner.run_kat(kat, o)
 
 
-@pytest.mark.parametrize("bad", [
+@pytest.mark.parametrize("good", [
     "definition a { relation r: a | b:* }\ndefinition b {}",
     "definition u {}\ndefinition a { relation r: u\n permission p = r & r }",
     "definition u {}\ndefinition a { relation r: u\n permission p = r - r }",
+    "definition u {}\ndefinition a { relation r: u | u:*\n relation q: a\n permission p = (r - q->p) & r + nil }",
+])
+def test_oracle_accepts_round4_schema_features(good):
+    orc.Oracle(good).close()
+
+
+@pytest.mark.parametrize("bad", [
+    "definition a { relation r: a | b:x }\ndefinition b {}",
+    "definition u {}\ndefinition a { relation r: u | u:*\n relation q: a\n permission p = r->q }",  # arrow over a relation that allows wildcards
+    "definition u {}\ndefinition a { relation r: u\n permission p = r & }",
     "caveat c(x int) { x > 1 }\ndefinition u {}",
     "definition u {}\ndefinition a { relation r: u with c }",
     "definition u {}\ndefinition a { relation r: a\n permission p = r.all(p) }",
