@@ -126,7 +126,7 @@ int acl_delete_by_filter_pre(acl_engine_t *h, const acl_filter_t *filter, const 
 typedef void (*acl_read_cb)(void *user, const acl_relationship_t *rel);
 int acl_read(acl_engine_t *h, const acl_filter_t *filter, acl_read_cb cb, void *user);
 /* bulk load with caller-chosen dense numeric ids (ImportBulkRelationships analogue; TOUCH semantics) */
-int acl_add_edges(acl_engine_t *h, int rtype, int relation, int stype, int srel /* -1 none */, size_t n, const uint32_t *resource_ids,
+int acl_add_edges(acl_engine_t *h, int rtype, int relation, int stype, int srel /* -1 none; -2: `stype:*` wildcard relationships (subject_ids ignored) */, size_t n, const uint32_t *resource_ids,
                   const uint32_t *subject_ids);
 uint64_t acl_revision(acl_engine_t *h);
 /* test clock for relationship expiration; 0 = wall clock */

@@ -157,8 +157,9 @@ class Engine:
         res = np.ascontiguousarray(res, dtype=np.uint32)
         subj = np.ascontiguousarray(subj, dtype=np.uint32)
         assert res.shape == subj.shape
+        # srel "*": `stype:*` relationships, one per entry of res (subj is ignored)
         self._check(self._L.acl_add_edges(self._h, self.type_id(rtype), self.relation_id(rtype, rel), self.type_id(stype),
-                                          self.relation_id(stype, srel), res.size, res.ctypes.data, subj.ctypes.data))
+                                          -2 if srel == "*" else self.relation_id(stype, srel), res.size, res.ctypes.data, subj.ctypes.data))
 
     def set_now(self, t: int):
         self._check(self._L.acl_set_now(self._h, int(t)))

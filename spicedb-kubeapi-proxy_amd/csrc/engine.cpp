@@ -172,7 +172,7 @@ static bool compaction_due(acl_engine *h) {
         if (low(h->store.objects(sc.slot_owner[slot].first).count(), l.nrows)) return true;
         for (size_t k = 0; k < l.cls.size(); k++) {
             const auto [t, m] = sc.slot_owner[slot];
-            if (l.cls[k].hashed && low(h->store.objects(sc.defs[t].members[m].classes[k].stype).count(), l.cls[k].nsubjects)) return true;
+            if (l.cls[k].hashed && !sc.defs[t].members[m].classes[k].wildcard && low(h->store.objects(sc.defs[t].members[m].classes[k].stype).count(), l.cls[k].nsubjects)) return true;
         }
     }
     return false;
@@ -204,7 +204,7 @@ static void compaction_start(acl_engine *h) {
             if (c->with_reverse) build_reverse(*view, c->now, &c->snap, c->shard);
             const Snapshot &s = c->snap;
             ok = std::max({s.meta.size(), s.edges.size(), s.buckets.size()}) < ((size_t)1 << 30) && up(c->d_meta, s.meta) && up(c->d_edges, s.edges) &&
-                 up(c->d_buckets, s.buckets) && up(c->d_ops, s.ops) && up(c->d_progs, s.progs) && up(c->d_tsb, s.type_slot_base) && up(c->d_tnm, s.type_nmembers);
+                 up(c->d_buckets, s.buckets) && up(c->d_ops, s.ops) && up(c->d_progs, s.progs) && up(c->d_bexpr, s.bexpr) && up(c->d_tsb, s.type_slot_base) && up(c->d_tnm, s.type_nmembers);
             if (ok && c->with_reverse)
                 ok = up(c->d_rmeta, s.rmeta) && up(c->d_redges, s.redges) && up(c->d_rops, s.rops) && up(c->d_rprogs, s.rprogs) && up(c->d_rseeds, s.rseeds) &&
                      up(c->d_sbb, s.slot_bit_base) && up(c->d_snobj, s.slot_nobjects);
@@ -252,6 +252,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     h->d_buckets.swap(c->d_buckets);
     h->d_ops.swap(c->d_ops);
     h->d_progs.swap(c->d_progs);
+    h->d_bexpr.swap(c->d_bexpr);
     h->d_tsb.swap(c->d_tsb);
     h->d_tnm.swap(c->d_tnm);
     if (rev_ok) {
@@ -283,6 +284,8 @@ int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     if (snapshot_current(h, false)) return ACL_OK;
+    if (h->shard.world > 1 && h->store.schema().has_combine)
+        return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated on a sharded graph: a state's operands may live on different shards (use replicas)");
     const int64_t now = h->store.now();
     hipStream_t s = h->up_stream;
     if (h->snap_valid && h->dev_valid && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
@@ -345,6 +348,7 @@ int ensure_snapshot(acl_engine *h) {
     HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
     HIP_TRY(h->d_ops.upload(h->snap.ops, s));
     HIP_TRY(h->d_progs.upload(h->snap.progs, s));
+    HIP_TRY(h->d_bexpr.upload(h->snap.bexpr, s));
     HIP_TRY(h->d_tsb.upload(h->snap.type_slot_base, s));
     HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -525,10 +529,37 @@ static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     return G;
 }
 
+int combine_prepare(acl_engine *h, PassCtx *c, DevGraph *g, uint32_t n, uint32_t blocks, uint32_t rpw) {
+    if (!h->snap.has_combine) return ACL_OK;
+    // nodes: one per visited state with a combine program; cells: its leaves (<= kMaxLeaves, typically 2-3).  A block of the single-launch walk
+    // that outgrows its share sends the batch to the level loop; the level loop's pool running out fails the call.
+    uint64_t node_cap, regions = 1;
+    if (blocks) {
+        node_cap = std::max<uint64_t>(1024, (uint64_t)rpw * 8);
+        regions = blocks;
+    } else {
+        node_cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)1 << 20, (uint64_t)n * 16), (uint64_t)1 << 26);
+    }
+    const uint64_t cell_cap = node_cap * 4;
+    if ((uint64_t)n + regions * cell_cap >= 0xFFFFFFF0ull) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "combine cells beyond 2^32: lower max_sub_batch");
+    HIP_TRY(c->d_nodes.ensure(regions * node_cap));
+    HIP_TRY(c->d_has.ensure((size_t)n + regions * cell_cap));
+    HIP_TRY(c->d_err.ensure((size_t)n + regions * cell_cap));
+    g->bexpr = h->d_bexpr.p;
+    g->nodes = c->d_nodes.p;
+    g->node_cap = (uint32_t)node_cap;
+    g->cell_cap = (uint32_t)cell_cap;
+    g->cell0 = n;
+    g->ccount = blocks ? nullptr : c->d_status.p + 2 * kLevelSlots + 2;  // (the per-destination export counters of the sharded walk: unused here, reset by k_seed)
+    return ACL_OK;
+}
+
 // enqueue-only half (memset of the flag, the launch, the flag's read-back): what check_ids_host chains on the device
-static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
+static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
+    DevGraph g = g0;
+    if (int rc = combine_prepare(h, c, &g, n, G.nblocks, G.rpw)) return rc;
     uint32_t *d_over = c->d_status.p + 2 * kLevelSlots;  // [0] overflow flag, [1] next unit (the sharded walk's export counter: unused here)
     HIP_TRY(hipMemsetAsync(d_over, 0, 3 * sizeof(uint32_t), c->stream));  // [2]: deepest level (a per-destination export counter of the sharded walk: unused here)
     ev_begin(c, 2);
@@ -618,8 +649,10 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     //  way -- the second one's blocks move in as the first one's finish, which fills the tail a lone launch leaves idle: 2 / 4 / 8 / 16 callers
     //  with 262 144-item batches measure 886 / 890 / 914 / 916 M decisions/s, ABOVE the 873 M/s of back-to-back device-resident launches, and a
     //  host mutex around launch + synchronise costs a third of that; profiles/r03_hostmapped_batches.txt.)
+    DevGraph g = h->dev_graph();
+    if (int rc = combine_prepare(h, c, &g, n, G.nblocks, G.rpw)) return rc;
     ev_begin(c, 2);
-    launch_check_local(c->stream, h->dev_graph(), (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_flag, c->d_has.p, c->d_err.p,
+    launch_check_local(c->stream, g, (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_flag, c->d_has.p, c->d_err.p,
                        (uint8_t *)d_perm, (int32_t *)d_errp, nullptr, 0, 0, G.wide);
     ev_end(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -656,7 +689,12 @@ static void walk_outcome(acl_engine *h, size_t n, int rc) {
 constexpr int kRetryMerging = -1002;  // internal: the level loop ran out of frontier on its first attempt
 
 // the level-synchronous pass (one k_expand launch per dispatch level); `merging`: duplicate entries are struck after every level
-static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool merging) {
+static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool merging_asked) {
+    // Schemas with `&` / `-`: entries carry result CELLS, not requests, and the dedup key has 14 request bits -- no duplicate merging there (a
+    // pass that outgrows its frontier only grows it); the combine nodes are evaluated behind the last level, before the answers are written.
+    const bool combine = h->snap.has_combine, merging = merging_asked && !combine;
+    DevGraph g = g0;
+    if (int rc = combine_prepare(h, c, &g, n, 0, 0)) return rc;
     for (int attempt = 0;; attempt++) {
         if ((uint64_t)n > c->frontier_entries) {
             int rc = alloc_frontier(h, c, (uint64_t)n * 4);
@@ -680,12 +718,18 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4
             },
             &levels,
             [&] {
+                if (combine) return;  // (no speculative epilogue: a cell read before its walk is over would turn `a - b` true for good)
                 ev_begin(c, 0);
                 launch_finalize(c->stream, n, c->d_has.p, c->d_err.p, d_perm, d_errout);
                 ev_end(c);
             });
+        if (!rc && combine) {
+            for (uint32_t it = levels + 1; it >= 1; it--) launch_resolve(c->stream, g, it, c->d_has.p, c->d_err.p);
+            launch_finalize(c->stream, n, c->d_has.p, c->d_err.p, d_perm, d_errout);
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
-            if (!merging) return kRetryMerging;
+            if (!merging_asked) return kRetryMerging;
             // out of chunks even with duplicates merged: grow (up to 2^28 entries) and redo the pass
             c->stats.overflow_retries++;
             if (c->frontier_entries >= (uint64_t)kMaxFrontierChunks * kChunk || attempt > 8)
@@ -1274,6 +1318,48 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
     return ACL_OK;
 }
 
+// Schemas with `&` / `-`: the reverse walk only follows POSITIVE occurrences (plan_reverse.cpp), so what it marks is a superset -- the
+// candidates.  The answer is the candidates the forward walk grants: one bulk Check per lookup batch, bits of everything but HAS cleared.
+// (LookupResources(T, p, S) = {id : Check(T:id#p@S) = HAS}; reference call site pkg/authz/lookups.go:65.)
+static int lookup_refine(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words, size_t cw,
+                         uint64_t *counts) {
+    std::vector<acl_item_t> items;
+    std::vector<uint8_t> answers;
+    const uint16_t sr = (uint16_t)(srel < 0 ? ACL_NO_RELATION : srel);
+    const size_t chunk = std::max<size_t>(h->max_sub_batch, 1);
+    size_t i0 = 0;  // first lookup whose candidates are in `items`
+    auto flush = [&](size_t i1) -> int {  // answers the candidates of lookups [i0, i1) and clears the denied ones
+        if (!items.empty()) {
+            answers.resize(items.size());
+            for (size_t b = 0; b < items.size(); b += chunk) {
+                int rc = check_ids_host(h, c, items.data() + b, std::min(chunk, items.size() - b), answers.data() + b, nullptr);
+                if (rc) return rc;
+            }
+            size_t k = 0;
+            for (size_t i = i0; i < i1; i++) {
+                uint32_t *row = bitmaps + i * words;
+                for (size_t w = 0; w < cw; w++)
+                    for (uint32_t m = row[w]; m; m &= m - 1, k++)
+                        if (answers[k] != ACL_PERM_HAS_PERMISSION) row[w] &= ~(m & (0u - m));
+            }
+        }
+        for (size_t i = i0; i < i1; i++)
+            if (counts) counts[i] = popcount_words(bitmaps + i * words, cw);
+        items.clear();
+        i0 = i1;
+        return ACL_OK;
+    };
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t *row = bitmaps + i * words;
+        for (size_t w = 0; w < cw; w++)
+            for (uint32_t m = row[w]; m; m &= m - 1)
+                items.push_back(acl_item_t{(uint16_t)rtype, (uint16_t)perm, (uint32_t)(w * 32 + (size_t)__builtin_ctz(m)), (uint16_t)stype, sr, sids[i]});
+        if (items.size() >= chunk)
+            if (int rc = flush(i + 1)) return rc;
+    }
+    return flush(n);
+}
+
 // one batched reverse walk: n subjects of one class against one (type, permission); bitmaps in host memory
 int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
                  uint64_t *counts) {
@@ -1347,6 +1433,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
             if (counts) counts[b + i] = popcount_words(dst, cw);
         }
     }
+    if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return lookup_refine(h, c, rtype, perm, stype, srel, sids, n, bitmaps, words, cw, counts);
     return ACL_OK;
 }
 

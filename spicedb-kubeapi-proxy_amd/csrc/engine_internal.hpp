@@ -230,6 +230,7 @@ struct PassCtx {
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
     DevArray<uint32_t> d_sids, d_visited, d_rows;
+    DevArray<uint4> d_nodes;     // schemas with `&` / `-`: the CombineNode records of a pass (plan.hpp)
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers
     // native sharded loop (engine_shard_native.cpp): exchange blocks [header | xcap entries], per-level control records
@@ -275,6 +276,7 @@ struct Compaction {
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm, d_rmeta, d_redges, d_sbb, d_snobj;
     DevArray<FwdOp> d_ops;
     DevArray<SlotProg> d_progs;
+    DevArray<uint32_t> d_bexpr;
     DevArray<RevOp> d_rops;
     DevArray<RevProg> d_rprogs, d_rseeds;
     std::string error;
@@ -310,6 +312,7 @@ struct acl_engine {
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
     DevArray<FwdOp> d_ops;
     DevArray<SlotProg> d_progs;
+    DevArray<uint32_t> d_bexpr;  // boolean programs of the combine slots (schemas with `&` / `-`)
     // reverse graph
     DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj;
     DevArray<RevOp> d_rops;
@@ -420,6 +423,9 @@ DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap);
 int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index);
 void merge_stats(acl_engine *h, PassCtx *c);
 
+// schemas with `&` / `-`: sizes the pass's node list and result cells (has[] / err[] behind the n requests' own) and points g at them.
+// blocks > 0: the single-launch walk (per-block regions for units of rpw requests); 0: the level loop (one pool, counters in the status block)
+int combine_prepare(acl_engine *h, PassCtx *c, DevGraph *g, uint32_t n, uint32_t blocks, uint32_t rpw);
 int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local = true);
 // every level in ONE launch, wave-private frontiers; an internal negative code when a wave's private frontier overflowed (engine.cpp)
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
@@ -484,6 +490,7 @@ int level_loop(acl_engine *h, PassCtx *c, uint32_t max_iter, F launch, uint32_t 
         HIP_TRY(hipStreamSynchronize(c->stream));
         ev_collect(c);
         if (c->h_status[2 * kLevelSlots] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+        if (c->h_status[2 * kLevelSlots] == 3) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "the batch visits more states with intersection / exclusion rewrites than one pass holds: lower max_sub_batch");
         if (c->h_status[2 * kLevelSlots]) return ACL_ERR_RESOURCE_EXHAUSTED;
         uint32_t done_at = 0;
         for (uint32_t it = next; it <= last; it++)

@@ -36,6 +36,8 @@ int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse) {
         int rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;
     }
+    if (h->store.schema().has_combine)  // (the sharded kernels are the monotone instantiations: a state's operands may live on different shards)
+        return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated through the sharded entry points (use replicas)");
     if (!h->shard_ctx) {
         std::unique_ptr<PassCtx> nc;
         int rc = new_ctx(h, &nc, -1);

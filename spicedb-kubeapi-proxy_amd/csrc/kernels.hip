@@ -234,6 +234,7 @@ __device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ bu
 // lanes of a wave (which hold a few requests' worth of neighbouring entries) keep hitting the same descriptor
 // and the same few bucket lines instead of 64 different resource rows.
 __device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const FwdOp &op, uint32_t id, uint32_t sid) {
+    if (op.flags & OP_WILD) sid = op.K;  // `T:*`: the wildcard subject's row, whoever asks (the fast paths only take plain OP_PROBE_HASH programs)
     if (sid >= op.nrows) return false;
     const uint2 md = gld(reinterpret_cast<const uint2 *>(g.meta), op.base + sid);
     return md.y > md.x && bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, id);
@@ -248,6 +249,57 @@ __device__ __forceinline__ uint2 row_meta(const DevGraph &g, const FwdOp &op, ui
         return op.k ? make_uint2(v.z, v.w) : make_uint2(v.x, v.y);
     }
     return gld(reinterpret_cast<const uint2 *>(g.meta), op.base + id * op.K + op.k);
+}
+
+// ---- combine programs (rewrites with `&` / `-`; plan.hpp SlotProg::combine).  A visited state with such a program gets `nleaves` fresh result
+// cells (bytes of has[] / err[] behind the requests' own) and a CombineNode; its ops answer those cells exactly as a monotone walk answers a
+// request; when the walk is over the nodes are evaluated deepest iteration first (resolve_node).  Everything here is compiled only into the
+// CMB instantiations: the monotone kernels carry none of it.
+struct CombineOut {  // (wave-uniform)
+    uint4 *nodes = nullptr;                        // the region this walk appends to
+    uint32_t *nnode = nullptr, *ncell = nullptr;   // its counters: LDS (single launch) or the status block (level loop)
+    uint32_t node_cap = 0, cell_cap = 0, cell0 = 0;  // cell0: index of the region's first cell in has[] / err[]
+    uint32_t iter = 0;                             // frontier iteration being processed
+    const uint32_t *bexpr = nullptr;
+};
+enum : uint32_t { V_NO = 0u, V_HAS = 1u, V_ERR = 2u };
+__device__ __forceinline__ uint32_t cell_value(const uint8_t *has, const uint8_t *err, uint32_t c) {
+    const uint32_t h = __hip_atomic_load(has + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t e = __hip_atomic_load(err + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return h ? V_HAS : (e ? V_ERR : V_NO);
+}
+// value stack: two bits per value in one 64-bit register (<= kMaxLeaves values)
+__device__ __forceinline__ void resolve_node(const uint4 &nd, const SlotProg *progs, const uint32_t *__restrict__ bexpr, uint8_t *has, uint8_t *err) {
+    const SlotProg p = progs[nd.z & 0xFFFFu];
+    const uint32_t *be = bexpr + p.combine;
+    const uint32_t ntok = be[0];
+    const uint32_t *tok = be + 2 + p.nleaves;
+    unsigned long long st = 0;
+    for (uint32_t i = 0; i < ntok; i++) {
+        const uint32_t t = tok[i], kind = t & 0xFF000000u, arg = t & 0xFFFFFFu;
+        uint32_t v;
+        if (kind == BX_LEAF) {
+            v = cell_value(has, err, nd.y + arg - 1u);
+        } else if (kind == BX_EXCL) {
+            const uint32_t sub = (uint32_t)st & 3u, base = (uint32_t)(st >> 2) & 3u;
+            st >>= 4;
+            v = base != V_HAS ? base : (sub == V_ERR ? V_ERR : (sub == V_HAS ? V_NO : V_HAS));
+        } else {  // BX_OR: HAS > ERR > NO; BX_AND: NO > ERR > HAS
+            bool any_has = false, any_err = false, any_no = false;
+            for (uint32_t k = 0; k < arg; k++) {
+                const uint32_t x = (uint32_t)st & 3u;
+                st >>= 2;
+                any_has |= x == V_HAS;
+                any_err |= x == V_ERR;
+                any_no |= x == V_NO;
+            }
+            v = kind == BX_OR ? (any_has ? V_HAS : (any_err ? V_ERR : V_NO)) : (any_no ? V_NO : (any_err ? V_ERR : V_HAS));
+        }
+        st = (st << 2) | v;
+    }
+    const uint32_t v = ntok ? ((uint32_t)st & 3u) : V_NO;
+    if (v == V_HAS) has[nd.x] = 1;
+    else if (v == V_ERR) err[nd.x] = ITEM_ERR_DEPTH;
 }
 
 // Child mode: evaluate every probe of state (slot, id) at `level` for subject (key, sid) without creating tasks.
@@ -551,7 +603,7 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
     }
 }
 
-template <bool INLINE, bool SHARDED, bool LOCAL, bool DESC = false>  // DESC: the tasks carry the subject's hashed row (TaskLds b0 / nb)
+template <bool INLINE, bool SHARDED, bool LOCAL, bool DESC = false, bool CMB = false>  // DESC: the tasks carry the subject's hashed row (TaskLds b0 / nb); CMB: child slots may hold combine programs
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
                                             const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh,
                                             bool same = false /* the caller made every task from ONE op: child slot, key and flags agree */) {
@@ -582,7 +634,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             if (!only) return;
         } else
         // second shape: <= 2 hashed probes + <= 2 enumerate ops that are only looked at; uniform slot, key and leaf authority
-        if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2) {
+        if (k0 >= g.nslots && (!SHARDED || cp.owner == sh.rank) && cp.n_probe <= 2 && cp.n_main - cp.n_probe <= 2 && !(CMB && cp.combine)) {
             const FwdOp *cops = ops + cp.first;
             bool shape = true;
             for (uint32_t q = 0; q < cp.n_main; q++) {
@@ -627,6 +679,8 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     // the child's rows live on another shard: it leaves unprobed and is evaluated by its owner
                     push = false;
                     xport = true;
+                } else if (INLINE && CMB && progs[meta_slot(e.z)].combine) {
+                    // a combine child is visited as a state of its own, unprobed: its probes answer leaf cells that only exist once it is
                 } else if (INLINE) {
                     bool hit = false, derr = false;
                     push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, (c & kLeafAuthBit) != 0,
@@ -714,9 +768,10 @@ __global__ __launch_bounds__(256) void k_rev_seed(DevFrontier f, const uint32_t 
 // come from the wave's private region).  `next` lets the simple-parent fast path pull the following segment in early:
 //   bool peek(uint4 &e, bool &valid)  loads the next segment's entries if there is one (not consumed yet)
 //   void take()                       consumes it
-template <bool SHARDED, bool LOCAL, typename Next>
+template <bool SHARDED, bool LOCAL, bool CMB, typename Next>
 __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next &next, TaskLds &t, WaveOut &wo, uint32_t lane, const DevGraph &g,
-                                                const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh) {
+                                                const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh,
+                                                const CombineOut &co = CombineOut()) {
     const uint32_t id = e.x, req = e.y, meta = e.z;
     // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
     // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read, the
@@ -814,7 +869,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, LA, 0u);
             if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, LB, T);
             ACL_MARK(wo, PH_TASKS);
-            if (T) flush_tasks<true, SHARDED, LOCAL, true>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh, oneslot);
+            if (T) flush_tasks<true, SHARDED, LOCAL, true, CMB>(t, T, wo, lane, g, progs, ops, g.edges, has, err, sh, oneslot);
             ACL_MARK(wo, PH_PUSH);
             return;
         }
@@ -827,6 +882,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
     uint4 ee = e;
     uint32_t jstart = 0;
     bool hit = false;
+    uint32_t cbase = 0;  // CMB: first leaf cell of this lane's combine state (allocated on the first pass over the entry)
     for (;;) {
         // (re)derive everything from the entry: nothing but `ee`, `hit` and `jstart` lives across the expansions below
         asm volatile("" : "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(ee.w));
@@ -837,24 +893,62 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
         SlotProg p{};
         if (active) p = progs[slot];
+        bool cmb = false;
+        if (CMB) {
+            cmb = active && p.combine != 0;
+            if (jstart == 0) {  // first pass over the entry: leaf cells, the node, the leaves' depth errors
+                bool over = false;
+                if (cmb) {
+                    const uint32_t c0 = atomicAdd(co.ncell, p.nleaves), ni = atomicAdd(co.nnode, 1u);
+                    over = c0 + p.nleaves > co.cell_cap || ni >= co.node_cap;
+                    if (!over) {
+                        cbase = co.cell0 + c0;
+                        for (uint32_t k = 0; k < p.nleaves; k++) {
+                            has[cbase + k] = 0;
+                            err[cbase + k] = ITEM_ERR_NONE;
+                        }
+                        co.nodes[ni] = make_uint4(req, cbase, slot | (co.iter << 16), 0u);
+                    }
+                }
+                if (__ballot(over)) {  // out of cells / nodes: the pass is redone elsewhere (single launch -> level loop) or fails (level loop)
+                    if (LOCAL) {
+                        if (lane == 0) *wo.cold->overflow = 1u;
+                        wo.cur = kNoSpace;
+                    } else if (lane == 0) {
+                        *wo.cold->overflow = 3u;
+                    }
+                    if (over) active = cmb = false;
+                }
+                // (the zeroes above are acknowledged before any hit is stored into a cell, by this lane or by the lanes that expand its tasks)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (cmb) {
+                    const uint32_t *be = co.bexpr + p.combine + 1;  // deepest inlined dispatch offset per leaf (0 = the direct ops)
+                    for (uint32_t k = 0; k <= p.nleaves; k++)
+                        if (level + be[k] > kMaxLevels) err[k ? cbase + k - 1u : req] = ITEM_ERR_DEPTH;
+                }
+            }
+        }
         const uint32_t j0 = probed ? p.n_probe : 0u;
         const uint32_t j1 = active ? ((probed || key >= g.nslots) ? p.n_main : p.n_total) : 0u;
-        bool depth_err = active && level + p.max_dlevel > kMaxLevels;
+        bool depth_err = active && !cmb && level + p.max_dlevel > kMaxLevels;
         uint32_t T = 0, nseg = 0, seg_end[kMaxSeg] = {0, 0, 0, 0};
             const uint32_t maxops = uniform(wave_max(j1 > j0 ? j1 - j0 : 0u));
         uint32_t jj = jstart;
         for (; jj < maxops; jj++) {
             const uint32_t j = j0 + jj;
             bool want = false;
-            uint32_t tstart = 0, tcount = 0, tmeta = 0;
+            uint32_t tstart = 0, tcount = 0, tmeta = 0, tcell = req;
             if (j < j1) {
                 const FwdOp op = ops[p.first + j];
                 const uint32_t L = level + op.dlevel;
+                const bool leafop = CMB && op.leaf != 0;  // the op answers one of the state's leaf cells, not the entry's own cell
+                if (leafop) tcell = cbase + op.leaf - 1u;
                 if (L <= kMaxLevels) {
+                    bool h = false, derr = false;  // this op's probe hit / it would dispatch beyond the depth limit
                     if (op.flags & OP_REFLEX) {
-                        if (key == op.key && id == sid) hit = true;
+                        h = key == op.key && id == sid;
                     } else if (op.flags & OP_PUSH_SAME) {
-                        if (L + 1 > kMaxLevels) depth_err = true;
+                        if (L + 1 > kMaxLevels) derr = true;
                         else {
                             want = true;
                             tstart = id;
@@ -862,15 +956,15 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                             tmeta = make_meta(op.key, L + 1, key);
                         }
                     } else if (op.flags & OP_PROBE_HASH) {
-                        if (key == op.key) hit |= subject_row_contains(g, op, id, sid);
+                        if (key == op.key) h = subject_row_contains(g, op, id, sid);
                     } else if (id < op.nrows) {
                         const uint2 md = row_meta(g, op, id);
                         if (md.y > md.x) {
-                            if ((op.flags & OP_PROBE) && key == op.key) hit |= row_contains(g.edges, md.x, md.y, sid);
+                            if ((op.flags & OP_PROBE) && key == op.key) h = row_contains(g.edges, md.x, md.y, sid);
                             if (op.flags & OP_ENUM) {
-                                if (L + 1 > kMaxLevels) depth_err = true;
+                                if (L + 1 > kMaxLevels) derr = true;
                                 else if (md.y - md.x > kMaxRow) *wo.cold->overflow = 2u;
-                                else if (!hit) {
+                                else if (!(leafop ? h : (hit || h))) {
                                     want = true;
                                     tstart = md.x;
                                     tcount = (md.y - md.x) | ((op.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
@@ -879,13 +973,20 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                             }
                         }
                     }
+                    if (leafop) {
+                        if (h) has[tcell] = 1;
+                        else if (derr) err[tcell] = ITEM_ERR_DEPTH;
+                    } else {
+                        hit |= h;
+                        depth_err |= derr;
+                    }
                 }
             }
             const uint64_t b = __ballot(want);
             if (b) {
                 if (want) {
                     const uint32_t q = T + lanes_below(b);
-                    t.a[q] = make_uint4(tstart, 0u, 1u, req);  // (the subject's row is looked up by the expansion that needs it)
+                    t.a[q] = make_uint4(tstart, 0u, 1u, tcell);  // (the subject's row is looked up by the expansion that needs it)
                     t.count[q] = tcount;
                     t.meta[q] = tmeta;
                     t.sid[q] = sid;
@@ -916,7 +1017,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 wave_lds_fence();
                 if (lane < cnt) { t.a[lane] = c0; t.count[lane] = c1; t.meta[lane] = c3; t.sid[lane] = c4; }
             }
-            flush_tasks<true, SHARDED, LOCAL>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            flush_tasks<true, SHARDED, LOCAL, false, CMB>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh);
             a = bnd;
         }
         if (!more) break;
@@ -982,7 +1083,7 @@ struct ChunkWalk {
     __device__ __forceinline__ void take() { work &= work - 1; }
 };
 
-template <bool LDSPROG, bool SHARDED>
+template <bool LDSPROG, bool SHARDED, bool CMB = false>
 __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGraph g, DevFrontier f, uint32_t iter, uint8_t *has, uint8_t *err,
                                                                            DevShard sh) {
     __shared__ TaskLds lds[kWavesPerBlock];
@@ -1003,6 +1104,8 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     WaveOut wo = chunked_out(f, iter, wave, &s_cold[wib], lane);
     uint32_t *slots = s_slots[wib];
     ChunkWalk cw{f.buf[pin], lane, slots, 0ull};
+    CombineOut co;
+    if (CMB) co = CombineOut{g.nodes, g.ccount + 1, g.ccount, g.node_cap, g.cell_cap, g.cell0, iter, g.bexpr};
     const uint32_t nslot = C * kSegsPerChunk;
     for (uint32_t x0 = wave; x0 < nslot; x0 += 64 * nwaves) {
         // (once per 64 slots: keep the division's precomputed reciprocal out of a VGPR that would live across every expansion)
@@ -1027,7 +1130,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
             uint4 e;
             bool valid;
             cw.load(wl, e, valid);
-            process_segment<SHARDED, false>(e, valid, cw, t, wo, lane, g, progs, ops, has, err, sh);
+            process_segment<SHARDED, false, CMB>(e, valid, cw, t, wo, lane, g, progs, ops, has, err, sh, co);
         }
     }
     if (lane == 0) {
@@ -1080,7 +1183,7 @@ struct NoNext {
 // unit pools, the less the slowest block's sum sticks out: C4's 262 144-item batch 303 us with 4 waves per block (2 048 units of 128 requests),
 // 286 us with 8, 276 us with 16 (512 units of 512), same-box A/B in profiles/r03_waves_per_block_ab.txt.
 constexpr int kLocalNarrow = 4, kLocalWide = 16;
-template <bool LDSPROG, int WAVES>
+template <bool LDSPROG, int WAVES, bool CMB = false>
 __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
                                                                                   uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
                                                                                   uint32_t cap,
@@ -1091,10 +1194,13 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
     // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
     __shared__ uint32_t s_fill[3], s_next[3], s_stop, s_unit;
+    __shared__ uint32_t s_ccount[2];  // CMB: {leaf cells, nodes} of the unit being walked
     extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
     load_programs<LDSPROG>(g, s_prog, progs, ops, WAVES * 64);
+    CombineOut co;  // the block's own region of nodes and leaf cells
+    if (CMB) co = CombineOut{g.nodes + (size_t)blockIdx.x * g.node_cap, &s_ccount[1], &s_ccount[0], g.node_cap, g.cell_cap, g.cell0 + blockIdx.x * g.cell_cap, 1u, g.bexpr};
     const uint32_t lane = lane_id();
     const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
@@ -1125,6 +1231,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             s_fill[threadIdx.x] = 0;
             s_next[threadIdx.x] = 0;
         }
+        if (CMB && threadIdx.x < 2) s_ccount[threadIdx.x] = 0;
         __syncthreads();
         // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit
         const bool valid = threadIdx.x < mine;
@@ -1149,7 +1256,8 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         ACL_MARK(wo, PH_SEED);
         {
             NoNext nn;
-            process_segment<false, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh);
+            co.iter = 1u;
+            process_segment<false, true, CMB>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
         }
         uint32_t parity = 0, level_reached = 1;
         for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
@@ -1170,6 +1278,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             LocalWalk lw{bufs[parity], cnt, 0u, lane, false};
             parity ^= 1u;
             wo.buf = bufs[parity];
+            co.iter = level;
             for (;;) {
                 uint32_t sg = 0;
                 if (lane == 0) sg = atomicAdd(next_seg, 2u);
@@ -1180,13 +1289,27 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
                     const bool v = lw.s * 64 + lane < cnt;
                     const uint4 en = lw.in[v ? lw.s * 64 + lane : lw.s * 64];  // unconditional; process_segment masks by `v`
                     if (lw.s > sg) lw.second = false;
-                    process_segment<false, true>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh);
+                    process_segment<false, true, CMB>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh, co);
                 }
             }
         }
         // (statistics: dispatch levels the deepest request of the batch needed.  Test before the atomic: 2 048 blocks ending together on
         //  one address serialise at ~12 ns each -- C2's 18 us kernel took 38 us with an unconditional atomicMax.)
         if (max_level && threadIdx.x == 0 && level_reached > __hip_atomic_load(max_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_level, level_reached);
+        // ---- combine nodes: deepest iteration first (a node's leaves are answered by the walk and by nodes of LATER iterations only)
+        if (CMB) {
+            __syncthreads();
+            const uint32_t nn = min(s_ccount[1], co.node_cap);
+            if (nn && !s_stop) {
+                for (uint32_t it = level_reached; it >= 1u; it--) {
+                    for (uint32_t i = threadIdx.x; i < nn; i += WAVES * 64) {
+                        const uint4 nd = co.nodes[i];
+                        if ((nd.z >> 16) == it) resolve_node(nd, progs, co.bexpr, has, err);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
         // ---- answers (k_finalize): every wave's has[] / err[] stores are behind a block barrier
         __syncthreads();
         if (valid) {
@@ -1248,6 +1371,16 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
     const uint8_t e = h ? (uint8_t)ITEM_ERR_NONE : err[i];
     perm_out[i] = h ? 2 : (e ? 0 : 1);
     if (err_out) err_out[i] = e == ITEM_ERR_DEPTH ? 100 : (e == ITEM_ERR_INVALID ? 9 : 0);
+}
+
+// Level loop, schemas with `&` / `-`: the combine nodes of ONE frontier iteration (launched for iter = last .. 1; the list is scanned whole
+// every time -- this is the overflow path, not the fast one).
+__global__ __launch_bounds__(256) void k_resolve(DevGraph g, uint32_t iter, uint8_t *has, uint8_t *err) {
+    const uint32_t nn = min(g.ccount[1], g.node_cap);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const uint4 nd = g.nodes[i];
+        if ((nd.z >> 16) == iter) resolve_node(nd, g.progs, g.bexpr, has, err);
+    }
 }
 
 // Post-filter hand-off (reference pkg/authz/postfilter.go:144-178): list item i owns the bulk-check pairs
@@ -1353,8 +1486,8 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                     want = true;
                     tstart = id;
                     tcount = 1u | kSelfBit;
-                } else if (id < op.nrows) {
-                    const uint2 rd = reinterpret_cast<const uint2 *>(r.rmeta)[op.roff_base + id];
+                } else if ((op.flags & OP_WILD) || id < op.nrows) {  // (OP_WILD, seeds only: the wildcard subject's row, whatever the seed's id)
+                    const uint2 rd = reinterpret_cast<const uint2 *>(r.rmeta)[op.roff_base + ((op.flags & OP_WILD) ? 0u : id)];
                     const uint32_t s0 = rd.x, s1 = rd.y;
                     if (s1 - s0 > kMaxRow) *f.overflow = 2u;
                     else if (s1 > s0) {
@@ -1536,8 +1669,8 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                     tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all;
                     if (op.flags & OP_PUSH_SAME) {
                         same = true;
-                    } else if (id < op.nrows) {
-                        const uint2 rd = rmeta2[op.roff_base + id];
+                    } else if ((op.flags & OP_WILD) || id < op.nrows) {  // (OP_WILD, seeds only: the wildcard subject's row, whatever the seed's id)
+                        const uint2 rd = rmeta2[op.roff_base + ((op.flags & OP_WILD) ? 0u : id)];
                         if (rd.y - rd.x > kMaxRow) s_stop = 2u;
                         else if (rd.y > rd.x) {
                             start = rd.x;
@@ -1823,6 +1956,11 @@ void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const u
 void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const dim3 grid(f.nwaves / kWavesPerBlock);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
+    if (g.bexpr) {  // schemas with `&` / `-` (never sharded: acl_shard_configure refuses them)
+        if (lds) hipLaunchKernelGGL((k_expand<true, false, true>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
+        else hipLaunchKernelGGL((k_expand<false, false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+        return;
+    }
     if (sh.world > 1) {
         if (lds) hipLaunchKernelGGL((k_expand<true, true>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
@@ -1836,7 +1974,17 @@ static void launch_check_local_w(hipStream_t s, const DevGraph &g, const uint4 *
                                  uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
                                  uint32_t *max_level) {
     const dim3 grid(nblocks);
-    if (g.nslots + g.nops <= kProgLdsEntries && prog_in_lds())
+    const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
+    if (g.bexpr) {  // schemas with `&` / `-`: the combine instantiations
+        if (lds)
+            hipLaunchKernelGGL((k_check_local<true, WAVES, true>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow,
+                               has, err, perm_out, err_out, max_level);
+        else
+            hipLaunchKernelGGL((k_check_local<false, WAVES, true>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
+                               perm_out, err_out, max_level);
+        return;
+    }
+    if (lds)
         hipLaunchKernelGGL((k_check_local<true, WAVES>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
                            perm_out, err_out, max_level);
     else
@@ -1874,6 +2022,9 @@ void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return;
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
+}
+void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err) {
+    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, has, err);
 }
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key) {
     const uint32_t threads = std::max(std::max(n, f.nwaves), kStatusWords);

@@ -32,6 +32,12 @@ struct DevGraph {
     const SlotProg *progs;
     const uint32_t *type_slot_base, *type_nmembers;
     uint32_t nslots, ntypes, nops;
+    // combine programs (schemas with `&` / `-`, plan.hpp SlotProg::combine); all unused by the monotone instantiations
+    const uint32_t *bexpr = nullptr;   // boolean programs
+    uint4 *nodes = nullptr;            // CombineNode records the walk appends (single launch: node_cap per block; level loop: node_cap in all)
+    uint32_t *ccount = nullptr;        // level loop: {leaf cells handed out, nodes appended} (the single-launch walk counts in LDS)
+    uint32_t node_cap = 0, cell_cap = 0;  // per block (single launch) / in all (level loop)
+    uint32_t cell0 = 0;                // index of the first leaf cell in has[] / err[] (= the batch size: cells follow the requests' own)
 };
 struct DevReverse {
     const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids
@@ -107,6 +113,9 @@ uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= th
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits);
 constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key holds 14 request bits)
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
+// level loop, schemas with `&` / `-`: evaluates the combine nodes of frontier iteration `iter` (call for iter = last .. 1: a node only depends
+// on nodes of later iterations); the node count is read from g.ccount[1] on the device
+void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err);
 void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase = REV_FUSED,
                        const DevShard &sh = DevShard());
 // single-launch LookupResources: block b walks lookup b (subject sids[b] of class `key`) through every reverse level; visited rows r.visited

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
 
 namespace acl {
 namespace {
@@ -62,29 +63,47 @@ struct Flattener {
     const std::vector<RelLayout> &lay;  // [slot]
     const std::vector<uint32_t> &type_owner;
     uint32_t rank;
+    const Store *store = nullptr;  // wildcard subject ids
+    Flattener(const Schema &sc_, const std::vector<RelLayout> &lay_, const std::vector<uint32_t> &owner_, uint32_t rank_, const Store *store_)
+        : sc(sc_), lay(lay_), type_owner(owner_), rank(rank_), store(store_) {}
     std::vector<FwdOp> probes, makers, reflex;
     std::vector<int> stack;
     uint32_t max_d = 0;
+    // combine programs (rewrites with `&` / `-`): every op reports into a LEAF (0 = the state's own result cell)
+    uint32_t cur_leaf = 0;
+    std::vector<uint32_t> leaf_maxd{0};  // [leaf] deepest inlined dispatch offset
+    std::vector<uint32_t> tokens;        // postfix boolean program over the leaves
+    bool combine = false;
 
     size_t nops() const { return probes.size() + makers.size() + reflex.size(); }
+    void note_depth(uint32_t d) {
+        max_d = std::max(max_d, d);
+        leaf_maxd[cur_leaf] = std::max(leaf_maxd[cur_leaf], d);
+    }
     void push_same(int target, uint32_t d) {
         FwdOp op{};
         op.flags = OP_PUSH_SAME;
         op.dlevel = d;
         op.key = (uint32_t)target;
+        op.leaf = cur_leaf;
         makers.push_back(op);
     }
-    void row_op(uint32_t flags, int rel_slot, int k, uint32_t d, uint32_t key) {
+    void row_op(uint32_t flags, int rel_slot, int k, uint32_t d, uint32_t key, uint32_t wild_id = 0xFFFFFFFFu) {
         const RelLayout &l = lay[rel_slot];
         const ClassLayout &c = l.cls[k];
         if (!c.live) return;  // rows held by another shard and referenced from here only through exports (sharded graph)
         FwdOp op{};
         op.dlevel = d;
         op.key = key;
+        op.leaf = cur_leaf;
         if (c.hashed) {  // only ever asked for membership
             op.flags = OP_PROBE_HASH;
             op.base = c.smeta_base;
             op.nrows = c.nsubjects;
+            if (wild_id != 0xFFFFFFFFu) {  // `T:*`: the row of the wildcard subject, whoever asks
+                op.flags |= OP_WILD;
+                op.K = wild_id;
+            }
         } else {
             op.flags = flags;
             op.base = l.meta_base;
@@ -97,18 +116,20 @@ struct Flattener {
     // state (type, member) entered at depth offset d
     void state(int type, int member, uint32_t d) {
         const Member &m = sc.defs[type].members[member];
-        max_d = std::max(max_d, d);
+        note_depth(d);
         {  // the subject itself, when it is exactly this object#relation, is a member
             FwdOp op{};
             op.flags = OP_REFLEX;
             op.dlevel = d;
             op.key = (uint32_t)m.slot;
+            op.leaf = cur_leaf;
             reflex.push_back(op);
         }
         if (!m.is_permission) {
             for (size_t k = 0; k < m.classes.size(); k++) {
                 const SubjectClass &c = m.classes[k];
-                if (c.srel == kNoRelation) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
+                if (c.wildcard) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation), store->wildcard_id(c.stype));
+                else if (c.srel == kNoRelation) row_op(OP_PROBE, m.slot, (int)k, d, sc.subject_key(c.stype, kNoRelation));
                 else  // leaf flags are only computed (and only trusted) for children whose rows this shard holds
                     row_op(OP_PROBE | OP_ENUM | (type_owner[c.stype] == rank ? (uint32_t)OP_LEAFBIT : 0u), m.slot, (int)k, d,
                            (uint32_t)sc.slot(c.stype, c.srel));
@@ -116,10 +137,77 @@ struct Flattener {
             return;
         }
         stack.push_back(m.slot);
-        expr(type, m.expr, d);
+        if (d == 0 && !m.expr.monotone()) root(type, m.expr);
+        else expr(type, m.expr, d);
         stack.pop_back();
     }
-    void expr(int type, const Node &n, uint32_t d) {
+    // ---- combine programs.  The state's value = OR(direct ops, the boolean program's result).  A union at the root keeps its monotone
+    // operands direct (they answer the state's own cell, exactly as in a monotone program); everything under a `&` or `-` is cut into
+    // leaves: maximal union-only sub-expressions, each flattened like a monotone program but reporting into its own cell.
+    uint32_t new_leaf() {
+        leaf_maxd.push_back(0);
+        if (leaf_maxd.size() - 1 > kMaxLeaves) throw std::runtime_error("schema: a permission combines more than " + std::to_string(kMaxLeaves) + " operands under `&` / `-`");
+        return (uint32_t)leaf_maxd.size() - 1;
+    }
+    void leaf_of(int type, const std::vector<const Node *> &parts) {  // one leaf for a union of monotone operands
+        const uint32_t saved = cur_leaf;
+        cur_leaf = new_leaf();
+        for (const Node *n : parts) expr(type, *n, 0);
+        tokens.push_back(BX_LEAF | cur_leaf);
+        cur_leaf = saved;
+    }
+    void build(int type, const Node &n) {
+        if (n.monotone()) {
+            leaf_of(type, {&n});
+            return;
+        }
+        switch (n.kind) {
+            case Node::kUnion: {
+                std::vector<const Node *> mono;
+                uint32_t parts = 0;
+                for (const Node &k : n.kids)
+                    if (k.monotone()) mono.push_back(&k);
+                if (!mono.empty()) {
+                    leaf_of(type, mono);
+                    parts++;
+                }
+                for (const Node &k : n.kids)
+                    if (!k.monotone()) {
+                        build(type, k);
+                        parts++;
+                    }
+                if (parts > 1) tokens.push_back(BX_OR | parts);
+                break;
+            }
+            case Node::kIntersect:
+                for (const Node &k : n.kids) build(type, k);
+                tokens.push_back(BX_AND | (uint32_t)n.kids.size());
+                break;
+            case Node::kExclude:
+                build(type, n.kids[0]);
+                build(type, n.kids[1]);
+                tokens.push_back(BX_EXCL);
+                break;
+            default: break;  // (refs, arrows and nil are monotone)
+        }
+    }
+    void root(int type, const Node &n) {
+        combine = true;
+        if (n.kind != Node::kUnion) {
+            build(type, n);
+            return;
+        }
+        uint32_t parts = 0;
+        for (const Node &k : n.kids) {
+            if (k.monotone()) expr(type, k, 0);  // direct
+            else {
+                build(type, k);
+                parts++;
+            }
+        }
+        if (parts > 1) tokens.push_back(BX_OR | parts);
+    }
+    void expr(int type, const Node &n, uint32_t d) {  // monotone sub-expressions only
         const Definition &def = sc.defs[type];
         switch (n.kind) {
             case Node::kNil: break;
@@ -130,7 +218,9 @@ struct Flattener {
                 int tm = def.find(n.a);
                 int tslot = sc.slot(type, tm);
                 bool recursive = std::find(stack.begin(), stack.end(), tslot) != stack.end();
-                if (recursive || d + 1 > kMaxDepth || nops() >= kMaxOpsPerSlot) push_same(tslot, d);
+                // a referenced permission with `&` / `-` of its own is never inlined: it is a state (and a combine node) of its own
+                const bool nonmono = def.members[tm].is_permission && !def.members[tm].expr.monotone();
+                if (recursive || nonmono || d + 1 > kMaxDepth || nops() >= kMaxOpsPerSlot) push_same(tslot, d);
                 else state(type, tm, d + 1);
                 break;
             }
@@ -145,6 +235,7 @@ struct Flattener {
                 }
                 break;
             }
+            default: break;  // (kIntersect / kExclude never reach here: state() sends them to root(), refs to them are pushed)
         }
     }
 };
@@ -243,19 +334,20 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             if (!c.live || !c.hashed) continue;
             const ClassTable &ct = tables[slot][k];
             const bool filt = !ct.expiry.empty();
-            const uint32_t ns = with_headroom(store.objects(mem.classes[k].stype).count());
+            // (a `T:*` class has ONE subject, the id of the name "*": its descriptor table ends there)
+            const uint32_t ns = mem.classes[k].wildcard ? store.wildcard_id(mem.classes[k].stype) + 1 : with_headroom(store.objects(mem.classes[k].stype).count());
             c.nsubjects = ns;
             c.smeta_base = (uint32_t)(s.meta.size() / 2);
             s.meta.resize(s.meta.size() + 2 * (size_t)ns, 0);
             // group the class's resource ids by subject (counting sort), then lay the rows out one after the other
             cnt.assign((size_t)ns + 1, 0);
             for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) cnt[(uint32_t)key + 1]++;
+                if ((uint32_t)key < ns && (!filt || store.live(ct, key, now))) cnt[(uint32_t)key + 1]++;
             for (uint32_t sid = 0; sid < ns; sid++) cnt[sid + 1] += cnt[sid];
             fill.assign(cnt.begin(), cnt.end() - 1);
             std::vector<uint32_t> by_subject(cnt[ns]);
             for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) by_subject[fill[(uint32_t)key]++] = (uint32_t)(key >> 32);
+                if ((uint32_t)key < ns && (!filt || store.live(ct, key, now))) by_subject[fill[(uint32_t)key]++] = (uint32_t)(key >> 32);
             for (uint32_t sid = 0; sid < ns; sid++) {
                 const auto r = append_hashed_row(s.buckets, by_subject.data() + cnt[sid], cnt[sid + 1] - cnt[sid], 0);
                 uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
@@ -293,7 +385,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     s.progs.resize(sc.nslots);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
-        Flattener f{sc, lay, s.type_owner, shard.rank, {}, {}, {}, {}, 0};
+        Flattener f(sc, lay, s.type_owner, shard.rank, &store);
         f.state(t, m, 0);
         SlotProg p{};
         p.owner = s.type_owner[t];
@@ -302,12 +394,57 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         p.n_main = (uint32_t)(f.probes.size() + f.makers.size());
         p.n_total = (uint32_t)f.nops();
         p.max_dlevel = f.max_d;
+        if (f.combine) {
+            // A parent never evaluates a combine child's probes for it (they answer leaf cells that only exist once the state is visited):
+            // no probe-only prefix, no leaf flags.  The boolean program: [ntokens][deepest offset per leaf 0..nleaves][tokens]
+            p.n_probe = 0;
+            p.nleaves = (uint32_t)f.leaf_maxd.size() - 1;
+            if (s.bexpr.empty()) s.bexpr.push_back(0);
+            p.combine = (uint32_t)s.bexpr.size();
+            s.bexpr.push_back((uint32_t)f.tokens.size());
+            s.bexpr.insert(s.bexpr.end(), f.leaf_maxd.begin(), f.leaf_maxd.end());
+            s.bexpr.insert(s.bexpr.end(), f.tokens.begin(), f.tokens.end());
+            s.has_combine = true;
+        }
         s.ops.insert(s.ops.end(), f.probes.begin(), f.probes.end());
         s.ops.insert(s.ops.end(), f.makers.begin(), f.makers.end());
         s.ops.insert(s.ops.end(), f.reflex.begin(), f.reflex.end());
         s.progs[slot] = p;
     }
     if (s.ops.empty()) s.ops.push_back(FwdOp{});
+    if (s.bexpr.empty()) s.bexpr.push_back(0);
+    // which slots' values can depend on a combine program (their LookupResources is candidates + a forward Check): the combine slots and
+    // whatever reaches one through a reference, an arrow or a userset subject
+    s.slot_nonmono.assign(sc.nslots, 0);
+    for (int slot = 0; slot < sc.nslots; slot++) s.slot_nonmono[slot] = s.progs[slot].combine ? 1 : 0;
+    for (bool grew = s.has_combine; grew;) {
+        grew = false;
+        for (int slot = 0; slot < sc.nslots; slot++) {
+            if (s.slot_nonmono[slot]) continue;
+            auto [t, m] = sc.slot_owner[slot];
+            const Member &mem = sc.defs[t].members[m];
+            bool taint = false;
+            if (!mem.is_permission) {
+                for (const SubjectClass &c : mem.classes)
+                    if (c.srel != kNoRelation && s.slot_nonmono[sc.slot(c.stype, c.srel)]) taint = true;
+            } else {
+                std::vector<const Node *> refs, arrows;
+                collect(mem.expr, Node::kRef, &refs);
+                collect(mem.expr, Node::kArrow, &arrows);
+                for (const Node *r : refs)
+                    if (s.slot_nonmono[sc.slot(t, sc.defs[t].find(r->a))]) taint = true;
+                for (const Node *a : arrows)
+                    for (const SubjectClass &c : sc.defs[t].members[sc.defs[t].find(a->a)].classes) {
+                        const int tm = sc.defs[c.stype].find(a->b);
+                        if (tm >= 0 && s.slot_nonmono[sc.slot(c.stype, tm)]) taint = true;
+                    }
+            }
+            if (taint) {
+                s.slot_nonmono[slot] = 1;
+                grew = true;
+            }
+        }
+    }
     // ---- leaf bits: a userset edge `... @ T:c#m` always expands into the state (slot(T, m), c); mark the edges whose
     // child state has nothing left to enumerate, so the expansion can skip both the child's row descriptors and the
     // frontier write (kernels.hip, eval_child)
@@ -326,7 +463,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             if (!c.live || c.hashed || mem.classes[k].srel == kNoRelation) continue;
             if (s.type_owner[mem.classes[k].stype] != shard.rank) continue;  // child rows are elsewhere: no leaf flags
             const SlotProg &tp = s.progs[sc.slot(mem.classes[k].stype, mem.classes[k].srel)];
-            bool always = false;
+            bool always = tp.combine != 0;  // (a combine child must be visited: its probes are its own business)
             std::vector<FwdOp> enums;
             for (uint32_t j = tp.n_probe; j < tp.n_main; j++) {
                 const FwdOp &op = s.ops[tp.first + j];
@@ -416,6 +553,7 @@ struct Patcher {
     // leaf flag of a new userset edge -> child (target slot, child id): nothing left to enumerate there
     bool child_is_leaf(uint32_t target_slot, uint32_t child) const {
         const SlotProg &tp = s.progs[target_slot];
+        if (tp.combine) return false;
         for (uint32_t j = tp.n_probe; j < tp.n_main; j++) {
             const FwdOp &op = s.ops[tp.first + j];
             if (op.flags & OP_PUSH_SAME) return false;
@@ -511,7 +649,7 @@ bool patch_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard, s
         const RelLayout &l = s.lay[slot];
         if (store.objects(t).count() > l.nrows) return unpatchable("objects of a relation's type outgrew its row table", store.objects(t).count(), l.nrows);
         for (size_t k = 0; k < mem.classes.size(); k++)
-            if (l.cls[k].live && l.cls[k].hashed && store.objects(mem.classes[k].stype).count() > l.cls[k].nsubjects)
+            if (l.cls[k].live && l.cls[k].hashed && !mem.classes[k].wildcard && store.objects(mem.classes[k].stype).count() > l.cls[k].nsubjects)
                 return unpatchable("subjects of a hashed class outgrew its descriptor table", store.objects(mem.classes[k].stype).count(), l.cls[k].nsubjects);
     }
     std::sort(ch.begin(), ch.end(), [](const Store::Change &a, const Store::Change &b) {

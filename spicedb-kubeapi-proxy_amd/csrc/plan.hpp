@@ -26,7 +26,9 @@ enum : uint32_t {
     OP_REFLEX = 4u,     // subject == this very object#relation
     OP_PUSH_SAME = 8u,  // non-inlined computed userset: child state on the same object
     OP_PROBE_HASH = 16u, // membership test in a membership-only class: SUBJECT-indexed hashed rows (4-slot buckets)
-    OP_LEAFBIT = 32u     // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
+    OP_LEAFBIT = 32u,    // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
+    OP_WILD = 64u        // with OP_PROBE_HASH: the row probed is the one of the class's wildcard subject `T:*` (its id in FwdOp::K), whoever the
+                         // request's subject is; reverse ops (RevOp): the row read is the wildcard subject's (roff_base points at it), whatever the seed's id
 };
 // Hashed rows use two-choice (cuckoo) placement over 4-slot buckets: an id lives in bucket h1 or h2 of its row, so a
 // membership test is exactly two independent 16-byte gathers -- no probing chain whose longest lane stalls the wave.
@@ -51,10 +53,10 @@ struct FwdOp {        // 32 B
     uint32_t base;    // index (uint2 units) into `meta`: sorted ops -> the relation's per-object row descriptors,
                       // PROBE_HASH -> the class's per-SUBJECT row descriptors
     uint32_t nrows;   // ids covered by those descriptors (ids >= nrows have no relationships)
-    uint32_t K;       // sorted subject classes of the relation (row stride); unused by PROBE_HASH
+    uint32_t K;       // sorted subject classes of the relation (row stride); PROBE_HASH | WILD: the wildcard subject's id
     uint32_t k;       // sorted-class index of this op
     uint32_t key;     // PROBE*/REFLEX: subject key to match; ENUM/PUSH_SAME: target slot
-    uint32_t pad;
+    uint32_t leaf;    // 0: a hit answers the entry's own result cell; L > 0 (programs with `&` / `-` only): cell L - 1 of the state's leaf cells
 };
 struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create children][REFLEX ops]
     uint32_t first;     // first op
@@ -63,7 +65,23 @@ struct SlotProg {       // 32 B.  Op order: [probe-only ops][ops that may create
     uint32_t n_total;   // n_main + REFLEX ops (only requests whose subject carries a relation)
     uint32_t max_dlevel;  // deepest inlined state
     uint32_t owner;       // shard that holds this slot's type (rows + program); 0 when the graph is not sharded
-    uint32_t pad[2];
+    // Rewrites with intersection / exclusion ("combine" programs; reference pkg/spicedb/spicedb.go:19-24 boots any schema): the state's value is
+    // a boolean program over LEAVES -- maximal union-only sub-expressions, each answered by an ordinary monotone walk into a result cell of
+    // its own -- evaluated when the whole walk is over (kernels.hip, resolve).  combine = index of that program in Snapshot::bexpr, 0 = none.
+    uint32_t combine;
+    uint32_t nleaves;
+};
+// Snapshot::bexpr at SlotProg::combine: [ntokens][deepest inlined dispatch offset of leaf 0 (the direct ops) .. leaf nleaves][tokens...], postfix:
+constexpr uint32_t BX_LEAF = 1u << 24;  // | leaf number (1-based): push the leaf cell's value
+constexpr uint32_t BX_OR = 2u << 24;    // | n: HAS > ERR > NO over the n topmost values
+constexpr uint32_t BX_AND = 3u << 24;   // | n: NO > ERR > HAS
+constexpr uint32_t BX_EXCL = 4u << 24;  // base, subtracted: base unless HAS; then subtracted ERR -> ERR, HAS -> NO, NO -> HAS
+constexpr uint32_t kMaxLeaves = 30;     // per state (the resolve keeps its value stack in one 64-bit register, two bits per value)
+struct CombineNode {  // 16 B: one visited state with a combine program (written by the walk, read by the resolve)
+    uint32_t out;     // result cell the state's value is OR-ed into
+    uint32_t cells;   // first of its nleaves leaf cells
+    uint32_t slot_iter;  // slot | frontier iteration << 16: a node only depends on nodes of LATER iterations
+    uint32_t pad;
 };
 struct RevOp {          // 16 B
     uint32_t flags;     // OP_ENUM (reverse row) or OP_PUSH_SAME
@@ -103,6 +121,9 @@ struct Snapshot {
     std::vector<uint32_t> buckets;  // hashed rows: uint4 buckets of RESOURCE ids of one subject, empty slot = 0xFFFFFFFF
     std::vector<FwdOp> ops;
     std::vector<SlotProg> progs;  // [nslots]
+    std::vector<uint32_t> bexpr;  // boolean programs of the combine slots (word 0 unused: SlotProg::combine == 0 means none)
+    bool has_combine = false;     // some slot's rewrite uses `&` / `-`: evaluations run the kernels' combine instantiations
+    std::vector<uint8_t> slot_nonmono;  // [nslots] the slot's value can depend on a combine program: LookupResources = candidates + a forward Check
     // per type: first slot + member count (request validation on device)
     std::vector<uint32_t> type_slot_base, type_nmembers;
     std::vector<uint32_t> type_nobjects;

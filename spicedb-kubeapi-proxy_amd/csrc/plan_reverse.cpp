@@ -12,8 +12,15 @@
 namespace acl {
 namespace {
 
+// References / arrows in POSITIVE positions: a rewrite with `&` / `-` is walked backwards as a superset -- X true makes the parent a CANDIDATE
+// when X occurs anywhere but under the subtracted operand of an exclusion (every true value of `a - b`, `a & b` has a true positive operand);
+// the engine then runs the forward Check over the candidates (engine.cpp lookup_batch, Snapshot::slot_nonmono).
 void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
     if (n.kind == kind) out->push_back(&n);
+    if (n.kind == Node::kExclude) {
+        collect(n.kids[0], kind, out);
+        return;
+    }
     for (const Node &k : n.kids) collect(k, kind, out);
 }
 
@@ -49,7 +56,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
                 continue;
             }
             const bool filt = !ct.expiry.empty();
-            const uint32_t ns = with_headroom(store.objects(mem.classes[k].stype).count());
+            const uint32_t ns = mem.classes[k].wildcard ? store.wildcard_id(mem.classes[k].stype) + 1 : with_headroom(store.objects(mem.classes[k].stype).count());
             RevLayout &l = rl[slot][k];
             l.any = true;
             l.nrows = ns;
@@ -57,7 +64,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             s.rmeta.resize(s.rmeta.size() + 2 * (size_t)ns, 0);
             cursor.assign((size_t)ns + 1, 0);
             for (uint64_t key : ct.keys)
-                if (!filt || store.live(ct, key, now)) cursor[(uint32_t)key + 1]++;
+                if ((uint32_t)key < ns && (!filt || store.live(ct, key, now))) cursor[(uint32_t)key + 1]++;
             uint32_t *rm = s.rmeta.data() + 2 * (size_t)l.base;
             uint32_t run = (uint32_t)s.redges.size();
             for (uint32_t i = 0; i < ns; i++) {
@@ -69,13 +76,13 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             }
             s.redges.resize(run);
             for (uint64_t key : ct.keys)  // keys ascend by resource => each reverse row ascends by resource
-                if (!filt || store.live(ct, key, now)) s.redges[cursor[(uint32_t)key]++] = (uint32_t)(key >> 32);
+                if ((uint32_t)key < ns && (!filt || store.live(ct, key, now))) s.redges[cursor[(uint32_t)key]++] = (uint32_t)(key >> 32);
         }
     }
     if (s.rmeta.empty()) s.rmeta.assign(2, 0);
     if (s.redges.empty()) s.redges.push_back(0);
     bool remote = false;  // set by enum_op when a live parent row set belongs to another shard
-    auto enum_op = [&](int rel_slot, size_t k, int target) {
+    auto enum_op = [&](int rel_slot, size_t k, int target, uint32_t wild_id = 0xFFFFFFFFu) {
         const RevLayout &l = rl[rel_slot][k];
         if (!l.any) return;
         if (type_owner[sc.slot_owner[rel_slot].first] != shard.rank) {
@@ -86,6 +93,10 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         op.flags = OP_ENUM;
         op.roff_base = l.base;
         op.nrows = l.nrows;
+        if (wild_id != 0xFFFFFFFFu) {  // `T:*`: the wildcard subject's row, whatever the seed's id
+            op.flags |= OP_WILD;
+            op.roff_base = l.base + wild_id;
+        }
         op.target = (uint32_t)target;
         s.rops.push_back(op);
     };
@@ -104,7 +115,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
                 if (!m2.is_permission) {
                     // userset subjects `t:id#m` stored on relation m2
                     for (size_t k = 0; k < m2.classes.size(); k++)
-                        if (m2.classes[k].stype == t && m2.classes[k].srel == m) enum_op(m2.slot, k, m2.slot);
+                        if (m2.classes[k].stype == t && m2.classes[k].srel == m && !m2.classes[k].wildcard) enum_op(m2.slot, k, m2.slot);
                     continue;
                 }
                 std::vector<const Node *> refs, arrows;
@@ -153,7 +164,8 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             auto [t2, m2] = sc.slot_owner[slot];
             const Member &mem = sc.defs[t2].members[m2];
             for (size_t k = 0; k < mem.classes.size(); k++)
-                if (mem.classes[k].stype == st && mem.classes[k].srel == sr) enum_op(slot, k, slot);
+                if (mem.classes[k].stype == st && mem.classes[k].srel == sr)  // (a plain subject is also covered by every `st:*` relationship)
+                    enum_op(slot, k, slot, mem.classes[k].wildcard ? store.wildcard_id(st) : 0xFFFFFFFFu);
         }
         p.n = (uint32_t)s.rops.size() - p.first;
         s.rseeds[key] = p;

@@ -80,12 +80,12 @@ class Lexer {
     Tok cur_;
 };
 
-Node parse_union(Lexer &lx);
+Node parse_expr(Lexer &lx);
 
 Node parse_operand(Lexer &lx) {
     if (lx.is_punct('(')) {
         lx.take();
-        Node n = parse_union(lx);
+        Node n = parse_expr(lx);
         lx.expect_punct(')');
         return n;
     }
@@ -118,17 +118,19 @@ Node parse_operand(Lexer &lx) {
     return n;
 }
 
-Node parse_union(Lexer &lx) {
-    Node lhs = parse_operand(lx);
-    while (lx.is_punct('+') || lx.is_punct('&') || lx.is_punct('-')) {
-        if (!lx.is_punct('+')) lx.fail("unsupported: intersection (`&`) and exclusion (`-`)");
+// one binary level of the expression grammar: operands from `sub`, joined by `op`, left-associative.  Unions and intersections flatten
+// (a + b + c is one node of three operands); an exclusion stays binary {base, subtracted}.
+template <typename Sub>
+Node parse_level(Lexer &lx, char op, Node::Kind kind, Sub sub) {
+    Node lhs = sub(lx);
+    while (lx.is_punct(op)) {
         lx.take();
-        Node rhs = parse_operand(lx);
-        if (lhs.kind == Node::kUnion) {
+        Node rhs = sub(lx);
+        if (lhs.kind == kind && kind != Node::kExclude) {
             lhs.kids.push_back(std::move(rhs));
         } else {
             Node u;
-            u.kind = Node::kUnion;
+            u.kind = kind;
             u.kids.push_back(std::move(lhs));
             u.kids.push_back(std::move(rhs));
             lhs = std::move(u);
@@ -136,15 +138,22 @@ Node parse_union(Lexer &lx) {
     }
     return lhs;
 }
+// precedence, loosest first: exclusion, intersection, union (schema.hpp)
+Node parse_union(Lexer &lx) { return parse_level(lx, '+', Node::kUnion, parse_operand); }
+Node parse_inter(Lexer &lx) { return parse_level(lx, '&', Node::kIntersect, parse_union); }
+Node parse_expr(Lexer &lx) { return parse_level(lx, '-', Node::kExclude, parse_inter); }
 
 struct PendingClass {
     std::string type, rel;
     bool expiring;
+    bool wildcard;
 };
 
 void check_refs(const Schema &s, const Definition &d, const Member &m, const Node &n) {
     switch (n.kind) {
         case Node::kUnion:
+        case Node::kIntersect:
+        case Node::kExclude:
             for (const Node &k : n.kids) check_refs(s, d, m, k);
             break;
         case Node::kRef:
@@ -154,10 +163,25 @@ void check_refs(const Schema &s, const Definition &d, const Member &m, const Nod
             int ts = d.find(n.a);
             if (ts < 0 || d.members[ts].is_permission)
                 throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` has an arrow over `" + n.a + "`, which is not a relation");
+            for (const SubjectClass &c : d.members[ts].classes)
+                if (c.wildcard)
+                    throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` has an arrow over `" + n.a + "`, which allows wildcard subjects");
             break;
         }
         case Node::kNil: break;
     }
+}
+
+// result cells a permission's boolean program needs (plan.cpp cuts everything under `&` / `-` into union-only leaves)
+size_t combine_leaves(const Node &n) {
+    if (n.monotone()) return 1;
+    size_t c = 0;
+    bool mono = false;
+    for (const Node &k : n.kids) {
+        if (n.kind == Node::kUnion && k.monotone()) mono = true;
+        else c += combine_leaves(k);
+    }
+    return c + (mono ? 1 : 0);
 }
 
 }  // namespace
@@ -192,15 +216,19 @@ bool parse_schema(const std::string &text, Schema *out, std::string *err) {
                 std::vector<PendingClass> classes;
                 if (is_perm) {
                     lx.expect_punct('=');
-                    m.expr = parse_union(lx);
+                    m.expr = parse_expr(lx);
                 } else {
                     lx.expect_punct(':');
                     for (;;) {
                         PendingClass pc;
                         pc.type = lx.expect_ident("a subject type");
                         pc.expiring = false;
-                        if (lx.is_punct(':')) lx.fail("unsupported: wildcard subjects (`" + pc.type + ":*`)");
-                        if (lx.is_punct('#')) {
+                        pc.wildcard = false;
+                        if (lx.is_punct(':')) {  // `T:*`
+                            lx.take();
+                            lx.expect_punct('*');
+                            pc.wildcard = true;
+                        } else if (lx.is_punct('#')) {
                             lx.take();
                             pc.rel = lx.expect_ident("a subject relation after `#`");
                         }
@@ -247,15 +275,21 @@ bool parse_schema(const std::string &text, Schema *out, std::string *err) {
                         if (sc.srel < 0) throw std::runtime_error("schema: relation `" + s.defs[t].name + "#" + mem.name + "` allows unknown `" + pc.type + "#" + pc.rel + "`");
                     }
                     sc.expiring = pc.expiring;
+                    sc.wildcard = pc.wildcard;
                     bool dup = false;
                     for (SubjectClass &e : mem.classes)
-                        if (e.stype == sc.stype && e.srel == sc.srel) { e.expiring |= sc.expiring; dup = true; }
+                        if (e.stype == sc.stype && e.srel == sc.srel && e.wildcard == sc.wildcard) { e.expiring |= sc.expiring; dup = true; }
                     if (!dup) mem.classes.push_back(sc);
                 }
             }
         for (const Definition &d : s.defs)
             for (const Member &m : d.members)
-                if (m.is_permission) check_refs(s, d, m, m.expr);
+                if (m.is_permission) {
+                    check_refs(s, d, m, m.expr);
+                    if (!m.expr.monotone()) s.has_combine = true;
+                    if (!m.expr.monotone() && combine_leaves(m.expr) > 30)  // (plan.hpp kMaxLeaves)
+                        throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` combines more than 30 operands under `&` / `-`");
+                }
         *out = std::move(s);
         return true;
     } catch (const std::exception &e) {

@@ -5,7 +5,12 @@
 // accepted here is the one the reference's bootstrap, e2e rules and BASELINE
 // configs use: relations with typed subjects (`T`, `T#rel`,
 // `with expiration`), permissions built from `+`, `->` / `.any()`, references and
-// `nil`.  Caveats, wildcards, `&`, `-` and `.all()` are rejected at load.
+// `nil` -- and, since the reference boots ARBITRARY schemas (spicedb.go:19-24,
+// pkg/proxy/options.go:313-316, e2e/embedded_integration_test.go:34-250), intersection
+// `&`, exclusion `-` and wildcard subjects `T:*`.  Operator precedence, loosest to
+// tightest: `-`, `&`, `+`; same-operator chains associate to the left (EXTERNAL: the
+// schema language of github.com/authzed/spicedb, restated, unverified -- DESIGN.md 6).
+// Caveats and `.all()` are rejected at load.
 #pragma once
 #include <cstdint>
 #include <memory>
@@ -21,12 +26,20 @@ struct SubjectClass {  // one allowed subject form of a relation: `stype` or `st
     int stype = 0;
     int srel = kNoRelation;  // member index inside stype, or kNoRelation
     bool expiring = false;   // `with expiration`
+    bool wildcard = false;   // `stype:*`: one relationship covers every plain subject of the type (srel == kNoRelation)
 };
 
 struct Node {  // permission expression tree
-    enum Kind { kUnion, kRef, kArrow, kNil } kind = kNil;
-    std::vector<Node> kids;   // kUnion
+    enum Kind { kUnion, kRef, kArrow, kNil, kIntersect, kExclude } kind = kNil;
+    std::vector<Node> kids;   // kUnion, kIntersect: operands; kExclude: {base, subtracted}
     std::string a, b;         // kRef: a ; kArrow: a -> b
+    // no `&` / `-` anywhere below: "any HAS wins" (the walk's fast path)
+    bool monotone() const {
+        if (kind == kIntersect || kind == kExclude) return false;
+        for (const Node &k : kids)
+            if (!k.monotone()) return false;
+        return true;
+    }
 };
 
 struct Member {  // a relation or a permission of a definition
@@ -53,6 +66,7 @@ struct Schema {
     std::vector<int> slot_base;                  // per type: first slot
     std::vector<std::pair<int, int>> slot_owner; // slot -> (type, member)
     int nslots = 0;
+    bool has_combine = false;  // some permission uses `&` / `-`
 
     int type_of(const std::string &n) const {
         auto it = def_index.find(n);

@@ -164,6 +164,13 @@ Status Store::load_schema(const std::string &text) {
         auto [t, m] = schema_.slot_owner[slot];
         tables_[slot].assign(schema_.defs[t].members[m].classes.size(), ClassTable());
     }
+    // `T:*` subjects: the name "*" gets an id in T's table right away, so that programs built before the first wildcard relationship
+    // exists can already name the wildcard subject's row
+    wildcard_id_.assign(schema_.defs.size(), 0xFFFFFFFFu);
+    for (const Definition &d : schema_.defs)
+        for (const Member &m : d.members)
+            for (const SubjectClass &c : m.classes)
+                if (c.wildcard && wildcard_id_[c.stype] == 0xFFFFFFFFu) wildcard_id_[c.stype] = objects_[c.stype].intern("*");
     revision_++;
     log_.clear();  // ids of the previous schema mean nothing now
     log_floor_ = revision_;
@@ -175,11 +182,11 @@ int64_t Store::now() const {
     return std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 }
 
-int Store::class_index(int slot, int stype, int srel) const {
+int Store::class_index(int slot, int stype, int srel, bool wildcard) const {
     auto [t, m] = schema_.slot_owner[slot];
     const auto &cls = schema_.defs[t].members[m].classes;
     for (size_t k = 0; k < cls.size(); k++)
-        if (cls[k].stype == stype && cls[k].srel == srel) return (int)k;
+        if (cls[k].stype == stype && cls[k].srel == srel && cls[k].wildcard == wildcard) return (int)k;
     return -1;
 }
 
@@ -192,6 +199,7 @@ Store Store::view() {
     for (size_t t = 0; t < objects_.size(); t++) v.objects_[t].reserve_ids(objects_[t].count());
     v.tables_ = tables_;  // CowKeys copies share their vectors; the expiry maps and their index are copied
     v.expiry_index_ = expiry_index_;
+    v.wildcard_id_ = wildcard_id_;
     v.revision_ = revision_;
     v.now_override_ = now_override_;
     v.log_floor_ = revision_;
@@ -278,9 +286,12 @@ Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
     out->slot = mem.slot;
     out->rtype = rt;
     out->stype = st;
-    out->cls = class_index(mem.slot, st, sr);
+    // `T:*` is a subject class of its own (its one subject id is the name "*" in T's table); it never carries a relation
+    const bool wild = r.sid == "*";
+    if (wild && sr != kNoRelation) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: a wildcard subject cannot carry a relation");
+    out->cls = class_index(mem.slot, st, sr, wild);
     if (out->cls < 0)
-        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "subjects of type `" + r.stype + (sr == kNoRelation ? "" : "#" + r.srel) + "` are not allowed on relation `" + r.rtype + "#" + r.rel + "`");
+        return Status::Err(ACL_ERR_INVALID_ARGUMENT, "subjects of type `" + r.stype + (wild ? ":*" : sr == kNoRelation ? "" : "#" + r.srel) + "` are not allowed on relation `" + r.rtype + "#" + r.rel + "`");
     if (r.expires_at && !mem.classes[out->cls].expiring)
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relation `" + r.rtype + "#" + r.rel + "` does not allow expiration for that subject type");
     if (create_ids) {
@@ -533,17 +544,19 @@ Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: type or relation index out of range");
     const Member &mem = schema_.defs[rtype].members[rel];
     if (mem.is_permission) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: cannot write a relationship to a permission");
-    int cls = class_index(mem.slot, stype, srel < 0 ? kNoRelation : srel);
+    const bool wild = srel == -2;  // `stype:*` relationships: the subject is the type's wildcard id, subj[] is ignored
+    int cls = class_index(mem.slot, stype, srel < 0 ? kNoRelation : srel, wild);
     if (cls < 0) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: subject type not allowed on relation");
     ClassTable &ct = tables_[mem.slot][cls];
     for (size_t i = 0; i < n; i++)  // bit 31 of a stored subject id is the snapshot's leaf flag
-        if ((res[i] | subj[i]) & 0x80000000u) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: object ids must be below 2^31");
+        if ((res[i] | (wild ? 0u : subj[i])) & 0x80000000u) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: object ids must be below 2^31");
     ct.pending.reserve(ct.pending.size() + n);
     uint32_t maxr = 0, maxs = 0;
     for (size_t i = 0; i < n; i++) {
-        ct.pending.push_back((uint64_t)res[i] << 32 | subj[i]);
+        const uint32_t sj = wild ? wildcard_id_[stype] : subj[i];
+        ct.pending.push_back((uint64_t)res[i] << 32 | sj);
         maxr = std::max(maxr, res[i]);
-        maxs = std::max(maxs, subj[i]);
+        maxs = std::max(maxs, sj);
     }
     if (n) {
         objects_[rtype].reserve_ids(maxr + 1);

@@ -205,7 +205,8 @@ class Store {
     static constexpr int64_t kGcWindowSeconds = 24 * 3600;
     size_t expiring_relationships() const { return expiry_index_.size(); }
 
-    int class_index(int slot, int stype, int srel) const;
+    int class_index(int slot, int stype, int srel, bool wildcard = false) const;
+    uint32_t wildcard_id(int type) const { return wildcard_id_[type]; }  // id of the name "*" in a type some relation allows as `type:*`; else 0xFFFFFFFF
 
     // ---- change feed (WatchService.Watch, reference pkg/authz/watch.go:29-38): every update committed through
     // write() / delete_by_filter(), in commit order.  Bulk loads (bootstrap, add_edges) are not part of the feed.
@@ -251,6 +252,7 @@ class Store {
     Schema schema_;
     bool schema_loaded_ = false;
     std::vector<ObjectTable> objects_;
+    std::vector<uint32_t> wildcard_id_;  // [type]
     std::vector<std::vector<ClassTable>> tables_;
     uint64_t revision_ = 1;
     int64_t now_override_ = 0;

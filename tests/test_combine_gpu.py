@@ -1,0 +1,201 @@
+"""GPU parity for schemas with intersection `&`, exclusion `-` and wildcard subjects `T:*` (the reference boots
+arbitrary schemas: pkg/spicedb/spicedb.go:19-24, e2e/embedded_integration_test.go:34-250).  The kernels' combine instantiations
+(k_check_local / k_expand <..., CMB>, the resolve pass, LookupResources = candidates + forward Check) against BOTH oracle restatements:
+bit-exact (permissionship, error) per item, identical id sets per lookup."""
+import numpy as np
+import pytest
+
+from oracle import orc
+from oracle.pyoracle import PyOracle
+from tests.test_oracle_cross import NM_QUERIES, PY2C, SCHEMA_NM, nm_tuples_strategy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aclgpu(aclgpu_lib):
+    import aclgpu as m
+    return m
+
+
+def test_combine_hypothesis(aclgpu):
+    """Random small graphs (cyclic group nesting, wildcards in positive and subtracted operands, arrows into permissions that are themselves
+    non-monotone, depth errors on both sides of `&` / `-`): every answer equals the C oracle's AND the Python oracle's."""
+    from hypothesis import given, settings
+
+    eng = aclgpu.Engine(SCHEMA_NM)
+    subjects = [("user", "u0", ""), ("user", "u3", ""), ("group", "g0", "member")]
+
+    @settings(max_examples=60, deadline=None)
+    @given(nm_tuples_strategy())
+    def run(tuples):
+        eng.load_bootstrap(SCHEMA_NM)
+        co, po = orc.Oracle(SCHEMA_NM), PyOracle(SCHEMA_NM)
+        tuples = list(dict.fromkeys(tuples))
+        if tuples:
+            co.write([(orc.OP_TOUCH, t) for t in tuples])
+            eng.write([(aclgpu.OP_TOUCH, t) for t in tuples])
+        for t in tuples:
+            po.touch(*t)
+        perms, errs = eng.check_bulk(NM_QUERIES)
+        want = [co.check(*q) for q in NM_QUERIES]
+        assert list(zip(perms, errs)) == want
+        assert want == [PY2C[po.check(*q)] for q in NM_QUERIES]
+        for s in subjects:
+            for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("doc", "edit"), ("folder", "audit"), ("folder", "view"), ("group", "active"), ("doc", "nothing")]:
+                assert eng.lookup(rt, p, *s) == co.lookup(rt, p, *s), (rt, p, s)
+
+    run()
+    eng.close()
+
+
+def test_precedence_and_three_valued_rules_on_the_gpu(aclgpu):
+    """tests/test_oracle_cross.py::test_precedence_and_three_valued_rules through the engine: `-` loosest, then `&`, then `+`; an error in the
+    subtracted operand only matters when the base holds; NO beats an error under `&`."""
+    schema = """
+    definition user {}
+    definition g { relation member: user | g#member }
+    definition d {
+      relation a: user | g#member
+      relation b: user | g#member
+      relation c: user | g#member
+      permission p1 = a + b - c
+      permission p2 = a - b + c
+      permission p3 = a & b + c
+      permission p4 = a - b & c
+      permission p5 = a - b - c
+      permission deny_err = a - b
+      permission and_err = a & b
+      permission nested = (a - deny_err) + (and_err & c)
+    }
+    """
+    rels = [("d", "x", "a", "user", "u", ""), ("d", "x", "c", "user", "u", ""), ("d", "y", "a", "user", "u", ""), ("d", "y", "b", "user", "u", ""),
+            ("g", "g0", "member", "user", "deep", "")] + [("g", f"g{i + 1}", "member", "g", f"g{i}", "member") for i in range(60)] + [
+            ("d", "e1", "a", "user", "deep", ""), ("d", "e1", "b", "g", "g59", "member"), ("d", "e2", "b", "g", "g59", "member"),
+            ("d", "e3", "a", "g", "g59", "member"), ("d", "e3", "b", "user", "deep", ""), ("d", "e1", "c", "user", "deep", "")]
+    co = orc.Oracle(schema)
+    co.write([(orc.OP_TOUCH, r) for r in rels])
+    qs = [("d", o, p, "user", u, "") for o in ("x", "y", "e1", "e2", "e3") for p in ("p1", "p2", "p3", "p4", "p5", "deny_err", "and_err", "nested") for u in ("u", "deep", "nobody")]
+    with aclgpu.Engine(schema) as e:
+        e.write([(aclgpu.OP_TOUCH, r) for r in rels])
+        perms, errs = e.check_bulk(qs)
+        assert list(zip(perms, errs)) == [co.check(*q) for q in qs]
+        assert e.check("d", "e1", "deny_err", "user", "deep") == (0, aclgpu.ERR_DEPTH)
+        assert e.check("d", "e2", "deny_err", "user", "deep") == (1, 0)
+        assert e.check("d", "x", "p1", "user", "u") == (1, 0) and e.check("d", "x", "p3", "user", "u") == (2, 0)
+        for p in ("p1", "p4", "deny_err", "nested"):
+            for u in ("u", "deep"):
+                assert e.lookup("d", p, "user", u) == co.lookup("d", p, "user", u), (p, u)
+
+
+SCHEMA_BANS = """
+definition user {}
+definition group {
+  relation member: user | group#member
+  relation banned: user
+  permission active = member - banned
+}
+definition namespace {
+  relation viewer: user | group#member
+  relation banned: user | user:*
+  permission view = viewer - banned
+}
+definition pod {
+  relation namespace: namespace
+  relation viewer: user | group#active | user:*
+  relation creator: user
+  relation banned: user | group#member
+  permission view = (viewer + creator + namespace->view) - banned
+  permission strict = creator & namespace->view
+  permission loose = viewer + creator + namespace->view
+}
+"""
+
+
+def bans_graph(seed, n_user=4000, n_group=600, n_ns=200, n_pod=30000):
+    rng = np.random.default_rng(seed)
+    E = []  # (rtype, rel, stype, srel, res[], subj[])
+    u = lambda n: rng.integers(0, n_user, size=n).astype(np.uint32)  # noqa: E731
+    g = lambda n: rng.integers(0, n_group, size=n).astype(np.uint32)  # noqa: E731
+    E.append(("group", "member", "user", "", g(6 * n_group), u(6 * n_group)))
+    lo = rng.integers(0, n_group // 2, size=n_group).astype(np.uint32)           # nesting: groups of the upper half contain groups of the lower half (acyclic)
+    hi = (n_group // 2 + rng.integers(0, n_group - n_group // 2, size=n_group)).astype(np.uint32)
+    E.append(("group", "member", "group", "member", hi, lo))
+    E.append(("group", "banned", "user", "", g(n_group), u(n_group)))
+    E.append(("namespace", "viewer", "user", "", rng.integers(0, n_ns, size=8 * n_ns).astype(np.uint32), u(8 * n_ns)))
+    E.append(("namespace", "viewer", "group", "member", rng.integers(0, n_ns, size=3 * n_ns).astype(np.uint32), g(3 * n_ns)))
+    E.append(("namespace", "banned", "user", "", rng.integers(0, n_ns, size=2 * n_ns).astype(np.uint32), u(2 * n_ns)))
+    E.append(("namespace", "banned", "user", "*", rng.integers(0, n_ns, size=n_ns // 20).astype(np.uint32), np.zeros(n_ns // 20, dtype=np.uint32)))
+    pods = np.arange(n_pod, dtype=np.uint32)
+    pod_ns, pod_creator = rng.integers(0, n_ns, size=n_pod).astype(np.uint32), u(n_pod)
+    E.append(("pod", "namespace", "namespace", "", pods, pod_ns))
+    E.append(("pod", "creator", "user", "", pods, pod_creator))
+    E.append(("pod", "banned", "user", "", pods[::7], pod_creator[::7]))            # every 7th creator is banned from their own pod
+    E.append(("namespace", "viewer", "user", "", pod_ns[::5], pod_creator[::5]))     # every 5th creator also views the pod's namespace (`strict`)
+    E.append(("pod", "viewer", "user", "", rng.integers(0, n_pod, size=3 * n_pod).astype(np.uint32), u(3 * n_pod)))
+    E.append(("pod", "viewer", "group", "active", rng.integers(0, n_pod, size=n_pod).astype(np.uint32), g(n_pod)))
+    E.append(("pod", "viewer", "user", "*", rng.integers(0, n_pod, size=n_pod // 50).astype(np.uint32), np.zeros(n_pod // 50, dtype=np.uint32)))
+    E.append(("pod", "banned", "user", "", rng.integers(0, n_pod, size=n_pod).astype(np.uint32), u(n_pod)))
+    E.append(("pod", "banned", "group", "member", rng.integers(0, n_pod, size=n_pod // 4).astype(np.uint32), g(n_pod // 4)))
+    return E, dict(user=n_user, group=n_group, namespace=n_ns, pod=n_pod)
+
+
+def load_numeric(target, E):
+    for rt, rel, st, sr, res, subj in E:
+        target.add_edges(rt, rel, st, sr, res, subj)
+
+
+@pytest.mark.parametrize("mode", ["walk", "level-loop", "overflow", "tiny-units"])
+def test_bans_workload(mode, aclgpu, monkeypatch):
+    """A pod graph with bans, wildcards and an `active = member - banned` userset under nested groups, 120 000 checks per permission through the
+    interned-id bulk call: the single-launch walk (both instantiations), the level loop alone, and the walk overflowing into the level loop --
+    all equal to the oracle; LookupResources for a few users equals the definition."""
+    E, n = bans_graph(11)
+    co = orc.Oracle(SCHEMA_BANS)
+    load_numeric(co, E)
+    co.freeze()
+    if mode == "level-loop":
+        monkeypatch.setenv("ACL_LOCAL_MAX", "0")
+    if mode == "overflow":
+        monkeypatch.setenv("ACL_LOCAL_CAP", "256")
+    rng = np.random.default_rng(3)
+    B = 120000 if mode != "tiny-units" else 3000
+    res = rng.integers(0, n["pod"], size=B).astype(np.uint32)
+    sub = rng.integers(0, n["user"], size=B).astype(np.uint32)
+    # a share of requests that hit: the pod's creator / one of its viewers asks
+    creators = dict(zip(E[8][4].tolist(), E[8][5].tolist()))
+    assert E[8][1] == "creator"
+    for i in range(0, B, 3):
+        sub[i] = creators[int(res[i])]
+    with aclgpu.Engine(SCHEMA_BANS) as e:
+        load_numeric(e, E)
+        for perm in ("view", "strict", "loose"):
+            p, er = e.check_bulk_ids(e.make_items("pod", perm, res, "user", "", sub))
+            op, oe = co.check_bulk_ids_mt(8, "pod", perm, res, "user", "", sub)
+            assert np.array_equal(p, op) and np.array_equal(er, oe), (mode, perm, int((p != op).sum()))
+            assert 0 < int((p == 2).sum()) < B
+        p, er = e.check_bulk_ids(e.make_items("group", "active", rng.integers(0, n["group"], size=5000), "user", "", rng.integers(0, n["user"], size=5000)))
+        st = e.stats()
+        if mode == "walk":
+            assert st["local_passes"] >= 4 and st["expand_launches"] == 0
+        if mode == "level-loop":
+            assert st["local_passes"] == 0 and st["expand_launches"] > 0
+        # Filter: candidates + forward Check
+        subs = [int(x) for x in rng.integers(0, n["user"], size=5)] + [int(sub[0])]
+        for perm in ("view", "strict"):
+            bms, counts = e.lookup_ids_batch("pod", perm, "user", "", subs)
+            for i, s in enumerate(subs):
+                want = np.sort(co.lookup_ids("pod", perm, "user", "", s))
+                got = np.flatnonzero(np.unpackbits(bms[i].view(np.uint8), bitorder="little")).astype(np.uint32)
+                assert np.array_equal(got, want), (mode, perm, s, got.size, want.size)
+                assert counts[i] == want.size
+
+
+def test_monotone_schema_takes_the_monotone_kernels(aclgpu):
+    """A union-only schema never pays for the combine machinery: no boolean programs in its snapshot (the launchers pick the CMB kernels by that)."""
+    from aclgpu import workloads
+    w = workloads.c2(scale=0.02, batch=2000)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        e.check_bulk_ids(e.make_items("pod", "view", w.res, "user", "", w.subj))
+        assert e.stats()["local_passes"] == 1

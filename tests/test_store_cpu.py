@@ -69,10 +69,39 @@ def test_store_kat(kat, aclgpu_lib):
         assert sorted(e.read(rtype=t)) == sorted(o.read(rtype=t)), t
 
 
-@pytest.mark.parametrize("bad", [
+@pytest.mark.parametrize("good", [
     "definition a { relation r: a | b:* }\ndefinition b {}",
     "definition u {}\ndefinition a { relation r: u\n permission p = r & r }",
     "definition u {}\ndefinition a { relation r: u\n permission p = r - r }",
+    "definition u {}\ndefinition a { relation r: u | u:*\n relation q: a\n permission p = (r - q->p) & r + nil }",
+])
+def test_engine_accepts_round4_schema_features(good, aclgpu_lib):
+    """intersection, exclusion, wildcard subjects: the reference boots any schema (pkg/spicedb/spicedb.go:19-24)"""
+    import aclgpu
+    aclgpu.Engine(good, store_only=True).close()
+
+
+def test_wildcard_relationships_in_the_store(aclgpu_lib):
+    """`T:*` is a subject class of its own: written, read back with subject id "*", refused where the relation does not allow it."""
+    import aclgpu
+    e = aclgpu.Engine("definition user {}\ndefinition doc { relation viewer: user | user:*\n relation editor: user }", store_only=True)
+    e.write([(aclgpu.OP_TOUCH, ("doc", "d1", "viewer", "user", "*", "")), (aclgpu.OP_TOUCH, ("doc", "d1", "viewer", "user", "alice", ""))])
+    assert sorted(r[4] for r in e.read(rtype="doc", rid="d1")) == ["*", "alice"]
+    assert [r[4] for r in e.read(rtype="doc", stype="user", sid="*")] == ["*"]
+    for bad in [("doc", "d1", "editor", "user", "*", ""), ("doc", "d1", "viewer", "user", "*", "viewer")]:
+        with pytest.raises(aclgpu.AclError):
+            e.write([(aclgpu.OP_TOUCH, bad)])
+    with pytest.raises(aclgpu.AclError):  # CREATE of an existing wildcard relationship conflicts like any other
+        e.write([(aclgpu.OP_CREATE, ("doc", "d1", "viewer", "user", "*", ""))])
+    e.write([(aclgpu.OP_DELETE, ("doc", "d1", "viewer", "user", "*", ""))])
+    assert [r[4] for r in e.read(rtype="doc", rid="d1")] == ["alice"]
+    e.close()
+
+
+@pytest.mark.parametrize("bad", [
+    "definition a { relation r: a | b:x }\ndefinition b {}",
+    "definition u {}\ndefinition a { relation r: u | u:*\n relation q: a\n permission p = r->q }",
+    "definition u {}\ndefinition a { relation r: u\n permission p = r & }",
     "caveat c(x int) { x > 1 }\ndefinition u {}",
     "definition u {}\ndefinition a { relation r: u with c }",
     "definition u {}\ndefinition a { relation r: a\n permission p = r.all(p) }",
