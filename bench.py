@@ -263,13 +263,20 @@ def filter_bench(args, w, eng, steps, warmup):
     lb = c3_lookup_bytes(w, subs)
     batch_bytes = float(lb.sum())
     ach = batch_bytes * steps / (kms * 1e-3) / 1e9 if kms > 0 else None
-    traffic = None
+    traffic = traffic_bounds = None
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
             tj = json.load(open(tr))
-            if tj.get("C3") and (tj.get("C3_detail") or {}).get("kernel") == kname:
-                traffic = float(tj["C3"])
+            det = tj.get("C3_detail") or {}
+            if tj.get("C3") and det.get("kernel") == kname:
+                # counters -> bytes by the round-4 calibration (calibrated_traffic): the reverse walk gathers descriptors (counter exact) and reads
+                # reverse rows as short coalesced runs (counter between exact and half): the midpoint of the two bounds, both recorded
+                lo_b = float(det.get("fetch_bytes_per_launch_raw") or 0.0) + float(det.get("write_bytes_per_launch") or 0.0)
+                hi_b = 2.0 * float(det.get("fetch_bytes_per_launch_raw") or 0.0) + float(det.get("write_bytes_per_launch") or 0.0)
+                traffic = (lo_b + hi_b) / 2.0
+                traffic_bounds = {"lower": lo_b, "upper": hi_b, "write_bytes": float(det.get("write_bytes_per_launch") or 0.0), "profile": det.get("tag"),
+                                  "source": "profiles/traffic.json (an earlier run's rocprofv3 --pmc passes); midpoint of the calibrated bounds, profiles/r04_counter_calibration.md"}
         except Exception:  # noqa: BLE001
             pass
     out = {"metric": "lookup_resources_per_sec", "value": subs.size * steps / el, "unit": "lookups/s", "steps": steps, "warmup": warmup,
@@ -282,7 +289,7 @@ def filter_bench(args, w, eng, steps, warmup):
            "kernel_ms_per_step": stats["kernel_ms"] / steps, "launches_per_step": launches / steps, "reverse_levels": int(stats.get("levels_last", 0)),
            "bitmap_bytes_per_lookup": int(bms.shape[1] * 4),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                        "kernel": kname, "kernel_avg_us": 1e3 * kms / launches,
+                        "traffic_detail": traffic_bounds, "kernel": kname, "kernel_avg_us": 1e3 * kms / launches,
                         "algorithmic_bytes_per_lookup": batch_bytes / subs.size, "algorithmic_bytes_per_launch": batch_bytes * steps / launches,
                         "model": "SURVEY.md 8(d) LookupResources formula on the generator's arrays: 17 + sum over reverse rows (8 + 4 deg) + N_pod / 8"}}
     if not pageable_equal or (conc and not conc["equal_to_sequential_run"]):
@@ -960,15 +967,15 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
             tj = json.load(open(tr))
             det = tj.get(label + "_detail") or {}
             if tj.get(label) and det.get("kernel") == k["name"]:  # (only a profile of the SAME kernel says anything about this run's launches)
-                traffic = float(tj[label])
-                traffic_detail = {"bytes_per_launch": tj[label], "fetch_bytes_raw": det.get("fetch_bytes_per_launch_raw"), "write_bytes": det.get("write_bytes_per_launch"),
-                           "profile": det.get("tag"),
-                           "source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command (gfx950 x2 FETCH "
-                                     "correction applied), NOT measured in this run"}
+                traffic_detail = calibrated_traffic(float(det.get("fetch_bytes_per_launch_raw") or 0.0), float(det.get("write_bytes_per_launch") or 0.0), n)
+                traffic = float(traffic_detail["bytes_per_launch"])
+                traffic_detail.update({"profile": det.get("tag"),
+                                       "source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, NOT measured in "
+                                                 "this run; counters -> bytes by the round-4 calibration"})
         except Exception:  # noqa: BLE001
             pass
     if getattr(args, "traffic", "static") == "measure":
-        m = measure_traffic(args, label, k["name"])
+        m = measure_traffic(args, label, k["name"], n)
         if m.get("bytes_per_launch"):
             traffic, traffic_detail = float(m["bytes_per_launch"]), m
         elif traffic_detail is not None:
@@ -982,11 +989,28 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
                                 "userset as a dispatch, the kernels inline them)", "model_seconds": round(t_bytes, 2)}
 
 
-def measure_traffic(args, label, kernel):
+def calibrated_traffic(fetch_raw, write_bytes, n_items, answer_bytes_per_item=6):
+    """HBM bytes of one launch from its FETCH_SIZE / WRITE_SIZE counter values, by the calibration of profiles/r04_counter_calibration.md
+    (tools/counter_calib.hip: every access shape of this engine at a known byte count, same rocprofv3 passes):
+      * FETCH_SIZE counts 64 B per read REQUEST whatever its size (TCC_BUBBLE, the 128-B-request counter, reads 0 on gfx950): exact for the
+        4 / 8 / 16 B gathers (each fetches one 64 B sector), HALF for coalesced streams (128 B requests) -- the guide's x2 applies to those only;
+      * WRITE_SIZE is exact for coalesced and wave-compacted stores (32 B granules).
+    The walk's only coalesced reads are its own frontier (every entry it wrote is read back once, 64 lanes x 16 B side by side) and the items;
+    so reads = counter + (frontier bytes written + items) / 2, frontier bytes written = WRITE_SIZE - answers.  The blanket x2 of rounds 1-3
+    (an upper bound) and the raw sum (a lower bound) ride beside the estimate."""
+    stream = max(0.0, write_bytes - n_items * answer_bytes_per_item) + n_items * 16.0
+    stream = min(stream, 2.0 * fetch_raw)  # (the stream part cannot exceed what the counter saw at half weight)
+    return {"bytes_per_launch": fetch_raw + stream / 2.0 + write_bytes, "fetch_bytes_raw": fetch_raw, "write_bytes": write_bytes,
+            "stream_read_bytes_estimated": stream, "bytes_per_launch_lower_bound": fetch_raw + write_bytes, "bytes_per_launch_upper_bound": 2.0 * fetch_raw + write_bytes,
+            "calibration": "profiles/r04_counter_calibration.md: FETCH_SIZE = 64 B x read requests (exact for gathers, half for 128 B stream requests); WRITE_SIZE exact"}
+
+
+def measure_traffic(args, label, kernel, n_items=0):
     """HBM traffic of `kernel` per launch, measured NOW: this command's device-resident leg re-run twice under `rocprofv3 --kernel-trace --pmc`
     (FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; no other trace domain), mean over the
-    child's launches; reads x2 for gfx950's FETCH_SIZE under-count (the guide's correction; raw figures beside it).  {"error": ...} when
-    rocprofv3 is missing or a pass fails -- the caller then keeps the figure of profiles/traffic.json, labelled as such."""
+    child's launches, turned into bytes by calibrated_traffic() (round 4: the calibration on this engine's own access shapes replaces the
+    blanket x2 of the guide's stream case).  {"error": ...} when rocprofv3 is missing or a pass fails -- the caller then keeps the figure of
+    profiles/traffic.json, labelled as such."""
     import glob
     import shutil
     import signal
@@ -1035,10 +1059,11 @@ def measure_traffic(args, label, kernel):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     f, w_ = per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
-    return {"bytes_per_launch": 2 * f + w_, "fetch_bytes_raw": f, "write_bytes": w_, "bytes_per_launch_raw": f + w_, "launches_sampled": per["FETCH_SIZE"][1],
-            "seconds": round(time.time() - t0, 1),
-            "source": "measured in THIS run: the device-resident leg of this command re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE "
-                      "(separate passes, mean over the launches; gfx950 x2 FETCH correction applied, raw figures beside it)"}
+    out = calibrated_traffic(f, w_, n_items)
+    out.update({"launches_sampled": per["FETCH_SIZE"][1], "seconds": round(time.time() - t0, 1),
+                "source": "measured in THIS run: the device-resident leg of this command re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE "
+                          "(separate passes, mean over the launches), counters -> bytes by the round-4 calibration"})
+    return out
 
 
 def launch_ranks(n, dry):

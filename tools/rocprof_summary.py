@@ -4,9 +4,11 @@
 usage: rocprof_summary.py <tag> <stats.db> [<fetch.db> <write.db>] [--workload C4] [--steps K --warmup W]
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
-separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE under-reports a wide coalesced read stream by 2x.
-Both the raw and the x2-corrected read figure are recorded; the kernels here are dominated by 4-64 B gathers,
-for which the guide calls the counter uncalibrated, so the corrected figure is an upper bound.
+separate --pmc passes and are in KiB.  Round 4 calibrated them on this engine's own access shapes (profiles/r04_counter_calibration.md):
+FETCH_SIZE counts 64 B per read request whatever its size -- exact for 4-16 B gathers (one 64 B sector each), half for coalesced
+128 B stream requests; WRITE_SIZE is exact.  So raw + write is a LOWER bound, 2 x raw + write (the guide's stream correction applied to
+everything) an UPPER bound; with --items N the walk's stream share (its own frontier, read back once, + the items) gives the estimate
+bench.py's calibrated_traffic() uses.
 """
 import argparse
 import json
@@ -32,6 +34,7 @@ def main():
     ap.add_argument("--workload", default="C4")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--kernel", default="k_expand")
+    ap.add_argument("--items", type=int, default=0, help="requests per launch: enables the calibrated estimate (frontier bytes = WRITE_SIZE - 6 B x items)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles"))
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -63,9 +66,15 @@ def main():
         corr = (2 * fk + wk) * 1024
         summary.update({"fetch_bytes_per_launch_raw": fk * 1024, "write_bytes_per_launch": wk * 1024, "traffic_bytes_per_launch_raw": raw,
                         "traffic_bytes_per_launch_fetch_x2": corr})
+        est = None
+        if a.items:
+            stream = min(max(0.0, wk * 1024 - 6.0 * a.items) + 16.0 * a.items, 2 * fk * 1024)
+            est = fk * 1024 + stream / 2 + wk * 1024
+            summary["traffic_bytes_per_launch_calibrated"] = est
         lines += ["## --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), kernel `%s`" % a.kernel, "",
                   f"- FETCH_SIZE: {nf} launches, mean {fk:.1f} KiB/launch", f"- WRITE_SIZE: {nw} launches, mean {wk:.1f} KiB/launch",
-                  f"- HBM traffic per launch: raw {(raw) / 1e6:.2f} MB; with the guide's gfx950 x2 FETCH correction {(corr) / 1e6:.2f} MB", ""]
+                  f"- HBM traffic per launch: lower bound (counters as they are: exact for gathers) {(raw) / 1e6:.2f} MB; upper bound (x2 on every read) {(corr) / 1e6:.2f} MB"
+                  + (f"; calibrated estimate (stream share = the walk's own frontier + items, profiles/r04_counter_calibration.md) {est / 1e6:.2f} MB" if est else ""), ""]
         # last step, level by level
         lv = [r for r in per.get("FETCH_SIZE", [])][-7:]
         lw = [r for r in per.get("WRITE_SIZE", [])][-7:]
@@ -75,7 +84,7 @@ def main():
             lines.append(f"| {i + 1} | {f[2] / 1e3:.1f} | {f[1]:.0f} | {w:.0f} |")
         tj = os.path.join(a.out, "traffic.json")
         cur = json.load(open(tj)) if os.path.exists(tj) else {}
-        cur[a.workload] = corr
+        cur[a.workload] = est if est else corr
         cur[a.workload + "_detail"] = {"tag": a.tag, **{k: v for k, v in summary.items()}}
         json.dump(cur, open(tj, "w"), indent=1)
     open(os.path.join(a.out, a.tag + ".md"), "w").write("\n".join(lines) + "\n")
