@@ -460,6 +460,53 @@ static int parse_schema(orc_t *o, const char *text) {
     return 1;
 }
 
+/* ---------------------------------------------------------- API validation
+ * EXTERNAL, UNVERIFIED (authzed.api.v1 `validate` rules, authzed-go v1.10.0, go.mod:6; restated from memory): a request with an
+ * ill-formed field is InvalidArgument as a whole, BEFORE the schema is consulted.
+ *   object type     ^([a-z][a-z0-9_]{1,61}[a-z0-9]/)*[a-z][a-z0-9_]{1,62}[a-z0-9]$   <= 128 bytes
+ *   relation        ^[a-z][a-z0-9_]{1,62}[a-z0-9]$                                    <= 64 bytes
+ *   object id       ^[a-zA-Z0-9/_|\-=+]+$                                            <= 1024 bytes
+ *   `*`             only as the subject id of a relationship / relationship filter, without a relation
+ * A name the loaded schema DECLARES is accepted whatever its spelling (this restatement's schema parser takes names the real
+ * compiler refuses; for schemas the real engine accepts the two readings coincide).  Reference-held vector: the empty
+ * CheckPermissionRequest, pkg/proxy/options_test.go:101-102. */
+static int ok_id(const char *s) {
+    size_t n = strlen(s);
+    if (!n || n > 1024) return 0;
+    for (; *s; s++)
+        if (!(isalnum((unsigned char)*s) || strchr("/_|-=+", *s))) return 0;
+    return 1;
+}
+static int ok_segment(const char *s, size_t n, size_t maxlen) {
+    if (n < 3 || n > maxlen) return 0;
+    if (!(s[0] >= 'a' && s[0] <= 'z')) return 0;
+    if (!((s[n - 1] >= 'a' && s[n - 1] <= 'z') || isdigit((unsigned char)s[n - 1]))) return 0;
+    for (size_t i = 1; i + 1 < n; i++)
+        if (!((s[i] >= 'a' && s[i] <= 'z') || isdigit((unsigned char)s[i]) || s[i] == '_')) return 0;
+    return 1;
+}
+static int ok_relname(const char *s) { return ok_segment(s, strlen(s), 64); }
+static int ok_typename(const char *s) {
+    if (strlen(s) > 128) return 0;
+    for (;;) {
+        const char *slash = strchr(s, '/');
+        if (!slash) return ok_segment(s, strlen(s), 64);
+        if (!ok_segment(s, (size_t)(slash - s), 63)) return 0;
+        s = slash + 1;
+    }
+}
+static int rel_index(const type_t *t, const char *name);
+static int type_index(orc_t *o, const char *name);
+/* names of a request: declared or well-formed; srel may be NULL / "" / "..." */
+static int names_wellformed(orc_t *o, const char *rtype, const char *rel, const char *stype, const char *srel) {
+    int rt = type_index(o, rtype), st = stype ? type_index(o, stype) : -1;
+    if (rt < 0 && !ok_typename(rtype)) return 0;
+    if (stype && st < 0 && !ok_typename(stype)) return 0;
+    if (rel && *rel && (rt < 0 || rel_index(&o->types[rt], rel) < 0) && !ok_relname(rel)) return 0;
+    if (srel && *srel && strcmp(srel, "...") != 0 && (st < 0 || rel_index(&o->types[st], srel) < 0) && !ok_relname(srel)) return 0;
+    return 1;
+}
+
 /* --------------------------------------------------------------- tuple index */
 static int tup_cmp(const void *pa, const void *pb) {
     const tuple_t *a = pa, *b = pb;
@@ -773,6 +820,10 @@ static int resolve_rel(orc_t *o, const orc_rel_t *r, tuple_t *out, int intern) {
         seterr(o, "invalid relationship: empty field");
         return ORC_ERR_INVALID_ARGUMENT;
     }
+    if (!names_wellformed(o, r->rtype, r->rel, r->stype, r->srel) || !ok_id(r->rid) || (strcmp(r->sid, "*") != 0 && !ok_id(r->sid))) {
+        seterr(o, "invalid relationship: a field does not match the API's pattern");
+        return ORC_ERR_INVALID_ARGUMENT;
+    }
     int rt = type_index(o, r->rtype);
     if (rt < 0) { seterr(o, "object definition `%s` not found", r->rtype); return ORC_ERR_FAILED_PRECONDITION; }
     int rl = rel_index(&o->types[rt], r->rel);
@@ -822,6 +873,11 @@ static int filter_match(orc_t *o, const orc_filter_t *f, const tuple_t *t) {
 
 static int filter_valid(orc_t *o, const orc_filter_t *f) {
     if (!f->rtype || !*f->rtype) { seterr(o, "filter: resource type required"); return ORC_ERR_INVALID_ARGUMENT; }
+    if (!names_wellformed(o, f->rtype, f->rel, f->stype, f->stype ? f->srel : NULL) || (f->rid && *f->rid && !ok_id(f->rid)) ||
+        (f->stype && f->sid && *f->sid && strcmp(f->sid, "*") != 0 && !ok_id(f->sid))) {
+        seterr(o, "filter: a field does not match the API's pattern");
+        return ORC_ERR_INVALID_ARGUMENT;
+    }
     int rt = type_index(o, f->rtype);
     if (rt < 0) { seterr(o, "object definition `%s` not found", f->rtype); return ORC_ERR_FAILED_PRECONDITION; }
     if (f->rel && *f->rel && rel_index(&o->types[rt], f->rel) < 0) {
@@ -939,6 +995,11 @@ int orc_check(orc_t *o, const char *rtype, const char *rid, const char *perm, co
     if (!rtype || !rid || !perm || !stype || !sid || !*rtype || !*rid || !*perm || !*stype || !*sid) {
         seterr(o, "invalid CheckPermissionRequest: empty field");
         *err = ORC_ERR_INVALID_ARGUMENT; /* KAT-3: pkg/proxy/options_test.go:101-102 */
+        return ORC_PERM_UNSPEC;
+    }
+    if (!names_wellformed(o, rtype, perm, stype, srel) || !ok_id(rid) || !ok_id(sid)) { /* (`*` is not an object id in a Check) */
+        seterr(o, "invalid CheckPermissionRequest: a field does not match the API's pattern");
+        *err = ORC_ERR_INVALID_ARGUMENT;
         return ORC_PERM_UNSPEC;
     }
     int rt = type_index(o, rtype);
@@ -1067,6 +1128,7 @@ long orc_lookup(orc_t *o, const char *rtype, const char *perm, const char *stype
     *err = 0;
     o->lr_n = 0;
     if (!rtype || !perm || !stype || !sid || !*rtype || !*perm || !*stype || !*sid) { seterr(o, "invalid LookupResourcesRequest"); *err = ORC_ERR_INVALID_ARGUMENT; return -1; }
+    if (!names_wellformed(o, rtype, perm, stype, srel) || !ok_id(sid)) { seterr(o, "invalid LookupResourcesRequest: a field does not match the API's pattern"); *err = ORC_ERR_INVALID_ARGUMENT; return -1; }
     int rt = type_index(o, rtype);
     if (rt < 0) { seterr(o, "object definition `%s` not found", rtype); *err = ORC_ERR_FAILED_PRECONDITION; return -1; }
     int rl = rel_index(&o->types[rt], perm);

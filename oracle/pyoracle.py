@@ -160,6 +160,16 @@ _INTER = {(a, b): (NO if NO in (a, b) else ERR if ERR in (a, b) else HAS) for a 
 _MINUS = {NO: HAS, HAS: NO, ERR: ERR}
 
 
+# ---- API validation (EXTERNAL, unverified: the `validate` rules of authzed.api.v1, see oracle/acl_oracle.c): whole-request InvalidArgument
+_ID = re.compile(r"[a-zA-Z0-9/_|\-=+]{1,1024}\Z")
+_REL = re.compile(r"[a-z][a-z0-9_]{1,62}[a-z0-9]\Z")
+_TYPE = re.compile(r"([a-z][a-z0-9_]{1,61}[a-z0-9]/)*[a-z][a-z0-9_]{1,62}[a-z0-9]\Z")
+
+
+class InvalidArgument(ValueError):
+    pass
+
+
 class PyOracle:
     """Relationship store + evaluator.  Tuples are 6-tuples of strings
     (rtype, rid, rel, stype, sid, srel) with srel == '' for no subject relation."""
@@ -171,6 +181,7 @@ class PyOracle:
 
     # -- writes (TOUCH semantics; the C oracle covers CREATE/preconditions)
     def touch(self, rtype, rid, rel, stype, sid, srel="", expires=0):
+        self.validate(rtype, rid, rel, stype, sid, srel, star_subject=True)
         mem = self.defs[rtype].members[rel]
         assert isinstance(mem, Relation)
         if sid == "*":  # `T:*`: its own allowed form, stored as the subject (T, "*", "")
@@ -235,8 +246,19 @@ class PyOracle:
                     rs.append(self._check(st, sid, e[2], subject, depth - 1))
         return HAS if HAS in rs else ERR if ERR in rs else NO
 
+    def validate(self, rtype, rid, rel, stype, sid, srel="", star_subject=False):
+        """raises InvalidArgument for a request the API's validation refuses (declared names pass whatever their spelling)"""
+        d, sd = self.defs.get(rtype), self.defs.get(stype)
+        ok = (d is not None or (len(rtype) <= 128 and _TYPE.match(rtype))) and (sd is not None or (len(stype) <= 128 and _TYPE.match(stype)))
+        ok = ok and ((d is not None and rel in d.members) or _REL.match(rel))
+        ok = ok and (srel in ("", "...") or (sd is not None and srel in sd.members) or _REL.match(srel))
+        ok = ok and (rid is None or _ID.match(rid)) and (_ID.match(sid) or (star_subject and sid == "*"))
+        if not ok:
+            raise InvalidArgument((rtype, rid, rel, stype, sid, srel))
+
     def check(self, rtype, rid, perm, stype, sid, srel=""):
-        """returns 'HAS' | 'NO' | 'ERR' (depth) ; raises KeyError for unknown type/relation."""
+        """returns 'HAS' | 'NO' | 'ERR' (depth) ; raises InvalidArgument for an ill-formed request, KeyError for unknown type/relation."""
+        self.validate(rtype, rid, perm, stype, sid, srel)
         if perm not in self.defs[rtype].members:
             raise KeyError(perm)
         if srel and srel not in self.defs[stype].members:
@@ -245,6 +267,7 @@ class PyOracle:
         return self._check(rtype, rid, perm, (stype, sid, srel), MAX_DEPTH)
 
     def lookup_resources(self, rtype, perm, stype, sid, srel=""):
+        self.validate(rtype, None, perm, stype, sid, srel)
         ids = {k[1] for k in self.rows if k[0] == rtype}
         if stype == rtype:
             ids.add(sid)

@@ -9,6 +9,7 @@
 // There is no CPU evaluation path: without a GPU acl_open() fails.
 // Threading: engine_internal.hpp (state_mu / names_mu / PassCtx pool).
 #include "engine_internal.hpp"
+#include "validate.hpp"
 
 #include <pthread.h>
 #include <sched.h>
@@ -913,15 +914,26 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
     int pm = rt < 0 ? -1 : sc.defs[rt].find(it.permission);
     int sr = kNoRelation;
     bool bad = rt < 0 || st < 0 || pm < 0;
-    if (!bad && !empty(it.subject_relation) && std::strcmp(it.subject_relation, "...") != 0) {
-        sr = sc.defs[st].find(it.subject_relation);
-        bad = sr < 0;
+    const bool srel_given = !empty(it.subject_relation) && std::strcmp(it.subject_relation, "...") != 0;
+    if (srel_given) {
+        sr = st < 0 ? -1 : sc.defs[st].find(it.subject_relation);
+        bad = bad || sr < 0;
     }
-    if (bad) return ACL_ERR_FAILED_PRECONDITION;
+    // API validation beats "not found" (validate.hpp): ill-formed names and ids, and `*` anywhere in a Check
+    if ((rt < 0 && !valid_type_name(it.resource_type)) || (st < 0 && !valid_type_name(it.subject_type)) || (pm < 0 && !valid_relation_name(it.permission)) ||
+        (srel_given && sr < 0 && !valid_relation_name(it.subject_relation)))
+        return ACL_ERR_INVALID_ARGUMENT;
+    if (bad) {
+        if (!valid_object_id(it.resource_id) || !valid_object_id(it.subject_id)) return ACL_ERR_INVALID_ARGUMENT;
+        return ACL_ERR_FAILED_PRECONDITION;
+    }
     // unknown object ids have no relationships: sentinels above every dense id, equal only when
     // resource and subject are the same (unknown) object
     uint32_t res, sub;
     bool kr = h->store.objects(rt).find(it.resource_id, &res), ks = h->store.objects(st).find(it.subject_id, &sub);
+    // (every name IN a table passed the id pattern when it was interned -- except "*", the wildcard subject's name: only unknown ids are spelled out)
+    if ((!kr && !valid_object_id(it.resource_id)) || (!ks && !valid_object_id(it.subject_id)) || std::strcmp(it.resource_id, "*") == 0 || std::strcmp(it.subject_id, "*") == 0)
+        return ACL_ERR_INVALID_ARGUMENT;
     if (!kr && !ks && rt == st && std::strcmp(it.resource_id, it.subject_id) == 0) res = sub = 0xFFFFFFFEu;
     else {
         if (!kr) res = 0xFFFFFFFDu;
@@ -961,6 +973,7 @@ struct NameMemo {
     std::string s[4];
     int rti = -1, pmi = -1, sti = -1, sri = kNoRelation;
     bool bad = true, valid = false;
+    bool malformed = false;  // an undeclared name that does not even match the API's pattern: InvalidArgument, not "not found" (validate.hpp)
 };
 
 // names -> indices of item i (memoised per thread); false: *err says why the item cannot be checked
@@ -988,15 +1001,17 @@ static bool intern_names(const Schema &sc, const Items &its, size_t i, NameMemo 
             m.pmi = m.rti < 0 ? -1 : sc.defs[m.rti].find(m.s[1]);
             m.sri = kNoRelation;
             m.bad = m.rti < 0 || m.sti < 0 || m.pmi < 0;
-            if (!m.bad && !m.s[3].empty()) {
-                m.sri = sc.defs[m.sti].find(m.s[3]);
-                m.bad = m.sri < 0;
+            if (!m.s[3].empty()) {
+                m.sri = m.sti < 0 ? -1 : sc.defs[m.sti].find(m.s[3]);
+                m.bad = m.bad || m.sri < 0;
             }
+            m.malformed = (m.rti < 0 && !valid_type_name(m.s[0])) || (m.sti < 0 && !valid_type_name(m.s[2])) || (m.pmi < 0 && !valid_relation_name(m.s[1])) ||
+                          (!m.s[3].empty() && m.sri < 0 && !valid_relation_name(m.s[3]));
         }
         m.valid = true;
     }
     // empty request fields: pkg/proxy/options_test.go:101-102 (the subject relation may be empty)
-    if (m.s[0].empty() || m.s[1].empty() || m.s[2].empty()) {
+    if (m.s[0].empty() || m.s[1].empty() || m.s[2].empty() || m.malformed) {
         *err = ACL_ERR_INVALID_ARGUMENT;
         return false;
     }
@@ -1179,7 +1194,9 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 p.rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
                 p.sid = u ? std::string_view(u, its.len(i, F_SID)) : std::string_view();
                 p.ok = intern_names(sc, its, i, m, &err);
-                if (err != ACL_ERR_INVALID_ARGUMENT && (p.rid.empty() || p.sid.empty())) {  // an empty field beats an unknown name
+                // an empty or ill-formed id beats an unknown name (API validation comes first); ids of items that resolve are spelled out
+                // only where the table does not know them (third stage below: every name IN a table passed the pattern when it was interned)
+                if (err != ACL_ERR_INVALID_ARGUMENT && (p.rid.empty() || p.sid.empty() || (!p.ok && (!valid_object_id(p.rid) || !valid_object_id(p.sid))))) {
                     p.ok = false;
                     err = ACL_ERR_INVALID_ARGUMENT;
                 }
@@ -1207,6 +1224,11 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 // resource and subject are the same (unknown) object
                 uint32_t res, sub;
                 const bool kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &res), ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &sub);
+                if ((!kr && !valid_object_id(p.rid)) || (!ks && !valid_object_id(p.sid)) || p.rid == "*" || p.sid == "*") {  // (`*` never in a Check)
+                    out[i] = acl_item_t{kDeadType, 0, 0, kDeadType, 0, 0};
+                    mybad.emplace_back((uint32_t)i, (int32_t)ACL_ERR_INVALID_ARGUMENT);
+                    continue;
+                }
                 if (!kr && !ks && p.rt == p.st && p.rid == p.sid) res = sub = 0xFFFFFFFEu;
                 else {
                     if (!kr) res = 0xFFFFFFFDu;
@@ -1249,6 +1271,12 @@ static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8
         if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
         intern_items(h, its, n, staged, &bad);
     }
+    // A request that fails the API's validation fails AS A WHOLE with InvalidArgument -- no pairs at all (validate.hpp; the reference denies
+    // everything it asked on any error of the call, check.go:48-52, and fails the list response, postfilter.go:134-137).  Unknown types /
+    // permissions stay per-item errors (check.go:55-60).
+    for (const auto &be : bad)
+        if (be.second == ACL_ERR_INVALID_ARGUMENT)
+            return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(be.first) + " has an empty or ill-formed field");
     if (bad.size() == n) {  // nothing to ask the device
         std::memset(perm_out, ACL_PERM_UNSPECIFIED, n);
     } else {
@@ -1379,7 +1407,10 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
     const size_t group = std::max<size_t>(1, std::min<size_t>(n ? n : 1, ((size_t)1 << 28) / vwords));  // <= 1 GiB of visited bits
     for (size_t b = 0; b < n; b += group) {
         const size_t m = std::min(group, n - b);
-        HIP_TRY(c->d_visited.ensure(m * vwords));
+        if (c->d_visited.n < m * vwords || !c->d_visited.p) {
+            HIP_TRY(c->d_visited.ensure(m * vwords));
+            c->visited_zero_words = 0;  // (fresh memory)
+        }
         HIP_TRY(c->d_sids.ensure(m));
         HIP_TRY(c->h_in.ensure(m * sizeof(uint32_t)));
         std::memcpy(c->h_in.p, sids + b, m * sizeof(uint32_t));
@@ -1390,10 +1421,18 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
         // memset, no D2H copies.  A lookup that outgrows its block (private frontier region, children per level) sends the group to the
         // level loop below, which spreads it over the chip.
         if (h->rev_local) {
+            // the single-launch walk takes the visited rows all zero and leaves them all zero (every block clears what it marked): one memset
+            // per context and size, not one per call
+            if (c->visited_zero_words < m * vwords) {
+                HIP_TRY(hipMemsetAsync(c->d_visited.p, 0, m * vwords * 4, c->stream));
+                c->visited_zero_words = m * vwords;
+            }
             rc = lookup_pass_local(h, c, r, key, target, m, bitmaps + b * words, words, cw, counts ? counts + b : nullptr);
             if (rc == ACL_OK) continue;
+            c->visited_zero_words = 0;  // a block gave up half-way (or the call failed): its marks are still there
             if (rc != kTakeLevelLoop) return rc;
         }
+        c->visited_zero_words = 0;  // (the level loop below marks and does not clear)
         HIP_TRY(hipMemcpyAsync(c->d_sids.p, c->h_in.p, m * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c->h_out.ensure(m * std::max<size_t>(cw, 1) * 4));
         for (int attempt = 0;; attempt++) {
@@ -1447,6 +1486,13 @@ int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const c
     const Schema &sc = h->store.schema();
     int sr = -1;
     const int rt = sc.type_of(rtype);
+    {   // API validation first (validate.hpp)
+        const int vs = sc.type_of(stype);
+        const bool srel_given = !empty(srel) && std::strcmp(srel, "...") != 0;
+        if ((rt < 0 && !valid_type_name(rtype)) || (vs < 0 && !valid_type_name(stype)) || ((rt < 0 || sc.defs[rt].find(perm) < 0) && !valid_relation_name(perm)) ||
+            (srel_given && (vs < 0 || sc.defs[vs].find(srel) < 0) && !valid_relation_name(srel)) || !valid_object_id(sid))
+            return fail(ACL_ERR_INVALID_ARGUMENT, "invalid LookupResourcesRequest: a field does not match the API's pattern");  // (`*` is not an object id here)
+    }
     if (rt < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + rtype + "` not found");
     const int pm = sc.defs[rt].find(perm);
     if (pm < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation/permission `") + perm + "` not found under definition `" + rtype + "`");
@@ -1631,6 +1677,7 @@ int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_ou
     std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
+    if (!valid_object_id(object_id)) return fail(ACL_ERR_INVALID_ARGUMENT, std::string("acl_intern: `") + object_id + "` does not match the API's object id pattern");  // (validate.hpp: names in the tables are well-formed)
     *id_out = h->store.objects(type).intern(object_id);
     return ACL_OK;
 }

@@ -230,6 +230,7 @@ struct PassCtx {
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
     DevArray<uint32_t> d_sids, d_visited, d_rows;
+    size_t visited_zero_words = 0;  // leading words of d_visited known to be all zero: k_rev_local takes `visited` zeroed and hands it back zeroed (kernels.hip)
     DevArray<uint4> d_nodes;     // schemas with `&` / `-`: the CombineNode records of a pass (plan.hpp)
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
     PinnedBuf h_in, h_out;  // staging for pageable caller buffers

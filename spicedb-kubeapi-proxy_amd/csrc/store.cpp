@@ -2,6 +2,8 @@
 // observe from SpiceDB at the seam (SURVEY.md 8(b) "Error conventions").
 #include "store.hpp"
 
+#include "validate.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -270,6 +272,17 @@ size_t Store::gc_expired(int64_t now) {
 Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
     if (r.rtype.empty() || r.rid.empty() || r.rel.empty() || r.stype.empty() || r.sid.empty())
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: empty field");
+    {   // API validation comes first and fails the whole request (validate.hpp): ill-formed names and ids are InvalidArgument, not "not found"
+        const int vt = schema_.type_of(r.rtype), vs = schema_.type_of(r.stype);
+        const bool srel_given = !r.srel.empty() && r.srel != "...";
+        if ((vt < 0 && !valid_type_name(r.rtype)) || (vs < 0 && !valid_type_name(r.stype)))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: object type does not match the API's pattern");
+        if (((vt < 0 || schema_.defs[vt].find(r.rel) < 0) && !valid_relation_name(r.rel)) ||
+            (srel_given && (vs < 0 || schema_.defs[vs].find(r.srel) < 0) && !valid_relation_name(r.srel)))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: relation does not match the API's pattern");
+        if (!valid_object_id(r.rid)) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: resource id `" + r.rid + "` does not match the API's pattern");
+        if (r.sid != "*" && !valid_object_id(r.sid)) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: subject id `" + r.sid + "` does not match the API's pattern");
+    }
     int rt = schema_.type_of(r.rtype);
     if (rt < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + r.rtype + "` not found");
     int rl = schema_.defs[rt].find(r.rel);
@@ -307,6 +320,18 @@ Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
 
 Status Store::validate_filter(const FilterText &f) const {
     if (f.rtype.empty()) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: resource type is required");
+    {   // API validation first (validate.hpp): optional fields are checked when present
+        const int vt = schema_.type_of(f.rtype), vs = f.has_stype ? schema_.type_of(f.stype) : -1;
+        if ((vt < 0 && !valid_type_name(f.rtype)) || (f.has_stype && vs < 0 && !valid_type_name(f.stype)))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: object type does not match the API's pattern");
+        if (f.has_rel && !f.rel.empty() && (vt < 0 || schema_.defs[vt].find(f.rel) < 0) && !valid_relation_name(f.rel))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: relation does not match the API's pattern");
+        if (f.has_srel && !f.srel.empty() && f.srel != "..." && (vs < 0 || schema_.defs[vs].find(f.srel) < 0) && !valid_relation_name(f.srel))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: subject relation does not match the API's pattern");
+        if (f.has_rid && !f.rid.empty() && !valid_object_id(f.rid)) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: resource id does not match the API's pattern");
+        if (f.has_sid && !f.sid.empty() && f.sid != "*" && !valid_object_id(f.sid))
+            return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relationship filter: subject id does not match the API's pattern");
+    }
     int rt = schema_.type_of(f.rtype);
     if (rt < 0) return Status::Err(ACL_ERR_FAILED_PRECONDITION, "object definition `" + f.rtype + "` not found");
     if (f.has_rel && !f.rel.empty() && schema_.defs[rt].find(f.rel) < 0)

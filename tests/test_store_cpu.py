@@ -196,12 +196,16 @@ def test_object_names_of_every_length_round_trip(aclgpu_lib):
     base = "ns-0123456789/pod-abcdefghijklmnopqrstuvwxyz-0123456789-ABCDEFGHIJKLMNOPQRSTUVWXYZ"
     names = [base[:k] for k in (1, 2, 15, 16, 45, 46, 47, 48, 63, 64, 65, len(base))]
     names += [base[:46] + s for s in ("x", "y", "xx", "x" * 30)]          # same inline prefix, different tails
-    names += ["é" * 23, "é" * 24, "z" * 65535, "z" * 65536, "z" * 70000]  # multi-byte; around the saturating length
+    names += ["y" * 23, "y" * 24, "z" * 1022, "z" * 1023, "z" * 1024]     # up to the API's 1024-byte limit (validate.hpp)
     names += [f"filler-{i}" for i in range(3000)]                          # several growth steps: slots are re-hashed with their names
     ids = [e.intern("user", n) for n in names]
     assert ids == list(range(len(names)))
     assert [e.intern("user", n) for n in names] == ids  # idempotent
     assert [e.find("user", n) for n in names] == ids
-    for n in (base[:44], base[:46] + "z", base + "!", "z" * 65534, "z" * 69999, "filler-3000", ""):
+    for n in (base[:44], base[:46] + "z", base + "!", "z" * 1021, "z" * 1025, "filler-3000", ""):
         assert e.find("user", n) is None, n[:60]
+    for bad in ("é" * 23, "z" * 1025, "a.b", "a b", "*", "a:b"):  # what the API's object-id pattern refuses never enters a table
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.intern("user", bad)
+        assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
     assert [e.object_name("user", i) for i in ids[:21]] == names[:21]
