@@ -51,6 +51,10 @@ type fixture struct {
 	Perm          string           `json:"perm"`          // one digit per check: Permissionship (1 NO, 2 HAS, 3 CONDITIONAL), 0 = the pair carried an error
 	ErrCodes      map[string]int32 `json:"err_codes"`     // check index -> gRPC code of the pair's error
 	Lookups       [][]string       `json:"lookups"`       // per lookups.txt line: sorted resource ids with HAS_PERMISSION
+	// requests.txt (optional; API validation, tests/ref_cases.py `requests`): one outcome per request, in file order --
+	// "check" / "write": the call's gRPC code ("0" = OK; a check adds ":<permissionship>"); "bulk": "error:<code>" when the CALL failed,
+	// else one digit per item as in `perm` ("0" = the pair carried an error)
+	Requests []string `json:"requests,omitempty"`
 }
 
 func lines(path string) ([]string, []byte, error) {
@@ -193,6 +197,70 @@ func runCase(ctx context.Context, dir, outDir string) error {
 		}
 		sort.Strings(ids)
 		fx.Lookups = append(fx.Lookups, ids)
+	}
+	// requests.txt: `check <tuple>` | `write <tuple>` (one TOUCH) | `bulk <tuple> <tuple> ...` -- whole requests whose ERROR BEHAVIOUR is the
+	// thing pinned (ill-formed ids, `*`, unknown names: InvalidArgument of the call vs an error inside a pair).  Replayed last: the
+	// writes that succeed change the store.
+	if reqs, _, err := lines(filepath.Join(dir, "requests.txt")); err == nil {
+		item := func(l string) (*v1.CheckBulkPermissionsRequestItem, error) {
+			m := relRe.FindStringSubmatch(l)
+			if m == nil {
+				return nil, fmt.Errorf("%s: bad request tuple %q", name, l)
+			}
+			return &v1.CheckBulkPermissionsRequestItem{Resource: &v1.ObjectReference{ObjectType: m[1], ObjectId: m[2]}, Permission: m[3], Subject: subject(m[4], m[5], m[7])}, nil
+		}
+		for _, l := range reqs {
+			f := strings.Fields(l)
+			if len(f) < 2 {
+				return fmt.Errorf("%s: bad request line %q", name, l)
+			}
+			switch f[0] {
+			case "check":
+				it, err := item(f[1])
+				if err != nil {
+					return err
+				}
+				r, err := client.CheckPermission(ctx, &v1.CheckPermissionRequest{Consistency: full(), Resource: it.Resource, Permission: it.Permission, Subject: it.Subject})
+				if err != nil {
+					fx.Requests = append(fx.Requests, fmt.Sprint(int(status.Code(err))))
+				} else {
+					fx.Requests = append(fx.Requests, fmt.Sprintf("0:%d", int(r.Permissionship)))
+				}
+			case "write":
+				it, err := item(f[1])
+				if err != nil {
+					return err
+				}
+				_, err = client.WriteRelationships(ctx, &v1.WriteRelationshipsRequest{Updates: []*v1.RelationshipUpdate{{Operation: v1.RelationshipUpdate_OPERATION_TOUCH,
+					Relationship: &v1.Relationship{Resource: it.Resource, Relation: it.Permission, Subject: it.Subject}}}})
+				fx.Requests = append(fx.Requests, fmt.Sprint(int(status.Code(err))))
+			case "bulk":
+				var items []*v1.CheckBulkPermissionsRequestItem
+				for _, t := range f[1:] {
+					it, err := item(t)
+					if err != nil {
+						return err
+					}
+					items = append(items, it)
+				}
+				resp, err := client.CheckBulkPermissions(ctx, &v1.CheckBulkPermissionsRequest{Consistency: full(), Items: items})
+				if err != nil {
+					fx.Requests = append(fx.Requests, fmt.Sprintf("error:%d", int(status.Code(err))))
+					break
+				}
+				digits := make([]byte, len(resp.Pairs))
+				for k, p := range resp.Pairs {
+					if p.GetError() != nil {
+						digits[k] = '0'
+					} else {
+						digits[k] = byte('0' + int(p.GetItem().Permissionship))
+					}
+				}
+				fx.Requests = append(fx.Requests, string(digits))
+			default:
+				return fmt.Errorf("%s: unknown request kind %q", name, f[0])
+			}
+		}
 	}
 	out, err := json.Marshal(fx)
 	if err != nil {

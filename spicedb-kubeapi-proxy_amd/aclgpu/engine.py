@@ -184,7 +184,14 @@ class Engine:
         return perm[:n].tolist(), err[:n].tolist()
 
     def check(self, rt, rid, perm, st, sid, srel=""):
-        p, e = self.check_bulk([(rt, rid, perm, st, sid, srel)])
+        """CheckPermission: (permissionship, error code).  A request the API's validation refuses fails as a whole (validate.hpp): for a
+        single check the call's InvalidArgument is the item's."""
+        try:
+            p, e = self.check_bulk([(rt, rid, perm, st, sid, srel)])
+        except AclError as x:
+            if x.code == ERR_INVALID_ARGUMENT:
+                return 0, x.code
+            raise
         return p[0], e[0]
 
     def make_items(self, rtype, perm, res, stype, srel, subj):

@@ -1570,6 +1570,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
         auto *so = new acl_engine();
         so->store_only = true;
         so->device = -1;
+        if (const char *ev = getenv("ACL_RAW_INTERN")) so->raw_intern = atoi(ev) != 0;  // (test knob, see below)
         batcher_create(so);
         *out = so;
         return ACL_OK;
@@ -1599,6 +1600,7 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (const char *ev = getenv("ACL_HOSTMAP_MAX")) h->hostmap_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob: batches up to this size are read / answered across PCIe by the kernel itself
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
+    if (const char *ev = getenv("ACL_RAW_INTERN")) h->raw_intern = atoi(ev) != 0;  // test knob: acl_intern takes any bytes (the JSON scanners' decoding tests name objects no API request could)
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch
     if (const char *ev = getenv("ACL_LOCAL_DYN_UNIT")) h->local_dyn_unit = (uint32_t)std::min(256, std::max(1, atoi(ev)));       // in static units; size of the hand-out units
@@ -1677,7 +1679,7 @@ int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_ou
     std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
-    if (!valid_object_id(object_id)) return fail(ACL_ERR_INVALID_ARGUMENT, std::string("acl_intern: `") + object_id + "` does not match the API's object id pattern");  // (validate.hpp: names in the tables are well-formed)
+    if (!h->raw_intern && !valid_object_id(object_id)) return fail(ACL_ERR_INVALID_ARGUMENT, std::string("acl_intern: `") + object_id + "` does not match the API's object id pattern");  // (validate.hpp: names in the tables are well-formed)
     *id_out = h->store.objects(type).intern(object_id);
     return ACL_OK;
 }

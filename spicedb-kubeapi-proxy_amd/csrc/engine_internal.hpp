@@ -298,6 +298,7 @@ struct acl_engine {
     hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
     int grid_blocks = 2048;
     std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
+    bool raw_intern = false;       // test knob (ACL_RAW_INTERN): acl_intern skips the API's object-id pattern
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
     int local_blocks = 1024;   // resident blocks of the single-launch kernel (4 waves per block)
     int local_blocks_wide = 512;  // ... of its 16-wave instantiation

@@ -98,6 +98,17 @@ def run_kat(kat, client):
             else:
                 got = [_outcome(*client.check(*it)) for it in items]
             assert all(_match(e, g) for e, g in zip(step[2], got)) and len(got) == len(step[2]), f"{where}: expected {step[2]} got {got}"
+        elif kind == "bulk_err":  # a request the API's validation refuses fails AS A WHOLE (no pairs)
+            items = [parse_rel(t) for t in step[1]]
+            if hasattr(client, "check_bulk"):
+                try:
+                    client.check_bulk(items)
+                    got = None
+                except Exception as e:  # noqa: BLE001
+                    got = getattr(e, "code", None)
+            else:  # one-at-a-time adapters: the call fails iff some item is ill-formed
+                got = 3 if any(client.check(*it)[1] == 3 for it in items) else None
+            assert got == step[2], f"{where}: expected the call to fail with {step[2]}, got {got}"
         elif kind == "lookup":
             st, sid, srel = parse_subject(step[3])
             got = client.lookup(step[1], step[2], st, sid, srel)

@@ -101,13 +101,120 @@ def _bootstrap_case():
     return {"name": "bootstrap", "schema": b["schema"], "relationships": rels, "checks": checks, "lookups": lookups}
 
 
+def _combine_case():
+    """Round 4: intersection, exclusion, wildcards -- operator precedence, wildcards in positive and subtracted operands, arrows into
+    permissions that are themselves non-monotone, depth errors under `&` / `-` (a 60-long nesting chain).  Names are >= 3 characters:
+    the real schema compiler refuses shorter ones."""
+    from tests.test_oracle_cross import SCHEMA_NM
+    rels = [
+        ("group", "eng", "member", "user", "alice", ""), ("group", "eng", "member", "user", "bob", ""), ("group", "eng", "banned", "user", "bob", ""),
+        ("group", "all", "member", "user", "*", ""), ("group", "all", "banned", "group", "eng", "member"), ("group", "ops", "member", "group", "eng", "member"),
+        ("folder", "root", "viewer", "group", "eng", "active"), ("folder", "root", "viewer", "user", "carol", ""), ("folder", "root", "banned", "user", "carol", ""),
+        ("folder", "root", "auditor", "user", "alice", ""), ("folder", "root", "auditor", "group", "ops", "member"),
+        ("folder", "sub", "parent", "folder", "root", ""), ("folder", "sub", "viewer", "user", "*", ""), ("folder", "sub", "banned", "user", "dave", ""),
+        ("folder", "open", "viewer", "group", "all", "active"), ("folder", "shut", "viewer", "user", "erin", ""), ("folder", "shut", "banned", "user", "*", ""),
+        ("doc", "spec", "folder", "folder", "sub", ""), ("doc", "spec", "viewer", "user", "frank", ""), ("doc", "spec", "editor", "user", "frank", ""),
+        ("doc", "spec", "editor", "group", "eng", "member"), ("doc", "spec", "banned", "user", "alice", ""),
+        ("doc", "plan", "folder", "folder", "root", ""), ("doc", "plan", "viewer", "group", "eng", "active"), ("doc", "plan", "editor", "user", "alice", ""),
+        ("doc", "plan", "viewer", "user", "alice", ""), ("doc", "memo", "folder", "folder", "shut", ""), ("doc", "memo", "editor", "user", "erin", ""),
+        ("doc", "memo", "banned", "group", "ops", "member"), ("doc", "free", "folder", "folder", "open", ""),
+    ]
+    n = 60
+    rels += [("group", f"chain{i}", "member", "group", f"chain{i + 1}", "member") for i in range(n)] + [("group", f"chain{n}", "member", "user", "deep", "")]
+    rels += [("doc", "deep1", "editor", "user", "deep", ""), ("doc", "deep1", "banned", "group", "chain0", "member"),   # base HAS, subtracted too deep
+             ("doc", "deep2", "banned", "group", "chain0", "member"),                                                   # base NO: the error is never looked at
+             ("doc", "deep3", "viewer", "user", "deep", ""), ("doc", "deep3", "editor", "group", "chain0", "member")]   # `&` with an operand too deep
+    users = ["alice", "bob", "carol", "dave", "erin", "frank", "deep", "nobody"]
+    checks = []
+    for u in users:
+        for d in ("spec", "plan", "memo", "free", "deep1", "deep2", "deep3", "missing"):
+            for p in ("view", "edit", "strict", "odd", "nothing", "viewer"):
+                checks.append(("doc", d, p, "user", u, ""))
+        for f in ("root", "sub", "open", "shut"):
+            for p in ("view", "audit"):
+                checks.append(("folder", f, p, "user", u, ""))
+        for g in ("eng", "all", "ops", "chain0", "chain30"):
+            for p in ("member", "active"):
+                checks.append(("group", g, p, "user", u, ""))
+    for s_ in (("group", "eng", "member"), ("group", "eng", "active"), ("group", "all", "active")):
+        for d in ("spec", "plan", "free"):
+            checks.append(("doc", d, "view") + s_)
+        checks.append(("folder", "root", "view") + s_)
+    lookups = [("doc", p, "user", u, "") for u in ("alice", "bob", "frank", "nobody") for p in ("view", "edit", "strict", "odd")]
+    lookups += [("folder", "view", "user", "carol", ""), ("folder", "audit", "user", "alice", ""), ("group", "active", "user", "bob", ""), ("group", "active", "user", "zed", ""),
+                ("doc", "view", "group", "eng", "member")]
+    return {"name": "combine", "schema": SCHEMA_NM, "relationships": rels, "checks": checks, "lookups": lookups}
+
+
+def _validation_case():
+    """Round 4: the API's request validation (EXTERNAL, unverified -- spicedb-kubeapi-proxy_amd/csrc/validate.hpp): WHOLE requests whose
+    error behaviour is the thing pinned.  Kubernetes names may hold `.` (`kube-root-ca.crt`), which the object-id pattern refuses: the
+    reference then denies, because any error of the call denies (check.go:48-52)."""
+    b = json.load(open(os.path.join(HERE, "golden", "bootstrap.json")))
+    from tests import kat_runner
+    rels = [kat_runner.parse_rel(line) for line in b["relationships"]] + [("pod", "ns/p1", "creator", "user", "paul", ""), ("namespace", "ns", "viewer", "user", "paul", "")]
+    ok = ("pod", "ns/p1", "view", "user", "paul", "")
+    long_ok, long_bad = "x" * 1024, "x" * 1025
+    requests = [
+        ("check", [ok]),
+        ("check", [("pod", "ns/kube-root-ca.crt", "view", "user", "paul", "")]),        # `.` in a resource id
+        ("check", [("pod", "ns/p1", "view", "user", "system:admin", "")]),              # `:` in a subject id
+        ("check", [("pod", "ns/p1", "view", "user", "a%b", "")]),
+        ("check", [("pod", "a_b|c-d=e+f/G9", "view", "user", "paul", "")]),             # every allowed punctuation mark
+        ("check", [("pod", long_ok, "view", "user", "paul", "")]), ("check", [("pod", long_bad, "view", "user", "paul", "")]),
+        ("check", [("pod", "ns/p1", "view", "user", "*", "")]), ("check", [("pod", "*", "view", "user", "paul", "")]),
+        ("check", [("nosuchtype", "x", "view", "user", "paul", "")]),                   # well-formed, undeclared: not found
+        ("check", [("No_Such", "x", "view", "user", "paul", "")]), ("check", [("pod", "x", "View", "user", "paul", "")]), ("check", [("pod", "x", "vw", "user", "paul", "")]),
+        ("check", [("pod", "ns/p1", "view", "user", "paul", "Bad")]), ("check", [("pod", "ns/p1", "view", "user", "paul", "nosuchrel")]),
+        ("bulk", [ok, ("pod", "ns/p2", "view", "user", "paul", ""), ("namespace", "ns", "view", "user", "paul", "")]),
+        ("bulk", [ok, ("pod", "ns/a.b", "view", "user", "paul", "")]),                  # one ill-formed item fails the call
+        ("bulk", [ok, ("pod", "ns/p1", "nosuchperm", "user", "paul", ""), ok]),         # an undeclared permission is an error INSIDE its pair
+        ("bulk", [ok, ("pod", "ns/p1", "view", "user", "*", "")]),
+        ("write", [("pod", "ns/new", "creator", "user", "chani", "")]),
+        ("write", [("pod", "ns/a.b", "creator", "user", "chani", "")]), ("write", [("pod", "ns/new", "creator", "user", "cha ni".replace(" ", "$"), "")]),
+        ("write", [("pod", "*", "creator", "user", "chani", "")]), ("write", [("pod", "ns/new", "creator", "user", "*", "")]),   # `*` where no wildcard is declared
+        ("write", [("pod", "ns/new", "nosuchrel", "user", "chani", "")]), ("write", [("pod", "ns/new", "view", "user", "chani", "")]),
+        ("check", [("pod", "ns/new", "view", "user", "chani", "")]),
+    ]
+    checks = [ok, ("pod", "ns/p2", "view", "user", "paul", "")]
+    return {"name": "validation", "schema": b["schema"], "relationships": rels, "checks": checks, "lookups": [("pod", "view", "user", "paul", "")], "requests": requests}
+
+
+def replay_requests(client, requests):
+    """The outcome strings oracle/ref_spicedb/main.go records for a case's `requests`, from an adapter with check(*tuple) -> (perm, err),
+    write([(op, tuple)]) raising an error with .code, and -- optionally -- check_bulk(items) raising on a failed CALL.  Without check_bulk
+    (the oracles answer one item at a time) the call fails with InvalidArgument iff some item does: the API validates the request whole."""
+    out = []
+    for kind, ts in requests:
+        if kind == "check":
+            perm, err = client.check(*ts[0])
+            out.append(str(err) if err else f"0:{perm}")
+        elif kind == "write":
+            try:
+                client.write([(2, ts[0])])
+                out.append("0")
+            except Exception as e:  # noqa: BLE001
+                out.append(str(e.code))
+        else:
+            if hasattr(client, "check_bulk"):
+                try:
+                    perms, errs = client.check_bulk(list(ts))
+                    out.append("".join("0" if e else str(p) for p, e in zip(perms, errs)))
+                except Exception as e:  # noqa: BLE001
+                    out.append(f"error:{e.code}")
+            else:
+                res = [client.check(*t) for t in ts]
+                out.append("error:3" if any(e == 3 for _, e in res) else "".join("0" if e else str(p) for p, e in res))
+    return out
+
+
 def cases():
     import sys
     pkg = os.path.join(os.path.dirname(HERE), "spicedb-kubeapi-proxy_amd")
     if pkg not in sys.path:
         sys.path.insert(0, pkg)
     from aclgpu import workloads
-    out = [_bootstrap_case(), _shapes_case(),
+    out = [_bootstrap_case(), _shapes_case(), _combine_case(), _validation_case(),
            _workload_case("c1", workloads.c1(), 100),
            _workload_case("c2_s005", workloads.c2(scale=0.05, batch=20000), 20000),
            _workload_case("c3_s005", workloads.c3(scale=0.05, batch=4000, power_users=8), 4000),

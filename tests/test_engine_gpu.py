@@ -308,17 +308,29 @@ definition pod { relation namespace: namespace
     qs[11] = ("namespace", "ns1", "view", "group", "g1", "member")
     qs[12] = ("nosuchtype", "x", "view", "user", "u1", "")            # FAILED_PRECONDITION
     qs[13] = ("pod", "ns0/p0", "nosuchperm", "user", "u1", "")
-    qs[14] = ("pod", "", "view", "user", "u1", "")                    # INVALID_ARGUMENT (options_test.go:101-102)
+    qs[14] = ("pod", "ns0/p0", "view", "nosuchtype", "u1", "")
     qs[15] = ("pod", "ns0/p0", "view", "user", "u1", "nosuchrel")
     qs[16] = ("pod", "same", "view", "pod", "same", "")               # unknown object that is its own subject
-    qs[5000] = ("", "", "", "", "", "")
+    qs[5000] = ("pod", "never-written", "view", "user", "never-seen", "")
+    # requests the API's validation refuses (validate.hpp): a single check answers INVALID_ARGUMENT, a bulk request fails AS A WHOLE
+    invalid = [("pod", "", "view", "user", "u1", ""), ("", "", "", "", "", ""),   # empty fields: pkg/proxy/options_test.go:101-102
+               ("pod", "ns0/kube-root-ca.crt", "view", "user", "u1", ""), ("pod", "ns0/p0", "view", "user", "system:admin", ""), ("pod", "ns0/p0", "view", "user", "*", ""),
+               ("No_Such", "x", "view", "user", "u1", ""), ("pod", "ns0/p0", "vw", "user", "u1", "")]
     with aclgpu.Engine(schema, "\n".join(rels)) as e:
-        want = [o.check(*q) if all(q[:5]) else (0, aclgpu.ERR_INVALID_ARGUMENT) for q in qs]
+        want = [o.check(*q) for q in qs]
         for idx in (10, 11, 12, 13, 14, 15, 16, 5000):
             assert e.check(*qs[idx]) == want[idx], (idx, qs[idx])
+        for bad in invalid:
+            assert e.check(*bad) == (0, aclgpu.ERR_INVALID_ARGUMENT), bad
+            if all(bad[:5]):
+                assert o.check(*bad) == (0, aclgpu.ERR_INVALID_ARGUMENT), bad
+            for batch in ([bad], qs[:50] + [bad] + qs[50:100], qs[:5000] + [bad]):  # single-thread and pooled interning
+                with pytest.raises(aclgpu.AclError) as ei:
+                    e.check_bulk(batch)
+                assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, bad
         for form, prep, call in (("c strings", e.make_check_strings_named(qs), e.check_bulk_prepared), ("views", e.make_check_views(qs), e.check_bulk_views)):
             p, er = call(prep)
             assert list(zip(p.tolist(), er.tolist())) == want, form
             p2, er2 = call((prep[0], 100, prep[2]))  # a small batch takes the single-thread path
             assert list(zip(p2.tolist(), er2.tolist())) == want[:100], form
-        assert {w_[1] for w_ in want} >= {0, aclgpu.ERR_INVALID_ARGUMENT, aclgpu.ERR_FAILED_PRECONDITION} and 0 < sum(w_[0] == 2 for w_ in want) < len(want)
+        assert {w_[1] for w_ in want} >= {0, aclgpu.ERR_FAILED_PRECONDITION} and 0 < sum(w_[0] == 2 for w_ in want) < len(want)

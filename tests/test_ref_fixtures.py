@@ -30,7 +30,7 @@ def all_cases():
     return {c["name"]: c for c in ref_cases.cases()}
 
 
-CASE_NAMES = ["bootstrap", "shapes", "c1", "c2_s005", "c3_s005", "c4_s002"]
+CASE_NAMES = ["bootstrap", "shapes", "combine", "validation", "c1", "c2_s005", "c3_s005", "c4_s002"]
 
 
 def load_fixture(name, case):
@@ -57,6 +57,12 @@ def compare(fx, case, perms, errs, lookup_sets):
         assert sorted(lookup_sets[i]) == want, (lk, len(lookup_sets[i]), len(want))
 
 
+def compare_requests(fx, case, client):
+    """whole requests whose error behaviour is pinned (ref_cases `requests`): the call's code / the pairs, request by request"""
+    if case.get("requests"):
+        assert ref_cases.replay_requests(client, case["requests"]) == fx["requests"]
+
+
 def test_inputs_are_deterministic(all_cases):
     """The consumer regenerates the inputs the fixtures were made from: they must not drift."""
     again = {c["name"]: c for c in ref_cases.cases()}
@@ -74,6 +80,7 @@ def test_oracle_matches_embedded_spicedb(name, all_cases):
         o.write([(orc.OP_TOUCH, r) for r in rels[i:i + 1000]])
     res = [o.check(*q) for q in case["checks"]]
     compare(fx, case, [r[0] for r in res], [r[1] for r in res], [o.lookup(*lk) for lk in case["lookups"]])
+    compare_requests(fx, case, o)
 
 
 @pytest.mark.gpu
@@ -88,6 +95,7 @@ def test_engine_matches_embedded_spicedb(name, all_cases, aclgpu_lib):
             e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 1000]])
         perms, errs = e.check_bulk(case["checks"])  # the string entry point, as the Go shim calls it
         compare(fx, case, perms, errs, [e.lookup(*lk) for lk in case["lookups"]])
+        compare_requests(fx, case, e)
 
 
 @pytest.mark.gpu
@@ -108,3 +116,5 @@ def test_engine_matches_oracle_on_ref_cases(name, all_cases, aclgpu_lib):
         assert list(zip(perms, errs)) == want
         for lk in case["lookups"]:
             assert e.lookup(*lk) == o.lookup(*lk), lk
+        if case.get("requests"):  # API validation: the call's code / the pairs, request by request (the writes that succeed change both stores)
+            assert ref_cases.replay_requests(e, case["requests"]) == ref_cases.replay_requests(o, case["requests"])

@@ -26,6 +26,8 @@ def main():
         checks = "".join(fmt(q) + "\n" for q in c["checks"])
         open(os.path.join(d, "checks.txt"), "w").write(checks)
         open(os.path.join(d, "lookups.txt"), "w").write("".join(f"{rt}#{p}@{st}:{sid}" + (f"#{srel}" if srel else "") + "\n" for rt, p, st, sid, srel in c["lookups"]))
+        if c.get("requests"):  # whole requests whose error behaviour is pinned: `check t` | `write t` | `bulk t t ...`
+            open(os.path.join(d, "requests.txt"), "w").write("".join(kind + " " + " ".join(fmt(t) for t in ts) + "\n" for kind, ts in c["requests"]))
         print(c["name"], len(c["relationships"]), "relationships,", len(c["checks"]), "checks,", len(c["lookups"]), "lookups, sha256(checks)",
               hashlib.sha256(checks.encode()).hexdigest()[:16])
 
