@@ -696,7 +696,8 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     import torch
     rt, perm_name, st = w.check
     n = int(w.res.size)
-    NB = 8  # distinct pre-generated batches: rotations of the request stream (same mix, different items in every lane)
+    nrep = max(1, len(getattr(args, "replica_devices", []) or []))  # in-process replicas (--devices): callers and batches per step scale with them
+    NB = max(8, args.callers * nrep + 2)  # distinct pre-generated batches: rotations of the request stream (same mix, different items in every lane)
     items0 = eng.make_items(rt, perm_name, w.res, st, "", w.subj)
     rec = {"workload": WORKLOAD_DESC[label], "batch": n, "relationships": w.ntuples, "objects": int(sum(w.nobjects.values()))}
 
@@ -772,7 +773,8 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     for b in range(NB):
         h_items[b] = np.roll(items0, b * 4099)
     window = max(1, min(args.window, NB))
-    callers = max(1, args.callers)
+    callers = max(1, args.callers) * nrep
+    steps_all = steps * nrep  # a step = one batch per replica
 
     def submit_wait(k_steps):  # acl_check_bulk_ids_submit / acl_ticket_wait: `window` batches in flight from ONE host thread
         q = []
@@ -822,8 +824,8 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     # warm-up long enough to reach the steady state of the mode: the HIP runtime sets up its copy paths lazily -- the first time a 2nd, then a
     # 3rd host<->device copy is in flight at once, hipMemcpyAsync blocks ~7 ms (profiles/r03_submit_window_trace.txt); a `window`-ticket
     # warm-up left the second of them for the timed region (the "630 M/s at windows 3-4" of earlier runs was that one stall averaged over 40 steps)
-    pipelined(max(warmup, 3 * window, 3 * callers, 12))()
-    fire = pipelined(steps)
+    pipelined(max(warmup * nrep, 3 * window, 3 * callers, 12))()
+    fire = pipelined(steps_all)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -834,9 +836,19 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         dist.barrier()
     elapsed = time.perf_counter() - t0
     host_ok = bool(np.array_equal(h_perm[0], gpu_perm) and np.array_equal(h_err[0], gpu_err))
-    rec["value"] = n * steps / elapsed
+    rec["value"] = n * steps_all / elapsed
     rec["elapsed"] = elapsed
-    rec["host_ids"] = {"decisions_per_s": n * steps / elapsed, "ms_per_batch": 1e3 * elapsed / steps, "distinct_batches": NB, "answers_equal_device_leg": host_ok,
+    # the same leg over >= 200 steps (the driver's 20-step region is 5.6 ms): reported beside the K-step figure, never as `value`
+    long_steps = max(200, steps) * nrep
+    fire_long = pipelined(long_steps)
+    torch.cuda.synchronize()
+    tl = time.perf_counter()
+    fire_long()
+    torch.cuda.synchronize()
+    el_long = time.perf_counter() - tl
+    rec["host_ids"] = {"decisions_per_s": n * steps_all / elapsed, "ms_per_batch": 1e3 * elapsed / steps_all, "distinct_batches": NB, "answers_equal_device_leg": host_ok,
+                       "long_run": {"steps": long_steps // nrep, "decisions_per_s": n * long_steps / el_long, "ms_per_step": 1e3 * el_long / (long_steps // nrep)},
+                       "replicas_in_process": nrep, "replica_calls": eng.replica_calls(),
                        "mode": (f"acl_check_bulk_ids_submit/wait, {window} in flight" if args.pipeline == "submit" else f"{callers} caller thread(s) in blocking acl_check_bulk_ids"),
                        "note": "pinned host buffers in, pinned host buffers out: the items and the answers cross PCIe inside every call -- read and written by the kernel itself where the single-launch walk takes the batch (no copies), H2D + kernels + D2H otherwise"}
     # ---------------- batch latency: >= 200 single unpipelined host-id calls (SURVEY.md 8(d) "p50 over >= 200 batches after 20 warm-ups")
@@ -1129,6 +1141,10 @@ def main():
     ap.add_argument("--native-loop", default="on", choices=["on", "off"], help="sharded leg: also time the level loop inside libaclgpu.so (acl_shard_check_bulk)")
     ap.add_argument("--pipeline", default="blocking", choices=["blocking", "submit"], help="how the timed host-id leg keeps batches in flight")
     ap.add_argument("--callers", type=int, default=3, help="--pipeline blocking: host threads issuing blocking acl_check_bulk_ids calls (default 3 = the batches the engine admits at once: its chain lanes; Python threads, so a native caller needs fewer)")
+    ap.add_argument("--devices", default="", help="ONE process in front of several GPUs: comma-separated HIP ordinals of the engine's in-process replicas "
+                    "(acl_open_replicas: one relationship store, one HBM snapshot per entry; an ordinal may repeat: logical replicas on one GPU).  A step is then one "
+                    "batch PER replica, `--callers` is per replica.")
+    ap.add_argument("--one-process", action="store_true", help="with --gpus N: do not launch N ranks; one process with the replicas 0..N-1 (= --devices 0,...,N-1)")
     ap.add_argument("--window", type=int, default=2, help="--pipeline submit: batches in flight (<= the engine's evaluation contexts)")
     ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"], help="also measure C2 and C3 in the same run (auto: at N=1 with the default workload)")
     ap.add_argument("--sharded", default="auto", choices=["auto", "on", "off"],
@@ -1142,6 +1158,13 @@ def main():
     args = ap.parse_args()
 
     under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    args.replica_devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+    if args.one_process and not args.replica_devices:
+        args.replica_devices = list(range(args.gpus or 1))
+    if args.replica_devices:
+        if under_launcher:
+            raise SystemExit("bench.py: --devices / --one-process is the ONE-process mode; do not start it under a launcher")
+        args.gpus = None  # (n_gpus of the line = distinct devices of the replica set)
     if not under_launcher and (args.gpus or 1) > 1:
         return launch_ranks(args.gpus, args.dry_spawn)  # this process is the launcher: the ranks print, it forwards their exit code
 
@@ -1219,7 +1242,7 @@ def main():
     if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
     label = "C5R" if args.workload == "C5" else args.workload
-    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
+    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1, devices=args.replica_devices or None)
     t0 = time.time()
     if args.legs == "all" and rank == 0 and args.workload != "C3" and args.strings != "off":
         name_objects(eng, w)  # (before the load: ids follow interning order)
@@ -1259,15 +1282,17 @@ def main():
 
     out = None
     if rank == 0:
-        total = n * args.steps * world
+        nrep = max(1, len(args.replica_devices))  # one process, in-process replicas (--devices): a step is one batch per replica
+        total = n * args.steps * world * nrep
         rec.pop("value")
         out = {
-            "metric": "check_decisions_per_sec", "value": total / elapsed, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "metric": "check_decisions_per_sec", "value": total / elapsed, "unit": "decisions/s", "n_gpus": len(set(args.replica_devices)) if args.replica_devices else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec.pop("workload"), "batch_per_gpu": rec.pop("batch"), "relationships": rec.pop("relationships"),
-                       "objects": rec.pop("objects"), "scale": args.scale, "parallelism": f"replicas x{world} (request-level data parallel)", "numa_node_of_rank0": numa_node,
-                       "timed": "host-id ABI calls (host buffers in, host buffers out: PCIe both ways inside the call) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers} blocking caller thread(s)") if args.legs == "all"
+                       "objects": rec.pop("objects"), "scale": args.scale, "parallelism": (f"ONE process, {nrep} in-process replica(s) on device(s) {args.replica_devices}: one relationship store, one HBM snapshot per replica (acl_open_replicas)"
+                                                                      if args.replica_devices else f"replicas x{world} (request-level data parallel)"), "numa_node_of_rank0": numa_node,
+                       "timed": "host-id ABI calls (host buffers in, host buffers out: PCIe both ways inside the call) over 8 distinct pinned batches, " + (f"submit/wait window {args.window}" if args.pipeline == "submit" else f"{args.callers * nrep} blocking caller thread(s)") if args.legs == "all"
                                 else "device-resident calls only (--legs device)"},
             "p50_batch_ms": rec.get("latency", {}).get("p50_batch_ms", rec["device_resident"]["p50_batch_ms"]),
             "setup_s": {"generate": round(t_gen, 2), "name_objects": round(t_names, 2), "load+snapshot": round(t_load, 2)},

@@ -79,6 +79,16 @@ typedef struct {
 
 /* replaces spicedb.NewServer (pkg/spicedb/spicedb.go:18-71): builds the engine. */
 int acl_open(const acl_config_t *cfg, acl_engine_t **out);
+/* ONE engine in front of several GPUs of this process: one relationship store, one set of name tables, one HBM snapshot PER DEVICE of
+ * `devices` (HIP ordinals; a device may be listed more than once: logical replicas).  Every snapshot update reaches every replica before the
+ * write / read that caused it returns, evaluations are spread over the replicas, so the handle behaves as the reference's single
+ * PermissionsClient does (pkg/proxy/options.go:371-377; the dual-write worker shares it, pkg/proxy/server.go:136-153): read-your-writes for
+ * the whole process.  Entry points that take DEVICE pointers run on the replica of the pointers' device.  acl_open honours
+ * ACL_DEVICES="0,1,2,3" the same way.  The acl_shard_* entry points use the first replica only. */
+int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t n_devices, acl_engine_t **out);
+/* returns the number of replicas; fills (up to cap) how many evaluations each has been handed since open and its HIP ordinal.  The handle
+ * still is the reference's ONE client (options.go:371-377): this only shows how the calls were spread. */
+int acl_replica_calls(acl_engine_t *h, uint64_t *calls_out, int32_t *devices_out, uint32_t cap);
 /* no other call on the handle may be in flight (a poller blocked in acl_check_completions included: stop it first) */
 void acl_close(acl_engine_t *h);
 const char *acl_last_error(void);

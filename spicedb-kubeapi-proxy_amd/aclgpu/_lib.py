@@ -27,7 +27,7 @@ SYMBOLS = [
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
-    "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response",
+    "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls",
 ]
 
 
@@ -132,6 +132,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     L.acl_open.argtypes = [C.POINTER(Config), C.POINTER(H)]
+    L.acl_open_replicas.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(H)]
+    L.acl_replica_calls.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_uint32]
     L.acl_close.argtypes = [H]
     L.acl_close.restype = None
     L.acl_last_error.restype = C.c_char_p

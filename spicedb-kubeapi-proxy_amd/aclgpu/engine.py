@@ -43,11 +43,17 @@ def _b(s):
 
 class Engine:
     def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
-                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0):
+                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None):
+        """devices: HIP ordinals of the replicas (acl_open_replicas: ONE store and one set of name tables in front of one HBM snapshot per
+        entry; a device may be listed more than once); default one replica on `device`."""
         self._L = _lib.load()
         cfg = Config(device, frontier_entries, max_sub_batch, 1 if store_only else 0, contexts, 0)
         h = C.c_void_p()
-        rc = self._L.acl_open(C.byref(cfg), C.byref(h))
+        if devices:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self._L.acl_open_replicas(C.byref(cfg), arr, len(devices), C.byref(h))
+        else:
+            rc = self._L.acl_open(C.byref(cfg), C.byref(h))
         self._h = h if rc == 0 else None
         self._check(rc)
         if schema is not None:
@@ -544,6 +550,12 @@ class Engine:
         a = C.c_int(1)
         self._check(self._L.acl_selfcheck_compaction(self._h, int(phase), C.byref(a)))
         return bool(a.value)
+
+    def replica_calls(self):
+        """[(HIP device ordinal, evaluations handed to that replica since open)]"""
+        calls, devs = (C.c_uint64 * 64)(), (C.c_int32 * 64)()
+        n = self._L.acl_replica_calls(self._h, calls, devs, 64)
+        return [(int(devs[i]), int(calls[i])) for i in range(n)]
 
     # ---- measurement
     def stats(self) -> dict:

@@ -37,7 +37,7 @@ PassCtx::~PassCtx() {
 
 int alloc_frontier(acl_engine *h, PassCtx *c, uint64_t entries) {
     // every wave of an expand launch owns one static chunk; at least one dynamic chunk on top
-    entries = std::max<uint64_t>(entries, ((uint64_t)h->grid_blocks * kWavesPerBlock + 1) * kChunk);
+    entries = std::max<uint64_t>(entries, ((uint64_t)c->dev->grid_blocks * kWavesPerBlock + 1) * kChunk);
     uint64_t chunks = (entries + kChunk - 1) / kChunk;
     if (chunks > kMaxFrontierChunks) chunks = kMaxFrontierChunks;  // byte offsets of entries stay below 2^32 (kernels.hip gld / gst)
     for (int i = 0; i < 2; i++) {
@@ -51,15 +51,17 @@ int alloc_frontier(acl_engine *h, PassCtx *c, uint64_t entries) {
     return ACL_OK;
 }
 
-int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index) {
+int new_ctx(acl_engine *h, DevState *d, std::unique_ptr<PassCtx> *out, int index) {
+    HIP_TRY(hipSetDevice(d->device));
     auto c = std::make_unique<PassCtx>();
     c->index = index;
+    c->dev = d;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->chain_ev, hipEventDisableTiming));
     HIP_TRY(c->d_status.ensure(kStatusWords));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
     int rc = alloc_frontier(h, c.get(),
-                            h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(32u << 20, (uint64_t)2 * h->grid_blocks * kWavesPerBlock * kChunk));  // 2 x 512 MiB: the single-launch walk carves its blocks' private regions out of these
+                            h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(32u << 20, (uint64_t)2 * d->grid_blocks * kWavesPerBlock * kChunk));  // 2 x 512 MiB: the single-launch walk carves its blocks' private regions out of these
     if (rc) return rc;
     *out = std::move(c);
     return ACL_OK;
@@ -117,10 +119,10 @@ void merge_stats(acl_engine *h, PassCtx *c) {
 }
 
 bool snapshot_current(acl_engine *h, bool need_reverse) {
-    if (!h->snap_valid || !h->dev_valid || h->snap.revision != h->store.revision()) return false;
+    if (!h->snap_valid || !h->all_dev_valid() || h->snap.revision != h->store.revision()) return false;
     const int64_t now = h->store.now();
     if (now < h->snap.valid_lo || now >= h->snap.valid_hi) return false;
-    return !need_reverse || h->rev_uploaded;
+    return !need_reverse || h->all_rev_uploaded();
 }
 
 // Uploads the regions a patch touched.  A region is one hipMemcpyAsync (a few microseconds of API time each): past a few
@@ -189,28 +191,36 @@ static void compaction_start(acl_engine *h) {
     if (c->state.load() == 1 || c->state.load() == 2) return;
     if (getenv("ACL_DEBUG_REBUILD")) fprintf(stderr, "[aclgpu] background build starts at revision %llu (previous state %d)\n", (unsigned long long)h->store.revision(), c->state.load());
     if (c->worker.joinable()) c->worker.join();
-    if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
+    // one set of fresh arrays + an upload stream per replica (created on that replica's device)
+    while (c->per.size() < h->devs.size()) c->per.push_back(std::make_unique<Compaction::PerDevice>());
+    for (size_t i = 0; i < h->devs.size(); i++) {
+        Compaction::PerDevice &pd = *c->per[i];
+        pd.device = h->devs[i]->device;
+        if (!pd.stream && (hipSetDevice(pd.device) != hipSuccess || hipStreamCreateWithFlags(&pd.stream, hipStreamNonBlocking) != hipSuccess)) return;
+    }
     auto view = std::make_shared<Store>(h->store.view());  // tables shared copy-on-write: O(#tables), not O(#relationships)
     c->shard = h->shard;
-    c->with_reverse = h->rev_uploaded;
+    c->with_reverse = h->all_rev_uploaded();
     c->now = h->store.now();
     c->error.clear();
     c->state.store(1);
-    const int device = h->device;
-    c->worker = std::thread([c, view, device] {
-        auto up = [&](auto &dev, const auto &host) { return dev.upload(host, c->stream) == hipSuccess; };
-        bool ok = hipSetDevice(device) == hipSuccess;
-        if (ok) {
-            build_forward(*view, c->now, &c->snap, c->shard);
-            if (c->with_reverse) build_reverse(*view, c->now, &c->snap, c->shard);
-            const Snapshot &s = c->snap;
-            ok = std::max({s.meta.size(), s.edges.size(), s.buckets.size()}) < ((size_t)1 << 30) && up(c->d_meta, s.meta) && up(c->d_edges, s.edges) &&
-                 up(c->d_buckets, s.buckets) && up(c->d_ops, s.ops) && up(c->d_progs, s.progs) && up(c->d_bexpr, s.bexpr) && up(c->d_tsb, s.type_slot_base) && up(c->d_tnm, s.type_nmembers);
+    const size_t ndev = h->devs.size();
+    c->worker = std::thread([c, view, ndev] {
+        // ONE host build, uploaded to every replica
+        build_forward(*view, c->now, &c->snap, c->shard);
+        if (c->with_reverse) build_reverse(*view, c->now, &c->snap, c->shard);
+        const Snapshot &s = c->snap;
+        bool ok = std::max({s.meta.size(), s.edges.size(), s.buckets.size()}) < ((size_t)1 << 30);
+        for (size_t i = 0; ok && i < ndev; i++) {
+            Compaction::PerDevice &pd = *c->per[i];
+            auto up = [&](auto &dev, const auto &host) { return dev.upload(host, pd.stream) == hipSuccess; };
+            ok = hipSetDevice(pd.device) == hipSuccess && up(pd.d_meta, s.meta) && up(pd.d_edges, s.edges) && up(pd.d_buckets, s.buckets) && up(pd.d_ops, s.ops) &&
+                 up(pd.d_progs, s.progs) && up(pd.d_bexpr, s.bexpr) && up(pd.d_tsb, s.type_slot_base) && up(pd.d_tnm, s.type_nmembers);
             if (ok && c->with_reverse)
-                ok = up(c->d_rmeta, s.rmeta) && up(c->d_redges, s.redges) && up(c->d_rops, s.rops) && up(c->d_rprogs, s.rprogs) && up(c->d_rseeds, s.rseeds) &&
-                     up(c->d_sbb, s.slot_bit_base) && up(c->d_snobj, s.slot_nobjects);
-            ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+                ok = up(pd.d_rmeta, s.rmeta) && up(pd.d_redges, s.redges) && up(pd.d_rops, s.rops) && up(pd.d_rprogs, s.rprogs) && up(pd.d_rseeds, s.rseeds) &&
+                     up(pd.d_sbb, s.slot_bit_base) && up(pd.d_snobj, s.slot_nobjects);
         }
+        for (size_t i = 0; ok && i < ndev; i++) ok = hipSetDevice(c->per[i]->device) == hipSuccess && hipStreamSynchronize(c->per[i]->stream) == hipSuccess;
         c->state.store(ok ? 2 : 3);
     });
 }
@@ -221,7 +231,14 @@ void compaction_join(acl_engine *h) {
     h->compaction->state.store(0);
 }
 
-// A finished build: bring it from the view's revision to the store's with the ordinary patcher, then swap it in.
+static void refresh_local_blocks(acl_engine *h) {  // (the single-launch kernel's LDS depends on the schema)
+    for (auto &d : h->devs) {
+        d->local_blocks = local_grid_blocks(d->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
+        d->local_blocks_wide = local_grid_blocks(d->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
+    }
+}
+
+// A finished build: bring it from the view's revision to the store's with the ordinary patcher, then swap it in on every replica.
 // Returns true when the engine's snapshot is now the compacted one (and current).
 static bool compaction_adopt(acl_engine *h, int64_t now) {
     Compaction *c = h->compaction.get();
@@ -234,43 +251,49 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     }
     c->state.store(0);
     if (c->worker.joinable()) c->worker.join();
-    if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world) return false;
+    if (c->shard.rank != h->shard.rank || c->shard.world != h->shard.world || c->per.size() < h->devs.size()) return false;
     std::vector<Patch> patches;
     const uint64_t from = c->snap.revision;
     if (getenv("ACL_DEBUG_REBUILD")) fprintf(stderr, "[aclgpu] adopting the background build of revision %llu at revision %llu\n", (unsigned long long)from, (unsigned long long)h->store.revision());
     if (!patch_forward(h->store, now, &c->snap, h->shard, &patches, (size_t)1 << 19)) return false;  // (a bulk load meanwhile: the synchronous path decides)
     bool rev_ok = c->with_reverse && patch_reverse(h->store, now, from, &c->snap, h->shard, &patches);
-    hipStream_t s = h->up_stream;
-    bool fits = true;
-    const hipError_t pe = upload_patches(c->snap, patches, SnapArrays{&c->d_meta, &c->d_edges, &c->d_buckets, &c->d_rmeta, &c->d_redges, &c->d_ops}, rev_ok, s, &fits);
-    if (pe != hipSuccess || !fits || hipStreamSynchronize(s) != hipSuccess) return false;
+    for (size_t i = 0; i < h->devs.size(); i++) {  // the catch-up patch reaches every replica's fresh arrays before any of them is swapped in
+        Compaction::PerDevice &pd = *c->per[i];
+        bool fits = true;
+        if (hipSetDevice(pd.device) != hipSuccess) return false;
+        const hipError_t pe = upload_patches(c->snap, patches, SnapArrays{&pd.d_meta, &pd.d_edges, &pd.d_buckets, &pd.d_rmeta, &pd.d_redges, &pd.d_ops}, rev_ok, h->devs[i]->up_stream, &fits);
+        if (pe != hipSuccess || !fits || hipStreamSynchronize(h->devs[i]->up_stream) != hipSuccess) return false;
+    }
     // swap: the old arrays go to the compaction object and are freed (or reused) by its next run
-    h->dev_valid = false;
+    h->set_dev_valid(false);
     h->snap = std::move(c->snap);
     c->snap = Snapshot();
-    h->d_meta.swap(c->d_meta);
-    h->d_edges.swap(c->d_edges);
-    h->d_buckets.swap(c->d_buckets);
-    h->d_ops.swap(c->d_ops);
-    h->d_progs.swap(c->d_progs);
-    h->d_bexpr.swap(c->d_bexpr);
-    h->d_tsb.swap(c->d_tsb);
-    h->d_tnm.swap(c->d_tnm);
-    if (rev_ok) {
-        h->d_rmeta.swap(c->d_rmeta);
-        h->d_redges.swap(c->d_redges);
-        h->d_rops.swap(c->d_rops);
-        h->d_rprogs.swap(c->d_rprogs);
-        h->d_rseeds.swap(c->d_rseeds);
-        h->d_sbb.swap(c->d_sbb);
-        h->d_snobj.swap(c->d_snobj);
+    for (size_t i = 0; i < h->devs.size(); i++) {
+        DevState &d = *h->devs[i];
+        Compaction::PerDevice &pd = *c->per[i];
+        d.d_meta.swap(pd.d_meta);
+        d.d_edges.swap(pd.d_edges);
+        d.d_buckets.swap(pd.d_buckets);
+        d.d_ops.swap(pd.d_ops);
+        d.d_progs.swap(pd.d_progs);
+        d.d_bexpr.swap(pd.d_bexpr);
+        d.d_tsb.swap(pd.d_tsb);
+        d.d_tnm.swap(pd.d_tnm);
+        if (rev_ok) {
+            d.d_rmeta.swap(pd.d_rmeta);
+            d.d_redges.swap(pd.d_redges);
+            d.d_rops.swap(pd.d_rops);
+            d.d_rprogs.swap(pd.d_rprogs);
+            d.d_rseeds.swap(pd.d_rseeds);
+            d.d_sbb.swap(pd.d_sbb);
+            d.d_snobj.swap(pd.d_snobj);
+        }
+        d.rev_uploaded = rev_ok;
+        d.dev_valid = true;
     }
-    h->rev_uploaded = rev_ok;
     if (!rev_ok) h->snap.has_reverse = false;
     h->snap_valid = true;
-    h->dev_valid = true;
-    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
-    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
+    refresh_local_blocks(h);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_compactions++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -280,7 +303,9 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
     return true;
 }
 
-// caller holds state_mu EXCLUSIVE: no evaluation is reading the device arrays
+// caller holds state_mu EXCLUSIVE: no evaluation is reading the device arrays of ANY replica.  Whatever changes the snapshot here reaches
+// every replica before the function returns (DevState): an evaluation that starts afterwards answers for the store as it is now, whichever
+// device it lands on -- the reference's one client is read-your-writes for the whole process (check.go:41-46, activity.go:60-77).
 int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
@@ -288,39 +313,46 @@ int ensure_snapshot(acl_engine *h) {
     if (h->shard.world > 1 && h->store.schema().has_combine)
         return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated on a sharded graph: a state's operands may live on different shards (use replicas)");
     const int64_t now = h->store.now();
-    hipStream_t s = h->up_stream;
-    if (h->snap_valid && h->dev_valid && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
+    if (h->snap_valid && h->all_dev_valid() && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships
     // (... or an expiration passed: the relationships that ran out are part of the patcher's feed)
-    if (h->snap_valid && h->dev_valid &&
+    if (h->snap_valid && h->all_dev_valid() &&
         h->snap.garbage_words * 4 < (h->snap.edges.size() + h->snap.buckets.size()) + 65536) {
         std::vector<Patch> patches;
         const uint64_t from_revision = h->snap.revision;
         if (patch_forward(h->store, now, &h->snap, h->shard, &patches)) {
-            h->dev_valid = false;  // until every region below has reached the device
-            // the reverse rows (LookupResources), if they are on the device, follow the same feed
-            bool rev_ok = h->rev_uploaded && patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches);
-            const bool had_rev = h->rev_uploaded;
-            h->rev_uploaded = false;
-            bool fits = true;
-            const hipError_t pe = upload_patches(h->snap, patches, SnapArrays{&h->d_meta, &h->d_edges, &h->d_buckets, &h->d_rmeta, &h->d_redges, &h->d_ops}, rev_ok, s, &fits);
-            if (pe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("snapshot patch upload: ") + hipGetErrorString(pe));
+            // the reverse rows (LookupResources), if they are on the devices, follow the same feed
+            const bool had_rev = h->all_rev_uploaded();
+            bool rev_ok = had_rev && patch_reverse(h->store, now, from_revision, &h->snap, h->shard, &patches);
+            h->set_dev_valid(false);  // until every region below has reached every device
+            h->set_rev_uploaded(false);
             if (std::max({h->snap.meta.size(), h->snap.edges.size(), h->snap.buckets.size()}) >= ((size_t)1 << 30))
                 return fail(ACL_ERR_RESOURCE_EXHAUSTED, "snapshot array beyond 4 GiB (more than ~1 G relationships in one array): shard the graph (acl_shard_configure)");
-            if (!fits) {  // an array outgrew its device allocation: the host copy is already exact, upload it whole
-                HIP_TRY(h->d_meta.upload(h->snap.meta, s));
-                HIP_TRY(h->d_edges.upload(h->snap.edges, s));
-                HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
-                HIP_TRY(h->d_ops.upload(h->snap.ops, s));
-                if (rev_ok) {
-                    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, s));
-                    HIP_TRY(h->d_redges.upload(h->snap.redges, s));
+            for (auto &dp : h->devs) {
+                DevState &d = *dp;
+                hipStream_t s = d.up_stream;
+                HIP_TRY(hipSetDevice(d.device));
+                bool fits = true;
+                const hipError_t pe = upload_patches(h->snap, patches, SnapArrays{&d.d_meta, &d.d_edges, &d.d_buckets, &d.d_rmeta, &d.d_redges, &d.d_ops}, rev_ok, s, &fits);
+                if (pe != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("snapshot patch upload: ") + hipGetErrorString(pe));
+                if (!fits) {  // an array outgrew its device allocation: the host copy is already exact, upload it whole
+                    HIP_TRY(d.d_meta.upload(h->snap.meta, s));
+                    HIP_TRY(d.d_edges.upload(h->snap.edges, s));
+                    HIP_TRY(d.d_buckets.upload(h->snap.buckets, s));
+                    HIP_TRY(d.d_ops.upload(h->snap.ops, s));
+                    if (rev_ok) {
+                        HIP_TRY(d.d_rmeta.upload(h->snap.rmeta, s));
+                        HIP_TRY(d.d_redges.upload(h->snap.redges, s));
+                    }
                 }
             }
-            HIP_TRY(hipStreamSynchronize(s));
-            h->dev_valid = true;
-            h->rev_uploaded = had_rev && rev_ok;
-            if (!h->rev_uploaded) h->snap.has_reverse = false;  // not patchable (or never built): rebuilt lazily by the next lookup
+            for (auto &dp : h->devs) {  // (the replicas' uploads overlap; one wait each)
+                HIP_TRY(hipSetDevice(dp->device));
+                HIP_TRY(hipStreamSynchronize(dp->up_stream));
+                dp->dev_valid = true;
+                dp->rev_uploaded = had_rev && rev_ok;
+            }
+            if (!(had_rev && rev_ok)) h->snap.has_reverse = false;  // not patchable (or never built): rebuilt lazily by the next lookup
             {
                 std::lock_guard<std::mutex> lk(h->stats_mu);
                 h->stats.snapshot_patches++;
@@ -333,29 +365,36 @@ int ensure_snapshot(acl_engine *h) {
     }
     if (getenv("ACL_DEBUG_REBUILD"))
         fprintf(stderr, "[aclgpu] synchronous rebuild: snap_valid=%d dev_valid=%d window=[%lld,%lld) now=%lld garbage=%llu of %zu store_rev=%llu snap_rev=%llu\n",
-                (int)h->snap_valid, (int)h->dev_valid, (long long)h->snap.valid_lo, (long long)h->snap.valid_hi, (long long)now,
+                (int)h->snap_valid, (int)h->all_dev_valid(), (long long)h->snap.valid_lo, (long long)h->snap.valid_hi, (long long)now,
                 (unsigned long long)h->snap.garbage_words, h->snap.edges.size() + h->snap.buckets.size(), (unsigned long long)h->store.revision(),
                 (unsigned long long)h->snap.revision);
     h->snap_valid = false;
-    h->dev_valid = false;
-    h->rev_uploaded = false;
+    h->set_dev_valid(false);
+    h->set_rev_uploaded(false);
     build_forward(h->store, now, &h->snap, h->shard);
     h->snap_valid = true;
     // the kernels address every snapshot array as base + 32-bit byte offset (kernels.hip gld): refuse what does not fit
     if (std::max({h->snap.meta.size(), h->snap.edges.size(), h->snap.buckets.size()}) >= ((size_t)1 << 30))
         return fail(ACL_ERR_RESOURCE_EXHAUSTED, "snapshot array beyond 4 GiB (more than ~1 G relationships in one array): shard the graph (acl_shard_configure)");
-    HIP_TRY(h->d_meta.upload(h->snap.meta, s));
-    HIP_TRY(h->d_edges.upload(h->snap.edges, s));
-    HIP_TRY(h->d_buckets.upload(h->snap.buckets, s));
-    HIP_TRY(h->d_ops.upload(h->snap.ops, s));
-    HIP_TRY(h->d_progs.upload(h->snap.progs, s));
-    HIP_TRY(h->d_bexpr.upload(h->snap.bexpr, s));
-    HIP_TRY(h->d_tsb.upload(h->snap.type_slot_base, s));
-    HIP_TRY(h->d_tnm.upload(h->snap.type_nmembers, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    h->dev_valid = true;
-    h->local_blocks = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
-    h->local_blocks_wide = local_grid_blocks(h->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);  // (the single-launch kernel's LDS depends on the schema)
+    for (auto &dp : h->devs) {
+        DevState &d = *dp;
+        hipStream_t s = d.up_stream;
+        HIP_TRY(hipSetDevice(d.device));
+        HIP_TRY(d.d_meta.upload(h->snap.meta, s));
+        HIP_TRY(d.d_edges.upload(h->snap.edges, s));
+        HIP_TRY(d.d_buckets.upload(h->snap.buckets, s));
+        HIP_TRY(d.d_ops.upload(h->snap.ops, s));
+        HIP_TRY(d.d_progs.upload(h->snap.progs, s));
+        HIP_TRY(d.d_bexpr.upload(h->snap.bexpr, s));
+        HIP_TRY(d.d_tsb.upload(h->snap.type_slot_base, s));
+        HIP_TRY(d.d_tnm.upload(h->snap.type_nmembers, s));
+    }
+    for (auto &dp : h->devs) {
+        HIP_TRY(hipSetDevice(dp->device));
+        HIP_TRY(hipStreamSynchronize(dp->up_stream));
+        dp->dev_valid = true;
+    }
+    refresh_local_blocks(h);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
     h->stats.snapshot_edges = h->snap.nedges;
@@ -377,28 +416,45 @@ static bool reverse_covers(acl_engine *h) {
 int ensure_reverse(acl_engine *h) {
     int rc = ensure_snapshot(h);
     if (rc) return rc;
-    if (h->rev_uploaded && reverse_covers(h)) return ACL_OK;
-    hipStream_t s = h->up_stream;
-    h->rev_uploaded = false;
+    if (h->all_rev_uploaded() && reverse_covers(h)) return ACL_OK;
+    h->set_rev_uploaded(false);
     build_reverse(h->store, h->store.now(), &h->snap, h->shard);
-    HIP_TRY(h->d_rmeta.upload(h->snap.rmeta, s));
-    HIP_TRY(h->d_redges.upload(h->snap.redges, s));
-    HIP_TRY(h->d_rops.upload(h->snap.rops, s));
-    HIP_TRY(h->d_rprogs.upload(h->snap.rprogs, s));
-    HIP_TRY(h->d_rseeds.upload(h->snap.rseeds, s));
-    HIP_TRY(h->d_sbb.upload(h->snap.slot_bit_base, s));
-    HIP_TRY(h->d_snobj.upload(h->snap.slot_nobjects, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    h->rev_uploaded = true;
+    for (auto &dp : h->devs) {
+        DevState &d = *dp;
+        hipStream_t s = d.up_stream;
+        HIP_TRY(hipSetDevice(d.device));
+        HIP_TRY(d.d_rmeta.upload(h->snap.rmeta, s));
+        HIP_TRY(d.d_redges.upload(h->snap.redges, s));
+        HIP_TRY(d.d_rops.upload(h->snap.rops, s));
+        HIP_TRY(d.d_rprogs.upload(h->snap.rprogs, s));
+        HIP_TRY(d.d_rseeds.upload(h->snap.rseeds, s));
+        HIP_TRY(d.d_sbb.upload(h->snap.slot_bit_base, s));
+        HIP_TRY(d.d_snobj.upload(h->snap.slot_nobjects, s));
+    }
+    for (auto &dp : h->devs) {
+        HIP_TRY(hipSetDevice(dp->device));
+        HIP_TRY(hipStreamSynchronize(dp->up_stream));
+        dp->rev_uploaded = true;
+    }
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_bytes += h->snap.rmeta.size() * 4 + h->snap.redges.size() * 4;
     return ACL_OK;
 }
 
-int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, bool chain_lane) {
+// device ordinal a device pointer lives on (-1: one replica, or not a device pointer: any replica will do)
+int device_of(acl_engine *h, const void *p) {
+    if (h->devs.size() < 2 || !p) return -1;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return a.device;
+}
+
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, bool chain_lane, int on_device) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
-    HIP_TRY(hipSetDevice(h->device));
     int rc = check_opts(opts);
     if (rc) return rc;
     for (;;) {
@@ -433,33 +489,59 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
     const uint32_t lanes = std::min<uint32_t>(kChainLanes, h->max_ctx);
     std::unique_lock<std::mutex> lk(h->pool_mu);
     for (;;) {
-        int pick = -1;
-        for (int i = 0; i < (int)h->free_ctxs.size(); i++) {
-            const int idx = h->free_ctxs[i]->index;
-            if (chain_lane ? (idx < (int)lanes && (pick < 0 || idx < h->free_ctxs[pick]->index))
-                           : (pick < 0 || (idx >= (int)lanes) > (h->free_ctxs[pick]->index >= (int)lanes) ||
-                              ((idx >= (int)lanes) == (h->free_ctxs[pick]->index >= (int)lanes) && idx > h->free_ctxs[pick]->index)))
-                pick = i;
+        // Replicas (engines opened on several devices): the least loaded one that can serve the call -- ties go round the devices, so N
+        // blocking callers end up on N devices.  Within a replica: the lane / non-lane preference described above.
+        DevState *bd = nullptr;
+        int bpick = -1;
+        bool bcreate = false;
+        const size_t nd = h->devs.size(), d0 = nd > 1 ? h->next_dev++ % nd : 0;
+        for (size_t k = 0; k < nd; k++) {
+            DevState *d = h->devs[(d0 + k) % nd].get();
+            if (on_device >= 0 && d->device != on_device) continue;
+            int pick = -1;
+            for (int i = 0; i < (int)d->free_ctxs.size(); i++) {
+                const int idx = d->free_ctxs[i]->index;
+                if (chain_lane ? (idx < (int)lanes && (pick < 0 || idx < d->free_ctxs[pick]->index))
+                               : (pick < 0 || (idx >= (int)lanes) > (d->free_ctxs[pick]->index >= (int)lanes) ||
+                                  ((idx >= (int)lanes) == (d->free_ctxs[pick]->index >= (int)lanes) && idx > d->free_ctxs[pick]->index)))
+                    pick = i;
+            }
+            const bool may_create = d->ctxs.size() < (chain_lane ? lanes : h->max_ctx);
+            // (a free lane is the last resort of a call that is not chained: a new context first)
+            const bool take = pick >= 0 && (chain_lane || d->free_ctxs[pick]->index >= (int)lanes || !may_create);
+            if (!take && !may_create) continue;
+            if (!bd || d->in_use < bd->in_use) {
+                bd = d;
+                bpick = take ? pick : -1;
+                bcreate = !take;
+            }
         }
-        const bool may_create = h->ctxs.size() < (chain_lane ? lanes : h->max_ctx);
-        // (a free lane is the last resort of a call that is not chained: a new context first)
-        if (pick >= 0 && (chain_lane || h->free_ctxs[pick]->index >= (int)lanes || !may_create)) {
-            c = h->free_ctxs[pick];
-            h->free_ctxs.erase(h->free_ctxs.begin() + pick);
+        if (bd && !bcreate) {
+            c = bd->free_ctxs[bpick];
+            bd->free_ctxs.erase(bd->free_ctxs.begin() + bpick);
+            bd->in_use++;
+            bd->calls++;
             break;
         }
-        if (may_create) {
+        if (bd) {
             std::unique_ptr<PassCtx> nc;
-            rc = new_ctx(h, &nc, (int)h->ctxs.size());
+            rc = new_ctx(h, bd, &nc, (int)bd->ctxs.size());
             if (rc) return rc;
             c = nc.get();
-            h->ctxs.push_back(std::move(nc));
+            bd->ctxs.push_back(std::move(nc));
+            bd->in_use++;
+            bd->calls++;
             break;
         }
         if (try_only) {
             lk.unlock();
             end();  // gives the shared lock back
             return kNoContextFree;
+        }
+        if (on_device >= 0) {
+            bool any = false;
+            for (auto &d : h->devs) any = any || d->device == on_device;
+            if (!any) return fail(ACL_ERR_INVALID_ARGUMENT, "the device buffers live on a device this engine holds no replica on");
         }
         if (opts.cancel || opts.deadline_ns) {
             h->pool_cv.wait_for(lk, std::chrono::microseconds(500));
@@ -469,6 +551,9 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
             h->pool_cv.wait(lk);
         }
     }
+    lk.unlock();
+    // everything this call allocates, copies and launches happens on the context's device
+    HIP_TRY(hipSetDevice(c->dev->device));
     c->opts = opts;
     c->timing = h->timing.load(std::memory_order_relaxed);
     return ACL_OK;
@@ -480,7 +565,8 @@ void Eval::end() {
         c->opts = CallOpts();
         {
             std::lock_guard<std::mutex> lk(h->pool_mu);
-            h->free_ctxs.push_back(c);
+            c->dev->free_ctxs.push_back(c);
+            c->dev->in_use--;
         }
         // every waiter: chain_lane callers can only take contexts 0..kChainLanes-1 and ordinary callers prefer the others -- a single wake-up
         // that lands on a waiter who cannot use THIS context is consumed while another waiter sleeps next to a free context
@@ -507,7 +593,7 @@ struct LocalGeom {
 static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     LocalGeom G{};
     G.wide = n >= h->local_wide_min;
-    const uint32_t blocks = (uint32_t)(G.wide ? h->local_blocks_wide : h->local_blocks);  // what is resident at once; a unit is walked by one block (4 or 16 waves)
+    const uint32_t blocks = (uint32_t)(G.wide ? c->dev->local_blocks_wide : c->dev->local_blocks);  // what is resident at once; a unit is walked by one block (4 or 16 waves)
     // latency: while the batch has fewer requests than the chip has blocks, every request gets a block of its own; beyond that
     // every block gets ONE unit of n / blocks requests (`upw` > 1: several smaller ones, a second round of per-level chains)
     G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), local_unit_max(G.wide));
@@ -546,7 +632,7 @@ int combine_prepare(acl_engine *h, PassCtx *c, DevGraph *g, uint32_t n, uint32_t
     HIP_TRY(c->d_nodes.ensure(regions * node_cap));
     HIP_TRY(c->d_has.ensure((size_t)n + regions * cell_cap));
     HIP_TRY(c->d_err.ensure((size_t)n + regions * cell_cap));
-    g->bexpr = h->d_bexpr.p;
+    g->bexpr = c->dev->d_bexpr.p;
     g->nodes = c->d_nodes.p;
     g->node_cap = (uint32_t)node_cap;
     g->cell_cap = (uint32_t)cell_cap;
@@ -599,15 +685,15 @@ int chained_enqueue(acl_engine *h, PassCtx *c, size_t n, bool asked) {
     if (!(chains(h, n) && (asked || walk_allowed(h, n)))) return kChainDeclined;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    std::lock_guard<std::mutex> ck(h->chain_mu);
-    hipError_t he = h->chain_prev ? hipStreamWaitEvent(c->stream, h->chain_prev, 0) : hipSuccess;
+    std::lock_guard<std::mutex> ck(c->dev->chain_mu);  // (per replica: kernels of different devices have nothing to wait for)
+    hipError_t he = c->dev->chain_prev ? hipStreamWaitEvent(c->stream, c->dev->chain_prev, 0) : hipSuccess;
     if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
-    int rc = local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
+    int rc = local_enqueue(h, c, h->dev_graph(c), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
     if (rc == kTakeLevelLoop) return kChainDeclined;
     if (rc) return rc;
     he = hipEventRecord(c->chain_ev, c->stream);
     if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipEventRecord: ") + hipGetErrorString(he));
-    h->chain_prev = c->chain_ev;
+    c->dev->chain_prev = c->chain_ev;
     return ACL_OK;
 }
 // ... and its other half: synchronises the context's stream.  kChainDeclined: a block ran out of private frontier -- redo on the level loop.
@@ -650,7 +736,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     //  way -- the second one's blocks move in as the first one's finish, which fills the tail a lone launch leaves idle: 2 / 4 / 8 / 16 callers
     //  with 262 144-item batches measure 886 / 890 / 914 / 916 M decisions/s, ABOVE the 873 M/s of back-to-back device-resident launches, and a
     //  host mutex around launch + synchronise costs a third of that; profiles/r03_hostmapped_batches.txt.)
-    DevGraph g = h->dev_graph();
+    DevGraph g = h->dev_graph(c);
     if (int rc = combine_prepare(h, c, &g, n, G.nblocks, G.rpw)) return rc;
     ev_begin(c, 2);
     launch_check_local(c->stream, g, (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_flag, c->d_has.p, c->d_err.p,
@@ -672,7 +758,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
 bool hostmap_takes(acl_engine *h, size_t n) {
     if (!(n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && n <= h->hostmap_max)) return false;
     const bool wide = n >= h->local_wide_min;
-    return n <= (uint64_t)(wide ? h->local_blocks_wide : h->local_blocks) * local_unit_max(wide);  // (one unit per resident block)
+    return n <= (uint64_t)(wide ? h->dev0().local_blocks_wide : h->dev0().local_blocks) * local_unit_max(wide);  // (one unit per resident block; replicas are alike)
 }
 
 // A graph whose walks keep outgrowing the blocks' private regions should not pay for a failed walk before every level loop: after an
@@ -752,7 +838,7 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint
 int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local) {
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    DevGraph g = h->dev_graph();
+    DevGraph g = h->dev_graph(c);
     // small batches (the proxy's own call shape: check.go:76-94, watch.go:50): ONE launch runs every level, each wave
     // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
     if (try_local && n <= h->local_max_items && walk_allowed(h, n)) {
@@ -861,9 +947,9 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
         // chip-filling batches of several callers: kernels one at a time (host mutex, held from the launch to the one synchronisation); the
         // next caller's H2D, already enqueued on its own stream, runs meanwhile
-        std::unique_lock<std::mutex> tk(h->compute_mu, std::defer_lock);
+        std::unique_lock<std::mutex> tk(c->dev->compute_mu, std::defer_lock);
         if (n >= kComputeTokenItems) tk.lock();
-        rc = local_enqueue(h, c, h->dev_graph(), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
+        rc = local_enqueue(h, c, h->dev_graph(c), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
         if (!rc) {
             rc = results_d2h();
             if (rc) return rc;
@@ -876,7 +962,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
     if (rc == kTakeLevelLoop) {  // a block ran out of private frontier, or the walk is switched off / backing off: the level loop, one batch at a time
         HIP_TRY(hipStreamSynchronize(c->stream));
         {
-            std::unique_lock<std::mutex> tk(h->compute_mu, std::defer_lock);
+            std::unique_lock<std::mutex> tk(c->dev->compute_mu, std::defer_lock);
             if (n >= kComputeTokenItems) tk.lock();
             rc = check_device(h, c, c->d_items.p, n, c->d_perm.p, c->d_errout.p, !tried);  // (ends with the context's stream synchronised; a batch the walk has not tried -- sub-batched ones -- tries it per pass)
         }
@@ -1414,8 +1500,7 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
         HIP_TRY(c->d_sids.ensure(m));
         HIP_TRY(c->h_in.ensure(m * sizeof(uint32_t)));
         std::memcpy(c->h_in.p, sids + b, m * sizeof(uint32_t));
-        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords,
-                     (uint32_t)h->snap.rprogs.size(), (uint32_t)h->snap.rops.size()};
+        DevReverse r = h->dev_reverse(c, (uint32_t)vwords);
         // ONE launch for the whole group (k_rev_local: a block per lookup walks every reverse level, marks the result bits where they are
         // produced, and writes the result rows + id counts straight into host memory): no per-level launches, no status round trips, no
         // memset, no D2H copies.  A lookup that outgrows its block (private frontier region, children per level) sends the group to the
@@ -1563,13 +1648,14 @@ extern "C" {
 
 const char *acl_last_error(void) { return g_last_error.c_str(); }
 
-int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
+int acl_open(const acl_config_t *cfg, acl_engine_t **out) { return acl_open_replicas(cfg, nullptr, 0, out); }
+
+int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t n_devices, acl_engine_t **out) {
     if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: out is NULL");
     *out = nullptr;
     if (cfg && (cfg->flags & ACL_FLAG_STORE_ONLY)) {
         auto *so = new acl_engine();
         so->store_only = true;
-        so->device = -1;
         if (const char *ev = getenv("ACL_RAW_INTERN")) so->raw_intern = atoi(ev) != 0;  // (test knob, see below)
         batcher_create(so);
         *out = so;
@@ -1579,18 +1665,38 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(ACL_ERR_UNAVAILABLE, "acl_open: no HIP device available (this engine has no CPU evaluation path)");
     auto h = std::make_unique<acl_engine>();
-    int dev = cfg ? cfg->device : -1;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    // the replicas: the device list of acl_open_replicas, else ACL_DEVICES="0,1,2,3" (a device may be named more than once: N logical replicas
+    // on one GPU -- what the one-GPU test boxes exercise), else the one device of the config
+    std::vector<int> list;
+    if (devices && n_devices) list.assign(devices, devices + n_devices);
+    else if (const char *ev = getenv("ACL_DEVICES")) {
+        for (const char *q = ev; *q;) {
+            char *end = nullptr;
+            const long v = std::strtol(q, &end, 10);
+            if (end == q) break;
+            list.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+        }
     }
-    if (dev >= ndev) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: device ordinal out of range");
-    h->device = dev;
-    hipError_t e = hipSetDevice(dev);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
-    h->grid_blocks = expand_grid_blocks(dev);
-    h->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
-    h->local_blocks_wide = local_grid_blocks(dev, 2048, true);
+    if (list.empty()) list.push_back(cfg ? cfg->device : -1);
+    if (list.size() > 64) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: at most 64 replicas");
+    for (size_t i = 0; i < list.size(); i++) {
+        int dev = list[i];
+        if (dev < 0) {
+            if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        }
+        if (dev >= ndev) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_open: device ordinal out of range");
+        auto d = std::make_unique<DevState>();
+        d->device = dev;
+        d->index = (int)i;
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(ACL_ERR_UNAVAILABLE, std::string("acl_open: ") + hipGetErrorString(e));
+        d->grid_blocks = expand_grid_blocks(dev);
+        d->local_blocks = local_grid_blocks(dev, 2048);  // (refined per snapshot: ensure_snapshot)
+        d->local_blocks_wide = local_grid_blocks(dev, 2048, true);
+        h->devs.push_back(std::move(d));
+    }
     if (const char *ev = getenv("ACL_LOCAL_WIDE_MIN")) h->local_wide_min = (uint32_t)std::max(0, atoi(ev));  // A/B knob
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
@@ -1608,12 +1714,15 @@ int acl_open(const acl_config_t *cfg, acl_engine_t **out) {
     if (cfg && cfg->frontier_entries) h->cfg_frontier_entries = cfg->frontier_entries;
     if (cfg && cfg->contexts) h->max_ctx = std::min<uint32_t>(cfg->contexts, 16);
     if (const char *ev = getenv("ACL_LOCAL_MAX")) h->local_max_items = (uint32_t)atoi(ev);  // A/B knob: 0 disables the single-launch path
-    // the first context is created here, so that "out of device memory" surfaces at open
-    std::unique_ptr<PassCtx> c0;
-    int rc = new_ctx(h.get(), &c0, 0);
-    if (rc) return rc;
-    h->free_ctxs.push_back(c0.get());
-    h->ctxs.push_back(std::move(c0));
+    // the first context of every replica is created here, so that "out of device memory" surfaces at open
+    for (auto &d : h->devs) {
+        std::unique_ptr<PassCtx> c0;
+        int rc = new_ctx(h.get(), d.get(), &c0, 0);
+        if (rc) return rc;
+        d->free_ctxs.push_back(c0.get());
+        d->ctxs.push_back(std::move(c0));
+    }
+    (void)hipSetDevice(h->dev0().device);
     batcher_create(h.get());
     *out = h.release();
     return ACL_OK;
@@ -1631,20 +1740,33 @@ void acl_close(acl_engine_t *h) {
         delete h;
         return;
     }
-    (void)hipSetDevice(h->device);
     {
         std::lock_guard<RwLock> lk(h->state_mu);  // waits for evaluations in flight
-        h->ctxs.clear();
+        for (auto &d : h->devs) {
+            (void)hipSetDevice(d->device);
+            d->ctxs.clear();
+        }
+        (void)hipSetDevice(h->dev0().device);
         h->shard_ctx.reset();
-        if (h->compaction && h->compaction->stream) (void)hipStreamDestroy(h->compaction->stream);
+        if (h->compaction)
+            for (auto &pd : h->compaction->per)
+                if (pd->stream) {
+                    (void)hipSetDevice(pd->device);
+                    (void)hipStreamDestroy(pd->stream);
+                }
         h->compaction.reset();
         std::lock_guard<std::mutex> plk(h->pinned_mu);
         for (auto &r : h->pinned) (void)hipHostFree((void *)r.first);
         h->pinned.clear();
     }
-    hipStream_t s = h->up_stream;
-    delete h;
-    if (s) (void)hipStreamDestroy(s);
+    std::vector<std::pair<int, hipStream_t>> ups;
+    for (auto &d : h->devs) ups.emplace_back(d->device, d->up_stream);
+    delete h;  // (frees the replicas' arrays: hipFree takes pointers of any device)
+    for (auto &u : ups)
+        if (u.second) {
+            (void)hipSetDevice(u.first);
+            (void)hipStreamDestroy(u.second);
+        }
 }
 
 int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, const char *rels, size_t rels_len) {
@@ -1655,8 +1777,8 @@ int acl_load_bootstrap(acl_engine_t *h, const char *schema, size_t schema_len, c
     Status s = h->store.load_schema(std::string(schema, schema_len));
     if (!s.ok()) return fail(s);
     h->snap_valid = false;
-    h->dev_valid = false;
-    h->rev_uploaded = false;
+    h->set_dev_valid(false);
+    h->set_rev_uploaded(false);
     if (rels && rels_len) {
         s = h->store.load_relationship_lines(std::string(rels, rels_len));
         if (!s.ok()) return fail(s);
@@ -1773,28 +1895,38 @@ int acl_set_now(acl_engine_t *h, int64_t t) {
 }
 int acl_snapshot(acl_engine_t *h) {
     std::lock_guard<RwLock> lk(h->state_mu);
-    if (h->store_only) return ensure_snapshot(h);
-    HIP_TRY(hipSetDevice(h->device));
-    return ensure_snapshot(h);
+    return ensure_snapshot(h);  // (sets the device of every replica it uploads to)
 }
 
-void *acl_stream(acl_engine_t *h) { return h->ctxs.empty() ? nullptr : (void *)h->ctxs[0]->stream; }
+int acl_replica_calls(acl_engine_t *h, uint64_t *calls_out, int32_t *devices_out, uint32_t cap) {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    for (uint32_t i = 0; i < cap && i < h->devs.size(); i++) {
+        if (calls_out) calls_out[i] = h->devs[i]->calls;
+        if (devices_out) devices_out[i] = h->devs[i]->device;
+    }
+    return (int)h->devs.size();
+}
+
+void *acl_stream(acl_engine_t *h) { return (h->devs.empty() || h->dev0().ctxs.empty()) ? nullptr : (void *)h->dev0().ctxs[0]->stream; }
 int acl_sync(acl_engine_t *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
-    HIP_TRY(hipSetDevice(h->device));
-    std::vector<hipStream_t> ss;
+    std::vector<std::pair<int, hipStream_t>> ss;
     {
         std::lock_guard<std::mutex> lk(h->pool_mu);
-        for (auto &c : h->ctxs) ss.push_back(c->stream);
+        for (auto &d : h->devs)
+            for (auto &c : d->ctxs) ss.emplace_back(d->device, c->stream);
     }
-    for (hipStream_t s : ss) HIP_TRY(hipStreamSynchronize(s));
+    for (auto &s : ss) {
+        HIP_TRY(hipSetDevice(s.first));
+        HIP_TRY(hipStreamSynchronize(s.second));
+    }
     return ACL_OK;
 }
 
 int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out) {
     if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids_device: NULL buffer");
     Eval ev;
-    int rc = ev.begin(h, false);
+    int rc = ev.begin(h, false, CallOpts(), -1, false, false, device_of(h, d_perm_out));  // (a replica on the device the caller's buffers live on)
     if (rc) return rc;
     rc = check_device(h, ev.c, (const uint4 *)d_items, n, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
     if (rc) return rc;

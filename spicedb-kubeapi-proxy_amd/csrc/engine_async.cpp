@@ -131,7 +131,7 @@ int stage_copies(acl_engine_t *h, acl_ticket *t) {
 }
 
 void compute_loop(acl_engine_t *h, AsyncPool *P) {
-    (void)hipSetDevice(h->device);
+    (void)hipSetDevice(h->dev0().device);  // (Eval::begin moves this thread to the device of whatever context it takes)
     std::deque<acl_ticket *> staged;  // context taken, H2D under way
     for (;;) {
         // look ahead: stage queued batches while contexts are free (never waiting for one)
@@ -171,7 +171,7 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
         if (rc == ACL_OK) {
             t->chained = true;
         } else if (rc == kChainDeclined) {
-            std::lock_guard<std::mutex> tk(h->compute_mu);  // (blocking callers with chip-filling batches take turns with the pipeline)
+            std::lock_guard<std::mutex> tk(c->dev->compute_mu);  // (blocking callers with chip-filling batches take turns with the pipeline)
             rc = check_device(h, c, c->d_items.p, t->n, c->d_perm.p, c->d_errout.p);  // (the stream already carries the H2D)
         }
         if (!rc) {
@@ -199,7 +199,7 @@ void compute_loop(acl_engine_t *h, AsyncPool *P) {
 // the context back -- WITHOUT the caller: a ticket nobody waits for no longer pins the engine's state lock (a writer used to starve behind
 // it) or a context, and acl_ticket_wait is a plain wait for the ticket's answer.
 void completer_loop(acl_engine_t *h, AsyncPool *P) {
-    (void)hipSetDevice(h->device);
+    (void)hipSetDevice(h->dev0().device);
     for (;;) {
         acl_ticket *t = nullptr;
         {
@@ -212,13 +212,14 @@ void completer_loop(acl_engine_t *h, AsyncPool *P) {
         PassCtx *c = t->ev.c;
         int rc = ACL_OK;
         hipError_t e = hipSuccess;
+        (void)hipSetDevice(c->dev->device);  // (the batch may have run on any replica)
         g_trace.mark(t->seq, "completer_takes");
         if (t->chained) {
             rc = chained_finish(h, c, t->n);  // synchronises the stream (kernel + result copies)
             g_trace.mark(t->seq, "stream_synchronised");
             if (rc == kChainDeclined) {       // a block ran out of private frontier: the level loop, and the copies once more
                 {
-                    std::lock_guard<std::mutex> tk(h->compute_mu);
+                    std::lock_guard<std::mutex> tk(c->dev->compute_mu);
                     rc = check_device(h, c, c->d_items.p, t->n, c->d_perm.p, c->d_errout.p, false);
                 }
                 if (!rc) {
@@ -330,9 +331,10 @@ int acl_host_alloc(acl_engine_t *h, size_t bytes, void **out) {
     if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_host_alloc: out is NULL");
     *out = nullptr;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU)");
-    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipSetDevice(h->dev0().device));
     void *p = nullptr;
-    HIP_TRY(hipHostMalloc(&p, std::max<size_t>(bytes, 64), hipHostMallocDefault));
+    // (portable + mapped: the kernels of EVERY replica read items from, and write answers to, these buffers across PCIe)
+    HIP_TRY(hipHostMalloc(&p, std::max<size_t>(bytes, 64), h->devs.size() > 1 ? (hipHostMallocPortable | hipHostMallocMapped) : hipHostMallocDefault));
     std::lock_guard<std::mutex> lk(h->pinned_mu);
     h->pinned.emplace_back((uintptr_t)p, std::max<size_t>(bytes, 64));
     *out = p;

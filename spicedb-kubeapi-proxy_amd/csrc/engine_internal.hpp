@@ -40,6 +40,8 @@
 
 using namespace acl;
 
+struct DevState;  // one replica of the HBM snapshot (below)
+
 namespace aclint {
 
 extern thread_local std::string g_last_error;  // engine.cpp
@@ -216,7 +218,8 @@ int check_opts(const CallOpts &o);
 
 // Device state of ONE in-flight evaluation.
 struct PassCtx {
-    int index = 0;
+    int index = 0;           // among the contexts of ITS device
+    DevState *dev = nullptr;  // the replica (device) this context's stream and buffers live on
     hipStream_t stream = nullptr;
     hipEvent_t chain_ev = nullptr;  // recorded behind this context's single-launch kernel (engine::chain_prev)
     // frontier
@@ -273,14 +276,50 @@ struct Compaction {
     ShardSpec shard;
     bool with_reverse = false;
     int64_t now = 0;
-    hipStream_t stream = nullptr;
-    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm, d_rmeta, d_redges, d_sbb, d_snobj;
+    struct PerDevice {  // one fresh set of snapshot arrays per replica, uploaded on a stream of that device
+        int device = 0;
+        hipStream_t stream = nullptr;
+        DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm, d_rmeta, d_redges, d_sbb, d_snobj;
+        DevArray<FwdOp> d_ops;
+        DevArray<SlotProg> d_progs;
+        DevArray<uint32_t> d_bexpr;
+        DevArray<RevOp> d_rops;
+        DevArray<RevProg> d_rprogs, d_rseeds;
+    };
+    std::vector<std::unique_ptr<PerDevice>> per;  // [replica]
+    std::string error;
+};
+
+// One REPLICA of the HBM snapshot: a device, its copy of the snapshot arrays, the evaluation contexts (streams) on it.  An engine opened on
+// several devices (acl_config_t.devices) is ONE relationship store, ONE set of name tables and ONE host snapshot in front of N of these: the
+// reference holds one PermissionsClient per process (pkg/proxy/options.go:371-377) and the dual-write worker shares it (server.go:136-153).
+// Every snapshot update (patch / rebuild / adoption of a background build) reaches EVERY replica under state_mu exclusive before the lock is
+// released, so whichever replica an evaluation lands on answers for the store as it is: read-your-writes holds per process, not per device.
+struct DevState {
+    int device = 0;  // HIP ordinal
+    int index = 0;   // among the engine's replicas
+    bool dev_valid = false, rev_uploaded = false;  // the device arrays hold exactly the host snapshot / its reverse rows
+    hipStream_t up_stream = nullptr;               // snapshot uploads (always under state_mu exclusive)
+    int grid_blocks = 2048;
+    int local_blocks = 1024;       // resident blocks of the single-launch kernel (4 waves per block)
+    int local_blocks_wide = 512;   // ... of its 16-wave instantiation
+    // forward graph
+    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
     DevArray<FwdOp> d_ops;
     DevArray<SlotProg> d_progs;
-    DevArray<uint32_t> d_bexpr;
+    DevArray<uint32_t> d_bexpr;  // boolean programs of the combine slots (schemas with `&` / `-`)
+    // reverse graph
+    DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj;
     DevArray<RevOp> d_rops;
     DevArray<RevProg> d_rprogs, d_rseeds;
-    std::string error;
+    // evaluation contexts of this device (the pool's lock and condition variable are the engine's)
+    std::vector<std::unique_ptr<PassCtx>> ctxs;  // created lazily up to max_ctx
+    std::vector<PassCtx *> free_ctxs;
+    uint32_t in_use = 0;  // contexts handed out (Eval::begin spreads calls over the replicas by it)
+    uint64_t calls = 0;   // evaluations this replica has been handed since open (acl_replica_calls; under pool_mu)
+    std::mutex compute_mu;  // turn-taking of chip-filling batches on the level loop (check_ids_host's fallback, the submit/wait pipeline)
+    std::mutex chain_mu;    // chip-filling single-launch passes follow each other ON THE DEVICE: each waits for the previous one's event
+    hipEvent_t chain_prev = nullptr;  // (a context's chain_ev; contexts live until acl_close)
 };
 
 struct acl_engine {
@@ -292,16 +331,29 @@ struct acl_engine {
     // snap_valid: the HOST snapshot matches `snap.revision`; dev_valid: the device arrays hold exactly the host snapshot.
     // Both are cleared before the snapshot is touched and set again only after every upload succeeded (advice r1: a failed
     // upload used to leave a "valid" snapshot behind).
-    bool snap_valid = false, dev_valid = false, rev_uploaded = false;
-    int device = 0;
+    bool snap_valid = false;
+    std::vector<std::unique_ptr<DevState>> devs;  // the replicas: one per entry of acl_config_t.devices (default: one, on acl_config_t.device)
+    DevState &dev0() { return *devs[0]; }          // (the sharded entry points and the test hooks run on the first replica)
+    bool all_dev_valid() const {
+        for (const auto &d : devs)
+            if (!d->dev_valid) return false;
+        return !devs.empty();
+    }
+    bool all_rev_uploaded() const {
+        for (const auto &d : devs)
+            if (!d->rev_uploaded) return false;
+        return !devs.empty();
+    }
+    void set_dev_valid(bool v) {
+        for (auto &d : devs) d->dev_valid = v;
+    }
+    void set_rev_uploaded(bool v) {
+        for (auto &d : devs) d->rev_uploaded = v;
+    }
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
-    hipStream_t up_stream = nullptr;  // snapshot uploads (always under state_mu exclusive)
-    int grid_blocks = 2048;
     std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
     bool raw_intern = false;       // test knob (ACL_RAW_INTERN): acl_intern skips the API's object-id pattern
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
-    int local_blocks = 1024;   // resident blocks of the single-launch kernel (4 waves per block)
-    int local_blocks_wide = 512;  // ... of its 16-wave instantiation
     uint64_t compaction_slack = 65536;  // words of garbage a snapshot may hold on top of an eighth of its rows before a background build starts
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
@@ -310,31 +362,16 @@ struct acl_engine {
                                // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round
     uint32_t local_static_pct = 100, local_dyn_unit = 32;  // chip-filling single-launch passes: share of the batch in static (one per block) units; hand-out unit size
     uint64_t cfg_frontier_entries = 0;
-    // forward graph
-    DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
-    DevArray<FwdOp> d_ops;
-    DevArray<SlotProg> d_progs;
-    DevArray<uint32_t> d_bexpr;  // boolean programs of the combine slots (schemas with `&` / `-`)
-    // reverse graph
-    DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj;
-    DevArray<RevOp> d_rops;
-    DevArray<RevProg> d_rprogs, d_rseeds;
-    // evaluation contexts
+    // evaluation contexts: per replica (DevState), one lock and one condition variable for all
     std::mutex pool_mu;
     std::condition_variable pool_cv;
-    std::vector<std::unique_ptr<PassCtx>> ctxs;  // created lazily up to max_ctx
-    std::vector<PassCtx *> free_ctxs;
-    uint32_t max_ctx = 4;
+    uint32_t max_ctx = 4;  // per replica
+    size_t next_dev = 0;   // where Eval::begin starts looking (under pool_mu)
     std::unique_ptr<PassCtx> shard_ctx;  // the acl_shard_* protocol keeps state across calls: its own context, never pooled
     void *rccl_comm = nullptr;           // ncclComm_t of acl_shard_rccl_init
     std::unique_ptr<Compaction> compaction;  // touched only under state_mu exclusive (the worker owns its innards while state == 1)
     bool compaction_enabled = true;
     std::mutex shard_mu;
-    std::mutex compute_mu;  // turn-taking of chip-filling batches on the level loop (check_ids_host's fallback, the submit/wait pipeline)
-    std::mutex chain_mu;    // chip-filling single-launch passes follow each other ON THE DEVICE: each waits for the previous one's event
-    hipEvent_t chain_prev = nullptr;  // (a context's chain_ev; contexts live until acl_close)
-    std::condition_variable chain_cv;
-    uint32_t chain_inflight = 0;
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
@@ -362,8 +399,14 @@ struct acl_engine {
     std::atomic<bool> timing{false};
 
 
-    DevGraph dev_graph() const {
-        return DevGraph{d_meta.p, d_edges.p, d_buckets.p, d_ops.p, d_progs.p, d_tsb.p, d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
+    DevGraph dev_graph(const DevState &d) const {
+        return DevGraph{d.d_meta.p, d.d_edges.p, d.d_buckets.p, d.d_ops.p, d.d_progs.p, d.d_tsb.p, d.d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
+    }
+    DevGraph dev_graph(const PassCtx *c) const { return dev_graph(*c->dev); }
+    DevReverse dev_reverse(const PassCtx *c, uint32_t vwords) const {
+        const DevState &d = *c->dev;
+        return DevReverse{d.d_rmeta.p, d.d_redges.p, d.d_rops.p, d.d_rprogs.p, d.d_rseeds.p, d.d_sbb.p, d.d_snobj.p, c->d_visited.p, vwords,
+                          (uint32_t)snap.rprogs.size(), (uint32_t)snap.rops.size()};
     }
     DevFrontier dev_frontier(const PassCtx &c) const {
         DevFrontier f;
@@ -374,7 +417,7 @@ struct acl_engine {
         f.nchunks = c.d_status.p;
         f.any = c.d_status.p + kLevelSlots;
         f.overflow = c.d_status.p + 2 * kLevelSlots;  // [+1]: the level's export counter (sharded graph)
-        f.nwaves = (uint32_t)grid_blocks * kWavesPerBlock;
+        f.nwaves = (uint32_t)c.dev->grid_blocks * kWavesPerBlock;
         f.max_chunks = c.max_chunks;
         return f;
     }
@@ -406,7 +449,8 @@ struct Eval {
     // rev_key_slot >= 0: the lookup's subject is `type#relation` of that slot -- the reverse rows must cover its id space
     // try_only: never wait for a context -- kNoContextFree when every one is taken
     // chain_lane: the call carries a chip-filling host batch: only the first kChainLanes contexts will do (the chained pipeline's admission queue)
-    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, bool chain_lane = false);
+    // on_device >= 0: only a replica on that HIP device will do (calls that are handed device pointers)
+    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, bool chain_lane = false, int on_device = -1);
     void end();
 };
 
@@ -422,7 +466,7 @@ struct ShardCall {
     int begin(acl_engine *h_, bool fresh, bool need_reverse);
 };
 DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap);
-int new_ctx(acl_engine *h, std::unique_ptr<PassCtx> *out, int index);
+int new_ctx(acl_engine *h, DevState *d, std::unique_ptr<PassCtx> *out, int index);  // (leaves the calling thread on d's device)
 void merge_stats(acl_engine *h, PassCtx *c);
 
 // schemas with `&` / `-`: sizes the pass's node list and result cells (has[] / err[] behind the n requests' own) and points g at them.
@@ -432,6 +476,7 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
 // every level in ONE launch, wave-private frontiers; an internal negative code when a wave's private frontier overflowed (engine.cpp)
 int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout);
 int not_sharded(acl_engine *h);
+int device_of(acl_engine *h, const void *p);  // HIP ordinal a device pointer lives on; -1 = any replica will do
 int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local = true);  // try_local: the single-launch walk first
 // host items -> answers in host buffers through context c (pinned staging unless the caller's buffers are pinned)
 int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);

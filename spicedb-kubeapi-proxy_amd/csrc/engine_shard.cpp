@@ -22,7 +22,7 @@ DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap) {
 int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
-    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipSetDevice(h->dev0().device));  // (the sharded entry points run on the first replica)
     h->shard_mu.lock();
     have_mu = true;
     for (;;) {
@@ -40,7 +40,7 @@ int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse) {
         return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated through the sharded entry points (use replicas)");
     if (!h->shard_ctx) {
         std::unique_ptr<PassCtx> nc;
-        int rc = new_ctx(h, &nc, -1);
+        int rc = new_ctx(h, &h->dev0(), &nc, -1);
         if (rc) return rc;
         h->shard_ctx = std::move(nc);
     }
@@ -71,7 +71,7 @@ int shard_report(PassCtx *c, uint32_t iter, acl_shard_step_t *out) {
 
 int shard_ready(acl_engine *h, uint32_t iter) {
     if (iter == 0 || iter >= kLevelSlots) return fail(ACL_ERR_INVALID_ARGUMENT, "shard step: iteration out of range");
-    if (!h->snap_valid || !h->dev_valid) return fail(ACL_ERR_FAILED_PRECONDITION, "shard step without acl_shard_*_begin");
+    if (!h->snap_valid || !h->dev0().dev_valid) return fail(ACL_ERR_FAILED_PRECONDITION, "shard step without acl_shard_*_begin");
     return ACL_OK;
 }
 
@@ -89,7 +89,7 @@ int check_step(acl_engine *h, uint32_t level, void *d_has, void *d_err, void *d_
     DevShard sh = dev_shard(h, c, d_export, cap);
     sh.by_dest = by_dest ? 1u : 0u;
     ev_begin(c, 1);
-    launch_expand(c->stream, h->dev_graph(), h->dev_frontier(*c), level, (uint8_t *)d_has, (uint8_t *)d_err, sh);
+    launch_expand(c->stream, h->dev_graph(c), h->dev_frontier(*c), level, (uint8_t *)d_has, (uint8_t *)d_err, sh);
     ev_end(c);
     c->stats.expand_launches++;
     c->stats.levels_last = level;
@@ -117,8 +117,8 @@ int acl_shard_configure(acl_engine_t *h, uint32_t rank, uint32_t world) {
     h->shard.rank = rank;
     h->shard.world = world;
     h->snap_valid = false;
-    h->dev_valid = false;
-    h->rev_uploaded = false;
+    h->set_dev_valid(false);
+    h->set_rev_uploaded(false);
     return ACL_OK;
 }
 
@@ -156,7 +156,7 @@ int acl_shard_check_begin(acl_engine_t *h, const void *d_items, size_t n, void *
         if (rc) return rc;
     }
     ev_begin(c, 0);
-    launch_seed(c->stream, h->dev_graph(), h->dev_frontier(*c), (const uint4 *)d_items, (uint32_t)n, (uint8_t *)d_has, (uint8_t *)d_err,
+    launch_seed(c->stream, h->dev_graph(c), h->dev_frontier(*c), (const uint4 *)d_items, (uint32_t)n, (uint8_t *)d_has, (uint8_t *)d_err,
                 dev_shard(h, c, nullptr, 0));  // also resets the status block
     ev_end(c);
     c->stats.check_items += n;
@@ -182,7 +182,7 @@ int acl_shard_check_import(acl_engine_t *h, uint32_t level, const void *d_entrie
     if (rc) return rc;
     PassCtx *c = sc.c;
     ev_begin(c, 0);
-    launch_import(c->stream, h->dev_graph(), h->dev_frontier(*c), level, (const uint4 *)d_entries, (uint32_t)n, dev_shard(h, c, nullptr, 0));
+    launch_import(c->stream, h->dev_graph(c), h->dev_frontier(*c), level, (const uint4 *)d_entries, (uint32_t)n, dev_shard(h, c, nullptr, 0));
     ev_end(c);
     return ACL_OK;
 }
@@ -245,10 +245,10 @@ int acl_shard_lookup_step(acl_engine_t *h, uint32_t iter, int phase, void *d_exp
     if (rc) return rc;
     rc = shard_ready(h, iter);
     if (rc) return rc;
-    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_step without acl_shard_lookup_begin");
+    if (!h->dev0().rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_step without acl_shard_lookup_begin");
     PassCtx *c = sc.c;
     const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
-    DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords};
+    DevReverse r = h->dev_reverse(c, (uint32_t)vwords);
     HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), c->stream));
     ev_begin(c, 1);
     launch_rev_expand(c->stream, r, h->dev_frontier(*c), iter, phase == ACL_SHARD_VISIT ? REV_VISIT : REV_EXPAND, dev_shard(h, c, d_export, export_cap));
@@ -264,9 +264,9 @@ int acl_shard_lookup_import(acl_engine_t *h, uint32_t iter, const void *d_entrie
     if (rc) return rc;
     rc = shard_ready(h, iter);
     if (rc) return rc;
-    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_import without acl_shard_lookup_begin");
+    if (!h->dev0().rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_import without acl_shard_lookup_begin");
     PassCtx *c = sc.c;
-    DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, 0};
+    DevReverse r = h->dev_reverse(c, 0);
     launch_rev_import(c->stream, r, h->dev_frontier(*c), iter, (const uint4 *)d_entries, (uint32_t)n);
     return ACL_OK;
 }
@@ -275,7 +275,7 @@ int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_
     ShardCall sc;
     int rc = sc.begin(h, false, false);
     if (rc) return rc;
-    if (!h->rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_finish without acl_shard_lookup_begin");
+    if (!h->dev0().rev_uploaded) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_shard_lookup_finish without acl_shard_lookup_begin");
     PassCtx *c = sc.c;
     const uint32_t nobj = h->store.objects(h->store.schema().slot_owner[h->lk_target].first).count();
     const size_t need = (nobj + 31) / 32;

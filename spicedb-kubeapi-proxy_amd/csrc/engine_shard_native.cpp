@@ -236,7 +236,7 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
         rc = X.alloc();
         if (rc) return rc;
         uint32_t *hc = (uint32_t *)c->h_xctrl.p;
-        DevGraph g = h->dev_graph();
+        DevGraph g = h->dev_graph(c);
         DevFrontier f = h->dev_frontier(*c);
         DevShard sh = X.shard();
         HIP_TRY(hipMemsetAsync(c->d_xctrl.p, 0, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), c->stream));
@@ -346,7 +346,7 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
         if (rc) return rc;
         uint32_t *hc = (uint32_t *)c->h_xctrl.p;
         DevFrontier f = h->dev_frontier(*c);
-        DevReverse r{h->d_rmeta.p, h->d_redges.p, h->d_rops.p, h->d_rprogs.p, h->d_rseeds.p, h->d_sbb.p, h->d_snobj.p, c->d_visited.p, (uint32_t)vwords};
+        DevReverse r = h->dev_reverse(c, (uint32_t)vwords);
         DevShard sh = X.shard();
         HIP_TRY(hipMemsetAsync(c->d_xctrl.p, 0, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), c->stream));
         HIP_TRY(hipMemsetAsync(c->d_visited.p, 0, std::max<size_t>(n, 1) * vwords * 4, c->stream));
@@ -436,7 +436,7 @@ int acl_shard_rccl_init(acl_engine_t *h, const void *unique_id, uint32_t rank, u
     if (!r->lib || !r->err.empty()) return fail(ACL_ERR_UNAVAILABLE, r->err.empty() ? "RCCL unavailable" : r->err);
     int rc = acl_shard_configure(h, rank, world);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipSetDevice(h->dev0().device));
     std::lock_guard<std::mutex> lk(h->shard_mu);
     if (h->rccl_comm) {
         (void)r->CommDestroy((ncclComm_t)h->rccl_comm);

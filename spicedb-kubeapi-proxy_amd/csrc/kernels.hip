@@ -38,6 +38,9 @@ namespace {
                        // 6 ~60 VALU / child, 7 random bucket gather / child, 8 six LDS reads / child, 9 entry re-read / entry
 #endif
 #define ACL_KEEP(x) asm volatile("" ::"v"(x))
+#ifndef ACL_ANS_LDS
+#define ACL_ANS_LDS 1  // with ACL_ENTRY8: the unit's answer bytes (has / err) in LDS (ans_get / ans_set); 0 = in global memory as before (A/B builds)
+#endif
 #ifndef ACL_ENTRY8
 #define ACL_ENTRY8 1  // 8-byte frontier entries in the single-launch walk (put_entry); 0 = the 16-byte form everywhere (A/B builds, tools/build_variant.sh)
 #endif
@@ -212,6 +215,18 @@ template <bool E8>
 __device__ __forceinline__ void put_entry(const WaveOut &wo, uint32_t idx, uint32_t id, uint32_t req, uint32_t meta, uint32_t sid) {
     if (E8) gst(reinterpret_cast<uint2 *>(wo.buf), idx, make_uint2(id | (((meta >> 19) & 1u) << 31), (meta & 0x7FFFFu) | ((req - wo.first) << 19)));
     else gst(wo.buf, idx, make_uint4(id, req, meta, sid));
+}
+// ... and the requests' answer bytes (has[] / err[]) of such a walk live in the block's LDS too, indexed by the request's place in the unit: the
+// "is this request answered yet" read per entry and every hit / depth-error store are LDS accesses, not gathers and scattered byte stores in
+// global memory (one of the ~6 vector-L1 line accesses per entry; each byte store was a 32 B write-through).  A: the array (LDS when L).
+template <bool L>
+__device__ __forceinline__ uint32_t ans_get(const uint8_t *a, uint32_t req, uint32_t first) {
+    return L ? (uint32_t)a[req - first] : (uint32_t)gld(a, req);
+}
+template <bool L>
+__device__ __forceinline__ void ans_set(uint8_t *a, uint32_t req, uint32_t first, uint8_t v) {
+    if (L) a[req - first] = v;
+    else a[req] = v;
 }
 __device__ __forceinline__ uint4 decode_entry8(const uint2 &v, const uint2 *sreq, uint32_t first) {
     const uint32_t rl = v.y >> 19;
@@ -488,7 +503,7 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 // (vmcnt counts stores too, and the compiler must assume the store was not issued)
 #pragma unroll
                 for (int k = 0; k < W; k++)
-                    if (hit[k]) has[rq[k]] = 1;
+                    if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], wo.first, 1);
                 if (np) {
                     const uint32_t base = reserve<LOCAL>(wo, np, lane);
                     if (base != kNoSpace) {
@@ -579,10 +594,10 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             hit = hit && valid;
             push = push && valid;
             if (hit) {
-                has[req] = 1;
+                ans_set<E8 && ACL_ANS_LDS>(has, req, wo.first, 1);
                 push = false;
             } else if (valid && level + cp.max_dlevel > kMaxLevels) {
-                err[req] = ITEM_ERR_DEPTH;
+                ans_set<E8 && ACL_ANS_LDS>(err, req, wo.first, ITEM_ERR_DEPTH);
             }
             const uint64_t b = __ballot(push);
             if (b) {
@@ -704,10 +719,10 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     push = eval_child(g, progs, ops, meta_slot(e.z), meta_level(e.z), meta_key(e.z), child, e.w, (c & kLeafAuthBit) != 0,
                                       (edge & kLeafBit) != 0, hit, derr);
                     if (hit) {
-                        has[e.y] = 1;
+                        ans_set<E8 && ACL_ANS_LDS>(has, e.y, wo.first, 1);
                         push = false;
                     } else if (derr) {
-                        err[e.y] = ITEM_ERR_DEPTH;
+                        ans_set<E8 && ACL_ANS_LDS>(err, e.y, wo.first, ITEM_ERR_DEPTH);
                     }
                     e.z |= kProbedBit;
                     if (ACL_PERTURB == 3) {
@@ -790,6 +805,7 @@ template <bool SHARDED, bool LOCAL, bool CMB, typename Next>
 __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next &next, TaskLds &t, WaveOut &wo, uint32_t lane, const DevGraph &g,
                                                 const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh,
                                                 const CombineOut &co = CombineOut()) {
+    constexpr bool E8 = ACL_ENTRY8 && LOCAL && !CMB;  // 8-byte entries + answers in LDS (put_entry, ans_get)
     const uint32_t id = e.x, req = e.y, meta = e.z;
     // ---- fast path: every entry of the segment is a "simple parent" -- probes already done by its own parent (kProbedBit),
     // plain subject, and a program whose only remaining op enumerates one sorted row.  No interpreter: the has[] read, the
@@ -858,7 +874,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                     else if (md.y - md.x > kMaxRow) *wo.cold->overflow = 2u;
                     else want = true;
                 }
-                if (derr) err[se.y] = ITEM_ERR_DEPTH;
+                if (derr) ans_set<E8 && ACL_ANS_LDS>(err, se.y, wo.first, ITEM_ERR_DEPTH);
                 const uint64_t b = __ballot(want);
                 if (want) {
                     const uint32_t q = Tb + lanes_below(b);
@@ -870,7 +886,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 return (uint32_t)__popcll(b);
             };
             // all six gathers in flight together
-            const uint32_t hvA = gld(has, valid ? req : 0u);
+            const uint32_t hvA = ans_get<E8 && ACL_ANS_LDS>(has, valid ? req : ((E8 && ACL_ANS_LDS) ? wo.first : 0u), wo.first);
             const bool inA = valid && id < LA.nrows;
             const uint2 mdA = row_desc(id, inA, LA);
             const uint2 sdA = subj_desc(e, valid, LA);
@@ -878,7 +894,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             uint2 mdB = make_uint2(0, 0), sdB = make_uint2(0, 1);
             const bool inB = validB && eB.x < LB.nrows;
             if (pairB) {
-                hvB = gld(has, validB ? eB.y : 0u);
+                hvB = ans_get<E8 && ACL_ANS_LDS>(has, validB ? eB.y : ((E8 && ACL_ANS_LDS) ? wo.first : 0u), wo.first);
                 mdB = row_desc(eB.x, inB, LB);
                 sdB = subj_desc(eB, validB, LB);
             }
@@ -906,7 +922,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         asm volatile("" : "+v"(ee.x), "+v"(ee.y), "+v"(ee.z), "+v"(ee.w));
         const uint32_t id = ee.x, req = ee.y, meta = ee.z, sid = ee.w;
         bool active = valid && meta != kDeadMeta;
-        if (active && (hit || has[req])) active = false;  // request already answered HAS: drop its pending work
+        if (active && (hit || ans_get<E8 && ACL_ANS_LDS>(has, req, wo.first))) active = false;  // request already answered HAS: drop its pending work
         const uint32_t slot = meta_slot(meta), level = meta_level(meta), key = meta_key(meta);
         const bool probed = meta & kProbedBit;  // the parent already ran this state's probes
         SlotProg p{};
@@ -1019,8 +1035,8 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         }
         jstart = jj;
         if (active) {
-            if (hit) has[req] = 1;
-            else if (depth_err) err[req] = ITEM_ERR_DEPTH;
+            if (hit) ans_set<E8 && ACL_ANS_LDS>(has, req, wo.first, 1);
+            else if (depth_err) ans_set<E8 && ACL_ANS_LDS>(err, req, wo.first, ITEM_ERR_DEPTH);
         }
         const bool more = jstart < maxops;
         // ---- expand the recorded segments (the interpreter's state is dead from here to the loop's top)
@@ -1222,6 +1238,12 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     __shared__ uint32_t s_ccount[2];  // CMB: {leaf cells, nodes} of the unit being walked
     constexpr bool E8 = ACL_ENTRY8 && !CMB;  // 8-byte frontier entries (put_entry)
     __shared__ uint2 s_req[E8 ? WAVES * 64 : 1];  // E8: {subject id, subject key} of the unit's requests
+    constexpr bool AL = E8 && ACL_ANS_LDS;
+    __shared__ uint8_t s_has[AL ? WAVES * 64 : 1], s_err[AL ? WAVES * 64 : 1];  // the unit's answer bytes (ans_get / ans_set)
+    if (AL) {
+        has = s_has;
+        err = s_err;
+    }
     extern __shared__ uint4 s_prog[];  // dynamic: sized by the launcher to THIS snapshot's program table (a fixed 8 KiB cost two blocks per CU)
     const SlotProg *progs;
     const FwdOp *ops;
@@ -1271,8 +1293,8 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             const uint32_t rt = tok ? rtype : 0u, st = tok ? stype : 0u;
             const uint32_t rmem = gld(g.type_nmembers, rt), smem = gld(g.type_nmembers, st), rbase = gld(g.type_slot_base, rt), sbase = gld(g.type_slot_base, st);
             const bool ok = tok && perm < rmem && (srel == 0xFFFFu || srel < smem);
-            gst(has, req, (uint8_t)0);
-            gst(err, req, (uint8_t)(ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID));
+            ans_set<E8 && ACL_ANS_LDS>(has, req, first, 0);
+            ans_set<E8 && ACL_ANS_LDS>(err, req, first, (uint8_t)(ok ? ITEM_ERR_NONE : ITEM_ERR_INVALID));
             const uint32_t skey = srel == 0xFFFFu ? g.nslots + stype : sbase + srel;
             const uint32_t meta = ok ? make_meta(rbase + perm, 1u, skey) : kDeadMeta;
             e = make_uint4(it.y, req, meta, it.w);
@@ -1343,8 +1365,8 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         // ---- answers (k_finalize): every wave's has[] / err[] stores are behind a block barrier
         __syncthreads();
         if (valid) {
-            const bool h = __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool h = AL ? s_has[threadIdx.x] != 0 : __hip_atomic_load(has + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+            const uint8_t er = h ? (uint8_t)ITEM_ERR_NONE : (AL ? s_err[threadIdx.x] : __hip_atomic_load(err + req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             perm_out[req] = h ? 2 : (er ? 0 : 1);
             if (err_out) err_out[req] = er == ITEM_ERR_DEPTH ? 100 : (er == ITEM_ERR_INVALID ? 9 : 0);
         }
@@ -1577,6 +1599,7 @@ constexpr int kRevLocalThreads = 1024;
 constexpr uint32_t kRevTaskCap = kRevLocalThreads;  // one (state, op) pair per thread and round => at most one task per thread
 constexpr uint32_t kRevLocalBudget = 1u << 22;      // children of one round a single block may enumerate
 constexpr uint32_t kRevTerminal = 0x80000000u;      // task target flag: children are only marked, never expanded
+constexpr uint32_t kRevNoMark = 0x40000000u;        // task target flag (OP_NOMARK seed ops): every child is a first visit by construction -- no visited bit
 struct RevTaskLds {
     uint32_t start[kRevTaskCap];       // first resource id of the row in `redges`
     uint32_t prefix[kRevTaskCap + 1];  // exclusive prefix of the degrees (a thread without a task: degree 0)
@@ -1600,6 +1623,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     // The block's frontier is ONE append-only log (buf0's region; buf1 is unused): level L reads [lvl_lo, lvl_hi) and appends behind the end.
     // Every entry is a first visit whose bit this block set in `visited` -- so the log is also the list of what to clear afterwards (below).
     __shared__ uint32_t s_end, s_wave_tot[kRevLocalThreads / 64], s_stop, s_maxops, s_count[kRevLocalThreads / 64];
+    __shared__ uint32_t s_nomark[kRevLdsSlots / 32];  // slots whose states carry no visited bit in this launch (nothing to clear afterwards)
     const uint32_t tid = threadIdx.x, lane = lane_id(), wib = tid >> 6;
     const uint32_t req = blockIdx.x;
     uint32_t *__restrict__ visited = r.visited + (size_t)req * r.visited_words;
@@ -1612,6 +1636,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         s_stop = 0;
         s_maxops = 0;
     }
+    if (tid < kRevLdsSlots / 32) s_nomark[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < r.nrops; i += kRevLocalThreads) pl.ops[i] = r.rops[i];
     for (uint32_t i = tid; i < r.nslots; i += kRevLocalThreads) {
@@ -1623,6 +1648,10 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     const RevProg seed = r.rseeds[key];
     const uint32_t sid = sids[req];
     const uint32_t row_w0 = r.slot_bit_base[target_slot] >> 5;  // first word of the result slot's rows in `visited`
+    for (uint32_t i = tid; i < (seed.n & ~kRevRemoteBit); i += kRevLocalThreads) {
+        const RevOp so = r.rops[seed.first + i];
+        if ((so.flags & OP_NOMARK) && so.target != target_slot) atomicOr(&s_nomark[so.target >> 5], 1u << (so.target & 31u));
+    }
     for (uint32_t i = tid; i < lds_words; i += kRevLocalThreads) s_row[i] = 0u;
     // `visited` is NOT zeroed here (round 4; VERDICT r3 weak #3: 64 blocks zeroing ~50 KB each were 7x the result rows in write traffic):
     // the host hands it over all-zero once, and every block clears exactly the bits it set before it ends -- the non-terminal first visits
@@ -1634,7 +1663,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
 
     // marks child (slot, id); returns true when it was a first visit of a state that has parents of its own
     auto visit = [&](uint32_t id, uint32_t tgt, bool valid) -> bool {
-        const uint32_t slot = tgt & ~kRevTerminal;
+        const uint32_t slot = tgt & ~(kRevTerminal | kRevNoMark);
         const uint2 si = pl.slot[slot];
         const bool ok = valid && id < si.y;
         bool push = false;
@@ -1647,6 +1676,8 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
             }
         } else if (tgt & kRevTerminal) {
             return false;  // neither expanded nor part of the answer: no bit
+        } else if (tgt & kRevNoMark) {
+            return ok;     // the only producer of this slot's states, each id once: a first visit without asking
         }
         const uint32_t bit = si.x + (ok ? id : 0u);
         uint32_t *w = visited + (bit >> 5);
@@ -1700,7 +1731,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                 if (j < (p.n & ~kRevRemoteBit)) {
                     const RevOp op = pl.ops[p.first + j];
                     const uint32_t np = pl.progs[op.target].n & ~kRevRemoteBit;
-                    tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all;
+                    tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all | ((op.flags & OP_NOMARK) ? kRevNoMark : 0u);
                     if (op.flags & OP_PUSH_SAME) {
                         same = true;
                     } else if ((op.flags & OP_WILD) || id < op.nrows) {  // (OP_WILD, seeds only: the wildcard subject's row, whatever the seed's id)
@@ -1715,7 +1746,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
             }
             {  // same-object parents are visited right here (wave-uniform control flow: the append ballots)
                 const bool push = visit(id, tgt, same);
-                append(push, id, tgt & ~kRevTerminal);
+                append(push, id, tgt & ~(kRevTerminal | kRevNoMark));
             }
             // ---- block-wide exclusive prefix of the degrees
             const uint32_t incl = wave_incl_scan(deg, lane);
@@ -1759,7 +1790,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                             if (!__ballot(valid[k])) break;  // (wave-uniform)
                             const uint32_t tg = t.target[tj[k]];
                             const bool push = visit(edge[k], tg, valid[k]);
-                            append(push, edge[k], tg & ~kRevTerminal);
+                            append(push, edge[k], tg & ~(kRevTerminal | kRevNoMark));
                         }
                     }
                 }
@@ -1810,6 +1841,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     for (uint32_t i = tid; i < nlog; i += kRevLocalThreads) {
         const uint2 en = log[i];
         if (lds_words && en.y == target_slot) continue;  // (marked in LDS)
+        if (s_nomark[en.y >> 5] >> (en.y & 31u) & 1u) continue;  // (never marked)
         visited[(pl.slot[en.y].x + en.x) >> 5] = 0u;
     }
     if (!lds_words) {

@@ -27,6 +27,8 @@ enum : uint32_t {
     OP_PUSH_SAME = 8u,  // non-inlined computed userset: child state on the same object
     OP_PROBE_HASH = 16u, // membership test in a membership-only class: SUBJECT-indexed hashed rows (4-slot buckets)
     OP_LEAFBIT = 32u,    // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
+    OP_NOMARK = 128u,    // reverse seed ops (RevOp): the children of this op are the ONLY states of their slot the walk can ever produce, each once
+                         // (no other op targets the slot; ids of a reverse row are distinct): no visited bit is needed to tell a first visit
     OP_WILD = 64u        // with OP_PROBE_HASH: the row probed is the one of the class's wildcard subject `T:*` (its id in FwdOp::K), whoever the
                          // request's subject is; reverse ops (RevOp): the row read is the wildcard subject's (roff_base points at it), whatever the seed's id
 };

@@ -170,6 +170,22 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         p.n = (uint32_t)s.rops.size() - p.first;
         s.rseeds[key] = p;
     }
+    // Seed ops whose target slot has no other producer anywhere: their children need no visited bits (kernels.hip k_rev_local) -- in the
+    // reference's own schema that is every relation a user is named on directly (pod#viewer, pod#creator, namespace#viewer, ...): two thirds
+    // of the atomics of a list-pods lookup.  (Sharded graphs keep their bits: other shards may produce the same state.)
+    if (shard.world == 1) {
+        std::vector<uint32_t> produced(sc.nslots, 0);
+        for (const RevProg &p : s.rprogs)
+            for (uint32_t j = 0; j < (p.n & ~kRevRemoteBit); j++) produced[s.rops[p.first + j].target]++;
+        for (const RevProg &p : s.rseeds) {
+            for (uint32_t j = 0; j < p.n; j++) {
+                const uint32_t tgt = s.rops[p.first + j].target;
+                uint32_t same = 0;
+                for (uint32_t k = 0; k < p.n; k++) same += s.rops[p.first + k].target == tgt ? 1u : 0u;
+                if (!produced[tgt] && same == 1) s.rops[p.first + j].flags |= OP_NOMARK;
+            }
+        }
+    }
     if (s.rops.empty()) s.rops.push_back(RevOp{});
     s.slot_bit_base.assign(sc.nslots + 1, 0);
     s.slot_nobjects.assign(sc.nslots, 0);

@@ -53,6 +53,10 @@ def reference_filter_list_response(body: bytes, templates, user, check):
     if not bulk:
         return None
     answers = [check(*r) for r in bulk]
+    if any(a[1] == 3 for a in answers):
+        # one ill-formed item (an empty or non-conforming object id: validate.hpp) fails the CheckBulkPermissions CALL, and the reference
+        # returns that error instead of a filtered list (postfilter.go:134-137)
+        return "INVALID_ARGUMENT"
     allowed = [it for i, it in enumerate(items) if i not in item_reqs or all(answers[k] == (2, 0) for k in item_reqs[i])]
     doc["items"] = allowed if allowed else None  # appending to a nil slice: nothing allowed marshals as null
     return doc
@@ -136,6 +140,11 @@ def test_matches_reference_algorithm_on_random_lists(aclgpu_lib):
                                ["namespace:{{namespace}}#view@user:{{user.name}}"], ["pod:{{ namespacedName }}#view@user:{{user.name}}", "pod:{{unknownVar}}#view@user:x"], []])
             user = f"u{rng.randrange(6)}"
             want = reference_filter_list_response(body, [t.replace("{{ namespacedName }}", "{{namespacedName}}") for t in tpls], user, o.check)
+            if want == "INVALID_ARGUMENT":
+                with pytest.raises(aclgpu.AclError) as ei:
+                    e.filter_list_response(body, tpls, user)
+                assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, (trial, tpls)
+                continue
             out, kept, total = e.filter_list_response(body, tpls, user)
             if want is None:
                 assert out == body, (trial, tpls)
