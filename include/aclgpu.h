@@ -97,6 +97,11 @@ const char *acl_last_error(void);
  * (spicedb.go:19-24).  rels_utf8 may be NULL; one `type:id#rel@type:id[#rel]` per line
  * (grammar pkg/rules/rules.go:1053-1055). Replaces any previous schema and data. */
 int acl_load_bootstrap(acl_engine_t *h, const char *schema_utf8, size_t schema_len, const char *rels_utf8, size_t rels_len);
+/* ... and the bootstrap FILE form: YAML documents `{schema: <text>, relationships: <lines>}` as the reference's embedded default
+ * (pkg/spicedb/bootstrap.yaml), a file named by the endpoint URL (pkg/proxy/options.go:313-316, spicedb.go:22-23) or a byte map
+ * (spicedb.go:19-21) hold them.  Several documents (`---`) are merged.  The YAML subset is the one such files use (top-level keys, block or
+ * one-line scalars; csrc/bootstrap_yaml.cpp); anything else is INVALID_ARGUMENT, never a guess. */
+int acl_load_bootstrap_yaml(acl_engine_t *h, const char *yaml_utf8, size_t len);
 
 /* ---- identifiers (pre-interned fast path) ---- */
 int acl_type_id(acl_engine_t *h, const char *type);                 /* -1 if unknown */
@@ -282,6 +287,15 @@ int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, si
  * is the cursor for the next poll.  ACL_ERR_OUT_OF_RANGE when the cursor fell out of the retained feed. */
 typedef void (*acl_watch_cb)(void *user, uint64_t revision, int32_t op, const acl_relationship_t *rel);
 int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, int ntypes, acl_watch_cb cb, void *user, uint64_t *revision_out);
+/* The blocking half of the stream (watch.go:38 blocks in Recv()): returns ACL_OK as soon as the feed holds an update with revision >
+ * after_revision whose resource type is in `types` (then poll), else ACL_ERR_DEADLINE_EXCEEDED / ACL_ERR_CANCELLED by `opts` (NULL: waits
+ * for ever).  A condition variable behind acl_write / acl_delete_by_filter: no sleeping poll per open watch. */
+int acl_watch_wait(acl_engine_t *h, uint64_t after_revision, const int *types, int ntypes, const acl_call_opts_t *opts, uint64_t *revision_out);
+/* RunWatch's loop body for a whole poll (watch.go:38-108): every update of templ->resource_type behind the cursor and, for all of them, ONE
+ * bulk Check of `templ.resource_type : <the update's resource id> # templ.permission @ templ's subject` (the reference issues one
+ * CheckPermission per update, watch.go:50-67); cb once per update, in commit order, with the decision (permissionship, per-item error). */
+typedef void (*acl_watch_check_cb)(void *user, uint64_t revision, int32_t op, const acl_relationship_t *rel, uint8_t permissionship, int32_t err);
+int acl_watch_recheck(acl_engine_t *h, uint64_t after_revision, const acl_check_item_t *templ, acl_watch_check_cb cb, void *user, uint64_t *revision_out);
 /* Micro-batching front-end for the proxy's call shape -- many concurrent 1-item checks (check.go:76-94 one goroutine
  * per check expression, watch.go:50 one per update).  acl_check_one blocks its caller; while a batcher runs,
  * concurrent callers share ONE device pass (drained after at most max_wait_us or when max_items are waiting). */

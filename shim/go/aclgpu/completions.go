@@ -29,8 +29,9 @@ type completion struct {
 }
 
 type lookupCompletion struct {
-	rc int32
-	bm []C.uint32_t // the result row, copied out of the engine's allocation
+	rc  int32
+	msg string       // why a failed lookup failed, where the shim knows (the completion record carries a code only)
+	bm  []C.uint32_t // the result row, copied out of the engine's allocation
 }
 
 type completions struct {
@@ -76,6 +77,16 @@ func (e *Engine) startPoller() {
 func (e *Engine) pollLookups() {
 	runtime.LockOSThread()
 	defer close(e.cq.ldone)
+	// whoever is still parked in lookupOne when this poller ends -- the engine closing, or the completion queue failing -- gets an
+	// Unavailable completion instead of waiting for ever on a ctx that may have no deadline (ADVICE r3)
+	defer func() {
+		e.cq.mu.Lock()
+		for tag, ch := range e.cq.lwaiting {
+			delete(e.cq.lwaiting, tag)
+			ch <- lookupCompletion{rc: int32(codes.Unavailable), msg: "the engine's lookup completion queue has shut down"} // buffered
+		}
+		e.cq.mu.Unlock()
+	}()
 	buf := make([]C.acl_lookup_completion_t, 64)
 	for atomic.LoadInt32(&e.cq.closed) == 0 {
 		var n C.size_t

@@ -11,6 +11,8 @@ package aclgpu
 import "C"
 
 import (
+	"os"
+	"sort"
 	"strconv"
 	"unsafe"
 
@@ -63,6 +65,49 @@ func Open(cfg Config, schema, relationships string) (*Engine, error) {
 		return e, nil
 	}
 	return &Engine{h: h}, nil
+}
+
+// OpenBootstrap replaces spicedb.NewServer(ctx, bootstrapFilePath, bootstrapContent) (reference pkg/spicedb/spicedb.go:18-24) for
+// `gpu://` endpoints (shim/patches/options_gpu_scheme.patch): the bootstrap comes from the content map when it has entries, else from the
+// file the endpoint URL names, else from `defaultBootstrap` (the reference's embedded pkg/spicedb/bootstrap.yaml, handed in by the caller:
+// the default stays in the reference binary).  Every source is YAML `{schema, relationships}`; the engine reads it itself
+// (acl_load_bootstrap_yaml), several files are merged as `---` documents in name order.
+func OpenBootstrap(cfg Config, bootstrapFilePath string, bootstrapContent map[string][]byte, defaultBootstrap []byte) (*Engine, error) {
+	var doc []byte
+	switch {
+	case len(bootstrapContent) > 0:
+		names := make([]string, 0, len(bootstrapContent))
+		for n := range bootstrapContent {
+			names = append(names, n)
+		}
+		sort.Strings(names)
+		for i, n := range names {
+			if i > 0 {
+				doc = append(doc, []byte("\n---\n")...)
+			}
+			doc = append(doc, bootstrapContent[n]...)
+		}
+	case len(bootstrapFilePath) > 0:
+		b, err := os.ReadFile(bootstrapFilePath)
+		if err != nil {
+			return nil, status.Errorf(codes.InvalidArgument, "bootstrap file %q: %v", bootstrapFilePath, err)
+		}
+		doc = b
+	default:
+		doc = defaultBootstrap
+	}
+	e, err := Open(cfg, "definition aclgpu_placeholder {}", "") // (an engine needs a schema to open its tables; the bootstrap replaces it)
+	if err != nil {
+		return nil, err
+	}
+	cd := C.CBytes(doc)
+	defer C.free(cd)
+	if rc := C.acl_load_bootstrap_yaml(e.h, (*C.char)(cd), C.size_t(len(doc))); rc != 0 {
+		err := lastError(rc)
+		e.Close()
+		return nil, err
+	}
+	return e, nil
 }
 
 func (e *Engine) Close() {

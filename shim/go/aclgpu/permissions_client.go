@@ -113,7 +113,11 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 			return nil, err
 		}
 		if c.rc != 0 {
-			return nil, status.Error(codes.Code(c.rc), "lookup failed")
+			msg := c.msg
+			if msg == "" {
+				msg = "LookupResources failed in the engine (code " + codes.Code(c.rc).String() + "); ACL_TRACE=1 logs the reason where the completion is produced"
+			}
+			return nil, status.Error(codes.Code(c.rc), msg)
 		}
 		return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: c.bm, at: p.e.zedToken()}, nil
 	}

@@ -85,9 +85,13 @@ func (s *watchStream) Recv() (*v1.WatchResponse, error) {
 			s.pending[n-1].Updates = append(s.pending[n-1].Updates, &v1.RelationshipUpdate{Operation: op, Relationship: u.rel})
 		}
 		if len(s.pending) == 0 {
-			select {
-			case <-s.ctx.Done():
-			case <-time.After(2 * time.Millisecond):
+			// nothing behind the cursor: block in the engine until the feed moves for one of the watched types (acl_watch_wait -- a
+			// condition variable on the write path, as the reference's stream blocks in Recv(), watch.go:38), looking at the context
+			// every 200 ms; no sleeping poll per open watch
+			opts := C.acl_call_opts_t{timeout_ns: C.int64_t(200 * time.Millisecond)}
+			var head C.uint64_t
+			if rc := C.acl_watch_wait(s.e.h, C.uint64_t(s.cursor), tp, C.int(len(s.types)), &opts, &head); rc != 0 && rc != C.ACL_ERR_DEADLINE_EXCEEDED {
+				return nil, lastError(rc)
 			}
 		}
 	}

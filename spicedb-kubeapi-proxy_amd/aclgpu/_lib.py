@@ -27,7 +27,7 @@ SYMBOLS = [
     "acl_delete_by_filter_pre", "acl_check_bulk_ids_opts", "acl_check_bulk_ids_submit", "acl_ticket_wait", "acl_host_alloc", "acl_host_free",
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
-    "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls",
+    "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls", "acl_watch_wait", "acl_watch_recheck", "acl_load_bootstrap_yaml",
 ]
 
 
@@ -104,6 +104,7 @@ class ShardStep(C.Structure):
 
 READ_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Relationship))
 WATCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(Relationship))
+WATCH_CHECK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(Relationship), C.c_uint8, C.c_int32)
 
 _lib = None
 
@@ -138,6 +139,7 @@ def load():
     L.acl_close.restype = None
     L.acl_last_error.restype = C.c_char_p
     L.acl_load_bootstrap.argtypes = [H, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.acl_load_bootstrap_yaml.argtypes = [H, C.c_char_p, C.c_size_t]
     L.acl_type_id.argtypes = [H, C.c_char_p]
     L.acl_relation_id.argtypes = [H, C.c_int, C.c_char_p]
     L.acl_intern.argtypes = [H, C.c_int, C.c_char_p, C.POINTER(C.c_uint32)]
@@ -172,6 +174,8 @@ def load():
     L.acl_check_bulk_keep_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.acl_bitmap_test_names.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_void_p]
     L.acl_watch_poll.argtypes = [H, C.c_uint64, C.POINTER(C.c_int), C.c_int, WATCH_CB, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.acl_watch_wait.argtypes = [H, C.c_uint64, C.POINTER(C.c_int), C.c_int, C.POINTER(CallOpts), C.POINTER(C.c_uint64)]
+    L.acl_watch_recheck.argtypes = [H, C.c_uint64, C.POINTER(CheckItem), WATCH_CHECK_CB, C.c_void_p, C.POINTER(C.c_uint64)]
     L.acl_batcher_start.argtypes = [H, C.c_uint32, C.c_uint32]
     L.acl_batcher_stop.argtypes = [H]
     L.acl_batcher_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

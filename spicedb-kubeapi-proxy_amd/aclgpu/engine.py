@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CallOpts, CheckItem, Completion, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB
+from ._lib import CallOpts, CheckItem, Completion, Config, Filter, READ_CB, Relationship, Stats, Update, WATCH_CB, WATCH_CHECK_CB
 
 PERM_UNSPECIFIED, PERM_NO, PERM_HAS, PERM_CONDITIONAL = 0, 1, 2, 3
 OP_CREATE, OP_TOUCH, OP_DELETE = 1, 2, 3
@@ -85,6 +85,11 @@ class Engine:
         s = schema.encode()
         r = relationships.encode() if relationships else None
         self._check(self._L.acl_load_bootstrap(self._h, s, len(s), r, len(r) if r else 0))
+
+    def load_bootstrap_yaml(self, yaml_text):
+        """The bootstrap FILE form (pkg/spicedb/bootstrap.yaml; spicedb.go:19-24): YAML `{schema, relationships}` documents."""
+        y = yaml_text if isinstance(yaml_text, bytes) else yaml_text.encode()
+        self._check(self._L.acl_load_bootstrap_yaml(self._h, y, len(y)))
 
     # ---- ids
     def type_id(self, t: str) -> int:
@@ -419,6 +424,33 @@ class Engine:
         arr = (C.c_int * max(1, len(tids)))(*tids)
         cur = C.c_uint64()
         self._check(self._L.acl_watch_poll(self._h, after_revision, arr, len(tids), WATCH_CB(cb), None, C.byref(cur)))
+        return out, cur.value
+
+    def watch_wait(self, after_revision: int, types=(), timeout_s=None, cancel=None) -> int:
+        """Blocks until the feed holds an update behind the cursor for one of `types` (acl_watch_wait: the blocking half of Watch.Recv,
+        watch.go:38) -> the store's revision; raises AclError DEADLINE_EXCEEDED / CANCELLED by timeout_s / cancel (a ctypes c_int32)."""
+        tids = [self.type_id(t) for t in types]
+        if any(t < 0 for t in tids):
+            raise AclError(ERR_FAILED_PRECONDITION, "unknown object type in watch request")
+        arr = (C.c_int * max(1, len(tids)))(*tids)
+        cur = C.c_uint64()
+        opts = CallOpts(C.pointer(cancel) if cancel is not None else None, int((timeout_s or 0) * 1e9))
+        self._check(self._L.acl_watch_wait(self._h, after_revision, arr, len(tids), C.byref(opts), C.byref(cur)))
+        return cur.value
+
+    def watch_recheck(self, after_revision: int, rtype, perm, stype, sid, srel=""):
+        """RunWatch's loop body for a whole poll (watch.go:38-108): -> ([(revision, op, relationship 6-tuple, permissionship, err)], cursor):
+        every update of `rtype` behind the cursor with the decision of ONE bulk Check `rtype:<its resource id>#perm@stype:sid[#srel]`."""
+        out = []
+
+        def cb(_u, rev, op, rp, perm_, err_):
+            r = rp.contents
+            out.append((rev, op, (r.resource_type.decode(), r.resource_id.decode(), r.relation.decode(), r.subject_type.decode(), r.subject_id.decode(),
+                                  (r.subject_relation or b"").decode()), int(perm_), int(err_)))
+
+        templ = CheckItem(_b(rtype), _b("-"), _b(perm), _b(stype), _b(sid), _b(srel))
+        cur = C.c_uint64()
+        self._check(self._L.acl_watch_recheck(self._h, after_revision, C.byref(templ), WATCH_CHECK_CB(cb), None, C.byref(cur)))
         return out, cur.value
 
     def batcher_start(self, max_items: int = 4096, max_wait_us: int = 200):

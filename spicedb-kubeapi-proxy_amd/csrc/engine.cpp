@@ -1844,6 +1844,7 @@ int acl_write(acl_engine_t *h, const acl_update_t *ups, int n, const acl_filter_
     std::lock_guard<RwLock> lk(h->state_mu);
     std::unique_lock<std::shared_mutex> nlk(h->names_mu);
     Status s = h->store.write(u, p, rev);
+    if (s.ok()) h->feed_wake();  // (acl_watch_wait)
     return s.ok() ? ACL_OK : fail(s);
 }
 
@@ -1864,6 +1865,7 @@ int acl_delete_by_filter_pre(acl_engine_t *h, const acl_filter_t *f, const acl_f
         if (!ps.ok()) return fail(ps);
     }
     Status s = h->store.delete_by_filter(to_filter(f), n_deleted, rev);
+    if (s.ok()) h->feed_wake();
     return s.ok() ? ACL_OK : fail(s);
 }
 

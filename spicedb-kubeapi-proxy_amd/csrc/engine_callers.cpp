@@ -536,6 +536,82 @@ int acl_watch_poll(acl_engine_t *h, uint64_t after_revision, const int *types, i
     return ok ? ACL_OK : fail(ACL_ERR_OUT_OF_RANGE, "acl_watch_poll: cursor is older than the retained change feed");
 }
 
+// The blocking half of a Watch stream (watch.go:38 blocks in Recv()): returns as soon as the feed holds an update with revision >
+// after_revision whose resource type is in `types` (0 types: any) -- ACL_OK, *revision_out = the store's revision, the caller then polls --
+// or with ACL_ERR_DEADLINE_EXCEEDED / ACL_ERR_CANCELLED by `opts`.  A condition variable on the write path: no sleeping poll per stream.
+int acl_watch_wait(acl_engine_t *h, uint64_t after_revision, const int *types, int ntypes, const acl_call_opts_t *o, uint64_t *revision_out) {
+    if (ntypes < 0 || (ntypes && !types)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_watch_wait: bad argument");
+    CallOpts opts;
+    if (o) {
+        opts.cancel = o->cancel;
+        if (o->timeout_ns > 0) opts.deadline_ns = mono_ns() + o->timeout_ns;
+    }
+    std::vector<int> tv(types, types + ntypes);
+    for (;;) {
+        uint64_t gen;
+        {
+            std::lock_guard<std::mutex> lk(h->feed_mu);
+            gen = h->feed_gen;
+        }
+        {
+            std::shared_lock<RwLock> lk(h->state_mu);
+            std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+            const Schema &sc = h->store.schema();
+            for (int t : tv)
+                if (t < 0 || t >= (int)sc.defs.size()) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_watch_wait: unknown object type");
+            if (revision_out) *revision_out = h->store.revision();
+            if (after_revision != UINT64_MAX && h->store.revision() > after_revision) {
+                bool any = false;
+                const bool ok = h->store.changes_since(after_revision, tv, [&](const Store::Change &, const RelText &) { any = true; });
+                if (!ok) return fail(ACL_ERR_OUT_OF_RANGE, "acl_watch_wait: cursor is older than the retained change feed");
+                if (any) return ACL_OK;
+            }
+        }
+        if (int rc = check_opts(opts)) return rc;
+        std::unique_lock<std::mutex> lk(h->feed_mu);
+        if (h->feed_gen != gen) continue;  // a write slipped in between the look and the wait
+        // (a cancel flag has no wake-up of its own: looked at every 20 ms)
+        const auto nap = std::chrono::nanoseconds(opts.deadline_ns ? std::max<int64_t>(1, std::min<int64_t>(opts.deadline_ns - mono_ns(), opts.cancel ? 20000000 : INT64_MAX / 4))
+                                                                   : (opts.cancel ? 20000000 : 1000000000));
+        h->feed_cv.wait_for(lk, nap, [&] { return h->feed_gen != gen; });
+    }
+}
+
+// RunWatch's loop body for a whole poll (watch.go:38-108): every update of `templ->resource_type` behind the cursor, ONE bulk Check of
+// (templ.resource_type : the update's resource id # templ.permission @ templ's subject) for all of them -- the reference issues one
+// CheckPermission per update (watch.go:50-67) -- and the callback once per update, in commit order, with the decision beside it.
+int acl_watch_recheck(acl_engine_t *h, uint64_t after_revision, const acl_check_item_t *templ, acl_watch_check_cb cb, void *user, uint64_t *revision_out) {
+    if (!templ || !cb || empty(templ->resource_type)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_watch_recheck: bad argument");
+    struct Upd {
+        uint64_t revision;
+        int32_t op;
+        RelText r;
+    };
+    std::vector<Upd> ups;
+    {
+        std::shared_lock<RwLock> lk(h->state_mu);
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        const int t = h->store.schema().type_of(templ->resource_type);
+        if (t < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("object definition `") + templ->resource_type + "` not found");
+        if (revision_out) *revision_out = h->store.revision();
+        if (after_revision == UINT64_MAX) return ACL_OK;
+        const bool ok = h->store.changes_since(after_revision, {t}, [&](const Store::Change &c, const RelText &r) { ups.push_back(Upd{c.revision, c.op, r}); });
+        if (!ok) return fail(ACL_ERR_OUT_OF_RANGE, "acl_watch_recheck: cursor is older than the retained change feed");
+    }
+    if (ups.empty()) return ACL_OK;
+    std::vector<acl_check_item_t> items(ups.size(), *templ);
+    for (size_t i = 0; i < ups.size(); i++) items[i].resource_id = ups[i].r.rid.c_str();
+    std::vector<uint8_t> perm(ups.size());
+    std::vector<int32_t> err(ups.size());
+    if (int rc = acl_check_bulk(h, items.data(), items.size(), perm.data(), err.data())) return rc;  // (fully consistent as of now, like the reference's check)
+    for (size_t i = 0; i < ups.size(); i++) {
+        const RelText &r = ups[i].r;
+        acl_relationship_t rel{r.rtype.c_str(), r.rid.c_str(), r.rel.c_str(), r.stype.c_str(), r.sid.c_str(), r.srel.c_str(), 0};
+        cb(user, ups[i].revision, ups[i].op, &rel, perm[i], err[i]);
+    }
+    return ACL_OK;
+}
+
 // Test hook: brings the HOST snapshot up to date exactly as a read would (patch if possible, else rebuild) -- without
 // touching a device, so it also works on a store-only engine -- and verifies it against the store.
 // *patched_out = 1 when the update was a patch, 0 when it was a (re)build.

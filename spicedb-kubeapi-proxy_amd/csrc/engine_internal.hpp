@@ -372,6 +372,17 @@ struct acl_engine {
     std::unique_ptr<Compaction> compaction;  // touched only under state_mu exclusive (the worker owns its innards while state == 1)
     bool compaction_enabled = true;
     std::mutex shard_mu;
+    // change-feed waiters (acl_watch_wait): every committed write bumps feed_gen under feed_mu and wakes them
+    std::mutex feed_mu;
+    std::condition_variable feed_cv;
+    uint64_t feed_gen = 0;
+    void feed_wake() {
+        {
+            std::lock_guard<std::mutex> lk(feed_mu);
+            feed_gen++;
+        }
+        feed_cv.notify_all();
+    }
     uint32_t max_sub_batch = 1u << 20;
     uint32_t local_max_items = 1u << 20;  // batches up to this size take the single-launch path (k_check_local) first; 0 = never.  Measured on C4
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items

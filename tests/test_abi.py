@@ -224,6 +224,31 @@ def test_docs_and_go_shim_name_only_declared_entry_points():
         assert not missing, (f, missing)
 
 
+def test_gpu_scheme_patch_names_what_the_shim_defines():
+    """shim/patches/options_gpu_scheme.patch (the `--spicedb-endpoint gpu://` branch next to pkg/proxy/options.go:313-321): every `aclgpu.X` it
+    calls is a func / type the shim sources define, its hunks apply to the reference checkout where one is present, and the C entry points
+    the shim's new code needs are exported."""
+    import glob
+    import re
+    import subprocess
+    root = os.path.dirname(HERE)
+    patch = open(os.path.join(root, "shim", "patches", "options_gpu_scheme.patch")).read()
+    shim_src = "".join(open(f).read() for f in glob.glob(os.path.join(root, "shim", "go", "aclgpu", "*.go")))
+    used = set(re.findall(r"\baclgpu\.([A-Z][A-Za-z0-9]*)", "\n".join(ln for ln in patch.split("\n") if ln.startswith("+"))))
+    assert {"OpenBootstrap", "NewPermissionsClient", "NewWatchClient", "Config"} <= used
+    for name in used:
+        assert re.search(r"\bfunc %s\(|\btype %s \b" % (name, name), shim_src), name
+    for field in re.findall(r"aclgpu\.Config\{([^}]*)\}", patch)[0].split(","):
+        assert re.search(r"\b%s\s" % field.split(":")[0].strip(), shim_src[shim_src.index("type Config struct"):shim_src.index("type Engine struct")]), field
+    hdr = open(HEADER).read()
+    for sym in ("acl_load_bootstrap_yaml", "acl_watch_wait"):
+        assert sym in shim_src and re.search(r"\b%s\s*\(" % sym, hdr), sym
+    if os.path.isdir("/root/reference/pkg/proxy") and subprocess.run(["git", "--version"], capture_output=True).returncode == 0:
+        r = subprocess.run(["git", "apply", "--check", "--unsafe-paths", "--directory=/root/reference", os.path.join(root, "shim", "patches", "options_gpu_scheme.patch")],
+                           capture_output=True, text=True, cwd="/")
+        assert r.returncode == 0, r.stderr
+
+
 def test_reference_citations_resolve():
     """Every `file.go:line[-line]` citation in the sources and docs names a file that exists in the reference checkout and lines inside
     it (so that the judge can follow them).  Skipped where the reference is not present (the GPU box)."""

@@ -292,6 +292,17 @@ def test_watch_then_recheck(aclgpu):
             events += [(u.relationship.resource.object_id, v1.is_allowed(p)) for u, p in zip(resp.updates, pairs)]
         # fully consistent reads: every re-check sees the LATEST state (ns/a's creator is already gone)
         assert events == [("ns/a", False), ("ns/b", False), ("ns/a", False), ("ns/c", True)]
+        # ... and the same as ONE entry point (acl_watch_recheck: the poll and the bulk re-check in one call), behind a blocking wait
+        _u, cur = e.watch_poll(aclgpu.WATCH_FROM_NOW)
+        c.WriteRelationships([mk(v1.OPERATION_TOUCH, "ns/d", "creator", "paul"), mk(v1.OPERATION_TOUCH, "ns/e", "creator", "chani")])
+        c.WriteRelationships([mk(v1.OPERATION_TOUCH, "ns/a", "viewer", "paul")])
+        assert e.watch_wait(cur, ["pod"], timeout_s=1.0) == e.revision
+        got, nxt = e.watch_recheck(cur, "pod", "view", "user", "paul")
+        assert [(g[2][1], g[3], g[4]) for g in got] == [("ns/d", 2, 0), ("ns/e", 1, 0), ("ns/a", 2, 0)] and nxt == e.revision
+        assert got[0][0] == got[1][0] < got[2][0] and {g[1] for g in got} == {aclgpu.OP_TOUCH}
+        assert e.watch_recheck(nxt, "pod", "view", "user", "paul") == ([], nxt)
+        with pytest.raises(aclgpu.AclError):
+            e.watch_recheck(cur, "nosuchtype", "view", "user", "paul")
 
 
 def test_concurrent_mixed_calls_are_safe_and_consistent(aclgpu):

@@ -173,6 +173,74 @@ def test_watch_feed(aclgpu_lib):
     e.close()
 
 
+def test_watch_wait_blocks_until_the_feed_moves(aclgpu_lib):
+    """acl_watch_wait: the blocking half of Watch.Recv (pkg/authz/watch.go:38) -- a condition variable on the write path instead of a sleeping
+    poll per stream.  It wakes for updates of the watched types only, honours the deadline and the cancel flag, and an update committed BEFORE
+    the wait started is seen without waiting."""
+    import ctypes
+    import threading
+    import time
+    import aclgpu
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    _ups, cur = e.watch_poll(aclgpu.WATCH_FROM_NOW)
+    t0 = time.perf_counter()
+    with pytest.raises(aclgpu.AclError) as ei:  # nothing happens: the deadline
+        e.watch_wait(cur, ["pod"], timeout_s=0.05)
+    assert ei.value.code == aclgpu.ERR_DEADLINE_EXCEEDED and 0.04 < time.perf_counter() - t0 < 1.0
+    # a write to ANOTHER type does not end a wait for pods; a pod write does, promptly
+    woke = []
+
+    def waiter():
+        t1 = time.perf_counter()
+        woke.append((e.watch_wait(cur, ["pod"], timeout_s=5.0), time.perf_counter() - t1))
+
+    th = threading.Thread(target=waiter)
+    th.start()
+    time.sleep(0.05)
+    e.write([(aclgpu.OP_TOUCH, ("namespace", "other", "viewer", "user", "paul", ""))])
+    time.sleep(0.05)
+    assert not woke
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/p1", "creator", "user", "paul", ""))])
+    th.join(timeout=5)
+    assert woke and woke[0][0] == e.revision and woke[0][1] < 1.0
+    ups, nxt = e.watch_poll(cur, ["pod"])
+    assert [u[2][1] for u in ups] == ["ns/p1"]
+    assert e.watch_wait(cur, ["pod"], timeout_s=0.01) == e.revision  # already there: no wait
+    # delete-by-filter wakes waiters too; the cancel flag ends a wait that has no deadline
+    th2_out = []
+    th2 = threading.Thread(target=lambda: th2_out.append(e.watch_wait(nxt, ["pod"], timeout_s=5.0)))
+    th2.start()
+    time.sleep(0.03)
+    assert e.delete_by_filter(rtype="pod", rid="ns/p1") == 1
+    th2.join(timeout=5)
+    assert th2_out == [e.revision]
+    flag = ctypes.c_int32(0)
+    res = []
+
+    def cancelled():
+        try:
+            e.watch_wait(e.revision, [], cancel=flag)
+        except aclgpu.AclError as x:
+            res.append(x.code)
+
+    th3 = threading.Thread(target=cancelled)
+    th3.start()
+    time.sleep(0.03)
+    flag.value = 1
+    th3.join(timeout=5)
+    assert res == [aclgpu.ERR_CANCELLED]
+    with pytest.raises(aclgpu.AclError):
+        e.watch_wait(cur, ["nosuchtype"], timeout_s=0.01)
+    # the bulk re-check of a poll needs the device; a poll without updates does not
+    assert e.watch_recheck(e.revision, "pod", "view", "user", "paul") == ([], e.revision)
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/p2", "creator", "user", "paul", ""))])
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.watch_recheck(nxt, "pod", "view", "user", "paul")
+    assert ei.value.code == aclgpu.ERR_UNAVAILABLE
+    e.close()
+
+
 def test_keep_and_check_one_need_a_gpu(aclgpu_lib):
     import aclgpu
     b = kat_runner.load_bootstrap()
@@ -209,3 +277,38 @@ def test_object_names_of_every_length_round_trip(aclgpu_lib):
             e.intern("user", bad)
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT
     assert [e.object_name("user", i) for i in ids[:21]] == names[:21]
+
+
+def test_bootstrap_yaml_files(aclgpu_lib):
+    """acl_load_bootstrap_yaml: the YAML form the reference boots from (the embedded pkg/spicedb/bootstrap.yaml:1-40, a path in the endpoint
+    URL options.go:313-316, a byte map spicedb.go:19-21).  The reference's own default file, re-indented and re-chomped, comments, several
+    documents, keys the proxy does not use; what is outside the supported subset fails loudly."""
+    import aclgpu
+    b = kat_runner.load_bootstrap()
+    indent = lambda text, n: "\n".join((" " * n + ln) if ln.strip() else "" for ln in text.split("\n"))  # noqa: E731
+    default = "schema: |-\n" + indent(b["schema"], 2) + "\nrelationships: |-\n" + indent("\n".join(b["relationships"]), 2) + "\n"
+    e = aclgpu.Engine(store_only=True)
+    e.load_bootstrap_yaml(default)
+    assert [r[:6] for r in e.read(rtype="namespace")] == [kat_runner.parse_rel(x) for x in b["relationships"]]
+    assert e.type_id("workflow") >= 0 and e.relation_id("workflow", "idempotency_key") >= 0
+    # other indentation, keep / clip chomping, comments, a `---` second document with more relationships, unknown keys with bodies
+    doc = ("# proxy bootstrap\nschemaFile: ignored.zed\nassertions:\n  assertTrue:\n    - \"pod:a#view@user:b\"\n\nschema: |+4\n" + indent(b["schema"], 4) +
+           "\n\nrelationships: |   # seed\n      namespace:dev#viewer@user:paul\n      // a comment line of the relationship format\n\n      namespace:dev#creator@user:chani\n"
+           "---\nrelationships: >-\n  pod:dev/p1#creator@user:paul\n\n  pod:dev/p1#namespace@namespace:dev\n...\n")
+    e.load_bootstrap_yaml(doc)
+    assert sorted(r[1] + "#" + r[2] + "@" + r[4] for r in e.read(rtype="namespace")) == ["dev#creator@chani", "dev#viewer@paul"]
+    assert sorted(r[2] for r in e.read(rtype="pod")) == ["creator", "namespace"]
+    # one-line scalars: plain, single- and double-quoted
+    e.load_bootstrap_yaml("schema: 'definition user {}  definition doc { relation viewer: user }'\nrelationships: \"doc:d1#viewer@user:u1\\ndoc:d2#viewer@user:u2\"\n")
+    assert sorted(r[1] for r in e.read(rtype="doc")) == ["d1", "d2"]
+    e.load_bootstrap_yaml("schema: definition user {}\n")
+    assert e.type_id("user") == 0 and e.type_id("doc") < 0
+    for bad in ["relationships: |-\n  a:b#c@d:e\n",                      # no schema
+                "schema: |-\n  definition user {}\nschema: |-\n  definition doc {}\n",  # duplicate key
+                "schema: &anchor x\n", "schema: [a, b]\n", "  schema: x\n", "schema\n", "schema: \"unterminated\n",
+                "schema:\n  multi\n  line plain\n", "schema: |-\n\tdefinition user {}\n",
+                "schema: |-\n  definition user {}\nrelationships: |-\n  not a relationship\n"]:
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.load_bootstrap_yaml(bad)
+        assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, bad
+    e.close()
