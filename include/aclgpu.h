@@ -456,6 +456,7 @@ typedef struct {
     double rev_local_ms;           /* HIP-event time of the single-launch LookupResources kernel (k_rev_local) */
     uint64_t rev_local_passes;     /* LookupResources groups answered by that kernel (one launch for all reverse levels) */
     uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
+    uint64_t ids_recycled;         /* object ids given a new name after their object had lost its last relationship (since the schema was loaded) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

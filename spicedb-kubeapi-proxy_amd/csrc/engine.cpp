@@ -31,7 +31,6 @@ PassCtx::~PassCtx() {
     if (stream) (void)hipStreamSynchronize(stream);
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     if (h_status) (void)hipHostFree(h_status);
-    if (chain_ev) (void)hipEventDestroy(chain_ev);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -57,7 +56,6 @@ int new_ctx(acl_engine *h, DevState *d, std::unique_ptr<PassCtx> *out, int index
     c->index = index;
     c->dev = d;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->chain_ev, hipEventDisableTiming));
     HIP_TRY(c->d_status.ensure(kStatusWords));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
     int rc = alloc_frontier(h, c.get(),
@@ -452,7 +450,7 @@ int device_of(acl_engine *h, const void *p) {
     return a.device;
 }
 
-int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, bool chain_lane, int on_device) {
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, int on_device) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     int rc = check_opts(opts);
@@ -481,12 +479,7 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
         rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;
     }
-    // a context from the pool (created on demand up to max_ctx).  Chip-filling host batches (chain_lane) only ever run on the first kChainLanes
-    // contexts: that is the admission queue of the chained-kernel pipeline -- callers 4 ... N wait HERE for a lane, before they have put a
-    // byte on any stream, and hold it until their results are back.  The runtime multiplexes streams onto 4 hardware queues; a fourth
-    // stream carrying such a batch (even only its D2H copies) shares a queue with one that waits for an event and halved everybody's
-    // throughput (4 callers 566 M/s against 748 M/s for 2-3, profiles/r02_hostid_modes_chained.txt).  Everything else prefers the other contexts.
-    const uint32_t lanes = std::min<uint32_t>(kChainLanes, h->max_ctx);
+    // a context from the pool (created on demand up to max_ctx per replica)
     std::unique_lock<std::mutex> lk(h->pool_mu);
     for (;;) {
         // Replicas (engines opened on several devices): the least loaded one that can serve the call -- ties go round the devices, so N
@@ -498,17 +491,9 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
         for (size_t k = 0; k < nd; k++) {
             DevState *d = h->devs[(d0 + k) % nd].get();
             if (on_device >= 0 && d->device != on_device) continue;
-            int pick = -1;
-            for (int i = 0; i < (int)d->free_ctxs.size(); i++) {
-                const int idx = d->free_ctxs[i]->index;
-                if (chain_lane ? (idx < (int)lanes && (pick < 0 || idx < d->free_ctxs[pick]->index))
-                               : (pick < 0 || (idx >= (int)lanes) > (d->free_ctxs[pick]->index >= (int)lanes) ||
-                                  ((idx >= (int)lanes) == (d->free_ctxs[pick]->index >= (int)lanes) && idx > d->free_ctxs[pick]->index)))
-                    pick = i;
-            }
-            const bool may_create = d->ctxs.size() < (chain_lane ? lanes : h->max_ctx);
-            // (a free lane is the last resort of a call that is not chained: a new context first)
-            const bool take = pick >= 0 && (chain_lane || d->free_ctxs[pick]->index >= (int)lanes || !may_create);
+            const int pick = d->free_ctxs.empty() ? -1 : (int)d->free_ctxs.size() - 1;  // (the one released last: its buffers are the warmest)
+            const bool may_create = d->ctxs.size() < h->max_ctx;
+            const bool take = pick >= 0;
             if (!take && !may_create) continue;
             if (!bd || d->in_use < bd->in_use) {
                 bd = d;
@@ -568,8 +553,8 @@ void Eval::end() {
             c->dev->free_ctxs.push_back(c);
             c->dev->in_use--;
         }
-        // every waiter: chain_lane callers can only take contexts 0..kChainLanes-1 and ordinary callers prefer the others -- a single wake-up
-        // that lands on a waiter who cannot use THIS context is consumed while another waiter sleeps next to a free context
+        // every waiter: one that asked for a replica on a particular device cannot use a context of another one, and a wake-up it consumed
+        // would leave a second waiter asleep next to a free context
         h->pool_cv.notify_all();
         c = nullptr;
     }
@@ -641,7 +626,7 @@ int combine_prepare(acl_engine *h, PassCtx *c, DevGraph *g, uint32_t n, uint32_t
     return ACL_OK;
 }
 
-// enqueue-only half (memset of the flag, the launch, the flag's read-back): what check_ids_host chains on the device
+// enqueue-only half (memset of the flag, the launch, the flag's read-back)
 static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout) {
     const LocalGeom G = local_geom(h, c, n);
     if (G.cap < 256) return kTakeLevelLoop;
@@ -676,41 +661,22 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
 static bool walk_allowed(acl_engine *h, size_t n);
 static void walk_outcome(acl_engine *h, size_t n, int rc);
 
-// Chip-filling single-launch passes follow each other ON THE DEVICE: the context's stream waits for the event behind the previous
-// such kernel, the kernel is enqueued (context buffers d_items -> d_perm / d_errout), its own event becomes the one the next pass
-// waits for.  Nothing is synchronised here.  kChainDeclined: take the turn-taking path instead (batch too small, walk switched off / backing off).
-bool chains(acl_engine *h, size_t n) { return n >= kChainItems && n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1; }
-int chained_enqueue(acl_engine *h, PassCtx *c, size_t n, bool asked) {
-    // asked: the caller already drew this batch's walk_allowed() -- the question counts the back-off down, so it is put ONCE per batch
-    if (!(chains(h, n) && (asked || walk_allowed(h, n)))) return kChainDeclined;
-    HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
-    HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
-    std::lock_guard<std::mutex> ck(c->dev->chain_mu);  // (per replica: kernels of different devices have nothing to wait for)
-    hipError_t he = c->dev->chain_prev ? hipStreamWaitEvent(c->stream, c->dev->chain_prev, 0) : hipSuccess;
-    if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipStreamWaitEvent: ") + hipGetErrorString(he));
-    int rc = local_enqueue(h, c, h->dev_graph(c), c->d_items.p, (uint32_t)n, c->d_perm.p, c->d_errout.p);
-    if (rc == kTakeLevelLoop) return kChainDeclined;
-    if (rc) return rc;
-    he = hipEventRecord(c->chain_ev, c->stream);
-    if (he != hipSuccess) return fail(ACL_ERR_INTERNAL, std::string("hipEventRecord: ") + hipGetErrorString(he));
-    c->dev->chain_prev = c->chain_ev;
-    return ACL_OK;
-}
-// ... and its other half: synchronises the context's stream.  kChainDeclined: a block ran out of private frontier -- redo on the level loop.
-int chained_finish(acl_engine *h, PassCtx *c, size_t n) {
-    int rc = local_finish(h, c, (uint32_t)n);
-    walk_outcome(h, n, rc);
-    return rc == kTakeLevelLoop ? kChainDeclined : rc;
-}
-
 // The same for a batch in HOST memory, with no copy engine in the path: the kernel reads the items from pinned host memory
 // and writes the answers (and its overflow flag) straight back into pinned host memory, so a pass is ONE launch and ONE
 // stream synchronisation -- no H2D, no flag memset, no D2H copies, each of which costs a few microseconds of API time that a
 // 64-item batch cannot amortise.  Returns ACL_ERR_RESOURCE_EXHAUSTED (quietly) when the batch must take the level loop.
 static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *items, uint32_t n, uint8_t *perm_out, int32_t *err_out, bool *attempted) {
     *attempted = false;
-    const LocalGeom G = local_geom(h, c, n);
-    if (G.cap < 256 || n > h->hostmap_max || G.nunits > G.nblocks) return kTakeLevelLoop;  // (units handed out through a device counter: the copying path)
+    // A batch beyond what one launch takes with one unit per resident block (524 288 items on this chip) goes as SUB-PASSES of equal size: one
+    // launch each, back to back on the context's stream, every one reading its slice of the items from -- and answering into -- the caller's
+    // pinned memory, ONE synchronisation for all (round 4: this retired the copying pipeline -- look-ahead H2D, lanes, kernels chained on the
+    // device through events, a completer thread -- that served only such batches).
+    const bool wide0 = n >= h->local_wide_min;
+    const uint64_t per_launch = (uint64_t)(wide0 ? c->dev->local_blocks_wide : c->dev->local_blocks) * local_unit_max(wide0);
+    const uint32_t npass = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n + per_launch - 1) / per_launch);
+    const uint32_t chunk = npass == 1 ? n : (uint32_t)((((uint64_t)n + npass - 1) / npass + 63) / 64 * 64);
+    const LocalGeom G = local_geom(h, c, std::min(n, chunk));
+    if (G.cap < 256 || n > h->hostmap_max || G.nunits > G.nblocks || npass > 15) return kTakeLevelLoop;
     *attempted = true;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
@@ -723,10 +689,10 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     }
     const bool pin_p = h->is_pinned(perm_out, n), pin_e = err_out && h->is_pinned(err_out, (size_t)n * sizeof(int32_t));
     HIP_TRY(c->h_out.ensure(64 + (size_t)n * 5));
-    uint32_t *flag = (uint32_t *)c->h_out.p;
+    uint32_t *flag = (uint32_t *)c->h_out.p;  // one overflow flag per sub-pass (16 words)
     int32_t *h_err = pin_e ? err_out : (int32_t *)((char *)c->h_out.p + 64);
     uint8_t *h_perm = pin_p ? perm_out : (uint8_t *)c->h_out.p + 64 + (size_t)n * 4;
-    *flag = 0;
+    std::memset(flag, 0, 64);
     void *d_in = nullptr, *d_flag = nullptr, *d_perm = nullptr, *d_errp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_in, const_cast<void *>(src), 0));
     HIP_TRY(hipHostGetDevicePointer(&d_flag, c->h_out.p, 0));
@@ -737,20 +703,26 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     //  with 262 144-item batches measure 886 / 890 / 914 / 916 M decisions/s, ABOVE the 873 M/s of back-to-back device-resident launches, and a
     //  host mutex around launch + synchronise costs a third of that; profiles/r03_hostmapped_batches.txt.)
     DevGraph g = h->dev_graph(c);
-    if (int rc = combine_prepare(h, c, &g, n, G.nblocks, G.rpw)) return rc;
-    ev_begin(c, 2);
-    launch_check_local(c->stream, g, (const uint4 *)d_in, n, G.rpw, G.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, G.cap, (uint32_t *)d_flag, c->d_has.p, c->d_err.p,
-                       (uint8_t *)d_perm, (int32_t *)d_errp, nullptr, 0, 0, G.wide);
-    ev_end(c);
+    if (int rc = combine_prepare(h, c, &g, std::min(n, chunk), G.nblocks, G.rpw)) return rc;  // (the sub-passes follow each other on one stream: they share the scratch)
+    for (uint32_t k = 0; k < npass; k++) {
+        const uint32_t off = k * chunk, m = std::min(chunk, n - off);
+        const LocalGeom Gk = k + 1 < npass || npass == 1 ? G : local_geom(h, c, m);  // (the last one may be shorter)
+        ev_begin(c, 2);
+        launch_check_local(c->stream, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, Gk.cap, (uint32_t *)d_flag + k, c->d_has.p,
+                           c->d_err.p, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide);
+        ev_end(c);
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
-    if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
-    if (*flag) return kTakeLevelLoop;
+    for (uint32_t k = 0; k < npass; k++)
+        if (flag[k] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+    for (uint32_t k = 0; k < npass; k++)
+        if (flag[k]) return kTakeLevelLoop;
     if (!pin_p) std::memcpy(perm_out, h_perm, n);
     if (err_out && !pin_e) std::memcpy(err_out, h_err, (size_t)n * sizeof(int32_t));
     c->stats.check_items += n;
-    c->stats.check_passes++;
-    c->stats.local_passes++;
+    c->stats.check_passes += npass;
+    c->stats.local_passes += npass;
     return ACL_OK;
 }
 
@@ -758,7 +730,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
 bool hostmap_takes(acl_engine *h, size_t n) {
     if (!(n <= h->local_max_items && n <= h->max_sub_batch && h->shard.world == 1 && n <= h->hostmap_max)) return false;
     const bool wide = n >= h->local_wide_min;
-    return n <= (uint64_t)(wide ? h->dev0().local_blocks_wide : h->dev0().local_blocks) * local_unit_max(wide);  // (one unit per resident block; replicas are alike)
+    return n <= 15 * (uint64_t)(wide ? h->dev0().local_blocks_wide : h->dev0().local_blocks) * local_unit_max(wide);  // (up to 15 sub-passes of one unit per resident block; replicas are alike)
 }
 
 // A graph whose walks keep outgrowing the blocks' private regions should not pay for a failed walk before every level loop: after an
@@ -900,9 +872,6 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         std::memcpy(c->h_in.p, items, n * sizeof(acl_item_t));
         src = c->h_in.p;
     }
-    // Chained (chip-filling) batches run on one of kChainLanes contexts: the caller was admitted to a lane in Eval::begin and keeps it until
-    // its results are back (callers beyond the lanes wait there).
-    const bool chained = chains(h, n) && (uint32_t)c->index < std::min<uint32_t>(kChainLanes, h->max_ctx);  // (a caller that did not ask for a lane takes turns instead)
     HIP_TRY(hipMemcpyAsync(c->d_items.p, src, n * sizeof(acl_item_t), hipMemcpyHostToDevice, c->stream));
     const bool pin_p = h->is_pinned(perm_out, n), pin_e = !err_out || h->is_pinned(err_out, n * sizeof(int32_t));
     uint8_t *hp = perm_out;
@@ -917,31 +886,11 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         if (err_out) HIP_TRY(hipMemcpyAsync(he, c->d_errout.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         return ACL_OK;
     };
-    // The common case is ONE launch (the single-launch walk): H2D, kernel, overflow-flag read-back and result copies all go onto the stream
-    // and the host synchronises ONCE (three synchronisations -- after the H2D, after the kernel, after the D2H -- cost a 65 536-item call
-    // 30-40 us of wake-ups, a third of its kernel).  Only a walk that overflowed its private regions comes back for the level loop.
+    // (What is left of the copying path: batches the host-mapped walk above does not take -- switched off, backing off after an overflow, beyond
+    // its sub-pass limit.)  ONE launch where the single-launch walk takes it: H2D, kernel, overflow-flag read-back and result copies all go onto
+    // the stream and the host synchronises ONCE.  Only a walk that overflowed its private regions comes back for the level loop.
     int rc = kTakeLevelLoop;
-    if (chained && !tried && allowed) {
-        tried = true;
-        // (The copying pipeline: what a batch takes when it needs more units than the chip holds blocks -- beyond 262 144 items -- and what
-        //  submitted tickets use.)  With copies in the picture two such batches' kernels running at once only took turns (round 1's chunked
-        //  kernels: 4 in flight 190 M/s, 1 at a time 308 M/s).  What is worth overlapping is this batch's
-        // copies with ANOTHER batch's kernel -- and the kernels themselves should follow each other without a gap.  So the
-        // turn-taking happens ON THE DEVICE: this context's stream waits for the event the previous batch's kernel recorded,
-        // the single-launch kernel is enqueued behind it (the H2D above is already under way and is not held up), and its
-        // own event becomes the one the next caller waits for; the result copies follow the event, under the next batch's kernel.
-        // (Only for batches whose kernel is long: a cross-stream event wait costs the runtime ~20 us of queue-to-queue signalling, more
-        //  than the host gap it removes when the kernel itself takes 20 us -- C2's 65 536-item batches: 846 M/s with the mutex, 496 M/s chained.)
-        rc = chained_enqueue(h, c, n, true);
-        if (!rc) {
-            rc = results_d2h();
-            if (rc) return rc;
-            rc = chained_finish(h, c, n);
-        } else if (rc != kChainDeclined) {
-            (void)hipStreamSynchronize(c->stream);
-        }
-        if (rc == kChainDeclined) rc = kTakeLevelLoop;
-    } else if (allowed && !tried) {
+    if (allowed && !tried) {
         tried = true;
         HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
         HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
@@ -1346,7 +1295,7 @@ template <class Items>
 static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
     Eval ev;
-    int rc = ev.begin(h, false, CallOpts(), -1, false, chains(h, n));
+    int rc = ev.begin(h, false);
     if (rc) return rc;
     PassCtx *c = ev.c;
     HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
@@ -1587,7 +1536,7 @@ int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const c
         sr = sc.defs[st].find(srel);
         if (sr < 0) return fail(ACL_ERR_FAILED_PRECONDITION, std::string("relation `") + srel + "` not found under definition `" + stype + "`");
     }
-    *sub_out = h->store.objects(st).intern(sid);
+    *sub_out = h->store.intern_object(st, sid);  // (a subject nobody has a relationship with: reusable after the quarantine, store.hpp)
     *rt_out = rt;
     *pm_out = pm;
     *st_out = st;
@@ -1802,7 +1751,7 @@ int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_ou
     const Schema &sc = h->store.schema();
     if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_intern: bad argument");
     if (!h->raw_intern && !valid_object_id(object_id)) return fail(ACL_ERR_INVALID_ARGUMENT, std::string("acl_intern: `") + object_id + "` does not match the API's object id pattern");  // (validate.hpp: names in the tables are well-formed)
-    *id_out = h->store.objects(type).intern(object_id);
+    *id_out = h->store.intern_object(type, object_id, true);  // (the caller keeps this id: never recycled)
     return ACL_OK;
 }
 int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out) {
@@ -1928,7 +1877,7 @@ int acl_sync(acl_engine_t *h) {
 int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out) {
     if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids_device: NULL buffer");
     Eval ev;
-    int rc = ev.begin(h, false, CallOpts(), -1, false, false, device_of(h, d_perm_out));  // (a replica on the device the caller's buffers live on)
+    int rc = ev.begin(h, false, CallOpts(), -1, false, device_of(h, d_perm_out));  // (a replica on the device the caller's buffers live on)
     if (rc) return rc;
     rc = check_device(h, ev.c, (const uint4 *)d_items, n, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
     if (rc) return rc;
@@ -1950,7 +1899,7 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
     }
     if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
     Eval ev;
-    int rc = ev.begin(h, false, opts, -1, false, chains(h, n));
+    int rc = ev.begin(h, false, opts);
     if (rc) return rc;
     return check_ids_host(h, ev.c, items, n, perm_out, err_out);
 }
@@ -2015,8 +1964,14 @@ void acl_free(void *p) { std::free(p); }
 
 int acl_stats(acl_engine_t *h, acl_stats_t *out) {
     if (!out) return fail(ACL_ERR_INVALID_ARGUMENT, "out is NULL");
+    uint64_t recycled;
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        recycled = h->store.ids_recycled();
+    }
     std::lock_guard<std::mutex> lk(h->stats_mu);
     *out = h->stats;
+    out->ids_recycled = recycled;
     return ACL_OK;
 }
 int acl_stats_reset(acl_engine_t *h) {

@@ -204,7 +204,6 @@ struct PinnedBuf {
 
 constexpr int kNoContextFree = -1001;  // internal (Eval::begin with try_only)
 constexpr size_t kComputeTokenItems = 32768;  // host-buffer batches at least this large run their kernels one batch at a time
-constexpr size_t kChainItems = 131072;         // ... and from here on they are chained on the device instead of taking turns through a host mutex
 
 // per-call cancellation / deadline (reference: LookupResources runs on the HTTP request's ctx and is abandoned when it is
 // cancelled, responsefilterer.go:165-170; the prefilter join times out after 10 s, responsefilterer.go:44,196-204)
@@ -221,7 +220,6 @@ struct PassCtx {
     int index = 0;           // among the contexts of ITS device
     DevState *dev = nullptr;  // the replica (device) this context's stream and buffers live on
     hipStream_t stream = nullptr;
-    hipEvent_t chain_ev = nullptr;  // recorded behind this context's single-launch kernel (engine::chain_prev)
     // frontier
     DevArray<uint4> d_fbuf[2];
     DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow | export counters
@@ -318,8 +316,6 @@ struct DevState {
     uint32_t in_use = 0;  // contexts handed out (Eval::begin spreads calls over the replicas by it)
     uint64_t calls = 0;   // evaluations this replica has been handed since open (acl_replica_calls; under pool_mu)
     std::mutex compute_mu;  // turn-taking of chip-filling batches on the level loop (check_ids_host's fallback, the submit/wait pipeline)
-    std::mutex chain_mu;    // chip-filling single-launch passes follow each other ON THE DEVICE: each waits for the previous one's event
-    hipEvent_t chain_prev = nullptr;  // (a context's chain_ev; contexts live until acl_close)
 };
 
 struct acl_engine {
@@ -459,9 +455,8 @@ struct Eval {
     ~Eval() { end(); }
     // rev_key_slot >= 0: the lookup's subject is `type#relation` of that slot -- the reverse rows must cover its id space
     // try_only: never wait for a context -- kNoContextFree when every one is taken
-    // chain_lane: the call carries a chip-filling host batch: only the first kChainLanes contexts will do (the chained pipeline's admission queue)
     // on_device >= 0: only a replica on that HIP device will do (calls that are handed device pointers)
-    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, bool chain_lane = false, int on_device = -1);
+    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, int on_device = -1);
     void end();
 };
 
@@ -499,11 +494,6 @@ FilterText to_filter(const acl_filter_t *f);
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
 void intern_pool_destroy(acl_engine_t *h);
 bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n items is answered by the kernel across PCIe (no copies)
-constexpr uint32_t kChainLanes = 3;  // contexts (streams) that carry chip-filling host batches
-bool chains(acl_engine *h, size_t n);  // does a host batch of n items take the chained-kernel pipeline?
-constexpr int kChainDeclined = -1003;  // internal: chained_enqueue / chained_finish hand the batch to the turn-taking path
-int chained_enqueue(acl_engine *h, PassCtx *c, size_t n, bool asked = false);  // context buffers d_items -> d_perm / d_errout; nothing synchronised
-int chained_finish(acl_engine *h, PassCtx *c, size_t n);
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
 int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,

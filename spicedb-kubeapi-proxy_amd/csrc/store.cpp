@@ -44,8 +44,10 @@ void ObjectTable::grow() {
     old.swap(slots_);
     slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
     const size_t mask = slots_.size() - 1;
+    used_ -= tombs_;
+    tombs_ = 0;
     for (const Slot &s : old) {
-        if (s.id == 0xFFFFFFFFu) continue;
+        if (s.id == 0xFFFFFFFFu || s.id == kTomb) continue;
         size_t i = hash(names_[name_of_[s.id]]) & mask;
         while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
         slots_[i] = s;
@@ -59,7 +61,7 @@ bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) c
     for (size_t i = h & mask;; i = (i + 1) & mask) {
         const Slot &s = slots_[i];
         if (s.id == 0xFFFFFFFFu) return false;
-        if (s.tag == tag) {
+        if (s.tag == tag && s.id != kTomb) {
             const size_t n = name.size();
             if (n <= kInline) {
                 if (s.len == n && !std::memcmp(s.inl, name.data(), n)) {
@@ -96,11 +98,51 @@ uint32_t ObjectTable::intern(std::string_view name) {
     const uint64_t h = hash(name);
     const size_t mask = slots_.size() - 1;
     size_t i = h & mask;
-    while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = (i + 1) & mask;
+    if (slots_[i].id == kTomb) tombs_--;
+    else used_++;
     slots_[i] = make_slot(h, id, names_.back());
-    used_++;
     count_.store(id + 1, std::memory_order_release);
     return id;
+}
+void ObjectTable::rename(uint32_t id, std::string_view new_name) {
+    std::string &stored = names_[name_of_[id]];
+    {   // the old name's slot becomes a tombstone
+        const uint64_t h = hash(stored);
+        const size_t mask = slots_.size() - 1;
+        for (size_t i = h & mask;; i = (i + 1) & mask) {
+            Slot &s = slots_[i];
+            if (s.id == 0xFFFFFFFFu) break;  // (cannot happen: the name is in the table)
+            if (s.id == id) {
+                s = Slot{0, kTomb, 0, {}, nullptr};
+                tombs_++;
+                break;
+            }
+        }
+    }
+    stored.assign(new_name.data(), new_name.size());
+    if (tombs_ * 4 > slots_.size()) {  // tombstones lengthen every probe: re-hash in place
+        std::vector<Slot> old;
+        old.swap(slots_);
+        slots_.assign(old.size(), Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
+        used_ -= tombs_;
+        tombs_ = 0;
+        const size_t mask = slots_.size() - 1;
+        for (const Slot &s : old) {
+            if (s.id == 0xFFFFFFFFu || s.id == kTomb) continue;
+            size_t i = hash(names_[name_of_[s.id]]) & mask;
+            while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+            slots_[i] = s;
+        }
+    }
+    if ((used_ + 1) * 2 > slots_.size()) grow();
+    const uint64_t h = hash(new_name);
+    const size_t mask = slots_.size() - 1;
+    size_t i = h & mask;
+    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = (i + 1) & mask;
+    if (slots_[i].id == kTomb) tombs_--;
+    else used_++;
+    slots_[i] = make_slot(h, id, stored);
 }
 const std::string *ObjectTable::name(uint32_t id) const {
     if (id >= name_of_.size() || name_of_[id] == 0xFFFFFFFFu) return nullptr;
@@ -168,15 +210,87 @@ Status Store::load_schema(const std::string &text) {
     }
     // `T:*` subjects: the name "*" gets an id in T's table right away, so that programs built before the first wildcard relationship
     // exists can already name the wildcard subject's row
+    refcnt_.assign(schema_.defs.size(), {});
+    freed_.assign(schema_.defs.size(), {});
+    freed_at_.assign(schema_.defs.size(), {});
+    no_recycle_.assign(schema_.defs.size(), 0);
+    recycled_rev_.clear();
+    if (const char *ev = getenv("ACL_ID_QUARANTINE_MS")) reuse_quarantine_ms_ = std::max(0, atoi(ev));  // test knob
     wildcard_id_.assign(schema_.defs.size(), 0xFFFFFFFFu);
     for (const Definition &d : schema_.defs)
         for (const Member &m : d.members)
             for (const SubjectClass &c : m.classes)
-                if (c.wildcard && wildcard_id_[c.stype] == 0xFFFFFFFFu) wildcard_id_[c.stype] = objects_[c.stype].intern("*");
+                if (c.wildcard && wildcard_id_[c.stype] == 0xFFFFFFFFu) wildcard_id_[c.stype] = intern_object(c.stype, "*", true);
     revision_++;
     log_.clear();  // ids of the previous schema mean nothing now
     log_floor_ = revision_;
     return Status::Ok();
+}
+
+static int64_t steady_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void Store::ref(int type, uint32_t id, int delta) {
+    if (no_recycle_[type]) return;
+    auto &rc = refcnt_[type];
+    if (rc.size() <= id) rc.resize((size_t)id + 1 + rc.size() / 2, 0);
+    uint32_t &c = rc[id];
+    if (delta > 0) {
+        c++;
+    } else if ((c & ~kPinned) > 0) {
+        c--;
+        if (c == 0) note_free(type, id);  // (pinned ids never reach 0)
+    }
+}
+// the object just became (or was born) unreferenced: on the free list, stamped -- an older entry of the same id is void from here on
+void Store::note_free(int type, uint32_t id) {
+    auto &fa = freed_at_[type];
+    if (fa.size() <= id) fa.resize((size_t)id + 1 + fa.size() / 2, 0);
+    const int64_t t = steady_ms();
+    fa[id] = t;
+    freed_[type].push_back(Freed{id, t});
+}
+void Store::ref_key(int slot, int cls, uint64_t key, int delta) {
+    auto [t, m] = schema_.slot_owner[slot];
+    ref(t, (uint32_t)(key >> 32), delta);
+    ref(schema_.defs[t].members[m].classes[cls].stype, (uint32_t)key, delta);
+}
+
+uint32_t Store::intern_object(int type, std::string_view name, bool pin, bool hold) {
+    ObjectTable &tab = objects_[type];
+    uint32_t id;
+    if (tab.find(name, &id)) {
+        if (pin && !no_recycle_[type]) {
+            auto &rc = refcnt_[type];
+            if (rc.size() <= id) rc.resize((size_t)id + 1 + rc.size() / 2, 0);
+            rc[id] |= kPinned;
+        }
+        return id;
+    }
+    // a NEW name: the oldest free id that has sat out its quarantine, if its object is still unreferenced; else the next dense id
+    auto &fq = freed_[type];
+    const int64_t now_ms = steady_ms();
+    while (!no_recycle_[type] && !fq.empty() && now_ms - fq.front().at_ms >= reuse_quarantine_ms_) {
+        const Freed f = fq.front();
+        fq.pop_front();
+        // void entries: referenced (or pinned) again since, or freed AGAIN later (the younger entry carries the quarantine)
+        if (f.id >= refcnt_[type].size() || refcnt_[type][f.id] != 0 || !tab.name(f.id) || f.id >= freed_at_[type].size() || freed_at_[type][f.id] != f.at_ms) continue;
+        tab.rename(f.id, name);
+        recycled_rev_[(uint64_t)type << 32 | f.id] = revision_;
+        ids_recycled_++;
+        if (pin) refcnt_[type][f.id] |= kPinned;
+        else if (hold) refcnt_[type][f.id]++;  // (the caller's reference: released with ref(type, id, -1) once its relationships are in)
+        else note_free(type, f.id);  // (unreferenced until a relationship names it: a lookup subject that never gets one is reusable again)
+        return f.id;
+    }
+    id = tab.intern(name);
+    if (!no_recycle_[type]) {
+        auto &rc = refcnt_[type];
+        if (rc.size() <= id) rc.resize((size_t)id + 1 + rc.size() / 2, 0);
+        if (pin) rc[id] |= kPinned;
+        else if (hold) rc[id]++;
+        else note_free(type, id);
+    }
+    return id;
 }
 
 int64_t Store::now() const {
@@ -256,6 +370,7 @@ size_t Store::gc_expired(int64_t now) {
         if (ct.contains(e.key)) {
             auto &kv = ct.keys.mut();
             kv.erase(std::lower_bound(kv.begin(), kv.end(), e.key));
+            ref_key(e.slot, e.cls, e.key, -1);
         }
         ct.expiry.erase(e.key);
         expiry_index_.erase(expiry_index_.begin());
@@ -269,7 +384,7 @@ size_t Store::gc_expired(int64_t now) {
     return n;
 }
 
-Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
+Status Store::resolve(const RelText &r, Resolved *out) {
     if (r.rtype.empty() || r.rid.empty() || r.rel.empty() || r.stype.empty() || r.sid.empty())
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid relationship: empty field");
     {   // API validation comes first and fails the whole request (validate.hpp): ill-formed names and ids are InvalidArgument, not "not found"
@@ -307,13 +422,9 @@ Status Store::resolve(const RelText &r, bool create_ids, Resolved *out) {
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "subjects of type `" + r.stype + (wild ? ":*" : sr == kNoRelation ? "" : "#" + r.srel) + "` are not allowed on relation `" + r.rtype + "#" + r.rel + "`");
     if (r.expires_at && !mem.classes[out->cls].expiring)
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "relation `" + r.rtype + "#" + r.rel + "` does not allow expiration for that subject type");
-    if (create_ids) {
-        out->res = objects_[rt].intern(r.rid);
-        out->subj = objects_[st].intern(r.sid);
-    } else {  // unknown objects resolve to kUnknownId: they take part in no relationship yet
-        if (!objects_[rt].find(r.rid, &out->res)) out->res = kUnknownId;
-        if (!objects_[st].find(r.sid, &out->subj)) out->subj = kUnknownId;
-    }
+    // unknown objects resolve to kUnknownId: they take part in no relationship yet (Store::write gives them ids once the request is accepted)
+    if (!objects_[rt].find(r.rid, &out->res)) out->res = kUnknownId;
+    if (!objects_[st].find(r.sid, &out->subj)) out->subj = kUnknownId;
     out->expires = r.expires_at;
     return Status::Ok();
 }
@@ -392,7 +503,7 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
     std::vector<Resolved> rs(updates.size());
     for (size_t i = 0; i < updates.size(); i++) {
         if (updates[i].op < ACL_OP_CREATE || updates[i].op > ACL_OP_DELETE) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "invalid update operation");
-        Status s = resolve(updates[i].rel, false, &rs[i]);
+        Status s = resolve(updates[i].rel, &rs[i]);
         if (!s.ok()) return s;
         for (size_t j = 0; j < i; j++)
             if (rs[j].slot == rs[i].slot && rs[j].cls == rs[i].cls && updates[j].rel.rid == updates[i].rel.rid && updates[j].rel.sid == updates[i].rel.sid)
@@ -417,8 +528,18 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
             skip[i] = rs[i].res == kUnknownId || rs[i].subj == kUnknownId;
             continue;
         }
-        if (rs[i].res == kUnknownId) rs[i].res = objects_[rs[i].rtype].intern(updates[i].rel.rid);
-        if (rs[i].subj == kUnknownId) rs[i].subj = objects_[rs[i].stype].intern(updates[i].rel.sid);
+    }
+    // Every object this write names is HELD (one reference) until its relationships are in: a new name must not be given the id of an object
+    // that is free right now but named by another update of this very request -- nor the id of a sibling interned a line earlier.
+    std::vector<std::pair<int, uint32_t>> held;
+    for (size_t i = 0; i < updates.size(); i++) {
+        if (rs[i].res != kUnknownId) { ref(rs[i].rtype, rs[i].res, +1); held.emplace_back(rs[i].rtype, rs[i].res); }
+        if (rs[i].subj != kUnknownId) { ref(rs[i].stype, rs[i].subj, +1); held.emplace_back(rs[i].stype, rs[i].subj); }
+    }
+    for (size_t i = 0; i < updates.size(); i++) {
+        if (updates[i].op == ACL_OP_DELETE) continue;
+        if (rs[i].res == kUnknownId) { rs[i].res = intern_object(rs[i].rtype, updates[i].rel.rid, false, true); held.emplace_back(rs[i].rtype, rs[i].res); }
+        if (rs[i].subj == kUnknownId) { rs[i].subj = intern_object(rs[i].stype, updates[i].rel.sid, false, true); held.emplace_back(rs[i].stype, rs[i].subj); }
     }
     for (size_t i = 0; i < updates.size(); i++) {
         if (skip[i]) continue;
@@ -429,16 +550,19 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
             if (present) {
                 auto &kv = ct.keys.mut();
                 kv.erase(std::lower_bound(kv.begin(), kv.end(), key));
+                ref_key(rs[i].slot, rs[i].cls, key, -1);
             }
             set_expiry(rs[i].slot, rs[i].cls, key, 0);
         } else {
             if (!present) {
                 auto &kv = ct.keys.mut();
                 kv.insert(std::lower_bound(kv.begin(), kv.end(), key), key);
+                ref_key(rs[i].slot, rs[i].cls, key, +1);
             }
             set_expiry(rs[i].slot, rs[i].cls, key, rs[i].expires);
         }
     }
+    for (const auto &hd : held) ref(hd.first, hd.second, -1);  // (an object left without any relationship goes on its type's free list here)
     revision_++;
     for (size_t i = 0; i < updates.size(); i++)
         if (!skip[i]) log_change(updates[i].op == ACL_OP_DELETE ? ACL_OP_DELETE : ACL_OP_TOUCH, rs[i].slot, rs[i].cls, (uint64_t)rs[i].res << 32 | rs[i].subj);
@@ -491,6 +615,7 @@ Status Store::delete_by_filter(const FilterText &f, uint64_t *ndeleted, uint64_t
         if (ct.contains(h.key)) {
             auto &kv = ct.keys.mut();
             kv.erase(std::lower_bound(kv.begin(), kv.end(), h.key));
+            ref_key(h.slot, h.cls, h.key, -1);
         }
         set_expiry(h.slot, h.cls, h.key, 0);
     }
@@ -525,6 +650,8 @@ void Store::log_change(int op, int slot, int cls, uint64_t key) {
         size_t d = drop;
         while (d < log_.size() && log_[d].revision == log_floor_) d++;
         log_.erase(log_.begin(), log_.begin() + (long)d);
+        for (auto it = recycled_rev_.begin(); it != recycled_rev_.end();)  // (changes older than the floor cannot be replayed anyway)
+            it = it->second <= log_floor_ ? recycled_rev_.erase(it) : std::next(it);
     }
     log_.push_back(Change{revision_, op, slot, cls, key});
 }
@@ -543,6 +670,11 @@ bool Store::changes_since(uint64_t after, const std::vector<int> &types, const s
         if (!it->op) continue;  // garbage collection of a long-expired relationship: not an API write
         const int t = schema_.slot_owner[it->slot].first;
         if (!types.empty() && std::find(types.begin(), types.end(), t) == types.end()) continue;
+        if (!recycled_rev_.empty()) {  // an id that was given a new name AFTER this change: its old name is gone -- the cursor is too old to replay
+            const int st = schema_.defs[t].members[schema_.slot_owner[it->slot].second].classes[it->cls].stype;
+            auto a = recycled_rev_.find((uint64_t)t << 32 | (uint32_t)(it->key >> 32)), b = recycled_rev_.find((uint64_t)st << 32 | (uint32_t)it->key);
+            if ((a != recycled_rev_.end() && a->second >= it->revision) || (b != recycled_rev_.end() && b->second >= it->revision)) return false;
+        }
         fn(*it, rel_text(it->slot, it->cls, it->key));
     }
     return true;
@@ -569,6 +701,7 @@ Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const
         return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: type or relation index out of range");
     const Member &mem = schema_.defs[rtype].members[rel];
     if (mem.is_permission) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: cannot write a relationship to a permission");
+    no_recycle_[rtype] = no_recycle_[stype] = 1;  // caller-chosen ids: their lifetimes are the caller's business (intern_object)
     const bool wild = srel == -2;  // `stype:*` relationships: the subject is the type's wildcard id, subj[] is ignored
     int cls = class_index(mem.slot, stype, srel < 0 ? kNoRelation : srel, wild);
     if (cls < 0) return Status::Err(ACL_ERR_INVALID_ARGUMENT, "add_edges: subject type not allowed on relation");

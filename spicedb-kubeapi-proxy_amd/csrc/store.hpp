@@ -79,25 +79,29 @@ class ObjectTable {
         for (size_t i = h & mask;; i = (i + 1) & mask) {
             const Slot &s = slots_[i];
             if (s.id == 0xFFFFFFFFu) return;
-            if (s.tag == tag) {
+            if (s.id != kTomb && s.tag == tag) {
                 if (s.len > kInline) __builtin_prefetch(s.far);
                 return;
             }
         }
     }
     bool find_hashed(std::string_view name, uint64_t h, uint32_t *id) const;
+    // Gives a RECYCLED id its new name (Store::intern_object): the old name leaves the table (its slot becomes a tombstone, its bytes are
+    // overwritten -- a pointer handed out by acl_object_name for the OLD name dies here), `new_name` must not be in the table.
+    void rename(uint32_t id, std::string_view new_name);
     const std::string *name(uint32_t id) const;  // nullptr for anonymous ids
     uint32_t count() const { return count_.load(std::memory_order_acquire); }
     void reserve_ids(uint32_t n) {  // numeric bulk loads: ids < n exist (anonymous)
         if (n > count()) count_.store(n, std::memory_order_release);
     }
     ObjectTable() = default;
-    ObjectTable(const ObjectTable &o) : names_(o.names_), name_of_(o.name_of_), slots_(o.slots_), used_(o.used_), count_(o.count()) { repoint(); }
+    ObjectTable(const ObjectTable &o) : names_(o.names_), name_of_(o.name_of_), slots_(o.slots_), used_(o.used_), tombs_(o.tombs_), count_(o.count()) { repoint(); }
     ObjectTable &operator=(const ObjectTable &o) {
         names_ = o.names_;
         name_of_ = o.name_of_;
         slots_ = o.slots_;
         used_ = o.used_;
+        tombs_ = o.tombs_;
         count_.store(o.count());
         repoint();
         return *this;
@@ -109,8 +113,9 @@ class ObjectTable {
     // stable: a deque never moves its elements).  A slot that held only {tag, id, pointer} cost every lookup a second dependent miss for the
     // name's bytes -- half of a bulk string call's interning time in tables of millions of names.
     static constexpr uint32_t kInline = 46;
+    static constexpr uint32_t kTomb = 0xFFFFFFFEu;  // a slot whose name left the table (rename): probes walk over it, inserts may take it
     struct alignas(64) Slot {
-        uint32_t tag, id;  // id == 0xFFFFFFFF: empty
+        uint32_t tag, id;  // id == 0xFFFFFFFF: empty; kTomb: tombstone
         uint16_t len;      // of the whole name (names longer than 65 535 bytes are stored with len = 0xFFFF and compared at `far`)
         char inl[kInline];
         const char *far;   // the whole name (len > kInline), else nullptr
@@ -121,12 +126,12 @@ class ObjectTable {
     void grow();
     void repoint() {  // after a copy: the slots must point into THIS table's names
         for (Slot &s : slots_)
-            if (s.id != 0xFFFFFFFFu && s.far) s.far = names_[name_of_[s.id]].c_str();
+            if (s.id != 0xFFFFFFFFu && s.id != kTomb && s.far) s.far = names_[name_of_[s.id]].c_str();
     }
     std::deque<std::string> names_;      // stable addresses (acl_object_name hands out c_str())
     std::vector<uint32_t> name_of_;      // id -> index in names_ (0xFFFFFFFF anonymous); covers ids < name_of_.size()
     std::vector<Slot> slots_;            // power-of-two capacity, load <= 0.5
-    size_t used_ = 0;
+    size_t used_ = 0, tombs_ = 0;  // occupied slots incl. tombstones; tombstones among them
     std::atomic<uint32_t> count_{0};
 };
 
@@ -206,6 +211,20 @@ class Store {
     size_t expiring_relationships() const { return expiry_index_.size(); }
 
     int class_index(int slot, int stype, int srel, bool wildcard = false) const;
+    // ---- object ids are RECYCLED.  Every kube write of the dual-write workflow names a new lock, a new workflow and two
+    // new activities (workflow.go:392-462, activity.go:80-102) whose relationships are gone seconds later (the lock) or collected after 24 h
+    // (the expiring keys, spicedb.go:66): without reuse a proxy doing 1 M kube writes held ~0.8 GB of dead names and dense id spaces -- and
+    // with them every per-type descriptor table and bitmap row -- that only grew.  An id whose object takes part in NO relationship (live,
+    // expired-not-yet-collected, or pending) goes on its type's free list; the next NEW name of the type takes the oldest entry that has
+    // been free for kReuseQuarantineMs (ids behind a LookupResources bitmap still in a caller's hands must not change meaning: the
+    // reference abandons a prefilter after 10 s, responsefilterer.go:44,196-204) instead of extending the id space.  Ids handed out by
+    // acl_intern are the caller's (pinned), ids of numeric bulk loads (add_edges) are caller-chosen: neither is ever recycled.
+    // the id of `name`, new or recycled (names lock held exclusively).  pin: never recycled.  hold: comes with one reference the caller releases
+    // (ref(type, id, -1)) once it has put the object's relationships in -- Store::write
+    uint32_t intern_object(int type, std::string_view name, bool pin = false, bool hold = false);
+    uint64_t ids_recycled() const { return ids_recycled_; }
+    static constexpr int64_t kReuseQuarantineMs = 30000;
+    void set_reuse_quarantine_ms(int64_t ms) { reuse_quarantine_ms_ = ms; }  // test knob (ACL_ID_QUARANTINE_MS)
     uint32_t wildcard_id(int type) const { return wildcard_id_[type]; }  // id of the name "*" in a type some relation allows as `type:*`; else 0xFFFFFFFF
 
     // ---- change feed (WatchService.Watch, reference pkg/authz/watch.go:29-38): every update committed through
@@ -225,13 +244,13 @@ class Store {
     bool raw_changes_since(uint64_t after, std::vector<Change> *out) const;
 
   private:
-    static constexpr uint32_t kUnknownId = 0xFFFFFFFFu;  // resolve(create_ids = false): the object has no id (yet)
+    static constexpr uint32_t kUnknownId = 0xFFFFFFFFu;  // resolve(): the object has no id (yet)
     struct Resolved {
         int slot, cls, rtype, stype;
         uint32_t res, subj;
         int64_t expires;
     };
-    Status resolve(const RelText &r, bool create_ids, Resolved *out);
+    Status resolve(const RelText &r, Resolved *out);
     Status validate_filter(const FilterText &f) const;
     Status validate_preconditions(const std::vector<FilterText> &pre) const;
     Status eval_preconditions(const std::vector<FilterText> &pre, int64_t now);
@@ -253,6 +272,22 @@ class Store {
     bool schema_loaded_ = false;
     std::vector<ObjectTable> objects_;
     std::vector<uint32_t> wildcard_id_;  // [type]
+    // id recycling (see intern_object)
+    static constexpr uint32_t kPinned = 0x80000000u;
+    struct Freed {
+        uint32_t id;
+        int64_t at_ms;  // steady clock
+    };
+    std::vector<std::vector<uint32_t>> refcnt_;  // [type][id] relationships naming the object (either side) | kPinned
+    std::vector<std::deque<Freed>> freed_;        // [type] ids whose count reached zero, oldest first
+    std::vector<std::vector<int64_t>> freed_at_;  // [type][id] stamp of the id's LATEST entry in freed_ (older entries are void)
+    void note_free(int type, uint32_t id);
+    std::vector<uint8_t> no_recycle_;             // [type] a numeric bulk load chose ids of this type: its counts are not tracked
+    std::unordered_map<uint64_t, uint64_t> recycled_rev_;  // type << 32 | id -> revision at which the id changed its name (changes_since)
+    uint64_t ids_recycled_ = 0;
+    int64_t reuse_quarantine_ms_ = kReuseQuarantineMs;
+    void ref(int type, uint32_t id, int delta);
+    void ref_key(int slot, int cls, uint64_t key, int delta);
     std::vector<std::vector<ClassTable>> tables_;
     uint64_t revision_ = 1;
     int64_t now_override_ = 0;

@@ -261,3 +261,65 @@ def test_long_random_write_streams_keep_the_snapshot_exact(aclgpu):
     assert codes[1] > 1400  # patched in place, not rebuilt
     codes = fz.run_patcher(6, 300, universe=8, burst=400)
     assert codes[0] + codes[1] + codes[2] == 300 and codes["adopted"] >= 1 and codes["dropped"] == 0  # (background builds adopted with the writes since replayed)
+
+
+def test_object_ids_are_recycled_and_the_snapshot_stays_exact(aclgpu, monkeypatch):
+    """an object that has lost its last relationship gives its id to the next NEW name of its type (after a quarantine:
+    zero here), so the dense id spaces -- and every table sized by them -- stop growing under the dual-write stream (a new lock, workflow and
+    two activities per kube write: workflow.go:392-462, activity.go:80-102).  The patched host snapshot is verified against the store all
+    along; names resolve to the right ids before and after; ids handed out by acl_intern and ids still referenced are never taken; a Watch
+    cursor from before an id changed its name is refused instead of replaying the old change under the new name."""
+    from oracle import orc
+    from tests import kat_runner
+    monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "0")  # (read when the schema is loaded)
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    o = orc.Oracle(b["schema"])
+    o.write([(orc.OP_TOUCH, r) for r in b["relationships"]])
+    now = 1_700_000_000
+    e.set_now(now)
+    o.set_now(now)
+    pinned = e.intern("lock", "kept-by-its-caller")
+    assert e.selfcheck_snapshot() is False
+    _u, first_cursor = e.watch_poll(aclgpu.WATCH_FROM_NOW)
+    counts = []
+    for i in range(600):
+        lock = ("lock", f"h{i}", "workflow", "workflow", f"w{i}", "")
+        w1 = [(aclgpu.OP_CREATE, ("pod", f"ns/p{i % 40}", "creator", "user", f"u{i % 7}", "")) if i < 40 else (aclgpu.OP_TOUCH, ("pod", f"ns/p{i % 40}", "viewer", "user", f"u{i % 7}", "")),
+              (aclgpu.OP_CREATE, lock), (aclgpu.OP_CREATE, ("workflow", f"w{i}", "idempotency_key", "activity", f"a{i}", ""), now + 5)]
+        w2 = [(aclgpu.OP_DELETE, lock), (aclgpu.OP_CREATE, ("workflow", f"w{i}", "idempotency_key", "activity", f"b{i}", ""), now + 5)]
+        for ups in (w1, w2):
+            e.write(ups, [(aclgpu.PRE_MUST_NOT_MATCH, dict(rtype="lock", rid=f"h{i}", rel="workflow", stype="workflow"))] if ups is w1 else ())
+            o.write(ups)
+            assert e.selfcheck_snapshot() is True, i  # patched in place, verified against the store
+        now += 24 * 3600 // 50  # the clock runs: keys expire after 5 s and are collected 24 h later (spicedb.go:66) -- every 50 kube writes here
+        e.set_now(now)
+        o.set_now(now)
+        if i % 25 == 0:
+            for t in ("lock", "workflow", "pod"):
+                assert sorted(e.read(rtype=t)) == sorted(o.read(rtype=t)), (i, t)
+        counts.append((e.object_count("lock"), e.object_count("workflow"), e.object_count("activity")))
+    # the id spaces plateau: locks are free again right after W2, workflows / activities once their keys are collected
+    assert counts[-1][0] <= 3 and counts[-1][1] <= 60 and counts[-1][2] <= 120, counts[-1]
+    assert counts[-1] == counts[300], (counts[300], counts[-1])
+    assert e.stats()["ids_recycled"] > 1500
+    assert e.find("lock", "kept-by-its-caller") == pinned and e.find("lock", "h5") is None and e.object_name("lock", pinned) == "kept-by-its-caller"
+    # ids still referenced are never taken: every pod keeps its id and its relationships
+    assert e.object_count("pod") == 40 and len(e.read(rtype="pod")) == len(o.read(rtype="pod"))
+    # a cursor from before the ids changed their names cannot be replayed
+    with pytest.raises(aclgpu.AclError) as ei:
+        e.watch_poll(first_cursor, ["lock"])
+    assert ei.value.code == aclgpu.ERR_OUT_OF_RANGE
+    ups_now, _c = e.watch_poll(e.revision - 1)
+    assert all(u[0] == e.revision for u in ups_now)
+    # one request naming several NEW objects while ids are free, plus an object that is free right now (u-free lost its only relationship a
+    # write ago): every name keeps an id of its own -- what the write names is held until its relationships are in
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/once", "viewer", "user", "u-free", ""))])
+    e.write([(aclgpu.OP_DELETE, ("pod", "ns/once", "viewer", "user", "u-free", ""))])
+    many = [(aclgpu.OP_TOUCH, ("pod", f"ns/fresh{k}", "viewer", "user", "u-free" if k == 3 else f"u-new{k}", "")) for k in range(6)]
+    e.write(many)
+    got = sorted(r[:6] for r in e.read(rtype="pod") if r[1].startswith("ns/fresh"))
+    assert got == sorted(u[1] for u in many), got
+    assert len({e.find("pod", f"ns/fresh{k}") for k in range(6)}) == 6 and len({e.find("user", f"u-new{k}") for k in (0, 1, 2, 4, 5)} | {e.find("user", "u-free")}) == 6
+    assert e.selfcheck_snapshot() is True
+    e.close()

@@ -210,3 +210,32 @@ def test_dual_write_sequence_never_rebuilds(aclgpu):
         assert st["snapshot_builds"] == st0["snapshot_builds"], (st0, st)
         assert st["snapshot_patches"] - st0["snapshot_patches"] >= 120
         assert len(e.read(rtype="workflow")) <= 2 * 8
+
+
+def test_a_freed_id_keeps_its_meaning_under_a_bitmap_in_flight(aclgpu, monkeypatch):
+    """Ids are recycled (store.hpp intern_object) -- but a LookupResources bitmap in a caller's hands still says "bit X = the object that held
+    id X when the walk ran".  A pod that loses its relationships right after the lookup must not hand its id to the next new pod while such a
+    bitmap can be alive: with the default quarantine (30 s; the reference abandons a prefilter after 10 s, responsefilterer.go:44) the new pod
+    gets a NEW id and the old bitmap denies it; with the quarantine switched off the same sequence shows what the quarantine is for."""
+    from tests import kat_runner
+    b = kat_runner.load_bootstrap()
+    for quarantine_off in (False, True):
+        if quarantine_off:
+            monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "0")
+        with aclgpu.Engine(b["schema"], "\n".join(b["relationships"])) as e:
+            e.write([(aclgpu.OP_TOUCH, ("pod", f"ns/p{i}", "creator", "user", "paul", "")) for i in range(5)])
+            bm, cnt = e.lookup_bitmap("pod", "view", "user", "paul")
+            assert cnt == 5 and e.bitmap_test_names("pod", bm, ["ns/p3"]).tolist() == [True]
+            old = e.find("pod", "ns/p3")
+            assert e.delete_by_filter(rtype="pod", rid="ns/p3") == 1       # ns/p3 loses its only relationship ...
+            e.write([(aclgpu.OP_TOUCH, ("pod", "ns/brand-new", "creator", "user", "chani", ""))])  # ... and a pod paul has nothing to do with appears
+            new = e.find("pod", "ns/brand-new")
+            allowed = e.bitmap_test_names("pod", bm, ["ns/brand-new", "ns/p3", "ns/p1"]).tolist()
+            if not quarantine_off:
+                assert new != old and allowed == [False, True, True] and e.stats()["ids_recycled"] == 0  # (ns/p3 WAS allowed when the walk ran)
+            else:
+                assert new == old and e.stats()["ids_recycled"] == 1 and e.find("pod", "ns/p3") is None
+                assert allowed[0] is True  # the stale bitmap now vouches for a pod its subject never saw: what the quarantine prevents
+            # fresh lookups are right either way
+            assert e.lookup("pod", "view", "user", "paul") == {f"ns/p{i}" for i in (0, 1, 2, 4)} and e.lookup("pod", "view", "user", "chani") == {"ns/brand-new"}
+            assert e.check("pod", "ns/brand-new", "view", "user", "paul") == (1, 0) and e.check("pod", "ns/brand-new", "view", "user", "chani") == (2, 0)
