@@ -264,6 +264,7 @@ uint32_t Store::intern_object(int type, std::string_view name, bool pin, bool ho
             if (rc.size() <= id) rc.resize((size_t)id + 1 + rc.size() / 2, 0);
             rc[id] |= kPinned;
         }
+        if (hold) ref(type, id, +1);  // (every hold is released once: a write naming one new subject in five updates holds it five times)
         return id;
     }
     // a NEW name: the oldest free id that has sat out its quarantine, if its object is still unreferenced; else the next dense id

@@ -321,5 +321,11 @@ def test_object_ids_are_recycled_and_the_snapshot_stays_exact(aclgpu, monkeypatc
     got = sorted(r[:6] for r in e.read(rtype="pod") if r[1].startswith("ns/fresh"))
     assert got == sorted(u[1] for u in many), got
     assert len({e.find("pod", f"ns/fresh{k}") for k in range(6)}) == 6 and len({e.find("user", f"u-new{k}") for k in (0, 1, 2, 4, 5)} | {e.find("user", "u-free")}) == 6
+    # ... and a NEW subject named by several updates of one request keeps every one of its references
+    e.write([(aclgpu.OP_TOUCH, ("pod", f"ns/fresh{k}", "creator", "user", "u-shared", "")) for k in range(5)])
+    e.write([(aclgpu.OP_DELETE, ("pod", "ns/fresh3", "creator", "user", "u-shared", ""))])
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/fresh0", "viewer", "user", "u-latest", ""))])  # (must not be handed u-shared's id)
+    assert sorted(r[1] for r in e.read(rtype="pod", stype="user", sid="u-shared")) == [f"ns/fresh{k}" for k in (0, 1, 2, 4)]
+    assert e.find("user", "u-latest") != e.find("user", "u-shared")
     assert e.selfcheck_snapshot() is True
     e.close()
