@@ -493,7 +493,7 @@ def isolated_sharded_leg(rank, world, timeout_s=180.0):
 
 
 def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
-    """The north star's multi-GPU layout: rows partitioned by fnv1a(object type) mod G, one shard per
+    """The north star's multi-GPU layout: rows partitioned by hash(object type) mod G (FNV-1a, avalanched), one shard per
     rank, per-level all-gather of cross-shard frontier entries over RCCL.  All ranks answer ONE batch together; the
     answers are compared with the replica engine's.  world == 1: G logical shards (threads) on this device -- emulated."""
     import threading
@@ -566,7 +566,7 @@ def sharded_leg(args, w, replica, res, subj, world, rank, local_rank, result):
         return {"modes": res_by_mode, "shard_relationships": None}
 
     result.update({
-        "layout": f"fnv1a(object type) mod {G}; 16 B frontier entries cross shards once per level",
+        "layout": f"hash(object type) mod {G} (FNV-1a, avalanched); 16 B frontier entries cross shards once per level",
         "transport": "RCCL over xGMI (torch.distributed nccl)" if world > 1 else "in-process copies between logical shards on ONE GPU (emulated, not a multi-GPU measurement)",
         "shards": G, "batch": n, "steps": steps})
 

@@ -345,7 +345,7 @@ int acl_lookup_one_opts(acl_engine_t *h, const char *resource_type, const char *
 int acl_batcher_lookup_stats(acl_engine_t *h, uint64_t *walks, uint64_t *lookups);
 
 /* ---- sharded graph: the north star's multi-GPU configuration ----
- * One engine per GPU holds the rows of the object types with fnv1a(type name) mod world == rank; the
+ * One engine per GPU holds the rows of the object types with hash(type name) mod world == rank (FNV-1a, avalanched: acl_shard_of_type); the
  * relationship store (ids, writes) stays replicated.  A batch advances one dispatch level at a time on every
  * shard; sub-checks whose rows live elsewhere are appended to the caller's export buffer (16-byte frontier
  * entries) and the host exchanges them between levels -- RCCL all-gather in aclgpu/sharded.py, ncclAllGather in

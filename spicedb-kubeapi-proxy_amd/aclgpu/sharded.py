@@ -24,13 +24,15 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
+import subprocess
 import threading
 
 import numpy as np
 import torch
 
 from . import _lib
-from .engine import AclError, ERR_RESOURCE_EXHAUSTED, Engine
+from .engine import AclError, ERR_INTERNAL, ERR_RESOURCE_EXHAUSTED, Engine
 
 MAX_LEVELS = 50  # dispatch max depth, reference pkg/spicedb/spicedb.go:34
 VISIT, EXPAND = 1, 2
@@ -257,6 +259,62 @@ class RcclNative:
         self.struct = None  # acl_shard_check_bulk_rccl uses the engine's communicator
 
 
+class IpcNative:
+    """acl_shard_comm_t between PROCESSES sharing one device (tools/ipc_comm.hip -> tools/bin/libaclipc.so): windows of device memory exported
+    with hipIpcGetMemHandle and mapped by every peer, a barrier in POSIX shared memory.  Test infrastructure (RCCL refuses two ranks on one
+    device; the test boxes have one): separate address spaces, HIP contexts and streams under the same level loops."""
+
+    _lib = None
+
+    @classmethod
+    def library(cls, build: bool = True):
+        if cls._lib is None:
+            root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            so = os.path.join(root, "tools", "bin", "libaclipc.so")
+            src = os.path.join(root, "tools", "ipc_comm.hip")
+            if build and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)):
+                os.makedirs(os.path.dirname(so), exist_ok=True)
+                subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-I", os.path.join(root, "include"),
+                                       "-lrt", "-o", so])
+            L = C.CDLL(so)
+            L.aclipc_last_error.restype = C.c_char_p
+            L.aclipc_open.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+            L.aclipc_comm.argtypes = [C.c_void_p, C.POINTER(_lib.ShardComm)]
+            L.aclipc_comm.restype = None
+            L.aclipc_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            L.aclipc_stats.restype = None
+            L.aclipc_barrier.argtypes = [C.c_void_p]
+            L.aclipc_close.argtypes = [C.c_void_p]
+            L.aclipc_close.restype = None
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, name: str, rank: int, world: int, device: int = 0, window_bytes: int = 8 << 20, deadline_s: int = 60, with_all_to_all: bool = True):
+        L = self.library()
+        self.rank, self.world = rank, world
+        self._c = C.c_void_p()
+        if L.aclipc_open(name.encode(), rank, world, device, window_bytes, deadline_s, C.byref(self._c)):
+            raise AclError(ERR_INTERNAL, (L.aclipc_last_error() or b"").decode())
+        self.struct = _lib.ShardComm()
+        L.aclipc_comm(self._c, C.byref(self.struct))
+        if not with_all_to_all:
+            self.struct.all_to_all = _lib.ALL_TO_ALL_CB()
+
+    def barrier(self):
+        if self.library().aclipc_barrier(self._c):
+            raise AclError(ERR_INTERNAL, (self.library().aclipc_last_error() or b"").decode())
+
+    def stats(self):
+        out = (C.c_uint64 * 4)()
+        self.library().aclipc_stats(self._c, out)
+        return {"collectives": int(out[0]), "foreign_bytes": int(out[1]), "barriers": int(out[2]), "longest_barrier_wait_ms": out[3] / 1e6}
+
+    def close(self):
+        if self._c:
+            self.library().aclipc_close(self._c)
+            self._c = C.c_void_p()
+
+
 # ----------------------------------------------------------------------------- one shard on one GPU
 class GpuShard:
     """One shard of the graph on one MI355X: an Engine configured with (rank, world), stepped through the
@@ -336,7 +394,7 @@ class _Redo(Exception):
 class ShardedEngine:
     """SPMD driver: call the same method with the same arguments on every rank."""
 
-    def __init__(self, shard, comm, export_entries: int = 1 << 16, exchange: str = "allgather"):
+    def __init__(self, shard, comm, export_entries: int = 1 << 16, exchange: str = "allgather", native=None):
         """exchange: how Check frontiers cross shards -- "allgather" (the north star's form: every rank receives every export
         buffer and keeps what it owns) or "alltoall" (exports grouped by owner on the device, each rank receives only its own:
         G times fewer bytes).  LookupResources always all-gathers (a visited state goes to every shard that
@@ -344,6 +402,7 @@ class ShardedEngine:
         assert shard.rank == comm.rank and shard.world == comm.world
         assert exchange in ("allgather", "alltoall")
         self.shard, self.comm, self.exchange = shard, comm, exchange
+        self._native = native  # the native loops' communicator (default: made from `comm` on first use)
         self.cap = 0
         self._alloc(export_entries)
         self.levels_last = 0

@@ -215,7 +215,7 @@ static void compaction_start(acl_engine *h) {
             ok = hipSetDevice(pd.device) == hipSuccess && up(pd.d_meta, s.meta) && up(pd.d_edges, s.edges) && up(pd.d_buckets, s.buckets) && up(pd.d_ops, s.ops) &&
                  up(pd.d_progs, s.progs) && up(pd.d_bexpr, s.bexpr) && up(pd.d_tsb, s.type_slot_base) && up(pd.d_tnm, s.type_nmembers);
             if (ok && c->with_reverse)
-                ok = up(pd.d_rmeta, s.rmeta) && up(pd.d_redges, s.redges) && up(pd.d_rops, s.rops) && up(pd.d_rprogs, s.rprogs) && up(pd.d_rseeds, s.rseeds) &&
+                ok = up(pd.d_rmeta, s.rmeta) && up(pd.d_redges, s.redges) && up(pd.d_rops, s.rops) && up(pd.d_rprogs, s.rprogs) && up(pd.d_rseeds, s.rseeds) && up(pd.d_rdest, s.rdest) &&
                      up(pd.d_sbb, s.slot_bit_base) && up(pd.d_snobj, s.slot_nobjects);
         }
         for (size_t i = 0; ok && i < ndev; i++) ok = hipSetDevice(c->per[i]->device) == hipSuccess && hipStreamSynchronize(c->per[i]->stream) == hipSuccess;
@@ -283,6 +283,7 @@ static bool compaction_adopt(acl_engine *h, int64_t now) {
             d.d_rops.swap(pd.d_rops);
             d.d_rprogs.swap(pd.d_rprogs);
             d.d_rseeds.swap(pd.d_rseeds);
+            d.d_rdest.swap(pd.d_rdest);
             d.d_sbb.swap(pd.d_sbb);
             d.d_snobj.swap(pd.d_snobj);
         }
@@ -426,6 +427,7 @@ int ensure_reverse(acl_engine *h) {
         HIP_TRY(d.d_rops.upload(h->snap.rops, s));
         HIP_TRY(d.d_rprogs.upload(h->snap.rprogs, s));
         HIP_TRY(d.d_rseeds.upload(h->snap.rseeds, s));
+        HIP_TRY(d.d_rdest.upload(h->snap.rdest, s));
         HIP_TRY(d.d_sbb.upload(h->snap.slot_bit_base, s));
         HIP_TRY(d.d_snobj.upload(h->snap.slot_nobjects, s));
     }

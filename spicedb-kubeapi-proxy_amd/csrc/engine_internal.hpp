@@ -283,6 +283,7 @@ struct Compaction {
         DevArray<uint32_t> d_bexpr;
         DevArray<RevOp> d_rops;
         DevArray<RevProg> d_rprogs, d_rseeds;
+        DevArray<uint64_t> d_rdest;
     };
     std::vector<std::unique_ptr<PerDevice>> per;  // [replica]
     std::string error;
@@ -310,6 +311,7 @@ struct DevState {
     DevArray<uint32_t> d_rmeta, d_redges, d_sbb, d_snobj;
     DevArray<RevOp> d_rops;
     DevArray<RevProg> d_rprogs, d_rseeds;
+    DevArray<uint64_t> d_rdest;
     // evaluation contexts of this device (the pool's lock and condition variable are the engine's)
     std::vector<std::unique_ptr<PassCtx>> ctxs;  // created lazily up to max_ctx
     std::vector<PassCtx *> free_ctxs;
@@ -412,7 +414,7 @@ struct acl_engine {
     DevGraph dev_graph(const PassCtx *c) const { return dev_graph(*c->dev); }
     DevReverse dev_reverse(const PassCtx *c, uint32_t vwords) const {
         const DevState &d = *c->dev;
-        return DevReverse{d.d_rmeta.p, d.d_redges.p, d.d_rops.p, d.d_rprogs.p, d.d_rseeds.p, d.d_sbb.p, d.d_snobj.p, c->d_visited.p, vwords,
+        return DevReverse{d.d_rmeta.p, d.d_redges.p, d.d_rops.p, d.d_rprogs.p, d.d_rseeds.p, d.d_rdest.p, d.d_sbb.p, d.d_snobj.p, c->d_visited.p, vwords,
                           (uint32_t)snap.rprogs.size(), (uint32_t)snap.rops.size()};
     }
     DevFrontier dev_frontier(const PassCtx &c) const {

@@ -305,7 +305,8 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
 // LookupResources (pkg/authz/lookups.go:49-83) for n subjects of one class on the sharded graph, the whole reverse level loop inside the
 // library.  Iteration 1 expands the seeds; then pairs (VISIT: first visits marked, states whose parents' rows also live on other shards
 // exported -> exchange -> import of the foreign states this shard holds parent rows for | EXPAND) until a visit step neither produced nor
-// exported anything on any shard.  A visited state goes to every shard that may hold parent rows for it: always the all-gather form.
+// exported anything on any shard.  A visited state goes to the shards that hold parent rows for its slot: per-destination blocks through the
+// communicator's all_to_all, or -- without one -- one block to everybody, filtered by the importers.
 // d_bitmaps_out: n rows of bitmap_words words on the device, the same on every shard afterwards (the rows exist on the resource type's owner
 // only; a byte-wise max hands them to everybody).
 int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n,
@@ -327,7 +328,9 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
     const size_t vwords = std::max<size_t>((size_t)((h->snap.visited_bits + 31) / 32), 1);
     if (n * vwords > ((size_t)1 << 30)) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "lookup batch too large for one pass (visited bitmaps > 4 GiB)");
     acl_shard_bulk_stats_t st{};
-    Exchange X{h, c, comm, h->shard.world, h->shard.rank, 0, false, &st, &c->xplan_rev};
+    // all-to-all by parent-row owner (round 4): a visited state travels to the shards that hold parent rows for its slot (Snapshot::rdest), one
+    // block per destination, instead of to everybody; the all-gather form remains for communicators without all_to_all and worlds beyond 64
+    Exchange X{h, c, comm, h->shard.world, h->shard.rank, 0, comm->all_to_all != nullptr && h->shard.world <= kMaxShards && h->shard_a2a, &st, &c->xplan_rev};
     if (n > c->frontier_entries) {
         rc = alloc_frontier(h, c, n * 4);
         if (rc) return rc;
@@ -361,7 +364,7 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
         while (!verdict) {
             const uint32_t last = std::min<uint32_t>(kMaxIter, next + 2 * pairs - 2);  // VISIT iterations next, next + 2, ..., last
             for (uint32_t it = next; it <= last; it += 2) {
-                HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, sizeof(uint32_t), c->stream));
+                HIP_TRY(hipMemsetAsync(c->d_status.p + 2 * kLevelSlots + 1, 0, (1 + kMaxShards) * sizeof(uint32_t), c->stream));
                 ev_begin(c, 1);
                 launch_rev_expand(c->stream, r, f, it, REV_VISIT, sh);
                 ev_end(c);

@@ -1523,7 +1523,20 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
                 const uint32_t base = reserve<false>(wo, (uint32_t)__popcll(b), lane);
                 if (active && base != kNoSpace) out[base + lanes_below(b)] = o;
             }
-            export_entries(first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels, make_uint4(id, req, meta | kRevForeign, 0), 0u, lane, sh);
+            const bool xport = first_visit && (p.n & kRevRemoteBit) && dist < kMaxLevels;
+            const uint4 xe = make_uint4(id, req, meta | kRevForeign, 0);
+            if (!sh.by_dest) {
+                export_entries(xport, xe, 0u, lane, sh);  // one block every shard receives; the importers keep what they hold parent rows for
+            } else {
+                // all-to-all form: a copy into the block of every shard that holds parent rows of this slot's states -- one round per distinct
+                // destination among the lanes' lowest pending bits (a slot has one or two such shards; rounds = the wave's distinct destinations)
+                uint64_t pend = xport ? r.rdest[slot] : 0ull;
+                while (__ballot(pend != 0)) {
+                    const uint32_t d = pend ? (uint32_t)(__ffsll((unsigned long long)pend) - 1) : 0u;
+                    export_entries(pend != 0, xe, d, lane, sh);
+                    pend &= pend - 1;
+                }
+            }
             continue;
         }
         const uint32_t nops = (active && dist < kMaxLevels) ? (p.n & ~kRevRemoteBit) : 0u;  // parents of a dist-50 state would need 51 levels

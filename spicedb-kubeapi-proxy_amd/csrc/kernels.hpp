@@ -43,6 +43,7 @@ struct DevReverse {
     const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids
     const RevOp *rops;
     const RevProg *rprogs, *rseeds;
+    const uint64_t *rdest;          // [nslots] other shards holding parent rows of the slot's states (all-to-all form of the sharded walk)
     const uint32_t *slot_bit_base;  // [nslots]
     const uint32_t *slot_nobjects;  // [nslots] id space of the slot's type
     uint32_t *visited;              // [nreq][visited_words]

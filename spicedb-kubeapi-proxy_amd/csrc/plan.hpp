@@ -148,13 +148,14 @@ struct Snapshot {
     std::vector<RevOp> rops;
     std::vector<RevProg> rprogs;   // [nslots]: parents of a true state
     std::vector<RevProg> rseeds;   // [nkeys]: seeds for a subject key
+    std::vector<uint64_t> rdest;   // [nslots]: the OTHER shards that hold parent rows of a state of this slot (bit per shard < 64; sharded graphs)
     std::vector<uint32_t> slot_bit_base;  // [nslots+1] first bit of each slot's visited bitmap (32-bit aligned)
     std::vector<uint32_t> slot_nobjects;  // [nslots] id space of the slot's type the visited bitmaps cover (with headroom for new objects)
     uint64_t visited_bits = 0;
 };
 
 // Graph partition of the north star's multi-GPU configuration: rows (and programs) of an object type live on
-// shard fnv1a(type name) mod world.  world == 1: everything is local.
+// shard mix(fnv1a(type name)) mod world (plan.cpp shard_of_type).  world == 1: everything is local.
 struct ShardSpec {
     uint32_t rank = 0, world = 1;
 };

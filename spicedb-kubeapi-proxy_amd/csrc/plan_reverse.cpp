@@ -82,11 +82,13 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     if (s.rmeta.empty()) s.rmeta.assign(2, 0);
     if (s.redges.empty()) s.redges.push_back(0);
     bool remote = false;  // set by enum_op when a live parent row set belongs to another shard
+    uint64_t remote_shards = 0;  // ... which ones (shards beyond 63 are reached by the all-gather form only)
     auto enum_op = [&](int rel_slot, size_t k, int target, uint32_t wild_id = 0xFFFFFFFFu) {
         const RevLayout &l = rl[rel_slot][k];
         if (!l.any) return;
         if (type_owner[sc.slot_owner[rel_slot].first] != shard.rank) {
             remote = true;
+            if (type_owner[sc.slot_owner[rel_slot].first] < 64) remote_shards |= 1ull << type_owner[sc.slot_owner[rel_slot].first];
             return;
         }
         RevOp op{};
@@ -102,12 +104,14 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
     };
     // parents of a true state X = (t, m)
     s.rprogs.assign(sc.nslots, RevProg{0, 0});
+    s.rdest.assign(sc.nslots, 0);
     for (int slot = 0; slot < sc.nslots; slot++) {
         auto [t, m] = sc.slot_owner[slot];
         const std::string &xname = sc.defs[t].members[m].name;
         RevProg p;
         p.first = (uint32_t)s.rops.size();
         remote = false;
+        remote_shards = 0;
         const bool mine = type_owner[t] == shard.rank;  // computed usersets stay on the object: only its owner runs them
         for (size_t t2 = 0; t2 < sc.defs.size(); t2++) {
             const Definition &d2 = sc.defs[t2];
@@ -140,6 +144,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
         }
         p.n = ((uint32_t)s.rops.size() - p.first) | (remote && mine ? kRevRemoteBit : 0u);
         s.rprogs[slot] = p;
+        s.rdest[slot] = remote && mine ? remote_shards : 0;
     }
     // seeds for a subject key
     s.rseeds.assign(sc.nkeys(), RevProg{0, 0});

@@ -23,6 +23,11 @@ def fnv1a(s: str) -> int:
     h = 2166136261
     for c in s.encode():
         h = ((h ^ c) * 16777619) & 0xFFFFFFFF
+    h ^= h >> 16  # avalanche (murmur's 32-bit finaliser), as plan.cpp shard_of_type
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    h ^= h >> 16
     return h
 
 

@@ -155,6 +155,21 @@ def test_batcher_wakeups_with_native_threads_without_gpu(aclgpu_lib, tmp_path):
         assert r["batcher_passes"] < r["checks"], r  # calls were coalesced
 
 
+def test_ipc_communicator_builds_and_exports_its_entry_points(aclgpu_lib):
+    """tools/ipc_comm.hip (the acl_shard_comm_t between processes that tests/test_sharded_gpu.py runs the native loops over) compiles for gfx950 and
+    exports what aclgpu/sharded.py IpcNative binds; opening one needs a GPU and fails loudly without."""
+    import ctypes as C
+    from aclgpu import sharded
+    L = sharded.IpcNative.library()
+    for sym in ("aclipc_open", "aclipc_comm", "aclipc_stats", "aclipc_barrier", "aclipc_close", "aclipc_last_error"):
+        assert hasattr(L, sym), sym
+    import torch
+    if not torch.cuda.is_available():
+        out = C.c_void_p()
+        assert L.aclipc_open(b"/aclipc-abi-test", 0, 1, 0, 1 << 20, 2, C.byref(out)) != 0 and not out.value
+        assert b"aclipc rank 0" in L.aclipc_last_error()
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(os.path.dirname(HERE), "spicedb-kubeapi-proxy_amd")
     for root, _d, files in os.walk(pkg):
