@@ -29,6 +29,11 @@ int check_opts(const CallOpts &o) {
 
 PassCtx::~PassCtx() {
     if (stream) (void)hipStreamSynchronize(stream);
+    for (hipStream_t a : aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     if (h_status) (void)hipHostFree(h_status);
     if (stream) (void)hipStreamDestroy(stream);
@@ -675,10 +680,30 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     // device through events, a completer thread -- that served only such batches).
     const bool wide0 = n >= h->local_wide_min;
     const uint64_t per_launch = (uint64_t)(wide0 ? c->dev->local_blocks_wide : c->dev->local_blocks) * local_unit_max(wide0);
-    const uint32_t npass = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n + per_launch - 1) / per_launch);
+    uint32_t npass = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n + per_launch - 1) / per_launch);
+    // CONCURRENT slices: the items of a launch cross PCIe while its blocks wait for their seeds (4 MB per 262 144 items: ~80 us in which a lone
+    // caller's chip idles).  On two streams, the first slice's blocks fill the chip and compute while the second slice's blocks -- which move in
+    // as those finish -- fetch theirs; each stream walks in a frontier region of its own.  Sub-passes of a batch beyond one launch always
+    // alternate between the two streams (1 048 576 items from one caller: 800 -> 933 M decisions/s); a batch that fits one launch is cut in two
+    // only for a LONE caller and only from 262 144 items on (0.336 -> 0.324 ms): the halves' units are half as long, which costs three concurrent
+    // callers a tenth of their throughput, and three or four slices lose outright (profiles/r04_host_split.txt).  Not with combine schemas (the
+    // slices would share the node / cell scratch) and not while kernels are being timed (the events sit on the context's stream).
+    uint32_t nstreams = 1;
+    bool lone = false;
+    if (npass == 1 && n >= 262144) {
+        std::lock_guard<std::mutex> lk(h->pool_mu);
+        lone = c->dev->in_use <= 1;
+    }
+    if (h->host_split > 1 && !h->snap.has_combine && !c->timing && (npass > 1 || lone)) {
+        nstreams = std::min<uint32_t>(h->host_split, 4);
+        npass = std::max(npass, nstreams);
+    }
     const uint32_t chunk = npass == 1 ? n : (uint32_t)((((uint64_t)n + npass - 1) / npass + 63) / 64 * 64);
-    const LocalGeom G = local_geom(h, c, std::min(n, chunk));
+    LocalGeom G = local_geom(h, c, std::min(n, chunk));
+    G.cap /= nstreams;
     if (G.cap < 256 || n > h->hostmap_max || G.nunits > G.nblocks || npass > 15) return kTakeLevelLoop;
+    for (uint32_t k = 1; k < nstreams; k++)
+        if (!c->aux[k - 1]) HIP_TRY(hipStreamCreateWithFlags(&c->aux[k - 1], hipStreamNonBlocking));
     *attempted = true;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
@@ -708,13 +733,21 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     if (int rc = combine_prepare(h, c, &g, std::min(n, chunk), G.nblocks, G.rpw)) return rc;  // (the sub-passes follow each other on one stream: they share the scratch)
     for (uint32_t k = 0; k < npass; k++) {
         const uint32_t off = k * chunk, m = std::min(chunk, n - off);
-        const LocalGeom Gk = k + 1 < npass || npass == 1 ? G : local_geom(h, c, m);  // (the last one may be shorter)
-        ev_begin(c, 2);
-        launch_check_local(c->stream, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p, c->d_fbuf[1].p, Gk.cap, (uint32_t *)d_flag + k, c->d_has.p,
-                           c->d_err.p, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide);
-        ev_end(c);
+        LocalGeom Gk = G;
+        if (k + 1 == npass && npass > 1 && m != chunk) {  // (the last one may be shorter)
+            Gk = local_geom(h, c, m);
+            Gk.cap = std::min(G.cap, Gk.cap);
+        }
+        const uint32_t lane = k % nstreams;  // slices of one lane follow each other on its stream and share its frontier region
+        const size_t region = (size_t)lane * (c->frontier_entries / nstreams);
+        hipStream_t st = lane ? c->aux[lane - 1] : c->stream;
+        if (nstreams == 1) ev_begin(c, 2);
+        launch_check_local(st, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p + region, c->d_fbuf[1].p + region, Gk.cap, (uint32_t *)d_flag + k,
+                           c->d_has.p + off, c->d_err.p + off, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide);
+        if (nstreams == 1) ev_end(c);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t k = 1; k < nstreams; k++) HIP_TRY(hipStreamSynchronize(c->aux[k - 1]));
     ev_collect(c);
     for (uint32_t k = 0; k < npass; k++)
         if (flag[k] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
@@ -1658,6 +1691,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_RAW_INTERN")) h->raw_intern = atoi(ev) != 0;  // test knob: acl_intern takes any bytes (the JSON scanners' decoding tests name objects no API request could)
+    if (const char *ev = getenv("ACL_HOST_SPLIT")) h->host_split = (uint32_t)std::min(4, std::max(1, atoi(ev)));
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch
     if (const char *ev = getenv("ACL_LOCAL_DYN_UNIT")) h->local_dyn_unit = (uint32_t)std::min(256, std::max(1, atoi(ev)));       // in static units; size of the hand-out units

@@ -220,6 +220,7 @@ struct PassCtx {
     int index = 0;           // among the contexts of ITS device
     DevState *dev = nullptr;  // the replica (device) this context's stream and buffers live on
     hipStream_t stream = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};  // further streams of a host batch cut into concurrent slices (engine.cpp check_pass_local_host), made on first use
     // frontier
     DevArray<uint4> d_fbuf[2];
     DevArray<uint32_t> d_fcounts[2], d_status;  // status = nchunks[kLevelSlots] | any[kLevelSlots] | overflow | export counters
@@ -356,6 +357,7 @@ struct acl_engine {
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
     uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)
+    uint32_t host_split = 2;   // streams the slices of one large host batch are spread over (ACL_HOST_SPLIT, 1 = off; engine.cpp check_pass_local_host)
     uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
                                // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round
     uint32_t local_static_pct = 100, local_dyn_unit = 32;  // chip-filling single-launch passes: share of the batch in static (one per block) units; hand-out unit size

@@ -334,3 +334,27 @@ definition pod { relation namespace: namespace
             p2, er2 = call((prep[0], 100, prep[2]))  # a small batch takes the single-thread path
             assert list(zip(p2.tolist(), er2.tolist())) == want[:100], form
         assert {w_[1] for w_ in want} >= {0, aclgpu.ERR_FAILED_PRECONDITION} and 0 < sum(w_[0] == 2 for w_ in want) < len(want)
+
+
+@pytest.mark.parametrize("split", ["1", "2", "4"])
+def test_host_batches_as_concurrent_slices(split, aclgpu, monkeypatch):
+    """A host batch beyond one launch goes as sub-passes that alternate between streams of their own, each with a frontier region of its own
+    (engine.cpp check_pass_local_host; ACL_HOST_SPLIT streams, 1 = one after the other); a lone caller's 262 144-item batch is cut in two the same
+    way.  1 200 000 items (3 slices over 1 / 2 / 3 lanes), 262 144 and 300 001 items: every answer equals the oracle's whatever the lanes."""
+    from aclgpu import workloads
+    monkeypatch.setenv("ACL_HOST_SPLIT", split)  # (read at acl_open)
+    w = workloads.c4(scale=0.02, batch=1200000, n_user=20000)
+    o = orc.Oracle(w.schema)
+    w.load(o)
+    o.freeze()
+    op, oe = o.check_bulk_ids_mt(16, "pod", "view", w.res, "user", "", w.subj)
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        items = e.make_items("pod", "view", w.res, "user", "", w.subj)
+        for n in (1200000, 262144, 300001):
+            p, er = e.check_bulk_ids(items[:n])
+            assert np.array_equal(p, op[:n]) and np.array_equal(er, oe[:n]), (split, n)
+        st = e.stats()
+        assert st["local_passes"] == st["check_passes"] and st["overflow_retries"] == 0  # the single-launch walk took every slice
+        lanes = int(split)
+        assert st["check_passes"] >= (4 if lanes == 1 else 3 * lanes)  # (one launch holds one unit per resident block: >= 2 slices for 1.2 M items; else one per lane)
