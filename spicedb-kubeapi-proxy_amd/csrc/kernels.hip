@@ -1234,7 +1234,8 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
     // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
-    __shared__ uint32_t s_fill[3], s_next[3], s_stop, s_unit;
+    __shared__ uint32_t s_cursors[6], s_stop, s_unit;  // (one array: the per-unit reset is ONE store through one address -- two arrays cost a spilled VGPR)
+    uint32_t *const s_fill = s_cursors, *const s_next = s_cursors + 3;
     __shared__ uint32_t s_ccount[2];  // CMB: {leaf cells, nodes} of the unit being walked
     constexpr bool E8 = ACL_ENTRY8 && !CMB;  // 8-byte frontier entries (put_entry)
     __shared__ uint2 s_req[E8 ? WAVES * 64 : 1];  // E8: {subject id, subject key} of the unit's requests
@@ -1276,10 +1277,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     for (uint32_t unit = blockIdx.x; unit < nunits;) {
         const uint32_t first = unit < nstatic ? unit * rpw : nstat_req + (unit - nstatic) * rdyn;
         const uint32_t mine = unit < nstatic ? min(rpw, nstat_req - first) : min(rdyn, n - first);  // <= 256: thread i seeds and answers request first + i
-        if (threadIdx.x < 3) {
-            s_fill[threadIdx.x] = 0;
-            s_next[threadIdx.x] = 0;
-        }
+        if (threadIdx.x < 6) s_cursors[threadIdx.x] = 0;
         if (CMB && threadIdx.x < 2) s_ccount[threadIdx.x] = 0;
         __syncthreads();
         // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit

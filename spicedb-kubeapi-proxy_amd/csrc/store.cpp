@@ -364,7 +364,9 @@ void Store::set_expiry(int slot, int cls, uint64_t key, int64_t at) {
 size_t Store::gc_expired(int64_t now) {
     size_t n = 0;
     bool bumped = false;
-    while (!expiry_index_.empty() && expiry_index_.begin()->at <= now - kGcWindowSeconds) {
+    // (at most kGcPerWrite per call: the first write after a long idle period must not pay for a day's worth of keys -- the rest goes with the
+    //  following writes; an expired relationship is dead to every reader whether or not it has been collected)
+    while (n < kGcPerWrite && !expiry_index_.empty() && expiry_index_.begin()->at <= now - kGcWindowSeconds) {
         const ExpiryEntry e = *expiry_index_.begin();
         ClassTable &ct = tables_[e.slot][e.cls];
         ct.settle();

@@ -206,6 +206,7 @@ class Store {
     // Drops relationships that expired more than kGcWindowSeconds ago (the reference's engine collects garbage after 24 h,
     // pkg/spicedb/spicedb.go:66).  They have been invisible since their expiry; each removal still enters the change feed as a
     // "look it up" entry (op 0) so that a snapshot which was idle across the expiry patches the row out.  Runs inside write().
+    static constexpr size_t kGcPerWrite = 4096;
     size_t gc_expired(int64_t now);
     static constexpr int64_t kGcWindowSeconds = 24 * 3600;
     size_t expiring_relationships() const { return expiry_index_.size(); }
