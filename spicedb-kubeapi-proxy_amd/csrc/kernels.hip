@@ -1223,7 +1223,10 @@ struct NoNext {
 // requests: more, smaller blocks) and kLocalWide for chip-filling ones -- requests differ 100-fold in work, so the more requests (and waves) a
 // unit pools, the less the slowest block's sum sticks out: C4's 262 144-item batch 303 us with 4 waves per block (2 048 units of 128 requests),
 // 286 us with 8, 276 us with 16 (512 units of 512), same-box A/B in profiles/r03_waves_per_block_ab.txt.
-constexpr int kLocalNarrow = 4, kLocalWide = 16;
+#ifndef ACL_LOCAL_WIDE
+#define ACL_LOCAL_WIDE 16  // (A/B builds: 12 waves per block leave room for 84 VGPRs at two blocks per CU)
+#endif
+constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
 template <bool LDSPROG, int WAVES, bool CMB = false>
 __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
                                                                                   uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
