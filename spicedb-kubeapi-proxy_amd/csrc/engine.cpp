@@ -784,9 +784,10 @@ constexpr int kRetryMerging = -1002;  // internal: the level loop ran out of fro
 
 // the level-synchronous pass (one k_expand launch per dispatch level); `merging`: duplicate entries are struck after every level
 static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint4 *d_items, uint32_t n, uint8_t *d_perm, int32_t *d_errout, bool merging_asked) {
-    // Schemas with `&` / `-`: entries carry result CELLS, not requests, and the dedup key has 14 request bits -- no duplicate merging there (a
-    // pass that outgrows its frontier only grows it); the combine nodes are evaluated behind the last level, before the answers are written.
-    const bool combine = h->snap.has_combine, merging = merging_asked && !combine;
+    // Schemas with `&` / `-`: entries carry result CELLS where the request would be; duplicates are merged on (cell, state, level) through a
+    // two-part key (k_dedup_cells), before the duplicate could create a combine node of its own; the combine nodes are evaluated behind the
+    // last level, before the answers are written.
+    const bool combine = h->snap.has_combine, merging = merging_asked;
     DevGraph g = g0;
     if (int rc = combine_prepare(h, c, &g, n, 0, 0)) return rc;
     for (int attempt = 0;; attempt++) {
@@ -797,7 +798,7 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint
         uint32_t bits = 0;
         if (merging) {
             while ((1ull << bits) < 2 * c->frontier_entries) bits++;
-            HIP_TRY(c->d_dedup.ensure((size_t)1 << bits));
+            HIP_TRY(c->d_dedup.ensure(((size_t)1 << bits) + (combine ? (size_t)1 << (bits - 1) : 0)));  // (+ 2^bits u32 second halves)
         }
         DevFrontier f = h->dev_frontier(*c);
         ev_begin(c, 0);
@@ -808,7 +809,7 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint
             h, c, kMaxLevels,
             [&](uint32_t it) {
                 launch_expand(c->stream, g, f, it, c->d_has.p, c->d_err.p);
-                if (merging) launch_dedup(c->stream, f, it, c->d_dedup.p, bits);
+                if (merging) launch_dedup(c->stream, f, it, c->d_dedup.p, bits, combine);
             },
             &levels,
             [&] {
@@ -822,6 +823,9 @@ static int levels_pass(acl_engine *h, PassCtx *c, const DevGraph &g0, const uint
             launch_finalize(c->stream, n, c->d_has.p, c->d_err.p, d_perm, d_errout);
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
+        // (combine schemas: a pass that ran out of nodes / cells is first redone with duplicates merged as well -- on a cyclic graph every
+        //  repeated visit of a non-monotone state was about to create a node of its own)
+        if (rc == ACL_ERR_RESOURCE_EXHAUSTED && combine && !merging_asked && c->h_status[2 * kLevelSlots] == 3) return kRetryMerging;
         if (rc == ACL_ERR_RESOURCE_EXHAUSTED && c->h_status[2 * kLevelSlots] == 1) {
             if (!merging_asked) return kRetryMerging;
             // out of chunks even with duplicates merged: grow (up to 2^28 entries) and redo the pass

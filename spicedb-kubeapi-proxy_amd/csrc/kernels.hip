@@ -1416,6 +1416,45 @@ __global__ __launch_bounds__(256) void k_dedup(DevFrontier f, uint32_t iter, uns
     }
 }
 
+// The same for schemas with `&` / `-`, whose entries carry a result CELL (32 bits) where the request was: cell | object id is the 64-bit key
+// of the table, level | slot sits in a second table the slot's winner fills right behind its CAS -- a lane that meets its own first half
+// reads the second one, and comes back in the next round while it is still empty (the winner has left the loop by then: no lane ever waits
+// for a lane of its own wave).  Identical (cell, state, level) entries have identical subtrees AND identical combine nodes to create, so
+// all but one are struck before any node exists.
+__global__ __launch_bounds__(256) void k_dedup_cells(DevFrontier f, uint32_t iter, unsigned long long *table, uint32_t *second, uint32_t bits) {
+    uint4 *buf = f.buf[iter & 1u];
+    const uint32_t *counts = f.counts[iter & 1u];
+    if (*f.overflow) return;
+    const uint32_t C = f.nwaves + min(f.nchunks[iter], f.max_chunks - f.nwaves);
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint32_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const uint32_t cnt = counts[c];
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const uint4 e = buf[(size_t)c * kChunk + i];
+            if (e.z == kDeadMeta) continue;
+            const unsigned long long key = ((unsigned long long)e.y << 32) | (unsigned long long)(e.x & kIdMask);  // (bit 31 clear: never the empty mark)
+            const uint32_t rest = 1u + (e.z & 0x7FFFFu);                                                           // level | slot, never 0
+            uint32_t h = (uint32_t)(((key ^ ((unsigned long long)rest << 40)) * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+            for (;;) {
+                const unsigned long long old = atomicCAS(table + h, ~0ull, key);
+                if (old == ~0ull) {  // first of its kind: publish the second half
+                    __hip_atomic_store(second + h, rest, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                if (old == key) {
+                    const uint32_t r2 = __hip_atomic_load(second + h, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (r2 == 0u) continue;  // the winner is between its CAS and its store: look again
+                    if (r2 == rest) {
+                        buf[(size_t)c * kChunk + i].z = kDeadMeta;
+                        break;
+                    }
+                }
+                h = (h + 1u) & mask;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__restrict__ has, const uint8_t *__restrict__ err, uint8_t *perm_out,
                                                    int32_t *err_out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2109,8 +2148,14 @@ int local_grid_blocks(int device, size_t prog_bytes, bool wide) {
     return cus * (wide ? local_occupancy<kLocalWide>(lds, prog_bytes) : local_occupancy<kLocalNarrow>(lds, prog_bytes));
 }
 uint32_t local_unit_max(bool wide) { return (uint32_t)(wide ? kLocalWide : kLocalNarrow) * 64u; }
-void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits) {
+void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits, bool cells) {
     (void)hipMemsetAsync(table, 0xFF, sizeof(uint64_t) << bits, s);
+    if (cells) {  // (`table` holds 2^bits keys and, behind them, 2^bits second halves)
+        uint32_t *second = reinterpret_cast<uint32_t *>(table + ((size_t)1 << bits));
+        (void)hipMemsetAsync(second, 0, sizeof(uint32_t) << bits, s);
+        hipLaunchKernelGGL(k_dedup_cells, dim3(f.nwaves / kWavesPerBlock), dim3(256), 0, s, f, iter, reinterpret_cast<unsigned long long *>(table), second, bits);
+        return;
+    }
     hipLaunchKernelGGL(k_dedup, dim3(f.nwaves / kWavesPerBlock), dim3(256), 0, s, f, iter, reinterpret_cast<unsigned long long *>(table), bits);
 }
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out) {

@@ -111,7 +111,7 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
 int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
 uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= threads per block of the single-launch kernel: thread i seeds request i of the unit)
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
-void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits);
+void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits, bool cells = false);  // cells: the entries carry result cells (combine schemas): `table` is 1.5 x 2^bits words
 constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key holds 14 request bits)
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
 // level loop, schemas with `&` / `-`: evaluates the combine nodes of frontier iteration `iter` (call for iter = last .. 1: a node only depends

@@ -199,3 +199,52 @@ def test_monotone_schema_takes_the_monotone_kernels(aclgpu):
         w.load(e)
         e.check_bulk_ids(e.make_items("pod", "view", w.res, "user", "", w.subj))
         assert e.stats()["local_passes"] == 1
+
+
+def test_branching_cycles_under_exclusion_and_intersection(aclgpu):
+    """Group nesting with BRANCHING cycles (g0 -> {g0, g1}, g1 -> g0, ...) under `-` and `&`: without merging, the pending sub-checks double per
+    dispatch level for 50 levels.  A pass that outgrows its frontier is redone with identical (cell, state, level) entries merged
+    (k_dedup_cells); answers equal the oracle's, which memoises on the same key: found by the live-graph fuzz (tools/fuzz_gpu.py --schema
+    combine), pinned here.  A cycle THROUGH a non-monotone permission (teams whose members are teams' `active` members) is walked too -- every
+    visit of such a state is a combine node of its own -- as long as it does not branch; where it branches the nodes double per level and the
+    call fails LOUDLY with RESOURCE_EXHAUSTED instead of answering (the reference's engine, run with every cache off as the proxy runs it,
+    spicedb.go:45-47, would be dispatching 2^50 sub-checks there)."""
+    schema = """
+definition user {}
+definition group {
+  relation member: user | group#member
+  relation banned: user
+  relation vip: user | group#member
+  permission active = member - banned
+  permission inner = member & vip
+}
+definition team {
+  relation member: user | team#active
+  relation banned: user
+  permission active = member - banned
+}
+"""
+    rels = ["group:g0#member@group:g0#member", "group:g0#member@group:g1#member", "group:g1#member@group:g0#member",
+            "group:g1#member@group:g2#member", "group:g2#member@group:g0#member", "group:g2#member@group:g1#member", "group:g2#member@user:deep",
+            "group:g2#member@user:outcast", "group:g0#banned@user:outcast", "group:g1#vip@group:g2#member", "group:g0#vip@user:deep",
+            # a cycle through team#active (non-monotone) that does not branch: t0 <- t1#active <- t0#active
+            "team:t0#member@team:t1#active", "team:t1#member@team:t0#active", "team:t1#member@user:deep", "team:t1#member@user:outcast", "team:t0#banned@user:outcast",
+            # ... and one that does: b0 <- {b0, b1}#active, b1 <- {b0, b1}#active
+            "team:b0#member@team:b0#active", "team:b0#member@team:b1#active", "team:b1#member@team:b0#active", "team:b1#member@team:b1#active", "team:b1#member@user:deep"]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    qs = [("group", g, p, "user", u, "") for g in ("g0", "g1", "g2") for p in ("active", "inner", "member") for u in ("deep", "outcast", "nobody")]
+    qs += [("team", t, "active", "user", u, "") for t in ("t0", "t1") for u in ("deep", "outcast", "nobody")]
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        for q in qs:
+            assert e.check(*q[:5]) == o.check(*q), q
+        perms, errs = e.check_bulk(qs * 40)
+        assert list(zip(perms, errs)) == [o.check(*q) for q in qs] * 40
+        assert e.stats()["overflow_retries"] >= 1  # (the merging pass was what answered)
+        for rt, perm in (("group", "active"), ("group", "inner")):
+            for u in ("deep", "outcast"):
+                assert e.lookup(rt, perm, "user", u) == set(o.lookup(rt, perm, "user", u)), (rt, perm, u)
+        assert e.check("team", "b0", "active", "user", "deep") == (2, 0)  # (answered HAS before the tree of nodes outgrows anything)
+        with pytest.raises(aclgpu.AclError) as ei:
+            e.check("team", "b0", "active", "user", "nobody")
+        assert ei.value.code == aclgpu.ERR_RESOURCE_EXHAUSTED

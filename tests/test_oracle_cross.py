@@ -242,3 +242,27 @@ def test_precedence_and_three_valued_rules():
         assert co.check("d", obj, perm, "user", "u") == w == PY2C[po.check("d", obj, perm, "user", "u")], (obj, perm)
     for obj, perm, w in [("e1", "deny_err", E), ("e1", "and_err", E), ("e2", "deny_err", N), ("e2", "and_err", N), ("e3", "deny_err", E), ("e3", "and_err", E)]:
         assert co.check("d", obj, perm, "user", "deep") == w == PY2C[po.check("d", obj, perm, "user", "deep")], (obj, perm)
+
+
+def test_cycles_through_nonmonotone_permissions_agree():
+    """Branching cycles under `-` and `&`, and a cycle THROUGH a non-monotone permission (team#active members of teams): the recursive Python
+    oracle (no memo: every path walked to the depth limit... on a graph this small) and the memoising C oracle give the same answers and the
+    same lookup sets -- the vectors tests/test_combine_gpu.py::test_branching_cycles_under_exclusion_and_intersection holds the engine to."""
+    import re
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_combine_gpu.py")).read()
+    blk = src[src.index("def test_branching_cycles_under_exclusion_and_intersection"):]
+    schema = re.search(r'schema = """(.*?)"""', blk, re.S).group(1)
+    rels = eval("[" + re.search(r"rels = \[(.*?)\]\n    o = ", blk, re.S).group(1) + "]")
+    co, po = orc.Oracle(schema), PyOracle(schema)
+    co.write([(orc.OP_TOUCH, r) for r in rels])
+    for r in rels:
+        m = re.match(r"(\w+):([^#]+)#(\w+)@(\w+):([^#]+)(?:#(\w+))?$", r)
+        po.touch(m.group(1), m.group(2), m.group(3), m.group(4), m.group(5), m.group(6) or "")
+    qs = [("group", g, p, "user", u, "") for g in ("g0", "g1", "g2") for p in ("active", "inner", "member") for u in ("deep", "outcast", "nobody")]
+    qs += [("team", t, "active", "user", u, "") for t in ("t0", "t1") for u in ("deep", "outcast", "nobody")]
+    for q in qs:
+        assert co.check(*q) == PY2C[po.check(*q)], q
+    for rt, perm in (("group", "active"), ("group", "inner")):
+        for u in ("deep", "outcast"):
+            assert co.lookup(rt, perm, "user", u, "") == po.lookup_resources(rt, perm, "user", u, ""), (rt, perm, u)

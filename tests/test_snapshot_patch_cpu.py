@@ -261,6 +261,9 @@ def test_long_random_write_streams_keep_the_snapshot_exact(aclgpu):
     assert codes[1] > 1400  # patched in place, not rebuilt
     codes = fz.run_patcher(6, 300, universe=8, burst=400)
     assert codes[0] + codes[1] + codes[2] == 300 and codes["adopted"] >= 1 and codes["dropped"] == 0  # (background builds adopted with the writes since replayed)
+    # the same stream on the schema with exclusions, intersections, wildcard classes and a non-monotone userset subject (fuzz_gpu.SCHEMA_COMBINE)
+    codes = fz.run_patcher(7, 400, schema="combine")
+    assert codes[1] > 380 and codes["dropped"] == 0
 
 
 def test_object_ids_are_recycled_and_the_snapshot_stays_exact(aclgpu, monkeypatch):

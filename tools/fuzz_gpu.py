@@ -17,10 +17,43 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "spicedb-kubeapi-proxy_amd")]
 
 
-def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False) -> dict:
+# The C4 schema with every non-monotone construct the engine compiles into combine programs (plan.hpp BX_*): exclusion at the top of a permission
+# that arrows reach, intersection over an arrow, a userset subject that is itself a non-monotone permission (group#active), wildcards on both
+# sides of a `-`, and a permission that subtracts an intersection.  Cycles through group#member (and through group#active, via pod viewers) stay
+# legal: a non-monotone cycle ends at the depth limit on both sides.
+SCHEMA_COMBINE = """
+definition user {}
+definition group {
+  relation member: user | group#member
+  relation banned: user
+  permission active = member - banned
+}
+definition namespace {
+  relation viewer: user | group#member | user:*
+  relation creator: user
+  relation banned: user | group#member
+  permission view = (viewer + creator) - banned
+}
+definition pod {
+  relation namespace: namespace
+  relation viewer: user | group#member | group#active
+  relation creator: user
+  relation auditor: user | group#member
+  relation banned: user | user:*
+  permission view = (viewer + creator + namespace->view) - banned
+  permission audit = auditor & namespace->view
+  permission edit = creator + (viewer & auditor) - banned
+  permission hidden = view - (auditor & creator)
+}
+"""
+
+
+def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False, schema: str = "c4") -> dict:
     import aclgpu
     from aclgpu import workloads
     from oracle import orc
+    combine = schema == "combine"
+    schema_text = SCHEMA_COMBINE if combine else workloads.SCHEMA_C4
 
     rng = random.Random(seed)
     users = [f"u{i}" for i in range(160 * universe)]
@@ -29,6 +62,17 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     pods = [f"{rng.choice(nss)}/p{i}" for i in range(240 * universe)]
 
     def rand_tuple():
+        if combine and rng.random() < 0.3:  # the relations only the combine schema has
+            k = rng.randrange(9)
+            if k == 0: return f"group:{rng.choice(groups)}#banned@user:{rng.choice(users)}"
+            if k == 1: return f"namespace:{rng.choice(nss)}#banned@user:{rng.choice(users)}"
+            if k == 2: return f"namespace:{rng.choice(nss)}#banned@group:{rng.choice(groups)}#member"
+            if k == 3: return f"namespace:{rng.choice(nss)}#viewer@user:*" if rng.random() < 0.3 else f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#active"
+            if k == 4: return f"pod:{rng.choice(pods)}#auditor@user:{rng.choice(users)}"
+            if k == 5: return f"pod:{rng.choice(pods)}#auditor@group:{rng.choice(groups)}#member"
+            if k == 6: return f"pod:{rng.choice(pods)}#banned@user:{rng.choice(users)}"
+            if k == 7: return f"pod:{rng.choice(pods)}#banned@user:*" if rng.random() < 0.2 else f"pod:{rng.choice(pods)}#banned@user:{rng.choice(users)}"
+            return f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#active"
         k = rng.randrange(9)
         if k == 0: return f"group:{rng.choice(groups)}#member@group:{rng.choice(groups)}#member"   # (cycles welcome)
         if k == 1: return f"group:{rng.choice(groups)}#member@user:{rng.choice(users)}"
@@ -43,6 +87,12 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     def rand_query():
         k = rng.randrange(10)
         u = rng.choice(users) if rng.random() < 0.97 else "stranger"
+        if combine and rng.random() < 0.45:
+            kk = rng.randrange(6)
+            if kk < 3: return ("pod", rng.choice(pods), ("audit", "edit", "hidden")[kk], "user", u, "")
+            if kk == 3: return ("group", rng.choice(groups), "active", "user", u, "")
+            if kk == 4: return ("pod", rng.choice(pods), "view", "group", rng.choice(groups), "active")  # a non-monotone userset as the subject
+            return ("namespace", rng.choice(nss), "view", "group", rng.choice(groups), "member")
         if k < 6: return ("pod", rng.choice(pods) if rng.random() < 0.97 else "n0/ghost", "view", "user", u, "")
         if k < 8: return ("namespace", rng.choice(nss), "view", "user", u, "")
         if k < 9: return ("group", rng.choice(groups), "member", "user", u, "")
@@ -51,10 +101,10 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     if compact_early:
         os.environ["ACL_COMPACTION_SLACK"] = "0"  # (read at acl_open) background compactions, adopted with the writes since replayed, on this small graph too
     try:
-        e = aclgpu.Engine(workloads.SCHEMA_C4)
+        e = aclgpu.Engine(schema_text)
     finally:
         os.environ.pop("ACL_COMPACTION_SLACK", None)
-    o = orc.Oracle(workloads.SCHEMA_C4)
+    o = orc.Oracle(schema_text)
     live = set()
     init = list(dict.fromkeys(rand_tuple() for _ in range(2500 * universe)))
     for i in range(0, len(init), 500):
@@ -93,7 +143,8 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
                 stats["write_errors"] += 1
         elif r < 0.5:  # ---- DeleteRelationships by filter
             f = rng.choice([dict(rtype="pod", rid=rng.choice(pods)), dict(rtype="group", rel="member", stype="user", sid=rng.choice(users)),
-                            dict(rtype="namespace", rid=rng.choice(nss), rel="viewer")])
+                            dict(rtype="namespace", rid=rng.choice(nss), rel="viewer")] +
+                           ([dict(rtype="pod", rel="banned", stype="user", sid="*"), dict(rtype="namespace", rel="banned")] if combine else []))
             n1, n2 = o.delete_by_filter(**f), e.delete_by_filter(**f)
             assert n1 == n2, f"step {step}: delete_by_filter {f}: oracle removed {n1}, engine {n2}"
             live = set(f"{a}:{b}#{c}@{d}:{x}" + (f"#{y}" if y else "") for t in ("group", "namespace", "pod") for a, b, c, d, x, y, _ in o.read(rtype=t))
@@ -113,7 +164,8 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
                 assert tuple(got[i]) == tuple(want[q]), f"step {step}: check {q} (item {i} of {n}): engine {got[i]}, oracle {want[q]}"
             stats["checks"] += n
         else:  # ---- LookupResources: one subject, or a batch of subjects in one walk
-            rt, perm = rng.choice([("pod", "view"), ("namespace", "view"), ("group", "member")])
+            rt, perm = rng.choice([("pod", "view"), ("namespace", "view"), ("group", "member")] +
+                                  ([("pod", "audit"), ("pod", "edit"), ("pod", "hidden"), ("group", "active")] if combine else []))
             subs = rng.sample(users, rng.choice([1, 1, 3, 20]))
             for u in subs[:3]:
                 a, b = e.lookup(rt, perm, "user", u), o.lookup(rt, perm, "user", u)
@@ -134,7 +186,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     return stats
 
 
-def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25, shard=None) -> dict:
+def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25, shard=None, schema: str = "c4") -> dict:
     """No GPU: the same kind of write stream on a STORE-ONLY engine, and after every write the host snapshot is brought up to date the way a read
     would (patched in place, or rebuilt) and verified against the store (acl_selfcheck_snapshot: every relationship findable by the kernels'
     search, nothing dead left, rows sorted, no unsound leaf flag).  -> how often it was patched (1), rebuilt (0) or current (2)."""
@@ -151,7 +203,12 @@ def run_patcher(seed: int, steps: int, universe: int = 1, burst: int = 25, shard
               lambda: f"namespace:{rng.choice(nss)}#creator@user:{rng.choice(users)}", lambda: f"pod:{rng.choice(pods)}#viewer@user:{rng.choice(users)}",
               lambda: f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#member", lambda: f"namespace:{rng.choice(nss)}#viewer@user:{rng.choice(users)}",
               lambda: f"namespace:{rng.choice(nss)}#viewer@group:{rng.choice(groups)}#member"]
-    e = aclgpu.Engine(workloads.SCHEMA_C4, store_only=True)
+    if schema == "combine":  # wildcard classes, a non-monotone userset subject, the relations behind `-` and `&`
+        shapes += [lambda: f"group:{rng.choice(groups)}#banned@user:{rng.choice(users)}", lambda: f"namespace:{rng.choice(nss)}#banned@group:{rng.choice(groups)}#member",
+                   lambda: f"namespace:{rng.choice(nss)}#viewer@user:*", lambda: f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#active",
+                   lambda: f"pod:{rng.choice(pods)}#auditor@group:{rng.choice(groups)}#member", lambda: f"pod:{rng.choice(pods)}#banned@user:*",
+                   lambda: f"pod:{rng.choice(pods)}#banned@user:{rng.choice(users)}", lambda: f"pod:{rng.choice(pods)}#auditor@user:{rng.choice(users)}"]
+    e = aclgpu.Engine(SCHEMA_COMBINE if schema == "combine" else workloads.SCHEMA_C4, store_only=True)
     if shard:  # (rank, world): the snapshot of ONE shard of the type-hash layout -- it holds, and patches, only the rows of the types it owns
         e._check(e._L.acl_shard_configure(e._h, shard[0], shard[1]))
     live = set(dict.fromkeys(rng.choice(shapes)() for _ in range(2500 * universe)))
@@ -276,10 +333,12 @@ if __name__ == "__main__":
     ap.add_argument("--compact-early", action="store_true", help="ACL_COMPACTION_SLACK=0: background compactions (and their adoption with the writes since replayed) happen on this small graph too")
     ap.add_argument("--patcher", action="store_true", help="no GPU: a store-only engine whose host snapshot is verified against the store after every write")
     ap.add_argument("--expiry", action="store_true", help="the other campaign: the reference's bootstrap schema, dual-write shapes, expiring idempotency keys, a moving clock")
+    ap.add_argument("--schema", choices=["c4", "combine"], default="c4", help="combine: the C4 schema with exclusions, intersections, wildcards and a non-monotone userset subject")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
-        print(run_patcher(a.seed, a.steps, a.universe, a.burst) if a.patcher else run_expiry(a.seed, a.steps) if a.expiry else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early))
+        print(run_patcher(a.seed, a.steps, a.universe, a.burst, schema=a.schema) if a.patcher else run_expiry(a.seed, a.steps) if a.expiry
+              else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early, schema=a.schema))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)
