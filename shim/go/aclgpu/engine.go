@@ -24,6 +24,7 @@ import (
 // Config mirrors acl_config_t plus the micro-batcher settings (acl_batcher_start).
 type Config struct {
 	Device             int32  // HIP device ordinal, -1 = current
+	Devices            []int32 // several ordinals: ONE engine in front of one HBM snapshot per device (acl_open_replicas); overrides Device
 	FrontierEntries    uint64 // 0 = default
 	BatchMaxItems      uint32 // 0 = no micro-batching of single checks
 	BatchMaxWaitMicros uint32
@@ -45,7 +46,17 @@ func lastError(rc C.int) error {
 func Open(cfg Config, schema, relationships string) (*Engine, error) {
 	var h *C.acl_engine_t
 	c := C.acl_config_t{device: C.int32_t(cfg.Device), frontier_entries: C.uint64_t(cfg.FrontierEntries), contexts: C.uint32_t(cfg.Contexts)}
-	if rc := C.acl_open(&c, &h); rc != 0 {
+	if len(cfg.Devices) > 0 {
+		// the proxy holds ONE PermissionsClient (options.go:371-377) and its dual-write worker shares it (server.go:136-153): every write is
+		// patched into every replica before its next read, calls are spread over the devices by load
+		devs := make([]C.int32_t, len(cfg.Devices))
+		for i, d := range cfg.Devices {
+			devs[i] = C.int32_t(d)
+		}
+		if rc := C.acl_open_replicas(&c, &devs[0], C.uint32_t(len(devs)), &h); rc != 0 {
+			return nil, lastError(rc)
+		}
+	} else if rc := C.acl_open(&c, &h); rc != 0 {
 		return nil, lastError(rc)
 	}
 	cs, cr := C.CString(schema), C.CString(relationships)
