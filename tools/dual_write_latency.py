@@ -109,6 +109,7 @@ for i in range(nb):
     if c is not None:
         confl.append(c)
 st3 = e.stats()
+objects_end = {t: e.object_count(t) for t in ("lock", "workflow", "activity", "pod")}
 lk0 = time.perf_counter()
 got = e.lookup("pod", "view", "user", "paul7")
 lk = time.perf_counter() - lk0
@@ -130,6 +131,10 @@ print(json.dumps({
     "across_compaction": {"bulk_creates_before": k, "kube_writes": nb, "check_after_W1": pct(c1), "check_after_W2": pct(c2), "two_writes_ms_p50": round(1e3 * float(np.median(cw)), 4),
                           "snapshot_compactions": st3["snapshot_compactions"] - st2["snapshot_compactions"],
                           "synchronous_rebuilds": st3["snapshot_builds"] - st2["snapshot_builds"], "patches": st3["snapshot_patches"] - st2["snapshot_patches"]},
+    # object ids are recycled (round 4): a lock is free again behind its W2, a workflow / its activities once their keys are collected (24 h) --
+    # with the production quarantine (30 s) a run this short recycles little; ACL_ID_QUARANTINE_MS shortens it for the run
+    "id_recycling": {"quarantine_ms": int(os.environ.get("ACL_ID_QUARANTINE_MS", "30000")), "ids_recycled": int(st3.get("ids_recycled", 0)), "objects_at_end": objects_end,
+                     "locks_written": 400 + nb},
     "lookup_after_all_ms": round(1e3 * lk, 3), "lookup_ids": len(got)}))
 if not all(oks) or not all(confl):
     raise SystemExit("dual-write run: a read was wrong or a lock conflict went unnoticed")
