@@ -483,6 +483,13 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                     const uint32_t b0 = ta.y;
                     p[k] = gld(buckets, b0 + h1);
                     q[k] = gld(buckets, b0 + h2);
+#ifdef ACL_EXPERIMENT_THIRD_BUCKET  // (timing experiment only, answers unchanged: one MORE 16-byte gather per child, into the same row -- the
+                                    //  walk's sensitivity to the number of bucket gathers; profiles/r04_bucket_gather_sensitivity.txt)
+                    if (ACL_EXPERIMENT_THIRD_BUCKET == 1 || (lane % ACL_EXPERIMENT_THIRD_BUCKET) == 0u) {  // (N > 1: only every N-th lane issues it)
+                        const uint4 x3 = gld(buckets, b0 + (h1 + 1u < ta.z ? h1 + 1u : 0u));
+                        ACL_KEEP(x3.x);
+                    }
+#endif
                 }
                 issue_fence();  // trip 2: the 2 x W buckets
                 ACL_MARK(wo, PH_BUCKETS);
