@@ -690,11 +690,12 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     // slices would share the node / cell scratch) and not while kernels are being timed (the events sit on the context's stream).
     uint32_t nstreams = 1;
     bool lone = false;
-    if (npass == 1 && n >= 262144) {
+    if (n >= 65536) {
         std::lock_guard<std::mutex> lk(h->pool_mu);
         lone = c->dev->in_use <= 1;
     }
-    if (h->host_split > 1 && !h->snap.has_combine && !c->timing && (npass > 1 || lone)) {
+    const bool lone_split = lone && npass == 1 && n >= 262144;
+    if (h->host_split > 1 && !h->snap.has_combine && !c->timing && (npass > 1 || lone_split)) {
         nstreams = std::min<uint32_t>(h->host_split, 4);
         npass = std::max(npass, nstreams);
     }
@@ -743,7 +744,8 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
         hipStream_t st = lane ? c->aux[lane - 1] : c->stream;
         if (nstreams == 1) ev_begin(c, 2);
         launch_check_local(st, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p + region, c->d_fbuf[1].p + region, Gk.cap, (uint32_t *)d_flag + k,
-                           c->d_has.p + off, c->d_err.p + off, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide);
+                           c->d_has.p + off, c->d_err.p + off, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide,
+                           lone && Gk.nunits > 1 ? Gk.rpw * h->host_skew_pct / 100 : 0u);
         if (nstreams == 1) ev_end(c);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1695,6 +1697,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_RAW_INTERN")) h->raw_intern = atoi(ev) != 0;  // test knob: acl_intern takes any bytes (the JSON scanners' decoding tests name objects no API request could)
+    if (const char *ev = getenv("ACL_HOST_SKEW_PCT")) h->host_skew_pct = (uint32_t)std::min(90, std::max(0, atoi(ev)));
     if (const char *ev = getenv("ACL_HOST_SPLIT")) h->host_split = (uint32_t)std::min(4, std::max(1, atoi(ev)));
     if (const char *ev = getenv("ACL_LOCAL_UPW")) h->local_upw = (uint32_t)std::max(1, atoi(ev));  // A/B knob: units per resident wave
     if (const char *ev = getenv("ACL_LOCAL_STATIC_PCT")) h->local_static_pct = (uint32_t)std::min(100, std::max(10, atoi(ev)));  // A/B knobs: share of a chip-filling batch

@@ -357,6 +357,8 @@ struct acl_engine {
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
     uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)
+    uint32_t host_skew_pct = 8;  // a lone caller's host-mapped launch: first unit this many percent larger than the mean, last one as much smaller (ACL_HOST_SKEW_PCT;
+                                 // worth 1-3 % of such a call -- the items do NOT arrive in block order, or 16 % would have hidden half the transfer: profiles/r04_host_skew.txt)
     uint32_t host_split = 2;   // streams the slices of one large host batch are spread over (ACL_HOST_SPLIT, 1 = off; engine.cpp check_pass_local_host)
     uint32_t local_upw = 1;    // single-launch pass over a large batch: work units per resident wave.  1 = every wave one unit of n / waves requests (no
                                // second round of per-level latency chains); 2 balances C4's uneven requests 3 % better but costs C2 a whole second round

@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
                                                                                   uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
                                                                                   uint32_t cap,
                                                                                   uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
-                                                                                  int32_t *err_out, uint32_t *max_level) {
+                                                                                  int32_t *err_out, uint32_t *max_level, uint32_t skew) {
     __shared__ TaskLds lds[WAVES];
     __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
@@ -1285,8 +1285,16 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     // handed out through `next_unit` as blocks finish -- the launch's tail is then a small unit's walk, not the slowest big unit's
     const uint32_t nstat_req = min(n, nstatic * rpw);
     for (uint32_t unit = blockIdx.x; unit < nunits;) {
-        const uint32_t first = unit < nstatic ? unit * rpw : nstat_req + (unit - nstatic) * rdyn;
-        const uint32_t mine = unit < nstatic ? min(rpw, nstat_req - first) : min(rdyn, n - first);  // <= 256: thread i seeds and answers request first + i
+        // skew != 0 (host-mapped batches of a lone caller, static units only): the items cross PCIe in block order, so block u's seeds arrive
+        // ~ u / nunits of the transfer late -- unit u gets rpw + skew (first block) ... rpw - skew (last) requests, and the blocks end together
+        // instead of the last ones trailing by the transfer time: boundary(u) = u rpw + skew u (nunits - u) / nunits, `skew` in 1/256ths per unit
+        uint32_t first = unit < nstatic ? unit * rpw : nstat_req + (unit - nstatic) * rdyn;
+        uint32_t mine = unit < nstatic ? min(rpw, nstat_req - first) : min(rdyn, n - first);  // <= WAVES * 64: thread i seeds and answers request first + i
+        if (skew) {
+            const uint32_t u = uniform(unit);
+            first = min(n, u * rpw + ((skew * u * (nunits - u)) >> 8));
+            mine = min(n, (u + 1u) * rpw + ((skew * (u + 1u) * (nunits - u - 1u)) >> 8)) - first;
+        }
         if (threadIdx.x < 6) s_cursors[threadIdx.x] = 0;
         if (CMB && threadIdx.x < 2) s_ccount[threadIdx.x] = 0;
         __syncthreads();
@@ -2112,33 +2120,36 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 template <int WAVES>
 static void launch_check_local_w(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t nunits, uint32_t nstatic, uint32_t rdyn,
                                  uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
-                                 uint32_t *max_level) {
+                                 uint32_t *max_level, uint32_t skew) {
     const dim3 grid(nblocks);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
     if (g.bexpr) {  // schemas with `&` / `-`: the combine instantiations
         if (lds)
             hipLaunchKernelGGL((k_check_local<true, WAVES, true>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow,
-                               has, err, perm_out, err_out, max_level);
+                               has, err, perm_out, err_out, max_level, skew);
         else
             hipLaunchKernelGGL((k_check_local<false, WAVES, true>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                               perm_out, err_out, max_level);
+                               perm_out, err_out, max_level, skew);
         return;
     }
     if (lds)
         hipLaunchKernelGGL((k_check_local<true, WAVES>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                           perm_out, err_out, max_level);
+                           perm_out, err_out, max_level, skew);
     else
         hipLaunchKernelGGL((k_check_local<false, WAVES>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out,
-                           err_out, max_level);
+                           err_out, max_level, skew);
 }
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
                         uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level,
-                        uint32_t nstatic, uint32_t rdyn, bool wide) {
+                        uint32_t nstatic, uint32_t rdyn, bool wide, uint32_t skew) {
     uint32_t nunits = (n + rpw - 1) / rpw;
+    if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) skew = 0;  // (static units only)
+    skew = std::min(skew, std::min(rpw - 1u, (wide ? kLocalWide : kLocalNarrow) * 64u - rpw));  // the largest unit still fits the block: thread i seeds request first + i
+    skew = nunits > 1 && nunits <= 4096 ? (skew << 8) / nunits : 0u;                             // (the kernel's fixed-point form: 1/256ths per unit; u (nunits - u) skew < 2^32)
     if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) nunits = nstatic + (n - nstatic * rpw + rdyn - 1) / rdyn;  // static units, then small ones
     else nstatic = nunits, rdyn = rpw;
-    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
-    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level);
+    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew);
+    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew);
 }
 template <int WAVES>
 static int local_occupancy(bool lds, size_t prog_bytes) {
