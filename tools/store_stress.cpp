@@ -19,7 +19,10 @@ static const char *kSchema =
     "definition group {\n  relation member: user | group#member\n}\n"
     "definition namespace {\n  relation viewer: user | group#member\n  relation creator: user\n  permission view = viewer + creator\n}\n"
     "definition pod {\n  relation namespace: namespace\n  relation viewer: user | group#member\n  relation creator: user\n"
-    "  permission view = viewer + creator + namespace->view\n}\n";
+    "  permission view = viewer + creator + namespace->view\n}\n"
+    // the dual write's short-lived objects (workflow.go:392-462): their ids are recycled under everybody else (quarantine 0 below)
+    "definition lock {\n  relation workflow: workflow\n}\n"
+    "definition workflow {}\n";
 
 int main(int argc, char **argv) {
     const int ROUNDS = argc > 1 ? atoi(argv[1]) : 300;
@@ -43,6 +46,7 @@ int main(int argc, char **argv) {
         snprintf(b, sizeof b, "group:g%d#member@user:u%d\ngroup:g%d#member@group:g%d#member\nnamespace:ns%d#viewer@group:g%d#member\n", g, g, g, (g + 1) % 100, g % 50, g);
         rels += b;
     }
+    setenv("ACL_ID_QUARANTINE_MS", "0", 1);  // (read when a schema is loaded) freed ids are taken by the next new name at once
     if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) { fprintf(stderr, "load: %s\n", acl_last_error()); return 1; }
     if (acl_batcher_start(h, 256, 50)) return 1;
     std::atomic<int> bad{0};
@@ -62,6 +66,16 @@ int main(int argc, char **argv) {
                                      {ACL_OP_TOUCH, {"pod", rid, "creator", "user", sid, "", 0}}};
                 uint64_t rev = 0;
                 if (acl_write(h, u, 2, nullptr, 0, &rev) || !rev) bad++;
+                {   // W1 / W2 of a kube write: a lock behind MUST_NOT_MATCH, deleted again -- its id (and the workflow's) goes round
+                    char lk[48], wf[48];
+                    snprintf(lk, sizeof lk, "l%d-%d", wtr, r);
+                    snprintf(wf, sizeof wf, "w%d-%d", wtr, r);
+                    acl_filter_t pre{ACL_PRE_MUST_NOT_MATCH, "lock", lk, "workflow", "workflow", nullptr, nullptr};
+                    acl_update_t c{ACL_OP_CREATE, {"lock", lk, "workflow", "workflow", wf, "", 0}};
+                    if (acl_write(h, &c, 1, &pre, 1, &rev) && !reload) bad++;
+                    acl_update_t d{ACL_OP_DELETE, {"lock", lk, "workflow", "workflow", wf, "", 0}};
+                    if (acl_write(h, &d, 1, nullptr, 0, &rev) && !reload) bad++;
+                }
                 if (r % 16 == 0) {  // CREATE of something that exists must fail, atomically (activity.go:62-74)
                     acl_update_t c{ACL_OP_CREATE, {"pod", rid, "creator", "user", sid, "", 0}};
                     if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS && !reload) bad++;
@@ -100,6 +114,26 @@ int main(int argc, char **argv) {
                 else bad++;
             }
         });
+    // a Watch stream as the shim holds it: blocked in acl_watch_wait (a condition variable behind the write path), then a poll; a cursor that an
+    // id's recycling has overtaken is refused (OUT_OF_RANGE) and the stream starts over at the head
+    th.emplace_back([&] {
+        uint64_t cursor = 0, head = 0;
+        acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
+        const int tl = acl_type_id(h, "lock");
+        long seen = 0, waits = 0;
+        while (!stop.load()) {
+            acl_call_opts_t o{nullptr, 5 * 1000 * 1000};  // 5 ms
+            const int wrc = acl_watch_wait(h, cursor, &tl, 1, &o, &head);
+            if (wrc && wrc != ACL_ERR_DEADLINE_EXCEEDED && wrc != ACL_ERR_OUT_OF_RANGE) bad++;
+            waits++;
+            uint64_t next = 0;
+            const int rc = acl_watch_poll(h, cursor, &tl, 1, [](void *u, uint64_t, int32_t, const acl_relationship_t *) { ++*(long *)u; }, &seen, &next);
+            if (rc == ACL_OK) cursor = next;
+            else if (rc == ACL_ERR_OUT_OF_RANGE) acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
+            else bad++;
+        }
+        if (!waits) bad++;
+    });
     // snapshot maintenance: the patcher and the background compaction's two halves, verified against the store each time
     th.emplace_back([&] {
         int k = 0;
