@@ -83,7 +83,7 @@ enum {
 #define WILDCARD 0xFFFEu /* tuple_t.srel of `T:*` subjects (subj = the interned id of "*", never compared) */
 
 /* ------------------------------------------------------------------ schema */
-enum { EX_UNION, EX_REF, EX_ARROW, EX_NIL, EX_INTERSECT, EX_EXCLUDE };
+enum { EX_UNION, EX_REF, EX_ARROW, EX_NIL, EX_INTERSECT, EX_EXCLUDE, EX_ARROW_ALL /* a.all(b): the intersection arrow */ };
 typedef struct expr {
     int kind;
     struct expr *l, *r; /* union, intersection; exclusion: l minus r */
@@ -286,14 +286,15 @@ static expr_t *parse_term(lex_t *L) {
         lx_next(L);
         return e;
     }
-    if (L->tok == '.') { /* a.any(b) == a->b ; a.all(b) rejected */
+    if (L->tok == '.') { /* a.any(b) == a->b ; a.all(b): b must hold on EVERY subject of a (and there must be one) */
         lx_next(L);
         if (L->tok != 'i') { lx_fail(L, "expected any/all"); return NULL; }
-        if (strcmp(L->text, "any") != 0) { lx_fail(L, "unsupported: .all() arrows (intersection arrows)"); return NULL; }
+        const int all = strcmp(L->text, "all") == 0;
+        if (!all && strcmp(L->text, "any") != 0) { lx_fail(L, "unsupported arrow function (any / all)"); return NULL; }
         lx_next(L);
         if (!lx_expect(L, '(', "expected '('")) return NULL;
         if (L->tok != 'i') { lx_fail(L, "expected identifier"); return NULL; }
-        expr_t *e = ex_new(EX_ARROW);
+        expr_t *e = ex_new(all ? EX_ARROW_ALL : EX_ARROW);
         e->a = strdup(a); e->b = strdup(L->text);
         lx_next(L);
         if (!lx_expect(L, ')', "expected ')'")) { ex_free(e); return NULL; }
@@ -448,7 +449,7 @@ static int parse_schema(orc_t *o, const char *text) {
                 if (e->kind == EX_UNION || e->kind == EX_INTERSECT || e->kind == EX_EXCLUDE) { stack[sp++] = e->l; stack[sp++] = e->r; }
                 else if (e->kind == EX_REF) {
                     if (rel_index(t, e->a) < 0) { seterr(o, "schema: %s#%s references unknown '%s'", t->name, r->name, e->a); return 0; }
-                } else if (e->kind == EX_ARROW) {
+                } else if (e->kind == EX_ARROW || e->kind == EX_ARROW_ALL) {
                     int x = rel_index(t, e->a);
                     if (x < 0 || t->rels[x].is_perm) { seterr(o, "schema: %s#%s arrow over non-relation '%s'", t->name, r->name, e->a); return 0; }
                     for (int k = 0; k < t->rels[x].nallowed; k++)
@@ -664,6 +665,27 @@ static int eval_expr(orc_t *o, int type, const expr_t *e, uint32_t id, const sub
             acc = join_union(acc, r);
         }
         return acc;
+    }
+    case EX_ARROW_ALL: { /* intersection arrow (EXTERNAL, unverified: restated from SpiceDB's documentation of `.all()`): every subject of the
+                          * tupleset is dispatched; no subject -> NO; one NO decides; else an error wins over HAS.  A subject whose type lacks
+                          * the computed permission is not dispatched, as for `->` */
+        int ts = rel_index(t, e->a);
+        size_t lo, hi;
+        row_range(o, type, ts, id, &lo, &hi);
+        o->cnt_rows++;
+        int n = 0, any_err = 0;
+        for (size_t i = lo; i < hi; i++) {
+            const tuple_t *tp = &o->tup[i];
+            if (!tup_live(o, tp)) continue;
+            o->cnt_edges++;
+            int tr = rel_index(&o->types[tp->stype], e->b);
+            if (tr < 0) continue;
+            int r = check_rel(o, tp->stype, tr, tp->subj, s, depth_remaining - 1);
+            if (r == R_NO) return R_NO;
+            if (r == R_ERR) any_err = 1;
+            n++;
+        }
+        return n == 0 ? R_NO : (any_err ? R_ERR : R_HAS);
     }
     }
     return R_NO;
@@ -1234,7 +1256,7 @@ static uint64_t check_bytes_core(orc_t *o, int rtype, int perm, uint32_t res, in
                     const expr_t *e = stack[--sp];
                     if (e->kind == EX_UNION || e->kind == EX_INTERSECT || e->kind == EX_EXCLUDE) { stack[sp++] = e->l; stack[sp++] = e->r; }
                     else if (e->kind == EX_REF) PUSH_NEXT(st.type, rel_index(&o->types[st.type], e->a), st.id);
-                    else if (e->kind == EX_ARROW) {
+                    else if (e->kind == EX_ARROW || e->kind == EX_ARROW_ALL) {
                         int ts = rel_index(&o->types[st.type], e->a);
                         rel_t *tr = &o->types[st.type].rels[ts];
                         size_t lo, hi;

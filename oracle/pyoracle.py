@@ -40,7 +40,7 @@ class Relation:
 @dataclass
 class Permission:
     name: str
-    expr: tuple  # ('union' | 'inter' | 'excl', a, b) | ('ref', name) | ('arrow', tupleset, computed) | ('nil',)
+    expr: tuple  # ('union' | 'inter' | 'excl', a, b) | ('ref', name) | ('arrow' | 'arrow_all', tupleset, computed) | ('nil',)
 
 
 @dataclass
@@ -69,9 +69,9 @@ def _parse_expr(tokens: list, pos: int):
         if p + 1 < len(tokens) and tokens[p + 1] == "->":
             return ("arrow", t, tokens[p + 2]), p + 3
         if p + 1 < len(tokens) and tokens[p + 1] == ".":
-            if tokens[p + 2] != "any":
-                raise SchemaError("unsupported: .all()")
-            return ("arrow", t, tokens[p + 4]), p + 6
+            if tokens[p + 2] not in ("any", "all"):
+                raise SchemaError("unsupported arrow function (any / all)")
+            return ("arrow" if tokens[p + 2] == "any" else "arrow_all", t, tokens[p + 4]), p + 6
         return ("ref", t), p + 1
 
     # precedence climbing: a level's operands are the next-tighter level's expressions
@@ -147,7 +147,7 @@ def _validate(defs, d, e):
         _validate(defs, d, e[2])
     elif e[0] == "ref" and e[1] not in d.members:
         raise SchemaError(f"unknown reference {e[1]}")
-    elif e[0] == "arrow":
+    elif e[0] in ("arrow", "arrow_all"):
         ts = d.members.get(e[1])
         if not isinstance(ts, Relation):
             raise SchemaError(f"arrow over non-relation {e[1]}")
@@ -235,6 +235,9 @@ class PyOracle:
         if e[0] == "excl":
             a = self._eval(rtype, rid, e[1], subject, depth)
             return a if a != HAS else _MINUS[self._eval(rtype, rid, e[2], subject, depth)]
+        if e[0] == "arrow_all":  # intersection arrow (EXTERNAL, unverified): every subject of the tupleset must hold the permission, and there must be one
+            rs = [self._check(st, sid, e[2], subject, depth - 1) for (st, sid, _sr) in self._subjects(rtype, rid, e[1]) if e[2] in self.defs[st].members]
+            return NO if not rs or NO in rs else ERR if ERR in rs else HAS
         if e[0] == "union":
             rs = [self._eval(rtype, rid, e[1], subject, depth), self._eval(rtype, rid, e[2], subject, depth)]
         elif e[0] == "ref":

@@ -52,7 +52,8 @@ constexpr uint32_t kTaskCap = 128;  // LDS task slots per wave
 constexpr uint32_t kHeadWords = 32;  // flush_simple maps work items to tasks through head bits: rounds of <= 64 * kHeadWords children
 constexpr uint32_t kSelfBit = 0x80000000u;      // task: the child is the same object (start holds its id)
 constexpr uint32_t kLeafAuthBit = 0x40000000u;  // task: the row's edges carry authoritative leaf flags
-constexpr uint32_t kCountMask = 0x3FFFFFFFu;
+constexpr uint32_t kAllBit = 0x20000000u;       // task (combine schemas): the tupleset of an intersection arrow -- every child gets a result cell of its own (OP_ALL)
+constexpr uint32_t kCountMask = 0x1FFFFFFFu;
 constexpr uint32_t kMaxRow = 1u << 25;  // rows longer than this cannot be enumerated in one task
 constexpr uint32_t kNoSpace = 0xFFFFFFFFu;
 
@@ -316,6 +317,10 @@ __device__ __forceinline__ void resolve_node(const uint4 &nd, const SlotProg *pr
         uint32_t v;
         if (kind == BX_LEAF) {
             v = cell_value(has, err, nd.y + arg - 1u);
+        } else if (kind == BX_LEAF_ALL) {  // a.all(b): folded from the children's cells by the member nodes (resolve_member)
+            const uint32_t c = nd.y + arg - 1u;
+            const uint32_t h = __hip_atomic_load(has + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), e = __hip_atomic_load(err + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            v = (e & kAllNoBit) ? V_NO : ((e & 0x7Fu) ? V_ERR : (h ? V_HAS : V_NO));
         } else if (kind == BX_EXCL) {
             const uint32_t sub = (uint32_t)st & 3u, base = (uint32_t)(st >> 2) & 3u;
             st >>= 4;
@@ -336,6 +341,19 @@ __device__ __forceinline__ void resolve_node(const uint4 &nd, const SlotProg *pr
     const uint32_t v = ntok ? ((uint32_t)st & 3u) : V_NO;
     if (v == V_HAS) has[nd.x] = 1;
     else if (v == V_ERR) err[nd.x] = ITEM_ERR_DEPTH;
+}
+// member node of an intersection arrow {x: the arrow's leaf cell, y: the child's own cell, z: iteration << 16, w: 1}: the child's verdict is folded
+// into the leaf cell -- HAS: "some child holds it"; NO / ERR: bits of the err byte, set with a word-wide atomic OR (several members of one
+// arrow resolve at once; the neighbouring bytes' bits stay what they are).  Resolved BEFORE the regular nodes of its iteration.
+__device__ __forceinline__ void resolve_member(const uint4 &nd, uint8_t *has, uint8_t *err) {
+    const uint32_t v = cell_value(has, err, nd.y);
+    if (v == V_HAS) {
+        has[nd.x] = 1;
+        return;
+    }
+    uint8_t *p = err + nd.x;
+    const uint32_t sh = 8u * (uint32_t)((uintptr_t)p & 3u);
+    atomicOr(reinterpret_cast<unsigned int *>((uintptr_t)p & ~(uintptr_t)3), (uint32_t)(v == V_NO ? kAllNoBit : ITEM_ERR_DEPTH) << sh);
 }
 
 // Child mode: evaluate every probe of state (slot, id) at `level` for subject (key, sid) without creating tasks.
@@ -646,7 +664,8 @@ __device__ __forceinline__ void export_entries(bool xport, const uint4 &e, uint3
 template <bool INLINE, bool SHARDED, bool LOCAL, bool DESC = false, bool CMB = false>  // DESC: the tasks carry the subject's hashed row (TaskLds b0 / nb); CMB: child slots may hold combine programs
 __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg *progs,
                                             const FwdOp *ops, const uint32_t *__restrict__ edges, uint8_t *has, uint8_t *err, const DevShard &sh,
-                                            bool same = false /* the caller made every task from ONE op: child slot, key and flags agree */) {
+                                            bool same = false /* the caller made every task from ONE op: child slot, key and flags agree */,
+                                            const CombineOut &co = CombineOut() /* CMB: where the children of an intersection arrow get their cells and member nodes */) {
     constexpr bool E8 = ACL_ENTRY8 && INLINE && LOCAL && !CMB;  // (8-byte entries: the single-launch walk's monotone instantiations)
     uint32_t only = ~0u;  // rounds of 64 tasks left for the generic loop
     wave_lds_fence();
@@ -666,7 +685,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
         } else {
             for (uint32_t i = lane; i < T; i += 64) {
                 const uint32_t mi = t.meta[i], ci = t.count[i];
-                agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & kSelfBit);
+                agree = agree && meta_slot(mi) == cs && meta_key(mi) == k0 && (ci & kLeafAuthBit) && !(ci & (kSelfBit | kAllBit));
             }
         }
         if (ok && !__ballot(!agree)) {
@@ -685,7 +704,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
             bool agree2 = true;
             for (uint32_t i = lane; i < T; i += 64) {
                 const uint32_t mi = t.meta[i], ci = t.count[i];
-                agree2 = agree2 && meta_slot(mi) == cs && meta_key(mi) == k0 && ((ci & kLeafAuthBit) != 0) == la0 && !(ci & kSelfBit);
+                agree2 = agree2 && meta_slot(mi) == cs && meta_key(mi) == k0 && ((ci & kLeafAuthBit) != 0) == la0 && !(ci & (kSelfBit | kAllBit));
             }
             if (shape && !__ballot(!agree2)) {
                 flush_probes<SHARDED, LOCAL, E8>(t, T, wo, lane, g, cp, cops, k0, la0, has, err);
@@ -702,19 +721,55 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
         wave_lds_fence();
         for (uint32_t w0 = 0; w0 < total; w0 += 64) {
             const uint32_t w = w0 + lane;
-            bool push = false, xport = false;
+            bool push = false, xport = false, live = false, isall = false;
             uint4 e = make_uint4(0, 0, 0, 0);
+            uint32_t c = 0, edge = 0, child = 0, s = 0, j = 0;
             if (w < total) {
-                uint32_t j = 0;  // largest j with scan[j] <= w
+                // largest j with scan[j] <= w
 #pragma unroll
                 for (uint32_t step = 32; step >= 1; step >>= 1)
                     if (t.scan[j + step] <= w) j += step;
                 const uint32_t tj = gq + j;
-                const uint32_t c = t.count[tj], s = t.a[tj].x;
-                const uint32_t edge = (c & kSelfBit) ? s : gld(edges, s + (w - t.scan[j]));
-                const uint32_t child = INLINE ? (edge & kIdMask) : edge;
+                c = t.count[tj];
+                s = t.a[tj].x;
+                edge = (c & kSelfBit) ? s : gld(edges, s + (w - t.scan[j]));
+                child = INLINE ? (edge & kIdMask) : edge;
                 e = make_uint4(child, t.a[tj].w, t.meta[tj], t.sid[tj]);
-                push = true;
+                push = live = true;
+                isall = CMB && (c & kAllBit);
+            }
+            if (CMB) {
+                // children of an intersection arrow a.all(b): a result cell of its own for every child, and a member node that folds the child's
+                // verdict into the arrow's leaf cell (resolve_member) -- one reservation per wave and window
+                const uint64_t ab = __ballot(isall);
+                if (ab) {
+                    const uint32_t k = (uint32_t)__popcll(ab);
+                    uint32_t c0 = 0, n0 = 0;
+                    if (lane == 0) {
+                        c0 = atomicAdd(co.ncell, k);
+                        n0 = atomicAdd(co.nnode, k);
+                    }
+                    c0 = uniform(c0);
+                    n0 = uniform(n0);
+                    if (c0 + k > co.cell_cap || n0 + k > co.node_cap) {  // out of cells / nodes: as where a combine state is visited (process_segment)
+                        if (LOCAL) {
+                            if (lane == 0) *wo.cold->overflow = 1u;
+                            wo.cur = kNoSpace;
+                        } else if (lane == 0) {
+                            *wo.cold->overflow = 3u;
+                        }
+                        if (isall) push = live = false;
+                    } else if (isall) {
+                        const uint32_t r = lanes_below(ab), cell = co.cell0 + c0 + r;
+                        has[cell] = 0;
+                        err[cell] = ITEM_ERR_NONE;
+                        co.nodes[n0 + r] = make_uint4(e.y, cell, co.iter << 16, 1u);
+                        e.y = cell;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (the zeroes are acknowledged before a probe of the child stores a hit)
+                }
+            }
+            if (live) {
                 if (INLINE && SHARDED && progs[meta_slot(e.z)].owner != sh.rank) {
                     // the child's rows live on another shard: it leaves unprobed and is evaluated by its owner
                     push = false;
@@ -747,7 +802,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     if (ACL_PERTURB == 8) {
                         uint32_t x = 0;
 #pragma unroll
-                        for (int q = 0; q < 6; q++) x += t.meta[(tj + q * 7 + x) & (kTaskCap - 1)];
+                        for (int q = 0; q < 6; q++) x += t.meta[(gq + j + q * 7 + x) & (kTaskCap - 1)];
                         ACL_KEEP(x);
                     }
                 }
@@ -836,7 +891,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         auto lane_op = [&](uint32_t m, LaneOp &L) -> bool {  // false: not a simple parent
             if (m == kDeadMeta || !(m & kProbedBit) || meta_key(m) < g.nslots) return false;
             const SlotProg sp = progs[meta_slot(m)];
-            if (sp.n_main != sp.n_probe + 1) return false;
+            if (sp.n_main != sp.n_probe + 1 || (CMB && sp.combine)) return false;
             const FwdOp o = ops[sp.first + sp.n_probe];
             if (!(o.flags & OP_ENUM) || (o.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH))) return false;
             L.flags = o.flags; L.dlevel = o.dlevel; L.base = o.base; L.nrows = o.nrows; L.Kk = o.K | (o.k << 16); L.key = o.key; L.maxd = sp.max_dlevel;
@@ -1008,7 +1063,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                                 else if (!(leafop ? h : (hit || h))) {
                                     want = true;
                                     tstart = md.x;
-                                    tcount = (md.y - md.x) | ((op.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u);
+                                    tcount = (md.y - md.x) | ((op.flags & OP_LEAFBIT) ? kLeafAuthBit : 0u) | ((CMB && (op.flags & OP_ALL)) ? kAllBit : 0u);
                                     tmeta = make_meta(op.key, L + 1, key);
                                 }
                             }
@@ -1058,7 +1113,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                 wave_lds_fence();
                 if (lane < cnt) { t.a[lane] = c0; t.count[lane] = c1; t.meta[lane] = c3; t.sid[lane] = c4; }
             }
-            flush_tasks<true, SHARDED, LOCAL, false, CMB>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh);
+            flush_tasks<true, SHARDED, LOCAL, false, CMB>(t, cnt, wo, lane, g, progs, ops, g.edges, has, err, sh, false, co);
             a = bnd;
         }
         if (!more) break;
@@ -1370,11 +1425,15 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             const uint32_t nn = min(s_ccount[1], co.node_cap);
             if (nn && !s_stop) {
                 for (uint32_t it = level_reached; it >= 1u; it--) {
-                    for (uint32_t i = threadIdx.x; i < nn; i += WAVES * 64) {
-                        const uint4 nd = co.nodes[i];
-                        if ((nd.z >> 16) == it) resolve_node(nd, progs, co.bexpr, has, err);
+                    for (uint32_t ph = 0; ph < 2u; ph++) {  // the member nodes of intersection arrows first: the regular nodes of `it` read what they fold
+                        for (uint32_t i = threadIdx.x; i < nn; i += WAVES * 64) {
+                            const uint4 nd = co.nodes[i];
+                            if ((nd.z >> 16) != it || (nd.w != 0u) != (ph == 0u)) continue;
+                            if (ph == 0u) resolve_member(nd, has, err);
+                            else resolve_node(nd, progs, co.bexpr, has, err);
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                 }
             }
         }
@@ -1482,11 +1541,13 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
 
 // Level loop, schemas with `&` / `-`: the combine nodes of ONE frontier iteration (launched for iter = last .. 1; the list is scanned whole
 // every time -- this is the overflow path, not the fast one).
-__global__ __launch_bounds__(256) void k_resolve(DevGraph g, uint32_t iter, uint8_t *has, uint8_t *err) {
+__global__ __launch_bounds__(256) void k_resolve(DevGraph g, uint32_t iter, uint32_t members, uint8_t *has, uint8_t *err) {
     const uint32_t nn = min(g.ccount[1], g.node_cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         const uint4 nd = g.nodes[i];
-        if ((nd.z >> 16) == iter) resolve_node(nd, g.progs, g.bexpr, has, err);
+        if ((nd.z >> 16) != iter || (nd.w != 0u) != (members != 0u)) continue;
+        if (members) resolve_member(nd, has, err);  // (launched first: the regular nodes of the iteration read what the members fold)
+        else resolve_node(nd, g.progs, g.bexpr, has, err);
     }
 }
 
@@ -2181,7 +2242,8 @@ void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_
     hipLaunchKernelGGL(k_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, has, err, perm_out, err_out);
 }
 void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err) {
-    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, has, err);
+    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, 1u, has, err);
+    hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, 0u, has, err);
 }
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key) {
     const uint32_t threads = std::max(std::max(n, f.nwaves), kStatusWords);

@@ -188,6 +188,22 @@ struct Flattener {
                 build(type, n.kids[1]);
                 tokens.push_back(BX_EXCL);
                 break;
+            case Node::kArrowAll: {
+                // a.all(b): a leaf of its own whose only ops enumerate the tupleset, every child answering a result cell of ITS own
+                // (OP_ALL); the leaf's value = NO if there is no child or one says NO, else ERR if one errs, else HAS (BX_LEAF_ALL)
+                const Definition &def = sc.defs[type];
+                const Member &rel = def.members[def.find(n.a)];
+                const uint32_t saved = cur_leaf;
+                cur_leaf = new_leaf();
+                for (size_t k = 0; k < rel.classes.size(); k++) {
+                    const int st = rel.classes[k].stype, tm = sc.defs[st].find(n.b);
+                    if (tm < 0) continue;  // subject type lacks the computed permission: not dispatched (as for `->`; EXTERNAL, unverified)
+                    row_op(OP_ENUM | OP_ALL, rel.slot, (int)k, 0, (uint32_t)sc.slot(st, tm));
+                }
+                tokens.push_back(BX_LEAF_ALL | cur_leaf);
+                cur_leaf = saved;
+                break;
+            }
             default: break;  // (refs, arrows and nil are monotone)
         }
     }
@@ -241,7 +257,7 @@ struct Flattener {
 };
 
 void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
-    if (n.kind == kind) out->push_back(&n);
+    if (n.kind == kind || (kind == Node::kArrow && n.kind == Node::kArrowAll)) out->push_back(&n);  // (an intersection arrow walks its tupleset like any arrow)
     for (const Node &k : n.kids) collect(k, kind, out);
 }
 

@@ -29,6 +29,8 @@ enum : uint32_t {
     OP_LEAFBIT = 32u,    // with OP_ENUM: bit 31 of every edge says "this child has nothing to enumerate"
     OP_NOMARK = 128u,    // reverse seed ops (RevOp): the children of this op are the ONLY states of their slot the walk can ever produce, each once
                          // (no other op targets the slot; ids of a reverse row are distinct): no visited bit is needed to tell a first visit
+    OP_ALL = 256u,       // with OP_ENUM, inside the leaf of an intersection arrow `a.all(b)`: every child answers a result cell of its OWN, folded
+                         // into the leaf's cell by a member node (kernels.hip kAllBit; BX_LEAF_ALL)
     OP_WILD = 64u        // with OP_PROBE_HASH: the row probed is the one of the class's wildcard subject `T:*` (its id in FwdOp::K), whoever the
                          // request's subject is; reverse ops (RevOp): the row read is the wildcard subject's (roff_base points at it), whatever the seed's id
 };
@@ -78,6 +80,9 @@ constexpr uint32_t BX_LEAF = 1u << 24;  // | leaf number (1-based): push the lea
 constexpr uint32_t BX_OR = 2u << 24;    // | n: HAS > ERR > NO over the n topmost values
 constexpr uint32_t BX_AND = 3u << 24;   // | n: NO > ERR > HAS
 constexpr uint32_t BX_EXCL = 4u << 24;  // base, subtracted: base unless HAS; then subtracted ERR -> ERR, HAS -> NO, NO -> HAS
+constexpr uint32_t BX_LEAF_ALL = 5u << 24;  // | leaf number: the cell of an intersection arrow `a.all(b)` -- has = some child said HAS, err bit 7 = some child
+                                            // said NO, err low bits = some child erred: NO if bit 7 or no child, else ERR, else HAS (kAllNoBit)
+constexpr uint8_t kAllNoBit = 0x80u;
 constexpr uint32_t kMaxLeaves = 30;     // per state (the resolve keeps its value stack in one 64-bit register, two bits per value)
 struct CombineNode {  // 16 B: one visited state with a combine program (written by the walk, read by the resolve)
     uint32_t out;     // result cell the state's value is OR-ed into

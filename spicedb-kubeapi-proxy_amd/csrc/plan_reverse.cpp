@@ -16,7 +16,8 @@ namespace {
 // when X occurs anywhere but under the subtracted operand of an exclusion (every true value of `a - b`, `a & b` has a true positive operand);
 // the engine then runs the forward Check over the candidates (engine.cpp lookup_batch, Snapshot::slot_nonmono).
 void collect(const Node &n, Node::Kind kind, std::vector<const Node *> *out) {
-    if (n.kind == kind) out->push_back(&n);
+    // (a.all(b) true needs a true b on EVERY a: any true b makes the parent a candidate, as for a->b)
+    if (n.kind == kind || (kind == Node::kArrow && n.kind == Node::kArrowAll)) out->push_back(&n);
     if (n.kind == Node::kExclude) {
         collect(n.kids[0], kind, out);
         return;

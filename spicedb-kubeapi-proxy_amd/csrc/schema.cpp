@@ -105,11 +105,11 @@ Node parse_operand(Lexer &lx) {
     if (lx.is_punct('.')) {  // a.any(b) is a->b; a.all(b) is an intersection arrow
         lx.take();
         std::string fn = lx.expect_ident("`any` or `all`");
-        if (fn != "any") lx.fail("unsupported: `." + fn + "()` arrows");
+        if (fn != "any" && fn != "all") lx.fail("unsupported: `." + fn + "()` arrows");
         lx.expect_punct('(');
-        n.kind = Node::kArrow;
+        n.kind = fn == "all" ? Node::kArrowAll : Node::kArrow;
         n.a = first;
-        n.b = lx.expect_ident("a name inside `.any()`");
+        n.b = lx.expect_ident("a name inside `.any()` / `.all()`");
         lx.expect_punct(')');
         return n;
     }
@@ -159,7 +159,8 @@ void check_refs(const Schema &s, const Definition &d, const Member &m, const Nod
         case Node::kRef:
             if (d.find(n.a) < 0) throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` references unknown `" + n.a + "`");
             break;
-        case Node::kArrow: {
+        case Node::kArrow:
+        case Node::kArrowAll: {
             int ts = d.find(n.a);
             if (ts < 0 || d.members[ts].is_permission)
                 throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` has an arrow over `" + n.a + "`, which is not a relation");

@@ -30,12 +30,12 @@ struct SubjectClass {  // one allowed subject form of a relation: `stype` or `st
 };
 
 struct Node {  // permission expression tree
-    enum Kind { kUnion, kRef, kArrow, kNil, kIntersect, kExclude } kind = kNil;
+    enum Kind { kUnion, kRef, kArrow, kNil, kIntersect, kExclude, kArrowAll } kind = kNil;
     std::vector<Node> kids;   // kUnion, kIntersect: operands; kExclude: {base, subtracted}
-    std::string a, b;         // kRef: a ; kArrow: a -> b
-    // no `&` / `-` anywhere below: "any HAS wins" (the walk's fast path)
+    std::string a, b;         // kRef: a ; kArrow: a -> b (a.any(b)) ; kArrowAll: a.all(b), the intersection arrow
+    // no `&` / `-` / `.all()` anywhere below: "any HAS wins" (the walk's fast path)
     bool monotone() const {
-        if (kind == kIntersect || kind == kExclude) return false;
+        if (kind == kIntersect || kind == kExclude || kind == kArrowAll) return false;
         for (const Node &k : kids)
             if (!k.monotone()) return false;
         return true;

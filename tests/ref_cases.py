@@ -102,7 +102,7 @@ def _bootstrap_case():
 
 
 def _combine_case():
-    """Round 4: intersection, exclusion, wildcards -- operator precedence, wildcards in positive and subtracted operands, arrows into
+    """Round 4: intersection, exclusion, wildcards, intersection arrows -- operator precedence, wildcards in positive and subtracted operands, arrows into
     permissions that are themselves non-monotone, depth errors under `&` / `-` (a 60-long nesting chain).  Names are >= 3 characters:
     the real schema compiler refuses shorter ones."""
     from tests.test_oracle_cross import SCHEMA_NM
@@ -118,6 +118,9 @@ def _combine_case():
         ("doc", "plan", "folder", "folder", "root", ""), ("doc", "plan", "viewer", "group", "eng", "active"), ("doc", "plan", "editor", "user", "alice", ""),
         ("doc", "plan", "viewer", "user", "alice", ""), ("doc", "memo", "folder", "folder", "shut", ""), ("doc", "memo", "editor", "user", "erin", ""),
         ("doc", "memo", "banned", "group", "ops", "member"), ("doc", "free", "folder", "folder", "open", ""),
+        # intersection arrows (`.all()`): docs in several folders, a folder with two parents
+        ("doc", "spec", "folder", "folder", "root", ""), ("doc", "free", "folder", "folder", "sub", ""), ("folder", "sub", "parent", "folder", "open", ""),
+        ("folder", "leafy", "parent", "folder", "sub", ""), ("doc", "nest", "folder", "folder", "leafy", ""), ("doc", "nest", "folder", "folder", "sub", ""),
     ]
     n = 60
     rels += [("group", f"chain{i}", "member", "group", f"chain{i + 1}", "member") for i in range(n)] + [("group", f"chain{n}", "member", "user", "deep", "")]
@@ -127,11 +130,11 @@ def _combine_case():
     users = ["alice", "bob", "carol", "dave", "erin", "frank", "deep", "nobody"]
     checks = []
     for u in users:
-        for d in ("spec", "plan", "memo", "free", "deep1", "deep2", "deep3", "missing"):
-            for p in ("view", "edit", "strict", "odd", "nothing", "viewer"):
+        for d in ("spec", "plan", "memo", "free", "nest", "deep1", "deep2", "deep3", "missing"):
+            for p in ("view", "edit", "strict", "odd", "nothing", "viewer", "everywhere", "vetted", "deep_all"):
                 checks.append(("doc", d, p, "user", u, ""))
-        for f in ("root", "sub", "open", "shut"):
-            for p in ("view", "audit"):
+        for f in ("root", "sub", "open", "shut", "leafy"):
+            for p in ("view", "audit", "sealed"):
                 checks.append(("folder", f, p, "user", u, ""))
         for g in ("eng", "all", "ops", "chain0", "chain30"):
             for p in ("member", "active"):
@@ -140,7 +143,7 @@ def _combine_case():
         for d in ("spec", "plan", "free"):
             checks.append(("doc", d, "view") + s_)
         checks.append(("folder", "root", "view") + s_)
-    lookups = [("doc", p, "user", u, "") for u in ("alice", "bob", "frank", "nobody") for p in ("view", "edit", "strict", "odd")]
+    lookups = [("doc", p, "user", u, "") for u in ("alice", "bob", "frank", "nobody") for p in ("view", "edit", "strict", "odd", "everywhere", "vetted")]
     lookups += [("folder", "view", "user", "carol", ""), ("folder", "audit", "user", "alice", ""), ("group", "active", "user", "bob", ""), ("group", "active", "user", "zed", ""),
                 ("doc", "view", "group", "eng", "member")]
     return {"name": "combine", "schema": SCHEMA_NM, "relationships": rels, "checks": checks, "lookups": lookups}

@@ -20,7 +20,8 @@ def aclgpu(aclgpu_lib):
 
 def test_combine_hypothesis(aclgpu):
     """Random small graphs (cyclic group nesting, wildcards in positive and subtracted operands, arrows into permissions that are themselves
-    non-monotone, depth errors on both sides of `&` / `-`): every answer equals the C oracle's AND the Python oracle's."""
+    non-monotone, intersection arrows `.all()` over docs with several folders and folders with several parents -- also nested and under `-` / `&`
+    -- depth errors on both sides of `&` / `-`): every answer equals the C oracle's AND the Python oracle's."""
     from hypothesis import given, settings
 
     eng = aclgpu.Engine(SCHEMA_NM)
@@ -42,7 +43,8 @@ def test_combine_hypothesis(aclgpu):
         assert list(zip(perms, errs)) == want
         assert want == [PY2C[po.check(*q)] for q in NM_QUERIES]
         for s in subjects:
-            for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("doc", "edit"), ("folder", "audit"), ("folder", "view"), ("group", "active"), ("doc", "nothing")]:
+            for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("doc", "edit"), ("folder", "audit"), ("folder", "view"), ("group", "active"), ("doc", "nothing"),
+                          ("doc", "everywhere"), ("doc", "vetted"), ("doc", "deep_all"), ("folder", "sealed")]:
                 assert eng.lookup(rt, p, *s) == co.lookup(rt, p, *s), (rt, p, s)
 
     run()
@@ -248,3 +250,65 @@ definition team {
         with pytest.raises(aclgpu.AclError) as ei:
             e.check("team", "b0", "active", "user", "nobody")
         assert ei.value.code == aclgpu.ERR_RESOURCE_EXHAUSTED
+
+
+@pytest.mark.parametrize("mode", ["walk", "level-loop"])
+def test_intersection_arrows(mode, aclgpu, monkeypatch):
+    """`a.all(b)` (row a12's last construct but caveats; EXTERNAL, unverified semantics restated in oracle/acl_oracle.c EX_ARROW_ALL): every
+    subject of the tupleset is dispatched into a result cell of its own, member nodes fold the verdicts into the arrow's cell -- no subject: NO,
+    one NO decides, else an error beats HAS.  Known outcomes (a doc in two folders, one of them banning the user; no folder at all; under `&`,
+    `+` and `-`), a tupleset of 3 000 folders (cells and member nodes reserved window by window; one dissenting folder among them), a depth
+    error on one member, LookupResources -- on the single-launch walk and on the level loop, against the C oracle."""
+    schema = """
+definition user {}
+definition group { relation member: user | group#member }
+definition folder {
+  relation viewer: user | group#member
+  relation banned: user
+  permission view = viewer - banned
+}
+definition doc {
+  relation parent: folder
+  relation owner: user
+  permission view_all = parent.all(view)
+  permission view_any = parent.any(view)
+  permission strict = owner & parent.all(view)
+  permission lax = owner + parent.all(view)
+  permission outside = owner - parent.all(view)
+}
+"""
+    rels = [("folder", "f1", "viewer", "user", "a", ""), ("folder", "f2", "viewer", "user", "a", ""), ("folder", "f2", "viewer", "user", "b", ""), ("folder", "f2", "banned", "user", "b", ""),
+            ("doc", "d1", "parent", "folder", "f1", ""), ("doc", "d1", "parent", "folder", "f2", ""), ("doc", "d2", "parent", "folder", "f2", ""),
+            ("doc", "d1", "owner", "user", "a", ""), ("doc", "d3", "owner", "user", "b", ""), ("doc", "d2", "owner", "user", "b", "")]
+    # a doc in 3 000 folders that all let `a` and `c` in -- but one of them bans `c`
+    rels += [("folder", f"w{i}", "viewer", "user", u, "") for i in range(3000) for u in ("a", "c")] + [("doc", "wide", "parent", "folder", f"w{i}", "") for i in range(3000)]
+    rels += [("folder", "w1717", "banned", "user", "c", "")]
+    # a folder whose viewers sit at the end of a 60-long group chain: `deep` is beyond the depth limit there, `a` is a direct viewer elsewhere
+    rels += [("group", "g0", "member", "user", "deep", "")] + [("group", f"g{i + 1}", "member", "group", f"g{i}", "member") for i in range(60)]
+    rels += [("folder", "far", "viewer", "group", "g59", "member"), ("folder", "near", "viewer", "user", "deep", ""), ("doc", "e1", "parent", "folder", "far", ""),
+             ("doc", "e1", "parent", "folder", "near", ""), ("doc", "e2", "parent", "folder", "far", ""), ("doc", "e2", "parent", "folder", "f1", "")]
+    co = orc.Oracle(schema)
+    for i in range(0, len(rels), 900):
+        co.write([(orc.OP_TOUCH, r) for r in rels[i:i + 900]])
+    if mode == "level-loop":
+        monkeypatch.setenv("ACL_LOCAL_MAX", "0")
+    docs = ["d1", "d2", "d3", "wide", "e1", "e2", "ghost"]
+    qs = [("doc", d, p, "user", u, "") for d in docs for p in ("view_all", "view_any", "strict", "lax", "outside") for u in ("a", "b", "c", "deep", "nobody")]
+    with aclgpu.Engine(schema) as e:
+        for i in range(0, len(rels), 900):
+            e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 900]])
+        perms, errs = e.check_bulk(qs * 3)
+        assert list(zip(perms, errs)) == [co.check(*q) for q in qs] * 3
+        assert e.check("doc", "d1", "view_all", "user", "a") == (2, 0) and e.check("doc", "d1", "view_all", "user", "b") == (1, 0)  # f2 bans b
+        assert e.check("doc", "d3", "view_all", "user", "b") == (1, 0) and e.check("doc", "d3", "lax", "user", "b") == (2, 0)      # no folder: NO; the owner still gets `lax`
+        assert e.check("doc", "wide", "view_all", "user", "a") == (2, 0) and e.check("doc", "wide", "view_all", "user", "c") == (1, 0)  # one dissenting folder of 3 000
+        assert e.check("doc", "e1", "view_all", "user", "deep") == (0, aclgpu.ERR_DEPTH)  # near: HAS, far: beyond the depth limit -> the error wins over HAS
+        assert e.check("doc", "e2", "view_all", "user", "deep") == (1, 0)                  # f1 says NO: decides whatever `far` would have said
+        for p in ("view_all", "strict", "lax", "outside"):
+            for u in ("a", "b", "c"):
+                assert e.lookup("doc", p, "user", u) == co.lookup("doc", p, "user", u), (p, u)
+        st = e.stats()
+        if mode == "walk":
+            assert st["local_passes"] >= 1
+        else:
+            assert st["local_passes"] == 0 and st["expand_launches"] > 0

@@ -124,6 +124,7 @@ definition folder {
   relation auditor: user | group#member
   permission view = (viewer - banned) + parent->view
   permission audit = auditor & view
+  permission sealed = parent.all(view) - banned
 }
 definition doc {
   relation folder: folder
@@ -135,6 +136,9 @@ definition doc {
   permission strict = viewer & editor & folder->audit
   permission odd = (viewer - (editor & folder->view)) + (edit & folder->view)
   permission nothing = nil & viewer
+  permission everywhere = folder.all(view)
+  permission vetted = viewer + folder.all(audit) & folder.any(view)
+  permission deep_all = folder.all(sealed)
 }
 """
 FOLDERS = [f"f{i}" for i in range(3)]
@@ -174,10 +178,10 @@ def nm_queries():
     subjects = [("user", u, "") for u in USERS] + [("group", GROUPS[0], "member"), ("group", GROUPS[1], "active")]
     for s in subjects:
         for d in DOCS:
-            for p in ("view", "edit", "strict", "odd", "nothing", "viewer"):
+            for p in ("view", "edit", "strict", "odd", "nothing", "viewer", "everywhere", "vetted", "deep_all"):
                 qs.append(("doc", d, p) + s)
         for f in FOLDERS:
-            for p in ("view", "audit"):
+            for p in ("view", "audit", "sealed"):
                 qs.append(("folder", f, p) + s)
         for g in GROUPS:
             for p in ("member", "active"):
@@ -200,7 +204,8 @@ def test_c_oracle_matches_python_oracle_nonmonotone(tuples):
     for q in NM_QUERIES:
         assert co.check(*q) == PY2C[po.check(*q)], q
     for s in [("user", USERS[0], ""), ("group", GROUPS[0], "member")]:
-        for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("folder", "audit"), ("group", "active")]:
+        for rt, p in [("doc", "view"), ("doc", "odd"), ("doc", "strict"), ("folder", "audit"), ("group", "active"), ("doc", "everywhere"), ("doc", "vetted"),
+                      ("folder", "sealed")]:
             assert co.lookup(rt, p, *s) == po.lookup_resources(rt, p, *s), (rt, p, s)
 
 

@@ -74,6 +74,7 @@ def test_store_kat(kat, aclgpu_lib):
     "definition u {}\ndefinition a { relation r: u\n permission p = r & r }",
     "definition u {}\ndefinition a { relation r: u\n permission p = r - r }",
     "definition u {}\ndefinition a { relation r: u | u:*\n relation q: a\n permission p = (r - q->p) & r + nil }",
+    "definition u {}\ndefinition a { relation r: a\n relation v: u\n permission p = v + r.all(p) - r.any(p) }",  # the intersection arrow
 ])
 def test_engine_accepts_round4_schema_features(good, aclgpu_lib):
     """intersection, exclusion, wildcard subjects: the reference boots any schema (pkg/spicedb/spicedb.go:19-24)"""
@@ -104,7 +105,7 @@ def test_wildcard_relationships_in_the_store(aclgpu_lib):
     "definition u {}\ndefinition a { relation r: u\n permission p = r & }",
     "caveat c(x int) { x > 1 }\ndefinition u {}",
     "definition u {}\ndefinition a { relation r: u with c }",
-    "definition u {}\ndefinition a { relation r: a\n permission p = r.all(p) }",
+    "definition u {}\ndefinition a { relation r: a\n permission p = r.some(p) }",  # (only .any() and .all() are arrow functions)
     "definition a { relation r: nosuch }",
     "definition u {}\ndefinition a { relation r: u\n permission p = nosuch }",
     "definition u {}\ndefinition u {}",

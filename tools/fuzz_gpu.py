@@ -20,7 +20,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "spicedb-kubeapi-proxy_amd")]
 # The C4 schema with every non-monotone construct the engine compiles into combine programs (plan.hpp BX_*): exclusion at the top of a permission
 # that arrows reach, intersection over an arrow, a userset subject that is itself a non-monotone permission (group#active), wildcards on both
 # sides of a `-`, and a permission that subtracts an intersection.  Cycles through group#member (and through group#active, via pod viewers) stay
-# legal: a non-monotone cycle ends at the depth limit on both sides.
+# legal: a non-monotone cycle ends at the depth limit on both sides.  `everywhere` / `vetted`: intersection arrows over a pod's namespaces (a
+# fifth of the pod#namespace relationships name a second namespace).
 SCHEMA_COMBINE = """
 definition user {}
 definition group {
@@ -44,6 +45,8 @@ definition pod {
   permission audit = auditor & namespace->view
   permission edit = creator + (viewer & auditor) - banned
   permission hidden = view - (auditor & creator)
+  permission everywhere = namespace.all(view)
+  permission vetted = creator + namespace.all(view) & viewer
 }
 """
 
@@ -89,7 +92,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
         u = rng.choice(users) if rng.random() < 0.97 else "stranger"
         if combine and rng.random() < 0.45:
             kk = rng.randrange(6)
-            if kk < 3: return ("pod", rng.choice(pods), ("audit", "edit", "hidden")[kk], "user", u, "")
+            if kk < 3: return ("pod", rng.choice(pods), rng.choice(("audit", "edit", "hidden", "everywhere", "vetted")), "user", u, "")
             if kk == 3: return ("group", rng.choice(groups), "active", "user", u, "")
             if kk == 4: return ("pod", rng.choice(pods), "view", "group", rng.choice(groups), "active")  # a non-monotone userset as the subject
             return ("namespace", rng.choice(nss), "view", "group", rng.choice(groups), "member")
@@ -165,7 +168,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
             stats["checks"] += n
         else:  # ---- LookupResources: one subject, or a batch of subjects in one walk
             rt, perm = rng.choice([("pod", "view"), ("namespace", "view"), ("group", "member")] +
-                                  ([("pod", "audit"), ("pod", "edit"), ("pod", "hidden"), ("group", "active")] if combine else []))
+                                  ([("pod", "audit"), ("pod", "edit"), ("pod", "hidden"), ("group", "active"), ("pod", "everywhere"), ("pod", "vetted")] if combine else []))
             subs = rng.sample(users, rng.choice([1, 1, 3, 20]))
             for u in subs[:3]:
                 a, b = e.lookup(rt, perm, "user", u), o.lookup(rt, perm, "user", u)
