@@ -20,8 +20,10 @@
  * limit 50 (pkg/spicedb/spicedb.go:34), relationship expiration
  * (pkg/spicedb/spicedb.go:60), and -- round 4, because the reference boots ARBITRARY
  * schemas (pkg/spicedb/spicedb.go:19-24, pkg/proxy/options.go:313-316,
- * e2e/embedded_integration_test.go:34-250) -- intersection `&`, exclusion `-` and
- * wildcard subjects `type:*`.  Caveats and `.all()` are REJECTED at schema load.
+ * e2e/embedded_integration_test.go:34-250) -- intersection `&`, exclusion `-`,
+ * wildcard subjects `type:*` and intersection arrows `a.all(b)` (every subject of `a`
+ * must hold `b`, and there must be one; eval_expr EX_ARROW_ALL).  Caveats are REJECTED
+ * at schema load.
  *
  * Intersection / exclusion (EXTERNAL: SpiceDB internal/graph/check.go `all` /
  * `difference`, restated from memory, unverified):
