@@ -14,14 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(burst=300, universe=3)), (13, dict(compact_early=True)), (21, dict(schema="combine")),
-                                     (22, dict(schema="combine", compact_early=True))],
-                         ids=["small-universe", "write-bursts", "compactions", "combine-schema", "combine-schema-compactions"])
+                                     (22, dict(schema="combine", compact_early=True)), (23, dict(recycle=True)), (24, dict(recycle=True, schema="combine", compact_early=True))],
+                         ids=["small-universe", "write-bursts", "compactions", "combine-schema", "combine-schema-compactions", "recycled-ids", "recycled-ids-combine-compactions"])
 def test_differential_fuzz(seed, kw, aclgpu_lib):
     spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     st = fz.run(seed, 60 if "burst" in kw else (250 if kw else 120), verbose=False, **kw)  # (the oracle's brute-force lookups are what takes the time: ~10 s and ~20 s)
     assert st["writes"] > 5 and st["checks"] > 100 and st["lookups"] >= 1 and st["snapshot_patches"] >= 1  # (the run itself asserts every answer)
+    if kw.get("recycle"):
+        assert st["ids_recycled"] >= 5  # never-seen names took over the ids of objects that had lost their last relationship, under the reads
     if kw.get("compact_early"):
         assert st["snapshot_compactions"] >= 1  # background builds were adopted in mid-stream, the writes since their start replayed onto them
 

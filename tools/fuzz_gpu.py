@@ -51,7 +51,8 @@ definition pod {
 """
 
 
-def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False, schema: str = "c4") -> dict:
+def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False, schema: str = "c4",
+        recycle: bool = False) -> dict:
     import aclgpu
     from aclgpu import workloads
     from oracle import orc
@@ -64,7 +65,13 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
     nss = [f"n{i}" for i in range(8 * universe)]
     pods = [f"{rng.choice(nss)}/p{i}" for i in range(240 * universe)]
 
+    fresh = [0]
+
     def rand_tuple():
+        if recycle and rng.random() < 0.15:  # objects nobody has named before: they take over the ids of objects that lost their last relationship
+            fresh[0] += 1
+            return rng.choice([f"pod:{rng.choice(nss)}/fresh{fresh[0]}#viewer@user:{rng.choice(users)}", f"pod:{rng.choice(pods)}#viewer@user:newcomer{fresh[0]}",
+                               f"group:team{fresh[0]}#member@user:{rng.choice(users)}", f"pod:{rng.choice(pods)}#viewer@group:team{fresh[0] - rng.randrange(3)}#member"])
         if combine and rng.random() < 0.3:  # the relations only the combine schema has
             k = rng.randrange(9)
             if k == 0: return f"group:{rng.choice(groups)}#banned@user:{rng.choice(users)}"
@@ -101,12 +108,15 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
         if k < 9: return ("group", rng.choice(groups), "member", "user", u, "")
         return ("pod", rng.choice(pods), "view", "group", rng.choice(groups), "member")  # a userset as the subject
 
+    if recycle:
+        os.environ["ACL_ID_QUARANTINE_MS"] = "0"  # (read when the schema is loaded) freed ids are reused by the next new name at once
     if compact_early:
         os.environ["ACL_COMPACTION_SLACK"] = "0"  # (read at acl_open) background compactions, adopted with the writes since replayed, on this small graph too
     try:
         e = aclgpu.Engine(schema_text)
     finally:
         os.environ.pop("ACL_COMPACTION_SLACK", None)
+        os.environ.pop("ACL_ID_QUARANTINE_MS", None)
     o = orc.Oracle(schema_text)
     live = set()
     init = list(dict.fromkeys(rand_tuple() for _ in range(2500 * universe)))
@@ -184,7 +194,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
         if verbose and step % 50 == 49:
             print(f"step {step + 1}/{steps}: {stats}, {len(live)} relationships, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     st = e.stats()
-    stats.update({k: int(st[k]) for k in ("snapshot_builds", "snapshot_patches", "snapshot_compactions", "local_passes", "rev_local_passes") if k in st})
+    stats.update({k: int(st[k]) for k in ("snapshot_builds", "snapshot_patches", "snapshot_compactions", "local_passes", "rev_local_passes", "ids_recycled") if k in st})
     e.close()
     return stats
 
@@ -337,11 +347,12 @@ if __name__ == "__main__":
     ap.add_argument("--patcher", action="store_true", help="no GPU: a store-only engine whose host snapshot is verified against the store after every write")
     ap.add_argument("--expiry", action="store_true", help="the other campaign: the reference's bootstrap schema, dual-write shapes, expiring idempotency keys, a moving clock")
     ap.add_argument("--schema", choices=["c4", "combine"], default="c4", help="combine: the C4 schema with exclusions, intersections, wildcards and a non-monotone userset subject")
+    ap.add_argument("--recycle", action="store_true", help="ACL_ID_QUARANTINE_MS=0 and a stream of never-seen object names in the writes: ids of objects that lost their last relationship are taken over under the reads")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
         print(run_patcher(a.seed, a.steps, a.universe, a.burst, schema=a.schema) if a.patcher else run_expiry(a.seed, a.steps) if a.expiry
-              else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early, schema=a.schema))
+              else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early, schema=a.schema, recycle=a.recycle))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)
