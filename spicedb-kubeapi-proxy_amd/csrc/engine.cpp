@@ -1260,7 +1260,16 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             std::string_view rid, sid;
             int rt, st, pm, sr;
             bool ok;
+            bool same_res, same_sub;  // the same object as the item before it: its id is taken over, not looked up again
+            bool kr, ks;              // (third stage) the table knows the name
+            uint32_t res, sub;
         } pend[kGroup];
+        // The proxy's batches repeat themselves: every pair of a PostFilter call names the requesting user (postfilter.go:88-119), the F templates
+        // of a list item name the same object one after the other, check.go:17-72 builds all of a request's pairs for one user.  A name equal
+        // to the previous item's (same type; pointer + length, or content) costs no hash, no prefetch and no probe.
+        Pending last{};  // the last item of the previous group that resolved
+        bool have_last = false;
+        auto same_name = [](std::string_view x, std::string_view y) { return x.size() == y.size() && (x.data() == y.data() || std::memcmp(x.data(), y.data(), x.size()) == 0); };
         for (size_t g0 = a; g0 < b; g0 += kGroup) {
             const size_t g1 = std::min(b, g0 + kGroup);
             for (size_t i = g0; i < g1; i++) {
@@ -1282,24 +1291,36 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                     continue;
                 }
                 p.rt = m.rti; p.st = m.sti; p.pm = m.pmi; p.sr = m.sri;
-                p.hr = ObjectTable::hash_of(p.rid);
-                p.hs = ObjectTable::hash_of(p.sid);
-                h->store.objects(p.rt).prefetch(p.hr);
-                h->store.objects(p.st).prefetch(p.hs);
+                const Pending *prev = i > g0 && pend[i - g0 - 1].ok ? &pend[i - g0 - 1] : (i == g0 && have_last ? &last : nullptr);
+                p.same_res = prev && prev->rt == p.rt && same_name(prev->rid, p.rid);
+                p.same_sub = prev && prev->st == p.st && same_name(prev->sid, p.sid);
+                if (!p.same_res) {
+                    p.hr = ObjectTable::hash_of(p.rid);
+                    h->store.objects(p.rt).prefetch(p.hr);
+                }
+                if (!p.same_sub) {
+                    p.hs = ObjectTable::hash_of(p.sid);
+                    h->store.objects(p.st).prefetch(p.hs);
+                }
             }
             for (size_t i = g0; i < g1; i++) {
                 const Pending &p = pend[i - g0];
                 if (!p.ok) continue;
-                h->store.objects(p.rt).prefetch_name(p.hr);
-                h->store.objects(p.st).prefetch_name(p.hs);
+                if (!p.same_res) h->store.objects(p.rt).prefetch_name(p.hr);
+                if (!p.same_sub) h->store.objects(p.st).prefetch_name(p.hs);
             }
             for (size_t i = g0; i < g1; i++) {
-                const Pending &p = pend[i - g0];
+                Pending &p = pend[i - g0];
                 if (!p.ok) continue;
                 // unknown object ids have no relationships: sentinels above every dense id, equal only when
                 // resource and subject are the same (unknown) object
-                uint32_t res, sub;
-                const bool kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &res), ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &sub);
+                const Pending *prev = i > g0 ? &pend[i - g0 - 1] : &last;  // (same_res / same_sub were only set against an item that resolved)
+                if (p.same_res) p.kr = prev->kr, p.res = prev->res;
+                else p.kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &p.res);
+                if (p.same_sub) p.ks = prev->ks, p.sub = prev->sub;
+                else p.ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &p.sub);
+                const bool kr = p.kr, ks = p.ks;
+                uint32_t res = p.res, sub = p.sub;
                 if ((!kr && !valid_object_id(p.rid)) || (!ks && !valid_object_id(p.sid)) || p.rid == "*" || p.sid == "*") {  // (`*` never in a Check)
                     out[i] = acl_item_t{kDeadType, 0, 0, kDeadType, 0, 0};
                     mybad.emplace_back((uint32_t)i, (int32_t)ACL_ERR_INVALID_ARGUMENT);
@@ -1312,6 +1333,8 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 }
                 out[i] = acl_item_t{(uint16_t)p.rt, (uint16_t)p.pm, res, (uint16_t)p.st, (uint16_t)(p.sr == kNoRelation ? ACL_NO_RELATION : p.sr), sub};
             }
+            have_last = pend[g1 - g0 - 1].ok;  // (the next group's first item is compared with this group's last one)
+            if (have_last) last = pend[g1 - g0 - 1];
         }
         if (!mybad.empty()) {
             std::lock_guard<std::mutex> lk(bad_mu);
