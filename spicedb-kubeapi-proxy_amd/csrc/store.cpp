@@ -247,7 +247,18 @@ void Store::note_free(int type, uint32_t id) {
     if (fa.size() <= id) fa.resize((size_t)id + 1 + fa.size() / 2, 0);
     const int64_t t = steady_ms();
     fa[id] = t;
-    freed_[type].push_back(Freed{id, t});
+    auto &fq = freed_[type];
+    fq.push_back(Freed{id, t});
+    // Entries go void when their object is referenced again (or freed again: the younger entry counts) and are only dropped when a NEW name
+    // looks for an id -- a fixed set of objects whose relationships come and go for ever would grow the list by an entry per round.  Past
+    // twice the type's id space the void ones are swept out.
+    if (fq.size() > 2 * (size_t)objects_[type].count() + 4096) {
+        std::deque<Freed> keep;
+        const auto &rc = refcnt_[type];
+        for (const Freed &f : fq)
+            if (f.id < rc.size() && rc[f.id] == 0 && f.id < fa.size() && fa[f.id] == f.at_ms && (keep.empty() || keep.back().id != f.id || keep.back().at_ms != f.at_ms)) keep.push_back(f);
+        fq.swap(keep);
+    }
 }
 void Store::ref_key(int slot, int cls, uint64_t key, int delta) {
     auto [t, m] = schema_.slot_owner[slot];
