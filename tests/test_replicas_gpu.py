@@ -88,9 +88,13 @@ def test_concurrent_callers_and_a_writer_on_replicas(aclgpu):
         stop = threading.Event()
         bad = []
 
+        writes = [0]
+
         def caller(k):
             rot = np.roll(items, k * 997)
-            for _ in range(25):
+            for it in range(400):  # at least 25 batches each, and on until the writer has got 30 writes in under them (how many it gets per batch is the box's business)
+                if it >= 25 and writes[0] >= 30:
+                    break
                 p, er = e.check_bulk_ids(rot)
                 if not (np.array_equal(np.roll(p, -k * 997), want) and np.array_equal(np.roll(er, -k * 997), want_err)):
                     bad.append(k)
@@ -103,7 +107,8 @@ def test_concurrent_callers_and_a_writer_on_replicas(aclgpu):
                 if e.check("pod", f"new-{i}", "view", "user", f"new-user-{i}") != (2, 0) or e.check("pod", f"new-{i}", "view", "user", "somebody-else") != (1, 0):
                     bad.append(("writer", i))
                 i += 1
-            bad.append(("writes", i)) if i < 20 else None
+                writes[0] = i
+            bad.append(("writes", i)) if i < 30 else None
 
         ts = [threading.Thread(target=caller, args=(k,)) for k in range(6)]
         wt = threading.Thread(target=writer)
