@@ -1292,8 +1292,9 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 }
                 p.rt = m.rti; p.st = m.sti; p.pm = m.pmi; p.sr = m.sri;
                 const Pending *prev = i > g0 && pend[i - g0 - 1].ok ? &pend[i - g0 - 1] : (i == g0 && have_last ? &last : nullptr);
-                p.same_res = prev && prev->rt == p.rt && same_name(prev->rid, p.rid);
-                p.same_sub = prev && prev->st == p.st && same_name(prev->sid, p.sid);
+                static const bool kRepeat = !getenv("ACL_INTERN_REPEAT") || atoi(getenv("ACL_INTERN_REPEAT")) != 0;  // (A/B knob)
+                p.same_res = kRepeat && prev && prev->rt == p.rt && same_name(prev->rid, p.rid);
+                p.same_sub = kRepeat && prev && prev->st == p.st && same_name(prev->sid, p.sid);
                 if (!p.same_res) {
                     p.hr = ObjectTable::hash_of(p.rid);
                     h->store.objects(p.rt).prefetch(p.hr);
