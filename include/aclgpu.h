@@ -188,20 +188,14 @@ typedef struct {
 } acl_call_opts_t;
 int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
 
-/* Pipelined form of acl_check_bulk_ids: submit returns at once, the batch is answered by one of the engine's evaluation
- * contexts (own HIP stream: the H2D copy of batch N+1 and the D2H copy of batch N-1 overlap the kernels of batch N);
- * acl_ticket_wait blocks until perm_out / err_out are filled, returns the call's status and frees the ticket.
- * Buffers must stay valid until the wait returns.  Tickets complete by themselves, in submission order: a completer thread inside the
- * engine waits for each batch's device work, copies the answers out and gives the batch's evaluation context and its (shared) hold on
- * the engine's state back -- a ticket nobody has waited for yet pins nothing, so the holder of tickets may make any other call on the
- * engine (writes included) before it waits.  Batches that fill the chip (>= 32 768 items) form a pipeline run by one worker: it stages up
- * to three batches ahead (context + H2D), runs the batches' kernels strictly one after the other (from 131 072 items on they are chained
- * ON THE DEVICE -- each stream waits for the event behind the previous kernel), and each batch's D2H drains while the next one's kernel
- * runs.  Such batches -- submitted or issued by blocking callers -- only ever use three of the engine's contexts: further ones queue for a
- * lane.  That pipeline is for batches that have to be COPIED (beyond 262 144 items on an MI355X).  A batch the single-launch walk takes is
- * answered by the kernel itself across PCIe -- it reads the items from, and writes the answers to, the (pinned) host buffers: no copies, no
- * turn-taking -- whether a blocking caller brings it or a ticket (then a whole call on one of the pool's workers): 2 ... 16 callers 884-912 M
- * decisions/s on C4, one caller 692, windows of 2 ... 6 tickets 899-945 (profiles/r03_hostmapped_batches.txt). */
+/* Pipelined form of acl_check_bulk_ids for hosts that cannot park a thread per call: submit returns at once, the batch is answered as a
+ * whole blocking call on one of the engine's pool workers (one worker per evaluation context); acl_ticket_wait blocks until perm_out /
+ * err_out are filled, returns the call's status and frees the ticket.  Buffers must stay valid until the wait returns.  A ticket nobody
+ * has waited for yet pins nothing: the holder of tickets may make any other call on the engine (writes included) before it waits.
+ * Every batch -- a blocking caller's or a ticket's -- is answered by the kernel itself across PCIe: it reads the items from, and writes
+ * the answers to, the host buffers (pinned: in place; else through the context's pinned staging), in one launch, or -- beyond what one
+ * launch takes -- in sub-passes on two streams.  No copies, no turn-taking: concurrent calls overlap on the chip (three callers 1.05-1.13 G
+ * decisions/s on C4, one caller 0.8 G; profiles/r04_host_split.txt).  Go callers simply block goroutines in acl_check_bulk_ids. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);

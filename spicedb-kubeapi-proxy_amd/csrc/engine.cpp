@@ -457,20 +457,13 @@ int device_of(acl_engine *h, const void *p) {
     return a.device;
 }
 
-int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, bool try_only, int on_device) {
+int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev_key_slot, int on_device) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     int rc = check_opts(opts);
     if (rc) return rc;
     for (;;) {
-        // try_only (the submit pipeline staging a batch AHEAD of the one it is about to run): never wait for the state lock either.  The
-        // batches already staged hold it shared until they are waited for; a writer queued behind them keeps new readers out (writer
-        // preference), and the pipeline blocking here could then never run the batches whose locks the writer is waiting for.
-        if (try_only) {
-            if (!h->state_mu.try_lock_shared()) return kNoContextFree;
-        } else {
-            h->state_mu.lock_shared();
-        }
+        h->state_mu.lock_shared();
         bool ok = snapshot_current(h, need_reverse);
         // a `type#relation` lookup subject is itself a state of the walk: its id must lie inside the visited bitmap
         if (ok && need_reverse && rev_key_slot >= 0 &&
@@ -481,7 +474,6 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
             break;
         }
         h->state_mu.unlock_shared();
-        if (try_only) return kNoContextFree;  // (the snapshot needs maintenance -- exclusive work: not while batches of this pipeline hold the lock)
         std::lock_guard<RwLock> lk(h->state_mu);
         rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;
@@ -490,7 +482,7 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
     std::unique_lock<std::mutex> lk(h->pool_mu);
     for (;;) {
         // Replicas (engines opened on several devices): the least loaded one that can serve the call -- ties go round the devices, so N
-        // blocking callers end up on N devices.  Within a replica: the lane / non-lane preference described above.
+        // blocking callers end up on N devices.  Within a replica: the context released last (its buffers are the warmest).
         DevState *bd = nullptr;
         int bpick = -1;
         bool bcreate = false;
@@ -524,11 +516,6 @@ int Eval::begin(acl_engine *h_, bool need_reverse, const CallOpts &opts, int rev
             bd->in_use++;
             bd->calls++;
             break;
-        }
-        if (try_only) {
-            lk.unlock();
-            end();  // gives the shared lock back
-            return kNoContextFree;
         }
         if (on_device >= 0) {
             bool any = false;
@@ -1944,7 +1931,7 @@ int acl_sync(acl_engine_t *h) {
 int acl_check_bulk_ids_device(acl_engine_t *h, const void *d_items, size_t n, void *d_perm_out, void *d_err_out) {
     if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_ids_device: NULL buffer");
     Eval ev;
-    int rc = ev.begin(h, false, CallOpts(), -1, false, device_of(h, d_perm_out));  // (a replica on the device the caller's buffers live on)
+    int rc = ev.begin(h, false, CallOpts(), -1, device_of(h, d_perm_out));  // (a replica on the device the caller's buffers live on)
     if (rc) return rc;
     rc = check_device(h, ev.c, (const uint4 *)d_items, n, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
     if (rc) return rc;

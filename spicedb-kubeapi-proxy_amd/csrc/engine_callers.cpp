@@ -453,7 +453,7 @@ static int keep_device(acl_engine_t *h, PassCtx *c, const void *d_items, size_t 
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out) {
     if ((n && !d_items) || (k_items && (!d_item_off || !d_keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_ids_device: NULL buffer");
     Eval ev;
-    int rc = ev.begin(h, false, CallOpts(), -1, false, device_of(h, d_keep_out));  // (a replica on the device the caller's buffers live on)
+    int rc = ev.begin(h, false, CallOpts(), -1, device_of(h, d_keep_out));  // (a replica on the device the caller's buffers live on)
     if (rc) return rc;
     rc = keep_device(h, ev.c, d_items, n, d_item_off, k_items, d_keep_out);
     if (rc) return rc;

@@ -202,7 +202,6 @@ struct PinnedBuf {
     }
 };
 
-constexpr int kNoContextFree = -1001;  // internal (Eval::begin with try_only)
 constexpr size_t kComputeTokenItems = 32768;  // host-buffer batches at least this large run their kernels one batch at a time
 
 // per-call cancellation / deadline (reference: LookupResources runs on the HTTP request's ctx and is abandoned when it is
@@ -460,9 +459,8 @@ struct Eval {
     Eval &operator=(const Eval &) = delete;
     ~Eval() { end(); }
     // rev_key_slot >= 0: the lookup's subject is `type#relation` of that slot -- the reverse rows must cover its id space
-    // try_only: never wait for a context -- kNoContextFree when every one is taken
     // on_device >= 0: only a replica on that HIP device will do (calls that are handed device pointers)
-    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, bool try_only = false, int on_device = -1);
+    int begin(acl_engine *h_, bool need_reverse, const CallOpts &opts = CallOpts(), int rev_key_slot = -1, int on_device = -1);
     void end();
 };
 
