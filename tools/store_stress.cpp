@@ -24,6 +24,9 @@ static const char *kSchema =
     "definition lock {\n  relation workflow: workflow\n}\n"
     "definition workflow {}\n";
 
+// (every failed expectation says where: the harness runs many shapes at once and a count alone does not say which one)
+#define BAD() (fprintf(stderr, "expectation failed: store_stress.cpp:%d\n", __LINE__), bad.fetch_add(1))
+
 int main(int argc, char **argv) {
     const int ROUNDS = argc > 1 ? atoi(argv[1]) : 300;
     // "reload": a thread re-runs acl_load_bootstrap (same schema and relationships) under everybody else; the expectations that a reload
@@ -65,23 +68,23 @@ int main(int argc, char **argv) {
                 acl_update_t u[2] = {{(int32_t)(r % 3 == 2 ? ACL_OP_DELETE : ACL_OP_TOUCH), {"pod", rid, "viewer", "user", sid, "", 0}},
                                      {ACL_OP_TOUCH, {"pod", rid, "creator", "user", sid, "", 0}}};
                 uint64_t rev = 0;
-                if (acl_write(h, u, 2, nullptr, 0, &rev) || !rev) bad++;
+                if (acl_write(h, u, 2, nullptr, 0, &rev) || !rev) BAD();
                 {   // W1 / W2 of a kube write: a lock behind MUST_NOT_MATCH, deleted again -- its id (and the workflow's) goes round
                     char lk[48], wf[48];
                     snprintf(lk, sizeof lk, "l%d-%d", wtr, r);
                     snprintf(wf, sizeof wf, "w%d-%d", wtr, r);
                     acl_filter_t pre{ACL_PRE_MUST_NOT_MATCH, "lock", lk, "workflow", "workflow", nullptr, nullptr};
                     acl_update_t c{ACL_OP_CREATE, {"lock", lk, "workflow", "workflow", wf, "", 0}};
-                    if (acl_write(h, &c, 1, &pre, 1, &rev) && !reload) bad++;
+                    if (acl_write(h, &c, 1, &pre, 1, &rev) && !reload) BAD();
                     acl_update_t d{ACL_OP_DELETE, {"lock", lk, "workflow", "workflow", wf, "", 0}};
-                    if (acl_write(h, &d, 1, nullptr, 0, &rev) && !reload) bad++;
+                    if (acl_write(h, &d, 1, nullptr, 0, &rev) && !reload) BAD();
                 }
                 if (r % 16 == 0) {  // CREATE of something that exists must fail, atomically (activity.go:62-74)
                     acl_update_t c{ACL_OP_CREATE, {"pod", rid, "creator", "user", sid, "", 0}};
-                    if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS && !reload) bad++;
+                    if (acl_write(h, &c, 1, nullptr, 0, &rev) != ACL_ERR_ALREADY_EXISTS && !reload) BAD();
                     acl_filter_t pre{ACL_PRE_MUST_MATCH, "pod", rid, "creator", "user", sid, nullptr};
                     acl_update_t t{ACL_OP_TOUCH, {"pod", rid, "viewer", "group", "g1", "member", 0}};
-                    if (acl_write(h, &t, 1, &pre, 1, &rev) && !reload) bad++;
+                    if (acl_write(h, &t, 1, &pre, 1, &rev) && !reload) BAD();
                 }
             }
         });
@@ -99,11 +102,11 @@ int main(int argc, char **argv) {
                 snprintf(rid, sizeof rid, "ns%d/p%d", p % 50, p);
                 acl_filter_t f{0, "pod", rid, nullptr, nullptr, nullptr, nullptr};
                 long n = 0;
-                if (acl_read(h, &f, [](void *u, const acl_relationship_t *r) { if (r->resource_id) ++*(long *)u; }, &n) || n < 1) bad++;  // (its namespace row is never deleted)
+                if (acl_read(h, &f, [](void *u, const acl_relationship_t *r) { if (r->resource_id) ++*(long *)u; }, &n) || n < 1) BAD();  // (its namespace row is never deleted)
                 uint32_t id = 0;
-                if (acl_find(h, tp, rid, &id)) bad++;
+                if (acl_find(h, tp, rid, &id)) BAD();
                 else if (!reload) {  // (a reload renumbers: the id may name another object by the time the name is asked for)
-                    if (const char *nm = acl_object_name(h, tp, id)) { if (strcmp(nm, rid) != 0) bad++; }
+                    if (const char *nm = acl_object_name(h, tp, id)) { if (strcmp(nm, rid) != 0) BAD(); }
                 }
                 acl_intern(h, tu, ("fresh" + std::to_string(s % 5000)).c_str(), &id);
                 uint64_t next = 0;
@@ -111,7 +114,7 @@ int main(int argc, char **argv) {
                 const int rc = acl_watch_poll(h, cursor, &tp, 1, [](void *u, uint64_t, int32_t, const acl_relationship_t *) { ++*(long *)u; }, &seen, &next);
                 if (rc == ACL_OK) cursor = next;
                 else if (rc == ACL_ERR_OUT_OF_RANGE) acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
-                else bad++;
+                else BAD();
             }
         });
     // a Watch stream as the shim holds it: blocked in acl_watch_wait (a condition variable behind the write path), then a poll; a cursor that an
@@ -124,43 +127,43 @@ int main(int argc, char **argv) {
         while (!stop.load()) {
             acl_call_opts_t o{nullptr, 5 * 1000 * 1000};  // 5 ms
             const int wrc = acl_watch_wait(h, cursor, &tl, 1, &o, &head);
-            if (wrc && wrc != ACL_ERR_DEADLINE_EXCEEDED && wrc != ACL_ERR_OUT_OF_RANGE) bad++;
+            if (wrc && wrc != ACL_ERR_DEADLINE_EXCEEDED && wrc != ACL_ERR_OUT_OF_RANGE) BAD();
             waits++;
             uint64_t next = 0;
             const int rc = acl_watch_poll(h, cursor, &tl, 1, [](void *u, uint64_t, int32_t, const acl_relationship_t *) { ++*(long *)u; }, &seen, &next);
             if (rc == ACL_OK) cursor = next;
             else if (rc == ACL_ERR_OUT_OF_RANGE) acl_watch_poll(h, UINT64_MAX, nullptr, 0, nullptr, nullptr, &cursor);
-            else bad++;
+            else BAD();
         }
-        if (!waits) bad++;
+        if (!waits && ROUNDS >= 100) BAD();  // (a short run may be over before this thread is scheduled at all)
     });
     // snapshot maintenance: the patcher and the background compaction's two halves, verified against the store each time
     th.emplace_back([&] {
         int k = 0;
         while (!stop.load()) {
             int patched = 0, adopted = 0;
-            if (acl_selfcheck_snapshot(h, &patched)) { fprintf(stderr, "selfcheck: %s\n", acl_last_error()); bad++; }
+            if (acl_selfcheck_snapshot(h, &patched)) { fprintf(stderr, "selfcheck: %s\n", acl_last_error()); BAD(); }
             if (++k % 4 == 0) {
-                if (acl_selfcheck_compaction(h, 0, &adopted)) { fprintf(stderr, "compaction 0: %s\n", acl_last_error()); bad++; }
+                if (acl_selfcheck_compaction(h, 0, &adopted)) { fprintf(stderr, "compaction 0: %s\n", acl_last_error()); BAD(); }
                 std::this_thread::sleep_for(std::chrono::milliseconds(2));
                 const int rc1 = acl_selfcheck_compaction(h, 1, &adopted);  // (a bootstrap reload in between drops the build: "phase 1 without phase 0")
-                if (rc1 && !(reload && rc1 == ACL_ERR_FAILED_PRECONDITION)) { fprintf(stderr, "compaction 1: %s\n", acl_last_error()); bad++; }
+                if (rc1 && !(reload && rc1 == ACL_ERR_FAILED_PRECONDITION)) { fprintf(stderr, "compaction 1: %s\n", acl_last_error()); BAD(); }
             }
         }
     });
     if (reload)
         th.emplace_back([&] {
             while (!stop.load()) {
-                if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) bad++;
+                if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) BAD();
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));
             }
         });
     if (restart)
         th.emplace_back([&] {
             while (!stop.load()) {
-                if (acl_batcher_stop(h)) bad++;
+                if (acl_batcher_stop(h)) BAD();
                 std::this_thread::sleep_for(std::chrono::microseconds(200));
-                if (acl_batcher_start(h, 256, 50)) bad++;
+                if (acl_batcher_start(h, 256, 50)) BAD();
                 std::this_thread::sleep_for(std::chrono::microseconds(700));
             }
         });
@@ -179,19 +182,19 @@ int main(int argc, char **argv) {
                 uint8_t perm = 9;
                 int32_t err = 0;
                 if (c & 1) {
-                    if (acl_check_one(h, &it, &perm, &err) != ACL_ERR_UNAVAILABLE) bad++;
+                    if (acl_check_one(h, &it, &perm, &err) != ACL_ERR_UNAVAILABLE) BAD();
                 } else {
                     const int src = acl_check_one_submit(h, &it, s);
-                    if (src && !(restart && src == ACL_ERR_FAILED_PRECONDITION)) bad++;  // (no batcher at this instant: the shim falls back to a blocking call)
+                    if (src && !(restart && src == ACL_ERR_FAILED_PRECONDITION)) BAD();  // (no batcher at this instant: the shim falls back to a blocking call)
                     size_t k = 0;
-                    if (acl_check_completions(h, comp, 16, 1000000, &k)) bad++;
+                    if (acl_check_completions(h, comp, 16, 1000000, &k)) BAD();
                     for (size_t j = 0; j < k; j++)
-                        if (comp[j].rc != ACL_ERR_UNAVAILABLE || comp[j].perm != ACL_PERM_UNSPECIFIED) bad++;
+                        if (comp[j].rc != ACL_ERR_UNAVAILABLE || comp[j].perm != ACL_PERM_UNSPECIFIED) BAD();
                 }
                 uint8_t pb[4];
                 int32_t eb[4];
                 acl_check_item_t four[4] = {it, it, it, it};
-                if (acl_check_bulk(h, four, 4, pb, eb) != ACL_ERR_UNAVAILABLE) bad++;
+                if (acl_check_bulk(h, four, 4, pb, eb) != ACL_ERR_UNAVAILABLE) BAD();
             }
         });
     for (int i = 0; i < 2; i++) th[i].join();
@@ -199,7 +202,7 @@ int main(int argc, char **argv) {
     for (size_t i = 2; i < th.size(); i++) th[i].join();
     acl_batcher_stop(h);
     int patched = 0;
-    if (acl_selfcheck_snapshot(h, &patched)) bad++;
+    if (acl_selfcheck_snapshot(h, &patched)) BAD();
     acl_close(h);
     printf("store_stress%s: %d rounds per writer, %d failed expectations\n", restart ? " (batcher restarts)" : "", ROUNDS, bad.load());
     return bad.load() ? 1 : 0;
