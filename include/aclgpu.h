@@ -387,8 +387,8 @@ int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_
  * callbacks: acl_shard_rccl_* below supply RCCL (ncclAllGather / ncclAllReduce, grouped ncclSend / ncclRecv over xGMI); a host with its own
  * ncclComm_t (the cgo shim) or a test double plugs in the same way.  Callbacks enqueue on `hip_stream` and return 0 or an ACL_ERR_* code.
  * all_to_all may be NULL: Check then exchanges one block per shard through all_gather (every shard receives everything and keeps what it
- * owns) instead of one block per (shard, destination) -- `world` times the bytes.  LookupResources always all-gathers (a visited state goes
- * to every shard that holds parent rows for it). */
+ * owns) instead of one block per (shard, destination) -- `world` times the bytes.  LookupResources travels the same way: a visited state
+ * goes into the block of every shard that holds parent rows for its slot (all_to_all), or to everybody (all_gather). */
 typedef struct {
     void *user;
     int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);

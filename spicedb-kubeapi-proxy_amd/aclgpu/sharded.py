@@ -397,8 +397,8 @@ class ShardedEngine:
     def __init__(self, shard, comm, export_entries: int = 1 << 16, exchange: str = "allgather", native=None):
         """exchange: how Check frontiers cross shards -- "allgather" (the north star's form: every rank receives every export
         buffer and keeps what it owns) or "alltoall" (exports grouped by owner on the device, each rank receives only its own:
-        G times fewer bytes).  LookupResources always all-gathers (a visited state goes to every shard that
-        holds parent rows for it)."""
+        G times fewer bytes).  This host-driven protocol's LookupResources always all-gathers (a visited state goes to every
+        shard that holds parent rows for it); the native loop (lookup_ids_batch_native) sends it to exactly those shards."""
         assert shard.rank == comm.rank and shard.world == comm.world
         assert exchange in ("allgather", "alltoall")
         self.shard, self.comm, self.exchange = shard, comm, exchange
