@@ -301,3 +301,14 @@ def test_reference_citations_resolve():
             if not cands or not any(last <= nlines(r) for r in cands):
                 bad.append((rel, m.group(0)))
     assert total > 300 and not bad, bad[:10]
+
+
+def test_docs_are_hard_wrapped():
+    """DESIGN / INTEGRATION / README (and the history notes) are hard-wrapped -- no prose line beyond 120 columns (tables, code
+    blocks and headings excepted): tools/wrap_md.py --check."""
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(HERE)
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "HISTORY.md"), os.path.join("profiles", "README.md")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wrap_md.py"), os.path.join(ROOT, doc), "--check"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
