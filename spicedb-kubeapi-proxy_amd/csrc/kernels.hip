@@ -399,6 +399,11 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 // per step with branch-free loads (dummy in-range addresses for inactive lanes), so the edge, descriptor and bucket
 // gathers of 64 x kSimpleWidth children are in flight together instead of 64 at a time behind three dependent waits.
 // Bit-for-bit the same decisions, the same output entries in the same order as the generic path.
+#ifndef ACL_PUSH_RECHECK
+#define ACL_PUSH_RECHECK 1  // the expansions look at the request's answer byte (LDS) once more before they write its children: a request answered
+                            // by this step's hits -- or by another wave a moment ago -- needs none of them, and an entry not written is not read
+                            // back and frees a lane of a segment of the next level (C4 253 -> 238 us; profiles/r04_push_recheck_ab.txt); 0 = A/B builds
+#endif
 #ifndef ACL_SIMPLE_WIDTH
 #define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
 #endif
@@ -520,15 +525,27 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                     //  loads at the end of every step; depth limits were checked per task above)
                     hit[k] = valid[k0 + k] & bucket_pair_has(p[k], q[k], edge[k0 + k] & kIdMask);
                     push[k] = valid[k0 + k] & !hit[k] & ((edge[k0 + k] & kLeafBit) == 0u);
-                    pb[k] = __ballot(push[k]);
-                    pre[k] = np;
-                    np += (uint32_t)__popcll(pb[k]);
                 }
                 // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
                 // (vmcnt counts stores too, and the compiler must assume the store was not issued)
 #pragma unroll
                 for (int k = 0; k < W; k++)
                     if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], wo.first, 1);
+#if ACL_PUSH_RECHECK
+                if (E8 && ACL_ANS_LDS) {
+                    // a request answered by THIS step's hits (or by another wave a moment ago) needs none of its other children any more: looked at
+                    // once more before they are written -- an entry not written is not read back, and frees a lane of a segment of the next level
+                    wave_lds_fence();
+#pragma unroll
+                    for (int k = 0; k < W; k++) push[k] = push[k] & (ans_get<true>(has, rq[k], wo.first) == 0u);
+                }
+#endif
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    pb[k] = __ballot(push[k]);
+                    pre[k] = np;
+                    np += (uint32_t)__popcll(pb[k]);
+                }
                 if (np) {
                     const uint32_t base = reserve<LOCAL>(wo, np, lane);
                     if (base != kNoSpace) {
@@ -624,6 +641,12 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
             } else if (valid && level + cp.max_dlevel > kMaxLevels) {
                 ans_set<E8 && ACL_ANS_LDS>(err, req, wo.first, ITEM_ERR_DEPTH);
             }
+#if ACL_PUSH_RECHECK
+            if (E8 && ACL_ANS_LDS) {  // (as in flush_simple: a request answered meanwhile needs none of its other children)
+                wave_lds_fence();
+                push = push && ans_get<true>(has, req, wo.first) == 0u;
+            }
+#endif
             const uint64_t b = __ballot(push);
             if (b) {
                 const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
@@ -807,6 +830,12 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                     }
                 }
             }
+#if ACL_PUSH_RECHECK
+            if (E8 && ACL_ANS_LDS && INLINE) {  // (as in flush_simple: a request answered meanwhile needs none of its other children)
+                wave_lds_fence();
+                push = push && ans_get<true>(has, e.y, wo.first) == 0u;
+            }
+#endif
             const uint64_t b = __ballot(push);
             if (b) {
                 const uint32_t base = reserve<LOCAL>(wo, (uint32_t)__popcll(b), lane);
