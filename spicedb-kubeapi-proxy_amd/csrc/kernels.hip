@@ -991,6 +991,18 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             }
             issue_fence();
             ACL_MARK(wo, PH_GATHERS);
+#if ACL_PROFILE_PHASES  // (instrumented builds: entries the deep levels read, and how many of them belong to requests that were answered meanwhile)
+            {
+                const uint32_t nA = (uint32_t)__popcll(__ballot(valid)), dA = (uint32_t)__popcll(__ballot(valid && hvA != 0u));
+                const uint32_t nB = pairB ? (uint32_t)__popcll(__ballot(validB)) : 0u, dB = pairB ? (uint32_t)__popcll(__ballot(validB && hvB != 0u)) : 0u;
+                if (lane == 0) {
+                    wo.cold->prof[12] += nA + nB;
+                    wo.cold->prof[13] += dA + dB;
+                    wo.cold->prof[14] += 1u + (pairB ? 1u : 0u);                                  // segments walked
+                    wo.cold->prof[15] += (nA + nB - dA - dB <= 64u && pairB) ? 1u : 0u;            // pairs whose live entries would fit ONE segment
+                }
+            }
+#endif
             uint32_t T = seg_tasks(e, valid, hvA, mdA, sdA, inA, LA, 0u);
             if (pairB) T += seg_tasks(eB, validB, hvB, mdB, sdB, inB, LB, T);
             ACL_MARK(wo, PH_TASKS);
@@ -1481,7 +1493,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     }
 #if ACL_PROFILE_PHASES
     ACL_MARK(wo, PH_OTHER);
-    if (lane < PH_COUNT) atomicAdd(&acl_phase_cycles[lane], (unsigned long long)s_cold[wib].prof[lane]);
+    if (lane < 16) atomicAdd(&acl_phase_cycles[lane], (unsigned long long)s_cold[wib].prof[lane]);
 #endif
 }
 

@@ -42,4 +42,8 @@ tot = sum(out[i] for i in range(len(NAMES)))
 print(f"{w.name}: {n} items, kernel {1e3 * st_['local_ms'] / K:.1f} us per batch (instrumented), {tot / K / 1e6:.1f} M wave-cycles per batch")
 for i, nm in enumerate(NAMES):
     print(f"  {nm:40s} {100.0 * out[i] / max(tot, 1):5.1f} %")
+# counters of the deep levels' fast path (slots 12-15): entries read, entries of requests answered meanwhile, segments, pairs that would fit one segment
+if out[12]:
+    print(f"  deep-level entries read per batch {out[12] / K / 1e6:.2f} M, of which dead on arrival {100.0 * out[13] / out[12]:.1f} %; segments {out[14] / K / 1e3:.0f} k, "
+          f"pairs whose live entries fit ONE segment {100.0 * 2 * out[15] / max(out[14], 1):.1f} % of the segments")
 e.close()
