@@ -194,8 +194,8 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * has waited for yet pins nothing: the holder of tickets may make any other call on the engine (writes included) before it waits.
  * Every batch -- a blocking caller's or a ticket's -- is answered by the kernel itself across PCIe: it reads the items from, and writes
  * the answers to, the host buffers (pinned: in place; else through the context's pinned staging), in one launch, or -- beyond what one
- * launch takes -- in sub-passes on two streams.  No copies, no turn-taking: concurrent calls overlap on the chip (three callers 1.05-1.13 G
- * decisions/s on C4, one caller 0.8 G; profiles/r04_host_split.txt).  Go callers simply block goroutines in acl_check_bulk_ids. */
+ * launch takes -- in sub-passes on two streams.  No copies, no turn-taking: concurrent calls overlap on the chip (three callers 1.12-1.22 G
+ * decisions/s on C4, one caller 0.85 G; profiles/r04_host_split.txt).  Go callers simply block goroutines in acl_check_bulk_ids. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
 int acl_ticket_wait(acl_engine_t *h, acl_ticket_t *ticket);
