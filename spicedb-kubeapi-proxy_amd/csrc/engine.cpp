@@ -994,6 +994,9 @@ int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_
     // resource and subject are the same (unknown) object
     uint32_t res, sub;
     bool kr = h->store.objects(rt).find(it.resource_id, &res), ks = h->store.objects(st).find(it.subject_id, &sub);
+    // (these ids leave the names lock in the caller's hands -- a single Check queued in the batcher: their recycling quarantine starts over, store.hpp touch)
+    if (kr) h->store.touch(rt, res);
+    if (ks) h->store.touch(st, sub);
     // (every name IN a table passed the id pattern when it was interned -- except "*", the wildcard subject's name: only unknown ids are spelled out)
     if ((!kr && !valid_object_id(it.resource_id)) || (!ks && !valid_object_id(it.subject_id)) || std::strcmp(it.resource_id, "*") == 0 || std::strcmp(it.subject_id, "*") == 0)
         return ACL_ERR_INVALID_ARGUMENT;
@@ -1812,7 +1815,9 @@ int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out)
     std::shared_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();
     if (empty(object_id) || !id_out || type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_find: bad argument");
-    return h->store.objects(type).find(object_id, id_out) ? ACL_OK : fail(ACL_ERR_NOT_FOUND, "object not found");
+    if (!h->store.objects(type).find(object_id, id_out)) return fail(ACL_ERR_NOT_FOUND, "object not found");
+    h->store.touch(type, *id_out);  // (the id is the caller's for the length of a quarantine: an unreferenced object is not renamed under it)
+    return ACL_OK;
 }
 const char *acl_object_name(acl_engine_t *h, int type, uint32_t id) {
     std::shared_lock<std::shared_mutex> nlk(h->names_mu);

@@ -246,24 +246,20 @@ __device__ __forceinline__ bool row_contains(const uint32_t *__restrict__ edges,
     return lo < end && (gld(edges, lo) & kIdMask) == key;
 }
 
-// hashed row: nb = b1 - b0 buckets of 4 ids, two-choice placement (plan.hpp hashed_row_buckets): the id is in bucket h1
-// or h2 or nowhere -- two INDEPENDENT 16 B gathers in flight together, never a probing chain (with linear probing the
-// slowest of the 64 lanes made almost every wave walk 3-5 dependent buckets; profiles/r01_c4_bottleneck_analysis.md)
-// is `want` one of the eight ids of two buckets?  Written as xor + min3: 8 v_xor + 3 v_min3 + v_min + v_cmp.  The obvious
-// `p.x == want || ...` compiles to ~35 VALU instructions (the compiler packs the eight i1 results into a 16-bit vector), and
-// the deep levels of a large batch are bound by VALU issue (profiles/r02_pmc_issue_breakdown.txt).
-__device__ __forceinline__ bool bucket_pair_has(const uint4 &p, const uint4 &q, uint32_t want) {
-    uint32_t m = min(min(p.x ^ want, p.y ^ want), p.z ^ want);
-    m = min(min(m, p.w ^ want), q.x ^ want);
-    m = min(min(m, q.y ^ want), q.z ^ want);
-    return min(m, q.w ^ want) == 0u;
+// hashed row (plan.hpp): buckets of 4 ids; a SEEDED single-choice row keeps an id in bucket hrow_bucket(id, y) or nowhere -- ONE 16 B gather per
+// membership test (round 5; rounds 1-4 placed every row two-choice: two gathers per test, and the walk's time follows the number of gather
+// instructions its waves issue, profiles/r04_bucket_gather_sensitivity.txt) -- and a two-choice row (kRowTwoBit: a long row no seed was found
+// for) in bucket h1 or h2: two independent gathers, never a probing chain.
+// is `want` one of the four ids of a bucket?  Written as xor + min3: 4 v_xor + v_min3 + v_min + v_cmp (the obvious `p.x == want || ...`
+// compiles to a chain of compares and i1 packing; the deep levels of a large batch are sensitive to VALU issue, profiles/r02_pmc_issue_breakdown.txt).
+__device__ __forceinline__ bool bucket_has(const uint4 &p, uint32_t want) {
+    return min(min(min(p.x ^ want, p.y ^ want), p.z ^ want), p.w ^ want) == 0u;
 }
-__device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t b1, uint32_t want) {
-    uint32_t h1, h2;
-    hashed_row_buckets(want, b1 - b0, &h1, &h2);
-    const uint4 p = gld(buckets, b0 + h1);
-    const uint4 q = gld(buckets, b0 + h2);
-    return bucket_pair_has(p, q, want);
+__device__ __forceinline__ bool bucket_row_contains(const uint4 *__restrict__ buckets, uint32_t b0, uint32_t y, uint32_t want) {
+    const uint32_t h1 = hrow_bucket(want, y);
+    bool hit = bucket_has(gld(buckets, b0 + h1), want);
+    if (y & kRowTwoBit) hit = hit || bucket_has(gld(buckets, b0 + hrow_bucket2(want, y, h1)), want);
+    return hit;
 }
 
 // Membership of (resource id, subject sid) in a membership-only class.  The class is stored SUBJECT-indexed:
@@ -274,7 +270,7 @@ __device__ __forceinline__ bool subject_row_contains(const DevGraph &g, const Fw
     if (op.flags & OP_WILD) sid = op.K;  // `T:*`: the wildcard subject's row, whoever asks (the fast paths only take plain OP_PROBE_HASH programs)
     if (sid >= op.nrows) return false;
     const uint2 md = gld(reinterpret_cast<const uint2 *>(g.meta), op.base + sid);
-    return md.y > md.x && bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, id);
+    return md.y != 0u && bucket_row_contains(reinterpret_cast<const uint4 *>(g.buckets), md.x, md.y, id);
 }
 
 // Row descriptor {start, end} of (object id, sorted class op.k).  Relations with two sorted classes keep both
@@ -453,9 +449,9 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 if (i < T) {
                     const uint32_t sidt = t.sid[i];
                     const uint2 d = gld(reinterpret_cast<const uint2 *>(g.meta), pop.base + (sidt < pop.nrows ? sidt : 0u));
-                    const bool row = sidt < pop.nrows && d.y > d.x;
+                    const bool row = sidt < pop.nrows && d.y != 0u;
                     t.a[i].y = row ? d.x : 0u;
-                    t.a[i].z = row ? d.y - d.x : 1u;
+                    t.a[i].z = row ? d.y : 1u;  // (the row's y: buckets | two-choice | seed; {0, 1} = the reserved empty bucket)
                 }
             }
         }
@@ -495,35 +491,38 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
 #pragma unroll
             for (int k0 = 0; k0 < E; k0 += W) {
                 if (w0 + 64u * k0 >= total) break;  // (uniform)
-                uint4 p[W], q[W];
+                uint4 p[W];
                 uint32_t rq[W];
+                bool two = false;
 #pragma unroll
                 for (int k = 0; k < W; k++) {
-                    const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, bucket count, request} in one 16-byte read
+                    const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, the row's y (buckets | two-choice | seed), request} in one 16-byte read
                     rq[k] = ta.w;
-                    uint32_t h1, h2;
-                    hashed_row_buckets(edge[k0 + k] & kIdMask, ta.z, &h1, &h2);
-                    const uint32_t b0 = ta.y;
-                    p[k] = gld(buckets, b0 + h1);
-                    q[k] = gld(buckets, b0 + h2);
-#ifdef ACL_EXPERIMENT_THIRD_BUCKET  // (timing experiment only, answers unchanged: one MORE 16-byte gather per child, into the same row -- the
-                                    //  walk's sensitivity to the number of bucket gathers; profiles/r04_bucket_gather_sensitivity.txt)
-                    if (ACL_EXPERIMENT_THIRD_BUCKET == 1 || (lane % ACL_EXPERIMENT_THIRD_BUCKET) == 0u) {  // (N > 1: only every N-th lane issues it)
-                        const uint4 x3 = gld(buckets, b0 + (h1 + 1u < ta.z ? h1 + 1u : 0u));
-                        ACL_KEEP(x3.x);
-                    }
-#endif
+                    p[k] = gld(buckets, ta.y + hrow_bucket(edge[k0 + k] & kIdMask, ta.z));
+                    two = two | ((ta.z & kRowTwoBit) != 0u);
                 }
-                issue_fence();  // trip 2: the 2 x W buckets
+                issue_fence();  // trip 2: the W buckets
                 ACL_MARK(wo, PH_BUCKETS);
                 bool hit[W], push[W];
                 uint64_t pb[W];
                 uint32_t pre[W], np = 0;
 #pragma unroll
+                for (int k = 0; k < W; k++) hit[k] = valid[k0 + k] & bucket_has(p[k], edge[k0 + k] & kIdMask);
+                if (__ballot(two)) {  // (rare: a child whose request's subject has a two-choice row -- its second bucket, one child at a time)
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        const uint4 ta = t.a[tj[k0 + k]];
+                        if (ta.z & kRowTwoBit) {
+                            const uint32_t cid = edge[k0 + k] & kIdMask;
+                            const uint4 q = gld(buckets, ta.y + hrow_bucket2(cid, ta.z, hrow_bucket(cid, ta.z)));
+                            hit[k] = hit[k] | (valid[k0 + k] & bucket_has(q, cid));
+                        }
+                    }
+                }
+#pragma unroll
                 for (int k = 0; k < W; k++) {
                     // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
                     //  loads at the end of every step; depth limits were checked per task above)
-                    hit[k] = valid[k0 + k] & bucket_pair_has(p[k], q[k], edge[k0 + k] & kIdMask);
                     push[k] = valid[k0 + k] & !hit[k] & ((edge[k0 + k] & kLeafBit) == 0u);
                 }
                 // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
@@ -604,17 +603,18 @@ __device__ __forceinline__ void flush_probes(TaskLds &t, uint32_t T, WaveOut &wo
                 hd[k] = gld(meta2, (hk ? cops[k].base : 0u) + (hrow[k] ? sid : 0u));
             }
             const uint32_t child = edge & kIdMask;
-            // trips 2 and 3: both buckets of the first probe, then of the second (two-probe programs only).  One probe's
-            // buckets at a time: four 16 B gathers in flight at once cost 16 VGPRs, which is what pushed this kernel into
-            // scratch at 5 waves/SIMD.
+            // trips 2 and 3: the bucket of the first probe, then of the second (two-probe programs only), one after the other (register budget)
             bool hit = false, push = leafauth && !(edge & kLeafBit);
             auto probe = [&](const uint2 &hdk, bool hrk, uint32_t dl) {
-                const bool hr = hrk && hdk.y > hdk.x;
-                const uint32_t b0 = hr ? hdk.x : 0u, nb = hr ? hdk.y - hdk.x : 1u;
-                uint32_t h1, h2;
-                hashed_row_buckets(child, nb, &h1, &h2);
-                const uint4 bp = gld(buckets, b0 + h1), bq = gld(buckets, b0 + h2);
-                if (hr && level + dl <= kMaxLevels) hit = hit || bucket_pair_has(bp, bq, child);
+                const bool hr = hrk && hdk.y != 0u;
+                const uint32_t b0 = hr ? hdk.x : 0u, y = hr ? hdk.y : 1u;  // (no row: the reserved empty bucket)
+                const uint32_t h1 = hrow_bucket(child, y);
+                const uint4 bp = gld(buckets, b0 + h1);
+                bool h = bucket_has(bp, child);
+                if (__ballot((y & kRowTwoBit) != 0u)) {  // (rare: two-choice rows)
+                    if (y & kRowTwoBit) h = h || bucket_has(gld(buckets, b0 + hrow_bucket2(child, y, h1)), child);
+                }
+                if (hr && level + dl <= kMaxLevels) hit = hit || h;
             };
             if (nh > 0) probe(hd[0], hrow[0], cops[0].dlevel);
             asm volatile("" ::: "memory");  // keep the second probe's gathers behind the first's (register budget, see above)
@@ -952,7 +952,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             auto subj_desc = [&](const uint4 &se, bool sv, const LaneOp &L) -> uint2 {
                 const bool ok = sv && meta_key(se.z) == L.ckey && se.w < L.cnrows;
                 const uint2 d = gld(meta2, L.cbase + (ok ? se.w : 0u));
-                return (ok && d.y > d.x) ? make_uint2(d.x, d.y - d.x) : make_uint2(0u, 1u);  // no row: the reserved empty bucket
+                return (ok && d.y != 0u) ? d : make_uint2(0u, 1u);  // {first bucket, the row's y}; no row: the reserved empty bucket
             };
             auto row_desc = [&](uint32_t rid, bool in, const LaneOp &L) -> uint2 { return gld(meta2, L.base + (in ? rid * (L.Kk & 0xFFFFu) + (L.Kk >> 16) : 0u)); };
             // tasks of one simple segment -> LDS task slots [Tb, Tb + n); returns n
@@ -1330,6 +1330,9 @@ struct NoNext {
 #define ACL_LOCAL_WIDE 16  // (A/B builds: 12 waves per block leave room for 84 VGPRs at two blocks per CU)
 #endif
 constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
+#ifndef ACL_TAIL_SINGLES
+#define ACL_TAIL_SINGLES 0  // N > 0 (A/B builds): the last 2 N x WAVES segments of a level are claimed one by one instead of in pairs (see the claim loop)
+#endif
 template <bool LDSPROG, int WAVES, bool CMB = false>
 __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_local(DevGraph g, const uint4 *__restrict__ items, uint32_t n, uint32_t rpw,
                                                                                   uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
@@ -1443,12 +1446,19 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             parity ^= 1u;
             wo.buf = bufs[parity];
             co.iter = level;
+            // Segments are claimed in PAIRS: one prologue and one set of trips for 128 entries.  (ACL_TAIL_SINGLES = N > 0, A/B builds: the level's last
+            // 2 N x WAVES segments one by one, so that what a wave still holds when the counter runs dry is half as long -- the level barriers are a
+            // fifth of the walk's wave-time.  Measured slower, 227.5 -> 231 -> 238 us for N = 0, 1, 2 on C4: profiles/r05_ab_seeded_rows.txt.)
+            const uint32_t nseg = (cnt + 63u) >> 6;
+            const uint32_t npair = (ACL_TAIL_SINGLES && nseg > 2u * WAVES * ACL_TAIL_SINGLES) ? (nseg - 2u * WAVES * ACL_TAIL_SINGLES + 1u) >> 1 : (ACL_TAIL_SINGLES ? 0u : nseg);
             for (;;) {
                 uint32_t sg = 0;
-                if (lane == 0) sg = atomicAdd(next_seg, 2u);
+                if (lane == 0) sg = atomicAdd(next_seg, 1u);
                 sg = uniform(sg);
-                if (sg * 64 >= cnt) break;
-                for (lw.s = sg, lw.second = true; lw.s < sg + 2 && lw.s * 64 < cnt; lw.s++) {
+                const uint32_t take = sg < npair ? 2u : 1u;
+                sg = sg < npair ? 2u * sg : npair + sg;  // (= 2 npair + (claim - npair))
+                if (sg >= nseg) break;
+                for (lw.s = sg, lw.second = take > 1u; lw.s < sg + take && lw.s * 64 < cnt; lw.s++) {
                     if (lw.s > sg && !lw.second) break;  // the pair's second segment went with the first
                     const bool v = lw.s * 64 + lane < cnt;
                     const uint4 en = lw.at(v ? lw.s * 64 + lane : lw.s * 64);  // unconditional; process_segment masks by `v`

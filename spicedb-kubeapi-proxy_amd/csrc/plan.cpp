@@ -15,12 +15,13 @@ constexpr uint32_t kMaxDepth = 50;  // pkg/spicedb/spicedb.go:34
 
 
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+// ---- hashed rows (plan.hpp): seeded single-choice where a seed can be found, two-choice (cuckoo) otherwise.  A row is named by its descriptor
+// {first bucket, y = buckets | two-choice bit | seed}.
 // two-choice insertion with random-walk eviction; false when the row is too tight (the caller gives it more buckets)
-bool cuckoo_insert(uint32_t *row, uint32_t nb, uint32_t id) {
+bool cuckoo_insert(uint32_t *row, uint32_t y, uint32_t id) {
     uint32_t cur = id;
     for (uint32_t kick = 0; kick < 512; kick++) {
-        uint32_t h1, h2;
-        hashed_row_buckets(cur, nb, &h1, &h2);
+        const uint32_t h1 = hrow_bucket(cur, y), h2 = hrow_bucket2(cur, y, h1);
         for (uint32_t b : {h1, h2})
             for (int k = 0; k < 4; k++)
                 if (row[4 * (size_t)b + k] == kEmpty) {
@@ -34,27 +35,81 @@ bool cuckoo_insert(uint32_t *row, uint32_t nb, uint32_t id) {
     // undo is not needed: the caller discards the row
     return false;
 }
-// builds the row of `ids` at the end of `buckets`; returns {first bucket, end bucket}
-std::pair<uint32_t, uint32_t> append_hashed_row(std::vector<uint32_t> &buckets, const uint32_t *ids, size_t n, uint32_t min_buckets);
-bool hashed_row_has(const uint32_t *row, uint32_t nb, uint32_t id) {
-    if (!nb) return false;
-    uint32_t h1, h2;
-    hashed_row_buckets(id, nb, &h1, &h2);
-    for (uint32_t b : {h1, h2})
-        for (int k = 0; k < 4; k++)
-            if (row[4 * (size_t)b + k] == id) return true;
+bool hashed_row_has(const uint32_t *row, uint32_t y, uint32_t id) {
+    if (!hrow_nb(y)) return false;
+    const uint32_t h1 = hrow_bucket(id, y);
+    for (int k = 0; k < 4; k++)
+        if (row[4 * (size_t)h1 + k] == id) return true;
+    if (!(y & kRowTwoBit)) return false;
+    const uint32_t h2 = hrow_bucket2(id, y, h1);
+    for (int k = 0; k < 4; k++)
+        if (row[4 * (size_t)h2 + k] == id) return true;
     return false;
 }
 inline uint32_t buckets_for(uint32_t n) { return n <= 4 ? 1u : (n + 2) / 3; }  // load <= 0.75 (<= 1.0 for a single bucket)
+// A/B knob (ACL_SEEDED_ROWS=0: every row two-choice, as in rounds 1-4)
+bool seeded_rows() {
+    static const bool on = [] {
+        const char *e = getenv("ACL_SEEDED_ROWS");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+constexpr uint32_t kSeeds = 256;
+// Places `ids` into `row` (nb buckets, all empty on entry) single-choice under the first seed that leaves no bucket with more than four ids;
+// returns the seed or -1.  fill: scratch of nb bytes.
+int seeded_place(uint32_t *row, uint32_t nb, const uint32_t *ids, size_t n, std::vector<uint8_t> &fill) {
+    for (uint32_t seed = 0; seed < kSeeds; seed++) {
+        const uint32_t y = hrow_pack(nb, seed, false);
+        fill.assign(nb, 0);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) ok = ++fill[hrow_bucket(ids[i], y)] <= 4;
+        if (!ok) continue;
+        fill.assign(nb, 0);
+        for (size_t i = 0; i < n; i++) {
+            const uint32_t b = hrow_bucket(ids[i], y);
+            row[4 * (size_t)b + fill[b]++] = ids[i];
+        }
+        return (int)seed;
+    }
+    return -1;
+}
+// Fills `row` (nb buckets) with `ids`: single-choice when a seed is found, else two-choice; returns the descriptor's y or 0 when the ids do not fit nb buckets
+uint32_t place_row(uint32_t *row, uint32_t nb, const uint32_t *ids, size_t n, bool try_seeded, std::vector<uint8_t> &fill) {
+    std::fill(row, row + 4 * (size_t)nb, kEmpty);
+    if (try_seeded && (uint64_t)n <= 4ull * nb) {
+        const int seed = seeded_place(row, nb, ids, n, fill);
+        if (seed >= 0) return hrow_pack(nb, (uint32_t)seed, false);
+    }
+    if (buckets_for((uint32_t)n) > nb) return 0;
+    const uint32_t y = hrow_pack(nb, 0, true);
+    for (size_t i = 0; i < n; i++)
+        if (!cuckoo_insert(row, y, ids[i])) return 0;
+    return y;
+}
+// builds the row of `ids` at the end of `buckets`; returns {first bucket, y}.  Seeded single-choice at the smallest bucket count that finds a seed
+// between load 0.75 and load 1/3 (min_buckets: the patcher's room to grow); beyond that two-choice at load <= 0.75.
 std::pair<uint32_t, uint32_t> append_hashed_row(std::vector<uint32_t> &buckets, const uint32_t *ids, size_t n, uint32_t min_buckets) {
     const uint32_t b0 = (uint32_t)(buckets.size() / 4);
-    if (!n && !min_buckets) return {b0, b0};
-    for (uint32_t nb = std::max(min_buckets, buckets_for((uint32_t)n));; nb += std::max(1u, nb / 4)) {
+    if (!n && !min_buckets) return {b0, 0u};
+    static thread_local std::vector<uint8_t> fill;
+    const uint32_t nb0 = std::max(min_buckets, buckets_for((uint32_t)n));
+    if ((uint64_t)nb0 + nb0 / 4 + 1 > kRowNbMask) throw std::runtime_error("a subject's hashed row exceeds 2^23 buckets");
+    if (seeded_rows()) {
+        const uint32_t nb_max = std::max<uint32_t>(nb0, (uint32_t)std::min<uint64_t>(((uint64_t)n * 3 + 3) / 4, kRowNbMask));  // load >= 1/3
+        for (uint32_t nb = nb0; nb <= nb_max; nb += std::max(1u, nb / 8)) {
+            buckets.resize(4 * (size_t)(b0 + nb));
+            uint32_t *row = buckets.data() + 4 * (size_t)b0;
+            std::fill(row, row + 4 * (size_t)nb, kEmpty);
+            const int seed = seeded_place(row, nb, ids, n, fill);
+            if (seed >= 0) return {b0, hrow_pack(nb, (uint32_t)seed, false)};
+        }
+    }
+    for (uint32_t nb = nb0;; nb += std::max(1u, nb / 4)) {
+        if (nb > kRowNbMask) throw std::runtime_error("a subject's hashed row exceeds 2^23 buckets");
         buckets.resize(4 * (size_t)(b0 + nb));
-        std::fill(buckets.begin() + 4 * (long)b0, buckets.end(), kEmpty);
-        bool ok = true;
-        for (size_t i = 0; i < n && ok; i++) ok = cuckoo_insert(buckets.data() + 4 * (size_t)b0, nb, ids[i]);
-        if (ok) return {b0, b0 + nb};
+        const uint32_t y = place_row(buckets.data() + 4 * (size_t)b0, nb, ids, n, false, fill);
+        if (y) return {b0, y};
     }
 }
 
@@ -375,7 +430,7 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
                 const auto r = append_hashed_row(s.buckets, by_subject.data() + cnt[sid], cnt[sid + 1] - cnt[sid], 0);
                 uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
                 md[0] = r.first;
-                md[1] = r.second;
+                md[1] = r.second;  // (y: buckets | two-choice | seed)
             }
         }
         // ---- enumerable classes: sorted sub-rows per (object, class)
@@ -506,6 +561,23 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             }
         }
     }
+    if (getenv("ACL_DEBUG_ROWS")) {  // how the hashed rows were placed (tools/row_stats.py)
+        uint64_t rows = 0, two = 0, ids = 0, nbs = 0, nb_two = 0;
+        for (int slot = 0; slot < sc.nslots; slot++)
+            for (const ClassLayout &c : lay[slot].cls) {
+                if (!c.live || !c.hashed) continue;
+                for (uint32_t sid = 0; sid < c.nsubjects; sid++) {
+                    const uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
+                    if (!md[1]) continue;
+                    rows++;
+                    nbs += hrow_nb(md[1]);
+                    if (md[1] & kRowTwoBit) two++, nb_two += hrow_nb(md[1]);
+                    for (size_t i = 4 * (size_t)md[0]; i < 4 * ((size_t)md[0] + hrow_nb(md[1])); i++) ids += s.buckets[i] != kEmpty;
+                }
+            }
+        fprintf(stderr, "[aclgpu] hashed rows: %llu (%llu two-choice holding %llu buckets), %llu ids in %llu buckets (load %.3f), %.1f MB\n", (unsigned long long)rows,
+                (unsigned long long)two, (unsigned long long)nb_two, (unsigned long long)ids, (unsigned long long)nbs, nbs ? ids / (4.0 * nbs) : 0.0, nbs * 16 / 1e6);
+    }
     s.lay = std::move(lay);
     *snap = std::move(s);
 }
@@ -526,24 +598,28 @@ struct Patcher {
     uint32_t *hdesc(const ClassLayout &c, uint32_t sid) { return s.meta.data() + 2 * ((size_t)c.smeta_base + sid); }
     bool hashed_has(const ClassLayout &c, uint32_t sid, uint32_t res) {
         const uint32_t *md = hdesc(c, sid);
-        return hashed_row_has(s.buckets.data() + 4 * (size_t)md[0], md[1] - md[0], res);
+        return hashed_row_has(s.buckets.data() + 4 * (size_t)md[0], md[1], res);
     }
-    // rebuilds the row of `sid` with `res` added or removed: in place while it fits its buckets, else at the end of
-    // `buckets` with room to grow before the next move
+    // rebuilds the row of `sid` with `res` added or removed: in place while it fits its buckets (a seeded row gets a new seed when the old
+    // one no longer places every id: the descriptor is re-uploaded with the row), else at the end of `buckets` with room to grow before the next move
     void hashed_set(const ClassLayout &c, uint32_t sid, uint32_t res, bool add) {
         uint32_t *md = hdesc(c, sid);
-        const uint32_t b0 = md[0], nb = md[1] - md[0];
+        const uint32_t b0 = md[0], nb = hrow_nb(md[1]);
         std::vector<uint32_t> el;
         for (size_t i = 4 * (size_t)b0; i < 4 * (size_t)(b0 + nb); i++)
             if (s.buckets[i] != kEmpty && (add || s.buckets[i] != res)) el.push_back(s.buckets[i]);
         if (add) el.push_back(res);
-        if (nb && (el.empty() || buckets_for((uint32_t)el.size()) <= nb)) {
-            std::vector<uint32_t> row(4 * (size_t)nb, kEmpty);
-            bool ok = true;
-            for (size_t i = 0; i < el.size() && ok; i++) ok = cuckoo_insert(row.data(), nb, el[i]);
-            if (ok) {
+        if (nb) {
+            static thread_local std::vector<uint8_t> fill;
+            std::vector<uint32_t> row(4 * (size_t)nb);
+            const uint32_t y = place_row(row.data(), nb, el.data(), el.size(), seeded_rows(), fill);
+            if (y) {
                 std::copy(row.begin(), row.end(), s.buckets.begin() + 4 * (long)b0);
                 out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)b0, 4 * (size_t)nb});
+                if (y != md[1]) {
+                    md[1] = y;
+                    out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
+                }
                 return;
             }
         }
@@ -552,7 +628,7 @@ struct Patcher {
         md[0] = r.first;
         md[1] = r.second;
         s.garbage_words += 4 * (uint64_t)nb;
-        out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)r.first, 4 * (size_t)(r.second - r.first)});
+        out.push_back(Patch{Patch::BUCKETS, 4 * (size_t)r.first, 4 * (size_t)hrow_nb(r.second)});
         out.push_back(Patch{Patch::META, (size_t)(md - s.meta.data()), 2});
     }
 
@@ -762,8 +838,8 @@ bool verify_snapshot(Store &store, int64_t now, const Snapshot &s, ShardSpec sha
                     if ((uint32_t)key >= c.nsubjects || !P.hashed_has(c, (uint32_t)key, (uint32_t)(key >> 32))) return bad(rel + ": hashed row misses a relationship");
                 for (uint32_t sid = 0; sid < c.nsubjects; sid++) {
                     const uint32_t *md = s.meta.data() + 2 * ((size_t)c.smeta_base + sid);
-                    if (md[1] < md[0] || 4 * (size_t)md[1] > s.buckets.size()) return bad(rel + ": hashed descriptor out of range");
-                    for (size_t i = 4 * (size_t)md[0]; i < 4 * (size_t)md[1]; i++)
+                    if (4 * ((size_t)md[0] + hrow_nb(md[1])) > s.buckets.size()) return bad(rel + ": hashed descriptor out of range");
+                    for (size_t i = 4 * (size_t)md[0]; i < 4 * ((size_t)md[0] + hrow_nb(md[1])); i++)
                         if (s.buckets[i] != 0xFFFFFFFFu) {
                             stored++;
                             if (!std::binary_search(live.begin(), live.end(), (uint64_t)s.buckets[i] << 32 | sid)) return bad(rel + ": hashed row holds a dead relationship");

@@ -34,19 +34,31 @@ enum : uint32_t {
     OP_WILD = 64u        // with OP_PROBE_HASH: the row probed is the one of the class's wildcard subject `T:*` (its id in FwdOp::K), whoever the
                          // request's subject is; reverse ops (RevOp): the row read is the wildcard subject's (roff_base points at it), whatever the seed's id
 };
-// Hashed rows use two-choice (cuckoo) placement over 4-slot buckets: an id lives in bucket h1 or h2 of its row, so a
-// membership test is exactly two independent 16-byte gathers -- no probing chain whose longest lane stalls the wave.
+// Hashed rows: 4-slot buckets (16 B) of ids.  Round 5: a row is SEEDED SINGLE-CHOICE wherever that can be had -- the builder searches the
+// row's 8-bit seed for a placement in which no bucket overflows, so a membership test is ONE 16-byte gather (an id lives in bucket
+// hrow_bucket(id) or nowhere).  Rows of a few dozen ids (a user's groups, a user's pods) find a seed at the old load of 0.75; longer rows get
+// more buckets (load down to 1/3) and rows for which that is not enough keep the two-choice (cuckoo) placement of rounds 1-4: bucket h1 or h2,
+// two independent gathers, which the kernels issue only for wave steps that hold such a row.  Either way there is never a probing chain whose
+// longest lane stalls the wave.
+//   descriptor {x, y}: x = first bucket, y = buckets[0:23) | two-choice[23] | seed[24:32); y == 0: the subject has no row
 #if defined(__HIPCC__)
 #define ACL_HD __host__ __device__
 #else
 #define ACL_HD
 #endif
-ACL_HD inline void hashed_row_buckets(uint32_t id, uint32_t nb, uint32_t *h1, uint32_t *h2) {
-    const uint32_t a = (uint32_t)(((uint64_t)(id * 0x9E3779B1u) * nb) >> 32);
-    uint32_t b = (uint32_t)(((uint64_t)((id ^ 0x5bd1e995u) * 0x85EBCA6Bu) * nb) >> 32);
-    if (b == a) b = a + 1 == nb ? 0 : a + 1;  // nb == 1: both are bucket 0
-    *h1 = a;
-    *h2 = b;
+constexpr uint32_t kRowNbMask = 0x7FFFFFu;   // buckets of one row (< 2^23: 25 M ids of one subject; the builder fails loudly beyond)
+constexpr uint32_t kRowTwoBit = 1u << 23;    // two-choice row (seed 0)
+ACL_HD inline uint32_t hrow_nb(uint32_t y) { return y & kRowNbMask; }
+ACL_HD inline uint32_t hrow_pack(uint32_t nb, uint32_t seed, bool two) { return nb | (two ? kRowTwoBit : 0u) | (seed << 24); }
+// the bucket of `id` in a single-choice row -- and the first choice in a two-choice row (seed 0)
+ACL_HD inline uint32_t hrow_bucket(uint32_t id, uint32_t y) {
+    return (uint32_t)(((uint64_t)((id ^ ((y >> 24) * 0x85EBCA6Bu)) * 0x9E3779B1u) * (y & kRowNbMask)) >> 32);
+}
+// the second choice of a two-choice row
+ACL_HD inline uint32_t hrow_bucket2(uint32_t id, uint32_t y, uint32_t h1) {
+    const uint32_t nb = y & kRowNbMask;
+    const uint32_t b = (uint32_t)(((uint64_t)((id ^ 0x5bd1e995u) * 0x85EBCA6Bu) * nb) >> 32);
+    return b != h1 ? b : (h1 + 1 == nb ? 0u : h1 + 1);  // nb == 1: both are bucket 0
 }
 constexpr uint32_t kLeafBit = 0x80000000u;  // object ids are < 2^31
 constexpr uint32_t kIdMask = 0x7FFFFFFFu;

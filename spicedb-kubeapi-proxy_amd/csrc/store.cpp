@@ -213,6 +213,7 @@ Status Store::load_schema(const std::string &text) {
     refcnt_.assign(schema_.defs.size(), {});
     freed_.assign(schema_.defs.size(), {});
     freed_at_.assign(schema_.defs.size(), {});
+    touched_at_.assign(schema_.defs.size(), {});
     no_recycle_.assign(schema_.defs.size(), 0);
     recycled_rev_.clear();
     if (const char *ev = getenv("ACL_ID_QUARANTINE_MS")) reuse_quarantine_ms_ = std::max(0, atoi(ev));  // test knob
@@ -227,6 +228,7 @@ Status Store::load_schema(const std::string &text) {
     return Status::Ok();
 }
 
+int64_t Store::steady_now_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int64_t steady_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 void Store::ref(int type, uint32_t id, int delta) {
@@ -276,6 +278,7 @@ uint32_t Store::intern_object(int type, std::string_view name, bool pin, bool ho
             rc[id] |= kPinned;
         }
         if (hold) ref(type, id, +1);  // (every hold is released once: a write naming one new subject in five updates holds it five times)
+        touch(type, id);  // (found by name: the quarantine of an unreferenced object starts over)
         return id;
     }
     // a NEW name: the oldest free id that has sat out its quarantine, if its object is still unreferenced; else the next dense id
@@ -286,7 +289,18 @@ uint32_t Store::intern_object(int type, std::string_view name, bool pin, bool ho
         fq.pop_front();
         // void entries: referenced (or pinned) again since, or freed AGAIN later (the younger entry carries the quarantine)
         if (f.id >= refcnt_[type].size() || refcnt_[type][f.id] != 0 || !tab.name(f.id) || f.id >= freed_at_[type].size() || freed_at_[type][f.id] != f.at_ms) continue;
+        // handed out by name since it became free (touch): the quarantine counts from then -- back into the queue with that stamp
+        if (f.id < touched_at_[type].size()) {
+            const int64_t t = __atomic_load_n(&touched_at_[type][f.id], __ATOMIC_RELAXED);
+            if (t > f.at_ms && now_ms - t < reuse_quarantine_ms_) {
+                freed_at_[type][f.id] = t;
+                fq.push_back(Freed{f.id, t});
+                continue;
+            }
+        }
         tab.rename(f.id, name);
+        size_touched(type, f.id);
+        touch(type, f.id);
         recycled_rev_[(uint64_t)type << 32 | f.id] = revision_;
         ids_recycled_++;
         if (pin) refcnt_[type][f.id] |= kPinned;
@@ -295,6 +309,8 @@ uint32_t Store::intern_object(int type, std::string_view name, bool pin, bool ho
         return f.id;
     }
     id = tab.intern(name);
+    size_touched(type, id);
+    touch(type, id);
     if (!no_recycle_[type]) {
         auto &rc = refcnt_[type];
         if (rc.size() <= id) rc.resize((size_t)id + 1 + rc.size() / 2, 0);

@@ -224,6 +224,15 @@ class Store {
     // (ref(type, id, -1)) once it has put the object's relationships in -- Store::write
     uint32_t intern_object(int type, std::string_view name, bool pin = false, bool hold = false);
     uint64_t ids_recycled() const { return ids_recycled_; }
+    // An id that leaves the name tables' lock in a caller's hands (a resolved single Check or LookupResources waiting in the batcher, the subject of
+    // a lookup that drops the state lock before its walk) is STAMPED: the recycling quarantine of an unreferenced object counts from the last time
+    // its id was handed out, not from when it became free (a subject without relationships, interned by a lookup long ago, could be
+    // renamed between a later request's name resolution and its evaluation).  Callable under the names lock held SHARED: a relaxed atomic store
+    // into a table that only grows under the exclusive lock.
+    void touch(int type, uint32_t id) {
+        if ((size_t)type < touched_at_.size() && id < touched_at_[type].size()) __atomic_store_n(&touched_at_[type][id], steady_now_ms(), __ATOMIC_RELAXED);
+    }
+    static int64_t steady_now_ms();
     static constexpr int64_t kReuseQuarantineMs = 30000;
     void set_reuse_quarantine_ms(int64_t ms) { reuse_quarantine_ms_ = ms; }  // test knob (ACL_ID_QUARANTINE_MS)
     uint32_t wildcard_id(int type) const { return wildcard_id_[type]; }  // id of the name "*" in a type some relation allows as `type:*`; else 0xFFFFFFFF
@@ -283,6 +292,11 @@ class Store {
     std::vector<std::deque<Freed>> freed_;        // [type] ids whose count reached zero, oldest first
     std::vector<std::vector<int64_t>> freed_at_;  // [type][id] stamp of the id's LATEST entry in freed_ (older entries are void)
     void note_free(int type, uint32_t id);
+    std::vector<std::vector<int64_t>> touched_at_;  // [type][id] steady-clock ms of the last hand-out of the id by name (touch); sized with the id space
+    void size_touched(int type, uint32_t id) {
+        auto &ta = touched_at_[type];
+        if (ta.size() <= id) ta.resize((size_t)id + 1 + ta.size() / 2, 0);
+    }
     std::vector<uint8_t> no_recycle_;             // [type] a numeric bulk load chose ids of this type: its counts are not tracked
     std::unordered_map<uint64_t, uint64_t> recycled_rev_;  // type << 32 | id -> revision at which the id changed its name (changes_since)
     uint64_t ids_recycled_ = 0;

@@ -332,3 +332,27 @@ def test_object_ids_are_recycled_and_the_snapshot_stays_exact(aclgpu, monkeypatc
     assert e.find("user", "u-latest") != e.find("user", "u-shared")
     assert e.selfcheck_snapshot() is True
     e.close()
+
+
+def test_an_id_handed_out_by_name_restarts_its_quarantine(aclgpu, monkeypatch):
+    """the recycling quarantine of an unreferenced object counts from the last time its id was handed to a caller by name
+    (acl_find, a resolved single Check, the subject of a LookupResources), not from when it became free -- otherwise a subject without
+    relationships that a request has just resolved could be renamed by a concurrent write before the request is evaluated."""
+    import time
+    from tests import kat_runner
+    monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "300")  # (read when the schema is loaded)
+    b = kat_runner.load_bootstrap()
+    for handed_out in (False, True):
+        e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+        e.write([(aclgpu.OP_TOUCH, ("pod", "ns/a", "viewer", "user", "u-x", ""))])
+        e.write([(aclgpu.OP_DELETE, ("pod", "ns/a", "viewer", "user", "u-x", ""))])  # u-x takes part in no relationship any more
+        ux = e.find("user", "u-x")
+        time.sleep(0.4)  # ... and has sat out the quarantine
+        if handed_out:
+            assert e.find("user", "u-x") == ux  # a caller resolves the name: the id is theirs for another quarantine
+        e.write([(aclgpu.OP_TOUCH, ("pod", "ns/b", "viewer", "user", "u-new", ""))])
+        if handed_out:
+            assert e.find("user", "u-x") == ux and e.find("user", "u-new") != ux
+        else:
+            assert e.find("user", "u-x") is None and e.find("user", "u-new") == ux  # (the control: without the hand-out the id is reused)
+        e.close()
