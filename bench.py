@@ -854,6 +854,27 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     fire_long()
     torch.cuda.synchronize()
     el_long = time.perf_counter() - tl
+    # ... and once more with the engine's HIP events ON (every caller's context records begin / end on ITS stream around its launch): what a
+    # launch lasts INSIDE this leg, where the callers' launches overlap -- blocks of the next batch move in while the previous one's last blocks
+    # finish -- and how much of consecutive launches overlaps (the roofline's kernel time is the SEQUENTIAL device leg's and
+    # is longer than ms_per_step).  A pass of its own, after `value` was taken: events cost a few us per call, and timing switches the lone
+    # caller's two-slice split off.
+    fire_ev = pipelined(steps_all)
+    eng.stats_reset()
+    eng.set_timing(True)
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    fire_ev()
+    torch.cuda.synchronize()
+    el_ev = time.perf_counter() - te
+    eng.set_timing(False)
+    st_ev = eng.stats()
+    k_ms, k_n = (st_ev.get("local_ms", 0.0), st_ev["local_passes"]) if st_ev.get("local_ms", 0.0) >= st_ev["expand_ms"] else (st_ev["expand_ms"], st_ev["expand_launches"])
+    rec["timed_leg_kernels"] = {"kernel_us_in_leg": 1e3 * k_ms / max(1, k_n), "launches": int(k_n), "ms_per_step_with_events": 1e3 * el_ev / steps_all * nrep,
+                                "overlap_factor": (k_ms * 1e-3) / el_ev if el_ev > 0 else None,
+                                "note": "the timed leg repeated with HIP events on the callers' streams: kernel_us_in_leg = mean launch duration while the callers' launches "
+                                        "overlap (longer than a sequential launch: the blocks share the chip); overlap_factor = sum of launch durations / wall time of the "
+                                        "pass = launches in flight on average -- ms_per_step = kernel_us_in_leg / overlap_factor"}
     rec["host_ids"] = {"decisions_per_s": n * steps_all / elapsed, "ms_per_batch": 1e3 * elapsed / steps_all, "distinct_batches": NB, "answers_equal_device_leg": host_ok,
                        "long_run": {"steps": long_steps // nrep, "decisions_per_s": n * long_steps / el_long, "ms_per_step": 1e3 * el_long / (long_steps // nrep)},
                        "replicas_in_process": nrep, "replica_calls": eng.replica_calls(),
@@ -1000,7 +1021,10 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
             traffic, traffic_detail = float(m["bytes_per_launch"]), m
         elif traffic_detail is not None:
             traffic_detail["live_measurement_failed"] = m.get("error")
+    k_s = k["ms"] * 1e-3 / k["launches"] if k.get("launches") else 0.0  # one launch, seconds
     rec["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+                       # HBM UTILISATION, as opposed to the byte model's `frac`: counter traffic of a launch / its duration / peak
+                       "traffic_gbs": (traffic / k_s / 1e9) if (traffic and k_s) else None, "traffic_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if (traffic and k_s) else None,
                        "traffic_detail": traffic_detail, "kernel": k["name"], "kernel_avg_us": 1e3 * k["ms"] / k["launches"], "launches_per_batch": k["launches"] / steps,
                        "measured_in": "device_resident leg (sequential launches, HIP events on the launching stream)",
                        "algorithmic_bytes_per_check": tot / n, "algorithmic_bytes_per_batch": tot, "algorithmic_bytes_per_launch": tot * steps / k["launches"],
@@ -1084,6 +1108,40 @@ def measure_traffic(args, label, kernel, n_items=0):
                 "source": "measured in THIS run: the device-resident leg of this command re-run under rocprofv3 --kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE "
                           "(separate passes, mean over the launches), counters -> bytes by the round-4 calibration"})
     return out
+
+
+def c5r_leg(args, local_rank, budget_s):
+    """The 100 M-relationship replica (the HBM-regime data point: a 0.7 GB snapshot does not fit the 256 MiB Infinity Cache), in the DEFAULT run
+    (VERDICT r4 next #2): device-resident kernel time over >= 10 launches (HIP events), every answer of the batch against the CPU oracle, the
+    byte model's roofline and -- while the time budget lasts -- the counter traffic of the same command under rocprofv3 (two --pmc passes)."""
+    import aclgpu
+    from aclgpu import workloads
+    t0 = time.time()
+    w5 = workloads.c5(scale=1.0)
+    t_gen = time.time() - t0
+    e5 = aclgpu.Engine(w5.schema, device=local_rank)
+    w5.load(e5)
+    e5.snapshot()
+    t_load = time.time() - t0 - t_gen
+    sub = argparse.Namespace(**vars(args))
+    sub.workload, sub.scale, sub.batch, sub.replica = "C5", 1.0, 0, True
+    r5, p5, er5 = check_bench(sub, w5, e5, max(10, min(args.steps, 40)), max(3, args.warmup), 1, 0, "C5R", "device")
+    r5.pop("elapsed", None)
+    r5.pop("value", None)
+    snap_bytes = int(e5.stats()["snapshot_bytes"])
+    e5.close()
+    r5["setup_s"] = {"generate": round(t_gen, 1), "load+snapshot": round(t_load, 1)}
+    r5["snapshot_bytes"] = snap_bytes
+    if not args.no_cpu:
+        r5["_steps"] = max(10, min(args.steps, 40))
+        sub.traffic = "measure" if (args.traffic == "measure" and time.time() - t0 < budget_s) else "static"
+        cpu_and_roofline(sub, w5, r5, p5, er5, "C5R")
+        r5.pop("_steps")
+        r5["roofline"]["traffic_mode"] = sub.traffic
+    else:
+        r5.pop("kernel", None)
+    r5["seconds"] = round(time.time() - t0, 1)
+    return r5
 
 
 def launch_ranks(n, dry):
@@ -1314,6 +1372,11 @@ def main():
             out["_steps"] = args.steps
             cpu_and_roofline(args, w, out, gpu_perm, gpu_err, label)
             out.pop("_steps")
+            tk, lr = out.get("timed_leg_kernels") or {}, (out.get("host_ids") or {}).get("long_run") or {}
+            # the timed leg reconciled with the roofline's sequential kernel time, and the >= 200-step figure, as flat numbers inside `roofline`
+            out["roofline"].update({"kernel_us_in_leg": tk.get("kernel_us_in_leg"), "overlap_factor": tk.get("overlap_factor"),
+                                    "long_run_decisions_per_s": lr.get("decisions_per_s"), "long_run_ms_per_step": lr.get("ms_per_step"), "long_run_steps": lr.get("steps")})
+            out["long_run"] = lr or None
             if per_rank:
                 rf = out["roofline"]
                 bpl = rf["algorithmic_bytes_per_launch"]
@@ -1372,8 +1435,19 @@ def main():
             e3.close()
         except Exception as ex:  # noqa: BLE001 -- the headline line is printed whatever happens here
             cfgs["error"] = f"{type(ex).__name__}: {ex}"
+        # the 100 M-relationship replica: the honest HBM-regime point beside the cache-resident headline (its own time budget: ~1-2 minutes)
+        if os.environ.get("ACL_BENCH_C5R", "1") != "0":
+            try:
+                cfgs["C5R"] = c5r_leg(args, local_rank, float(os.environ.get("ACL_BENCH_C5R_BUDGET_S", "150")))
+            except Exception as ex:  # noqa: BLE001
+                cfgs["C5R"] = {"error": f"{type(ex).__name__}: {ex}"}
         out["configs"] = cfgs
         out["single_checks"] = single_checks_leg()
+        rf5 = (cfgs.get("C5R") or {}).get("roofline") or {}
+        if out.get("roofline") is not None and rf5:  # flat, inside `roofline`: what the driver's record keeps of this line
+            out["roofline"].update({"c5r_kernel_avg_us": rf5.get("kernel_avg_us"), "c5r_frac": rf5.get("frac"), "c5r_achieved": rf5.get("achieved"), "c5r_traffic": rf5.get("traffic"),
+                                    "c5r_traffic_frac": rf5.get("traffic_frac"), "c5r_parity_checked": (cfgs["C5R"].get("parity") or {}).get("checked_against_oracle"),
+                                    "c5r_parity_mismatches": (cfgs["C5R"].get("parity") or {}).get("mismatches")})
 
     # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
     # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.

@@ -187,6 +187,9 @@ typedef struct {
     int64_t timeout_ns;             /* <= 0: none; else relative to the call's start */
 } acl_call_opts_t;
 int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
+/* acl_check_bulk_v under the caller's context (reference pkg/authz/check.go:48, postfilter.go:134: CheckBulkPermissions(ctx, ...)): a raised
+ * cancel flag or a passed deadline ends the call with CANCELLED / DEADLINE_EXCEEDED while it waits for an evaluation context. */
+int acl_check_bulk_v_opts(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
 
 /* Pipelined form of acl_check_bulk_ids for hosts that cannot park a thread per call: submit returns at once, the batch is answered as a
  * whole blocking call on one of the engine's pool workers (one worker per evaluation context); acl_ticket_wait blocks until perm_out /

@@ -456,6 +456,14 @@ static int parse_schema(orc_t *o, const char *text) {
                     if (x < 0 || t->rels[x].is_perm) { seterr(o, "schema: %s#%s arrow over non-relation '%s'", t->name, r->name, e->a); return 0; }
                     for (int k = 0; k < t->rels[x].nallowed; k++)
                         if (t->rels[x].allowed[k].srel == WILDCARD) { seterr(o, "schema: %s#%s arrow over '%s', which allows wildcard subjects", t->name, r->name, e->a); return 0; }
+                    /* a.all(b) FAILS CLOSED: "every subject of a holds b" is not defined here for a subject whose type has no b -- a plain
+                     * arrow skips such subjects, an intersection arrow that skipped them could grant what the real engine denies: refused at load */
+                    if (e->kind == EX_ARROW_ALL)
+                        for (int k = 0; k < t->rels[x].nallowed; k++)
+                            if (rel_index(&o->types[t->rels[x].allowed[k].stype], e->b) < 0) {
+                                seterr(o, "schema: %s#%s: %s.all(%s) over a subject type without '%s'", t->name, r->name, e->a, e->b, e->b);
+                                return 0;
+                            }
                 }
             }
         }

@@ -153,6 +153,8 @@ def _validate(defs, d, e):
             raise SchemaError(f"arrow over non-relation {e[1]}")
         if any(a[1] == "*" for a in ts.allowed):
             raise SchemaError(f"arrow over {e[1]}, which allows wildcard subjects")
+        if e[0] == "arrow_all" and any(e[2] not in defs[a[0]].members for a in ts.allowed):  # fails closed (see oracle/acl_oracle.c)
+            raise SchemaError(f"{e[1]}.all({e[2]}) over a subject type without {e[2]}")
 
 
 # intersection: an empty operand decides (NO), then an error, then HAS; exclusion with a HAS base: by the subtracted operand

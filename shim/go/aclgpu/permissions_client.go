@@ -75,7 +75,9 @@ func (p *permissionsClient) CheckBulkPermissions(ctx context.Context, in *v1.Che
 	}
 	perm := make([]C.uint8_t, n)
 	errs := make([]C.int32_t, n)
-	if rc := C.acl_check_bulk_v(p.e.h, vi.items, C.size_t(n), &perm[0], &errs[0]); rc != 0 {
+	opts, stop := callOpts(ctx) // ctx cancellation / deadline reach the engine through acl_call_opts_t (check.go:48 passes the request's ctx)
+	defer stop()
+	if rc := C.acl_check_bulk_v_opts(p.e.h, vi.items, C.size_t(n), &perm[0], &errs[0], opts); rc != 0 {
 		return nil, lastError(rc)
 	}
 	for i := range in.Items {

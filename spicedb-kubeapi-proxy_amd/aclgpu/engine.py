@@ -278,11 +278,16 @@ class Engine:
         views[:, :, 0] = np.where(offs >= 0, buf.ctypes.data + offs, 0).astype(np.uint64)
         return views, n, buf
 
-    def check_bulk_views(self, prepared):
+    def check_bulk_views(self, prepared, cancel=None, timeout_s=None):
+        """acl_check_bulk_v; with `cancel` (a ctypes c_int32 the caller raises) or `timeout_s`: acl_check_bulk_v_opts -- CheckBulkPermissions(ctx, ...)"""
         views, n, _blob = prepared
         perm = np.zeros(max(1, n), dtype=np.uint8)
         err = np.zeros(max(1, n), dtype=np.int32)
-        self._check(self._L.acl_check_bulk_v(self._h, views.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
+        if cancel is None and timeout_s is None:
+            self._check(self._L.acl_check_bulk_v(self._h, views.ctypes.data, n, perm.ctypes.data, err.ctypes.data))
+        else:
+            o = _lib.CallOpts(C.pointer(cancel) if cancel is not None else None, int((timeout_s or 0) * 1e9))
+            self._check(self._L.acl_check_bulk_v_opts(self._h, views.ctypes.data, n, perm.ctypes.data, err.ctypes.data, C.byref(o)))
         return perm[:n], err[:n]
 
     def check_bulk_prepared(self, prepared):

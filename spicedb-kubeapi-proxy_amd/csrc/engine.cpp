@@ -1347,10 +1347,15 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
 
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
 template <class Items>
-static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out) {
+static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o = nullptr) {
     if (!n) return h->store_only ? fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable") : ACL_OK;
+    CallOpts opts;  // (cancellation / deadline: honoured while the call waits for an evaluation context, as in acl_check_bulk_ids_opts)
+    if (o) {
+        opts.cancel = o->cancel;
+        if (o->timeout_ns > 0) opts.deadline_ns = mono_ns() + o->timeout_ns;
+    }
     Eval ev;
-    int rc = ev.begin(h, false);
+    int rc = ev.begin(h, false, opts);
     if (rc) return rc;
     PassCtx *c = ev.c;
     HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
@@ -1972,6 +1977,11 @@ int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uin
 int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v: NULL buffer");
     return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
+}
+
+int acl_check_bulk_v_opts(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts) {
+    if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v_opts: NULL buffer");
+    return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out, opts);
 }
 
 int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps,

@@ -1330,6 +1330,9 @@ struct NoNext {
 #define ACL_LOCAL_WIDE 16  // (A/B builds: 12 waves per block leave room for 84 VGPRs at two blocks per CU)
 #endif
 constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
+#ifndef ACL_SPLIT_UNITS
+#define ACL_SPLIT_UNITS 1  // the wide monotone walk cuts a unit into two HALVES whose levels turn over independently (k_check_local); 0 = one barrier per level (A/B builds)
+#endif
 #ifndef ACL_TAIL_SINGLES
 #define ACL_TAIL_SINGLES 0  // N > 0 (A/B builds): the last 2 N x WAVES segments of a level are claimed one by one instead of in pairs (see the claim loop)
 #endif
@@ -1343,8 +1346,12 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
     // start of L + 2 (every wave has read them by then) and reused at L + 3 -- ONE block barrier per level instead of three
-    __shared__ uint32_t s_cursors[6], s_stop, s_unit;  // (one array: the per-unit reset is ONE store through one address -- two arrays cost a spilled VGPR)
-    uint32_t *const s_fill = s_cursors, *const s_next = s_cursors + 3;
+    // NH = 2 (chip-filling monotone batches): the unit's requests are cut into two halves with cursor sets, frontier regions and arrival counters of
+    // their own, walked by the same waves in alternation -- see the phase loop below
+    constexpr uint32_t NH = (ACL_SPLIT_UNITS && !CMB && WAVES >= 8) ? 2u : 1u;
+    __shared__ uint32_t s_cursors[6 * NH + NH], s_stop, s_unit;  // (one array: the per-unit reset is ONE store through one address -- two arrays cost a spilled VGPR)
+    uint32_t *const s_fill = s_cursors, *const s_next = s_cursors + 3;  // half h: s_fill + 6 h, s_next + 6 h; s_done = s_cursors + 6 NH
+    uint32_t *const s_done = s_cursors + 6 * NH;
     __shared__ uint32_t s_ccount[2];  // CMB: {leaf cells, nodes} of the unit being walked
     constexpr bool E8 = ACL_ENTRY8 && !CMB;  // 8-byte frontier entries (put_entry)
     __shared__ uint2 s_req[E8 ? WAVES * 64 : 1];  // E8: {subject id, subject key} of the unit's requests
@@ -1394,7 +1401,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             first = min(n, u * rpw + ((skew * u * (nunits - u)) >> 8));
             mine = min(n, (u + 1u) * rpw + ((skew * (u + 1u) * (nunits - u - 1u)) >> 8)) - first;
         }
-        if (threadIdx.x < 6) s_cursors[threadIdx.x] = 0;
+        if (threadIdx.x < 6 * NH + NH) s_cursors[threadIdx.x] = 0;
         if (CMB && threadIdx.x < 2) s_ccount[threadIdx.x] = 0;
         __syncthreads();
         // ---- seeds (k_seed's validation), in registers: wave w holds requests [64 w, 64 w + 64) of the unit
@@ -1417,6 +1424,89 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         }
         wo.first = first;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t level_reached = 1;
+        if (NH == 2) {
+            // ---- TWO HALF-UNITS, no block barrier between levels (round 5; VERDICT r4 next #1c).  With one cursor set a level ends at a block
+            // barrier: a wave that finds the claim counter dry waits there for the waves still expanding their last pair -- a fifth of the walk's
+            // wave-time (profiles/r04_phases_final.txt), because a unit's level is only a few dozen segment pairs for 16 waves.  Here the unit's
+            // requests are cut in two (at a multiple of 64: a wave's seeds belong to one half), each half with its own cursors, frontier region
+            // (half of the block's) and an ARRIVAL COUNTER; every wave walks the phases  (half 0, level 2), (half 1, level 2), (half 0, level 3), ...
+            // in that order and, done with its share of a phase, goes straight on to the next one -- which only needs the OTHER half's previous
+            // level complete, long finished as a rule.  A phase is complete when all WAVES waves have arrived at its counter (monotonic: phase
+            // (h, L) needs s_done[h] >= WAVES (L - 2)); the counter is raised behind a workgroup release fence and read before an acquire fence,
+            // the pairing __syncthreads() provided.  Cursor slot (L + 1) % 3 of a half is cleared by every wave that enters (h, L): nobody uses
+            // it between the end of (h, L - 1) -- all waves have arrived there -- and the start of (h, L + 1).
+            const uint32_t split = min(mine, ((mine / 2u + 63u) >> 6) << 6);  // requests [0, split) of the unit are half 0
+            const uint32_t hcap = wo.cold->cap >> 1;                          // entries of a half's region (the same in both buffers)
+            const uint32_t myh = (wib * 64u >= split) ? 1u : 0u;              // the half this wave's seeds belong to
+            const size_t hoff = (size_t)(E8 ? hcap / 2u : hcap);              // ... in uint4 units
+            if (lane == 0) wo.cold->cap = hcap;
+            wo.buf = bufs[0] + myh * hoff;
+            wo.cur = 0;
+            wo.lfill = &s_fill[6 * myh + 1];  // level 1
+            ACL_MARK(wo, PH_SEED);
+            {
+                NoNext nn;
+                co.iter = 1u;
+                process_segment<false, true, CMB>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
+            }
+            if (wo.cur == kNoSpace && lane == 0) s_stop = 1;
+            __syncthreads();  // (the seeds' children are written; from here on the halves' counters order everything)
+            uint32_t lvl[2] = {2u, 2u}, par[2] = {0u, 0u};
+            bool alive[2] = {true, true};
+            for (uint32_t ph = 0; alive[0] || alive[1]; ph++) {
+                const uint32_t h = ph & 1u;
+                if (!alive[h]) continue;
+                const uint32_t level = lvl[h];
+                if (level > kMaxLevels + 1) {
+                    alive[h] = false;
+                    continue;
+                }
+                // ---- every wave has left (h, level - 1): its entries are written, its cursors final
+                const uint32_t target = WAVES * (level - 2u);
+                while (__hip_atomic_load(&s_done[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target && !__hip_atomic_load(&s_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                ACL_MARK(wo, PH_BARRIER);
+                if (__hip_atomic_load(&s_stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // overflow somewhere: the host redoes the batch
+                uint32_t *const fill = s_fill + 6 * h, *const nexts = s_next + 6 * h;
+                const uint32_t cnt = uniform(fill[(level - 1) % 3]);
+                if (lane == 0) {
+                    fill[(level + 1) % 3] = 0;
+                    nexts[(level + 1) % 3] = 0;
+                }
+                if (!cnt) {
+                    alive[h] = false;
+                    continue;
+                }
+                level_reached = max(level_reached, level);
+                wo.lfill = &fill[level % 3];
+                uint32_t *const next_seg = &nexts[level % 3];
+                LocalWalk<E8> lw{bufs[par[h]] + h * hoff, cnt, 0u, lane, false, s_req, first};
+                par[h] ^= 1u;
+                wo.buf = bufs[par[h]] + h * hoff;
+                co.iter = level;
+                const uint32_t nseg = (cnt + 63u) >> 6;
+                for (;;) {
+                    uint32_t sg = 0;
+                    if (lane == 0) sg = atomicAdd(next_seg, 2u);
+                    sg = uniform(sg);
+                    if (sg >= nseg) break;
+                    for (lw.s = sg, lw.second = true; lw.s < sg + 2 && lw.s * 64 < cnt; lw.s++) {
+                        if (lw.s > sg && !lw.second) break;  // the pair's second segment went with the first
+                        const bool v = lw.s * 64 + lane < cnt;
+                        const uint4 en = lw.at(v ? lw.s * 64 + lane : lw.s * 64);  // unconditional; process_segment masks by `v`
+                        if (lw.s > sg) lw.second = false;
+                        process_segment<false, true, CMB>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh, co);
+                    }
+                }
+                if (wo.cur == kNoSpace && lane == 0) s_stop = 1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's entries and answer bytes before its arrival
+                if (lane == 0) __hip_atomic_fetch_add(&s_done[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lvl[h] = level + 1u;
+            }
+            if (lane == 0) wo.cold->cap = hcap << 1;  // (the next unit sets its own geometry from the full region)
+        } else {
         wo.buf = bufs[0];
         wo.cur = 0;
         wo.lfill = &s_fill[1];  // level 1
@@ -1426,7 +1516,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             co.iter = 1u;
             process_segment<false, true, CMB>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
         }
-        uint32_t parity = 0, level_reached = 1;
+        uint32_t parity = 0;
         for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {
             // ---- level boundary: everybody's children are written, the cursors turn over
             if (wo.cur == kNoSpace && lane == 0) s_stop = 1;  // overflow: the host redoes the batch
@@ -1466,6 +1556,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
                     process_segment<false, true, CMB>(en, v, lw, t, wo, lane, g, progs, ops, has, err, nosh, co);
                 }
             }
+        }
         }
         // (statistics: dispatch levels the deepest request of the batch needed.  Test before the atomic: 2 048 blocks ending together on
         //  one address serialise at ~12 ns each -- C2's 18 us kernel took 38 us with an unconditional atomicMax.)

@@ -167,6 +167,13 @@ void check_refs(const Schema &s, const Definition &d, const Member &m, const Nod
             for (const SubjectClass &c : d.members[ts].classes)
                 if (c.wildcard)
                     throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "` has an arrow over `" + n.a + "`, which allows wildcard subjects");
+            // a.all(b) fails CLOSED: a plain arrow skips tupleset subjects whose type has no `b`; an intersection arrow that skipped them
+            // could grant what the real engine denies (its rule there is unverified), so such a schema is refused at load
+            if (n.kind == Node::kArrowAll)
+                for (const SubjectClass &c : d.members[ts].classes)
+                    if (s.defs[c.stype].find(n.b) < 0)
+                        throw std::runtime_error("schema: permission `" + d.name + "#" + m.name + "`: `" + n.a + ".all(" + n.b + ")` over subject type `" + s.defs[c.stype].name +
+                                                 "`, which has no `" + n.b + "`");
             break;
         }
         case Node::kNil: break;

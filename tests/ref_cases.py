@@ -211,6 +211,45 @@ def replay_requests(client, requests):
     return out
 
 
+def racy_checks(case, limit=50):
+    """Indices of the checks whose ERROR-vs-NO split is not a function of the inputs in the real engine: embedded SpiceDB evaluates the operands
+    of a union / intersection / exclusion concurrently and returns on the first DECISIVE result, so when one operand fails (max depth exceeded)
+    while another one decides, which of the two the caller sees is a race (oracle/acl_oracle.c header; the restatements fix ONE order).  Errors
+    only come from the depth limit, so the tag is structural and conservative: a check is racy when its resource can reach -- along ANY
+    relationship, resource -> subject object -- an object that lies on a cycle or heads a chain of `limit - 5` or more hops.  For exactly these
+    tests/test_ref_fixtures.compare accepts either kind of DENY; the allow / deny bit stays pinned for every check."""
+    import sys
+    succ = {}
+    for rt, rid, _rel, st, sid, _srel in case["relationships"]:
+        succ.setdefault((rt, rid), set()).add((st, sid))
+        succ.setdefault((st, sid), set())
+    # longest path from every node, cycles = infinite (iterative DFS with colours)
+    depth, state = {}, {}
+    sys.setrecursionlimit(max(sys.getrecursionlimit(), 10000))
+    for root in succ:
+        if root in state:
+            continue
+        stack = [(root, iter(succ[root]))]
+        state[root] = 1
+        while stack:
+            node, it = stack[-1]
+            nxt = next(it, None)
+            if nxt is None:
+                state[node] = 2
+                depth[node] = max([0] + [1 + depth[c] for c in succ[node]]) if depth.get(node) != float("inf") else float("inf")
+                if any(depth[c] == float("inf") for c in succ[node]):
+                    depth[node] = float("inf")
+                stack.pop()
+            elif state.get(nxt) == 1:  # back edge: everything on the stack from nxt on lies on a cycle
+                for n_, _ in stack[[x for x, _ in stack].index(nxt):]:
+                    depth[n_] = float("inf")
+            elif nxt not in state:
+                state[nxt] = 1
+                stack.append((nxt, iter(succ[nxt])))
+    tainted = {n for n, d in depth.items() if d >= limit - 5}
+    return {i for i, q in enumerate(case["checks"]) if (q[0], q[1]) in tainted}
+
+
 def cases():
     import sys
     pkg = os.path.join(os.path.dirname(HERE), "spicedb-kubeapi-proxy_amd")

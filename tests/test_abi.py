@@ -239,6 +239,183 @@ def test_docs_and_go_shim_name_only_declared_entry_points():
         assert not missing, (f, missing)
 
 
+def _c_prototypes(text):
+    """name -> list of parameter declarations, for every `... acl_x(...)` prototype / inline definition in C source text (comments stripped)"""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(acl_[a-z0-9_]+)\s*\(", text):
+        # a prototype / definition: the identifier is preceded by a type (`int `, `*`), not by `return`, `=`, `(`, `,` (those are calls)
+        before = text[:m.start()].rstrip()
+        if not before or before.endswith(("return", "=", "(", ",", "?", ":")) or before[-1] in "{;" and False:
+            continue
+        if not re.search(r"(\b(int|void|char|uint64_t|uint32_t|size_t|acl_engine_t|const)\b|\*)\s*$", before):
+            continue
+        depth, i = 1, m.end()
+        while depth and i < len(text):
+            depth += text[i] == "("
+            depth -= text[i] == ")"
+            i += 1
+        params = _split_top(text[m.end():i - 1])
+        protos.setdefault(m.group(1), [p for p in params if p and p != "void"])
+    return protos
+
+
+def _split_top(argtext):
+    """split at top-level commas (parentheses, brackets and braces nest; Go / C string and rune literals are skipped)"""
+    out, depth, cur, i = [], 0, "", 0
+    while i < len(argtext):
+        ch = argtext[i]
+        if ch in "\"`'":
+            j = i + 1
+            while j < len(argtext) and argtext[j] != ch:
+                j += 2 if argtext[j] == "\\" and ch != "`" else 1
+            cur += argtext[i:j + 1]
+            i = j + 1
+            continue
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+        i += 1
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _go_calls(src, pattern):
+    """(name, [args]) for every `C.<name>(` / `C.<name>{` in Go source (comments stripped): balanced-bracket argument lists"""
+    import re
+    src = re.sub(r"//[^\n]*", "", src)
+    opener, closer = pattern[-1], {"(": ")", "{": "}"}[pattern[-1]]
+    for m in re.finditer(r"\bC\.(acl_[a-z0-9_]+)" + re.escape(opener), src):
+        depth, i = 1, m.end()
+        while depth and i < len(src):
+            depth += src[i] == opener
+            depth -= src[i] == closer
+            i += 1
+        yield m.group(1), _split_top(src[m.end():i - 1]), src.count("\n", 0, m.start()) + 1
+
+
+def test_go_shim_calls_match_the_header(tmp_path):
+    """the Go shim has never met a compiler (no Go toolchain in this image), so the text is checked against include/aclgpu.h --
+    for every `C.acl_*(...)` call the ARGUMENT COUNT equals the prototype's parameter count (shim.h's two trampolines included, and the calls
+    inside them); for every `C.acl_*_t{...}` literal and every `x.field` use of a variable of such a type, the FIELD NAMES exist in the struct;
+    every `//export`ed callback has the parameter list of the typedef it is cast to; and the check itself fails when an argument is dropped."""
+    import glob
+    import re
+    root = os.path.dirname(HERE)
+    shim_dir = os.path.join(root, "shim", "go", "aclgpu")
+    hdr = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    protos = _c_prototypes(hdr)
+    shim_h = open(os.path.join(shim_dir, "shim.h")).read()
+    protos.update({k: v for k, v in _c_prototypes(shim_h).items() if k.endswith("_go")})
+    assert len(protos) >= 85 and len(protos["acl_check_bulk_v_opts"]) == 6 and protos["acl_close"] and len(protos["acl_watch_poll_go"]) == 6
+    # struct fields of the header: typedef struct { ... } name;
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct(?:\s+\w+)?\s*\{(.*?)\}\s*(acl_[a-z0-9_]+_t)\s*;", hdr, flags=re.S):
+        fields = []
+        for decl in m.group(1).split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            fp = re.search(r"\(\s*\*\s*(\w+)\s*\)\s*\(", decl)  # function-pointer member
+            if fp:
+                fields.append(fp.group(1))
+                continue
+            for part in decl.split(","):
+                name = re.sub(r"\[.*?\]", "", part).strip().split()[-1].lstrip("*")
+                fields.append(name)
+        structs[m.group(2)] = fields
+    assert "cancel" in structs["acl_call_opts_t"] and "frontier_entries" in structs["acl_config_t"] and len(structs) >= 10
+
+    def check_sources(sources):
+        problems, ncalls, nlits, nfields = [], 0, 0, 0
+        for fname, src in sources.items():
+            for name, args, line in _go_calls(src, "C.x("):
+                if name.endswith("_t") or name.endswith("_cb"):
+                    continue  # a conversion C.acl_x_t(...), not a call
+                ncalls += 1
+                if name not in protos:
+                    problems.append(f"{fname}:{line}: C.{name} is not declared")
+                elif len(args) != len(protos[name]):
+                    problems.append(f"{fname}:{line}: C.{name} called with {len(args)} argument(s), the prototype has {len(protos[name])}")
+            for name, args, line in _go_calls(src, "C.x{"):
+                nlits += 1
+                if name not in structs:
+                    problems.append(f"{fname}:{line}: C.{name} is not a struct of the header")
+                    continue
+                for a in args:
+                    f = a.split(":", 1)[0].strip()
+                    if ":" in a and f not in structs[name]:
+                        problems.append(f"{fname}:{line}: C.{name} has no field `{f}`")
+            # x := C.acl_T{...} / (*C.acl_T)(...) / var x C.acl_T / (x *C.acl_T): every later `x.field` inside the same func names a field of T
+            for body in re.split(r"\nfunc ", re.sub(r"//[^\n]*", "", src)):
+                typed = {}
+                for m in re.finditer(r"\b(\w+)\s*:?=\s*&?\(?\*?C\.(acl_[a-z0-9_]+_t)\b", body):
+                    typed[m.group(1)] = m.group(2)
+                for m in re.finditer(r"\b(\w+)\s+\*?C\.(acl_[a-z0-9_]+_t)\b", body):
+                    typed.setdefault(m.group(1), m.group(2))
+                for var, t in typed.items():
+                    if t not in structs or var in ("var", "return"):
+                        continue
+                    for m in re.finditer(r"(?<![\w.])" + re.escape(var) + r"\.(\w+)", body):
+                        nfields += 1
+                        if m.group(1) not in structs[t]:
+                            problems.append(f"{fname}: `{var}.{m.group(1)}`: {t} has no such field")
+        return problems, ncalls, nlits, nfields
+
+    sources = {os.path.basename(f): open(f).read() for f in glob.glob(os.path.join(shim_dir, "*.go"))}
+    problems, ncalls, nlits, nfields = check_sources(sources)
+    assert not problems, "\n".join(problems)
+    assert ncalls >= 30 and nlits >= 5 and nfields >= 10, (ncalls, nlits, nfields)
+    # the trampolines' own calls (shim.h: C calling C)
+    inner = re.sub(r"/\*.*?\*/", " ", shim_h, flags=re.S)
+    for m in re.finditer(r"return\s+(acl_[a-z0-9_]+)\s*\(", inner):
+        depth, i = 1, m.end()
+        while depth:
+            depth += inner[i] == "("
+            depth -= inner[i] == ")"
+            i += 1
+        assert len(_split_top(inner[m.end():i - 1])) == len(protos[m.group(1)]), m.group(1)
+    # exported callbacks: parameter list == the typedef's (cgo types: void* -> unsafe.Pointer, T -> C.T, const S* -> *C.S)
+    cb = {m.group(1): _split_top(m.group(2)) for m in re.finditer(r"typedef\s+void\s*\(\s*\*\s*(acl_[a-z0-9_]+_cb)\s*\)\s*\((.*?)\)\s*;", hdr, flags=re.S)}
+
+    def go_type(cdecl):
+        t = re.sub(r"\b(const)\b", "", cdecl).strip()
+        t = re.sub(r"\s*\w+$", "", t).strip() if not t.endswith("*") else t  # drop the parameter name
+        if re.fullmatch(r"void\s*\*", t):
+            return "unsafe.Pointer"
+        return ("*" if t.endswith("*") else "") + "C." + t.rstrip("*").strip()
+
+    casts = dict(re.findall(r"\((acl_[a-z0-9_]+_cb)\)\s*(go\w+)", shim_h))  # (acl_read_cb)goReadCallback
+    assert set(casts.values()) == {"goReadCallback", "goWatchCallback"}
+    cbsrc = sources["callbacks.go"]
+    for cbt, gofn in casts.items():
+        m = re.search(r"//export " + gofn + r"\nfunc " + gofn + r"\((.*?)\)\s*\{", cbsrc)
+        assert m, gofn
+        got = [p.split(None, 1)[1].strip() for p in _split_top(m.group(1))]
+        want = [go_type(p) for p in cb[cbt]]
+        assert got == want, (gofn, got, want)
+        ext = re.search(r"extern\s+void\s+" + gofn + r"\s*\((.*?)\)\s*;", shim_h)
+        assert ext and len(_split_top(ext.group(1))) == len(cb[cbt]), gofn
+    # ... and the check has teeth: drop one argument from a call, rename one field -> both are reported
+    broken = dict(sources)
+    pc = broken["permissions_client.go"]
+    assert "&perm[0], &errs[0], opts)" in pc
+    broken["permissions_client.go"] = pc.replace("&perm[0], &errs[0], opts)", "&perm[0], &errs[0])", 1)
+    eg = broken["engine.go"]
+    assert "C.acl_config_t{device:" in eg
+    broken["engine.go"] = eg.replace("C.acl_config_t{device:", "C.acl_config_t{dev:", 1)
+    bad, _a, _b, _c = check_sources(broken)
+    assert any("acl_check_bulk_v_opts called with 5" in b for b in bad) and any("no field `dev`" in b for b in bad), bad
+
+
 def test_gpu_scheme_patch_names_what_the_shim_defines():
     """shim/patches/options_gpu_scheme.patch (the `--spicedb-endpoint gpu://` branch next to pkg/proxy/options.go:313-321): every `aclgpu.X` it
     calls is a func / type the shim sources define, its hunks apply to the reference checkout where one is present, and the C entry points

@@ -106,6 +106,7 @@ def test_wildcard_relationships_in_the_store(aclgpu_lib):
     "caveat c(x int) { x > 1 }\ndefinition u {}",
     "definition u {}\ndefinition a { relation r: u with c }",
     "definition u {}\ndefinition a { relation r: a\n permission p = r.some(p) }",  # (only .any() and .all() are arrow functions)
+    "definition u {}\ndefinition b {}\ndefinition a { relation r: a | b\n relation v: u\n permission p = v + r.all(p) }",  # .all() over a subject type without the permission: refused (fails closed)
     "definition a { relation r: nosuch }",
     "definition u {}\ndefinition a { relation r: u\n permission p = nosuch }",
     "definition u {}\ndefinition u {}",
