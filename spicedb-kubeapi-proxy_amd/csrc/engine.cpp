@@ -401,6 +401,7 @@ int ensure_snapshot(acl_engine *h) {
     refresh_local_blocks(h);
     std::lock_guard<std::mutex> lk(h->stats_mu);
     h->stats.snapshot_builds++;
+    h->walk_no_direct.store(false, std::memory_order_relaxed);  // (a new snapshot: the direct task lists get another chance)
     h->stats.snapshot_edges = h->snap.nedges;
     h->stats.snapshot_edges_local = h->snap.nedges_local;
     h->stats.snapshot_bytes = h->snap.meta.size() * 4 + h->snap.edges.size() * 4 + h->snap.buckets.size() * 4 + h->snap.ops.size() * sizeof(FwdOp) + h->snap.progs.size() * sizeof(SlotProg);
@@ -636,10 +637,13 @@ static int local_enqueue(acl_engine *h, PassCtx *c, const DevGraph &g0, const ui
     return ACL_OK;
 }
 static int local_finish(acl_engine *h, PassCtx *c, uint32_t n) {
-    (void)h;
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
+    if (c->h_status[0] == kOverflowDirect) {
+        h->walk_no_direct.store(true, std::memory_order_relaxed);
+        h->direct_tripped.store(true, std::memory_order_relaxed);
+    }
     if (c->h_status[0]) return kTakeLevelLoop;
     c->stats.levels_last = c->h_status[2];
     c->stats.check_items += n;
@@ -741,6 +745,11 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     for (uint32_t k = 0; k < npass; k++)
         if (flag[k] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     for (uint32_t k = 0; k < npass; k++)
+        if (flag[k] == kOverflowDirect) {
+            h->walk_no_direct.store(true, std::memory_order_relaxed);
+            h->direct_tripped.store(true, std::memory_order_relaxed);
+        }
+    for (uint32_t k = 0; k < npass; k++)
         if (flag[k]) return kTakeLevelLoop;
     if (!pin_p) std::memcpy(perm_out, h_perm, n);
     if (err_out && !pin_e) std::memcpy(err_out, h_err, (size_t)n * sizeof(int32_t));
@@ -765,6 +774,7 @@ static bool walk_allowed(acl_engine *h, size_t n) {
 }
 static void walk_outcome(acl_engine *h, size_t n, int rc) {
     if (n < kComputeTokenItems) return;
+    if (rc == kTakeLevelLoop && h->direct_tripped.exchange(false, std::memory_order_relaxed)) return;  // (not a frontier overflow: the next walk simply builds its task lists the general way)
     if (rc == kTakeLevelLoop) h->local_skip.store(1 << std::min(6, 1 + h->local_fail_streak.fetch_add(1, std::memory_order_relaxed)), std::memory_order_relaxed);
     else if (!rc) h->local_fail_streak.store(0, std::memory_order_relaxed);
 }

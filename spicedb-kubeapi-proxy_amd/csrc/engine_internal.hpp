@@ -349,6 +349,9 @@ struct acl_engine {
         for (auto &d : devs) d->rev_uploaded = v;
     }
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
+    // the single-launch walk met rows too long for its direct task lists on this snapshot (kOverflowDirect): later walks build their lists the general
+    // way (reset when a snapshot is rebuilt); direct_tripped: that batch's redo is not a frontier overflow -- no back-off for it (walk_outcome)
+    std::atomic<bool> walk_no_direct{false}, direct_tripped{false};
     std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
     bool raw_intern = false;       // test knob (ACL_RAW_INTERN): acl_intern skips the API's object-id pattern
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
@@ -412,7 +415,9 @@ struct acl_engine {
 
 
     DevGraph dev_graph(const DevState &d) const {
-        return DevGraph{d.d_meta.p, d.d_edges.p, d.d_buckets.p, d.d_ops.p, d.d_progs.p, d.d_tsb.p, d.d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
+        DevGraph g{d.d_meta.p, d.d_edges.p, d.d_buckets.p, d.d_ops.p, d.d_progs.p, d.d_tsb.p, d.d_tnm.p, snap.nslots, snap.ntypes, (uint32_t)snap.ops.size()};
+        g.walk_flags = walk_no_direct.load(std::memory_order_relaxed) ? kWalkNoDirect : 0u;
+        return g;
     }
     DevGraph dev_graph(const PassCtx *c) const { return dev_graph(*c->dev); }
     DevReverse dev_reverse(const PassCtx *c, uint32_t vwords) const {

@@ -400,6 +400,9 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
                             // by this step's hits -- or by another wave a moment ago -- needs none of them, and an entry not written is not read
                             // back and frees a lane of a segment of the next level (C4 253 -> 238 us; profiles/r04_push_recheck_ab.txt); 0 = A/B builds
 #endif
+#ifndef ACL_DIRECT_TASKS
+#define ACL_DIRECT_TASKS 1  // the deep levels' segments build their task list with the prefix sums taken in registers (process_segment); 0 = through flush_tasks (A/B builds)
+#endif
 #ifndef ACL_SIMPLE_WIDTH
 #define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
 #endif
@@ -420,6 +423,109 @@ constexpr int kEdgesAhead = ACL_EDGES_AHEAD;    // children per lane whose edges
 //     (LDS atomic or) at their first work item; a lane's task is then `tasks before this 64-item window` + the head bits at or
 //     below its lane (two v_mbcnt) -- the 6-step binary search over the LDS prefix array cost ~30 VALU + 6 LDS reads per child;
 //   - one output reservation per step for the W x 64 children, not one per 64.
+// The steps of the simple expansion: the wave's task list holds T tasks whose children are `total` work items, t.a[j].x = first edge minus first work
+// item, t.heads = one bit per task at its first work item (set by the caller's prologue).  UM: every child carries the same meta `umeta` and the
+// entries are 8-byte ones (no per-task meta / subject id reads at the push).
+template <bool LOCAL, bool E8, bool UM>
+__device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t total, WaveOut &wo, uint32_t lane, const uint32_t *__restrict__ edges, const uint4 *__restrict__ buckets,
+                                             uint8_t *has, uint8_t *err, uint32_t umeta) {
+    constexpr int W = kSimpleWidth;
+    uint32_t before = 0;  // tasks that start before the current 64-item window
+    ACL_MARK(wo, PH_PROLOGUE);
+    // A step = kEdgesAhead windows of 64 children: their edges go out in one trip (one VGPR each), then the buckets follow W windows
+    // at a time (8 VGPRs per child).
+    constexpr int E = kEdgesAhead;
+    static_assert(E % W == 0, "the bucket stage walks the fetched windows W at a time");
+    for (uint32_t w0 = 0; w0 < total; w0 += 64 * E) {
+        bool valid[E];
+        uint32_t tj[E], edge[E];
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const uint32_t win = (w0 >> 6) + (uint32_t)k;
+            const uint64_t hw = win < kHeadWords ? t.heads[win] : 0ull;
+            const uint32_t hlo = uniform((uint32_t)hw), hhi = uniform((uint32_t)(hw >> 32));
+            const uint32_t w = w0 + 64u * k + lane;
+            valid[k] = w < total;
+            const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
+            // tasks starting at or before this lane's work item, minus one (beyond `total` there are no head bits: the last task)
+            const uint32_t j = before + __builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, 0u)) + (uint32_t)((hw >> lane) & 1ull) - 1u;
+            before += (uint32_t)__popc(hlo) + (uint32_t)__popc(hhi);
+            tj[k] = j;
+            edge[k] = gld(edges, t.a[j].x + wv);
+        }
+        issue_fence();  // trip 1: every edge of the step
+        ACL_MARK(wo, PH_EDGES);
+#pragma unroll
+        for (int k0 = 0; k0 < E; k0 += W) {
+            if (w0 + 64u * k0 >= total) break;  // (uniform)
+            uint4 p[W];
+            uint32_t rq[W];
+            bool two = false;
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, the row's y (buckets | two-choice | seed), request} in one 16-byte read
+                rq[k] = ta.w;
+                p[k] = gld(buckets, ta.y + hrow_bucket(edge[k0 + k] & kIdMask, ta.z));
+                two = two | ((ta.z & kRowTwoBit) != 0u);
+            }
+            issue_fence();  // trip 2: the W buckets
+            ACL_MARK(wo, PH_BUCKETS);
+            bool hit[W], push[W];
+            uint64_t pb[W];
+            uint32_t pre[W], np = 0;
+#pragma unroll
+            for (int k = 0; k < W; k++) hit[k] = valid[k0 + k] & bucket_has(p[k], edge[k0 + k] & kIdMask);
+            if (__ballot(two)) {  // (rare: a child whose request's subject has a two-choice row -- its second bucket, one child at a time)
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    const uint4 ta = t.a[tj[k0 + k]];
+                    if (ta.z & kRowTwoBit) {
+                        const uint32_t cid = edge[k0 + k] & kIdMask;
+                        const uint4 q = gld(buckets, ta.y + hrow_bucket2(cid, ta.z, hrow_bucket(cid, ta.z)));
+                        hit[k] = hit[k] | (valid[k0 + k] & bucket_has(q, cid));
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
+                //  loads at the end of every step; depth limits were checked per task above)
+                push[k] = valid[k0 + k] & !hit[k] & ((edge[k0 + k] & kLeafBit) == 0u);
+            }
+            // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
+            // (vmcnt counts stores too, and the compiler must assume the store was not issued)
+#pragma unroll
+            for (int k = 0; k < W; k++)
+                if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], wo.first, 1);
+#if ACL_PUSH_RECHECK
+            if (E8 && ACL_ANS_LDS) {
+                // a request answered by THIS step's hits (or by another wave a moment ago) needs none of its other children any more: looked at
+                // once more before they are written -- an entry not written is not read back, and frees a lane of a segment of the next level
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < W; k++) push[k] = push[k] & (ans_get<true>(has, rq[k], wo.first) == 0u);
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                pb[k] = __ballot(push[k]);
+                pre[k] = np;
+                np += (uint32_t)__popcll(pb[k]);
+            }
+            if (np) {
+                const uint32_t base = reserve<LOCAL>(wo, np, lane);
+                if (base != kNoSpace) {
+#pragma unroll
+                    for (int k = 0; k < W; k++)
+                        if (push[k])
+                            put_entry<E8>(wo, base + pre[k] + lanes_below(pb[k]), edge[k0 + k] & kIdMask, rq[k], (UM ? umeta : t.meta[tj[k0 + k]]) | kProbedBit, UM ? 0u : t.sid[tj[k0 + k]]);
+                }
+            }
+            ACL_MARK(wo, PH_PUSH);
+        }
+    }
+}
+
 template <bool SHARDED, bool LOCAL, bool DESC, bool E8>
 __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
                                                   uint8_t *has, uint8_t *err) {
@@ -455,108 +561,15 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
                 }
             }
         }
-        if (lane < kHeadWords) t.heads[lane] = 0ull;
+        // (t.heads is all zero here: zeroed at kernel start and behind every expansion)
         // first edge of the task minus its first work item: edge index = this + work item
         if (mine0) t.a[lane].x -= excl0;
         if (mine1) t.a[64u + lane].x -= excl1;
-        wave_lds_fence();
         if (mine0) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl0 >> 6]), 1ull << (excl0 & 63u));
         if (mine1) atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[excl1 >> 6]), 1ull << (excl1 & 63u));
         wave_lds_fence();
-        uint32_t before = 0;  // tasks that start before the current 64-item window
-        ACL_MARK(wo, PH_PROLOGUE);
-        // A step = kEdgesAhead windows of 64 children: their edges go out in one trip (one VGPR each), then the buckets follow W windows
-        // at a time (8 VGPRs per child).
-        constexpr int E = kEdgesAhead;
-        static_assert(E % W == 0, "the bucket stage walks the fetched windows W at a time");
-        for (uint32_t w0 = 0; w0 < total; w0 += 64 * E) {
-            bool valid[E];
-            uint32_t tj[E], edge[E];
-#pragma unroll
-            for (int k = 0; k < E; k++) {
-                const uint32_t win = (w0 >> 6) + (uint32_t)k;
-                const uint64_t hw = win < kHeadWords ? t.heads[win] : 0ull;
-                const uint32_t hlo = uniform((uint32_t)hw), hhi = uniform((uint32_t)(hw >> 32));
-                const uint32_t w = w0 + 64u * k + lane;
-                valid[k] = w < total;
-                const uint32_t wv = valid[k] ? w : total - 1;  // inactive lanes shadow the last child: every load stays in range
-                // tasks starting at or before this lane's work item, minus one (beyond `total` there are no head bits: the last task)
-                const uint32_t j = before + __builtin_amdgcn_mbcnt_hi(hhi, __builtin_amdgcn_mbcnt_lo(hlo, 0u)) + (uint32_t)((hw >> lane) & 1ull) - 1u;
-                before += (uint32_t)__popc(hlo) + (uint32_t)__popc(hhi);
-                tj[k] = gq + j;
-                edge[k] = gld(edges, t.a[j].x + wv);
-            }
-            issue_fence();  // trip 1: every edge of the step
-            ACL_MARK(wo, PH_EDGES);
-#pragma unroll
-            for (int k0 = 0; k0 < E; k0 += W) {
-                if (w0 + 64u * k0 >= total) break;  // (uniform)
-                uint4 p[W];
-                uint32_t rq[W];
-                bool two = false;
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    const uint4 ta = t.a[tj[k0 + k]];  // the child's task: {edge base, first bucket, the row's y (buckets | two-choice | seed), request} in one 16-byte read
-                    rq[k] = ta.w;
-                    p[k] = gld(buckets, ta.y + hrow_bucket(edge[k0 + k] & kIdMask, ta.z));
-                    two = two | ((ta.z & kRowTwoBit) != 0u);
-                }
-                issue_fence();  // trip 2: the W buckets
-                ACL_MARK(wo, PH_BUCKETS);
-                bool hit[W], push[W];
-                uint64_t pb[W];
-                uint32_t pre[W], np = 0;
-#pragma unroll
-                for (int k = 0; k < W; k++) hit[k] = valid[k0 + k] & bucket_has(p[k], edge[k0 + k] & kIdMask);
-                if (__ballot(two)) {  // (rare: a child whose request's subject has a two-choice row -- its second bucket, one child at a time)
-#pragma unroll
-                    for (int k = 0; k < W; k++) {
-                        const uint4 ta = t.a[tj[k0 + k]];
-                        if (ta.z & kRowTwoBit) {
-                            const uint32_t cid = edge[k0 + k] & kIdMask;
-                            const uint4 q = gld(buckets, ta.y + hrow_bucket2(cid, ta.z, hrow_bucket(cid, ta.z)));
-                            hit[k] = hit[k] | (valid[k0 + k] & bucket_has(q, cid));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    // (bitwise, not &&: a short-circuit puts the compare under a branch, and the compiler then waits for "maybe still pending"
-                    //  loads at the end of every step; depth limits were checked per task above)
-                    push[k] = valid[k0 + k] & !hit[k] & ((edge[k0 + k] & kLeafBit) == 0u);
-                }
-                // stores only after the last compare: a conditional store between two compares makes the second one's wait cover it
-                // (vmcnt counts stores too, and the compiler must assume the store was not issued)
-#pragma unroll
-                for (int k = 0; k < W; k++)
-                    if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], wo.first, 1);
-#if ACL_PUSH_RECHECK
-                if (E8 && ACL_ANS_LDS) {
-                    // a request answered by THIS step's hits (or by another wave a moment ago) needs none of its other children any more: looked at
-                    // once more before they are written -- an entry not written is not read back, and frees a lane of a segment of the next level
-                    wave_lds_fence();
-#pragma unroll
-                    for (int k = 0; k < W; k++) push[k] = push[k] & (ans_get<true>(has, rq[k], wo.first) == 0u);
-                }
-#endif
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    pb[k] = __ballot(push[k]);
-                    pre[k] = np;
-                    np += (uint32_t)__popcll(pb[k]);
-                }
-                if (np) {
-                    const uint32_t base = reserve<LOCAL>(wo, np, lane);
-                    if (base != kNoSpace) {
-#pragma unroll
-                        for (int k = 0; k < W; k++)
-                            if (push[k])
-                                put_entry<E8>(wo, base + pre[k] + lanes_below(pb[k]), edge[k0 + k] & kIdMask, rq[k], t.meta[tj[k0 + k]] | kProbedBit, t.sid[tj[k0 + k]]);
-                    }
-                }
-                ACL_MARK(wo, PH_PUSH);
-            }
-        }
+        simple_steps<LOCAL, E8, false>(t, total, wo, lane, edges, buckets, has, err, 0u);
+        if (lane < kHeadWords) t.heads[lane] = 0ull;  // (left zero for the next expansion: one LDS round trip less in its prologue)
         wave_lds_fence();
     }
     return skipped;
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(256) void k_rev_seed(DevFrontier f, const uint32_t 
 // come from the wave's private region).  `next` lets the simple-parent fast path pull the following segment in early:
 //   bool peek(uint4 &e, bool &valid)  loads the next segment's entries if there is one (not consumed yet)
 //   void take()                       consumes it
-template <bool SHARDED, bool LOCAL, bool CMB, typename Next>
+template <bool SHARDED, bool LOCAL, bool CMB, typename Next, bool SEEDS = false /* the entries are a batch's seeds: never probed, so never "simple parents" -- the fast path is not compiled in */>
 __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next &next, TaskLds &t, WaveOut &wo, uint32_t lane, const DevGraph &g,
                                                 const SlotProg *progs, const FwdOp *ops, uint8_t *has, uint8_t *err, const DevShard &sh,
                                                 const CombineOut &co = CombineOut()) {
@@ -904,9 +917,9 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
     // and the wave's next one (B) at once.  The slots may differ from lane to lane (level 2 of a pod check holds `namespace#view`
     // and `group#member` states side by side): each lane reads ITS program from the LDS copy; a segment of one slot (the deep
     // levels) reads it once, through the scalar path.
-    {
+    if (!__ballot(valid)) return;
+    if (!SEEDS) {
         const uint64_t vb = __ballot(valid);
-        if (!vb) return;
         // B is loaded right behind A: their entries arrive in one trip
         bool validB = false;
         uint4 eB = make_uint4(0, 0, kDeadMeta, 0);
@@ -916,6 +929,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         struct LaneOp {  // the lane's one remaining op + what its tasks need to know about the child state
             uint32_t flags, dlevel, base, nrows, Kk, key, maxd;  // Kk = K | k << 16
             uint32_t cbase, cnrows, ckey;                        // child's hashed probe (cnrows == 0: the child is not "one hashed probe")
+            uint32_t cdl, cmaxd;                                 // ... its dispatch-depth offset and the child program's deepest inlined state
         };
         auto lane_op = [&](uint32_t m, LaneOp &L) -> bool {  // false: not a simple parent
             if (m == kDeadMeta || !(m & kProbedBit) || meta_key(m) < g.nslots) return false;
@@ -925,10 +939,10 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
             if (!(o.flags & OP_ENUM) || (o.flags & (OP_PUSH_SAME | OP_REFLEX | OP_PROBE_HASH))) return false;
             L.flags = o.flags; L.dlevel = o.dlevel; L.base = o.base; L.nrows = o.nrows; L.Kk = o.K | (o.k << 16); L.key = o.key; L.maxd = sp.max_dlevel;
             const SlotProg cp = progs[o.key];
-            L.cbase = 0; L.cnrows = 0; L.ckey = 0;
+            L.cbase = 0; L.cnrows = 0; L.ckey = 0; L.cdl = 0; L.cmaxd = cp.max_dlevel;
             if (cp.n_probe == 1) {
                 const FwdOp co = ops[cp.first];
-                if (co.flags == OP_PROBE_HASH) { L.cbase = co.base; L.cnrows = co.nrows; L.ckey = co.key; }
+                if (co.flags == OP_PROBE_HASH) { L.cbase = co.base; L.cnrows = co.nrows; L.ckey = co.key; L.cdl = co.dlevel; }
             }
             return true;
         };
@@ -938,7 +952,75 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
         const uint64_t vbB = haveB ? __ballot(validB) : 0ull;
         const bool oneslot = !__ballot(valid && meta != m0) && !(vbB && __ballot(validB && eB.z != m0));  // (same slot, level, key: the deep levels)
         if (oneslot) {
-            simple = lane_op(m0, LA);  // wave-uniform argument: scalar loads
+#if ACL_DIRECT_TASKS
+            // ---- the deep levels' shape, without the task list's round trips (round 5): ONE slot, level and subject key for both segments, children
+            // that are "one hashed probe + authoritative leaf flags" (what flush_simple takes).  Decided and run HERE, while the program's fields are
+            // still scalars.  The lane that creates a task already holds its degree, so the prefix sums run over the creating lanes' registers
+            // (compaction keeps the order: the prefix over lanes IS the prefix over tasks), each lane writes its task with the edge base already
+            // rebased and sets its head bit itself, and every child carries the same meta: no count / meta / subject-id stores, no read-back of the
+            // counts, no read-modify-write of the edge bases -- the prologue's chain of dependent LDS trips (14 % of the walk's wave-time,
+            // profiles/r05_ab_split_units.txt) shrinks to one fence.
+            LaneOp LD{};  // (a copy of its own: nothing of it is live behind this block, so the general path's LA / LB are not carried -- spilled -- across it)
+            if (E8 && !(g.walk_flags & kWalkNoDirect) && lane_op(m0, LD)) {
+                // (the program's fields come out of the LDS copy in VGPRs, uniform or not: pinned into SGPRs here -- a dozen VGPRs held across the
+                //  gathers otherwise, and the walk runs at exactly 64)
+                const uint32_t lv = meta_level(m0), Lv = lv + uniform(LD.dlevel);
+                const uint32_t d_cnrows = uniform(LD.cnrows), d_cbase = uniform(LD.cbase), d_base = uniform(LD.base), d_nrows = uniform(LD.nrows), d_Kk = uniform(LD.Kk), d_key = uniform(LD.key);
+                if (d_cnrows != 0u && uniform(LD.ckey) == meta_key(m0) && (uniform(LD.flags) & OP_LEAFBIT) != 0u && Lv + 1u <= kMaxLevels && Lv + 1u + uniform(LD.cdl) <= kMaxLevels &&
+                    Lv + 1u + uniform(LD.cmaxd) <= kMaxLevels && lv + uniform(LD.maxd) <= kMaxLevels) {
+                    const bool dpair = vbB != 0;
+                    if (dpair) next.take();
+                    const uint2 *__restrict__ dmeta2 = reinterpret_cast<const uint2 *>(g.meta);
+                    const uint32_t rK = d_Kk & 0xFFFFu, rk = d_Kk >> 16;
+                    const bool vB = dpair && validB;
+                    // all six gathers in flight together
+                    const uint32_t hvA = ans_get<true>(has, valid ? req : wo.first, wo.first), hvB = ans_get<true>(has, vB ? eB.y : wo.first, wo.first);
+                    const bool inA = valid && id < d_nrows, inB = vB && eB.x < d_nrows;
+                    const uint2 mdA = gld(dmeta2, d_base + (inA ? id * rK + rk : 0u)), mdB = gld(dmeta2, d_base + (inB ? eB.x * rK + rk : 0u));
+                    const bool okA = valid && e.w < d_cnrows, okB = vB && eB.w < d_cnrows;
+                    uint2 sdA = gld(dmeta2, d_cbase + (okA ? e.w : 0u)), sdB = gld(dmeta2, d_cbase + (okB ? eB.w : 0u));
+                    issue_fence();
+                    ACL_MARK(wo, PH_GATHERS);
+                    if (!(okA && sdA.y != 0u)) sdA = make_uint2(0u, 1u);  // no row: the reserved empty bucket
+                    if (!(okB && sdB.y != 0u)) sdB = make_uint2(0u, 1u);
+                    const uint32_t degA = (valid && !hvA && inA && mdA.y > mdA.x) ? mdA.y - mdA.x : 0u;
+                    const uint32_t degB = (vB && !hvB && inB && mdB.y > mdB.x) ? mdB.y - mdB.x : 0u;
+                    const uint32_t inclA = wave_incl_scan(degA, lane), totA = wave_last(inclA);
+                    const uint32_t inclB = wave_incl_scan(degB, lane) + totA, total = wave_last(inclB);
+                    if (total > 64u * kHeadWords || __ballot(degA > kMaxRow || degB > kMaxRow)) {
+                        // more children than the head-bit window maps (an average fan-out beyond 16), or a row beyond the enumeration limit: this form has
+                        // no second round (one would have to keep the pair's registers across the steps -- the walk runs at exactly 64 VGPRs).  The batch is
+                        // redone on the level loop and the host switches the form off for this snapshot (kOverflowDirect; a row beyond kMaxRow fails
+                        // the call as it does on every path).
+                        if (lane == 0) *wo.cold->overflow = __ballot(degA > kMaxRow || degB > kMaxRow) ? 2u : kOverflowDirect;
+                        wo.cur = kNoSpace;
+                        return;
+                    }
+                    {
+                        if (!total) return;
+                        const uint64_t bA = __ballot(degA != 0u), bB = __ballot(degB != 0u);
+                        if (degA) {
+                            const uint32_t ex = inclA - degA;
+                            t.a[lanes_below(bA)] = make_uint4(mdA.x - ex, sdA.x, sdA.y, req);
+                            atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[ex >> 6]), 1ull << (ex & 63u));
+                        }
+                        if (degB) {
+                            const uint32_t ex = inclB - degB;
+                            t.a[(uint32_t)__popcll(bA) + lanes_below(bB)] = make_uint4(mdB.x - ex, sdB.x, sdB.y, eB.y);
+                            atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[ex >> 6]), 1ull << (ex & 63u));
+                        }
+                        wave_lds_fence();
+                        ACL_MARK(wo, PH_TASKS);
+                        simple_steps<LOCAL, true, true>(t, total, wo, lane, g.edges, reinterpret_cast<const uint4 *>(g.buckets), has, err, make_meta(d_key, Lv + 1u, meta_key(m0)));
+                        if (lane < kHeadWords) t.heads[lane] = 0ull;
+                        wave_lds_fence();
+                        ACL_MARK(wo, PH_PUSH);
+                        return;
+                    }
+                }
+            }
+#endif
+            simple = lane_op(m0, LA);  // wave-uniform argument
             LB = LA;
         } else {
             simple = !__ballot(valid && !lane_op(meta, LA));
@@ -1233,6 +1315,7 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_expand(DevGr
     const uint32_t lane = lane_id();
     const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
+    if (lane < kHeadWords) t.heads[lane] = 0ull;  // (flush_simple's head bits: zero between expansions)
     const uint32_t wave = blockIdx.x * kWavesPerBlock + wib, nwaves = f.nwaves;
     const uint32_t pin = (iter + 1) & 1u;  // iteration i reads parity (i-1)&1
     const uint32_t *__restrict__ in_counts = f.counts[pin];
@@ -1331,7 +1414,7 @@ struct NoNext {
 #endif
 constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
 #ifndef ACL_SPLIT_UNITS
-#define ACL_SPLIT_UNITS 1  // the wide monotone walk cuts a unit into two HALVES whose levels turn over independently (k_check_local); 0 = one barrier per level (A/B builds)
+#define ACL_SPLIT_UNITS 0  // 1 (A/B builds; measured C4 228.4 -> 226.0 us but C5R 297 -> 304 us, level barriers 19 -> 15 % of the wave-time: profiles/r05_ab_split_units.txt): the wide monotone walk cuts a unit into two HALVES whose levels turn over independently (k_check_local); 0 = one barrier per level (A/B builds)
 #endif
 #ifndef ACL_TAIL_SINGLES
 #define ACL_TAIL_SINGLES 0  // N > 0 (A/B builds): the last 2 N x WAVES segments of a level are claimed one by one instead of in pairs (see the claim loop)
@@ -1370,6 +1453,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     const uint32_t lane = lane_id();
     const uint32_t wib = uniform(threadIdx.x >> 6);  // (wave-uniform, and the compiler is told so: per-wave pointers then live in SGPRs)
     TaskLds &t = lds[wib];
+    if (lane < kHeadWords) t.heads[lane] = 0ull;  // (flush_simple's head bits: zero between expansions)
     const DevShard nosh{};
     uint4 *bufs[2] = {buf0 + (size_t)blockIdx.x * cap, buf1 + (size_t)blockIdx.x * cap};
     if (lane == 0) {
@@ -1448,7 +1532,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             {
                 NoNext nn;
                 co.iter = 1u;
-                process_segment<false, true, CMB>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
+                process_segment<false, true, CMB, NoNext, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
             }
             if (wo.cur == kNoSpace && lane == 0) s_stop = 1;
             __syncthreads();  // (the seeds' children are written; from here on the halves' counters order everything)
@@ -1514,7 +1598,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         {
             NoNext nn;
             co.iter = 1u;
-            process_segment<false, true, CMB>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
+            process_segment<false, true, CMB, NoNext, true>(e, valid, nn, t, wo, lane, g, progs, ops, has, err, nosh, co);
         }
         uint32_t parity = 0;
         for (uint32_t level = 2; level <= kMaxLevels + 1; level++) {

@@ -38,7 +38,11 @@ struct DevGraph {
     uint32_t *ccount = nullptr;        // level loop: {leaf cells handed out, nodes appended} (the single-launch walk counts in LDS)
     uint32_t node_cap = 0, cell_cap = 0;  // per block (single launch) / in all (level loop)
     uint32_t cell0 = 0;                // index of the first leaf cell in has[] / err[] (= the batch size: cells follow the requests' own)
+    uint32_t walk_flags = 0;           // kWalkNoDirect: the single-launch walk builds every task list the general way (set by the host after a walk met a
+                                       // pair of segments with more children than the direct form's head-bit window: kernels.hip, process_segment)
 };
+constexpr uint32_t kWalkNoDirect = 1u;
+constexpr uint32_t kOverflowDirect = 4u;  // single-launch walk's overflow code: "redo, and stop using the direct task lists on this snapshot"
 struct DevReverse {
     const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids
     const RevOp *rops;

@@ -231,6 +231,41 @@ def test_walk_overflow_falls_back_and_backs_off(aclgpu, monkeypatch):
         assert np.array_equal(p, op[:64]) and np.array_equal(er, oe[:64])
 
 
+def test_direct_task_lists_step_aside_on_wide_fanout(aclgpu):
+    """Round 5: the deep levels' direct task lists map a pair of segments' children through a 2 048-item head-bit window.  Nested groups with 40
+    subgroups each overrun it: that walk raises kOverflowDirect, the batch is redone on the level loop, and the NEXT walk builds its lists the
+    general way -- same answers every time, and the walk is back in service at once (no back-off: nothing was wrong with the frontier)."""
+    from aclgpu import workloads
+    rng = np.random.default_rng(5)
+    fan, n_user, n_pod = 40, 4000, 3000
+    g1 = np.arange(1, 1 + fan, dtype=np.uint32)                       # g0 -> 40 groups
+    g2 = np.arange(1 + fan, 1 + fan + fan * fan, dtype=np.uint32)     # each of them -> 40 more
+    gg_r = np.concatenate([np.zeros(fan, np.uint32), np.repeat(g1, fan)])
+    gg_s = np.concatenate([g1, g2])
+    gu_r = rng.choice(g2, size=n_user).astype(np.uint32)              # every user sits in one leaf group
+    gu_s = np.arange(n_user, dtype=np.uint32)
+    pods = np.arange(n_pod, dtype=np.uint32)
+    o = orc.Oracle(workloads.SCHEMA_C4)
+    with aclgpu.Engine(workloads.SCHEMA_C4) as e:
+        for t in (o, e):
+            t.add_edges("group", "member", "group", "member", gg_r, gg_s)
+            t.add_edges("group", "member", "user", "", gu_r, gu_s)
+            t.add_edges("pod", "namespace", "namespace", "", pods, np.zeros(n_pod, np.uint32))
+            t.add_edges("pod", "viewer", "group", "member", pods, np.zeros(n_pod, np.uint32))
+            t.add_edges("pod", "creator", "user", "", pods[:8], np.arange(8, dtype=np.uint32))
+        n = 100000  # (>= the wide walk's threshold: 16 waves per unit, segments of ONE slot from level 3 on)
+        res = rng.integers(0, n_pod, size=n).astype(np.uint32)
+        sub = rng.integers(0, n_user + 500, size=n).astype(np.uint32)  # some users are in no group: full misses walk every level
+        op, oe = o.check_bulk_ids_mt(4, "pod", "view", res, "user", "", sub)
+        items = e.make_items("pod", "view", res, "user", "", sub)
+        e.stats_reset()
+        for _ in range(3):
+            p, er = e.check_bulk_ids(items)
+            assert np.array_equal(p, op) and np.array_equal(er, oe)
+        s_ = e.stats()
+        assert s_["check_passes"] == 3 and s_["expand_launches"] > 0 and s_["local_passes"] == 2, s_  # first walk tripped, the next two ran
+
+
 def test_frontier_overflow_grows(aclgpu, monkeypatch):
     """A frontier too small for the batch is grown and the pass redone -- same answers.  (The LEVEL LOOP's frontier: the single-launch walk,
     whose blocks may or may not fit their regions at this size, is switched off for the first engine.)"""
