@@ -62,6 +62,8 @@ int new_ctx(acl_engine *h, DevState *d, std::unique_ptr<PassCtx> *out, int index
     c->dev = d;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(c->d_status.ensure(kStatusWords));
+    HIP_TRY(c->d_done.ensure(1));
+    HIP_TRY(hipMemset(c->d_done.p, 0, sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc((void **)&c->h_status, kStatusWords * sizeof(uint32_t), hipHostMallocDefault));
     int rc = alloc_frontier(h, c.get(),
                             h->cfg_frontier_entries ? h->cfg_frontier_entries : std::max<uint64_t>(32u << 20, (uint64_t)2 * d->grid_blocks * kWavesPerBlock * kChunk));  // 2 x 512 MiB: the single-launch walk carves its blocks' private regions out of these
@@ -711,7 +713,10 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     uint32_t *flag = (uint32_t *)c->h_out.p;  // one overflow flag per sub-pass (16 words)
     int32_t *h_err = pin_e ? err_out : (int32_t *)((char *)c->h_out.p + 64);
     uint8_t *h_perm = pin_p ? perm_out : (uint8_t *)c->h_out.p + 64 + (size_t)n * 4;
-    std::memset(flag, 0, 64);
+    std::memset(flag, 0, 64);  // (word 15: the completion word of small batches)
+    const bool spin = npass == 1 && nstreams == 1 && !c->timing && n <= h->spin_max && !h->snap.has_combine;
+    uint32_t done_val = 0;
+    if (spin && !(done_val = ++c->done_seq)) done_val = c->done_seq = 1;  // (0 never names a launch)
     void *d_in = nullptr, *d_flag = nullptr, *d_perm = nullptr, *d_errp = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_in, const_cast<void *>(src), 0));
     HIP_TRY(hipHostGetDevicePointer(&d_flag, c->h_out.p, 0));
@@ -736,10 +741,30 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
         if (nstreams == 1) ev_begin(c, 2);
         launch_check_local(st, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p + region, c->d_fbuf[1].p + region, Gk.cap, (uint32_t *)d_flag + k,
                            c->d_has.p + off, c->d_err.p + off, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide,
-                           lone && Gk.nunits > 1 ? Gk.rpw * h->host_skew_pct / 100 : 0u);
+                           lone && Gk.nunits > 1 ? Gk.rpw * h->host_skew_pct / 100 : 0u, spin ? c->d_done.p : nullptr, spin ? (uint32_t *)d_flag + 15 : nullptr, done_val);
         if (nstreams == 1) ev_end(c);
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // Small batches: the kernel's last block stores `done_val` into flag[15] behind a system-scope release of every answer; the caller spins on
+    // that word instead of entering hipStreamSynchronize, which returns ~5.5 us after the store is visible (tools/launch_latency.hip).  The stream
+    // is left un-synchronised on purpose: everything else on it is ordered behind the kernel anyway, and the kernel has nothing left to do but
+    // retire.  A word that does not arrive within 2 ms (a fault, a debugger) falls back to the synchronising wait, which reports the error.
+    bool spun = false;
+    if (spin) {
+        const volatile uint32_t *dw = flag + 15;
+        const int64_t t_end = mono_ns() + 2000000;
+        for (uint32_t it = 0;; it++) {
+            if (*dw == done_val) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                spun = true;
+                break;
+            }
+            if ((it & 1023u) == 1023u && mono_ns() > t_end) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    if (!spun) HIP_TRY(hipStreamSynchronize(c->stream));
     for (uint32_t k = 1; k < nstreams; k++) HIP_TRY(hipStreamSynchronize(c->aux[k - 1]));
     ev_collect(c);
     for (uint32_t k = 0; k < npass; k++)
@@ -1716,6 +1741,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
         d->local_blocks_wide = local_grid_blocks(dev, 2048, true);
         h->devs.push_back(std::move(d));
     }
+    if (const char *ev = getenv("ACL_SPIN_MAX")) h->spin_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob
     if (const char *ev = getenv("ACL_LOCAL_WIDE_MIN")) h->local_wide_min = (uint32_t)std::max(0, atoi(ev));  // A/B knob
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");

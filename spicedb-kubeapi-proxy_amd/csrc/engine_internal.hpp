@@ -226,6 +226,8 @@ struct PassCtx {
     uint64_t frontier_entries = 0;
     uint32_t max_chunks = 0;
     uint32_t *h_status = nullptr;  // pinned
+    DevArray<uint32_t> d_done;     // [1] arrival counter of a small host batch's blocks (zero between launches: the last block re-arms it; kernels.hip done_flag)
+    uint32_t done_seq = 0;         // the value the next such launch stores into its pinned completion word
     // batch scratch
     DevArray<uint8_t> d_has, d_err, d_perm;
     DevArray<int32_t> d_errout;
@@ -356,6 +358,7 @@ struct acl_engine {
     bool raw_intern = false;       // test knob (ACL_RAW_INTERN): acl_intern skips the API's object-id pattern
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most
     uint64_t compaction_slack = 65536;  // words of garbage a snapshot may hold on top of an eighth of its rows before a background build starts
+    uint32_t spin_max = 64;  // (every block pays a system-scope release of its answers: worth it up to 64 blocks -- 1 item 21.3 -> 17.6 us, 64 items 23.0 -> 20.6 us; at 256 items it already loses, 23 -> 27 us, profiles/r05_spin_wait_ab.txt) host batches up to this size wait for their kernel by spinning on a pinned word its last block stores, not in hipStreamSynchronize (ACL_SPIN_MAX; 0 = off)
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
     uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)

@@ -1424,7 +1424,8 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
                                                                                   uint32_t nunits, uint32_t nstatic, uint32_t rdyn, uint32_t *next_unit, uint4 *buf0, uint4 *buf1,
                                                                                   uint32_t cap,
                                                                                   uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
-                                                                                  int32_t *err_out, uint32_t *max_level, uint32_t skew) {
+                                                                                  int32_t *err_out, uint32_t *max_level, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag,
+                                                                                  uint32_t done_val) {
     __shared__ TaskLds lds[WAVES];
     __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
@@ -1680,6 +1681,20 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
     ACL_MARK(wo, PH_OTHER);
     if (lane < 16) atomicAdd(&acl_phase_cycles[lane], (unsigned long long)s_cold[wib].prof[lane]);
 #endif
+    // ---- small host batches (round 5): the caller does not wait in hipStreamSynchronize -- that costs ~5.5 us AFTER the kernel's
+    // last store is visible to a spinning host thread (tools/launch_latency.hip: flag visible 6.6 us after the launch call, synchronize returns at
+    // 11.9-15 us) -- it spins on `done_flag`, a word of pinned host memory that the LAST block to finish sets.  Every block releases its answers
+    // (stores into host memory) at system scope before it arrives at the device counter; the last arrival re-arms the counter and raises the flag.
+    if (done_flag) {
+        __syncthreads();  // (every wave's answer stores are issued)
+        if (threadIdx.x == 0) {
+            __threadfence_system();
+            if (__hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+                __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // Merges identical pending sub-checks of one level: two frontier entries with the same (request, state, level) have identical
@@ -2407,36 +2422,36 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 template <int WAVES>
 static void launch_check_local_w(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t nunits, uint32_t nstatic, uint32_t rdyn,
                                  uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
-                                 uint32_t *max_level, uint32_t skew) {
+                                 uint32_t *max_level, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
     const dim3 grid(nblocks);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
     if (g.bexpr) {  // schemas with `&` / `-`: the combine instantiations
         if (lds)
             hipLaunchKernelGGL((k_check_local<true, WAVES, true>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow,
-                               has, err, perm_out, err_out, max_level, skew);
+                               has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
         else
             hipLaunchKernelGGL((k_check_local<false, WAVES, true>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                               perm_out, err_out, max_level, skew);
+                               perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
         return;
     }
     if (lds)
         hipLaunchKernelGGL((k_check_local<true, WAVES>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                           perm_out, err_out, max_level, skew);
+                           perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
     else
         hipLaunchKernelGGL((k_check_local<false, WAVES>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out,
-                           err_out, max_level, skew);
+                           err_out, max_level, skew, done_ctr, done_flag, done_val);
 }
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
                         uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level,
-                        uint32_t nstatic, uint32_t rdyn, bool wide, uint32_t skew) {
+                        uint32_t nstatic, uint32_t rdyn, bool wide, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
     uint32_t nunits = (n + rpw - 1) / rpw;
     if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) skew = 0;  // (static units only)
     skew = std::min(skew, std::min(rpw - 1u, (wide ? kLocalWide : kLocalNarrow) * 64u - rpw));  // the largest unit still fits the block: thread i seeds request first + i
     skew = nunits > 1 && nunits <= 4096 ? (skew << 8) / nunits : 0u;                             // (the kernel's fixed-point form: 1/256ths per unit; u (nunits - u) skew < 2^32)
     if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) nunits = nstatic + (n - nstatic * rpw + rdyn - 1) / rdyn;  // static units, then small ones
     else nstatic = nunits, rdyn = rpw;
-    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew);
-    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew);
+    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
+    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
 }
 template <int WAVES>
 static int local_occupancy(bool lds, size_t prog_bytes) {
