@@ -108,7 +108,12 @@ int acl_type_id(acl_engine_t *h, const char *type);                 /* -1 if unk
 int acl_relation_id(acl_engine_t *h, int type, const char *name);   /* relation or permission; -1 if unknown */
 int acl_intern(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out); /* creates if missing */
 int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out);   /* ACL_ERR_NOT_FOUND if missing */
-const char *acl_object_name(acl_engine_t *h, int type, uint32_t id); /* NULL for anonymous/unknown ids */
+const char *acl_object_name(acl_engine_t *h, int type, uint32_t id); /* NULL for anonymous/unknown ids.  The pointer is only good while the id keeps its
+                                                                      * name: ids of objects that take part in no relationship are recycled (a quarantine after
+                                                                      * they were last handed out), and a recycled id's name bytes are overwritten.  Prefer: */
+/* Copies the name of `id` into buf (NUL-terminated, at most cap bytes incl. the NUL) under the names lock and returns its length (which may exceed cap - 1:
+ * the copy is then truncated); -1 for anonymous / unknown ids.  What the cgo shim's LookupResources stream calls per result id (lookups.go:75-83). */
+int64_t acl_object_name_copy(acl_engine_t *h, int type, uint32_t id, char *buf, size_t cap);
 uint32_t acl_object_count(acl_engine_t *h, int type);                /* size of the type's dense id space */
 
 /* ---- relationship store: the write side of the seam ---- */

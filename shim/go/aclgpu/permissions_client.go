@@ -159,8 +159,20 @@ func (s *bitmapStream) Recv() (*v1.LookupResourcesResponse, error) {
 	}
 	bit := bits.TrailingZeros32(uint32(s.bm[s.word]))
 	s.bm[s.word] &^= 1 << uint(bit)
-	name := C.acl_object_name(s.e.h, s.typeID, C.uint32_t(s.word*32+bit))
-	return &v1.LookupResourcesResponse{LookedUpAt: s.at, ResourceObjectId: C.GoString(name),
+	// the name is COPIED under the engine's names lock (acl_object_name_copy): an id whose object takes part in no relationship may be given to a new
+	// name later, and the bytes acl_object_name points at are then overwritten
+	var buf [256]C.char
+	id := C.uint32_t(s.word*32 + bit)
+	n := C.acl_object_name_copy(s.e.h, s.typeID, id, &buf[0], C.size_t(len(buf)))
+	var name string
+	if int(n) >= len(buf) { // (object ids may be up to 1024 bytes long)
+		big := make([]C.char, int(n)+1)
+		n = C.acl_object_name_copy(s.e.h, s.typeID, id, &big[0], C.size_t(len(big)))
+		name = C.GoStringN(&big[0], C.int(n))
+	} else if n >= 0 {
+		name = C.GoStringN(&buf[0], C.int(n))
+	}
+	return &v1.LookupResourcesResponse{LookedUpAt: s.at, ResourceObjectId: name,
 		Permissionship: v1.LookupPermissionship_LOOKUP_PERMISSIONSHIP_HAS_PERMISSION}, nil
 }
 func (s *bitmapStream) Header() (metadata.MD, error) { return nil, nil }

@@ -109,8 +109,13 @@ class Engine:
         return out.value if rc == 0 else None
 
     def object_name(self, t: str, i: int):
-        n = self._L.acl_object_name(self._h, self.type_id(t), int(i))
-        return None if n is None else n.decode()
+        """acl_object_name_copy: the name is copied out under the names lock (an id that takes part in no relationship may be renamed later)"""
+        buf = C.create_string_buffer(256)
+        n = self._L.acl_object_name_copy(self._h, self.type_id(t), int(i), buf, len(buf))
+        if n >= len(buf):
+            buf = C.create_string_buffer(n + 1)
+            n = self._L.acl_object_name_copy(self._h, self.type_id(t), int(i), buf, len(buf))
+        return None if n < 0 else buf.raw[:n].decode()
 
     def object_count(self, t: str) -> int:
         return self._L.acl_object_count(self._h, self.type_id(t))

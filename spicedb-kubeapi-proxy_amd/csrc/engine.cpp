@@ -718,10 +718,14 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     uint32_t done_val = 0;
     if (spin && !(done_val = ++c->done_seq)) done_val = c->done_seq = 1;  // (0 never names a launch)
     void *d_in = nullptr, *d_flag = nullptr, *d_perm = nullptr, *d_errp = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&d_in, const_cast<void *>(src), 0));
-    HIP_TRY(hipHostGetDevicePointer(&d_flag, c->h_out.p, 0));
-    HIP_TRY(hipHostGetDevicePointer(&d_perm, h_perm, 0));
-    HIP_TRY(hipHostGetDevicePointer(&d_errp, h_err, 0));
+    // (the staging buffers' device pointers are kept with them; only a caller's own pinned buffer is asked for)
+    if (src == c->h_in.p) d_in = c->h_in.dp;
+    else HIP_TRY(hipHostGetDevicePointer(&d_in, const_cast<void *>(src), 0));
+    d_flag = c->h_out.dp;
+    if (pin_p) HIP_TRY(hipHostGetDevicePointer(&d_perm, h_perm, 0));
+    else d_perm = (char *)c->h_out.dp + ((char *)h_perm - (char *)c->h_out.p);
+    if (pin_e) HIP_TRY(hipHostGetDevicePointer(&d_errp, h_err, 0));
+    else d_errp = (char *)c->h_out.dp + ((char *)h_err - (char *)c->h_out.p);
     // (No turn-taking between callers here, whatever the batch size: two single-launch kernels on the chip at once do not get in each other's
     //  way -- the second one's blocks move in as the first one's finish, which fills the tail a lone launch leaves idle: 2 / 4 / 8 / 16 callers
     //  with 262 144-item batches measure 886 / 890 / 914 / 916 M decisions/s, ABOVE the 873 M/s of back-to-back device-resident launches, and a
@@ -1859,6 +1863,19 @@ int acl_find(acl_engine_t *h, int type, const char *object_id, uint32_t *id_out)
     if (!h->store.objects(type).find(object_id, id_out)) return fail(ACL_ERR_NOT_FOUND, "object not found");
     h->store.touch(type, *id_out);  // (the id is the caller's for the length of a quarantine: an unreferenced object is not renamed under it)
     return ACL_OK;
+}
+int64_t acl_object_name_copy(acl_engine_t *h, int type, uint32_t id, char *buf, size_t cap) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return -1;
+    const std::string *n = h->store.objects(type).name(id);
+    if (!n) return -1;
+    if (buf && cap) {
+        const size_t k = std::min(n->size(), cap - 1);
+        std::memcpy(buf, n->data(), k);
+        buf[k] = 0;
+    }
+    return (int64_t)n->size();
 }
 const char *acl_object_name(acl_engine_t *h, int type, uint32_t id) {
     std::shared_lock<std::shared_mutex> nlk(h->names_mu);

@@ -184,6 +184,7 @@ struct DevArray {
 // pinned host staging (grow-only)
 struct PinnedBuf {
     void *p = nullptr;
+    void *dp = nullptr;  // the device's pointer to the same memory (hipHostGetDevicePointer, asked once per allocation: the small-call path asked four times per call)
     size_t n = 0;
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
@@ -196,7 +197,9 @@ struct PinnedBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr;
         n = 0;
+        dp = nullptr;
         hipError_t e = hipHostMalloc(&p, std::max<size_t>(bytes, 64), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, p, 0);
         if (e == hipSuccess) n = bytes;
         return e;
     }

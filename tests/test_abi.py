@@ -249,7 +249,7 @@ def _c_prototypes(text):
         before = text[:m.start()].rstrip()
         if not before or before.endswith(("return", "=", "(", ",", "?", ":")) or before[-1] in "{;" and False:
             continue
-        if not re.search(r"(\b(int|void|char|uint64_t|uint32_t|size_t|acl_engine_t|const)\b|\*)\s*$", before):
+        if not re.search(r"(\b(int|void|char|int64_t|uint64_t|uint32_t|int32_t|uint8_t|size_t|acl_engine_t|const)\b|\*)\s*$", before):
             continue
         depth, i = 1, m.end()
         while depth and i < len(text):
