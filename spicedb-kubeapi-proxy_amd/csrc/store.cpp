@@ -42,14 +42,15 @@ uint64_t ObjectTable::hash(std::string_view s) {
 void ObjectTable::grow() {
     std::vector<Slot> old;
     old.swap(slots_);
-    slots_.assign(old.empty() ? 64 : old.size() * 2, Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
-    const size_t mask = slots_.size() - 1;
+    // (doubling while small; a quarter more, rounded to whole 4 KiB pages of slots, from kBigTable slots on -- see store.hpp)
+    const size_t cap = old.empty() ? 64 : (old.size() * 2 <= kBigTable ? old.size() * 2 : ((old.size() + old.size() / 4 + 63) / 64) * 64);
+    slots_.assign(cap, Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
     used_ -= tombs_;
     tombs_ = 0;
     for (const Slot &s : old) {
         if (s.id == 0xFFFFFFFFu || s.id == kTomb) continue;
-        size_t i = hash(names_[name_of_[s.id]]) & mask;
-        while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+        size_t i = home(hash(names_[name_of_[s.id]]));
+        while (slots_[i].id != 0xFFFFFFFFu) i = next(i);
         slots_[i] = s;
     }
 }
@@ -57,8 +58,7 @@ bool ObjectTable::find(std::string_view name, uint32_t *id) const { return find_
 bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) const {
     if (slots_.empty()) return false;
     const uint32_t tag = (uint32_t)(h >> 32);
-    const size_t mask = slots_.size() - 1;
-    for (size_t i = h & mask;; i = (i + 1) & mask) {
+    for (size_t i = home(h);; i = next(i)) {
         const Slot &s = slots_[i];
         if (s.id == 0xFFFFFFFFu) return false;
         if (s.tag == tag && s.id != kTomb) {
@@ -90,15 +90,14 @@ ObjectTable::Slot ObjectTable::make_slot(uint64_t h, uint32_t id, const std::str
 uint32_t ObjectTable::intern(std::string_view name) {
     uint32_t id;
     if (find(name, &id)) return id;
-    if ((used_ + 1) * 2 > slots_.size()) grow();
+    if (slots_.empty() || full_for_one_more()) grow();
     id = count();
     if (name_of_.size() <= id) name_of_.resize((size_t)id + 1, 0xFFFFFFFFu);
     name_of_[id] = (uint32_t)names_.size();
     names_.emplace_back(name);
     const uint64_t h = hash(name);
-    const size_t mask = slots_.size() - 1;
-    size_t i = h & mask;
-    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = (i + 1) & mask;
+    size_t i = home(h);
+    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = next(i);
     if (slots_[i].id == kTomb) tombs_--;
     else used_++;
     slots_[i] = make_slot(h, id, names_.back());
@@ -109,8 +108,7 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
     std::string &stored = names_[name_of_[id]];
     {   // the old name's slot becomes a tombstone
         const uint64_t h = hash(stored);
-        const size_t mask = slots_.size() - 1;
-        for (size_t i = h & mask;; i = (i + 1) & mask) {
+        for (size_t i = home(h);; i = next(i)) {
             Slot &s = slots_[i];
             if (s.id == 0xFFFFFFFFu) break;  // (cannot happen: the name is in the table)
             if (s.id == id) {
@@ -127,19 +125,17 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
         slots_.assign(old.size(), Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
         used_ -= tombs_;
         tombs_ = 0;
-        const size_t mask = slots_.size() - 1;
         for (const Slot &s : old) {
             if (s.id == 0xFFFFFFFFu || s.id == kTomb) continue;
-            size_t i = hash(names_[name_of_[s.id]]) & mask;
-            while (slots_[i].id != 0xFFFFFFFFu) i = (i + 1) & mask;
+            size_t i = home(hash(names_[name_of_[s.id]]));
+            while (slots_[i].id != 0xFFFFFFFFu) i = next(i);
             slots_[i] = s;
         }
     }
-    if ((used_ + 1) * 2 > slots_.size()) grow();
+    if (full_for_one_more()) grow();
     const uint64_t h = hash(new_name);
-    const size_t mask = slots_.size() - 1;
-    size_t i = h & mask;
-    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = (i + 1) & mask;
+    size_t i = home(h);
+    while (slots_[i].id != 0xFFFFFFFFu && slots_[i].id != kTomb) i = next(i);
     if (slots_[i].id == kTomb) tombs_--;
     else used_++;
     slots_[i] = make_slot(h, id, stored);
