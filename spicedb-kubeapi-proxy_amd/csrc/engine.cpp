@@ -745,7 +745,8 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
         if (nstreams == 1) ev_begin(c, 2);
         launch_check_local(st, g, (const uint4 *)d_in + off, m, Gk.rpw, Gk.nblocks, nullptr, c->d_fbuf[0].p + region, c->d_fbuf[1].p + region, Gk.cap, (uint32_t *)d_flag + k,
                            c->d_has.p + off, c->d_err.p + off, (uint8_t *)d_perm + off, (int32_t *)d_errp + off, nullptr, 0, 0, Gk.wide,
-                           lone && Gk.nunits > 1 ? Gk.rpw * h->host_skew_pct / 100 : 0u, spin ? c->d_done.p : nullptr, spin ? (uint32_t *)d_flag + 15 : nullptr, done_val);
+                           lone && Gk.nunits > 1 ? Gk.rpw * h->host_skew_pct / 100 : 0u, spin ? c->d_done.p : nullptr, spin ? (uint32_t *)d_flag + 15 : nullptr, done_val,
+                           npass == 1 && n <= 4 ? (const uint4 *)items : nullptr);
         if (nstreams == 1) ev_end(c);
     }
     // Small batches: the kernel's last block stores `done_val` into flag[15] behind a system-scope release of every answer; the caller spins on

@@ -1402,6 +1402,9 @@ struct NoNext {
 // Block b starts on unit b; further units (batches beyond 256 requests per resident block, or `upw` > 1) are handed out through
 // `next_unit`, one atomic per BLOCK-unit -- per wave-unit the same counter cost ~12 ns per unit in same-address contention
 // (profiles/r02_walk_units_per_wave.txt).
+struct InlineItems {  // up to four 16-byte items passed by value (kernel arguments)
+    uint4 v[4];
+};
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
 #define ACL_LOCAL_WAVES_PER_SIMD 8
 #endif
@@ -1425,7 +1428,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
                                                                                   uint32_t cap,
                                                                                   uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out,
                                                                                   int32_t *err_out, uint32_t *max_level, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag,
-                                                                                  uint32_t done_val) {
+                                                                                  uint32_t done_val, InlineItems inl) {
     __shared__ TaskLds lds[WAVES];
     __shared__ WaveOutCold s_cold[WAVES];
     // output cursor / segment-claim counter of level L live in slot L % 3: written during L, read at the start of L + 1, cleared at the
@@ -1494,7 +1497,14 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         const uint32_t req = first + threadIdx.x;
         uint4 e = make_uint4(0, 0, kDeadMeta, 0);
         if (valid) {
-            const uint4 it = gld(items, req);
+            // (items == nullptr: a batch of <= 4 items rides in the kernel's arguments -- a single check's item does not cost a trip across PCIe)
+            uint4 it;
+            if (items) {  // (uniform)
+                it = gld(items, req);
+            } else {
+                const uint32_t qi = req & 3u;
+                it = qi == 0u ? inl.v[0] : (qi == 1u ? inl.v[1] : (qi == 2u ? inl.v[2] : inl.v[3]));
+            }
             const uint32_t rtype = it.x & 0xFFFFu, perm = it.x >> 16, stype = it.z & 0xFFFFu, srel = it.z >> 16;
             const bool tok = rtype < g.ntypes && stype < g.ntypes;
             const uint32_t rt = tok ? rtype : 0u, st = tok ? stype : 0u;
@@ -2422,36 +2432,41 @@ void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint3
 template <int WAVES>
 static void launch_check_local_w(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t nunits, uint32_t nstatic, uint32_t rdyn,
                                  uint32_t *next_unit, uint4 *buf0, uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out,
-                                 uint32_t *max_level, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
+                                 uint32_t *max_level, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val, const InlineItems &inl) {
     const dim3 grid(nblocks);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
     if (g.bexpr) {  // schemas with `&` / `-`: the combine instantiations
         if (lds)
             hipLaunchKernelGGL((k_check_local<true, WAVES, true>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow,
-                               has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
+                               has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
         else
             hipLaunchKernelGGL((k_check_local<false, WAVES, true>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                               perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
+                               perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
         return;
     }
     if (lds)
         hipLaunchKernelGGL((k_check_local<true, WAVES>), grid, dim3(WAVES * 64), prog_lds_bytes(g), s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err,
-                           perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
+                           perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
     else
         hipLaunchKernelGGL((k_check_local<false, WAVES>), grid, dim3(WAVES * 64), 0, s, g, items, n, rpw, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out,
-                           err_out, max_level, skew, done_ctr, done_flag, done_val);
+                           err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
 }
 void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, uint32_t n, uint32_t rpw, uint32_t nblocks, uint32_t *next_unit, uint4 *buf0,
                         uint4 *buf1, uint32_t cap, uint32_t *overflow, uint8_t *has, uint8_t *err, uint8_t *perm_out, int32_t *err_out, uint32_t *max_level,
-                        uint32_t nstatic, uint32_t rdyn, bool wide, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
+                        uint32_t nstatic, uint32_t rdyn, bool wide, uint32_t skew, uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val, const uint4 *inline_items_host) {
+    InlineItems inl{};
+    if (inline_items_host && n <= 4) {  // (host memory: copied into the launch's arguments)
+        for (uint32_t i = 0; i < n; i++) inl.v[i] = inline_items_host[i];
+        items = nullptr;
+    }
     uint32_t nunits = (n + rpw - 1) / rpw;
     if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) skew = 0;  // (static units only)
     skew = std::min(skew, std::min(rpw - 1u, (wide ? kLocalWide : kLocalNarrow) * 64u - rpw));  // the largest unit still fits the block: thread i seeds request first + i
     skew = nunits > 1 && nunits <= 4096 ? (skew << 8) / nunits : 0u;                             // (the kernel's fixed-point form: 1/256ths per unit; u (nunits - u) skew < 2^32)
     if (nstatic && rdyn && (uint64_t)nstatic * rpw < n) nunits = nstatic + (n - nstatic * rpw + rdyn - 1) / rdyn;  // static units, then small ones
     else nstatic = nunits, rdyn = rpw;
-    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
-    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val);
+    if (wide) launch_check_local_w<kLocalWide>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
+    else launch_check_local_w<kLocalNarrow>(s, g, items, n, rpw, nblocks, nunits, nstatic, rdyn, next_unit, buf0, buf1, cap, overflow, has, err, perm_out, err_out, max_level, skew, done_ctr, done_flag, done_val, inl);
 }
 template <int WAVES>
 static int local_occupancy(bool lds, size_t prog_bytes) {

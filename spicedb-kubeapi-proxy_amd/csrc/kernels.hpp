@@ -114,7 +114,8 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
                         uint32_t skew = 0 /* static units only: unit u holds rpw + skew ... rpw - skew requests, falling with u (items read across PCIe arrive in block order) */,
                         uint32_t *done_ctr = nullptr /* device word, zero between launches */, uint32_t *done_flag = nullptr /* pinned host word (device pointer): the last block to
                         finish stores done_val there, behind a system-scope release of every block's answers -- the host spins on it instead of synchronising the stream */,
-                        uint32_t done_val = 0);
+                        uint32_t done_val = 0, const uint4 *inline_items_host = nullptr /* HOST pointer to the batch's items: a batch of <= 4 rides in the kernel's arguments
+                        and `items` is not read */);
 // blocks of the single-launch kernel that are resident at once on this device
 int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
 uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= threads per block of the single-launch kernel: thread i seeds request i of the unit)
