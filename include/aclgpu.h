@@ -202,7 +202,7 @@ int acl_check_bulk_v_opts(acl_engine_t *h, const acl_check_item_v_t *items, size
  * has waited for yet pins nothing: the holder of tickets may make any other call on the engine (writes included) before it waits.
  * Every batch -- a blocking caller's or a ticket's -- is answered by the kernel itself across PCIe: it reads the items from, and writes
  * the answers to, the host buffers (pinned: in place; else through the context's pinned staging), in one launch, or -- beyond what one
- * launch takes -- in sub-passes on two streams.  No copies, no turn-taking: concurrent calls overlap on the chip (three callers 1.12-1.22 G
+ * launch takes -- in sub-passes on two streams.  No copies, no turn-taking: concurrent calls overlap on the chip (three callers 1.22-1.29 G
  * decisions/s on C4, one caller 0.85 G; profiles/r04_host_split.txt).  Go callers simply block goroutines in acl_check_bulk_ids. */
 typedef struct acl_ticket acl_ticket_t;
 int acl_check_bulk_ids_submit(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, acl_ticket_t **ticket_out);
