@@ -563,6 +563,29 @@ void Eval::end() {
 
 constexpr int kTakeLevelLoop = -1000;  // internal: the single-launch path declines the batch (never leaves this file)
 
+// Small batches: the kernel's last block stores `val` into a pinned word behind a system-scope release of everything the launch wrote into host
+// memory; the caller spins on that word instead of entering hipStreamSynchronize, which returns ~5.5 us after the store is visible
+// (tools/launch_latency.hip).  false: the word did not arrive within 2 ms (a fault, a debugger) -- the caller falls back to the synchronising wait,
+// which reports the error.  The stream is left un-synchronised on purpose: everything else on it is ordered behind the kernel anyway.
+static bool spin_for(const volatile uint32_t *word, uint32_t val) {
+    const int64_t t_end = mono_ns() + 2000000;
+    for (uint32_t it = 0;; it++) {
+        if (*word == val) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            return true;
+        }
+        if ((it & 1023u) == 1023u && mono_ns() > t_end) return false;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+static uint32_t next_done_val(PassCtx *c) {
+    uint32_t v = ++c->done_seq;
+    if (!v) v = c->done_seq = 1;  // (0 never names a launch)
+    return v;
+}
+
 // Small batch: ONE launch (k_check_local) seeds, walks every level and writes the answers.  Requests per wave: one while the
 // batch fits the chip's wave slots (latency), more beyond that.  The waves' private frontier regions are carved from
 // the context's frontier buffers.
@@ -715,8 +738,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     uint8_t *h_perm = pin_p ? perm_out : (uint8_t *)c->h_out.p + 64 + (size_t)n * 4;
     std::memset(flag, 0, 64);  // (word 15: the completion word of small batches)
     const bool spin = npass == 1 && nstreams == 1 && !c->timing && n <= h->spin_max && !h->snap.has_combine;
-    uint32_t done_val = 0;
-    if (spin && !(done_val = ++c->done_seq)) done_val = c->done_seq = 1;  // (0 never names a launch)
+    const uint32_t done_val = spin ? next_done_val(c) : 0u;
     void *d_in = nullptr, *d_flag = nullptr, *d_perm = nullptr, *d_errp = nullptr;
     // (the staging buffers' device pointers are kept with them; only a caller's own pinned buffer is asked for)
     if (src == c->h_in.p) d_in = c->h_in.dp;
@@ -749,26 +771,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
                            npass == 1 && n <= 4 ? (const uint4 *)items : nullptr);
         if (nstreams == 1) ev_end(c);
     }
-    // Small batches: the kernel's last block stores `done_val` into flag[15] behind a system-scope release of every answer; the caller spins on
-    // that word instead of entering hipStreamSynchronize, which returns ~5.5 us after the store is visible (tools/launch_latency.hip).  The stream
-    // is left un-synchronised on purpose: everything else on it is ordered behind the kernel anyway, and the kernel has nothing left to do but
-    // retire.  A word that does not arrive within 2 ms (a fault, a debugger) falls back to the synchronising wait, which reports the error.
-    bool spun = false;
-    if (spin) {
-        const volatile uint32_t *dw = flag + 15;
-        const int64_t t_end = mono_ns() + 2000000;
-        for (uint32_t it = 0;; it++) {
-            if (*dw == done_val) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                spun = true;
-                break;
-            }
-            if ((it & 1023u) == 1023u && mono_ns() > t_end) break;
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-    }
+    const bool spun = spin && spin_for(flag + 15, done_val);  // (small batches: see spin_for)
     if (!spun) HIP_TRY(hipStreamSynchronize(c->stream));
     for (uint32_t k = 1; k < nstreams; k++) HIP_TRY(hipStreamSynchronize(c->aux[k - 1]));
     ev_collect(c);
@@ -1442,12 +1445,15 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
     uint64_t *h_counts = (uint64_t *)((char *)c->h_out.p + 64);
     uint32_t *h_rows = (uint32_t *)((char *)c->h_out.p + rows_off);
     *flag = 0;
+    flag[15] = 0;
     void *d_sids = nullptr, *d_out = nullptr, *d_rows = nullptr;
     HIP_TRY(hipHostGetDevicePointer(&d_sids, c->h_in.p, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_out, c->h_out.p, 0));
     // Result rows: written by the kernel straight into host memory (each block as it finishes), or -- rev_rows_device, A/B knob
     // ACL_REV_ROWS=device -- into a device buffer that one DMA copy brings over afterwards.
     const bool via_device = h->rev_rows_device && ostride;
+    const bool spin = m <= h->spin_max && !c->timing && !via_device;
+    const uint32_t done_val = spin ? next_done_val(c) : 0u;
     if (via_device) {
         HIP_TRY(c->d_rows.ensure(m * ostride));
         d_rows = c->d_rows.p;
@@ -1455,10 +1461,12 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
     else d_rows = (char *)d_out + rows_off;
     ev_begin(c, 3);
     launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target, c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
-                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u);
+                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u,
+                     spin ? c->d_done.p : nullptr, spin ? (uint32_t *)d_out + 15 : nullptr, done_val);
     ev_end(c);
     if (via_device) HIP_TRY(hipMemcpyAsync(direct ? (void *)bitmaps : (void *)h_rows, c->d_rows.p, m * ostride * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // (the proxy's shape is ONE LookupResources per list request, lookups.go:65: the caller spins on the completion word -- spin_for)
+    if (!(spin && spin_for(flag + 15, done_val))) HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     if (*flag) {

@@ -1991,9 +1991,24 @@ struct RevProgLds {  // the reverse programs, staged once per block (the host on
     uint2 slot[kRevLdsSlots];  // {first bit of the slot's visited rows, id space they cover}
 };
 
+// A small batch's caller spins on `done_flag` (pinned host memory) instead of synchronising the stream (see k_check_local): every block releases
+// what it stored into host memory at system scope, arrives at the device counter, and the last arrival re-arms the counter and raises the flag.
+__device__ __forceinline__ void signal_done(uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
+    if (!done_flag) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        if (__hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_slot,
                                                                  uint2 *buf0, uint2 *buf1, uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride,
-                                                                 uint32_t copy_words, unsigned long long *out_counts, uint32_t *status, uint32_t lds_words) {
+                                                                 uint32_t copy_words, unsigned long long *out_counts, uint32_t *status, uint32_t lds_words, uint32_t *done_ctr,
+                                                                 uint32_t *done_flag, uint32_t done_val) {
     __shared__ RevTaskLds t;
     __shared__ RevProgLds pl;
     // lds_words != 0: the RESULT slot's rows live here, not in `visited` -- the level that produces a lookup's ids (thousands of pods under
@@ -2190,6 +2205,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         // memory): blocks that race write non-zero either way, and a 2 lost to a 1 is found again by the level loop.
         // (`visited` is left dirty: the host zeroes it before the next single-launch lookup on this context)
         if (tid == 0) *status = s_stop;
+        signal_done(done_ctr, done_flag, done_val);
         return;
     }
     // ---- result rows: the target slot's words (every one of them was last written by an L2 atomic or is still the zero it was handed over
@@ -2228,6 +2244,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         const uint32_t rw = (pl.slot[target_slot].y + 31u) >> 5;
         for (uint32_t i = tid; i < rw; i += kRevLocalThreads) visited[row_w0 + i] = 0u;
     }
+    signal_done(done_ctr, done_flag, done_val);
 }
 
 // ------------------------------------------------------------------ import
@@ -2516,12 +2533,13 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
     else hipLaunchKernelGGL(k_rev_expand<REV_FUSED>, grid, dim3(kBlock), 0, s, r, f, iter, sh);
 }
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
-                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status, uint32_t lds_row_words) {
+                      uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status, uint32_t lds_row_words,
+                      uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
     if (!n) return;
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rev_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRevLdsRowBytes) == hipSuccess;
     if (lds_row_words * 4u > (big_lds ? kRevLdsRowBytes : 32768u)) lds_row_words = 0;  // rows stay in HBM
     hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), (size_t)lds_row_words * 4, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps,
-                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words);
+                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words, done_ctr, done_flag, done_val);
 }
 static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input per wave, at most 256 blocks
     const uint32_t b = (n + 4095) / 4096;

@@ -135,7 +135,9 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
 // out_counts[b] = ids in the row | reverse levels walked << 56
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
                       uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status,
-                      uint32_t lds_row_words /* words covering the result slot's id space: kept in LDS when <= kRevLdsRowBytes, else (or 0) in r.visited */);
+                      uint32_t lds_row_words /* words covering the result slot's id space: kept in LDS when <= kRevLdsRowBytes, else (or 0) in r.visited */,
+                      uint32_t *done_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_val = 0 /* as launch_check_local: the last block stores done_val into the pinned
+                      word done_flag behind a system-scope release of every block's rows, counts and status */);
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 
