@@ -529,7 +529,6 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t total, WaveOut
 template <bool SHARDED, bool LOCAL, bool DESC, bool E8>
 __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut &wo, uint32_t lane, const DevGraph &g, const SlotProg &cp, const FwdOp &pop,
                                                   uint8_t *has, uint8_t *err) {
-    constexpr int W = kSimpleWidth;
     const uint32_t *__restrict__ edges = g.edges;
     const uint4 *__restrict__ buckets = reinterpret_cast<const uint4 *>(g.buckets);
     uint32_t skipped = 0;
@@ -537,7 +536,6 @@ __device__ __forceinline__ uint32_t flush_simple(TaskLds &t, uint32_t T, WaveOut
     // prologue -- a chain of dependent LDS round trips: counts, scan, head bits, fences -- twice per pair of segments
     // (17 % of the walk's wave-time, profiles/r02_walk_phase_breakdown.txt).
     {
-        constexpr uint32_t gq = 0;
         const bool mine0 = lane < T, mine1 = 64u + lane < T;
         const uint32_t cnt0 = mine0 ? (t.count[lane] & kCountMask) : 0u, cnt1 = mine1 ? (t.count[64u + lane] & kCountMask) : 0u;
         const uint32_t incl0 = wave_incl_scan(cnt0, lane);
