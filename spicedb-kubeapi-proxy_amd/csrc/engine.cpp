@@ -316,8 +316,7 @@ int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     if (snapshot_current(h, false)) return ACL_OK;
-    if (h->shard.world > 1 && h->store.schema().has_combine)
-        return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated on a sharded graph: a state's operands may live on different shards (use replicas)");
+    // (schemas with `&` / `-` on a sharded graph: the snapshot builds like any other; which entry points evaluate it is ShardCall::begin's business)
     const int64_t now = h->store.now();
     if (h->snap_valid && h->all_dev_valid() && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
     // a few committed writes since the snapshot: patch the rows they touch instead of rebuilding 10 M relationships

@@ -229,6 +229,9 @@ struct PassCtx {
     uint64_t frontier_entries = 0;
     uint32_t max_chunks = 0;
     uint32_t *h_status = nullptr;  // pinned
+    DevArray<uint32_t> d_ccount;   // [2] sharded graph, schemas with `&` / `-`: {leaf cells handed out, nodes appended} of this shard (the unsharded level loop counts in the status block)
+    DevArray<uint4> d_nodes_all;   // ... the shards' node lists, all-gathered behind the walk
+    uint32_t shard_pool_shift = 0; // ... log2 of how far the node / cell pools have been grown beyond their first size (kOverflowPools)
     DevArray<uint32_t> d_done;     // [1] arrival counter of a small host batch's blocks (zero between launches: the last block re-arms it; kernels.hip done_flag)
     uint32_t done_seq = 0;         // the value the next such launch stores into its pinned completion word
     // batch scratch
@@ -484,7 +487,7 @@ struct ShardCall {
     ShardCall(const ShardCall &) = delete;
     ShardCall &operator=(const ShardCall &) = delete;
     ~ShardCall();
-    int begin(acl_engine *h_, bool fresh, bool need_reverse);
+    int begin(acl_engine *h_, bool fresh, bool need_reverse, bool combine_ok = false /* the caller evaluates schemas with `&` / `-` (the native Check loop) */);
 };
 DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap);
 int new_ctx(acl_engine *h, DevState *d, std::unique_ptr<PassCtx> *out, int index);  // (leaves the calling thread on d's device)

@@ -19,7 +19,7 @@ DevShard dev_shard(acl_engine *h, PassCtx *c, void *d_export, size_t cap) {
 }
 
 // one call of the step protocol: shard_mu + state_mu shared (+ the snapshot brought up to date when `fresh`)
-int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse) {
+int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse, bool combine_ok) {
     h = h_;
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     HIP_TRY(hipSetDevice(h->dev0().device));  // (the sharded entry points run on the first replica)
@@ -36,8 +36,10 @@ int ShardCall::begin(acl_engine *h_, bool fresh, bool need_reverse) {
         int rc = need_reverse ? ensure_reverse(h) : ensure_snapshot(h);
         if (rc) return rc;
     }
-    if (h->store.schema().has_combine)  // (the sharded kernels are the monotone instantiations: a state's operands may live on different shards)
-        return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion cannot be evaluated through the sharded entry points (use replicas)");
+    // Schemas with `&` / `-` / `.all()`: Check through the native loop (acl_shard_check_bulk: cells in per-shard ranges of one global cell space,
+    // round 5).  The host-driven step protocol and LookupResources on the sharded graph still refuse them.
+    if (h->store.schema().has_combine && !combine_ok)
+        return fail(ACL_ERR_FAILED_PRECONDITION, "a schema with intersection / exclusion is evaluated on the sharded graph by acl_shard_check_bulk only (LookupResources and the step protocol: use replicas)");
     if (!h->shard_ctx) {
         std::unique_ptr<PassCtx> nc;
         int rc = new_ctx(h, &h->dev0(), &nc, -1);

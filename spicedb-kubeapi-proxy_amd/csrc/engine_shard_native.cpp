@@ -168,8 +168,8 @@ struct Exchange {
             st->entries_exchanged += k[0];
             if (seen->size() <= it) seen->resize(it + 1, 0);
             (*seen)[it] = k[0] ? 1 : 0;
-            if (k[2]) {  // some shard overflowed (frontier, export block, a row beyond the enumeration limit) or exported on a level planned without entries
-                *redo_code = (k[2] & 2u) ? 2u : (k[2] & 1u) ? 1u : 4u;
+            if (k[2]) {  // some shard overflowed (frontier, export block, a row beyond the enumeration limit, the combine pools) or exported on a level planned without entries
+                *redo_code = (k[2] & 2u) ? 2u : (k[2] & kOverflowPools) ? kOverflowPools : (k[2] & 1u) ? 1u : 4u;
                 *redo_max = std::max(*redo_max, k[3]);
                 return 2;
             }
@@ -190,6 +190,10 @@ struct Exchange {
             plan->clear();  // exports where none were expected: entries on every level from now on
             return ACL_OK;
         }
+        if (redo_code == kOverflowPools) {  // a shard ran out of combine nodes / leaf cells: four times the pools (every shard alike)
+            c->shard_pool_shift += 2;
+            return ACL_OK;
+        }
         if (redo_max > cap) {
             uint32_t nc = cap;
             while (nc < redo_max + redo_max / 4 && nc < (1u << 27)) nc <<= 1;
@@ -208,21 +212,23 @@ uint32_t first_xcap(PassCtx *c) {
     return c->xcap;
 }
 
-}  // namespace
-
-extern "C" {
-
-int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const void *d_items, size_t n, void *d_perm_out, void *d_err_out,
-                         acl_shard_bulk_stats_t *stats_out) {
-    if (!comm || !comm->all_gather || !comm->all_reduce_max_u8) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: communicator callbacks missing");
-    if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: NULL buffer");
-    if (n > 0xFFFFFFFFu) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: batch too large");
-    ShardCall sc;
-    int rc = sc.begin(h, true, false);
-    if (rc) return rc;
-    PassCtx *c = sc.c;
+// the native Check loop on context c (the caller holds the shard call's locks): acl_shard_check_bulk, and the forward half of LookupResources over
+// a non-monotone permission (candidates + one Check)
+int shard_check_core(acl_engine_t *h, PassCtx *c, const acl_shard_comm_t *comm, const void *d_items, size_t n, void *d_perm_out, void *d_err_out,
+                     acl_shard_bulk_stats_t *stats_out) {
+    int rc = ACL_OK;
     acl_shard_bulk_stats_t st{};
     Exchange X{h, c, comm, h->shard.world, h->shard.rank, 0, comm->all_to_all != nullptr && h->shard.world <= kMaxShards && h->shard_a2a, &st, &c->xplan_fwd};
+    // Schemas with `&` / `-` / `.all()` on the sharded graph (round 5).  A state with a combine program is visited on the shard
+    // that owns its type: that shard appends the CombineNode and hands out the state's leaf cells from ITS range of one global cell space --
+    // cell ids [n + r cell_cap, n + (r + 1) cell_cap) belong to shard r, and a cell id is what a frontier entry carries where the request
+    // was, so the leaves' sub-walks cross shards like any other entry.  Every shard keeps has / err bytes for the WHOLE cell space and sets
+    // whatever a sub-walk answers locally; behind the walk a byte-wise max makes the arrays identical everywhere (HAS / error bytes are only ever
+    // raised during the walk), the node lists are all-gathered, and every shard resolves ALL nodes deepest iteration first -- redundantly and
+    // identically, so nothing travels between the resolve iterations.
+    const bool combine = h->snap.has_combine;
+    const uint32_t world = h->shard.world;
+    size_t node_cap = 0, cell_cap = 0, cells = 0;
     HIP_TRY(c->d_has.ensure(std::max<size_t>(n, 4096)));
     HIP_TRY(c->d_err.ensure(std::max<size_t>(n, 4096)));
     if ((uint64_t)n > c->frontier_entries) {
@@ -237,6 +243,25 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
         if (rc) return rc;
         uint32_t *hc = (uint32_t *)c->h_xctrl.p;
         DevGraph g = h->dev_graph(c);
+        if (combine) {
+            node_cap = std::max<size_t>((size_t)1 << 16, n * 4) << c->shard_pool_shift;
+            cell_cap = node_cap * 4;
+            cells = (size_t)world * cell_cap;
+            if ((uint64_t)n + cells >= 0xFFFFFFF0ull) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "combine cells beyond 2^32 on the sharded graph: smaller batches");
+            HIP_TRY(c->d_nodes.ensure(node_cap));
+            HIP_TRY(c->d_has.ensure(n + cells));
+            HIP_TRY(c->d_err.ensure(n + cells));
+            HIP_TRY(c->d_ccount.ensure(2));
+            HIP_TRY(hipMemsetAsync(c->d_ccount.p, 0, 2 * sizeof(uint32_t), c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_has.p + n, 0, cells, c->stream));  // (the other shards' cells too: the max behind the walk reads every byte)
+            HIP_TRY(hipMemsetAsync(c->d_err.p + n, 0, cells, c->stream));
+            g.bexpr = c->dev->d_bexpr.p;
+            g.nodes = c->d_nodes.p;
+            g.node_cap = (uint32_t)node_cap;
+            g.cell_cap = (uint32_t)cell_cap;
+            g.cell0 = (uint32_t)(n + (size_t)X.rank * cell_cap);
+            g.ccount = c->d_ccount.p;
+        }
         DevFrontier f = h->dev_frontier(*c);
         DevShard sh = X.shard();
         HIP_TRY(hipMemsetAsync(c->d_xctrl.p, 0, (size_t)kLevelSlots * kCtrlWords * sizeof(uint32_t), c->stream));
@@ -283,10 +308,33 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
     }
     // HAS beats error beats NO: a byte-wise max across shards, then the answers on every shard
     if (n) {
-        rc = comm->all_reduce_max_u8(comm->user, c->d_has.p, n, (void *)c->stream);
+        rc = comm->all_reduce_max_u8(comm->user, c->d_has.p, n + cells, (void *)c->stream);
         if (rc) return rc;
-        rc = comm->all_reduce_max_u8(comm->user, c->d_err.p, n, (void *)c->stream);
+        rc = comm->all_reduce_max_u8(comm->user, c->d_err.p, n + cells, (void *)c->stream);
         if (rc) return rc;
+    }
+    if (combine && n) {
+        // the shards' node lists: counts first (16-byte headers), then blocks of the largest count; resolved on every shard alike
+        HIP_TRY(c->d_xhsend.ensure(std::max<uint32_t>(world, 64)));
+        HIP_TRY(c->d_xhrecv.ensure(std::max<uint32_t>(world, 64)));
+        launch_node_hdr(c->stream, c->d_xhsend.p, c->d_ccount.p);
+        rc = comm->all_gather(comm->user, c->d_xhsend.p, c->d_xhrecv.p, sizeof(uint4), (void *)c->stream);
+        if (rc) return rc;
+        std::vector<uint4> hh(world);
+        HIP_TRY(hipMemcpyAsync(hh.data(), c->d_xhrecv.p, (size_t)world * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        st.host_syncs++;
+        uint32_t maxc = 0;
+        for (const uint4 &x : hh) maxc = std::max(maxc, std::min<uint32_t>(x.x, (uint32_t)node_cap));
+        if (maxc) {
+            HIP_TRY(c->d_nodes_all.ensure((size_t)world * maxc));
+            rc = comm->all_gather(comm->user, c->d_nodes.p, c->d_nodes_all.p, (size_t)maxc * sizeof(uint4), (void *)c->stream);
+            if (rc) return rc;
+            st.exchanged_bytes += (uint64_t)world * maxc * sizeof(uint4);
+            DevGraph g = h->dev_graph(c);
+            g.bexpr = c->dev->d_bexpr.p;
+            for (uint32_t it = std::max<uint32_t>(st.levels, 1); it >= 1; it--) launch_resolve_gathered(c->stream, g, c->d_nodes_all.p, maxc, c->d_xhrecv.p, world, it, c->d_has.p, c->d_err.p);
+        }
     }
     ev_begin(c, 0);
     launch_finalize(c->stream, (uint32_t)n, c->d_has.p, c->d_err.p, (uint8_t *)d_perm_out, (int32_t *)d_err_out);
@@ -302,6 +350,21 @@ int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const vo
     return ACL_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int acl_shard_check_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, const void *d_items, size_t n, void *d_perm_out, void *d_err_out,
+                         acl_shard_bulk_stats_t *stats_out) {
+    if (!comm || !comm->all_gather || !comm->all_reduce_max_u8) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: communicator callbacks missing");
+    if (n && (!d_items || !d_perm_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: NULL buffer");
+    if (n > 0xFFFFFFFFu) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_check_bulk: batch too large");
+    ShardCall sc;
+    int rc = sc.begin(h, true, false, true);
+    if (rc) return rc;
+    return shard_check_core(h, sc.c, comm, d_items, n, d_perm_out, d_err_out, stats_out);
+}
+
 // LookupResources (pkg/authz/lookups.go:49-83) for n subjects of one class on the sharded graph, the whole reverse level loop inside the
 // library.  Iteration 1 expands the seeds; then pairs (VISIT: first visits marked, states whose parents' rows also live on other shards
 // exported -> exchange -> import of the foreign states this shard holds parent rows for | EXPAND) until a visit step neither produced nor
@@ -314,7 +377,7 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
     if (!comm || !comm->all_gather || !comm->all_reduce_max_u8) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_bulk: communicator callbacks missing");
     if (n && (!sids || !d_bitmaps_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_shard_lookup_bulk: NULL buffer");
     ShardCall scall;
-    int rc = scall.begin(h, true, true);
+    int rc = scall.begin(h, true, true, true);
     if (rc) return rc;
     PassCtx *c = scall.c;
     const Schema &sc = h->store.schema();
@@ -412,6 +475,43 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
     HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
     st.host_syncs++;
+    // Schemas with `&` / `-` (round 5): the reverse walk follows only POSITIVE occurrences (plan_reverse.cpp), so the rows are candidates -- a
+    // superset.  The answer is the candidates the forward walk grants: every shard holds the same rows by now, builds the same items and takes
+    // part in ONE sharded Check (shard_check_core: the collectives stay in lockstep); bits of everything but HAS are cleared (as lookup_refine on
+    // the unsharded graph).
+    if (n && h->snap.has_combine && !h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) {
+        std::vector<uint32_t> rows(n * bitmap_words);
+        HIP_TRY(hipMemcpy(rows.data(), d_bitmaps_out, rows.size() * 4, hipMemcpyDeviceToHost));
+        const uint16_t sr = (uint16_t)(srel < 0 ? ACL_NO_RELATION : srel);
+        std::vector<acl_item_t> items;
+        for (size_t i = 0; i < n; i++)
+            for (size_t w = 0; w < bitmap_words; w++)
+                for (uint32_t m = rows[i * bitmap_words + w]; m; m &= m - 1)
+                    items.push_back(acl_item_t{(uint16_t)rtype, (uint16_t)perm, (uint32_t)(w * 32 + (size_t)__builtin_ctz(m)), (uint16_t)stype, sr, sids[i]});
+        if (items.size() > 0xFFFFFFF0ull) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "lookup over a non-monotone permission: too many candidates for one Check");
+        if (!items.empty()) {
+            HIP_TRY(c->d_items.ensure(items.size()));
+            HIP_TRY(c->d_perm.ensure(items.size()));
+            HIP_TRY(hipMemcpy(c->d_items.p, items.data(), items.size() * sizeof(acl_item_t), hipMemcpyHostToDevice));
+            acl_shard_bulk_stats_t cst{};
+            rc = shard_check_core(h, c, comm, c->d_items.p, items.size(), c->d_perm.p, nullptr, &cst);
+            if (rc) return rc;
+            st.exchanges += cst.exchanges;
+            st.entries_exchanged += cst.entries_exchanged;
+            st.exchanged_bytes += cst.exchanged_bytes;
+            st.host_syncs += cst.host_syncs;
+            std::vector<uint8_t> ans(items.size());
+            HIP_TRY(hipMemcpy(ans.data(), c->d_perm.p, ans.size(), hipMemcpyDeviceToHost));
+            size_t k = 0;
+            for (size_t i = 0; i < n; i++)
+                for (size_t w = 0; w < bitmap_words; w++) {
+                    uint32_t &word = rows[i * bitmap_words + w];
+                    for (uint32_t m = word; m; m &= m - 1, k++)
+                        if (ans[k] != ACL_PERM_HAS_PERMISSION) word &= ~(m & (0u - m));
+                }
+            HIP_TRY(hipMemcpy(d_bitmaps_out, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     st.export_capacity = c->xcap;
     c->stats.lookup_requests += n;
     c->stats.levels_last = st.levels;

@@ -790,7 +790,7 @@ __device__ __forceinline__ void flush_tasks(TaskLds &t, uint32_t T, WaveOut &wo,
                             if (lane == 0) *wo.cold->overflow = 1u;
                             wo.cur = kNoSpace;
                         } else if (lane == 0) {
-                            *wo.cold->overflow = 3u;
+                            *wo.cold->overflow = SHARDED ? kOverflowPools : 3u;
                         }
                         if (isall) push = live = false;
                     } else if (isall) {
@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                         if (lane == 0) *wo.cold->overflow = 1u;
                         wo.cur = kNoSpace;
                     } else if (lane == 0) {
-                        *wo.cold->overflow = 3u;
+                        *wo.cold->overflow = SHARDED ? kOverflowPools : 3u;
                     }
                     if (over) active = cmb = false;
                 }
@@ -1800,6 +1800,23 @@ __global__ __launch_bounds__(256) void k_resolve(DevGraph g, uint32_t iter, uint
     }
 }
 
+// Sharded graph, schemas with `&` / `-` (round 5): every shard appended the combine nodes of the states IT visited; after the walk the node lists are
+// all-gathered (world blocks of `stride` nodes, block b holding hdrs[b].x of them) and, has / err being identical on every shard by then (a
+// byte-wise max over the whole cell space), every shard resolves ALL nodes -- redundantly and identically, so no cell has to travel between
+// the resolve iterations.
+__global__ __launch_bounds__(256) void k_resolve_gathered(DevGraph g, const uint4 *__restrict__ nodes, uint32_t stride, const uint4 *__restrict__ hdrs, uint32_t iter, uint32_t members,
+                                                          uint8_t *has, uint8_t *err) {
+    const uint32_t nn = min(hdrs[blockIdx.y].x, stride);
+    const uint4 *__restrict__ mine = nodes + (size_t)blockIdx.y * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const uint4 nd = mine[i];
+        if ((nd.z >> 16) != iter || (nd.w != 0u) != (members != 0u)) continue;
+        if (members) resolve_member(nd, has, err);
+        else resolve_node(nd, g.progs, g.bexpr, has, err);
+    }
+}
+__global__ void k_node_hdr(uint4 *hdr, const uint32_t *ccount) { *hdr = make_uint4(ccount[1], ccount[0], 0u, 0u); }  // {nodes appended, cells handed out}
+
 // Post-filter hand-off (reference pkg/authz/postfilter.go:144-178): list item i owns the bulk-check pairs
 // [item_off[i], item_off[i+1]); it is kept iff every one of them is HAS_PERMISSION without error -- an item
 // with no pairs (templates that did not resolve, postfilter.go:92-95,145-150) is kept.
@@ -2431,7 +2448,12 @@ void launch_seed(hipStream_t s, const DevGraph &g, const DevFrontier &f, const u
 void launch_expand(hipStream_t s, const DevGraph &g, const DevFrontier &f, uint32_t iter, uint8_t *has, uint8_t *err, const DevShard &sh) {
     const dim3 grid(f.nwaves / kWavesPerBlock);
     const bool lds = g.nslots + g.nops <= kProgLdsEntries && prog_in_lds();
-    if (g.bexpr) {  // schemas with `&` / `-` (never sharded: acl_shard_configure refuses them)
+    if (g.bexpr) {  // schemas with `&` / `-`
+        if (sh.world > 1) {  // (round 5: the sharded graph too -- cells in per-shard ranges of one global cell space, engine_shard_native.cpp)
+            if (lds) hipLaunchKernelGGL((k_expand<true, true, true>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
+            else hipLaunchKernelGGL((k_expand<false, true, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
+            return;
+        }
         if (lds) hipLaunchKernelGGL((k_expand<true, false, true>), grid, dim3(kBlock), prog_lds_bytes(g), s, g, f, iter, has, err, sh);
         else hipLaunchKernelGGL((k_expand<false, false, true>), grid, dim3(kBlock), 0, s, g, f, iter, has, err, sh);
         return;
@@ -2515,6 +2537,11 @@ void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_
 void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err) {
     hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, 1u, has, err);
     hipLaunchKernelGGL(k_resolve, dim3(256), dim3(256), 0, s, g, iter, 0u, has, err);
+}
+void launch_node_hdr(hipStream_t s, uint4 *hdr, const uint32_t *ccount) { hipLaunchKernelGGL(k_node_hdr, dim3(1), dim3(1), 0, s, hdr, ccount); }
+void launch_resolve_gathered(hipStream_t s, const DevGraph &g, const uint4 *nodes, uint32_t stride, const uint4 *hdrs, uint32_t world, uint32_t iter, uint8_t *has, uint8_t *err) {
+    hipLaunchKernelGGL(k_resolve_gathered, dim3(64, world), dim3(256), 0, s, g, nodes, stride, hdrs, iter, 1u, has, err);
+    hipLaunchKernelGGL(k_resolve_gathered, dim3(64, world), dim3(256), 0, s, g, nodes, stride, hdrs, iter, 0u, has, err);
 }
 void launch_rev_seed(hipStream_t s, const DevFrontier &f, const uint32_t *d_sids, uint32_t n, uint32_t key) {
     const uint32_t threads = std::max(std::max(n, f.nwaves), kStatusWords);

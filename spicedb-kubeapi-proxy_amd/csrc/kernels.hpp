@@ -42,6 +42,7 @@ struct DevGraph {
                                        // pair of segments with more children than the direct form's head-bit window: kernels.hip, process_segment)
 };
 constexpr uint32_t kWalkNoDirect = 1u;
+constexpr uint32_t kOverflowPools = 8u;   // level loop on the SHARDED graph, schemas with `&` / `-`: a shard ran out of combine nodes / leaf cells -- the native loop grows the pools and redoes the batch
 constexpr uint32_t kOverflowDirect = 4u;  // single-launch walk's overflow code: "redo, and stop using the direct task lists on this snapshot"
 struct DevReverse {
     const uint32_t *rmeta, *redges;  // uint2 {start, end} per (relation, class, subject); resource ids
@@ -126,6 +127,10 @@ void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_
 // level loop, schemas with `&` / `-`: evaluates the combine nodes of frontier iteration `iter` (call for iter = last .. 1: a node only depends
 // on nodes of later iterations); the node count is read from g.ccount[1] on the device
 void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err);
+// sharded graph, schemas with `&` / `-`: {nodes appended, cells handed out} of this shard as a 16-byte header; the gathered node lists (world blocks of `stride`
+// nodes, hdrs[b].x valid ones in block b) resolved for frontier iteration `iter` (members first), on every shard alike
+void launch_node_hdr(hipStream_t s, uint4 *hdr, const uint32_t *ccount);
+void launch_resolve_gathered(hipStream_t s, const DevGraph &g, const uint4 *nodes, uint32_t stride, const uint4 *hdrs, uint32_t world, uint32_t iter, uint8_t *has, uint8_t *err);
 void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f, uint32_t iter, uint32_t phase = REV_FUSED,
                        const DevShard &sh = DevShard());
 // single-launch LookupResources: block b walks lookup b (subject sids[b] of class `key`) through every reverse level; visited rows r.visited

@@ -546,3 +546,199 @@ def test_native_loops_between_two_processes_on_one_gpu(a2a, window, aclgpu, tmp_
         assert outs[0]["check"][k]["stats"]["levels"] == outs[1]["check"][k]["stats"]["levels"]
         assert outs[0]["check"][k]["stats"]["entries_exchanged"] == outs[1]["check"][k]["stats"]["entries_exchanged"]
     assert all(o_["local_relationships"] > 0 for o_ in outs)  # both shards hold rows
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_native_loop_combine_schema_bans_workload(world, aclgpu):
+    """schemas with `-`, `&`, `T:*` and a non-monotone userset subject (`group#active`) on the SHARDED graph.  The native
+    Check loop hands out leaf cells from per-shard ranges of one global cell space, maxes the whole cell space behind the walk, gathers the
+    shards' combine nodes and resolves all of them on every shard: `view` = (...) - banned, `strict` = creator & namespace->view, `loose`
+    (pure union, same kernels) and `group#active` equal the oracle's on 2 / 5 / 8 logical shards, twice (the second batch runs on the plan
+    the first one left)."""
+    from aclgpu import sharded
+    from tests.test_combine_gpu import SCHEMA_BANS, bans_graph, load_numeric
+    E, n = bans_graph(11, n_user=2000, n_group=300, n_ns=100, n_pod=8000)
+    co = orc.Oracle(SCHEMA_BANS)
+    load_numeric(co, E)
+    co.freeze()
+    rng = np.random.default_rng(3)
+    B = 30000
+    res = rng.integers(0, n["pod"], size=B).astype(np.uint32)
+    sub = rng.integers(0, n["user"], size=B).astype(np.uint32)
+    creators = dict(zip(E[8][4].tolist(), E[8][5].tolist()))
+    for i in range(0, B, 3):
+        sub[i] = creators[int(res[i])]
+    gres = rng.integers(0, n["group"], size=5000).astype(np.uint32)
+    gsub = rng.integers(0, n["user"], size=5000).astype(np.uint32)
+    want = {p: co.check_bulk_ids_mt(8, "pod", p, res, "user", "", sub) for p in ("view", "strict", "loose")}
+    want_g = co.check_bulk_ids_mt(8, "group", "active", gres, "user", "", gsub)
+    assert all(0 < int((w[0] == 2).sum()) < B for w in want.values())
+    lsubs = np.array([int(x) for x in rng.integers(0, n["user"], size=5)] + [int(sub[0])], dtype=np.uint32)
+    want_lk = {p: [np.sort(co.lookup_ids("pod", p, "user", "", int(s_))) for s_ in lsubs] for p in ("view", "strict")}
+    want_lk["active"] = [np.sort(co.lookup_ids("group", "active", "user", "", int(s_))) for s_ in lsubs]
+    assert sum(x.size for x in want_lk["view"]) > 0
+    engines = []
+
+    def make(rank, nshards):
+        e = aclgpu.Engine(SCHEMA_BANS, contexts=1)
+        load_numeric(e, E)
+        engines.append(e)
+        return sharded.GpuShard(e, rank, nshards)
+
+    def run(se):
+        e = se.shard.e
+        out = {}
+        for _round in range(2):
+            for p in ("view", "strict", "loose"):
+                pp, er, stats = se.check_bulk_ids_native(e.make_items("pod", p, res, "user", "", sub))
+                out[(p, _round)] = (pp.cpu().numpy(), er.cpu().numpy(), stats)
+        pp, er, stats = se.check_bulk_ids_native(e.make_items("group", "active", gres, "user", "", gsub))
+        out["g"] = (pp.cpu().numpy(), er.cpu().numpy(), stats)
+        # Filter over non-monotone permissions: the sharded reverse walk's candidates + ONE sharded Check
+        for p in ("view", "strict"):
+            bm, lstat = se.lookup_ids_batch_native("pod", p, "user", "", lsubs)
+            out[("lk", p)] = ([bits(bm[i]) for i in range(len(lsubs))], lstat)
+        bm, lstat = se.lookup_ids_batch_native("group", "active", "user", "", lsubs)
+        out[("lk", "active")] = ([bits(bm[i]) for i in range(len(lsubs))], lstat)
+        return out
+
+    try:
+        outs = sharded.run_logical_shards(world, make, run)
+    finally:
+        for e in engines:
+            e.close()
+    moved = 0
+    for out in outs:
+        for p in ("view", "strict", "loose"):
+            for r in range(2):
+                got = out[(p, r)]
+                assert np.array_equal(got[0], want[p][0]) and np.array_equal(got[1], want[p][1]), (world, p, r, int((got[0] != want[p][0]).sum()))
+                moved += got[2]["entries_exchanged"]
+        assert np.array_equal(out["g"][0], want_g[0]) and np.array_equal(out["g"][1], want_g[1])
+        for p in ("view", "strict", "active"):
+            for got_ids, want_ids in zip(out[("lk", p)][0], want_lk[p]):
+                assert np.array_equal(got_ids, want_ids), (world, p, got_ids.size, want_ids.size)
+    assert moved > 0  # (sub-walks of leaf cells did cross shards)
+
+
+def test_native_loop_combine_schema_named_cases(aclgpu):
+    """The combine reference case (tests/ref_cases.py: precedence, wildcards in positive and subtracted operands, arrows into non-monotone
+    permissions, intersection arrows over several folders, depth errors on both sides of `&` / `-` through a 60-long chain) on 3 logical
+    shards: every answer equals the C oracle's AND the independent Python oracle's."""
+    from aclgpu import sharded
+    from oracle.pyoracle import PyOracle
+    from tests import ref_cases
+    from tests.test_combine_gpu import PY2C
+    case = ref_cases._combine_case()
+    co, po = orc.Oracle(case["schema"]), PyOracle(case["schema"])
+    co.write([(orc.OP_TOUCH, r) for r in case["relationships"]])
+    for r in case["relationships"]:
+        po.touch(*r)
+    queries = case["checks"]
+    want = [co.check(*q) for q in queries]
+    assert want == [PY2C[po.check(*q)] for q in queries]
+    assert any(w[1] for w in want) and any(w[0] == 2 for w in want)
+    engines = []
+
+    def make(rank, nshards):
+        e = aclgpu.Engine(case["schema"], contexts=1)
+        rels = case["relationships"]
+        for i in range(0, len(rels), 1000):
+            e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 1000]])
+        for q in queries:  # (unknown objects get ids too: every shard interns the same names in the same order)
+            e.intern(q[0], q[1])
+            e.intern(q[3], q[4])
+        engines.append(e)
+        return sharded.GpuShard(e, rank, nshards)
+
+    def run(se):
+        e = se.shard.e
+        items = np.zeros(len(queries), dtype=aclgpu.ITEM_DTYPE)
+        for i, (rt, rid, pm, st, sid, sr) in enumerate(queries):
+            items[i] = (e.type_id(rt), e.relation_id(rt, pm), e.find(rt, rid), e.type_id(st), e.relation_id(st, sr) if sr else aclgpu.NO_RELATION, e.find(st, sid))
+        p, er, _s = se.check_bulk_ids_native(items)
+        return list(zip(p.cpu().tolist(), er.cpu().tolist()))
+
+    try:
+        outs = sharded.run_logical_shards(3, make, run)
+    finally:
+        for e in engines:
+            e.close()
+    for got in outs:
+        bad = [(q, g, w) for q, g, w in zip(queries, got, want) if g != w]
+        assert not bad, bad[:5]
+
+
+IPC_WORLD_COMBINE = r"""
+import os, sys, json, types
+import numpy as np, torch
+sys.path[:0] = [os.environ["ACL_ROOT"], os.path.join(os.environ["ACL_ROOT"], "spicedb-kubeapi-proxy_amd")]
+import aclgpu
+from aclgpu import sharded
+from oracle import orc
+from tests.test_combine_gpu import SCHEMA_BANS, bans_graph, load_numeric
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+E, n = bans_graph(11, n_user=2000, n_group=300, n_ns=100, n_pod=8000)
+o = orc.Oracle(SCHEMA_BANS); load_numeric(o, E); o.freeze()
+rng = np.random.default_rng(3)
+B = 20000
+res = rng.integers(0, n["pod"], size=B).astype(np.uint32)
+sub = rng.integers(0, n["user"], size=B).astype(np.uint32)
+creators = dict(zip(E[8][4].tolist(), E[8][5].tolist()))
+for i in range(0, B, 3):
+    sub[i] = creators[int(res[i])]
+subs = np.array([int(x) for x in rng.integers(0, n["user"], size=4)] + [int(sub[0])], dtype=np.uint32)
+e = aclgpu.Engine(SCHEMA_BANS, contexts=1); load_numeric(e, E)
+ipc = sharded.IpcNative(os.environ["IPC_NAME"], rank, world, device=0, window_bytes=int(os.environ["IPC_WINDOW"]), deadline_s=120, with_all_to_all=os.environ["ACL_SHARD_A2A"] == "1")
+se = sharded.ShardedEngine(sharded.GpuShard(e, rank, world), types.SimpleNamespace(rank=rank, world=world), native=ipc)
+ipc.barrier()
+out = {"check": {}, "lookup": {}}
+for perm in ("view", "strict", "loose"):
+    want = o.check_bulk_ids_mt(4, "pod", perm, res, "user", "", sub)
+    for rnd in range(2):
+        p, er, st = se.check_bulk_ids_native(e.make_items("pod", perm, res, "user", "", sub))
+        out["check"][f"{perm}/{rnd}"] = {"ok": bool(np.array_equal(p.cpu().numpy(), want[0]) and np.array_equal(er.cpu().numpy(), want[1])), "stats": st, "has": int((want[0] == 2).sum())}
+for perm in ("view", "strict"):
+    bm, lstat = se.lookup_ids_batch_native("pod", perm, "user", "", subs)
+    rows = bm.cpu().numpy().view(np.uint32)
+    ok = all(np.array_equal(np.flatnonzero(np.unpackbits(rows[i].view(np.uint8), bitorder="little")), np.sort(o.lookup_ids("pod", perm, "user", "", int(s)))) for i, s in enumerate(subs))
+    out["lookup"][perm] = {"ok": bool(ok), "stats": lstat, "ids": int(sum(int(np.unpackbits(rows[i].view(np.uint8)).sum()) for i in range(len(subs))))}
+print(json.dumps({"rank": rank, "pid": os.getpid(), **out, "ipc": ipc.stats(), "local_relationships": e.stats()["snapshot_edges_local"]}))
+ipc.barrier()
+ipc.close(); e.close()
+"""
+
+
+@pytest.mark.parametrize("a2a", [True, False])
+def test_native_loops_combine_schema_between_two_processes(a2a, aclgpu):
+    """The "banned users" schema (`-`, `&`, `T:*`, a non-monotone userset subject) on TWO PROCESSES sharing the GPU, one shard each, over the hipIpc
+    communicator: Check (three permissions, twice) and LookupResources (candidates + one sharded Check) equal the oracle's on both ranks; leaf
+    cells' sub-walks crossed the process boundary (entries_exchanged > 0)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    name = f"/aclipc-cmb-{os.getpid()}-{int(a2a)}"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0", IPC_NAME=name, IPC_WINDOW=str(8 << 20), ACL_SHARD_A2A="1" if a2a else "0",
+                   ACL_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        procs.append(subprocess.Popen([sys.executable, "-c", IPC_WORLD_COMBINE], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            so, se_ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, so[-3000:] + se_[-3000:]
+        outs.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+    assert outs[0]["pid"] != outs[1]["pid"]
+    for o_ in outs:
+        assert all(v["ok"] for v in o_["check"].values()), (o_["rank"], {k: v["stats"] for k, v in o_["check"].items() if not v["ok"]})
+        assert all(v["ok"] for v in o_["lookup"].values()), (o_["rank"], o_["lookup"])
+        assert o_["check"]["view/0"]["stats"]["entries_exchanged"] > 0 and 0 < o_["check"]["view/0"]["has"] < 20000
+        assert o_["lookup"]["view"]["ids"] > 0 and o_["ipc"]["foreign_bytes"] > 0
+    assert all(o_["local_relationships"] > 0 for o_ in outs)
