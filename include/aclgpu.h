@@ -396,7 +396,10 @@ int acl_shard_lookup_finish(acl_engine_t *h, void *d_bitmaps_out, size_t bitmap_
  * ncclComm_t (the cgo shim) or a test double plugs in the same way.  Callbacks enqueue on `hip_stream` and return 0 or an ACL_ERR_* code.
  * all_to_all may be NULL: Check then exchanges one block per shard through all_gather (every shard receives everything and keeps what it
  * owns) instead of one block per (shard, destination) -- `world` times the bytes.  LookupResources travels the same way: a visited state
- * goes into the block of every shard that holds parent rows for its slot (all_to_all), or to everybody (all_gather). */
+ * goes into the block of every shard that holds parent rows for its slot (all_to_all), or to everybody (all_gather).
+ * Schemas with intersection / exclusion / `.all()` (reference pkg/spicedb/spicedb.go:19-24 boots any schema): evaluated by these two entry points
+ * (the host-driven step protocol above refuses them) -- leaf cells come from per-shard ranges of one global cell space, all_reduce_max_u8 then
+ * covers the batch's cells as well as its answers and the shards' combine nodes travel through all_gather once per batch. */
 typedef struct {
     void *user;
     int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);
