@@ -203,10 +203,10 @@ static void compaction_start(acl_engine *h) {
         pd.device = h->devs[i]->device;
         if (!pd.stream && (hipSetDevice(pd.device) != hipSuccess || hipStreamCreateWithFlags(&pd.stream, hipStreamNonBlocking) != hipSuccess)) return;
     }
-    auto view = std::make_shared<Store>(h->store.view());  // tables shared copy-on-write: O(#tables), not O(#relationships)
+    c->now = h->store.now();
+    auto view = std::make_shared<Store>(h->store.view(c->now));  // tables shared copy-on-write, expiry maps share their sorted bases: O(#tables), not O(#relationships) or O(#expiring keys)
     c->shard = h->shard;
     c->with_reverse = h->all_rev_uploaded();
-    c->now = h->store.now();
     c->error.clear();
     c->state.store(1);
     const size_t ndev = h->devs.size();

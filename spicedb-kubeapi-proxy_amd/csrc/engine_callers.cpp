@@ -9,6 +9,8 @@
 #include <climits>
 #include <tuple>
 
+#include <chrono>
+
 #include "engine_internal.hpp"
 
 // ---------------------------------------------------------------- micro-batching front-end
@@ -655,7 +657,11 @@ int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out) {
     if (!h->compaction) h->compaction = std::make_unique<Compaction>();
     Compaction *c = h->compaction.get();
     if (phase == 0) {
-        Store view = h->store.view();
+        const auto tv0 = std::chrono::steady_clock::now();
+        Store view = h->store.view(now);
+        if (getenv("ACL_DEBUG_REBUILD"))
+            fprintf(stderr, "[aclgpu] view() took %.3f ms with %zu expiring relationships\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count(),
+                    h->store.expiring_relationships());
         c->shard = h->shard;
         c->now = now;
         build_forward(view, now, &c->snap, c->shard);

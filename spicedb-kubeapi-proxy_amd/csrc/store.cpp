@@ -330,15 +330,22 @@ int Store::class_index(int slot, int stype, int srel, bool wildcard) const {
     return -1;
 }
 
-Store Store::view() {
+Store Store::view(int64_t at) {
     settle_all();
     Store v;
     v.schema_ = schema_;
     v.schema_loaded_ = schema_loaded_;
     v.objects_.resize(objects_.size());
     for (size_t t = 0; t < objects_.size(); t++) v.objects_[t].reserve_ids(objects_[t].count());
-    v.tables_ = tables_;  // CowKeys copies share their vectors; the expiry maps and their index are copied
-    v.expiry_index_ = expiry_index_;
+    // CowKeys copies share their vectors; ExpiryMap copies share their sorted bases (folded first: what is copied is a handful of delta
+    // entries); the expiry index is NOT copied -- the one thing a snapshot build asks it is the validity window of its `now`, taken here
+    for (auto &slot : tables_)
+        for (auto &ct : slot)
+            if (ct.expiry.delta_size() > 64) ct.expiry.fold();
+    v.tables_ = tables_;
+    v.frozen_ = true;
+    v.frozen_now_ = at ? at : now();
+    expiry_window(v.frozen_now_, &v.frozen_lo_, &v.frozen_hi_);
     v.wildcard_id_ = wildcard_id_;
     v.revision_ = revision_;
     v.now_override_ = now_override_;
@@ -352,7 +359,37 @@ void Store::settle_all() {
         for (auto &ct : slot) ct.settle();
 }
 
+void ExpiryMap::fold() {
+    if (delta_.empty()) return;
+    std::vector<std::pair<uint64_t, int64_t>> d(delta_.begin(), delta_.end());
+    std::sort(d.begin(), d.end());
+    auto nb = std::make_shared<Base>();
+    nb->reserve((base_ ? base_->size() : 0) + d.size());
+    size_t i = 0, j = 0;
+    const size_t nbase = base_ ? base_->size() : 0;
+    while (i < nbase || j < d.size()) {
+        if (j == d.size() || (i < nbase && (*base_)[i].first < d[j].first)) nb->push_back((*base_)[i++]);
+        else {
+            if (i < nbase && (*base_)[i].first == d[j].first) i++;  // (the delta's word on this key replaces the base's)
+            if (d[j].second != kGone) nb->push_back(d[j]);
+            j++;
+        }
+    }
+    base_ = std::move(nb);
+    delta_.clear();
+}
+
 void Store::expiry_window(int64_t now, int64_t *lo, int64_t *hi) const {
+    if (frozen_) {  // a view(): the window of the `now` it was taken at; any other `now` gets the empty window [now, now + 1) -- never too wide
+        if (now == frozen_now_) {
+            *lo = frozen_lo_;
+            *hi = frozen_hi_;
+        } else {
+            *lo = now;
+            *hi = now + 1;
+        }
+        return;
+    }
     *lo = LLONG_MIN;
     *hi = LLONG_MAX;
     // first entry expiring after `now`; the one before it is the last that expired at or before `now`
@@ -372,14 +409,14 @@ void Store::expiry_crossings(int64_t lo, int64_t hi, int64_t now, std::vector<Ch
 
 void Store::set_expiry(int slot, int cls, uint64_t key, int64_t at) {
     ClassTable &ct = tables_[slot][cls];
-    auto it = ct.expiry.find(key);
-    if (it != ct.expiry.end()) {
-        if (it->second == at) return;
-        expiry_index_.erase(ExpiryEntry{it->second, slot, cls, key});
-        if (at) it->second = at;
-        else ct.expiry.erase(it);
+    int64_t old;
+    if (ct.expiry.find(key, &old)) {
+        if (old == at) return;
+        expiry_index_.erase(ExpiryEntry{old, slot, cls, key});
+        if (at) ct.expiry.set(key, at);
+        else ct.expiry.erase(key);
     } else if (at) {
-        ct.expiry.emplace(key, at);
+        ct.expiry.set(key, at);
     }
     if (at) expiry_index_.insert(ExpiryEntry{at, slot, cls, key});
 }
@@ -712,8 +749,8 @@ Status Store::read(const FilterText &f, const std::function<void(const RelText &
     if (!s.ok()) return s;
     scan(f, now(), [&](int slot, int cls, uint64_t key) {
         RelText r = rel_text(slot, cls, key);
-        auto e = tables_[slot][cls].expiry.find(key);
-        r.expires_at = e == tables_[slot][cls].expiry.end() ? 0 : e->second;
+        int64_t at = 0;
+        r.expires_at = tables_[slot][cls].expiry.find(key, &at) ? at : 0;
         cb(r);
         return true;
     });

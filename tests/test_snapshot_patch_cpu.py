@@ -356,3 +356,44 @@ def test_an_id_handed_out_by_name_restarts_its_quarantine(aclgpu, monkeypatch):
         else:
             assert e.find("user", "u-x") is None and e.find("user", "u-new") == ux  # (the control: without the hand-out the id is reused)
         e.close()
+
+
+def test_expiry_maps_fold_and_views_stay_isolated(aclgpu):
+    """Round 5: a class's expiry times live in an immutable sorted base + a small delta (ExpiryMap); Store::view() shares the base instead of
+    copying one node per expiring key.  Thousands of expiring relationships (several folds), then updates, removals and re-creations on both
+    sides of a fold: reads, the patched snapshot and a background build taken in the middle (phase 0 ... writes ... phase 1) all agree with
+    the oracle, and keys expire exactly when their LATEST expiry says."""
+    from oracle import orc
+    from tests import kat_runner
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    o = orc.Oracle(b["schema"])
+    o.write([(orc.OP_TOUCH, r) for r in b["relationships"]])
+    now = 1_700_000_000
+    e.set_now(now)
+    o.set_now(now)
+    key = lambda j: ("workflow", f"w{j}", "idempotency_key", "activity", f"a{j}", "")  # noqa: E731
+    N = 9000  # (> 2 x the delta's fold threshold)
+    for i in range(0, N, 1000):
+        ups = [(aclgpu.OP_CREATE, key(j), now + 100 + (j % 7)) for j in range(i, i + 1000)]
+        e.write(ups)
+        o.write(ups)
+    assert e.selfcheck_snapshot() is False
+    e.selfcheck_compaction(0)  # a background build starts from a view taken HERE
+    # ... while writers go on: longer lives, shorter lives, removals, re-creations without an expiry
+    ups = [(aclgpu.OP_TOUCH, key(j), now + 1000) for j in range(0, N, 3)] + [(aclgpu.OP_TOUCH, key(j), now + 50) for j in range(1, 2000, 3)]
+    dels = [(aclgpu.OP_DELETE, key(j)) for j in range(2, 3000, 3)]
+    for chunk in (ups[:1000], ups[1000:2000], ups[2000:3000], ups[3000:], dels):
+        e.write(chunk)
+        o.write(chunk)
+    forever = [(aclgpu.OP_TOUCH, key(j)) for j in range(2, 300, 3)]
+    e.write(forever)
+    o.write(forever)
+    assert e.selfcheck_compaction(1) is True  # the view's build catches up with all of that and is verified against the store
+    for t in (now + 60, now + 104, now + 200, now + 2000):
+        e.set_now(t)
+        o.set_now(t)
+        assert e.selfcheck_snapshot() is True  # (the expiry crossings are patched, not rebuilt)
+        assert sorted(e.read(rtype="workflow")) == sorted(o.read(rtype="workflow")), t
+    assert len(e.read(rtype="workflow")) == 100  # only the re-created ones never expire
+    e.close()
