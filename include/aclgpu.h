@@ -76,6 +76,12 @@ typedef struct {
 /* open only the relationship store (writes, reads, preconditions) without touching a GPU: every entry
  * point that evaluates permissions then fails with ACL_ERR_UNAVAILABLE.  For tooling and CPU-side tests. */
 #define ACL_FLAG_STORE_ONLY 1u
+/* CheckBulkPermissions: an item whose fields fail the API's patterns carries InvalidArgument in ITS pair instead of failing the whole call.
+ * The validation rules are a restatement from memory of the authzed API's `validate` tags (csrc/validate.hpp: unverified until the Go reference
+ * harness replays them), and the default -- as embedded SpiceDB does -- fails the WHOLE request, which the reference turns into a blanket denial
+ * (pkg/authz/check.go:48-52) or a failed list (postfilter.go:134-137).  An operator who meets that for ids the real engine would take can
+ * confine the failure to the offending pairs with this flag. */
+#define ACL_FLAG_PER_ITEM_VALIDATION 2u
 
 /* replaces spicedb.NewServer (pkg/spicedb/spicedb.go:18-71): builds the engine. */
 int acl_open(const acl_config_t *cfg, acl_engine_t **out);

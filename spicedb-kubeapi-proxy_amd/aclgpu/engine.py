@@ -43,11 +43,11 @@ def _b(s):
 
 class Engine:
     def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
-                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None):
+                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None, per_item_validation: bool = False):
         """devices: HIP ordinals of the replicas (acl_open_replicas: ONE store and one set of name tables in front of one HBM snapshot per
         entry; a device may be listed more than once); default one replica on `device`."""
         self._L = _lib.load()
-        cfg = Config(device, frontier_entries, max_sub_batch, 1 if store_only else 0, contexts, 0)
+        cfg = Config(device, frontier_entries, max_sub_batch, (1 if store_only else 0) | (2 if per_item_validation else 0), contexts, 0)  # ACL_FLAG_STORE_ONLY | ACL_FLAG_PER_ITEM_VALIDATION
         h = C.c_void_p()
         if devices:
             arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])

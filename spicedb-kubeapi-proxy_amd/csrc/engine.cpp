@@ -1412,7 +1412,7 @@ static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8
     // everything it asked on any error of the call, check.go:48-52, and fails the list response, postfilter.go:134-137).  Unknown types /
     // permissions stay per-item errors (check.go:55-60).
     for (const auto &be : bad)
-        if (be.second == ACL_ERR_INVALID_ARGUMENT)
+        if (be.second == ACL_ERR_INVALID_ARGUMENT && !h->per_item_validation)
             return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(be.first) + " has an empty or ill-formed field");
     if (bad.size() == n) {  // nothing to ask the device
         std::memset(perm_out, ACL_PERM_UNSPECIFIED, n);
@@ -1712,6 +1712,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (cfg && (cfg->flags & ACL_FLAG_STORE_ONLY)) {
         auto *so = new acl_engine();
         so->store_only = true;
+        so->per_item_validation = (cfg->flags & ACL_FLAG_PER_ITEM_VALIDATION) != 0;
         if (const char *ev = getenv("ACL_RAW_INTERN")) so->raw_intern = atoi(ev) != 0;  // (test knob, see below)
         batcher_create(so);
         *out = so;
@@ -1721,6 +1722,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(ACL_ERR_UNAVAILABLE, "acl_open: no HIP device available (this engine has no CPU evaluation path)");
     auto h = std::make_unique<acl_engine>();
+    h->per_item_validation = cfg && (cfg->flags & ACL_FLAG_PER_ITEM_VALIDATION) != 0;
     // the replicas: the device list of acl_open_replicas, else ACL_DEVICES="0,1,2,3" (a device may be named more than once: N logical replicas
     // on one GPU -- what the one-GPU test boxes exercise), else the one device of the config
     std::vector<int> list;

@@ -356,6 +356,7 @@ struct acl_engine {
     void set_rev_uploaded(bool v) {
         for (auto &d : devs) d->rev_uploaded = v;
     }
+    bool per_item_validation = false;  // ACL_FLAG_PER_ITEM_VALIDATION: ill-formed items of a bulk Check fail their own pair, not the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
     // the single-launch walk met rows too long for its direct task lists on this snapshot (kOverflowDirect): later walks build their lists the general
     // way (reset when a snapshot is rebuilt); direct_tripped: that batch's redo is not a frontier overflow -- no back-off for it (walk_outcome)

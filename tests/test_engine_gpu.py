@@ -363,6 +363,15 @@ definition pod { relation namespace: namespace
                 with pytest.raises(aclgpu.AclError) as ei:
                     e.check_bulk(batch)
                 assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, bad
+        # ACL_FLAG_PER_ITEM_VALIDATION (the patterns are a restatement from memory): the ill-formed item fails ITS pair, the call is answered
+        with aclgpu.Engine(schema, "\n".join(rels), per_item_validation=True) as e_lax:
+            for bad in invalid[2:]:
+                for batch in (qs[:50] + [bad] + qs[50:100], qs[:5000] + [bad]):
+                    got = e_lax.check_bulk(batch)
+                    pairs = list(zip(got[0], got[1]))
+                    at = 50 if len(batch) == 101 else 5000
+                    assert pairs[at] == (0, aclgpu.ERR_INVALID_ARGUMENT), bad
+                    assert pairs[:at] == want[:at] and pairs[at + 1:] == want[at:len(batch) - 1], bad
         for form, prep, call in (("c strings", e.make_check_strings_named(qs), e.check_bulk_prepared), ("views", e.make_check_views(qs), e.check_bulk_views)):
             p, er = call(prep)
             assert list(zip(p.tolist(), er.tolist())) == want, form
