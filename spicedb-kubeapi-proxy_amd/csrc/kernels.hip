@@ -400,6 +400,9 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
                             // by this step's hits -- or by another wave a moment ago -- needs none of them, and an entry not written is not read
                             // back and frees a lane of a segment of the next level (C4 253 -> 238 us; profiles/r04_push_recheck_ab.txt); 0 = A/B builds
 #endif
+#ifndef ACL_LOCAL_REQ
+#define ACL_LOCAL_REQ 1  // the direct task lists hold the request's index INSIDE the unit: the answer-byte accesses and the entry's y word lose their subtractions (A/B builds: 0)
+#endif
 #ifndef ACL_DIRECT_TASKS
 #define ACL_DIRECT_TASKS 1  // the deep levels' segments build their task list with the prefix sums taken in registers (process_segment); 0 = through flush_tasks (A/B builds)
 #endif
@@ -496,14 +499,14 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t total, WaveOut
             // (vmcnt counts stores too, and the compiler must assume the store was not issued)
 #pragma unroll
             for (int k = 0; k < W; k++)
-                if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], wo.first, 1);
+                if (hit[k]) ans_set<E8 && ACL_ANS_LDS>(has, rq[k], (UM && ACL_LOCAL_REQ) ? 0u : wo.first, 1);
 #if ACL_PUSH_RECHECK
             if (E8 && ACL_ANS_LDS) {
                 // a request answered by THIS step's hits (or by another wave a moment ago) needs none of its other children any more: looked at
                 // once more before they are written -- an entry not written is not read back, and frees a lane of a segment of the next level
                 wave_lds_fence();
 #pragma unroll
-                for (int k = 0; k < W; k++) push[k] = push[k] & (ans_get<true>(has, rq[k], wo.first) == 0u);
+                for (int k = 0; k < W; k++) push[k] = push[k] & (ans_get<true>(has, rq[k], (UM && ACL_LOCAL_REQ) ? 0u : wo.first) == 0u);
             }
 #endif
 #pragma unroll
@@ -518,7 +521,10 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t total, WaveOut
 #pragma unroll
                     for (int k = 0; k < W; k++)
                         if (push[k])
-                            put_entry<E8>(wo, base + pre[k] + lanes_below(pb[k]), edge[k0 + k] & kIdMask, rq[k], (UM ? umeta : t.meta[tj[k0 + k]]) | kProbedBit, UM ? 0u : t.sid[tj[k0 + k]]);
+                            if (UM && ACL_LOCAL_REQ)  // (the task holds the request's index inside the unit: the entry's y word without the subtraction)
+                                gst(reinterpret_cast<uint2 *>(wo.buf), base + pre[k] + lanes_below(pb[k]), make_uint2((edge[k0 + k] & kIdMask) | 0x80000000u, (umeta & 0x7FFFFu) | (rq[k] << 19)));
+                            else
+                                put_entry<E8>(wo, base + pre[k] + lanes_below(pb[k]), edge[k0 + k] & kIdMask, rq[k], (UM ? umeta : t.meta[tj[k0 + k]]) | kProbedBit, UM ? 0u : t.sid[tj[k0 + k]]);
                 }
             }
             ACL_MARK(wo, PH_PUSH);
@@ -999,12 +1005,12 @@ __device__ __forceinline__ void process_segment(const uint4 &e, bool valid, Next
                         const uint64_t bA = __ballot(degA != 0u), bB = __ballot(degB != 0u);
                         if (degA) {
                             const uint32_t ex = inclA - degA;
-                            t.a[lanes_below(bA)] = make_uint4(mdA.x - ex, sdA.x, sdA.y, req);
+                            t.a[lanes_below(bA)] = make_uint4(mdA.x - ex, sdA.x, sdA.y, ACL_LOCAL_REQ ? req - wo.first : req);
                             atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[ex >> 6]), 1ull << (ex & 63u));
                         }
                         if (degB) {
                             const uint32_t ex = inclB - degB;
-                            t.a[(uint32_t)__popcll(bA) + lanes_below(bB)] = make_uint4(mdB.x - ex, sdB.x, sdB.y, eB.y);
+                            t.a[(uint32_t)__popcll(bA) + lanes_below(bB)] = make_uint4(mdB.x - ex, sdB.x, sdB.y, ACL_LOCAL_REQ ? eB.y - wo.first : eB.y);
                             atomicOr(reinterpret_cast<unsigned long long *>(&t.heads[ex >> 6]), 1ull << (ex & 63u));
                         }
                         wave_lds_fence();
