@@ -240,6 +240,7 @@ static void refresh_local_blocks(acl_engine *h) {  // (the single-launch kernel'
     for (auto &d : h->devs) {
         d->local_blocks = local_grid_blocks(d->device, (h->snap.progs.size() + h->snap.ops.size()) * 32);
         d->local_blocks_wide = local_grid_blocks(d->device, (h->snap.progs.size() + h->snap.ops.size()) * 32, true);
+        if (const char *ev = getenv("ACL_LOCAL_BLOCKS_WIDE")) d->local_blocks_wide = std::max(1, atoi(ev));  // A/B knob: resident blocks the wide walk plans its units for
     }
 }
 
