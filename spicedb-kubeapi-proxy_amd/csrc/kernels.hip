@@ -5,16 +5,17 @@
 // A pending sub-check is a 16-byte frontier entry (object id, request, slot | level | flags, subject id); a SEGMENT is 64 of them,
 // one per lane.  process_segment() advances a segment by one dispatch level:
 //   - every lane interprets its state's flattened program (plan.hpp, cached in LDS): probes of the request's subject in hashed rows
-//     (two-choice placement over 4-slot buckets: two independent 16 B gathers, never a probing chain) or sorted rows (binary
-//     search), and "enumerate" operations whose child states are produced by a wave-cooperative, load-balanced expansion:
+//     (4-slot buckets, seeded single-choice: ONE 16 B gather per test -- two-choice rows, two gathers, only where no seed was found;
+//     never a probing chain) or sorted rows (binary search), and "enumerate" operations whose child states are produced by a wave-cooperative, load-balanced expansion:
 //       - per-lane tasks (row start, degree, the subject's hashed row) are compacted into LDS with wave64 ballot + mbcnt,
 //       - a DPP prefix sum over task degrees sizes the work, and every task marks its first work item with a head bit,
 //       - lanes take consecutive work items, find their task from the head bits (two v_mbcnt) and load consecutive edges of a row,
 //       - each child's own probes are evaluated RIGHT THERE; only children that still have something to enumerate are written,
 //         compacted with a second ballot, as consecutive entries.  Leaf states never enter the frontier.
 //   - where a segment is uniform enough the interpreter is bypassed: already-probed single-op parents (the deep levels) fetch has[],
-//     their row descriptor and the subject's row of the child's probe in ONE trip, two segments at a time; flush_simple expands
-//     their tasks kSimpleWidth children per lane and step; flush_probes handles arrow-target states.
+//     their row descriptor and the subject's row of the child's probe in ONE trip, two segments at a time; segments of ONE slot build
+//     their task list with the prefix sums taken in registers (the direct form, round 5); simple_steps expands the tasks kSimpleWidth
+//     children per lane and step; flush_probes handles arrow-target states.
 //   Loads are pinned into trips (issue_fence): all loads of a trip are issued before the first of them is waited for.
 // Two drivers call it:
 //   k_check_local  ONE launch per batch: a block walks its share of the requests through every level inside a block-private
@@ -23,7 +24,7 @@
 //                  chunks from one atomicAdd per 1024 entries): the sharded graph, and batches that outgrow the private regions.
 // k_rev_expand is the reverse walk (LookupResources); k_dedup merges duplicate entries of a level when a frontier explodes.
 //
-// Bound (profiles/r02_*): instruction issue and the vector L1, not HBM -- no MFMA anywhere by design.
+// Bound (profiles/r05_pmc_c4.md): instruction issue and dependent trips, not HBM -- no MFMA anywhere by design.
 #include <algorithm>
 #include <cstdlib>
 
