@@ -2185,7 +2185,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                 // ---- phase B: the lanes walk the output index space; lane -> task by binary search (threads without a task have degree 0:
                 // "the last task whose prefix is <= w" is always the one that owns w)
                 if (total <= kRevLocalBudget) {
-                    constexpr int U = 4;  // children per lane in flight
+                    constexpr int U = 2;  // children per lane in flight (round 5, same-box A/B: a power-user lookup 20.3 us with 4, 19.0 with 2, 22.7 with 8)
                     for (uint32_t wb = 0; wb < total; wb += U * kRevLocalThreads) {  // (block-uniform trip count)
                         uint32_t edge[U], tj[U];
                         bool valid[U];
