@@ -408,11 +408,12 @@ __device__ __forceinline__ bool eval_child(const DevGraph &g, const SlotProg *pr
 #define ACL_DIRECT_TASKS 1  // the deep levels' segments build their task list with the prefix sums taken in registers (process_segment); 0 = through flush_tasks (A/B builds)
 #endif
 #ifndef ACL_SIMPLE_WIDTH
-#define ACL_SIMPLE_WIDTH 2  // children per lane and step: 2 fits the 64 VGPRs of 8 waves/SIMD (3 is 3-5 % faster at equal occupancy but costs two waves per SIMD)
+#define ACL_SIMPLE_WIDTH 3  // children per lane and step.  Round 5: with ONE bucket per child three of them cost the registers two used to, and the wide walk moved to 12 waves per
+                            // block = 6 per SIMD = room for 72 VGPRs without a spill (rounds 2-4: 2 at 64 VGPRs and 8 waves per SIMD); profiles/r05_ab_block_shape.txt
 #endif
 constexpr int kSimpleWidth = ACL_SIMPLE_WIDTH;  // children per lane whose buckets are in flight together
 #ifndef ACL_EDGES_AHEAD
-#define ACL_EDGES_AHEAD 2  // = the width.  4 and 6 (all edges of a pair of segments in ONE trip) measured the same 305 us: one more sign that the walk is not waiting on trips
+#define ACL_EDGES_AHEAD 3  // = the width (6 = both windows' edges in one trip: 1 us better on C4, 3.5 us worse on the 100 M-relationship replica)
 #endif
 constexpr int kEdgesAhead = ACL_EDGES_AHEAD;    // children per lane whose edges are fetched in one trip
 // Returns a bit mask of the 64-task rounds it did NOT handle (the caller expands those the generic way): a round whose rows
@@ -1411,14 +1412,17 @@ struct InlineItems {  // up to four 16-byte items passed by value (kernel argume
     uint4 v[4];
 };
 #ifndef ACL_LOCAL_WAVES_PER_SIMD
-#define ACL_LOCAL_WAVES_PER_SIMD 8
+#define ACL_LOCAL_WAVES_PER_SIMD 6  // (round 5; 8 in rounds 2-4: see ACL_LOCAL_WIDE)
 #endif
 // Waves per block = waves that share one unit.  Two instantiations: kLocalNarrow for batches that do not fill the chip (a unit is a handful of
 // requests: more, smaller blocks) and kLocalWide for chip-filling ones -- requests differ 100-fold in work, so the more requests (and waves) a
 // unit pools, the less the slowest block's sum sticks out: C4's 262 144-item batch 303 us with 4 waves per block (2 048 units of 128 requests),
 // 286 us with 8, 276 us with 16 (512 units of 512), same-box A/B in profiles/r03_waves_per_block_ab.txt.
 #ifndef ACL_LOCAL_WIDE
-#define ACL_LOCAL_WIDE 16  // (A/B builds: 12 waves per block leave room for 84 VGPRs at two blocks per CU)
+#define ACL_LOCAL_WIDE 12  // Round 5: 12 waves per block, two blocks per CU = 6 waves per SIMD with 72 VGPRs and three children per lane and step -- C4 221.4 -> 216.8 us, the
+                           // 100 M-relationship replica 294.4 -> 283.8 us (16 waves at 64 VGPRs and two children per step until then: every attempt to add live state to
+                           // the fast paths at 64 VGPRs ended in spills; 12 waves had lost to 16 in round 4, when a child still cost two bucket gathers = 8 VGPRs more).
+                           // 14 waves: 275 us, 10 waves x 3 blocks: 226 us, four children per step: 227 us (profiles/r05_ab_block_shape.txt)
 #endif
 constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
 #ifndef ACL_SPLIT_UNITS
