@@ -187,6 +187,13 @@ typedef struct {
     uint32_t subject_id;
 } acl_item_t;
 int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out);
+/* Names -> ids in bulk, no device pass (also on a store-only engine): out[i] is items[i] as acl_check_bulk_ids takes it -- exactly what
+ * acl_check_bulk_v resolves before it asks the device, so acl_check_bulk_ids(out) answers as acl_check_bulk_v(items) would.  A shim that is asked about the
+ * same objects again (the user of a request, check.go:17-72; the namespaces of a list, postfilter.go:88-119) resolves once and keeps the ids.
+ * Object names the graph does not know resolve to ids without relationships; err_out[i] != 0 (unknown type / permission: FAILED_PRECONDITION, an empty
+ * or ill-formed field: INVALID_ARGUMENT -- always per item here) makes out[i] an item that every Check answers UNSPECIFIED with an error.
+ * An id stays its object's while the object has relationships, and for the length of a recycling quarantine after this call otherwise. */
+int acl_resolve_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 
 /* Cancellation / deadline of one call -- the C side of a Go context.Context.  The reference runs LookupResources on the
  * HTTP request's ctx and abandons it when that is cancelled (responsefilterer.go:165-170); the prefilter join gives up

@@ -295,6 +295,14 @@ class Engine:
             self._check(self._L.acl_check_bulk_v_opts(self._h, views.ctypes.data, n, perm.ctypes.data, err.ctypes.data, C.byref(o)))
         return perm[:n], err[:n]
 
+    def resolve_bulk_views(self, prepared):
+        """acl_resolve_bulk_v: the prepared views as the 16-byte items of the id entry points (no device pass) + a per-item error array."""
+        views, n, _blob = prepared
+        items = np.zeros(max(1, n), dtype=ITEM_DTYPE)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_resolve_bulk_v(self._h, views.ctypes.data, n, items.ctypes.data, err.ctypes.data))
+        return items[:n], err[:n]
+
     def check_bulk_prepared(self, prepared):
         arr, n, _keep = prepared
         perm = np.zeros(max(1, n), dtype=np.uint8)

@@ -1278,16 +1278,17 @@ void intern_pool_destroy(acl_engine_t *h) {
 // "invalid" without touching the graph) and is listed in *bad with its error; the batch is never compacted or copied again.
 constexpr uint16_t kDeadType = 0xFFFFu;
 template <class Items>
-static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t *out, std::vector<std::pair<uint32_t, int32_t>> *bad) {
+static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t *out, std::vector<std::pair<uint32_t, int32_t>> *bad, bool ids_leave_the_call = false) {
     const Schema &sc = h->store.schema();
     std::mutex bad_mu;
     // Object ids: two lookups per item in tables of up to millions of names -- two dependent DRAM misses each (slot, then the name's
     // bytes).  Items go in groups of kGroup through three stages: hash + prefetch the slots; walk to the tag match + prefetch the names;
     // compare.  The misses of a group are in flight together.
-    constexpr size_t kGroup = 16;
+    constexpr size_t kGroup = 16;  // (32: no better on the GPU box's host; prefetching the NEXT group's id bytes ahead of their hashing: 0.33 against 0.32 ms per 65 536 items, not kept -- tools/intern_bench.py)
     const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
         NameMemo m;
         std::vector<std::pair<uint32_t, int32_t>> mybad;
+        const int64_t touch_ms = ids_leave_the_call ? Store::steady_now_ms() : 0;  // (one clock read per chunk, not per id)
         struct Pending {
             uint64_t hr, hs;
             std::string_view rid, sid;
@@ -1355,6 +1356,10 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 else p.ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &p.sub);
                 const bool kr = p.kr, ks = p.ks;
                 uint32_t res = p.res, sub = p.sub;
+                if (ids_leave_the_call) {  // (acl_resolve_bulk_v: the recycling quarantine of an unreferenced object starts over, store.hpp touch)
+                    if (kr && !p.same_res) h->store.touch(p.rt, res, touch_ms);
+                    if (ks && !p.same_sub) h->store.touch(p.st, sub, touch_ms);
+                }
                 if ((!kr && !valid_object_id(p.rid)) || (!ks && !valid_object_id(p.sid)) || p.rid == "*" || p.sid == "*") {  // (`*` never in a Check)
                     out[i] = acl_item_t{kDeadType, 0, 0, kDeadType, 0, 0};
                     mybad.emplace_back((uint32_t)i, (int32_t)ACL_ERR_INVALID_ARGUMENT);
@@ -2045,6 +2050,20 @@ int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uin
 int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v: NULL buffer");
     return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
+}
+
+// names -> the 16-byte items of the id entry points, in bulk and without a device pass (works on a store-only engine)
+int acl_resolve_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out) {
+    if (n && (!items || !out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_resolve_bulk_v: NULL buffer");
+    std::vector<std::pair<uint32_t, int32_t>> bad;
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+        intern_items(h, ViewItems{items}, n, out, &bad, true);
+    }
+    if (n) std::memset(err_out, 0, n * sizeof(int32_t));
+    for (const auto &be : bad) err_out[be.first] = be.second;
+    return ACL_OK;
 }
 
 int acl_check_bulk_v_opts(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts) {

@@ -293,8 +293,9 @@ class Store {
     // its id was handed out, not from when it became free (a subject without relationships, interned by a lookup long ago, could be
     // renamed between a later request's name resolution and its evaluation).  Callable under the names lock held SHARED: a relaxed atomic store
     // into a table that only grows under the exclusive lock.
-    void touch(int type, uint32_t id) {
-        if ((size_t)type < touched_at_.size() && id < touched_at_[type].size()) __atomic_store_n(&touched_at_[type][id], steady_now_ms(), __ATOMIC_RELAXED);
+    void touch(int type, uint32_t id) { touch(type, id, steady_now_ms()); }
+    void touch(int type, uint32_t id, int64_t at_ms) {  // (bulk callers read the clock once)
+        if ((size_t)type < touched_at_.size() && id < touched_at_[type].size()) __atomic_store_n(&touched_at_[type][id], at_ms, __ATOMIC_RELAXED);
     }
     static int64_t steady_now_ms();
     static constexpr int64_t kReuseQuarantineMs = 30000;

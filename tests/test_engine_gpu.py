@@ -395,6 +395,16 @@ definition pod { relation namespace: namespace
         for form, prep, call in (("c strings", e.make_check_strings_named(rep), e.check_bulk_prepared), ("views", e.make_check_views(rep), e.check_bulk_views)):
             p, er = call(prep)
             assert list(zip(p.tolist(), er.tolist())) == want_rep, form
+        # acl_resolve_bulk_v: the same names as 16-byte items, no device pass; the id entry point then answers as the string one did
+        for batch, want_b in ((rep, want_rep), (qs[:100], want[:100])):  # pooled and single-thread interning
+            items, rerr = e.resolve_bulk_views(e.make_check_views(batch))
+            p, er = e.check_bulk_ids(items)
+            for k, (wp, we) in enumerate(want_b):
+                if rerr[k]:
+                    assert (wp, we) == (0, int(rerr[k])) and p[k] == 0 and er[k] != 0, (k, batch[k])
+                else:
+                    assert (int(p[k]), int(er[k])) == (wp, we), (k, batch[k])
+            assert rerr.any() and not rerr.all()
             p2, er2 = call((prep[0], 100, prep[2]))
             assert list(zip(p2.tolist(), er2.tolist())) == want_rep[:100], form
 

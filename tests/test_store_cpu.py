@@ -314,3 +314,52 @@ def test_bootstrap_yaml_files(aclgpu_lib):
             e.load_bootstrap_yaml(bad)
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, bad
     e.close()
+
+
+def test_resolve_bulk_names_to_items(aclgpu_lib):
+    """acl_resolve_bulk_v (no device pass, works store-only): names -> the 16-byte items of the id entry points.  Known names get the ids acl_find
+    gives, unknown object names ids without relationships (equal only when resource and subject are the same unknown object), unknown types /
+    permissions and ill-formed fields a per-item error and an item no Check can answer; batches beyond 4 096 items (the interning pool) resolve
+    as the single-thread path does; a resolved id of an unreferenced object sits out a fresh quarantine (Store::touch)."""
+    import time
+    import aclgpu
+    import numpy as np
+    b = kat_runner.load_bootstrap()
+    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    rels = [("namespace", f"ns-{i}", "viewer", "user", f"user-{i % 7}", "") for i in range(40)]
+    e.write([(aclgpu.OP_TOUCH, r) for r in rels])
+    qs = [(rt, rid, "view", st, sid, srel) for rt, rid, _rel, st, sid, srel in rels]
+    qs += [("namespace", "never-seen", "view", "user", "nobody", ""), ("namespace", "same-unknown", "view", "namespace", "same-unknown", "view"),
+           ("nosuchtype", "x", "view", "user", "u", ""), ("namespace", "x", "nosuchperm", "user", "u", ""), ("namespace", "", "view", "user", "u", ""),
+           ("namespace", "bad id!", "view", "user", "u", "")]
+    items, err = e.resolve_bulk_views(e.make_check_views(qs))
+    nt, ut = e.type_id("namespace"), e.type_id("user")
+    for k, q in enumerate(qs[:len(rels)]):
+        assert err[k] == 0 and items["resource_type"][k] == nt and items["permission"][k] == e.relation_id("namespace", "view")
+        assert items["resource_id"][k] == e.find(q[0], q[1]) and items["subject_id"][k] == e.find(q[3], q[4]) and items["subject_type"][k] == e.type_id(q[3])
+    k = len(rels)
+    assert err[k] == 0 and items["resource_id"][k] >= 0xFFFFFFF0 and items["subject_id"][k] >= 0xFFFFFFF0 and items["resource_id"][k] != items["subject_id"][k]
+    assert err[k + 1] == 0 and items["resource_id"][k + 1] == items["subject_id"][k + 1] >= 0xFFFFFFF0
+    assert [int(x) for x in err[k + 2:]] == [aclgpu.ERR_FAILED_PRECONDITION, aclgpu.ERR_FAILED_PRECONDITION, aclgpu.ERR_INVALID_ARGUMENT, aclgpu.ERR_INVALID_ARGUMENT]
+    assert all(int(t) == 0xFFFF for t in items["resource_type"][k + 2:]) and ut >= 0
+    big = [qs[i % len(qs)] for i in range(9000)]  # the pool's path
+    items_b, err_b = e.resolve_bulk_views(e.make_check_views(big))
+    idx = np.arange(9000) % len(qs)
+    assert np.array_equal(items_b, items[idx]) and np.array_equal(err_b, err[idx])
+    e.close()
+    # a resolved id is the caller's for a quarantine
+    import os
+    os.environ["ACL_ID_QUARANTINE_MS"] = "300"
+    try:
+        e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+    finally:
+        del os.environ["ACL_ID_QUARANTINE_MS"]
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/a", "viewer", "user", "u-x", ""))])
+    e.write([(aclgpu.OP_DELETE, ("pod", "ns/a", "viewer", "user", "u-x", ""))])
+    ux = e.find("user", "u-x")
+    time.sleep(0.4)
+    items, err = e.resolve_bulk_views(e.make_check_views([("pod", "ns/a", "view", "user", "u-x", "")]))
+    assert err[0] == 0 and items["subject_id"][0] == ux
+    e.write([(aclgpu.OP_TOUCH, ("pod", "ns/b", "viewer", "user", "u-new", ""))])
+    assert e.find("user", "u-x") == ux and e.find("user", "u-new") != ux
+    e.close()
