@@ -593,12 +593,12 @@ static uint32_t next_done_val(PassCtx *c) {
 struct LocalGeom {
     uint32_t rpw, nblocks, nunits, cap;
     uint32_t nstatic = 0, rdyn = 0;  // != 0: static units for the head of the batch, small hand-out units for its tail
-    bool wide = false;               // 16 waves per block and unit (chip-filling batches) instead of 4
+    bool wide = false;               // 12 waves per block and unit (kLocalWide) (chip-filling batches) instead of 4
 };
 static LocalGeom local_geom(acl_engine *h, PassCtx *c, uint32_t n) {
     LocalGeom G{};
     G.wide = n >= h->local_wide_min;
-    const uint32_t blocks = (uint32_t)(G.wide ? c->dev->local_blocks_wide : c->dev->local_blocks);  // what is resident at once; a unit is walked by one block (4 or 16 waves)
+    const uint32_t blocks = (uint32_t)(G.wide ? c->dev->local_blocks_wide : c->dev->local_blocks);  // what is resident at once; a unit is walked by one block (4 or 12 waves)
     // latency: while the batch has fewer requests than the chip has blocks, every request gets a block of its own; beyond that
     // every block gets ONE unit of n / blocks requests (`upw` > 1: several smaller ones, a second round of per-level chains)
     G.rpw = n <= blocks ? 1u : std::min<uint32_t>(std::max<uint32_t>((n + blocks * h->local_upw - 1) / (blocks * h->local_upw), 1), local_unit_max(G.wide));

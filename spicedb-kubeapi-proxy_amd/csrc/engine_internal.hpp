@@ -309,7 +309,7 @@ struct DevState {
     hipStream_t up_stream = nullptr;               // snapshot uploads (always under state_mu exclusive)
     int grid_blocks = 2048;
     int local_blocks = 1024;       // resident blocks of the single-launch kernel (4 waves per block)
-    int local_blocks_wide = 512;   // ... of its 16-wave instantiation
+    int local_blocks_wide = 512;   // ... of its wide (12-wave) instantiation
     // forward graph
     DevArray<uint32_t> d_meta, d_edges, d_buckets, d_tsb, d_tnm;
     DevArray<FwdOp> d_ops;
@@ -368,7 +368,7 @@ struct acl_engine {
     uint32_t spin_max = 64;  // (every block pays a system-scope release of its answers: worth it up to 64 blocks -- 1 item 21.3 -> 17.6 us, 64 items 23.0 -> 20.6 us; at 256 items it already loses, 23 -> 27 us, profiles/r05_spin_wait_ab.txt) host batches up to this size wait for their kernel by spinning on a pinned word its last block stores, not in hipStreamSynchronize (ACL_SPIN_MAX; 0 = off)
     uint32_t hostmap_max = 0xFFFFFFFFu;  // host batches up to this size: the kernel reads the items from, and writes the answers to, pinned host memory (no copies; ACL_HOSTMAP_MAX, A/B knob)
     unsigned intern_threads = 32; // host threads (the caller included) of bulk string interning, at most
-    uint32_t local_wide_min = 65536;  // batches from this size on run the 16-wave instantiation (a unit pools more requests: shorter tail)
+    uint32_t local_wide_min = 65536;  // batches from this size on run the wide (12-wave) instantiation (a unit pools more requests: shorter tail)
     uint32_t host_skew_pct = 8;  // a lone caller's host-mapped launch: first unit this many percent larger than the mean, last one as much smaller (ACL_HOST_SKEW_PCT;
                                  // worth 1-3 % of such a call -- the items do NOT arrive in block order, or 16 % would have hidden half the transfer: profiles/r04_host_skew.txt)
     uint32_t host_split = 2;   // streams the slices of one large host batch are spread over (ACL_HOST_SPLIT, 1 = off; engine.cpp check_pass_local_host)

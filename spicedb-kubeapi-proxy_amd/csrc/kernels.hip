@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
         if (NH == 2) {
             // ---- TWO HALF-UNITS, no block barrier between levels (round 5; VERDICT r4 next #1c).  With one cursor set a level ends at a block
             // barrier: a wave that finds the claim counter dry waits there for the waves still expanding their last pair -- a fifth of the walk's
-            // wave-time (profiles/r04_phases_final.txt), because a unit's level is only a few dozen segment pairs for 16 waves.  Here the unit's
+            // wave-time (profiles/r04_phases_final.txt), because a unit's level is only a few dozen segment pairs for a block's waves.  Here the unit's
             // requests are cut in two (at a multiple of 64: a wave's seeds belong to one half), each half with its own cursors, frontier region
             // (half of the block's) and an ARRIVAL COUNTER; every wave walks the phases  (half 0, level 2), (half 1, level 2), (half 0, level 3), ...
             // in that order and, done with its share of a phase, goes straight on to the next one -- which only needs the OTHER half's previous

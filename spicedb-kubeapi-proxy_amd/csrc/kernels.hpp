@@ -111,14 +111,14 @@ void launch_check_local(hipStream_t s, const DevGraph &g, const uint4 *items, ui
                         uint32_t *max_level = nullptr /* device word (zeroed): atomicMax of the dispatch levels the units needed */,
                         uint32_t nstatic = 0, uint32_t rdyn = 0 /* != 0: only the first nstatic units hold rpw requests, the rest of the batch is cut into units of rdyn
                                                                    handed out through next_unit (which must then be given) */,
-                        bool wide = false /* 16 waves per block (and unit) instead of 4: chip-filling batches */,
+                        bool wide = false /* 12 waves per block (and unit) instead of 4: chip-filling batches */,
                         uint32_t skew = 0 /* static units only: unit u holds rpw + skew ... rpw - skew requests, falling with u (items read across PCIe arrive in block order) */,
                         uint32_t *done_ctr = nullptr /* device word, zero between launches */, uint32_t *done_flag = nullptr /* pinned host word (device pointer): the last block to
                         finish stores done_val there, behind a system-scope release of every block's answers -- the host spins on it instead of synchronising the stream */,
                         uint32_t done_val = 0, const uint4 *inline_items_host = nullptr /* HOST pointer to the batch's items: a batch of <= 4 rides in the kernel's arguments
                         and `items` is not read */);
 // blocks of the single-launch kernel that are resident at once on this device
-int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the 16-wave instantiation
+int local_grid_blocks(int device, size_t prog_bytes, bool wide = false);  // prog_bytes: (slots + ops) * 32, the kernel's dynamic LDS; wide: the wide (12-wave) instantiation
 uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= threads per block of the single-launch kernel: thread i seeds request i of the unit)
 // strikes duplicate (request, state, level) entries of the frontier iteration `iter` produced; table: 2^bits u64 (reset here)
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits, bool cells = false);  // cells: the entries carry result cells (combine schemas): `table` is 1.5 x 2^bits words
