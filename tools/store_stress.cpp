@@ -167,6 +167,35 @@ int main(int argc, char **argv) {
                 std::this_thread::sleep_for(std::chrono::microseconds(700));
             }
         });
+    // bulk name resolution (acl_resolve_bulk_v: the string entry points' host half, works store-only) under the writers -- 6 000 items go through the
+    // interning pool, 300 stay on the calling thread; a pod's id must be the one acl_find gives (its namespace row is never deleted, so the id is never
+    // recycled), whatever the writers intern or recycle meanwhile
+    th.emplace_back([&] {
+        const int tp = acl_type_id(h, "pod");
+        std::vector<std::string> names;
+        for (int p = 0; p < 2000; p++) names.push_back("ns" + std::to_string(p % 50) + "/p" + std::to_string(p));
+        std::vector<acl_check_item_v_t> items(6000);
+        std::vector<acl_item_t> out(items.size());
+        std::vector<int32_t> err(items.size());
+        std::vector<std::string> subj(items.size());
+        unsigned s = 4242u;
+        while (!stop.load()) {
+            for (size_t i = 0; i < items.size(); i++) {
+                s = s * 1664525u + 1013904223u;
+                const std::string &r = names[(s >> 8) % names.size()];
+                subj[i] = (i % 7 == 3 ? "fresh" : "u") + std::to_string((s >> 12) % 400);
+                items[i] = acl_check_item_v_t{{"pod", 3}, {r.data(), r.size()}, {"view", 4}, {"user", 4}, {subj[i].data(), subj[i].size()}, {nullptr, 0}};
+            }
+            for (size_t n : {items.size(), (size_t)300}) {
+                if (acl_resolve_bulk_v(h, items.data(), n, out.data(), err.data())) { BAD(); continue; }
+                for (size_t i = 0; i < n; i += 97) {
+                    uint32_t id = 0;
+                    if (err[i] || out[i].resource_type != tp) BAD();
+                    else if (!reload && (acl_find(h, tp, std::string(items[i].resource_id.p, items[i].resource_id.n).c_str(), &id) || id != out[i].resource_id)) BAD();
+                }
+            }
+        }
+    });
     // single checks: strings interned under the shared name lock, queued, refused by the pass (no GPU)
     for (int c = 0; c < 4; c++)
         th.emplace_back([&, c] {
