@@ -475,6 +475,7 @@ typedef struct {
     uint64_t rev_local_passes;     /* LookupResources groups answered by that kernel (one launch for all reverse levels) */
     uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
     uint64_t ids_recycled;         /* object ids given a new name after their object had lost its last relationship (since the schema was loaded) */
+    uint64_t device_name_calls;    /* string calls (acl_check_bulk / _v) whose object names were resolved on the device (k_resolve_names) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);
