@@ -522,11 +522,12 @@ __device__ __forceinline__ void simple_steps(TaskLds &t, uint32_t total, WaveOut
                 if (base != kNoSpace) {
 #pragma unroll
                     for (int k = 0; k < W; k++)
-                        if (push[k])
+                        if (push[k]) {
                             if (UM && ACL_LOCAL_REQ)  // (the task holds the request's index inside the unit: the entry's y word without the subtraction)
                                 gst(reinterpret_cast<uint2 *>(wo.buf), base + pre[k] + lanes_below(pb[k]), make_uint2((edge[k0 + k] & kIdMask) | 0x80000000u, (umeta & 0x7FFFFu) | (rq[k] << 19)));
                             else
                                 put_entry<E8>(wo, base + pre[k] + lanes_below(pb[k]), edge[k0 + k] & kIdMask, rq[k], (UM ? umeta : t.meta[tj[k0 + k]]) | kProbedBit, UM ? 0u : t.sid[tj[k0 + k]]);
+                        }
                 }
             }
             ACL_MARK(wo, PH_PUSH);
