@@ -9,6 +9,8 @@
 // There is no CPU evaluation path: without a GPU acl_open() fails.
 // Threading: engine_internal.hpp (state_mu / names_mu / PassCtx pool).
 #include "engine_internal.hpp"
+#include "name_copies.hpp"
+#include "name_probe.hpp"
 #include "validate.hpp"
 
 #include <pthread.h>
@@ -1523,6 +1525,31 @@ static int check_bulk_strings_device(acl_engine_t *h, PassCtx *c, const Items &i
     return ACL_OK;
 }
 
+// ---- acl_selfcheck_names: the same route on the CPU, over a byte copy of the slot arrays kept as the HBM mirror is (name_copies.hpp) and with
+// the code the kernel runs per record (name_probe.hpp) -- what the tests without a GPU see of it
+struct HostNameCopies {
+    std::mutex mu;
+    std::vector<NameCopyState> state;
+    std::vector<std::vector<uint4>> slots;
+    int resize(size_t nt) {
+        slots.resize(nt);
+        return 0;
+    }
+    int replace(size_t ty, size_t cap, const void *bytes) {
+        slots[ty].resize(cap * (ObjectTable::kSlotBytes / sizeof(uint4)));
+        if (cap) std::memcpy(slots[ty].data(), bytes, cap * ObjectTable::kSlotBytes);
+        return 0;
+    }
+    int patch(size_t ty, const std::vector<uint32_t> &idx, const void *bytes) {
+        for (uint32_t i : idx) std::memcpy((char *)slots[ty].data() + (size_t)i * ObjectTable::kSlotBytes, (const char *)bytes + (size_t)i * ObjectTable::kSlotBytes, ObjectTable::kSlotBytes);
+        return 0;
+    }
+};
+void host_name_copies_destroy(acl_engine *h) {
+    delete h->host_name_copies;
+    h->host_name_copies = nullptr;
+}
+
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
 template <class Items>
 static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o = nullptr) {
@@ -1951,6 +1978,7 @@ void acl_close(acl_engine_t *h) {
     intern_pool_destroy(h);
     (void)acl_shard_rccl_destroy(h);
     compaction_join(h);
+    host_name_copies_destroy(h);
     if (h->store_only) {
         delete h;
         return;
@@ -2195,6 +2223,49 @@ int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uin
 int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v: NULL buffer");
     return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
+}
+
+// the host-side twin of the device's name resolution (see HostNameCopies above)
+int acl_selfcheck_names(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out, uint64_t *n_unknown_out) {
+    if (n && (!items || !out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_selfcheck_names: NULL buffer");
+    if (!h->store_only) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_names: store-only engines (an engine with a GPU keeps the tables' change lists for its copy in HBM)");
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
+    {
+        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+        if (!h->host_name_copies) h->host_name_copies = new HostNameCopies();
+    }
+    HostNameCopies &hc = *h->host_name_copies;
+    std::lock_guard<std::mutex> lk(hc.mu);
+    bool replaced = false;
+    (void)name_copies_need_replacing(h->store, hc.state);  // (what the mirror asks before it locks its readers out: exercised, nothing to lock here)
+    if (sync_name_copies(h->store, hc.state, hc, &replaced)) return fail(ACL_ERR_INTERNAL, "acl_selfcheck_names: the copy could not be brought up to date");
+    const size_t nt = h->store.schema().defs.size();
+    std::vector<NameTab> tabs(nt);
+    for (size_t ty = 0; ty < nt; ty++) {
+        const ObjectTable &t = h->store.objects((int)ty);
+        if (hc.state[ty].cap != t.slot_count() || hc.state[ty].version != t.version() ||
+            (t.slot_count() && std::memcmp(hc.slots[ty].data(), t.slot_bytes(), t.slot_count() * ObjectTable::kSlotBytes) != 0))
+            return fail(ACL_ERR_INTERNAL, "acl_selfcheck_names: the copy of type " + h->store.schema().defs[ty].name + "'s name slots differs from the table");
+        tabs[ty] = NameTab{t.slot_count() ? hc.slots[ty].data() : nullptr, (uint32_t)t.slot_count(), 0u};
+    }
+    std::vector<PackedNames> recs(std::max<size_t>(n, 1));
+    std::vector<std::pair<uint32_t, int32_t>> bad;
+    std::mutex bad_mu;
+    std::atomic<bool> does_not_fit{false};
+    pack_names(h, ViewItems{items}, 0, n, recs.data(), &bad, &bad_mu, &does_not_fit);
+    if (does_not_fit.load()) return fail(ACL_ERR_OUT_OF_RANGE, "acl_selfcheck_names: an object id does not fit a 64-byte record");
+    uint64_t unknown = 0;
+    for (size_t i = 0; i < n; i++) {
+        bool unk = false;
+        const uint4 it = name_resolve_record(tabs.data(), reinterpret_cast<const uint32_t *>(&recs[i]), &unk, HostMulHi{});
+        std::memcpy(&out[i], &it, sizeof(acl_item_t));
+        unknown += unk;
+        err_out[i] = 0;
+    }
+    for (const auto &be : bad) err_out[be.first] = be.second;
+    if (n_unknown_out) *n_unknown_out = unknown;
+    return ACL_OK;
 }
 
 // names -> the 16-byte items of the id entry points, in bulk and without a device pass (works on a store-only engine)

@@ -271,6 +271,7 @@ struct AsyncPool;
 namespace aclint {
 struct InternPool;  // engine.cpp
 struct NameMirror;  // engine_names.cpp
+struct HostNameCopies;  // engine.cpp (acl_selfcheck_names)
 }  // engine_async.cpp
 
 // Background snapshot compaction (engine.cpp).  Patching writes into the HBM snapshot leaves garbage behind (relocated
@@ -416,6 +417,7 @@ struct acl_engine {
     // async submit / wait (engine_async.cpp)
     AsyncPool *async = nullptr;  // created by the first submit, destroyed by async_shutdown
     aclint::InternPool *intern_pool = nullptr;  // host threads of bulk string interning (engine.cpp), created by the first large string batch
+    aclint::HostNameCopies *host_name_copies = nullptr;  // store-only engines: the host-side twin of the HBM mirror (acl_selfcheck_names)
     aclint::NameMirror *name_mirror = nullptr;  // the name tables' slot arrays in HBM (engine_names.cpp), created by the first PostFilter-sized string call
     bool device_names = false;     // ACL_DEVICE_NAMES=1: string calls of >= device_names_min items resolve their object names on the device (engine_names.cpp; parity-green, no faster than the host's threads on the boxes measured: profiles/r05_device_names.txt)
     uint32_t device_names_min = 16384;

@@ -13,18 +13,15 @@
 // in place needs neither: a probe that meets a half-written slot sees a tag or a name that does not match and walks on, as it would have a
 // moment earlier).
 #include "engine_internal.hpp"
+#include "name_copies.hpp"
 
 namespace aclint {
 
 struct NameMirror {
     std::mutex mu;
     std::shared_mutex use;
-    struct PerType {
-        uint4 *d = nullptr;
-        size_t cap = 0;
-        uint64_t version = 0;
-    };
-    std::vector<PerType> types;
+    std::vector<NameCopyState> state;
+    std::vector<uint4 *> d;  // per type; nullptr: the type has no names
     DevArray<NameTab> d_tabs;
     PinnedBuf stage;
     int device = -1;
@@ -34,11 +31,42 @@ void names_mirror_destroy(acl_engine *h) {
     NameMirror *m = h->name_mirror;
     if (!m) return;
     if (m->device >= 0) (void)hipSetDevice(m->device);
-    for (auto &t : m->types)
-        if (t.d) (void)hipFree(t.d);
+    for (uint4 *p : m->d)
+        if (p) (void)hipFree(p);
     delete m;
     h->name_mirror = nullptr;
 }
+
+namespace {
+struct MirrorOps {  // name_copies.hpp sync_name_copies on device memory
+    NameMirror &m;
+    hipStream_t stream;
+    int resize(size_t nt) {
+        for (size_t ty = nt; ty < m.d.size(); ty++)
+            if (m.d[ty]) (void)hipFree(m.d[ty]);
+        m.d.resize(nt, nullptr);
+        return 0;
+    }
+    int replace(size_t ty, size_t cap, const void *bytes) {
+        if (m.d[ty]) (void)hipFree(m.d[ty]);  // (hipFree waits for the device: nothing reads the old array any more)
+        m.d[ty] = nullptr;
+        if (!cap) return 0;
+        HIP_TRY(hipMalloc((void **)&m.d[ty], cap * ObjectTable::kSlotBytes));
+        HIP_TRY(hipMemcpy(m.d[ty], bytes, cap * ObjectTable::kSlotBytes, hipMemcpyHostToDevice));
+        return 0;
+    }
+    int patch(size_t ty, const std::vector<uint32_t> &idx, const void *bytes) {
+        const size_t k = idx.size(), off = (k * sizeof(uint32_t) + 63) & ~(size_t)63;
+        HIP_TRY(m.stage.ensure(off + k * ObjectTable::kSlotBytes));
+        std::memcpy(m.stage.p, idx.data(), k * sizeof(uint32_t));
+        const char *src = static_cast<const char *>(bytes);
+        for (size_t j = 0; j < k; j++) std::memcpy((char *)m.stage.p + off + j * ObjectTable::kSlotBytes, src + (size_t)idx[j] * ObjectTable::kSlotBytes, ObjectTable::kSlotBytes);
+        launch_scatter_slots(stream, m.d[ty], (const uint32_t *)m.stage.dp, (const uint4 *)((const char *)m.stage.dp + off), (uint32_t)k);
+        HIP_TRY(hipStreamSynchronize(stream));  // (the staging is reused by the next update; other contexts' streams must find the slots in place)
+        return 0;
+    }
+};
+}  // namespace
 
 // Names lock held (shared at least).  On ACL_OK the mirror is current, *tabs_out is the device's table of tables and `use_out` holds the
 // mirror shared: the caller keeps it until its stream has run dry.
@@ -52,56 +80,21 @@ int names_mirror_acquire(acl_engine *h, PassCtx *c, const NameTab **tabs_out, st
     const size_t nt = h->store.schema().defs.size();
     m.device = c->dev->device;
     HIP_TRY(hipSetDevice(m.device));
-    // what has to be replaced (under `use` held exclusively) and what can be written in place
-    bool structural = m.types.size() != nt || m.d_tabs.n < nt;
-    for (size_t ty = 0; ty < nt && !structural; ty++) {
-        const ObjectTable &t = h->store.objects((int)ty);
-        // a new array, or a re-hashed one copied over the old: a probe that ran meanwhile could miss a name that is in the table
-        structural = m.types[ty].cap != t.slot_count() || (m.types[ty].version != t.version() && t.changes_are_wholesale());
-    }
+    // an array that is replaced, or copied over whole, is replaced under `use` held exclusively: no kernel of another call is reading it then
     std::unique_lock<std::shared_mutex> excl(m.use, std::defer_lock);
-    if (structural) {
-        excl.lock();  // (waits for the calls whose kernels may still be reading the arrays)
-        for (size_t ty = nt; ty < m.types.size(); ty++)
-            if (m.types[ty].d) (void)hipFree(m.types[ty].d);
-        m.types.resize(nt);
-    }
-    std::vector<uint32_t> idx;
-    for (size_t ty = 0; ty < nt; ty++) {
-        const ObjectTable &t = h->store.objects((int)ty);
-        NameMirror::PerType &p = m.types[ty];
-        if (p.d && p.version == t.version()) continue;
-        bool all = false;
-        t.changes(&idx, &all);
-        const size_t cap = t.slot_count();
-        if (cap != p.cap || (!p.d && cap)) {  // (only under the exclusive hold: `structural` covers every size change)
-            if (p.d) (void)hipFree(p.d);
-            p.d = nullptr;
-            p.cap = 0;
-            if (cap) HIP_TRY(hipMalloc((void **)&p.d, cap * ObjectTable::kSlotBytes));
-            p.cap = cap;
-            all = true;
-        }
-        if (all) {
-            if (cap) HIP_TRY(hipMemcpy(p.d, t.slot_bytes(), cap * ObjectTable::kSlotBytes, hipMemcpyHostToDevice));
-        } else if (!idx.empty()) {
-            const size_t k = idx.size(), off = (k * sizeof(uint32_t) + 63) & ~(size_t)63;
-            HIP_TRY(m.stage.ensure(off + k * ObjectTable::kSlotBytes));
-            std::memcpy(m.stage.p, idx.data(), k * sizeof(uint32_t));
-            const char *src = static_cast<const char *>(t.slot_bytes());
-            for (size_t j = 0; j < k; j++) std::memcpy((char *)m.stage.p + off + j * ObjectTable::kSlotBytes, src + (size_t)idx[j] * ObjectTable::kSlotBytes, ObjectTable::kSlotBytes);
-            launch_scatter_slots(c->stream, p.d, (const uint32_t *)m.stage.dp, (const uint4 *)((const char *)m.stage.dp + off), (uint32_t)k);
-            HIP_TRY(hipStreamSynchronize(c->stream));  // (the staging is reused by the next update; other contexts' streams must find the slots in place)
-        }
-        p.version = t.version();
-    }
-    if (structural) {
+    if (name_copies_need_replacing(h->store, m.state) || m.d_tabs.n < nt) excl.lock();
+    MirrorOps ops{m, c->stream};
+    bool replaced = false;
+    if (m.d.size() != m.state.size()) m.d.resize(m.state.size(), nullptr);
+    int rc = sync_name_copies(h->store, m.state, ops, &replaced);
+    if (rc) return rc;
+    if (replaced || m.d_tabs.n < nt) {  // (only ever under the exclusive hold: name_copies_need_replacing saw it coming)
         std::vector<NameTab> tabs(nt);
-        for (size_t ty = 0; ty < nt; ty++) tabs[ty] = NameTab{m.types[ty].d, (uint32_t)m.types[ty].cap, 0u};
+        for (size_t ty = 0; ty < nt; ty++) tabs[ty] = NameTab{m.d[ty], (uint32_t)m.state[ty].cap, 0u};
         HIP_TRY(m.d_tabs.ensure(std::max<size_t>(nt, 1)));
         if (nt) HIP_TRY(hipMemcpy(m.d_tabs.p, tabs.data(), nt * sizeof(NameTab), hipMemcpyHostToDevice));
-        excl.unlock();
     }
+    if (excl.owns_lock()) excl.unlock();
     *use_out = std::shared_lock<std::shared_mutex>(m.use);  // (taken before `mu` is given up: no replacement can slip in between)
     *tabs_out = m.d_tabs.p;
     return ACL_OK;

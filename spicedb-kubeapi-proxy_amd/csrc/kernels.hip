@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "name_probe.hpp"
 
 namespace acl {
 namespace {
@@ -1800,48 +1801,10 @@ __global__ __launch_bounds__(256) void k_finalize(uint32_t n, const uint8_t *__r
     if (err_out) err_out[i] = e == ITEM_ERR_DEPTH ? 100 : (e == ITEM_ERR_INVALID ? 9 : 0);
 }
 
-// ---- object names -> ids on the device (kernels.hpp "object names resolved on the device")
-__device__ __forceinline__ uint64_t name_mulfold(uint64_t a, uint64_t b) { return (a * b) ^ __umul64hi(a, b); }
-// ObjectTable::hash (store.cpp), bit for bit, over a name held as little-endian dwords (whatever lies behind the name's last byte is masked off)
-__device__ __forceinline__ uint64_t name_hash(const uint32_t *w, uint32_t n) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)n * 0xD6E8FEB86659FD93ull);
-    uint32_t k = 0, left = n;
-    for (; left >= 8; left -= 8, k += 2) h = name_mulfold(h ^ ((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32)), 0xE7037ED1A0B428DBull);
-    if (left) {
-        uint32_t lo = w[k], hi = left > 4 ? w[k + 1] : 0u;
-        if (left < 4) lo &= (1u << (8 * left)) - 1u;
-        else if (left > 4) hi &= (1u << (8 * (left - 4))) - 1u;
-        h = name_mulfold(h ^ ((uint64_t)lo | ((uint64_t)hi << 32)), 0x8EBC6AF09C88C6E3ull);
-    }
-    return name_mulfold(h, 0x589965CC75374CC3ull) ^ h;
-}
-// ObjectTable::find_hashed for names of at most 46 bytes (longer ones never reach the device: engine_names.cpp)
-__device__ __forceinline__ bool name_find(const NameTab &t, const uint32_t *w, uint32_t n, uint32_t *id_out) {
-    if (!t.slots || !t.cap) return false;
-    const uint64_t h = name_hash(w, n);
-    const uint32_t tag = (uint32_t)(h >> 32), nd = (n + 3) >> 2;
-    const uint32_t last_mask = (n & 3u) ? (1u << (8 * (n & 3u))) - 1u : 0xFFFFFFFFu;
-    uint32_t i = (uint32_t)(((h & 0xFFFFFFFFull) * t.cap) >> 32);
-    for (uint32_t step = 0; step < t.cap; step++, i = (i + 1 == t.cap) ? 0u : i + 1) {
-        const uint4 *sl = t.slots + (size_t)i * 4;
-        const uint4 a = sl[0];  // tag, id, length | the name's first two bytes, its next four
-        if (a.y == 0xFFFFFFFFu) return false;  // an empty slot ends the probe
-        if (a.y == 0xFFFFFFFEu || a.x != tag || (a.z & 0xFFFFu) != n) continue;  // (tombstones are walked over)
-        const uint4 b = sl[1], c = sl[2], d = sl[3];
-        const uint32_t sw[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-        bool eq = true;
-#pragma unroll
-        for (uint32_t j = 0; j < 12; j++) {  // the name starts at byte 10 of the slot: dword j of it straddles slot dwords 2 + j and 3 + j
-            const uint32_t have = (sw[2 + j] >> 16) | (sw[3 + j] << 16);
-            if (j < nd) eq = eq && (((have ^ w[j]) & (j + 1 == nd ? last_mask : 0xFFFFFFFFu)) == 0u);
-        }
-        if (eq) {
-            *id_out = a.y;
-            return true;
-        }
-    }
-    return false;
-}
+// ---- object names -> ids on the device (kernels.hpp "object names resolved on the device"; the per-record work is name_probe.hpp's)
+struct DevMulHi {
+    __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return __umul64hi(a, b); }
+};
 __global__ __launch_bounds__(256) void k_resolve_names(const NameTab *__restrict__ tabs, const uint4 *__restrict__ packed, uint32_t n, uint4 *__restrict__ items,
                                                        uint32_t *unknown, uint32_t unknown_cap, uint32_t base) {  // (base: index of record 0 in the call's batch, for the list)
     __shared__ uint32_t rec[256][17];  // (17: lanes walk their own rows, the odd stride keeps them on different banks)
@@ -1856,27 +1819,12 @@ __global__ __launch_bounds__(256) void k_resolve_names(const NameTab *__restrict
         w[4 * q + 2] = v.z;
         w[4 * q + 3] = v.w;
     }
-    const uint32_t rt = w[0] & 0xFFFFu, st = w[1] & 0xFFFFu, rlen = w[2] & 0xFFu, slen = (w[2] >> 8) & 0xFFu;
-    if (rt == 0xFFFFu) {  // the host marked the item: unknown type / permission, an empty or ill-formed field
-        items[i] = make_uint4(0xFFFFu, 0u, 0xFFFFu, 0u);
-        return;
-    }
-    const uint32_t *rw = w + 3, *sw = w + 3 + ((rlen + 3) >> 2);
-    uint32_t res = 0, sub = 0;
-    const bool kr = name_find(tabs[rt], rw, rlen, &res), ks = name_find(tabs[st], sw, slen, &sub);
-    if (!kr || !ks) {
-        bool same = !kr && !ks && rt == st && rlen == slen;
-        const uint32_t nd = (rlen + 3) >> 2;
-        for (uint32_t j = 0; same && j < nd; j++) same = rw[j] == sw[j];  // (both zero-padded by the host)
-        if (same) res = sub = kUnknownSame;
-        else {
-            if (!kr) res = kUnknownRes;
-            if (!ks) sub = kUnknownSub;
-        }
+    bool unk = false;
+    items[i] = name_resolve_record(tabs, w, &unk, DevMulHi{});
+    if (unk) {
         const uint32_t k = atomicAdd(unknown, 1u);
         if (k < unknown_cap) unknown[1 + k] = base + i;
     }
-    items[i] = make_uint4(w[0], res, w[1], sub);
 }
 __global__ __launch_bounds__(256) void k_scatter_slots(uint4 *slots, const uint32_t *__restrict__ idx, const uint4 *__restrict__ src, uint32_t n) {
     const uint32_t k = blockIdx.x * 64 + threadIdx.x / 4, q = threadIdx.x & 3u;
