@@ -433,3 +433,39 @@ def test_names_resolved_over_a_copy_of_the_tables(aclgpu_lib, monkeypatch):
         e.selfcheck_names(e.make_check_views([("namespace", "a" * 30, "view", "user", "b" * 30, "")]))
     assert ei.value.code == aclgpu.ERR_OUT_OF_RANGE
     e.close()
+
+
+def test_copy_of_the_name_tables_under_random_writes(aclgpu_lib, monkeypatch):
+    """Property form of the test above: random runs of writes that create, drop and re-create objects of a small universe (ids recycled at once),
+    with a bootstrap reload in the middle of some -- after every step the copy of the name tables equals the live tables (checked inside
+    acl_selfcheck_names) and resolves every name of the universe, present or not, as acl_resolve_bulk_v does."""
+    import aclgpu
+    import numpy as np
+    from hypothesis import given, settings, strategies as st
+    monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "0")
+    b = kat_runner.load_bootstrap()
+    universe = [("namespace", f"n{i}", "view", "user", f"u{i % 9}", "") for i in range(40)]
+    step = st.tuples(st.sampled_from(["touch", "delete", "reload", "burst"]), st.integers(0, 39), st.integers(0, 8))
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.lists(step, min_size=1, max_size=25))
+    def run(steps):
+        e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
+        try:
+            pv = e.make_check_views(universe)
+            for op, i, u in steps:
+                if op == "touch":
+                    e.write([(aclgpu.OP_TOUCH, ("namespace", f"n{i}", "viewer", "user", f"u{u}", ""))])
+                elif op == "delete":
+                    e.write([(aclgpu.OP_DELETE, ("namespace", f"n{i}", "viewer", "user", f"u{uu}", "")) for uu in range(9)])
+                elif op == "reload":
+                    e.load_bootstrap(b["schema"], "\n".join(b["relationships"]))
+                else:  # enough new names for the tables to re-hash
+                    e.write([(aclgpu.OP_TOUCH, ("namespace", f"burst{i}-{k}", "viewer", "user", f"burstuser{u}-{k}", "")) for k in range(90)])
+                want_items, want_err = e.resolve_bulk_views(pv)
+                items, err, _unknown = e.selfcheck_names(pv)
+                assert np.array_equal(items, want_items) and np.array_equal(err, want_err), (op, i, u)
+        finally:
+            e.close()
+
+    run()
