@@ -834,6 +834,11 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     # warm-up left the second of them for the timed region (the "630 M/s at windows 3-4" of earlier runs was that one stall averaged over 40 steps)
     pipelined(max(warmup * nrep, 3 * window, 3 * callers, 12))()
     fire = pipelined(steps_all)
+    # (no cyclic-GC pass of the interpreter inside the K-step region: the harness holds lists of a million name strings, and a full collection
+    #  that walks them is milliseconds of a region that is 4-5 ms long)
+    import gc
+    gc.collect()
+    gc.disable()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -843,6 +848,7 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     host_ok = bool(np.array_equal(h_perm[0], gpu_perm) and np.array_equal(h_err[0], gpu_err))
     rec["value"] = n * steps_all / elapsed
     rec["elapsed"] = elapsed
@@ -945,8 +951,9 @@ def aclgpu_item_dtype():
     return aclgpu.ITEM_DTYPE
 
 
-def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
-    """CPU oracle on the same batch (parity + baseline) and the roofline from the oracle's byte model over the WHOLE batch."""
+def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label, with_oracle=None):
+    """CPU oracle on the same batch (parity + baseline) and the roofline from the oracle's byte model over the WHOLE batch.
+    with_oracle(o, cores): a caller's own checks against the loaded oracle (the C5R leg's lookup definition sample) before it is dropped."""
     from oracle import orc
     rt, perm_name, st = w.check
     n = int(w.res.size)
@@ -983,6 +990,8 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label):
     mperm, merr = o.check_bulk_ids_mt(cores, rt, perm_name, w.res, st, "", w.subj)  # EVERY answer of the batch is checked
     t_mt = time.perf_counter() - t0
     mism_mt = int((mperm != gpu_perm).sum() + (merr != gpu_err).sum())
+    if with_oracle is not None:
+        with_oracle(o, cores)
     rot = rec.pop("rotations", None)
     str_bad = int(bool(rec.pop("string_path_mismatch", False)))  # named-object strings answered differently from the ids they name
     rec["parity"] = {"checked_against_oracle": n, "mismatches": mism + mism_mt + str_bad}
@@ -1110,6 +1119,166 @@ def measure_traffic(args, label, kernel, n_items=0):
     return out
 
 
+def c4_reverse_walk(w, subjects):
+    """LookupResources(pod, view, user:U) for the C4 / C5 schema on the HOST, straight from the generator's arrays: the reverse walk the device runs
+    (user -> the groups that hold it -> their ancestor groups -> what those view -> down the namespace arrow), in numpy without an index (masks over
+    the edge arrays: a handful of subjects do not pay for a CSR over 100 M edges).  Three uses: every bit of the device's 8.45 M-pod result rows is
+    compared with it, it prices the SURVEY 8(d) LookupResources byte model  17 + sum over reverse rows touched (8 + 4 deg) + N_pod / 8  (rows: the
+    subject's five, three per visited group, one per visited namespace), and it is the tuned CPU figure beside the definition-based oracle.
+    -> (list of sorted pod-id arrays, bytes per lookup, seconds per lookup)"""
+    E = {(e[0], e[1], e[2]): (e[4], e[5]) for e in w.edges}
+    gg_r, gg_s = E[("group", "member", "group")]
+    gu_r, gu_s = E[("group", "member", "user")]
+    pods, pod_ns = E[("pod", "namespace", "namespace")]
+    pc_r, pc_s = E[("pod", "creator", "user")]
+    nc_r, nc_s = E[("namespace", "creator", "user")]
+    pvu_r, pvu_s = E[("pod", "viewer", "user")]
+    pvg_r, pvg_s = E[("pod", "viewer", "group")]
+    nvu_r, nvu_s = E[("namespace", "viewer", "user")]
+    nvg_r, nvg_s = E[("namespace", "viewer", "group")]
+    npod = w.nobjects["pod"]
+    outs, nbytes, secs = [], [], []
+    for u in subjects:
+        t0 = time.perf_counter()
+        u = np.uint32(u)
+        edges = 0
+        G = np.unique(gu_r[gu_s == u])
+        edges += int(G.size)
+        front = G
+        while front.size:
+            par = gg_r[np.isin(gg_s, front)]
+            edges += int(par.size)
+            par = np.unique(par)
+            front = np.setdiff1d(par, G, assume_unique=True)
+            G = np.union1d(G, front)
+        p_direct = [pvu_r[pvu_s == u], pc_r[pc_s == u], pvg_r[np.isin(pvg_s, G)]]
+        n_direct = [nvu_r[nvu_s == u], nc_r[nc_s == u], nvg_r[np.isin(nvg_s, G)]]
+        edges += sum(int(a.size) for a in p_direct) + sum(int(a.size) for a in n_direct)
+        NS = np.unique(np.concatenate(n_direct))
+        via = pods[np.isin(pod_ns, NS)]
+        edges += int(via.size)
+        seen = np.zeros(npod, dtype=bool)
+        for part in p_direct + [via]:
+            seen[part] = True
+        outs.append(np.flatnonzero(seen).astype(np.uint32))
+        secs.append(time.perf_counter() - t0)
+        nbytes.append(17 + 8 * (5 + 3 * int(G.size) + int(NS.size)) + 4 * edges + (npod + 7) // 8)
+    return outs, np.asarray(nbytes, dtype=np.int64), np.asarray(secs)
+
+
+def c5r_mixed_stream(args, w5, e5, gpu_perm, gpu_err, steps):
+    """BASELINE configs[4]'s request stream on ONE replica: 90 % Check batches (262 144 host ids each, pinned buffers) / 10 %
+    Filter requests -- LookupResources(pod, view, user:U), one subject per request as the reference issues it per LIST (pkg/authz/lookups.go:49-65),
+    the 1 MB result row written into pinned host memory -- interleaved by the workload's seed (workloads.c5_stream) and issued by
+    `--callers` threads as goroutines behind the shim would.  Every Check step's answers are compared with the device leg's (which the oracle checks
+    item by item) and every lookup's row with the numpy reverse walk; k_rev_local's launch time comes from HIP events in a sequential pass."""
+    import torch
+    from aclgpu import workloads
+    rt, perm_name, st = w5.check
+    n = int(w5.res.size)
+    ops = workloads.c5_stream(w5, steps)
+    fsub = sorted({int(o_[1]) for o_ in ops if o_ != "C"})
+    items0 = e5.make_items(rt, perm_name, w5.res, st, "", w5.subj)
+    callers = max(1, args.callers)
+    NB = callers + 1
+    words = max(1, (e5.object_count(rt) + 31) // 32)
+    hb = e5.host_alloc(NB * n * 21 + callers * (words * 4 + 8))
+    h_items = hb[:NB * n * 16].view(aclgpu_item_dtype()).reshape(NB, n)
+    h_perm = hb[NB * n * 16:NB * n * 17].reshape(NB, n)
+    h_err = hb[NB * n * 17:NB * n * 21].view(np.int32).reshape(NB, n)
+    lb0 = NB * n * 21
+    lbufs = [(hb[lb0 + c * (words * 4 + 8):lb0 + c * (words * 4 + 8) + words * 4].view(np.uint32).reshape(1, words),
+              hb[lb0 + c * (words * 4 + 8) + words * 4:lb0 + (c + 1) * (words * 4 + 8)].view(np.uint64)) for c in range(callers)]
+    for b in range(NB):
+        h_items[b] = np.roll(items0, b * 4099)
+    # ---- sequential lookups with HIP events on: k_rev_local's launch time, and the rows every later step is compared with
+    rows, cnts = {}, {}
+    for s_ in fsub:  # warm (reverse rows are built on first use)
+        e5.lookup_ids_batch(rt, perm_name, st, "", [s_], out=lbufs[0])
+    e5.stats_reset()
+    e5.set_timing(True)
+    torch.cuda.synchronize()
+    lat = []
+    reps = max(1, 24 // max(1, len(fsub)))
+    for _ in range(reps):
+        for s_ in fsub:
+            t1 = time.perf_counter()
+            bm, ct = e5.lookup_ids_batch(rt, perm_name, st, "", [s_], out=lbufs[0])
+            lat.append(time.perf_counter() - t1)
+            rows[s_], cnts[s_] = bm[0].copy(), int(ct[0])
+    e5.set_timing(False)
+    stl = e5.stats()
+    kname = "k_rev_local" if stl.get("rev_local_passes") else "k_rev_expand"
+    kms, kn = (stl["rev_local_ms"], stl["rev_local_passes"]) if stl.get("rev_local_passes") else (stl["expand_ms"], stl["expand_launches"])
+    walks, wbytes, wsecs = c4_reverse_walk(w5, fsub)
+    npod = w5.nobjects[rt]
+    bad_rows = 0
+    for i, s_ in enumerate(fsub):
+        got = np.flatnonzero(np.unpackbits(rows[s_].view(np.uint8), bitorder="little")[:npod]).astype(np.uint32)
+        bad_rows += int(not np.array_equal(got, walks[i])) + int(cnts[s_] != walks[i].size)
+    # ---- the stream, timed
+    bad = []
+    nxt = [0]
+    lk = threading.Lock()
+    go = [False]
+
+    def run(ci):
+        while not go[0]:
+            time.sleep(0)
+        while True:
+            with lk:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= len(ops):
+                return
+            if ops[k] == "C":
+                b = ci  # (a caller's own batch buffers: NB > callers)
+                e5.check_bulk_ids_into(h_items[b], h_perm[b], h_err[b])
+                if not (np.array_equal(h_perm[b], np.roll(gpu_perm, b * 4099)) and np.array_equal(h_err[b], np.roll(gpu_err, b * 4099))):
+                    bad.append(("C", k))
+            else:
+                s_ = int(ops[k][1])
+                bm, ct = e5.lookup_ids_batch(rt, perm_name, st, "", [s_], out=lbufs[ci])
+                if not (np.array_equal(bm[0], rows[s_]) and int(ct[0]) == cnts[s_]):
+                    bad.append(("F", k, s_))
+
+    for c in range(callers):  # every caller's context and buffers exist before the clock starts
+        e5.check_bulk_ids_into(h_items[c], h_perm[c], h_err[c])
+    ts = [threading.Thread(target=run, args=(c,)) for c in range(callers)]
+    for t_ in ts:
+        t_.start()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go[0] = True
+    for t_ in ts:
+        t_.join()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    e5.host_free(hb)
+    nC = sum(1 for o_ in ops if o_ == "C")
+    nF = len(ops) - nC
+    tot_bytes = float(sum(wbytes[fsub.index(int(o_[1]))] for o_ in ops if o_ != "C"))
+    per_launch = float(wbytes.mean())
+    k_us = 1e3 * kms / max(1, kn)
+    ach = per_launch / (k_us * 1e-6) / 1e9 if k_us > 0 else None
+    return {"workload": "BASELINE configs[4] stream on one replica: 90 % Check batches (262 144 host ids) / 10 % Filter requests (LookupResources(pod, view, user:U) over 8.45 M pods, "
+                        "one subject per request), interleaved by seed 0x5ACE0005; " + f"{callers} caller thread(s)",
+            "steps": len(ops), "check_steps": nC, "filter_steps": nF, "seconds": round(el, 4), "ms_per_step": 1e3 * el / len(ops),
+            "decisions_per_s": nC * n / el, "lookups_per_s": nF / el, "allowed_ids_per_lookup": float(np.mean([cnts[s_] for s_ in fsub])),
+            "lookup_alone": {"p50_ms": 1e3 * float(np.median(lat)), "lookups_per_s": 1.0 / float(np.mean(lat)), "calls": len(lat), "result_row_bytes": int(words * 4),
+                             "note": "one acl_lookup_resources_batch call of ONE subject at a time, pinned result row (the proxy's shape)"},
+            "parity": {"check_steps_compared": nC, "lookups_compared": nF + len(fsub), "mismatches": len(bad) + bad_rows,
+                       "checkers": "Check steps: the device leg's answers rotated (themselves compared with the oracle item by item); lookups: every bit of the result row against a "
+                                   "numpy reverse walk over the generator's arrays, and against the oracle's DEFINITION on a pod sample (lookup_definition_sample)"},
+            "roofline_lookup": {"bound": "hbm", "kernel": kname, "kernel_avg_us": k_us, "launches": int(kn), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None, "algorithmic_bytes_per_lookup": per_launch,
+                                "algorithmic_bytes_in_stream": tot_bytes, "result_rows": "HBM (the 8.45 M-pod type's row is 1 MB: beyond the block's LDS)",
+                                "model": "SURVEY.md 8(d) LookupResources formula on the generator's arrays: 17 + sum over reverse rows touched (8 + 4 deg) + N_pod / 8"},
+            "cpu_tuned_reverse_walk": {"value": 1.0 / float(wsecs.mean()), "unit": "lookups/s", "cores": 1,
+                                       "sample": f"{len(fsub)} subjects, numpy masks over the generator's edge arrays (no index), one thread"},
+            "_fsub": fsub, "_rows": rows}
+
+
 def c5r_leg(args, local_rank, budget_s):
     """The 100 M-relationship replica (the HBM-regime data point: a 0.7 GB snapshot does not fit the 256 MiB Infinity Cache), in the DEFAULT run
     (VERDICT r4 next #2): device-resident kernel time over >= 10 launches (HIP events), every answer of the batch against the CPU oracle, the
@@ -1119,7 +1288,7 @@ def c5r_leg(args, local_rank, budget_s):
     t0 = time.time()
     w5 = workloads.c5(scale=1.0)
     t_gen = time.time() - t0
-    e5 = aclgpu.Engine(w5.schema, device=local_rank)
+    e5 = aclgpu.Engine(w5.schema, device=local_rank, eager_contexts=True)
     w5.load(e5)
     e5.snapshot()
     t_load = time.time() - t0 - t_gen
@@ -1129,17 +1298,45 @@ def c5r_leg(args, local_rank, budget_s):
     r5.pop("elapsed", None)
     r5.pop("value", None)
     snap_bytes = int(e5.stats()["snapshot_bytes"])
+    mix = None
+    if os.environ.get("ACL_BENCH_C5R_STREAM", "1") != "0":
+        try:
+            mix = c5r_mixed_stream(sub, w5, e5, p5, er5, max(40, min(args.steps, 80)))
+        except Exception as ex:  # noqa: BLE001
+            mix = {"error": f"{type(ex).__name__}: {ex}"}
     e5.close()
     r5["setup_s"] = {"generate": round(t_gen, 1), "load+snapshot": round(t_load, 1)}
     r5["snapshot_bytes"] = snap_bytes
+    fsub, rows = (mix.pop("_fsub", []), mix.pop("_rows", {})) if mix else ([], {})
+
+    def lookup_definition(o, cores):
+        # LookupResources by its DEFINITION {pod : Check == HAS} on a fixed 50 000-pod sample per stream subject, by the oracle
+        rt, perm_name, st = w5.check
+        pods = np.unique(np.random.default_rng(55).integers(0, w5.nobjects[rt], size=50_000)).astype(np.uint32)
+        bad = 0
+        for s_ in fsub:
+            lp, _le = o.check_bulk_ids_mt(cores, rt, perm_name, pods, st, "", np.full(pods.size, s_, dtype=np.uint32))
+            bits = np.unpackbits(rows[s_].view(np.uint8), bitorder="little")
+            bad += int(not np.array_equal(bits[pods] == 1, lp == 2))
+        mix["parity"]["lookup_definition_sample"] = {"subjects": len(fsub), "pods_per_subject": int(pods.size), "mismatching_subjects": bad}
+        mix["parity"]["mismatches"] += bad
+
     if not args.no_cpu:
         r5["_steps"] = max(10, min(args.steps, 40))
         sub.traffic = "measure" if (args.traffic == "measure" and time.time() - t0 < budget_s) else "static"
-        cpu_and_roofline(sub, w5, r5, p5, er5, "C5R")
+        cpu_and_roofline(sub, w5, r5, p5, er5, "C5R", with_oracle=lookup_definition if (mix and "parity" in mix) else None)
         r5.pop("_steps")
         r5["roofline"]["traffic_mode"] = sub.traffic
     else:
         r5.pop("kernel", None)
+    if mix is not None:
+        r5["mixed_stream"] = mix
+        if "roofline_lookup" in mix:
+            r5["lookups_per_s"] = mix["lookups_per_s"]
+            r5["roofline_lookup"] = mix["roofline_lookup"]
+            if "parity" in r5:
+                r5["parity"]["mixed_stream_mismatches"] = mix["parity"]["mismatches"]
+                r5["parity"]["mismatches"] += mix["parity"]["mismatches"]
     r5["seconds"] = round(time.time() - t0, 1)
     return r5
 
@@ -1202,6 +1399,7 @@ def main():
                     help="roofline.traffic: measure = two rocprofv3 --pmc passes of this command's device leg, now (about 25 s); static = profiles/traffic.json "
                          "(an earlier run's passes, labelled); auto = measure for the headline workload at N=1 with the CPU legs on")
     ap.add_argument("--replica", action="store_true", help="with --workload C5: the 100 M-relationship graph as one unsharded replica (the beyond-L3 data point)")
+    ap.add_argument("--stream", action="store_true", help="with --workload C5 --replica: also run the 90 / 10 Check + Filter stream (what the default run's C5R leg does)")
     ap.add_argument("--legs", default="all", choices=["all", "device"], help="device: only the device-resident leg (for rocprofv3 runs: every k_expand "
                     "launch of the process is then a sequential one, so the profiler's average equals the roofline's)")
     ap.add_argument("--native-loop", default="on", choices=["on", "off"], help="sharded leg: also time the level loop inside libaclgpu.so (acl_shard_check_bulk)")
@@ -1308,7 +1506,9 @@ def main():
     if args.workload == "C5" and not args.replica:
         return c5_bench(args, w, world, rank, local_rank, t_gen)
     label = "C5R" if args.workload == "C5" else args.workload
-    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1, devices=args.replica_devices or None)
+    # (every evaluation context exists before any clock starts: one made on demand inside the 20-step timed region -- the first time three callers
+    #  really overlap -- costs it 3 ms of allocations under the pool's lock: 0.38 instead of 0.20 ms per step in one of this round's runs)
+    eng = aclgpu.Engine(w.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1, devices=args.replica_devices or None, eager_contexts=True)
     t0 = time.time()
     if args.legs == "all" and rank == 0 and args.workload != "C3" and args.strings != "off":
         name_objects(eng, w)  # (before the load: ids follow interning order)
@@ -1331,6 +1531,11 @@ def main():
 
     rec, gpu_perm, gpu_err = check_bench(args, w, eng, args.steps, args.warmup, world, rank, label, args.legs, dist if world > 1 else None)
     elapsed = rec.pop("elapsed")
+    if label == "C5R" and args.stream and rank == 0:
+        mm = c5r_mixed_stream(args, w, eng, gpu_perm, gpu_err, max(40, args.steps))
+        mm.pop("_fsub", None)
+        mm.pop("_rows", None)
+        rec["mixed_stream"] = mm
     per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -1409,7 +1614,7 @@ def main():
         cfgs = {}
         try:
             w2 = workloads.c2()
-            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1)
+            e2 = aclgpu.Engine(w2.schema, device=local_rank, contexts=max(2, args.window, args.callers) + 1, eager_contexts=True)
             if args.strings != "off":
                 name_objects(e2, w2)
             w2.load(e2)
@@ -1448,6 +1653,12 @@ def main():
             out["roofline"].update({"c5r_kernel_avg_us": rf5.get("kernel_avg_us"), "c5r_frac": rf5.get("frac"), "c5r_achieved": rf5.get("achieved"), "c5r_traffic": rf5.get("traffic"),
                                     "c5r_traffic_frac": rf5.get("traffic_frac"), "c5r_parity_checked": (cfgs["C5R"].get("parity") or {}).get("checked_against_oracle"),
                                     "c5r_parity_mismatches": (cfgs["C5R"].get("parity") or {}).get("mismatches")})
+            rl5 = cfgs["C5R"].get("roofline_lookup") or {}
+            ms5 = cfgs["C5R"].get("mixed_stream") or {}
+            if rl5:  # the 90 / 10 Check + Filter stream on the replica: the reverse kernel's own roofline entry and the stream's rates
+                out["roofline"].update({"c5r_stream_decisions_per_s": ms5.get("decisions_per_s"), "c5r_stream_lookups_per_s": ms5.get("lookups_per_s"),
+                                        "c5r_lookup_kernel": rl5.get("kernel"), "c5r_lookup_kernel_avg_us": rl5.get("kernel_avg_us"), "c5r_lookup_frac": rl5.get("frac"),
+                                        "c5r_lookup_achieved": rl5.get("achieved"), "c5r_stream_mismatches": (ms5.get("parity") or {}).get("mismatches")})
 
     # ---- extra leg (outside the timed region, after the main line is complete): the sharded graph.  Whatever happens in
     # it -- an exception on this rank, a wedged collective -- the main line is still printed exactly once.

@@ -82,6 +82,14 @@ typedef struct {
  * (pkg/authz/check.go:48-52) or a failed list (postfilter.go:134-137).  An operator who meets that for ids the real engine would take can
  * confine the failure to the offending pairs with this flag. */
 #define ACL_FLAG_PER_ITEM_VALIDATION 2u
+/* LookupResources over a permission that holds an intersection / exclusion confirms its candidates with a forward Check; a candidate whose Check
+ * ERRS (a branch beyond the dispatch depth) fails the call with that item's code -- the reference's stream ends at the first Recv error and the list
+ * request with it (pkg/authz/lookups.go:75-83, responsefilterer.go:196-204).  This flag keeps the lenient form of rounds 4-5: such candidates are
+ * dropped from the answer and the call succeeds. */
+#define ACL_FLAG_LENIENT_LOOKUP 4u
+/* create all `contexts` evaluation contexts at acl_open instead of on demand: a server pays their allocation (frontier buffers, pinned staging:
+ * milliseconds each) before its first request, not inside the first requests that find the pool busy. */
+#define ACL_FLAG_EAGER_CONTEXTS 8u
 
 /* replaces spicedb.NewServer (pkg/spicedb/spicedb.go:18-71): builds the engine. */
 int acl_open(const acl_config_t *cfg, acl_engine_t **out);

@@ -150,6 +150,11 @@ typedef struct orc {
     uint8_t *memo_v;
     size_t memo_cap, memo_n;
     uint64_t memo_base; /* cnt_dispatch at the start of the current top-level check */
+    /* LookupResources: the POSITIVE relaxation of the schema (`a & b` -> a + b, `a - b` -> a, a.all(b) -> a->b) decides which resources are
+     * CANDIDATES -- what a reverse reachability walk from the subject finds; see orc_lookup_ids() */
+    int relaxed;
+    int lenient_lookup; /* 1: a candidate whose Check errs is dropped instead of failing the lookup (orc_set_lenient_lookup) */
+    int lookup_err;     /* code of the last failed orc_lookup_ids() */
 } orc_t;
 
 static void seterr(orc_t *o, const char *fmt, ...) {
@@ -639,6 +644,11 @@ static int eval_expr(orc_t *o, int type, const expr_t *e, uint32_t id, const sub
     switch (e->kind) {
     case EX_NIL: return R_NO;
     case EX_INTERSECT: { /* `all`: the first empty operand decides; neither operand is a dispatch of its own */
+        if (o->relaxed) { /* candidates: either operand's positive path reaches the subject */
+            int ra = eval_expr(o, type, e->l, id, s, depth_remaining);
+            if (ra == R_HAS) return R_HAS;
+            return join_union(ra, eval_expr(o, type, e->r, id, s, depth_remaining));
+        }
         int a = eval_expr(o, type, e->l, id, s, depth_remaining);
         if (a == R_NO) return R_NO;
         int b = eval_expr(o, type, e->r, id, s, depth_remaining);
@@ -647,7 +657,7 @@ static int eval_expr(orc_t *o, int type, const expr_t *e, uint32_t id, const sub
     }
     case EX_EXCLUDE: { /* `difference`: the base is waited for first; an empty base decides without the subtracted set */
         int a = eval_expr(o, type, e->l, id, s, depth_remaining);
-        if (a != R_HAS) return a;
+        if (a != R_HAS || o->relaxed) return a; /* (candidates: the subtracted operand is not a positive occurrence) */
         int b = eval_expr(o, type, e->r, id, s, depth_remaining);
         return b == R_ERR ? R_ERR : (b == R_HAS ? R_NO : R_HAS);
     }
@@ -691,10 +701,16 @@ static int eval_expr(orc_t *o, int type, const expr_t *e, uint32_t id, const sub
             int tr = rel_index(&o->types[tp->stype], e->b);
             if (tr < 0) continue;
             int r = check_rel(o, tp->stype, tr, tp->subj, s, depth_remaining - 1);
+            if (o->relaxed) { /* candidates: as `->` */
+                if (r == R_HAS) return R_HAS;
+                if (r == R_ERR) any_err = 1;
+                continue;
+            }
             if (r == R_NO) return R_NO;
             if (r == R_ERR) any_err = 1;
             n++;
         }
+        if (o->relaxed) return any_err ? R_ERR : R_NO;
         return n == 0 ? R_NO : (any_err ? R_ERR : R_HAS);
     }
     }
@@ -1126,7 +1142,14 @@ void orc_check_bulk_ids_mt(orc_t *o, int nthreads, size_t n, int rtype, int perm
 /* LookupResources restated as its definition: { id : Check(T:id#p @ S) == HAS }
  * evaluated by brute force over every object of type T that occurs as a
  * resource in any tuple (plus the subject itself for the reflexive case).
- * Returns the number of ids; fetch with orc_lookup_result(). */
+ * Returns the number of ids; fetch with orc_lookup_result().
+ *
+ * Errors (reference pkg/authz/lookups.go:75-83: the stream ends at the first Recv error and the list request fails with it,
+ * responsefilterer.go:196-204).  EXTERNAL, unverified: SpiceDB finds CANDIDATES by reverse reachability from the subject and confirms the
+ * ones that passed an intersection / exclusion with a Check; a Check that errs (a branch beyond the dispatch depth under `&` / `-`) ends the
+ * stream.  Restated: a resource whose Check is ERR fails the whole lookup iff it is a candidate -- iff the positive relaxation of the
+ * schema (o->relaxed) grants it.  Resources that merely sit on a cycle or a long chain the subject has nothing to do with are not
+ * candidates and stay out of the answer silently.  Returns -1 (orc_lookup_error() = the code) on failure. */
 static int u32_cmp(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
 static void lr_push(orc_t *o, uint32_t id) {
     if (o->lr_n == o->lr_cap) { o->lr_cap = o->lr_cap ? o->lr_cap * 2 : 256; o->lr_ids = realloc(o->lr_ids, sizeof(uint32_t) * o->lr_cap); }
@@ -1149,11 +1172,28 @@ long orc_lookup_ids(orc_t *o, int rtype, int perm, int stype, int srel, uint32_t
     for (size_t i = 0; i < ncand; i++) {
         if (i && cand[i] == cand[i - 1]) continue;
         memo_reset(o);
-        if (check_rel(o, rtype, perm, cand[i], &s, ORC_MAX_DEPTH) == R_HAS) lr_push(o, cand[i]);
+        int r = check_rel(o, rtype, perm, cand[i], &s, ORC_MAX_DEPTH);
+        if (r == R_HAS) lr_push(o, cand[i]);
+        else if (r == R_ERR && !o->lenient_lookup) {
+            memo_reset(o);
+            o->relaxed = 1;
+            int rr = check_rel(o, rtype, perm, cand[i], &s, ORC_MAX_DEPTH);
+            o->relaxed = 0;
+            memo_reset(o);
+            if (rr == R_HAS) {
+                seterr(o, "LookupResources: max depth exceeded while checking candidate id %u", cand[i]);
+                o->lookup_err = ORC_ERR_DEPTH;
+                free(cand);
+                o->lr_n = 0;
+                return -1;
+            }
+        }
     }
     free(cand);
     return (long)o->lr_n;
 }
+int orc_lookup_error(orc_t *o) { return o->lookup_err; }
+void orc_set_lenient_lookup(orc_t *o, int on) { o->lenient_lookup = on; }
 const uint32_t *orc_lookup_result(orc_t *o) { return o->lr_ids; }
 
 long orc_lookup(orc_t *o, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *err) {
@@ -1174,7 +1214,9 @@ long orc_lookup(orc_t *o, const char *rtype, const char *perm, const char *stype
     }
     /* the subject may be unknown to the store: intern it so the reflexive case has an id */
     uint32_t sub = st_intern(&o->types[st].objs, sid);
-    return orc_lookup_ids(o, rt, rl, st, sr, sub);
+    long n = orc_lookup_ids(o, rt, rl, st, sr, sub);
+    if (n < 0) *err = o->lookup_err;
+    return n;
 }
 
 /* ------------------------------------------------ algorithmic-bytes model

@@ -74,6 +74,8 @@ def lib():
         L.orc_lookup_ids.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.orc_lookup.restype = C.c_long
         L.orc_lookup.argtypes = [C.c_void_p] + [C.c_char_p] * 5 + [C.POINTER(C.c_int)]
+        L.orc_lookup_error.argtypes = [C.c_void_p]
+        L.orc_set_lenient_lookup.argtypes = [C.c_void_p, C.c_int]
         L.orc_lookup_result.restype = C.POINTER(C.c_uint32)
         L.orc_lookup_result.argtypes = [C.c_void_p]
         L.orc_check_bytes.restype = C.c_uint64
@@ -248,8 +250,14 @@ class Oracle:
     def lookup_ids(self, rtype, perm, stype, srel, subj):
         n = self._L.orc_lookup_ids(self._h, self.type_id(rtype), self.rel_id(rtype, perm), self.type_id(stype),
                                    self.rel_id(stype, srel), int(subj))
+        if n < 0:  # a candidate's Check erred: the reference's stream fails (pkg/authz/lookups.go:75-83)
+            raise self._err(self._L.orc_lookup_error(self._h))
         ids = self._L.orc_lookup_result(self._h)
         return np.ctypeslib.as_array(ids, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint32)
+
+    def set_lenient_lookup(self, on: bool):
+        """on: a candidate whose Check errs is dropped from the answer instead of failing the lookup (the engine's ACL_FLAG_LENIENT_LOOKUP)"""
+        self._L.orc_set_lenient_lookup(self._h, int(bool(on)))
 
     def check_bytes(self, rtype, perm, res, stype, srel, subj):
         r = C.c_int()

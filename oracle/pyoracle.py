@@ -172,6 +172,11 @@ class InvalidArgument(ValueError):
     pass
 
 
+class LookupFailed(Exception):
+    """a candidate's check erred: the whole LookupResources call fails (code 100 = max depth exceeded)"""
+    code = 100
+
+
 class PyOracle:
     """Relationship store + evaluator.  Tuples are 6-tuples of strings
     (rtype, rid, rel, stype, sid, srel) with srel == '' for no subject relation."""
@@ -180,6 +185,8 @@ class PyOracle:
         self.defs = parse_schema(schema)
         self.rows: dict = {}  # (rtype, rid, rel) -> {(stype, sid, srel): expires}
         self.now = 0
+        self.relaxed = False         # evaluate the POSITIVE relaxation of the schema (lookup_resources: which resources are candidates)
+        self.lenient_lookup = False  # True: a candidate whose check errs is dropped instead of failing the lookup
 
     # -- writes (TOUCH semantics; the C oracle covers CREATE/preconditions)
     def touch(self, rtype, rid, rel, stype, sid, srel="", expires=0):
@@ -230,6 +237,11 @@ class PyOracle:
     def _eval(self, rtype, rid, e, subject, depth):
         if e[0] == "nil":
             return NO
+        if self.relaxed:  # candidates: `a & b` as a + b, `a - b` as a, a.all(b) as a->b
+            if e[0] == "excl":
+                return self._eval(rtype, rid, e[1], subject, depth)
+            if e[0] in ("inter", "arrow_all"):
+                e = ("union" if e[0] == "inter" else "arrow", e[1], e[2])
         if e[0] == "inter":
             a = self._eval(rtype, rid, e[1], subject, depth)
             b = NO if a == NO else self._eval(rtype, rid, e[2], subject, depth)
@@ -276,4 +288,20 @@ class PyOracle:
         ids = {k[1] for k in self.rows if k[0] == rtype}
         if stype == rtype:
             ids.add(sid)
-        return {i for i in ids if self.check(rtype, i, perm, stype, sid, srel) == HAS}
+        # A resource whose check ERRS fails the whole lookup iff it is a CANDIDATE -- iff the positive relaxation of the schema grants it, i.e. a
+        # reverse reachability walk from the subject finds it (EXTERNAL, unverified; reference pkg/authz/lookups.go:75-83: the stream ends at the
+        # first Recv error).  Resources on cycles / long chains the subject has nothing to do with stay out silently.
+        out = set()
+        for i in ids:
+            r = self.check(rtype, i, perm, stype, sid, srel)
+            if r == HAS:
+                out.add(i)
+            elif r == ERR and not self.lenient_lookup:
+                self.relaxed = True
+                try:
+                    cand = self.check(rtype, i, perm, stype, sid, srel) == HAS
+                finally:
+                    self.relaxed = False
+                if cand:
+                    raise LookupFailed(f"LookupResources: max depth exceeded while checking candidate {rtype}:{i}")
+        return out

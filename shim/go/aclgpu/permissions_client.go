@@ -119,7 +119,9 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 			if msg == "" {
 				msg = "LookupResources failed in the engine (code " + codes.Code(c.rc).String() + "); ACL_TRACE=1 logs the reason where the completion is produced"
 			}
-			return nil, status.Error(codes.Code(c.rc), msg)
+			// (a candidate whose forward Check erred fails the call with the ITEM's code, ACL_ERR_DEPTH: SpiceDB's "max depth exceeded" is a
+			// ResourceExhausted; the reference ends the stream on it and fails the list request, lookups.go:75-83, responsefilterer.go:196-204)
+			return nil, status.Error(itemCode(C.int32_t(c.rc)), msg)
 		}
 		return &bitmapStream{ctx: ctx, e: p.e, typeID: typeID, bm: c.bm, at: p.e.zedToken()}, nil
 	}
@@ -129,7 +131,7 @@ func (p *permissionsClient) LookupResources(ctx context.Context, in *v1.LookupRe
 	opts, stop := callOpts(ctx)
 	defer stop()
 	if rc := C.acl_lookup_resources_alloc(p.e.h, rt, cs.add(in.Permission), cs.add(st), cs.add(sid), cs.add(srel), opts, &bmp, &words, &count); rc != 0 {
-		return nil, lastError(rc)
+		return nil, status.Error(itemCode(C.int32_t(rc)), C.GoString(C.acl_last_error()))
 	}
 	bm := make([]C.uint32_t, int(words))
 	copy(bm, unsafe.Slice(bmp, int(words)))
@@ -161,16 +163,22 @@ func (s *bitmapStream) Recv() (*v1.LookupResourcesResponse, error) {
 	s.bm[s.word] &^= 1 << uint(bit)
 	// the name is COPIED under the engine's names lock (acl_object_name_copy): an id whose object takes part in no relationship may be given to a new
 	// name later, and the bytes acl_object_name points at are then overwritten
-	var buf [256]C.char
+	// (object ids may be up to 1024 bytes long.  The id may be given a LONGER name between two copies -- it was recycled --, so a returned length is
+	//  only used once it fits the buffer the copy was made into; n < 0: the id lost its name meanwhile and an empty id is streamed)
+	var small [256]C.char
 	id := C.uint32_t(s.word*32 + bit)
-	n := C.acl_object_name_copy(s.e.h, s.typeID, id, &buf[0], C.size_t(len(buf)))
+	buf := small[:]
 	var name string
-	if int(n) >= len(buf) { // (object ids may be up to 1024 bytes long)
-		big := make([]C.char, int(n)+1)
-		n = C.acl_object_name_copy(s.e.h, s.typeID, id, &big[0], C.size_t(len(big)))
-		name = C.GoStringN(&big[0], C.int(n))
-	} else if n >= 0 {
-		name = C.GoStringN(&buf[0], C.int(n))
+	for {
+		n := C.acl_object_name_copy(s.e.h, s.typeID, id, &buf[0], C.size_t(len(buf)))
+		if n < 0 {
+			break
+		}
+		if int(n) < len(buf) {
+			name = C.GoStringN(&buf[0], C.int(n))
+			break
+		}
+		buf = make([]C.char, int(n)+1)
 	}
 	return &v1.LookupResourcesResponse{LookedUpAt: s.at, ResourceObjectId: name,
 		Permissionship: v1.LookupPermissionship_LOOKUP_PERMISSIONSHIP_HAS_PERMISSION}, nil

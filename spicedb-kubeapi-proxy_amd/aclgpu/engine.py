@@ -43,11 +43,13 @@ def _b(s):
 
 class Engine:
     def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
-                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None, per_item_validation: bool = False):
+                 max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None, per_item_validation: bool = False,
+                 lenient_lookup: bool = False, eager_contexts: bool = False):
         """devices: HIP ordinals of the replicas (acl_open_replicas: ONE store and one set of name tables in front of one HBM snapshot per
         entry; a device may be listed more than once); default one replica on `device`."""
         self._L = _lib.load()
-        cfg = Config(device, frontier_entries, max_sub_batch, (1 if store_only else 0) | (2 if per_item_validation else 0), contexts, 0)  # ACL_FLAG_STORE_ONLY | ACL_FLAG_PER_ITEM_VALIDATION
+        cfg = Config(device, frontier_entries, max_sub_batch, (1 if store_only else 0) | (2 if per_item_validation else 0) | (4 if lenient_lookup else 0) | (8 if eager_contexts else 0), contexts, 0)
+        # (ACL_FLAG_STORE_ONLY | _PER_ITEM_VALIDATION | _LENIENT_LOOKUP | _EAGER_CONTEXTS)
         h = C.c_void_p()
         if devices:
             arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
@@ -111,11 +113,13 @@ class Engine:
     def object_name(self, t: str, i: int):
         """acl_object_name_copy: the name is copied out under the names lock (an id that takes part in no relationship may be renamed later)"""
         buf = C.create_string_buffer(256)
-        n = self._L.acl_object_name_copy(self._h, self.type_id(t), int(i), buf, len(buf))
-        if n >= len(buf):
-            buf = C.create_string_buffer(n + 1)
+        while True:  # (the id may be given a longer name between two copies: a length is only used once it fits the buffer it was copied into)
             n = self._L.acl_object_name_copy(self._h, self.type_id(t), int(i), buf, len(buf))
-        return None if n < 0 else buf.raw[:n].decode()
+            if n < 0:
+                return None
+            if n < len(buf):
+                return buf.raw[:n].decode()
+            buf = C.create_string_buffer(n + 1)
 
     def object_count(self, t: str) -> int:
         return self._L.acl_object_count(self._h, self.type_id(t))

@@ -1670,20 +1670,34 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
 // Schemas with `&` / `-`: the reverse walk only follows POSITIVE occurrences (plan_reverse.cpp), so what it marks is a superset -- the
 // candidates.  The answer is the candidates the forward walk grants: one bulk Check per lookup batch, bits of everything but HAS cleared.
 // (LookupResources(T, p, S) = {id : Check(T:id#p@S) = HAS}; reference call site pkg/authz/lookups.go:65.)
+// A candidate whose Check ERRS (a branch beyond the dispatch depth under an `&` / `-`) fails the CALL with that item's code: the reference's
+// stream ends at the first Recv error (lookups.go:75-83) and the list request with it (responsefilterer.go:196-204) -- it never sees a
+// silently shorter list.  ACL_FLAG_LENIENT_LOOKUP keeps the round-4/5 behaviour (such candidates are dropped, the call succeeds).
+int lookup_candidate_error(acl_engine *h, int32_t code, uint32_t id, uint32_t sid) {
+    (void)h;
+    return fail(code, std::string(code == ACL_ERR_DEPTH ? "LookupResources: max depth exceeded" : "LookupResources: a candidate's check failed") + " while checking candidate id " +
+                          std::to_string(id) + " for subject id " + std::to_string(sid) + " (the permission holds an intersection / exclusion: candidates are confirmed by a forward Check)");
+}
 static int lookup_refine(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words, size_t cw,
                          uint64_t *counts) {
     std::vector<acl_item_t> items;
     std::vector<uint8_t> answers;
+    std::vector<int32_t> errs;
     const uint16_t sr = (uint16_t)(srel < 0 ? ACL_NO_RELATION : srel);
     const size_t chunk = std::max<size_t>(h->max_sub_batch, 1);
+    const bool strict = !h->lenient_lookup;
     size_t i0 = 0;  // first lookup whose candidates are in `items`
     auto flush = [&](size_t i1) -> int {  // answers the candidates of lookups [i0, i1) and clears the denied ones
         if (!items.empty()) {
             answers.resize(items.size());
+            if (strict) errs.assign(items.size(), 0);
             for (size_t b = 0; b < items.size(); b += chunk) {
-                int rc = check_ids_host(h, c, items.data() + b, std::min(chunk, items.size() - b), answers.data() + b, nullptr);
+                int rc = check_ids_host(h, c, items.data() + b, std::min(chunk, items.size() - b), answers.data() + b, strict ? errs.data() + b : nullptr);
                 if (rc) return rc;
             }
+            if (strict)
+                for (size_t k = 0; k < items.size(); k++)
+                    if (errs[k]) return lookup_candidate_error(h, errs[k], items[k].resource_id, items[k].subject_id);
             size_t k = 0;
             for (size_t i = i0; i < i1; i++) {
                 uint32_t *row = bitmaps + i * words;
@@ -1892,6 +1906,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
         auto *so = new acl_engine();
         so->store_only = true;
         so->per_item_validation = (cfg->flags & ACL_FLAG_PER_ITEM_VALIDATION) != 0;
+        so->lenient_lookup = (cfg->flags & ACL_FLAG_LENIENT_LOOKUP) != 0;
         if (const char *ev = getenv("ACL_RAW_INTERN")) so->raw_intern = atoi(ev) != 0;  // (test knob, see below)
         batcher_create(so);
         *out = so;
@@ -1902,6 +1917,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
         return fail(ACL_ERR_UNAVAILABLE, "acl_open: no HIP device available (this engine has no CPU evaluation path)");
     auto h = std::make_unique<acl_engine>();
     h->per_item_validation = cfg && (cfg->flags & ACL_FLAG_PER_ITEM_VALIDATION) != 0;
+    h->lenient_lookup = cfg && (cfg->flags & ACL_FLAG_LENIENT_LOOKUP) != 0;
     // the replicas: the device list of acl_open_replicas, else ACL_DEVICES="0,1,2,3" (a device may be named more than once: N logical replicas
     // on one GPU -- what the one-GPU test boxes exercise), else the one device of the config
     std::vector<int> list;
@@ -1963,6 +1979,15 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
         if (rc) return rc;
         d->free_ctxs.push_back(c0.get());
         d->ctxs.push_back(std::move(c0));
+        // ACL_FLAG_EAGER_CONTEXTS: every context of the pool now -- a context made on demand costs its caller (and, under pool_mu, every caller that
+        // arrives meanwhile) the allocation of its frontier buffers and pinned staging, milliseconds into the first request that finds the pool busy
+        for (uint32_t k = 1; cfg && (cfg->flags & ACL_FLAG_EAGER_CONTEXTS) && k < h->max_ctx; k++) {
+            std::unique_ptr<PassCtx> ck;
+            rc = new_ctx(h.get(), d.get(), &ck, (int)k);
+            if (rc) return rc;
+            d->free_ctxs.insert(d->free_ctxs.begin(), ck.get());  // (behind the first one: the pool hands out the context released last)
+            d->ctxs.push_back(std::move(ck));
+        }
     }
     (void)hipSetDevice(h->dev0().device);
     batcher_create(h.get());

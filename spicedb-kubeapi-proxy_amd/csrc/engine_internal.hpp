@@ -361,6 +361,7 @@ struct acl_engine {
         for (auto &d : devs) d->rev_uploaded = v;
     }
     bool per_item_validation = false;  // ACL_FLAG_PER_ITEM_VALIDATION: ill-formed items of a bulk Check fail their own pair, not the call
+    bool lenient_lookup = false;       // ACL_FLAG_LENIENT_LOOKUP: a LookupResources candidate whose forward Check errs is dropped instead of failing the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
     // the single-launch walk met rows too long for its direct task lists on this snapshot (kOverflowDirect): later walks build their lists the general
     // way (reset when a snapshot is rebuilt); direct_tripped: that batch's redo is not a frontier overflow -- no back-off for it (walk_outcome)
@@ -513,6 +514,7 @@ int device_of(acl_engine *h, const void *p);  // HIP ordinal a device pointer li
 int check_device(acl_engine *h, PassCtx *c, const uint4 *d_items, size_t n, uint8_t *d_perm, int32_t *d_errout, bool try_local = true);  // try_local: the single-launch walk first
 // host items -> answers in host buffers through context c (pinned staging unless the caller's buffers are pinned)
 int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, bool items_on_device = false);  // items_on_device: c->d_items already holds them (items is not read)
+int lookup_candidate_error(acl_engine *h, int32_t code, uint32_t id, uint32_t sid);  // fails a LookupResources call with a candidate's Check error (lookups.go:75-83)
 int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
                  uint64_t *counts);
 bool empty(const char *s);

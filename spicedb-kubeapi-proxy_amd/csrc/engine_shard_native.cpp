@@ -494,8 +494,16 @@ int acl_shard_lookup_bulk(acl_engine_t *h, const acl_shard_comm_t *comm, int rty
             HIP_TRY(c->d_perm.ensure(items.size()));
             HIP_TRY(hipMemcpy(c->d_items.p, items.data(), items.size() * sizeof(acl_item_t), hipMemcpyHostToDevice));
             acl_shard_bulk_stats_t cst{};
-            rc = shard_check_core(h, c, comm, c->d_items.p, items.size(), c->d_perm.p, nullptr, &cst);
+            const bool strict = !h->lenient_lookup;  // (a candidate whose Check errs fails the call, as on the unsharded graph: lookup_refine)
+            if (strict) HIP_TRY(c->d_errout.ensure(items.size()));
+            rc = shard_check_core(h, c, comm, c->d_items.p, items.size(), c->d_perm.p, strict ? c->d_errout.p : nullptr, &cst);
             if (rc) return rc;
+            if (strict) {  // (every shard holds the same answers: all of them fail, or none)
+                std::vector<int32_t> errs(items.size());
+                HIP_TRY(hipMemcpy(errs.data(), c->d_errout.p, errs.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+                for (size_t k = 0; k < errs.size(); k++)
+                    if (errs[k]) return lookup_candidate_error(h, errs[k], items[k].resource_id, items[k].subject_id);
+            }
             st.exchanges += cst.exchanges;
             st.entries_exchanged += cst.entries_exchanged;
             st.exchanged_bytes += cst.exchanged_bytes;

@@ -146,6 +146,11 @@ def _combine_case():
     lookups = [("doc", p, "user", u, "") for u in ("alice", "bob", "frank", "nobody") for p in ("view", "edit", "strict", "odd", "everywhere", "vetted")]
     lookups += [("folder", "view", "user", "carol", ""), ("folder", "audit", "user", "alice", ""), ("group", "active", "user", "bob", ""), ("group", "active", "user", "zed", ""),
                 ("doc", "view", "group", "eng", "member")]
+    # Round 6: lookups whose candidates' forward Check ERRS -- `deep` holds deep1 through an exclusion whose subtracted operand lies beyond the dispatch depth
+    # and deep3 through an intersection with such an operand (both operands are needed: no race decides these).  The reference's stream ends with
+    # that error (pkg/authz/lookups.go:75-83) and the list request fails; the engine and both oracles fail the call (ACL_FLAG_LENIENT_LOOKUP:
+    # drop the candidate instead).  The harness records "!error:<code>"; test_ref_fixtures.compare pins failure against failure.
+    lookups += [("doc", p, "user", "deep", "") for p in ("view", "edit", "strict", "odd", "everywhere", "vetted")]
     return {"name": "combine", "schema": SCHEMA_NM, "relationships": rels, "checks": checks, "lookups": lookups}
 
 

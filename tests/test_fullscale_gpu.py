@@ -192,11 +192,17 @@ def test_c4_full_named_objects_through_strings(aclgpu):
         assert all(op[k] == 2 for k in np.flatnonzero(w.subj == u) if int(w.res[k]) in set(ids.tolist())) and any(int(w.res[k]) in set(ids.tolist()) for k in np.flatnonzero(w.subj == u))
 
 
-@pytest.mark.skipif(os.environ.get("ACL_SKIP_C5_FULL") == "1", reason="ACL_SKIP_C5_FULL=1")
-def test_c5_full_emulated_8_shards(aclgpu):
-    """100 M relationships / 10 M objects, hash(type) mod 8 on ONE device (emulated layout, SURVEY.md 8(d) C5): all 262 144
-    answers of a Check batch and one Filter bitmap against the oracle."""
-    from aclgpu import sharded, workloads
+C5_SKIP = pytest.mark.skipif(os.environ.get("ACL_SKIP_C5_FULL") == "1", reason="ACL_SKIP_C5_FULL=1")
+
+
+@pytest.fixture(scope="module")
+def c5(aclgpu):
+    """BASELINE config 5's graph (100 M relationships / 10 M objects) with the oracle's answers, built ONCE for the tests below: the Check
+    batch's 262 144 answers, and for eight LookupResources subjects -- deep-group members (the stream's own lookup subjects), a direct
+    viewer of namespaces, a pod creator, and a user nobody has a relationship with -- the DEFINITION {pod : Check == HAS} over a fixed
+    sample of 400 000 pods (all 8.45 M pods x 8 subjects would keep the oracle busy for minutes).  The oracle stays loaded for the one-replica
+    test (it also confirms ids the engine returns OUTSIDE the sample) and is dropped before the 8-shard test needs the memory."""
+    from aclgpu import workloads
     w = workloads.c5()
     assert 99_000_000 <= w.ntuples <= 101_000_000
     o = orc.Oracle(w.schema)
@@ -205,10 +211,93 @@ def test_c5_full_emulated_8_shards(aclgpu):
     rt, perm, st = w.check
     nt = host_threads()
     op, oe = o.check_bulk_ids_mt(nt, rt, perm, w.res, st, "", w.subj)
-    sub = int(w.lookup_subjects[0])
+    E = {(e[0], e[1], e[2]): (e[4], e[5]) for e in w.edges}
+    ns_viewer = int(np.bincount(E[("namespace", "viewer", "user")][1]).argmax())  # the user that views the most namespaces directly
+    creator = int(E[("pod", "creator", "user")][1][12345])
+    nobody = int(w.nobjects["user"]) + 7  # no relationship names this id
+    subs = np.asarray([int(x) for x in w.lookup_subjects[:5]] + [ns_viewer, creator, nobody], dtype=np.uint32)
     rng = np.random.default_rng(5)
     pods = np.unique(rng.integers(0, w.nobjects[rt], size=400_000)).astype(np.uint32)
-    lp, _le = o.check_bulk_ids_mt(nt, rt, perm, pods, st, "", np.full(pods.size, sub, dtype=np.uint32))
+    lp = [o.check_bulk_ids_mt(nt, rt, perm, pods, st, "", np.full(pods.size, s, dtype=np.uint32))[0] for s in subs]
+    d = {"w": w, "o": o, "op": op, "oe": oe, "subs": subs, "pods": pods, "lp": lp}
+    yield d
+    d.clear()
+
+
+@C5_SKIP
+def test_c5_full_one_replica_mixed_stream(aclgpu, c5):
+    """BASELINE configs[4]'s workload on ONE replica: the 100 M-relationship graph unsharded -- what every GPU of the
+    replica layout holds -- answering the mixed stream: 256 k-item Check batches and LookupResources(pod, view, user:U) over the
+    8.45 M-pod type, whose result rows (1 MB each) do not fit the block's LDS, so k_rev_local keeps them in HBM (`lds_words == 0`: the path
+    tests/test_lookup_local_gpu.py only reaches at scale 0.02 behind ACL_REV_LDS_ROWS=0).  The reference issues exactly this call per LIST
+    (pkg/authz/lookups.go:49-65).  Checked: every Check answer; per lookup the DEFINITION on the 400 000-pod sample, the id count against
+    the bitmap, and up to 50 000 of the returned ids OUTSIDE the sample against the oracle (no false grants anywhere)."""
+    from aclgpu import workloads
+    w, o, subs, pods = c5["w"], c5["o"], c5["subs"], c5["pods"]
+    rt, perm, st = w.check
+    nt = host_threads()
+    with aclgpu.Engine(w.schema) as e:
+        w.load(e)
+        items = e.make_items(rt, perm, w.res, st, "", w.subj)
+        p, er = e.check_bulk_ids(items)
+        assert np.array_equal(p, c5["op"]) and np.array_equal(er, c5["oe"])
+        e.stats_reset()
+        bms, counts = e.lookup_ids_batch(rt, perm, st, "", subs)
+        stl = e.stats()
+        assert stl["rev_local_passes"] >= 1, stl  # the single-launch reverse walk took the batch (result rows in HBM)
+        in_sample = np.zeros(w.nobjects[rt], dtype=bool)
+        in_sample[pods] = True
+        for i, s in enumerate(subs):
+            bits = np.unpackbits(bms[i].view(np.uint8), bitorder="little")[:w.nobjects[rt]]
+            assert np.array_equal(bits[pods] == 1, c5["lp"][i] == 2), (i, int(s))
+            assert int(counts[i]) == int(bits.sum()), (i, int(s))
+            extra = np.flatnonzero((bits == 1) & ~in_sample).astype(np.uint32)[:50_000]
+            if extra.size:
+                xp, _xe = o.check_bulk_ids_mt(nt, rt, perm, extra, st, "", np.full(extra.size, s, dtype=np.uint32))
+                assert (xp == 2).all(), (i, int(s), int((xp != 2).sum()))
+        assert int(counts[-1]) == 0 and int(counts[:5].min()) > 1000, counts  # nobody sees nothing; a deep-group member sees thousands of pods
+        # one lookup per call (the proxy's shape) returns the batch's row
+        for i in (0, 5, 7):
+            one, c1 = e.lookup_ids_batch(rt, perm, st, "", [int(subs[i])])
+            assert np.array_equal(one[0], bms[i]) and c1[0] == counts[i]
+        # the mixed stream itself (SURVEY 8(d) C5: 90 % Check batches / 10 % Filter requests, interleaved by the workload's seed), two callers
+        # at once as goroutines behind the shim would be: every step's answer equals the sequential one
+        import threading
+        ops = workloads.c5_stream(w, 24)
+        assert any(x == "C" for x in ops) and any(x != "C" for x in ops)
+        bad = []
+
+        def caller(mine):
+            for k in mine:
+                if ops[k] == "C":
+                    pk, ek = e.check_bulk_ids(np.roll(items, k * 4099))
+                    if not (np.array_equal(pk, np.roll(c5["op"], k * 4099)) and np.array_equal(ek, np.roll(c5["oe"], k * 4099))):
+                        bad.append(("C", k))
+                else:
+                    j = k % subs.size
+                    bk, ck = e.lookup_ids_batch(rt, perm, st, "", [int(subs[j])])
+                    if not (np.array_equal(bk[0], bms[j]) and ck[0] == counts[j]):
+                        bad.append(("F", k, j))
+
+        ths = [threading.Thread(target=caller, args=(range(t, len(ops), 2),)) for t in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not bad, bad
+
+
+@C5_SKIP
+def test_c5_full_emulated_8_shards(aclgpu, c5):
+    """100 M relationships / 10 M objects, hash(type) mod 8 on ONE device (emulated layout, SURVEY.md 8(d) C5): all 262 144
+    answers of a Check batch and one Filter bitmap against the oracle."""
+    from aclgpu import sharded
+    w, op, oe, pods = c5["w"], c5["op"], c5["oe"], c5["pods"]
+    rt, perm, st = w.check
+    sub, lp = int(c5["subs"][0]), c5["lp"][0]
+    o = c5.pop("o", None)  # (the eight stores below need the memory)
+    if o is not None:
+        o.close()
     del o
     engines = []
 

@@ -15,6 +15,7 @@ import pytest
 
 from oracle import orc
 from tests import ref_cases
+from tests.outcomes import outcome
 
 UNPINNED = ("PARITY UNPINNED: tests/golden/ref_{}.json is absent -- run `make -C oracle ref` where a Go toolchain and the reference's "
             "module cache exist (oracle/ref_spicedb/README.md)")
@@ -54,8 +55,15 @@ def compare(fx, case, perms, errs, lookup_sets):
         if not want_allow and i not in racy:  # error vs NO_PERMISSION (both deny): recorded, so pinned as well
             assert bool(errs[i]) == (fx["perm"][i] == "0"), (i, q, fx["perm"][i], fx["err_codes"].get(str(i)), errs[i])
     for i, lk in enumerate(case["lookups"]):
-        want = [x for x in fx["lookups"][i] if not x.startswith("!error:")]
-        assert sorted(lookup_sets[i]) == want, (lk, len(lookup_sets[i]), len(want))
+        # lookup_sets[i] is an outcome (tests/outcomes.py): ("ok", ids) or ("err", code).  A stream the real engine ended with an error ("!error:<code>" behind
+        # whatever it had streamed, oracle/ref_spicedb/main.go) must FAIL here too -- the reference fails the list request with it (lookups.go:75-83) --
+        # and a stream that ended at EOF must succeed with exactly its ids.
+        failed = [x for x in fx["lookups"][i] if x.startswith("!error:")]
+        kind, got = lookup_sets[i]
+        if failed:
+            assert kind == "err", (lk, failed, kind)
+        else:
+            assert kind == "ok" and sorted(got) == fx["lookups"][i], (lk, kind, len(fx["lookups"][i]))
 
 
 def compare_requests(fx, case, client):
@@ -95,7 +103,7 @@ def test_oracle_matches_embedded_spicedb(name, all_cases):
     for i in range(0, len(rels), 1000):
         o.write([(orc.OP_TOUCH, r) for r in rels[i:i + 1000]])
     res = [o.check(*q) for q in case["checks"]]
-    compare(fx, case, [r[0] for r in res], [r[1] for r in res], [o.lookup(*lk) for lk in case["lookups"]])
+    compare(fx, case, [r[0] for r in res], [r[1] for r in res], [outcome(o.lookup, *lk) for lk in case["lookups"]])
     compare_requests(fx, case, o)
 
 
@@ -110,7 +118,7 @@ def test_engine_matches_embedded_spicedb(name, all_cases, aclgpu_lib):
         for i in range(0, len(rels), 1000):
             e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 1000]])
         perms, errs = e.check_bulk(case["checks"])  # the string entry point, as the Go shim calls it
-        compare(fx, case, perms, errs, [e.lookup(*lk) for lk in case["lookups"]])
+        compare(fx, case, perms, errs, [outcome(e.lookup, *lk) for lk in case["lookups"]])
         compare_requests(fx, case, e)
 
 
@@ -131,6 +139,6 @@ def test_engine_matches_oracle_on_ref_cases(name, all_cases, aclgpu_lib):
         want = [o.check(*q) for q in case["checks"]]
         assert list(zip(perms, errs)) == want
         for lk in case["lookups"]:
-            assert e.lookup(*lk) == o.lookup(*lk), lk
+            assert outcome(e.lookup, *lk) == outcome(o.lookup, *lk), lk
         if case.get("requests"):  # API validation: the call's code / the pairs, request by request (the writes that succeed change both stores)
             assert ref_cases.replay_requests(e, case["requests"]) == ref_cases.replay_requests(o, case["requests"])

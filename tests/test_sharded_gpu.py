@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import orc
+from tests.outcomes import outcome
 from tests.test_oracle_cross import QUERIES, SCHEMA
 from tests.test_sharded_gloo import CHAIN_SCHEMA, chain_case, random_tuples
 
@@ -152,8 +153,11 @@ def test_sharded_random_graphs_and_depth(world, aclgpu):
             p, er = se.check_bulk_ids(items)
             got = []
             for (rt, pm, st, sid, sr) in lookups:
-                bm = se.lookup_ids_batch(rt, pm, st, sr, [e.find(st, sid)])
-                got.append({e.object_name(rt, int(b)) for b in bits(bm[0])})
+                try:
+                    bm = se.lookup_ids_batch(rt, pm, st, sr, [e.find(st, sid)])
+                    got.append(("ok", {e.object_name(rt, int(b)) for b in bits(bm[0])}))
+                except aclgpu.AclError as ex:  # a candidate's Check erred: EVERY shard fails the call, at the same point (they hold the same answers)
+                    got.append(("err", ex.code))
             return list(zip(p.cpu().tolist(), er.cpu().tolist())), got
 
         run.exchange = "alltoall" if world % 2 else "allgather"
@@ -165,7 +169,7 @@ def test_sharded_random_graphs_and_depth(world, aclgpu):
         for (got, lk) in outs:
             assert got == want, (ci, world, [(q, g, w_) for q, g, w_ in zip(queries, got, want) if g != w_][:5])
             for l, ids in zip(lookups, lk):
-                assert ids == co.lookup(*l), (ci, world, l)
+                assert ids == outcome(co.lookup, *l), (ci, world, l)
 
 
 @pytest.mark.parametrize("world,xcap", [(2, 0), (8, 0), (5, 8)])

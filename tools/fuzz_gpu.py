@@ -180,16 +180,29 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
             rt, perm = rng.choice([("pod", "view"), ("namespace", "view"), ("group", "member")] +
                                   ([("pod", "audit"), ("pod", "edit"), ("pod", "hidden"), ("group", "active"), ("pod", "everywhere"), ("pod", "vetted")] if combine else []))
             subs = rng.sample(users, rng.choice([1, 1, 3, 20]))
+            def out(fn, *a):  # ("ok", ids) or ("err", code): a lookup whose candidate's Check errs fails as a whole, in the engine and in the oracle
+                try:
+                    return ("ok", sorted(fn(*a)))
+                except Exception as ex:  # noqa: BLE001
+                    if getattr(ex, "code", None) is None:
+                        raise
+                    return ("err", ex.code)
+
             for u in subs[:3]:
-                a, b = e.lookup(rt, perm, "user", u), o.lookup(rt, perm, "user", u)
-                assert sorted(a) == sorted(b), f"step {step}: lookup {rt}#{perm}@user:{u}: engine-only {sorted(set(a) - set(b))[:5]}, oracle-only {sorted(set(b) - set(a))[:5]}"
+                a, b = out(e.lookup, rt, perm, "user", u), out(o.lookup, rt, perm, "user", u)
+                assert a == b, f"step {step}: lookup {rt}#{perm}@user:{u}: engine {a[0]} {str(a[1])[:200]}, oracle {b[0]} {str(b[1])[:200]}"
+                stats["lookups_failed"] = stats.get("lookups_failed", 0) + int(a[0] == "err")
             if len(subs) > 3:
                 ids = [e.intern("user", u) for u in subs]
-                bm, counts = e.lookup_ids_batch(rt, perm, "user", "", ids)
-                for j, u in enumerate(subs):
-                    want = set(o.lookup(rt, perm, "user", u))
-                    got = {e.object_name(rt, i) for i in range(e.object_count(rt)) if (bm[j][i >> 5] >> (i & 31)) & 1}
-                    assert got == want, f"step {step}: batched lookup {rt}#{perm}@user:{u}"
+                wants = [out(o.lookup, rt, perm, "user", u) for u in subs]
+                batch = out(lambda: [0] if e.lookup_ids_batch(rt, perm, "user", "", ids) is None else [1])
+                if any(w_[0] == "err" for w_ in wants):  # one failing lookup fails the batch call
+                    assert batch[0] == "err", f"step {step}: batched lookup {rt}#{perm}: the oracle fails {[u for u, w_ in zip(subs, wants) if w_[0] == 'err'][:3]}, the engine answered"
+                else:
+                    bm, counts = e.lookup_ids_batch(rt, perm, "user", "", ids)
+                    for j, u in enumerate(subs):
+                        got = sorted(e.object_name(rt, i) for i in range(e.object_count(rt)) if (bm[j][i >> 5] >> (i & 31)) & 1)
+                        assert got == wants[j][1], f"step {step}: batched lookup {rt}#{perm}@user:{u}"
             stats["lookups"] += len(subs)
         if verbose and step % 50 == 49:
             print(f"step {step + 1}/{steps}: {stats}, {len(live)} relationships, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
