@@ -460,13 +460,6 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out); /* *patched_out: 
  * copy-on-write view of the store, phase 1 catches it up with the writes since (the ordinary patcher), adopts and verifies it.
  * *adopted_out = 0 when the catch-up was not expressible as a patch (the engine then rebuilds synchronously). */
 int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out);
-/* The host-side twin of the device's name resolution (ACL_DEVICE_NAMES=1; csrc/engine_names.cpp, csrc/name_probe.hpp), for store-only engines: keeps a
- * byte copy of every type's name-slot array current from the tables' change lists -- exactly as the copy in HBM is kept --, checks it against the live tables
- * (ACL_ERR_INTERNAL if they differ), then resolves the named items over the COPY with the code k_resolve_names runs per record.  out[i] / err_out[i] as
- * acl_resolve_bulk_v gives them for well-formed ids; *n_unknown_out: items naming an object no table knows.  ACL_ERR_OUT_OF_RANGE: an id that does not fit
- * a 64-byte record (such a call resolves its names on the host). */
-int acl_selfcheck_names(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out, uint64_t *n_unknown_out);
-
 /* ---- measurement ---- */
 typedef struct {
     uint64_t check_items;      /* items answered since open / last reset */
@@ -489,7 +482,6 @@ typedef struct {
     uint64_t rev_local_passes;     /* LookupResources groups answered by that kernel (one launch for all reverse levels) */
     uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
     uint64_t ids_recycled;         /* object ids given a new name after their object had lost its last relationship (since the schema was loaded) */
-    uint64_t device_name_calls;    /* string calls (acl_check_bulk / _v) whose object names were resolved on the device (k_resolve_names) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

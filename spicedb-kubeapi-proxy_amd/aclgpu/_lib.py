@@ -28,7 +28,7 @@ SYMBOLS = [
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls", "acl_watch_wait", "acl_watch_recheck", "acl_load_bootstrap_yaml",
-    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_selfcheck_names",
+    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v",
 ]
 
 
@@ -79,7 +79,7 @@ class Stats(C.Structure):
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
                 ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64),
                 ("local_ms", C.c_double), ("local_passes", C.c_uint64), ("snapshot_compactions", C.c_uint64),
-                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64), ("device_name_calls", C.c_uint64)]
+                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64)]
 
 
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -164,7 +164,6 @@ def load():
     L.acl_check_bulk_v_opts.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(CallOpts)]
     L.acl_check_bulk_ids.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_resolve_bulk_v.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-    L.acl_selfcheck_names.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
     L.acl_check_bulk_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.acl_stream.argtypes = [H]
     L.acl_stream.restype = C.c_void_p

@@ -307,16 +307,6 @@ class Engine:
         self._check(self._L.acl_resolve_bulk_v(self._h, views.ctypes.data, n, items.ctypes.data, err.ctypes.data))
         return items[:n], err[:n]
 
-    def selfcheck_names(self, prepared):
-        """acl_selfcheck_names (store-only engines): the device's name resolution run on the CPU over a byte copy of the name tables that is
-        kept as the copy in HBM is -> (items, errors, number of items naming an unknown object)"""
-        views, n, _blob = prepared
-        items = np.zeros(max(1, n), dtype=ITEM_DTYPE)
-        err = np.zeros(max(1, n), dtype=np.int32)
-        unk = C.c_uint64()
-        self._check(self._L.acl_selfcheck_names(self._h, views.ctypes.data, n, items.ctypes.data, err.ctypes.data, C.byref(unk)))
-        return items[:n], err[:n], unk.value
-
     def check_bulk_prepared(self, prepared):
         arr, n, _keep = prepared
         perm = np.zeros(max(1, n), dtype=np.uint8)

@@ -9,8 +9,6 @@
 // There is no CPU evaluation path: without a GPU acl_open() fails.
 // Threading: engine_internal.hpp (state_mu / names_mu / PassCtx pool).
 #include "engine_internal.hpp"
-#include "name_copies.hpp"
-#include "name_probe.hpp"
 #include "validate.hpp"
 
 #include <pthread.h>
@@ -122,7 +120,6 @@ void merge_stats(acl_engine *h, PassCtx *c) {
     a.rev_local_passes += b.rev_local_passes;
     a.lookup_requests += b.lookup_requests;
     a.overflow_retries += b.overflow_retries;
-    a.device_name_calls += b.device_name_calls;
     b = acl_stats_t{};
 }
 
@@ -1398,158 +1395,6 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
     h->intern_pool->run(n, n >= 32768 ? 1024 : 512, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1, run);
 }
 
-// ---- PostFilter-sized string calls: the object names are resolved on the device (engine_names.cpp, kernels.hip k_resolve_names).  The host's
-// share per item is what only it can do -- type / permission names to indices (memoised: a pointer compare per field), the checks that need no
-// table -- and copying the two ids into the item's 64-byte record in pinned memory; the kernel reads the records across PCIe, the walk follows
-// on the same stream.  OFF by default (ACL_DEVICE_NAMES=1 turns it on): parity-green, but on these hosts no faster than the interning threads
-// -- 65 536 items 0.255-0.267 ms against 0.278-0.298 ms on the same box, 16 384 items slower (profiles/r05_device_names.txt): the host still
-// touches every item (75 us per 65 536) and 64 bytes per item cross PCIe (4.2 MB: ~85 us that nothing overlaps without paying more elsewhere).
-constexpr int kNoDeviceNames = -1001;         // internal: this call takes the host path (a name too long for a record, no mirror, ...)
-constexpr uint32_t kUnknownNamesCap = 4096;   // indices of items naming unknown objects that come back (more: every item's ids are looked at on the host)
-constexpr size_t kNameBytesMax = ObjectTable::kSlotInline;
-template <class Items>
-static void pack_names(acl_engine_t *h, const Items &its, size_t a, size_t b, PackedNames *out, std::vector<std::pair<uint32_t, int32_t>> *bad, std::mutex *bad_mu,
-                       std::atomic<bool> *does_not_fit) {
-    const Schema &sc = h->store.schema();
-    NameMemo m;
-    std::vector<std::pair<uint32_t, int32_t>> mybad;
-    for (size_t i = a; i < b; i++) {
-        PackedNames &r = out[i];
-        int32_t err = 0;
-        const char *rp = its.ptr(i, F_RID), *up = its.ptr(i, F_SID);
-        const std::string_view rid = rp ? std::string_view(rp, its.len(i, F_RID)) : std::string_view();
-        const std::string_view sid = up ? std::string_view(up, its.len(i, F_SID)) : std::string_view();
-        bool ok = intern_names(sc, its, i, m, &err);
-        // (the order of intern_items: an empty or ill-formed id beats an unknown type / permission; `*` is never asked about)
-        if (err != ACL_ERR_INVALID_ARGUMENT && (rid.empty() || sid.empty() || (!ok && (!valid_object_id(rid) || !valid_object_id(sid))))) {
-            ok = false;
-            err = ACL_ERR_INVALID_ARGUMENT;
-        }
-        if (ok && (rid == "*" || sid == "*")) {
-            ok = false;
-            err = ACL_ERR_INVALID_ARGUMENT;
-        }
-        std::memset(&r, 0, sizeof(r));
-        if (!ok) {
-            r.rt = r.st = kDeadType;
-            mybad.emplace_back((uint32_t)i, err);
-            continue;
-        }
-        const size_t rpad = (rid.size() + 3) & ~(size_t)3;
-        if (rid.size() > kNameBytesMax || sid.size() > kNameBytesMax || rpad + ((sid.size() + 3) & ~(size_t)3) > sizeof(r.bytes)) {
-            does_not_fit->store(true, std::memory_order_relaxed);  // the whole call goes the host's way
-            r.rt = r.st = kDeadType;
-            continue;
-        }
-        r.rt = (uint16_t)m.rti;
-        r.pm = (uint16_t)m.pmi;
-        r.st = (uint16_t)m.sti;
-        r.sr = (uint16_t)(m.sri == kNoRelation ? ACL_NO_RELATION : m.sri);
-        r.rlen = (uint8_t)rid.size();
-        r.slen = (uint8_t)sid.size();
-        std::memcpy(r.bytes, rid.data(), rid.size());
-        std::memcpy(r.bytes + rpad, sid.data(), sid.size());
-    }
-    if (!mybad.empty()) {
-        std::lock_guard<std::mutex> lk(*bad_mu);
-        bad->insert(bad->end(), mybad.begin(), mybad.end());
-    }
-}
-
-template <class Items>
-static int check_bulk_strings_device(acl_engine_t *h, PassCtx *c, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out,
-                                     std::vector<std::pair<uint32_t, int32_t>> *bad) {
-    static const bool kTimeIt = getenv("ACL_DEBUG_STRING_TIMING") != nullptr;
-    const int64_t t_a = kTimeIt ? mono_ns() : 0;
-    HIP_TRY(c->h_in.ensure(n * sizeof(PackedNames)));
-    HIP_TRY(c->d_items.ensure(n));
-    HIP_TRY(c->d_unknown.ensure(1 + kUnknownNamesCap));
-    HIP_TRY(c->h_unknown.ensure((1 + kUnknownNamesCap) * sizeof(uint32_t)));
-    PackedNames *recs = static_cast<PackedNames *>(c->h_in.p);
-    const PackedNames *d_recs = static_cast<const PackedNames *>(c->h_in.dp);
-    std::shared_lock<std::shared_mutex> use;  // the mirror, until this call's stream has run dry
-    std::mutex bad_mu;
-    std::atomic<bool> does_not_fit{false};
-    {
-        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
-        if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
-        const NameTab *d_tabs = nullptr;
-        int rc = names_mirror_acquire(h, c, &d_tabs, &use);
-        if (rc) return kNoDeviceNames;  // (out of device memory for the copy, ...: the host resolves the names)
-        HIP_TRY(hipMemsetAsync(c->d_unknown.p, 0, sizeof(uint32_t), c->stream));
-        {
-            std::lock_guard<std::mutex> lk(h->intern_pool_mu);
-            if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
-        }
-        // One pass of the interning threads over the batch, then ONE kernel that reads the records where they are.  Measured and not kept
-        // (profiles/r05_device_names.txt): slices with a kernel each -- joining the pool costs ~60 us a time; a kernel per finished 8 192 items
-        // while the rest is written -- latency-bound, ~35 us each; the copy engine per stretch and one kernel over HBM -- ~20 us of host time
-        // per hipMemcpyAsync.
-        const std::function<void(size_t, size_t)> job = [&](size_t x, size_t y) { pack_names(h, its, x, y, recs, bad, &bad_mu, &does_not_fit); };
-        h->intern_pool->run(n, 512, std::max(1u, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1), job);
-        if (!does_not_fit.load()) launch_resolve_names(c->stream, d_tabs, d_recs, (uint32_t)n, c->d_items.p, c->d_unknown.p, kUnknownNamesCap, 0u);
-    }
-    if (does_not_fit.load()) {
-        HIP_TRY(hipStreamSynchronize(c->stream));  // (nothing was launched; the memset is all there is to wait for)
-        bad->clear();
-        return kNoDeviceNames;
-    }
-    const int64_t t_b = kTimeIt ? mono_ns() : 0;
-    for (const auto &be : *bad)  // (as on the host path: a request that fails the API's validation fails as a whole)
-        if (be.second == ACL_ERR_INVALID_ARGUMENT && !h->per_item_validation) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(be.first) + " has an empty or ill-formed field");
-        }
-    HIP_TRY(hipMemcpyAsync(c->h_unknown.p, c->d_unknown.p, (1 + kUnknownNamesCap) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    int rc = check_ids_host(h, c, nullptr, n, perm_out, err_out, true);  // (returns with the stream run dry)
-    if (rc) {
-        (void)hipStreamSynchronize(c->stream);
-        return rc;
-    }
-    // names no table knows: their items were asked about with ids that have no relationships -- unless a name is not even well-formed
-    const uint32_t *unk = static_cast<const uint32_t *>(c->h_unknown.p);
-    auto look_at = [&](size_t i) {
-        const char *rp = its.ptr(i, F_RID), *up = its.ptr(i, F_SID);
-        if (recs[i].rt == kDeadType) return;  // (already in `bad`)
-        if (!valid_object_id(std::string_view(rp, its.len(i, F_RID))) || !valid_object_id(std::string_view(up, its.len(i, F_SID)))) bad->emplace_back((uint32_t)i, (int32_t)ACL_ERR_INVALID_ARGUMENT);
-    };
-    if (unk[0] <= kUnknownNamesCap)
-        for (uint32_t k = 0; k < unk[0]; k++) look_at(unk[1 + k]);
-    else
-        for (size_t i = 0; i < n; i++) look_at(i);
-    for (const auto &be : *bad)
-        if (be.second == ACL_ERR_INVALID_ARGUMENT && !h->per_item_validation)
-            return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(be.first) + " has an empty or ill-formed field");
-    c->stats.device_name_calls++;
-    if (kTimeIt) fprintf(stderr, "[aclgpu] string call of %zu items, names resolved on the device: records %.1f us, device %.1f us, unknown names %u\n", n, (t_b - t_a) / 1e3, (mono_ns() - t_b) / 1e3, unk[0]);
-    return ACL_OK;
-}
-
-// ---- acl_selfcheck_names: the same route on the CPU, over a byte copy of the slot arrays kept as the HBM mirror is (name_copies.hpp) and with
-// the code the kernel runs per record (name_probe.hpp) -- what the tests without a GPU see of it
-struct HostNameCopies {
-    std::mutex mu;
-    std::vector<NameCopyState> state;
-    std::vector<std::vector<uint4>> slots;
-    int resize(size_t nt) {
-        slots.resize(nt);
-        return 0;
-    }
-    int replace(size_t ty, size_t cap, const void *bytes) {
-        slots[ty].resize(cap * (ObjectTable::kSlotBytes / sizeof(uint4)));
-        if (cap) std::memcpy(slots[ty].data(), bytes, cap * ObjectTable::kSlotBytes);
-        return 0;
-    }
-    int patch(size_t ty, const std::vector<uint32_t> &idx, const void *bytes) {
-        for (uint32_t i : idx) std::memcpy((char *)slots[ty].data() + (size_t)i * ObjectTable::kSlotBytes, (const char *)bytes + (size_t)i * ObjectTable::kSlotBytes, ObjectTable::kSlotBytes);
-        return 0;
-    }
-};
-void host_name_copies_destroy(acl_engine *h) {
-    delete h->host_name_copies;
-    h->host_name_copies = nullptr;
-}
-
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
 template <class Items>
 static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o = nullptr) {
@@ -1564,18 +1409,6 @@ static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8
     if (rc) return rc;
     PassCtx *c = ev.c;
     std::vector<std::pair<uint32_t, int32_t>> bad;
-    if (h->device_names && n >= h->device_names_min && h->devs.size() == 1 && h->shard.world == 1 && !h->store_only && n <= 0xFFFFFFFFull) {
-        rc = check_bulk_strings_device(h, c, its, n, perm_out, err_out, &bad);
-        if (rc != kNoDeviceNames) {
-            if (rc) return rc;
-            for (const auto &be : bad) {
-                perm_out[be.first] = ACL_PERM_UNSPECIFIED;
-                err_out[be.first] = be.second;
-            }
-            return ACL_OK;
-        }
-        bad.clear();
-    }
     HIP_TRY(c->h_in.ensure(n * sizeof(acl_item_t)));
     acl_item_t *staged = (acl_item_t *)c->h_in.p;
     static const bool kTimeIt = getenv("ACL_DEBUG_STRING_TIMING") != nullptr;  // (stderr: where a string call's time goes -- tools/string_path.py)
@@ -1958,8 +1791,6 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_COMPACTION_SLACK")) h->compaction_slack = (uint64_t)std::max(0, atoi(ev));  // test knob (tools/fuzz_gpu.py --compact-early): small graphs compact too
     if (const char *ev = getenv("ACL_HOSTMAP_MAX")) h->hostmap_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob: batches up to this size are read / answered across PCIe by the kernel itself
-    if (const char *ev = getenv("ACL_DEVICE_NAMES")) h->device_names = atoi(ev) != 0;  // 1 = PostFilter-sized string calls resolve their object names on the device (off by default: engine_internal.hpp device_names)
-    if (const char *ev = getenv("ACL_DEVICE_NAMES_MIN")) h->device_names_min = (uint32_t)std::max(1, atoi(ev));  // test knob
     if (const char *ev = getenv("ACL_INTERN_THREADS")) h->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // A/B knob: host threads of bulk string interning
     if (const char *ev = getenv("ACL_LOCAL_CAP")) h->local_cap_limit = (uint32_t)std::max(256, atoi(ev));  // test knob: forces walks to overflow
     if (const char *ev = getenv("ACL_RAW_INTERN")) h->raw_intern = atoi(ev) != 0;  // test knob: acl_intern takes any bytes (the JSON scanners' decoding tests name objects no API request could)
@@ -2003,7 +1834,6 @@ void acl_close(acl_engine_t *h) {
     intern_pool_destroy(h);
     (void)acl_shard_rccl_destroy(h);
     compaction_join(h);
-    host_name_copies_destroy(h);
     if (h->store_only) {
         delete h;
         return;
@@ -2015,7 +1845,6 @@ void acl_close(acl_engine_t *h) {
             d->ctxs.clear();
         }
         (void)hipSetDevice(h->dev0().device);
-        names_mirror_destroy(h);
         h->shard_ctx.reset();
         if (h->compaction)
             for (auto &pd : h->compaction->per)
@@ -2248,49 +2077,6 @@ int acl_check_bulk(acl_engine_t *h, const acl_check_item_t *items, size_t n, uin
 int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out) {
     if (n && (!items || !perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_v: NULL buffer");
     return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
-}
-
-// the host-side twin of the device's name resolution (see HostNameCopies above)
-int acl_selfcheck_names(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out, uint64_t *n_unknown_out) {
-    if (n && (!items || !out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_selfcheck_names: NULL buffer");
-    if (!h->store_only) return fail(ACL_ERR_FAILED_PRECONDITION, "acl_selfcheck_names: store-only engines (an engine with a GPU keeps the tables' change lists for its copy in HBM)");
-    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
-    if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
-    {
-        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
-        if (!h->host_name_copies) h->host_name_copies = new HostNameCopies();
-    }
-    HostNameCopies &hc = *h->host_name_copies;
-    std::lock_guard<std::mutex> lk(hc.mu);
-    bool replaced = false;
-    (void)name_copies_need_replacing(h->store, hc.state);  // (what the mirror asks before it locks its readers out: exercised, nothing to lock here)
-    if (sync_name_copies(h->store, hc.state, hc, &replaced)) return fail(ACL_ERR_INTERNAL, "acl_selfcheck_names: the copy could not be brought up to date");
-    const size_t nt = h->store.schema().defs.size();
-    std::vector<NameTab> tabs(nt);
-    for (size_t ty = 0; ty < nt; ty++) {
-        const ObjectTable &t = h->store.objects((int)ty);
-        if (hc.state[ty].cap != t.slot_count() || hc.state[ty].version != t.version() ||
-            (t.slot_count() && std::memcmp(hc.slots[ty].data(), t.slot_bytes(), t.slot_count() * ObjectTable::kSlotBytes) != 0))
-            return fail(ACL_ERR_INTERNAL, "acl_selfcheck_names: the copy of type " + h->store.schema().defs[ty].name + "'s name slots differs from the table");
-        tabs[ty] = NameTab{t.slot_count() ? hc.slots[ty].data() : nullptr, (uint32_t)t.slot_count(), 0u};
-    }
-    std::vector<PackedNames> recs(std::max<size_t>(n, 1));
-    std::vector<std::pair<uint32_t, int32_t>> bad;
-    std::mutex bad_mu;
-    std::atomic<bool> does_not_fit{false};
-    pack_names(h, ViewItems{items}, 0, n, recs.data(), &bad, &bad_mu, &does_not_fit);
-    if (does_not_fit.load()) return fail(ACL_ERR_OUT_OF_RANGE, "acl_selfcheck_names: an object id does not fit a 64-byte record");
-    uint64_t unknown = 0;
-    for (size_t i = 0; i < n; i++) {
-        bool unk = false;
-        const uint4 it = name_resolve_record(tabs.data(), reinterpret_cast<const uint32_t *>(&recs[i]), &unk, HostMulHi{});
-        std::memcpy(&out[i], &it, sizeof(acl_item_t));
-        unknown += unk;
-        err_out[i] = 0;
-    }
-    for (const auto &be : bad) err_out[be.first] = be.second;
-    if (n_unknown_out) *n_unknown_out = unknown;
-    return ACL_OK;
 }
 
 // names -> the 16-byte items of the id entry points, in bulk and without a device pass (works on a store-only engine)

@@ -232,8 +232,6 @@ struct PassCtx {
     DevArray<uint32_t> d_ccount;   // [2] sharded graph, schemas with `&` / `-`: {leaf cells handed out, nodes appended} of this shard (the unsharded level loop counts in the status block)
     DevArray<uint4> d_nodes_all;   // ... the shards' node lists, all-gathered behind the walk
     uint32_t shard_pool_shift = 0; // ... log2 of how far the node / cell pools have been grown beyond their first size (kOverflowPools)
-    DevArray<uint32_t> d_unknown;  // [1 + kUnknownNamesCap] string calls resolved on the device: how many items named an object no table knows, and which (engine.cpp)
-    PinnedBuf h_unknown;
     DevArray<uint32_t> d_done;     // [1] arrival counter of a small host batch's blocks (zero between launches: the last block re-arms it; kernels.hip done_flag)
     uint32_t done_seq = 0;         // the value the next such launch stores into its pinned completion word
     // batch scratch
@@ -270,8 +268,6 @@ using namespace aclint;
 struct AsyncPool;
 namespace aclint {
 struct InternPool;  // engine.cpp
-struct NameMirror;  // engine_names.cpp
-struct HostNameCopies;  // engine.cpp (acl_selfcheck_names)
 }  // engine_async.cpp
 
 // Background snapshot compaction (engine.cpp).  Patching writes into the HBM snapshot leaves garbage behind (relocated
@@ -418,10 +414,6 @@ struct acl_engine {
     // async submit / wait (engine_async.cpp)
     AsyncPool *async = nullptr;  // created by the first submit, destroyed by async_shutdown
     aclint::InternPool *intern_pool = nullptr;  // host threads of bulk string interning (engine.cpp), created by the first large string batch
-    aclint::HostNameCopies *host_name_copies = nullptr;  // store-only engines: the host-side twin of the HBM mirror (acl_selfcheck_names)
-    aclint::NameMirror *name_mirror = nullptr;  // the name tables' slot arrays in HBM (engine_names.cpp), created by the first PostFilter-sized string call
-    bool device_names = false;     // ACL_DEVICE_NAMES=1: string calls of >= device_names_min items resolve their object names on the device (engine_names.cpp; parity-green, no faster than the host's threads on the boxes measured: profiles/r05_device_names.txt)
-    uint32_t device_names_min = 16384;
     std::mutex intern_pool_mu;
     std::mutex async_mu;
     // pinned buffers handed out by acl_host_alloc: [base, base + bytes)
@@ -522,8 +514,6 @@ FilterText to_filter(const acl_filter_t *f);
 // strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55).  Caller holds names_mu shared.
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
 void intern_pool_destroy(acl_engine_t *h);
-void names_mirror_destroy(acl_engine *h);
-int names_mirror_acquire(acl_engine *h, PassCtx *c, const NameTab **tabs_out, std::shared_lock<std::shared_mutex> *use_out);  // engine_names.cpp
 bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n items is answered by the kernel across PCIe (no copies)
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);

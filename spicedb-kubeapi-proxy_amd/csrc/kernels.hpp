@@ -124,24 +124,6 @@ uint32_t local_unit_max(bool wide = false);  // requests per unit, at most (= th
 void launch_dedup(hipStream_t s, const DevFrontier &f, uint32_t iter, uint64_t *table, uint32_t bits, bool cells = false);  // cells: the entries carry result cells (combine schemas): `table` is 1.5 x 2^bits words
 constexpr uint32_t kDedupBatch = 1u << 14;  // requests per dedup pass (the key holds 14 request bits)
 void launch_finalize(hipStream_t s, uint32_t n, const uint8_t *has, const uint8_t *err, uint8_t *perm_out, int32_t *err_out);
-// ---- object names resolved on the device (engine_names.cpp; string calls of PostFilter size: reference pkg/authz/postfilter.go:67-134).  The name
-// tables' slot arrays (store.hpp ObjectTable: 64-byte slots, open addressing) are mirrored in HBM; the host only copies each item's two names into a
-// 64-byte record and the kernel hashes, probes and compares them -- one lane per item, the record staged through LDS.
-struct NameTab {  // one per object type, in device memory
-    const uint4 *slots;  // 4 x uint4 per slot; nullptr: the type has no names
-    uint32_t cap, pad;
-};
-struct PackedNames {  // what the host writes per item (pinned memory, read across PCIe by the kernel)
-    uint16_t rt, pm, st, sr;  // as in acl_item_t; rt == 0xFFFF: the host already knows the item cannot be checked (a dead item comes out)
-    uint8_t rlen, slen, pad[2];
-    uint8_t bytes[52];  // the resource id at 0, the subject id at (rlen + 3) & ~3, both zero-padded to whole dwords
-};
-static_assert(sizeof(PackedNames) == 64, "one cache line per item");
-constexpr uint32_t kUnknownRes = 0xFFFFFFFDu, kUnknownSub = 0xFFFFFFFCu, kUnknownSame = 0xFFFFFFFEu;  // ids of names no table knows (engine.cpp intern_items)
-// items_out[i] = the acl_item_t of record i; unknown[0] counts the records with a name no table knows, unknown[1 ..] lists the first unknown_cap of them
-// (packed / items_out point at record `base` of the call's batch: the list holds indices into the whole batch)
-void launch_resolve_names(hipStream_t s, const NameTab *tabs, const PackedNames *packed, uint32_t n, uint4 *items_out, uint32_t *unknown, uint32_t unknown_cap, uint32_t base);
-void launch_scatter_slots(hipStream_t s, uint4 *slots, const uint32_t *idx, const uint4 *src, uint32_t n);  // slots[idx[k]] = src[k] (64 bytes each)
 // level loop, schemas with `&` / `-`: evaluates the combine nodes of frontier iteration `iter` (call for iter = last .. 1: a node only depends
 // on nodes of later iterations); the node count is read from g.ccount[1] on the device
 void launch_resolve(hipStream_t s, const DevGraph &g, uint32_t iter, uint8_t *has, uint8_t *err);

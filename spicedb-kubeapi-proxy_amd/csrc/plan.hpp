@@ -50,10 +50,39 @@ constexpr uint32_t kRowNbMask = 0x7FFFFFu;   // buckets of one row (< 2^23: 25 M
 constexpr uint32_t kRowTwoBit = 1u << 23;    // two-choice row (seed 0)
 ACL_HD inline uint32_t hrow_nb(uint32_t y) { return y & kRowNbMask; }
 ACL_HD inline uint32_t hrow_pack(uint32_t nb, uint32_t seed, bool two) { return nb | (two ? kRowTwoBit : 0u) | (seed << 24); }
-// the bucket of `id` in a single-choice row -- and the first choice in a two-choice row (seed 0)
-ACL_HD inline uint32_t hrow_bucket(uint32_t id, uint32_t y) {
+#ifndef ACL_ROW_HASH
+#define ACL_ROW_HASH 1  // 1 (round 6): FAST rows -- single-choice, fewer than 2^16 buckets: every row of the BASELINE graphs -- hash in full-rate 24-bit multiplies;
+                        // 0 = the 32-bit hash of round 5 for every row (A/B builds; the host builds the rows with whatever this says)
+#endif
+// Round 6: the bucket of `id` is computed once per CHILD in the walk's hottest loop, and round 5's hash cost it three quarter-rate instructions
+// (v_mul_lo_u32 x 2, v_mul_hi_u32: 48 issue cycles of a wave64 SIMD) -- profiles/r05_pmc_c4.md: the walk is instruction-issue bound.  A FAST row
+// (y & kRowSlowMask == 0: single-choice and nb < 2^16) uses
+//     t = id ^ (id >> 12) ^ seed        the high id bits folded onto the low 24, the row's seed xor-ed into the low byte
+//     h = lo24(t) * 0x9E3779            v_mul_u32_u24: full rate; bits 8..23 of the product = the classic multiplicative hash of a 24-bit word
+//     bucket = (bits(h, 8, 16) * nb) >> 16   v_mul_u32_u24 again: a 16-bit fraction times nb < 2^16 stays inside 32 bits
+// -- eight full-rate instructions with the address arithmetic.  hrow_fast() is IN RANGE for every row (nb is cut to 16 bits), so the kernels issue it
+// for all lanes unconditionally and redo the rare slow rows (two-choice, or 2^16 buckets and more: > 196 000 ids of one subject) behind a ballot.
+constexpr uint32_t kRowSlowMask = ACL_ROW_HASH ? 0x00FF0000u : 0xFFFFFFFFu;
+ACL_HD inline bool hrow_is_slow(uint32_t y) { return (y & kRowSlowMask) != 0u; }
+ACL_HD inline uint32_t hrow_fast(uint32_t id, uint32_t y) {
+    const uint32_t t = id ^ (id >> 12) ^ (y >> 24);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (said in the ISA's own words: only bits 8..23 of the product are used and those depend on the low 24 bits of t alone, so the compiler drops every
+    //  mask put on t -- __umul24's included -- and is then left with a 32 x 32-bit multiply, quarter rate)
+    uint32_t h, b;
+    asm("v_mul_u32_u24 %0, 0x9e3779, %1" : "=v"(h) : "v"(t));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(b) : "v"((h >> 8) & 0xFFFFu), "v"(y & 0xFFFFu));
+    return b >> 16;
+#else
+    const uint32_t h = (t & 0xFFFFFFu) * 0x9E3779u;  // (24 x 24 bits: the low 32 bits of the product, what v_mul_u32_u24 returns)
+    return (((h >> 8) & 0xFFFFu) * (y & 0xFFFFu)) >> 16;
+#endif
+}
+ACL_HD inline uint32_t hrow_slow(uint32_t id, uint32_t y) {
     return (uint32_t)(((uint64_t)((id ^ ((y >> 24) * 0x85EBCA6Bu)) * 0x9E3779B1u) * (y & kRowNbMask)) >> 32);
 }
+// the bucket of `id` in a single-choice row -- and the first choice in a two-choice row (seed 0)
+ACL_HD inline uint32_t hrow_bucket(uint32_t id, uint32_t y) { return hrow_is_slow(y) ? hrow_slow(id, y) : hrow_fast(id, y); }
 // the second choice of a two-choice row
 ACL_HD inline uint32_t hrow_bucket2(uint32_t id, uint32_t y, uint32_t h1) {
     const uint32_t nb = y & kRowNbMask;

@@ -21,10 +21,6 @@ static inline uint64_t mulfold(uint64_t a, uint64_t b) {
     const __uint128_t r = (__uint128_t)a * b;
     return (uint64_t)r ^ (uint64_t)(r >> 64);
 }
-uint64_t ObjectTable::next_version() {
-    static std::atomic<uint64_t> v{0};
-    return v.fetch_add(1, std::memory_order_relaxed) + 1;
-}
 uint64_t ObjectTable::hash(std::string_view s) {
     const unsigned char *p = reinterpret_cast<const unsigned char *>(s.data());
     size_t n = s.size();
@@ -57,7 +53,6 @@ void ObjectTable::grow() {
         while (slots_[i].id != 0xFFFFFFFFu) i = next(i);
         slots_[i] = s;
     }
-    changed_all();
 }
 bool ObjectTable::find(std::string_view name, uint32_t *id) const { return find_hashed(name, hash(name), id); }
 bool ObjectTable::find_hashed(std::string_view name, uint64_t h, uint32_t *id) const {
@@ -106,7 +101,6 @@ uint32_t ObjectTable::intern(std::string_view name) {
     if (slots_[i].id == kTomb) tombs_--;
     else used_++;
     slots_[i] = make_slot(h, id, names_.back());
-    changed(i);
     count_.store(id + 1, std::memory_order_release);
     return id;
 }
@@ -120,7 +114,6 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
             if (s.id == id) {
                 s = Slot{0, kTomb, 0, {}, nullptr};
                 tombs_++;
-                changed(i);
                 break;
             }
         }
@@ -138,7 +131,6 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
             while (slots_[i].id != 0xFFFFFFFFu) i = next(i);
             slots_[i] = s;
         }
-        changed_all();
     }
     if (full_for_one_more()) grow();
     const uint64_t h = hash(new_name);
@@ -147,7 +139,6 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
     if (slots_[i].id == kTomb) tombs_--;
     else used_++;
     slots_[i] = make_slot(h, id, stored);
-    changed(i);
 }
 const std::string *ObjectTable::name(uint32_t id) const {
     if (id >= name_of_.size() || name_of_[id] == 0xFFFFFFFFu) return nullptr;

@@ -105,26 +105,9 @@ class ObjectTable {
         tombs_ = o.tombs_;
         count_.store(o.count());
         repoint();
-        changed_all();
         return *this;
     }
-    // ---- the slot array as the device sees it (engine_names.cpp keeps a copy in HBM and resolves PostFilter-sized string calls there).  A slot
-    // is kSlotBytes bytes: {u32 tag, u32 id (0xFFFFFFFF empty, 0xFFFFFFFE tombstone), u16 length, kSlotInline name bytes, 8 bytes the device ignores};
-    // a name's home is home_of(hash, slot_count()), probes go to the next slot and wrap.  version() moves with every change of a slot; changes()
-    // hands over WHICH slots changed since it was last asked (or "all of them": a re-hash, an assignment, more than kDirtyMax changes) -- one
-    // consumer, which holds the names lock at least shared and its own mutex (the lists are written under the names lock held exclusively).
     static constexpr uint32_t kSlotBytes = 64, kSlotInline = 46, kSlotEmpty = 0xFFFFFFFFu, kSlotTomb = 0xFFFFFFFEu;
-    const void *slot_bytes() const { return slots_.data(); }
-    size_t slot_count() const { return slots_.size(); }
-    uint64_t version() const { return version_; }
-    static uint64_t home_of(uint64_t h, uint64_t slots) { return ((h & 0xFFFFFFFFull) * slots) >> 32; }
-    bool changes_are_wholesale() const { return dirty_all_; }  // what changes() would say, without taking it
-    void changes(std::vector<uint32_t> *slots_out, bool *all_out) const {
-        *all_out = dirty_all_;
-        slots_out->swap(dirty_);
-        dirty_.clear();
-        dirty_all_ = false;
-    }
 
   private:
     // One slot = one 64-byte cache line: tag = high half of the hash, the id, the name's length and its first kInline bytes.  A name that
@@ -139,7 +122,7 @@ class ObjectTable {
         char inl[kInline];
         const char *far;   // the whole name (len > kInline), else nullptr
     };
-    static_assert(sizeof(Slot) == kSlotBytes && offsetof(Slot, len) == 8 && offsetof(Slot, inl) == 10, "a slot is a cache line; the device mirror reads this layout");
+    static_assert(sizeof(Slot) == kSlotBytes && offsetof(Slot, len) == 8 && offsetof(Slot, inl) == 10, "a slot is a cache line");
     static Slot make_slot(uint64_t h, uint32_t id, const std::string &stored);
     // Capacity is NOT a power of two (round 5): a slot's home is the low half of the hash scaled into [0, capacity) (the
     // high half is the tag), so the table can grow by a quarter at a time.  Small tables double at load 0.5 as before (their probes stay
@@ -160,23 +143,6 @@ class ObjectTable {
     std::vector<Slot> slots_;            // load <= 0.5 (small tables, doubling) / <= 0.68 (from kBigTable slots on, growing by a quarter); < 2^32 slots
     size_t used_ = 0, tombs_ = 0;  // occupied slots incl. tombstones; tombstones among them
     std::atomic<uint32_t> count_{0};
-    // what the device mirror has yet to see (changes())
-    static constexpr size_t kDirtyMax = 16384;
-    static uint64_t next_version();  // process-wide: a table that REPLACES another one (schema reload) never repeats its predecessor's stamps
-    uint64_t version_ = next_version();
-    mutable std::vector<uint32_t> dirty_;
-    mutable bool dirty_all_ = true;
-    void changed(size_t slot) {
-        version_ = next_version();
-        if (dirty_all_) return;
-        if (dirty_.size() >= kDirtyMax) changed_all();
-        else dirty_.push_back((uint32_t)slot);
-    }
-    void changed_all() {
-        version_ = next_version();
-        dirty_all_ = true;
-        dirty_.clear();
-    }
 };
 
 // Sorted unique relationship keys behind a shared pointer (copy on write): a background snapshot build (engine.cpp, snapshot

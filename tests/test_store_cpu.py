@@ -363,109 +363,3 @@ def test_resolve_bulk_names_to_items(aclgpu_lib):
     e.write([(aclgpu.OP_TOUCH, ("pod", "ns/b", "viewer", "user", "u-new", ""))])
     assert e.find("user", "u-x") == ux and e.find("user", "u-new") != ux
     e.close()
-
-
-def test_names_resolved_over_a_copy_of_the_tables(aclgpu_lib, monkeypatch):
-    """What ACL_DEVICE_NAMES=1 does on the GPU (csrc/engine_names.cpp, k_resolve_names), run on the CPU by acl_selfcheck_names: a byte copy of the
-    name-slot arrays kept current from the tables' change lists (single slots, re-hashed arrays, tombstones of recycled ids), compared with the live
-    tables at every call, and the per-record code of the kernel (name_probe.hpp: record layout, hash, probe, compare) resolving ids of every length
-    over that copy -- item for item what acl_resolve_bulk_v gives."""
-    import aclgpu
-    import numpy as np
-    monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "0")  # freed ids go to the next new name at once
-    b = kat_runner.load_bootstrap()
-    e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
-    rng = np.random.default_rng(3)
-
-    def name(k, salt):  # an object id of exactly k bytes
-        s = f"{salt}-{k}-"
-        return (s + "x" * k)[:k] if k > len(s) else "abcdefghijklmnopqrstuvwxyz0123456789/_|-=+"[(k * 7 + salt) % 42] * k
-
-    def agree(qs, min_unknown=0):
-        pv = e.make_check_views(qs)
-        want_items, want_err = e.resolve_bulk_views(pv)
-        items, err, unknown = e.selfcheck_names(pv)
-        assert np.array_equal(err, want_err), [q for q, a, b_ in zip(qs, err, want_err) if a != b_][:3]
-        assert np.array_equal(items, want_items), [q for q, a, b_ in zip(qs, items, want_items) if a != b_][:3]
-        assert unknown >= min_unknown
-        return unknown
-
-    # ids of every length a slot holds inline, in two types; resource and subject share a record's 52 name bytes
-    rels = [("namespace", name(k, 1), "viewer", "user", name(min(k, 52 - ((k + 3) & ~3)), 2), "") for k in range(1, 47)]
-    e.write([(aclgpu.OP_TOUCH, r) for r in rels])
-    qs = []
-    for _ in range(1500):
-        k = int(rng.integers(1, 47))
-        j = int(rng.integers(1, min(46, 52 - ((k + 3) & ~3)) + 1))
-        kind = int(rng.integers(0, 4))
-        if kind == 0:
-            qs.append(("namespace", name(k, 1), "view", "user", name(j, 2), ""))
-        elif kind == 1:
-            qs.append(("namespace", name(k, 5), "view", "user", name(j, 2), ""))       # unknown resource
-        elif kind == 2:
-            qs.append(("namespace", name(k, 1), "view", "user", name(j, 6), ""))       # unknown subject (or a known one of another salt's letter)
-        else:
-            kk = (k - 1) % 24 + 1
-            qs.append(("namespace", name(kk, 7), "view", "namespace", name(kk, 7), "view"))  # the same unknown object twice
-    qs[3] = ("nosuchtype", "x", "view", "user", "u", "")
-    qs[4] = ("namespace", name(4, 1), "nosuchperm", "user", "u", "")
-    qs[5] = ("namespace", name(4, 1), "view", "user", "*", "")
-    qs[6] = ("namespace", "", "view", "user", "u", "")
-    assert agree(qs, min_unknown=300) < len(qs)
-    # a few new names (slots written in place), then thousands (re-hashes), then objects that leave and whose ids take new names (tombstones)
-    ups = [(aclgpu.OP_TOUCH, ("namespace", f"late-{i}", "viewer", "user", f"lateuser-{i}", "")) for i in range(12)]
-    e.write(ups)
-    agree(qs + [(u[1][0], u[1][1], "view", u[1][3], u[1][4], "") for u in ups])
-    for base in range(0, 5000, 1000):
-        e.write([(aclgpu.OP_TOUCH, ("namespace", f"bulk-{i}", "viewer", "user", f"bulkuser-{i % 900}", "")) for i in range(base, base + 1000)])
-    many = [("namespace", f"bulk-{i}", "view", "user", f"bulkuser-{i % 900}", "") for i in range(0, 5000, 7)]
-    assert agree(qs + many) < len(qs)
-    e.write([(aclgpu.OP_DELETE, u[1]) for u in ups])
-    e.write([(aclgpu.OP_TOUCH, ("namespace", f"reborn-{i}", "viewer", "user", f"rebornuser-{i}", "")) for i in range(12)])
-    assert e.stats()["ids_recycled"] > 0
-    gone = [(u[1][0], u[1][1], "view", u[1][3], u[1][4], "") for u in ups]
-    reborn = [("namespace", f"reborn-{i}", "view", "user", f"rebornuser-{i}", "") for i in range(12)]
-    items, err, unknown = e.selfcheck_names(e.make_check_views(gone + reborn))
-    assert unknown == 12 and not err.any() and all(int(x) >= 0xFFFFFFF0 for x in items["resource_id"][:12]) and all(int(x) < 0xFFFFFFF0 for x in items["resource_id"][12:])
-    agree(qs + many + gone + reborn)
-    # ids that do not fit a record are refused (such a call resolves its names on the host)
-    with pytest.raises(aclgpu.AclError) as ei:
-        e.selfcheck_names(e.make_check_views([("namespace", "a" * 30, "view", "user", "b" * 30, "")]))
-    assert ei.value.code == aclgpu.ERR_OUT_OF_RANGE
-    e.close()
-
-
-def test_copy_of_the_name_tables_under_random_writes(aclgpu_lib, monkeypatch):
-    """Property form of the test above: random runs of writes that create, drop and re-create objects of a small universe (ids recycled at once),
-    with a bootstrap reload in the middle of some -- after every step the copy of the name tables equals the live tables (checked inside
-    acl_selfcheck_names) and resolves every name of the universe, present or not, as acl_resolve_bulk_v does."""
-    import aclgpu
-    import numpy as np
-    from hypothesis import given, settings, strategies as st
-    monkeypatch.setenv("ACL_ID_QUARANTINE_MS", "0")
-    b = kat_runner.load_bootstrap()
-    universe = [("namespace", f"n{i}", "view", "user", f"u{i % 9}", "") for i in range(40)]
-    step = st.tuples(st.sampled_from(["touch", "delete", "reload", "burst"]), st.integers(0, 39), st.integers(0, 8))
-
-    @settings(max_examples=25, deadline=None)
-    @given(st.lists(step, min_size=1, max_size=25))
-    def run(steps):
-        e = aclgpu.Engine(b["schema"], "\n".join(b["relationships"]), store_only=True)
-        try:
-            pv = e.make_check_views(universe)
-            for op, i, u in steps:
-                if op == "touch":
-                    e.write([(aclgpu.OP_TOUCH, ("namespace", f"n{i}", "viewer", "user", f"u{u}", ""))])
-                elif op == "delete":
-                    e.write([(aclgpu.OP_DELETE, ("namespace", f"n{i}", "viewer", "user", f"u{uu}", "")) for uu in range(9)])
-                elif op == "reload":
-                    e.load_bootstrap(b["schema"], "\n".join(b["relationships"]))
-                else:  # enough new names for the tables to re-hash
-                    e.write([(aclgpu.OP_TOUCH, ("namespace", f"burst{i}-{k}", "viewer", "user", f"burstuser{u}-{k}", "")) for k in range(90)])
-                want_items, want_err = e.resolve_bulk_views(pv)
-                items, err, _unknown = e.selfcheck_names(pv)
-                assert np.array_equal(items, want_items) and np.array_equal(err, want_err), (op, i, u)
-        finally:
-            e.close()
-
-    run()

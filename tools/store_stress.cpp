@@ -194,17 +194,6 @@ int main(int argc, char **argv) {
                     else if (!reload && (acl_find(h, tp, std::string(items[i].resource_id.p, items[i].resource_id.n).c_str(), &id) || id != out[i].resource_id)) BAD();
                 }
             }
-            // the host-side twin of the device's name resolution: its copy of the slot arrays follows the writers' changes (checked against the live
-            // tables inside the call), and the pods' ids come out as above
-            {
-                std::vector<acl_item_t> twin(300);
-                std::vector<int32_t> terr(300);
-                uint64_t unknown = 0;
-                if (acl_selfcheck_names(h, items.data(), 300, twin.data(), terr.data(), &unknown)) { fprintf(stderr, "selfcheck_names: %s\n", acl_last_error()); BAD(); }
-                else if (!reload)
-                    for (size_t i = 0; i < 300; i += 7)
-                        if (terr[i] || twin[i].resource_id != out[i].resource_id || twin[i].resource_type != tp) BAD();
-            }
         }
     });
     // single checks: strings interned under the shared name lock, queued, refused by the pass (no GPU)

@@ -14,7 +14,7 @@ T=${T:-/tmp/aclgpu_tsan}
 mkdir -p $T
 T=$(cd $T && pwd)
 make -C $P -j8 lib/libaclgpu.so > /dev/null
-for f in schema store plan plan_reverse engine engine_names engine_shard engine_shard_native engine_callers engine_async engine_list bootstrap_yaml; do
+for f in schema store plan plan_reverse engine engine_shard engine_shard_native engine_callers engine_async engine_list bootstrap_yaml; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=thread -Wno-option-ignored -x hip -c $P/csrc/$f.cpp -o $T/$f.o 2> /dev/null &
 done
 wait
