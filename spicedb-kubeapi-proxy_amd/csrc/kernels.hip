@@ -130,10 +130,12 @@ __device__ unsigned long long acl_phase_cycles[16];
 
 // LDS-staged task list of one wave.
 #ifndef ACL_TASK_PAD
-#define ACL_TASK_PAD 1  // a task record is 20 bytes, not 16 (round 6; VERDICT r5 weak #2: 40 % of the walk's LDS cycles were bank-conflict cycles).  The children of a window
+#define ACL_TASK_PAD 0  // 1: a task record is 20 bytes, not 16 (round 6; VERDICT r5 weak #2: 40 % of the walk's LDS cycles were bank-conflict cycles).  The children of a window
                         // read the records of ~25 consecutive tasks, one dword each: at a 16-byte stride eight records cover the 32 banks and record j meets
                         // j + 8, j + 16, j + 24 in one bank (4-way conflicts on every per-child read); at 20 bytes (5 dwords, coprime with 32) 32 consecutive
-                        // records sit in 32 different banks.  0 = the 16-byte records (A/B builds)
+                        // records sit in 32 different banks.  MEASURED, same box (profiles/r06_ab_check_local.txt): C4 209.2 us padded against 208.4 us plain, the
+                        // replica 280.2 against 279.8 -- the conflicts lengthen LDS accesses that sit in the shadow of the global trips, and the padded
+                        // records cost 6 KB of LDS per block.  Off by default; kept as an A/B knob
 #endif
 struct TaskRec {
     uint32_t x, y, z, w;
@@ -1437,14 +1439,18 @@ struct LocalWalk {
     bool second;          // the pair's second segment is still to be taken
     const uint2 *sreq;    // E8: the unit's per-request constants {subject id, subject key} (LDS)
     uint32_t first;       // E8: the unit's first request
+    uint2 rawB = make_uint2(0u, 0u);  // ACL_PREFETCH_ENTRIES: the pair's second segment, fetched (undecoded) when the pair was claimed
+    bool have_rawB = false;
+    __device__ __forceinline__ uint2 raw(uint32_t i) const { return gld(reinterpret_cast<const uint2 *>(in), i); }
     __device__ __forceinline__ uint4 at(uint32_t i) const {
-        if (E8) return decode_entry8(gld(reinterpret_cast<const uint2 *>(in), i), sreq, first);
+        if (E8) return decode_entry8(raw(i), sreq, first);
         return gld(in, i);
     }
     __device__ __forceinline__ bool peek(uint4 &e, bool &valid) const {
         if (!second || (s + 1) * 64 >= n) return false;
         valid = (s + 1) * 64 + lane < n;
-        e = at(valid ? (s + 1) * 64 + lane : (s + 1) * 64);  // unconditional, like ChunkWalk::load
+        if (E8 && have_rawB) e = decode_entry8(rawB, sreq, first);
+        else e = at(valid ? (s + 1) * 64 + lane : (s + 1) * 64);  // unconditional, like ChunkWalk::load
         return true;
     }
     __device__ __forceinline__ void take() { second = false; }
@@ -1483,6 +1489,9 @@ struct InlineItems {  // up to four 16-byte items passed by value (kernel argume
 constexpr int kLocalNarrow = 4, kLocalWide = ACL_LOCAL_WIDE;
 #ifndef ACL_SPLIT_UNITS
 #define ACL_SPLIT_UNITS 0  // 1 (A/B builds; measured C4 228.4 -> 226.0 us but C5R 297 -> 304 us, level barriers 19 -> 15 % of the wave-time: profiles/r05_ab_split_units.txt): the wide monotone walk cuts a unit into two HALVES whose levels turn over independently (k_check_local); 0 = one barrier per level (A/B builds)
+#endif
+#ifndef ACL_PREFETCH_ENTRIES
+#define ACL_PREFETCH_ENTRIES 1  // the single-launch walk fetches the NEXT pair's entries before it expands the current pair (k_check_local's claim loop); 0 = A/B builds
 #endif
 #ifndef ACL_TAIL_SINGLES
 #define ACL_TAIL_SINGLES 0  // N > 0 (A/B builds): the last 2 N x WAVES segments of a level are claimed one by one instead of in pairs (see the claim loop)
@@ -1704,6 +1713,60 @@ __global__ __launch_bounds__(WAVES * 64, ACL_LOCAL_WAVES_PER_SIMD) void k_check_
             // fifth of the walk's wave-time.  Measured slower, 227.5 -> 231 -> 238 us for N = 0, 1, 2 on C4: profiles/r05_ab_seeded_rows.txt.)
             const uint32_t nseg = (cnt + 63u) >> 6;
             const uint32_t npair = (ACL_TAIL_SINGLES && nseg > 2u * WAVES * ACL_TAIL_SINGLES) ? (nseg - 2u * WAVES * ACL_TAIL_SINGLES + 1u) >> 1 : (ACL_TAIL_SINGLES ? 0u : nseg);
+#if ACL_PREFETCH_ENTRIES
+            if (E8 && !ACL_TAIL_SINGLES) {
+                // ---- the NEXT pair's entries travel while the current pair is expanded (round 6).  A pair's walk is a chain of dependent trips -- its entries,
+                // the parents' descriptors, then edges and buckets per step -- and the first of them, the entries (an L2 hit: this block wrote them a level
+                // ago), was a tenth of the walk's wave-time (profiles/r04_phases_final.txt "entries wait").  A wave now claims pair k + 1 and issues the
+                // loads of its 128 raw 8-byte entries (4 VGPRs) BEFORE it expands pair k; they are decoded when their turn comes.  Claiming ahead
+                // is only done while at least a round of pairs is still unclaimed: a pair held by a busy wave while other waves stand at the level
+                // barrier would lengthen the level's tail (the last WAVES pairs are claimed the old way, when their wave is free).
+                auto claim = [&]() -> uint32_t {
+                    uint32_t c = 0;
+                    if (lane == 0) c = atomicAdd(next_seg, 1u);
+                    return 2u * uniform(c);
+                };
+                auto fetch = [&](uint32_t sgp, uint2 &ra, uint2 &rb) {
+                    const uint32_t last = cnt - 1u;
+                    ra = lw.raw(min(sgp * 64u + lane, last));
+                    rb = lw.raw(min(sgp * 64u + 64u + lane, last));
+                };
+                uint32_t sg = claim();
+                uint2 rA = make_uint2(0u, 0u), rB = rA;
+                if (sg < nseg) fetch(sg, rA, rB);
+                while (sg < nseg) {
+                    uint32_t sgn = nseg;
+                    uint2 nA = make_uint2(0u, 0u), nB = nA;
+                    const uint32_t seen = uniform(__hip_atomic_load(next_seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    const bool ahead = 2u * (seen + (uint32_t)WAVES) < nseg;
+                    if (ahead) {
+                        sgn = claim();
+                        if (sgn < nseg) fetch(sgn, nA, nB);
+                    }
+                    {
+                        lw.s = sg;
+                        lw.second = true;
+                        lw.rawB = rB;
+                        lw.have_rawB = true;
+                        const bool v = sg * 64u + lane < cnt;
+                        process_segment<false, true, CMB>(decode_entry8(rA, s_req, first), v, lw, t, wo, lane, g, progs, ops, has, err, nosh, co);
+                        if (lw.second && (sg + 1u) * 64u < cnt) {  // the pair's second segment did not go with the first
+                            lw.s = sg + 1u;
+                            lw.second = false;
+                            const bool vb = (sg + 1u) * 64u + lane < cnt;
+                            process_segment<false, true, CMB>(decode_entry8(rB, s_req, first), vb, lw, t, wo, lane, g, progs, ops, has, err, nosh, co);
+                        }
+                    }
+                    if (!ahead) {
+                        sgn = claim();
+                        if (sgn < nseg) fetch(sgn, nA, nB);
+                    }
+                    sg = sgn;
+                    rA = nA;
+                    rB = nB;
+                }
+            } else
+#endif
             for (;;) {
                 uint32_t sg = 0;
                 if (lane == 0) sg = atomicAdd(next_seg, 1u);
