@@ -1470,15 +1470,61 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
         d_rows = c->d_rows.p;
     } else if (direct) HIP_TRY(hipHostGetDevicePointer(&d_rows, bitmaps, 0));
     else d_rows = (char *)d_out + rows_off;
+    // Rows that do not fit the block's LDS (a type of more than 1 M objects; reference pkg/authz/lookups.go:49-65 asks for the whole type): the heavy terminal
+    // rows are deferred to a chip-wide launch and the rows are copied / counted / cleared by a third one (kernels.hip RevDefer; ACL_REV_BIG_ROWS=0: one block
+    // does it all, as in round 5 -- A/B)
+    const uint32_t lds_row_words = h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u;
+    RevBigRows big;
+    const size_t bm_stride = (((size_t)h->snap.slot_nobjects[target] + 127) / 128) * 128;
+    const bool use_big = h->rev_big_rows && (lds_row_words == 0 || (size_t)lds_row_words * 4 > kRevLdsRowBytes) && cw > 0 &&
+                         (h->snap.rprogs[target].n & ~kRevRemoteBit) == 0 &&  // (a result slot nobody expands: its marks need no first-visit answer)
+                         m * bm_stride <= ((size_t)2 << 30) && bm_stride <= 0xFFFFFF80ull;
+    if (use_big) {
+        if (c->d_big_bytes.n < m * bm_stride || !c->d_big_bytes.p) {
+            HIP_TRY(c->d_big_bytes.ensure(m * bm_stride));
+            c->big_bytes_zeroed = 0;
+        }
+        if (c->big_bytes_zeroed < m * bm_stride) {
+            HIP_TRY(hipMemsetAsync(c->d_big_bytes.p, 0, m * bm_stride, c->stream));
+            c->big_bytes_zeroed = m * bm_stride;
+        }
+        const size_t tcap = std::min<size_t>(1u << 16, std::max<size_t>(4096, ((size_t)64 << 20) / 8 / m));  // <= 64 MiB of task lists per batch
+        HIP_TRY(c->d_big_tasks.ensure(m * tcap));
+        HIP_TRY(c->d_big_meta.ensure(2 * m));
+        if (c->d_big_counts.n < m || !c->d_big_counts.p) {
+            HIP_TRY(c->d_big_counts.ensure(m));
+            c->big_counts_zeroed = 0;
+        }
+        if (c->big_counts_zeroed < m) {
+            HIP_TRY(hipMemsetAsync(c->d_big_counts.p, 0, m * sizeof(uint64_t), c->stream));
+            c->big_counts_zeroed = m;
+        }
+        HIP_TRY(c->d_done.ensure(1));
+        big = RevBigRows{c->d_big_bytes.p, (uint32_t)bm_stride, c->d_big_tasks.p, c->d_big_meta.p, c->d_big_meta.p + m, c->d_big_counts.p, (uint32_t)tcap, h->rev_defer_min};
+    }
     ev_begin(c, 3);
     launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target, c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
-                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u,
-                     spin ? c->d_done.p : nullptr, spin ? (uint32_t *)d_out + 15 : nullptr, done_val);
+                     (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, lds_row_words,
+                     (spin || use_big) ? c->d_done.p : nullptr, spin ? (uint32_t *)d_out + 15 : nullptr, done_val, use_big ? &big : nullptr);
     ev_end(c);
     if (via_device) HIP_TRY(hipMemcpyAsync(direct ? (void *)bitmaps : (void *)h_rows, c->d_rows.p, m * ostride * 4, hipMemcpyDeviceToHost, c->stream));
     // (the proxy's shape is ONE LookupResources per list request, lookups.go:65: the caller spins on the completion word -- spin_for)
     if (!(spin && spin_for(flag + 15, done_val))) HIP_TRY(hipStreamSynchronize(c->stream));
     ev_collect(c);
+    if (*flag && use_big) c->big_bytes_zeroed = 0;  // (a block gave up half-way: marks of rows nobody folded may be left)
+    static const bool kDebugRev = getenv("ACL_DEBUG_REV") != nullptr;  // (stderr: what the walk deferred -- tools/lookup_big_probe.py)
+    if (kDebugRev && use_big) {
+        std::vector<uint32_t> meta(2 * m);
+        std::vector<uint64_t> tk(std::min<size_t>(big.task_cap, 4096));
+        (void)hipMemcpy(meta.data(), c->d_big_meta.p, meta.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < std::min<size_t>(m, 4); i++) {
+            (void)hipMemcpy(tk.data(), c->d_big_tasks.p + i * big.task_cap, std::min<size_t>(meta[i], tk.size()) * 8, hipMemcpyDeviceToHost);
+            uint64_t kids = 0;
+            for (size_t k = 0; k < std::min<size_t>(meta[i], tk.size()); k++) kids += tk[k] >> 32;
+            fprintf(stderr, "[aclgpu] lookup %zu: %u deferred rows (%llu children in the first %zu), %u reverse levels, status %u\n", i, meta[i], (unsigned long long)kids,
+                    std::min<size_t>(meta[i], tk.size()), meta[m + i], *flag);
+        }
+    }
     if (*flag == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     if (*flag) {
         c->stats.overflow_retries++;
@@ -1788,6 +1834,8 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_REV_DEFER_MIN")) h->rev_defer_min = (uint32_t)std::max(1, atoi(ev));  // test knob: small graphs defer too
+    if (const char *ev = getenv("ACL_REV_BIG_ROWS")) h->rev_big_rows = atoi(ev) != 0;  // A/B knob: 0 = rows beyond the LDS are walked, copied and cleared by ONE block (round 5)
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_COMPACTION_SLACK")) h->compaction_slack = (uint64_t)std::max(0, atoi(ev));  // test knob (tools/fuzz_gpu.py --compact-early): small graphs compact too
     if (const char *ev = getenv("ACL_HOSTMAP_MAX")) h->hostmap_max = (uint32_t)std::max(0, atoi(ev));  // A/B knob: batches up to this size are read / answered across PCIe by the kernel itself

@@ -239,6 +239,12 @@ struct PassCtx {
     DevArray<int32_t> d_errout;
     DevArray<uint4> d_items;
     DevArray<uint32_t> d_sids, d_visited, d_rows;
+    // result rows beyond the block's LDS (kernels.hpp RevBigRows): the lookups' deferred terminal rows, their counts / levels, the id-count accumulators
+    DevArray<uint8_t> d_big_bytes;  // the lookups' byte maps, zero between launches (bytes_zeroed: the leading bytes known to be)
+    size_t big_bytes_zeroed = 0;
+    DevArray<uint64_t> d_big_tasks, d_big_counts;
+    DevArray<uint32_t> d_big_meta;  // [2 m]: task counts, levels
+    size_t big_counts_zeroed = 0;   // leading accumulators known to be zero (k_rev_rows re-arms what it used)
     size_t visited_zero_words = 0;  // leading words of d_visited known to be all zero: k_rev_local takes `visited` zeroed and hands it back zeroed (kernels.hip)
     DevArray<uint4> d_nodes;     // schemas with `&` / `-`: the CombineNode records of a pass (plan.hpp)
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
@@ -404,6 +410,8 @@ struct acl_engine {
     bool rev_rows_device = false;  // k_rev_local's result rows through a device buffer + one DMA copy instead of kernel writes to host memory (A/B)
     bool shard_a2a = true;  // native sharded Check: per-destination blocks through the communicator's all_to_all when it has one (ACL_SHARD_A2A=0: all-gather)
     bool rev_lds_rows = true;  // k_rev_local keeps the result slot's rows in LDS when they fit (ACL_REV_LDS_ROWS=0: always in HBM; A/B and tests)
+    uint32_t rev_defer_min = 0;  // 0 = the kernels' default (4096 children per round); ACL_REV_DEFER_MIN: test knob
+    bool rev_big_rows = true;   // result rows beyond the LDS: deferred terminal rows + chip-wide row copy (kernels.hip RevDefer); ACL_REV_BIG_ROWS=0 switches it off (A/B)
     bool rev_local = true;  // LookupResources: the single-launch reverse walk (k_rev_local) first; ACL_REV_LOCAL=0 = always the level loop (A/B)
     uint32_t lk_target = 0;  // sharded lookup in flight: target slot, number of requests
     size_t lk_n = 0;

@@ -2153,10 +2153,33 @@ __device__ __forceinline__ void signal_done(uint32_t *done_ctr, uint32_t *done_f
     }
 }
 
+// Round 6 -- BIG result types (rows beyond the block's LDS: the 8.45 M pods of BASELINE configs[4]'s graph, a 1 MB row).  One block enumerated every child of
+// such a lookup -- 100-200 k pods under a few hundred namespaces and groups -- at ~5.5 ns each: 0.65-1.2 ms per lookup (profiles/r06_lookup_big.txt), and the
+// level loop, which spreads a lookup over the chip, pays ~80 us per level for it.  What makes these lookups heavy is almost entirely TERMINAL: children in the
+// lookup's own result slot, which are marked and never expanded -- no first-visit answer is needed, no order, no frontier.  So with `dfr.tasks` given the block
+// does not enumerate such rows when a round holds `min_children` children or more: it appends {first edge, degree} to the lookup's DEFERRED list and walks on;
+//   k_rev_terminal  (the next launch on the stream, blocks all over the chip) marks the deferred rows' ids in the lookup's result row -- a kernel boundary
+//                   later, so the block's workgroup-scope marks are in memory and agent-scope atomics from every XCD meet them there;
+//   k_rev_rows      (the launch after) copies the rows out slice by slice from all CUs, counts the ids, clears the slices it copied -- the three things that
+//                   cost one block 80 us per lookup -- and the last block to finish hands the counts over and raises the caller's completion word.
+struct RevDefer {
+    uint2 *tasks = nullptr;      // [lookups][cap] {first edge, degree}; nullptr: nothing is deferred and the block copies its row itself (rows in LDS)
+    uint32_t *count = nullptr;   // [lookups] tasks appended (zeroed by the block)
+    uint32_t *levels = nullptr;  // [lookups] reverse levels walked (statistics; k_rev_rows packs them into the counts)
+    uint32_t cap = 0;
+    uint32_t min_children = 4096;  // children of one round from which its terminal rows go to the chip-wide launch (below: the block is done with them sooner than a launch starts)
+    // The marks themselves are BYTES, not bits: one byte per object of the result type, [lookups][bm_stride], zero between launches.  Marking 100-200 k ids with
+    // atomic ORs -- workgroup scope from one CU (round 5) or agent scope from all of them (this round's first version) -- ran at ~5 ns per id either way
+    // (profiles/r06_lookup_big.txt): the read-modify-write is the cost.  A result slot nobody expands needs no answer from the mark, so a plain byte store does
+    // (idempotent, no neighbour to lose); k_rev_rows folds 32 bytes into a word of the caller's row and zeroes the bytes it found set.
+    uint8_t *bytemap = nullptr;
+    uint32_t bm_stride = 0;
+};
+
 __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_slot,
                                                                  uint2 *buf0, uint2 *buf1, uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride,
                                                                  uint32_t copy_words, unsigned long long *out_counts, uint32_t *status, uint32_t lds_words, uint32_t *done_ctr,
-                                                                 uint32_t *done_flag, uint32_t done_val) {
+                                                                 uint32_t *done_flag, uint32_t done_val, RevDefer dfr) {
     __shared__ RevTaskLds t;
     __shared__ RevProgLds pl;
     // lds_words != 0: the RESULT slot's rows live here, not in `visited` -- the level that produces a lookup's ids (thousands of pods under
@@ -2174,10 +2197,12 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     (void)buf1;
     const uint2 *__restrict__ rmeta2 = reinterpret_cast<const uint2 *>(r.rmeta);
     const uint32_t *__restrict__ redges = r.redges;
+    __shared__ uint32_t s_dfr;  // tasks this block has deferred
     if (tid == 0) {
         s_end = 0;
         s_stop = 0;
         s_maxops = 0;
+        s_dfr = 0;
     }
     if (tid < kRevLdsSlots / 32) s_nomark[tid] = 0;
     __syncthreads();
@@ -2216,6 +2241,10 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                 if (tgt & kRevTerminal) (void)atomicOr(&s_row[id >> 5], m);
                 else push = !(atomicOr(&s_row[id >> 5], m) & m);
                 return push;
+            }
+            if (dfr.bytemap) {  // (rows in HBM, result slot terminal: the mark is the object's byte)
+                if (ok) dfr.bytemap[(size_t)req * dfr.bm_stride + id] = 1;
+                return false;
             }
         } else if (tgt & kRevTerminal) {
             return false;  // neither expanded nor part of the answer: no bit
@@ -2273,9 +2302,23 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                 }
                 if (j < (p.n & ~kRevRemoteBit)) {
                     const RevOp op = pl.ops[p.first + j];
-                    const uint32_t np = pl.progs[op.target].n & ~kRevRemoteBit;
+                    uint32_t np = pl.progs[op.target].n & ~kRevRemoteBit;
                     tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all | ((op.flags & OP_NOMARK) ? kRevNoMark : 0u);
-                    if (op.flags & OP_PUSH_SAME) {
+                    // Round 6: a row whose children land in a relation that does nothing but feed ONE permission nobody expands -- `pod#viewer`, whose only
+                    // parent is the computed userset in `pod#view = viewer + ...` -- marks that permission's objects directly, one dispatch level further
+                    // on (so only while that level is still inside the depth limit).  The intermediate states were first-visited, logged and pushed
+                    // through a level of their own, 1 024 per round: half of a big lookup's ids took that detour at ~5 ns each (profiles/r06_lookup_big.txt),
+                    // and it is what kept their rows out of the deferred list.  Nobody reads the intermediate slot's bits unless it is the result slot.
+                    if (!(op.flags & OP_PUSH_SAME) && np == 1u && op.target != target_slot) {
+                        const RevOp via = pl.ops[pl.progs[op.target].first];
+                        if ((via.flags & OP_PUSH_SAME) && (pl.progs[via.target].n & ~kRevRemoteBit) == 0u) {
+                            if (level + 1u <= kMaxLevels) tgt = via.target | kRevTerminal;
+                            else np = 0xFFFFFFFFu;  // (the permission's level lies beyond the limit: the relation's states are marked -- nobody asks -- and end there)
+                        }
+                    }
+                    if (np == 0xFFFFFFFFu) {
+                        // nothing to enumerate for this op
+                    } else if (op.flags & OP_PUSH_SAME) {
                         same = true;
                     } else if ((op.flags & OP_WILD) || id < op.nrows) {  // (OP_WILD, seeds only: the wildcard subject's row, whatever the seed's id)
                         const uint2 rd = rmeta2[op.roff_base + ((op.flags & OP_WILD) ? 0u : id)];
@@ -2301,6 +2344,34 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                 const uint32_t wt = s_wave_tot[w];
                 before += w < wib ? wt : 0u;
                 total += wt;
+            }
+            if (dfr.tasks && total >= dfr.min_children) {  // (block-uniform) a heavy round: its terminal rows of the result slot go to the chip-wide launch
+                const bool mine = deg != 0u && (tgt & kRevTerminal) && (tgt & ~(kRevTerminal | kRevNoMark)) == target_slot;
+                const uint64_t b = __ballot(mine);
+                if (b) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_dfr, (uint32_t)__popcll(b));
+                    base = uniform(base);
+                    if (base + (uint32_t)__popcll(b) > dfr.cap) {
+                        if (lane == 0) s_stop = 1u;  // (more rows than the list holds: the level loop takes the batch)
+                    } else if (mine) {
+                        dfr.tasks[(size_t)req * dfr.cap + base + lanes_below(b)] = make_uint2(start, deg);
+                        deg = 0;
+                    }
+                }
+                __syncthreads();  // (every wave has read the totals above)
+                const uint32_t incl2 = wave_incl_scan(deg, lane);
+                if (lane == 63) s_wave_tot[wib] = incl2;
+                __syncthreads();
+                before = 0;
+                total = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < kRevLocalThreads / 64; w++) {
+                    const uint32_t wt = s_wave_tot[w];
+                    before += w < wib ? wt : 0u;
+                    total += wt;
+                }
+                before += incl2 - incl;  // (the code below takes this thread's exclusive prefix as before + incl - deg)
             }
             if (total) {  // (block-uniform)
                 t.prefix[tid] = before + incl - deg;
@@ -2352,8 +2423,31 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         // 1: redo on the level loop, 2: a row beyond the per-task enumeration limit.  A plain store (the flag may live in pinned host
         // memory): blocks that race write non-zero either way, and a 2 lost to a 1 is found again by the level loop.
         // (`visited` is left dirty: the host zeroes it before the next single-launch lookup on this context)
-        if (tid == 0) *status = s_stop;
-        signal_done(done_ctr, done_flag, done_val);
+        if (tid == 0) {
+            *status = s_stop;
+            if (dfr.tasks) {  // (the launches behind this one find nothing to do for this lookup; the host redoes the batch)
+                dfr.count[req] = 0u;
+                dfr.levels[req] = 0u;
+            }
+        }
+        if (!dfr.tasks) signal_done(done_ctr, done_flag, done_val);  // (deferral: k_rev_rows raises the completion word, behind everything)
+        return;
+    }
+    if (dfr.tasks) {
+        // ---- rows in HBM, handled by the two launches behind this one (k_rev_terminal, k_rev_rows): what is left here is to leave `visited` as it was
+        // handed over OUTSIDE the result row -- the logged first visits -- and to publish how much was deferred
+        __syncthreads();
+        const uint32_t nlog = min(s_end, cap);
+        for (uint32_t i = tid; i < nlog; i += kRevLocalThreads) {
+            const uint2 en = log[i];
+            if (en.y == target_slot) continue;  // (the row is cleared by k_rev_rows, behind the copy)
+            if (s_nomark[en.y >> 5] >> (en.y & 31u) & 1u) continue;
+            visited[(pl.slot[en.y].x + en.x) >> 5] = 0u;
+        }
+        if (tid == 0) {
+            dfr.count[req] = min(s_dfr, dfr.cap);
+            dfr.levels[req] = min(level, kMaxLevels);
+        }
         return;
     }
     // ---- result rows: the target slot's words (every one of them was last written by an L2 atomic or is still the zero it was handed over
@@ -2393,6 +2487,75 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
         for (uint32_t i = tid; i < rw; i += kRevLocalThreads) visited[row_w0 + i] = 0u;
     }
     signal_done(done_ctr, done_flag, done_val);
+}
+
+// The deferred rows of k_rev_local (see RevDefer): blockIdx.y = lookup, the launch's waves take its tasks round-robin and a wave's lanes read consecutive ids
+// of a reverse row.  An id's mark is its byte of the lookup's byte map (RevDefer::bytemap): a plain store, whichever block and XCD makes it.
+__global__ __launch_bounds__(256) void k_rev_terminal(DevReverse r, uint32_t target_slot, RevDefer dfr) {
+    // (a lookup whose block gave up has published zero tasks; the status word itself lives in the caller's pinned memory and is not worth a trip across PCIe
+    //  from every thread of a chip-wide launch -- a first version read it and spent 100 us of a 220 us empty lookup doing so)
+    const uint32_t req = blockIdx.y, lane = lane_id();
+    const uint32_t nt = min(dfr.count[req], dfr.cap), nobj = r.slot_nobjects[target_slot];
+    uint8_t *__restrict__ bm = dfr.bytemap + (size_t)req * dfr.bm_stride;
+    const uint2 *__restrict__ tasks = dfr.tasks + (size_t)req * dfr.cap;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    for (uint32_t t = wave; t < nt; t += nwaves) {
+        const uint2 tk = tasks[t];
+        for (uint32_t i = lane; i < tk.y; i += 64u) {
+            const uint32_t id = gld(r.redges, tk.x + i);
+            if (id < nobj) bm[id] = 1;
+        }
+    }
+}
+
+// The result rows of a batch whose rows live in HBM (see RevDefer): blockIdx.y = lookup, the x blocks take slices of its row -- copy out (device or pinned
+// host memory), count, clear -- so that a 1 MB row crosses PCIe from all CUs at once instead of from one.  d_count: [lookups] device accumulators (zero
+// between launches: re-armed by the last block); the last block of the LAUNCH writes every lookup's count | levels << 56 to out_counts and raises done_flag.
+__global__ __launch_bounds__(256) void k_rev_rows(DevReverse r, uint32_t target_slot, uint32_t n, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words,
+                                                  unsigned long long *out_counts, unsigned long long *d_count, RevDefer dfr, uint32_t *done_ctr,
+                                                  uint32_t *done_flag, uint32_t done_val) {
+    __shared__ uint32_t s_cnt[4];
+    __shared__ bool s_last;
+    const uint32_t req = blockIdx.y, lane = lane_id(), wib = threadIdx.x >> 6;
+    // (a batch in which some block gave up is redone by the host on the level loop: copying its partial rows is harmless, and the host zeroes the byte map again)
+    uint4 *__restrict__ bm = reinterpret_cast<uint4 *>(dfr.bytemap + (size_t)req * dfr.bm_stride);  // (bm_stride is a multiple of 128 bytes: 32 ids = two aligned uint4)
+    uint32_t *__restrict__ orow = out_bitmaps + (size_t)req * out_stride;
+    uint32_t c32 = 0;
+    auto nibble = [](uint32_t x) -> uint32_t { return (x * 0x01020408u) >> 24 & 0xFu; };  // four 0 / 1 bytes -> four bits, byte 0 lowest (no two partial products meet)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < out_stride; i += gridDim.x * 256u) {  // one word of the caller's row = 32 bytes of the map
+        uint32_t v = 0;
+        if (i < copy_words) {
+            const uint4 a = bm[2u * i], b = bm[2u * i + 1u];
+            v = nibble(a.x) | nibble(a.y) << 4 | nibble(a.z) << 8 | nibble(a.w) << 12 | nibble(b.x) << 16 | nibble(b.y) << 20 | nibble(b.z) << 24 | nibble(b.w) << 28;
+            if (v) {  // (zero again for the next lookup: only where something was set)
+                bm[2u * i] = make_uint4(0u, 0u, 0u, 0u);
+                bm[2u * i + 1u] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        orow[i] = v;
+        c32 += (uint32_t)__popc(v);
+    }
+    c32 = wave_last(wave_incl_scan(c32, lane));
+    if (lane == 0) s_cnt[wib] = c32;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (tot) (void)__hip_atomic_fetch_add(d_count + req, (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();  // this block's slices are in the caller's memory before it arrives
+        s_last = __hip_atomic_fetch_add(done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        const unsigned long long c = __hip_atomic_exchange(d_count + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (out_counts) out_counts[i] = c | ((unsigned long long)dfr.levels[i] << 56);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done_flag) __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------ import
@@ -2692,12 +2855,22 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
 }
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
                       uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status, uint32_t lds_row_words,
-                      uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val) {
+                      uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val, const RevBigRows *big) {
     if (!n) return;
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rev_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRevLdsRowBytes) == hipSuccess;
     if (lds_row_words * 4u > (big_lds ? kRevLdsRowBytes : 32768u)) lds_row_words = 0;  // rows stay in HBM
+    RevDefer dfr;
+    if (!lds_row_words && big && big->tasks)
+        dfr = RevDefer{reinterpret_cast<uint2 *>(big->tasks), big->task_count, big->levels, big->task_cap, big->defer_min ? big->defer_min : 4096u, big->bytemap, big->bytemap_stride};
     hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), (size_t)lds_row_words * 4, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps,
-                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words, done_ctr, done_flag, done_val);
+                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words, done_ctr, done_flag, done_val, dfr);
+    if (!dfr.tasks) return;
+    // the two chip-wide launches behind it: the deferred rows' ids, then the rows themselves (copy out, count, clear)
+    const uint32_t per = std::max(1u, std::min(256u, 2048u / n));  // blocks per lookup: the chip for a single lookup, ~8 blocks per CU in all for a batch
+    hipLaunchKernelGGL(k_rev_terminal, dim3(per, n), dim3(256), 0, s, r, target_slot, dfr);
+    const uint32_t slices = std::max(1u, std::min(per, (out_stride + 1023u) / 1024u));
+    hipLaunchKernelGGL(k_rev_rows, dim3(slices, n), dim3(256), 0, s, r, target_slot, n, out_bitmaps, out_stride, copy_words, (unsigned long long *)out_counts,
+                       (unsigned long long *)big->counts, dfr, done_ctr, done_flag, done_val);
 }
 static uint32_t import_blocks(uint32_t n) {  // ~one 1024-entry chunk of input per wave, at most 256 blocks
     const uint32_t b = (n + 4095) / 4096;

@@ -138,11 +138,25 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
 // words go to out_bitmaps + b * out_stride (device or pinned host memory; the rest of the row is zeroed), the id counts to out_counts.
 // *status != 0 afterwards (the caller zeroes it; it may live in pinned host memory): redo on the level loop (1) / a row beyond the enumeration limit (2);
 // out_counts[b] = ids in the row | reverse levels walked << 56
+// Result rows beyond the block's LDS (a type of more than 1 M objects) of a result slot that nothing expands further (the usual case: the permission a list is
+// filtered by): with `big` given the ids are marked as BYTES of a per-lookup byte map, the walk defers the heavy rows of the result slot to a chip-wide launch
+// and a third launch folds the bytes into the callers' rows from all CUs (kernels.hip RevDefer) -- three launches on `s`, the completion word raised by the last.
+struct RevBigRows {
+    uint8_t *bytemap = nullptr;     // [n][bytemap_stride], all zero (the third launch zeroes what it found set); bytemap_stride: a multiple of 128 >= the slot's id space
+    uint32_t bytemap_stride = 0;
+    void *tasks = nullptr;          // [n][task_cap] x 8 bytes
+    uint32_t *task_count = nullptr; // [n]
+    uint32_t *levels = nullptr;     // [n]
+    uint64_t *counts = nullptr;     // [n] device accumulators, zero between launches
+    uint32_t task_cap = 0;
+    uint32_t defer_min = 0;         // children of one round from which terminal rows are deferred (0 = the default, 4096)
+};
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
                       uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status,
                       uint32_t lds_row_words /* words covering the result slot's id space: kept in LDS when <= kRevLdsRowBytes, else (or 0) in r.visited */,
                       uint32_t *done_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_val = 0 /* as launch_check_local: the last block stores done_val into the pinned
-                      word done_flag behind a system-scope release of every block's rows, counts and status */);
+                      word done_flag behind a system-scope release of every block's rows, counts and status */,
+                      const RevBigRows *big = nullptr);
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 

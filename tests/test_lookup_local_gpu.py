@@ -65,6 +65,31 @@ def test_nested_groups_equal_level_loop_and_oracle(aclgpu, monkeypatch):
             b3, c3 = e3.lookup_ids_batch(rt, perm, stype, srel, subs)
             assert np.array_equal(bms, b3) and np.array_equal(counts, c3), (rt, perm, stype)
         assert e3.stats()["rev_local_passes"] == 6
+    # ... with every terminal row of the result slot DEFERRED to the chip-wide launch (round 6: what the heavy rounds of a lookup over a big type do;
+    # ACL_REV_DEFER_MIN=1 makes every round of this small graph one), single lookups (the completion word raised by the third launch) and batches
+    monkeypatch.setenv("ACL_REV_DEFER_MIN", "1")
+    with aclgpu.Engine(w.schema) as e4:
+        w.load(e4)
+        e4.stats_reset()
+        for (rt, perm, stype), (bms, counts) in got.items():
+            subs, srel = (users, "") if stype == "user" else (groups, "member")
+            b4, c4 = e4.lookup_ids_batch(rt, perm, stype, srel, subs)
+            assert np.array_equal(bms, b4) and np.array_equal(counts, c4), (rt, perm, stype)
+            for i in (0, subs.size // 2, subs.size - 1):
+                b1, c1 = e4.lookup_ids_batch(rt, perm, stype, srel, [int(subs[i])])
+                assert np.array_equal(b1[0], bms[i]) and c1[0] == counts[i], (rt, perm, stype, i)
+            b4b, c4b = e4.lookup_ids_batch(rt, perm, stype, srel, subs)  # (the rows were handed back all zero: a second walk finds nothing stale)
+            assert np.array_equal(bms, b4b) and np.array_equal(counts, c4b), (rt, perm, stype)
+        assert e4.stats()["rev_local_passes"] >= 6 * 5 and e4.stats()["expand_launches"] == 0
+    # ... and with the round-5 form (ONE block walks, copies and clears the row in HBM): the A/B knob's other side stays correct
+    monkeypatch.delenv("ACL_REV_DEFER_MIN")
+    monkeypatch.setenv("ACL_REV_BIG_ROWS", "0")
+    with aclgpu.Engine(w.schema) as e5:
+        w.load(e5)
+        for (rt, perm, stype), (bms, counts) in got.items():
+            subs, srel = (users, "") if stype == "user" else (groups, "member")
+            b5, c5 = e5.lookup_ids_batch(rt, perm, stype, srel, subs)
+            assert np.array_equal(bms, b5) and np.array_equal(counts, c5), (rt, perm, stype)
 
 
 def test_pinned_and_pageable_result_rows_agree(aclgpu):
@@ -113,7 +138,11 @@ def test_depth_limit_and_cycles_reverse(aclgpu):
 def test_block_that_outgrows_its_region_falls_back(aclgpu, monkeypatch):
     from aclgpu import workloads
     w = workloads.c3(scale=0.2, batch=256, power_users=8)
-    big = 7  # an ordinary user made a direct viewer of 700 pods: 700 first-level states
+    # an ordinary user made a direct viewer of every namespace: 200 first-level states (namespace#viewer) and 200 behind them (namespace#view) in a log of 256.
+    # (Round 6: 700 direct POD grants no longer do it -- a relation that only feeds the result permission is marked through, its states never enter the log.)
+    big, nns = 7, w.nobjects["namespace"]
+    assert nns >= 150
+    w.edges.append(("namespace", "viewer", "user", "", np.arange(nns, dtype=np.uint32), np.full(nns, big, dtype=np.uint32)))
     w.edges.append(("pod", "viewer", "user", "", np.arange(100, 800, dtype=np.uint32), np.full(700, big, dtype=np.uint32)))
     o = orc.Oracle(w.schema)
     w.load(o)
@@ -135,3 +164,34 @@ def test_block_that_outgrows_its_region_falls_back(aclgpu, monkeypatch):
         e.stats_reset()
         b4, c4 = e.lookup_ids_batch(rt, perm, st, "", subs[:4])
         assert e.stats()["rev_local_passes"] == 1 and np.array_equal(b4, bms[:4]) and np.array_equal(c4, counts[:4])
+
+
+@pytest.mark.parametrize("rows", ["lds", "hbm"])
+def test_relation_that_only_feeds_the_result_permission_is_marked_through_exactly(aclgpu, monkeypatch, rows):
+    """Round 6: a row whose children land in a relation whose only parent is the result permission (`doc#viewer` under `view = viewer + owner`) marks the
+    permission's objects directly, one dispatch level further on -- so at the depth limit the shortcut must stop exactly where the two-step walk
+    stopped: a doc whose viewer group sits K nested groups above the user is visible iff K + 2 <= 50 (reference pkg/spicedb/spicedb.go:34), in both
+    row forms (result rows in the block's LDS; in HBM as bytes, with every row deferred to the chip-wide launch)."""
+    schema = """
+    definition user {}
+    definition group { relation member: user | group#member }
+    definition doc {
+      relation viewer: user | group#member
+      relation owner: user
+      permission view = viewer + owner
+    }
+    """
+    rels = [("group", "g1", "member", "user", "deep", "")] + [("group", f"g{i + 1}", "member", "group", f"g{i}", "member") for i in range(1, 55)]
+    rels += [("doc", f"d{k}", "viewer", "group", f"g{k}", "member") for k in range(40, 56)] + [("doc", "direct", "viewer", "user", "deep", ""), ("doc", "own", "owner", "user", "deep", "")]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    want = o.lookup("doc", "view", "user", "deep")
+    assert want == {f"d{k}" for k in range(40, 49)} | {"direct", "own"}  # (K + 2 <= 50)
+    if rows == "hbm":
+        monkeypatch.setenv("ACL_REV_LDS_ROWS", "0")
+        monkeypatch.setenv("ACL_REV_DEFER_MIN", "1")
+    with aclgpu.Engine(schema) as e:
+        e.write([(aclgpu.OP_TOUCH, r) for r in rels])
+        assert e.lookup("doc", "view", "user", "deep") == want
+        assert e.lookup("doc", "viewer", "user", "deep") == o.lookup("doc", "viewer", "user", "deep") == {f"d{k}" for k in range(40, 50)} | {"direct"}  # the relation ITSELF asked for: K + 1 <= 50
+        assert e.stats()["rev_local_passes"] == 2
