@@ -20,6 +20,10 @@ w = workloads.c5(scale=scale)
 E = {(e[0], e[1], e[2]): (e[4], e[5]) for e in w.edges}
 subs = {"nobody": int(w.nobjects["user"]) + 7, "ns-viewer": int(np.bincount(E[("namespace", "viewer", "user")][1]).argmax()),
         "deep-0": int(w.lookup_subjects[0]), "deep-1": int(w.lookup_subjects[1]), "deep-2": int(w.lookup_subjects[2])}
+# ... and a power user who views 6 000 namespaces directly: ~1 M pods in one lookup ("a lookup returning >= 1 M ids")
+n_pw = min(6000, w.nobjects["namespace"])
+subs["power-1M"] = int(w.nobjects["user"]) + 11
+w.edges.append(("namespace", "viewer", "user", "", np.arange(n_pw, dtype=np.uint32), np.full(n_pw, subs["power-1M"], dtype=np.uint32)))
 e = aclgpu.Engine(w.schema)
 w.load(e)
 rt, perm, st = w.check
