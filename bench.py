@@ -921,9 +921,9 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         for m in (1024, 16384, 65536):
             m = min(m, n)
             qs = [(rt, names[rt][int(r_)], perm_name, st, names[st][int(s_)], "") for r_, s_ in zip(w.res[:m], w.subj[:m])]
-            pv, pc = eng.make_check_views(qs), eng.make_check_strings_named(qs)
+            pv, pc, pp = eng.make_check_views(qs), eng.make_check_strings_named(qs), eng.make_check_packed(qs)
             row = {}
-            for form, call, prep in (("views", eng.check_bulk_views, pv), ("c_strings", eng.check_bulk_prepared, pc)):
+            for form, call, prep in (("views", eng.check_bulk_views, pv), ("c_strings", eng.check_bulk_prepared, pc), ("packed", eng.check_bulk_packed, pp)):
                 got = call(prep)
                 ok = bool(np.array_equal(got[0], gpu_perm[:m]) and np.array_equal(got[1], gpu_err[:m]))
                 ok_all = ok_all and ok
@@ -935,8 +935,54 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
                 row[form] = {"decisions_per_s": m / float(np.mean(ts)), "ms_per_batch": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "best_ms": 1e3 * min(ts),
                              "calls": len(ts), "answers_equal_id_path": ok}  # (the rate is the MEAN over the calls, stragglers included)
             sp["sizes"][str(m)] = row
+        # PostFilter's own shape (postfilter.go:67-119: K list items, ONE subject for every pair): acl_check_bulk_keep_v / _packed answer it by one reverse walk
+        # from the subject + K bit tests (engine.cpp keep_by_reverse_walk); the keep mask is compared with the id path's answers for the same pairs
+        kr = {"note": "K list items x 1 template for ONE user: acl_check_bulk_keep_v / acl_check_bulk_keep_packed (one reverse walk + K name tests) against the forward "
+                      "string path (acl_check_bulk_v + the AND); keep masks compared with the id path's answers", "sizes": {}}
+        # ... and for a user as the proxy's users are -- a handful of grants, not the benchmark graph's deep-group members who see a quarter of all pods:
+        # `user-sparse` is made a direct viewer of 24 pods of the list (a write through the ABI: patched into the snapshot like any other)
+        import aclgpu as aclgpu_mod
+        grants = sorted({int(x) for x in w.res[:min(65536, n):2731]})[:24]
+        eng.write([(aclgpu_mod.OP_TOUCH, (rt, names[rt][g_], "viewer", st, "user-sparse", "")) for g_ in grants])
+        for m in (1024, 16384, 65536):
+            m = min(m, n)
+            rowk = {}
+            for who, u_ in (("batch_user", int(w.subj[0])), ("other_user", int(w.subj[m // 2])), ("sparse_user", None)):
+                uname_ = "user-sparse" if u_ is None else names[st][u_]
+                qk = [(rt, names[rt][int(r_)], perm_name, st, uname_, "") for r_ in w.res[:m]]
+                off = np.arange(m + 1, dtype=np.uint32)
+                if u_ is None:
+                    want = np.isin(w.res[:m], np.asarray(grants, dtype=w.res.dtype))
+                else:
+                    tp, te = eng.check_bulk_ids(eng.make_items(rt, perm_name, w.res[:m], st, "", np.full(m, u_, dtype=np.uint32)))
+                    want = (tp == 2) & (te == 0)
+                kv_prep, kp_prep = eng.make_check_views(qk), eng.make_check_packed(qk)
+                before = eng.stats()["keep_route_calls"]
+                entry = {"kept": int(want.sum())}
+                for form, call, prep in (("keep_v", eng.check_bulk_keep_views, kv_prep), ("keep_packed", eng.check_bulk_keep_packed, kp_prep)):
+                    got = call(prep, off).astype(bool)
+                    okk = bool(np.array_equal(got, want))
+                    ok_all = ok_all and okk
+                    ts = []
+                    for _ in range(40):
+                        t1 = time.perf_counter()
+                        call(prep, off)
+                        ts.append(time.perf_counter() - t1)
+                    entry[form] = {"items_per_s": m / float(np.mean(ts)), "ms_per_call": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "mask_equals_id_path": okk}
+                entry["calls_answered_by_the_reverse_walk"] = int(eng.stats()["keep_route_calls"] - before)
+                ts = []
+                for _ in range(20):  # the forward string path on the same pairs, for the ratio
+                    t1 = time.perf_counter()
+                    eng.check_bulk_views(kv_prep)
+                    ts.append(time.perf_counter() - t1)
+                entry["forward_views"] = {"items_per_s": m / float(np.mean(ts)), "ms_per_call": 1e3 * float(np.mean(ts))}
+                rowk[who] = entry
+            kr["sizes"][str(m)] = rowk
+        sp["keep_route"] = kr
         big = sp["sizes"][str(min(65536, n))]
-        sp.update({"decisions_per_s": big["views"]["decisions_per_s"], "ms_per_batch": big["views"]["ms_per_batch"], "items": min(65536, n), "answers_equal_id_path": ok_all})
+        sp.update({"decisions_per_s": big["views"]["decisions_per_s"], "ms_per_batch": big["views"]["ms_per_batch"], "items": min(65536, n), "answers_equal_id_path": ok_all,
+                   "keep_route_items_per_s": {who_: e_["keep_v"]["items_per_s"] for who_, e_ in kr["sizes"][str(min(65536, n))].items()},
+                   "packed_decisions_per_s": {k_: v_["packed"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()}})
         rec["string_path"] = sp
         if not ok_all:
             rec["string_path_mismatch"] = True

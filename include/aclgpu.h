@@ -216,6 +216,23 @@ int acl_check_bulk_ids_opts(acl_engine_t *h, const acl_item_t *items, size_t n, 
 /* acl_check_bulk_v under the caller's context (reference pkg/authz/check.go:48, postfilter.go:134: CheckBulkPermissions(ctx, ...)): a raised
  * cancel flag or a passed deadline ends the call with CANCELLED / DEADLINE_EXCEEDED while it waits for an evaluation context. */
 int acl_check_bulk_v_opts(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
+/* The same request PACKED (round 6): the call's DISTINCT strings once, back to back, and six dictionary indices per item.  A shim that walks a kube list
+ * copies every string once anyway; written into one buffer an item is 24 bytes instead of six {pointer, length} views, the fields every pair of a
+ * PostFilter call shares (type, permission, the user: pkg/authz/postfilter.go:88-119) are ONE dictionary entry -- found equal by index --, and a name that
+ * many items carry is resolved once per call.  String s is bytes[offsets[s], offsets[s + 1]); item i is items[6 i .. 6 i + 5] = resource type, resource id,
+ * permission, subject type, subject id, subject relation; ACL_PACKED_NONE = the member is absent (an empty request's nil Resource: that pair is answered
+ * InvalidArgument as for {NULL, 0} views, pkg/proxy/options_test.go:101-102).  Any other index >= n_strings fails the call with INVALID_ARGUMENT. */
+#define ACL_PACKED_NONE 0xFFFFFFFFu
+typedef struct {
+    const char *bytes;
+    const uint32_t *offsets; /* [n_strings + 1], ascending */
+    uint32_t n_strings;
+    uint32_t reserved;
+    const uint32_t *items;   /* [n_items][6] */
+    size_t n_items;
+} acl_packed_request_t;
+/* opts: the caller's context (cancel flag / deadline), as acl_check_bulk_v_opts takes it; NULL = neither. */
+int acl_check_bulk_packed(acl_engine_t *h, const acl_packed_request_t *req, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts);
 
 /* Pipelined form of acl_check_bulk_ids for hosts that cannot park a thread per call: submit returns at once, the batch is answered as a
  * whole blocking call on one of the engine's pool workers (one worker per evaluation context); acl_ticket_wait blocks until perm_out /
@@ -264,6 +281,14 @@ int acl_lookup_resources_batch(acl_engine_t *h, int rtype, int permission, int s
  * is kept (postfilter.go:145-150).  K bytes come back; the *_device form does the AND on the device (its answers never leave the HBM). */
 int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
+/* ... with {pointer, length} fields / a packed request.  Round 6: the reference's PostFilter names ONE subject for all K x F pairs (postfilter.go:67-119:
+ * every template is resolved for the requesting user).  When every pair of the call shares (resource type, permission, subject) -- a plain subject, a
+ * permission without `&` / `-` -- the call is answered by ONE reverse walk from that subject (the LookupResources kernel) and K bit tests: the pairs' resource
+ * names are hashed and tested against the few ALLOWED names first, so a name the user may not see never touches the type's name table (the string path's
+ * cost is that table: one DRAM miss per name).  Any other call -- subjects or permissions that differ, a userset subject, an item the API would refuse --
+ * takes the forward path; the keep mask and the call's error are the same either way (tests/test_callers_gpu.py compares the two routes and the oracle). */
+int acl_check_bulk_keep_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
+int acl_check_bulk_keep_packed(acl_engine_t *h, const acl_packed_request_t *req, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);
 /* PostFilter at LIST level: filterListResponse (postfilter.go:17-55).  body = the kube list response (JSON).  Every element
  * of its "items" array gets one check per template, rendered from the item's metadata: placeholders {{name}}, {{namespace}},
@@ -482,6 +507,7 @@ typedef struct {
     uint64_t rev_local_passes;     /* LookupResources groups answered by that kernel (one launch for all reverse levels) */
     uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
     uint64_t ids_recycled;         /* object ids given a new name after their object had lost its last relationship (since the schema was loaded) */
+    uint64_t keep_route_calls;     /* acl_check_bulk_keep_v / _packed calls answered by ONE reverse walk and bit tests (since open) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

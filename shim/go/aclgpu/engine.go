@@ -145,68 +145,70 @@ func (c *cstrings) free() {
 	}
 }
 
-// viewItems builds an acl_check_item_v_t array in C memory over ONE C blob holding every distinct string of the request.
-type viewItems struct {
-	items *C.acl_check_item_v_t
-	n     int
-	blob  []byte            // staged in Go, copied to C once (finish)
-	at    map[string]int    // string -> offset in blob
-	refs  [][6][2]int       // per item and field: {offset, length}; offset -1 = absent
-	cblob unsafe.Pointer
+// packedItems builds an acl_packed_request_t (aclgpu.h): the request's DISTINCT strings once, back to back, and six dictionary indices per item.  The
+// strings of a bulk request repeat -- one rule template per item (pkg/authz/check.go:23-39), one user for every pair of a PostFilter call
+// (postfilter.go:88-119) -- so an item costs 24 bytes of indices instead of six {pointer, length} views, the engine finds the repeated fields equal BY
+// INDEX, and resolves a name that many items carry once per call.  Two C allocations per call (the bytes + offsets, the indices).
+type packedItems struct {
+	n       int
+	dict    map[string]uint32
+	bytes   []byte
+	offsets []uint32 // [strings + 1]
+	idx     []uint32 // [n][6]
+	cbytes  unsafe.Pointer
+	coffs   unsafe.Pointer
+	cidx    unsafe.Pointer
+	req     C.acl_packed_request_t
 }
 
-func newViewItems(n int) *viewItems {
-	return &viewItems{n: n, at: make(map[string]int), refs: make([][6][2]int, n)}
+const packedNone = ^uint32(0) // ACL_PACKED_NONE
+
+func newPackedItems(n int) *packedItems {
+	return &packedItems{n: n, dict: make(map[string]uint32), offsets: []uint32{0}, idx: make([]uint32, 6*n)}
 }
-func (v *viewItems) ref(s string, present bool) [2]int {
-	if !present {
-		return [2]int{-1, 0}
-	}
-	off, ok := v.at[s]
+func (v *packedItems) ref(s string) uint32 {
+	k, ok := v.dict[s]
 	if !ok {
-		off = len(v.blob)
-		v.at[s] = off
-		v.blob = append(v.blob, s...)
+		k = uint32(len(v.offsets) - 1)
+		v.dict[s] = k
+		v.bytes = append(v.bytes, s...)
+		v.offsets = append(v.offsets, uint32(len(v.bytes)))
 	}
-	return [2]int{off, len(s)}
+	return k
 }
-func (v *viewItems) set(i int, resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) {
-	r := &v.refs[i] // nil members (an empty request) stay absent: the engine answers InvalidArgument (options_test.go:101-102)
+func (v *packedItems) set(i int, resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) {
+	r := v.idx[6*i : 6*i+6] // nil members (an empty request) stay absent: that pair is answered InvalidArgument (options_test.go:101-102)
 	for f := range r {
-		r[f] = [2]int{-1, 0}
+		r[f] = packedNone
 	}
 	if resource != nil {
-		r[0], r[1] = v.ref(resource.ObjectType, true), v.ref(resource.ObjectId, true)
+		r[0], r[1] = v.ref(resource.ObjectType), v.ref(resource.ObjectId)
 	}
-	r[2] = v.ref(permission, true)
+	r[2] = v.ref(permission)
 	if subject != nil && subject.Object != nil {
-		r[3], r[4] = v.ref(subject.Object.ObjectType, true), v.ref(subject.Object.ObjectId, true)
-		r[5] = v.ref(subject.OptionalRelation, subject.OptionalRelation != "")
+		r[3], r[4] = v.ref(subject.Object.ObjectType), v.ref(subject.Object.ObjectId)
+		if subject.OptionalRelation != "" {
+			r[5] = v.ref(subject.OptionalRelation)
+		}
 	}
 	if i == v.n-1 {
 		v.finish()
 	}
 }
-func (v *viewItems) finish() {
-	v.cblob = C.malloc(C.size_t(len(v.blob) + 1))
-	if len(v.blob) > 0 {
-		copy(unsafe.Slice((*byte)(v.cblob), len(v.blob)), v.blob)
-	}
-	v.items = (*C.acl_check_item_v_t)(C.calloc(C.size_t(v.n), C.size_t(unsafe.Sizeof(C.acl_check_item_v_t{}))))
-	out := unsafe.Slice(v.items, v.n)
-	for i := range out {
-		fields := (*[6]C.acl_str_t)(unsafe.Pointer(&out[i])) // six consecutive {p, n} views (aclgpu.h)
-		for f, rf := range v.refs[i] {
-			if rf[0] >= 0 {
-				fields[f].p = (*C.char)(unsafe.Add(v.cblob, rf[0]))
-				fields[f].n = C.size_t(rf[1])
-			}
-		}
-	}
+func (v *packedItems) finish() {
+	v.cbytes = C.malloc(C.size_t(len(v.bytes) + 1))
+	copy(unsafe.Slice((*byte)(v.cbytes), len(v.bytes)), v.bytes)
+	v.coffs = C.malloc(C.size_t(4 * len(v.offsets)))
+	copy(unsafe.Slice((*uint32)(v.coffs), len(v.offsets)), v.offsets)
+	v.cidx = C.malloc(C.size_t(4*len(v.idx) + 4))
+	copy(unsafe.Slice((*uint32)(v.cidx), len(v.idx)), v.idx)
+	v.req = C.acl_packed_request_t{bytes: (*C.char)(v.cbytes), offsets: (*C.uint32_t)(v.coffs), n_strings: C.uint32_t(len(v.offsets) - 1),
+		items: (*C.uint32_t)(v.cidx), n_items: C.size_t(v.n)}
 }
-func (v *viewItems) free() {
-	C.free(unsafe.Pointer(v.items))
-	C.free(v.cblob)
+func (v *packedItems) free() {
+	C.free(v.cbytes)
+	C.free(v.coffs)
+	C.free(v.cidx)
 }
 
 func (c *cstrings) item(resource *v1.ObjectReference, permission string, subject *v1.SubjectReference) C.acl_check_item_t {

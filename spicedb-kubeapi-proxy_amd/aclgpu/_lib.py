@@ -28,13 +28,17 @@ SYMBOLS = [
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls", "acl_watch_wait", "acl_watch_recheck", "acl_load_bootstrap_yaml",
-    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v",
+    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_check_bulk_packed", "acl_check_bulk_keep_v", "acl_check_bulk_keep_packed",
 ]
 
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("frontier_entries", C.c_uint64), ("max_sub_batch", C.c_uint32), ("flags", C.c_uint32),
                 ("contexts", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class PackedRequest(C.Structure):  # acl_packed_request_t
+    _fields_ = [("bytes", C.c_void_p), ("offsets", C.c_void_p), ("n_strings", C.c_uint32), ("reserved", C.c_uint32), ("items", C.c_void_p), ("n_items", C.c_size_t)]
 
 
 class CallOpts(C.Structure):
@@ -79,7 +83,7 @@ class Stats(C.Structure):
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
                 ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64),
                 ("local_ms", C.c_double), ("local_passes", C.c_uint64), ("snapshot_compactions", C.c_uint64),
-                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64)]
+                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64), ("keep_route_calls", C.c_uint64)]
 
 
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -176,6 +180,9 @@ def load():
     L.acl_set_timing.argtypes = [H, C.c_int]
     L.acl_check_bulk_keep.argtypes = [H, C.POINTER(CheckItem), C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.acl_check_bulk_keep_ids.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_check_bulk_keep_v.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.acl_check_bulk_packed.argtypes = [H, C.POINTER(PackedRequest), C.c_void_p, C.c_void_p, C.POINTER(CallOpts)]
+    L.acl_check_bulk_keep_packed.argtypes = [H, C.POINTER(PackedRequest), C.c_void_p, C.c_size_t, C.c_void_p]
     L.acl_check_bulk_keep_ids_device.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.acl_bitmap_test_names.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_void_p]
     L.acl_watch_poll.argtypes = [H, C.c_uint64, C.POINTER(C.c_int), C.c_int, WATCH_CB, C.c_void_p, C.POINTER(C.c_uint64)]

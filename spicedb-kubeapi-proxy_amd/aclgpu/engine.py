@@ -42,6 +42,8 @@ def _b(s):
 
 
 class Engine:
+    names_invalid_fields = True  # a request the API's validation refuses fails with a message naming the item, the field, the value and the pattern (tests/kat_runner.py)
+
     def __init__(self, schema: str | None = None, relationships: str | None = None, device: int = -1, frontier_entries: int = 0,
                  max_sub_batch: int = 0, store_only: bool = False, contexts: int = 0, devices=None, per_item_validation: bool = False,
                  lenient_lookup: bool = False, eager_contexts: bool = False):
@@ -378,6 +380,53 @@ class Engine:
         off = np.ascontiguousarray(item_off, dtype=np.uint32)
         keep = np.zeros(max(1, off.size - 1), dtype=np.uint8)
         self._check(self._L.acl_check_bulk_keep(self._h, arr, n, off.ctypes.data, off.size - 1, keep.ctypes.data))
+        return keep[:off.size - 1]
+
+    def check_bulk_keep_views(self, prepared, item_off):
+        """acl_check_bulk_keep_v: the pairs as {pointer, length} views (make_check_views); a call whose pairs share type, permission and subject is
+        answered by one reverse walk + bit tests (stats()["keep_route_calls"])."""
+        views, n, _blob = prepared
+        off = np.ascontiguousarray(item_off, dtype=np.uint32)
+        keep = np.zeros(max(1, off.size - 1), dtype=np.uint8)
+        self._check(self._L.acl_check_bulk_keep_v(self._h, views.ctypes.data, n, off.ctypes.data, off.size - 1, keep.ctypes.data))
+        return keep[:off.size - 1]
+
+    @staticmethod
+    def make_check_packed(items):
+        """An acl_packed_request_t of [(rt, rid, perm, st, sid, srel)]: every distinct string once in a dictionary, six u32 indices per item (an absent
+        subject relation: ACL_PACKED_NONE) -- what the cgo shim fills while it walks a kube list.  -> (request struct, the arrays it points into)"""
+        n = len(items)
+        where, blob, offsets = {}, bytearray(), [0]
+        idx = np.full((max(1, n), 6), 0xFFFFFFFF, dtype=np.uint32)
+        for i, it in enumerate(items):
+            for f, x in enumerate(it):
+                b = _b(x if x is not None else "") or b""
+                if f == 5 and not b:
+                    continue
+                k = where.get(b)
+                if k is None:
+                    k = where[b] = len(offsets) - 1
+                    blob += b
+                    offsets.append(len(blob))
+                idx[i, f] = k
+        buf = np.frombuffer(bytes(blob) or b"\0", dtype=np.uint8).copy()
+        offs = np.asarray(offsets, dtype=np.uint32)
+        rq = _lib.PackedRequest(buf.ctypes.data, offs.ctypes.data, len(offsets) - 1, 0, idx.ctypes.data, n)
+        return rq, (buf, offs, idx)
+
+    def check_bulk_packed(self, prepared):
+        rq, _keep_alive = prepared
+        n = rq.n_items
+        perm = np.zeros(max(1, n), dtype=np.uint8)
+        err = np.zeros(max(1, n), dtype=np.int32)
+        self._check(self._L.acl_check_bulk_packed(self._h, C.byref(rq), perm.ctypes.data, err.ctypes.data, None))
+        return perm[:n], err[:n]
+
+    def check_bulk_keep_packed(self, prepared, item_off):
+        rq, _keep_alive = prepared
+        off = np.ascontiguousarray(item_off, dtype=np.uint32)
+        keep = np.zeros(max(1, off.size - 1), dtype=np.uint8)
+        self._check(self._L.acl_check_bulk_keep_packed(self._h, C.byref(rq), off.ctypes.data, off.size - 1, keep.ctypes.data))
         return keep[:off.size - 1]
 
     def check_bulk_keep_ids(self, items: np.ndarray, item_off):

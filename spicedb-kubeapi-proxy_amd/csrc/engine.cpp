@@ -1074,7 +1074,70 @@ struct ViewItems {
     const char *ptr(size_t i, int f) const { return (&it[i].resource_type)[f].p; }
     size_t len(size_t i, int f) const { return (&it[i].resource_type)[f].p ? (&it[i].resource_type)[f].n : 0; }
 };
+// ... and the PACKED form (acl_check_bulk_packed, round 6): a dictionary of the call's DISTINCT strings and six u32 indices per item.  A shim that walks a kube
+// list copies every string once anyway (shim/go/aclgpu/engine.go); written into one buffer, an item is 24 bytes instead of six views (96), the constant
+// fields of a PostFilter call -- type, permission, the user -- are the SAME dictionary entry (found equal by index, no bytes compared), and a name that
+// occurs in many items of the call is resolved once (PackedCache below).
+struct PackedItems {
+    const acl_packed_request_t *rq;
+    static constexpr bool kHasLen = true;
+    uint32_t idx(size_t i, int f) const { return rq->items[6 * i + f]; }
+    const char *ptr(size_t i, int f) const {
+        const uint32_t k = idx(i, f);
+        return k == ACL_PACKED_NONE ? nullptr : rq->bytes + rq->offsets[k];
+    }
+    size_t len(size_t i, int f) const {
+        const uint32_t k = idx(i, f);
+        return k == ACL_PACKED_NONE ? 0 : rq->offsets[k + 1] - rq->offsets[k];
+    }
+};
 enum { F_RT = 0, F_RID = 1, F_PM = 2, F_ST = 3, F_SID = 4, F_SR = 5 };
+// Which field of item i fails the API's validation, and why -- for acl_last_error() ("check failed" told an operator nothing; the
+// reference denies everything a failed CheckBulkPermissions asked, pkg/authz/check.go:48-52, so the message is all there is to diagnose a blanket denial).
+template <class Items>
+static std::string describe_invalid(const Schema &sc, const Items &its, size_t i) {
+    static const char *const kField[6] = {"resource type", "resource id", "permission", "subject type", "subject id", "subject relation"};
+    auto view = [&](int f) {
+        const char *q = its.ptr(i, f);
+        return q ? std::string_view(q, its.len(i, f)) : std::string_view();
+    };
+    auto shown = [](std::string_view v) {
+        std::string o(v.substr(0, 48));
+        for (char &ch : o)
+            if ((unsigned char)ch < 0x20 || (unsigned char)ch > 0x7E) ch = '?';
+        return "`" + o + (v.size() > 48 ? "...` (" + std::to_string(v.size()) + " bytes)" : "`");
+    };
+    const std::string_view rt = view(F_RT), rid = view(F_RID), pm = view(F_PM), st = view(F_ST), sid = view(F_SID);
+    std::string_view sr = view(F_SR);
+    if (sr == "...") sr = std::string_view();
+    const int rti = sc.type_of(std::string(rt)), sti = sc.type_of(std::string(st));
+    auto bad_id = [&](int f, std::string_view v) -> std::string {
+        if (v.empty()) return std::string(kField[f]) + " is empty";
+        if (v == "*") return std::string(kField[f]) + " `*`: a wildcard is not an object of a Check";
+        if (v.size() > 1024) return std::string(kField[f]) + " " + shown(v) + " is longer than 1024 bytes";
+        size_t at = 0;
+        while (at < v.size() && valid_object_id(v.substr(at, 1))) at++;
+        if (at < v.size()) return std::string(kField[f]) + " " + shown(v) + " does not match ^[a-zA-Z0-9/_|\\-=+]{1,1024}$ (byte " + std::to_string(at) + " `" +
+                                  ((unsigned char)v[at] >= 0x20 && (unsigned char)v[at] <= 0x7E ? std::string(1, v[at]) : std::string("?")) + "`)";
+        return std::string();
+    };
+    if (rt.empty()) return "resource type is empty";
+    if (rti < 0 && !valid_type_name(rt)) return "resource type " + shown(rt) + " does not match ^([a-z][a-z0-9_]{1,61}[a-z0-9]/)*[a-z][a-z0-9_]{1,62}[a-z0-9]$";
+    if (std::string e = bad_id(F_RID, rid); !e.empty()) return e;
+    if (pm.empty()) return "permission is empty";
+    if ((rti < 0 || sc.defs[rti].find(std::string(pm)) < 0) && !valid_relation_name(pm)) return "permission " + shown(pm) + " does not match ^[a-z][a-z0-9_]{1,62}[a-z0-9]$";
+    if (st.empty()) return "subject type is empty";
+    if (sti < 0 && !valid_type_name(st)) return "subject type " + shown(st) + " does not match ^([a-z][a-z0-9_]{1,61}[a-z0-9]/)*[a-z][a-z0-9_]{1,62}[a-z0-9]$";
+    if (std::string e = bad_id(F_SID, sid); !e.empty()) return e;
+    if (!sr.empty() && (sti < 0 || sc.defs[sti].find(std::string(sr)) < 0) && !valid_relation_name(sr))
+        return "subject relation " + shown(sr) + " does not match ^[a-z][a-z0-9_]{1,62}[a-z0-9]$ (or empty, or `...`)";
+    return "a field is empty or ill-formed";
+}
+template <class Items>
+static int fail_invalid_item(acl_engine_t *h, const Items &its, size_t i) {
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(i) + ": " + describe_invalid(h->store.schema(), its, i));
+}
 static_assert(offsetof(acl_check_item_t, subject_relation) == 5 * sizeof(const char *), "acl_check_item_t: six consecutive pointers");
 static_assert(offsetof(acl_check_item_v_t, subject_relation) == 5 * sizeof(acl_str_t), "acl_check_item_v_t: six consecutive views");
 
@@ -1283,6 +1346,39 @@ template <class Items>
 static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t *out, std::vector<std::pair<uint32_t, int32_t>> *bad, bool ids_leave_the_call = false) {
     const Schema &sc = h->store.schema();
     std::mutex bad_mu;
+    // Packed requests: a name that many items of the call carry -- the namespace of every pod of a list, the user of every pair -- is looked up ONCE: entry d of
+    // this table remembers what dictionary string d resolved to as an object of one type ((type + 1) << 33 | known << 32 | id; 0 = not yet; racing threads store the
+    // same value).  Items that name an object for the first time pay the table's DRAM miss as before.
+    constexpr bool kPacked = std::is_same_v<Items, PackedItems>;
+    std::unique_ptr<std::atomic<uint64_t>[]> dict_cache;
+    if constexpr (kPacked) {
+        // (only where the dictionary says names REPEAT: a call of K distinct resources and one user has about one string per item, and a table that is
+        //  zeroed, filled and never hit cost the 65 536-item call 60 us)
+        if (n >= 64 && (size_t)its.rq->n_strings * 2 <= n) {
+            dict_cache.reset(new std::atomic<uint64_t>[its.rq->n_strings]);
+            for (uint32_t d = 0; d < its.rq->n_strings; d++) dict_cache[d].store(0, std::memory_order_relaxed);
+        }
+    }
+    auto cached = [&](size_t i, int f, int type, bool *known, uint32_t *id) -> bool {
+        if constexpr (kPacked) {
+            if (!dict_cache) return false;
+            const uint64_t v = dict_cache[its.idx(i, f)].load(std::memory_order_relaxed);
+            if ((v >> 33) != (uint64_t)type + 1u) return false;
+            *known = (v >> 32) & 1u;
+            *id = (uint32_t)v;
+            return true;
+        } else {
+            (void)i, (void)f, (void)type, (void)known, (void)id;
+            return false;
+        }
+    };
+    auto remember = [&](size_t i, int f, int type, bool known, uint32_t id) {
+        if constexpr (kPacked) {
+            if (dict_cache) dict_cache[its.idx(i, f)].store(((uint64_t)type + 1u) << 33 | (uint64_t)known << 32 | id, std::memory_order_relaxed);
+        } else {
+            (void)i, (void)f, (void)type, (void)known, (void)id;
+        }
+    };
     // Object ids: two lookups per item in tables of up to millions of names -- two dependent DRAM misses each (slot, then the name's
     // bytes).  Items go in groups of kGroup through three stages: hash + prefetch the slots; walk to the tag match + prefetch the names;
     // compare.  The misses of a group are in flight together.
@@ -1297,6 +1393,7 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             int rt, st, pm, sr;
             bool ok;
             bool same_res, same_sub;  // the same object as the item before it: its id is taken over, not looked up again
+            bool hit_res, hit_sub;    // packed requests: the dictionary entry was resolved earlier in this call (kr / res, ks / sub already hold the answer)
             bool kr, ks;              // (third stage) the table knows the name
             uint32_t res, sub;
         } pend[kGroup];
@@ -1331,11 +1428,16 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 static const bool kRepeat = !getenv("ACL_INTERN_REPEAT") || atoi(getenv("ACL_INTERN_REPEAT")) != 0;  // (A/B knob)
                 p.same_res = kRepeat && prev && prev->rt == p.rt && same_name(prev->rid, p.rid);
                 p.same_sub = kRepeat && prev && prev->st == p.st && same_name(prev->sid, p.sid);
-                if (!p.same_res) {
+                p.hit_res = !p.same_res && cached(i, F_RID, p.rt, &p.kr, &p.res);  // (packed requests: this dictionary entry was resolved earlier in the call)
+                p.hit_sub = !p.same_sub && cached(i, F_SID, p.st, &p.ks, &p.sub);
+                if (p.hit_res) p.same_res = false;
+                if (p.hit_sub) p.same_sub = false;
+                if (p.hit_res && p.hit_sub) continue;
+                if (!p.same_res && !p.hit_res) {
                     p.hr = ObjectTable::hash_of(p.rid);
                     h->store.objects(p.rt).prefetch(p.hr);
                 }
-                if (!p.same_sub) {
+                if (!p.same_sub && !p.hit_sub) {
                     p.hs = ObjectTable::hash_of(p.sid);
                     h->store.objects(p.st).prefetch(p.hs);
                 }
@@ -1343,8 +1445,8 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             for (size_t i = g0; i < g1; i++) {
                 const Pending &p = pend[i - g0];
                 if (!p.ok) continue;
-                if (!p.same_res) h->store.objects(p.rt).prefetch_name(p.hr);
-                if (!p.same_sub) h->store.objects(p.st).prefetch_name(p.hs);
+                if (!p.same_res && !p.hit_res) h->store.objects(p.rt).prefetch_name(p.hr);
+                if (!p.same_sub && !p.hit_sub) h->store.objects(p.st).prefetch_name(p.hs);
             }
             for (size_t i = g0; i < g1; i++) {
                 Pending &p = pend[i - g0];
@@ -1353,9 +1455,15 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
                 // resource and subject are the same (unknown) object
                 const Pending *prev = i > g0 ? &pend[i - g0 - 1] : &last;  // (same_res / same_sub were only set against an item that resolved)
                 if (p.same_res) p.kr = prev->kr, p.res = prev->res;
-                else p.kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &p.res);
+                else if (!p.hit_res) {
+                    p.kr = h->store.objects(p.rt).find_hashed(p.rid, p.hr, &p.res);
+                    remember(i, F_RID, p.rt, p.kr, p.res);
+                }
                 if (p.same_sub) p.ks = prev->ks, p.sub = prev->sub;
-                else p.ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &p.sub);
+                else if (!p.hit_sub) {
+                    p.ks = h->store.objects(p.st).find_hashed(p.sid, p.hs, &p.sub);
+                    remember(i, F_SID, p.st, p.ks, p.sub);
+                }
                 const bool kr = p.kr, ks = p.ks;
                 uint32_t res = p.res, sub = p.sub;
                 if (ids_leave_the_call) {  // (acl_resolve_bulk_v: the recycling quarantine of an unreferenced object starts over, store.hpp touch)
@@ -1423,8 +1531,7 @@ static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8
     // everything it asked on any error of the call, check.go:48-52, and fails the list response, postfilter.go:134-137).  Unknown types /
     // permissions stay per-item errors (check.go:55-60).
     for (const auto &be : bad)
-        if (be.second == ACL_ERR_INVALID_ARGUMENT && !h->per_item_validation)
-            return fail(ACL_ERR_INVALID_ARGUMENT, "invalid CheckBulkPermissionsRequest: item " + std::to_string(be.first) + " has an empty or ill-formed field");
+        if (be.second == ACL_ERR_INVALID_ARGUMENT && !h->per_item_validation) return fail_invalid_item(h, its, be.first);
     if (bad.size() == n) {  // nothing to ask the device
         std::memset(perm_out, ACL_PERM_UNSPECIFIED, n);
     } else {
@@ -1750,6 +1857,217 @@ int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel,
     rc = lookup_args_ok(h, rtype, perm, stype, srel);  // (the schema may have been reloaded in between)
     if (rc) return rc;
     return lookup_batch(h, ev.c, rtype, perm, stype, srel, sids, n, bitmaps, words, counts);
+}
+
+// ---- PostFilter by ONE reverse walk (round 6).  filterItemsWithBulkPermissions (reference pkg/authz/postfilter.go:58-182) resolves every
+// template of every list item for the REQUESTING USER: K x F pairs that share their subject and, per template, type and permission.  K forward walks from K
+// resources ask the graph the same question LookupResources answers once: which objects of the type may this subject see.  So when all pairs of a call share
+// (resource type, permission, subject type, subject id) -- a plain subject, a permission whose value no `&` / `-` can change -- the engine runs the reverse
+// walk once and tests the K resource names against its row.  And it tests them the cheap way round: the row's few ALLOWED objects give a small set of
+// name-hash tags that stays in cache; a pair's resource name is hashed (no memory touched but its own bytes) and looked up THERE -- only a tag hit goes on
+// to the type's name table for the id and the bit.  A name the user may not see never pays the table's DRAM miss, which is what a string call costs
+// (56 ns per item and thread against ~15: tools/intern_bench.py).  Every deviation -- fields that differ, a userset subject, an item the API's validation
+// would refuse, a non-monotone permission, a sharded or store-only engine -- returns kRouteNotTaken BEFORE anything is written, and the caller takes the
+// forward path: keep mask and error behaviour are the forward path's by construction (an unknown or unreachable resource is NO_PERMISSION there, a depth
+// error is a pair error there: both drop the item, postfilter.go:162-172, as the missing bit does here).
+constexpr int kRouteNotTaken = -1002;
+template <class Items>
+static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    static const size_t kMin = [] {
+        const char *e = getenv("ACL_KEEP_ROUTE_MIN");  // (A/B and test knob; 0 switches the route off)
+        return e ? (size_t)std::max(0, atoi(e)) : (size_t)512;
+    }();
+    if (!kMin || n < kMin || h->store_only || h->shard.world > 1) return kRouteNotTaken;
+    int rt, pm, st;
+    uint32_t sub = 0;
+    bool sub_known = false;
+    {   // the call's constants, from item 0
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        if (!h->store.has_schema()) return kRouteNotTaken;
+        NameMemo m;
+        int32_t err = 0;
+        if (!intern_names(h->store.schema(), its, 0, m, &err) || m.sri != kNoRelation) return kRouteNotTaken;
+        rt = m.rti, pm = m.pmi, st = m.sti;
+        const char *u = its.ptr(0, F_SID);
+        const std::string_view sid = u ? std::string_view(u, its.len(0, F_SID)) : std::string_view();
+        if (sid.empty() || sid == "*" || !valid_object_id(sid)) return kRouteNotTaken;
+        sub_known = h->store.objects(st).find(sid, &sub);
+        if (sub_known) h->store.touch(st, sub);  // (the id leaves the names lock: its recycling quarantine starts over, store.hpp)
+    }
+    // ---- the reverse walk (none for a subject no table knows: it has no relationships, and without a subject relation it is nobody's member)
+    std::vector<uint32_t> row;
+    std::vector<uint32_t> tags;  // open addressing over the allowed objects' name tags (0 = empty; a tag of 0 is stored as 1: only costs a rare extra probe)
+    uint32_t tmask = 0;
+    uint64_t count = 0;
+    if (sub_known) {
+        Eval ev;
+        int rc = ev.begin(h, true, CallOpts());
+        if (rc) return rc;
+        const Schema &sc = h->store.schema();
+        if (rt >= (int)sc.defs.size() || st >= (int)sc.defs.size() || pm >= (int)sc.defs[rt].members.size()) return kRouteNotTaken;  // (the schema was reloaded in between)
+        const uint32_t target = (uint32_t)sc.slot(rt, pm);
+        if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
+        const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
+        row.assign(std::max<size_t>(words, 1), 0u);
+        rc = lookup_batch(h, ev.c, rt, pm, st, -1, &sub, 1, row.data(), row.size(), &count);
+        if (rc) return rc;
+    }
+    std::atomic<int> outcome{0};  // 0 fine; 1: not a uniform call after all / an item the forward path must judge -> not taken
+    {
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        const ObjectTable &tab = h->store.objects(rt);
+        auto pool = [&]() -> InternPool * {
+            std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+            if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
+            return h->intern_pool;
+        };
+        const unsigned workers = (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1;
+        // Two ways to test a name against the row.  FEW allowed objects (at most half as many as there are pairs): their names' hash tags make a small set that
+        // stays in cache, and only a tag hit goes on to the name table.  MANY: every name goes to the table (one miss, prefetched a group ahead) -- still
+        // half of what the forward path's interning pays (it resolves the subject too) and no device pass over K items.
+        const bool few = count != 0 && count <= n / 2;
+        if (few) {
+            size_t cap = 64;
+            while (cap < 2 * count) cap <<= 1;
+            tags.assign(cap, 0u);
+            tmask = (uint32_t)(cap - 1);
+            std::atomic<uint32_t> *at = reinterpret_cast<std::atomic<uint32_t> *>(tags.data());
+            std::atomic<bool> anonymous{false};
+            const std::function<void(size_t, size_t)> fill = [&](size_t wa, size_t wb) {
+                for (size_t w = wa; w < wb; w++)
+                    for (uint32_t mbits = row[w]; mbits; mbits &= mbits - 1) {
+                        const std::string *nm = tab.name((uint32_t)(w * 32 + (size_t)__builtin_ctz(mbits)));
+                        if (!nm) {
+                            anonymous.store(true, std::memory_order_relaxed);
+                            return;
+                        }
+                        uint32_t tg = (uint32_t)(ObjectTable::hash_of(*nm) >> 32);
+                        tg += tg == 0u;
+                        for (uint32_t q = tg & tmask;; q = (q + 1) & tmask) {
+                            uint32_t seen = at[q].load(std::memory_order_relaxed);
+                            if (seen == tg || (seen == 0u && at[q].compare_exchange_strong(seen, tg, std::memory_order_relaxed)) || seen == tg) break;
+                        }
+                    }
+            };
+            if (count < 2048) fill(0, row.size());
+            else pool()->run(row.size(), std::max<size_t>(256, row.size() / 64), workers, fill);
+            if (anonymous.load()) return kRouteNotTaken;  // (anonymous ids -- bulk-loaded numeric graphs -- have no names to compare with: forward path)
+        }
+        // ---- the pairs: constants compared with item 0 (by pointer, then by content), the resource name validated, hashed, tested
+        std::vector<uint8_t> pair_ok(n);
+        const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
+            static const int kConst[5] = {F_RT, F_PM, F_ST, F_SID, F_SR};
+            constexpr size_t kGroup = 16;
+            uint64_t hv[kGroup];
+            std::string_view rids[kGroup];
+            for (size_t g0 = a; g0 < b && !outcome.load(std::memory_order_relaxed); g0 += kGroup) {
+                const size_t g1 = std::min(b, g0 + kGroup);
+                for (size_t i = g0; i < g1; i++) {
+                    bool same = true;
+                    for (int k = 0; k < 5 && same; k++) {
+                        const int f = kConst[k];
+                        const char *x = its.ptr(i, f), *y = its.ptr(0, f);
+                        const size_t lx = its.len(i, f), ly = its.len(0, f);
+                        same = lx == ly && (x == y || (x && y && std::memcmp(x, y, lx) == 0) || (lx == 0 && (!x || !y)));
+                    }
+                    const char *r = its.ptr(i, F_RID);
+                    const std::string_view rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
+                    if (!same || rid.empty() || rid == "*" || !valid_object_id(rid)) {  // (the forward path knows what to do with it: per-item error, whole-call failure, ...)
+                        outcome.store(1, std::memory_order_relaxed);
+                        return;
+                    }
+                    rids[i - g0] = rid;
+                    if (count) {
+                        hv[i - g0] = ObjectTable::hash_of(rid);
+                        if (!few) tab.prefetch(hv[i - g0]);
+                    }
+                }
+                for (size_t i = g0; i < g1 && count; i++) {
+                    const std::string_view rid = rids[i - g0];
+                    const uint64_t hh = hv[i - g0];
+                    bool maybe = !few;
+                    if (few) {
+                        uint32_t tg = (uint32_t)(hh >> 32);
+                        tg += tg == 0u;
+                        for (uint32_t q = tg & tmask; tags[q] != 0u && !maybe; q = (q + 1) & tmask) maybe = tags[q] == tg;
+                    }
+                    uint32_t id;
+                    // (the name table has the last word: id, then the row's bit)
+                    pair_ok[i] = maybe && tab.find_hashed(rid, hh, &id) && (size_t)(id >> 5) < row.size() && ((row[id >> 5] >> (id & 31u)) & 1u);
+                }
+            }
+        };
+        if (n < 2048) run(0, n);
+        else pool()->run(n, n >= 32768 ? 2048 : 512, workers, run);
+        if (outcome.load()) return kRouteNotTaken;
+        for (size_t i = 0; i < k_items; i++) {
+            uint8_t all = 1;  // (an item without pairs is kept: postfilter.go:145-150)
+            for (uint32_t j = item_off[i]; j < item_off[i + 1]; j++) all &= pair_ok[j];
+            keep_out[i] = all;
+        }
+    }
+    h->keep_route_calls.fetch_add(1, std::memory_order_relaxed);
+    return ACL_OK;
+}
+
+template <class Items>
+static int check_bulk_keep_strings(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out, const char *who) {
+    for (size_t i = 0; i < k_items; i++)
+        if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, std::string(who) + ": item_off must ascend and end within n");
+    int rc = keep_by_reverse_walk(h, its, n, item_off, k_items, keep_out);
+    if (rc != kRouteNotTaken) return rc;
+    std::vector<uint8_t> perm(std::max<size_t>(n, 1));
+    std::vector<int32_t> err(std::max<size_t>(n, 1));
+    rc = check_bulk_strings(h, its, n, perm.data(), err.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < k_items; i++) {
+        bool all = true;  // pair error or anything but HAS_PERMISSION drops the item: postfilter.go:162-172
+        for (uint32_t j = item_off[i]; j < item_off[i + 1]; j++) all = all && !err[j] && perm[j] == ACL_PERM_HAS_PERMISSION;
+        keep_out[i] = all ? 1 : 0;
+    }
+    return ACL_OK;
+}
+static int packed_ok(acl_engine_t *h, const acl_packed_request_t *rq, const char *who) {
+    if (!rq || (rq->n_items && (!rq->items || !rq->offsets || !rq->bytes))) return fail(ACL_ERR_INVALID_ARGUMENT, std::string(who) + ": NULL buffer");
+    const size_t n6 = rq->n_items * 6;
+    // (one pass over 24 bytes per item: nothing below reads a string through an index it has not seen; large requests share it out)
+    std::atomic<uint32_t> worst_a{0};
+    const std::function<void(size_t, size_t)> scan = [&](size_t a, size_t b) {
+        uint32_t wv = 0;
+        for (size_t k = a; k < b; k++) {
+            const uint32_t v = rq->items[k];
+            wv = std::max(wv, v == ACL_PACKED_NONE ? 0u : v + 1u);
+        }
+        uint32_t seen = worst_a.load(std::memory_order_relaxed);
+        while (wv > seen && !worst_a.compare_exchange_weak(seen, wv, std::memory_order_relaxed)) {
+        }
+    };
+    if (rq->n_items < 16384) {
+        scan(0, n6);
+    } else {
+        {
+            std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+            if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
+        }
+        h->intern_pool->run(n6, 6 * 4096, std::min(16u, h->intern_threads) - 1, scan);
+    }
+    const uint32_t worst = worst_a.load();
+    if (worst > rq->n_strings) return fail(ACL_ERR_INVALID_ARGUMENT, std::string(who) + ": a dictionary index lies beyond n_strings");
+    return ACL_OK;  // (an absent member -- ACL_PACKED_NONE -- is the pair's own InvalidArgument, as a {NULL, 0} view is)
+}
+int check_bulk_packed_call(acl_engine_t *h, const acl_packed_request_t *rq, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts) {
+    if (int rc = packed_ok(h, rq, "acl_check_bulk_packed")) return rc;
+    if (rq->n_items && (!perm_out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_packed: NULL buffer");
+    return check_bulk_strings(h, PackedItems{rq}, rq->n_items, perm_out, err_out, opts);
+}
+int check_bulk_keep_packed_call(acl_engine_t *h, const acl_packed_request_t *rq, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    if (int rc = packed_ok(h, rq, "acl_check_bulk_keep_packed")) return rc;
+    if (k_items && (!item_off || !keep_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_packed: NULL buffer");
+    return check_bulk_keep_strings(h, PackedItems{rq}, rq->n_items, item_off, k_items, keep_out, "acl_check_bulk_keep_packed");
+}
+int check_bulk_keep_v_call(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    if ((n && !items) || (k_items && (!item_off || !keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_v: NULL buffer");
+    return check_bulk_keep_strings(h, ViewItems{items}, n, item_off, k_items, keep_out, "acl_check_bulk_keep_v");
 }
 
 int lookup_opts_call(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, uint32_t *bitmap_out,
@@ -2127,6 +2445,16 @@ int acl_check_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n,
     return check_bulk_strings(h, ViewItems{items}, n, perm_out, err_out);
 }
 
+int acl_check_bulk_packed(acl_engine_t *h, const acl_packed_request_t *req, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *opts) {
+    return check_bulk_packed_call(h, req, perm_out, err_out, opts);
+}
+int acl_check_bulk_keep_packed(acl_engine_t *h, const acl_packed_request_t *req, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    return check_bulk_keep_packed_call(h, req, item_off, k_items, keep_out);
+}
+int acl_check_bulk_keep_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    return check_bulk_keep_v_call(h, items, n, item_off, k_items, keep_out);
+}
+
 // names -> the 16-byte items of the id entry points, in bulk and without a device pass (works on a store-only engine)
 int acl_resolve_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out) {
     if (n && (!items || !out || !err_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_resolve_bulk_v: NULL buffer");
@@ -2203,6 +2531,7 @@ int acl_stats(acl_engine_t *h, acl_stats_t *out) {
     std::lock_guard<std::mutex> lk(h->stats_mu);
     *out = h->stats;
     out->ids_recycled = recycled;
+    out->keep_route_calls = h->keep_route_calls.load(std::memory_order_relaxed);
     return ACL_OK;
 }
 int acl_stats_reset(acl_engine_t *h) {

@@ -362,6 +362,7 @@ struct acl_engine {
     void set_rev_uploaded(bool v) {
         for (auto &d : devs) d->rev_uploaded = v;
     }
+    std::atomic<uint64_t> keep_route_calls{0};  // PostFilter calls answered by ONE reverse walk + bit tests (engine.cpp keep_by_reverse_walk)
     bool per_item_validation = false;  // ACL_FLAG_PER_ITEM_VALIDATION: ill-formed items of a bulk Check fail their own pair, not the call
     bool lenient_lookup = false;       // ACL_FLAG_LENIENT_LOOKUP: a LookupResources candidate whose forward Check errs is dropped instead of failing the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)

@@ -5,7 +5,7 @@
 // `type:id#perm@type:id` from the item's metadata.name / metadata.namespace (postfilter.go:73-119) -> ONE
 // CheckBulkPermissions (postfilter.go:134) -> keep the items whose pairs are all HAS_PERMISSION (postfilter.go:144-178)
 // -> json.Marshal.  Here the body is scanned once for the item spans and their metadata, the K x F resolved pairs go
-// through acl_check_bulk_keep (one device pass), and the answer is the ORIGINAL bytes with the dropped items' spans cut
+// through acl_check_bulk_keep_v (one reverse walk + bit tests for the usual one-user, one-template list; else one forward device pass), and the answer is the ORIGINAL bytes with the dropped items' spans cut
 // out -- no generic decode / re-encode of a body that can be many megabytes.  (The reference's re-marshal sorts object
 // keys; the spliced document is the same JSON value for every key order, which is what kube clients parse.)
 //
@@ -404,11 +404,16 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     }
     off[items.size()] = (uint32_t)rels.size();
     if (rels.empty()) return unchanged(items.size());  // postfilter.go:122-125
-    std::vector<acl_check_item_t> ci(rels.size());
-    for (size_t k = 0; k < rels.size(); k++)
-        ci[k] = acl_check_item_t{rels[k].rtype.c_str(), rels[k].rid.c_str(), rels[k].rel.c_str(), rels[k].stype.c_str(), rels[k].sid.c_str(), rels[k].srel.c_str()};
+    // {pointer, length} views through acl_check_bulk_keep_v: a list filtered for ONE user by one template -- every pair shares type, permission and subject --
+    // is answered by one reverse walk and K bit tests (engine.cpp keep_by_reverse_walk), any other shape by the forward path
+    std::vector<acl_check_item_v_t> ci(rels.size());
+    auto sv = [](const std::string &x) { return acl_str_t{x.data(), x.size()}; };
+    for (size_t k = 0; k < rels.size(); k++) {
+        ci[k] = acl_check_item_v_t{sv(rels[k].rtype), sv(rels[k].rid), sv(rels[k].rel), sv(rels[k].stype), sv(rels[k].sid), sv(rels[k].srel)};
+        if (rels[k].srel.empty()) ci[k].subject_relation = acl_str_t{nullptr, 0};
+    }
     std::vector<uint8_t> keep(items.size());
-    int rc = acl_check_bulk_keep(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
+    int rc = acl_check_bulk_keep_v(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
     if (rc) return rc;
     // ---- splice: the original bytes minus the dropped items (the reference appends to a nil slice, postfilter.go:142: with nothing allowed, "items" marshals as null)
     size_t kept = 0;

@@ -100,15 +100,21 @@ def run_kat(kat, client):
             assert all(_match(e, g) for e, g in zip(step[2], got)) and len(got) == len(step[2]), f"{where}: expected {step[2]} got {got}"
         elif kind == "bulk_err":  # a request the API's validation refuses fails AS A WHOLE (no pairs)
             items = [parse_rel(t) for t in step[1]]
+            msg = None
             if hasattr(client, "check_bulk"):
                 try:
                     client.check_bulk(items)
                     got = None
                 except Exception as e:  # noqa: BLE001
                     got = getattr(e, "code", None)
+                    msg = str(e)
             else:  # one-at-a-time adapters: the call fails iff some item is ill-formed
                 got = 3 if any(client.check(*it)[1] == 3 for it in items) else None
             assert got == step[2], f"{where}: expected the call to fail with {step[2]}, got {got}"
+            # what the ENGINE says about it (step[3], optional): the reference denies everything a failed CheckBulkPermissions asked (check.go:48-52), so the
+            # message is all an operator has -- it names the item, the field, the value and the byte that breaks the pattern (the oracles carry no messages)
+            if len(step) > 3 and msg is not None and getattr(client, "names_invalid_fields", False):
+                assert all(part in msg for part in step[3]), f"{where}: the message {msg!r} should name {step[3]}"
         elif kind == "lookup":
             st, sid, srel = parse_subject(step[3])
             got = client.lookup(step[1], step[2], st, sid, srel)

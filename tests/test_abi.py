@@ -413,7 +413,7 @@ def test_go_shim_calls_match_the_header(tmp_path):
     assert "C.acl_config_t{device:" in eg
     broken["engine.go"] = eg.replace("C.acl_config_t{device:", "C.acl_config_t{dev:", 1)
     bad, _a, _b, _c = check_sources(broken)
-    assert any("acl_check_bulk_v_opts called with 5" in b for b in bad) and any("no field `dev`" in b for b in bad), bad
+    assert any("acl_check_bulk_packed called with 4" in b for b in bad) and any("no field `dev`" in b for b in bad), bad
 
 
 def test_gpu_scheme_patch_names_what_the_shim_defines():
