@@ -1036,6 +1036,22 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label, with_oracle=None):
     mperm, merr = o.check_bulk_ids_mt(cores, rt, perm_name, w.res, st, "", w.subj)  # EVERY answer of the batch is checked
     t_mt = time.perf_counter() - t0
     mism_mt = int((mperm != gpu_perm).sum() + (merr != gpu_err).sum())
+    # ... and the TUNED CPU Check beside it (oracle/acl_oracle.c orc_tuned_*: a row index instead of three binary searches per row, the
+    # level-synchronous frontier the device walks with identical states merged, dynamic chunks over the same host threads): the same batch, every answer
+    # asserted equal to the recursive evaluator's.  Building its index is setup (like the snapshot build on the other side) and timed apart.
+    tuned = None
+    t0 = time.perf_counter()
+    if o.tuned_build():
+        t_tb = time.perf_counter() - t0
+        tt = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            tperm, terr = o.tuned_check_bulk_ids_mt(cores, rt, perm_name, w.res, st, "", w.subj)
+            tt.append(time.perf_counter() - t0)
+        tuned = {"value": n / min(tt), "unit": "decisions/s", "cores": cores, "seconds": round(min(tt), 3), "index_build_s": round(t_tb, 2),
+                 "equal_to_recursive_oracle": bool(np.array_equal(tperm, mperm) and np.array_equal(terr, merr)),
+                 "sample": f"the whole {n}-item batch, {cores} host threads, best of 2; oracle/acl_oracle.c orc_tuned_check_bulk_ids_mt (checker-side code: never linked into the product)"}
+        mism_mt += int((tperm != mperm).sum() + (terr != merr).sum())
     if with_oracle is not None:
         with_oracle(o, cores)
     rot = rec.pop("rotations", None)
@@ -1047,7 +1063,8 @@ def cpu_and_roofline(args, w, rec, gpu_perm, gpu_err, label, with_oracle=None):
     rec["cpu_baseline"] = {"value": n / t_mt, "unit": "decisions/s", "cores": cores, "kind": "port",
                            "sample": f"the whole {n}-item batch split statically over {cores} host threads, restated CPU oracle (not embedded SpiceDB)",
                            "seconds": round(t_mt, 2), "load_s": round(t_oload, 2),
-                           "single_thread": {"value": m / t_cpu, "sample": f"first {m} items", "seconds": round(t_cpu, 2)}}
+                           "single_thread": {"value": m / t_cpu, "sample": f"first {m} items", "seconds": round(t_cpu, 2)},
+                           "tuned": tuned}
     # algorithmic bytes (SURVEY.md 8(d) model) over the WHOLE batch, multi-threaded, with the per-level split
     t0 = time.perf_counter()
     tot, lvl_b, lvl_s = o.check_bytes_bulk(max(cores, 4), rt, perm_name, w.res, st, "", w.subj)
@@ -1414,17 +1431,41 @@ def dry_spawn(world, rank, local_rank):
     prints ONE line."""
     import torch
     import torch.distributed as dist
+    import aclgpu
+    from aclgpu import workloads
     seen = [rank]
+    # what every rank of a real run does before and after its timed region, on a STORE-ONLY engine (no GPU): its own rotation of the request stream, the
+    # graph loaded through the ABI, the type -> shard map of the 8-rank sharded leg, the max-over-ranks clock and the per-rank records -- over gloo
+    w = workloads.c1()
+    shift = (rank * 32749) % max(1, int(w.res.size))
+    res = np.roll(w.res, shift)
+    eng = aclgpu.Engine(w.schema, store_only=True)
+    w.load(eng)
+    owners = {t_: int(eng._L.acl_shard_of_type(eng._h, eng.type_id(t_))) for t_ in ("user", "namespace")}
+    if world > 1:
+        eng._check(eng._L.acl_shard_configure(eng._h, rank, world))
+        owners = {t_: int(eng._L.acl_shard_of_type(eng._h, eng.type_id(t_))) for t_ in ("user", "namespace")}
+    eng.close()
+    elapsed = 1.0 + 0.01 * rank
+    per_rank = [{"rank": rank, "elapsed_s": elapsed, "first_resource": int(res[0])}]
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.zeros(world, dtype=torch.int64)
         t[rank] = 1 + local_rank
         dist.all_reduce(t)
         seen = [int(x) - 1 for x in t]
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)  # the contract's max-over-ranks timing
+        elapsed = float(tt.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "elapsed_s": 1.0 + 0.01 * rank, "first_resource": int(res[0])})
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_spawn": True, "n_gpus": world, "local_ranks_seen": seen, "metric": "check_decisions_per_sec", "value": None}), flush=True)
+        print(json.dumps({"dry_spawn": True, "n_gpus": world, "local_ranks_seen": seen, "metric": "check_decisions_per_sec", "value": None, "scaling": "weak",
+                          "max_elapsed_s": elapsed, "per_rank": per_rank, "shard_of_type": owners,
+                          "sharded_leg": "on" if world == 8 else "off (auto: the type-hash sharded leg runs at 8 ranks; replicas are `value` at every N)",
+                          "distinct_request_streams": len({r_["first_resource"] for r_ in per_rank})}), flush=True)
 
 
 def main():

@@ -200,7 +200,11 @@ int acl_check_bulk_ids(acl_engine_t *h, const acl_item_t *items, size_t n, uint8
  * same objects again (the user of a request, check.go:17-72; the namespaces of a list, postfilter.go:88-119) resolves once and keeps the ids.
  * Object names the graph does not know resolve to ids without relationships; err_out[i] != 0 (unknown type / permission: FAILED_PRECONDITION, an empty
  * or ill-formed field: INVALID_ARGUMENT -- always per item here) makes out[i] an item that every Check answers UNSPECIFIED with an error.
- * An id stays its object's while the object has relationships, and for the length of a recycling quarantine after this call otherwise. */
+ * An id stays its object's while the object has relationships, and for the length of a recycling quarantine (30 s) after this call otherwise.
+ * KEEPING the ids: an object name no table knows resolves to a sentinel id >= ACL_UNKNOWN_ID_MIN, which stays "nobody" after the object is
+ * created -- items that carry one must NOT be cached; and a cached id of an object that may lose all its relationships must be resolved again (or touched
+ * through acl_find) within the quarantine, or it may come to name another object.  Ids of objects that keep relationships are stable. */
+#define ACL_UNKNOWN_ID_MIN 0xFFFFFFF0u
 int acl_resolve_bulk_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, acl_item_t *out, int32_t *err_out);
 
 /* Cancellation / deadline of one call -- the C side of a Go context.Context.  The reference runs LookupResources on the

@@ -155,6 +155,10 @@ typedef struct orc {
     int relaxed;
     int lenient_lookup; /* 1: a candidate whose Check errs is dropped instead of failing the lookup (orc_set_lenient_lookup) */
     int lookup_err;     /* code of the last failed orc_lookup_ids() */
+    /* the tuned evaluator's row index (orc_tuned_*): first tuple of (type, rel, resource id) */
+    uint32_t **tn_rowptr; /* [ntypes * maxrels] -> [maxid + 2], NULL where the relation has no tuples */
+    uint32_t *tn_maxid;   /* [ntypes * maxrels] */
+    int tn_maxrels, tn_ready;
 } orc_t;
 
 static void seterr(orc_t *o, const char *fmt, ...) {
@@ -534,8 +538,19 @@ static int tup_cmp(const void *pa, const void *pb) {
     if (a->subj != b->subj) return a->subj < b->subj ? -1 : 1;
     return 0;
 }
+static void tn_drop(orc_t *o) { /* the tuned evaluator's row index follows the tuple array: rebuilt on the next orc_tuned_* call */
+    if (o->tn_rowptr) {
+        for (size_t k = 0; k < (size_t)o->ntypes * (size_t)o->tn_maxrels; k++) free(o->tn_rowptr[k]);
+        free(o->tn_rowptr);
+        free(o->tn_maxid);
+    }
+    o->tn_rowptr = NULL;
+    o->tn_maxid = NULL;
+    o->tn_ready = 0;
+}
 static void ensure_sorted(orc_t *o) {
     if (o->sorted) return;
+    tn_drop(o);
     qsort(o->tup, o->ntup, sizeof(tuple_t), tup_cmp);
     /* dedupe (TOUCH semantics for bulk loads) */
     size_t w = 0;
@@ -793,6 +808,7 @@ void orc_free(orc_t *o) {
     free(o->lr_ids);
     free(o->memo_k);
     free(o->memo_v);
+    tn_drop(o);
     free(o);
 }
 
@@ -1393,3 +1409,175 @@ uint64_t orc_check_bytes_bulk_mt(orc_t *o, int nthreads, size_t n, int rtype, in
 
 /* multi-threaded helper for the cpu_baseline leg is deliberately absent: the
  * oracle is a scalar single-thread port ("cores": 1). */
+
+
+/* ------------------------------------------------------------------ tuned CPU Check (bench.py `cpu_baseline.tuned`)
+ * the recursive evaluator above is the CHECKER -- written to be obviously right, it binary-searches a 24-byte tuple array
+ * three times per row and memoises in a hash table -- and a GPU / CPU ratio against it says nothing.  This is the same decision procedure written to be
+ * fast on a CPU, for the schemas the BASELINE configurations use (unions, arrows, computed usersets, userset subjects, `nil`; anything with `&`, `-`,
+ * `.all()` or a wildcard relationship is REFUSED: orc_tuned_supported() == 0):
+ *   - a row is found through an index: rowptr[type][relation][resource id] = its first tuple (one load, no search);
+ *   - a Check is evaluated LEVEL-SYNCHRONOUSLY, as the device does: the frontier of (type, relation, id) states at dispatch level L is expanded into
+ *     level L + 1, identical states of a level are merged (their subtrees are identical), the walk stops at the first membership hit;
+ *   - the batch is handed out in chunks of 256 requests to `nthreads` threads (requests differ 100-fold in work: a static split leaves threads idle).
+ * Semantics = check_rel()'s: HAS if some chain of <= 50 dispatches reaches a relationship naming the subject (or the subject itself, as a userset);
+ * else ERR if some chain needs a 51st dispatch; else NO.  Every caller asserts the answers EQUAL the recursive evaluator's (tests/test_oracle_cross.py,
+ * bench.py).  Test infrastructure like the rest of this file: never linked into the product. */
+static int tn_expr_ok(const expr_t *e) {
+    if (!e) return 1;
+    if (e->kind == EX_INTERSECT || e->kind == EX_EXCLUDE || e->kind == EX_ARROW_ALL) return 0;
+    return tn_expr_ok(e->l) && tn_expr_ok(e->r);
+}
+int orc_tuned_supported(orc_t *o) {
+    ensure_sorted(o);
+    for (int t = 0; t < o->ntypes; t++)
+        for (int r = 0; r < o->types[t].nrels; r++)
+            if (o->types[t].rels[r].is_perm && !tn_expr_ok(o->types[t].rels[r].expr)) return 0;
+    for (size_t i = 0; i < o->ntup; i++)
+        if (o->tup[i].srel == WILDCARD) return 0;
+    return 1;
+}
+int orc_tuned_build(orc_t *o) {
+    if (!orc_tuned_supported(o)) return -1;
+    if (o->tn_ready) return 0;
+    int maxrels = 1;
+    for (int t = 0; t < o->ntypes; t++) if (o->types[t].nrels > maxrels) maxrels = o->types[t].nrels;
+    o->tn_maxrels = maxrels;
+    o->tn_rowptr = calloc((size_t)o->ntypes * (size_t)maxrels, sizeof *o->tn_rowptr);
+    o->tn_maxid = calloc((size_t)o->ntypes * (size_t)maxrels, sizeof *o->tn_maxid);
+    for (size_t i = 0; i < o->ntup;) { /* the tuples are sorted by (type, relation, resource, ...): one run per relation */
+        const tuple_t *a = &o->tup[i];
+        size_t j = i;
+        while (j < o->ntup && o->tup[j].rtype == a->rtype && o->tup[j].rel == a->rel) j++;
+        const uint32_t maxid = o->tup[j - 1].res;
+        uint32_t *rp = malloc(((size_t)maxid + 2) * sizeof *rp);
+        size_t k = i;
+        for (uint32_t id = 0; id <= maxid; id++) {
+            rp[id] = (uint32_t)k;
+            while (k < j && o->tup[k].res == id) k++;
+        }
+        rp[maxid + 1] = (uint32_t)j;
+        o->tn_rowptr[(size_t)a->rtype * (size_t)maxrels + a->rel] = rp;
+        o->tn_maxid[(size_t)a->rtype * (size_t)maxrels + a->rel] = maxid;
+        i = j;
+    }
+    o->tn_ready = 1;
+    return 0;
+}
+static inline void tn_row(const orc_t *o, int type, int rel, uint32_t id, size_t *lo, size_t *hi) {
+    const size_t k = (size_t)type * (size_t)o->tn_maxrels + (size_t)rel;
+    const uint32_t *rp = o->tn_rowptr[k];
+    if (!rp || id > o->tn_maxid[k]) { *lo = *hi = 0; return; }
+    *lo = rp[id];
+    *hi = rp[id + 1];
+}
+typedef struct { uint64_t *a, *b; size_t na, nb, cap; } tn_scratch_t;
+static inline void tn_push(tn_scratch_t *s, int type, int rel, uint32_t id) {
+    if (s->nb == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : 1024;
+        s->a = realloc(s->a, s->cap * sizeof(uint64_t));
+        s->b = realloc(s->b, s->cap * sizeof(uint64_t));
+    }
+    s->b[s->nb++] = ((uint64_t)(unsigned)type << 48) | ((uint64_t)(unsigned)rel << 32) | id;
+}
+static int u64_cmp(const void *x, const void *y) { uint64_t a = *(const uint64_t *)x, b = *(const uint64_t *)y; return a < b ? -1 : a > b; }
+/* the children of permission expression e on (type, id): states of the NEXT dispatch level */
+static void tn_expr(const orc_t *o, tn_scratch_t *s, int type, const expr_t *e, uint32_t id) {
+    const type_t *t = &o->types[type];
+    switch (e->kind) {
+    case EX_UNION: tn_expr(o, s, type, e->l, id); tn_expr(o, s, type, e->r, id); break;
+    case EX_REF: tn_push(s, type, rel_index(t, e->a), id); break;
+    case EX_ARROW: {
+        size_t lo, hi;
+        tn_row(o, type, rel_index(t, e->a), id, &lo, &hi);
+        for (size_t i = lo; i < hi; i++) {
+            const tuple_t *tp = &o->tup[i];
+            if (!tup_live(o, tp)) continue;
+            const int tr = rel_index(&o->types[tp->stype], e->b);
+            if (tr >= 0) tn_push(s, tp->stype, tr, tp->subj);
+        }
+        break;
+    }
+    default: break; /* nil */
+    }
+}
+static int tn_check(const orc_t *o, tn_scratch_t *s, int rtype, int perm, uint32_t res, const subject_t *sub) {
+    s->na = 0;
+    s->nb = 0;
+    tn_push(s, rtype, perm, res);
+    for (int level = 1; level <= ORC_MAX_DEPTH; level++) {
+        /* level L = what tn_push collected: merge identical states, then expand every one */
+        { uint64_t *x = s->a; s->a = s->b; s->b = x; s->na = s->nb; s->nb = 0; }
+        if (s->na > 1) {
+            qsort(s->a, s->na, sizeof(uint64_t), u64_cmp);
+            size_t w = 1;
+            for (size_t i = 1; i < s->na; i++) if (s->a[i] != s->a[w - 1]) s->a[w++] = s->a[i];
+            s->na = w;
+        }
+        if (!s->na) return R_NO;
+        for (size_t q = 0; q < s->na; q++) {
+            const int type = (int)(s->a[q] >> 48), rel = (int)((s->a[q] >> 32) & 0xFFFF);
+            const uint32_t id = (uint32_t)s->a[q];
+            if (sub->stype == type && sub->srel == (unsigned)rel && sub->sid == id) return R_HAS; /* the subject itself, as a userset */
+            const rel_t *r = &o->types[type].rels[rel];
+            if (r->is_perm) { tn_expr(o, s, type, r->expr, id); continue; }
+            size_t lo, hi;
+            tn_row(o, type, rel, id, &lo, &hi);
+            if (lo < hi) {
+                const size_t p = row_find(o, lo, hi, sub->stype, sub->srel, sub->sid);
+                if (p < hi && tup_live(o, &o->tup[p])) return R_HAS;
+                for (size_t i = lo; i < hi; i++) { /* userset subjects: one dispatch level further */
+                    const tuple_t *tp = &o->tup[i];
+                    if (tp->srel == ELLIPSIS || !tup_live(o, tp)) continue;
+                    tn_push(s, tp->stype, (int)tp->srel, tp->subj);
+                }
+            }
+        }
+    }
+    return s->nb ? R_ERR : R_NO; /* a 51st dispatch would be needed */
+}
+typedef struct {
+    const orc_t *o;
+    size_t n, *next;
+    pthread_mutex_t *mu;
+    int rtype, perm, stype, srel;
+    const uint32_t *res, *subj;
+    uint8_t *out;
+    int32_t *err;
+} tn_job_t;
+static void *tn_run(void *p) {
+    tn_job_t *j = (tn_job_t *)p;
+    tn_scratch_t s = {0};
+    for (;;) {
+        pthread_mutex_lock(j->mu);
+        const size_t lo = *j->next;
+        *j->next = lo + 256;
+        pthread_mutex_unlock(j->mu);
+        if (lo >= j->n) break;
+        const size_t hi = lo + 256 < j->n ? lo + 256 : j->n;
+        for (size_t i = lo; i < hi; i++) {
+            const subject_t sub = {j->stype, j->srel < 0 ? ELLIPSIS : (unsigned)j->srel, j->subj[i]};
+            const int r = tn_check(j->o, &s, j->rtype, j->perm, j->res[i], &sub);
+            j->out[i] = r == R_HAS ? ORC_PERM_HAS : (r == R_ERR ? ORC_PERM_UNSPEC : ORC_PERM_NO);
+            if (j->err) j->err[i] = r == R_ERR ? ORC_ERR_DEPTH : 0;
+        }
+    }
+    free(s.a);
+    free(s.b);
+    return NULL;
+}
+/* -1: the schema / data are outside what the tuned evaluator takes (the caller keeps the recursive one) */
+int orc_tuned_check_bulk_ids_mt(orc_t *o, int nthreads, size_t n, int rtype, int perm, const uint32_t *res, int stype, int srel, const uint32_t *subj,
+                                uint8_t *out, int32_t *err) {
+    if (orc_tuned_build(o)) return -1;
+    if (nthreads < 1) nthreads = 1;
+    size_t next = 0;
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    tn_job_t job = {o, n, &next, &mu, rtype, perm, stype, srel, res, subj, out, err};
+    pthread_t *th = calloc((size_t)nthreads, sizeof *th);
+    for (int t = 1; t < nthreads; t++) pthread_create(&th[t], NULL, tn_run, &job);
+    tn_run(&job);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(th);
+    return 0;
+}

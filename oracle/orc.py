@@ -70,6 +70,11 @@ def lib():
         L.orc_check.argtypes = [C.c_void_p] + [C.c_char_p] * 6 + [C.POINTER(C.c_int)]
         L.orc_check_bulk_ids.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_check_bulk_ids_mt.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_intern.restype = C.c_uint32
+        L.orc_intern.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+        L.orc_tuned_supported.argtypes = [C.c_void_p]
+        L.orc_tuned_build.argtypes = [C.c_void_p]
+        L.orc_tuned_check_bulk_ids_mt.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lookup_ids.restype = C.c_long
         L.orc_lookup_ids.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.orc_lookup.restype = C.c_long
@@ -246,6 +251,25 @@ class Oracle:
         self._L.orc_check_bulk_ids_mt(self._h, int(nthreads), res.size, self.type_id(rtype), self.rel_id(rtype, perm), res.ctypes.data,
                                       self.type_id(stype), self.rel_id(stype, srel), subj.ctypes.data, out.ctypes.data, err.ctypes.data)
         return out, err
+
+    def intern(self, t, oid) -> int:
+        """the dense id of object `oid` of type `t` (created if missing): what the numeric entry points take"""
+        return self._L.orc_intern(self._h, self.type_id(t), _b(oid))
+
+    def tuned_build(self) -> bool:
+        """builds the tuned evaluator's row index (setup, not evaluation); False: the schema / data are outside what it takes (`&`, `-`, `.all()`, wildcards)"""
+        return self._L.orc_tuned_build(self._h) == 0
+
+    def tuned_check_bulk_ids_mt(self, nthreads, rtype, perm, res, stype, srel, subj):
+        """The tuned CPU Check (row index, level-synchronous frontier with merged states, dynamic chunks over `nthreads`): same answers as check_bulk_ids --
+        every caller asserts that -- or None when the schema is outside what it takes."""
+        res = np.ascontiguousarray(res, dtype=np.uint32)
+        subj = np.ascontiguousarray(subj, dtype=np.uint32)
+        out = np.zeros(res.size, dtype=np.uint8)
+        err = np.zeros(res.size, dtype=np.int32)
+        rc = self._L.orc_tuned_check_bulk_ids_mt(self._h, int(nthreads), res.size, self.type_id(rtype), self.rel_id(rtype, perm), res.ctypes.data,
+                                                 self.type_id(stype), self.rel_id(stype, srel), subj.ctypes.data, out.ctypes.data, err.ctypes.data)
+        return None if rc else (out, err)
 
     def lookup_ids(self, rtype, perm, stype, srel, subj):
         n = self._L.orc_lookup_ids(self._h, self.type_id(rtype), self.rel_id(rtype, perm), self.type_id(stype),

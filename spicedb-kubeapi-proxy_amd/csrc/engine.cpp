@@ -667,7 +667,7 @@ static int local_finish(acl_engine *h, PassCtx *c, uint32_t n) {
     if (c->h_status[0] == 2) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "a relationship row exceeds the per-task enumeration limit");
     if (c->h_status[0] == kOverflowDirect) {
         h->walk_no_direct.store(true, std::memory_order_relaxed);
-        h->direct_tripped.store(true, std::memory_order_relaxed);
+        c->direct_tripped = true;
     }
     if (c->h_status[0]) return kTakeLevelLoop;
     c->stats.levels_last = c->h_status[2];
@@ -682,7 +682,7 @@ int check_pass_local(acl_engine *h, PassCtx *c, const DevGraph &g, const uint4 *
 }
 
 static bool walk_allowed(acl_engine *h, size_t n);
-static void walk_outcome(acl_engine *h, size_t n, int rc);
+static void walk_outcome(acl_engine *h, PassCtx *c, size_t n, int rc);
 
 // The same for a batch in HOST memory, with no copy engine in the path: the kernel reads the items from pinned host memory
 // and writes the answers (and its overflow flag) straight back into pinned host memory, so a pass is ONE launch and ONE
@@ -780,7 +780,7 @@ static int check_pass_local_host(acl_engine *h, PassCtx *c, const acl_item_t *it
     for (uint32_t k = 0; k < npass; k++)
         if (flag[k] == kOverflowDirect) {
             h->walk_no_direct.store(true, std::memory_order_relaxed);
-            h->direct_tripped.store(true, std::memory_order_relaxed);
+            c->direct_tripped = true;
         }
     for (uint32_t k = 0; k < npass; k++)
         if (flag[k]) return kTakeLevelLoop;
@@ -805,9 +805,12 @@ static bool walk_allowed(acl_engine *h, size_t n) {
     if (n < kComputeTokenItems) return true;
     return !(h->local_skip.load(std::memory_order_relaxed) > 0 && h->local_skip.fetch_sub(1, std::memory_order_relaxed) > 0);
 }
-static void walk_outcome(acl_engine *h, size_t n, int rc) {
+static void walk_outcome(acl_engine *h, PassCtx *c, size_t n, int rc) {
+    // (what THIS call's walk met, kept in its own context: an engine-wide flag let two concurrent callers swap outcomes -- ADVICE r5)
+    const bool direct = c->direct_tripped;
+    c->direct_tripped = false;
     if (n < kComputeTokenItems) return;
-    if (rc == kTakeLevelLoop && h->direct_tripped.exchange(false, std::memory_order_relaxed)) return;  // (not a frontier overflow: the next walk simply builds its task lists the general way)
+    if (rc == kTakeLevelLoop && direct) return;  // (not a frontier overflow: the next walk simply builds its task lists the general way)
     if (rc == kTakeLevelLoop) h->local_skip.store(1 << std::min(6, 1 + h->local_fail_streak.fetch_add(1, std::memory_order_relaxed)), std::memory_order_relaxed);
     else if (!rc) h->local_fail_streak.store(0, std::memory_order_relaxed);
 }
@@ -886,7 +889,7 @@ int check_pass(acl_engine *h, PassCtx *c, const uint4 *d_items, uint32_t n, uint
     // walking its own slice of the batch through a wave-private frontier -- no host round trip between levels
     if (try_local && n <= h->local_max_items && walk_allowed(h, n)) {
         int rc = check_pass_local(h, c, g, d_items, n, d_perm, d_errout);
-        walk_outcome(h, n, rc);
+        walk_outcome(h, c, n, rc);
         if (rc != kTakeLevelLoop) return rc;  // kTakeLevelLoop: a block ran out of private frontier, the level-synchronous path takes the batch
     }
     int rc = levels_pass(h, c, g, d_items, n, d_perm, d_errout, false);
@@ -930,7 +933,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         // first choice at every size: the kernel reads the items from, and writes the answers to, pinned host memory itself -- one launch, one
         // synchronisation, no copy engine, no turn-taking between callers
         int rc = check_pass_local_host(h, c, items, (uint32_t)n, perm_out, err_out, &tried);
-        if (tried) walk_outcome(h, n, rc);
+        if (tried) walk_outcome(h, c, n, rc);
         if (rc != kTakeLevelLoop) return rc;
         // a block ran out of private frontier (-> the level loop below), or the batch needs more units than blocks (-> the copying walk below)
     }
@@ -979,7 +982,7 @@ int check_ids_host(acl_engine *h, PassCtx *c, const acl_item_t *items, size_t n,
         } else if (rc != kTakeLevelLoop) {
             (void)hipStreamSynchronize(c->stream);
         }
-        walk_outcome(h, n, rc);
+        walk_outcome(h, c, n, rc);
     }
     if (rc == kTakeLevelLoop) {  // a block ran out of private frontier, or the walk is switched off / backing off: the level loop, one batch at a time
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -245,6 +245,7 @@ struct PassCtx {
     DevArray<uint64_t> d_big_tasks, d_big_counts;
     DevArray<uint32_t> d_big_meta;  // [2 m]: task counts, levels
     size_t big_counts_zeroed = 0;   // leading accumulators known to be zero (k_rev_rows re-arms what it used)
+    bool direct_tripped = false;   // this context's last walk gave up on the direct task lists (kOverflowDirect): its redo is not a frontier overflow (walk_outcome)
     size_t visited_zero_words = 0;  // leading words of d_visited known to be all zero: k_rev_local takes `visited` zeroed and hands it back zeroed (kernels.hip)
     DevArray<uint4> d_nodes;     // schemas with `&` / `-`: the CombineNode records of a pass (plan.hpp)
     DevArray<uint64_t> d_dedup;  // duplicate-merging passes only (check_pass): open-addressing table over one level's entries
@@ -367,8 +368,8 @@ struct acl_engine {
     bool lenient_lookup = false;       // ACL_FLAG_LENIENT_LOOKUP: a LookupResources candidate whose forward Check errs is dropped instead of failing the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
     // the single-launch walk met rows too long for its direct task lists on this snapshot (kOverflowDirect): later walks build their lists the general
-    // way (reset when a snapshot is rebuilt); direct_tripped: that batch's redo is not a frontier overflow -- no back-off for it (walk_outcome)
-    std::atomic<bool> walk_no_direct{false}, direct_tripped{false};
+    // way (reset when a snapshot is rebuilt); (the batch that found out is redone without a back-off: PassCtx::direct_tripped, walk_outcome)
+    std::atomic<bool> walk_no_direct{false};
     std::atomic<int> local_skip{0}, local_fail_streak{0};  // large passes the walk sits out after it overflowed (check_pass)
     bool raw_intern = false;       // test knob (ACL_RAW_INTERN): acl_intern skips the API's object-id pattern
     uint32_t local_cap_limit = 0;  // test knob (ACL_LOCAL_CAP): private frontier entries per block, at most

@@ -244,7 +244,10 @@ int shard_check_core(acl_engine_t *h, PassCtx *c, const acl_shard_comm_t *comm, 
         uint32_t *hc = (uint32_t *)c->h_xctrl.p;
         DevGraph g = h->dev_graph(c);
         if (combine) {
-            node_cap = std::max<size_t>((size_t)1 << 16, n * 4) << c->shard_pool_shift;
+            // (the cell space is memset and max-reduced whole, per batch and shard -- world x 4 x node_cap bytes twice -- whatever the batch creates.  It starts a
+            //  quarter of round 5's size; a shard that runs out raises kOverflowPools and the batch is redone with pools x 4 (shard_pool_shift += 2); a batch that used
+            //  less than an eighth of its pools gives half of the growth back, below)
+            node_cap = std::max<size_t>((size_t)1 << 14, n) << c->shard_pool_shift;
             cell_cap = node_cap * 4;
             cells = (size_t)world * cell_cap;
             if ((uint64_t)n + cells >= 0xFFFFFFF0ull) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "combine cells beyond 2^32 on the sharded graph: smaller batches");
@@ -324,8 +327,12 @@ int shard_check_core(acl_engine_t *h, PassCtx *c, const acl_shard_comm_t *comm, 
         HIP_TRY(hipMemcpyAsync(hh.data(), c->d_xhrecv.p, (size_t)world * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         st.host_syncs++;
-        uint32_t maxc = 0;
-        for (const uint4 &x : hh) maxc = std::max(maxc, std::min<uint32_t>(x.x, (uint32_t)node_cap));
+        uint32_t maxc = 0, max_cells = 0;
+        for (const uint4 &x : hh) {
+            maxc = std::max(maxc, std::min<uint32_t>(x.x, (uint32_t)node_cap));
+            max_cells = std::max(max_cells, x.y);
+        }
+        if (c->shard_pool_shift && (uint64_t)maxc * 8 < node_cap && (uint64_t)max_cells * 8 < cell_cap) c->shard_pool_shift--;  // (identical on every shard: the headers are)
         if (maxc) {
             HIP_TRY(c->d_nodes_all.ensure((size_t)world * maxc));
             rc = comm->all_gather(comm->user, c->d_nodes.p, c->d_nodes_all.p, (size_t)maxc * sizeof(uint4), (void *)c->stream);

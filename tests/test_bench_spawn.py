@@ -63,3 +63,18 @@ def test_gpus_flag_must_match_world_size():
                         env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert pr.returncode != 0 and "--gpus 4" in pr.stderr + pr.stdout
     assert not _json_lines(pr.stdout)
+
+
+def test_eight_ranks_from_a_cold_start():
+    """`bench.py --gpus 8` -- what the driver runs on an 8-GPU node -- starts its eight ranks without manual steps: every rank opens an engine
+    (store-only here: no GPU), loads the graph through the ABI, takes ITS rotation of the request stream, configures the 8-way type-hash sharding of the extra
+    leg, and the ranks agree on the max-over-ranks clock and gather their records over gloo; rank 0 prints ONE line with n_gpus == 8."""
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-spawn"], capture_output=True, text=True, timeout=600, env=_env(OMP_NUM_THREADS="1"))
+    assert pr.returncode == 0, pr.stderr[-3000:]
+    lines = _json_lines(pr.stdout)
+    assert len(lines) == 1, pr.stdout
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["local_ranks_seen"] == list(range(8)) and ln["scaling"] == "weak"
+    assert sorted(r_["rank"] for r_ in ln["per_rank"]) == list(range(8)) and abs(ln["max_elapsed_s"] - 1.07) < 1e-9  # the slowest rank's clock
+    assert ln["distinct_request_streams"] >= 7  # every rank answers its own rotation of the stream
+    assert ln["sharded_leg"] == "on" and all(0 <= v < 8 for v in ln["shard_of_type"].values())

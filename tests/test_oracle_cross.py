@@ -1,6 +1,9 @@
 """Cross-checks the two independent oracle restatements (C: oracle/acl_oracle.c,
 Python: oracle/pyoracle.py) on hypothesis-generated graphs, including cyclic
 group nesting -- the shapes no reference test pins (SURVEY.md 8(c) last row)."""
+import os
+
+import numpy as np
 from hypothesis import given, settings, strategies as st
 
 from oracle import orc
@@ -89,6 +92,37 @@ def test_c_oracle_matches_python_oracle(tuples):
     for s in [("user", USERS[0], ""), ("group", GROUPS[0], "member")]:
         for rt, p in [("doc", "view"), ("org", "view"), ("group", "member"), ("group", "manage")]:
             assert outcome(co.lookup, rt, p, *s) == outcome(po.lookup_resources, rt, p, *s), (rt, p, s)
+    # the TUNED CPU evaluator (bench.py's cpu_baseline.tuned: row index, level-synchronous frontier, merged states) answers every query as the recursive
+    # one does -- cycles, usersets that are their own members, chains across the depth limit included
+    assert co.tuned_build()
+    for q in QUERIES:
+        rt, rid, perm, st, sid, srel = q
+        got = co.tuned_check_bulk_ids_mt(2, rt, perm, [co.intern(rt, rid)], st, srel, [co.intern(st, sid)])
+        assert (int(got[0][0]), int(got[1][0])) == co.check(*q), q
+
+
+def test_tuned_cpu_check_equals_the_recursive_oracle_on_the_workloads():
+    """... and on the BASELINE-shaped graphs, whole batches, several threads (dynamic chunks); a schema with `&` / `-` is refused, not guessed at."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spicedb-kubeapi-proxy_amd"))
+    from aclgpu import workloads
+    for w in (workloads.c1(), workloads.c2(scale=0.05, batch=6000), workloads.c4(scale=0.02, batch=20000, n_user=20000)):
+        o = orc.Oracle(w.schema)
+        w.load(o)
+        o.freeze()
+        rt, perm, st = w.check
+        want = o.check_bulk_ids_mt(4, rt, perm, w.res, st, "", w.subj)
+        got = o.tuned_check_bulk_ids_mt(5, rt, perm, w.res, st, "", w.subj)
+        assert got is not None and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), w.name
+    # a 60-long nesting chain: HAS up to the depth limit, the depth error beyond it, exactly where the recursive evaluator puts them
+    o = orc.Oracle(SCHEMA)
+    o.write([(orc.OP_TOUCH, ("group", "c0", "member", "user", "deep", ""))] + [(orc.OP_TOUCH, ("group", f"c{i + 1}", "member", "group", f"c{i}", "member")) for i in range(60)])
+    ids = [o.intern("group", f"c{i}") for i in range(61)]
+    want = o.check_bulk_ids("group", "member", ids, "user", "", [o.intern("user", "deep")] * 61)
+    got = o.tuned_check_bulk_ids_mt(3, "group", "member", ids, "user", "", [o.intern("user", "deep")] * 61)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and (want[0] == 2).sum() == 50 and (want[1] == orc.ERR_DEPTH).sum() == 11
+    nm = orc.Oracle(SCHEMA_NM)
+    assert not nm.tuned_build() and nm.tuned_check_bulk_ids_mt(2, "doc", "view", [0], "user", "", [0]) is None
 
 
 def test_bytes_model_result_agrees_with_check():
