@@ -7,6 +7,8 @@ import sqlite3
 import sys
 
 root, cfg = sys.argv[1], sys.argv[2]
+rnd = sys.argv[3] if len(sys.argv) > 3 else "round-5"
+tool = sys.argv[4] if len(sys.argv) > 4 else "tools/pmc_r05.sh"
 vals, durs, fails = {}, [], []
 for d in sorted(glob.glob(os.path.join(root, "s*"))):
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
@@ -22,7 +24,7 @@ for d in sorted(glob.glob(os.path.join(root, "s*"))):
         durs.append(dur / 1e3)
     for c, v in by.items():
         vals[c] = (sum(v) / len(v), len(v))
-print(f"# rocprofv3 --pmc passes on the round-5 `k_check_local`, {cfg} (262 144-item batch; tools/pmc_r05.sh)\n")
+print(f"# rocprofv3 --pmc passes on the {rnd} `k_check_local`, {cfg} (262 144-item batch; {tool})\n")
 print("One pass per counter set (own run, `--kernel-trace --pmc` only), mean per launch over the launches of the pass; counters with `_sum` are summed over the")
 print(f"instances (XCDs / channels) by rocprofv3.  Kernel duration under the profiler: {sum(durs) / max(1, len(durs)):.1f} us (mean over {len(durs)} samples; counter collection serialises launches).\n")
 print("| counter | per launch | launches |\n|---|---|---|")
