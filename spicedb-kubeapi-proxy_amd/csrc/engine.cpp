@@ -1070,12 +1070,22 @@ struct CStrItems {
         const char *p = ptr(i, f);
         return p ? std::strlen(p) : 0;
     }
+    static constexpr size_t kAhead = 16;  // (48 bytes per item; see ViewItems)
+    void prefetch(size_t i) const { __builtin_prefetch(&it[i]); }
 };
 struct ViewItems {
     const acl_check_item_v_t *it;
     static constexpr bool kHasLen = true;
     const char *ptr(size_t i, int f) const { return (&it[i].resource_type)[f].p; }
     size_t len(size_t i, int f) const { return (&it[i].resource_type)[f].p ? (&it[i].resource_type)[f].n : 0; }
+    // The caller's items were written by another core: a worker pulls its share (96 bytes per item) out of that core's cache or out of memory, and the hardware's
+    // stream prefetcher alone keeps too few lines in flight -- the pull, not the arithmetic, is what a pair's host pass costs (tools/host_pass_probe.cpp: 7 ns of
+    // work per pair on cached data against 25-30 ns in a call).  The loops over items ask for item i + kAhead before they work on item i.
+    static constexpr size_t kAhead = 12;
+    void prefetch(size_t i) const {
+        __builtin_prefetch(reinterpret_cast<const char *>(&it[i]));
+        __builtin_prefetch(reinterpret_cast<const char *>(&it[i]) + 64);
+    }
 };
 // ... and the PACKED form (acl_check_bulk_packed, round 6): a dictionary of the call's DISTINCT strings and six u32 indices per item.  A shim that walks a kube
 // list copies every string once anyway (shim/go/aclgpu/engine.go); written into one buffer, an item is 24 bytes instead of six views (96), the constant
@@ -1093,8 +1103,14 @@ struct PackedItems {
         const uint32_t k = idx(i, f);
         return k == ACL_PACKED_NONE ? 0 : rq->offsets[k + 1] - rq->offsets[k];
     }
+    static constexpr size_t kAhead = 32;
+    void prefetch(size_t i) const { __builtin_prefetch(&rq->items[6 * i]); }
 };
 enum { F_RT = 0, F_RID = 1, F_PM = 2, F_ST = 3, F_SID = 4, F_SR = 5 };
+static const bool kItemsAhead = [] {
+    const char *e = getenv("ACL_ITEMS_AHEAD");  // (A/B knob: 0 = the loops over items leave their streaming to the hardware prefetcher)
+    return !(e && atoi(e) == 0);
+}();
 // Which field of item i fails the API's validation, and why -- for acl_last_error() ("check failed" told an operator nothing; the
 // reference denies everything a failed CheckBulkPermissions asked, pkg/authz/check.go:48-52, so the message is all there is to diagnose a blanket denial).
 template <class Items>
@@ -1202,28 +1218,49 @@ static bool intern_names(const Schema &sc, const Items &its, size_t i, NameMemo 
 // Host threads of the string entry points' interning: persistent (spawning 15 threads costs 0.2-2 ms per call -- more than interning a
 // 64 k-item batch), woken per batch; the caller works too.
 struct InternPool {
+    // A batch is OPEN between run()'s two stores to `open`.  A worker enters one by counting itself in (`inside`) and THEN reading `open`; run() closes the batch
+    // and THEN waits for `inside` to drain: whichever of the two sequentially consistent pairs comes first, either the worker sees the batch closed and leaves
+    // without touching it, or run() sees the worker and waits -- `fn` and the batch's fields are never read after run() returned.  No mutex on this path:
+    // 31 workers signing in and out of every batch through one lock cost a 65 536-item call 40-60 us per batch, three batches per call (round 6).  Only a worker
+    // that has polled kSpinNs for nothing sleeps, on `mu` / `cv`; one that wakes up late finds its batch closed and does not hold anybody up.
     std::mutex mu;
-    std::condition_variable cv, done_cv;
+    std::condition_variable cv;
     std::vector<std::thread> threads;
     const std::function<void(size_t, size_t)> *job = nullptr;
     size_t n = 0, chunk = 1;
     std::atomic<size_t> next{0};
-    std::atomic<unsigned> limit{0};  // workers that take chunks of the current batch
-    size_t outstanding = 0;  // workers that have not yet passed through the current batch (every worker passes through every batch)
-    uint64_t gen = 0;
-    bool stop = false;
-    std::atomic<uint64_t> gen_a{0};  // = gen, for the workers that poll instead of sleeping
-    std::atomic<bool> stop_a{false};
-    unsigned sleepers = 0;
+    unsigned limit = 0;  // workers that take chunks of the current batch
+    std::atomic<uint64_t> gen_a{0};
+    std::atomic<bool> open{false}, stop_a{false};
+    std::atomic<int> inside{0};
+    std::atomic<unsigned> sleepers{0};
     static constexpr int64_t kSpinNs = 150000;
     std::mutex call_mu;  // one batch at a time
 
-    void work() {
-        for (;;) {
-            const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
-            if (a >= n) return;
-            (*job)(a, std::min(n, a + chunk));
+    // most workers are still polling (a batch ended less than kSpinNs ago): a batch of a few hundred items is worth spreading, nobody has to be woken up
+    bool awake() const { return (size_t)sleepers.load(std::memory_order_relaxed) * 2 < threads.size(); }
+    // Which piece goes to whom: participant p (the workers 0 .. limit - 1, the caller = limit) takes the pieces p, p + P, p + 2 P, ... first and only then whatever
+    // is left (a participant that shows up late loses its pieces to the others).  The SAME thread then writes the same part of the per-call arrays -- hashes,
+    // staged items, keep bytes -- in every pass of a call and call after call: their lines stay in its cache instead of being pulled, modified, out of
+    // another core's for every eighth item (ACL_POOL_AFFINITY=0: first come, first served -- the A/B).
+    std::unique_ptr<std::atomic<uint8_t>[]> taken;
+    size_t taken_cap = 0, npieces = 0;
+    bool affine = true;
+    void work(unsigned me) {
+        if (!affine) {
+            for (;;) {
+                const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
+                if (a >= n) return;
+                (*job)(a, std::min(n, a + chunk));
+            }
         }
+        const size_t P = (size_t)limit + 1;
+        auto take = [&](size_t c) {
+            if (taken[c].load(std::memory_order_relaxed) || taken[c].exchange(1, std::memory_order_relaxed)) return;
+            (*job)(c * chunk, std::min(n, (c + 1) * chunk));
+        };
+        for (size_t c = me; c < npieces; c += P) take(c);
+        for (size_t k = 0, c = me; k < npieces; k++, c = c + 1 == npieces ? 0 : c + 1) take(c);
     }
     void loop(unsigned me) {
         uint64_t seen = 0;
@@ -1237,22 +1274,17 @@ struct InternPool {
                     if (!got) __builtin_ia32_pause();
                 }
             }
-            {
+            if (!got) {
                 std::unique_lock<std::mutex> lk(mu);
-                if (!got) {
-                    sleepers++;
-                    cv.wait(lk, [&] { return stop || gen != seen; });
-                    sleepers--;
-                }
-                if (stop) return;
-                seen = gen;
+                sleepers.fetch_add(1);  // (before the predicate's first look at gen_a: run() bumps gen_a and then reads `sleepers`)
+                cv.wait(lk, [&] { return stop_a.load() || gen_a.load() != seen; });
+                sleepers.fetch_sub(1);
             }
-            if (me < limit.load(std::memory_order_relaxed)) work();  // (every worker passes through every batch; the ones beyond the batch's limit only sign off)
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                outstanding--;
-            }
-            done_cv.notify_one();
+            if (stop_a.load()) return;
+            seen = gen_a.load(std::memory_order_acquire);
+            inside.fetch_add(1);
+            if (open.load() && me < limit) work(me);
+            inside.fetch_sub(1);
         }
     }
     // The workers stay on the NUMA node of the thread that creates the pool (the first large string batch's caller): the name tables were
@@ -1300,39 +1332,52 @@ struct InternPool {
     }
     explicit InternPool(unsigned nthreads) {
         for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this, i] { loop(i); });
+        if (const char *e = getenv("ACL_POOL_AFFINITY")) affine = atoi(e) != 0;
         const char *ev = getenv("ACL_INTERN_PIN");
         cpu_set_t set;
         if (!(ev && atoi(ev) == 0) && node_cpus(&set))
             for (auto &t : threads) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
     }
     ~InternPool() {
+        stop_a.store(true);
         {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-            stop_a.store(true, std::memory_order_relaxed);
+            std::lock_guard<std::mutex> lk(mu);  // (a worker between its predicate and its wait holds mu: the notify below cannot slip in there)
         }
         cv.notify_all();
         for (auto &t : threads) t.join();
     }
-    void run(size_t total, size_t chunk_items, unsigned workers, const std::function<void(size_t, size_t)> &fn) {
+    // meanwhile: what the CALLER does between starting the batch and joining it (a device call it waits for while the workers go through the items).  It must
+    // not take state_mu or names_mu: interning callers wait for call_mu under names_mu (lock order: state_mu, names_mu, call_mu).
+    void run(size_t total, size_t chunk_items, unsigned workers, const std::function<void(size_t, size_t)> &fn, const std::function<void()> *meanwhile = nullptr) {
         std::lock_guard<std::mutex> one(call_mu);
-        bool wake;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            job = &fn;
-            n = total;
-            chunk = chunk_items;
-            next.store(0, std::memory_order_relaxed);
-            limit.store(workers, std::memory_order_relaxed);
-            outstanding = threads.size();
-            gen++;
-            gen_a.store(gen, std::memory_order_release);
-            wake = sleepers != 0;
+        job = &fn;
+        n = total;
+        chunk = chunk_items;
+        limit = workers;
+        next.store(0, std::memory_order_relaxed);
+        npieces = (total + chunk_items - 1) / chunk_items;
+        if (affine) {
+            if (taken_cap < npieces) {
+                taken_cap = std::max<size_t>(256, npieces * 2);
+                taken.reset(new std::atomic<uint8_t>[taken_cap]);
+            }
+            for (size_t c = 0; c < npieces; c++) taken[c].store(0, std::memory_order_relaxed);
         }
-        if (wake) cv.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu);
-        done_cv.wait(lk, [&] { return outstanding == 0; });  // no worker is still inside (or yet to enter) this batch: `fn` may go out of scope
+        open.store(true);
+        gen_a.fetch_add(1);
+        if (sleepers.load() != 0) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+            }
+            cv.notify_all();
+        }
+        if (meanwhile) (*meanwhile)();
+        work(limit);
+        open.store(false);
+        for (unsigned spins = 0; inside.load() != 0; spins++) {  // (workers still in their last chunk)
+            if (spins < 4096) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
     }
 };
 
@@ -1411,6 +1456,7 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             for (size_t i = g0; i < g1; i++) {
                 Pending &p = pend[i - g0];
                 int32_t err = 0;
+                if (kItemsAhead && i + Items::kAhead < n) its.prefetch(i + Items::kAhead);
                 const char *r = its.ptr(i, F_RID), *u = its.ptr(i, F_SID);
                 p.rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
                 p.sid = u ? std::string_view(u, its.len(i, F_SID)) : std::string_view();
@@ -1493,7 +1539,14 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             bad->insert(bad->end(), mybad.begin(), mybad.end());
         }
     };
-    if (n < 4096) {  // tens of nanoseconds per item on one thread: below this the pool's wake-up costs more than it saves
+    // tens of nanoseconds per item on one thread: below 4 096 items waking the pool up (20-100 us per sleeping thread) costs more than it saves -- unless its
+    // workers are still polling after the previous batch (a busy proxy's calls follow each other within that window): then from 512 items on
+    bool hot = false;
+    if (n >= 512 && n < 4096) {
+        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+        hot = h->intern_pool && h->intern_pool->awake();
+    }
+    if (n < 4096 && !hot) {
         run(0, n);
         return;
     }
@@ -1503,7 +1556,7 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
     }
     // threads per batch: 16 up to 32 767 items, 32 beyond (same-box A/B on a 256-thread host, profiles/r03_string_path_ab.txt: 65 536 named
     // items 135 -> 170 M decisions/s with 32; 16 384 items the same with either, 48 threads slower at both sizes)
-    h->intern_pool->run(n, n >= 32768 ? 1024 : 512, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1, run);
+    h->intern_pool->run(n, n >= 32768 ? 1024 : n >= 8192 ? 512 : n >= 2048 ? 128 : 64, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1, run);
 }
 
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
@@ -1881,6 +1934,7 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
         return e ? (size_t)std::max(0, atoi(e)) : (size_t)512;
     }();
     if (!kMin || n < kMin || h->store_only || h->shard.world > 1) return kRouteNotTaken;
+    if (!k_items || item_off[0] != 0 || item_off[k_items] != n) return kRouteNotTaken;  // (pairs outside every item: the forward path checks them all the same)
     int rt, pm, st;
     uint32_t sub = 0;
     bool sub_known = false;
@@ -1897,34 +1951,133 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
         sub_known = h->store.objects(st).find(sid, &sub);
         if (sub_known) h->store.touch(st, sub);  // (the id leaves the names lock: its recycling quarantine starts over, store.hpp)
     }
-    // ---- the reverse walk (none for a subject no table knows: it has no relationships, and without a subject relation it is nobody's member)
+    auto pool = [&](bool create = true) -> InternPool * {
+        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+        if (!h->intern_pool && create) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
+        return h->intern_pool;
+    };
+    const unsigned workers = (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1;
+    // ---- the reverse walk (none for a subject no table knows: it has no relationships, and without a subject relation it is nobody's member) AND, while the
+    // device walks, the host's pass over the pairs: constants compared with item 0 (by pointer, then by content), the resource name validated and hashed.
+    // The walk is a launch, ~30 us of kernel and the row's way back; the pass is ~10 ns per pair and thread and touches no table: they overlap entirely, the
+    // caller waiting for the device, the pool's workers on the pairs (the caller joins them when the row is back).
+    static const bool kTrace = getenv("ACL_DEBUG_KEEP") != nullptr;  // (phase times of the route on stderr)
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto us_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); };
+    double us_walk = 0, us_a = 0, us_fill = 0;
+    std::atomic<uint64_t> tr_sum{0}, tr_first{~0ull}, tr_last{0};  // (pass chunks: ns inside them, when the first began, when the last ended)
+    static thread_local std::vector<uint64_t> hv_buf;  // (per calling thread: 512 KB of fresh pages per 65 536-item call cost more than the pass itself)
+    if (hv_buf.size() < n) hv_buf.resize(n);
+    uint64_t *hv = hv_buf.data();
     std::vector<uint32_t> row;
-    std::vector<uint32_t> tags;  // open addressing over the allowed objects' name tags (0 = empty; a tag of 0 is stored as 1: only costs a rare extra probe)
-    uint32_t tmask = 0;
     uint64_t count = 0;
+    std::atomic<int> outcome{0};  // 0 fine; 1: not a uniform call after all / an item the forward path must judge -> not taken
+    int walk_rc = ACL_OK;
+    Eval ev;
     if (sub_known) {
-        Eval ev;
         int rc = ev.begin(h, true, CallOpts());
         if (rc) return rc;
-        const Schema &sc = h->store.schema();
-        if (rt >= (int)sc.defs.size() || st >= (int)sc.defs.size() || pm >= (int)sc.defs[rt].members.size()) return kRouteNotTaken;  // (the schema was reloaded in between)
-        const uint32_t target = (uint32_t)sc.slot(rt, pm);
-        if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
-        const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
-        row.assign(std::max<size_t>(words, 1), 0u);
-        rc = lookup_batch(h, ev.c, rt, pm, st, -1, &sub, 1, row.data(), row.size(), &count);
-        if (rc) return rc;
     }
-    std::atomic<int> outcome{0};  // 0 fine; 1: not a uniform call after all / an item the forward path must judge -> not taken
+    // (state_mu -- the evaluation's -- then names_mu: engine_internal.hpp's order.  The names stay locked while the device walks: the pass below already pulls
+    //  every pair's slot of the name table towards the cores, so that the test after the walk finds them in cache)
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    if (!h->store.has_schema() || rt >= (int)h->store.schema().defs.size()) return kRouteNotTaken;  // (reloaded in between)
+    const ObjectTable &tab = h->store.objects(rt);
     {
-        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
-        const ObjectTable &tab = h->store.objects(rt);
-        auto pool = [&]() -> InternPool * {
-            std::lock_guard<std::mutex> lk(h->intern_pool_mu);
-            if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
-            return h->intern_pool;
+        if (sub_known) {
+            const Schema &sc = h->store.schema();
+            if (rt >= (int)sc.defs.size() || st >= (int)sc.defs.size() || pm >= (int)sc.defs[rt].members.size()) return kRouteNotTaken;  // (the schema was reloaded in between)
+            const uint32_t target = (uint32_t)sc.slot(rt, pm);
+            if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
+            const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
+            row.assign(std::max<size_t>(words, 1), 0u);
+        }
+        const std::function<void()> walk = [&] {
+            const auto t_w = std::chrono::steady_clock::now();
+            if (sub_known) walk_rc = lookup_batch(h, ev.c, rt, pm, st, -1, &sub, 1, row.data(), row.size(), &count);
+            us_walk = us_since(t_w);
         };
-        const unsigned workers = (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1;
+        // (both passes go over ITEMS, each worker through its items' pairs [item_off[a], item_off[b]): the keep bytes are then written where they are computed)
+        const std::function<void(size_t, size_t)> pass = [&](size_t a, size_t b) {
+            static const int kConst[5] = {F_RT, F_PM, F_ST, F_SID, F_SR};
+            struct ChunkTrace {
+                std::chrono::steady_clock::time_point t0, c0;
+                std::atomic<uint64_t> *sum, *first, *last;
+                ~ChunkTrace() {
+                    if (!sum) return;
+                    const auto now = std::chrono::steady_clock::now();
+                    sum->fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - c0).count());
+                    const uint64_t st = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(c0 - t0).count(), en = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t0).count();
+                    for (uint64_t v = first->load(); st < v && !first->compare_exchange_weak(v, st);) {}
+                    for (uint64_t v = last->load(); en > v && !last->compare_exchange_weak(v, en);) {}
+                }
+            } ct{t_0, std::chrono::steady_clock::now(), kTrace ? &tr_sum : nullptr, &tr_first, &tr_last};
+            // Blocks of 64 items, stage by stage: the offsets; every pair's constant fields and resource id judged; the ids hashed into a LOCAL array; the hashes
+            // copied out and their table slots asked for.  (Fused into one loop per pair -- judge, hash, store -- the same work measured 85 cycles per pair
+            // instead of 50 on the box's EPYC, 30 of them on the store into the shared array between a pair's loads: rdtsc per stage, round 6.)
+            constexpr size_t kBlock = 64;
+            uint64_t loc[kBlock];
+            for (size_t g = a; g < b; g += kBlock) {
+                if (outcome.load(std::memory_order_relaxed)) return;
+                const size_t ge = std::min(b, g + kBlock);
+                bool fine = true;
+                for (size_t it = g; it < ge; it++) fine &= item_off[it] <= item_off[it + 1] && item_off[it + 1] <= n;  // (else not an ascending offset array: the caller's check says so)
+                if (!fine) {
+                    outcome.store(1, std::memory_order_relaxed);
+                    return;
+                }
+                for (size_t lo = item_off[g], hi = item_off[ge]; lo < hi; lo += kBlock) {
+                    const size_t le = std::min(hi, lo + kBlock);
+                    for (size_t i = lo; i < le; i++) {
+                        if (kItemsAhead && i + Items::kAhead < n) its.prefetch(i + Items::kAhead);
+                        // (the usual case first: the shim points every pair's constant fields at the same strings / dictionary entries -- no bytes compared)
+                        bool same = true, identical = false;
+                        if constexpr (std::is_same_v<Items, PackedItems>) {
+                            const uint32_t *x = its.rq->items + 6 * i, *y = its.rq->items;
+                            identical = ((x[F_RT] ^ y[F_RT]) | (x[F_PM] ^ y[F_PM]) | (x[F_ST] ^ y[F_ST]) | (x[F_SID] ^ y[F_SID]) | (x[F_SR] ^ y[F_SR])) == 0;
+                        } else if constexpr (std::is_same_v<Items, ViewItems>) {
+                            const auto *x = &its.it[i].resource_type, *y = &its.it[0].resource_type;
+                            identical = true;
+                            for (int k = 0; k < 5; k++) identical &= x[kConst[k]].p == y[kConst[k]].p && x[kConst[k]].n == y[kConst[k]].n;
+                        }
+                        for (int k = 0; k < 5 && same && !identical; k++) {
+                            const int f = kConst[k];
+                            const char *x = its.ptr(i, f), *y = its.ptr(0, f);
+                            const size_t lx = its.len(i, f), ly = its.len(0, f);
+                            same = lx == ly && (x == y || (x && y && std::memcmp(x, y, lx) == 0) || (lx == 0 && (!x || !y)));
+                        }
+                        const char *r = its.ptr(i, F_RID);
+                        const std::string_view rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
+                        fine &= same && !rid.empty() && rid != "*" && valid_object_id(rid);  // (else the forward path knows what to do with it: per-item error, whole-call failure, ...)
+                    }
+                    if (!fine) {
+                        outcome.store(1, std::memory_order_relaxed);
+                        return;
+                    }
+                    for (size_t i = lo; i < le; i++) loc[i - lo] = ObjectTable::hash_of(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)));
+                    for (size_t i = lo; i < le; i++) {
+                        hv[i] = loc[i - lo];
+                        tab.prefetch(loc[i - lo]);
+                    }
+                }
+            }
+        };
+        // (the pool from 2 048 items on, from 512 when its workers are still polling after the previous call: intern_items)
+        InternPool *const P = pool(k_items >= 2048);
+        const bool spread = k_items >= 2048 || (k_items >= 512 && P && P->awake());
+        const size_t piece = k_items >= 32768 ? 1024 : k_items >= 8192 ? 512 : k_items >= 2048 ? 128 : 64;  // (two pieces per worker: one that starts late does not make the others wait)
+        if (!spread) {
+            walk();
+            pass(0, k_items);
+        } else P->run(k_items, piece, workers, pass, &walk);
+    }
+    if (walk_rc) return walk_rc;
+    if (outcome.load()) return kRouteNotTaken;
+    us_a = us_since(t_0);
+    ev.end();
+    std::vector<uint32_t> tags;  // open addressing over the allowed objects' name tags (0 = empty; a tag of 0 is stored as 1: only costs a rare extra probe)
+    uint32_t tmask = 0;
+    {
         // Two ways to test a name against the row.  FEW allowed objects (at most half as many as there are pairs): their names' hash tags make a small set that
         // stays in cache, and only a tag hit goes on to the name table.  MANY: every name goes to the table (one miss, prefetched a group ahead) -- still
         // half of what the forward path's interning pays (it resolves the subject too) and no device pass over K items.
@@ -1956,69 +2109,49 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
             else pool()->run(row.size(), std::max<size_t>(256, row.size() / 64), workers, fill);
             if (anonymous.load()) return kRouteNotTaken;  // (anonymous ids -- bulk-loaded numeric graphs -- have no names to compare with: forward path)
         }
-        // ---- the pairs: constants compared with item 0 (by pointer, then by content), the resource name validated, hashed, tested
-        std::vector<uint8_t> pair_ok(n);
-        const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
-            static const int kConst[5] = {F_RT, F_PM, F_ST, F_SID, F_SR};
+        us_fill = us_since(t_0);
+        // ---- the pairs' names against the row; an item is kept when every one of its pairs is (one without pairs too: postfilter.go:145-150)
+        const std::function<void(size_t, size_t)> test = [&](size_t a, size_t b) {
             constexpr size_t kGroup = 16;
-            uint64_t hv[kGroup];
-            std::string_view rids[kGroup];
-            for (size_t g0 = a; g0 < b && !outcome.load(std::memory_order_relaxed); g0 += kGroup) {
+            for (size_t g0 = a; g0 < b; g0 += kGroup) {
                 const size_t g1 = std::min(b, g0 + kGroup);
-                for (size_t i = g0; i < g1; i++) {
-                    bool same = true;
-                    for (int k = 0; k < 5 && same; k++) {
-                        const int f = kConst[k];
-                        const char *x = its.ptr(i, f), *y = its.ptr(0, f);
-                        const size_t lx = its.len(i, f), ly = its.len(0, f);
-                        same = lx == ly && (x == y || (x && y && std::memcmp(x, y, lx) == 0) || (lx == 0 && (!x || !y)));
+                if (!few)
+                    for (size_t i = item_off[g0]; i < item_off[g1]; i++) tab.prefetch(hv[i]);
+                for (size_t it = g0; it < g1; it++) {
+                    uint8_t all = 1;
+                    for (size_t i = item_off[it]; i < item_off[it + 1]; i++) {
+                        const uint64_t hh = hv[i];
+                        bool maybe = !few;
+                        if (few) {
+                            uint32_t tg = (uint32_t)(hh >> 32);
+                            tg += tg == 0u;
+                            for (uint32_t q = tg & tmask; tags[q] != 0u && !maybe; q = (q + 1) & tmask) maybe = tags[q] == tg;
+                        }
+                        uint32_t id;
+                        // (the name table has the last word: id, then the row's bit)
+                        all &= (uint8_t)(maybe && tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hh, &id) && (size_t)(id >> 5) < row.size() &&
+                                         ((row[id >> 5] >> (id & 31u)) & 1u));
                     }
-                    const char *r = its.ptr(i, F_RID);
-                    const std::string_view rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
-                    if (!same || rid.empty() || rid == "*" || !valid_object_id(rid)) {  // (the forward path knows what to do with it: per-item error, whole-call failure, ...)
-                        outcome.store(1, std::memory_order_relaxed);
-                        return;
-                    }
-                    rids[i - g0] = rid;
-                    if (count) {
-                        hv[i - g0] = ObjectTable::hash_of(rid);
-                        if (!few) tab.prefetch(hv[i - g0]);
-                    }
-                }
-                for (size_t i = g0; i < g1 && count; i++) {
-                    const std::string_view rid = rids[i - g0];
-                    const uint64_t hh = hv[i - g0];
-                    bool maybe = !few;
-                    if (few) {
-                        uint32_t tg = (uint32_t)(hh >> 32);
-                        tg += tg == 0u;
-                        for (uint32_t q = tg & tmask; tags[q] != 0u && !maybe; q = (q + 1) & tmask) maybe = tags[q] == tg;
-                    }
-                    uint32_t id;
-                    // (the name table has the last word: id, then the row's bit)
-                    pair_ok[i] = maybe && tab.find_hashed(rid, hh, &id) && (size_t)(id >> 5) < row.size() && ((row[id >> 5] >> (id & 31u)) & 1u);
+                    keep_out[it] = all;
                 }
             }
         };
-        if (n < 2048) run(0, n);
-        else pool()->run(n, n >= 32768 ? 2048 : 512, workers, run);
-        if (outcome.load()) return kRouteNotTaken;
-        for (size_t i = 0; i < k_items; i++) {
-            uint8_t all = 1;  // (an item without pairs is kept: postfilter.go:145-150)
-            for (uint32_t j = item_off[i]; j < item_off[i + 1]; j++) all &= pair_ok[j];
-            keep_out[i] = all;
-        }
+        if (!count) {
+            for (size_t it = 0; it < k_items; it++) keep_out[it] = item_off[it] == item_off[it + 1];
+        } else if (k_items < 512 || (few && k_items < 8192) || !pool(k_items >= 2048)) test(0, k_items);  // (a cache-resident tag probe is ~2 ns per pair)
+        else pool()->run(k_items, k_items >= 32768 ? 1024 : k_items >= 8192 ? 512 : k_items >= 2048 ? 128 : 64, workers, test);  // (its workers polled through the walk)
     }
     h->keep_route_calls.fetch_add(1, std::memory_order_relaxed);
+    if (kTrace) std::fprintf(stderr, "keep route: n %zu allowed %llu | walk %.1f us | walk + pass done at %.1f (chunks: %.1f us in all, first began at %.1f, last ended at %.1f) | tags at %.1f | end %.1f\n", n, (unsigned long long)count, us_walk, us_a, tr_sum.load() / 1e3, tr_first.load() / 1e3, tr_last.load() / 1e3, us_fill, us_since(t_0));
     return ACL_OK;
 }
 
 template <class Items>
 static int check_bulk_keep_strings(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out, const char *who) {
+    int rc = keep_by_reverse_walk(h, its, n, item_off, k_items, keep_out);  // (checks the offsets it uses as it goes, in parallel; anything irregular comes back here)
+    if (rc != kRouteNotTaken) return rc;
     for (size_t i = 0; i < k_items; i++)
         if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, std::string(who) + ": item_off must ascend and end within n");
-    int rc = keep_by_reverse_walk(h, its, n, item_off, k_items, keep_out);
-    if (rc != kRouteNotTaken) return rc;
     std::vector<uint8_t> perm(std::max<size_t>(n, 1));
     std::vector<int32_t> err(std::max<size_t>(n, 1));
     rc = check_bulk_strings(h, its, n, perm.data(), err.data());
@@ -2108,6 +2241,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
         so->per_item_validation = (cfg->flags & ACL_FLAG_PER_ITEM_VALIDATION) != 0;
         so->lenient_lookup = (cfg->flags & ACL_FLAG_LENIENT_LOOKUP) != 0;
         if (const char *ev = getenv("ACL_RAW_INTERN")) so->raw_intern = atoi(ev) != 0;  // (test knob, see below)
+        if (const char *ev = getenv("ACL_INTERN_THREADS")) so->intern_threads = (unsigned)std::min(64, std::max(2, atoi(ev)));  // (A/B knob, see below)
         batcher_create(so);
         *out = so;
         return ACL_OK;

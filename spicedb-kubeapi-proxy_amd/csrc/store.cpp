@@ -8,6 +8,9 @@
 #include <chrono>
 #include <climits>
 #include <cstring>
+#include <cstdlib>
+#include <new>
+#include <sys/mman.h>
 
 #include "../../include/aclgpu.h"
 
@@ -39,8 +42,34 @@ uint64_t ObjectTable::hash(std::string_view s) {
     }
     return mulfold(h, 0x589965CC75374CC3ull) ^ h;
 }
+void *slot_pages_alloc(size_t bytes) {
+    constexpr size_t kHuge = (size_t)2 << 20;
+    if (bytes < kHuge) {
+        void *p = nullptr;
+        if (posix_memalign(&p, 64, bytes) != 0) throw std::bad_alloc();
+        return p;
+    }
+    const size_t len = (bytes + kHuge - 1) & ~(kHuge - 1);
+    // (over-map by one huge page and trim both ends: mmap only promises 4 KiB alignment)
+    char *raw = static_cast<char *>(mmap(nullptr, len + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (raw == MAP_FAILED) throw std::bad_alloc();
+    char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(raw) + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+    if (p != raw) munmap(raw, (size_t)(p - raw));
+    if (p + len != raw + len + kHuge) munmap(p + len, (size_t)(raw + len + kHuge - (p + len)));
+    static const bool kAsk = [] {
+        const char *e = getenv("ACL_SLOT_HUGE_PAGES");  // (A/B knob: 0 leaves the table on 4 KiB pages)
+        return !(e && atoi(e) == 0);
+    }();
+    if (kAsk) (void)madvise(p, len, MADV_HUGEPAGE);  // (advice only: refused on kernels without THP)
+    return p;
+}
+void slot_pages_free(void *p, size_t bytes) {
+    constexpr size_t kHuge = (size_t)2 << 20;
+    if (bytes < kHuge) std::free(p);
+    else munmap(p, (bytes + kHuge - 1) & ~(kHuge - 1));
+}
 void ObjectTable::grow() {
-    std::vector<Slot> old;
+    std::vector<Slot, SlotPages<Slot>> old;
     old.swap(slots_);
     // (doubling while small; a quarter more, rounded to whole 4 KiB pages of slots, from kBigTable slots on -- see store.hpp)
     const size_t cap = old.empty() ? 64 : (old.size() * 2 <= kBigTable ? old.size() * 2 : ((old.size() + old.size() / 4 + 63) / 64) * 64);
@@ -120,7 +149,7 @@ void ObjectTable::rename(uint32_t id, std::string_view new_name) {
     }
     stored.assign(new_name.data(), new_name.size());
     if (tombs_ * 4 > slots_.size()) {  // tombstones lengthen every probe: re-hash in place
-        std::vector<Slot> old;
+        std::vector<Slot, SlotPages<Slot>> old;
         old.swap(slots_);
         slots_.assign(old.size(), Slot{0, 0xFFFFFFFFu, 0, {}, nullptr});
         used_ -= tombs_;

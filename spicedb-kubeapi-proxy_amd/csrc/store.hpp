@@ -57,6 +57,25 @@ struct FilterText {  // authzed.api.v1.RelationshipFilter (+ precondition op)
     std::string rid, rel, stype, sid, srel;  // srel: "" means "only relationships without subject relation"
 };
 
+// Storage of the name tables' slots: from 2 MiB on, 2 MiB-aligned anonymous memory that asks for transparent huge pages.  A probe lands on a random 64-byte
+// line of a table of tens of MB; on 4 KiB pages nearly every one also misses the TLB, and the page walk's own misses come BEFORE the line's (software
+// prefetches included).  Where the kernel will not give huge pages (THP "never") this is plain page-aligned memory.
+void *slot_pages_alloc(size_t bytes);
+void slot_pages_free(void *p, size_t bytes);
+template <class T>
+struct SlotPages {
+    using value_type = T;
+    SlotPages() = default;
+    template <class U>
+    SlotPages(const SlotPages<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(slot_pages_alloc(n * sizeof(T))); }
+    void deallocate(T *p, size_t n) { slot_pages_free(p, n * sizeof(T)); }
+    template <class U>
+    bool operator==(const SlotPages<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const SlotPages<U> &) const { return false; }
+};
+
 // Dense local ids of one object type.  string -> id is an open-addressing table of (32-bit hash tag, id) pairs over
 // names kept in stable storage: a lookup hashes the caller's bytes in place (no std::string is built) -- this is the
 // per-item cost of the string entry points (acl_check_bulk: reference pkg/authz/check.go:23-39 builds 5 strings per
@@ -140,7 +159,7 @@ class ObjectTable {
     }
     std::deque<std::string> names_;      // stable addresses (acl_object_name hands out c_str())
     std::vector<uint32_t> name_of_;      // id -> index in names_ (0xFFFFFFFF anonymous); covers ids < name_of_.size()
-    std::vector<Slot> slots_;            // load <= 0.5 (small tables, doubling) / <= 0.68 (from kBigTable slots on, growing by a quarter); < 2^32 slots
+    std::vector<Slot, SlotPages<Slot>> slots_;  // load <= 0.5 (small tables, doubling) / <= 0.68 (from kBigTable slots on, growing by a quarter); < 2^32 slots
     size_t used_ = 0, tombs_ = 0;  // occupied slots incl. tombstones; tombstones among them
     std::atomic<uint32_t> count_{0};
 };

@@ -18,10 +18,13 @@
 // itself got past.  For every schema the real engine accepts the two readings coincide.
 #pragma once
 #include <string_view>
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 namespace acl {
 
-inline bool valid_object_id(std::string_view s) {
+inline bool valid_object_id_bytewise(std::string_view s) {  // (the definition; what the vector form below is checked against, tests/test_store_cpu.py)
     static const struct Table {
         bool ok[256] = {};
         Table() {
@@ -36,6 +39,45 @@ inline bool valid_object_id(std::string_view s) {
         if (!t.ok[c]) return false;
     return true;
 }
+
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+// 16 bytes per step: a PostFilter call validates one resource id per pair, and a byte-at-a-time table walk was half of what its host pass cost per pair
+// (13 of 25 ns on a 15-byte `namespace/name`).  Every load lies inside the string: ids of 16 bytes and more end with an overlapping block, shorter ones are
+// assembled from two overlapping 8- or 4-byte loads.  Bytes >= 0x80 are negative in the signed compares and fall out of every range.
+inline bool object_id_bytes_ok(__m128i c) {
+    const __m128i lower = _mm_or_si128(c, _mm_set1_epi8(0x20));  // A-Z -> a-z; nothing else lands in a-z
+    const __m128i alpha = _mm_and_si128(_mm_cmpgt_epi8(lower, _mm_set1_epi8('a' - 1)), _mm_cmplt_epi8(lower, _mm_set1_epi8('z' + 1)));
+    const __m128i digit = _mm_and_si128(_mm_cmpgt_epi8(c, _mm_set1_epi8('/' - 1)), _mm_cmplt_epi8(c, _mm_set1_epi8('9' + 1)));  // '/' is '0' - 1
+    const __m128i punct = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(c, _mm_set1_epi8('_')), _mm_cmpeq_epi8(c, _mm_set1_epi8('|'))),
+                                       _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(c, _mm_set1_epi8('-')), _mm_cmpeq_epi8(c, _mm_set1_epi8('='))), _mm_cmpeq_epi8(c, _mm_set1_epi8('+'))));
+    return _mm_movemask_epi8(_mm_or_si128(_mm_or_si128(alpha, digit), punct)) == 0xFFFF;
+}
+inline bool valid_object_id(std::string_view s) {
+    const size_t n = s.size();
+    const char *p = s.data();
+    if (n == 0 || n > 1024) return false;
+    if (n >= 16) {
+        for (size_t i = 0; i + 16 <= n; i += 16)
+            if (!object_id_bytes_ok(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i)))) return false;
+        return (n & 15u) == 0 || object_id_bytes_ok(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + n - 16)));
+    }
+    if (n >= 8) {
+        long long a, b;
+        __builtin_memcpy(&a, p, 8);
+        __builtin_memcpy(&b, p + n - 8, 8);
+        return object_id_bytes_ok(_mm_set_epi64x(b, a));
+    }
+    if (n >= 4) {
+        int a, b;
+        __builtin_memcpy(&a, p, 4);
+        __builtin_memcpy(&b, p + n - 4, 4);
+        return object_id_bytes_ok(_mm_set_epi32(b, a, b, a));
+    }
+    return valid_object_id_bytewise(s);
+}
+#else
+inline bool valid_object_id(std::string_view s) { return valid_object_id_bytewise(s); }
+#endif
 
 inline bool valid_name_segment(std::string_view s, size_t max_len) {  // [a-z][a-z0-9_]{1,max_len-2}[a-z0-9]
     if (s.size() < 3 || s.size() > max_len) return false;

@@ -281,6 +281,30 @@ def test_object_names_of_every_length_round_trip(aclgpu_lib):
     assert [e.object_name("user", i) for i in ids[:21]] == names[:21]
 
 
+def test_object_id_pattern_byte_by_byte(aclgpu_lib):
+    """validate.hpp checks an object id 16 bytes per step (two overlapping 8- or 4-byte loads below 16 bytes, an overlapping last block above): every byte
+    value 1..255 at the first, middle and last position of ids of every length 1..40 -- each block shape, each lane -- must be judged as the API's pattern
+    `^[a-zA-Z0-9/_|\\-=+]{1,}$` judges it (UNVERIFIED restatement, validate.hpp header).  NUL cannot be passed through a C string and ends the id."""
+    import ctypes
+    import re
+    import aclgpu
+    e = aclgpu.Engine("definition user {}", store_only=True)
+    pat = re.compile(rb"[a-zA-Z0-9/_|\-=+]+")
+    tid, out = e.type_id("user"), ctypes.c_uint32()
+    wrong = []
+    for n in range(1, 41):
+        for pos in sorted({0, n // 2, n - 1, min(n - 1, 7), min(n - 1, 8), min(n - 1, 15), min(n - 1, 16)}):
+            for c in range(1, 256):
+                b = bytearray(b"q" * n)
+                b[pos] = c
+                rc = e._L.acl_intern(e._h, tid, bytes(b), ctypes.byref(out))
+                want = pat.fullmatch(bytes(b)) is not None
+                if (rc == 0) != want or (rc != 0 and rc != aclgpu.ERR_INVALID_ARGUMENT):
+                    wrong.append((n, pos, c, rc))
+    assert not wrong, wrong[:10]
+    e.close()
+
+
 def test_bootstrap_yaml_files(aclgpu_lib):
     """acl_load_bootstrap_yaml: the YAML form the reference boots from (the embedded pkg/spicedb/bootstrap.yaml:1-40, a path in the endpoint
     URL options.go:313-316, a byte map spicedb.go:19-21).  The reference's own default file, re-indented and re-chomped, comments, several

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""usage (GPU box): [ACL_DEBUG_KEEP=1] python tools/keep_route_probe.py [--calls 40] -- PostFilter's shape on C4's named graph (K list items x one template for ONE
+user): acl_check_bulk_keep_v through the reverse-walk route and, with ACL_KEEP_ROUTE_MIN=0 in a child, the forward path; one line per (K, user).  The masks are
+compared with the id path's answers.  ACL_DEBUG_KEEP=1 prints the route's phase times per call on stderr."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "spicedb-kubeapi-proxy_amd"), os.path.join(ROOT, "tests")]
+import aclgpu  # noqa: E402
+import bench  # noqa: E402
+from aclgpu import workloads  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--calls", type=int, default=40)
+ap.add_argument("--sizes", default="1024,16384,65536")
+a = ap.parse_args()
+w = workloads.c4()
+eng = aclgpu.Engine(w.schema, contexts=3, eager_contexts=True)
+bench.name_objects(eng, w)
+w.load(eng)
+eng.snapshot()
+rt, perm_name, st = w.check
+names = w.names
+grants = sorted({int(x) for x in w.res[:65536:2731]})[:24]
+eng.write([(aclgpu.OP_TOUCH, (rt, names[rt][g], "viewer", st, "user-sparse", "")) for g in grants])
+out = {}
+for m in [int(x) for x in a.sizes.split(",")]:
+    for who, u in (("batch_user", int(w.subj[0])), ("other_user", int(w.subj[m // 2])), ("sparse_user", None)):
+        uname = "user-sparse" if u is None else names[st][u]
+        qk = [(rt, names[rt][int(r)], perm_name, st, uname, "") for r in w.res[:m]]
+        off = np.arange(m + 1, dtype=np.uint32)
+        if u is None:
+            want = np.isin(w.res[:m], np.asarray(grants, dtype=w.res.dtype))
+        else:
+            tp, te = eng.check_bulk_ids(eng.make_items(rt, perm_name, w.res[:m], st, "", np.full(m, u, dtype=np.uint32)))
+            want = (tp == 2) & (te == 0)
+        row = {"kept": int(want.sum())}
+        for form, call, prep in (("keep_v", eng.check_bulk_keep_views, eng.make_check_views(qk)), ("keep_packed", eng.check_bulk_keep_packed, eng.make_check_packed(qk))):
+            before = eng.stats()["keep_route_calls"]
+            ok = bool(np.array_equal(call(prep, off).astype(bool), want))
+            ts = []
+            for _ in range(a.calls):
+                t1 = time.perf_counter()
+                call(prep, off)
+                ts.append(time.perf_counter() - t1)
+            row[form] = {"M_items_per_s": round(m / float(np.mean(ts)) / 1e6, 1), "p50_ms": round(1e3 * float(np.median(ts)), 4), "best_ms": round(1e3 * min(ts), 4),
+                         "mask_ok": ok, "by_reverse_walk": int(eng.stats()["keep_route_calls"] - before)}
+        out[f"{m}/{who}"] = row
+        print(m, who, json.dumps(row), flush=True)
+eng.close()
