@@ -918,7 +918,7 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         sp = {"note": "acl_check_bulk_v / acl_check_bulk on named objects (every pod and user of the graph has a name; tables of "
                       f"{len(names[rt])} + {len(names[st])} names); answers compared with the id path's", "sizes": {}}
         ok_all = True
-        for m in (1024, 16384, 65536):
+        for m in (65536, 16384, 1024):  # (largest first: the pool's threads exist from the first call of 4 096 items on, as in a proxy that has served one list)
             m = min(m, n)
             qs = [(rt, names[rt][int(r_)], perm_name, st, names[st][int(s_)], "") for r_, s_ in zip(w.res[:m], w.subj[:m])]
             pv, pc, pp = eng.make_check_views(qs), eng.make_check_strings_named(qs), eng.make_check_packed(qs)
@@ -934,6 +934,16 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
                     ts.append(time.perf_counter() - t1)
                 row[form] = {"decisions_per_s": m / float(np.mean(ts)), "ms_per_batch": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "best_ms": 1e3 * min(ts),
                              "calls": len(ts), "answers_equal_id_path": ok}  # (the rate is the MEAN over the calls, stragglers included)
+                if form == "views":
+                    # ... and 2 ms apart: the interning pool's workers poll for 150 us after a batch and are asleep by then -- what a call finds when the proxy is
+                    # not busy (the back-to-back figure above is what it finds when it is)
+                    ts = []
+                    for _ in range(20):
+                        time.sleep(0.002)
+                        t1 = time.perf_counter()
+                        call(prep)
+                        ts.append(time.perf_counter() - t1)
+                    row["views_2ms_apart"] = {"decisions_per_s": m / float(np.mean(ts)), "ms_per_batch": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "calls": len(ts)}
             sp["sizes"][str(m)] = row
         # PostFilter's own shape (postfilter.go:67-119: K list items, ONE subject for every pair): acl_check_bulk_keep_v / _packed answer it by one reverse walk
         # from the subject + K bit tests (engine.cpp keep_by_reverse_walk); the keep mask is compared with the id path's answers for the same pairs
@@ -982,7 +992,9 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
         big = sp["sizes"][str(min(65536, n))]
         sp.update({"decisions_per_s": big["views"]["decisions_per_s"], "ms_per_batch": big["views"]["ms_per_batch"], "items": min(65536, n), "answers_equal_id_path": ok_all,
                    "keep_route_items_per_s": {who_: e_["keep_v"]["items_per_s"] for who_, e_ in kr["sizes"][str(min(65536, n))].items()},
-                   "packed_decisions_per_s": {k_: v_["packed"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()}})
+                   "packed_decisions_per_s": {k_: v_["packed"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()},
+                   "views_decisions_per_s": {k_: v_["views"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()},
+                   "views_2ms_apart_decisions_per_s": {k_: v_["views_2ms_apart"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()}})
         rec["string_path"] = sp
         if not ok_all:
             rec["string_path_mismatch"] = True

@@ -1070,22 +1070,12 @@ struct CStrItems {
         const char *p = ptr(i, f);
         return p ? std::strlen(p) : 0;
     }
-    static constexpr size_t kAhead = 16;  // (48 bytes per item; see ViewItems)
-    void prefetch(size_t i) const { __builtin_prefetch(&it[i]); }
 };
 struct ViewItems {
     const acl_check_item_v_t *it;
     static constexpr bool kHasLen = true;
     const char *ptr(size_t i, int f) const { return (&it[i].resource_type)[f].p; }
     size_t len(size_t i, int f) const { return (&it[i].resource_type)[f].p ? (&it[i].resource_type)[f].n : 0; }
-    // The caller's items were written by another core: a worker pulls its share (96 bytes per item) out of that core's cache or out of memory, and the hardware's
-    // stream prefetcher alone keeps too few lines in flight -- the pull, not the arithmetic, is what a pair's host pass costs (tools/host_pass_probe.cpp: 7 ns of
-    // work per pair on cached data against 25-30 ns in a call).  The loops over items ask for item i + kAhead before they work on item i.
-    static constexpr size_t kAhead = 12;
-    void prefetch(size_t i) const {
-        __builtin_prefetch(reinterpret_cast<const char *>(&it[i]));
-        __builtin_prefetch(reinterpret_cast<const char *>(&it[i]) + 64);
-    }
 };
 // ... and the PACKED form (acl_check_bulk_packed, round 6): a dictionary of the call's DISTINCT strings and six u32 indices per item.  A shim that walks a kube
 // list copies every string once anyway (shim/go/aclgpu/engine.go); written into one buffer, an item is 24 bytes instead of six views (96), the constant
@@ -1103,14 +1093,8 @@ struct PackedItems {
         const uint32_t k = idx(i, f);
         return k == ACL_PACKED_NONE ? 0 : rq->offsets[k + 1] - rq->offsets[k];
     }
-    static constexpr size_t kAhead = 32;
-    void prefetch(size_t i) const { __builtin_prefetch(&rq->items[6 * i]); }
 };
 enum { F_RT = 0, F_RID = 1, F_PM = 2, F_ST = 3, F_SID = 4, F_SR = 5 };
-static const bool kItemsAhead = [] {
-    const char *e = getenv("ACL_ITEMS_AHEAD");  // (A/B knob: 0 = the loops over items leave their streaming to the hardware prefetcher)
-    return !(e && atoi(e) == 0);
-}();
 // Which field of item i fails the API's validation, and why -- for acl_last_error() ("check failed" told an operator nothing; the
 // reference denies everything a failed CheckBulkPermissions asked, pkg/authz/check.go:48-52, so the message is all there is to diagnose a blanket denial).
 template <class Items>
@@ -1239,28 +1223,12 @@ struct InternPool {
 
     // most workers are still polling (a batch ended less than kSpinNs ago): a batch of a few hundred items is worth spreading, nobody has to be woken up
     bool awake() const { return (size_t)sleepers.load(std::memory_order_relaxed) * 2 < threads.size(); }
-    // Which piece goes to whom: participant p (the workers 0 .. limit - 1, the caller = limit) takes the pieces p, p + P, p + 2 P, ... first and only then whatever
-    // is left (a participant that shows up late loses its pieces to the others).  The SAME thread then writes the same part of the per-call arrays -- hashes,
-    // staged items, keep bytes -- in every pass of a call and call after call: their lines stay in its cache instead of being pulled, modified, out of
-    // another core's for every eighth item (ACL_POOL_AFFINITY=0: first come, first served -- the A/B).
-    std::unique_ptr<std::atomic<uint8_t>[]> taken;
-    size_t taken_cap = 0, npieces = 0;
-    bool affine = true;
-    void work(unsigned me) {
-        if (!affine) {
-            for (;;) {
-                const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
-                if (a >= n) return;
-                (*job)(a, std::min(n, a + chunk));
-            }
+    void work() {
+        for (;;) {
+            const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (a >= n) return;
+            (*job)(a, std::min(n, a + chunk));
         }
-        const size_t P = (size_t)limit + 1;
-        auto take = [&](size_t c) {
-            if (taken[c].load(std::memory_order_relaxed) || taken[c].exchange(1, std::memory_order_relaxed)) return;
-            (*job)(c * chunk, std::min(n, (c + 1) * chunk));
-        };
-        for (size_t c = me; c < npieces; c += P) take(c);
-        for (size_t k = 0, c = me; k < npieces; k++, c = c + 1 == npieces ? 0 : c + 1) take(c);
     }
     void loop(unsigned me) {
         uint64_t seen = 0;
@@ -1275,15 +1243,23 @@ struct InternPool {
                 }
             }
             if (!got) {
-                std::unique_lock<std::mutex> lk(mu);
-                sleepers.fetch_add(1);  // (before the predicate's first look at gen_a: run() bumps gen_a and then reads `sleepers`)
-                cv.wait(lk, [&] { return stop_a.load() || gen_a.load() != seen; });
-                sleepers.fetch_sub(1);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1);  // (before the predicate's first look at gen_a: run() bumps gen_a and then reads `sleepers`)
+                    cv.wait(lk, [&] { return stop_a.load() || gen_a.load() != seen; });
+                    sleepers.fetch_sub(1);
+                }
+                // the wake-ups fan out: run() wakes two sleepers, each of them two more -- 31 futex wake-ups in a row kept the CALLER from its own share of the
+                // batch for 40 us (round 6: "first piece began at 39 us" with every worker asleep)
+                if (!stop_a.load() && open.load() && sleepers.load() != 0) {
+                    cv.notify_one();
+                    cv.notify_one();
+                }
             }
             if (stop_a.load()) return;
             seen = gen_a.load(std::memory_order_acquire);
             inside.fetch_add(1);
-            if (open.load() && me < limit) work(me);
+            if (open.load() && me < limit) work();
             inside.fetch_sub(1);
         }
     }
@@ -1332,7 +1308,6 @@ struct InternPool {
     }
     explicit InternPool(unsigned nthreads) {
         for (unsigned i = 0; i < nthreads; i++) threads.emplace_back([this, i] { loop(i); });
-        if (const char *e = getenv("ACL_POOL_AFFINITY")) affine = atoi(e) != 0;
         const char *ev = getenv("ACL_INTERN_PIN");
         cpu_set_t set;
         if (!(ev && atoi(ev) == 0) && node_cpus(&set))
@@ -1355,24 +1330,17 @@ struct InternPool {
         chunk = chunk_items;
         limit = workers;
         next.store(0, std::memory_order_relaxed);
-        npieces = (total + chunk_items - 1) / chunk_items;
-        if (affine) {
-            if (taken_cap < npieces) {
-                taken_cap = std::max<size_t>(256, npieces * 2);
-                taken.reset(new std::atomic<uint8_t>[taken_cap]);
-            }
-            for (size_t c = 0; c < npieces; c++) taken[c].store(0, std::memory_order_relaxed);
-        }
         open.store(true);
         gen_a.fetch_add(1);
         if (sleepers.load() != 0) {
             {
                 std::lock_guard<std::mutex> lk(mu);
             }
-            cv.notify_all();
+            cv.notify_one();
+            cv.notify_one();
         }
         if (meanwhile) (*meanwhile)();
-        work(limit);
+        work();
         open.store(false);
         for (unsigned spins = 0; inside.load() != 0; spins++) {  // (workers still in their last chunk)
             if (spins < 4096) __builtin_ia32_pause();
@@ -1431,7 +1399,25 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
     // bytes).  Items go in groups of kGroup through three stages: hash + prefetch the slots; walk to the tag match + prefetch the names;
     // compare.  The misses of a group are in flight together.
     constexpr size_t kGroup = 16;  // (32: no better on the GPU box's host; prefetching the NEXT group's id bytes ahead of their hashing: 0.33 against 0.32 ms per 65 536 items, not kept -- tools/intern_bench.py)
+    static const bool kPieces = getenv("ACL_DEBUG_INTERN_PIECES") != nullptr;
+    const int64_t tp0 = kPieces ? mono_ns() : 0;
+    std::atomic<int64_t> p_sum{0}, p_first{INT64_MAX}, p_last{0}, p_max{0};
+    std::atomic<int> p_threads{0};
     const std::function<void(size_t, size_t)> run = [&](size_t a, size_t b) {
+        struct PieceTrace {
+            int64_t t0, c0;
+            std::atomic<int64_t> *sum, *first, *last, *mx;
+            ~PieceTrace() {
+                if (!sum) return;
+                const int64_t now = mono_ns();
+                sum->fetch_add(now - c0);
+                for (int64_t v = first->load(); c0 - t0 < v && !first->compare_exchange_weak(v, c0 - t0);) {}
+                for (int64_t v = last->load(); now - t0 > v && !last->compare_exchange_weak(v, now - t0);) {}
+                for (int64_t v = mx->load(); now - c0 > v && !mx->compare_exchange_weak(v, now - c0);) {}
+            }
+        } pt{tp0, kPieces ? mono_ns() : 0, kPieces ? &p_sum : nullptr, &p_first, &p_last, &p_max};
+        static thread_local int64_t seen_call = 0;
+        if (kPieces && seen_call != tp0) { seen_call = tp0; p_threads.fetch_add(1); }
         NameMemo m;
         std::vector<std::pair<uint32_t, int32_t>> mybad;
         const int64_t touch_ms = ids_leave_the_call ? Store::steady_now_ms() : 0;  // (one clock read per chunk, not per id)
@@ -1456,7 +1442,6 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
             for (size_t i = g0; i < g1; i++) {
                 Pending &p = pend[i - g0];
                 int32_t err = 0;
-                if (kItemsAhead && i + Items::kAhead < n) its.prefetch(i + Items::kAhead);
                 const char *r = its.ptr(i, F_RID), *u = its.ptr(i, F_SID);
                 p.rid = r ? std::string_view(r, its.len(i, F_RID)) : std::string_view();
                 p.sid = u ? std::string_view(u, its.len(i, F_SID)) : std::string_view();
@@ -1557,6 +1542,7 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
     // threads per batch: 16 up to 32 767 items, 32 beyond (same-box A/B on a 256-thread host, profiles/r03_string_path_ab.txt: 65 536 named
     // items 135 -> 170 M decisions/s with 32; 16 384 items the same with either, 48 threads slower at both sizes)
     h->intern_pool->run(n, n >= 32768 ? 1024 : n >= 8192 ? 512 : n >= 2048 ? 128 : 64, (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1, run);
+    if (kPieces) std::fprintf(stderr, "intern pieces of %zu items: %d threads, %.1f us inside pieces in all (longest %.1f), first began at %.1f, last ended at %.1f, back at %.1f\n", n, p_threads.load(), p_sum.load() / 1e3, p_max.load() / 1e3, p_first.load() / 1e3, p_last.load() / 1e3, (mono_ns() - tp0) / 1e3);
 }
 
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
@@ -2029,7 +2015,6 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
                 for (size_t lo = item_off[g], hi = item_off[ge]; lo < hi; lo += kBlock) {
                     const size_t le = std::min(hi, lo + kBlock);
                     for (size_t i = lo; i < le; i++) {
-                        if (kItemsAhead && i + Items::kAhead < n) its.prefetch(i + Items::kAhead);
                         // (the usual case first: the shim points every pair's constant fields at the same strings / dictionary entries -- no bytes compared)
                         bool same = true, identical = false;
                         if constexpr (std::is_same_v<Items, PackedItems>) {
