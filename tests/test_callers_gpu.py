@@ -535,8 +535,9 @@ def test_cancellation_and_deadline(aclgpu):
 
 def test_every_call_shape_at_once_native_threads(aclgpu, tmp_path):
     """tools/engine_stress.cpp: three blocking callers with chip-filling batches (chained on the device), a submit/wait window, 64-item
-    batches, single checks (blocking and completion queue), LookupResources and a writer that forces snapshot patches -- all at once on one
-    engine, every answer compared with the same call made alone.  (Found the pipeline's look-ahead staging deadlocking against a queued
+    batches, single checks (blocking and completion queue), string batches through the interning pool (one caller back to back, one that finds the
+    pool asleep), PostFilter calls for one user (the reverse-walk route), LookupResources and a writer that forces snapshot patches -- all at
+    once on one engine, every answer compared with the same call made alone.  (Found the pipeline's look-ahead staging deadlocking against a queued
     writer: Eval::begin with try_only must not wait for the state lock.)"""
     import os
     import subprocess

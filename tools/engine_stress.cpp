@@ -1,6 +1,6 @@
 // engine_stress -- every concurrent call shape of the seam at once against ONE engine on a GPU, answers compared with the same calls made
 // alone: chip-filling batches from three blocking callers (the chained path), a submit/wait window, 64-item batches, single checks through
-// the micro-batcher (blocking and completion queue), LookupResources, and a writer whose relationships touch only pods no request names
+// the micro-batcher (blocking and completion queue), string batches, PostFilter calls for one user, LookupResources, and a writer whose relationships touch only pods no request names
 // (so every answer must stay what it was) but force snapshot patches and background compactions under the readers.
 //   g++ -O2 -std=c++17 tools/engine_stress.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -o tools/bin/engine_stress
 // (tools/tsan.sh also builds it instrumented, but ThreadSanitizer on a GPU box only reports the uninstrumented HIP / HSA runtimes' own
@@ -139,6 +139,59 @@ int main(int argc, char **argv) {
                 }
             }
         });
+    // string batches (acl_check_bulk_v: the interning pool under concurrent callers, its workers polling or asleep) and PostFilter calls for one user
+    // (acl_check_bulk_keep_v: one reverse walk + the pool's two passes, the names locked shared while the device walks) -- under the writer, who interns
+    // new users and patches the snapshot meanwhile.  Expected answers: the id path's, taken alone before the threads start.
+    struct Named { std::vector<std::string> rid, sid; std::vector<acl_check_item_v_t> v; std::vector<uint8_t> want; std::vector<uint32_t> off; };
+    auto named = [&](size_t n, unsigned seed, int one_user) {
+        Named N;
+        Job j = job(n, seed);
+        if (one_user >= 0) {
+            for (auto &it : j.items) it.subject_id = user_id[one_user];
+            std::vector<int32_t> err(n);
+            if (acl_check_bulk_ids(h, j.items.data(), n, j.want.data(), err.data())) exit(2);
+        }
+        N.want = j.want;
+        for (const auto &it : j.items) {
+            N.rid.emplace_back(acl_object_name(h, tp, it.resource_id));
+            N.sid.emplace_back(acl_object_name(h, tu, it.subject_id));
+        }
+        static const char kPod[] = "pod", kView[] = "view", kUser[] = "user";
+        for (size_t i = 0; i < n; i++)
+            N.v.push_back(acl_check_item_v_t{{kPod, 3}, {N.rid[i].data(), N.rid[i].size()}, {kView, 4}, {kUser, 4}, {one_user >= 0 ? N.sid[0].data() : N.sid[i].data(), N.sid[i].size()}, {nullptr, 0}});
+        for (size_t i = 0; i <= n; i++) N.off.push_back((uint32_t)i);
+        return N;
+    };
+    std::vector<Named> strs, keeps;
+    strs.push_back(named(8192, 41, -1));
+    strs.push_back(named(700, 42, -1));
+    keeps.push_back(named(4096, 51, 7));
+    keeps.push_back(named(1500, 52, 100));
+    for (size_t i = 0; i < strs.size(); i++)
+        th.emplace_back([&, i] {
+            const Named &N = strs[i];
+            std::vector<uint8_t> p(N.v.size());
+            std::vector<int32_t> e(N.v.size());
+            while (!stop.load()) {
+                if (acl_check_bulk_v(h, N.v.data(), N.v.size(), p.data(), e.data())) { bad++; break; }
+                if (memcmp(p.data(), N.want.data(), p.size()) != 0) bad++;
+                for (int32_t x : e) if (x) { bad++; break; }
+                calls++;
+                if (i) std::this_thread::sleep_for(std::chrono::microseconds(400));  // (this one finds the pool asleep)
+            }
+        });
+    for (size_t i = 0; i < keeps.size(); i++)
+        th.emplace_back([&, i] {
+            const Named &N = keeps[i];
+            std::vector<uint8_t> keep(N.v.size());
+            while (!stop.load()) {
+                if (acl_check_bulk_keep_v(h, N.v.data(), N.v.size(), N.off.data(), N.v.size(), keep.data())) { bad++; break; }
+                for (size_t k = 0; k < keep.size(); k++)
+                    if ((keep[k] != 0) != (N.want[k] == ACL_PERM_HAS_PERMISSION)) { bad++; break; }
+                calls++;
+                if (i) std::this_thread::sleep_for(std::chrono::microseconds(250));
+            }
+        });
     th.emplace_back([&] {  // LookupResources
         std::vector<uint32_t> bm(words);
         while (!stop.load()) {
@@ -171,8 +224,8 @@ int main(int argc, char **argv) {
     acl_batcher_stop(h);
     acl_stats_t st;
     acl_stats(h, &st);
-    printf("engine_stress: %.1f s, %ld calls checked, %ld wrong or failed; snapshot patches %llu, compactions %llu, single-launch passes %llu\n", SECONDS, calls.load(), bad.load(),
-           (unsigned long long)st.snapshot_patches, (unsigned long long)st.snapshot_compactions, (unsigned long long)st.local_passes);
+    printf("engine_stress: %.1f s, %ld calls checked, %ld wrong or failed; snapshot patches %llu, compactions %llu, single-launch passes %llu, PostFilter calls by reverse walk %llu\n", SECONDS, calls.load(), bad.load(),
+           (unsigned long long)st.snapshot_patches, (unsigned long long)st.snapshot_compactions, (unsigned long long)st.local_passes, (unsigned long long)st.keep_route_calls);
     acl_close(h);
-    return bad.load() ? 1 : 0;
+    return bad.load() || !st.keep_route_calls ? 1 : 0;
 }
