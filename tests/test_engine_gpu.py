@@ -359,7 +359,9 @@ definition pod { relation namespace: namespace
             assert e.check(*bad) == (0, aclgpu.ERR_INVALID_ARGUMENT), bad
             if all(bad[:5]):
                 assert o.check(*bad) == (0, aclgpu.ERR_INVALID_ARGUMENT), bad
-            for batch in ([bad], qs[:50] + [bad] + qs[50:100], qs[:5000] + [bad]):  # single-thread and pooled interning
+            # (single-thread and pooled interning; from 2 048 items on the batch goes to the device in parts while the rest is interned: the ill-formed item in the
+            #  last part, in the first)
+            for batch in ([bad], qs[:50] + [bad] + qs[50:100], qs[:5000] + [bad], qs[:1000] + [bad] + qs[1000:5000]):
                 with pytest.raises(aclgpu.AclError) as ei:
                     e.check_bulk(batch)
                 assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT, bad
