@@ -22,9 +22,12 @@
 //                  frontier region (LDS cursors, one barrier per level).  The default for every batch size.
 //   k_expand       one launch per level over a chunked global frontier (every wave owns one static 16 KiB chunk per level, further
 //                  chunks from one atomicAdd per 1024 entries): the sharded graph, and batches that outgrow the private regions.
-// k_rev_expand is the reverse walk (LookupResources); k_dedup merges duplicate entries of a level when a frontier explodes.
+// The reverse walk (LookupResources): k_rev_local, one block per lookup through every reverse level (result rows in LDS for types up to 1 M objects;
+// beyond that k_rev_terminal marks the deferred heavy rows chip-wide and k_rev_rows folds the byte marks into the caller's rows); k_rev_expand is its
+// level-loop form (sharded graph, overflows).  k_dedup merges duplicate entries of a level when a frontier explodes.
 //
-// Bound (profiles/r05_pmc_c4.md): instruction issue and dependent trips, not HBM -- no MFMA anywhere by design.
+// Bound (profiles/r06_pmc_c4.md, r06_ab_check_local.txt): the CHAIN of dependent trips a wave makes per pair of segments, not HBM and
+// (round 6's A/Bs) not instruction issue -- no MFMA anywhere by design.
 #include <algorithm>
 #include <cstdlib>
 
