@@ -1223,12 +1223,20 @@ struct InternPool {
 
     // most workers are still polling (a batch ended less than kSpinNs ago): a batch of a few hundred items is worth spreading, nobody has to be woken up
     bool awake() const { return (size_t)sleepers.load(std::memory_order_relaxed) * 2 < threads.size(); }
-    void work() {
-        for (;;) {
-            const size_t a = next.fetch_add(chunk, std::memory_order_relaxed);
-            if (a >= n) return;
-            (*job)(a, std::min(n, a + chunk));
-        }
+    // Which piece goes to whom: participant p (the workers 0 .. limit - 1, the caller = limit) takes the pieces p, p + P, p + 2 P, ... first and only then whatever
+    // is left (a participant that shows up late loses its pieces to the others).  Two batches over the same items -- the PostFilter route's pass and its test --
+    // then meet the same thread per piece: what the first wrote about an item (its hash, its id) is in the cache of the thread that reads it in the second,
+    // not a modified line in another core's (12-25 ns per item to pull over, against 1-2).
+    std::unique_ptr<std::atomic<uint8_t>[]> taken;
+    size_t taken_cap = 0, npieces = 0;
+    void work(unsigned me) {
+        const size_t P = (size_t)limit + 1;
+        auto take = [&](size_t c) {
+            if (taken[c].load(std::memory_order_relaxed) || taken[c].exchange(1, std::memory_order_relaxed)) return;
+            (*job)(c * chunk, std::min(n, (c + 1) * chunk));
+        };
+        for (size_t c = me; c < npieces; c += P) take(c);
+        for (size_t k = 0, c = me < npieces ? me : 0; k < npieces; k++, c = c + 1 == npieces ? 0 : c + 1) take(c);
     }
     void loop(unsigned me) {
         uint64_t seen = 0;
@@ -1259,7 +1267,7 @@ struct InternPool {
             if (stop_a.load()) return;
             seen = gen_a.load(std::memory_order_acquire);
             inside.fetch_add(1);
-            if (open.load() && me < limit) work();
+            if (open.load() && me < limit) work(me);
             inside.fetch_sub(1);
         }
     }
@@ -1330,6 +1338,12 @@ struct InternPool {
         chunk = chunk_items;
         limit = workers;
         next.store(0, std::memory_order_relaxed);
+        npieces = (total + chunk_items - 1) / chunk_items;
+        if (taken_cap < npieces) {
+            taken_cap = std::max<size_t>(256, npieces * 2);
+            taken.reset(new std::atomic<uint8_t>[taken_cap]);
+        }
+        for (size_t c = 0; c < npieces; c++) taken[c].store(0, std::memory_order_relaxed);
         open.store(true);
         gen_a.fetch_add(1);
         if (sleepers.load() != 0) {
@@ -1340,7 +1354,7 @@ struct InternPool {
             cv.notify_one();
         }
         if (meanwhile) (*meanwhile)();
-        work();
+        work(limit);
         open.store(false);
         for (unsigned spins = 0; inside.load() != 0; spins++) {  // (workers still in their last chunk)
             if (spins < 4096) __builtin_ia32_pause();
@@ -1951,10 +1965,25 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     const auto t_0 = std::chrono::steady_clock::now();
     auto us_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); };
     double us_walk = 0, us_a = 0, us_fill = 0;
-    std::atomic<uint64_t> tr_sum{0}, tr_first{~0ull}, tr_last{0};  // (pass chunks: ns inside them, when the first began, when the last ended)
+    std::atomic<uint64_t> tr_sum{0}, tr_first{~0ull}, tr_last{0}, tr_test{0};  // (pass chunks: ns inside them, when the first began, when the last ended)
     static thread_local std::vector<uint64_t> hv_buf;  // (per calling thread: 512 KB of fresh pages per 65 536-item call cost more than the pass itself)
     if (hv_buf.size() < n) hv_buf.resize(n);
     uint64_t *hv = hv_buf.data();
+    // ... and, while the device still walks (or once it is known that MANY objects are allowed: every name goes to the table then), the pass also RESOLVES the
+    // names it has just hashed -- one block of 64 behind the block whose slots it asks for, the names' bytes still in this thread's cache -- so that the test
+    // after the walk is a bit test per pair.  A walk that is back with FEW allowed objects stops that: the rest is tested through the tags, no table involved.
+    constexpr uint32_t kUnresolved = 0xFFFFFFFEu, kAbsent = 0xFFFFFFFFu;
+    static thread_local std::vector<uint32_t> idv_buf;
+    if (idv_buf.size() < n) idv_buf.resize(n);
+    uint32_t *idv = idv_buf.data();
+    std::atomic<bool> walk_done{false}, many_a{false}, resolved_any{false};
+    // (a user's reach does not change from one list request to the next: a subject last seen with FEW allowed objects is not resolved for while the device
+    //  walks -- a third of the pass's work, wasted, for the proxy's ordinary user; one never seen, or seen with MANY, is)
+    const uint64_t seen_key = (((uint64_t)sub * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)rt << 40) ^ ((uint64_t)pm << 24) ^ ((uint64_t)st << 8)) | 3ull;
+    std::atomic<uint64_t> &seen_slot = h->keep_seen[(seen_key >> 20) & 255u];
+    const uint64_t seen_was = seen_slot.load(std::memory_order_relaxed);
+    const bool guess_few = (seen_was | 3ull) == seen_key && (seen_was & 3ull) == 1ull;
+    static const bool kResolveInPass = !getenv("ACL_KEEP_RESOLVE") || atoi(getenv("ACL_KEEP_RESOLVE")) != 0;  // (A/B knob)
     std::vector<uint32_t> row;
     uint64_t count = 0;
     std::atomic<int> outcome{0};  // 0 fine; 1: not a uniform call after all / an item the forward path must judge -> not taken
@@ -1982,6 +2011,9 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
             const auto t_w = std::chrono::steady_clock::now();
             if (sub_known) walk_rc = lookup_batch(h, ev.c, rt, pm, st, -1, &sub, 1, row.data(), row.size(), &count);
             us_walk = us_since(t_w);
+            many_a.store(count != 0 && count > n / 2, std::memory_order_relaxed);
+            walk_done.store(true, std::memory_order_release);
+            if (sub_known && !walk_rc) seen_slot.store((seen_key & ~3ull) | (count > n / 2 ? 2ull : 1ull), std::memory_order_relaxed);
         };
         // (both passes go over ITEMS, each worker through its items' pairs [item_off[a], item_off[b]): the keep bytes are then written where they are computed)
         const std::function<void(size_t, size_t)> pass = [&](size_t a, size_t b) {
@@ -2003,6 +2035,21 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
             // instead of 50 on the box's EPYC, 30 of them on the store into the shared array between a pair's loads: rdtsc per stage, round 6.)
             constexpr size_t kBlock = 64;
             uint64_t loc[kBlock];
+            uint32_t rid_loc[kBlock];
+            size_t prev_lo = 0, prev_le = 0;  // the block whose slots were asked for last: resolved while the next block's are on their way
+            auto resolve_prev = [&] {
+                if (prev_le == prev_lo) return;
+                const bool back = walk_done.load(std::memory_order_acquire);
+                if (kResolveInPass && (back ? many_a.load(std::memory_order_relaxed) : !guess_few)) {
+                    if (!resolved_any.load(std::memory_order_relaxed)) resolved_any.store(true, std::memory_order_relaxed);
+                    for (size_t i = prev_lo; i < prev_le; i++) {
+                        uint32_t id;
+                        rid_loc[i - prev_lo] = tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hv[i], &id) ? id : kAbsent;
+                    }
+                    for (size_t i = prev_lo; i < prev_le; i++) idv[i] = rid_loc[i - prev_lo];
+                }
+                prev_lo = prev_le = 0;
+            };
             for (size_t g = a; g < b; g += kBlock) {
                 if (outcome.load(std::memory_order_relaxed)) return;
                 const size_t ge = std::min(b, g + kBlock);
@@ -2042,10 +2089,15 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
                     for (size_t i = lo; i < le; i++) loc[i - lo] = ObjectTable::hash_of(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)));
                     for (size_t i = lo; i < le; i++) {
                         hv[i] = loc[i - lo];
-                        tab.prefetch(loc[i - lo]);
+                        idv[i] = kUnresolved;
+                        tab.prefetch2(loc[i - lo]);
                     }
+                    resolve_prev();
+                    prev_lo = lo;
+                    prev_le = le;
                 }
             }
+            resolve_prev();  // (the chunk's last block: one exposed trip per 1 024 pairs)
         };
         // (the pool from 2 048 items on, from 512 when its workers are still polling after the previous call: intern_items)
         InternPool *const P = pool(k_items >= 2048);
@@ -2095,16 +2147,42 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
             if (anonymous.load()) return kRouteNotTaken;  // (anonymous ids -- bulk-loaded numeric graphs -- have no names to compare with: forward path)
         }
         us_fill = us_since(t_0);
-        // ---- the pairs' names against the row; an item is kept when every one of its pairs is (one without pairs too: postfilter.go:145-150)
+        // ---- the pairs against the row; an item is kept when every one of its pairs is (one without pairs too: postfilter.go:145-150).  A pair the pass has
+        // resolved is a bit test; one it has not goes through the tags (FEW) and, on a tag hit or with MANY allowed, to the name table -- blocks of 64 pairs, the
+        // outcomes into a local array first, then into the ids' place.
         const std::function<void(size_t, size_t)> test = [&](size_t a, size_t b) {
-            constexpr size_t kGroup = 16;
-            for (size_t g0 = a; g0 < b; g0 += kGroup) {
-                const size_t g1 = std::min(b, g0 + kGroup);
-                if (!few)
-                    for (size_t i = item_off[g0]; i < item_off[g1]; i++) tab.prefetch(hv[i]);
-                for (size_t it = g0; it < g1; it++) {
+            struct T2 {
+                std::chrono::steady_clock::time_point c0;
+                std::atomic<uint64_t> *sum;
+                ~T2() { if (sum) sum->fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c0).count()); }
+            } t2{std::chrono::steady_clock::now(), kTrace ? &tr_test : nullptr};
+            if (few && !resolved_any.load(std::memory_order_relaxed)) {  // (nothing was resolved: tags only, straight into the keep bytes)
+                for (size_t it = a; it < b; it++) {
                     uint8_t all = 1;
                     for (size_t i = item_off[it]; i < item_off[it + 1]; i++) {
+                        const uint64_t hh = hv[i];
+                        uint32_t tg = (uint32_t)(hh >> 32), id;
+                        tg += tg == 0u;
+                        bool maybe = false;
+                        for (uint32_t q = tg & tmask; tags[q] != 0u && !maybe; q = (q + 1) & tmask) maybe = tags[q] == tg;
+                        all &= (uint8_t)(maybe && tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hh, &id) && (size_t)(id >> 5) < row.size() &&
+                                         ((row[id >> 5] >> (id & 31u)) & 1u));
+                    }
+                    keep_out[it] = all;
+                }
+                return;
+            }
+            constexpr size_t kBlock = 64;
+            const size_t p_lo = item_off[a], p_hi = item_off[b];
+            uint8_t ok[kBlock];
+            for (size_t lo = p_lo; lo < p_hi; lo += kBlock) {
+                const size_t le = std::min(p_hi, lo + kBlock);
+                if (!few)
+                    for (size_t i = lo; i < le; i++)
+                        if (idv[i] == kUnresolved) tab.prefetch2(hv[i]);
+                for (size_t i = lo; i < le; i++) {
+                    uint32_t id = idv[i];
+                    if (id == kUnresolved) {
                         const uint64_t hh = hv[i];
                         bool maybe = !few;
                         if (few) {
@@ -2112,22 +2190,26 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
                             tg += tg == 0u;
                             for (uint32_t q = tg & tmask; tags[q] != 0u && !maybe; q = (q + 1) & tmask) maybe = tags[q] == tg;
                         }
-                        uint32_t id;
                         // (the name table has the last word: id, then the row's bit)
-                        all &= (uint8_t)(maybe && tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hh, &id) && (size_t)(id >> 5) < row.size() &&
-                                         ((row[id >> 5] >> (id & 31u)) & 1u));
+                        if (!maybe || !tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hh, &id)) id = kAbsent;
                     }
-                    keep_out[it] = all;
+                    ok[i - lo] = id != kAbsent && (size_t)(id >> 5) < row.size() && ((row[id >> 5] >> (id & 31u)) & 1u);
                 }
+                for (size_t i = lo; i < le; i++) idv[i] = ok[i - lo];
+            }
+            for (size_t it = a; it < b; it++) {
+                uint8_t all = 1;
+                for (size_t i = item_off[it]; i < item_off[it + 1]; i++) all &= (uint8_t)idv[i];
+                keep_out[it] = all;
             }
         };
         if (!count) {
             for (size_t it = 0; it < k_items; it++) keep_out[it] = item_off[it] == item_off[it + 1];
-        } else if (k_items < 512 || (few && k_items < 8192) || !pool(k_items >= 2048)) test(0, k_items);  // (a cache-resident tag probe is ~2 ns per pair)
+        } else if (k_items < 512 || !pool(k_items >= 2048)) test(0, k_items);
         else pool()->run(k_items, k_items >= 32768 ? 1024 : k_items >= 8192 ? 512 : k_items >= 2048 ? 128 : 64, workers, test);  // (its workers polled through the walk)
     }
     h->keep_route_calls.fetch_add(1, std::memory_order_relaxed);
-    if (kTrace) std::fprintf(stderr, "keep route: n %zu allowed %llu | walk %.1f us | walk + pass done at %.1f (chunks: %.1f us in all, first began at %.1f, last ended at %.1f) | tags at %.1f | end %.1f\n", n, (unsigned long long)count, us_walk, us_a, tr_sum.load() / 1e3, tr_first.load() / 1e3, tr_last.load() / 1e3, us_fill, us_since(t_0));
+    if (kTrace) std::fprintf(stderr, "keep route: n %zu allowed %llu | walk %.1f us | walk + pass done at %.1f (chunks: %.1f us in all, first began at %.1f, last ended at %.1f) | tags at %.1f | end %.1f (test chunks: %.1f us in all)\n", n, (unsigned long long)count, us_walk, us_a, tr_sum.load() / 1e3, tr_first.load() / 1e3, tr_last.load() / 1e3, us_fill, us_since(t_0), tr_test.load() / 1e3);
     return ACL_OK;
 }
 

@@ -90,6 +90,12 @@ class ObjectTable {
     void prefetch(uint64_t h) const {
         if (!slots_.empty()) __builtin_prefetch(&slots_[home(h)]);
     }
+    void prefetch2(uint64_t h) const {  // ... and the slot behind it: at a load of 0.68 a name that is in the table sits 1.1 slots from home on average
+        if (slots_.empty()) return;
+        const size_t i = home(h);
+        __builtin_prefetch(&slots_[i]);
+        __builtin_prefetch(&slots_[next(i)]);
+    }
     // second stage of a pipelined lookup: names longer than a slot holds (kInline bytes) live outside the slot -- walk to the first slot whose
     // tag matches (slot lines: prefetched by the first stage) and pull that name's line towards the core.  Short names (the usual case) need
     // no second stage: their bytes are in the slot's own cache line, a lookup is ONE miss.
