@@ -31,3 +31,7 @@ tail -6 $O/fuzz.txt | cut -c1-300
 g++ -O2 -std=c++17 tools/engine_stress.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -Wl,-rpath,$R/spicedb-kubeapi-proxy_amd/lib -o /tmp/engine_stress
 { echo "# tools/engine_stress 25 (every call shape of the seam at once -- string batches and PostFilter calls by reverse walk among them --, each answer compared with the same call made alone), one replica | ACL_DEVICES=0,0,0"; timeout 120 /tmp/engine_stress 25 2>&1 | tail -1; ACL_DEVICES=0,0,0 timeout 120 /tmp/engine_stress 25 2>&1 | tail -1; } > $O/engine_stress.txt 2>&1
 cat $O/engine_stress.txt
+python tools/keep_route_probe.py > $O/keep.txt 2>/dev/null
+ACL_DEBUG_KEEP=1 python tools/keep_route_probe.py --calls 10 --sizes 65536 2>&1 | grep "keep route" | awk "NR%4==0" > $O/keep_trace.txt
+python tools/string_cold_probe.py > $O/string_cold.txt 2>/dev/null
+cat $O/keep.txt | cut -c1-150; cat $O/string_cold.txt
