@@ -1919,10 +1919,10 @@ int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel,
 // template of every list item for the REQUESTING USER: K x F pairs that share their subject and, per template, type and permission.  K forward walks from K
 // resources ask the graph the same question LookupResources answers once: which objects of the type may this subject see.  So when all pairs of a call share
 // (resource type, permission, subject type, subject id) -- a plain subject, a permission whose value no `&` / `-` can change -- the engine runs the reverse
-// walk once and tests the K resource names against its row.  And it tests them the cheap way round: the row's few ALLOWED objects give a small set of
-// name-hash tags that stays in cache; a pair's resource name is hashed (no memory touched but its own bytes) and looked up THERE -- only a tag hit goes on
-// to the type's name table for the id and the bit.  A name the user may not see never pays the table's DRAM miss, which is what a string call costs
-// (56 ns per item and thread against ~15: tools/intern_bench.py).  Every deviation -- fields that differ, a userset subject, an item the API's validation
+// walk once and tests the K resource names against its row.  For a subject with FEW allowed objects it tests them the cheap way round: the row's allowed
+// objects give a small set of name-hash tags that stays in cache; a pair's resource name is hashed (no memory touched but its own bytes) and looked up THERE
+// -- only a tag hit goes on to the type's name table for the id and the bit, and a name the user may not see never pays the table's miss.  With MANY allowed
+// every name is resolved in the table -- by the host's pass over the pairs, while the device still walks.  Every deviation -- fields that differ, a userset subject, an item the API's validation
 // would refuse, a non-monotone permission, a sharded or store-only engine -- returns kRouteNotTaken BEFORE anything is written, and the caller takes the
 // forward path: keep mask and error behaviour are the forward path's by construction (an unknown or unreachable resource is NO_PERMISSION there, a depth
 // error is a pair error there: both drop the item, postfilter.go:162-172, as the missing bit does here).
@@ -1938,8 +1938,15 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     int rt, pm, st;
     uint32_t sub = 0;
     bool sub_known = false;
+    // (state_mu -- the evaluation's -- then names_mu: engine_internal.hpp's order.  The evaluation begins BEFORE the call's constants are resolved: no schema
+    //  reload can come between the ids taken here and the walk that uses them.  The names stay locked while the device walks: the pass resolves names then.)
+    Eval ev;
+    {
+        int rc = ev.begin(h, true, CallOpts());
+        if (rc) return rc;
+    }
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
     {   // the call's constants, from item 0
-        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
         if (!h->store.has_schema()) return kRouteNotTaken;
         NameMemo m;
         int32_t err = 0;
@@ -1959,8 +1966,8 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     const unsigned workers = (n >= 32768 ? h->intern_threads : std::min(16u, h->intern_threads)) - 1;
     // ---- the reverse walk (none for a subject no table knows: it has no relationships, and without a subject relation it is nobody's member) AND, while the
     // device walks, the host's pass over the pairs: constants compared with item 0 (by pointer, then by content), the resource name validated and hashed.
-    // The walk is a launch, ~30 us of kernel and the row's way back; the pass is ~10 ns per pair and thread and touches no table: they overlap entirely, the
-    // caller waiting for the device, the pool's workers on the pairs (the caller joins them when the row is back).
+    // The walk is a launch, 30-90 us of kernel and the row's way back; the pass is ~17 ns per pair and thread (30 when it resolves the names too): they
+    // overlap, the caller waiting for the device, the pool's workers on the pairs (the caller joins them when the row is back).
     static const bool kTrace = getenv("ACL_DEBUG_KEEP") != nullptr;  // (phase times of the route on stderr)
     const auto t_0 = std::chrono::steady_clock::now();
     auto us_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t).count(); };
@@ -1988,20 +1995,10 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     uint64_t count = 0;
     std::atomic<int> outcome{0};  // 0 fine; 1: not a uniform call after all / an item the forward path must judge -> not taken
     int walk_rc = ACL_OK;
-    Eval ev;
-    if (sub_known) {
-        int rc = ev.begin(h, true, CallOpts());
-        if (rc) return rc;
-    }
-    // (state_mu -- the evaluation's -- then names_mu: engine_internal.hpp's order.  The names stay locked while the device walks: the pass below already pulls
-    //  every pair's slot of the name table towards the cores, so that the test after the walk finds them in cache)
-    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
-    if (!h->store.has_schema() || rt >= (int)h->store.schema().defs.size()) return kRouteNotTaken;  // (reloaded in between)
     const ObjectTable &tab = h->store.objects(rt);
     {
         if (sub_known) {
             const Schema &sc = h->store.schema();
-            if (rt >= (int)sc.defs.size() || st >= (int)sc.defs.size() || pm >= (int)sc.defs[rt].members.size()) return kRouteNotTaken;  // (the schema was reloaded in between)
             const uint32_t target = (uint32_t)sc.slot(rt, pm);
             if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
             const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
