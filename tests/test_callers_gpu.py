@@ -104,6 +104,28 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
             assert np.array_equal(kv.astype(bool), want) and np.array_equal(kp.astype(bool), want) and np.array_equal(forward(items, off), want), uname
             if uid == int(w.lookup_subjects[0]):
                 assert 0.02 < want.mean() < 0.9  # (the power user sees a good part of the list, not all of it)
+        # a user whose reach CHANGES between calls: the engine remembers per subject whether the last walk allowed few or many objects (a hint for the host's
+        # pass: resolve names while the device walks, or not) -- the masks must be right with the hint stale in either direction
+        uname = names["user"][5]
+        pods = rng.integers(0, npod, size=K)
+        items = [("pod", names["pod"][int(p_)], "view", "user", uname, "") for p_ in pods]
+        off = np.arange(K + 1, dtype=np.uint32)
+        prep = e.make_check_views(items)
+        granted = sorted({int(p_) for p_ in pods})[:2400]
+        grants = [("pod", names["pod"][g_], "viewer", "user", uname, "") for g_ in granted]
+        kept = []
+        for phase in ("few", "few again", "many after the grants (hint: few)", "many again", "few after the deletes (hint: many)"):
+            if phase.startswith("many after"):
+                for b_ in range(0, len(grants), 1000):
+                    e.write([(aclgpu.OP_TOUCH, g_) for g_ in grants[b_:b_ + 1000]])
+            if phase.startswith("few after"):
+                for b_ in range(0, len(grants), 1000):
+                    e.write([(aclgpu.OP_DELETE, g_) for g_ in grants[b_:b_ + 1000]])
+            before = e.stats()["keep_route_calls"]
+            kv = e.check_bulk_keep_views(prep, off).astype(bool)
+            assert e.stats()["keep_route_calls"] == before + 1 and np.array_equal(kv, forward(items, off)), phase
+            kept.append(int(kv.sum()))
+        assert kept[0] == kept[1] < K // 2 < kept[2] == kept[3] and 0 < kept[4] <= kept[0], kept  # (the deletes also take the viewer grants the user had before)
         # ragged pair ranges (0..3 pairs per list item, all for one user and permission: an item without pairs is kept, postfilter.go:145-150)
         uname = names["user"][int(w.lookup_subjects[1])]
         nper = rng.integers(0, 4, size=1500)
