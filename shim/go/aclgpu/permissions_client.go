@@ -300,20 +300,28 @@ func (p *permissionsClient) ImportBulkRelationships(context.Context, ...grpc.Cal
 
 // KeepMask is the fused form of filterItemsWithBulkPermissions (pkg/authz/postfilter.go:58-182) for callers patched to use
 // it: pairs = the resolved PostFilter checks of all list items, off[i]..off[i+1] = item i's pairs; true = keep the item.
+// The pairs go over PACKED (acl_check_bulk_keep_packed): the reference's PostFilter names ONE subject for all of them
+// (postfilter.go:88-119), which the engine recognises by dictionary index and answers with one reverse walk + bit tests
+// instead of K forward walks; any other call takes the forward path behind the same entry point, with the same mask.
 func (e *Engine) KeepMask(pairs []*v1.CheckBulkPermissionsRequestItem, off []uint32) ([]bool, error) {
 	k := len(off) - 1
 	if k <= 0 {
 		return nil, nil
 	}
-	var cs cstrings
-	defer cs.free()
-	items := make([]C.acl_check_item_t, len(pairs)+1)
-	for i, it := range pairs {
-		items[i] = cs.item(it.Resource, it.Permission, it.Subject)
-	}
 	keep := make([]C.uint8_t, k)
-	if rc := C.acl_check_bulk_keep(e.h, &items[0], C.size_t(len(pairs)), (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(k), &keep[0]); rc != 0 {
-		return nil, lastError(rc)
+	if len(pairs) > 0 {
+		pi := newPackedItems(len(pairs))
+		defer pi.free()
+		for i, it := range pairs {
+			pi.set(i, it.Resource, it.Permission, it.Subject)
+		}
+		if rc := C.acl_check_bulk_keep_packed(e.h, &pi.req, (*C.uint32_t)(unsafe.Pointer(&off[0])), C.size_t(k), &keep[0]); rc != 0 {
+			return nil, lastError(rc)
+		}
+	} else {
+		for i := range keep {
+			keep[i] = 1 // (an item without pairs is kept: postfilter.go:145-150)
+		}
 	}
 	out := make([]bool, k)
 	for i := range out {
