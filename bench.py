@@ -1004,6 +1004,51 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     return rec, gpu_perm, gpu_err
 
 
+def postfilter_c3_leg(local_rank):
+    """The reference's PostFilter as the UNPATCHED proxy sends it (pkg/authz/postfilter.go:67-134): one CheckBulkPermissions of K pairs that all name the requesting
+    user, on C3's graph -- a schema without recursion, as the reference's own bootstrap schema is, so that no Check of pod#view can end at the depth limit and the
+    engine may answer the call by ONE reverse walk + bit tests (engine.cpp keep_by_reverse_walk, pair form).  Per kind of user: acl_check_bulk_v of 65 536 named
+    pairs (mean of 30 back-to-back calls), the same pairs through names -> ids -> acl_check_bulk_ids (the forward walk; its id resolution is not timed), and
+    whether every permissionship and error of the two agree."""
+    import aclgpu
+    from aclgpu import workloads
+    w = workloads.c3(batch=65536)
+    eng = aclgpu.Engine(w.schema, device=local_rank, eager_contexts=True)
+    name_objects(eng, w)
+    w.load(eng)
+    eng.snapshot()
+    rt, perm_name, st = w.check
+    names = w.names
+    m = min(65536, len(w.res))
+    out = {"pairs": m, "note": "acl_check_bulk_v of one user's pairs (CheckBulkPermissions as filterItemsWithBulkPermissions sends it) on C3's named graph: by the reverse walk; "
+                               "forward = the same pairs by id through acl_check_bulk_ids", "users": {}}
+    ok_all = True
+    for who, u in (("power_user", int(w.lookup_subjects[0])), ("ordinary_user", 3)):
+        qk = [(rt, names[rt][int(r_)], perm_name, st, names[st][u], "") for r_ in w.res[:m]]
+        prep = eng.make_check_views(qk)
+        items16 = eng.make_items(rt, perm_name, w.res[:m], st, "", np.full(m, u, dtype=np.uint32))
+        fp, fe = eng.check_bulk_ids(items16)
+        before = eng.stats()["keep_route_calls"]
+        gp, ge = eng.check_bulk_views(prep)
+        same = bool(np.array_equal(gp, fp) and np.array_equal(ge, fe))
+        ok_all = ok_all and same
+        ts, tf = [], []
+        for _ in range(30):
+            t1 = time.perf_counter()
+            eng.check_bulk_views(prep)
+            ts.append(time.perf_counter() - t1)
+        for _ in range(30):
+            t1 = time.perf_counter()
+            eng.check_bulk_ids(items16)
+            tf.append(time.perf_counter() - t1)
+        out["users"][who] = {"allowed_among_the_pairs": int((fp == 2).sum()), "decisions_per_s": m / float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)),
+                             "calls_answered_by_the_reverse_walk": int(eng.stats()["keep_route_calls"] - before), "forward_by_id_decisions_per_s": m / float(np.mean(tf)),
+                             "forward_by_id_p50_ms": 1e3 * float(np.median(tf)), "answers_equal_forward": same}
+    out["answers_equal_forward"] = ok_all
+    eng.close()
+    return out
+
+
 def aclgpu_item_dtype():
     import aclgpu
     return aclgpu.ITEM_DTYPE
@@ -1737,6 +1782,8 @@ def main():
             e3.snapshot()
             cfgs["C3"] = filter_bench(args, w3, e3, max(args.steps, 20), args.warmup)
             e3.close()
+            if args.strings != "off":
+                cfgs["C3"]["postfilter_one_user"] = postfilter_c3_leg(local_rank)
         except Exception as ex:  # noqa: BLE001 -- the headline line is printed whatever happens here
             cfgs["error"] = f"{type(ex).__name__}: {ex}"
         # the 100 M-relationship replica: the honest HBM-regime point beside the cache-resident headline (its own time budget: ~1-2 minutes)

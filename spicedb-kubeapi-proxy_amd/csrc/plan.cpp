@@ -523,6 +523,49 @@ void build_forward(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             }
         }
     }
+    // which slots' Checks can reach the depth limit: the longest chain of dependencies below a slot (every userset subject, reference and arrow counted as a
+    // dispatch: an upper bound of what the walk counts), unbounded when the dependencies close a cycle
+    {
+        std::vector<std::vector<int>> deps(sc.nslots);
+        for (int slot = 0; slot < sc.nslots; slot++) {
+            auto [t, m] = sc.slot_owner[slot];
+            const Member &mem = sc.defs[t].members[m];
+            if (!mem.is_permission) {
+                for (const SubjectClass &c : mem.classes)
+                    if (c.srel != kNoRelation) deps[slot].push_back(sc.slot(c.stype, c.srel));
+            } else {
+                std::vector<const Node *> refs, arrows;
+                collect(mem.expr, Node::kRef, &refs);
+                collect(mem.expr, Node::kArrow, &arrows);
+                for (const Node *r : refs) {
+                    const int rm = sc.defs[t].find(r->a);
+                    if (rm >= 0) deps[slot].push_back(sc.slot(t, rm));
+                }
+                for (const Node *a : arrows) {
+                    const int am = sc.defs[t].find(a->a);
+                    if (am < 0) continue;
+                    deps[slot].push_back(sc.slot(t, am));
+                    for (const SubjectClass &c : sc.defs[t].members[am].classes) {
+                        const int tm = sc.defs[c.stype].find(a->b);
+                        if (tm >= 0) deps[slot].push_back(sc.slot(c.stype, tm));
+                    }
+                }
+            }
+        }
+        constexpr int kUnbounded = 1 << 20;
+        std::vector<int> depth(sc.nslots, -1);  // -1 not visited, -2 on the stack
+        std::function<int(int)> longest = [&](int v) -> int {
+            if (depth[v] == -2) return kUnbounded;
+            if (depth[v] >= 0) return depth[v];
+            depth[v] = -2;
+            int best = 0;
+            for (int d : deps[v]) best = std::max(best, std::min(kUnbounded, longest(d) + 1));
+            depth[v] = best;
+            return best;
+        };
+        s.slot_deep.assign(sc.nslots, 0);
+        for (int slot = 0; slot < sc.nslots; slot++) s.slot_deep[slot] = longest(slot) > 25 ? 1 : 0;
+    }
     // ---- leaf bits: a userset edge `... @ T:c#m` always expands into the state (slot(T, m), c); mark the edges whose
     // child state has nothing left to enumerate, so the expansion can skip both the child's row descriptors and the
     // frontier write (kernels.hip, eval_child)

@@ -172,6 +172,10 @@ struct Snapshot {
     std::vector<uint32_t> bexpr;  // boolean programs of the combine slots (word 0 unused: SlotProg::combine == 0 means none)
     bool has_combine = false;     // some slot's rewrite uses `&` / `-`: evaluations run the kernels' combine instantiations
     std::vector<uint8_t> slot_nonmono;  // [nslots] the slot's value can depend on a combine program: LookupResources = candidates + a forward Check
+    // [nslots] 1: a Check of this slot could run into the dispatch-depth limit -- its dependencies (userset subjects, references, arrows) reach a cycle
+    // (`group#member@group#member`) or a chain of more than 25 of them.  0: whatever the relationships are, no Check of it ends in a depth error, so
+    // "the reverse walk's bit is not set" and "NO_PERMISSION without an error" are the same statement (engine.cpp: CheckBulkPermissions by one reverse walk).
+    std::vector<uint8_t> slot_deep;
     // per type: first slot + member count (request validation on device)
     std::vector<uint32_t> type_slot_base, type_nmembers;
     std::vector<uint32_t> type_nobjects;

@@ -79,8 +79,13 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
                 e._check(e._L.acl_intern(e._h, tid, nm.encode(), ctypes.byref(out)))
         w.load(e)
 
+        def forward_pairs(items):  # names -> ids, then the id entry point: the forward walk whatever the pairs look like (a string call of one user's pairs
+            it16, rerr = e.resolve_bulk_views(e.make_check_views(items))  # takes the reverse walk itself on this schema: below)
+            assert not rerr.any()
+            return e.check_bulk_ids(it16)
+
         def forward(items, off):
-            p, er = e.check_bulk_views(e.make_check_views(items))
+            p, er = forward_pairs(items)
             return np.array([all(p[j] == 2 and er[j] == 0 for j in range(off[i], off[i + 1])) for i in range(len(off) - 1)])
 
         K = 3000
@@ -102,6 +107,14 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
             assert e.stats()["keep_route_calls"] == before + 2, uname  # both calls took the reverse walk
             routed += 2
             assert np.array_equal(kv.astype(bool), want) and np.array_equal(kp.astype(bool), want) and np.array_equal(forward(items, off), want), uname
+            # CheckBulkPermissions itself -- what the unpatched proxy sends for a list (postfilter.go:134) -- takes the walk too on this schema (no recursion: no
+            # Check of pod#view can end at the depth limit): every pair's permissionship AND error as the forward walk gives them, by all three string forms
+            fp, fe = forward_pairs(items)
+            before = e.stats()["keep_route_calls"]
+            for got in (e.check_bulk_views(e.make_check_views(items)), e.check_bulk_packed(e.make_check_packed(items)), e.check_bulk_prepared(e.make_check_strings_named(items))):
+                assert np.array_equal(got[0], fp) and np.array_equal(got[1], fe) and not fe.any(), uname
+            assert e.stats()["keep_route_calls"] == before + 3, uname
+            routed += 3
             if uid == int(w.lookup_subjects[0]):
                 assert 0.02 < want.mean() < 0.9  # (the power user sees a good part of the list, not all of it)
         # a user whose reach CHANGES between calls: the engine remembers per subject whether the last walk allowed few or many objects (a hint for the host's
@@ -163,7 +176,7 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
         with pytest.raises(aclgpu.AclError) as ei:
             e.check_bulk_packed((rq, keep_alive))
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT and "dictionary index" in str(ei.value)
-        assert routed == 6
+        assert routed == 15
 
 
 def test_postfilter_and_prefilter_mirror(aclgpu):
@@ -571,3 +584,30 @@ def test_every_call_shape_at_once_native_threads(aclgpu, tmp_path):
     pr = subprocess.run([str(exe), "2"], capture_output=True, text=True, timeout=120)
     assert pr.returncode == 0, (pr.stdout + pr.stderr)[-600:]
     assert " 0 wrong or failed" in pr.stdout, pr.stdout
+
+
+
+def test_check_bulk_of_one_subject_on_a_recursive_schema_stays_forward(aclgpu):
+    """CheckBulkPermissions by one reverse walk (engine.cpp keep_by_reverse_walk, pair form) is only for permissions whose Checks cannot end at the dispatch-depth
+    limit (Snapshot::slot_deep): the row's missing bit cannot tell NO_PERMISSION from "gave up".  Here `group#member` is recursive and two groups contain each
+    other: pods shared with them answer a depth ERROR for a user who is in neither -- per pair, as the oracle does -- so the string call must walk forward
+    (the counter stands still), while the keep call, which drops an item on either answer, still takes the reverse walk."""
+    schema = """definition user {}
+definition group { relation member: user | group#member }
+definition pod { relation viewer: user | group#member
+ permission view = viewer }"""
+    rels = ["group:g1#member@group:g2#member", "group:g2#member@group:g1#member", "group:g3#member@user:u1"]
+    rels += [f"pod:p{i}#viewer@group:g1#member" for i in range(0, 700, 3)] + [f"pod:p{i}#viewer@user:u1" for i in range(1, 700, 3)] + [f"pod:p{i}#viewer@group:g3#member" for i in range(2, 700, 3)]
+    o = orc.Oracle(schema)
+    o.write([(orc.OP_TOUCH, r) for r in rels])
+    items = [("pod", f"p{i}", "view", "user", "u1", "") for i in range(700)]
+    want = [o.check(*q) for q in items]
+    assert {w_[1] for w_ in want} == {0, aclgpu.ERR_DEPTH} and sum(w_[0] == 2 for w_ in want) > 400
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        before = e.stats()["keep_route_calls"]
+        for got in (e.check_bulk_views(e.make_check_views(items)), e.check_bulk_packed(e.make_check_packed(items))):
+            assert list(zip(got[0].tolist(), got[1].tolist())) == want
+        assert e.stats()["keep_route_calls"] == before
+        keep = e.check_bulk_keep_views(e.make_check_views(items), np.arange(701, dtype=np.uint32)).astype(bool)
+        assert e.stats()["keep_route_calls"] == before + 1 and keep.tolist() == [w_ == (2, 0) for w_ in want]
+

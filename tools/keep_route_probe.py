@@ -19,8 +19,10 @@ from aclgpu import workloads  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--calls", type=int, default=40)
 ap.add_argument("--sizes", default="1024,16384,65536")
+ap.add_argument("--workload", default="c4", choices=["c4", "c3"], help="c3: the 1 M-relationship cluster -> namespace -> pod graph with 64 power users -- a schema without recursion, "
+                "on which CheckBulkPermissions itself (acl_check_bulk_v of one user's pairs) takes the reverse walk too")
 a = ap.parse_args()
-w = workloads.c4()
+w = workloads.c4() if a.workload == "c4" else workloads.c3(batch=65536)
 eng = aclgpu.Engine(w.schema, contexts=3, eager_contexts=True)
 bench.name_objects(eng, w)
 w.load(eng)
@@ -31,7 +33,11 @@ grants = sorted({int(x) for x in w.res[:65536:2731]})[:24]
 eng.write([(aclgpu.OP_TOUCH, (rt, names[rt][g], "viewer", st, "user-sparse", "")) for g in grants])
 out = {}
 for m in [int(x) for x in a.sizes.split(",")]:
-    for who, u in (("batch_user", int(w.subj[0])), ("other_user", int(w.subj[m // 2])), ("sparse_user", None)):
+    m = min(m, len(w.res))
+    users = (("batch_user", int(w.subj[0])), ("other_user", int(w.subj[m // 2])), ("sparse_user", None))
+    if a.workload == "c3":
+        users = (("power_user", int(w.lookup_subjects[0])), ("ordinary_user", 3), ("sparse_user", None))
+    for who, u in users:
         uname = "user-sparse" if u is None else names[st][u]
         qk = [(rt, names[rt][int(r)], perm_name, st, uname, "") for r in w.res[:m]]
         off = np.arange(m + 1, dtype=np.uint32)
@@ -41,7 +47,11 @@ for m in [int(x) for x in a.sizes.split(",")]:
             tp, te = eng.check_bulk_ids(eng.make_items(rt, perm_name, w.res[:m], st, "", np.full(m, u, dtype=np.uint32)))
             want = (tp == 2) & (te == 0)
         row = {"kept": int(want.sum())}
-        for form, call, prep in (("keep_v", eng.check_bulk_keep_views, eng.make_check_views(qk)), ("keep_packed", eng.check_bulk_keep_packed, eng.make_check_packed(qk))):
+        def pairs_views(prep, _off):  # CheckBulkPermissions of the same pairs: a keep mask out of its permissionships and errors
+            p_, e_ = eng.check_bulk_views(prep)
+            return (p_ == 2) & (e_ == 0)
+        for form, call, prep in (("keep_v", eng.check_bulk_keep_views, eng.make_check_views(qk)), ("keep_packed", eng.check_bulk_keep_packed, eng.make_check_packed(qk)),
+                                 ("check_bulk_v", pairs_views, eng.make_check_views(qk))):
             before = eng.stats()["keep_route_calls"]
             ok = bool(np.array_equal(call(prep, off).astype(bool), want))
             ts = []
