@@ -165,6 +165,7 @@ int main(int argc, char **argv) {
     std::vector<Named> strs, keeps;
     strs.push_back(named(8192, 41, -1));
     strs.push_back(named(700, 42, -1));
+    strs.push_back(named(3000, 43, 9));  // (one user's pairs: on this schema -- no recursion -- the string call itself takes the reverse walk)
     keeps.push_back(named(4096, 51, 7));
     keeps.push_back(named(1500, 52, 100));
     for (size_t i = 0; i < strs.size(); i++)
