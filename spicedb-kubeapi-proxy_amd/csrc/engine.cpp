@@ -2304,6 +2304,10 @@ int check_bulk_keep_packed_call(acl_engine_t *h, const acl_packed_request_t *rq,
     if (k_items && (!item_off || !keep_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_packed: NULL buffer");
     return check_bulk_keep_strings(h, PackedItems{rq}, rq->n_items, item_off, k_items, keep_out, "acl_check_bulk_keep_packed");
 }
+int check_bulk_keep_cstr_call(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    if ((n && !items) || (k_items && (!item_off || !keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep: NULL buffer");
+    return check_bulk_keep_strings(h, CStrItems{items}, n, item_off, k_items, keep_out, "acl_check_bulk_keep");
+}
 int check_bulk_keep_v_call(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
     if ((n && !items) || (k_items && (!item_off || !keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep_v: NULL buffer");
     return check_bulk_keep_strings(h, ViewItems{items}, n, item_off, k_items, keep_out, "acl_check_bulk_keep_v");

@@ -491,19 +491,9 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
     return ACL_OK;
 }
 
+// (the NUL-terminated form of acl_check_bulk_keep_v: the one-subject reverse route, else the string path + the AND of postfilter.go:162-172)
 int acl_check_bulk_keep(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
-    if ((n && !items) || (k_items && (!item_off || !keep_out))) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep: NULL buffer");
-    std::vector<uint8_t> perm(std::max<size_t>(n, 1));
-    std::vector<int32_t> err(std::max<size_t>(n, 1));
-    int rc = acl_check_bulk(h, items, n, perm.data(), err.data());
-    if (rc) return rc;
-    for (size_t i = 0; i < k_items; i++) {
-        if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_check_bulk_keep: item_off must ascend and end within n");
-        bool all = true;  // pair error or anything but HAS_PERMISSION drops the item: postfilter.go:162-172
-        for (uint32_t j = item_off[i]; j < item_off[i + 1]; j++) all = all && !err[j] && perm[j] == ACL_PERM_HAS_PERMISSION;
-        keep_out[i] = all ? 1 : 0;
-    }
-    return ACL_OK;
+    return check_bulk_keep_cstr_call(h, items, n, item_off, k_items, keep_out);
 }
 
 // prefilterResult.IsAllowed (lookups.go:25-36) over a LookupResources bitmap instead of a set of NamespacedNames

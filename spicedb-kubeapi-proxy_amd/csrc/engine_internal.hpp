@@ -530,6 +530,7 @@ void intern_pool_destroy(acl_engine_t *h);
 bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n items is answered by the kernel across PCIe (no copies)
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);
+int check_bulk_keep_cstr_call(acl_engine_t *h, const acl_check_item_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);  // engine.cpp: acl_check_bulk_keep
 int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel, const uint32_t *sids, size_t n, uint32_t *bitmaps, size_t words,
                       uint64_t *counts, const CallOpts &opts);
 int lookup_one_routed(acl_engine_t *h, int rt, int pm, int st, int sr, uint32_t sub, uint32_t *bitmap_out, size_t words, uint64_t *count_out,

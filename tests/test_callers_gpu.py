@@ -104,9 +104,11 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
             before = e.stats()["keep_route_calls"]
             kv = e.check_bulk_keep_views(e.make_check_views(items), off)
             kp = e.check_bulk_keep_packed(e.make_check_packed(items), off)
-            assert e.stats()["keep_route_calls"] == before + 2, uname  # both calls took the reverse walk
-            routed += 2
-            assert np.array_equal(kv.astype(bool), want) and np.array_equal(kp.astype(bool), want) and np.array_equal(forward(items, off), want), uname
+            kc = e.check_bulk_keep(items, off)  # (the NUL-terminated form: the same route)
+            assert e.stats()["keep_route_calls"] == before + 3, uname  # all three calls took the reverse walk
+            routed += 3
+            assert np.array_equal(kv.astype(bool), want) and np.array_equal(kp.astype(bool), want) and np.array_equal(np.asarray(kc).astype(bool), want), uname
+            assert np.array_equal(forward(items, off), want), uname
             # CheckBulkPermissions itself -- what the unpatched proxy sends for a list (postfilter.go:134) -- takes the walk too on this schema (no recursion: no
             # Check of pod#view can end at the depth limit): every pair's permissionship AND error as the forward walk gives them, by all three string forms
             fp, fe = forward_pairs(items)
@@ -176,7 +178,7 @@ def test_postfilter_one_subject_reverse_route(aclgpu):
         with pytest.raises(aclgpu.AclError) as ei:
             e.check_bulk_packed((rq, keep_alive))
         assert ei.value.code == aclgpu.ERR_INVALID_ARGUMENT and "dictionary index" in str(ei.value)
-        assert routed == 15
+        assert routed == 18
 
 
 def test_postfilter_and_prefilter_mirror(aclgpu):
