@@ -364,9 +364,10 @@ struct acl_engine {
         for (auto &d : devs) d->rev_uploaded = v;
     }
     std::atomic<uint64_t> keep_route_calls{0};  // PostFilter calls answered by ONE reverse walk + bit tests (engine.cpp keep_by_reverse_walk)
-    // ... and what the last such call for a (type, permission, subject) found: 62 bits of the key's hash | 1 = FEW objects allowed, 2 = MANY (0: never seen).
+    // ... and what the last such call for a (type, permission, subject) found: 58 bits of the key's hash | 1 + the bit width of the allowed count (0: never seen).
     // A hint only -- it decides whether the host's pass resolves names while the device still walks -- and direct-mapped: a collision costs a wrong guess.
     std::atomic<uint64_t> keep_seen[256] = {};
+    std::atomic<uint32_t> keep_route_skips{0};  // short lists for far-reaching subjects that went forward instead (one in sixteen still walks)
     bool per_item_validation = false;  // ACL_FLAG_PER_ITEM_VALIDATION: ill-formed items of a bulk Check fail their own pair, not the call
     bool lenient_lookup = false;       // ACL_FLAG_LENIENT_LOOKUP: a LookupResources candidate whose forward Check errs is dropped instead of failing the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)
