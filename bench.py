@@ -980,18 +980,31 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
                         ts.append(time.perf_counter() - t1)
                     entry[form] = {"items_per_s": m / float(np.mean(ts)), "ms_per_call": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "mask_equals_id_path": okk}
                 entry["calls_answered_by_the_reverse_walk"] = int(eng.stats()["keep_route_calls"] - before)
+                # CheckBulkPermissions ITSELF of the same pairs (what filterItemsWithBulkPermissions sends, postfilter.go:134): the pair form of the same route --
+                # on a recursive permission (C4's nested groups) once a forward sweep has shown that no Check of it ends at the depth limit on this snapshot
+                # (engine.cpp no_object_is_deep: the first call at a snapshot goes forward, the second sweeps); permissionships AND errors compared with the id path's
+                before = eng.stats()["keep_route_calls"]
+                for _ in range(3):
+                    gp, ge = eng.check_bulk_views(kv_prep)
+                okp = bool(np.array_equal((gp == 2) & (ge == 0), want) and not ge.any())
+                ok_all = ok_all and okp
                 ts = []
-                for _ in range(20):  # the forward string path on the same pairs, for the ratio
+                for _ in range(40):
                     t1 = time.perf_counter()
                     eng.check_bulk_views(kv_prep)
                     ts.append(time.perf_counter() - t1)
-                entry["forward_views"] = {"items_per_s": m / float(np.mean(ts)), "ms_per_call": 1e3 * float(np.mean(ts))}
+                entry["pairs_views"] = {"decisions_per_s": m / float(np.mean(ts)), "ms_per_call": 1e3 * float(np.mean(ts)), "p50_ms": 1e3 * float(np.median(ts)), "pairs_equal_id_path": okp,
+                                        "calls_answered_by_the_reverse_walk": int(eng.stats()["keep_route_calls"] - before), "of_calls": 43}
+                # (the forward string path at this size: the same number of pairs with mixed subjects, measured above)
+                entry["forward_views"] = {"items_per_s": sp["sizes"][str(m)]["views"]["decisions_per_s"], "ms_per_call": sp["sizes"][str(m)]["views"]["ms_per_batch"]}
                 rowk[who] = entry
             kr["sizes"][str(m)] = rowk
         sp["keep_route"] = kr
         big = sp["sizes"][str(min(65536, n))]
         sp.update({"decisions_per_s": big["views"]["decisions_per_s"], "ms_per_batch": big["views"]["ms_per_batch"], "items": min(65536, n), "answers_equal_id_path": ok_all,
                    "keep_route_items_per_s": {who_: e_["keep_v"]["items_per_s"] for who_, e_ in kr["sizes"][str(min(65536, n))].items()},
+                   "one_user_pairs_decisions_per_s": {who_: e_["pairs_views"]["decisions_per_s"] for who_, e_ in kr["sizes"][str(min(65536, n))].items()},
+                   "depth_sweeps": int(eng.stats()["depth_sweeps"]),
                    "packed_decisions_per_s": {k_: v_["packed"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()},
                    "views_decisions_per_s": {k_: v_["views"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()},
                    "views_2ms_apart_decisions_per_s": {k_: v_["views_2ms_apart"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()}})

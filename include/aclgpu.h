@@ -290,7 +290,11 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * permission without `&` / `-` -- the call is answered by ONE reverse walk from that subject (the LookupResources kernel) and K bit tests: the pairs' resource
  * names are hashed and tested against the few ALLOWED names first, so a name the user may not see never touches the type's name table (the string path's
  * cost is that table: one DRAM miss per name).  Any other call -- subjects or permissions that differ, a userset subject, an item the API would refuse --
- * takes the forward path; the keep mask and the call's error are the same either way (tests/test_callers_gpu.py compares the two routes and the oracle). */
+ * takes the forward path; the keep mask and the call's error are the same either way (tests/test_callers_gpu.py compares the two routes and the oracle).
+ * acl_check_bulk / _v / _packed (CheckBulkPermissions itself, what the unpatched proxy's PostFilter sends) take the same walk for one subject's pairs where no Check
+ * of the permission can end at the dispatch-depth limit -- by the schema (no recursion), or, for a recursive permission, on the snapshot at hand: one forward
+ * sweep over the type's objects for a subject nobody is decides that for every subject (acl_stats_t.depth_sweeps; the first call at a snapshot goes forward,
+ * the second sweeps; ACL_DEPTH_SWEEP=0 in the environment switches the sweep off). */
 int acl_check_bulk_keep_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_packed(acl_engine_t *h, const acl_packed_request_t *req, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);
@@ -512,6 +516,7 @@ typedef struct {
     uint64_t lookup_requests;      /* LookupResources requests answered since open / last reset */
     uint64_t ids_recycled;         /* object ids given a new name after their object had lost its last relationship (since the schema was loaded) */
     uint64_t keep_route_calls;     /* acl_check_bulk_keep_v / _packed calls answered by ONE reverse walk and bit tests (since open) */
+    uint64_t depth_sweeps;         /* forward sweeps over a whole type that established "no Check of this permission ends at the depth limit" for the snapshot (since open) */
 } acl_stats_t;
 int acl_stats(acl_engine_t *h, acl_stats_t *out);
 int acl_stats_reset(acl_engine_t *h);

@@ -83,7 +83,7 @@ class Stats(C.Structure):
                 ("frontier_entries", C.c_uint64), ("kernel_ms", C.c_double), ("expand_ms", C.c_double), ("snapshot_edges", C.c_uint64),
                 ("snapshot_bytes", C.c_uint64), ("snapshot_builds", C.c_uint64), ("overflow_retries", C.c_uint64), ("snapshot_edges_local", C.c_uint64), ("snapshot_patches", C.c_uint64),
                 ("local_ms", C.c_double), ("local_passes", C.c_uint64), ("snapshot_compactions", C.c_uint64),
-                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64), ("keep_route_calls", C.c_uint64)]
+                ("rev_local_ms", C.c_double), ("rev_local_passes", C.c_uint64), ("lookup_requests", C.c_uint64), ("ids_recycled", C.c_uint64), ("keep_route_calls", C.c_uint64), ("depth_sweeps", C.c_uint64)]
 
 
 ALL_GATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

@@ -317,6 +317,7 @@ int ensure_snapshot(acl_engine *h) {
     if (h->store_only) return fail(ACL_ERR_UNAVAILABLE, "engine was opened store-only (no GPU): Check / LookupResources are unavailable");
     if (!h->store.has_schema()) return fail(ACL_ERR_FAILED_PRECONDITION, "no schema loaded");
     if (snapshot_current(h, false)) return ACL_OK;
+    h->snap_epoch++;  // (whatever happens below changes the snapshot or fails: what was learnt about the old one -- acl_engine::deep_known -- is not carried over)
     // (schemas with `&` / `-` on a sharded graph: the snapshot builds like any other; which entry points evaluate it is ShardCall::begin's business)
     const int64_t now = h->store.now();
     if (h->snap_valid && h->all_dev_valid() && compaction_adopt(h, now) && snapshot_current(h, false)) return ACL_OK;  // a background rebuild finished: swap it in
@@ -1937,12 +1938,68 @@ int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel,
 // would refuse, a non-monotone permission, a sharded or store-only engine -- returns kRouteNotTaken BEFORE anything is written, and the caller takes the
 // forward path: keep mask and error behaviour are the forward path's by construction (an unknown or unreachable resource is NO_PERMISSION there, a depth
 // error is a pair error there: both drop the item, postfilter.go:162-172, as the missing bit does here).
+// "No Check of (rt, pm) for a subject of type st ends at the dispatch-depth limit on this snapshot" -- what lets the PAIR form below answer a RECURSIVE permission
+// (nested groups: the schema alone allows a chain of any length) from the reverse walk's row.  A Check that does not find its subject explores every path below
+// its resource, whoever the subject is (the oracle's and the kernels' rule: HAS_PERMISSION wins, else a path beyond the limit is the pair's error, else NO; no
+// path's length depends on who is looked for), so the set of resources with a depth error is the set a subject NOBODY IS gets one for: one forward sweep over the
+// type's ids with the unknown-subject id (what intern_check_item gives a name no table holds), through the ordinary walk.  The outcome is remembered per snapshot
+// epoch (acl_engine::snap_epoch: any write starts a new one); the sweep costs a forward pass over the whole type (845 000 pods: ~1 ms), so it is only run for a
+// graph that holds still: the first call that needs it at an epoch goes forward and leaves a note, the next one at the SAME epoch sweeps.
+// true: none is deep; false: some object is, or it is not known (yet): the caller takes the forward path (a sweep that fails is "not known").  Caller holds
+// state_mu shared (an Eval) and owns context c.
+static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st, size_t n_pairs) {
+    static const bool kOff = getenv("ACL_DEPTH_SWEEP") && atoi(getenv("ACL_DEPTH_SWEEP")) == 0;  // (A/B and test knob)
+    if (kOff) return false;
+    const uint64_t epoch = h->snap_epoch;
+    const size_t count = h->store.objects(rt).count();
+    if (count > std::max<size_t>((size_t)1 << 20, 64 * n_pairs)) return false;  // (a sweep of more than ~1 ms for a call that is not itself that long: forward)
+    {
+        std::lock_guard<std::mutex> lk(h->deep_mu);
+        acl_engine::DeepKnown *k = nullptr;
+        for (auto &d : h->deep_known)
+            if (d.rt == rt && d.pm == pm && d.st == st) k = &d;
+        if (!k) {
+            if (h->deep_known.size() >= 64) h->deep_known.erase(h->deep_known.begin());
+            h->deep_known.push_back(acl_engine::DeepKnown{});
+            k = &h->deep_known.back();
+            k->rt = rt, k->pm = pm, k->st = st;
+        }
+        if (k->epoch == epoch) return k->none;
+        static const bool kEager = getenv("ACL_DEPTH_SWEEP") && atoi(getenv("ACL_DEPTH_SWEEP")) == 2;  // (tests: sweep at the first call)
+        if (k->wanted_epoch != epoch && !kEager) {
+            k->wanted_epoch = epoch;
+            return false;
+        }
+    }
+    // (two callers may sweep the same epoch side by side: same answer, stored twice)
+    const size_t chunk = std::min<size_t>(std::max<size_t>(h->max_sub_batch, 1), 262144);
+    std::vector<acl_item_t> items(std::min(chunk, std::max<size_t>(count, 1)));
+    std::vector<uint8_t> perm(items.size());
+    std::vector<int32_t> err(items.size());
+    bool none = true;
+    for (size_t b = 0; b < count && none; b += chunk) {
+        const size_t m = std::min(chunk, count - b);
+        for (size_t i = 0; i < m; i++) items[i] = acl_item_t{(uint16_t)rt, (uint16_t)pm, (uint32_t)(b + i), (uint16_t)st, (uint16_t)ACL_NO_RELATION, 0xFFFFFFFCu};
+        if (check_ids_host(h, c, items.data(), m, perm.data(), err.data())) return false;
+        for (size_t i = 0; i < m; i++) none &= err[i] == 0;  // (any error: a depth error; an invalid item cannot happen -- the ids are the call's resolved ones)
+    }
+    h->depth_sweeps.fetch_add(1, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lk(h->deep_mu);
+    for (auto &d : h->deep_known)
+        if (d.rt == rt && d.pm == pm && d.st == st) {
+            d.epoch = epoch;
+            d.none = none;
+        }
+    return none;
+}
+
 template <class Items>
 static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off_p, size_t k_items, uint8_t *keep_out, uint8_t *pair_perm, int32_t *pair_err,
                                 const CallOpts &opts) {
     // PAIR form (CheckBulkPermissions itself, keep_out == NULL): every pair is an "item" of its own and is answered HAS_PERMISSION / NO_PERMISSION without an
-    // error -- only for a permission whose Checks cannot end in a depth error whatever the relationships are (Snapshot::slot_deep), because the row's missing bit
-    // cannot tell "no" from "gave up at the depth limit", which the forward path reports per pair.
+    // error -- only where no Check of the permission can end in a depth error: whatever the relationships are (Snapshot::slot_deep says so of the schema), or, for a
+    // recursive permission, on THIS snapshot (no_object_is_deep) -- because the row's missing bit cannot tell "no" from "gave up at the depth limit", which the
+    // forward path reports per pair.
     struct PairRanges {
         const uint32_t *off;
         size_t operator[](size_t i) const { return off ? off[i] : i; }
@@ -2043,7 +2100,7 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     {
         const uint32_t target = (uint32_t)h->store.schema().slot(rt, pm);
         // (the pair form also for a subject no table knows: a walk through a cycle of groups ends at the depth limit whoever is looked for)
-        if (pair_form && (h->snap.slot_deep.size() <= target || h->snap.slot_deep[target])) return kRouteNotTaken;
+        if (pair_form && (h->snap.slot_deep.size() <= target || (h->snap.slot_deep[target] && !no_object_is_deep(h, ev.c, rt, pm, st, n)))) return kRouteNotTaken;
         if (sub_known) {
             if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
             const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
@@ -2785,6 +2842,7 @@ int acl_stats(acl_engine_t *h, acl_stats_t *out) {
     *out = h->stats;
     out->ids_recycled = recycled;
     out->keep_route_calls = h->keep_route_calls.load(std::memory_order_relaxed);
+    out->depth_sweeps = h->depth_sweeps.load(std::memory_order_relaxed);
     return ACL_OK;
 }
 int acl_stats_reset(acl_engine_t *h) {

@@ -368,6 +368,18 @@ struct acl_engine {
     // A hint only -- it decides whether the host's pass resolves names while the device still walks -- and direct-mapped: a collision costs a wrong guess.
     std::atomic<uint64_t> keep_seen[256] = {};
     std::atomic<uint32_t> keep_route_skips{0};  // short lists for far-reaching subjects that went forward instead (one in sixteen still walks)
+    // The pair form of that route on a RECURSIVE permission (Snapshot::slot_deep: the schema alone cannot rule a depth error out) needs to know that THE DATA rules it
+    // out: no object of the type whose Check runs into the dispatch-depth limit.  That is a property of the snapshot, not of the subject (engine.cpp
+    // no_object_is_deep): one forward sweep over the type's objects for a subject nobody is, remembered per (type, permission, subject type) and snapshot epoch.
+    uint64_t snap_epoch = 0;  // counts the snapshot's changes (ensure_snapshot, under state_mu exclusive; read under state_mu shared)
+    struct DeepKnown {
+        uint64_t epoch = 0, wanted_epoch = 0;  // the epoch `none` answers for (0: never swept); the epoch at which a call last asked and was sent forward
+        int rt = -1, pm = -1, st = -1;
+        bool none = false;  // no object of rt whose Check of pm for a subject of type st ends at the depth limit
+    };
+    std::mutex deep_mu;
+    std::vector<DeepKnown> deep_known;  // (a handful: one per list rule's template)
+    std::atomic<uint64_t> depth_sweeps{0};
     bool per_item_validation = false;  // ACL_FLAG_PER_ITEM_VALIDATION: ill-formed items of a bulk Check fail their own pair, not the call
     bool lenient_lookup = false;       // ACL_FLAG_LENIENT_LOOKUP: a LookupResources candidate whose forward Check errs is dropped instead of failing the call
     bool store_only = false;  // ACL_FLAG_STORE_ONLY: relationship store without a device (reads that need the GPU fail)

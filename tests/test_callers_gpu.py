@@ -607,9 +607,71 @@ definition pod { relation viewer: user | group#member
     assert {w_[1] for w_ in want} == {0, aclgpu.ERR_DEPTH} and sum(w_[0] == 2 for w_ in want) > 400
     with aclgpu.Engine(schema, "\n".join(rels)) as e:
         before = e.stats()["keep_route_calls"]
-        for got in (e.check_bulk_views(e.make_check_views(items)), e.check_bulk_packed(e.make_check_packed(items))):
+        for got in (e.check_bulk_views(e.make_check_views(items)), e.check_bulk_packed(e.make_check_packed(items)), e.check_bulk_views(e.make_check_views(items))):
             assert list(zip(got[0].tolist(), got[1].tolist())) == want
-        assert e.stats()["keep_route_calls"] == before
+        # (the second call at the same snapshot swept the type -- no_object_is_deep -- and found the pods behind the cycle: every call stays forward)
+        assert e.stats()["keep_route_calls"] == before and e.stats()["depth_sweeps"] == 1
         keep = e.check_bulk_keep_views(e.make_check_views(items), np.arange(701, dtype=np.uint32)).astype(bool)
         assert e.stats()["keep_route_calls"] == before + 1 and keep.tolist() == [w_ == (2, 0) for w_ in want]
 
+
+
+def test_check_bulk_of_one_subject_on_nested_groups_takes_the_reverse_walk_once_the_snapshot_is_known_shallow(aclgpu):
+    """The pair form on a RECURSIVE permission (nested groups, SURVEY 8(d) C4's schema): the schema cannot rule a depth error out, the snapshot can -- one forward
+    sweep over the type for a subject nobody is (engine.cpp no_object_is_deep; the property it rests on: tests/test_oracle_cross.py
+    test_a_depth_error_does_not_depend_on_the_subject).  First call at a snapshot: forward, and a note; second: the sweep, then the reverse walk; a write starts
+    over.  A cycle written behind some pods sends the calls forward again (their pairs carry the depth error, as the oracle's do); deleting it brings the route back.
+    Every answer is the oracle's (check.go:54-69: pair i answers item i)."""
+    schema = """definition user {}
+definition group { relation member: user | group#member }
+definition namespace { relation viewer: user | group#member
+ permission view = viewer }
+definition pod { relation namespace: namespace
+ relation viewer: user | group#member
+ permission view = viewer + namespace->view }"""
+    rels = [f"group:l{d}-{k}#member@group:l{d + 1}-{(2 * k + j) % 8}#member" for d in range(4) for k in range(8) for j in range(2)]
+    rels += [f"group:l4-{k}#member@user:u{k}" for k in range(8)] + ["group:l2-3#member@user:mid"]
+    rels += [f"namespace:n{k}#viewer@group:l1-{k}#member" for k in range(8)]
+    rels += [f"pod:p{i}#namespace@namespace:n{i % 16}" for i in range(900)]  # (n8..n15 have no viewers)
+    rels += [f"pod:p{i}#viewer@group:l0-{i % 8}#member" for i in range(0, 900, 5)] + [f"pod:p{i}#viewer@user:u{i % 8}" for i in range(1, 900, 7)]
+    o = orc.Oracle(schema)
+    for b in range(0, len(rels), 1000):  # (spicedb.go:35: at most 1 000 updates per write)
+        o.write([(orc.OP_TOUCH, r) for r in rels[b:b + 1000]])
+    users = ["u0", "u5", "mid", "stranger"]
+    items = {u: [("pod", f"p{i}", "view", "user", u, "") for i in range(900)] + [("pod", "no-such-pod", "view", "user", u, "")] for u in users}
+
+    def answers(e, u, packed=False):
+        got = e.check_bulk_packed(e.make_check_packed(items[u])) if packed else e.check_bulk_views(e.make_check_views(items[u]))
+        return list(zip(got[0].tolist(), got[1].tolist()))
+
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        want = {u: [o.check(*q) for q in items[u]] for u in users}
+        assert all(w_[1] == 0 for u in users for w_ in want[u]) and 100 < sum(w_[0] == 2 for w_ in want["u0"]) < 900
+        st0 = e.stats()
+        assert answers(e, "u0") == want["u0"]  # forward: nothing is known about this snapshot yet
+        st1 = e.stats()
+        assert (st1["keep_route_calls"], st1["depth_sweeps"]) == (st0["keep_route_calls"], st0["depth_sweeps"])
+        for k, u in enumerate(users):  # the sweep (once), then the walk -- for every user, the unknown one too
+            assert answers(e, u, packed=bool(k & 1)) == want[u], u
+        st2 = e.stats()
+        assert st2["depth_sweeps"] == st1["depth_sweeps"] + 1 and st2["keep_route_calls"] == st1["keep_route_calls"] + len(users)
+        # ---- a cycle behind the l3 groups: pods that reach it answer a depth error for whoever is not found first
+        cyc = ["group:l4-1#member@group:l3-0#member"]
+        e.write([(aclgpu.OP_TOUCH, cyc[0])])
+        o.write([(orc.OP_TOUCH, cyc[0])])
+        want = {u: [o.check(*q) for q in items[u]] for u in users}
+        assert any(w_[1] == aclgpu.ERR_DEPTH for w_ in want["stranger"]) and any(w_ == (2, 0) for w_ in want["u0"])
+        for rnd in range(3):
+            for u in users:
+                assert answers(e, u) == want[u], (rnd, u)
+        st3 = e.stats()
+        assert st3["depth_sweeps"] == st2["depth_sweeps"] + 1 and st3["keep_route_calls"] == st2["keep_route_calls"]  # swept once more, found deep pods: forward
+        # ---- the cycle deleted: a new snapshot, shallow again
+        e.write([(aclgpu.OP_DELETE, cyc[0])])
+        o.write([(orc.OP_DELETE, cyc[0])])
+        want = {u: [o.check(*q) for q in items[u]] for u in users}
+        for rnd in range(2):
+            for u in users:
+                assert answers(e, u) == want[u], (rnd, u)
+        st4 = e.stats()
+        assert st4["depth_sweeps"] == st3["depth_sweeps"] + 1 and st4["keep_route_calls"] == st3["keep_route_calls"] + 2 * len(users) - 1

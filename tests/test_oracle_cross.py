@@ -318,3 +318,60 @@ def test_cycles_through_nonmonotone_permissions_agree():
     for rt, perm in (("group", "active"), ("group", "inner")):
         for u in ("deep", "outcast"):
             assert outcome(co.lookup, rt, perm, "user", u, "") == outcome(po.lookup_resources, rt, perm, "user", u, ""), (rt, perm, u)
+
+
+def test_a_depth_error_does_not_depend_on_the_subject():
+    """What the engine's depth sweep rests on (csrc/engine.cpp no_object_is_deep): a Check that does not find its subject explores every path below its resource,
+    so whether it ends at the dispatch-depth limit (spicedb.go:34) is a property of the RESOURCE -- the same for a subject nobody is.  Random group graphs with
+    cycles, self-memberships and chains across the limit, unions and arrows only (the route is not taken for `&` / `-`), both oracles."""
+    import random
+    schema = """definition user {}
+definition group { relation member: user | group#member
+ relation parent: group
+ permission reach = member + parent->reach }
+definition pod { relation viewer: user | group#member | user:*
+ relation owner: group
+ permission view = viewer + owner->reach }"""
+    rng = random.Random(0x5ACE0D)
+    for trial in range(12):
+        ng, nu, npod = 14, 6, 20
+        rels = set()
+        for g in range(ng):
+            for _ in range(rng.randrange(0, 3)):
+                rels.add(("group", f"g{g}", "member", "user", f"u{rng.randrange(nu)}", ""))
+            for _ in range(rng.randrange(0, 3)):
+                rels.add(("group", f"g{g}", "member", "group", f"g{rng.randrange(ng)}", "member"))  # (cycles and g#member @ g#member included)
+            if rng.random() < 0.3:
+                rels.add(("group", f"g{g}", "parent", "group", f"g{rng.randrange(ng)}", ""))
+        if trial % 3 == 0:  # a chain of 60 nested groups: deeper than the limit without a cycle
+            for k in range(60):
+                rels.add(("group", f"c{k}", "member", "group", f"c{k + 1}", "member"))
+            rels.add(("group", "c60", "member", "user", "u0", ""))
+            rels.add(("pod", "p0", "viewer", "group", "c0", "member"))
+            rels.add(("pod", "p1", "viewer", "group", "c30", "member"))
+        for p in range(npod):
+            for _ in range(rng.randrange(0, 3)):
+                rels.add(("pod", f"p{p}", "viewer", "group", f"g{rng.randrange(ng)}", "member"))
+            if rng.random() < 0.3:
+                rels.add(("pod", f"p{p}", "viewer", "user", f"u{rng.randrange(nu)}", ""))
+            if rng.random() < 0.3:
+                rels.add(("pod", f"p{p}", "owner", "group", f"g{rng.randrange(ng)}", ""))
+            if rng.random() < 0.05:
+                rels.add(("pod", f"p{p}", "viewer", "user", "*", ""))
+        co, po = orc.Oracle(schema), PyOracle(schema)
+        co.write([(orc.OP_TOUCH, f"{a}:{b}#{c}@{d}:{e}" + (f"#{f}" if f else "")) for a, b, c, d, e, f in sorted(rels)])
+        for t in sorted(rels):
+            po.touch(*t)
+        seen = set()
+        for rt, perm, ids in (("pod", "view", [f"p{p}" for p in range(npod)]), ("group", "reach", [f"g{g}" for g in range(ng)]), ("group", "member", ["c0", "c20"])):
+            for rid in ids:
+                nobody = co.check(rt, rid, perm, "user", "nobody-at-all", "")
+                assert nobody == PY2C[po.check(rt, rid, perm, "user", "nobody-at-all", "")]
+                for u in range(nu):
+                    got = co.check(rt, rid, perm, "user", f"u{u}", "")
+                    seen.add(got)
+                    if got[0] != orc.PERM_HAS:
+                        assert got == nobody, (trial, rt, rid, perm, u, got, nobody)  # NO for both or the depth error for both
+                    if nobody[0] == orc.PERM_HAS:  # (a wildcard: then everybody has it)
+                        assert got == nobody
+        assert (orc.PERM_HAS, 0) in seen and (orc.PERM_NO, 0) in seen and (trial % 3 or (orc.PERM_UNSPEC, orc.ERR_DEPTH) in seen)

@@ -124,16 +124,16 @@ def test_concurrent_callers_and_a_writer_on_replicas(aclgpu):
         assert len(calls) == 3 and min(c for _d, c in calls) > 10, calls
 
 
-def test_engine_stress_on_a_replica_set(aclgpu):
+def test_engine_stress_on_a_replica_set(aclgpu, tmp_path):
     """tools/engine_stress (every call shape of the seam at once, each answer compared with the same call made alone) against an engine
     that ACL_DEVICES turns into three replicas."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tools", "bin", "engine_stress")
-    if not os.path.exists(exe):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tools", "engine_stress.cpp"), "-I", os.path.join(root, "include"), "-L",
-                               os.path.join(root, "spicedb-kubeapi-proxy_amd", "lib"), "-laclgpu", "-lpthread", "-Wl,-rpath,$ORIGIN/../../spicedb-kubeapi-proxy_amd/lib", "-o", exe])
+    lib = os.path.join(root, "spicedb-kubeapi-proxy_amd", "lib")
+    exe = str(tmp_path / "engine_stress")  # (built from the source as it is: a binary left under tools/bin may be older than the tool, or lack the library's path)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(root, "tools", "engine_stress.cpp"), "-I", os.path.join(root, "include"), "-L", lib,
+                           "-laclgpu", "-lpthread", f"-Wl,-rpath,{lib}", "-o", exe])
     env = dict(os.environ, ACL_DEVICES="0,0,0")
     out = subprocess.run([exe, "2"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

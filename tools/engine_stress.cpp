@@ -20,7 +20,11 @@ static const char *kSchema =
     "definition user {}\n"
     "definition namespace {\n  relation viewer: user\n  relation creator: user\n  permission view = viewer + creator\n}\n"
     "definition pod {\n  relation namespace: namespace\n  relation viewer: user\n  relation creator: user\n"
-    "  permission view = viewer + creator + namespace->view\n}\n";
+    "  permission view = viewer + creator + namespace->view\n}\n"
+    // (a RECURSIVE corner of the schema, which neither the writer nor the other requests touch: one user's doc pairs through acl_check_bulk_v take the reverse
+    //  walk only after a forward sweep has shown that no doc's Check ends at the depth limit on the snapshot at hand -- engine.cpp no_object_is_deep)
+    "definition group {\n  relation member: user | group#member\n}\n"
+    "definition doc {\n  relation viewer: user | group#member\n  permission view = viewer\n}\n";
 
 int main(int argc, char **argv) {
     const double SECONDS = argc > 1 ? atof(argv[1]) : 3.0;
@@ -39,6 +43,17 @@ int main(int argc, char **argv) {
     }
     for (int n = 0; n < NNS; n++)
         for (int k = 0; k < 10; k++) { char b[96]; snprintf(b, sizeof b, "namespace:ns%d#viewer@user:u%d\n", n, (int)((n * 31 + k * 977) % NUSER)); rels += b; }
+    const int NDOC = 20000, NGROUP = 200;
+    for (int g = 0; g < NGROUP; g++) {
+        char b[160];
+        if (g + 50 < NGROUP) { snprintf(b, sizeof b, "group:g%d#member@group:g%d#member\ngroup:g%d#member@group:g%d#member\n", g, g + 50, g, g + 1 + (g * 7 + 3) % 49); rels += b; }  // (children above their parent: no cycle)
+        for (int k = 0; k < 6; k++) { snprintf(b, sizeof b, "group:g%d#member@user:u%d\n", g, (g * 13 + k * 101) % 64); rels += b; }
+    }
+    for (int d = 0; d < NDOC; d++) {
+        char b[160];
+        snprintf(b, sizeof b, "doc:d%d#viewer@group:g%d#member\ndoc:d%d#viewer@user:u%d\n", d, (int)rnd(NGROUP), d, (int)rnd(64));
+        rels += b;
+    }
     if (acl_load_bootstrap(h, kSchema, strlen(kSchema), rels.data(), rels.size())) { fprintf(stderr, "load: %s\n", acl_last_error()); return 2; }
     if (acl_snapshot(h)) { fprintf(stderr, "snapshot: %s\n", acl_last_error()); return 2; }
     const int tp = acl_type_id(h, "pod"), tu = acl_type_id(h, "user"), pv = acl_relation_id(h, tp, "view");
@@ -74,11 +89,13 @@ int main(int argc, char **argv) {
     if (acl_lookup_resources_ids(h, tp, pv, tu, -1, user_id[7], bm0.data(), words, &cnt0)) { fprintf(stderr, "lookup: %s\n", acl_last_error()); return 2; }
     if (acl_batcher_start(h, 1024, 50)) return 2;
 
-    std::atomic<long> bad{0}, calls{0};
+    std::atomic<long> bad{0}, calls{0}, by[12] = {};  // by: big, submit window, 64-item, singles, string sets 0..3, keep sets 0..1, lookup, writer
+#define BAD(leg) do { if (!bad++) fprintf(stderr, "first failure: leg %d: %s\n", (int)(leg), acl_last_error()); by[leg]++; } while (0)
     std::atomic<bool> stop{false};
     auto check = [&](const Job &j, const std::vector<uint8_t> &got) {
-        if (memcmp(j.want.data(), got.data(), got.size()) != 0) bad++;
+        const bool same = memcmp(j.want.data(), got.data(), got.size()) == 0;
         calls++;
+        return same;
     };
     std::vector<std::thread> th;
     for (int i = 0; i < 3; i++)  // chip-filling batches, blocking (>= 131 072 items: chained on the device)
@@ -86,8 +103,8 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> p(big[i].items.size());
             std::vector<int32_t> e(p.size());
             while (!stop.load()) {
-                if (acl_check_bulk_ids(h, big[i].items.data(), p.size(), p.data(), e.data())) { bad++; break; }
-                check(big[i], p);
+                if (acl_check_bulk_ids(h, big[i].items.data(), p.size(), p.data(), e.data())) { BAD(0); break; }
+                if (!check(big[i], p)) BAD(0);
             }
         });
     th.emplace_back([&] {  // a submit / wait window of two
@@ -96,10 +113,10 @@ int main(int argc, char **argv) {
         while (!stop.load()) {
             acl_ticket_t *t[2] = {nullptr, nullptr};
             for (int k = 0; k < 2; k++)
-                if (acl_check_bulk_ids_submit(h, mid[k].items.data(), 65536, p[k].data(), e[k].data(), &t[k])) bad++;
+                if (acl_check_bulk_ids_submit(h, mid[k].items.data(), 65536, p[k].data(), e[k].data(), &t[k])) BAD(1);
             for (int k = 0; k < 2; k++) {
-                if (t[k] && acl_ticket_wait(h, t[k])) bad++;
-                else check(mid[k], p[k]);
+                if (t[k] && acl_ticket_wait(h, t[k])) BAD(1);
+                else if (!check(mid[k], p[k])) BAD(1);
             }
         }
     });
@@ -108,8 +125,8 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> p(64);
             std::vector<int32_t> e(64);
             while (!stop.load()) {
-                if (acl_check_bulk_ids(h, small[i].items.data(), 64, p.data(), e.data())) { bad++; break; }
-                check(small[i], p);
+                if (acl_check_bulk_ids(h, small[i].items.data(), 64, p.data(), e.data())) { BAD(2); break; }
+                if (!check(small[i], p)) BAD(2);
             }
         });
     for (int i = 0; i < 4; i++)  // single checks by name: blocking and through the completion queue
@@ -121,20 +138,20 @@ int main(int argc, char **argv) {
                 const int k = (q >> 8) % 64;
                 const acl_item_t &it0 = small[0].items[k];
                 const char *pn = acl_object_name(h, tp, it0.resource_id), *un = acl_object_name(h, tu, it0.subject_id);
-                if (!pn || !un) { bad++; break; }
+                if (!pn || !un) { BAD(3); break; }
                 std::string pns(pn), uns(un);  // (engine-owned strings are only good until the next mutating call)
                 acl_check_item_t it{"pod", pns.c_str(), "view", "user", uns.c_str(), ""};
                 if (i & 1) {
                     uint8_t perm = 0;
                     int32_t err = 0;
-                    if (acl_check_one(h, &it, &perm, &err) || err || perm != small[0].want[k]) bad++;
+                    if (acl_check_one(h, &it, &perm, &err) || err || perm != small[0].want[k]) BAD(3);
                     calls++;
                 } else {
-                    if (acl_check_one_submit(h, &it, (uint64_t)k)) bad++;
+                    if (acl_check_one_submit(h, &it, (uint64_t)k)) BAD(3);
                     size_t n = 0;
-                    if (acl_check_completions(h, comp, 32, 2000000, &n)) bad++;
+                    if (acl_check_completions(h, comp, 32, 2000000, &n)) BAD(3);
                     for (size_t j = 0; j < n; j++)
-                        if (comp[j].rc || comp[j].err || comp[j].perm != small[0].want[comp[j].tag]) bad++;
+                        if (comp[j].rc || comp[j].err || comp[j].perm != small[0].want[comp[j].tag]) BAD(3);
                     calls += (long)n;
                 }
             }
@@ -162,7 +179,31 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i <= n; i++) N.off.push_back((uint32_t)i);
         return N;
     };
+    // one user's doc pairs (the recursive corner): expected answers by id, alone
+    const int td = acl_type_id(h, "doc"), dv = acl_relation_id(h, td, "view");
+    auto named_docs = [&](size_t n, unsigned seed, int user) {
+        Named N;
+        std::vector<acl_item_t> items(n);
+        unsigned q = seed;
+        for (auto &it : items) {
+            q = q * 1664525u + 1013904223u;
+            char nm[32];
+            snprintf(nm, sizeof nm, "d%d", (int)((q >> 8) % NDOC));
+            uint32_t id = 0;
+            if (acl_find(h, td, nm, &id)) exit(2);
+            N.rid.emplace_back(nm);
+            it = acl_item_t{(uint16_t)td, (uint16_t)dv, id, (uint16_t)tu, ACL_NO_RELATION, user_id[user]};
+        }
+        N.want.resize(n);
+        std::vector<int32_t> err(n);
+        if (acl_check_bulk_ids(h, items.data(), n, N.want.data(), err.data())) exit(2);
+        N.sid.emplace_back("u" + std::to_string(user));
+        static const char kDoc[] = "doc", kView[] = "view", kUser[] = "user";
+        for (size_t i = 0; i < n; i++) N.v.push_back(acl_check_item_v_t{{kDoc, 3}, {N.rid[i].data(), N.rid[i].size()}, {kView, 4}, {kUser, 4}, {N.sid[0].data(), N.sid[0].size()}, {nullptr, 0}});
+        return N;
+    };
     std::vector<Named> strs, keeps;
+    strs.push_back(named_docs(2500, 44, 5));  // (recursive permission: forward until a sweep has shown the snapshot shallow, then by the reverse walk)
     strs.push_back(named(8192, 41, -1));
     strs.push_back(named(700, 42, -1));
     strs.push_back(named(3000, 43, 9));  // (one user's pairs: on this schema -- no recursion -- the string call itself takes the reverse walk)
@@ -174,11 +215,11 @@ int main(int argc, char **argv) {
             std::vector<uint8_t> p(N.v.size());
             std::vector<int32_t> e(N.v.size());
             while (!stop.load()) {
-                if (acl_check_bulk_v(h, N.v.data(), N.v.size(), p.data(), e.data())) { bad++; break; }
-                if (memcmp(p.data(), N.want.data(), p.size()) != 0) bad++;
-                for (int32_t x : e) if (x) { bad++; break; }
+                if (acl_check_bulk_v(h, N.v.data(), N.v.size(), p.data(), e.data())) { BAD(4 + (int)i); break; }
+                if (memcmp(p.data(), N.want.data(), p.size()) != 0) BAD(4 + (int)i);
+                for (int32_t x : e) if (x) { BAD(4 + (int)i); break; }
                 calls++;
-                if (i) std::this_thread::sleep_for(std::chrono::microseconds(400));  // (this one finds the pool asleep)
+                if (i > 1) std::this_thread::sleep_for(std::chrono::microseconds(400));  // (this one finds the pool asleep)
             }
         });
     for (size_t i = 0; i < keeps.size(); i++)
@@ -186,9 +227,9 @@ int main(int argc, char **argv) {
             const Named &N = keeps[i];
             std::vector<uint8_t> keep(N.v.size());
             while (!stop.load()) {
-                if (acl_check_bulk_keep_v(h, N.v.data(), N.v.size(), N.off.data(), N.v.size(), keep.data())) { bad++; break; }
+                if (acl_check_bulk_keep_v(h, N.v.data(), N.v.size(), N.off.data(), N.v.size(), keep.data())) { BAD(8 + (int)i); break; }
                 for (size_t k = 0; k < keep.size(); k++)
-                    if ((keep[k] != 0) != (N.want[k] == ACL_PERM_HAS_PERMISSION)) { bad++; break; }
+                    if ((keep[k] != 0) != (N.want[k] == ACL_PERM_HAS_PERMISSION)) { BAD(8 + (int)i); break; }
                 calls++;
                 if (i) std::this_thread::sleep_for(std::chrono::microseconds(250));
             }
@@ -197,9 +238,9 @@ int main(int argc, char **argv) {
         std::vector<uint32_t> bm(words);
         while (!stop.load()) {
             uint64_t cnt = 0;
-            if (acl_lookup_resources_ids(h, tp, pv, tu, -1, user_id[7], bm.data(), words, &cnt)) { bad++; break; }
+            if (acl_lookup_resources_ids(h, tp, pv, tu, -1, user_id[7], bm.data(), words, &cnt)) { BAD(10); break; }
             // the writer only adds viewers u7 never is, on pods above NREQ_POD ... of other users: this user's set must not change
-            if (cnt != cnt0 || memcmp(bm.data(), bm0.data(), (NREQ_POD / 32) * 4) != 0) bad++;
+            if (cnt != cnt0 || memcmp(bm.data(), bm0.data(), (NREQ_POD / 32) * 4) != 0) BAD(10);
             calls++;
         }
     });
@@ -214,9 +255,10 @@ int main(int argc, char **argv) {
             snprintf(sid, sizeof sid, "u%d", 8 + (int)((q >> 12) % (NUSER - 8)));
             acl_update_t u{(int32_t)(w % 3 == 2 ? ACL_OP_DELETE : ACL_OP_TOUCH), {"pod", rid, "viewer", "user", sid, "", 0}};
             uint64_t rev = 0;
-            if (acl_write(h, &u, 1, nullptr, 0, &rev)) bad++;
+            if (acl_write(h, &u, 1, nullptr, 0, &rev)) BAD(11);
             w++;
-            std::this_thread::sleep_for(std::chrono::microseconds(300));
+            // (every 64th write is followed by a quiet spell: the depth sweep is only run for a snapshot that two calls in a row have seen)
+            std::this_thread::sleep_for(std::chrono::microseconds(w % 64 ? 300 : 12000));
         }
     });
     std::this_thread::sleep_for(std::chrono::milliseconds((long)(SECONDS * 1000)));
@@ -225,8 +267,14 @@ int main(int argc, char **argv) {
     acl_batcher_stop(h);
     acl_stats_t st;
     acl_stats(h, &st);
-    printf("engine_stress: %.1f s, %ld calls checked, %ld wrong or failed; snapshot patches %llu, compactions %llu, single-launch passes %llu, PostFilter calls by reverse walk %llu\n", SECONDS, calls.load(), bad.load(),
-           (unsigned long long)st.snapshot_patches, (unsigned long long)st.snapshot_compactions, (unsigned long long)st.local_passes, (unsigned long long)st.keep_route_calls);
+    printf("engine_stress: %.1f s, %ld calls checked, %ld wrong or failed; snapshot patches %llu, compactions %llu, single-launch passes %llu, PostFilter calls by reverse walk %llu, depth sweeps %llu\n", SECONDS, calls.load(), bad.load(),
+           (unsigned long long)st.snapshot_patches, (unsigned long long)st.snapshot_compactions, (unsigned long long)st.local_passes, (unsigned long long)st.keep_route_calls,
+           (unsigned long long)st.depth_sweeps);
+    if (bad.load()) {
+        printf("wrong or failed by leg (big, submit window, 64-item, singles, strings x 4, keeps x 2, lookup, writer):");
+        for (auto &b : by) printf(" %ld", b.load());
+        printf("\n");
+    }
     acl_close(h);
     return bad.load() || !st.keep_route_calls ? 1 : 0;
 }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """usage (GPU box): [ACL_DEBUG_KEEP=1] python tools/keep_route_probe.py [--calls 40] -- PostFilter's shape on C4's named graph (K list items x one template for ONE
-user): acl_check_bulk_keep_v through the reverse-walk route and, with ACL_KEEP_ROUTE_MIN=0 in a child, the forward path; one line per (K, user).  The masks are
+user): acl_check_bulk_keep_v / _packed through the reverse-walk route and acl_check_bulk_v of the same pairs (CheckBulkPermissions itself: the pair form of the route --
+on C4's recursive schema after the depth sweep, engine.cpp no_object_is_deep; ACL_KEEP_ROUTE_MIN=0 or ACL_DEPTH_SWEEP=0 in the environment gives the forward path); one line per (K, user).  The masks are
 compared with the id path's answers.  ACL_DEBUG_KEEP=1 prints the route's phase times per call on stderr."""
 import argparse
 import json
