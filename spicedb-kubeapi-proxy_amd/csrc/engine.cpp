@@ -1942,15 +1942,17 @@ int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel,
 // (nested groups: the schema alone allows a chain of any length) from the reverse walk's row.  A Check that does not find its subject explores every path below
 // its resource, whoever the subject is (the oracle's and the kernels' rule: HAS_PERMISSION wins, else a path beyond the limit is the pair's error, else NO; no
 // path's length depends on who is looked for), so the set of resources with a depth error is the set a subject NOBODY IS gets one for: one forward sweep over the
-// type's ids with the unknown-subject id (what intern_check_item gives a name no table holds), through the ordinary walk.  The outcome is remembered per snapshot
-// epoch (acl_engine::snap_epoch: any write starts a new one); the sweep costs a forward pass over the whole type (845 000 pods: ~1 ms), so it is only run for a
-// graph that holds still: the first call that needs it at an epoch goes forward and leaves a note, the next one at the SAME epoch sweeps.
+// type's ids with the unknown-subject id (what intern_check_item gives a name no table holds), through the ordinary walk.  "None is deep" then holds until a
+// write ADDS a path (Store::path_adds: a userset subject, an arrow's tupleset, a bulk load -- a plain grant ends the paths it is on, a removal only takes paths
+// away); "some object is deep" is remembered for its own snapshot epoch only (acl_engine::snap_epoch).  The sweep costs a forward pass over the whole type
+// (845 000 pods: ~1 ms), so it is only run for a graph that holds still: the first call that needs it goes forward and leaves a note, the next one that finds
+// the note current sweeps.
 // true: none is deep; false: some object is, or it is not known (yet): the caller takes the forward path (a sweep that fails is "not known").  Caller holds
 // state_mu shared (an Eval) and owns context c.
 static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st, size_t n_pairs) {
     static const bool kOff = getenv("ACL_DEPTH_SWEEP") && atoi(getenv("ACL_DEPTH_SWEEP")) == 0;  // (A/B and test knob)
     if (kOff) return false;
-    const uint64_t epoch = h->snap_epoch;
+    const uint64_t epoch = h->snap_epoch, adds = h->store.path_adds();  // (writers hold state_mu exclusive: both belong to the snapshot the caller evaluates)
     const size_t count = h->store.objects(rt).count();
     if (count > std::max<size_t>((size_t)1 << 20, 64 * n_pairs)) return false;  // (a sweep of more than ~1 ms for a call that is not itself that long: forward)
     {
@@ -1964,10 +1966,17 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
             k = &h->deep_known.back();
             k->rt = rt, k->pm = pm, k->st = st;
         }
-        if (k->epoch == epoch) return k->none;
+        if (k->swept && k->none && k->adds == adds) return true;  // shallow when swept, and nothing written since could have added a path
+        if (k->swept && k->epoch == epoch) return k->none;        // (this very snapshot: deep objects were found)
+        // not known for this snapshot.  The sweep is for a graph that holds still: the first call that needs it leaves a note and goes forward, the next one
+        // that finds the note still current sweeps -- current by the store's path_adds (plain grants and removals come and go without touching it), or, after a
+        // sweep that FOUND deep objects, by the snapshot's epoch (only a removal can help then, and any write may be one)
         static const bool kEager = getenv("ACL_DEPTH_SWEEP") && atoi(getenv("ACL_DEPTH_SWEEP")) == 2;  // (tests: sweep at the first call)
-        if (k->wanted_epoch != epoch && !kEager) {
-            k->wanted_epoch = epoch;
+        const bool by_epoch = k->swept && !k->none && k->adds == adds;
+        const uint64_t key = by_epoch ? epoch : adds;
+        if ((k->wanted != key || k->wanted_by_epoch != by_epoch) && !kEager) {
+            k->wanted = key;
+            k->wanted_by_epoch = by_epoch;
             return false;
         }
     }
@@ -1987,8 +1996,10 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
     std::lock_guard<std::mutex> lk(h->deep_mu);
     for (auto &d : h->deep_known)
         if (d.rt == rt && d.pm == pm && d.st == st) {
-            d.epoch = epoch;
+            d.swept = true;
             d.none = none;
+            d.epoch = epoch;
+            d.adds = adds;
         }
     return none;
 }

@@ -373,9 +373,13 @@ struct acl_engine {
     // no_object_is_deep): one forward sweep over the type's objects for a subject nobody is, remembered per (type, permission, subject type) and snapshot epoch.
     uint64_t snap_epoch = 0;  // counts the snapshot's changes (ensure_snapshot, under state_mu exclusive; read under state_mu shared)
     struct DeepKnown {
-        uint64_t epoch = 0, wanted_epoch = 0;  // the epoch `none` answers for (0: never swept); the epoch at which a call last asked and was sent forward
         int rt = -1, pm = -1, st = -1;
-        bool none = false;  // no object of rt whose Check of pm for a subject of type st ends at the depth limit
+        bool swept = false, none = false;  // none: no object of rt whose Check of pm for a subject of type st ends at the depth limit ...
+        uint64_t epoch = 0, adds = 0;      // ... on the snapshot of this epoch, the store's path_adds() then.  `none` stays true while no write ADDS a path
+                                           // (Store::path_adds: plain-subject relationships and removals cannot make a Check deeper); "some object is
+                                           // deep" is only known for its own epoch (a DELETE may have cut the cycle)
+        uint64_t wanted = 0;               // the key (path_adds, or the epoch after a sweep that found deep objects) at which a call last asked and went forward
+        bool wanted_by_epoch = false;
     };
     std::mutex deep_mu;
     std::vector<DeepKnown> deep_known;  // (a handful: one per list rule's template)

@@ -247,6 +247,20 @@ Status Store::load_schema(const std::string &text) {
         for (const Member &m : d.members)
             for (const SubjectClass &c : m.classes)
                 if (c.wildcard && wildcard_id_[c.stype] == 0xFFFFFFFFu) wildcard_id_[c.stype] = intern_object(c.stype, "*", true);
+    tupleset_slot_.assign(schema_.nslots, 0);
+    for (size_t t = 0; t < schema_.defs.size(); t++)
+        for (const Member &m : schema_.defs[t].members) {
+            if (!m.is_permission) continue;
+            std::function<void(const Node &)> arrows = [&](const Node &n) {
+                if (n.kind == Node::kArrow || n.kind == Node::kArrowAll) {
+                    const int am = schema_.defs[t].find(n.a);
+                    if (am >= 0) tupleset_slot_[schema_.defs[t].members[am].slot] = 1;
+                }
+                for (const Node &k : n.kids) arrows(k);
+            };
+            arrows(m.expr);
+        }
+    path_adds_++;
     revision_++;
     log_.clear();  // ids of the previous schema mean nothing now
     log_floor_ = revision_;
@@ -652,6 +666,10 @@ Status Store::write(const std::vector<UpdateText> &updates, const std::vector<Fi
                 ref_key(rs[i].slot, rs[i].cls, key, +1);
             }
             set_expiry(rs[i].slot, rs[i].cls, key, rs[i].expires);
+            {   // (a TOUCH of a relationship that is there counts too: it may have been expired, that is invisible)
+                auto [ot, om] = schema_.slot_owner[rs[i].slot];
+                if (tupleset_slot_[rs[i].slot] || schema_.defs[ot].members[om].classes[rs[i].cls].srel != kNoRelation) path_adds_++;
+            }
         }
     }
     for (const auto &hd : held) ref(hd.first, hd.second, -1);  // (an object left without any relationship goes on its type's free list here)
@@ -813,6 +831,7 @@ Status Store::add_edges(int rtype, int rel, int stype, int srel, size_t n, const
         objects_[stype].reserve_ids(maxs + 1);
     }
     revision_++;
+    path_adds_++;
     bulk_revision_ = revision_;  // not in the change feed: snapshots older than this must be rebuilt, not patched
     return Status::Ok();
 }

@@ -274,6 +274,10 @@ class Store {
     Status load_relationship_lines(const std::string &text);
 
     uint64_t revision() const { return revision_; }
+    // counts the writes that can ADD a path to the graph: relationships whose subject carries a relation (`group:g#member`) or whose relation is an arrow's
+    // tupleset (`pod#namespace`), bulk loads, schema loads.  A relationship with a plain subject on any other relation ends every path it is on, and a removal
+    // (DELETE, expiry) only takes paths away: neither can make a Check end at the depth limit that did not before (engine.cpp no_object_is_deep).
+    uint64_t path_adds() const { return path_adds_; }
     void settle_all();
     // A read-only twin for a background snapshot build: same schema, revision and clock, relationship tables SHARED
     // (copy on write), object tables reduced to their id counts, no change feed.  Take it with the store lock held.
@@ -400,6 +404,8 @@ class Store {
     void ref_key(int slot, int cls, uint64_t key, int delta);
     std::vector<std::vector<ClassTable>> tables_;
     uint64_t revision_ = 1;
+    uint64_t path_adds_ = 1;
+    std::vector<uint8_t> tupleset_slot_;  // [nslots] the relation is the left side of an arrow somewhere in its definition
     int64_t now_override_ = 0;
     std::vector<Change> log_;       // bounded: the oldest half is dropped when it reaches kLogCap
     uint64_t log_floor_ = 0;        // changes with revision <= log_floor_ may have been dropped

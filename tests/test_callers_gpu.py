@@ -655,6 +655,26 @@ definition pod { relation namespace: namespace
             assert answers(e, u, packed=bool(k & 1)) == want[u], u
         st2 = e.stats()
         assert st2["depth_sweeps"] == st1["depth_sweeps"] + 1 and st2["keep_route_calls"] == st1["keep_route_calls"] + len(users)
+        # ---- plain grants and removals end paths or take them away (Store::path_adds): the snapshot changes, what the sweep showed still holds -- the very
+        # next call walks, and answers for the store as it is now
+        for op, rel in ((aclgpu.OP_TOUCH, "pod:p3#viewer@user:stranger"), (aclgpu.OP_DELETE, "pod:p1#viewer@user:u1"), (aclgpu.OP_DELETE, "group:l1-0#member@group:l2-0#member")):
+            e.write([(op, rel)])
+            o.write([(op, rel)])
+            want = {u: [o.check(*q) for q in items[u]] for u in users}
+            for u in users:
+                assert answers(e, u) == want[u], (rel, u)
+        assert want["stranger"][3] == (2, 0)
+        st2b = e.stats()
+        assert st2b["depth_sweeps"] == st2["depth_sweeps"] and st2b["keep_route_calls"] == st2["keep_route_calls"] + 3 * len(users)
+        # ... a new nesting edge may add a path: forward once, then a sweep
+        for op, rel in ((aclgpu.OP_TOUCH, "group:l1-0#member@group:l2-0#member"),):
+            e.write([(op, rel)])
+            o.write([(op, rel)])
+        want = {u: [o.check(*q) for q in items[u]] for u in users}
+        for u in users:
+            assert answers(e, u) == want[u], u
+        st2 = e.stats()
+        assert st2["depth_sweeps"] == st2b["depth_sweeps"] + 1 and st2["keep_route_calls"] == st2b["keep_route_calls"] + len(users) - 1
         # ---- a cycle behind the l3 groups: pods that reach it answer a depth error for whoever is not found first
         cyc = ["group:l4-1#member@group:l3-0#member"]
         e.write([(aclgpu.OP_TOUCH, cyc[0])])

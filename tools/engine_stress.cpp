@@ -257,8 +257,7 @@ int main(int argc, char **argv) {
             uint64_t rev = 0;
             if (acl_write(h, &u, 1, nullptr, 0, &rev)) BAD(11);
             w++;
-            // (every 64th write is followed by a quiet spell: the depth sweep is only run for a snapshot that two calls in a row have seen)
-            std::this_thread::sleep_for(std::chrono::microseconds(w % 64 ? 300 : 12000));
+            std::this_thread::sleep_for(std::chrono::microseconds(300));  // (plain grants: they do not touch what the depth sweep showed, Store::path_adds)
         }
     });
     std::this_thread::sleep_for(std::chrono::milliseconds((long)(SECONDS * 1000)));
