@@ -493,6 +493,11 @@ int acl_selfcheck_snapshot(acl_engine_t *h, int *patched_out); /* *patched_out: 
  * copy-on-write view of the store, phase 1 catches it up with the writes since (the ordinary patcher), adopts and verifies it.
  * *adopted_out = 0 when the catch-up was not expressible as a patch (the engine then rebuilds synchronously). */
 int acl_selfcheck_compaction(acl_engine_t *h, int phase, int *adopted_out);
+/* The elements of the JSON array at body[arr_open] (`[`) as the list-level filters find them (csrc/engine_list.cpp scan_array): chunk_bytes > 0 forces the
+ * parallel index (csrc/json_index.hpp) with chunks of that size, 0 = what a call of that size would do.  spans_out: {begin, end} byte offsets per element
+ * (cap elements at most), *n_out elements, *close_out the offset of `]`.  ACL_ERR_INVALID_ARGUMENT when the array or one of its elements is not JSON. */
+int acl_selfcheck_json_array(acl_engine_t *h, const char *body, size_t body_len, size_t arr_open, size_t chunk_bytes, size_t *spans_out, size_t cap, size_t *n_out,
+                             size_t *close_out);
 /* ---- measurement ---- */
 typedef struct {
     uint64_t check_items;      /* items answered since open / last reset */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls", "acl_watch_wait", "acl_watch_recheck", "acl_load_bootstrap_yaml",
-    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_check_bulk_packed", "acl_check_bulk_keep_v", "acl_check_bulk_keep_packed",
+    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_check_bulk_packed", "acl_check_bulk_keep_v", "acl_check_bulk_keep_packed", "acl_selfcheck_json_array",
 ]
 
 
@@ -196,6 +196,7 @@ def load():
     L.acl_batcher_lookup_stats.argtypes = [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_selfcheck_snapshot.argtypes = [H, C.POINTER(C.c_int)]
     L.acl_selfcheck_compaction.argtypes = [H, C.c_int, C.POINTER(C.c_int)]
+    L.acl_selfcheck_json_array.argtypes = [H, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.acl_delete_by_filter_pre.argtypes = [H, C.POINTER(Filter), C.POINTER(Filter), C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.acl_check_bulk_ids_opts.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(CallOpts)]
     L.acl_check_bulk_ids_submit.argtypes = [H, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]

@@ -647,6 +647,14 @@ class Engine:
         self._check(self._L.acl_selfcheck_snapshot(self._h, C.byref(p)))
         return int(p.value)
 
+    def selfcheck_json_array(self, body: bytes, arr_open: int, chunk_bytes: int = 0):
+        """Test hook: the element spans of the JSON array at body[arr_open] as the list filters find them -> ([(begin, end)], offset of `]`)."""
+        cap = max(1, len(body))
+        spans = np.zeros(2 * cap, dtype=np.uint64)
+        n, close = C.c_size_t(), C.c_size_t()
+        self._check(self._L.acl_selfcheck_json_array(self._h, body, len(body), arr_open, chunk_bytes, spans.ctypes.data, cap, C.byref(n), C.byref(close)))
+        return [(int(spans[2 * i]), int(spans[2 * i + 1])) for i in range(n.value)], close.value
+
     def selfcheck_compaction(self, phase: int) -> bool:
         """Test hook (store-only engines): phase 0 = build from a copy-on-write view; phase 1 = catch up, adopt, verify.
         Returns True when phase 1 adopted the background build."""

@@ -1369,6 +1369,25 @@ void intern_pool_destroy(acl_engine_t *h) {
     h->intern_pool = nullptr;
 }
 
+// fn over [0, total) in pieces, on the interning pool's threads and the caller (engine_list.cpp: a list response's bytes).  Lock order as for the interning
+// callers: names_mu (shared) may be held, state_mu must not be waited for inside fn.
+void host_parallel(acl_engine_t *h, size_t total, size_t piece, const std::function<void(size_t, size_t)> &fn) {
+    piece = std::max<size_t>(piece, 1);
+    const unsigned threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), h->intern_threads);
+    if (threads <= 1 || total <= piece) {
+        if (total) fn(0, total);
+        return;
+    }
+    InternPool *P;
+    {
+        std::lock_guard<std::mutex> lk(h->intern_pool_mu);
+        if (!h->intern_pool) h->intern_pool = new InternPool(std::min<unsigned>(std::max(2u, std::thread::hardware_concurrency()), h->intern_threads) - 1);
+        P = h->intern_pool;
+    }
+    P->run(total, piece, h->intern_threads - 1, fn);
+}
+unsigned host_threads(acl_engine_t *h) { return std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), h->intern_threads); }
+
 // Interns n items into `out` (the evaluation context's pinned staging: what the H2D copy reads).  An item that cannot be checked -- empty
 // field, unknown type / permission / relation: the pair carries an error, check.go:55 -- becomes a DEAD item (the kernel answers it
 // "invalid" without touching the graph) and is listed in *bad with its error; the batch is never compacted or copied again.

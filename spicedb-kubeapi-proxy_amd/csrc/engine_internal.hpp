@@ -544,6 +544,8 @@ FilterText to_filter(const acl_filter_t *f);
 // strings -> interned item; returns 0 or the per-item error the pair carries (check.go:55).  Caller holds names_mu shared.
 int32_t intern_check_item(acl_engine_t *h, const acl_check_item_t &it, acl_item_t *out);
 void intern_pool_destroy(acl_engine_t *h);
+void host_parallel(acl_engine_t *h, size_t total, size_t piece, const std::function<void(size_t, size_t)> &fn);  // engine.cpp: pieces of [0, total) on the interning pool's threads + the caller
+unsigned host_threads(acl_engine_t *h);
 bool hostmap_takes(acl_engine *h, size_t n);  // engine.cpp: a host batch of n items is answered by the kernel across PCIe (no copies)
 int resolve_lookup(acl_engine_t *h, const char *rtype, const char *perm, const char *stype, const char *sid, const char *srel, int *rt_out, int *pm_out,
                    int *st_out, int *sr_out, uint32_t *sub_out);

@@ -17,6 +17,7 @@
 // 349-416) keep what prefilterResult.IsAllowed(namespace, name) admits (lookups.go:25-36) -- here the LookupResources bitmap tested by the
 // object id the rule's inverse mapping gives an item, over the same scanned spans.
 #include "engine_internal.hpp"
+#include "json_index.hpp"
 
 namespace {
 
@@ -275,15 +276,31 @@ bool scan_row(Scanner &s, Item *it, bool *decodable) {
     });
 }
 
+// a big copy in pieces on all host threads (a 135 MB body: 25 ms by one thread)
+void big_copy(acl_engine_t *h, char *dst, const char *src, size_t n) {
+    constexpr size_t kPiece = (size_t)1 << 20;
+    if (n < 4 * kPiece || !h) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    host_parallel(h, (n + kPiece - 1) / kPiece, 1, [&](size_t a, size_t b) { std::memcpy(dst + a * kPiece, src + a * kPiece, std::min(n, b * kPiece) - a * kPiece); });
+}
+
 // the body with only the kept elements of the array at [arr_open, arr_close] ('[' and ']'); `none` = what an array without survivors becomes
-char *splice_kept(const char *body, size_t body_len, size_t arr_open, size_t arr_close, const std::vector<Item> &items, const std::vector<uint8_t> &keep, const char *none,
-                  size_t *out_len, size_t *kept_out) {
+char *splice_kept(acl_engine_t *h, const char *body, size_t body_len, size_t arr_open, size_t arr_close, const std::vector<Item> &items, const std::vector<uint8_t> &keep,
+                  const char *none, size_t *out_len, size_t *kept_out) {
     size_t kept = 0, bytes = arr_open + 1 + (body_len - arr_close) + std::strlen(none);
-    for (size_t i = 0; i < items.size(); i++)
+    std::vector<size_t> at(items.size() + 1);  // where element i goes (kept ones: behind their comma)
+    size_t w0 = arr_open + 1;
+    for (size_t i = 0; i < items.size(); i++) {
+        at[i] = w0;
         if (keep[i]) {
+            w0 += (kept ? 1 : 0) + (items[i].e - items[i].b);
             kept++;
-            bytes += items[i].e - items[i].b + 1;
         }
+    }
+    at[items.size()] = w0;
+    bytes += w0;
     char *o = (char *)std::malloc(std::max<size_t>(bytes, 1) + 8), *w = o;
     if (!o) return nullptr;
     if (!kept) {
@@ -291,25 +308,108 @@ char *splice_kept(const char *body, size_t body_len, size_t arr_open, size_t arr
         w += arr_open;
         std::memcpy(w, none, std::strlen(none));
         w += std::strlen(none);
-        std::memcpy(w, body + arr_close + 1, body_len - arr_close - 1);
+        big_copy(h, w, body + arr_close + 1, body_len - arr_close - 1);
         w += body_len - arr_close - 1;
     } else {
         std::memcpy(w, body, arr_open + 1);
-        w += arr_open + 1;
-        bool first = true;
-        for (size_t i = 0; i < items.size(); i++) {
-            if (!keep[i]) continue;
-            if (!first) *w++ = ',';
-            first = false;
-            std::memcpy(w, body + items[i].b, items[i].e - items[i].b);
-            w += items[i].e - items[i].b;
-        }
+        auto copy_items = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                if (!keep[i]) continue;
+                char *d = o + at[i];
+                if (at[i] != arr_open + 1) *d++ = ',';
+                std::memcpy(d, body + items[i].b, items[i].e - items[i].b);
+            }
+        };
+        if (w0 - arr_open >= ((size_t)4 << 20) && h) host_parallel(h, items.size(), std::max<size_t>(64, items.size() / (8 * (size_t)host_threads(h))), copy_items);
+        else copy_items(0, items.size());
+        w = o + w0;
         std::memcpy(w, body + arr_close, body_len - arr_close);
         w += body_len - arr_close;
     }
     *out_len = (size_t)(w - o);
     *kept_out = kept;
     return o;
+}
+
+// The elements of the array that s.p stands at (`[`): their spans, their metadata (scan_item; table rows: scan_row) -- and s.p behind the array's `]`.
+// Small arrays: element by element.  From kParallelBytes on: the element spans by all host threads (json_index.hpp: every chunk indexed under both
+// in-string hypotheses, a sequential fix-up over the chunks), then every span scanned -- validated, its metadata taken -- in parallel.  Which bodies are JSON
+// does not change: an array is valid exactly when its spans are valid values separated by single commas, and the scanner decides that per span.
+constexpr size_t kParallelBytes = (size_t)1 << 19;
+bool scan_array(acl_engine_t *h, Scanner &s, const char *body, bool table, std::vector<Item> *items, std::vector<uint8_t> *decodable, size_t *arr_open, size_t *arr_close,
+                size_t chunk_bytes = 0) {
+    items->clear();
+    if (decodable) decodable->clear();
+    *arr_open = (size_t)(s.p - body);
+    const size_t region_b = *arr_open + 1, region_e = (size_t)(s.e - body);
+    if (!chunk_bytes && (region_e - region_b < kParallelBytes || host_threads(h) <= 1)) {
+        s.p++;
+        s.ws();
+        if (s.p < s.e && *s.p == ']') {
+            *arr_close = (size_t)(s.p - body);
+            s.p++;
+            return true;
+        }
+        for (;;) {
+            s.ws();
+            Item it;
+            bool dec = true;
+            const char *b0 = s.p;
+            if (!(table ? scan_row(s, &it, &dec) : scan_item(s, &it))) return false;
+            it.b = (size_t)(b0 - body);
+            it.e = (size_t)(s.p - body);
+            if (decodable) decodable->push_back(dec && it.is_object);
+            items->push_back(std::move(it));
+            s.ws();
+            if (s.p < s.e && *s.p == ',') { s.p++; continue; }
+            if (s.p < s.e && *s.p == ']') {
+                *arr_close = (size_t)(s.p - body);
+                s.p++;
+                return true;
+            }
+            return s.fail();
+        }
+    }
+    // ---- structure: chunks of the rest of the body (the array is nearly all of it), four per thread so that a slow one does not hold the others up
+    const size_t len = region_e - region_b;
+    size_t chunk = chunk_bytes ? chunk_bytes : std::min<size_t>((size_t)1 << 20, std::max<size_t>((size_t)1 << 16, len / (4 * (size_t)host_threads(h))));
+    chunk = (chunk + 63) & ~(size_t)63;
+    const size_t nchunks = (len + chunk - 1) / chunk;
+    std::vector<jsonidx::Chunk> chunks(nchunks);
+    host_parallel(h, nchunks, 1, [&](size_t a, size_t b) {
+        for (size_t c = a; c < b; c++) jsonidx::index_chunk(body, region_b, region_b + c * chunk, std::min(region_e, region_b + (c + 1) * chunk), &chunks[c]);
+    });
+    std::vector<jsonidx::Span> spans;
+    if (!jsonidx::array_spans(chunks, region_b, &spans, arr_close)) return s.fail();
+    chunks.clear();
+    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; };
+    for (jsonidx::Span &sp : spans) {
+        while (sp.b < sp.e && is_ws(body[sp.b])) sp.b++;
+        while (sp.e > sp.b && is_ws(body[sp.e - 1])) sp.e--;
+    }
+    if (spans.size() == 1 && spans[0].b == spans[0].e) spans.clear();  // `[ ]`
+    // ---- every element through the scanner (an empty span -- `[1,,2]` -- fails there like any other non-value)
+    items->resize(spans.size());
+    if (decodable) decodable->resize(spans.size());
+    std::atomic<bool> bad{false};
+    host_parallel(h, spans.size(), std::max<size_t>(16, spans.size() / (8 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
+        for (size_t i = a; i < b && !bad.load(std::memory_order_relaxed); i++) {
+            Scanner es{body + spans[i].b, body + spans[i].e};
+            Item &it = (*items)[i];
+            bool dec = true;
+            const bool ok = table ? scan_row(es, &it, &dec) : scan_item(es, &it);
+            if (!ok || !es.ok || es.p != es.e) {
+                bad.store(true, std::memory_order_relaxed);
+                return;
+            }
+            it.b = spans[i].b;
+            it.e = spans[i].e;
+            if (decodable) (*decodable)[i] = dec && it.is_object;
+        }
+    });
+    if (bad.load()) return s.fail();
+    s.p = body + *arr_close + 1;
+    return true;
 }
 
 }  // namespace
@@ -329,13 +429,17 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     auto unchanged = [&](uint64_t n) {
         char *o = (char *)std::malloc(std::max<size_t>(body_len, 1));
         if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
-        std::memcpy(o, body, body_len);
+        big_copy(h, o, body, body_len);
         *out_body = o;
         *out_len = body_len;
         if (kept_out) *kept_out = n;
         if (total_out) *total_out = n;
         return (int)ACL_OK;
     };
+    static const bool kTrace = getenv("ACL_DEBUG_LIST") != nullptr;  // (phase times of the call on stderr)
+    const auto t_0 = std::chrono::steady_clock::now();
+    auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
+    double ms_scan = 0, ms_resolve = 0, ms_keep = 0;
     // ---- one scan: the top-level object's "items" array and its elements
     Scanner s{body, body + body_len};
     s.ws();
@@ -349,79 +453,66 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
             return s.skip();
         }
         have_items = true;
-        items.clear();
-        arr_open = (size_t)(s.p - body);
-        s.p++;
-        s.ws();
-        if (s.p < s.e && *s.p == ']') {
-            arr_close = (size_t)(s.p - body);
-            s.p++;
-            return true;
-        }
-        for (;;) {
-            s.ws();
-            Item it;
-            const char *b0 = s.p;
-            if (!scan_item(s, &it)) return false;
-            it.b = (size_t)(b0 - body);
-            it.e = (size_t)(s.p - body);
-            items.push_back(std::move(it));
-            s.ws();
-            if (s.p < s.e && *s.p == ',') { s.p++; continue; }
-            if (s.p < s.e && *s.p == ']') {
-                arr_close = (size_t)(s.p - body);
-                s.p++;
-                return true;
-            }
-            return s.fail();
-        }
+        return scan_array(h, s, body, false, &items, nullptr, &arr_open, &arr_close);
     });
     s.ws();
     if (!parsed || !s.ok || s.p != s.e) return fail(ACL_ERR_INVALID_ARGUMENT, "failed to parse list response: invalid JSON");
     if (!have_items || items.empty()) return unchanged(0);  // postfilter.go:26-35: nothing to filter, the body stays as it is
+    ms_scan = ms_since();
     // ---- resolve K x F pairs
     const std::string user = user_name ? user_name : "";
     std::vector<std::string> tpls(templates, templates + n_templates);
-    std::vector<RelText> rels;
-    std::vector<uint32_t> off(items.size() + 1, 0);
-    std::string text;
+    const size_t F = tpls.size();
+    std::vector<RelText> rels(items.size() * F);  // item i's resolved pairs: rels[i F ...], cnt[i] of them
+    std::vector<uint32_t> off(items.size() + 1, 0), cnt(items.size(), 0);
     // every item's template input is rules.NewResolveInput(input.Request, ...) (postfilter.go:88, rules.go:315-342): the item's own metadata first,
     // the REQUEST's name / namespace where the item has none, and no namespace at all for the `namespaces` resource (its requests carry the
     // namespace name in both fields)
     const std::string req_name = req && req->name ? req->name : "", req_ns = req && req->namespace_ ? req->namespace_ : "";
     const bool cluster_scoped = req && req->resource && std::strcmp(req->resource, "namespaces") == 0;
-    for (size_t i = 0; i < items.size(); i++) {
-        off[i] = (uint32_t)rels.size();
-        if (!items[i].is_object) continue;  // postfilter.go:68-71
-        if (items[i].name.empty()) items[i].name = req_name;
-        if (items[i].ns.empty()) items[i].ns = req_ns;
-        if (cluster_scoped) items[i].ns.clear();
-        for (const std::string &t : tpls) {
-            RelText r;
-            if (!render(t, items[i], user, &text) || !parse_relationship_text(text, &r)) continue;  // resolution failed: no check (postfilter.go:92-95)
-            rels.push_back(std::move(r));
+    host_parallel(h, items.size(), std::max<size_t>(256, items.size() / (8 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
+        std::string text;
+        for (size_t i = a; i < b; i++) {
+            if (!items[i].is_object) continue;  // postfilter.go:68-71
+            if (items[i].name.empty()) items[i].name = req_name;
+            if (items[i].ns.empty()) items[i].ns = req_ns;
+            if (cluster_scoped) items[i].ns.clear();
+            for (const std::string &t : tpls) {
+                RelText &r = rels[i * F + cnt[i]];
+                if (!render(t, items[i], user, &text) || !parse_relationship_text(text, &r)) continue;  // resolution failed: no check (postfilter.go:92-95)
+                cnt[i]++;
+            }
         }
-    }
-    off[items.size()] = (uint32_t)rels.size();
-    if (rels.empty()) return unchanged(items.size());  // postfilter.go:122-125
+    });
+    for (size_t i = 0; i < items.size(); i++) off[i + 1] = off[i] + cnt[i];
+    const size_t npairs = off[items.size()];
+    if (!npairs) return unchanged(items.size());  // postfilter.go:122-125
     // {pointer, length} views through acl_check_bulk_keep_v: a list filtered for ONE user by one template -- every pair shares type, permission and subject --
     // is answered by one reverse walk and K bit tests (engine.cpp keep_by_reverse_walk), any other shape by the forward path
-    std::vector<acl_check_item_v_t> ci(rels.size());
-    auto sv = [](const std::string &x) { return acl_str_t{x.data(), x.size()}; };
-    for (size_t k = 0; k < rels.size(); k++) {
-        ci[k] = acl_check_item_v_t{sv(rels[k].rtype), sv(rels[k].rid), sv(rels[k].rel), sv(rels[k].stype), sv(rels[k].sid), sv(rels[k].srel)};
-        if (rels[k].srel.empty()) ci[k].subject_relation = acl_str_t{nullptr, 0};
-    }
+    std::vector<acl_check_item_v_t> ci(npairs);
+    host_parallel(h, items.size(), std::max<size_t>(1024, items.size() / (4 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
+        auto sv = [](const std::string &x) { return acl_str_t{x.data(), x.size()}; };
+        for (size_t i = a; i < b; i++)
+            for (uint32_t j = 0; j < cnt[i]; j++) {
+                const RelText &r = rels[i * F + j];
+                acl_check_item_v_t &c = ci[off[i] + j];
+                c = acl_check_item_v_t{sv(r.rtype), sv(r.rid), sv(r.rel), sv(r.stype), sv(r.sid), sv(r.srel)};
+                if (r.srel.empty()) c.subject_relation = acl_str_t{nullptr, 0};
+            }
+    });
+    ms_resolve = ms_since();
     std::vector<uint8_t> keep(items.size());
     int rc = acl_check_bulk_keep_v(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
     if (rc) return rc;
+    ms_keep = ms_since();
     // ---- splice: the original bytes minus the dropped items (the reference appends to a nil slice, postfilter.go:142: with nothing allowed, "items" marshals as null)
     size_t kept = 0;
-    char *o = splice_kept(body, body_len, arr_open, arr_close, items, keep, "null", out_len, &kept);
+    char *o = splice_kept(h, body, body_len, arr_open, arr_close, items, keep, "null", out_len, &kept);
     if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
     *out_body = o;
     if (kept_out) *kept_out = kept;
     if (total_out) *total_out = items.size();
+    if (kTrace) std::fprintf(stderr, "list filter: %zu items, %.1f MB | scan %.2f ms | pairs resolved at %.2f | kept known at %.2f | spliced at %.2f (%zu kept)\n", items.size(), body_len / 1e6, ms_scan, ms_resolve, ms_keep, ms_since(), kept);
     return ACL_OK;
 }
 
@@ -435,7 +526,7 @@ int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, si
     auto unchanged = [&](uint64_t kept, uint64_t total) {
         char *o = (char *)std::malloc(std::max<size_t>(body_len, 1));
         if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
-        std::memcpy(o, body, body_len);
+        big_copy(h, o, body, body_len);
         *out_body = o;
         *out_len = body_len;
         if (kept_out) *kept_out = kept;
@@ -461,35 +552,7 @@ int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, si
                 return s.skip();
             }
             have = true;
-            items.clear();
-            decodable.clear();
-            arr_open = (size_t)(s.p - body);
-            s.p++;
-            s.ws();
-            if (s.p < s.e && *s.p == ']') {
-                arr_close = (size_t)(s.p - body);
-                s.p++;
-                return true;
-            }
-            for (;;) {
-                s.ws();
-                Item it;
-                bool dec = true;
-                const char *b0 = s.p;
-                if (!(kind == ACL_BODY_TABLE ? scan_row(s, &it, &dec) : scan_item(s, &it))) return false;
-                it.b = (size_t)(b0 - body);
-                it.e = (size_t)(s.p - body);
-                decodable.push_back(dec && it.is_object);
-                items.push_back(std::move(it));
-                s.ws();
-                if (s.p < s.e && *s.p == ',') { s.p++; continue; }
-                if (s.p < s.e && *s.p == ']') {
-                    arr_close = (size_t)(s.p - body);
-                    s.p++;
-                    return true;
-                }
-                return s.fail();
-            }
+            return scan_array(h, s, body, kind == ACL_BODY_TABLE, &items, &decodable, &arr_open, &arr_close);
         });
     }
     s.ws();
@@ -513,16 +576,41 @@ int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, si
         if (!decodable[i])
             return fail(ACL_ERR_INVALID_ARGUMENT, kind == ACL_BODY_TABLE ? "error decoding partial object metadata from table row" : "failed to decode response body: list item is not an object");
     std::vector<uint8_t> keep(items.size());
-    for (size_t i = 0; i < items.size(); i++) keep[i] = allowed(items[i]);
+    // (names_mu shared, then the pool: the order of the interning callers -- InternPool::run)
+    host_parallel(h, items.size(), std::max<size_t>(256, items.size() / (8 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
+        std::string idt;
+        for (size_t i = a; i < b; i++) {
+            uint32_t id;
+            keep[i] = render(tpl, items[i], std::string(), &idt) && ot.find(idt, &id) && (size_t)(id >> 5) < bitmap_words && ((bitmap[id >> 5] >> (id & 31u)) & 1u);
+        }
+    });
     nlk.unlock();
     // both consumers start from make([]T, 0): an array without survivors is [], not null (responsefilterer.go:358,375)
     size_t kept = 0;
-    char *o = items.empty() ? nullptr : splice_kept(body, body_len, arr_open, arr_close, items, keep, "[]", out_len, &kept);
+    char *o = items.empty() ? nullptr : splice_kept(h, body, body_len, arr_open, arr_close, items, keep, "[]", out_len, &kept);
     if (items.empty()) return unchanged(0, 0);
     if (!o) return fail(ACL_ERR_RESOURCE_EXHAUSTED, "out of host memory");
     *out_body = o;
     if (kept_out) *kept_out = kept;
     if (total_out) *total_out = items.size();
+    return ACL_OK;
+}
+
+// Test hook: the elements of the array at body[arr_open] (`[`) as the list filters find them -- chunk_bytes > 0: through the parallel index with chunks of
+// that size (tests/test_list_filter.py walks it over random documents with chunks of 64 bytes and up), 0: as a call of that size would.  spans_out: {begin, end}
+// per element (at most cap elements written), *n_out: elements found, *close_out: the `]`.  Touches no device and no store: any engine will do.
+int acl_selfcheck_json_array(acl_engine_t *h, const char *body, size_t body_len, size_t arr_open, size_t chunk_bytes, size_t *spans_out, size_t cap, size_t *n_out, size_t *close_out) {
+    if (!body || arr_open >= body_len || body[arr_open] != '[' || !n_out || !close_out || (cap && !spans_out)) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_selfcheck_json_array: bad argument");
+    Scanner s{body + arr_open, body + body_len};
+    std::vector<Item> items;
+    size_t ao = 0, ac = 0;
+    if (!scan_array(h, s, body, false, &items, nullptr, &ao, &ac, chunk_bytes) || !s.ok) return fail(ACL_ERR_INVALID_ARGUMENT, "invalid JSON");
+    for (size_t i = 0; i < items.size() && i < cap; i++) {
+        spans_out[2 * i] = items[i].b;
+        spans_out[2 * i + 1] = items[i].e;
+    }
+    *n_out = items.size();
+    *close_out = ac;
     return ACL_OK;
 }
 

@@ -175,3 +175,50 @@ def test_unchanged_and_invalid_bodies_need_no_gpu(aclgpu_lib):
         e.filter_list_response(b'{"items":[{"metadata":{"name":"p"}}]}', tpl, "u")
     assert ei.value.code == aclgpu.ERR_UNAVAILABLE
     e.close()
+
+
+def _random_value(rng, depth=0):
+    """JSON values whose strings are full of what a naive splitter trips over: quotes, backslash runs of every parity, brackets, commas."""
+    k = rng.random()
+    if depth > 4 or k < 0.35:
+        if rng.random() < 0.6:
+            pieces = ['"', "\\", "\\\\", '\\"', "{", "}", "[", "]", ",", ":", " ", "a", "é", "\n", "\t", "\\\\\\", '","', '"},{"', "x" * rng.randrange(0, 70)]
+            return "".join(rng.choice(pieces) for _ in range(rng.randrange(0, 12)))
+        return rng.choice([0, -1, 1.5e-7, True, False, None, 12345678901234])
+    if k < 0.7:
+        return {(str(_random_value(rng, 9)) + str(j) if rng.random() < 0.3 else f"k{j}"): _random_value(rng, depth + 1) for j in range(rng.randrange(0, 5))}
+    return [_random_value(rng, depth + 1) for _ in range(rng.randrange(0, 5))]
+
+
+def test_parallel_element_index_matches_a_json_decoder(aclgpu_lib):
+    """csrc/json_index.hpp through acl_selfcheck_json_array: the element spans of an `items` array found chunk by chunk (every chunk indexed under both
+    in-string hypotheses, escapes carried across 64-byte blocks and across chunks) must be exactly the elements json.loads sees -- chunk sizes from one
+    64-byte block up, documents whose strings hold quotes, backslash runs, brackets and commas, different separators and indentation; broken documents fail."""
+    import aclgpu
+    rng = random.Random(0x5ACE0115)
+    e = aclgpu.Engine(SCHEMA, store_only=True)
+    try:
+        for trial in range(160):
+            items = [_random_value(rng) for _ in range(rng.randrange(0, 40))]
+            if trial % 7 == 0:
+                items = [{"metadata": {"name": f"p{j}", "annotations": {"last-applied": json.dumps({"a": [1, {"b": "}]"}], "c": "\\"})}}, "spec": {"x": [j, [j]]}} for j in range(rng.randrange(1, 60))]
+            kw = rng.choice([dict(separators=(",", ":")), dict(), dict(indent=1), dict(separators=(" ,\n", " : ")), dict(ensure_ascii=False, separators=(",", ":"))])
+            doc = {"kind": "List", "note": 'tricky "[{" \\', "items": items, "tail": [1, {"z": "]"}]}
+            body = json.dumps(doc, **kw).encode()
+            arr_open = body.index(b'"items"') + len(b'"items"')
+            arr_open = body.index(b"[", arr_open)
+            want = [json.dumps(v, **kw).encode() for v in items]
+            for chunk in (64, 128, 192, 448, 4096, 0):
+                spans, close = e.selfcheck_json_array(body, arr_open, chunk)
+                got = [body[b:e_] for b, e_ in spans]
+                assert len(got) == len(want), (trial, chunk, len(got), len(want))
+                for g, w_ in zip(got, want):
+                    assert json.loads(g) == json.loads(w_) and g == g.strip(), (trial, chunk, g[:80])
+                assert body[close:close + 1] == b"]" and json.loads(b"[" + b",".join(got) + b"]") == items
+            # a document cut short, an element that is not a value, a stray separator: all refused, at every chunk size
+            for broken in (body[:max(arr_open + 1, len(body) // 2)], body[:arr_open + 1] + b"1,,2" + body[arr_open + 1:], body[:arr_open + 1] + b'{"a":tru},' + body[arr_open + 1:]):
+                for chunk in (64, 4096):
+                    with pytest.raises(aclgpu.AclError):
+                        e.selfcheck_json_array(broken, arr_open, chunk)
+    finally:
+        e.close()
