@@ -57,6 +57,19 @@ struct Scanner {
         if (p >= e || *p != '"') return fail();
         p++;
         for (;;) {
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+            // sixteen bytes at a time, straight to the first '"', '\\' or control character (keys and values of a kube response are 5-40 bytes: one or two steps)
+            while (e - p >= 16) {
+                const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p));
+                const __m128i special = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(c, _mm_set1_epi8('"')), _mm_cmpeq_epi8(c, _mm_set1_epi8('\\'))),
+                                                     _mm_cmpeq_epi8(_mm_max_epu8(c, _mm_set1_epi8(0x1F)), _mm_set1_epi8(0x1F)));  // (unsigned c <= 0x1F)
+                const int m = _mm_movemask_epi8(special);
+                const int k = m ? __builtin_ctz((unsigned)m) : 16;
+                if (out && k) out->append(p, (size_t)k);
+                p += k;
+                if (m) break;
+            }
+#endif
             // eight bytes at a time while none of them is '"', '\\' or a control character (most of a kube response is string content)
             while (e - p >= 8) {
                 uint64_t w;
@@ -181,8 +194,21 @@ struct Scanner {
         if (p < e && *p == '}') { p++; return true; }
         for (;;) {
             ws();
-            std::string key;
-            if (!string(&key)) return false;
+            // (the key in place when it has no escape: a list of 65 536 pods has a million keys at the levels that are looked at)
+            std::string decoded;
+            std::string_view key;
+            {
+                if (p >= e || *p != '"') return fail();
+                const char *q = p + 1;
+                while (q < e && *q != '"' && *q != '\\' && (unsigned char)*q >= 0x20) q++;
+                if (q < e && *q == '"') {
+                    key = std::string_view(p + 1, (size_t)(q - p - 1));
+                    p = q + 1;
+                } else {
+                    if (!string(&decoded)) return false;
+                    key = decoded;
+                }
+            }
             ws();
             if (p >= e || *p++ != ':') return fail();
             ws();
@@ -206,7 +232,7 @@ bool scan_item(Scanner &s, Item *it) {
     s.ws();
     if (s.p < s.e && *s.p == '{') {
         it->is_object = true;
-        return s.object([&](const std::string &k) {
+        return s.object([&](std::string_view k) {
             if (k != "metadata" || s.p >= s.e || *s.p != '{') {
                 if (k == "metadata") it->has_meta = false;  // a later non-object "metadata" replaces an earlier object
                 return s.skip();
@@ -214,7 +240,7 @@ bool scan_item(Scanner &s, Item *it) {
             it->has_meta = true;
             it->name.clear();
             it->ns.clear();
-            return s.object([&](const std::string &mk) {
+            return s.object([&](std::string_view mk) {
                 if ((mk == "name" || mk == "namespace") && s.p < s.e && *s.p == '"') {
                     std::string v;
                     if (!s.string(&v)) return false;
@@ -263,7 +289,7 @@ bool scan_row(Scanner &s, Item *it, bool *decodable) {
     s.ws();
     if (s.p >= s.e || *s.p != '{') return s.skip();
     it->is_object = true;
-    return s.object([&](const std::string &k) {
+    return s.object([&](std::string_view k) {
         if (k != "object") return s.skip();
         s.ws();
         Item inner;
@@ -331,13 +357,74 @@ char *splice_kept(acl_engine_t *h, const char *body, size_t body_len, size_t arr
     return o;
 }
 
+// A template cut into the six fields of `type:id#relation@type:id[#relation]` ONCE, at the separators its LITERAL text holds (the grammar of rules.go:1053-1055
+// splits at the first `:`, `#`, `@`, `:`, `#`): rendering it per item and parsing the text again gives the same six fields as long as no substituted value
+// holds a separator itself -- kube names and namespaces never do; a call in which one does takes the render-and-parse path for all its items.
+struct CompiledTemplate {
+    struct Seg {
+        int var;  // -1: literal text, 0 name, 1 namespace, 2 namespacedName, 3 user.name
+        std::string lit;
+    };
+    std::vector<Seg> field[6];
+    bool compile(const std::string &tpl) {
+        std::vector<Seg> segs;
+        size_t i = 0;
+        while (i < tpl.size()) {
+            const size_t o = tpl.find("{{", i);
+            if (o == std::string::npos) {
+                segs.push_back(Seg{-1, tpl.substr(i)});
+                break;
+            }
+            if (o > i) segs.push_back(Seg{-1, tpl.substr(i, o - i)});
+            const size_t c = tpl.find("}}", o + 2);
+            if (c == std::string::npos) return false;
+            std::string var = tpl.substr(o + 2, c - o - 2);
+            const size_t a = var.find_first_not_of(" \t"), z = var.find_last_not_of(" \t");
+            var = a == std::string::npos ? "" : var.substr(a, z - a + 1);
+            const int v = var == "name" ? 0 : var == "namespace" ? 1 : var == "namespacedName" ? 2 : var == "user.name" ? 3 : -1;
+            if (v < 0) return false;
+            segs.push_back(Seg{v, std::string()});
+            i = c + 2;
+        }
+        static const char kSep[5] = {':', '#', '@', ':', '#'};
+        int f = 0;
+        for (const Seg &sg : segs) {
+            if (sg.var >= 0) {
+                field[f].push_back(sg);
+                continue;
+            }
+            size_t from = 0;
+            while (f < 5) {
+                const size_t at = sg.lit.find(kSep[f], from);
+                if (at == std::string::npos) break;
+                if (at > from) field[f].push_back(Seg{-1, sg.lit.substr(from, at - from)});
+                from = at + 1;
+                f++;
+            }
+            if (from < sg.lit.size()) field[f].push_back(Seg{-1, sg.lit.substr(from)});
+        }
+        return f >= 4;  // (f == 4: no subject relation)
+    }
+    bool per_item(int f) const {
+        for (const Seg &sg : field[f])
+            if (sg.var >= 0 && sg.var != 3) return true;
+        return false;
+    }
+};
+inline bool has_separator(std::string_view v) {
+    for (char c : v)
+        if (c == ':' || c == '#' || c == '@') return true;
+    return false;
+}
+
 // The elements of the array that s.p stands at (`[`): their spans, their metadata (scan_item; table rows: scan_row) -- and s.p behind the array's `]`.
 // Small arrays: element by element.  From kParallelBytes on: the element spans by all host threads (json_index.hpp: every chunk indexed under both
 // in-string hypotheses, a sequential fix-up over the chunks), then every span scanned -- validated, its metadata taken -- in parallel.  Which bodies are JSON
 // does not change: an array is valid exactly when its spans are valid values separated by single commas, and the scanner decides that per span.
 constexpr size_t kParallelBytes = (size_t)1 << 19;
 bool scan_array(acl_engine_t *h, Scanner &s, const char *body, bool table, std::vector<Item> *items, std::vector<uint8_t> *decodable, size_t *arr_open, size_t *arr_close,
-                size_t chunk_bytes = 0) {
+                size_t chunk_bytes = 0, double *ms_index = nullptr) {
+    const auto t_0 = std::chrono::steady_clock::now();
     items->clear();
     if (decodable) decodable->clear();
     *arr_open = (size_t)(s.p - body);
@@ -382,6 +469,7 @@ bool scan_array(acl_engine_t *h, Scanner &s, const char *body, bool table, std::
     std::vector<jsonidx::Span> spans;
     if (!jsonidx::array_spans(chunks, region_b, &spans, arr_close)) return s.fail();
     chunks.clear();
+    if (ms_index) *ms_index = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count();
     auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; };
     for (jsonidx::Span &sp : spans) {
         while (sp.b < sp.e && is_ws(body[sp.b])) sp.b++;
@@ -439,7 +527,7 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     static const bool kTrace = getenv("ACL_DEBUG_LIST") != nullptr;  // (phase times of the call on stderr)
     const auto t_0 = std::chrono::steady_clock::now();
     auto ms_since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
-    double ms_scan = 0, ms_resolve = 0, ms_keep = 0;
+    double ms_scan = 0, ms_resolve = 0, ms_keep = 0, ms_index = 0;
     // ---- one scan: the top-level object's "items" array and its elements
     Scanner s{body, body + body_len};
     s.ws();
@@ -447,13 +535,13 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     bool have_items = false;
     size_t arr_open = 0, arr_close = 0;  // positions of '[' and ']'
     if (s.p >= s.e || *s.p != '{') return fail(ACL_ERR_INVALID_ARGUMENT, "failed to parse list response: not a JSON object");
-    const bool parsed = s.object([&](const std::string &k) {
+    const bool parsed = s.object([&](std::string_view k) {
         if (k != "items" || s.p >= s.e || *s.p != '[') {
             if (k == "items") have_items = false;
             return s.skip();
         }
         have_items = true;
-        return scan_array(h, s, body, false, &items, nullptr, &arr_open, &arr_close);
+        return scan_array(h, s, body, false, &items, nullptr, &arr_open, &arr_close, 0, &ms_index);
     });
     s.ws();
     if (!parsed || !s.ok || s.p != s.e) return fail(ACL_ERR_INVALID_ARGUMENT, "failed to parse list response: invalid JSON");
@@ -463,13 +551,94 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     const std::string user = user_name ? user_name : "";
     std::vector<std::string> tpls(templates, templates + n_templates);
     const size_t F = tpls.size();
-    std::vector<RelText> rels(items.size() * F);  // item i's resolved pairs: rels[i F ...], cnt[i] of them
-    std::vector<uint32_t> off(items.size() + 1, 0), cnt(items.size(), 0);
+    std::vector<uint32_t> off(items.size() + 1, 0);
+    std::vector<acl_check_item_v_t> ci;
     // every item's template input is rules.NewResolveInput(input.Request, ...) (postfilter.go:88, rules.go:315-342): the item's own metadata first,
     // the REQUEST's name / namespace where the item has none, and no namespace at all for the `namespaces` resource (its requests carry the
     // namespace name in both fields)
     const std::string req_name = req && req->name ? req->name : "", req_ns = req && req->namespace_ ? req->namespace_ : "";
     const bool cluster_scoped = req && req->resource && std::strcmp(req->resource, "namespaces") == 0;
+    // ---- the usual call: every template cut into its six fields once, the per-item fields rendered straight into the views' bytes
+    std::vector<CompiledTemplate> ct(F);
+    std::vector<std::array<std::string, 6>> cst(F);  // the fields that do not depend on the item
+    std::vector<std::unique_ptr<char[]>> arenas;
+    std::mutex arenas_mu;
+    std::vector<std::array<bool, 6>> varies(F);      // ... and the ones that do
+    bool compiled = F > 0 && !has_separator(user);
+    for (size_t t = 0; t < F && compiled; t++) {
+        compiled = ct[t].compile(tpls[t]);
+        for (int f = 0; f < 6 && compiled; f++) {
+            varies[t][f] = ct[t].per_item(f);
+            if (!varies[t][f])
+                for (const auto &sg : ct[t].field[f]) cst[t][f] += sg.var == 3 ? user : sg.lit;
+        }
+    }
+    if (compiled) {
+        for (size_t i = 0; i < items.size(); i++) off[i + 1] = off[i] + (items[i].is_object ? (uint32_t)F : 0u);
+        ci.resize(off[items.size()]);
+        std::atomic<bool> odd{false};
+        host_parallel(h, items.size(), std::max<size_t>(256, items.size() / (8 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
+            static const std::string kNone;
+            auto value = [&](const Item &it, int var, char *w) -> size_t {  // bytes of a variable (written at w when not null)
+                const std::string *nm = it.name.empty() ? &req_name : &it.name, *ns = cluster_scoped ? &kNone : (it.ns.empty() ? &req_ns : &it.ns);
+                auto put = [&](const std::string &x, size_t at) {
+                    if (w) std::memcpy(w + at, x.data(), x.size());
+                    return x.size();
+                };
+                if (var == 0) return put(*nm, 0);
+                if (var == 1) return put(*ns, 0);
+                if (var == 3) return put(user, 0);
+                if (ns->empty()) return put(*nm, 0);
+                const size_t n = put(*ns, 0);
+                if (w) w[n] = '/';
+                return n + 1 + put(*nm, n + 1);
+            };
+            size_t bytes = 0;
+            for (size_t i = a; i < b; i++) {
+                if (!items[i].is_object) continue;  // postfilter.go:68-71
+                const std::string &nm = items[i].name.empty() ? req_name : items[i].name, &ns = items[i].ns.empty() ? req_ns : items[i].ns;
+                if (has_separator(nm) || (!cluster_scoped && has_separator(ns))) {
+                    odd.store(true, std::memory_order_relaxed);
+                    return;
+                }
+                for (size_t t = 0; t < F; t++)
+                    for (int f = 0; f < 6; f++)
+                        if (varies[t][f])
+                            for (const auto &sg : ct[t].field[f]) bytes += sg.var < 0 ? sg.lit.size() : value(items[i], sg.var, nullptr);
+            }
+            std::unique_ptr<char[]> arena(new char[std::max<size_t>(bytes, 1)]);
+            char *w = arena.get();
+            for (size_t i = a; i < b; i++) {
+                if (!items[i].is_object) continue;
+                for (size_t t = 0; t < F; t++) {
+                    acl_str_t fld[6];
+                    for (int f = 0; f < 6; f++) {
+                        if (!varies[t][f]) {
+                            fld[f] = acl_str_t{cst[t][f].data(), cst[t][f].size()};
+                            continue;
+                        }
+                        char *const f0 = w;
+                        for (const auto &sg : ct[t].field[f]) {
+                            if (sg.var < 0) {
+                                std::memcpy(w, sg.lit.data(), sg.lit.size());
+                                w += sg.lit.size();
+                            } else w += value(items[i], sg.var, w);
+                        }
+                        fld[f] = acl_str_t{f0, (size_t)(w - f0)};
+                    }
+                    if (fld[5].n == 0) fld[5] = acl_str_t{nullptr, 0};
+                    ci[off[i] + t] = acl_check_item_v_t{fld[0], fld[1], fld[2], fld[3], fld[4], fld[5]};
+                }
+            }
+            std::lock_guard<std::mutex> lk(arenas_mu);
+            arenas.push_back(std::move(arena));
+        });
+        if (odd.load()) compiled = false;  // (a name with a separator in it: the text decides, for every item)
+    }
+    std::vector<RelText> rels;
+    if (!compiled) {
+    rels.resize(items.size() * F);
+    std::vector<uint32_t> cnt(items.size(), 0);  // item i's resolved pairs: rels[i F ...], cnt[i] of them
     host_parallel(h, items.size(), std::max<size_t>(256, items.size() / (8 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
         std::string text;
         for (size_t i = a; i < b; i++) {
@@ -489,7 +658,7 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     if (!npairs) return unchanged(items.size());  // postfilter.go:122-125
     // {pointer, length} views through acl_check_bulk_keep_v: a list filtered for ONE user by one template -- every pair shares type, permission and subject --
     // is answered by one reverse walk and K bit tests (engine.cpp keep_by_reverse_walk), any other shape by the forward path
-    std::vector<acl_check_item_v_t> ci(npairs);
+    ci.assign(npairs, acl_check_item_v_t{});
     host_parallel(h, items.size(), std::max<size_t>(1024, items.size() / (4 * (size_t)host_threads(h))), [&](size_t a, size_t b) {
         auto sv = [](const std::string &x) { return acl_str_t{x.data(), x.size()}; };
         for (size_t i = a; i < b; i++)
@@ -500,6 +669,8 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
                 if (r.srel.empty()) c.subject_relation = acl_str_t{nullptr, 0};
             }
     });
+    }
+    if (ci.empty()) return unchanged(items.size());  // postfilter.go:122-125
     ms_resolve = ms_since();
     std::vector<uint8_t> keep(items.size());
     int rc = acl_check_bulk_keep_v(h, ci.data(), ci.size(), off.data(), items.size(), keep.data());
@@ -512,7 +683,7 @@ int acl_filter_list_response_req(acl_engine_t *h, const char *body, size_t body_
     *out_body = o;
     if (kept_out) *kept_out = kept;
     if (total_out) *total_out = items.size();
-    if (kTrace) std::fprintf(stderr, "list filter: %zu items, %.1f MB | scan %.2f ms | pairs resolved at %.2f | kept known at %.2f | spliced at %.2f (%zu kept)\n", items.size(), body_len / 1e6, ms_scan, ms_resolve, ms_keep, ms_since(), kept);
+    if (kTrace) std::fprintf(stderr, "list filter: %zu items, %.1f MB | element spans at %.2f ms | elements scanned at %.2f | pairs resolved at %.2f | kept known at %.2f | spliced at %.2f (%zu kept)\n", items.size(), body_len / 1e6, ms_index, ms_scan, ms_resolve, ms_keep, ms_since(), kept);
     return ACL_OK;
 }
 
@@ -546,7 +717,7 @@ int acl_prefilter_response(acl_engine_t *h, int type, const uint32_t *bitmap, si
         parsed = scan_item(s, &single);
     } else {
         const char *const key = kind == ACL_BODY_TABLE ? "rows" : "items";
-        parsed = s.object([&](const std::string &k) {
+        parsed = s.object([&](std::string_view k) {
             if (k != key || s.p >= s.e || *s.p != '[') {
                 if (k == key) have = false;
                 return s.skip();

@@ -125,15 +125,19 @@ def test_matches_reference_algorithm_on_random_lists(aclgpu_lib):
             e.write([(aclgpu.OP_TOUCH, r) for r in rels[i:i + 500]])
         pod_ids = [r[1] for r in rels if r[0] == "pod" and r[2] == "namespace"]
         weird = [7, "str", None, {"no": "metadata"}, {"metadata": "not-an-object"}, {"metadata": {"name": 5}}, {"metadata": {"name": "qé\"x\\y", "namespace": "ns1"}},
-                 {"metadata": {"name": "dup", "namespace": "ns0"}, "spec": {"containers": [{"image": "a:b", "ports": [1, 2.5, -3e2]}], "x": [[], {}, [[]]]}}]
-        for trial in range(40):
+                 {"metadata": {"name": "dup", "namespace": "ns0"}, "spec": {"containers": [{"image": "a:b", "ports": [1, 2.5, -3e2]}], "x": [[], {}, [[]]]}},
+                 {"metadata": {"name": "a:b", "namespace": "ns1"}}, {"metadata": {"name": "x#view@user:u1", "namespace": "ns2"}}]  # (names that hold the grammar's separators)
+        for trial in range(44):
             items = []
-            for _ in range(rng.randrange(0, 60)):
+            # (the last trials are long lists of padded items: bodies of 1-2 MB, which take the parallel element index and the parallel resolve / splice)
+            for k in range(rng.randrange(0, 60) if trial < 40 else 2500):
                 if rng.random() < 0.15:
                     items.append(rng.choice(weird))
                 else:
                     ns, name = rng.choice(pod_ids).split("/")
                     items.append({"metadata": {"name": name, "namespace": ns, "labels": {"a": "b"}}, "status": {"phase": "Running"}})
+                    if trial >= 40:
+                        items[-1]["spec"] = {"pad": "x\\\"}],[{" * (k % 7) + "y" * 400}
             doc = {"kind": "PodList", "metadata": {"resourceVersion": str(trial)}, "items": items, "apiVersion": "v1"}
             body = json.dumps(doc, indent=rng.choice([None, 1]), ensure_ascii=rng.random() < 0.5).encode()
             tpls = rng.choice([["pod:{{namespacedName}}#view@user:{{user.name}}"], ["pod:{{namespacedName}}#view@user:{{user.name}}", "pod:{{namespacedName}}#edit@user:{{user.name}}"],
