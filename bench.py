@@ -1058,8 +1058,90 @@ def postfilter_c3_leg(local_rank):
                              "calls_answered_by_the_reverse_walk": int(eng.stats()["keep_route_calls"] - before), "forward_by_id_decisions_per_s": m / float(np.mean(tf)),
                              "forward_by_id_p50_ms": 1e3 * float(np.median(tf)), "answers_equal_forward": same}
     out["answers_equal_forward"] = ok_all
+    out["list_level"] = list_level_leg(eng, w, 10000)
     eng.close()
     return out
+
+
+def pod_json(full_name, k):
+    """A pod as a kube list response carries it, trimmed to ~2 KB: metadata with labels / annotations / ownerReferences / managedFields, a container, status."""
+    ns, name = full_name.split("/", 1)
+    return {"apiVersion": "v1", "kind": "Pod",
+            "metadata": {"annotations": {"kubernetes.io/config.seen": "2026-01-01T00:00:00.000000000Z", "checksum/config": "%064x" % (k * 2654435761)},
+                         "creationTimestamp": "2026-01-01T00:00:00Z", "generateName": name.rsplit("-", 1)[0] + "-",
+                         "labels": {"app": "web", "pod-template-hash": "%010x" % k, "tier": "frontend \\ \"quoted\""}, "name": name, "namespace": ns,
+                         "ownerReferences": [{"apiVersion": "apps/v1", "blockOwnerDeletion": True, "controller": True, "kind": "ReplicaSet", "name": "web-%x" % k,
+                                              "uid": "00000000-0000-4000-8000-%012x" % k}],
+                         "managedFields": [{"apiVersion": "v1", "fieldsType": "FieldsV1", "fieldsV1": {"f:metadata": {"f:labels": {".": {}, "f:app": {}}}, "f:spec": {"f:containers": {}}},
+                                            "manager": "kube-controller-manager", "operation": "Update", "time": "2026-01-01T00:00:00Z"}],
+                         "resourceVersion": str(1000000 + k), "uid": "11111111-0000-4000-8000-%012x" % k},
+            "spec": {"containers": [{"image": "registry.example/web:1.%d" % (k % 50), "imagePullPolicy": "IfNotPresent", "name": "web",
+                                     "ports": [{"containerPort": 8080, "protocol": "TCP"}], "resources": {"limits": {"cpu": "500m", "memory": "256Mi"}, "requests": {"cpu": "100m", "memory": "128Mi"}},
+                                     "env": [{"name": "POD_NAME", "valueFrom": {"fieldRef": {"apiVersion": "v1", "fieldPath": "metadata.name"}}}],
+                                     "terminationMessagePath": "/dev/termination-log", "terminationMessagePolicy": "File"}],
+                     "dnsPolicy": "ClusterFirst", "nodeName": "node-%d" % (k % 97), "restartPolicy": "Always", "schedulerName": "default-scheduler", "serviceAccountName": "default",
+                     "tolerations": [{"effect": "NoExecute", "key": "node.kubernetes.io/not-ready", "operator": "Exists", "tolerationSeconds": 300}]},
+            "status": {"conditions": [{"lastTransitionTime": "2026-01-01T00:00:05Z", "status": "True", "type": t} for t in ("Initialized", "Ready", "ContainersReady", "PodScheduled")],
+                       "hostIP": "10.0.%d.%d" % (k % 250, k % 199), "phase": "Running", "podIP": "10.244.%d.%d" % (k % 250, k % 251), "qosClass": "Burstable", "startTime": "2026-01-01T00:00:01Z"}}
+
+
+def list_level_leg(eng, w, m, calls=15):
+    """The filters on the BYTES of a kube list response: acl_filter_list_response = filterListResponse (postfilter.go:17-55: decode the
+    list, K checks for the requesting user, re-encode) and acl_prefilter_response = filterList (responsefilterer.go:376-400) over a LookupResources bitmap, for a
+    PodList of m pods (~2 KB each) of the named graph and its first power user.  The engine finds the items' spans with all host threads, validates and resolves
+    them in parallel and splices the kept ones' original bytes (csrc/engine_list.cpp, json_index.hpp); generic_*: python's json (C, one thread) decoding and
+    re-encoding the same body, which is what the reference does around its one CheckBulkPermissions with encoding/json."""
+    import ctypes as C
+    import json as js
+    rt, perm_name, st = w.check
+    names = w.names
+    m = min(m, len(w.res))
+    res = w.res[:m]
+    u = int(w.lookup_subjects[0]) if getattr(w, "lookup_subjects", None) is not None else int(w.subj[0])
+    uname = names[st][u]
+    body = js.dumps({"apiVersion": "v1", "kind": "PodList", "metadata": {"resourceVersion": "123456"}, "items": [pod_json(names[rt][int(r_)], k) for k, r_ in enumerate(res)]},
+                    separators=(",", ":")).encode()
+    t1 = time.perf_counter()
+    doc = js.loads(body)
+    t_dec = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    js.dumps(doc, separators=(",", ":"))
+    t_enc = time.perf_counter() - t1
+    del doc
+    tp, te = eng.check_bulk_ids(eng.make_items(rt, perm_name, res, st, "", np.full(m, u, dtype=np.uint32)))
+    want = (tp == 2) & (te == 0)
+    template = f"{rt}:{{{{namespacedName}}}}#{perm_name}@{st}:{{{{user.name}}}}"
+    out, kept, total = eng.filter_list_response(body, [template], uname)
+    kept_names = [it["metadata"]["namespace"] + "/" + it["metadata"]["name"] for it in (js.loads(out)["items"] or [])]
+    ok = bool(kept == int(want.sum()) and total == m and kept_names == [names[rt][int(r_)] for r_, k_ in zip(res, want) if k_])
+    arr = (C.c_char_p * 1)(template.encode())
+    outp, outn, k_, t_ = C.c_void_p(), C.c_size_t(), C.c_uint64(), C.c_uint64()
+    ts = []
+    for _ in range(calls):  # (the C call: the Python mirror's copy of the output body is the harness's)
+        t1 = time.perf_counter()
+        rc = eng._L.acl_filter_list_response(eng._h, body, len(body), arr, 1, uname.encode(), C.byref(outp), C.byref(outn), C.byref(k_), C.byref(t_))
+        ts.append(time.perf_counter() - t1)
+        eng._L.acl_free(outp)
+        if rc:
+            raise SystemExit("acl_filter_list_response failed")
+    bms, _cnt = eng.lookup_ids_batch(rt, perm_name, st, "", [u])
+    bm = np.ascontiguousarray(bms[0], dtype=np.uint32)
+    out2, kept2, _total2 = eng.prefilter_response(rt, bm, "{{namespacedName}}", eng.BODY_LIST, body)
+    tq = []
+    for _ in range(calls):
+        t1 = time.perf_counter()
+        rc = eng._L.acl_prefilter_response(eng._h, eng.type_id(rt), bm.ctypes.data, bm.size, b"{{namespacedName}}", eng.BODY_LIST, body, len(body), C.byref(outp), C.byref(outn),
+                                           C.byref(k_), C.byref(t_))
+        tq.append(time.perf_counter() - t1)
+        eng._L.acl_free(outp)
+        if rc:
+            raise SystemExit("acl_prefilter_response failed")
+    return {"items": m, "body_MB": len(body) / 1e6, "kept": int(want.sum()), "user": "power user",
+            "postfilter": {"p50_ms": 1e3 * float(np.median(ts)), "items_per_s": m / float(np.median(ts)), "body_GB_per_s": len(body) / float(np.median(ts)) / 1e9, "kept_equal_id_path": ok},
+            "prefilter": {"p50_ms": 1e3 * float(np.median(tq)), "items_per_s": m / float(np.median(tq)), "body_GB_per_s": len(body) / float(np.median(tq)) / 1e9,
+                          "body_equal_postfilter": bool(out2 == out and kept2 == kept)},
+            "generic_decode_ms": 1e3 * t_dec, "generic_encode_ms": 1e3 * t_enc,
+            "note": "bytes of a PodList in, filtered bytes out (postfilter.go:17-55 / responsefilterer.go:376-400); generic_* = python json.loads / json.dumps of the same body, one thread"}
 
 
 def aclgpu_item_dtype():

@@ -34,26 +34,7 @@ rt, perm_name, st = w.check
 names = w.names
 
 
-def pod_json(full_name, k):
-    """A pod as `kubectl get pods -o json` lists it, trimmed to ~1.6 KB: metadata with labels / annotations / ownerReferences / managedFields, a container, status."""
-    ns, name = full_name.split("/", 1)
-    return {"apiVersion": "v1", "kind": "Pod",
-            "metadata": {"annotations": {"kubernetes.io/config.seen": "2026-01-01T00:00:00.000000000Z", "checksum/config": "%064x" % (k * 2654435761)},
-                         "creationTimestamp": "2026-01-01T00:00:00Z", "generateName": name.rsplit("-", 1)[0] + "-",
-                         "labels": {"app": "web", "pod-template-hash": "%010x" % k, "tier": "frontend \\ \"quoted\""}, "name": name, "namespace": ns,
-                         "ownerReferences": [{"apiVersion": "apps/v1", "blockOwnerDeletion": True, "controller": True, "kind": "ReplicaSet", "name": "web-%x" % k,
-                                              "uid": "00000000-0000-4000-8000-%012x" % k}],
-                         "managedFields": [{"apiVersion": "v1", "fieldsType": "FieldsV1", "fieldsV1": {"f:metadata": {"f:labels": {".": {}, "f:app": {}}}, "f:spec": {"f:containers": {}}},
-                                            "manager": "kube-controller-manager", "operation": "Update", "time": "2026-01-01T00:00:00Z"}],
-                         "resourceVersion": str(1000000 + k), "uid": "11111111-0000-4000-8000-%012x" % k},
-            "spec": {"containers": [{"image": "registry.example/web:1.%d" % (k % 50), "imagePullPolicy": "IfNotPresent", "name": "web",
-                                     "ports": [{"containerPort": 8080, "protocol": "TCP"}], "resources": {"limits": {"cpu": "500m", "memory": "256Mi"}, "requests": {"cpu": "100m", "memory": "128Mi"}},
-                                     "env": [{"name": "POD_NAME", "valueFrom": {"fieldRef": {"apiVersion": "v1", "fieldPath": "metadata.name"}}}],
-                                     "terminationMessagePath": "/dev/termination-log", "terminationMessagePolicy": "File"}],
-                     "dnsPolicy": "ClusterFirst", "nodeName": "node-%d" % (k % 97), "restartPolicy": "Always", "schedulerName": "default-scheduler", "serviceAccountName": "default",
-                     "tolerations": [{"effect": "NoExecute", "key": "node.kubernetes.io/not-ready", "operator": "Exists", "tolerationSeconds": 300}]},
-            "status": {"conditions": [{"lastTransitionTime": "2026-01-01T00:00:05Z", "status": "True", "type": t} for t in ("Initialized", "Ready", "ContainersReady", "PodScheduled")],
-                       "hostIP": "10.0.%d.%d" % (k % 250, k % 199), "phase": "Running", "podIP": "10.244.%d.%d" % (k % 250, k % 251), "qosClass": "Burstable", "startTime": "2026-01-01T00:00:01Z"}}
+pod_json = bench.pod_json
 
 
 template = f"{rt}:{{{{namespacedName}}}}#{perm_name}@{st}:{{{{user.name}}}}"
