@@ -171,3 +171,40 @@ def test_string_scanning_fast_path_decodes_what_json_decodes(eng):
         with pytest.raises(Exception) as x:  # a raw control character, an unknown escape, an unterminated string: invalid JSON
             eng.prefilter_response("pod", bm, "{{name}}", eng.BODY_LIST, bad)
         assert x.value.code == 3
+
+
+def test_big_lists_and_tables_take_the_parallel_scan_and_match_the_reference(eng):
+    """Bodies beyond 512 KB: the element spans come from the parallel index (csrc/json_index.hpp), every element is scanned, tested and spliced by the pool's
+    threads -- lists and TABLES (scan_row), with strings that hold quotes, backslashes and brackets, against the same restated consumers; the bitmap test of
+    a long name list (acl_bitmap_test_names) against the set."""
+    rng = random.Random(11)
+    pods = [f"ns{n}/pod-{i}" for n in range(8) for i in range(500)]
+    for p in pods:
+        eng.intern("pod", p)
+    for trial in range(3):
+        allowed_ids = rng.sample(pods, rng.randrange(1, len(pods)))
+        bm = bitmap_of(eng, "pod", allowed_ids)
+        allowed = allowed_set(allowed_ids, split=True)
+        names = [rng.choice(pods) for _ in range(3500)] + [f"ns9/never-{trial}"]
+        items = []
+        for k, rid in enumerate(names):
+            ns, _, name = rid.partition("/")
+            items.append({"kind": "Pod", "metadata": {"name": name, "namespace": ns, "annotations": {"cfg": json.dumps({"a": ["}", "]", "\\", k]}), "pad": "z" * (300 + k % 64)}},
+                          "spec": {"containers": [{"name": "c", "args": ["{", "]", "\\\"", ","]}]}})
+        list_body = json.dumps({"kind": "PodList", "apiVersion": "v1", "metadata": {"resourceVersion": "1"}, "items": items}, indent=None if trial else 1).encode()
+        assert len(list_body) > (1 << 20)
+        out, kept, total = eng.prefilter_response("pod", bm, "{{namespacedName}}", eng.BODY_LIST, list_body)
+        want = reference_filter(list_body, allowed, "list")
+        assert json.loads(out) == want and kept == len(want["items"]) and total == len(items)
+        rows = [{"cells": [it["metadata"]["name"], "1/1"], "object": {"kind": "PartialObjectMetadata", "metadata": it["metadata"]}} for it in items]
+        table_body = json.dumps({"kind": "Table", "columnDefinitions": [{"name": "Name"}], "rows": rows}).encode()
+        out, kept, total = eng.prefilter_response("pod", bm, "{{namespacedName}}", eng.BODY_TABLE, table_body)
+        want = reference_filter(table_body, allowed, "table")
+        assert json.loads(out) == want and kept == len(want["rows"]) and total == len(rows)
+        got = eng.bitmap_test_names("pod", bm, names)
+        assert got.tolist() == [tuple(n.split("/", 1)) in allowed for n in names]
+        # one broken element in the middle of a big body fails the call as it fails a small one
+        broken = list_body.replace(b'"kind": "Pod"', b'"kind": Pod', 1) if b'"kind": "Pod"' in list_body else list_body.replace(b'"kind":"Pod"', b'"kind":Pod', 1)
+        with pytest.raises(Exception) as x:
+            eng.prefilter_response("pod", bm, "{{namespacedName}}", eng.BODY_LIST, broken)
+        assert x.value.code == 3
