@@ -52,7 +52,7 @@ definition pod {
 
 
 def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: int = 25, universe: int = 1, compact_early: bool = False, schema: str = "c4",
-        recycle: bool = False) -> dict:
+        recycle: bool = False, acyclic: bool = False) -> dict:
     import aclgpu
     from aclgpu import workloads
     from oracle import orc
@@ -84,6 +84,9 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
             if k == 7: return f"pod:{rng.choice(pods)}#banned@user:*" if rng.random() < 0.2 else f"pod:{rng.choice(pods)}#banned@user:{rng.choice(users)}"
             return f"pod:{rng.choice(pods)}#viewer@group:{rng.choice(groups)}#active"
         k = rng.randrange(9)
+        if k == 0 and acyclic:  # (--acyclic: a group only holds groups behind it in the list -- no Check ends at the depth limit, one-user calls take the reverse walk)
+            i, j = sorted(rng.sample(range(len(groups)), 2))
+            return f"group:{groups[i]}#member@group:{groups[j]}#member"
         if k == 0: return f"group:{rng.choice(groups)}#member@group:{rng.choice(groups)}#member"   # (cycles welcome)
         if k == 1: return f"group:{rng.choice(groups)}#member@user:{rng.choice(users)}"
         if k == 2: return f"pod:{(p := rng.choice(pods))}#namespace@namespace:{p.split('/')[0] if rng.random() < 0.8 else rng.choice(nss)}"
@@ -162,6 +165,23 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
             assert n1 == n2, f"step {step}: delete_by_filter {f}: oracle removed {n1}, engine {n2}"
             live = set(f"{a}:{b}#{c}@{d}:{x}" + (f"#{y}" if y else "") for t in ("group", "namespace", "pod") for a, b, c, d, x, y, _ in o.read(rtype=t))
             stats["filter_deletes"] += 1
+        elif r < 0.56 and not combine:  # ---- PostFilter's shape: ONE user's pairs -- CheckBulkPermissions itself twice (the second call may sweep the type for depth
+            # errors and take the reverse walk: engine.cpp no_object_is_deep; with a cycle behind some resource the calls stay forward and carry its depth errors),
+            # then the keep mask of the same pairs.  Every permissionship, every error and every keep byte against the oracle.
+            rt, perm, ids = rng.choice([("pod", "view", pods), ("namespace", "view", nss), ("group", "member", groups)])
+            u = rng.choice(users) if rng.random() < 0.9 else "stranger"
+            k_ = rng.choice([520, 900, 2500])
+            qs = [(rt, rng.choice(ids) if rng.random() < 0.98 else "n0/ghost", perm, "user", u, "") for _ in range(k_)]
+            want = {q: o.check(*q) for q in set(qs)}
+            for rep in range(2):
+                perms, errs = e.check_bulk(qs)
+                for i, q in enumerate(qs):
+                    assert (perms[i], errs[i]) == tuple(want[q]), f"step {step}: one-user check {q} (item {i} of {k_}, call {rep}): engine {(perms[i], errs[i])}, oracle {want[q]}"
+            keep = e.check_bulk_keep(qs, list(range(k_ + 1)))
+            for i, q in enumerate(qs):
+                assert bool(keep[i]) == (tuple(want[q]) == (2, 0)), f"step {step}: keep mask of {q} (item {i}): engine {keep[i]}, oracle {want[q]}"
+            stats["checks"] += 3 * k_
+            stats["one_user_calls"] = stats.get("one_user_calls", 0) + 3
         elif r < 0.85:  # ---- a Check batch
             n = rng.choice([1, 1, 7, 64, 64, 900, 5000, big if step % 7 == 3 else 3000])
             qs = [rand_query() for _ in range(min(n, 6000))]
@@ -207,7 +227,7 @@ def run(seed: int, steps: int, big: int = 70000, verbose: bool = True, burst: in
         if verbose and step % 50 == 49:
             print(f"step {step + 1}/{steps}: {stats}, {len(live)} relationships, {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
     st = e.stats()
-    stats.update({k: int(st[k]) for k in ("snapshot_builds", "snapshot_patches", "snapshot_compactions", "local_passes", "rev_local_passes", "ids_recycled") if k in st})
+    stats.update({k: int(st[k]) for k in ("snapshot_builds", "snapshot_patches", "snapshot_compactions", "local_passes", "rev_local_passes", "ids_recycled", "keep_route_calls", "depth_sweeps") if k in st})
     e.close()
     return stats
 
@@ -361,11 +381,12 @@ if __name__ == "__main__":
     ap.add_argument("--expiry", action="store_true", help="the other campaign: the reference's bootstrap schema, dual-write shapes, expiring idempotency keys, a moving clock")
     ap.add_argument("--schema", choices=["c4", "combine"], default="c4", help="combine: the C4 schema with exclusions, intersections, wildcards and a non-monotone userset subject")
     ap.add_argument("--recycle", action="store_true", help="ACL_ID_QUARANTINE_MS=0 and a stream of never-seen object names in the writes: ids of objects that lost their last relationship are taken over under the reads")
+    ap.add_argument("--acyclic", action="store_true", help="group nesting without cycles: one-user CheckBulkPermissions calls take the reverse walk once the depth sweep has run")
     ap.add_argument("--universe", type=int, default=1, help="scale of the object universe (x 160 users, 48 groups, 8 namespaces, 240 pods)")
     a = ap.parse_args()
     try:
         print(run_patcher(a.seed, a.steps, a.universe, a.burst, schema=a.schema) if a.patcher else run_expiry(a.seed, a.steps) if a.expiry
-              else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early, schema=a.schema, recycle=a.recycle))
+              else run(a.seed, a.steps, burst=a.burst, universe=a.universe, compact_early=a.compact_early, schema=a.schema, recycle=a.recycle, acyclic=a.acyclic))
     except AssertionError as x:
         print("MISMATCH:", x)
         sys.exit(1)

@@ -19,13 +19,15 @@ P
 python tools/rocprof_summary.py r06_bench_stats "$(find $R/gpurun_out/prof/r06_bench_stats -name '*.db' | head -1)" --workload "bench.py --steps 5 --no-cpu (every leg)" --steps 5 --kernel k_check_local --items 262144 --out $O > /dev/null 2>&1
 ls $O
 {
-echo "# tools/runs/gpu_r06_final.sh: the differential fuzz on a live graph on the round-6 code (marked-through reverse relations, strict lookups, the entry prefetch), then the stress harness"
+echo "# tools/runs/gpu_r06_final.sh: the differential fuzz on a live graph on the round-6 code (marked-through reverse relations, strict lookups, the entry prefetch; seeds 81 / 83: one user's pairs through CheckBulkPermissions twice + the keep mask -- with cycles the calls stay forward, --acyclic they take the reverse walk after the depth sweep), then the stress harness"
 run() { echo "== $*"; timeout 900 python tools/fuzz_gpu.py "$@" 2>&1 | tail -1 | cut -c1-700; }
 run --seed 71 --steps 600 --recycle
 run --seed 72 --steps 500 --recycle --compact-early
 run --seed 73 --steps 500 --recycle --schema combine
 run --seed 75 --steps 150 --recycle --burst 300 --universe 3
 run --seed 78 --steps 600 --expiry
+run --seed 81 --steps 400 --recycle
+run --seed 83 --steps 500 --recycle --acyclic
 } > $O/fuzz.txt 2>&1
 tail -6 $O/fuzz.txt | cut -c1-300
 g++ -O2 -std=c++17 tools/engine_stress.cpp -Iinclude -Lspicedb-kubeapi-proxy_amd/lib -laclgpu -lpthread -Wl,-rpath,$R/spicedb-kubeapi-proxy_amd/lib -o /tmp/engine_stress
@@ -35,3 +37,4 @@ python tools/keep_route_probe.py > $O/keep.txt 2>/dev/null
 ACL_DEBUG_KEEP=1 python tools/keep_route_probe.py --calls 10 --sizes 65536 2>&1 | grep "keep route" | awk "NR%4==0" > $O/keep_trace.txt
 python tools/string_cold_probe.py > $O/string_cold.txt 2>/dev/null
 cat $O/keep.txt | cut -c1-150; cat $O/string_cold.txt
+python tools/list_filter_probe.py --calls 10 > $O/list_filter.txt 2>/dev/null; cut -c1-260 $O/list_filter.txt | grep -E '^[0-9]'
