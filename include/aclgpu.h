@@ -289,7 +289,8 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * every template is resolved for the requesting user).  When every pair of the call shares (resource type, permission, subject) -- a plain subject, a
  * permission without `&` / `-` -- the call is answered by ONE reverse walk from that subject (the LookupResources kernel) and K bit tests: the pairs' resource
  * names are hashed and tested against the few ALLOWED names first, so a name the user may not see never touches the type's name table (the string path's
- * cost is that table: one DRAM miss per name).  Any other call -- subjects or permissions that differ, a userset subject, an item the API would refuse --
+ * cost is that table: one DRAM miss per name).  K items x F templates (every item F pairs, pair j from template j, F = 2 ... 4): one walk per template under one
+ * evaluation, an item kept when every template keeps it.  Any other call -- subjects or permissions that differ, a userset subject, an item the API would refuse --
  * takes the forward path; the keep mask and the call's error are the same either way (tests/test_callers_gpu.py compares the two routes and the oracle).
  * acl_check_bulk / _v / _packed (CheckBulkPermissions itself, what the unpatched proxy's PostFilter sends) take the same walk for one subject's pairs where no Check
  * of the permission can end at the dispatch-depth limit -- by the schema (no recursion), or, for a recursive permission, on the snapshot at hand: one forward

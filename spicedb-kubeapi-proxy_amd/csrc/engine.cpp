@@ -1582,7 +1582,7 @@ static void intern_items(acl_engine_t *h, const Items &its, size_t n, acl_item_t
 constexpr int kRouteNotTaken = -1002;
 template <class Items>
 static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off_p, size_t k_items, uint8_t *keep_out, uint8_t *pair_perm, int32_t *pair_err,
-                                const CallOpts &opts);
+                                const CallOpts &opts, Eval *outer = nullptr);
 // acl_check_bulk / acl_check_bulk_v: strings -> ids straight into the context's pinned staging, one device pass, per-item errors patched in
 template <class Items>
 static int check_bulk_strings(acl_engine_t *h, const Items &its, size_t n, uint8_t *perm_out, int32_t *err_out, const acl_call_opts_t *o = nullptr) {
@@ -2025,7 +2025,7 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
 
 template <class Items>
 static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off_p, size_t k_items, uint8_t *keep_out, uint8_t *pair_perm, int32_t *pair_err,
-                                const CallOpts &opts) {
+                                const CallOpts &opts, Eval *outer) {
     // PAIR form (CheckBulkPermissions itself, keep_out == NULL): every pair is an "item" of its own and is answered HAS_PERMISSION / NO_PERMISSION without an
     // error -- only where no Check of the permission can end in a depth error: whatever the relationships are (Snapshot::slot_deep says so of the schema), or, for a
     // recursive permission, on THIS snapshot (no_object_is_deep) -- because the row's missing bit cannot tell "no" from "gave up at the depth limit", which the
@@ -2062,8 +2062,10 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     bool sub_known = false;
     // (state_mu -- the evaluation's -- then names_mu: engine_internal.hpp's order.  The evaluation begins BEFORE the call's constants are resolved: no schema
     //  reload can come between the ids taken here and the walk that uses them.  The names stay locked while the device walks: the pass resolves names then.)
-    Eval ev;
-    {
+    // (outer: the caller's evaluation -- a K x F call answers its F templates one after the other on ONE snapshot, keep_by_reverse_walks)
+    Eval own;
+    Eval &ev = outer ? *outer : own;
+    if (!outer) {
         int rc = ev.begin(h, true, opts);
         if (rc) return rc;
     }
@@ -2243,7 +2245,7 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     if (walk_rc) return walk_rc;
     if (outcome.load()) return kRouteNotTaken;
     us_a = us_since(t_0);
-    ev.end();
+    if (!outer) ev.end();
     std::vector<uint32_t> tags;  // open addressing over the allowed objects' name tags (0 = empty; a tag of 0 is stored as 1: only costs a rare extra probe)
     uint32_t tmask = 0;
     {
@@ -2340,14 +2342,68 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
         } else if (k_items < 512 || !pool(k_items >= 2048)) test(0, k_items);
         else pool()->run(k_items, k_items >= 32768 ? 1024 : k_items >= 8192 ? 512 : k_items >= 2048 ? 128 : 64, workers, test);  // (its workers polled through the walk)
     }
-    h->keep_route_calls.fetch_add(1, std::memory_order_relaxed);
+    if (!outer) h->keep_route_calls.fetch_add(1, std::memory_order_relaxed);  // (a K x F call counts its F walks once all of them have answered)
     if (kTrace) std::fprintf(stderr, "keep route: n %zu allowed %llu | walk %.1f us | walk + pass done at %.1f (chunks: %.1f us in all, first began at %.1f, last ended at %.1f) | tags at %.1f | end %.1f (test chunks: %.1f us in all)\n", n, (unsigned long long)count, us_walk, us_a, tr_sum.load() / 1e3, tr_first.load() / 1e3, tr_last.load() / 1e3, us_fill, us_since(t_0), tr_test.load() / 1e3);
+    return ACL_OK;
+}
+
+// K items x F templates (postfilter.go:86-119: every PostFilter of every matching rule, resolved per item -- F = 2 ... 4 here): pair j of every item comes from
+// template j, so the pairs at positions j, j + F, j + 2 F, ... are a one-template call of their own.  Each is answered by its reverse walk (EveryNth: a view of
+// the call's items) under ONE evaluation -- one snapshot for the whole request, as the forward path has -- and an item is kept when every template keeps it.
+// Anything else -- items with different numbers of pairs, a template position whose pairs do not share type / permission / subject, a route that declines --
+// returns kRouteNotTaken before keep_out is touched.
+template <class Items>
+struct EveryNth {
+    const Items &base;
+    size_t stride, phase;
+    static constexpr bool kHasLen = Items::kHasLen;
+    const char *ptr(size_t i, int f) const { return base.ptr(i * stride + phase, f); }
+    size_t len(size_t i, int f) const { return base.len(i * stride + phase, f); }
+};
+template <class Items>
+static int keep_by_reverse_walks(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out) {
+    if (!k_items || n % k_items || h->store_only || h->shard.world > 1) return kRouteNotTaken;
+    const size_t F = n / k_items;
+    if (F < 2 || F > 4 || k_items < 512) return kRouteNotTaken;
+    for (size_t i = 0; i <= k_items; i++)
+        if (item_off[i] != i * F) return kRouteNotTaken;
+    Eval ev;
+    int rc = ev.begin(h, true, CallOpts());
+    if (rc) return rc;
+    {   // F walks must beat ONE forward pass over K F pairs: over a type of a few hundred thousand objects a walk is 20-40 us and they do from a few hundred
+        // items on; over C4's 845 000 pods a walk is 70 us (170 us when the result slot is one that other permissions expand) and the two break even at 16 384
+        // items (profiles/r06_keep_route.txt) -- such types only from 32 768 items on
+        std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+        if (!h->store.has_schema()) return kRouteNotTaken;
+        size_t biggest = 0;
+        for (size_t j = 0; j < F; j++) {
+            const char *t = its.ptr(j, F_RT);
+            const int rt = t ? h->store.schema().type_of(std::string(t, its.len(j, F_RT))) : -1;
+            if (rt < 0) return kRouteNotTaken;
+            biggest = std::max<size_t>(biggest, h->store.objects(rt).count());
+        }
+        if (biggest > 262144 && k_items < 32768) return kRouteNotTaken;
+    }
+    std::vector<uint8_t> kj(F * k_items);
+    for (size_t j = 0; j < F; j++) {
+        const EveryNth<Items> view{its, F, j};
+        rc = keep_by_reverse_walk(h, view, k_items, nullptr, k_items, kj.data() + j * k_items, nullptr, nullptr, CallOpts(), &ev);
+        if (rc) return rc;  // (kRouteNotTaken among them)
+    }
+    ev.end();
+    h->keep_route_calls.fetch_add(F, std::memory_order_relaxed);
+    for (size_t i = 0; i < k_items; i++) {
+        uint8_t all = 1;
+        for (size_t j = 0; j < F; j++) all &= kj[j * k_items + i];
+        keep_out[i] = all;
+    }
     return ACL_OK;
 }
 
 template <class Items>
 static int check_bulk_keep_strings(acl_engine_t *h, const Items &its, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out, const char *who) {
     int rc = keep_by_reverse_walk(h, its, n, item_off, k_items, keep_out, nullptr, nullptr, CallOpts());  // (checks the offsets it uses as it goes, in parallel; anything irregular comes back here)
+    if (rc == kRouteNotTaken) rc = keep_by_reverse_walks(h, its, n, item_off, k_items, keep_out);  // (K x F: one walk per template)
     if (rc != kRouteNotTaken) return rc;
     for (size_t i = 0; i < k_items; i++)
         if (item_off[i] > item_off[i + 1] || item_off[i + 1] > n) return fail(ACL_ERR_INVALID_ARGUMENT, std::string(who) + ": item_off must ascend and end within n");

@@ -695,3 +695,52 @@ definition pod { relation namespace: namespace
                 assert answers(e, u) == want[u], (rnd, u)
         st4 = e.stats()
         assert st4["depth_sweeps"] == st3["depth_sweeps"] + 1 and st4["keep_route_calls"] == st3["keep_route_calls"] + 2 * len(users) - 1
+
+
+def test_postfilter_k_items_times_f_templates_one_walk_per_template(aclgpu):
+    """K list items x F PostFilter templates for the requesting user (postfilter.go:86-119: every filter of every matching rule): pair j of every item comes
+    from template j, so each template position is a one-subject call of its own -- engine.cpp keep_by_reverse_walks answers the F of them by their reverse walks
+    under ONE evaluation and ANDs the masks.  Compared with the oracle (an item is kept when every pair is HAS_PERMISSION without error, postfilter.go:144-178);
+    the stats say F walks were taken.  Shapes the route must leave to the forward path: an item with a pair missing, a template position with two subjects."""
+    schema = """definition user {}
+definition group { relation member: user | group#member }
+definition namespace { relation viewer: user | group#member
+ permission view = viewer }
+definition pod { relation namespace: namespace
+ relation viewer: user | group#member
+ relation creator: user
+ permission view = viewer + creator + namespace->view
+ permission edit = creator }"""
+    rels = [f"group:g{k}#member@user:u{k}" for k in range(6)] + ["group:g0#member@group:g1#member"]
+    rels += [f"namespace:n{k}#viewer@group:g{k % 6}#member" for k in range(12)]
+    rels += [f"pod:n{i % 16}/p{i}#namespace@namespace:n{i % 16}" for i in range(800)]
+    rels += [f"pod:n{i % 16}/p{i}#creator@user:u{i % 7}" for i in range(0, 800, 2)] + [f"pod:n{i % 16}/p{i}#viewer@user:u{(i * 5) % 7}" for i in range(1, 800, 3)]
+    o = orc.Oracle(schema)
+    for b in range(0, len(rels), 1000):
+        o.write([(orc.OP_TOUCH, r) for r in rels[b:b + 1000]])
+    K = 800
+    with aclgpu.Engine(schema, "\n".join(rels)) as e:
+        for user in ("u1", "u0", "nobody"):
+            for tpls in ((("pod", "{pod}", "view"), ("pod", "{pod}", "edit")), (("pod", "{pod}", "view"), ("namespace", "{ns}", "view"), ("pod", "{pod}", "edit"))):
+                F = len(tpls)
+                pairs = [(t, rid.format(pod=f"n{i % 16}/p{i}", ns=f"n{i % 16}"), perm, "user", user, "") for i in range(K) for t, rid, perm in tpls]
+                off = np.arange(0, F * K + 1, F, dtype=np.uint32)
+                want = [all(o.check(*pairs[i * F + j]) == (2, 0) for j in range(F)) for i in range(K)]
+                before = e.stats()["keep_route_calls"]
+                for keep in (e.check_bulk_keep_views(e.make_check_views(pairs), off), e.check_bulk_keep_packed(e.make_check_packed(pairs), off)):
+                    assert keep.astype(bool).tolist() == want, (user, F)
+                assert e.stats()["keep_route_calls"] == before + 2 * F, (user, F)
+                assert user == "nobody" or 0 < sum(want) < K
+        # ---- not this route: item 5 lacks its second pair; position 1 names two subjects -- same masks by the forward path
+        tpls = (("pod", "{pod}", "view"), ("pod", "{pod}", "edit"))
+        pairs = [(t, rid.format(pod=f"n{i % 16}/p{i}"), perm, "user", "u1", "") for i in range(K) for t, rid, perm in tpls]
+        ragged = pairs[:11] + pairs[12:]
+        off = np.array([0] + [2 * i + 2 - (i >= 5) for i in range(K)], dtype=np.uint32)
+        before = e.stats()["keep_route_calls"]
+        keep = e.check_bulk_keep_views(e.make_check_views(ragged), off).astype(bool).tolist()
+        assert keep == [all(o.check(*ragged[j]) == (2, 0) for j in range(off[i], off[i + 1])) for i in range(K)]
+        two = list(pairs)
+        two[2 * 400 + 1] = two[2 * 400 + 1][:4] + ("u2", "")
+        keep = e.check_bulk_keep_views(e.make_check_views(two), np.arange(0, 2 * K + 1, 2, dtype=np.uint32)).astype(bool).tolist()
+        assert keep == [all(o.check(*two[2 * i + j]) == (2, 0) for j in range(2)) for i in range(K)]
+        assert e.stats()["keep_route_calls"] == before

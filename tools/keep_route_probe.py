@@ -62,6 +62,31 @@ for m in [int(x) for x in a.sizes.split(",")]:
                 ts.append(time.perf_counter() - t1)
             row[form] = {"M_items_per_s": round(m / float(np.mean(ts)) / 1e6, 1), "p50_ms": round(1e3 * float(np.median(ts)), 4), "best_ms": round(1e3 * min(ts), 4),
                          "mask_ok": ok, "by_reverse_walk": int(eng.stats()["keep_route_calls"] - before)}
+        if a.workload == "c4" and u is not None:
+            # K items x TWO templates (pod#view and pod#creator for the same user): one walk per template under one evaluation (engine.cpp keep_by_reverse_walks);
+            # beside it the same 2 K pairs by id through the forward walk + the AND
+            q2 = [x for r in w.res[:m] for x in ((rt, names[rt][int(r)], perm_name, st, uname, ""), (rt, names[rt][int(r)], "creator", st, uname, ""))]
+            off2 = np.arange(0, 2 * m + 1, 2, dtype=np.uint32)
+            cp, ce = eng.check_bulk_ids(eng.make_items(rt, "creator", w.res[:m], st, "", np.full(m, u, dtype=np.uint32)))
+            want2 = want & (cp == 2) & (ce == 0)
+            prep2 = eng.make_check_views(q2)
+            before = eng.stats()["keep_route_calls"]
+            ok2 = bool(np.array_equal(eng.check_bulk_keep_views(prep2, off2).astype(bool), want2))
+            ts = []
+            for _ in range(a.calls):
+                t1 = time.perf_counter()
+                eng.check_bulk_keep_views(prep2, off2)
+                ts.append(time.perf_counter() - t1)
+            it2 = np.empty(2 * m, dtype=aclgpu.ITEM_DTYPE)
+            it2[0::2] = eng.make_items(rt, perm_name, w.res[:m], st, "", np.full(m, u, dtype=np.uint32))
+            it2[1::2] = eng.make_items(rt, "creator", w.res[:m], st, "", np.full(m, u, dtype=np.uint32))
+            tf = []
+            for _ in range(a.calls):
+                t1 = time.perf_counter()
+                eng.check_bulk_ids(it2)
+                tf.append(time.perf_counter() - t1)
+            row["keep_v_two_templates"] = {"M_items_per_s": round(m / float(np.mean(ts)) / 1e6, 1), "p50_ms": round(1e3 * float(np.median(ts)), 4), "mask_ok": ok2, "kept": int(want2.sum()),
+                                           "walks": int(eng.stats()["keep_route_calls"] - before), "forward_by_id_p50_ms": round(1e3 * float(np.median(tf)), 4)}
         out[f"{m}/{who}"] = row
         print(m, who, json.dumps(row), flush=True)
 eng.close()
