@@ -1670,8 +1670,10 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
     const uint32_t lds_row_words = h->rev_lds_rows ? (uint32_t)(((size_t)h->snap.slot_nobjects[target] + 31) / 32) : 0u;
     RevBigRows big;
     const size_t bm_stride = (((size_t)h->snap.slot_nobjects[target] + 127) / 128) * 128;
+    // (a result slot that is a sink of the reverse graph is marked, not expanded: Snapshot::rev_sink; ACL_REV_SINK=0 at acl_open: A/B and test knob)
+    const bool sink = h->rev_sink_on && h->shard.world == 1 && target < h->snap.rev_sink.size() && h->snap.rev_sink[target];
     const bool use_big = h->rev_big_rows && (lds_row_words == 0 || (size_t)lds_row_words * 4 > kRevLdsRowBytes) && cw > 0 &&
-                         (h->snap.rprogs[target].n & ~kRevRemoteBit) == 0 &&  // (a result slot nobody expands: its marks need no first-visit answer)
+                         ((h->snap.rprogs[target].n & ~kRevRemoteBit) == 0 || sink) &&  // (a result slot nobody expands: its marks need no first-visit answer)
                          m * bm_stride <= ((size_t)2 << 30) && bm_stride <= 0xFFFFFF80ull;
     if (use_big) {
         if (c->d_big_bytes.n < m * bm_stride || !c->d_big_bytes.p) {
@@ -1697,9 +1699,12 @@ static int lookup_pass_local(acl_engine *h, PassCtx *c, const DevReverse &r, uin
         big = RevBigRows{c->d_big_bytes.p, (uint32_t)bm_stride, c->d_big_tasks.p, c->d_big_meta.p, c->d_big_meta.p + m, c->d_big_counts.p, (uint32_t)tcap, h->rev_defer_min};
     }
     ev_begin(c, 3);
-    launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target, c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
+    RevUseful useful;  // (the slots that can lead to the result slot: everything else is dead weight for this lookup)
+    const bool pruned = h->rev_sink_on && h->shard.world == 1 && h->snap.rev_useful.size() >= ((size_t)target + 1) * kRevUsefulWords;
+    if (pruned) std::memcpy(useful.w, h->snap.rev_useful.data() + (size_t)target * kRevUsefulWords, sizeof(useful.w));
+    launch_rev_local(c->stream, r, (const uint32_t *)d_sids, (uint32_t)m, key, target | (sink ? kRevTargetSink : 0u), c->d_fbuf[0].p, c->d_fbuf[1].p, (uint32_t)cap64, (uint32_t *)d_rows, (uint32_t)ostride,
                      (uint32_t)cw, (uint64_t *)((char *)d_out + 64), (uint32_t *)d_out, lds_row_words,
-                     (spin || use_big) ? c->d_done.p : nullptr, spin ? (uint32_t *)d_out + 15 : nullptr, done_val, use_big ? &big : nullptr);
+                     (spin || use_big) ? c->d_done.p : nullptr, spin ? (uint32_t *)d_out + 15 : nullptr, done_val, use_big ? &big : nullptr, pruned ? &useful : nullptr);
     ev_end(c);
     if (via_device) HIP_TRY(hipMemcpyAsync(direct ? (void *)bitmaps : (void *)h_rows, c->d_rows.p, m * ostride * 4, hipMemcpyDeviceToHost, c->stream));
     // (the proxy's shape is ONE LookupResources per list request, lookups.go:65: the caller spins on the completion word -- spin_for)
@@ -2548,6 +2553,7 @@ int acl_open_replicas(const acl_config_t *cfg, const int32_t *devices, uint32_t 
     if (const char *ev = getenv("ACL_REV_LOCAL")) h->rev_local = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_ROWS")) h->rev_rows_device = !std::strcmp(ev, "device");
     if (const char *ev = getenv("ACL_REV_LDS_ROWS")) h->rev_lds_rows = atoi(ev) != 0;
+    if (const char *ev = getenv("ACL_REV_SINK")) h->rev_sink_on = atoi(ev) != 0;
     if (const char *ev = getenv("ACL_REV_DEFER_MIN")) h->rev_defer_min = (uint32_t)std::max(1, atoi(ev));  // test knob: small graphs defer too
     if (const char *ev = getenv("ACL_REV_BIG_ROWS")) h->rev_big_rows = atoi(ev) != 0;  // A/B knob: 0 = rows beyond the LDS are walked, copied and cleared by ONE block (round 5)
     if (const char *ev = getenv("ACL_SHARD_A2A")) h->shard_a2a = atoi(ev) != 0;

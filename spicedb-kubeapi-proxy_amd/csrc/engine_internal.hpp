@@ -431,6 +431,7 @@ struct acl_engine {
                                           // (profiles/r02_walk_vs_levels.txt): faster than the level loop at every batch size, 1.5x at 262 144 items
     bool rev_rows_device = false;  // k_rev_local's result rows through a device buffer + one DMA copy instead of kernel writes to host memory (A/B)
     bool shard_a2a = true;  // native sharded Check: per-destination blocks through the communicator's all_to_all when it has one (ACL_SHARD_A2A=0: all-gather)
+    bool rev_sink_on = true;   // a lookup's result slot that nothing above leads back into is marked, not expanded (Snapshot::rev_sink; ACL_REV_SINK=0: A/B and tests)
     bool rev_lds_rows = true;  // k_rev_local keeps the result slot's rows in LDS when they fit (ACL_REV_LDS_ROWS=0: always in HBM; A/B and tests)
     uint32_t rev_defer_min = 0;  // 0 = the kernels' default (4096 children per round); ACL_REV_DEFER_MIN: test knob
     bool rev_big_rows = true;   // result rows beyond the LDS: deferred terminal rows + chip-wide row copy (kernels.hip RevDefer); ACL_REV_BIG_ROWS=0 switches it off (A/B)

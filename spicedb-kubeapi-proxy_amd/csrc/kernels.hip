@@ -2179,10 +2179,14 @@ struct RevDefer {
     uint32_t bm_stride = 0;
 };
 
-__global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_slot,
+__global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, const uint32_t *__restrict__ sids, uint32_t key, uint32_t target_in,
                                                                  uint2 *buf0, uint2 *buf1, uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride,
                                                                  uint32_t copy_words, unsigned long long *out_counts, uint32_t *status, uint32_t lds_words, uint32_t *done_ctr,
-                                                                 uint32_t *done_flag, uint32_t done_val, RevDefer dfr) {
+                                                                 uint32_t *done_flag, uint32_t done_val, RevDefer dfr, RevUseful useful) {
+    // (the result slot, and whether it is a SINK of the reverse graph -- Snapshot::rev_sink: no parent of its states can make another of its states true, so they are
+    //  marked and not expanded: a lookup of `edit` does not walk on into `view = viewer + edit`, a lookup of namespace#view not into the namespaces' pods)
+    const uint32_t target_slot = target_in & ~kRevTargetSink;
+    const bool target_sink = (target_in & kRevTargetSink) != 0u;
     __shared__ RevTaskLds t;
     __shared__ RevProgLds pl;
     // lds_words != 0: the RESULT slot's rows live here, not in `visited` -- the level that produces a lookup's ids (thousands of pods under
@@ -2209,7 +2213,12 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
     }
     if (tid < kRevLdsSlots / 32) s_nomark[tid] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < r.nrops; i += kRevLocalThreads) pl.ops[i] = r.rops[i];
+    // (ops whose target slot cannot lead to the result slot are dead for this lookup: Snapshot::rev_useful -- a lookup of pod#creator does not walk the user's groups)
+    for (uint32_t i = tid; i < r.nrops; i += kRevLocalThreads) {
+        RevOp o = r.rops[i];
+        if (o.target < kRevLdsSlots && !((useful.w[o.target >> 5] >> (o.target & 31u)) & 1u)) o.flags |= OP_DEAD;
+        pl.ops[i] = o;
+    }
     for (uint32_t i = tid; i < r.nslots; i += kRevLocalThreads) {
         const RevProg p = r.rprogs[i];
         pl.progs[i] = p;
@@ -2303,9 +2312,10 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                     id = en.x;
                     p = pl.progs[en.y];
                 }
-                if (j < (p.n & ~kRevRemoteBit)) {
+                if (j < (p.n & ~kRevRemoteBit) && !(pl.ops[p.first + j].flags & OP_DEAD)) {
                     const RevOp op = pl.ops[p.first + j];
                     uint32_t np = pl.progs[op.target].n & ~kRevRemoteBit;
+                    if (target_sink && op.target == target_slot) np = 0u;
                     tgt = op.target | (np == 0u ? kRevTerminal : 0u) | term_all | ((op.flags & OP_NOMARK) ? kRevNoMark : 0u);
                     // Round 6: a row whose children land in a relation that does nothing but feed ONE permission nobody expands -- `pod#viewer`, whose only
                     // parent is the computed userset in `pod#view = viewer + ...` -- marks that permission's objects directly, one dispatch level further
@@ -2314,7 +2324,7 @@ __global__ __launch_bounds__(kRevLocalThreads) void k_rev_local(DevReverse r, co
                     // and it is what kept their rows out of the deferred list.  Nobody reads the intermediate slot's bits unless it is the result slot.
                     if (!(op.flags & OP_PUSH_SAME) && np == 1u && op.target != target_slot) {
                         const RevOp via = pl.ops[pl.progs[op.target].first];
-                        if ((via.flags & OP_PUSH_SAME) && (pl.progs[via.target].n & ~kRevRemoteBit) == 0u) {
+                        if ((via.flags & OP_PUSH_SAME) && ((pl.progs[via.target].n & ~kRevRemoteBit) == 0u || (target_sink && via.target == target_slot))) {
                             if (level + 1u <= kMaxLevels) tgt = via.target | kRevTerminal;
                             else np = 0xFFFFFFFFu;  // (the permission's level lies beyond the limit: the relation's states are marked -- nobody asks -- and end there)
                         }
@@ -2858,16 +2868,19 @@ void launch_rev_expand(hipStream_t s, const DevReverse &r, const DevFrontier &f,
 }
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
                       uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status, uint32_t lds_row_words,
-                      uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val, const RevBigRows *big) {
+                      uint32_t *done_ctr, uint32_t *done_flag, uint32_t done_val, const RevBigRows *big, const RevUseful *useful_p) {
     if (!n) return;
+    RevUseful useful;
+    for (uint32_t k = 0; k < kRevUsefulWords; k++) useful.w[k] = useful_p ? useful_p->w[k] : 0xFFFFFFFFu;
     static const bool big_lds = hipFuncSetAttribute(reinterpret_cast<const void *>(k_rev_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRevLdsRowBytes) == hipSuccess;
     if (lds_row_words * 4u > (big_lds ? kRevLdsRowBytes : 32768u)) lds_row_words = 0;  // rows stay in HBM
     RevDefer dfr;
     if (!lds_row_words && big && big->tasks)
         dfr = RevDefer{reinterpret_cast<uint2 *>(big->tasks), big->task_count, big->levels, big->task_cap, big->defer_min ? big->defer_min : 4096u, big->bytemap, big->bytemap_stride};
     hipLaunchKernelGGL(k_rev_local, dim3(n), dim3(kRevLocalThreads), (size_t)lds_row_words * 4, s, r, sids, key, target_slot, (uint2 *)buf0, (uint2 *)buf1, cap, out_bitmaps,
-                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words, done_ctr, done_flag, done_val, dfr);
+                       out_stride, copy_words, (unsigned long long *)out_counts, status, lds_row_words, done_ctr, done_flag, done_val, dfr, useful);
     if (!dfr.tasks) return;
+    target_slot &= ~kRevTargetSink;
     // the two chip-wide launches behind it: the deferred rows' ids, then the rows themselves (copy out, count, clear)
     const uint32_t per = std::max(1u, std::min(256u, 2048u / n));  // blocks per lookup: the chip for a single lookup, ~8 blocks per CU in all for a batch
     hipLaunchKernelGGL(k_rev_terminal, dim3(per, n), dim3(256), 0, s, r, target_slot, dfr);

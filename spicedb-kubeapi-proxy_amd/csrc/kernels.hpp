@@ -151,12 +151,18 @@ struct RevBigRows {
     uint32_t task_cap = 0;
     uint32_t defer_min = 0;         // children of one round from which terminal rows are deferred (0 = the default, 4096)
 };
+constexpr uint32_t kRevUsefulWords = kRevLdsSlots / 32;
+struct RevUseful {  // the slots a lookup has to walk (Snapshot::rev_useful's row of its result slot); all ones: everything
+    uint32_t w[kRevUsefulWords];
+};
+// target_slot | kRevTargetSink: nothing above the result slot leads back into it (Snapshot::rev_sink) -- its states end the walk instead of being expanded
+constexpr uint32_t kRevTargetSink = 0x80000000u;
 void launch_rev_local(hipStream_t s, const DevReverse &r, const uint32_t *sids, uint32_t n, uint32_t key, uint32_t target_slot, void *buf0, void *buf1,
                       uint32_t cap, uint32_t *out_bitmaps, uint32_t out_stride, uint32_t copy_words, uint64_t *out_counts, uint32_t *status,
                       uint32_t lds_row_words /* words covering the result slot's id space: kept in LDS when <= kRevLdsRowBytes, else (or 0) in r.visited */,
                       uint32_t *done_ctr = nullptr, uint32_t *done_flag = nullptr, uint32_t done_val = 0 /* as launch_check_local: the last block stores done_val into the pinned
                       word done_flag behind a system-scope release of every block's rows, counts and status */,
-                      const RevBigRows *big = nullptr);
+                      const RevBigRows *big = nullptr, const RevUseful *useful = nullptr /* NULL: every slot */);
 // blocks per expand launch for this device (all co-resident); nwaves = blocks * kWavesPerBlock
 int expand_grid_blocks(int device);
 

@@ -31,6 +31,7 @@ enum : uint32_t {
                          // (no other op targets the slot; ids of a reverse row are distinct): no visited bit is needed to tell a first visit
     OP_ALL = 256u,       // with OP_ENUM, inside the leaf of an intersection arrow `a.all(b)`: every child answers a result cell of its OWN, folded
                          // into the leaf's cell by a member node (kernels.hip kAllBit; BX_LEAF_ALL)
+    OP_DEAD = 512u,      // reverse ops, set in k_rev_local's LDS copy only: the op's target slot cannot lead to the lookup's result slot (Snapshot::rev_useful) -- skipped
     OP_WILD = 64u        // with OP_PROBE_HASH: the row probed is the one of the class's wildcard subject `T:*` (its id in FwdOp::K), whoever the
                          // request's subject is; reverse ops (RevOp): the row read is the wildcard subject's (roff_base points at it), whatever the seed's id
 };
@@ -197,6 +198,11 @@ struct Snapshot {
     std::vector<std::vector<RevLayout>> rlay;  // [slot][class]
     std::vector<RevOp> rops;
     std::vector<RevProg> rprogs;   // [nslots]: parents of a true state
+    // [nslots][kRevUsefulWords]: bit x of row t -- slot x is t itself or some chain of parent programs leads from x to t: what a lookup of t has to walk.  States of
+    // any other slot can never make a state of t true; their ops are dead for that lookup (a lookup of pod#creator does not walk the user's groups, a lookup of
+    // group#member not the namespaces and pods the groups are named on).
+    std::vector<uint32_t> rev_useful;
+    std::vector<uint8_t> rev_sink;  // [nslots]: no chain of parent programs leads from the slot back into it -- as a lookup's RESULT slot its states need no expansion
     std::vector<RevProg> rseeds;   // [nkeys]: seeds for a subject key
     std::vector<uint64_t> rdest;   // [nslots]: the OTHER shards that hold parent rows of a state of this slot (bit per shard < 64; sharded graphs)
     std::vector<uint32_t> slot_bit_base;  // [nslots+1] first bit of each slot's visited bitmap (32-bit aligned)

@@ -192,6 +192,52 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             }
         }
     }
+    // which slots are sinks as a lookup's result: the slot cannot be reached again from its own parents (group#member reaches itself through nested groups;
+    // `edit` under `view = viewer + edit`, or namespace#view under pod#view = ... + namespace->view, do not)
+    // ... and, per result slot, the slots that can lead to it (the parent graph walked backwards from t)
+    {
+        constexpr uint32_t kWords = 256 / 32;  // (kernels.hpp kRevUsefulWords: k_rev_local's LDS copy holds 256 slots; larger schemas take the level loop)
+        std::vector<std::vector<int>> producers(sc.nslots);  // producers[y]: slots x with an op x -> y
+        for (int x = 0; x < sc.nslots; x++) {
+            const RevProg &p = s.rprogs[x];
+            for (uint32_t j = 0; j < (p.n & ~kRevRemoteBit); j++) producers[s.rops[p.first + j].target].push_back(x);
+        }
+        s.rev_useful.assign((size_t)sc.nslots * kWords, 0u);
+        for (int t = 0; t < sc.nslots && sc.nslots <= 256; t++) {
+            uint32_t *row = s.rev_useful.data() + (size_t)t * kWords;
+            std::vector<int> stack{t};
+            row[t >> 5] |= 1u << (t & 31);
+            while (!stack.empty()) {
+                const int y = stack.back();
+                stack.pop_back();
+                for (int x : producers[y])
+                    if (!((row[x >> 5] >> (x & 31)) & 1u)) {
+                        row[x >> 5] |= 1u << (x & 31);
+                        stack.push_back(x);
+                    }
+            }
+        }
+    }
+    s.rev_sink.assign(sc.nslots, 0);
+    for (int t = 0; t < sc.nslots; t++) {
+        std::vector<uint8_t> seen(sc.nslots, 0);
+        std::vector<int> stack{t};
+        bool back = false;
+        while (!stack.empty() && !back) {
+            const int v = stack.back();
+            stack.pop_back();
+            const RevProg &p = s.rprogs[v];
+            for (uint32_t j = 0; j < (p.n & ~kRevRemoteBit) && !back; j++) {
+                const int w = (int)s.rops[p.first + j].target;
+                if (w == t) back = true;
+                else if (!seen[w]) {
+                    seen[w] = 1;
+                    stack.push_back(w);
+                }
+            }
+        }
+        s.rev_sink[t] = back ? 0 : 1;
+    }
     if (s.rops.empty()) s.rops.push_back(RevOp{});
     s.slot_bit_base.assign(sc.nslots + 1, 0);
     s.slot_nobjects.assign(sc.nslots, 0);

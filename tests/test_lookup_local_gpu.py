@@ -195,3 +195,59 @@ def test_relation_that_only_feeds_the_result_permission_is_marked_through_exactl
         assert e.lookup("doc", "view", "user", "deep") == want
         assert e.lookup("doc", "viewer", "user", "deep") == o.lookup("doc", "viewer", "user", "deep") == {f"d{k}" for k in range(40, 50)} | {"direct"}  # the relation ITSELF asked for: K + 1 <= 50
         assert e.stats()["rev_local_passes"] == 2
+
+
+def test_result_slots_that_other_permissions_expand_end_the_walk(aclgpu, monkeypatch):
+    """A lookup's result slot that is a SINK of the reverse graph (Snapshot::rev_sink: nothing above it leads back into it) is marked and not expanded: `edit` under
+    `view = viewer + edit + ...`, a relation that feeds permissions, namespace#admin under namespace#view under pod#view.  Rows in LDS, rows in HBM (the deferred
+    chip-wide launches included: before this the walk of such a slot over a big type fell back to one block doing everything) -- every row against the oracle's ids
+    and against the same engine with ACL_REV_SINK=0; group#member (it reaches itself through nested groups) keeps being expanded."""
+    schema = """definition user {}
+definition group { relation member: user | group#member }
+definition namespace { relation owner: user | group#member
+ relation viewer: user | group#member
+ permission admin = owner
+ permission view = viewer + admin }
+definition pod { relation namespace: namespace
+ relation editor: user | group#member
+ relation creator: user
+ relation viewer: user | group#member
+ permission edit = editor + creator
+ permission view = viewer + edit + namespace->view }"""
+    rng = np.random.default_rng(5)
+    nu, ng, nn, npod = 300, 40, 30, 4000
+    rels = [f"group:g{g}#member@user:u{int(u)}" for g in range(ng) for u in rng.integers(0, nu, size=6)]
+    rels += [f"group:g{g}#member@group:g{int(h)}#member" for g in range(ng) for h in rng.integers(g + 1, ng + 1, size=1) if h < ng]
+    rels += [f"namespace:n{n}#owner@user:u{int(rng.integers(0, nu))}" for n in range(nn)] + [f"namespace:n{n}#viewer@group:g{int(rng.integers(0, ng))}#member" for n in range(nn)]
+    for p in range(npod):
+        rels.append(f"pod:p{p}#namespace@namespace:n{p % nn}")
+        rels.append(f"pod:p{p}#creator@user:u{int(rng.integers(0, nu))}")
+        if p % 3 == 0:
+            rels.append(f"pod:p{p}#editor@group:g{int(rng.integers(0, ng))}#member")
+        if p % 5 == 0:
+            rels.append(f"pod:p{p}#viewer@user:u{int(rng.integers(0, nu))}")
+    rels = list(dict.fromkeys(rels))
+    o = orc.Oracle(schema)
+    for b in range(0, len(rels), 1000):
+        o.write([(orc.OP_TOUCH, r) for r in rels[b:b + 1000]])
+    targets = [("pod", "edit"), ("pod", "creator"), ("pod", "editor"), ("pod", "view"), ("namespace", "admin"), ("namespace", "view"), ("group", "member")]
+    users = [f"u{int(u)}" for u in rng.integers(0, nu, size=12)]
+    want = {(rt, pm, u): sorted(o.lookup(rt, pm, "user", u)) for rt, pm in targets for u in users}
+    assert sum(len(v) for v in want.values()) > 2000
+    modes = [{}, {"ACL_REV_LDS_ROWS": "0"}, {"ACL_REV_LDS_ROWS": "0", "ACL_REV_DEFER_MIN": "1"}, {"ACL_REV_SINK": "0"}, {"ACL_REV_SINK": "0", "ACL_REV_LDS_ROWS": "0"}]
+    for env in modes:
+        for k in ("ACL_REV_LDS_ROWS", "ACL_REV_DEFER_MIN", "ACL_REV_SINK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)  # (read at acl_open)
+        with aclgpu.Engine(schema, "\n".join(rels)) as e:
+            e.stats_reset()
+            for rt, pm in targets:
+                sids = [e.intern("user", u) for u in users]
+                bms, counts = e.lookup_ids_batch(rt, pm, "user", "", sids)
+                for i, u in enumerate(users):
+                    got = sorted(e.object_name(rt, int(x)) for x in ids_of(bms[i]))
+                    assert got == want[(rt, pm, u)] and counts[i] == len(got), (env, rt, pm, u)
+                one, c1 = e.lookup_ids_batch(rt, pm, "user", "", sids[:1])  # (a single lookup: the completion word)
+                assert np.array_equal(one[0], bms[0]) and c1[0] == counts[0], (env, rt, pm)
+            assert e.stats()["expand_launches"] == 0
