@@ -2376,8 +2376,8 @@ static int keep_by_reverse_walks(acl_engine_t *h, const Items &its, size_t n, co
     int rc = ev.begin(h, true, CallOpts());
     if (rc) return rc;
     {   // F walks must beat ONE forward pass over K F pairs: over a type of a few hundred thousand objects a walk is 20-40 us and they do from a few hundred
-        // items on; over C4's 845 000 pods a walk is 70 us (170 us when the result slot is one that other permissions expand) and the two break even at 16 384
-        // items (profiles/r06_keep_route.txt) -- such types only from 32 768 items on
+        // items on; over C4's 845 000 pods a walk is 30-85 us and two of them (0.21 ms at 16 384 items) beat the forward string path (0.27 ms) from there on
+        // (profiles/r06_keep_route.txt) -- such types from 16 384 items on
         std::shared_lock<std::shared_mutex> nlk(h->names_mu);
         if (!h->store.has_schema()) return kRouteNotTaken;
         size_t biggest = 0;
@@ -2387,7 +2387,8 @@ static int keep_by_reverse_walks(acl_engine_t *h, const Items &its, size_t n, co
             if (rt < 0) return kRouteNotTaken;
             biggest = std::max<size_t>(biggest, h->store.objects(rt).count());
         }
-        if (biggest > 262144 && k_items < 32768) return kRouteNotTaken;
+        static const size_t kBigMin = getenv("ACL_KEEP_MULTI_MIN") ? (size_t)std::max(0, atoi(getenv("ACL_KEEP_MULTI_MIN"))) : (size_t)16384;  // (A/B knob)
+        if (biggest > 262144 && k_items < kBigMin) return kRouteNotTaken;
     }
     std::vector<uint8_t> kj(F * k_items);
     for (size_t j = 0; j < F; j++) {
