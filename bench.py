@@ -228,6 +228,15 @@ def filter_bench(args, w, eng, steps, warmup):
     if only_batched:
         one = [float("nan")]
     bms, counts = keep
+    # ... and "list namespaces" (e2e/proxy_test.go:656-659: LookupResources(namespace, view, user)): a result slot that pod#view expands through its arrow -- the
+    # walk is directed at the result slot and ends there (Snapshot::rev_useful / rev_sink), it does not go on into the allowed namespaces' pods
+    ns_one = []
+    if not only_batched and "namespace" in w.nobjects:
+        ns_bufs = None
+        for s_ in np.tile(subs, 4)[:100]:
+            t1 = time.perf_counter()
+            ns_bufs = eng.lookup_ids_batch("namespace", perm_name, st, "", [int(s_)], out=ns_bufs)
+            ns_one.append(time.perf_counter() - t1)
     # the reference runs every list request's prefilter in a goroutine of its own (responsefilterer.go:165): three callers, each with result
     # buffers of its own, each step one batched walk -- their kernels fill each other's gaps
     conc = None
@@ -284,6 +293,7 @@ def filter_bench(args, w, eng, steps, warmup):
            "objects": int(sum(w.nobjects.values())),
            "allowed_ids_per_lookup": float(np.mean(counts)), "allowed_ids_per_sec": float(np.sum(counts)) * steps / el,
            "p50_batch_ms": 1e3 * float(np.median(lat)), "p50_single_lookup_ms": 1e3 * float(np.median(one)), "p95_single_lookup_ms": 1e3 * float(np.percentile(one, 95)),
+           "p50_single_namespace_lookup_ms": (1e3 * float(np.median(ns_one))) if ns_one else None,
            "pageable_result_buffers": {"p50_batch_ms": 1e3 * float(np.median(pg)), "lookups_per_s": subs.size / float(np.median(pg)), "equal_to_pinned_run": pageable_equal},
            "concurrent_callers": conc,
            "kernel_ms_per_step": stats["kernel_ms"] / steps, "launches_per_step": launches / steps, "reverse_levels": int(stats.get("levels_last", 0)),
