@@ -202,7 +202,7 @@ void build_reverse(Store &store, int64_t now, Snapshot *snap, ShardSpec shard) {
             const RevProg &p = s.rprogs[x];
             for (uint32_t j = 0; j < (p.n & ~kRevRemoteBit); j++) producers[s.rops[p.first + j].target].push_back(x);
         }
-        s.rev_useful.assign((size_t)sc.nslots * kWords, 0u);
+        s.rev_useful.assign((size_t)sc.nslots * kWords, sc.nslots <= 256 ? 0u : 0xFFFFFFFFu);  // (beyond 256 slots nothing is pruned -- and k_rev_local is not used)
         for (int t = 0; t < sc.nslots && sc.nslots <= 256; t++) {
             uint32_t *row = s.rev_useful.data() + (size_t)t * kWords;
             std::vector<int> stack{t};
