@@ -128,6 +128,10 @@ const char *acl_object_name(acl_engine_t *h, int type, uint32_t id); /* NULL for
 /* Copies the name of `id` into buf (NUL-terminated, at most cap bytes incl. the NUL) under the names lock and returns its length (which may exceed cap - 1:
  * the copy is then truncated); -1 for anonymous / unknown ids.  What the cgo shim's LookupResources stream calls per result id (lookups.go:75-83). */
 int64_t acl_object_name_copy(acl_engine_t *h, int type, uint32_t id, char *buf, size_t cap);
+/* The names of the objects whose bits are set in a LookupResources bitmap (lookups.go:75-83: the reference drains one message per result), a BLOCK per call: from bit
+ * *cursor on (0 at first), up to max_names names back to back into buf (cap >= 1024 bytes, not NUL-terminated; ends[k] = offset one past name k; an id without a
+ * name gets an empty one).  *cursor is left at the first bit not reported yet, *n_out = names written; *n_out == 0: the bitmap is exhausted. */
+int acl_bitmap_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t words, uint64_t *cursor, char *buf, size_t cap, uint32_t *ends, size_t max_names, size_t *n_out);
 uint32_t acl_object_count(acl_engine_t *h, int type);                /* size of the type's dense id space */
 
 /* ---- relationship store: the write side of the seam ---- */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "acl_lookup_resources_alloc", "acl_free", "acl_check_one_opts", "acl_lookup_one_opts", "acl_shard_stream", "acl_filter_list_response", "acl_filter_list_response_req", "acl_shard_check_bulk", "acl_shard_rccl_unique_id", "acl_shard_rccl_init",
     "acl_shard_rccl_destroy", "acl_shard_check_bulk_rccl", "acl_shard_lookup_bulk", "acl_shard_lookup_bulk_rccl", "acl_selfcheck_compaction", "acl_check_one_submit", "acl_check_completions",
     "acl_lookup_one_submit", "acl_lookup_completions", "acl_prefilter_response", "acl_open_replicas", "acl_replica_calls", "acl_watch_wait", "acl_watch_recheck", "acl_load_bootstrap_yaml",
-    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_check_bulk_packed", "acl_check_bulk_keep_v", "acl_check_bulk_keep_packed", "acl_selfcheck_json_array",
+    "acl_check_bulk_v_opts", "acl_object_name_copy", "acl_resolve_bulk_v", "acl_check_bulk_packed", "acl_check_bulk_keep_v", "acl_check_bulk_keep_packed", "acl_selfcheck_json_array", "acl_bitmap_names",
 ]
 
 
@@ -153,6 +153,7 @@ def load():
     L.acl_object_name.restype = C.c_char_p
     L.acl_object_name_copy.argtypes = [H, C.c_int, C.c_uint32, C.c_char_p, C.c_size_t]
     L.acl_object_name_copy.restype = C.c_int64
+    L.acl_bitmap_names.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.acl_object_count.argtypes = [H, C.c_int]
     L.acl_object_count.restype = C.c_uint32
     L.acl_write.argtypes = [H, C.POINTER(Update), C.c_int, C.POINTER(Filter), C.c_int, C.POINTER(C.c_uint64)]

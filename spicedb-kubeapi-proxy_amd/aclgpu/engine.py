@@ -471,6 +471,22 @@ class Engine:
         finally:
             self._L.acl_free(out)
 
+    def bitmap_names(self, rtype: str, bitmap: np.ndarray, block: int = 512, buf_bytes: int = 1 << 16):
+        """acl_bitmap_names: the names of a LookupResources bitmap's objects in id order, fetched a block per call (what the shim's stream does)."""
+        bm = np.ascontiguousarray(bitmap, dtype=np.uint32)
+        buf = C.create_string_buffer(buf_bytes)
+        ends = np.zeros(block, dtype=np.uint32)
+        cur, n = C.c_uint64(0), C.c_size_t()
+        out = []
+        while True:
+            self._check(self._L.acl_bitmap_names(self._h, self.type_id(rtype), bm.ctypes.data, bm.size, C.byref(cur), buf, buf_bytes, ends.ctypes.data, block, C.byref(n)))
+            if not n.value:
+                return out
+            raw, prev = buf.raw, 0
+            for k in range(n.value):
+                out.append(raw[prev:int(ends[k])].decode())
+                prev = int(ends[k])
+
     def bitmap_test_names(self, rtype: str, bitmap: np.ndarray, object_ids):
         """prefilterResult.IsAllowed (lookups.go:25-36) over a LookupResources bitmap -> bool array."""
         bm = np.ascontiguousarray(bitmap, dtype=np.uint32)

@@ -2693,6 +2693,37 @@ int64_t acl_object_name_copy(acl_engine_t *h, int type, uint32_t id, char *buf, 
     }
     return (int64_t)n->size();
 }
+// The names behind a LookupResources bitmap, a block per call (the shim's stream, lookups.go:75-83: one cgo call and one turn at the names lock per BLOCK of results,
+// not per result).
+int acl_bitmap_names(acl_engine_t *h, int type, const uint32_t *bitmap, size_t words, uint64_t *cursor, char *buf, size_t cap, uint32_t *ends, size_t max_names, size_t *n_out) {
+    if (!cursor || !n_out || (words && !bitmap) || !buf || !ends || cap < 1024 || cap > 0xFFFFFFFFull || !max_names)
+        return fail(ACL_ERR_INVALID_ARGUMENT, "acl_bitmap_names: bad argument (buf must hold at least 1024 bytes: the longest object id)");
+    std::shared_lock<std::shared_mutex> nlk(h->names_mu);
+    const Schema &sc = h->store.schema();
+    if (type < 0 || type >= (int)sc.defs.size()) return fail(ACL_ERR_INVALID_ARGUMENT, "acl_bitmap_names: unknown object type");
+    const ObjectTable &ot = h->store.objects(type);
+    size_t n = 0, used = 0;
+    uint64_t bit = *cursor;
+    const uint64_t nbits = (uint64_t)words * 32;
+    while (bit < nbits && n < max_names) {
+        const uint32_t wv = bitmap[bit >> 5] >> (bit & 31u);
+        if (!wv) {
+            bit = (bit | 31u) + 1;
+            continue;
+        }
+        bit += (uint64_t)__builtin_ctz(wv);
+        const std::string *nm = ot.name((uint32_t)bit);  // (an id that lost its name meanwhile, or an anonymous bulk-loaded one: an empty name, as the per-id call's -1)
+        const size_t len = nm ? nm->size() : 0;
+        if (used + len > cap) break;  // (the next call starts here: cap >= the longest id, so a call always makes progress)
+        if (len) std::memcpy(buf + used, nm->data(), len);
+        used += len;
+        ends[n++] = (uint32_t)used;
+        bit++;
+    }
+    *cursor = bit;
+    *n_out = n;
+    return ACL_OK;
+}
 const char *acl_object_name(acl_engine_t *h, int type, uint32_t id) {
     std::shared_lock<std::shared_mutex> nlk(h->names_mu);
     const Schema &sc = h->store.schema();

@@ -208,3 +208,22 @@ def test_big_lists_and_tables_take_the_parallel_scan_and_match_the_reference(eng
         with pytest.raises(Exception) as x:
             eng.prefilter_response("pod", bm, "{{namespacedName}}", eng.BODY_LIST, broken)
         assert x.value.code == 3
+
+
+def test_bitmap_names_in_blocks(eng):
+    """acl_bitmap_names: the LookupResources stream's names a block per call -- every set bit once, in id order, whatever the block and buffer sizes; ids that
+    no object carries come out as empty names (as the per-id call's -1)."""
+    rng = random.Random(3)
+    pods = [f"ns{n}/pod-{i}" + "x" * rng.randrange(0, 40) for n in range(5) for i in range(300)] + ["z" * 1024]
+    for p in pods:
+        eng.intern("pod", p)
+    allowed = sorted(rng.sample(pods, 700), key=lambda p: eng.find("pod", p))
+    bm = bitmap_of(eng, "pod", allowed)
+    for block, buf in ((512, 1 << 16), (1, 1024), (7, 1500), (4096, 1 << 20)):
+        assert eng.bitmap_names("pod", bm, block, buf) == allowed
+    bm2 = np.concatenate([bm, np.array([0, 5], dtype=np.uint32)])  # two bits beyond every id: nameless
+    assert eng.bitmap_names("pod", bm2) == allowed + ["", ""]
+    assert eng.bitmap_names("pod", np.zeros(4, dtype=np.uint32)) == []
+    with pytest.raises(Exception) as x:
+        eng.bitmap_names("pod", bm, 16, 512)
+    assert x.value.code == 3
