@@ -1469,16 +1469,28 @@ def c5r_mixed_stream(args, w5, e5, gpu_perm, gpu_err, steps):
 
     for c in range(callers):  # every caller's context and buffers exist before the clock starts
         e5.check_bulk_ids_into(h_items[c], h_perm[c], h_err[c])
-    ts = [threading.Thread(target=run, args=(c,)) for c in range(callers)]
-    for t_ in ts:
-        t_.start()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    go[0] = True
-    for t_ in ts:
-        t_.join()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    # (the stream is 40 steps, 12-13 ms: one hiccup of the host -- a page fault storm, another thread's wake-up -- was a third of one run's figure, 404 M/s where three
+    #  runs of the same binary on another box said 680-705.  Three passes, every answer of every pass compared; the MEDIAN pass is reported, all three recorded.)
+    import gc
+    passes = []
+    for _rep in range(3):
+        nxt[0] = 0
+        go[0] = False
+        ts = [threading.Thread(target=run, args=(c,)) for c in range(callers)]
+        for t_ in ts:
+            t_.start()
+        torch.cuda.synchronize()
+        gc_was = gc.isenabled()
+        gc.disable()
+        t0 = time.perf_counter()
+        go[0] = True
+        for t_ in ts:
+            t_.join()
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+        if gc_was:
+            gc.enable()
+    el = float(np.median(passes))
     e5.host_free(hb)
     nC = sum(1 for o_ in ops if o_ == "C")
     nF = len(ops) - nC
@@ -1488,11 +1500,11 @@ def c5r_mixed_stream(args, w5, e5, gpu_perm, gpu_err, steps):
     ach = per_launch / (k_us * 1e-6) / 1e9 if k_us > 0 else None
     return {"workload": "BASELINE configs[4] stream on one replica: 90 % Check batches (262 144 host ids) / 10 % Filter requests (LookupResources(pod, view, user:U) over 8.45 M pods, "
                         "one subject per request), interleaved by seed 0x5ACE0005; " + f"{callers} caller thread(s)",
-            "steps": len(ops), "check_steps": nC, "filter_steps": nF, "seconds": round(el, 4), "ms_per_step": 1e3 * el / len(ops),
+            "steps": len(ops), "check_steps": nC, "filter_steps": nF, "seconds": round(el, 4), "passes_seconds": [round(x, 4) for x in passes], "ms_per_step": 1e3 * el / len(ops),
             "decisions_per_s": nC * n / el, "lookups_per_s": nF / el, "allowed_ids_per_lookup": float(np.mean([cnts[s_] for s_ in fsub])),
             "lookup_alone": {"p50_ms": 1e3 * float(np.median(lat)), "lookups_per_s": 1.0 / float(np.mean(lat)), "calls": len(lat), "result_row_bytes": int(words * 4),
                              "note": "one acl_lookup_resources_batch call of ONE subject at a time, pinned result row (the proxy's shape)"},
-            "parity": {"check_steps_compared": nC, "lookups_compared": nF + len(fsub), "mismatches": len(bad) + bad_rows,
+            "parity": {"check_steps_compared": 3 * nC, "lookups_compared": 3 * nF + len(fsub), "mismatches": len(bad) + bad_rows,
                        "checkers": "Check steps: the device leg's answers rotated (themselves compared with the oracle item by item); lookups: every bit of the result row against a "
                                    "numpy reverse walk over the generator's arrays, and against the oracle's DEFINITION on a pod sample (lookup_definition_sample)"},
             "roofline_lookup": {"bound": "hbm", "kernel": kname, "kernel_avg_us": k_us, "launches": int(kn), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
