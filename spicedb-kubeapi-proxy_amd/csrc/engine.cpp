@@ -1855,9 +1855,12 @@ int lookup_batch(acl_engine *h, PassCtx *c, int rtype, int perm, int stype, int 
             DevFrontier f = h->dev_frontier(*c);
             HIP_TRY(hipMemsetAsync(c->d_visited.p, 0, m * vwords * 4, c->stream));
             launch_rev_seed(c->stream, f, c->d_sids.p, (uint32_t)m, key);  // seeds + status block, on the device
+            DevReverse rl = r;  // (the level loop walks towards the result slot too: dead ops skipped -- not on a sharded graph, whose programs are one shard's)
+            if (h->rev_sink_on && h->shard.world == 1 && h->snap.rev_useful.size() >= ((size_t)target + 1) * kRevUsefulWords)
+                std::memcpy(rl.useful, h->snap.rev_useful.data() + (size_t)target * kRevUsefulWords, sizeof(rl.useful));
             uint32_t levels = 0;
             hipError_t cpe = hipSuccess;
-            rc = level_loop(h, c, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(c->stream, r, f, it); }, &levels, [&] {
+            rc = level_loop(h, c, kMaxLevels + 1, [&](uint32_t it) { launch_rev_expand(c->stream, rl, f, it); }, &levels, [&] {
                 // speculative epilogue: the result rows of the target slot, one strided copy for all requests
                 if (cw) {
                     hipError_t e = hipMemcpy2DAsync(c->h_out.p, cw * 4, c->d_visited.p + h->snap.slot_bit_base[target] / 32, vwords * 4, cw * 4, m,

@@ -2065,7 +2065,9 @@ __global__ __launch_bounds__(kBlock, ACL_MIN_WAVES_PER_SIMD) void k_rev_expand(D
             uint32_t tstart = 0, tcount = 0, tmeta = 0;
             if (j < nops) {
                 const RevOp op = r.rops[p.first + j];
-                if (op.flags & OP_PUSH_SAME) {
+                const bool dead = op.target < 256u && !((r.useful[op.target >> 5] >> (op.target & 31u)) & 1u);  // (cannot lead to the result slot: DevReverse::useful)
+                if (dead) {
+                } else if (op.flags & OP_PUSH_SAME) {
                     want = true;
                     tstart = id;
                     tcount = 1u | kSelfBit;

@@ -54,6 +54,9 @@ struct DevReverse {
     uint32_t *visited;              // [nreq][visited_words]
     uint32_t visited_words;
     uint32_t nslots = 0, nrops = 0;  // sizes of rprogs / rops (the single-launch walk stages them in LDS when they fit)
+    // level loop (k_rev_expand) on an unsharded graph: the slots that can lead to the lookup's result slot (Snapshot::rev_useful; bit of slot x < 256) -- ops into any
+    // other slot are skipped.  All ones: everything (sharded graphs: a shard's programs are not the whole slot graph).
+    uint32_t useful[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 };
 constexpr uint32_t kRevLdsRowBytes = 128u << 10;  // the result slot's rows live in LDS up to this size (1 M objects)
 constexpr uint32_t kRevLdsSlots = 256, kRevLdsOps = 384;  // what k_rev_local's LDS copy of the reverse programs holds

@@ -234,9 +234,10 @@ definition pod { relation namespace: namespace
     users = [f"u{int(u)}" for u in rng.integers(0, nu, size=12)]
     want = {(rt, pm, u): sorted(o.lookup(rt, pm, "user", u)) for rt, pm in targets for u in users}
     assert sum(len(v) for v in want.values()) > 2000
-    modes = [{}, {"ACL_REV_LDS_ROWS": "0"}, {"ACL_REV_LDS_ROWS": "0", "ACL_REV_DEFER_MIN": "1"}, {"ACL_REV_SINK": "0"}, {"ACL_REV_SINK": "0", "ACL_REV_LDS_ROWS": "0"}]
+    modes = [{}, {"ACL_REV_LDS_ROWS": "0"}, {"ACL_REV_LDS_ROWS": "0", "ACL_REV_DEFER_MIN": "1"}, {"ACL_REV_SINK": "0"}, {"ACL_REV_SINK": "0", "ACL_REV_LDS_ROWS": "0"},
+             {"ACL_REV_LOCAL": "0"}, {"ACL_REV_LOCAL": "0", "ACL_REV_SINK": "0"}]  # (the level loop -- k_rev_expand -- skips the dead ops too)
     for env in modes:
-        for k in ("ACL_REV_LDS_ROWS", "ACL_REV_DEFER_MIN", "ACL_REV_SINK"):
+        for k in ("ACL_REV_LDS_ROWS", "ACL_REV_DEFER_MIN", "ACL_REV_SINK", "ACL_REV_LOCAL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)  # (read at acl_open)
@@ -250,4 +251,4 @@ definition pod { relation namespace: namespace
                     assert got == want[(rt, pm, u)] and counts[i] == len(got), (env, rt, pm, u)
                 one, c1 = e.lookup_ids_batch(rt, pm, "user", "", sids[:1])  # (a single lookup: the completion word)
                 assert np.array_equal(one[0], bms[0]) and c1[0] == counts[0], (env, rt, pm)
-            assert e.stats()["expand_launches"] == 0
+            assert (e.stats()["expand_launches"] == 0) == ("ACL_REV_LOCAL" not in env)
