@@ -76,7 +76,7 @@ for m in [int(x) for x in a.sizes.split(",")]:
         row["postfilter"] = {"ms": round(1e3 * float(np.median(ts)), 3), "best_ms": round(1e3 * min(ts), 3), "M_items_per_s": round(m / float(np.median(ts)) / 1e6, 2),
                              "body_MB_per_s": round(len(body) / float(np.median(ts)) / 1e6, 1), "equal_to_id_path": bool(ok)}
         # the PreFilter form: one LookupResources for the user (the reference runs it beside the upstream request), then the body against the bitmap
-        if u is not None or True:
+        if True:  # (both kinds of user)
             sid = eng.intern(st, uname) if u is None else u
             t1 = time.perf_counter()
             bms, _cnt = eng.lookup_ids_batch(rt, perm_name, st, "", [sid])
