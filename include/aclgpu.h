@@ -299,7 +299,8 @@ int acl_check_bulk_keep_ids(acl_engine_t *h, const acl_item_t *items, size_t n, 
  * acl_check_bulk / _v / _packed (CheckBulkPermissions itself, what the unpatched proxy's PostFilter sends) take the same walk for one subject's pairs where no Check
  * of the permission can end at the dispatch-depth limit -- by the schema (no recursion), or, for a recursive permission, on the snapshot at hand: one forward
  * sweep over the type's objects for a subject nobody is decides that for every subject (acl_stats_t.depth_sweeps; the first call at a snapshot goes forward,
- * the second sweeps; ACL_DEPTH_SWEEP=0 in the environment switches the sweep off). */
+ * the second sweeps; ACL_DEPTH_SWEEP=0 in the environment switches the sweep off).  Where the sweep FINDS such objects (a cycle of groups behind some resources)
+ * their pairs answer ACL_ERR_DEPTH as the forward path does, out of the sweep's bitmap. */
 int acl_check_bulk_keep_v(acl_engine_t *h, const acl_check_item_v_t *items, size_t n, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_packed(acl_engine_t *h, const acl_packed_request_t *req, const uint32_t *item_off, size_t k_items, uint8_t *keep_out);
 int acl_check_bulk_keep_ids_device(acl_engine_t *h, const void *d_items, size_t n, const void *d_item_off, size_t k_items, void *d_keep_out);

@@ -1974,9 +1974,10 @@ int lookup_batch_call(acl_engine_t *h, int rtype, int perm, int stype, int srel,
 // away); "some object is deep" is remembered for its own snapshot epoch only (acl_engine::snap_epoch).  The sweep costs a forward pass over the whole type
 // (845 000 pods: ~1 ms), so it is only run for a graph that holds still: the first call that needs it goes forward and leaves a note, the next one that finds
 // the note current sweeps.
-// true: none is deep; false: some object is, or it is not known (yet): the caller takes the forward path (a sweep that fails is "not known").  Caller holds
-// state_mu shared (an Eval) and owns context c.
-static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st, size_t n_pairs) {
+// true: known for this snapshot -- none is deep, or *deep_out holds the deep objects' bitmap; false: not known (yet): the caller takes the forward path (a sweep that
+// fails is "not known").  Caller holds state_mu shared (an Eval) and owns context c.
+// *deep_out: the deep objects' bitmap when there are some (the pair form then answers their depth error per pair), empty when none is deep.
+static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st, size_t n_pairs, std::shared_ptr<const std::vector<uint32_t>> *deep_out) {
     static const bool kOff = getenv("ACL_DEPTH_SWEEP") && atoi(getenv("ACL_DEPTH_SWEEP")) == 0;  // (A/B and test knob)
     if (kOff) return false;
     const uint64_t epoch = h->snap_epoch, adds = h->store.path_adds();  // (writers hold state_mu exclusive: both belong to the snapshot the caller evaluates)
@@ -1994,7 +1995,10 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
             k->rt = rt, k->pm = pm, k->st = st;
         }
         if (k->swept && k->none && k->adds == adds) return true;  // shallow when swept, and nothing written since could have added a path
-        if (k->swept && k->epoch == epoch) return k->none;        // (this very snapshot: deep objects were found)
+        if (k->swept && k->epoch == epoch) {                      // (this very snapshot: deep objects were found -- here is which)
+            *deep_out = k->bits;
+            return true;
+        }
         // not known for this snapshot.  The sweep is for a graph that holds still: the first call that needs it leaves a note and goes forward, the next one
         // that finds the note still current sweeps -- current by the store's path_adds (plain grants and removals come and go without touching it), or, after a
         // sweep that FOUND deep objects, by the snapshot's epoch (only a removal can help then, and any write may be one)
@@ -2013,11 +2017,17 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
     std::vector<uint8_t> perm(items.size());
     std::vector<int32_t> err(items.size());
     bool none = true;
-    for (size_t b = 0; b < count && none; b += chunk) {
+    auto bits = std::make_shared<std::vector<uint32_t>>();
+    for (size_t b = 0; b < count; b += chunk) {
         const size_t m = std::min(chunk, count - b);
         for (size_t i = 0; i < m; i++) items[i] = acl_item_t{(uint16_t)rt, (uint16_t)pm, (uint32_t)(b + i), (uint16_t)st, (uint16_t)ACL_NO_RELATION, 0xFFFFFFFCu};
         if (check_ids_host(h, c, items.data(), m, perm.data(), err.data())) return false;
-        for (size_t i = 0; i < m; i++) none &= err[i] == 0;  // (any error: a depth error; an invalid item cannot happen -- the ids are the call's resolved ones)
+        for (size_t i = 0; i < m; i++)
+            if (err[i]) {  // (any error is the depth error: an invalid item cannot happen -- the ids are the type's own)
+                if (none) bits->assign((count + 31) / 32, 0u);
+                none = false;
+                (*bits)[(b + i) >> 5] |= 1u << ((b + i) & 31u);
+            }
     }
     h->depth_sweeps.fetch_add(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(h->deep_mu);
@@ -2027,8 +2037,10 @@ static bool no_object_is_deep(acl_engine *h, PassCtx *c, int rt, int pm, int st,
             d.none = none;
             d.epoch = epoch;
             d.adds = adds;
+            d.bits = none ? nullptr : bits;
         }
-    return none;
+    if (!none) *deep_out = bits;
+    return true;
 }
 
 template <class Items>
@@ -2117,7 +2129,12 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     uint32_t *idv = idv_buf.data();
     // FEW allowed objects: so few that hashing THEIR names (a dependent miss or three each: id -> name -> bytes) is cheaper than sending the call's names to the
     // table -- a thirty-second of the pairs (a power user with 10 000 allowed pods among 65 536 pairs took 0.32 ms through the tags, 0.13 through the table)
-    auto is_few = [n](uint64_t allowed) { return allowed != 0 && allowed <= std::max<uint64_t>(64, n / 32); };
+    // (pair form on a snapshot with DEEP objects -- a cycle of groups behind some resources: no_object_is_deep hands over their bitmap; a pair whose bit is missing
+    //  answers the depth error when its resource is one of them, so every name goes to the table: never "few")
+    std::shared_ptr<const std::vector<uint32_t>> deep;
+    const uint32_t *dbits = nullptr;
+    size_t dwords = 0;
+    auto is_few = [n, &dbits](uint64_t allowed) { return !dbits && allowed != 0 && allowed <= std::max<uint64_t>(64, n / 32); };
     std::atomic<bool> walk_done{false}, many_a{false}, resolved_any{false};
     // (a user's reach does not change from one list request to the next: a subject last seen with FEW allowed objects is not resolved for while the device
     //  walks -- a third of the pass's work, wasted, for the proxy's ordinary user; one never seen, or seen with MANY, is)
@@ -2140,7 +2157,9 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
     {
         const uint32_t target = (uint32_t)h->store.schema().slot(rt, pm);
         // (the pair form also for a subject no table knows: a walk through a cycle of groups ends at the depth limit whoever is looked for)
-        if (pair_form && (h->snap.slot_deep.size() <= target || (h->snap.slot_deep[target] && !no_object_is_deep(h, ev.c, rt, pm, st, n)))) return kRouteNotTaken;
+        if (pair_form && (h->snap.slot_deep.size() <= target || (h->snap.slot_deep[target] && !no_object_is_deep(h, ev.c, rt, pm, st, n, &deep)))) return kRouteNotTaken;
+        dbits = deep ? deep->data() : nullptr;
+        dwords = deep ? deep->size() : 0;
         if (sub_known) {
             if (!h->snap.slot_nonmono.empty() && h->snap.slot_nonmono[target]) return kRouteNotTaken;
             const size_t words = ((size_t)h->store.objects(rt).count() + 31) / 32;
@@ -2150,7 +2169,7 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
             const auto t_w = std::chrono::steady_clock::now();
             if (sub_known) walk_rc = lookup_batch(h, ev.c, rt, pm, st, -1, &sub, 1, row.data(), row.size(), &count);
             us_walk = us_since(t_w);
-            many_a.store(count != 0 && !is_few(count), std::memory_order_relaxed);
+            many_a.store(dbits || (count != 0 && !is_few(count)), std::memory_order_relaxed);
             walk_done.store(true, std::memory_order_release);
             if (sub_known && !walk_rc) {
                 const unsigned width = count ? 64u - (unsigned)__builtin_clzll(count) : 0u;
@@ -2336,16 +2355,22 @@ static int keep_by_reverse_walk(acl_engine_t *h, const Items &its, size_t n, con
                         if (!maybe || !tab.find_hashed(std::string_view(its.ptr(i, F_RID), its.len(i, F_RID)), hh, &id)) id = kAbsent;
                     }
                     ok[i - lo] = id != kAbsent && (size_t)(id >> 5) < row.size() && ((row[id >> 5] >> (id & 31u)) & 1u);
+                    if (dbits && !ok[i - lo] && id != kAbsent && (size_t)(id >> 5) < dwords && ((dbits[id >> 5] >> (id & 31u)) & 1u)) ok[i - lo] = 2;  // (gave up at the depth limit)
                 }
                 for (size_t i = lo; i < le; i++) idv[i] = ok[i - lo];
             }
             for (size_t it = a; it < b; it++) {
+                if (pair_form && idv[it] == 2u) {  // (pair form: item it IS pair it)
+                    pair_perm[it] = 0;
+                    pair_err[it] = ACL_ERR_DEPTH;
+                    continue;
+                }
                 uint8_t all = 1;
                 for (size_t i = item_off[it]; i < item_off[it + 1]; i++) all &= (uint8_t)idv[i];
                 emit(it, all);
             }
         };
-        if (!count) {
+        if (!count && !dbits) {
             for (size_t it = 0; it < k_items; it++) emit(it, item_off[it] == item_off[it + 1]);
         } else if (k_items < 512 || !pool(k_items >= 2048)) test(0, k_items);
         else pool()->run(k_items, k_items >= 32768 ? 1024 : k_items >= 8192 ? 512 : k_items >= 2048 ? 128 : 64, workers, test);  // (its workers polled through the walk)

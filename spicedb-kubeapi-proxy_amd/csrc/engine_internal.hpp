@@ -380,6 +380,7 @@ struct acl_engine {
                                            // deep" is only known for its own epoch (a DELETE may have cut the cycle)
         uint64_t wanted = 0;               // the key (path_adds, or the epoch after a sweep that found deep objects) at which a call last asked and went forward
         bool wanted_by_epoch = false;
+        std::shared_ptr<const std::vector<uint32_t>> bits;  // !none: the deep objects of rt (a bit per id), for `epoch`
     };
     std::mutex deep_mu;
     std::vector<DeepKnown> deep_known;  // (a handful: one per list rule's template)

@@ -589,11 +589,12 @@ def test_every_call_shape_at_once_native_threads(aclgpu, tmp_path):
 
 
 
-def test_check_bulk_of_one_subject_on_a_recursive_schema_stays_forward(aclgpu):
-    """CheckBulkPermissions by one reverse walk (engine.cpp keep_by_reverse_walk, pair form) is only for permissions whose Checks cannot end at the dispatch-depth
-    limit (Snapshot::slot_deep): the row's missing bit cannot tell NO_PERMISSION from "gave up".  Here `group#member` is recursive and two groups contain each
-    other: pods shared with them answer a depth ERROR for a user who is in neither -- per pair, as the oracle does -- so the string call must walk forward
-    (the counter stands still), while the keep call, which drops an item on either answer, still takes the reverse walk."""
+def test_check_bulk_of_one_subject_behind_a_cycle_of_groups_carries_the_depth_errors(aclgpu):
+    """CheckBulkPermissions by one reverse walk (engine.cpp keep_by_reverse_walk, pair form) where the row's missing bit cannot tell NO_PERMISSION from "gave up at
+    the dispatch-depth limit": `group#member` is recursive and two groups contain each other, so pods shared with them answer a depth ERROR for a user who is in
+    neither -- per pair, as the oracle does.  The depth sweep (no_object_is_deep) finds those pods and hands their bitmap to the route: the first call goes forward
+    (nothing known about the snapshot yet), the second sweeps and walks, the third walks -- every pair's permissionship AND error the oracle's each time; the keep
+    call, which drops an item on either answer, walks from the start."""
     schema = """definition user {}
 definition group { relation member: user | group#member }
 definition pod { relation viewer: user | group#member
@@ -609,8 +610,13 @@ definition pod { relation viewer: user | group#member
         before = e.stats()["keep_route_calls"]
         for got in (e.check_bulk_views(e.make_check_views(items)), e.check_bulk_packed(e.make_check_packed(items)), e.check_bulk_views(e.make_check_views(items))):
             assert list(zip(got[0].tolist(), got[1].tolist())) == want
-        # (the second call at the same snapshot swept the type -- no_object_is_deep -- and found the pods behind the cycle: every call stays forward)
-        assert e.stats()["keep_route_calls"] == before and e.stats()["depth_sweeps"] == 1
+        # (the second call at the same snapshot swept the type and found the pods behind the cycle: it and the third answered by the walk + their bitmap)
+        assert e.stats()["keep_route_calls"] == before + 2 and e.stats()["depth_sweeps"] == 1
+        for u in ("nobody", "u1"):  # a subject no table knows: no walk at all, NO_PERMISSION everywhere but behind the cycle
+            qs = [q[:4] + (u, "") for q in items]
+            got = e.check_bulk_views(e.make_check_views(qs))
+            assert list(zip(got[0].tolist(), got[1].tolist())) == [o.check(*q) for q in qs], u
+        before = e.stats()["keep_route_calls"]
         keep = e.check_bulk_keep_views(e.make_check_views(items), np.arange(701, dtype=np.uint32)).astype(bool)
         assert e.stats()["keep_route_calls"] == before + 1 and keep.tolist() == [w_ == (2, 0) for w_ in want]
 
@@ -620,7 +626,7 @@ def test_check_bulk_of_one_subject_on_nested_groups_takes_the_reverse_walk_once_
     """The pair form on a RECURSIVE permission (nested groups, SURVEY 8(d) C4's schema): the schema cannot rule a depth error out, the snapshot can -- one forward
     sweep over the type for a subject nobody is (engine.cpp no_object_is_deep; the property it rests on: tests/test_oracle_cross.py
     test_a_depth_error_does_not_depend_on_the_subject).  First call at a snapshot: forward, and a note; second: the sweep, then the reverse walk; a write starts
-    over.  A cycle written behind some pods sends the calls forward again (their pairs carry the depth error, as the oracle's do); deleting it brings the route back.
+    over.  A cycle written behind some pods: after one more sweep the calls still walk, their pairs' depth errors from the deep pods' bitmap (as the oracle's); deleting it: shallow again.
     Every answer is the oracle's (check.go:54-69: pair i answers item i)."""
     schema = """definition user {}
 definition group { relation member: user | group#member }
@@ -685,7 +691,8 @@ definition pod { relation namespace: namespace
             for u in users:
                 assert answers(e, u) == want[u], (rnd, u)
         st3 = e.stats()
-        assert st3["depth_sweeps"] == st2["depth_sweeps"] + 1 and st3["keep_route_calls"] == st2["keep_route_calls"]  # swept once more, found deep pods: forward
+        # (a new path: the first call forward, the second sweeps and finds deep pods; it and the ten after it walk, the depth errors from the pods' bitmap)
+        assert st3["depth_sweeps"] == st2["depth_sweeps"] + 1 and st3["keep_route_calls"] == st2["keep_route_calls"] + 3 * len(users) - 1
         # ---- the cycle deleted: a new snapshot, shallow again
         e.write([(aclgpu.OP_DELETE, cyc[0])])
         o.write([(orc.OP_DELETE, cyc[0])])
