@@ -925,6 +925,11 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
     # fields (acl_check_bulk) and {pointer, length} fields (acl_check_bulk_v: what a cgo shim points at Go strings without copying).
     names = getattr(w, "names", None)
     if names:
+        # (the interpreter's cyclic collector off for these legs: the harness holds a million name strings, and a full collection in the middle of a 0.15 ms call was a
+        #  9 ms straggler -- one of 40 calls, 60 % of that leg's mean rate in one of the round's runs)
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()
         sp = {"note": "acl_check_bulk_v / acl_check_bulk on named objects (every pod and user of the graph has a name; tables of "
                       f"{len(names[rt])} + {len(names[st])} names); answers compared with the id path's", "sizes": {}}
         ok_all = True
@@ -1019,6 +1024,8 @@ def check_bench(args, w, eng, steps, warmup, world, rank, label, legs, dist=None
                    "views_decisions_per_s": {k_: v_["views"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()},
                    "views_2ms_apart_decisions_per_s": {k_: v_["views_2ms_apart"]["decisions_per_s"] for k_, v_ in sp["sizes"].items()}})
         rec["string_path"] = sp
+        if gc_was:
+            gc.enable()
         if not ok_all:
             rec["string_path_mismatch"] = True
     else:
