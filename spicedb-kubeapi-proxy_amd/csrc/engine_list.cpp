@@ -4,8 +4,9 @@
 // Reference flow: json.Unmarshal(body) -> items[] -> for every item and every PostFilter template resolve
 // `type:id#perm@type:id` from the item's metadata.name / metadata.namespace (postfilter.go:73-119) -> ONE
 // CheckBulkPermissions (postfilter.go:134) -> keep the items whose pairs are all HAS_PERMISSION (postfilter.go:144-178)
-// -> json.Marshal.  Here the body is scanned once for the item spans and their metadata, the K x F resolved pairs go
-// through acl_check_bulk_keep_v (one reverse walk + bit tests for the usual one-user, one-template list; else one forward device pass), and the answer is the ORIGINAL bytes with the dropped items' spans cut
+// -> json.Marshal.  Here the body is scanned for the item spans and their metadata -- bodies from 512 KB on by all host threads: the spans through the parallel
+// element index (json_index.hpp), the elements validated side by side (scan_array) --, the K x F resolved pairs go through acl_check_bulk_keep_v (one reverse
+// walk per template + bit tests for the usual one-user list; else one forward device pass), and the answer is the ORIGINAL bytes with the dropped items' spans cut
 // out -- no generic decode / re-encode of a body that can be many megabytes.  (The reference's re-marshal sorts object
 // keys; the spliced document is the same JSON value for every key order, which is what kube clients parse.)
 //
